@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- skinned vertices/s of the HIP linear-blend-skinning hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch: ONE launch of the skinning kernel over the
+C4 workload (1 M vertices / 256 bones; position + normal + tangent, 4 influences) through the
+C ABI (fyx_lbs_skin_device), inputs resident in HBM.  Steps rotate through `--sets` disjoint
+buffer sets (default 8 x 100 MB > 2 x the 256 MiB Infinity Cache) so the stream comes from HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; every rank skins its own 1 M-vertex shard of an N x 1 M-vertex scene
+(vertex-range sharding, weak scaling, no data-path collective; `--allgather` adds the RCCL
+all-gather of the skinned buffers that a consumer needing the whole scene on every GPU would pay).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_VERTS = 1_000_000
+N_BONES = 256
+BYTES_PER_VERTEX = 100          # 60 read + 40 written
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+KERNEL_NAME = "lbs_skin"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--sets", type=int, default=8, help="disjoint buffer sets rotated through")
+    ap.add_argument("--verts", type=int, default=N_VERTS)
+    ap.add_argument("--bones", type=int, default=N_BONES)
+    ap.add_argument("--random-bones", action="store_true", help="fully random bone indices (worst-case LDS gather)")
+    ap.add_argument("--allgather", action="store_true", help="N>1: add the RCCL all-gather of the skinned buffers")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (e.g. lbs.vpt=4)")
+    ap.add_argument("--no-check", action="store_true", help="skip the parity spot-check before timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(mesh, pal, seconds: float) -> dict:
+    """The oracle (C restatement of the reference's SERIAL loop, mesh/mod.rs:501-522 + the shader's
+    normal/tangent math) timed on this host, 1 thread, on whole passes over the same workload."""
+    import oracle
+    oracle.lib()
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        oracle.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal, mesh.normal, mesh.tangent, threads=1)
+        passes += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and passes >= 2) or passes >= 1000:
+            break
+    serial = passes * mesh.n_verts / el
+    # generous upper bound that does NOT exist in the reference: same arithmetic, OpenMP over vertices
+    nthr = oracle.omp_max_threads()
+    t0 = time.perf_counter()
+    p2 = 0
+    while True:
+        oracle.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal, mesh.normal, mesh.tangent, threads=0)
+        p2 += 1
+        el2 = time.perf_counter() - t0
+        if (el2 >= seconds / 2 and p2 >= 2) or p2 >= 5000:
+            break
+    return {"value": serial, "unit": "vertices/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} full passes over the same {mesh.n_verts}-vertex/{pal.shape[0]}-bone workload "
+                      f"({el:.1f} s), C restatement of Fyrox's serial CPU loop (Rust toolchain unavailable)",
+            "omp_value": p2 * mesh.n_verts / el2, "omp_cores": nthr,
+            "omp_note": "OpenMP over vertices; not present in the reference (no rayon on this path)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import fyrox_amd
+    from fyrox_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    ctx = fyrox_amd.Context(local_rank)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)     # fyx kernels and torch.cuda.Event share this stream
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    opts = {k: ctx.get_option(k) for k in ("lbs.block", "lbs.blocks_per_cu", "lbs.vpt", "lbs.exact", "lbs.nt")}
+
+    # ---- synthetic inputs; each rank owns a different vertex-range shard --------
+    seed = synth.SEED_BASE + 4
+    mesh = synth.make_mesh(args.verts, args.bones, seed + 1000 * rank, coherent=not args.random_bones)
+    pal = synth.make_palette(args.bones, seed)
+    nv = mesh.n_verts
+    d_pal = torch.from_numpy(pal).cuda()
+    outs = []
+    for s in range(args.sets):
+        ctx.mesh_upload_soa(s, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+        outs.append((torch.empty(nv * 3 + 16, dtype=torch.float32, device="cuda"),
+                     torch.empty(nv * 3 + 16, dtype=torch.float32, device="cuda"),
+                     torch.empty(nv * 4 + 16, dtype=torch.float32, device="cuda")))
+    gathered = None
+    if world > 1 and args.allgather:
+        gathered = [torch.empty(world * (nv * 3 + 16), dtype=torch.float32, device="cuda"),
+                    torch.empty(world * (nv * 3 + 16), dtype=torch.float32, device="cuda"),
+                    torch.empty(world * (nv * 4 + 16), dtype=torch.float32, device="cuda")]
+
+    def step(i: int):
+        s = i % args.sets
+        op, on, ot = outs[s]
+        ctx.lbs_skin_device(s, d_pal.data_ptr(), args.bones, 1, op.data_ptr(), on.data_ptr(), ot.data_ptr())
+        if gathered is not None:
+            with torch.cuda.stream(stream):
+                for g, o in zip(gathered, (op, on, ot)):
+                    dist.all_gather_into_tensor(g, o)
+
+    # ---- parity spot-check against the oracle before timing (checker only) -------------------
+    parity = None
+    if not args.no_check and rank == 0:
+        import oracle
+        step(0)
+        ctx.sync()
+        n_chk = min(nv, 50_000)
+        ref = oracle.lbs_skin(mesh.pos[:n_chk], mesh.weights[:n_chk], mesh.indices[:n_chk], pal,
+                              mesh.normal[:n_chk], mesh.tangent[:n_chk], threads=0)
+        got_p = outs[0][0][:n_chk * 3].cpu().numpy().reshape(-1, 3)
+        got_t = outs[0][2][:n_chk * 4].cpu().numpy().reshape(-1, 4)
+        err = max(float(np.abs(got_p - ref["pos"]).max() / max(np.abs(ref["pos"]).max(), 1e-3)),
+                  float(np.abs(got_t - ref["tangent"]).max() / max(np.abs(ref["tangent"]).max(), 1e-3)))
+        parity = {"max_rel_err": err, "bit_exact": bool(np.array_equal(got_p, ref["pos"]) and np.array_equal(got_t, ref["tangent"])),
+                  "checked_vertices": n_chk}
+        if err > 1e-5:
+            raise SystemExit(f"parity check failed before timing: max rel err {err:.3e} > 1e-5")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream, whole timed region
+    if dist is not None:
+        t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, gpu_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        total_verts = float(world) * nv * args.steps
+        value = total_verts / elapsed
+        launch_us = gpu_ms * 1e3 / args.steps           # average per launch, HIP events
+        achieved = BYTES_PER_VERTEX * nv / (launch_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):                        # PMC-derived HBM bytes per launch (see profiles/README.md)
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "skinned vertices/sec at 1M verts/256 bones; achieved HBM GB/s vs peak",
+            "value": value, "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C4: {nv} verts / {args.bones} bones per GPU, 4-influence LBS of position+normal+tangent, "
+                                   f"{args.sets} rotating 100 MB buffer sets, "
+                                   f"{'random' if args.random_bones else 'spatially coherent'} bone indices",
+                       "sharding": "contiguous vertex range per GPU, palette replicated" + (", + RCCL all-gather" if gathered else ""),
+                       "kernel_options": opts},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": KERNEL_NAME, "avg_launch_us": launch_us,
+                         "algorithmic_bytes_per_launch": BYTES_PER_VERTEX * nv},
+            "parity": parity,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(mesh, pal, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

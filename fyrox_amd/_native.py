@@ -1,0 +1,110 @@
+"""ctypes binding of libfyrox_hip.so (the C ABI in include/fyrox_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, or no MI355X is visible when a
+context is created, this module raises.  Nothing here touches the CPU test oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfyrox_hip.so")
+
+FYX_OK = 0
+FYX_ERR_INVALID_ARG = -1
+FYX_ERR_NO_DEVICE = -2
+FYX_ERR_HIP = -3
+FYX_ERR_OOM = -4
+FYX_ERR_UNKNOWN_ID = -5
+FYX_ERR_BONE_INDEX = -6
+FYX_ERR_MISSING_ATTRIBUTE = -7
+FYX_ERR_UNSUPPORTED = -8
+
+_STATUS_NAMES = {
+    0: "FYX_OK", -1: "FYX_ERR_INVALID_ARG", -2: "FYX_ERR_NO_DEVICE", -3: "FYX_ERR_HIP",
+    -4: "FYX_ERR_OOM", -5: "FYX_ERR_UNKNOWN_ID", -6: "FYX_ERR_BONE_INDEX",
+    -7: "FYX_ERR_MISSING_ATTRIBUTE", -8: "FYX_ERR_UNSUPPORTED",
+}
+
+
+class FyxError(RuntimeError):
+    """A non-zero fyx_status returned by the native library."""
+
+    def __init__(self, code: int, message: str):
+        self.code = code
+        self.status = _STATUS_NAMES.get(code, str(code))
+        super().__init__(f"{self.status}: {message}")
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+_lib = None
+
+_P = c_void_p
+_SIGS = {
+    # name: (restype, [argtypes])
+    "fyx_version": (c_char_p, []),
+    "fyx_init": (c_int, [POINTER(c_void_p), c_int]),
+    "fyx_shutdown": (None, [_P]),
+    "fyx_last_error": (c_char_p, [_P]),
+    "fyx_set_stream": (c_int, [_P, _P]),
+    "fyx_get_stream": (c_void_p, [_P]),
+    "fyx_sync": (c_int, [_P]),
+    "fyx_timer_begin": (c_int, [_P]),
+    "fyx_timer_end": (c_int, [_P, POINTER(c_float)]),
+    "fyx_set_option": (c_int, [_P, c_char_p, c_int]),
+    "fyx_get_option": (c_int, [_P, c_char_p, POINTER(c_int)]),
+    "fyx_malloc": (c_int, [_P, c_size_t, POINTER(c_void_p)]),
+    "fyx_free": (c_int, [_P, _P]),
+    "fyx_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
+    "fyx_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
+    "fyx_mesh_upload": (c_int, [_P, c_uint64, _P, c_uint32, c_uint32, c_int, c_int, c_int, c_int, c_int]),
+    "fyx_mesh_upload_soa": (c_int, [_P, c_uint64, c_uint32, _P, _P, _P, _P, _P]),
+    "fyx_mesh_free": (c_int, [_P, c_uint64]),
+    "fyx_mesh_info": (c_int, [_P, c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "fyx_mesh_streams": (c_int, [_P, c_uint64] + [POINTER(c_void_p)] * 5),
+    "fyx_lbs_skin": (c_int, [_P, c_uint64, _P, c_uint32, c_uint32, _P, _P, _P, _P]),
+    "fyx_lbs_skin_device": (c_int, [_P, c_uint64, _P, c_uint32, c_uint32, _P, _P, _P]),
+    "fyx_lbs_skin_streams": (c_int, [_P, c_uint32, _P, _P, _P, _P, _P, _P, c_uint32, c_uint32, _P, _P, _P]),
+    "fyx_skinned_aabb": (c_int, [_P, c_uint64, _P, c_uint32, _P]),
+    "fyx_palette": (c_int, [_P, _P, _P, c_uint32, _P]),
+    "fyx_palette_device": (c_int, [_P, _P, _P, c_uint32, _P]),
+}
+
+
+def _preload_hip_runtime() -> None:
+    """If torch is importable, import it first so that libfyrox_hip.so binds to the SAME
+    libamdhip64.so.7 torch uses (one HIP runtime per process: device pointers and streams are
+    then interchangeable between torch tensors / RCCL and this library)."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the native library.  Raises NativeLibraryMissing when the HIP
+    extension has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fyrox_amd/csrc`. fyrox_amd has no CPU fallback.")
+    _preload_hip_runtime()
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(l, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def exported_symbols() -> list[str]:
+    return sorted(_SIGS)

@@ -1,0 +1,209 @@
+"""Pythonic wrapper over the C ABI (include/fyrox_hip.h).  Host-side plumbing only: every
+computation below happens in the HIP kernels of libfyrox_hip.so."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_int, c_uint32, c_void_p
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from ._native import FyxError
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def _f32(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by a Context (fyx_malloc / fyx_free)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = c_void_p()
+        ctx._check(ctx._l.fyx_malloc(ctx._h, self.nbytes, byref(p)))
+        self.ptr = p.value or 0
+
+    def upload(self, host: np.ndarray) -> "DeviceBuffer":
+        host = np.ascontiguousarray(host)
+        assert host.nbytes <= self.nbytes
+        self.ctx._check(self.ctx._l.fyx_memcpy_h2d(self.ctx._h, self.ptr, _ptr(host), host.nbytes))
+        return self
+
+    def download(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(self.ctx._l.fyx_memcpy_d2h(self.ctx._h, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            self.ctx._l.fyx_free(self.ctx._h, self.ptr)
+            self.ptr = 0
+
+
+class Context:
+    """One fyx_ctx: a GPU, a stream, the mesh registry.  Not thread-safe (as the reference's
+    update/render thread)."""
+
+    def __init__(self, device: int = 0):
+        self._l = _native.lib()
+        h = c_void_p()
+        rc = self._l.fyx_init(byref(h), int(device))
+        if rc != 0:
+            raise FyxError(rc, f"fyx_init(device={device}) failed: no MI355X/HIP device visible; "
+                               "fyrox_amd has no CPU fallback")
+        self._h = h
+        self.device = device
+
+    # -- plumbing ------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise FyxError(rc, self._l.fyx_last_error(self._h).decode())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._l.fyx_shutdown(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self) -> None:
+        self._check(self._l.fyx_sync(self._h))
+
+    def set_stream(self, hip_stream: int) -> None:
+        self._check(self._l.fyx_set_stream(self._h, hip_stream))
+
+    @property
+    def stream(self) -> int:
+        return self._l.fyx_get_stream(self._h) or 0
+
+    def timer_begin(self) -> None:
+        self._check(self._l.fyx_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = ctypes.c_float()
+        self._check(self._l.fyx_timer_end(self._h, byref(ms)))
+        return ms.value
+
+    def set_option(self, key: str, value: int) -> None:
+        self._check(self._l.fyx_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = c_int()
+        self._check(self._l.fyx_get_option(self._h, key.encode(), byref(v)))
+        return v.value
+
+    def malloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, host: np.ndarray) -> DeviceBuffer:
+        host = np.ascontiguousarray(host)
+        return DeviceBuffer(self, max(host.nbytes, 16)).upload(host)
+
+    # -- mesh registry -------------------------------------------------------------------
+    def mesh_upload(self, mesh_id: int, aos: np.ndarray, n_verts: int, stride: int, *, off_pos: int,
+                    off_normal: int = -1, off_tangent: int = -1, off_weights: int, off_indices: int) -> None:
+        aos = np.ascontiguousarray(aos, dtype=np.uint8)
+        assert aos.nbytes >= n_verts * stride
+        self._check(self._l.fyx_mesh_upload(self._h, mesh_id, _ptr(aos), n_verts, stride, off_pos,
+                                            off_normal, off_tangent, off_weights, off_indices))
+
+    def mesh_upload_soa(self, mesh_id: int, pos, weights, indices, normal=None, tangent=None) -> None:
+        pos = _f32(pos, (-1, 3))
+        n = pos.shape[0]
+        weights = _f32(weights, (n, 4))
+        indices = np.ascontiguousarray(indices, dtype=np.uint8).reshape(n, 4)
+        normal = None if normal is None else _f32(normal, (n, 3))
+        tangent = None if tangent is None else _f32(tangent, (n, 4))
+        self._check(self._l.fyx_mesh_upload_soa(self._h, mesh_id, n, _ptr(pos), _ptr(normal),
+                                                _ptr(tangent), _ptr(weights), _ptr(indices)))
+
+    def mesh_free(self, mesh_id: int) -> None:
+        self._check(self._l.fyx_mesh_free(self._h, mesh_id))
+
+    def mesh_info(self, mesh_id: int) -> dict:
+        n, mb, am = c_uint32(), c_uint32(), c_uint32()
+        self._check(self._l.fyx_mesh_info(self._h, mesh_id, byref(n), byref(mb), byref(am)))
+        return {"n_verts": n.value, "max_bone_index": mb.value, "has_normal": bool(am.value & 1),
+                "has_tangent": bool(am.value & 2)}
+
+    def mesh_streams(self, mesh_id: int) -> dict:
+        ps = [c_void_p() for _ in range(5)]
+        self._check(self._l.fyx_mesh_streams(self._h, mesh_id, *[byref(p) for p in ps]))
+        return dict(zip(("pos", "normal", "tangent", "weights", "indices"), [p.value or 0 for p in ps]))
+
+    # -- skinning ------------------------------------------------------------------------
+    def lbs_skin(self, mesh_id: int, palette, n_instances: int = 1, *, want: Sequence[str] = ("pos", "normal", "tangent"),
+                 aabb: bool = False) -> dict:
+        """Host palette in, host skinned vertices out (synchronous).  palette: (n_instances*n_bones, 16)
+        column-major mat4 rows."""
+        palette = _f32(palette, (-1, 16))
+        assert palette.shape[0] % n_instances == 0
+        n_bones = palette.shape[0] // n_instances
+        info = self.mesh_info(mesh_id)
+        nv = info["n_verts"] * n_instances
+        out = {}
+        if "pos" in want:
+            out["pos"] = np.empty((nv, 3), np.float32)
+        if "normal" in want:
+            out["normal"] = np.empty((nv, 3), np.float32)
+        if "tangent" in want:
+            out["tangent"] = np.empty((nv, 4), np.float32)
+        box = np.empty(6, np.float32) if aabb else None
+        self._check(self._l.fyx_lbs_skin(self._h, mesh_id, _ptr(palette), n_bones, n_instances,
+                                         _ptr(out.get("pos")), _ptr(out.get("normal")),
+                                         _ptr(out.get("tangent")), _ptr(box)))
+        if aabb:
+            out["aabb"] = box
+        return out
+
+    def lbs_skin_device(self, mesh_id: int, d_palette: int, n_bones: int, n_instances: int,
+                        d_out_pos: int = 0, d_out_normal: int = 0, d_out_tangent: int = 0) -> None:
+        self._check(self._l.fyx_lbs_skin_device(self._h, mesh_id, d_palette, n_bones, n_instances,
+                                                d_out_pos or None, d_out_normal or None, d_out_tangent or None))
+
+    def lbs_skin_streams(self, n_verts: int, d_pos: int, d_normal: int, d_tangent: int, d_weights: int,
+                         d_indices: int, d_palette: int, n_bones: int, n_instances: int,
+                         d_out_pos: int = 0, d_out_normal: int = 0, d_out_tangent: int = 0) -> None:
+        self._check(self._l.fyx_lbs_skin_streams(self._h, n_verts, d_pos or None, d_normal or None,
+                                                 d_tangent or None, d_weights, d_indices, d_palette,
+                                                 n_bones, n_instances, d_out_pos or None,
+                                                 d_out_normal or None, d_out_tangent or None))
+
+    def skinned_aabb(self, mesh_id: int, palette) -> np.ndarray:
+        palette = _f32(palette, (-1, 16))
+        box = np.empty(6, np.float32)
+        self._check(self._l.fyx_skinned_aabb(self._h, mesh_id, _ptr(palette), palette.shape[0], _ptr(box)))
+        return box
+
+    # -- palette -------------------------------------------------------------------------
+    def palette(self, global_, inv_bind) -> np.ndarray:
+        g = _f32(global_, (-1, 16))
+        ib = _f32(inv_bind, (-1, 16))
+        assert g.shape == ib.shape
+        out = np.empty_like(g)
+        self._check(self._l.fyx_palette(self._h, _ptr(g), _ptr(ib), g.shape[0], _ptr(out)))
+        return out
+
+    def palette_device(self, d_global: int, d_inv_bind: int, n: int, d_out: int) -> None:
+        self._check(self._l.fyx_palette_device(self._h, d_global, d_inv_bind, n, d_out))

@@ -1,0 +1,532 @@
+// fyx_api.hip -- the C ABI of libfyrox_hip.so (see include/fyrox_hip.h).
+// Owns: the context (device, stream, options, scratch), the mesh registry (device SoA streams
+// keyed by mesh id) and all argument validation.  No exception ever crosses the boundary.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_map>
+
+#include "../../include/fyrox_hip.h"
+#include "fyx_internal.h"
+
+namespace {
+
+struct Mesh {
+    uint32_t n_verts = 0;
+    uint32_t max_bone_index = 0;
+    void* block = nullptr;  // one allocation, streams carved at 256-byte boundaries
+    float* pos = nullptr;
+    float* nrm = nullptr;
+    float* tan = nullptr;
+    float* wgt = nullptr;
+    uint32_t* idx = nullptr;
+};
+
+}  // namespace
+
+struct fyx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    fyx::LbsTuning lbs;
+    std::unordered_map<uint64_t, Mesh> meshes;
+    std::string err = "";
+    // scratch: staging for host-variant calls, grown on demand
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    float* aabb_partials = nullptr;  // 6 * 2048 floats + 8
+    uint32_t* d_u32 = nullptr;       // 1 word
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(fyx_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+int hip_fail(fyx_ctx* c, hipError_t e, const char* what) {
+    const int code = (e == hipErrorOutOfMemory) ? FYX_ERR_OOM : FYX_ERR_HIP;
+    return fail(c, code, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+#define FYX_HIP(c, call)                                          \
+    do {                                                          \
+        hipError_t e_ = (call);                                   \
+        if (e_ != hipSuccess) return hip_fail((c), e_, #call);    \
+    } while (0)
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int ensure_scratch(fyx_ctx* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return FYX_OK;
+    if (c->scratch) {
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        FYX_HIP(c, hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    FYX_HIP(c, hipMalloc(&c->scratch, want));
+    c->scratch_bytes = want;
+    return FYX_OK;
+}
+
+void free_mesh(Mesh& m) {
+    if (m.block) (void)hipFree(m.block);
+    m = Mesh();
+}
+
+// Allocate the SoA streams for n vertices.  Each stream is padded to a whole number of
+// 1024-vertex chunks so vector loads of a ragged tail stay inside the allocation.
+int alloc_mesh(fyx_ctx* c, Mesh& m, uint32_t n, bool has_nrm, bool has_tan) {
+    const size_t np = align_up((size_t)n, 1024) + 1024;
+    const size_t b_pos = align_up(np * 12, 256), b_nrm = has_nrm ? b_pos : 0;
+    const size_t b_tan = has_tan ? align_up(np * 16, 256) : 0, b_wgt = align_up(np * 16, 256);
+    const size_t b_idx = align_up(np * 4, 256);
+    const size_t total = b_pos + b_nrm + b_tan + b_wgt + b_idx;
+    void* blk = nullptr;
+    FYX_HIP(c, hipMalloc(&blk, total));
+    hipError_t e = hipMemsetAsync(blk, 0, total, c->stream);
+    if (e != hipSuccess) { (void)hipFree(blk); return hip_fail(c, e, "hipMemsetAsync"); }
+    char* p = static_cast<char*>(blk);
+    m.block = blk;
+    m.n_verts = n;
+    m.pos = reinterpret_cast<float*>(p); p += b_pos;
+    m.nrm = has_nrm ? reinterpret_cast<float*>(p) : nullptr; p += b_nrm;
+    m.tan = has_tan ? reinterpret_cast<float*>(p) : nullptr; p += b_tan;
+    m.wgt = reinterpret_cast<float*>(p); p += b_wgt;
+    m.idx = reinterpret_cast<uint32_t*>(p);
+    return FYX_OK;
+}
+
+int finish_upload(fyx_ctx* c, uint64_t mesh_id, Mesh& m) {
+    hipError_t e = fyx::launch_max_bone_index(m.idx, m.n_verts, c->d_u32, c->stream);
+    if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "max_bone_index"); }
+    uint32_t mx = 0;
+    e = hipMemcpyAsync(&mx, c->d_u32, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "upload sync"); }
+    m.max_bone_index = mx;
+    auto it = c->meshes.find(mesh_id);
+    if (it != c->meshes.end()) { free_mesh(it->second); c->meshes.erase(it); }
+    c->meshes.emplace(mesh_id, m);
+    return FYX_OK;
+}
+
+Mesh* find_mesh(fyx_ctx* c, uint64_t id) {
+    auto it = c->meshes.find(id);
+    return it == c->meshes.end() ? nullptr : &it->second;
+}
+
+int check_skin_args(fyx_ctx* c, const Mesh* m, uint64_t mesh_id, const void* palette,
+                    uint32_t n_bones, uint32_t n_instances) {
+    if (!m) return fail(c, FYX_ERR_UNKNOWN_ID, "mesh %llu is not registered", (unsigned long long)mesh_id);
+    if (!palette) return fail(c, FYX_ERR_INVALID_ARG, "palette is null");
+    if (n_bones == 0 || n_bones > 256)
+        return fail(c, FYX_ERR_INVALID_ARG, "n_bones=%u outside 1..256 (bone indices are u8)", n_bones);
+    if (n_instances == 0) return fail(c, FYX_ERR_INVALID_ARG, "n_instances is 0");
+    if (m->n_verts > 0 && m->max_bone_index >= n_bones)
+        return fail(c, FYX_ERR_BONE_INDEX,
+                    "mesh %llu references bone %u but the palette has %u matrices",
+                    (unsigned long long)mesh_id, m->max_bone_index, n_bones);
+    return FYX_OK;
+}
+
+fyx::LbsArgs make_args(const Mesh& m, const float* d_palette, uint32_t n_bones, uint32_t n_inst,
+                       float* op, float* on, float* ot) {
+    fyx::LbsArgs a;
+    a.pos = m.pos; a.nrm = m.nrm; a.tan = m.tan; a.wgt = m.wgt; a.idx = m.idx;
+    a.palette = d_palette;
+    a.out_pos = op; a.out_nrm = on; a.out_tan = ot;
+    a.n_verts = m.n_verts; a.n_bones = n_bones; a.n_instances = n_inst;
+    return a;
+}
+
+}  // namespace
+
+#define FYX_GUARD_BEGIN try {
+#define FYX_GUARD_END(c)                                                        \
+    } catch (const std::bad_alloc&) {                                           \
+        return fail((c), FYX_ERR_OOM, "host allocation failed");                \
+    } catch (...) {                                                             \
+        return fail((c), FYX_ERR_HIP, "unexpected C++ exception");              \
+    }
+
+extern "C" {
+
+const char* fyx_version(void) { return "fyrox_hip 0.1.0 (gfx950)"; }
+
+int fyx_init(fyx_ctx** out_ctx, int device_ordinal) {
+    if (!out_ctx) return FYX_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    FYX_GUARD_BEGIN
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FYX_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return FYX_ERR_NO_DEVICE;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return FYX_ERR_NO_DEVICE;
+    fyx_ctx* c = new fyx_ctx();
+    c->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->aabb_partials), (6 * 2048 + 8) * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_u32), 64) != hipSuccess) {
+        fyx_shutdown(c);
+        return FYX_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    *out_ctx = c;
+    return FYX_OK;
+    FYX_GUARD_END(nullptr)
+}
+
+void fyx_shutdown(fyx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->meshes) free_mesh(kv.second);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->aabb_partials) (void)hipFree(c->aabb_partials);
+    if (c->d_u32) (void)hipFree(c->d_u32);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* fyx_last_error(const fyx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int fyx_set_stream(fyx_ctx* c, void* s) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+    return FYX_OK;
+}
+
+void* fyx_get_stream(fyx_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int fyx_sync(fyx_ctx* c) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+}
+
+int fyx_timer_begin(fyx_ctx* c) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    if (!c->ev0) { FYX_HIP(c, hipEventCreate(&c->ev0)); FYX_HIP(c, hipEventCreate(&c->ev1)); }
+    FYX_HIP(c, hipEventRecord(c->ev0, c->stream));
+    return FYX_OK;
+}
+
+int fyx_timer_end(fyx_ctx* c, float* out_ms) {
+    if (!c || !out_ms) return FYX_ERR_INVALID_ARG;
+    if (!c->ev0) return fail(c, FYX_ERR_INVALID_ARG, "fyx_timer_end without fyx_timer_begin");
+    FYX_HIP(c, hipEventRecord(c->ev1, c->stream));
+    FYX_HIP(c, hipEventSynchronize(c->ev1));
+    FYX_HIP(c, hipEventElapsedTime(out_ms, c->ev0, c->ev1));
+    return FYX_OK;
+}
+
+static int* option_slot(fyx_ctx* c, const char* key) {
+    if (!key) return nullptr;
+    if (!strcmp(key, "lbs.block")) return &c->lbs.block;
+    if (!strcmp(key, "lbs.blocks_per_cu")) return &c->lbs.blocks_per_cu;
+    if (!strcmp(key, "lbs.vpt")) return &c->lbs.vpt;
+    if (!strcmp(key, "lbs.exact")) return &c->lbs.exact;
+    if (!strcmp(key, "lbs.nt")) return &c->lbs.nt;
+    return nullptr;
+}
+
+int fyx_set_option(fyx_ctx* c, const char* key, int value) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    int* slot = option_slot(c, key);
+    if (!slot) return fail(c, FYX_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
+    if (slot == &c->lbs.block && value != 256 && value != 512 && value != 1024)
+        return fail(c, FYX_ERR_INVALID_ARG, "lbs.block must be 256, 512 or 1024");
+    if (slot == &c->lbs.vpt && value != 1 && value != 4)
+        return fail(c, FYX_ERR_INVALID_ARG, "lbs.vpt must be 1 or 4");
+    if (slot == &c->lbs.blocks_per_cu && (value < 1 || value > 64))
+        return fail(c, FYX_ERR_INVALID_ARG, "lbs.blocks_per_cu must be 1..64");
+    *slot = value;
+    return FYX_OK;
+}
+
+int fyx_get_option(fyx_ctx* c, const char* key, int* value) {
+    if (!c || !value) return FYX_ERR_INVALID_ARG;
+    int* slot = option_slot(c, key);
+    if (!slot) return fail(c, FYX_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
+    *value = *slot;
+    return FYX_OK;
+}
+
+int fyx_malloc(fyx_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return FYX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (bytes == 0) return FYX_OK;
+    FYX_HIP(c, hipMalloc(out, bytes));
+    return FYX_OK;
+}
+
+int fyx_free(fyx_ctx* c, void* p) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    if (!p) return FYX_OK;
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    FYX_HIP(c, hipFree(p));
+    return FYX_OK;
+}
+
+int fyx_memcpy_h2d(fyx_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    if (!bytes) return FYX_OK;
+    FYX_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+}
+
+int fyx_memcpy_d2h(fyx_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    if (!bytes) return FYX_OK;
+    FYX_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+}
+
+// ---- mesh registry ------------------------------------------------------------------------
+
+int fyx_mesh_upload(fyx_ctx* c, uint64_t mesh_id, const uint8_t* aos, uint32_t n_verts,
+                    uint32_t stride, int off_pos, int off_normal, int off_tangent, int off_weights,
+                    int off_indices) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (n_verts && !aos) return fail(c, FYX_ERR_INVALID_ARG, "vertex bytes are null");
+    if (stride == 0) return fail(c, FYX_ERR_INVALID_ARG, "vertex stride is 0");
+    if (off_pos < 0 || off_weights < 0 || off_indices < 0)
+        return fail(c, FYX_ERR_MISSING_ATTRIBUTE,
+                    "Position, BoneWeight and BoneIndices attributes are required for skinning");
+    struct { int off; uint32_t size; const char* name; } f[] = {
+        {off_pos, 12, "Position"}, {off_normal, 12, "Normal"}, {off_tangent, 16, "Tangent"},
+        {off_weights, 16, "BoneWeight"}, {off_indices, 4, "BoneIndices"}};
+    for (auto& a : f)
+        if (a.off >= 0 && (uint64_t)a.off + a.size > stride)
+            return fail(c, FYX_ERR_INVALID_ARG, "%s at offset %d does not fit vertex size %u", a.name,
+                        a.off, stride);
+    Mesh m;
+    int rc = alloc_mesh(c, m, n_verts, off_normal >= 0, off_tangent >= 0);
+    if (rc) return rc;
+    if (n_verts) {
+        const size_t bytes = (size_t)n_verts * stride;
+        rc = ensure_scratch(c, bytes);
+        if (rc) { free_mesh(m); return rc; }
+        hipError_t e = hipMemcpyAsync(c->scratch, aos, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess)
+            e = fyx::launch_deinterleave(static_cast<const uint8_t*>(c->scratch), n_verts, stride,
+                                         off_pos, off_normal, off_tangent, off_weights, off_indices,
+                                         m.pos, m.nrm, m.tan, m.wgt, m.idx, c->stream);
+        if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "mesh upload"); }
+    }
+    return finish_upload(c, mesh_id, m);
+    FYX_GUARD_END(c)
+}
+
+int fyx_mesh_upload_soa(fyx_ctx* c, uint64_t mesh_id, uint32_t n_verts, const float* pos,
+                        const float* normal, const float* tangent, const float* weights,
+                        const uint8_t* indices) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (n_verts && (!pos || !weights || !indices))
+        return fail(c, FYX_ERR_MISSING_ATTRIBUTE,
+                    "Position, BoneWeight and BoneIndices streams are required for skinning");
+    Mesh m;
+    int rc = alloc_mesh(c, m, n_verts, normal != nullptr, tangent != nullptr);
+    if (rc) return rc;
+    if (n_verts) {
+        const size_t n = n_verts;
+        hipError_t e = hipMemcpyAsync(m.pos, pos, n * 12, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && normal) e = hipMemcpyAsync(m.nrm, normal, n * 12, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && tangent) e = hipMemcpyAsync(m.tan, tangent, n * 16, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(m.wgt, weights, n * 16, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(m.idx, indices, n * 4, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "mesh upload"); }
+    }
+    return finish_upload(c, mesh_id, m);
+    FYX_GUARD_END(c)
+}
+
+int fyx_mesh_free(fyx_ctx* c, uint64_t mesh_id) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    auto it = c->meshes.find(mesh_id);
+    if (it == c->meshes.end())
+        return fail(c, FYX_ERR_UNKNOWN_ID, "mesh %llu is not registered", (unsigned long long)mesh_id);
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    free_mesh(it->second);
+    c->meshes.erase(it);
+    return FYX_OK;
+}
+
+int fyx_mesh_info(fyx_ctx* c, uint64_t mesh_id, uint32_t* n_verts, uint32_t* max_bone_index,
+                  uint32_t* attr_mask) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    const Mesh* m = find_mesh(c, mesh_id);
+    if (!m) return fail(c, FYX_ERR_UNKNOWN_ID, "mesh %llu is not registered", (unsigned long long)mesh_id);
+    if (n_verts) *n_verts = m->n_verts;
+    if (max_bone_index) *max_bone_index = m->max_bone_index;
+    if (attr_mask) *attr_mask = (m->nrm ? 1u : 0u) | (m->tan ? 2u : 0u);
+    return FYX_OK;
+}
+
+int fyx_mesh_streams(fyx_ctx* c, uint64_t mesh_id, const float** d_pos, const float** d_normal,
+                     const float** d_tangent, const float** d_weights, const uint32_t** d_indices) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    const Mesh* m = find_mesh(c, mesh_id);
+    if (!m) return fail(c, FYX_ERR_UNKNOWN_ID, "mesh %llu is not registered", (unsigned long long)mesh_id);
+    if (d_pos) *d_pos = m->pos;
+    if (d_normal) *d_normal = m->nrm;
+    if (d_tangent) *d_tangent = m->tan;
+    if (d_weights) *d_weights = m->wgt;
+    if (d_indices) *d_indices = m->idx;
+    return FYX_OK;
+}
+
+// ---- skinning -----------------------------------------------------------------------------
+
+int fyx_lbs_skin_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, uint32_t n_bones,
+                        uint32_t n_instances, float* d_out_pos, float* d_out_normal,
+                        float* d_out_tangent) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    const Mesh* m = find_mesh(c, mesh_id);
+    int rc = check_skin_args(c, m, mesh_id, d_palette, n_bones, n_instances);
+    if (rc) return rc;
+    if (d_out_normal && !m->nrm)
+        return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Normal attribute");
+    if (d_out_tangent && !m->tan)
+        return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Tangent attribute");
+    const fyx::LbsArgs a = make_args(*m, d_palette, n_bones, n_instances, d_out_pos, d_out_normal, d_out_tangent);
+    FYX_HIP(c, fyx::launch_lbs(a, c->lbs, c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_lbs_skin_streams(fyx_ctx* c, uint32_t n_verts, const float* d_pos, const float* d_normal,
+                         const float* d_tangent, const float* d_weights, const uint32_t* d_indices,
+                         const float* d_palette, uint32_t n_bones, uint32_t n_instances,
+                         float* d_out_pos, float* d_out_normal, float* d_out_tangent) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (!d_palette || !d_weights || !d_indices)
+        return fail(c, FYX_ERR_INVALID_ARG, "palette, weights and indices are required");
+    if (n_bones == 0 || n_bones > 256)
+        return fail(c, FYX_ERR_INVALID_ARG, "n_bones=%u outside 1..256 (bone indices are u8)", n_bones);
+    if (d_out_pos && !d_pos) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "no Position stream");
+    if (d_out_normal && !d_normal) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "no Normal stream");
+    if (d_out_tangent && !d_tangent) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "no Tangent stream");
+    fyx::LbsArgs a;
+    a.pos = d_pos; a.nrm = d_normal; a.tan = d_tangent; a.wgt = d_weights; a.idx = d_indices;
+    a.palette = d_palette;
+    a.out_pos = d_out_pos; a.out_nrm = d_out_normal; a.out_tan = d_out_tangent;
+    a.n_verts = n_verts; a.n_bones = n_bones; a.n_instances = n_instances;
+    FYX_HIP(c, fyx::launch_lbs(a, c->lbs, c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_lbs_skin(fyx_ctx* c, uint64_t mesh_id, const float* palette, uint32_t n_bones,
+                 uint32_t n_instances, float* out_pos, float* out_normal, float* out_tangent,
+                 float* out_aabb) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    const Mesh* m = find_mesh(c, mesh_id);
+    int rc = check_skin_args(c, m, mesh_id, palette, n_bones, n_instances);
+    if (rc) return rc;
+    if (out_normal && !m->nrm) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Normal attribute");
+    if (out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Tangent attribute");
+    const size_t nv = (size_t)m->n_verts * n_instances;
+    const size_t b_pal = align_up((size_t)n_bones * n_instances * 64, 256);
+    const bool need_pos = out_pos || out_aabb;
+    const size_t b_pos = need_pos ? align_up(nv * 12 + 64, 256) : 0;
+    const size_t b_nrm = out_normal ? align_up(nv * 12 + 64, 256) : 0;
+    const size_t b_tan = out_tangent ? align_up(nv * 16 + 64, 256) : 0;
+    rc = ensure_scratch(c, b_pal + b_pos + b_nrm + b_tan + 64);
+    if (rc) return rc;
+    char* p = static_cast<char*>(c->scratch);
+    float* d_pal = reinterpret_cast<float*>(p); p += b_pal;
+    float* d_pos = need_pos ? reinterpret_cast<float*>(p) : nullptr; p += b_pos;
+    float* d_nrm = out_normal ? reinterpret_cast<float*>(p) : nullptr; p += b_nrm;
+    float* d_tan = out_tangent ? reinterpret_cast<float*>(p) : nullptr; p += b_tan;
+    float* d_aabb = reinterpret_cast<float*>(p);
+    FYX_HIP(c, hipMemcpyAsync(d_pal, palette, (size_t)n_bones * n_instances * 64, hipMemcpyHostToDevice, c->stream));
+    const fyx::LbsArgs a = make_args(*m, d_pal, n_bones, n_instances, d_pos, d_nrm, d_tan);
+    FYX_HIP(c, fyx::launch_lbs(a, c->lbs, c->stream));
+    if (out_pos && nv) FYX_HIP(c, hipMemcpyAsync(out_pos, d_pos, nv * 12, hipMemcpyDeviceToHost, c->stream));
+    if (out_normal && nv) FYX_HIP(c, hipMemcpyAsync(out_normal, d_nrm, nv * 12, hipMemcpyDeviceToHost, c->stream));
+    if (out_tangent && nv) FYX_HIP(c, hipMemcpyAsync(out_tangent, d_tan, nv * 16, hipMemcpyDeviceToHost, c->stream));
+    if (out_aabb) {
+        FYX_HIP(c, fyx::launch_points_aabb(d_pos, nv, c->aabb_partials, d_aabb, c->stream));
+        FYX_HIP(c, hipMemcpyAsync(out_aabb, d_aabb, 24, hipMemcpyDeviceToHost, c->stream));
+    }
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_skinned_aabb(fyx_ctx* c, uint64_t mesh_id, const float* palette, uint32_t n_bones,
+                     float out_aabb[6]) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (!out_aabb) return fail(c, FYX_ERR_INVALID_ARG, "out_aabb is null");
+    const Mesh* m = find_mesh(c, mesh_id);
+    int rc = check_skin_args(c, m, mesh_id, palette, n_bones, 1);
+    if (rc) return rc;
+    rc = ensure_scratch(c, (size_t)n_bones * 64 + 256);
+    if (rc) return rc;
+    float* d_pal = static_cast<float*>(c->scratch);
+    float* d_aabb = d_pal + (size_t)n_bones * 16;
+    FYX_HIP(c, hipMemcpyAsync(d_pal, palette, (size_t)n_bones * 64, hipMemcpyHostToDevice, c->stream));
+    const fyx::LbsArgs a = make_args(*m, d_pal, n_bones, 1, nullptr, nullptr, nullptr);
+    FYX_HIP(c, fyx::launch_skinned_aabb(a, c->aabb_partials, d_aabb, c->stream));
+    FYX_HIP(c, hipMemcpyAsync(out_aabb, d_aabb, 24, hipMemcpyDeviceToHost, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+// ---- palette ------------------------------------------------------------------------------
+
+int fyx_palette_device(fyx_ctx* c, const float* d_global, const float* d_inv_bind, uint32_t n,
+                       float* d_out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    if (n && (!d_global || !d_inv_bind || !d_out)) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    FYX_HIP(c, fyx::launch_palette(d_global, d_inv_bind, n, d_out, c->stream));
+    return FYX_OK;
+}
+
+int fyx_palette(fyx_ctx* c, const float* global, const float* inv_bind, uint32_t n, float* out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (n == 0) return FYX_OK;
+    if (!global || !inv_bind || !out) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    const size_t b = (size_t)n * 64;
+    int rc = ensure_scratch(c, 3 * align_up(b, 256));
+    if (rc) return rc;
+    char* p = static_cast<char*>(c->scratch);
+    float* dg = reinterpret_cast<float*>(p);
+    float* di = reinterpret_cast<float*>(p + align_up(b, 256));
+    float* dout = reinterpret_cast<float*>(p + 2 * align_up(b, 256));
+    FYX_HIP(c, hipMemcpyAsync(dg, global, b, hipMemcpyHostToDevice, c->stream));
+    FYX_HIP(c, hipMemcpyAsync(di, inv_bind, b, hipMemcpyHostToDevice, c->stream));
+    FYX_HIP(c, fyx::launch_palette(dg, di, n, dout, c->stream));
+    FYX_HIP(c, hipMemcpyAsync(out, dout, b, hipMemcpyDeviceToHost, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+}  // extern "C"

@@ -1,0 +1,577 @@
+// lbs_kernels.hip -- gfx950 (MI355X / CDNA4) linear-blend skinning kernels.
+//
+// What is computed (reference semantics, file:line relative to the Fyrox repo):
+//   position : out = sum_{k=0..3} M[idx_k].transform_point(p) * w_k
+//              fyrox-impl/src/scene/mesh/mod.rs:501-522 (Mesh::accurate_world_bounding_box)
+//   normal, tangent.xyz : out = sum_k (mat3(M[idx_k]) * v) * w_k ; tangent.w copied
+//              fyrox-material/src/shader/standard/opengl/standard.shader:187-200
+// with nalgebra's operation order: M3x3*v is a column-axpy ((m_i0*x + m_i1*y) + m_i2*z),
+// transform_point adds the translation, then divides by the homogeneous n when n != 0.
+//
+// Hardware mapping (HBM-bound stream: 60 B read + 40 B written per vertex, ~300 VALU):
+//   * inputs/outputs are attribute streams in HBM; every lane access is 12- or 16-byte and
+//     lanes are contiguous, so each wave instruction covers one dense 768 B / 1 KiB span;
+//   * the bone palette of the current instance is staged ONCE per workgroup into LDS,
+//     transposed to three float4 rows per bone (48-byte stride: 3 is coprime with the 16
+//     b128 slots, so a random bone gather spreads over all LDS banks) + a separate row-3
+//     array that only the projective (non-affine) path reads;
+//   * persistent grid (blocks_per_cu x 256 CUs), each workgroup owns a contiguous range of
+//     vertex chunks, re-staging the palette only when the instance changes (crowds);
+//   * vertex loads of a chunk are issued BEFORE the palette staging barrier so the HBM
+//     latency of the first chunk overlaps the L2->LDS staging;
+//   * EXACT=true keeps the reference's unfused operation order (the library is compiled with
+//     -ffp-contract=off), making the GPU result bit-identical to the CPU path; EXACT=false
+//     uses explicit FMAs (<= 1e-5 relative).  f32 VALU only -- no MFMA: this is not a dense
+//     contraction (2.6 FLOP/B).
+#include "fyx_internal.h"
+
+namespace fyx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT, typename T>
+__device__ __forceinline__ T ldg(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void stg(T* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <bool NT>
+__device__ __forceinline__ void ld3(const float* p, float& x, float& y, float& z) {
+    x = ldg<NT>(p); y = ldg<NT>(p + 1); z = ldg<NT>(p + 2);
+}
+template <bool NT>
+__device__ __forceinline__ void st3(float* p, float x, float y, float z) {
+    stg<NT>(p, x); stg<NT>(p + 1, y); stg<NT>(p + 2, z);
+}
+
+// ---------------------------------------------------------------------------------------
+// Palette staging: global column-major mat4 -> LDS rows.  rows[b*3+r] = (m_r0, m_r1, m_r2, t_r),
+// row3[b] = (m30, m31, m32, m33).  Returns (per thread) whether any staged matrix is projective.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool stage_palette(const float* __restrict__ pal, uint32_t n_bones,
+                                              f32x4* rows, f32x4* row3, int tid, int nthreads) {
+    bool projective = false;
+    for (uint32_t b = tid; b < n_bones; b += nthreads) {
+        const f32x4* m = reinterpret_cast<const f32x4*>(pal + (size_t)b * 16);
+        f32x4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
+        rows[b * 3 + 0] = f32x4{c0.x, c1.x, c2.x, c3.x};
+        rows[b * 3 + 1] = f32x4{c0.y, c1.y, c2.y, c3.y};
+        rows[b * 3 + 2] = f32x4{c0.z, c1.z, c2.z, c3.z};
+        row3[b] = f32x4{c0.w, c1.w, c2.w, c3.w};
+        projective |= !(c0.w == 0.0f && c1.w == 0.0f && c2.w == 0.0f && c3.w == 1.0f);
+    }
+    return projective;
+}
+
+// mat3 rows * v, reference order.
+template <bool EXACT>
+__device__ __forceinline__ float dot3(f32x4 r, float x, float y, float z) {
+    if constexpr (EXACT) return (r.x * x + r.y * y) + r.z * z;
+    else return __builtin_fmaf(r.z, z, __builtin_fmaf(r.y, y, r.x * x));
+}
+template <bool EXACT>
+__device__ __forceinline__ float acc(float a, float r, float w) {
+    if constexpr (EXACT) return a + r * w;
+    else return __builtin_fmaf(r, w, a);
+}
+
+struct Skinned {
+    float px, py, pz, nx, ny, nz, tx, ty, tz;
+};
+
+// One vertex, four influences.  MASK bit0 position, bit1 normal, bit2 tangent.
+template <bool EXACT, int MASK>
+__device__ __forceinline__ Skinned skin_vertex(const f32x4* __restrict__ rows,
+                                               const f32x4* __restrict__ row3, bool projective,
+                                               uint32_t id, f32x4 w, float px, float py, float pz,
+                                               float nx, float ny, float nz, float tx, float ty,
+                                               float tz) {
+    Skinned o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = (id >> (8 * k)) & 0xffu;
+        const float wk = w[k];
+        const f32x4 r0 = rows[b * 3 + 0];
+        const f32x4 r1 = rows[b * 3 + 1];
+        const f32x4 r2 = rows[b * 3 + 2];
+        if constexpr (MASK & 1) {
+            float x, y, z;
+            if constexpr (EXACT) {
+                x = dot3<true>(r0, px, py, pz) + r0.w;
+                y = dot3<true>(r1, px, py, pz) + r1.w;
+                z = dot3<true>(r2, px, py, pz) + r2.w;
+            } else {
+                x = __builtin_fmaf(r0.z, pz, __builtin_fmaf(r0.y, py, __builtin_fmaf(r0.x, px, r0.w)));
+                y = __builtin_fmaf(r1.z, pz, __builtin_fmaf(r1.y, py, __builtin_fmaf(r1.x, px, r1.w)));
+                z = __builtin_fmaf(r2.z, pz, __builtin_fmaf(r2.y, py, __builtin_fmaf(r2.x, px, r2.w)));
+            }
+            if (projective) {  // workgroup-uniform
+                const f32x4 r3 = row3[b];
+                const float n = dot3<EXACT>(r3, px, py, pz) + r3.w;
+                if (n != 0.0f) { x = x / n; y = y / n; z = z / n; }
+            }
+            o.px = acc<EXACT>(o.px, x, wk);
+            o.py = acc<EXACT>(o.py, y, wk);
+            o.pz = acc<EXACT>(o.pz, z, wk);
+        }
+        if constexpr (MASK & 2) {
+            o.nx = acc<EXACT>(o.nx, dot3<EXACT>(r0, nx, ny, nz), wk);
+            o.ny = acc<EXACT>(o.ny, dot3<EXACT>(r1, nx, ny, nz), wk);
+            o.nz = acc<EXACT>(o.nz, dot3<EXACT>(r2, nx, ny, nz), wk);
+        }
+        if constexpr (MASK & 4) {
+            o.tx = acc<EXACT>(o.tx, dot3<EXACT>(r0, tx, ty, tz), wk);
+            o.ty = acc<EXACT>(o.ty, dot3<EXACT>(r1, tx, ty, tz), wk);
+            o.tz = acc<EXACT>(o.tz, dot3<EXACT>(r2, tx, ty, tz), wk);
+        }
+    }
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------
+// VPT = 1: one vertex per lane per chunk.  Lane accesses: 12 B (pos, normal), 16 B (tangent,
+// weights), 4 B (indices) -- all lane-contiguous.
+// ---------------------------------------------------------------------------------------
+template <int BLOCK, bool EXACT, bool NT, int MASK>
+__global__ __launch_bounds__(BLOCK) void lbs_skin_v1(LbsArgs a, uint32_t chunks_per_inst,
+                                                     uint32_t total_chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* rows = reinterpret_cast<f32x4*>(smem);
+    f32x4* row3 = rows + 3 * a.n_bones;
+
+    const int tid = threadIdx.x;
+    const uint32_t c_begin = (uint32_t)(((uint64_t)blockIdx.x * total_chunks) / gridDim.x);
+    const uint32_t c_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_chunks) / gridDim.x);
+
+    uint32_t cur_inst = 0xffffffffu;
+    bool projective = false;
+
+    for (uint32_t c = c_begin; c < c_end; ++c) {
+        const uint32_t inst = c / chunks_per_inst;
+        const uint32_t v = (c - inst * chunks_per_inst) * BLOCK + tid;
+        const bool live = v < a.n_verts;
+        const uint32_t vs = live ? v : 0;  // clamp: dead lanes re-read vertex 0 (never stored)
+
+        float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, tx = 0, ty = 0, tz = 0, tw = 0;
+        if constexpr (MASK & 1) ld3<NT>(a.pos + (size_t)vs * 3, px, py, pz);
+        if constexpr (MASK & 2) ld3<NT>(a.nrm + (size_t)vs * 3, nx, ny, nz);
+        if constexpr (MASK & 4) {
+            f32x4 t = ldg<NT>(reinterpret_cast<const f32x4*>(a.tan) + vs);
+            tx = t.x; ty = t.y; tz = t.z; tw = t.w;
+        }
+        const f32x4 w = ldg<NT>(reinterpret_cast<const f32x4*>(a.wgt) + vs);
+        const uint32_t id = ldg<NT>(a.idx + vs);
+
+        if (inst != cur_inst) {  // workgroup-uniform
+            if (cur_inst != 0xffffffffu) __syncthreads();  // all waves done with the old palette
+            const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones,
+                                          rows, row3, tid, BLOCK);
+            projective = __syncthreads_or(pj) != 0;
+            cur_inst = inst;
+        }
+
+        const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, id, w, px, py, pz, nx,
+                                                   ny, nz, tx, ty, tz);
+        if (live) {
+            const size_t ov = (size_t)inst * a.n_verts + v;
+            if constexpr (MASK & 1) st3<NT>(a.out_pos + ov * 3, o.px, o.py, o.pz);
+            if constexpr (MASK & 2) st3<NT>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
+            if constexpr (MASK & 4)
+                stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, tw});
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// VPT = 4: four consecutive vertices per lane; every global access is a 16-byte vector
+// (pos/normal: 3 x float4 per lane at a 48-byte lane stride; tangent/weights: 4 x float4;
+// indices: one uint4).  Requires n_verts % 4 == 0 when n_instances > 1 (16-byte aligned
+// instance pitch); the launcher falls back to VPT = 1 otherwise.  A ragged last group
+// (single instance) is finished by scalar accesses.
+// ---------------------------------------------------------------------------------------
+template <int BLOCK, bool EXACT, bool NT, int MASK>
+__global__ __launch_bounds__(BLOCK) void lbs_skin_v4(LbsArgs a, uint32_t chunks_per_inst,
+                                                     uint32_t total_chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* rows = reinterpret_cast<f32x4*>(smem);
+    f32x4* row3 = rows + 3 * a.n_bones;
+
+    const int tid = threadIdx.x;
+    const uint32_t c_begin = (uint32_t)(((uint64_t)blockIdx.x * total_chunks) / gridDim.x);
+    const uint32_t c_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_chunks) / gridDim.x);
+    const uint32_t n_groups = a.n_verts >> 2;  // full 4-vertex groups
+
+    uint32_t cur_inst = 0xffffffffu;
+    bool projective = false;
+
+    for (uint32_t c = c_begin; c < c_end; ++c) {
+        const uint32_t inst = c / chunks_per_inst;
+        const uint32_t g = (c - inst * chunks_per_inst) * BLOCK + tid;  // 4-vertex group index
+        const bool full = g < n_groups;
+        const bool ragged = (g == n_groups) && (a.n_verts & 3u);
+        const uint32_t gs = full ? g : 0;
+
+        f32x4 P[3], N[3], T[4], W[4];
+        u32x4 ID;
+        if constexpr (MASK & 1) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(a.pos) + (size_t)gs * 3;
+            P[0] = ldg<NT>(p); P[1] = ldg<NT>(p + 1); P[2] = ldg<NT>(p + 2);
+        }
+        if constexpr (MASK & 2) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(a.nrm) + (size_t)gs * 3;
+            N[0] = ldg<NT>(p); N[1] = ldg<NT>(p + 1); N[2] = ldg<NT>(p + 2);
+        }
+        if constexpr (MASK & 4) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(a.tan) + (size_t)gs * 4;
+            T[0] = ldg<NT>(p); T[1] = ldg<NT>(p + 1); T[2] = ldg<NT>(p + 2); T[3] = ldg<NT>(p + 3);
+        }
+        {
+            const f32x4* p = reinterpret_cast<const f32x4*>(a.wgt) + (size_t)gs * 4;
+            W[0] = ldg<NT>(p); W[1] = ldg<NT>(p + 1); W[2] = ldg<NT>(p + 2); W[3] = ldg<NT>(p + 3);
+            ID = ldg<NT>(reinterpret_cast<const u32x4*>(a.idx) + gs);
+        }
+
+        if (inst != cur_inst) {
+            if (cur_inst != 0xffffffffu) __syncthreads();
+            const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones,
+                                          rows, row3, tid, BLOCK);
+            projective = __syncthreads_or(pj) != 0;
+            cur_inst = inst;
+        }
+
+        if (full) {
+            // xyz of vertex j inside three float4: flat[3j..3j+2]
+            float pf[12], nf[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (MASK & 1) pf[q * 4 + e] = P[q][e];
+                    if constexpr (MASK & 2) nf[q * 4 + e] = N[q][e];
+                }
+            float po[12], no[12];
+            f32x4 TO[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Skinned o = skin_vertex<EXACT, MASK>(
+                    rows, row3, projective, ID[j], W[j], (MASK & 1) ? pf[3 * j] : 0.f,
+                    (MASK & 1) ? pf[3 * j + 1] : 0.f, (MASK & 1) ? pf[3 * j + 2] : 0.f,
+                    (MASK & 2) ? nf[3 * j] : 0.f, (MASK & 2) ? nf[3 * j + 1] : 0.f,
+                    (MASK & 2) ? nf[3 * j + 2] : 0.f, (MASK & 4) ? T[j].x : 0.f,
+                    (MASK & 4) ? T[j].y : 0.f, (MASK & 4) ? T[j].z : 0.f);
+                po[3 * j] = o.px; po[3 * j + 1] = o.py; po[3 * j + 2] = o.pz;
+                no[3 * j] = o.nx; no[3 * j + 1] = o.ny; no[3 * j + 2] = o.nz;
+                if constexpr (MASK & 4) TO[j] = f32x4{o.tx, o.ty, o.tz, T[j].w};
+                // keep the four vertices sequential: without this fence the scheduler hoists all
+                // 48 LDS row reads (192 VGPRs) ahead of the math and the kernel spills
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const size_t og = ((size_t)inst * a.n_verts >> 2) + g;  // n_verts%4==0 if inst>0
+            if constexpr (MASK & 1) {
+                f32x4* p = reinterpret_cast<f32x4*>(a.out_pos) + og * 3;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    stg<NT>(p + q, f32x4{po[q * 4], po[q * 4 + 1], po[q * 4 + 2], po[q * 4 + 3]});
+            }
+            if constexpr (MASK & 2) {
+                f32x4* p = reinterpret_cast<f32x4*>(a.out_nrm) + og * 3;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    stg<NT>(p + q, f32x4{no[q * 4], no[q * 4 + 1], no[q * 4 + 2], no[q * 4 + 3]});
+            }
+            if constexpr (MASK & 4) {
+                f32x4* p = reinterpret_cast<f32x4*>(a.out_tan) + og * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) stg<NT>(p + j, TO[j]);
+            }
+        } else if (ragged) {  // single instance only (launcher guarantees)
+            for (uint32_t v = n_groups * 4; v < a.n_verts; ++v) {
+                float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, tx = 0, ty = 0, tz = 0, tw = 0;
+                if constexpr (MASK & 1) ld3<false>(a.pos + (size_t)v * 3, px, py, pz);
+                if constexpr (MASK & 2) ld3<false>(a.nrm + (size_t)v * 3, nx, ny, nz);
+                if constexpr (MASK & 4) {
+                    tx = a.tan[(size_t)v * 4]; ty = a.tan[(size_t)v * 4 + 1];
+                    tz = a.tan[(size_t)v * 4 + 2]; tw = a.tan[(size_t)v * 4 + 3];
+                }
+                const f32x4 w = reinterpret_cast<const f32x4*>(a.wgt)[v];
+                const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, a.idx[v], w, px,
+                                                           py, pz, nx, ny, nz, tx, ty, tz);
+                if constexpr (MASK & 1) st3<false>(a.out_pos + (size_t)v * 3, o.px, o.py, o.pz);
+                if constexpr (MASK & 2) st3<false>(a.out_nrm + (size_t)v * 3, o.nx, o.ny, o.nz);
+                if constexpr (MASK & 4) {
+                    float* t = a.out_tan + (size_t)v * 4;
+                    t[0] = o.tx; t[1] = o.ty; t[2] = o.tz; t[3] = tw;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------
+template <int BLOCK, bool EXACT, bool NT, int MASK>
+static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s, bool v4) {
+    const uint32_t per_chunk = BLOCK * (v4 ? 4 : 1);
+    const uint32_t cpi = (a.n_verts + per_chunk - 1) / per_chunk;
+    const uint64_t total64 = (uint64_t)cpi * a.n_instances;
+    if (total64 == 0) return hipSuccess;
+    if (total64 > 0xffffffffull) return hipErrorInvalidValue;
+    const uint32_t total = (uint32_t)total64;
+    uint32_t grid = (uint32_t)kCUs * (uint32_t)(t.blocks_per_cu > 0 ? t.blocks_per_cu : 1);
+    if (grid > total) grid = total;
+    const size_t lds = (size_t)a.n_bones * 64;
+    if (v4)
+        hipLaunchKernelGGL((lbs_skin_v4<BLOCK, EXACT, NT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
+                           cpi, total);
+    else
+        hipLaunchKernelGGL((lbs_skin_v1<BLOCK, EXACT, NT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
+                           cpi, total);
+    return hipGetLastError();
+}
+
+template <int BLOCK, bool EXACT, bool NT>
+static hipError_t launch_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s, bool v4) {
+    const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
+    switch (mask) {
+        case 1: return launch_one<BLOCK, EXACT, NT, 1>(a, t, s, v4);
+        case 2: return launch_one<BLOCK, EXACT, NT, 2>(a, t, s, v4);
+        case 3: return launch_one<BLOCK, EXACT, NT, 3>(a, t, s, v4);
+        case 4: return launch_one<BLOCK, EXACT, NT, 4>(a, t, s, v4);
+        case 5: return launch_one<BLOCK, EXACT, NT, 5>(a, t, s, v4);
+        case 6: return launch_one<BLOCK, EXACT, NT, 6>(a, t, s, v4);
+        case 7: return launch_one<BLOCK, EXACT, NT, 7>(a, t, s, v4);
+        default: return hipSuccess;  // nothing requested
+    }
+}
+
+template <int BLOCK>
+static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t s, bool v4) {
+    if (t.exact) return t.nt ? launch_mask<BLOCK, true, true>(a, t, s, v4)
+                             : launch_mask<BLOCK, true, false>(a, t, s, v4);
+    return t.nt ? launch_mask<BLOCK, false, true>(a, t, s, v4)
+                : launch_mask<BLOCK, false, false>(a, t, s, v4);
+}
+
+hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream) {
+    if (a.n_verts == 0 || a.n_instances == 0) return hipSuccess;
+    bool v4 = (t.vpt == 4);
+    if (v4 && a.n_instances > 1 && (a.n_verts & 3u)) v4 = false;  // unaligned instance pitch
+    switch (t.block) {
+        case 512: return launch_block<512>(a, t, stream, v4);
+        case 1024: return launch_block<1024>(a, t, stream, v4);
+        default: return launch_block<256>(a, t, stream, v4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// AoS -> SoA de-interleave.  One thread per vertex; field reads are 4-byte loads at the
+// vertex stride (the AoS source is read once per mesh modification, not per frame).
+// Bytes are reinterpreted as little-endian f32/u8 exactly as VertexReadTrait does
+// (fyrox-impl/src/scene/mesh/buffer.rs:1279-1321).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rd_u32_unaligned(const uint8_t* p) {
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) return *reinterpret_cast<const uint32_t*>(p);
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+__global__ __launch_bounds__(256) void deinterleave_kernel(
+    const uint8_t* __restrict__ aos, uint32_t n_verts, uint32_t stride, int off_pos, int off_nrm,
+    int off_tan, int off_wgt, int off_idx, uint32_t* __restrict__ pos, uint32_t* __restrict__ nrm,
+    uint32_t* __restrict__ tan, uint32_t* __restrict__ wgt, uint32_t* __restrict__ idx) {
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_verts;
+         v += gridDim.x * blockDim.x) {
+        const uint8_t* b = aos + (size_t)v * stride;
+        for (int i = 0; i < 3; ++i) pos[(size_t)v * 3 + i] = rd_u32_unaligned(b + off_pos + 4 * i);
+        if (off_nrm >= 0)
+            for (int i = 0; i < 3; ++i) nrm[(size_t)v * 3 + i] = rd_u32_unaligned(b + off_nrm + 4 * i);
+        if (off_tan >= 0)
+            for (int i = 0; i < 4; ++i) tan[(size_t)v * 4 + i] = rd_u32_unaligned(b + off_tan + 4 * i);
+        for (int i = 0; i < 4; ++i) wgt[(size_t)v * 4 + i] = rd_u32_unaligned(b + off_wgt + 4 * i);
+        idx[v] = rd_u32_unaligned(b + off_idx);
+    }
+}
+
+hipError_t launch_deinterleave(const uint8_t* d_aos, uint32_t n_verts, uint32_t stride, int off_pos,
+                               int off_nrm, int off_tan, int off_wgt, int off_idx, float* d_pos,
+                               float* d_nrm, float* d_tan, float* d_wgt, uint32_t* d_idx,
+                               hipStream_t stream) {
+    if (n_verts == 0) return hipSuccess;
+    uint32_t grid = (n_verts + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(grid), dim3(256), 0, stream, d_aos, n_verts, stride,
+                       off_pos, off_nrm, off_tan, off_wgt, off_idx,
+                       reinterpret_cast<uint32_t*>(d_pos), reinterpret_cast<uint32_t*>(d_nrm),
+                       reinterpret_cast<uint32_t*>(d_tan), reinterpret_cast<uint32_t*>(d_wgt), d_idx);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// max bone index (validation at upload; skinning rejects palettes shorter than max+1,
+// where the Rust loop would panic on `bone_matrices[bone_index as usize]`).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void max_bone_index_kernel(const uint32_t* __restrict__ idx,
+                                                             uint32_t n, uint32_t* out) {
+    uint32_t m = 0;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const uint32_t id = idx[v];
+        m = max(m, max(max(id & 0xffu, (id >> 8) & 0xffu), max((id >> 16) & 0xffu, id >> 24)));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32_t* d_out,
+                                 hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess || n_verts == 0) return e;
+    uint32_t grid = (n_verts + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(max_bone_index_kernel, dim3(grid), dim3(256), 0, stream, d_idx, n_verts, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// AABB of skinned positions (Mesh::accurate_world_bounding_box, scene/mesh/mod.rs:470-526;
+// default box = (+MAX, -MAX), add_point = strict </> compares, fyrox-math/src/aabb.rs:33-104).
+// min/max are exact, so any reduction order gives the reference's result.
+// ---------------------------------------------------------------------------------------
+constexpr int kAabbBlock = 256;
+constexpr uint32_t kAabbMaxBlocks = 2048;
+
+uint32_t aabb_partial_blocks(uint32_t n) {
+    uint32_t g = (n + kAabbBlock - 1) / kAabbBlock;
+    if (g == 0) g = 1;
+    return g > kAabbMaxBlocks ? kAabbMaxBlocks : g;
+}
+
+__device__ __forceinline__ void block_minmax_store(float mn[3], float mx[3], float* partial) {
+    __shared__ float sm[kAabbBlock / 64][6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[i] = fminf(mn[i], __shfl_xor(mn[i], o, 64));
+            mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o, 64));
+        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 3; ++i) { sm[wave][i] = mn[i]; sm[wave][3 + i] = mx[i]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kAabbBlock / 64; ++w)
+            for (int i = 0; i < 3; ++i) {
+                sm[0][i] = fminf(sm[0][i], sm[w][i]);
+                sm[0][3 + i] = fmaxf(sm[0][3 + i], sm[w][3 + i]);
+            }
+        for (int i = 0; i < 6; ++i) partial[i] = sm[0][i];
+    }
+}
+
+__global__ __launch_bounds__(kAabbBlock) void skinned_aabb_kernel(LbsArgs a, float* partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* rows = reinterpret_cast<f32x4*>(smem);
+    f32x4* row3 = rows + 3 * a.n_bones;
+    const bool pj = stage_palette(a.palette, a.n_bones, rows, row3, threadIdx.x, kAabbBlock);
+    const bool projective = __syncthreads_or(pj) != 0;
+    float mn[3] = {__FLT_MAX__, __FLT_MAX__, __FLT_MAX__};
+    float mx[3] = {-__FLT_MAX__, -__FLT_MAX__, -__FLT_MAX__};
+    for (uint32_t v = blockIdx.x * kAabbBlock + threadIdx.x; v < a.n_verts;
+         v += gridDim.x * kAabbBlock) {
+        float px, py, pz;
+        ld3<false>(a.pos + (size_t)v * 3, px, py, pz);
+        const f32x4 w = reinterpret_cast<const f32x4*>(a.wgt)[v];
+        const Skinned o = skin_vertex<true, 1>(rows, row3, projective, a.idx[v], w, px, py, pz, 0, 0,
+                                               0, 0, 0, 0);
+        // strict compares as add_point: NaN never replaces a bound
+        if (o.px < mn[0]) mn[0] = o.px;
+        if (o.py < mn[1]) mn[1] = o.py;
+        if (o.pz < mn[2]) mn[2] = o.pz;
+        if (o.px > mx[0]) mx[0] = o.px;
+        if (o.py > mx[1]) mx[1] = o.py;
+        if (o.pz > mx[2]) mx[2] = o.pz;
+    }
+    block_minmax_store(mn, mx, partials + (size_t)blockIdx.x * 6);
+}
+
+__global__ __launch_bounds__(kAabbBlock) void points_aabb_kernel(const float* __restrict__ xyz,
+                                                                 uint64_t n, float* partials) {
+    float mn[3] = {__FLT_MAX__, __FLT_MAX__, __FLT_MAX__};
+    float mx[3] = {-__FLT_MAX__, -__FLT_MAX__, -__FLT_MAX__};
+    for (uint64_t v = (uint64_t)blockIdx.x * kAabbBlock + threadIdx.x; v < n;
+         v += (uint64_t)gridDim.x * kAabbBlock) {
+        float x, y, z;
+        ld3<false>(xyz + v * 3, x, y, z);
+        if (x < mn[0]) mn[0] = x;
+        if (y < mn[1]) mn[1] = y;
+        if (z < mn[2]) mn[2] = z;
+        if (x > mx[0]) mx[0] = x;
+        if (y > mx[1]) mx[1] = y;
+        if (z > mx[2]) mx[2] = z;
+    }
+    block_minmax_store(mn, mx, partials + (size_t)blockIdx.x * 6);
+}
+
+__global__ __launch_bounds__(kAabbBlock) void aabb_final_kernel(const float* partials, uint32_t n,
+                                                                float* out) {
+    float mn[3] = {__FLT_MAX__, __FLT_MAX__, __FLT_MAX__};
+    float mx[3] = {-__FLT_MAX__, -__FLT_MAX__, -__FLT_MAX__};
+    for (uint32_t b = threadIdx.x; b < n; b += kAabbBlock)
+        for (int i = 0; i < 3; ++i) {
+            mn[i] = fminf(mn[i], partials[(size_t)b * 6 + i]);
+            mx[i] = fmaxf(mx[i], partials[(size_t)b * 6 + 3 + i]);
+        }
+    block_minmax_store(mn, mx, out);
+}
+
+hipError_t launch_skinned_aabb(const LbsArgs& a, float* d_partials, float* d_out, hipStream_t s) {
+    const uint32_t grid = aabb_partial_blocks(a.n_verts);
+    hipLaunchKernelGGL(skinned_aabb_kernel, dim3(grid), dim3(kAabbBlock), (size_t)a.n_bones * 64, s, a,
+                       d_partials);
+    hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(kAabbBlock), 0, s, d_partials, grid, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_points_aabb(const float* d_xyz, uint64_t n_points, float* d_partials, float* d_out,
+                              hipStream_t s) {
+    const uint32_t grid = aabb_partial_blocks((uint32_t)(n_points > 0xffffffffull ? 0xffffffffu : n_points));
+    hipLaunchKernelGGL(points_aabb_kernel, dim3(grid), dim3(kAabbBlock), 0, s, d_xyz, n_points,
+                       d_partials);
+    hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(kAabbBlock), 0, s, d_partials, grid, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// palette[i] = global[i] * inv_bind[i]   (scene/mesh/mod.rs:781-793; nalgebra gemm order:
+// y = a_col0*b_0j ; y = a_colk*b_kj + y).  One thread per output element.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void palette_kernel(const float* __restrict__ A,
+                                                      const float* __restrict__ B, uint32_t n,
+                                                      float* __restrict__ out) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * 16) return;
+    const uint32_t m = e >> 4, j = (e >> 2) & 3, i = e & 3;
+    const float* a = A + (size_t)m * 16;
+    const float* b = B + (size_t)m * 16;
+    float y = a[i] * b[j * 4];
+    y = a[4 + i] * b[j * 4 + 1] + y;
+    y = a[8 + i] * b[j * 4 + 2] + y;
+    y = a[12 + i] * b[j * 4 + 3] + y;
+    out[e] = y;
+}
+
+hipError_t launch_palette(const float* d_global, const float* d_inv_bind, uint32_t n, float* d_out,
+                          hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(palette_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, d_global,
+                       d_inv_bind, n, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace fyx

@@ -1,0 +1,130 @@
+/*
+ * fyrox_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE).
+ *
+ * A plain-C, scalar-f32 restatement of the Fyrox skeletal-animation hot path
+ * (pose sampling/blending -> local TRS -> hierarchy -> bone palette -> 4-weight
+ * linear-blend skinning).  Each function cites the reference file:line it
+ * follows (paths relative to /root/reference).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+ * load this library.  The product path (fyrox_amd/ + libfyrox_hip.so) never
+ * links, imports or calls anything in oracle/.
+ *
+ * PARITY PINNING.  The reference is Rust and cannot be compiled here (no
+ * rustc/cargo), and its arithmetic leaves live in the un-vendored crate
+ * nalgebra 0.35 (fyrox-math/Cargo.toml; no Cargo.lock).  So:
+ *   - PINNED by the reference's own unit-test vectors (tests/golden/ .json files,
+ *     transcribed from the cited #[test] bodies): Curve::value_at /
+ *     CurveKey::interpolate (fyrox-math/src/curve.rs:429-566), wrapf
+ *     (fyrox-math/src/lib.rs:1142-1147), quat_from_euler (lib.rs:1462-1478),
+ *     BlendSpace::fetch_weights (machine/node/blendspace.rs:456-537),
+ *     vertex-buffer fixture (scene/mesh/buffer.rs:1678-1720),
+ *     graph hierarchy (scene/graph/mod.rs:2602-2739).
+ *   - PARITY UNPINNED (no reference test asserts any output): LBS, palette,
+ *     Transform::calculate_local_transform, every blend_with, Machine.  For
+ *     those the oracle's authority is line-by-line fidelity to the cited code
+ *     and to nalgebra's published operation order (restated in the comments),
+ *     plus the self-consistency properties in tests/test_oracle_*.py.
+ *
+ * Build: `make -C oracle` (gcc -O2 -ffp-contract=off: Rust never fuses a*b+c).
+ * All matrices are nalgebra-layout column-major float[16]: m[col*4 + row].
+ * Quaternions are nalgebra storage order float[4] = (i, j, k, w).
+ */
+#ifndef FYROX_ORACLE_H
+#define FYROX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------- nalgebra leaves ---------- */
+void fo_mat4_identity(float out[16]);
+void fo_mat4_mul(const float a[16], const float b[16], float out[16]);
+void fo_mat4_transform_point(const float m[16], const float p[3], float out[3]);
+void fo_mat4_transform_vector(const float m[16], const float v[3], float out[3]);
+void fo_mat3_of_mat4_mul_vec(const float m[16], const float v[3], float out[3]);
+float fo_vec4_dot(const float a[4], const float b[4]);
+void fo_quat_mul(const float a[4], const float b[4], float out[4]);
+void fo_quat_from_axis_angle(int axis, float angle, float out[4]);
+void fo_quat_normalize(const float q[4], float out[4]);
+void fo_quat_to_mat3(const float q[4], float out9_colmajor[9]);
+void fo_vec_lerp(const float* a, const float* b, float t, int n, float* out);
+void fo_quat_nlerp_shortest(const float a[4], const float b[4], float w, float out[4]);
+
+/* ---------- fyrox-math ---------- */
+float fo_lerpf(float a, float b, float t);
+float fo_cubicf(float p0, float p1, float t, float m0, float m1);
+float fo_wrapf(float n, float min_limit, float max_limit);
+float fo_stepf(float p0, float p1, float t);
+/* order: 0=XYZ 1=XZY 2=YZX 3=YXZ 4=ZXY 5=ZYX */
+void fo_quat_from_euler(const float euler[3], int order, float out[4]);
+
+/* Curve key kinds */
+enum { FO_KEY_CONSTANT = 0, FO_KEY_LINEAR = 1, FO_KEY_CUBIC = 2 };
+
+typedef struct fo_curve {
+    uint32_t n_keys;
+    const float* location;     /* sorted ascending */
+    const float* value;
+    const uint8_t* kind;       /* FO_KEY_* */
+    const float* left_tangent; /* only read for FO_KEY_CUBIC keys */
+    const float* right_tangent;
+} fo_curve;
+
+float fo_key_interpolate(float left_value, int left_kind, float left_right_tangent,
+                         float right_value, int right_kind, float right_left_tangent, float t);
+float fo_curve_value_at(const fo_curve* c, float location, size_t* hint);
+
+/* TrackValueKind */
+enum {
+    FO_KIND_REAL = 0, FO_KIND_VEC2 = 1, FO_KIND_VEC3 = 2, FO_KIND_VEC4 = 3,
+    FO_KIND_QUAT_EULER = 4, FO_KIND_QUAT = 5
+};
+/* returns number of floats written to out (0 == None) */
+int fo_track_fetch(const fo_curve* curves, uint32_t n_curves, int kind, float time,
+                   size_t hints[4], float out[4]);
+
+/* ---------- scene ---------- */
+typedef struct fo_transform {
+    float local_position[3];
+    float local_rotation[4];
+    float local_scale[3];
+    float pre_rotation[4];
+    float post_rotation_matrix[9]; /* Matrix3, column-major; identity by default */
+    float rotation_offset[3];
+    float rotation_pivot[3];
+    float scaling_offset[3];
+    float scaling_pivot[3];
+} fo_transform;
+void fo_transform_default(fo_transform* t);
+void fo_calculate_local_transform(const fo_transform* t, float out[16]);
+/* parent[i] < i or -1 (root): global = parent.global * local, depth first == topological */
+void fo_update_global_transforms(const float* local, const int32_t* parent, uint32_t n, float* global);
+void fo_palette(const float* global, const float* inv_bind, uint32_t n, float* out);
+
+/* ---------- LBS ---------- */
+/* packed streams: pos 3N, nrm 3N, tan 4N (w passed through), weights 4N, indices 4N u8.
+ * any of nrm/tan/out_* may be NULL.  Returns 0, or -1 if an index >= n_bones. */
+int fo_lbs_skin(uint32_t n_verts, const float* pos, const float* nrm, const float* tan,
+                const float* weights, const uint8_t* indices,
+                const float* palette, uint32_t n_bones,
+                float* out_pos, float* out_nrm, float* out_tan);
+/* OpenMP variant (NOT in the reference; labelled as such) */
+int fo_lbs_skin_omp(uint32_t n_verts, const float* pos, const float* nrm, const float* tan,
+                    const float* weights, const uint8_t* indices,
+                    const float* palette, uint32_t n_bones,
+                    float* out_pos, float* out_nrm, float* out_tan, int n_threads);
+/* Mesh::accurate_world_bounding_box skinned branch over an AoS vertex buffer.
+ * aabb = {min xyz, max xyz}.  Returns vertices consumed. */
+uint32_t fo_accurate_world_bounding_box(const uint8_t* aos, uint32_t n_verts, uint32_t stride,
+                                        int off_pos, int off_weights, int off_indices,
+                                        const float* palette, uint32_t n_bones, float aabb[6]);
+int fo_omp_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+"""The C-ABI library loads, exports every symbol include/fyrox_hip.h declares, and fails LOUDLY
+(no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import fyrox_amd
+from fyrox_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            src = open(os.path.join(ROOT, "include", fn)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names |= set(re.findall(r"\b(fyx_[a-z0-9_]+)\s*\(", src))
+    return names
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(fyrox_amd.LIB_PATH), "run __graft_entry__.build()"
+    assert os.path.dirname(fyrox_amd.LIB_PATH) == os.path.join(ROOT, "fyrox_amd")
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    raw = ctypes.CDLL(fyrox_amd.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in include/*.h but not exported"
+    assert declared == set(_native.exported_symbols()), declared ^ set(_native.exported_symbols())
+    _native.lib()  # binds argtypes for every symbol; AttributeError if one is missing
+
+
+def test_version_string():
+    assert b"gfx950" in _native.lib().fyx_version()
+
+
+def test_code_object_targets_gfx950_only():
+    data = open(fyrox_amd.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"nvptx"):
+        assert other not in data
+
+
+def test_product_never_references_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fyrox_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f)).read()
+                assert "fyrox_oracle" not in src, f
+                assert not re.search(r"^\s*(import oracle|from oracle)", src, flags=re.M), f
+    ldd = os.popen(f"objdump -p {fyrox_amd.LIB_PATH}").read()
+    assert "oracle" not in ldd
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_no_gpu_fails_loudly_instead_of_falling_back():
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        fyrox_amd.Context(0)
+    assert e.value.code == _native.FYX_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_null_context_is_rejected_not_crashing():
+    l = _native.lib()
+    assert l.fyx_sync(None) == _native.FYX_ERR_INVALID_ARG
+    assert l.fyx_mesh_free(None, 1) == _native.FYX_ERR_INVALID_ARG
+    assert l.fyx_lbs_skin(None, 1, None, 1, 1, None, None, None, None) == _native.FYX_ERR_INVALID_ARG
+    assert l.fyx_last_error(None) == b"null context"
+    l.fyx_shutdown(None)
