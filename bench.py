@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--allgather", action="store_true", help="N>1: add the RCCL all-gather of the skinned buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (e.g. lbs.vpt=4)")
+    ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (e.g. lbs.prefetch=0)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity spot-check before timing")
     return ap.parse_args()
 
@@ -104,13 +104,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    ctx = fyrox_amd.Context(local_rank)
-    stream = torch.cuda.Stream()
-    ctx.set_stream(stream.cuda_stream)     # fyx kernels and torch.cuda.Event share this stream
+    ctx = fyrox_amd.Context(local_rank)    # owns its launch streams; torch is only used for RCCL + barriers
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    opts = {k: ctx.get_option(k) for k in ("lbs.block", "lbs.blocks_per_cu", "lbs.vpt", "lbs.exact", "lbs.nt")}
+    opts = {k: ctx.get_option(k) for k in ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams")}
 
     # ---- synthetic inputs; each rank owns a different vertex-range shard --------
     seed = synth.SEED_BASE + 4
@@ -130,14 +128,24 @@ def main():
                     torch.empty(world * (nv * 3 + 16), dtype=torch.float32, device="cuda"),
                     torch.empty(world * (nv * 4 + 16), dtype=torch.float32, device="cuda")]
 
+    # One foreign call per step: fyx_lbs_skin_device(ctx, mesh_id, d_palette, n_bones, 1, out...) with
+    # the ctypes arguments converted once, so the Python side costs ~1 us per launch.
+    import ctypes
+    from functools import partial
+    fn = ctx._l.fyx_lbs_skin_device
+    calls = [partial(fn, ctx._h, ctypes.c_uint64(s), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones),
+                     ctypes.c_uint32(1), ctypes.c_void_p(o[0].data_ptr()), ctypes.c_void_p(o[1].data_ptr()),
+                     ctypes.c_void_p(o[2].data_ptr())) for s, o in enumerate(outs)]
+    n_sets = args.sets
+
     def step(i: int):
-        s = i % args.sets
-        op, on, ot = outs[s]
-        ctx.lbs_skin_device(s, d_pal.data_ptr(), args.bones, 1, op.data_ptr(), on.data_ptr(), ot.data_ptr())
+        rc = calls[i % n_sets]()
+        if rc:
+            ctx._check(rc)
         if gathered is not None:
-            with torch.cuda.stream(stream):
-                for g, o in zip(gathered, (op, on, ot)):
-                    dist.all_gather_into_tensor(g, o)
+            ctx.sync()                       # skinned shard complete before RCCL reads it
+            for g, o in zip(gathered, outs[i % n_sets]):
+                dist.all_gather_into_tensor(g, o)
 
     # ---- parity spot-check against the oracle before timing (checker only) -------------------
     parity = None
@@ -158,6 +166,7 @@ def main():
             raise SystemExit(f"parity check failed before timing: max rel err {err:.3e} > 1e-5")
 
     def barrier():
+        ctx.sync()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -165,16 +174,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
+    ctx.timer_begin()                        # hipEvent on the context stream (joins the launch streams)
     for i in range(args.steps):
         step(args.warmup + i)
-    ev1.record(stream)
+    gpu_ms = ctx.timer_end()                 # second hipEvent after a GPU-side join of all launch streams
     barrier()
     elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream, whole timed region
     if dist is not None:
         t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

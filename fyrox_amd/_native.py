@@ -54,6 +54,7 @@ _SIGS = {
     "fyx_set_stream": (c_int, [_P, _P]),
     "fyx_get_stream": (c_void_p, [_P]),
     "fyx_sync": (c_int, [_P]),
+    "fyx_join": (c_int, [_P]),
     "fyx_timer_begin": (c_int, [_P]),
     "fyx_timer_end": (c_int, [_P, POINTER(c_float)]),
     "fyx_set_option": (c_int, [_P, c_char_p, c_int]),
@@ -71,6 +72,7 @@ _SIGS = {
     "fyx_lbs_skin_device": (c_int, [_P, c_uint64, _P, c_uint32, c_uint32, _P, _P, _P]),
     "fyx_lbs_skin_streams": (c_int, [_P, c_uint32, _P, _P, _P, _P, _P, _P, c_uint32, c_uint32, _P, _P, _P]),
     "fyx_skinned_aabb": (c_int, [_P, c_uint64, _P, c_uint32, _P]),
+    "fyx_calib_stream_copy": (c_int, [_P, _P, _P, c_uint32]),
     "fyx_palette": (c_int, [_P, _P, _P, c_uint32, _P]),
     "fyx_palette_device": (c_int, [_P, _P, _P, c_uint32, _P]),
 }

@@ -90,6 +90,10 @@ class Context:
     def sync(self) -> None:
         self._check(self._l.fyx_sync(self._h))
 
+    def join(self) -> None:
+        """GPU-side join: the context stream waits for every in-flight skinning launch."""
+        self._check(self._l.fyx_join(self._h))
+
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._l.fyx_set_stream(self._h, hip_stream))
 
@@ -195,6 +199,9 @@ class Context:
         box = np.empty(6, np.float32)
         self._check(self._l.fyx_skinned_aabb(self._h, mesh_id, _ptr(palette), palette.shape[0], _ptr(box)))
         return box
+
+    def calib_stream_copy(self, d_src: int, d_dst: int, units: int) -> None:
+        self._check(self._l.fyx_calib_stream_copy(self._h, d_src, d_dst, units))
 
     # -- palette -------------------------------------------------------------------------
     def palette(self, global_, inv_bind) -> np.ndarray:

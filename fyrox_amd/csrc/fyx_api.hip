@@ -39,6 +39,17 @@ struct fyx_ctx {
     float* aabb_partials = nullptr;  // 6 * 2048 floats + 8
     uint32_t* d_u32 = nullptr;       // 1 word
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Worker streams for independent skinning launches (see "stream semantics" in fyrox_hip.h).
+    static constexpr int kMaxWorkers = 4;
+    int n_workers = 2;  // option "lbs.streams"; 1 = launch on the context stream itself
+    hipStream_t workers[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t worker_done[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
+    bool worker_busy[kMaxWorkers] = {false, false, false, false};
+    uint64_t worker_seen[kMaxWorkers] = {0, 0, 0, 0};
+    hipEvent_t fork_ev = nullptr;
+    uint64_t fork_gen = 0;
+    bool primary_dirty = true;  // context-stream work enqueued since the last fork event
+    int next_worker = 0;
 };
 
 namespace {
@@ -67,6 +78,53 @@ int hip_fail(fyx_ctx* c, hipError_t e, const char* what) {
     } while (0)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Make the context stream wait for every in-flight worker launch (GPU-side join, no host wait).
+int join_workers(fyx_ctx* c) {
+    for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
+        if (!c->worker_busy[w]) continue;
+        FYX_HIP(c, hipEventRecord(c->worker_done[w], c->workers[w]));
+        FYX_HIP(c, hipStreamWaitEvent(c->stream, c->worker_done[w], 0));
+        c->worker_busy[w] = false;
+    }
+    return FYX_OK;
+}
+
+// Called by every entry point that enqueues work on (or synchronises) the context stream.
+int enter_primary(fyx_ctx* c) {
+    int rc = join_workers(c);
+    c->primary_dirty = true;
+    return rc;
+}
+
+// Pick the stream for an independent skinning launch: a worker, ordered after everything that
+// was on the context stream at this moment (one fork event per batch of context-stream work).
+int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
+    if (c->n_workers <= 1) {
+        int rc = enter_primary(c);
+        *out = c->stream;
+        return rc;
+    }
+    const int w = c->next_worker;
+    c->next_worker = (w + 1) % c->n_workers;
+    if (!c->workers[w]) {
+        FYX_HIP(c, hipStreamCreateWithFlags(&c->workers[w], hipStreamNonBlocking));
+        FYX_HIP(c, hipEventCreateWithFlags(&c->worker_done[w], hipEventDisableTiming));
+    }
+    if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    if (c->primary_dirty || c->stream != c->own_stream) {  // a borrowed stream may have foreign work
+        FYX_HIP(c, hipEventRecord(c->fork_ev, c->stream));
+        ++c->fork_gen;
+        c->primary_dirty = false;
+    }
+    if (c->worker_seen[w] != c->fork_gen) {
+        FYX_HIP(c, hipStreamWaitEvent(c->workers[w], c->fork_ev, 0));
+        c->worker_seen[w] = c->fork_gen;
+    }
+    c->worker_busy[w] = true;
+    *out = c->workers[w];
+    return FYX_OK;
+}
 
 int ensure_scratch(fyx_ctx* c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return FYX_OK;
@@ -197,6 +255,11 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->aabb_partials) (void)hipFree(c->aabb_partials);
     if (c->d_u32) (void)hipFree(c->d_u32);
+    for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
+        if (c->workers[w]) { (void)hipStreamSynchronize(c->workers[w]); (void)hipStreamDestroy(c->workers[w]); }
+        if (c->worker_done[w]) (void)hipEventDestroy(c->worker_done[w]);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -207,14 +270,21 @@ const char* fyx_last_error(const fyx_ctx* c) { return c ? c->err.c_str() : "null
 
 int fyx_set_stream(fyx_ctx* c, void* s) {
     if (!c) return FYX_ERR_INVALID_ARG;
+    if (int rc = enter_primary(c)) return rc;
     c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
     return FYX_OK;
 }
 
 void* fyx_get_stream(fyx_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
 
+int fyx_join(fyx_ctx* c) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    return enter_primary(c);
+}
+
 int fyx_sync(fyx_ctx* c) {
     if (!c) return FYX_ERR_INVALID_ARG;
+    if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     return FYX_OK;
 }
@@ -222,6 +292,7 @@ int fyx_sync(fyx_ctx* c) {
 int fyx_timer_begin(fyx_ctx* c) {
     if (!c) return FYX_ERR_INVALID_ARG;
     if (!c->ev0) { FYX_HIP(c, hipEventCreate(&c->ev0)); FYX_HIP(c, hipEventCreate(&c->ev1)); }
+    if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipEventRecord(c->ev0, c->stream));
     return FYX_OK;
 }
@@ -229,6 +300,7 @@ int fyx_timer_begin(fyx_ctx* c) {
 int fyx_timer_end(fyx_ctx* c, float* out_ms) {
     if (!c || !out_ms) return FYX_ERR_INVALID_ARG;
     if (!c->ev0) return fail(c, FYX_ERR_INVALID_ARG, "fyx_timer_end without fyx_timer_begin");
+    if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipEventRecord(c->ev1, c->stream));
     FYX_HIP(c, hipEventSynchronize(c->ev1));
     FYX_HIP(c, hipEventElapsedTime(out_ms, c->ev0, c->ev1));
@@ -239,9 +311,10 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!key) return nullptr;
     if (!strcmp(key, "lbs.block")) return &c->lbs.block;
     if (!strcmp(key, "lbs.blocks_per_cu")) return &c->lbs.blocks_per_cu;
-    if (!strcmp(key, "lbs.vpt")) return &c->lbs.vpt;
+    if (!strcmp(key, "lbs.prefetch")) return &c->lbs.prefetch;
     if (!strcmp(key, "lbs.exact")) return &c->lbs.exact;
     if (!strcmp(key, "lbs.nt")) return &c->lbs.nt;
+    if (!strcmp(key, "lbs.streams")) return &c->n_workers;
     return nullptr;
 }
 
@@ -251,8 +324,12 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (!slot) return fail(c, FYX_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
     if (slot == &c->lbs.block && value != 256 && value != 512 && value != 1024)
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.block must be 256, 512 or 1024");
-    if (slot == &c->lbs.vpt && value != 1 && value != 4)
-        return fail(c, FYX_ERR_INVALID_ARG, "lbs.vpt must be 1 or 4");
+    if (slot == &c->n_workers) {
+        if (value < 1 || value > fyx_ctx::kMaxWorkers)
+            return fail(c, FYX_ERR_INVALID_ARG, "lbs.streams must be 1..%d", fyx_ctx::kMaxWorkers);
+        if (int rc = enter_primary(c)) return rc;
+        c->next_worker = 0;
+    }
     if (slot == &c->lbs.blocks_per_cu && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.blocks_per_cu must be 1..64");
     *slot = value;
@@ -278,6 +355,7 @@ int fyx_malloc(fyx_ctx* c, size_t bytes, void** out) {
 int fyx_free(fyx_ctx* c, void* p) {
     if (!c) return FYX_ERR_INVALID_ARG;
     if (!p) return FYX_OK;
+    if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     FYX_HIP(c, hipFree(p));
     return FYX_OK;
@@ -286,6 +364,7 @@ int fyx_free(fyx_ctx* c, void* p) {
 int fyx_memcpy_h2d(fyx_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
     if (!bytes) return FYX_OK;
+    if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     return FYX_OK;
@@ -294,6 +373,7 @@ int fyx_memcpy_h2d(fyx_ctx* c, void* dst, const void* src, size_t bytes) {
 int fyx_memcpy_d2h(fyx_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
     if (!bytes) return FYX_OK;
+    if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     return FYX_OK;
@@ -319,6 +399,7 @@ int fyx_mesh_upload(fyx_ctx* c, uint64_t mesh_id, const uint8_t* aos, uint32_t n
             return fail(c, FYX_ERR_INVALID_ARG, "%s at offset %d does not fit vertex size %u", a.name,
                         a.off, stride);
     Mesh m;
+    if (int jr = enter_primary(c)) return jr;
     int rc = alloc_mesh(c, m, n_verts, off_normal >= 0, off_tangent >= 0);
     if (rc) return rc;
     if (n_verts) {
@@ -345,6 +426,7 @@ int fyx_mesh_upload_soa(fyx_ctx* c, uint64_t mesh_id, uint32_t n_verts, const fl
         return fail(c, FYX_ERR_MISSING_ATTRIBUTE,
                     "Position, BoneWeight and BoneIndices streams are required for skinning");
     Mesh m;
+    if (int jr = enter_primary(c)) return jr;
     int rc = alloc_mesh(c, m, n_verts, normal != nullptr, tangent != nullptr);
     if (rc) return rc;
     if (n_verts) {
@@ -365,6 +447,7 @@ int fyx_mesh_free(fyx_ctx* c, uint64_t mesh_id) {
     auto it = c->meshes.find(mesh_id);
     if (it == c->meshes.end())
         return fail(c, FYX_ERR_UNKNOWN_ID, "mesh %llu is not registered", (unsigned long long)mesh_id);
+    if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     free_mesh(it->second);
     c->meshes.erase(it);
@@ -410,7 +493,9 @@ int fyx_lbs_skin_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, ui
     if (d_out_tangent && !m->tan)
         return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Tangent attribute");
     const fyx::LbsArgs a = make_args(*m, d_palette, n_bones, n_instances, d_out_pos, d_out_normal, d_out_tangent);
-    FYX_HIP(c, fyx::launch_lbs(a, c->lbs, c->stream));
+    hipStream_t st;
+    if (int sr = acquire_launch_stream(c, &st)) return sr;
+    FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
     return FYX_OK;
     FYX_GUARD_END(c)
 }
@@ -433,7 +518,9 @@ int fyx_lbs_skin_streams(fyx_ctx* c, uint32_t n_verts, const float* d_pos, const
     a.palette = d_palette;
     a.out_pos = d_out_pos; a.out_nrm = d_out_normal; a.out_tan = d_out_tangent;
     a.n_verts = n_verts; a.n_bones = n_bones; a.n_instances = n_instances;
-    FYX_HIP(c, fyx::launch_lbs(a, c->lbs, c->stream));
+    hipStream_t st;
+    if (int sr = acquire_launch_stream(c, &st)) return sr;
+    FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
     return FYX_OK;
     FYX_GUARD_END(c)
 }
@@ -448,6 +535,7 @@ int fyx_lbs_skin(fyx_ctx* c, uint64_t mesh_id, const float* palette, uint32_t n_
     if (rc) return rc;
     if (out_normal && !m->nrm) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Normal attribute");
     if (out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Tangent attribute");
+    if (int jr = enter_primary(c)) return jr;
     const size_t nv = (size_t)m->n_verts * n_instances;
     const size_t b_pal = align_up((size_t)n_bones * n_instances * 64, 256);
     const bool need_pos = out_pos || out_aabb;
@@ -485,6 +573,7 @@ int fyx_skinned_aabb(fyx_ctx* c, uint64_t mesh_id, const float* palette, uint32_
     const Mesh* m = find_mesh(c, mesh_id);
     int rc = check_skin_args(c, m, mesh_id, palette, n_bones, 1);
     if (rc) return rc;
+    if (int jr = enter_primary(c)) return jr;
     rc = ensure_scratch(c, (size_t)n_bones * 64 + 256);
     if (rc) return rc;
     float* d_pal = static_cast<float*>(c->scratch);
@@ -498,12 +587,23 @@ int fyx_skinned_aabb(fyx_ctx* c, uint64_t mesh_id, const float* palette, uint32_
     FYX_GUARD_END(c)
 }
 
+// ---- calibration --------------------------------------------------------------------------
+
+int fyx_calib_stream_copy(fyx_ctx* c, const float* d_src, float* d_dst, uint32_t units) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    if (units && (!d_src || !d_dst)) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    if (int jr = enter_primary(c)) return jr;
+    FYX_HIP(c, fyx::launch_stream_copy(d_src, d_dst, units, c->lbs.blocks_per_cu, c->stream));
+    return FYX_OK;
+}
+
 // ---- palette ------------------------------------------------------------------------------
 
 int fyx_palette_device(fyx_ctx* c, const float* d_global, const float* d_inv_bind, uint32_t n,
                        float* d_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     if (n && (!d_global || !d_inv_bind || !d_out)) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    if (int jr = enter_primary(c)) return jr;
     FYX_HIP(c, fyx::launch_palette(d_global, d_inv_bind, n, d_out, c->stream));
     return FYX_OK;
 }
@@ -514,6 +614,7 @@ int fyx_palette(fyx_ctx* c, const float* global, const float* inv_bind, uint32_t
     if (n == 0) return FYX_OK;
     if (!global || !inv_bind || !out) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
     const size_t b = (size_t)n * 64;
+    if (int jr = enter_primary(c)) return jr;
     int rc = ensure_scratch(c, 3 * align_up(b, 256));
     if (rc) return rc;
     char* p = static_cast<char*>(c->scratch);

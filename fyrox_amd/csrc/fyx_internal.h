@@ -10,7 +10,7 @@ constexpr int kCUs = 256;  // MI355X
 struct LbsTuning {
     int block = 256;         // threads per workgroup: 256 | 512 | 1024
     int blocks_per_cu = 8;   // persistent grid = kCUs * blocks_per_cu (capped by the work)
-    int vpt = 1;             // vertices per thread: 1 | 4
+    int prefetch = 0;        // software-pipeline each wave (loads of unit i+1 before math of unit i)
     int exact = 1;           // 1: reference operation order, unfused; 0: FMA
     int nt = 1;              // non-temporal streaming loads/stores
 };
@@ -55,5 +55,9 @@ hipError_t launch_points_aabb(const float* d_xyz, uint64_t n_points, float* d_pa
 // out[i] = a[i] * b[i] (mat4, nalgebra operation order)
 hipError_t launch_palette(const float* d_global, const float* d_inv_bind, uint32_t n,
                           float* d_out, hipStream_t stream);
+
+// calibration: read 48*units bytes from d_src, write 32*units bytes to d_dst
+hipError_t launch_stream_copy(const float* d_src, float* d_dst, uint32_t units, int blocks_per_cu,
+                              hipStream_t stream);
 
 }  // namespace fyx

@@ -136,180 +136,98 @@ __device__ __forceinline__ Skinned skin_vertex(const f32x4* __restrict__ rows,
 }
 
 // ---------------------------------------------------------------------------------------
-// VPT = 1: one vertex per lane per chunk.  Lane accesses: 12 B (pos, normal), 16 B (tangent,
-// weights), 4 B (indices) -- all lane-contiguous.
+// The skinning kernel.
+//
+// Work unit = 64 consecutive vertices of one instance (one wave, one vertex per lane; lane
+// accesses are 12 B pos/normal, 16 B tangent/weights, 4 B indices, all lane-contiguous, so every
+// wave instruction covers one dense, 128-byte-aligned 768 B / 1 KiB / 256 B span).
+// Units are dealt out evenly: workgroup b owns the contiguous unit range
+// [b*T/G, (b+1)*T/G) -- at most one unit (64 vertices) of imbalance between workgroups, so every
+// CU streams the same number of bytes -- and its waves take units round-robin inside that range.
+// A range that crosses an instance boundary (crowds) is processed per instance segment; the
+// palette is (re)staged into LDS once per segment.
+//
+// PREFETCH=true software-pipelines each wave: the loads of its next unit are issued before the
+// ~300 VALU + 12 LDS operations of the current one, so the wave always has a unit in flight in
+// the memory system while it computes (all waves start in lock-step at kernel launch, so
+// without this the whole chip alternates between a load phase and a compute phase).
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, bool NT, int MASK>
-__global__ __launch_bounds__(BLOCK) void lbs_skin_v1(LbsArgs a, uint32_t chunks_per_inst,
-                                                     uint32_t total_chunks) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f32x4* rows = reinterpret_cast<f32x4*>(smem);
-    f32x4* row3 = rows + 3 * a.n_bones;
+template <int MASK>
+struct VertexIn {
+    float px, py, pz, nx, ny, nz;
+    f32x4 t, w;
+    uint32_t id;
+};
 
-    const int tid = threadIdx.x;
-    const uint32_t c_begin = (uint32_t)(((uint64_t)blockIdx.x * total_chunks) / gridDim.x);
-    const uint32_t c_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_chunks) / gridDim.x);
-
-    uint32_t cur_inst = 0xffffffffu;
-    bool projective = false;
-
-    for (uint32_t c = c_begin; c < c_end; ++c) {
-        const uint32_t inst = c / chunks_per_inst;
-        const uint32_t v = (c - inst * chunks_per_inst) * BLOCK + tid;
-        const bool live = v < a.n_verts;
-        const uint32_t vs = live ? v : 0;  // clamp: dead lanes re-read vertex 0 (never stored)
-
-        float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, tx = 0, ty = 0, tz = 0, tw = 0;
-        if constexpr (MASK & 1) ld3<NT>(a.pos + (size_t)vs * 3, px, py, pz);
-        if constexpr (MASK & 2) ld3<NT>(a.nrm + (size_t)vs * 3, nx, ny, nz);
-        if constexpr (MASK & 4) {
-            f32x4 t = ldg<NT>(reinterpret_cast<const f32x4*>(a.tan) + vs);
-            tx = t.x; ty = t.y; tz = t.z; tw = t.w;
-        }
-        const f32x4 w = ldg<NT>(reinterpret_cast<const f32x4*>(a.wgt) + vs);
-        const uint32_t id = ldg<NT>(a.idx + vs);
-
-        if (inst != cur_inst) {  // workgroup-uniform
-            if (cur_inst != 0xffffffffu) __syncthreads();  // all waves done with the old palette
-            const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones,
-                                          rows, row3, tid, BLOCK);
-            projective = __syncthreads_or(pj) != 0;
-            cur_inst = inst;
-        }
-
-        const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, id, w, px, py, pz, nx,
-                                                   ny, nz, tx, ty, tz);
-        if (live) {
-            const size_t ov = (size_t)inst * a.n_verts + v;
-            if constexpr (MASK & 1) st3<NT>(a.out_pos + ov * 3, o.px, o.py, o.pz);
-            if constexpr (MASK & 2) st3<NT>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
-            if constexpr (MASK & 4)
-                stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, tw});
-        }
-    }
+template <bool NT, int MASK>
+__device__ __forceinline__ VertexIn<MASK> load_vertex(const LbsArgs& a, uint32_t vs) {
+    VertexIn<MASK> r;
+    r.px = r.py = r.pz = r.nx = r.ny = r.nz = 0.f;
+    r.t = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (MASK & 1) ld3<NT>(a.pos + (size_t)vs * 3, r.px, r.py, r.pz);
+    if constexpr (MASK & 2) ld3<NT>(a.nrm + (size_t)vs * 3, r.nx, r.ny, r.nz);
+    if constexpr (MASK & 4) r.t = ldg<NT>(reinterpret_cast<const f32x4*>(a.tan) + vs);
+    r.w = ldg<NT>(reinterpret_cast<const f32x4*>(a.wgt) + vs);
+    r.id = ldg<NT>(a.idx + vs);
+    return r;
 }
 
-// ---------------------------------------------------------------------------------------
-// VPT = 4: four consecutive vertices per lane; every global access is a 16-byte vector
-// (pos/normal: 3 x float4 per lane at a 48-byte lane stride; tangent/weights: 4 x float4;
-// indices: one uint4).  Requires n_verts % 4 == 0 when n_instances > 1 (16-byte aligned
-// instance pitch); the launcher falls back to VPT = 1 otherwise.  A ragged last group
-// (single instance) is finished by scalar accesses.
-// ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, bool NT, int MASK>
-__global__ __launch_bounds__(BLOCK) void lbs_skin_v4(LbsArgs a, uint32_t chunks_per_inst,
-                                                     uint32_t total_chunks) {
+template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK>
+__global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_inst,
+                                                  uint32_t total_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
 
+    constexpr uint32_t WPB = BLOCK / 64;
     const int tid = threadIdx.x;
-    const uint32_t c_begin = (uint32_t)(((uint64_t)blockIdx.x * total_chunks) / gridDim.x);
-    const uint32_t c_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_chunks) / gridDim.x);
-    const uint32_t n_groups = a.n_verts >> 2;  // full 4-vertex groups
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    if (u_begin >= u_end) return;
 
-    uint32_t cur_inst = 0xffffffffu;
-    bool projective = false;
+    const uint32_t inst_first = u_begin / units_per_inst;
+    const uint32_t inst_last = (u_end - 1) / units_per_inst;
 
-    for (uint32_t c = c_begin; c < c_end; ++c) {
-        const uint32_t inst = c / chunks_per_inst;
-        const uint32_t g = (c - inst * chunks_per_inst) * BLOCK + tid;  // 4-vertex group index
-        const bool full = g < n_groups;
-        const bool ragged = (g == n_groups) && (a.n_verts & 3u);
-        const uint32_t gs = full ? g : 0;
+    for (uint32_t inst = inst_first; inst <= inst_last; ++inst) {  // workgroup-uniform
+        const uint32_t inst_u0 = inst * units_per_inst;
+        const uint32_t seg_b = (u_begin > inst_u0 ? u_begin : inst_u0) - inst_u0;
+        const uint32_t seg_e = (u_end < inst_u0 + units_per_inst ? u_end : inst_u0 + units_per_inst) - inst_u0;
 
-        f32x4 P[3], N[3], T[4], W[4];
-        u32x4 ID;
-        if constexpr (MASK & 1) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(a.pos) + (size_t)gs * 3;
-            P[0] = ldg<NT>(p); P[1] = ldg<NT>(p + 1); P[2] = ldg<NT>(p + 2);
-        }
-        if constexpr (MASK & 2) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(a.nrm) + (size_t)gs * 3;
-            N[0] = ldg<NT>(p); N[1] = ldg<NT>(p + 1); N[2] = ldg<NT>(p + 2);
-        }
-        if constexpr (MASK & 4) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(a.tan) + (size_t)gs * 4;
-            T[0] = ldg<NT>(p); T[1] = ldg<NT>(p + 1); T[2] = ldg<NT>(p + 2); T[3] = ldg<NT>(p + 3);
-        }
-        {
-            const f32x4* p = reinterpret_cast<const f32x4*>(a.wgt) + (size_t)gs * 4;
-            W[0] = ldg<NT>(p); W[1] = ldg<NT>(p + 1); W[2] = ldg<NT>(p + 2); W[3] = ldg<NT>(p + 3);
-            ID = ldg<NT>(reinterpret_cast<const u32x4*>(a.idx) + gs);
-        }
+        // first unit of this wave: issue its loads before staging so HBM latency overlaps staging
+        uint32_t u = seg_b + wave;
+        uint32_t v = u * 64 + lane;
+        VertexIn<MASK> cur;
+        if (u < seg_e) cur = load_vertex<NT, MASK>(a, v < a.n_verts ? v : 0);
 
-        if (inst != cur_inst) {
-            if (cur_inst != 0xffffffffu) __syncthreads();
-            const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones,
-                                          rows, row3, tid, BLOCK);
-            projective = __syncthreads_or(pj) != 0;
-            cur_inst = inst;
-        }
+        if (inst != inst_first) __syncthreads();  // every wave is done with the previous palette
+        const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, rows,
+                                      row3, tid, BLOCK);
+        const bool projective = __syncthreads_or(pj) != 0;
 
-        if (full) {
-            // xyz of vertex j inside three float4: flat[3j..3j+2]
-            float pf[12], nf[12];
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if constexpr (MASK & 1) pf[q * 4 + e] = P[q][e];
-                    if constexpr (MASK & 2) nf[q * 4 + e] = N[q][e];
-                }
-            float po[12], no[12];
-            f32x4 TO[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const Skinned o = skin_vertex<EXACT, MASK>(
-                    rows, row3, projective, ID[j], W[j], (MASK & 1) ? pf[3 * j] : 0.f,
-                    (MASK & 1) ? pf[3 * j + 1] : 0.f, (MASK & 1) ? pf[3 * j + 2] : 0.f,
-                    (MASK & 2) ? nf[3 * j] : 0.f, (MASK & 2) ? nf[3 * j + 1] : 0.f,
-                    (MASK & 2) ? nf[3 * j + 2] : 0.f, (MASK & 4) ? T[j].x : 0.f,
-                    (MASK & 4) ? T[j].y : 0.f, (MASK & 4) ? T[j].z : 0.f);
-                po[3 * j] = o.px; po[3 * j + 1] = o.py; po[3 * j + 2] = o.pz;
-                no[3 * j] = o.nx; no[3 * j + 1] = o.ny; no[3 * j + 2] = o.nz;
-                if constexpr (MASK & 4) TO[j] = f32x4{o.tx, o.ty, o.tz, T[j].w};
-                // keep the four vertices sequential: without this fence the scheduler hoists all
-                // 48 LDS row reads (192 VGPRs) ahead of the math and the kernel spills
-                __builtin_amdgcn_sched_barrier(0);
+        while (u < seg_e) {  // wave-uniform
+            const uint32_t un = u + WPB;
+            const uint32_t vn = un * 64 + lane;
+            VertexIn<MASK> nxt;
+            if constexpr (PREFETCH) {
+                if (un < seg_e) nxt = load_vertex<NT, MASK>(a, vn < a.n_verts ? vn : 0);
             }
-            const size_t og = ((size_t)inst * a.n_verts >> 2) + g;  // n_verts%4==0 if inst>0
-            if constexpr (MASK & 1) {
-                f32x4* p = reinterpret_cast<f32x4*>(a.out_pos) + og * 3;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    stg<NT>(p + q, f32x4{po[q * 4], po[q * 4 + 1], po[q * 4 + 2], po[q * 4 + 3]});
+            const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.px,
+                                                       cur.py, cur.pz, cur.nx, cur.ny, cur.nz,
+                                                       cur.t.x, cur.t.y, cur.t.z);
+            if (v < a.n_verts) {
+                const size_t ov = (size_t)inst * a.n_verts + v;
+                if constexpr (MASK & 1) st3<NT>(a.out_pos + ov * 3, o.px, o.py, o.pz);
+                if constexpr (MASK & 2) st3<NT>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
+                if constexpr (MASK & 4)
+                    stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, cur.t.w});
             }
-            if constexpr (MASK & 2) {
-                f32x4* p = reinterpret_cast<f32x4*>(a.out_nrm) + og * 3;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    stg<NT>(p + q, f32x4{no[q * 4], no[q * 4 + 1], no[q * 4 + 2], no[q * 4 + 3]});
+            if constexpr (!PREFETCH) {
+                if (un < seg_e) nxt = load_vertex<NT, MASK>(a, vn < a.n_verts ? vn : 0);
             }
-            if constexpr (MASK & 4) {
-                f32x4* p = reinterpret_cast<f32x4*>(a.out_tan) + og * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) stg<NT>(p + j, TO[j]);
-            }
-        } else if (ragged) {  // single instance only (launcher guarantees)
-            for (uint32_t v = n_groups * 4; v < a.n_verts; ++v) {
-                float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, tx = 0, ty = 0, tz = 0, tw = 0;
-                if constexpr (MASK & 1) ld3<false>(a.pos + (size_t)v * 3, px, py, pz);
-                if constexpr (MASK & 2) ld3<false>(a.nrm + (size_t)v * 3, nx, ny, nz);
-                if constexpr (MASK & 4) {
-                    tx = a.tan[(size_t)v * 4]; ty = a.tan[(size_t)v * 4 + 1];
-                    tz = a.tan[(size_t)v * 4 + 2]; tw = a.tan[(size_t)v * 4 + 3];
-                }
-                const f32x4 w = reinterpret_cast<const f32x4*>(a.wgt)[v];
-                const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, a.idx[v], w, px,
-                                                           py, pz, nx, ny, nz, tx, ty, tz);
-                if constexpr (MASK & 1) st3<false>(a.out_pos + (size_t)v * 3, o.px, o.py, o.pz);
-                if constexpr (MASK & 2) st3<false>(a.out_nrm + (size_t)v * 3, o.nx, o.ny, o.nz);
-                if constexpr (MASK & 4) {
-                    float* t = a.out_tan + (size_t)v * 4;
-                    t[0] = o.tx; t[1] = o.ty; t[2] = o.tz; t[3] = tw;
-                }
-            }
+            cur = nxt;
+            u = un;
+            v = vn;
         }
     }
 }
@@ -317,57 +235,58 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_v4(LbsArgs a, uint32_t chunks_
 // ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, bool NT, int MASK>
-static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s, bool v4) {
-    const uint32_t per_chunk = BLOCK * (v4 ? 4 : 1);
-    const uint32_t cpi = (a.n_verts + per_chunk - 1) / per_chunk;
-    const uint64_t total64 = (uint64_t)cpi * a.n_instances;
+template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK>
+static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    const uint32_t upi = (a.n_verts + 63) / 64;
+    const uint64_t total64 = (uint64_t)upi * a.n_instances;
     if (total64 == 0) return hipSuccess;
     if (total64 > 0xffffffffull) return hipErrorInvalidValue;
     const uint32_t total = (uint32_t)total64;
     uint32_t grid = (uint32_t)kCUs * (uint32_t)(t.blocks_per_cu > 0 ? t.blocks_per_cu : 1);
-    if (grid > total) grid = total;
+    const uint32_t max_useful = (total + (BLOCK / 64) - 1) / (BLOCK / 64);
+    if (grid > max_useful) grid = max_useful;
     const size_t lds = (size_t)a.n_bones * 64;
-    if (v4)
-        hipLaunchKernelGGL((lbs_skin_v4<BLOCK, EXACT, NT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
-                           cpi, total);
-    else
-        hipLaunchKernelGGL((lbs_skin_v1<BLOCK, EXACT, NT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
-                           cpi, total);
+    hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
+                       upi, total);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool EXACT, bool NT>
-static hipError_t launch_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s, bool v4) {
+template <int BLOCK, bool EXACT, bool NT, bool PREFETCH>
+static hipError_t launch_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
     switch (mask) {
-        case 1: return launch_one<BLOCK, EXACT, NT, 1>(a, t, s, v4);
-        case 2: return launch_one<BLOCK, EXACT, NT, 2>(a, t, s, v4);
-        case 3: return launch_one<BLOCK, EXACT, NT, 3>(a, t, s, v4);
-        case 4: return launch_one<BLOCK, EXACT, NT, 4>(a, t, s, v4);
-        case 5: return launch_one<BLOCK, EXACT, NT, 5>(a, t, s, v4);
-        case 6: return launch_one<BLOCK, EXACT, NT, 6>(a, t, s, v4);
-        case 7: return launch_one<BLOCK, EXACT, NT, 7>(a, t, s, v4);
+        case 1: return launch_one<BLOCK, EXACT, NT, PREFETCH, 1>(a, t, s);
+        case 2: return launch_one<BLOCK, EXACT, NT, PREFETCH, 2>(a, t, s);
+        case 3: return launch_one<BLOCK, EXACT, NT, PREFETCH, 3>(a, t, s);
+        case 4: return launch_one<BLOCK, EXACT, NT, PREFETCH, 4>(a, t, s);
+        case 5: return launch_one<BLOCK, EXACT, NT, PREFETCH, 5>(a, t, s);
+        case 6: return launch_one<BLOCK, EXACT, NT, PREFETCH, 6>(a, t, s);
+        case 7: return launch_one<BLOCK, EXACT, NT, PREFETCH, 7>(a, t, s);
         default: return hipSuccess;  // nothing requested
     }
 }
 
 template <int BLOCK>
-static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t s, bool v4) {
-    if (t.exact) return t.nt ? launch_mask<BLOCK, true, true>(a, t, s, v4)
-                             : launch_mask<BLOCK, true, false>(a, t, s, v4);
-    return t.nt ? launch_mask<BLOCK, false, true>(a, t, s, v4)
-                : launch_mask<BLOCK, false, false>(a, t, s, v4);
+static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    const int key = (t.exact ? 4 : 0) | (t.nt ? 2 : 0) | (t.prefetch ? 1 : 0);
+    switch (key) {
+        case 7: return launch_mask<BLOCK, true, true, true>(a, t, s);
+        case 6: return launch_mask<BLOCK, true, true, false>(a, t, s);
+        case 5: return launch_mask<BLOCK, true, false, true>(a, t, s);
+        case 4: return launch_mask<BLOCK, true, false, false>(a, t, s);
+        case 3: return launch_mask<BLOCK, false, true, true>(a, t, s);
+        case 2: return launch_mask<BLOCK, false, true, false>(a, t, s);
+        case 1: return launch_mask<BLOCK, false, false, true>(a, t, s);
+        default: return launch_mask<BLOCK, false, false, false>(a, t, s);
+    }
 }
 
 hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream) {
     if (a.n_verts == 0 || a.n_instances == 0) return hipSuccess;
-    bool v4 = (t.vpt == 4);
-    if (v4 && a.n_instances > 1 && (a.n_verts & 3u)) v4 = false;  // unaligned instance pitch
     switch (t.block) {
-        case 512: return launch_block<512>(a, t, stream, v4);
-        case 1024: return launch_block<1024>(a, t, stream, v4);
-        default: return launch_block<256>(a, t, stream, v4);
+        case 512: return launch_block<512>(a, t, stream);
+        case 1024: return launch_block<1024>(a, t, stream);
+        default: return launch_block<256>(a, t, stream);
     }
 }
 
@@ -571,6 +490,34 @@ hipError_t launch_palette(const float* d_global, const float* d_inv_bind, uint32
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(palette_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, d_global,
                        d_inv_bind, n, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Calibration stream: reads 3 float4 planes and writes 2 float4 planes per unit (60 % read /
+// 40 % written, the skinning kernel's mix) with the same non-temporal 16-byte accesses and no
+// arithmetic.  Its launch time is the achievable ceiling the skinning kernel is compared to,
+// and its known byte count calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src,
+                                                          f32x4* __restrict__ dst, uint32_t units) {
+    for (uint32_t u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
+        const f32x4 a = __builtin_nontemporal_load(src + u);
+        const f32x4 b = __builtin_nontemporal_load(src + (size_t)units + u);
+        const f32x4 c = __builtin_nontemporal_load(src + 2 * (size_t)units + u);
+        __builtin_nontemporal_store(a + c, dst + u);
+        __builtin_nontemporal_store(b - c, dst + (size_t)units + u);
+    }
+}
+
+hipError_t launch_stream_copy(const float* d_src, float* d_dst, uint32_t units, int blocks_per_cu,
+                              hipStream_t stream) {
+    if (units == 0) return hipSuccess;
+    uint32_t grid = (units + 255) / 256;
+    const uint32_t cap = (uint32_t)kCUs * (uint32_t)(blocks_per_cu > 0 ? blocks_per_cu : 8);
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4*>(d_src), reinterpret_cast<f32x4*>(d_dst), units);
     return hipGetLastError();
 }
 

@@ -57,10 +57,22 @@ const char* fyx_version(void);
 int fyx_set_stream(fyx_ctx* ctx, void* hip_stream);
 void* fyx_get_stream(fyx_ctx* ctx);
 int fyx_sync(fyx_ctx* ctx);
-/* Kernel tuning knobs (block size, grid multiple, vertices/thread, exact vs fused arithmetic).
- * Unknown keys return FYX_ERR_INVALID_ARG.  Keys: "lbs.block", "lbs.blocks_per_cu", "lbs.vpt",
+/* Stream semantics.  Everything is ordered on the context stream EXCEPT fyx_lbs_skin_device /
+ * fyx_lbs_skin_streams launches: with option "lbs.streams" = K > 1 (default 2) those are dealt
+ * round-robin onto K internal worker streams so that the head of one launch overlaps the tail of
+ * the previous one (independent meshes / frames).  Each such launch is ordered AFTER everything
+ * enqueued on the context stream before the call, but NOT with respect to other skinning
+ * launches: two launches that touch the same output buffer need a fyx_join() between them.
+ * fyx_join makes the context stream wait (GPU-side, no host block) for every in-flight launch;
+ * every other entry point that uses the context stream (uploads, copies, fyx_sync, fyx_timer_*,
+ * host-variant calls, fyx_palette*) joins implicitly first.  A caller that borrowed a stream
+ * with fyx_set_stream must call fyx_join before consuming skinned output on that stream. */
+int fyx_join(fyx_ctx* ctx);
+/* Kernel tuning knobs (block size, grid multiple, prefetch, exact vs fused arithmetic).
+ * Unknown keys return FYX_ERR_INVALID_ARG.  Keys: "lbs.block", "lbs.blocks_per_cu", "lbs.prefetch",
  * "lbs.exact" (1 = reference operation order, no FMA contraction: bit-identical to the CPU path;
- * 0 = fused multiply-add, within 1e-5 relative), "lbs.nt" (non-temporal loads/stores). */
+ * 0 = fused multiply-add, within 1e-5 relative), "lbs.nt" (non-temporal loads/stores),
+ * "lbs.streams" (1..4 worker streams for independent skinning launches, see fyx_join). */
 int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
 int fyx_get_option(fyx_ctx* ctx, const char* key, int* value);
 
@@ -131,6 +143,14 @@ int fyx_lbs_skin_streams(fyx_ctx* ctx, uint32_t n_verts, const float* d_pos, con
  * Replaces the body of Mesh::accurate_world_bounding_box, scene/mesh/mod.rs:470-526. */
 int fyx_skinned_aabb(fyx_ctx* ctx, uint64_t mesh_id, const float* palette, uint32_t n_bones,
                      float out_aabb[6]);
+
+/* ---- calibration ---------------------------------------------------------------------- */
+
+/* A pure HBM stream with the skinning kernel's read/write mix and access width and no arithmetic:
+ * reads 48*units bytes from d_src and writes 32*units bytes to d_dst (units = 1 250 000 moves the
+ * same 100 MB as one 1 M-vertex skinning launch).  Used to measure the achievable ceiling next to
+ * the skinning kernel and to calibrate rocprofv3 FETCH_SIZE/WRITE_SIZE on a known byte count. */
+int fyx_calib_stream_copy(fyx_ctx* ctx, const float* d_src, float* d_dst, uint32_t units);
 
 /* ---- palette -------------------------------------------------------------------------- */
 

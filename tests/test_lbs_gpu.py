@@ -46,7 +46,7 @@ def assert_bit_exact(got, ref):
 
 @pytest.fixture(autouse=True)
 def _defaults(ctx):
-    for k, v in (("lbs.block", 256), ("lbs.blocks_per_cu", 8), ("lbs.vpt", 1), ("lbs.exact", 1), ("lbs.nt", 1)):
+    for k, v in (("lbs.block", 256), ("lbs.blocks_per_cu", 8), ("lbs.prefetch", 0), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2)):
         ctx.set_option(k, v)
     yield
 
@@ -101,48 +101,48 @@ def test_c4_1m_verts_256_bones(ctx, orc):
 # ---- kernel variants ----------------------------------------------------------------------
 
 @pytest.mark.parametrize("block", [256, 512, 1024])
-@pytest.mark.parametrize("vpt", [1, 4])
+@pytest.mark.parametrize("prefetch", [0, 1])
 @pytest.mark.parametrize("nt", [0, 1])
-def test_every_kernel_variant_is_bit_exact(ctx, orc, block, vpt, nt):
+def test_every_kernel_variant_is_bit_exact(ctx, orc, block, prefetch, nt):
     m = synth.make_mesh(70_001, 200, 99, coherent=False)   # ragged: not a multiple of 4 or 256
     pal = synth.make_palette(200, 99)
     upload(ctx, 5, m)
-    ctx.set_option("lbs.block", block); ctx.set_option("lbs.vpt", vpt); ctx.set_option("lbs.nt", nt)
+    ctx.set_option("lbs.block", block); ctx.set_option("lbs.prefetch", prefetch); ctx.set_option("lbs.nt", nt)
     ctx.set_option("lbs.blocks_per_cu", 2)
     assert_bit_exact(ctx.lbs_skin(5, pal), oracle_skin(orc, m, pal))
 
 
-@pytest.mark.parametrize("vpt", [1, 4])
-def test_fused_mode_within_1e5(ctx, orc, vpt):
+@pytest.mark.parametrize("prefetch", [0, 1])
+def test_fused_mode_within_1e5(ctx, orc, prefetch):
     m = synth.make_mesh(100_000, 64, 123)
     pal = synth.make_palette(64, 123)
     upload(ctx, 6, m)
-    ctx.set_option("lbs.exact", 0); ctx.set_option("lbs.vpt", vpt)
+    ctx.set_option("lbs.exact", 0); ctx.set_option("lbs.prefetch", prefetch)
     got, ref = ctx.lbs_skin(6, pal), oracle_skin(orc, m, pal)
     for k in ("pos", "normal", "tangent"):
         assert rel_err(got[k], ref[k]) <= REL_TOL, k
     assert np.array_equal(got["tangent"][:, 3], m.tangent[:, 3])
 
 
-@pytest.mark.parametrize("vpt", [1, 4])
-@pytest.mark.parametrize("n_inst,n_verts", [(3, 1000), (5, 1001), (2, 4096), (7, 13)])
-def test_instanced_variants(ctx, orc, vpt, n_inst, n_verts):
+@pytest.mark.parametrize("block,bpcu", [(256, 8), (1024, 1), (512, 64)])
+@pytest.mark.parametrize("n_inst,n_verts", [(3, 1000), (5, 1001), (2, 4096), (7, 13), (300, 65), (2000, 3)])
+def test_instanced_variants(ctx, orc, block, bpcu, n_inst, n_verts):
     m = synth.make_mesh(n_verts, 32, 7)
     pal = synth.make_palette(32, 7, n_instances=n_inst)
     upload(ctx, 7, m)
-    ctx.set_option("lbs.vpt", vpt)
+    ctx.set_option("lbs.block", block); ctx.set_option("lbs.blocks_per_cu", bpcu)
     assert_bit_exact(ctx.lbs_skin(7, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst))
 
 
 # ---- edge cases ---------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4099])
-@pytest.mark.parametrize("vpt", [1, 4])
-def test_ragged_sizes(ctx, orc, n, vpt):
+@pytest.mark.parametrize("block", [256, 1024])
+def test_ragged_sizes(ctx, orc, n, block):
     m = synth.make_mesh(n, 8, 5)
     pal = synth.make_palette(8, 5)
     upload(ctx, 8, m)
-    ctx.set_option("lbs.vpt", vpt)
+    ctx.set_option("lbs.block", block)
     got = ctx.lbs_skin(8, pal, aabb=True)
     if n == 0:
         assert got["pos"].shape == (0, 3)
@@ -168,8 +168,8 @@ def test_projective_palette_takes_the_divide_path(ctx, orc):
     pal = synth.make_palette(16, 31).copy()
     pal[3, 3] = 0.125; pal[3, 7] = -0.25; pal[3, 15] = 1.5      # only bone 3 is projective
     upload(ctx, 10, m)
-    for vpt in (1, 4):
-        ctx.set_option("lbs.vpt", vpt)
+    for prefetch in (0, 1):
+        ctx.set_option("lbs.prefetch", prefetch)
         assert_bit_exact(ctx.lbs_skin(10, pal), oracle_skin(orc, m, pal))
 
 
@@ -289,4 +289,39 @@ def test_device_resident_path_and_reupload(ctx, orc):
     assert ctx.mesh_info(17)["n_verts"] == 777
     assert_bit_exact(ctx.lbs_skin(17, pal), oracle_skin(orc, m2, pal))
     for b in (d_pal, d_pos, d_nrm, d_tan):
+        b.free()
+
+
+@pytest.mark.parametrize("streams", [1, 2, 3, 4])
+def test_overlapped_launch_streams_and_join(ctx, orc, streams):
+    # independent launches are dealt onto `lbs.streams` worker streams; results are complete after
+    # fyx_sync (implicit join); a dependent second pass over the same output needs fyx_join
+    ctx.set_option("lbs.streams", streams)
+    m = synth.make_mesh(30_011, 64, 131)
+    upload(ctx, 18, m)
+    pals = [synth.make_palette(64, 200 + i) for i in range(6)]
+    d_pals = [ctx.to_device(p) for p in pals]
+    outs = [(ctx.malloc(m.n_verts * 12), ctx.malloc(m.n_verts * 12), ctx.malloc(m.n_verts * 16)) for _ in pals]
+    for _ in range(3):
+        for dp, o in zip(d_pals, outs):
+            ctx.lbs_skin_device(18, dp.ptr, 64, 1, o[0].ptr, o[1].ptr, o[2].ptr)
+    ctx.sync()
+    for p, o in zip(pals, outs):
+        ref = oracle_skin(orc, m, p)
+        assert np.array_equal(o[0].download(np.float32, m.n_verts * 3).reshape(-1, 3), ref["pos"])
+        assert np.array_equal(o[1].download(np.float32, m.n_verts * 3).reshape(-1, 3), ref["normal"])
+        assert np.array_equal(o[2].download(np.float32, m.n_verts * 4).reshape(-1, 4), ref["tangent"])
+    # same output buffer reused by two launches: join in between -> the later palette wins
+    ctx.lbs_skin_device(18, d_pals[0].ptr, 64, 1, outs[0][0].ptr, 0, 0)
+    ctx.join()
+    ctx.lbs_skin_device(18, d_pals[1].ptr, 64, 1, outs[0][0].ptr, 0, 0)
+    ctx.sync()
+    assert np.array_equal(outs[0][0].download(np.float32, m.n_verts * 3).reshape(-1, 3), oracle_skin(orc, m, pals[1])["pos"])
+    # uploads are ordered before later launches (fork event): re-upload then skin immediately
+    m2 = synth.make_mesh(30_011, 64, 132)
+    upload(ctx, 18, m2)
+    ctx.lbs_skin_device(18, d_pals[2].ptr, 64, 1, outs[2][0].ptr, 0, 0)
+    ctx.sync()
+    assert np.array_equal(outs[2][0].download(np.float32, m.n_verts * 3).reshape(-1, 3), oracle_skin(orc, m2, pals[2])["pos"])
+    for b in d_pals + [x for o in outs for x in o]:
         b.free()

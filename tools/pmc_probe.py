@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""A short, serialized run for rocprofv3 PMC passes: N launches of the calibration stream
+(known bytes: 60 MB read + 40 MB written) followed by N launches of the skinning kernel on the
+C4 workload, rotating buffer sets.  Usage (separate passes, as MI355X_MICROARCH.md prescribes):
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/fetch -- python tools/pmc_probe.py
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out/write -- python tools/pmc_probe.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fyrox_amd
+from fyrox_amd import synth
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+SETS = 8
+ctx = fyrox_amd.Context(0)
+ctx.set_option("lbs.streams", 1)
+NV, NB, UNITS = 1_000_000, 256, 1_250_000
+mesh = synth.make_mesh(NV, NB, synth.SEED_BASE + 4)
+pal = synth.make_palette(NB, synth.SEED_BASE + 4)
+d_pal = ctx.to_device(pal)
+outs, srcs, dsts = [], [], []
+for s in range(SETS):
+    ctx.mesh_upload_soa(s, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    outs.append((ctx.malloc(NV * 12 + 64), ctx.malloc(NV * 12 + 64), ctx.malloc(NV * 16 + 64)))
+    srcs.append(ctx.to_device(np.full(UNITS * 12, np.float32(s + 1))))
+    dsts.append(ctx.malloc(UNITS * 32))
+for i in range(N):
+    ctx.calib_stream_copy(srcs[i % SETS].ptr, dsts[i % SETS].ptr, UNITS)
+ctx.sync()
+for i in range(N):
+    s = i % SETS
+    ctx.lbs_skin_device(s, d_pal.ptr, NB, 1, outs[s][0].ptr, outs[s][1].ptr, outs[s][2].ptr)
+ctx.sync()
+print("done")

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel-trace stats of the bench command + separate PMC passes.
+# Outputs under gpurun_out/prof/ ; summaries are copied into profiles/ by tools/summarize_profile.py.
+set -u
+OUT=${1:-gpurun_out/prof}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ROOT=$(pwd)
+BENCH="python $ROOT/bench.py --steps 1000 --warmup 100 --no-cpu-baseline"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace" -o bench -- $BENCH > "$ROOT/$OUT/bench_under_trace.json" 2> "$ROOT/$OUT/trace.err" )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_s1" -o bench -- $BENCH --opt lbs.streams=1 > "$ROOT/$OUT/bench_under_trace_s1.json" 2> "$ROOT/$OUT/trace_s1.err" )
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_fetch" -o pmc -- python $ROOT/tools/pmc_probe.py > /dev/null 2> "$ROOT/$OUT/pmc_fetch.err" )
+( cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_write" -o pmc -- python $ROOT/tools/pmc_probe.py > /dev/null 2> "$ROOT/$OUT/pmc_write.err" )
+( cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_lds" -o pmc -- python $ROOT/tools/pmc_probe.py > /dev/null 2> "$ROOT/$OUT/pmc_lds.err" )
+python $ROOT/bench.py --steps 2000 --warmup 100 --cpu-seconds 3 > "$ROOT/$OUT/bench_plain.json" 2> "$ROOT/$OUT/bench_plain.err"
+find "$OUT" -name "*.csv" | head -40
+du -sh "$OUT"
