@@ -338,13 +338,16 @@ hipError_t launch_deinterleave(const uint8_t* d_aos, uint32_t n_verts, uint32_t 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void max_bone_index_kernel(const uint32_t* __restrict__ idx,
                                                              uint32_t n, uint32_t* out) {
+    __shared__ uint32_t sm[4];
     uint32_t m = 0;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
         const uint32_t id = idx[v];
         m = max(m, max(max(id & 0xffu, (id >> 8) & 0xffu), max((id >> 16) & 0xffu, id >> 24)));
     }
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));  // one per block
 }
 
 hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32_t* d_out,
@@ -352,7 +355,7 @@ hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32
     hipError_t e = hipMemsetAsync(d_out, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess || n_verts == 0) return e;
     uint32_t grid = (n_verts + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    if (grid > 512) grid = 512;
     hipLaunchKernelGGL(max_bone_index_kernel, dim3(grid), dim3(256), 0, stream, d_idx, n_verts, d_out);
     return hipGetLastError();
 }

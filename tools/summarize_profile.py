@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof (written by tools/profile.sh on the GPU box) into the tracked
+profiles/ directory: kernel-trace stats, PMC medians with the gfx950 FETCH_SIZE correction, and
+profiles/hbm_traffic.json (read by bench.py for roofline.traffic)."""
+import collections, csv, json, os, shutil, sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+for sub, name in (("trace", f"{tag}_bench_streams2_kernel_stats.csv"), ("trace_s1", f"{tag}_bench_streams1_kernel_stats.csv")):
+    p = os.path.join(src, sub, "bench_kernel_stats.csv")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, name))
+for f in ("bench_plain.json", "bench_under_trace.json", "bench_under_trace_s1.json"):
+    p = os.path.join(src, f)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
+
+
+def trace_summary(sub):
+    """per-launch throughput time from the kernel trace (first start -> last end over N launches)"""
+    p = os.path.join(src, sub, "bench_kernel_trace.csv")
+    if not os.path.exists(p):
+        return None
+    rows = [r for r in csv.DictReader(open(p)) if "lbs_skin" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = rows[-1000:]  # the timed region (after warm-up)
+    st = [int(r["Start_Timestamp"]) for r in rows]
+    en = [int(r["End_Timestamp"]) for r in rows]
+    dur = sorted(e - s for s, e in zip(st, en))
+    return {"launches": len(rows), "span_us_per_launch": (max(en) - min(st)) / len(rows) / 1e3,
+            "kernel_duration_us_avg": sum(dur) / len(dur) / 1e3, "kernel_duration_us_median": dur[len(dur) // 2] / 1e3}
+
+
+pmc = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_lds"):
+    p = os.path.join(src, sub, "pmc_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        k = "lbs_skin" if "lbs_skin" in r["Kernel_Name"] else "stream_copy" if "stream_copy" in r["Kernel_Name"] else None
+        if k:
+            agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in agg.items():
+        v.sort()
+        pmc.setdefault(k, {})[c] = {"median": v[len(v) // 2], "min": v[0], "max": v[-1], "launches": len(v)}
+
+out = {"source": src, "trace_streams2": trace_summary("trace"), "trace_streams1": trace_summary("trace_s1"), "pmc": pmc}
+if "stream_copy" in pmc and "FETCH_SIZE" in pmc["stream_copy"] and "lbs_skin" in pmc:
+    KB = 1024.0
+    copy_rd_known, copy_wr_known = 48 * 1_250_000, 32 * 1_250_000
+    f_rd = copy_rd_known / (pmc["stream_copy"]["FETCH_SIZE"]["median"] * KB)   # ~2.0 on gfx950 (guide: FETCH_SIZE counts 1/2)
+    f_wr = copy_wr_known / (pmc["stream_copy"]["WRITE_SIZE"]["median"] * KB)   # ~1.0
+    rd = pmc["lbs_skin"]["FETCH_SIZE"]["median"] * KB * f_rd
+    wr = pmc["lbs_skin"]["WRITE_SIZE"]["median"] * KB * f_wr
+    out["calibration"] = {"known_copy_read_bytes": copy_rd_known, "known_copy_write_bytes": copy_wr_known,
+                          "fetch_size_correction": f_rd, "write_size_correction": f_wr}
+    out["lbs_hbm_bytes_per_launch"] = {"read": rd, "write": wr, "total": rd + wr, "algorithmic": 100_000_000}
+    json.dump({"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr,
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile.sh), KB units, corrected by "
+                         "the factors measured on fyx_calib_stream_copy's known 60 MB read / 40 MB written in the same run "
+                         f"(FETCH x{f_rd:.3f}, WRITE x{f_wr:.3f}); see profiles/{tag}_summary.json"},
+              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
