@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfyrox_hip.so")
@@ -75,6 +75,47 @@ _SIGS = {
     "fyx_calib_stream_copy": (c_int, [_P, _P, _P, c_uint32]),
     "fyx_palette": (c_int, [_P, _P, _P, c_uint32, _P]),
     "fyx_palette_device": (c_int, [_P, _P, _P, c_uint32, _P]),
+    # ---- pose path -------------------------------------------------------------------------
+    "fyx_init_control_only": (c_int, [POINTER(c_void_p)]),
+    "fyx_tracks_data_upload": (c_int, [_P, c_uint64, c_uint32, _P, c_uint32, _P, _P, _P, _P, _P]),
+    "fyx_tracks_data_free": (c_int, [_P, c_uint64]),
+    "fyx_rig_create": (c_int, [_P, c_uint64, c_uint32, _P, _P, _P]),
+    "fyx_rig_free": (c_int, [_P, c_uint64]),
+    "fyx_bone_list_create": (c_int, [_P, c_uint64, c_uint64, c_uint32, _P]),
+    "fyx_bone_list_free": (c_int, [_P, c_uint64]),
+    "fyx_animator_create": (c_int, [_P, c_uint64, c_uint64, c_uint32]),
+    "fyx_animator_free": (c_int, [_P, c_uint64]),
+    "fyx_animator_add_animation": (c_int, [_P, c_uint64, c_uint64, _P, _P, POINTER(c_uint32)]),
+    "fyx_animation_set_track_enabled": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int]),
+    "fyx_animation_set_time_slice": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_float, c_float]),
+    "fyx_animation_set_time_position": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_float]),
+    "fyx_animation_set_speed": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_float]),
+    "fyx_animation_set_loop": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int]),
+    "fyx_animation_set_enabled": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int]),
+    "fyx_animation_rewind": (c_int, [_P, c_uint64, c_uint32, c_uint32]),
+    "fyx_animation_get_state": (c_int, [_P, c_uint64, c_uint32, c_uint32, POINTER(c_float), POINTER(c_int), POINTER(c_int)]),
+    "fyx_machine_add_parameter": (c_int, [_P, c_uint64, c_int, c_float, c_float, c_uint32, POINTER(c_uint32)]),
+    "fyx_machine_set_parameter": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int, c_float, c_float, c_uint32]),
+    "fyx_machine_add_layer": (c_int, [_P, c_uint64, c_float, POINTER(c_uint32)]),
+    "fyx_layer_set_weight": (c_int, [_P, c_uint64, c_uint32, c_float]),
+    "fyx_layer_set_mask": (c_int, [_P, c_uint64, c_uint32, _P, c_uint32]),
+    "fyx_layer_add_play_animation": (c_int, [_P, c_uint64, c_uint32, c_uint32, POINTER(c_uint32)]),
+    "fyx_layer_add_blend_animations": (c_int, [_P, c_uint64, c_uint32, c_uint32, _P, _P, _P, POINTER(c_uint32)]),
+    "fyx_layer_add_blend_animations_by_index": (c_int, [_P, c_uint64, c_uint32, c_int32, c_uint32, _P, _P, POINTER(c_uint32)]),
+    "fyx_layer_add_blend_space": (c_int, [_P, c_uint64, c_uint32, c_int32, c_uint32, _P, _P, c_uint32, _P, POINTER(c_uint32)]),
+    "fyx_layer_add_state": (c_int, [_P, c_uint64, c_uint32, c_int32, POINTER(c_uint32)]),
+    "fyx_layer_set_entry_state": (c_int, [_P, c_uint64, c_uint32, c_uint32]),
+    "fyx_state_add_action": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int, c_int, c_uint32]),
+    "fyx_layer_add_transition": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, c_float, _P, c_uint32, POINTER(c_uint32)]),
+    "fyx_layer_get_state": (c_int, [_P, c_uint64, c_uint32, c_uint32, POINTER(c_int32), POINTER(c_int32)]),
+    "fyx_animation_player_update": (c_int, [_P, c_uint64, c_float]),
+    "fyx_absm_update": (c_int, [_P, c_uint64, c_float]),
+    "fyx_animator_update_transforms": (c_int, [_P, c_uint64]),
+    "fyx_animator_palette": (c_int, [_P, c_uint64, c_uint64, _P]),
+    "fyx_animator_set_local_trs": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, _P]),
+    "fyx_animator_read": (c_int, [_P, c_uint64, c_int, _P]),
+    "fyx_animator_device_ptr": (c_int, [_P, c_uint64, c_int, POINTER(c_void_p)]),
+    "fyx_animator_plan": (c_int, [_P, c_uint64, c_int, c_float, _P, _P, _P, _P, c_uint32, POINTER(c_uint32)]),
 }
 
 

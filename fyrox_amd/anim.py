@@ -1,0 +1,426 @@
+"""Host-side mirror of the reference's animation interface for the pose path.
+
+Plain descriptions named after the reference's types (fyrox-math Curve/CurveKey, fyrox-animation
+Track / AnimationTracksData / Animation / Machine / MachineLayer / State / Transition / PoseNode,
+fyrox-impl Transform) plus `Animator`, a thin wrapper over the C ABI (include/fyrox_hip.h, second
+half).  Nothing here computes a pose: descriptions are flattened into the arrays the C ABI takes and
+every per-bone operation runs in the HIP kernels of libfyrox_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, Structure, byref, c_float, c_int, c_int32, c_uint8, c_uint32, c_void_p
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+# ValueBinding / TrackValueKind / CurveKeyKind (values of include/fyrox_hip.h)
+BIND_POSITION, BIND_SCALE, BIND_ROTATION = 0, 1, 2
+KIND_REAL, KIND_VEC2, KIND_VEC3, KIND_VEC4, KIND_QUAT_EULER, KIND_QUAT = range(6)
+KEY_CONSTANT, KEY_LINEAR, KEY_CUBIC = 0, 1, 2
+PARAM_WEIGHT, PARAM_RULE, PARAM_INDEX, PARAM_SAMPLING_POINT = range(4)
+ACTION_NONE, ACTION_REWIND, ACTION_ENABLE, ACTION_DISABLE = range(4)
+LOGIC_PARAMETER, LOGIC_AND, LOGIC_OR, LOGIC_XOR, LOGIC_NOT, LOGIC_IS_ANIMATION_ENDED = range(6)
+ALL_INSTANCES = 0xFFFFFFFF
+READ_LOCAL_TRS, READ_LOCAL_MATRIX, READ_GLOBAL_MATRIX, READ_ANIMATION_POSE = 0, 1, 2, 16
+OP_NAMES = ("END", "BLEND_ANIM", "PUSH", "POP_BLEND", "RESET", "MASK", "APPLY", "APPLY_ANIM")
+
+
+# ---- curves / tracks (fyrox-math/src/curve.rs, fyrox-animation/src/track.rs, container.rs) ----------
+
+@dataclass
+class CurveKey:
+    location: float
+    value: float
+    kind: int = KEY_LINEAR
+    left_tangent: float = 0.0   # CurveKeyKind::Cubic only
+    right_tangent: float = 0.0
+
+
+class Curve:
+    """Keys kept sorted by location (stable), as Curve::from / add_key do (curve.rs:164-174)."""
+
+    def __init__(self, keys: Sequence[CurveKey] = ()):
+        self.keys: List[CurveKey] = sorted(keys, key=lambda k: k.location)
+
+    def __len__(self):
+        return len(self.keys)
+
+
+@dataclass
+class Track:
+    binding: int
+    kind: int
+    curves: List[Curve]
+
+
+@dataclass
+class AnimationTracksData:
+    tracks: List[Track] = field(default_factory=list)
+
+    def flatten(self):
+        """-> (track descriptors, location, value, kind, left_tangent, right_tangent) in the order
+        fyx_tracks_data_upload expects (track-major, curve-major)."""
+        descs = (TrackDesc * max(len(self.tracks), 1))()
+        loc, val, kind, lt, rt = [], [], [], [], []
+        for i, t in enumerate(self.tracks):
+            assert len(t.curves) <= 4
+            descs[i].binding = t.binding
+            descs[i].kind = t.kind
+            descs[i].n_curves = len(t.curves)
+            for c, cv in enumerate(t.curves):
+                descs[i].curve_n_keys[c] = len(cv)
+                for k in cv.keys:
+                    loc.append(k.location); val.append(k.value); kind.append(k.kind)
+                    lt.append(k.left_tangent); rt.append(k.right_tangent)
+        f = lambda a: np.asarray(a, np.float32)
+        return descs, f(loc), f(val), np.asarray(kind, np.uint8), f(lt), f(rt)
+
+    def time_length(self) -> float:
+        """TrackDataContainer::time_length over all tracks (what fit_length_to_content uses)."""
+        m = 0.0
+        for t in self.tracks:
+            for c in t.curves:
+                if c.keys:
+                    m = max(m, c.keys[-1].location)
+        return m
+
+
+class TrackDesc(Structure):
+    _fields_ = [("binding", c_int32), ("kind", c_int32), ("n_curves", c_uint32), ("curve_n_keys", c_uint32 * 4)]
+
+
+# ---- scene::transform::Transform ----------------------------------------------------------------
+
+class Transform(Structure):
+    _fields_ = [("local_position", c_float * 3), ("local_rotation", c_float * 4), ("local_scale", c_float * 3),
+                ("pre_rotation", c_float * 4), ("post_rotation_matrix", c_float * 9),
+                ("rotation_offset", c_float * 3), ("rotation_pivot", c_float * 3),
+                ("scaling_offset", c_float * 3), ("scaling_pivot", c_float * 3)]
+
+    @staticmethod
+    def identity() -> "Transform":
+        t = Transform()
+        t.local_rotation[:] = (0, 0, 0, 1)
+        t.local_scale[:] = (1, 1, 1)
+        t.pre_rotation[:] = (0, 0, 0, 1)
+        t.post_rotation_matrix[:] = (1, 0, 0, 0, 1, 0, 0, 0, 1)
+        return t
+
+
+@dataclass
+class Rig:
+    parent: np.ndarray                    # (n,) int32, parent[i] < i or -1
+    transforms: List[Transform]
+    inv_bind: Optional[np.ndarray] = None  # (n,16) column-major, None = identity
+
+    @property
+    def n_nodes(self) -> int:
+        return len(self.transforms)
+
+
+# ---- Machine (fyrox-animation/src/machine) --------------------------------------------------------
+
+@dataclass
+class Parameter:
+    kind: int
+    value: Union[float, bool, int, Tuple[float, float]] = 0.0
+
+    def packed(self):
+        if self.kind == PARAM_WEIGHT:
+            return float(self.value), 0.0, 0
+        if self.kind == PARAM_RULE:
+            return 0.0, 0.0, 1 if self.value else 0
+        if self.kind == PARAM_INDEX:
+            return 0.0, 0.0, int(self.value)
+        return float(self.value[0]), float(self.value[1]), 0
+
+
+@dataclass
+class PlayAnimation:
+    animation: int
+
+
+@dataclass
+class BlendPose:
+    pose_source: int
+    weight: float = 0.0               # PoseWeight::Constant
+    parameter: Optional[int] = None   # PoseWeight::Parameter
+
+
+@dataclass
+class BlendAnimations:
+    pose_sources: List[BlendPose]
+
+
+@dataclass
+class IndexedBlendInput:
+    blend_time: float
+    pose_source: int
+
+
+@dataclass
+class BlendAnimationsByIndex:
+    index_parameter: int
+    inputs: List[IndexedBlendInput]
+
+
+@dataclass
+class BlendSpacePoint:
+    position: Tuple[float, float]
+    pose_source: int
+
+
+@dataclass
+class BlendSpace:
+    sampling_parameter: int
+    points: List[BlendSpacePoint]
+    triangles: List[Tuple[int, int, int]] = field(default_factory=list)
+
+
+PoseNode = Union[PlayAnimation, BlendAnimations, BlendAnimationsByIndex, BlendSpace]
+
+
+@dataclass
+class State:
+    root: int
+    on_enter_actions: List[Tuple[int, int]] = field(default_factory=list)  # (ACTION_*, animation)
+    on_leave_actions: List[Tuple[int, int]] = field(default_factory=list)
+
+
+@dataclass
+class Transition:
+    source: int
+    dest: int
+    transition_time: float
+    condition: tuple = ("parameter", -1)   # ("parameter", p) | ("and"|"or"|"xor", a, b) | ("not", a) | ("ended", anim)
+
+
+@dataclass
+class MachineLayer:
+    nodes: List[PoseNode] = field(default_factory=list)
+    states: List[State] = field(default_factory=list)
+    transitions: List[Transition] = field(default_factory=list)
+    weight: float = 1.0
+    entry_state: Optional[int] = None
+    mask: List[int] = field(default_factory=list)
+
+
+@dataclass
+class Machine:
+    parameters: List[Parameter] = field(default_factory=list)
+    layers: List[MachineLayer] = field(default_factory=list)
+
+
+def encode_logic(cond) -> List[int]:
+    """LogicNode tree -> prefix int code (FYX_LOGIC_*)."""
+    op = cond[0]
+    if op == "parameter":
+        return [LOGIC_PARAMETER, int(cond[1])]
+    if op == "ended":
+        return [LOGIC_IS_ANIMATION_ENDED, int(cond[1])]
+    if op == "not":
+        return [LOGIC_NOT] + encode_logic(cond[1])
+    code = {"and": LOGIC_AND, "or": LOGIC_OR, "xor": LOGIC_XOR}[op]
+    return [code] + encode_logic(cond[1]) + encode_logic(cond[2])
+
+
+# ---- C ABI wrapper --------------------------------------------------------------------------------
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Animator:
+    """n_instances copies of one rig + its AnimationPlayer animations (+ optionally a Machine)."""
+
+    def __init__(self, ctx, animator_id: int, rig_id: int, rig: Rig, n_instances: int = 1):
+        self.ctx, self.id, self.rig_id, self.rig, self.n_instances = ctx, animator_id, rig_id, rig, n_instances
+        self._l, self._h = ctx._l, ctx._h
+        self.n_animations = 0
+        ctx._check(self._l.fyx_animator_create(self._h, animator_id, rig_id, n_instances))
+
+    def _check(self, rc):
+        self.ctx._check(rc)
+
+    # -- animations ------------------------------------------------------------------------------
+    def add_animation(self, tracks_id: int, track_target, track_enabled=None, *, time_slice=None, speed=None,
+                      looped=None, enabled=None) -> int:
+        tgt = _i32(track_target)
+        en = None if track_enabled is None else np.ascontiguousarray(track_enabled, dtype=np.uint8)
+        out = c_uint32()
+        self._check(self._l.fyx_animator_add_animation(self._h, self.id, tracks_id, _ptr(tgt), _ptr(en), byref(out)))
+        a = out.value
+        self.n_animations = a + 1
+        if looped is not None:
+            self.set_loop(a, looped)
+        if time_slice is not None:
+            self.set_time_slice(a, *time_slice)
+        if speed is not None:
+            self.set_speed(a, speed)
+        if enabled is not None:
+            self.set_enabled(a, enabled)
+        return a
+
+    def set_time_slice(self, a, start, end, instance=ALL_INSTANCES):
+        self._check(self._l.fyx_animation_set_time_slice(self._h, self.id, a, instance, start, end))
+
+    def set_time_position(self, a, t, instance=ALL_INSTANCES):
+        self._check(self._l.fyx_animation_set_time_position(self._h, self.id, a, instance, t))
+
+    def set_speed(self, a, s, instance=ALL_INSTANCES):
+        self._check(self._l.fyx_animation_set_speed(self._h, self.id, a, instance, s))
+
+    def set_loop(self, a, looped, instance=ALL_INSTANCES):
+        self._check(self._l.fyx_animation_set_loop(self._h, self.id, a, instance, int(bool(looped))))
+
+    def set_enabled(self, a, enabled, instance=ALL_INSTANCES):
+        self._check(self._l.fyx_animation_set_enabled(self._h, self.id, a, instance, int(bool(enabled))))
+
+    def rewind(self, a, instance=ALL_INSTANCES):
+        self._check(self._l.fyx_animation_rewind(self._h, self.id, a, instance))
+
+    def set_track_enabled(self, a, track, enabled):
+        self._check(self._l.fyx_animation_set_track_enabled(self._h, self.id, a, track, int(bool(enabled))))
+
+    def animation_state(self, a, instance=0) -> dict:
+        t, e, d = c_float(), c_int(), c_int()
+        self._check(self._l.fyx_animation_get_state(self._h, self.id, a, instance, byref(t), byref(e), byref(d)))
+        return {"time_position": t.value, "enabled": bool(e.value), "has_ended": bool(d.value)}
+
+    # -- machine ---------------------------------------------------------------------------------
+    def set_machine(self, m: Machine) -> None:
+        L = self._l
+        for p in m.parameters:
+            f0, f1, u = p.packed()
+            self._check(L.fyx_machine_add_parameter(self._h, self.id, p.kind, f0, f1, u, None))
+        for layer in m.layers:
+            li = c_uint32()
+            self._check(L.fyx_machine_add_layer(self._h, self.id, layer.weight, byref(li)))
+            li = li.value
+            if layer.mask:
+                mk = _i32(layer.mask)
+                self._check(L.fyx_layer_set_mask(self._h, self.id, li, _ptr(mk), len(mk)))
+            for n in layer.nodes:
+                if isinstance(n, PlayAnimation):
+                    self._check(L.fyx_layer_add_play_animation(self._h, self.id, li, n.animation, None))
+                elif isinstance(n, BlendAnimations):
+                    src = _i32([b.pose_source for b in n.pose_sources])
+                    par = _i32([-1 if b.parameter is None else b.parameter for b in n.pose_sources])
+                    wc = np.asarray([b.weight for b in n.pose_sources], np.float32)
+                    self._check(L.fyx_layer_add_blend_animations(self._h, self.id, li, len(src), _ptr(src), _ptr(par),
+                                                                 _ptr(wc), None))
+                elif isinstance(n, BlendAnimationsByIndex):
+                    src = _i32([i.pose_source for i in n.inputs])
+                    bt = np.asarray([i.blend_time for i in n.inputs], np.float32)
+                    self._check(L.fyx_layer_add_blend_animations_by_index(self._h, self.id, li, n.index_parameter,
+                                                                          len(src), _ptr(src), _ptr(bt), None))
+                elif isinstance(n, BlendSpace):
+                    pts = np.asarray([p.position for p in n.points], np.float32).reshape(-1, 2)
+                    src = _i32([p.pose_source for p in n.points])
+                    tri = np.asarray(n.triangles, np.uint32).reshape(-1, 3)
+                    self._check(L.fyx_layer_add_blend_space(self._h, self.id, li, n.sampling_parameter, len(src),
+                                                            _ptr(pts), _ptr(src), len(tri), _ptr(tri), None))
+                else:
+                    raise TypeError(n)
+            for si, s in enumerate(layer.states):
+                self._check(L.fyx_layer_add_state(self._h, self.id, li, s.root, None))
+                for kind, anim in s.on_enter_actions:
+                    self._check(L.fyx_state_add_action(self._h, self.id, li, si, 1, kind, anim))
+                for kind, anim in s.on_leave_actions:
+                    self._check(L.fyx_state_add_action(self._h, self.id, li, si, 0, kind, anim))
+            for t in layer.transitions:
+                code = _i32(encode_logic(t.condition))
+                self._check(L.fyx_layer_add_transition(self._h, self.id, li, t.source, t.dest, t.transition_time,
+                                                       _ptr(code), len(code), None))
+            if layer.entry_state is not None:
+                self._check(L.fyx_layer_set_entry_state(self._h, self.id, li, layer.entry_state))
+
+    def set_parameter(self, index: int, p: Parameter, instance=ALL_INSTANCES) -> None:
+        f0, f1, u = p.packed()
+        self._check(self._l.fyx_machine_set_parameter(self._h, self.id, index, instance, p.kind, f0, f1, u))
+
+    def layer_state(self, layer: int, instance: int = 0) -> Tuple[int, int]:
+        s, t = c_int32(), c_int32()
+        self._check(self._l.fyx_layer_get_state(self._h, self.id, layer, instance, byref(s), byref(t)))
+        return s.value, t.value
+
+    # -- per frame -------------------------------------------------------------------------------
+    def update_animations(self, dt: float) -> None:
+        """AnimationPlayer::update"""
+        self._check(self._l.fyx_animation_player_update(self._h, self.id, dt))
+
+    def update_machine(self, dt: float) -> None:
+        """AnimationBlendingStateMachine::update"""
+        self._check(self._l.fyx_absm_update(self._h, self.id, dt))
+
+    def update_transforms(self) -> None:
+        self._check(self._l.fyx_animator_update_transforms(self._h, self.id))
+
+    def palette(self, bones_id: int, d_out: int) -> None:
+        self._check(self._l.fyx_animator_palette(self._h, self.id, bones_id, d_out))
+
+    def set_local_trs(self, node: int, trs, first_instance: int = 0) -> None:
+        trs = np.ascontiguousarray(trs, dtype=np.float32).reshape(-1, 10)
+        self._check(self._l.fyx_animator_set_local_trs(self._h, self.id, node, first_instance, trs.shape[0], _ptr(trs)))
+
+    def read(self, what: int) -> np.ndarray:
+        width = 16 if what in (READ_LOCAL_MATRIX, READ_GLOBAL_MATRIX) else 12
+        out = np.empty((self.n_instances, self.rig.n_nodes, width), np.float32)
+        self._check(self._l.fyx_animator_read(self._h, self.id, what, _ptr(out)))
+        return out
+
+    def device_ptr(self, what: int) -> int:
+        p = c_void_p()
+        self._check(self._l.fyx_animator_device_ptr(self._h, self.id, what, byref(p)))
+        return p.value or 0
+
+    def plan(self, mode: int, dt: float) -> dict:
+        """Advance the control plane one frame WITHOUT running kernels; returns what would be sent."""
+        na = max(self.n_animations, 1)
+        times = np.zeros((self.n_instances, na), np.float32)
+        ticked = np.zeros((self.n_instances, na), np.uint8)
+        off = np.zeros(self.n_instances + 1, np.uint32)
+        cap = 4096
+        ops = np.zeros((cap, 2), np.uint32)
+        n = c_uint32()
+        self._check(self._l.fyx_animator_plan(self._h, self.id, mode, dt, _ptr(times), _ptr(ticked), _ptr(off),
+                                              _ptr(ops), cap, byref(n)))
+        if n.value > cap:
+            raise RuntimeError("program larger than the wrapper's buffer; plan() is a test hook")
+        return {"times": times[:, :self.n_animations], "ticked": ticked[:, :self.n_animations], "offsets": off,
+                "ops": ops[:n.value]}
+
+    def free(self) -> None:
+        self._check(self._l.fyx_animator_free(self._h, self.id))
+
+
+def upload_tracks_data(ctx, tracks_id: int, td: AnimationTracksData) -> None:
+    descs, loc, val, kind, lt, rt = td.flatten()
+    ctx._check(ctx._l.fyx_tracks_data_upload(ctx._h, tracks_id, len(td.tracks), descs, len(loc), _ptr(loc), _ptr(val),
+                                             _ptr(kind), _ptr(lt), _ptr(rt)))
+
+
+def create_rig(ctx, rig_id: int, rig: Rig) -> None:
+    n = rig.n_nodes
+    arr = (Transform * n)(*rig.transforms)
+    parent = _i32(rig.parent)
+    ib = None if rig.inv_bind is None else np.ascontiguousarray(rig.inv_bind, dtype=np.float32).reshape(n, 16)
+    ctx._check(ctx._l.fyx_rig_create(ctx._h, rig_id, n, _ptr(parent), arr, _ptr(ib)))
+
+
+def create_bone_list(ctx, bones_id: int, rig_id: int, bone_nodes) -> None:
+    b = _i32(bone_nodes)
+    ctx._check(ctx._l.fyx_bone_list_create(ctx._h, bones_id, rig_id, len(b), _ptr(b)))
+
+
+def decode_ops(ops: np.ndarray) -> List[Tuple[str, int, float]]:
+    out = []
+    for x, y in ops:
+        out.append((OP_NAMES[int(x) & 0xFF], int(x) >> 8, float(np.uint32(y).view(np.float32))))
+    return out

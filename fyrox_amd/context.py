@@ -55,9 +55,17 @@ class Context:
     """One fyx_ctx: a GPU, a stream, the mesh registry.  Not thread-safe (as the reference's
     update/render thread)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, *, control_only: bool = False):
         self._l = _native.lib()
         h = c_void_p()
+        if control_only:
+            # no GPU: registry + control-plane calls only; every data-path call raises FYX_ERR_NO_DEVICE
+            rc = self._l.fyx_init_control_only(byref(h))
+            if rc != 0:
+                raise FyxError(rc, "fyx_init_control_only failed")
+            self._h = h
+            self.device = -1
+            return
         rc = self._l.fyx_init(byref(h), int(device))
         if rc != 0:
             raise FyxError(rc, f"fyx_init(device={device}) failed: no MI355X/HIP device visible; "

@@ -1,0 +1,1638 @@
+// anim_api.hip -- C ABI of the pose path (see include/fyrox_hip.h, second half) and its host
+// control plane.
+//
+// The control plane mirrors, per instance, the scalar logic of the reference:
+//   Animation::tick / set_time_position / has_ended      fyrox-animation/src/lib.rs:432-496,736
+//   Machine::evaluate_pose                                machine/mod.rs:344-382
+//   MachineLayer::evaluate_pose                           machine/layer.rs:590-706
+//   Transition::update / is_done, LogicNode               machine/transition.rs:141-173,301-322
+//   PlayAnimation / BlendAnimations / ..ByIndex / BlendSpace::eval_pose
+//                                                         machine/node/{play,blend,blendspace}.rs
+//   StateAction::apply                                    machine/state.rs:48-80
+// but instead of touching poses it RECORDS what each pose node would have blended (a "recipe")
+// and flattens the consumed recipes into a fold program the pose_update kernel executes per
+// bone.  No per-bone arithmetic happens here.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "fyx_ctx.h"
+
+namespace fyx {
+
+namespace {
+
+struct TracksData {
+    uint32_t n_tracks = 0;
+    std::vector<fyx_track_desc> tracks;
+    TrackDev* d_tracks = nullptr;
+    float* d_loc = nullptr;
+    float4* d_aux = nullptr;
+};
+
+struct Rig {
+    uint32_t n_nodes = 0, n_levels = 0;
+    std::vector<int32_t> parent;
+    std::vector<float> init_trs;  // [n_nodes][12]
+    int32_t* d_parent = nullptr;
+    float* d_statics = nullptr;
+    uint32_t* d_level_nodes = nullptr;
+    uint32_t* d_level_start = nullptr;
+    float* d_inv_bind = nullptr;
+};
+
+struct BoneList {
+    uint64_t rig_id = 0;
+    uint32_t n_bones = 0;
+    int32_t* d_bone_nodes = nullptr;
+};
+
+// ---- shared structure of an animator ----
+struct AnimationDef {
+    uint64_t tracks_id = 0;
+    const TracksData* td = nullptr;
+    std::vector<int32_t> target;   // per track, <0: no TrackBinding
+    std::vector<uint8_t> enabled;  // TrackBinding::enabled
+    int32_t* d_slot_track = nullptr;
+    bool slots_dirty = true;
+};
+
+struct AnimState {  // per instance, per animation (Animation's scalar fields)
+    float time = 0.f, speed = 1.f, start = 0.f, end = 0.f;
+    uint8_t enabled = 1, looped = 1;
+};
+
+struct Param {
+    int kind = FYX_PARAM_WEIGHT;
+    float f0 = 0.f, f1 = 0.f;
+    uint32_t u = 0;
+};
+
+struct BlendInput {
+    int32_t source = -1;
+    int32_t weight_param = -1;
+    float weight_const = 0.f;
+    float blend_time = 0.f;
+};
+
+enum NodeType { NODE_PLAY, NODE_BLEND, NODE_BY_INDEX, NODE_BLEND_SPACE };
+
+struct PoseNodeDef {
+    NodeType type = NODE_PLAY;
+    uint32_t animation = 0;
+    int32_t param = -1;
+    std::vector<BlendInput> inputs;
+    std::vector<float> points;       // BlendSpace xy
+    std::vector<uint32_t> triangles;
+    uint32_t by_index_slot = 0;      // index into per-instance ByIndex state
+};
+
+struct Action { int kind; uint32_t animation; };
+struct StateDef { int32_t root = -1; std::vector<Action> on_enter, on_leave; };
+struct TransitionDef { uint32_t source = 0, dest = 0; float time = 0.f; std::vector<int32_t> logic; };
+
+struct LayerDef {
+    float weight = 1.f;
+    std::vector<PoseNodeDef> nodes;
+    std::vector<StateDef> states;
+    std::vector<TransitionDef> transitions;
+    int32_t entry_state = -1;
+    std::vector<int32_t> excluded;
+    uint32_t by_index_count = 0;
+};
+
+// ---- per-instance machine state ----
+struct TransitionState { float elapsed = 0.f, blend_factor = 0.f; };
+struct ByIndexState { bool has_prev = false; uint32_t prev = 0; float blend_time = 0.f; };
+struct LayerState {
+    int32_t active_state = -1, active_transition = -1;
+    std::vector<TransitionState> transitions;
+    std::vector<ByIndexState> by_index;
+};
+struct MachineState {
+    std::vector<Param> params;
+    std::vector<LayerState> layers;
+};
+
+// A recipe: what a pose node's output pose was made of at one evaluation.
+struct Recipe {
+    int32_t anim = -1;                  // >= 0: a copy of that animation's pose
+    uint32_t first = 0, count = 0;      // else: fold of items[first .. first+count)
+};
+struct RecipeItem { uint32_t recipe; float w; };
+
+struct Animator {
+    uint64_t rig_id = 0;
+    Rig* rig = nullptr;
+    uint32_t n_instances = 0;
+    std::vector<AnimationDef> anims;
+    std::vector<AnimState> anim_state;  // [inst][anim]
+    std::vector<Param> param_defaults;
+    std::vector<LayerDef> layers;
+    std::vector<MachineState> mstate;   // [inst]
+    uint32_t max_tracks = 0;
+    // device state
+    AnimDev* d_anims = nullptr;
+    bool anims_dirty = true;
+    uint32_t* d_hints = nullptr;
+    float4* d_anim_pose = nullptr;
+    uint32_t dev_anim_capacity = 0, dev_track_capacity = 0;
+    float4* d_node_trs = nullptr;
+    float* d_local = nullptr;
+    float* d_global = nullptr;
+    uint8_t* d_layer_masks = nullptr;
+    bool masks_dirty = true;
+    uint32_t dev_mask_layers = 0;
+    // per-frame control (device + pinned staging)
+    void* d_ctrl = nullptr;
+    size_t d_ctrl_bytes = 0;
+    void* h_ctrl[2] = {nullptr, nullptr};
+    size_t h_ctrl_bytes[2] = {0, 0};
+    hipEvent_t h_ctrl_ev[2] = {nullptr, nullptr};
+    bool h_ctrl_busy[2] = {false, false};
+    int h_ctrl_next = 0;
+    // frame plan (host)
+    std::vector<float> times;
+    std::vector<uint8_t> ticked;
+    std::vector<uint2> ops;
+    std::vector<uint32_t> prog_off;
+    // scratch of the planner
+    std::vector<Recipe> recipes;
+    std::vector<RecipeItem> items;
+    std::vector<int32_t> node_recipe;
+    std::vector<uint8_t> seen;
+};
+
+}  // namespace
+
+struct AnimStore {
+    std::unordered_map<uint64_t, TracksData> tracks;
+    std::unordered_map<uint64_t, Rig> rigs;
+    std::unordered_map<uint64_t, BoneList> bones;
+    std::unordered_map<uint64_t, std::unique_ptr<Animator>> animators;
+};
+
+namespace {
+
+bool has_device(const fyx_ctx* c) { return c->device >= 0; }
+
+AnimStore& store(fyx_ctx* c) {
+    if (!c->anim) c->anim = new AnimStore();
+    return *c->anim;
+}
+
+void dfree(void* p) { if (p) (void)hipFree(p); }
+
+void free_tracks(TracksData& t) { dfree(t.d_tracks); dfree(t.d_loc); dfree(t.d_aux); t = TracksData(); }
+void free_rig(Rig& r) {
+    dfree(r.d_parent); dfree(r.d_statics); dfree(r.d_level_nodes); dfree(r.d_level_start); dfree(r.d_inv_bind);
+    r = Rig();
+}
+void free_bones(BoneList& b) { dfree(b.d_bone_nodes); b = BoneList(); }
+void free_animator(Animator& a) {
+    for (auto& an : a.anims) dfree(an.d_slot_track);
+    dfree(a.d_anims); dfree(a.d_hints); dfree(a.d_anim_pose); dfree(a.d_node_trs); dfree(a.d_local);
+    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_ctrl);
+    for (int i = 0; i < 2; ++i) {
+        if (a.h_ctrl[i]) (void)hipHostFree(a.h_ctrl[i]);
+        if (a.h_ctrl_ev[i]) (void)hipEventDestroy(a.h_ctrl_ev[i]);
+    }
+}
+
+template <typename T>
+int upload(fyx_ctx* c, T** dst, const T* src, size_t count) {
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(dst), bytes));
+    if (count) FYX_HIP(c, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return FYX_OK;
+}
+
+Animator* find_animator(fyx_ctx* c, uint64_t id) {
+    if (!c->anim) return nullptr;
+    auto it = c->anim->animators.find(id);
+    return it == c->anim->animators.end() ? nullptr : it->second.get();
+}
+
+#define FYX_ANIMATOR(c, a, id)                                                                   \
+    Animator* a = find_animator((c), (id));                                                      \
+    if (!a) return fail((c), FYX_ERR_UNKNOWN_ID, "animator %llu is not registered", (unsigned long long)(id))
+
+// ------------------------------------------------------------------------------------------
+// Animation scalars
+// ------------------------------------------------------------------------------------------
+// fyrox-math/src/lib.rs:179-203
+float wrapf(float n, float min_limit, float max_limit) {
+    if (n >= min_limit && n <= max_limit) return n;
+    if (max_limit == 0.0f && min_limit == 0.0f) return 0.0f;
+    max_limit -= min_limit;
+    const float offset = min_limit;
+    min_limit = 0.0f;
+    n -= offset;
+    const float num_of_max = floorf(fabsf(n / max_limit));
+    if (n >= max_limit) {
+        n -= num_of_max * max_limit;
+    } else if (n < min_limit) {
+        n += (num_of_max + 1.0f) * max_limit;
+    }
+    return n + offset;
+}
+
+// lib.rs:432-440
+void set_time_position(AnimState& s, float time) {
+    if (s.looped) {
+        s.time = wrapf(time, s.start, s.end);
+    } else {
+        float t = time;  // f32::clamp
+        if (t < s.start) t = s.start;
+        if (t > s.end) t = s.end;
+        s.time = t;
+    }
+}
+// lib.rs:736-738
+bool has_ended(const AnimState& s) { return !s.looped && fabsf(s.time - s.end) <= FLT_EPSILON; }
+
+// ------------------------------------------------------------------------------------------
+// Planner
+// ------------------------------------------------------------------------------------------
+struct Planner {
+    Animator& A;
+    uint32_t inst;
+    float dt;
+    uint32_t n_anims;
+    AnimState* as;       // this instance's animation states
+    MachineState* ms;
+    int error = 0;       // FYX_ERR_UNSUPPORTED when the fold nests too deep
+    int depth = 0;
+
+    Planner(Animator& a, uint32_t i, float dt_) : A(a), inst(i), dt(dt_) {
+        n_anims = (uint32_t)a.anims.size();
+        as = a.anim_state.data() + (size_t)i * n_anims;
+        ms = a.mstate.empty() ? nullptr : &a.mstate[i];
+    }
+
+    void emit(uint32_t code, uint32_t arg, float w) {
+        uint2 op;
+        op.x = code | (arg << 8);
+        memcpy(&op.y, &w, 4);
+        A.ops.push_back(op);
+    }
+
+    // Animation::tick (lib.rs:471-496): the pose is sampled at the CURRENT time, then time advances.
+    void tick(uint32_t a) {
+        AnimState& s = as[a];
+        A.times[(size_t)inst * n_anims + a] = s.time;
+        A.ticked[(size_t)inst * n_anims + a] = 1;
+        set_time_position(s, s.time + dt * s.speed);
+    }
+
+    const Param* param(int32_t idx) const {
+        return (idx >= 0 && (size_t)idx < ms->params.size()) ? &ms->params[idx] : nullptr;
+    }
+
+    uint32_t new_recipe_anim(uint32_t a) {
+        Recipe r;
+        r.anim = (int32_t)a;
+        A.recipes.push_back(r);
+        return (uint32_t)A.recipes.size() - 1;
+    }
+    uint32_t new_recipe_fold(const RecipeItem* it, uint32_t n) {
+        Recipe r;
+        r.first = (uint32_t)A.items.size();
+        r.count = n;
+        for (uint32_t i = 0; i < n; ++i) A.items.push_back(it[i]);
+        A.recipes.push_back(r);
+        return (uint32_t)A.recipes.size() - 1;
+    }
+
+    // transition.rs:141-173
+    bool logic(const std::vector<int32_t>& code, size_t& pc) const {
+        if (pc >= code.size()) return false;
+        const int32_t op = code[pc++];
+        switch (op) {
+            case FYX_LOGIC_PARAMETER: {
+                const int32_t idx = pc < code.size() ? code[pc++] : -1;
+                const Param* p = param(idx);
+                return p && p->kind == FYX_PARAM_RULE && p->u != 0;
+            }
+            case FYX_LOGIC_AND: { const bool l = logic(code, pc); const bool r = logic(code, pc); return l & r; }
+            case FYX_LOGIC_OR: { const bool l = logic(code, pc); const bool r = logic(code, pc); return l | r; }
+            case FYX_LOGIC_XOR: { const bool l = logic(code, pc); const bool r = logic(code, pc); return l ^ r; }
+            case FYX_LOGIC_NOT: return !logic(code, pc);
+            case FYX_LOGIC_IS_ANIMATION_ENDED: {
+                const int32_t a = pc < code.size() ? code[pc++] : -1;
+                if (a < 0 || (uint32_t)a >= n_anims) return true;  // invalid handle: is_none_or -> true
+                return has_ended(as[a]);
+            }
+            default: return false;
+        }
+    }
+
+    // AnimationPoseSource::eval_pose, control part.  Returns the recipe of the node's output pose
+    // (-1: the handle does not resolve, nodes.try_borrow fails).
+    int32_t eval_node(const LayerDef& L, LayerState& LS, int32_t handle, int32_t* node_recipe) {
+        if (handle < 0 || (size_t)handle >= L.nodes.size()) return -1;
+        const PoseNodeDef& n = L.nodes[handle];
+        int32_t out = -1;
+        switch (n.type) {
+            case NODE_PLAY:  // play.rs:86-100
+                out = (int32_t)new_recipe_anim(n.animation);
+                break;
+            case NODE_BLEND: {  // blend.rs:136-164
+                std::vector<RecipeItem> its;
+                for (const BlendInput& in : n.inputs) {
+                    float w;
+                    if (in.weight_param < 0) {
+                        w = in.weight_const;
+                    } else {
+                        const Param* p = param(in.weight_param);
+                        w = (p && p->kind == FYX_PARAM_WEIGHT) ? p->f0 : 0.0f;
+                    }
+                    const int32_t src = eval_node(L, LS, in.source, node_recipe);
+                    if (src >= 0) its.push_back({(uint32_t)src, w});
+                }
+                out = (int32_t)new_recipe_fold(its.data(), (uint32_t)its.size());
+                break;
+            }
+            case NODE_BY_INDEX: {  // blend.rs:306-361
+                ByIndexState& st = LS.by_index[n.by_index_slot];
+                RecipeItem its[2];
+                uint32_t cnt = 0;
+                const Param* p = param(n.param);
+                if (p && p->kind == FYX_PARAM_INDEX) {
+                    const uint32_t current = p->u;
+                    bool applied = false;
+                    if (st.has_prev) {
+                        if (st.prev != current && st.prev < n.inputs.size() && current < n.inputs.size()) {
+                            const BlendInput& prev_in = n.inputs[st.prev];
+                            const BlendInput& cur_in = n.inputs[current];
+                            float bt = st.blend_time + dt;  // (blend_time + dt).min(current.blend_time)
+                            if (cur_in.blend_time < bt) bt = cur_in.blend_time;
+                            st.blend_time = bt;
+                            const float interpolator = st.blend_time / cur_in.blend_time;
+                            const int32_t pr = eval_node(L, LS, prev_in.source, node_recipe);
+                            if (pr >= 0) its[cnt++] = {(uint32_t)pr, 1.0f - interpolator};
+                            const int32_t cr = eval_node(L, LS, cur_in.source, node_recipe);
+                            if (cr >= 0) its[cnt++] = {(uint32_t)cr, interpolator};
+                            if (interpolator >= 1.0f) {
+                                st.prev = current;
+                                st.blend_time = 0.0f;
+                            }
+                            applied = true;
+                        }
+                    } else {
+                        st.has_prev = true;
+                        st.prev = current;
+                    }
+                    if (!applied) {
+                        st.blend_time = 0.0f;
+                        if (current < n.inputs.size()) {
+                            const int32_t cr = eval_node(L, LS, n.inputs[current].source, node_recipe);
+                            if (cr >= 0) its[cnt++] = {(uint32_t)cr, 1.0f};  // clone_into an empty pose
+                        }
+                    }
+                }
+                out = (int32_t)new_recipe_fold(its, cnt);
+                break;
+            }
+            case NODE_BLEND_SPACE: {  // blendspace.rs:118-150
+                RecipeItem its[3];
+                uint32_t cnt = 0;
+                const Param* p = param(n.param);
+                if (p && p->kind == FYX_PARAM_SAMPLING_POINT) {
+                    int idx[3];
+                    float w[3];
+                    const float sp[2] = {p->f0, p->f1};
+                    if (blend_space_weights(n, sp, idx, w)) {
+                        const int32_t sa = n.inputs[idx[0]].source, sb = n.inputs[idx[1]].source,
+                                      sc = n.inputs[idx[2]].source;
+                        auto ok = [&](int32_t h) { return h >= 0 && (size_t)h < L.nodes.size(); };
+                        if (ok(sa) && ok(sb) && ok(sc)) {
+                            its[cnt++] = {(uint32_t)eval_node(L, LS, sa, node_recipe), w[0]};
+                            its[cnt++] = {(uint32_t)eval_node(L, LS, sb, node_recipe), w[1]};
+                            its[cnt++] = {(uint32_t)eval_node(L, LS, sc, node_recipe), w[2]};
+                        }
+                    }
+                }
+                out = (int32_t)new_recipe_fold(its, cnt);
+                break;
+            }
+        }
+        node_recipe[handle] = out;  // the node's cached output_pose now holds this
+        return out;
+    }
+
+    // fyrox-math/src/lib.rs:291-313,326-328 and blendspace.rs:338-414 (fetch_weights)
+    static bool blend_space_weights(const PoseNodeDef& n, const float sp[2], int idx[3], float w[3]) {
+        const size_t np = n.inputs.size();
+        const float* pts = n.points.data();
+        if (np == 0) return false;
+        if (np == 1) { idx[0] = idx[1] = idx[2] = 0; w[0] = 1.0f; w[1] = w[2] = 0.0f; return true; }
+        if (np == 2) {
+            const float e[2] = {pts[2] - pts[0], pts[3] - pts[1]};
+            const float tp[2] = {sp[0] - pts[0], sp[1] - pts[1]};
+            const float t = (tp[0] * e[0] + tp[1] * e[1]) / (e[0] * e[0] + e[1] * e[1]);
+            if (t >= 0.0f && t <= 1.0f) {
+                idx[0] = 0; idx[1] = 1; idx[2] = 0;
+                w[0] = 1.0f - t; w[1] = t; w[2] = 0.0f;
+                return true;
+            }
+        }
+        const size_t nt = n.triangles.size() / 3;
+        for (size_t k = 0; k < nt; ++k) {
+            const uint32_t ia = n.triangles[k * 3], ib = n.triangles[k * 3 + 1], ic = n.triangles[k * 3 + 2];
+            const float* a = pts + ia * 2;
+            const float* b = pts + ib * 2;
+            const float* c = pts + ic * 2;
+            const float v0[2] = {b[0] - a[0], b[1] - a[1]}, v1[2] = {c[0] - a[0], c[1] - a[1]};
+            const float v2[2] = {sp[0] - a[0], sp[1] - a[1]};
+            const float d00 = v0[0] * v0[0] + v0[1] * v0[1], d01 = v0[0] * v1[0] + v0[1] * v1[1];
+            const float d11 = v1[0] * v1[0] + v1[1] * v1[1], d20 = v2[0] * v0[0] + v2[1] * v0[1];
+            const float d21 = v2[0] * v1[0] + v2[1] * v1[1];
+            const float inv_denom = 1.0f / (d00 * d11 - d01 * d01);
+            const float v = (d11 * d20 - d01 * d21) * inv_denom;
+            const float ww = (d00 * d21 - d01 * d20) * inv_denom;
+            const float u = 1.0f - v - ww;
+            if (u >= 0.0f && v >= 0.0f && u + v < 1.0f) {
+                idx[0] = (int)ia; idx[1] = (int)ib; idx[2] = (int)ic;
+                w[0] = u; w[1] = v; w[2] = ww;
+                return true;
+            }
+        }
+        float min_distance = FLT_MAX;
+        bool found = false;
+        for (size_t k = 0; k < nt; ++k)
+            for (int e = 0; e < 3; ++e) {
+                const uint32_t a = n.triangles[k * 3 + e], b = n.triangles[k * 3 + (e + 1) % 3];
+                const float* pa = pts + a * 2;
+                const float* pb = pts + b * 2;
+                const float edge[2] = {pb[0] - pa[0], pb[1] - pa[1]};
+                const float tp[2] = {sp[0] - pa[0], sp[1] - pa[1]};
+                const float t = (tp[0] * edge[0] + tp[1] * edge[1]) / (edge[0] * edge[0] + edge[1] * edge[1]);
+                if (t >= 0.0f && t <= 1.0f) {
+                    const float proj[2] = {pa[0] + edge[0] * t, pa[1] + edge[1] * t};
+                    const float dx = sp[0] - proj[0], dy = sp[1] - proj[1];
+                    const float distance = sqrtf(dx * dx + dy * dy);
+                    if (distance < min_distance) {
+                        min_distance = distance;
+                        idx[0] = (int)a; idx[1] = (int)b; idx[2] = (int)b;
+                        w[0] = 1.0f - t; w[1] = t; w[2] = 0.0f;
+                        found = true;
+                    }
+                }
+            }
+        return found;
+    }
+
+    // acc.blend_with(<pose described by recipe r>, w)
+    void emit_blend(uint32_t r, float w) {
+        const Recipe rc = A.recipes[r];
+        if (rc.anim >= 0) { emit(OP_BLEND_ANIM, (uint32_t)rc.anim, w); return; }
+        if (rc.count == 0) return;  // blending with an empty pose changes nothing
+        if (depth + 1 >= kMaxFoldDepth) { error = FYX_ERR_UNSUPPORTED; return; }
+        emit(OP_PUSH, 0, 0.f);
+        ++depth;
+        for (uint32_t i = 0; i < rc.count; ++i) {
+            const RecipeItem it = A.items[rc.first + i];
+            emit_blend(it.recipe, it.w);
+        }
+        --depth;
+        emit(OP_POP_BLEND, 0, w);
+    }
+
+    void collect(const LayerDef& L, int32_t handle) {  // node/mod.rs:116-150
+        if (handle < 0 || (size_t)handle >= L.nodes.size()) return;
+        const PoseNodeDef& n = L.nodes[handle];
+        if (n.type == NODE_PLAY) { A.seen[n.animation] = 1; return; }
+        for (const BlendInput& in : n.inputs) collect(L, in.source);
+    }
+
+    void apply_actions(const std::vector<Action>& acts) {  // state.rs:48-80
+        for (const Action& a : acts) {
+            if (a.animation >= n_anims) continue;
+            AnimState& s = as[a.animation];
+            switch (a.kind) {
+                case FYX_ACTION_REWIND_ANIMATION: set_time_position(s, s.start); break;
+                case FYX_ACTION_ENABLE_ANIMATION: s.enabled = 1; break;
+                case FYX_ACTION_DISABLE_ANIMATION: s.enabled = 0; break;
+                default: break;
+            }
+        }
+    }
+
+    // MachineLayer::evaluate_pose (layer.rs:590-706); the layer's final_pose is the accumulator
+    // the caller opened.
+    void plan_layer(uint32_t li) {
+        const LayerDef& L = A.layers[li];
+        LayerState& LS = ms->layers[li];
+        if (LS.active_state >= 0 || LS.active_transition >= 0) {
+            A.node_recipe.assign(L.nodes.size(), -1);
+            int32_t* nr = A.node_recipe.data();
+            for (const StateDef& s : L.states) eval_node(L, LS, s.root, nr);  // state.update
+
+            if (LS.active_transition < 0) {
+                for (size_t t = 0; t < L.transitions.size(); ++t) {
+                    const TransitionDef& tr = L.transitions[t];
+                    if ((int32_t)tr.dest == LS.active_state || (int32_t)tr.source != LS.active_state) continue;
+                    size_t pc = 0;
+                    if (logic(tr.logic, pc)) {
+                        if (LS.active_state >= 0 && (size_t)LS.active_state < L.states.size())
+                            apply_actions(L.states[LS.active_state].on_leave);
+                        if (tr.dest < L.states.size()) apply_actions(L.states[tr.dest].on_enter);
+                        LS.active_state = -1;
+                        LS.active_transition = (int32_t)t;
+                        break;
+                    }
+                }
+            }
+
+            auto root_recipe = [&](uint32_t state) -> int32_t {
+                if (state >= L.states.size()) return -1;
+                const int32_t r = L.states[state].root;
+                return (r >= 0 && (size_t)r < L.nodes.size()) ? nr[r] : -1;
+            };
+
+            if (LS.active_transition >= 0) {
+                const TransitionDef& tr = L.transitions[LS.active_transition];
+                TransitionState& ts = LS.transitions[LS.active_transition];
+                const int32_t src = root_recipe(tr.source), dst = root_recipe(tr.dest);
+                if (src >= 0) emit_blend((uint32_t)src, 1.0f - ts.blend_factor);
+                if (dst >= 0) emit_blend((uint32_t)dst, ts.blend_factor);
+                ts.elapsed += dt;  // transition.rs:315-321
+                if (ts.elapsed > tr.time) ts.elapsed = tr.time;
+                ts.blend_factor = ts.elapsed / tr.time;
+                if (fabsf(tr.time - ts.elapsed) <= FLT_EPSILON) {  // is_done
+                    ts.elapsed = 0.0f;
+                    ts.blend_factor = 0.0f;
+                    LS.active_transition = -1;
+                    LS.active_state = (int32_t)tr.dest;
+                }
+            } else {
+                const int32_t r = root_recipe((uint32_t)LS.active_state);
+                if (r >= 0) emit_blend((uint32_t)r, 1.0f);  // clone_into the (reset) final pose
+            }
+        }
+        if (!L.excluded.empty()) emit(OP_MASK, li, 0.f);
+    }
+
+    // Machine::evaluate_pose (machine/mod.rs:344-382) + apply
+    void plan_absm() {
+        std::fill(A.seen.begin(), A.seen.end(), 0);
+        for (size_t li = 0; li < A.layers.size(); ++li) {
+            const LayerDef& L = A.layers[li];
+            const LayerState& LS = ms->layers[li];
+            int32_t check[3] = {LS.active_state, -1, -1};
+            if (LS.active_transition >= 0 && (size_t)LS.active_transition < L.transitions.size()) {
+                check[1] = (int32_t)L.transitions[LS.active_transition].source;
+                check[2] = (int32_t)L.transitions[LS.active_transition].dest;
+            }
+            for (int k = 0; k < 3; ++k)
+                if (check[k] >= 0 && (size_t)check[k] < L.states.size()) collect(L, L.states[check[k]].root);
+        }
+        for (uint32_t a = 0; a < n_anims; ++a)
+            if (A.seen[a] && as[a].enabled) tick(a);
+        A.recipes.clear();
+        A.items.clear();
+        for (size_t li = 0; li < A.layers.size(); ++li) {
+            emit(OP_PUSH, 0, 0.f);
+            depth = 1;
+            plan_layer((uint32_t)li);
+            depth = 0;
+            emit(OP_POP_BLEND, 0, A.layers[li].weight);
+        }
+        emit(OP_APPLY, 0, 0.f);
+        emit(OP_END, 0, 0.f);
+    }
+
+    // AnimationContainerExt::update_animations (scene/animation/mod.rs:83-88)
+    void plan_player() {
+        for (uint32_t a = 0; a < n_anims; ++a)
+            if (as[a].enabled) {
+                tick(a);
+                emit(OP_APPLY_ANIM, a, 0.f);
+            }
+        emit(OP_END, 0, 0.f);
+    }
+};
+
+// The machine structure may still grow after some instance state exists (adding a parameter or
+// a transition): keep every instance's state vectors in step.
+void sync_machine_state(Animator& A) {
+    for (MachineState& m : A.mstate) {
+        while (m.params.size() < A.param_defaults.size()) m.params.push_back(A.param_defaults[m.params.size()]);
+        m.layers.resize(A.layers.size());
+        for (size_t l = 0; l < A.layers.size(); ++l) {
+            LayerState& LS = m.layers[l];
+            if (LS.active_state < 0 && LS.active_transition < 0) LS.active_state = A.layers[l].entry_state;
+            LS.transitions.resize(A.layers[l].transitions.size());
+            LS.by_index.resize(A.layers[l].by_index_count);
+        }
+    }
+}
+
+void ensure_machine_state(Animator& A) {
+    if (A.mstate.size() == A.n_instances) return;
+    A.mstate.assign(A.n_instances, MachineState());
+    sync_machine_state(A);
+}
+
+int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
+    const uint32_t na = (uint32_t)A.anims.size();
+    A.times.assign((size_t)A.n_instances * na, 0.f);
+    A.ticked.assign((size_t)A.n_instances * na, 0);
+    A.ops.clear();
+    A.prog_off.assign((size_t)A.n_instances + 1, 0);
+    A.seen.assign(na ? na : 1, 0);
+    if (mode == 1) ensure_machine_state(A);  // instances get their machine state lazily
+    for (uint32_t i = 0; i < A.n_instances; ++i) {
+        A.prog_off[i] = (uint32_t)A.ops.size();
+        Planner p(A, i, dt);
+        if (mode == 1) p.plan_absm(); else p.plan_player();
+        if (p.error) return fail(c, p.error, "pose nodes nest deeper than %d blend levels", kMaxFoldDepth - 2);
+    }
+    A.prog_off[A.n_instances] = (uint32_t)A.ops.size();
+    return FYX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Device side of an animator
+// ------------------------------------------------------------------------------------------
+int ensure_device_state(fyx_ctx* c, Animator& A) {
+    const Rig& rig = *A.rig;
+    const size_t in = (size_t)A.n_instances * rig.n_nodes;
+    if (!A.d_node_trs) {
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_node_trs), std::max<size_t>(in * 48, 16)));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_local), std::max<size_t>(in * 64, 16)));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_global), std::max<size_t>(in * 64, 16)));
+        for (uint32_t i = 0; i < A.n_instances; ++i)  // every instance starts from the rig's transforms
+            FYX_HIP(c, hipMemcpyAsync(reinterpret_cast<char*>(A.d_node_trs) + (size_t)i * rig.n_nodes * 48,
+                                      rig.init_trs.data(), (size_t)rig.n_nodes * 48, hipMemcpyHostToDevice,
+                                      c->stream));
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    const uint32_t na = (uint32_t)A.anims.size();
+    if (na > A.dev_anim_capacity || A.max_tracks > A.dev_track_capacity) {
+        // grow pose records / hints; existing contents are preserved
+        const uint32_t new_cap = std::max(na, A.dev_anim_capacity);
+        const uint32_t new_tracks = std::max(A.max_tracks, A.dev_track_capacity);
+        float4* np = nullptr;
+        uint32_t* nh = nullptr;
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&np), std::max<size_t>((size_t)new_cap * in * 48, 16)));
+        FYX_HIP(c, hipMemset(np, 0, std::max<size_t>((size_t)new_cap * in * 48, 16)));
+        const size_t hb = std::max<size_t>((size_t)new_cap * A.n_instances * std::max(new_tracks, 1u) * 16, 16);
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&nh), hb));
+        FYX_HIP(c, hipMemset(nh, 0, hb));
+        if (A.d_anim_pose && A.dev_anim_capacity)
+            FYX_HIP(c, hipMemcpy(np, A.d_anim_pose, (size_t)A.dev_anim_capacity * in * 48, hipMemcpyDeviceToDevice));
+        if (A.d_hints && A.dev_anim_capacity && A.dev_track_capacity) {
+            if (new_tracks == A.dev_track_capacity) {
+                FYX_HIP(c, hipMemcpy(nh, A.d_hints, (size_t)A.dev_anim_capacity * A.n_instances * new_tracks * 16,
+                                     hipMemcpyDeviceToDevice));
+            } else {
+                FYX_HIP(c, hipMemcpy2D(nh, (size_t)new_tracks * 16, A.d_hints, (size_t)A.dev_track_capacity * 16,
+                                       (size_t)A.dev_track_capacity * 16,
+                                       (size_t)A.dev_anim_capacity * A.n_instances, hipMemcpyDeviceToDevice));
+            }
+        }
+        dfree(A.d_anim_pose);
+        dfree(A.d_hints);
+        A.d_anim_pose = np;
+        A.d_hints = nh;
+        A.dev_anim_capacity = new_cap;
+        A.dev_track_capacity = new_tracks;
+        A.anims_dirty = true;
+    }
+    // slot tables + animation descriptors
+    bool any_slots = false;
+    for (AnimationDef& an : A.anims) any_slots |= an.slots_dirty;
+    if (any_slots || A.anims_dirty) {
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<AnimDev> hd(na);
+        for (uint32_t a = 0; a < na; ++a) {
+            AnimationDef& an = A.anims[a];
+            if (an.slots_dirty) {
+                std::vector<int32_t> slots((size_t)rig.n_nodes * 3, -1);
+                for (uint32_t t = 0; t < an.td->n_tracks; ++t) {
+                    if (an.target[t] < 0 || !an.enabled[t]) continue;
+                    const int b = an.td->tracks[t].binding;
+                    int32_t& s = slots[(size_t)an.target[t] * 3 + b];
+                    if (s < 0) s = (int32_t)t;
+                }
+                if (!an.d_slot_track)
+                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_slot_track), std::max<size_t>(slots.size() * 4, 16)));
+                FYX_HIP(c, hipMemcpy(an.d_slot_track, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+                an.slots_dirty = false;
+            }
+            hd[a].tracks = an.td->d_tracks;
+            hd[a].key_loc = an.td->d_loc;
+            hd[a].key_aux = an.td->d_aux;
+            hd[a].slot_track = an.d_slot_track;
+            hd[a].n_tracks = an.td->n_tracks;
+            hd[a].pad = 0;
+        }
+        dfree(A.d_anims);
+        A.d_anims = nullptr;
+        if (int rc = upload(c, &A.d_anims, hd.data(), hd.size())) return rc;
+        A.anims_dirty = false;
+    }
+    if (A.masks_dirty || A.dev_mask_layers != A.layers.size()) {
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<uint8_t> m(std::max<size_t>(A.layers.size() * rig.n_nodes, 1), 0);
+        for (size_t l = 0; l < A.layers.size(); ++l)
+            for (int32_t n : A.layers[l].excluded)
+                if (n >= 0 && (uint32_t)n < rig.n_nodes) m[l * rig.n_nodes + n] = 1;
+        dfree(A.d_layer_masks);
+        A.d_layer_masks = nullptr;
+        if (int rc = upload(c, &A.d_layer_masks, m.data(), m.size())) return rc;
+        A.masks_dirty = false;
+        A.dev_mask_layers = (uint32_t)A.layers.size();
+    }
+    return FYX_OK;
+}
+
+RigDev rig_dev(const Rig& r) {
+    RigDev d;
+    d.parent = r.d_parent;
+    d.statics = r.d_statics;
+    d.level_nodes = r.d_level_nodes;
+    d.level_start = r.d_level_start;
+    d.n_nodes = r.n_nodes;
+    d.n_levels = r.n_levels;
+    return d;
+}
+
+// Send the planned frame to the GPU and run sample + update.
+int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, A)) return rc;
+    PoseFrameDev f;
+    memset(&f, 0, sizeof f);
+    f.anims = A.d_anims;
+    f.n_anims = (uint32_t)A.anims.size();
+    f.n_instances = A.n_instances;
+    f.n_nodes = A.rig->n_nodes;
+    f.layer_masks = A.d_layer_masks;
+    f.hints = A.d_hints;
+    f.max_tracks = A.dev_track_capacity;
+    f.anim_pose = A.d_anim_pose;
+    f.node_trs = A.d_node_trs;
+    f.local = A.d_local;
+    f.global = A.d_global;
+    if (with_program) {
+        const size_t b_times = align_up(A.times.size() * 4, 256), b_tick = align_up(A.ticked.size(), 256);
+        const size_t b_off = align_up(A.prog_off.size() * 4, 256), b_ops = align_up(A.ops.size() * 8, 256);
+        const size_t total = b_times + b_tick + b_off + b_ops;
+        const int slot = A.h_ctrl_next;
+        A.h_ctrl_next ^= 1;
+        if (A.h_ctrl_busy[slot]) {
+            FYX_HIP(c, hipEventSynchronize(A.h_ctrl_ev[slot]));
+            A.h_ctrl_busy[slot] = false;
+        }
+        if (total > A.h_ctrl_bytes[slot]) {
+            if (A.h_ctrl[slot]) FYX_HIP(c, hipHostFree(A.h_ctrl[slot]));
+            A.h_ctrl[slot] = nullptr;
+            const size_t want = align_up(total + total / 2, 4096);
+            FYX_HIP(c, hipHostMalloc(&A.h_ctrl[slot], want, hipHostMallocDefault));
+            A.h_ctrl_bytes[slot] = want;
+        }
+        if (!A.h_ctrl_ev[slot]) FYX_HIP(c, hipEventCreateWithFlags(&A.h_ctrl_ev[slot], hipEventDisableTiming));
+        if (total > A.d_ctrl_bytes) {
+            FYX_HIP(c, hipStreamSynchronize(c->stream));
+            dfree(A.d_ctrl);
+            A.d_ctrl = nullptr;
+            const size_t want = align_up(total + total / 2, 4096);
+            FYX_HIP(c, hipMalloc(&A.d_ctrl, want));
+            A.d_ctrl_bytes = want;
+        }
+        char* h = static_cast<char*>(A.h_ctrl[slot]);
+        memcpy(h, A.times.data(), A.times.size() * 4);
+        memcpy(h + b_times, A.ticked.data(), A.ticked.size());
+        memcpy(h + b_times + b_tick, A.prog_off.data(), A.prog_off.size() * 4);
+        memcpy(h + b_times + b_tick + b_off, A.ops.data(), A.ops.size() * 8);
+        FYX_HIP(c, hipMemcpyAsync(A.d_ctrl, h, total, hipMemcpyHostToDevice, c->stream));
+        FYX_HIP(c, hipEventRecord(A.h_ctrl_ev[slot], c->stream));
+        A.h_ctrl_busy[slot] = true;
+        char* d = static_cast<char*>(A.d_ctrl);
+        f.times = reinterpret_cast<const float*>(d);
+        f.ticked = reinterpret_cast<const uint8_t*>(d + b_times);
+        f.prog_off = reinterpret_cast<const uint32_t*>(d + b_times + b_tick);
+        f.ops = reinterpret_cast<const uint2*>(d + b_times + b_tick + b_off);
+        FYX_HIP(c, launch_pose_sample(f, c->stream));
+    }
+    FYX_HIP(c, launch_pose_update(f, rig_dev(*A.rig), with_program, c->stream));
+    return FYX_OK;
+}
+
+template <typename F>
+int for_instances(fyx_ctx* c, Animator* A, uint32_t animation, uint32_t instance, F fn) {
+    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    const uint32_t na = (uint32_t)A->anims.size();
+    if (instance == FYX_ALL_INSTANCES) {
+        for (uint32_t i = 0; i < A->n_instances; ++i) fn(A->anim_state[(size_t)i * na + animation]);
+        return FYX_OK;
+    }
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    fn(A->anim_state[(size_t)instance * na + animation]);
+    return FYX_OK;
+}
+
+LayerDef* find_layer(Animator* A, uint32_t layer) { return layer < A->layers.size() ? &A->layers[layer] : nullptr; }
+
+#define FYX_LAYER(c, A, L, layer)                                                                \
+    LayerDef* L = find_layer((A), (layer));                                                      \
+    if (!L) return fail((c), FYX_ERR_INVALID_ARG, "layer %u does not exist", (layer))
+
+// Longest chain of nested blends below a node; -1 on a cycle (the reference would recurse forever).
+int node_depth(const LayerDef& L, int32_t h, std::vector<int>& state) {
+    if (h < 0 || (size_t)h >= L.nodes.size()) return 0;
+    if (state[h] == -2) return -1;
+    if (state[h] >= 0) return state[h];
+    state[h] = -2;
+    int d = 0;
+    const PoseNodeDef& n = L.nodes[h];
+    if (n.type != NODE_PLAY) {
+        for (const BlendInput& in : n.inputs) {
+            const int cd = node_depth(L, in.source, state);
+            if (cd < 0) return -1;
+            d = std::max(d, cd);
+        }
+        d += 1;
+    }
+    state[h] = d;
+    return d;
+}
+
+}  // namespace
+
+void anim_store_destroy(AnimStore* s) {
+    if (!s) return;
+    for (auto& kv : s->animators) free_animator(*kv.second);
+    for (auto& kv : s->bones) free_bones(kv.second);
+    for (auto& kv : s->rigs) free_rig(kv.second);
+    for (auto& kv : s->tracks) free_tracks(kv.second);
+    delete s;
+}
+
+}  // namespace fyx
+
+using namespace fyx;
+
+extern "C" {
+
+int fyx_init_control_only(fyx_ctx** out_ctx) {
+    if (!out_ctx) return FYX_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    FYX_GUARD_BEGIN
+    fyx_ctx* c = new fyx_ctx();
+    c->device = -1;
+    *out_ctx = c;
+    return FYX_OK;
+    FYX_GUARD_END(nullptr)
+}
+
+// ---- tracks data ---------------------------------------------------------------------------
+
+int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, const fyx_track_desc* tracks,
+                           uint32_t n_keys, const float* key_location, const float* key_value,
+                           const uint8_t* key_kind, const float* key_left_tangent,
+                           const float* key_right_tangent) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (n_tracks && !tracks) return fail(c, FYX_ERR_INVALID_ARG, "tracks is null");
+    if (n_keys && (!key_location || !key_value || !key_kind))
+        return fail(c, FYX_ERR_INVALID_ARG, "key arrays are null");
+    uint64_t total = 0;
+    for (uint32_t t = 0; t < n_tracks; ++t) {
+        const fyx_track_desc& d = tracks[t];
+        if (d.binding != FYX_BIND_POSITION && d.binding != FYX_BIND_SCALE && d.binding != FYX_BIND_ROTATION)
+            return fail(c, FYX_ERR_UNSUPPORTED,
+                        "track %u: only Position/Scale/Rotation bindings run on the GPU (Property bindings use reflection)", t);
+        const bool vec3 = d.kind == FYX_KIND_VEC3;
+        const bool quat = d.kind == FYX_KIND_QUAT || d.kind == FYX_KIND_QUAT_EULER;
+        if ((d.binding == FYX_BIND_ROTATION && !quat) || (d.binding != FYX_BIND_ROTATION && !vec3))
+            return fail(c, FYX_ERR_UNSUPPORTED,
+                        "track %u: value kind %d cannot be applied to binding %d (the reference logs an error and skips it)",
+                        t, d.kind, d.binding);
+        if (d.n_curves > 4) return fail(c, FYX_ERR_INVALID_ARG, "track %u has %u curves", t, d.n_curves);
+        for (uint32_t k = 0; k < d.n_curves; ++k) total += d.curve_n_keys[k];
+    }
+    if (total != n_keys)
+        return fail(c, FYX_ERR_INVALID_ARG, "tracks describe %llu keys but n_keys = %u", (unsigned long long)total, n_keys);
+    for (uint32_t k = 0; k < n_keys; ++k)
+        if (key_kind[k] > FYX_KEY_CUBIC) return fail(c, FYX_ERR_INVALID_ARG, "key %u has kind %u", k, key_kind[k]);
+    TracksData td;
+    td.n_tracks = n_tracks;
+    td.tracks.assign(tracks, tracks + n_tracks);
+    if (has_device(c)) {
+        if (int rc = enter_primary(c)) return rc;
+        std::vector<TrackDev> hd(n_tracks);
+        uint32_t key = 0;
+        for (uint32_t t = 0; t < n_tracks; ++t) {
+            hd[t].kind = tracks[t].kind;
+            hd[t].n_curves = tracks[t].n_curves;
+            for (uint32_t k = 0; k < 4; ++k) {
+                hd[t].first_key[k] = key;
+                hd[t].n_keys[k] = k < tracks[t].n_curves ? tracks[t].curve_n_keys[k] : 0;
+                key += hd[t].n_keys[k];
+            }
+        }
+        std::vector<float4> aux(n_keys);
+        for (uint32_t k = 0; k < n_keys; ++k) {
+            const uint32_t kind = key_kind[k];
+            float kb;
+            memcpy(&kb, &kind, 4);
+            const bool cubic = kind == FYX_KEY_CUBIC;
+            aux[k] = make_float4(key_value[k], kb, cubic && key_left_tangent ? key_left_tangent[k] : 0.f,
+                                 cubic && key_right_tangent ? key_right_tangent[k] : 0.f);
+        }
+        int rc = upload(c, &td.d_tracks, hd.data(), hd.size());
+        if (!rc) rc = upload(c, &td.d_loc, key_location, (size_t)n_keys);
+        if (!rc) rc = upload(c, &td.d_aux, aux.data(), aux.size());
+        if (rc) { free_tracks(td); return rc; }
+    }
+    auto& m = store(c).tracks;
+    auto it = m.find(tracks_id);
+    if (it != m.end()) {
+        for (auto& kv : store(c).animators)
+            for (auto& an : kv.second->anims)
+                if (an.td == &it->second) {
+                    free_tracks(td);
+                    return fail(c, FYX_ERR_INVALID_ARG, "tracks data %llu is in use by an animator", (unsigned long long)tracks_id);
+                }
+        if (has_device(c)) (void)hipStreamSynchronize(c->stream);
+        free_tracks(it->second);
+        m.erase(it);
+    }
+    m.emplace(tracks_id, std::move(td));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_tracks_data_free(fyx_ctx* c, uint64_t tracks_id) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    auto& m = store(c).tracks;
+    auto it = m.find(tracks_id);
+    if (it == m.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "tracks data %llu is not registered", (unsigned long long)tracks_id);
+    for (auto& kv : store(c).animators)
+        for (auto& an : kv.second->anims)
+            if (an.td == &it->second)
+                return fail(c, FYX_ERR_INVALID_ARG, "tracks data %llu is in use by an animator", (unsigned long long)tracks_id);
+    if (has_device(c)) { if (int rc = enter_primary(c)) return rc; FYX_HIP(c, hipStreamSynchronize(c->stream)); }
+    free_tracks(it->second);
+    m.erase(it);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+// ---- rigs / bone lists ---------------------------------------------------------------------
+
+int fyx_rig_create(fyx_ctx* c, uint64_t rig_id, uint32_t n_nodes, const int32_t* parent,
+                   const fyx_transform* transforms, const float* inv_bind) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (n_nodes == 0 || n_nodes > (uint32_t)kMaxRigNodes)
+        return fail(c, n_nodes ? FYX_ERR_UNSUPPORTED : FYX_ERR_INVALID_ARG, "n_nodes=%u outside 1..%d", n_nodes, kMaxRigNodes);
+    if (!parent || !transforms) return fail(c, FYX_ERR_INVALID_ARG, "parent / transforms are null");
+    if (store(c).rigs.count(rig_id)) return fail(c, FYX_ERR_INVALID_ARG, "rig %llu already exists", (unsigned long long)rig_id);
+    Rig r;
+    r.n_nodes = n_nodes;
+    r.parent.assign(parent, parent + n_nodes);
+    std::vector<uint32_t> depth(n_nodes, 0);
+    uint32_t max_depth = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        if (parent[i] >= (int32_t)i) return fail(c, FYX_ERR_INVALID_ARG, "parent[%u] = %d is not an earlier node", i, parent[i]);
+        depth[i] = parent[i] < 0 ? 0 : depth[parent[i]] + 1;
+        max_depth = std::max(max_depth, depth[i]);
+    }
+    r.n_levels = max_depth + 1;
+    std::vector<uint32_t> level_start(r.n_levels + 1, 0), level_nodes(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; ++i) ++level_start[depth[i] + 1];
+    for (uint32_t l = 0; l < r.n_levels; ++l) level_start[l + 1] += level_start[l];
+    {
+        std::vector<uint32_t> cur(level_start.begin(), level_start.end() - 1);
+        for (uint32_t i = 0; i < n_nodes; ++i) level_nodes[cur[depth[i]]++] = i;
+    }
+    r.init_trs.assign((size_t)n_nodes * 12, 0.f);
+    std::vector<float> statics((size_t)n_nodes * 28, 0.f);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const fyx_transform& t = transforms[i];
+        float* d = &r.init_trs[(size_t)i * 12];
+        memcpy(d, t.local_position, 12);
+        memcpy(d + 4, t.local_rotation, 16);
+        memcpy(d + 8, t.local_scale, 12);
+        float* s = &statics[(size_t)i * 28];
+        memcpy(s, t.pre_rotation, 16);
+        memcpy(s + 4, t.post_rotation_matrix, 36);
+        memcpy(s + 13, t.rotation_offset, 12);
+        memcpy(s + 16, t.rotation_pivot, 12);
+        memcpy(s + 19, t.scaling_offset, 12);
+        memcpy(s + 22, t.scaling_pivot, 12);
+    }
+    if (has_device(c)) {
+        if (int rc = enter_primary(c)) return rc;
+        std::vector<float> ib((size_t)n_nodes * 16, 0.f);
+        if (inv_bind) {
+            memcpy(ib.data(), inv_bind, ib.size() * 4);
+        } else {
+            for (uint32_t i = 0; i < n_nodes; ++i) ib[(size_t)i * 16] = ib[(size_t)i * 16 + 5] = ib[(size_t)i * 16 + 10] = ib[(size_t)i * 16 + 15] = 1.f;
+        }
+        int rc = upload(c, &r.d_parent, r.parent.data(), r.parent.size());
+        if (!rc) rc = upload(c, &r.d_statics, statics.data(), statics.size());
+        if (!rc) rc = upload(c, &r.d_level_nodes, level_nodes.data(), level_nodes.size());
+        if (!rc) rc = upload(c, &r.d_level_start, level_start.data(), level_start.size());
+        if (!rc) rc = upload(c, &r.d_inv_bind, ib.data(), ib.size());
+        if (rc) { free_rig(r); return rc; }
+    }
+    store(c).rigs.emplace(rig_id, std::move(r));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_rig_free(fyx_ctx* c, uint64_t rig_id) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    auto& m = store(c).rigs;
+    auto it = m.find(rig_id);
+    if (it == m.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "rig %llu is not registered", (unsigned long long)rig_id);
+    for (auto& kv : store(c).animators)
+        if (kv.second->rig == &it->second)
+            return fail(c, FYX_ERR_INVALID_ARG, "rig %llu is in use by an animator", (unsigned long long)rig_id);
+    if (has_device(c)) { if (int rc = enter_primary(c)) return rc; FYX_HIP(c, hipStreamSynchronize(c->stream)); }
+    free_rig(it->second);
+    m.erase(it);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_bone_list_create(fyx_ctx* c, uint64_t bones_id, uint64_t rig_id, uint32_t n_bones, const int32_t* bone_nodes) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    auto rit = store(c).rigs.find(rig_id);
+    if (rit == store(c).rigs.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "rig %llu is not registered", (unsigned long long)rig_id);
+    if (n_bones == 0 || n_bones > 256 || !bone_nodes)
+        return fail(c, FYX_ERR_INVALID_ARG, "n_bones=%u outside 1..256 (bone indices are u8)", n_bones);
+    for (uint32_t b = 0; b < n_bones; ++b)
+        if (bone_nodes[b] >= (int32_t)rit->second.n_nodes)
+            return fail(c, FYX_ERR_INVALID_ARG, "bone %u refers to node %d of a %u-node rig", b, bone_nodes[b], rit->second.n_nodes);
+    if (store(c).bones.count(bones_id)) return fail(c, FYX_ERR_INVALID_ARG, "bone list %llu already exists", (unsigned long long)bones_id);
+    BoneList bl;
+    bl.rig_id = rig_id;
+    bl.n_bones = n_bones;
+    if (has_device(c)) {
+        if (int rc = enter_primary(c)) return rc;
+        if (int rc = upload(c, &bl.d_bone_nodes, bone_nodes, (size_t)n_bones)) return rc;
+    }
+    store(c).bones.emplace(bones_id, bl);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_bone_list_free(fyx_ctx* c, uint64_t bones_id) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    auto& m = store(c).bones;
+    auto it = m.find(bones_id);
+    if (it == m.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
+    if (has_device(c)) { if (int rc = enter_primary(c)) return rc; FYX_HIP(c, hipStreamSynchronize(c->stream)); }
+    free_bones(it->second);
+    m.erase(it);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+// ---- animators -----------------------------------------------------------------------------
+
+int fyx_animator_create(fyx_ctx* c, uint64_t animator_id, uint64_t rig_id, uint32_t n_instances) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    auto rit = store(c).rigs.find(rig_id);
+    if (rit == store(c).rigs.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "rig %llu is not registered", (unsigned long long)rig_id);
+    if (n_instances == 0) return fail(c, FYX_ERR_INVALID_ARG, "n_instances is 0");
+    if (store(c).animators.count(animator_id))
+        return fail(c, FYX_ERR_INVALID_ARG, "animator %llu already exists", (unsigned long long)animator_id);
+    std::unique_ptr<Animator> a(new Animator());
+    a->rig_id = rig_id;
+    a->rig = &rit->second;
+    a->n_instances = n_instances;
+    store(c).animators.emplace(animator_id, std::move(a));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_free(fyx_ctx* c, uint64_t animator_id) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    auto& m = store(c).animators;
+    auto it = m.find(animator_id);
+    if (it == m.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "animator %llu is not registered", (unsigned long long)animator_id);
+    if (has_device(c)) { if (int rc = enter_primary(c)) return rc; FYX_HIP(c, hipStreamSynchronize(c->stream)); }
+    free_animator(*it->second);
+    m.erase(it);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_add_animation(fyx_ctx* c, uint64_t animator_id, uint64_t tracks_id, const int32_t* track_target,
+                               const uint8_t* track_enabled, uint32_t* out_animation) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    auto tit = store(c).tracks.find(tracks_id);
+    if (tit == store(c).tracks.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "tracks data %llu is not registered", (unsigned long long)tracks_id);
+    const TracksData& td = tit->second;
+    if (td.n_tracks && !track_target) return fail(c, FYX_ERR_INVALID_ARG, "track_target is null");
+    AnimationDef an;
+    an.tracks_id = tracks_id;
+    an.td = &td;
+    an.target.assign(td.n_tracks, -1);
+    an.enabled.assign(td.n_tracks, 1);
+    std::vector<uint8_t> used((size_t)A->rig->n_nodes * 3, 0);
+    for (uint32_t t = 0; t < td.n_tracks; ++t) {
+        an.target[t] = track_target[t];
+        if (track_enabled) an.enabled[t] = track_enabled[t] ? 1 : 0;
+        if (track_target[t] >= (int32_t)A->rig->n_nodes)
+            return fail(c, FYX_ERR_INVALID_ARG, "track %u targets node %d of a %u-node rig", t, track_target[t], A->rig->n_nodes);
+        if (track_target[t] >= 0) {
+            uint8_t& u = used[(size_t)track_target[t] * 3 + td.tracks[t].binding];
+            if (u) return fail(c, FYX_ERR_UNSUPPORTED, "two tracks drive the same binding of node %d", track_target[t]);
+            u = 1;
+        }
+    }
+    const uint32_t na = (uint32_t)A->anims.size();
+    // re-layout [inst][anim] state for the new animation count
+    std::vector<AnimState> ns((size_t)A->n_instances * (na + 1));
+    for (uint32_t i = 0; i < A->n_instances; ++i)
+        for (uint32_t a = 0; a < na; ++a) ns[(size_t)i * (na + 1) + a] = A->anim_state[(size_t)i * na + a];
+    A->anim_state.swap(ns);
+    A->anims.push_back(std::move(an));
+    A->max_tracks = std::max(A->max_tracks, td.n_tracks);
+    A->anims_dirty = true;
+    if (out_animation) *out_animation = na;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animation_set_track_enabled(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t track, int enabled) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    AnimationDef& an = A->anims[animation];
+    if (track >= an.enabled.size()) return fail(c, FYX_ERR_INVALID_ARG, "track %u does not exist", track);
+    an.enabled[track] = enabled ? 1 : 0;
+    an.slots_dirty = true;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animation_set_time_slice(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, float start, float end) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!(start <= end)) return fail(c, FYX_ERR_INVALID_ARG, "time slice start > end (the reference asserts)");
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { s.start = start; s.end = end; set_time_position(s, s.time); });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_set_time_position(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, float time) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { set_time_position(s, time); });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_set_speed(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, float speed) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { s.speed = speed; });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_set_loop(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, int looped) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { s.looped = looped ? 1 : 0; });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_set_enabled(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, int enabled) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { s.enabled = enabled ? 1 : 0; });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_rewind(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { set_time_position(s, s.start); });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_get_state(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance,
+                            float* time_position, int* enabled, int* ended) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    return for_instances(c, A, animation, instance, [&](AnimState& s) {
+        if (time_position) *time_position = s.time;
+        if (enabled) *enabled = s.enabled;
+        if (ended) *ended = has_ended(s) ? 1 : 0;
+    });
+    FYX_GUARD_END(c)
+}
+
+// ---- machine builder -----------------------------------------------------------------------
+
+int fyx_machine_add_parameter(fyx_ctx* c, uint64_t animator_id, int kind, float f0, float f1, uint32_t u, uint32_t* out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (kind < FYX_PARAM_WEIGHT || kind > FYX_PARAM_SAMPLING_POINT) return fail(c, FYX_ERR_INVALID_ARG, "parameter kind %d", kind);
+    Param p;
+    p.kind = kind; p.f0 = f0; p.f1 = f1; p.u = u;
+    A->param_defaults.push_back(p);
+    sync_machine_state(*A);
+    if (out) *out = (uint32_t)A->param_defaults.size() - 1;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_machine_set_parameter(fyx_ctx* c, uint64_t animator_id, uint32_t parameter, uint32_t instance, int kind,
+                              float f0, float f1, uint32_t u) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (parameter >= A->param_defaults.size()) return fail(c, FYX_ERR_INVALID_ARG, "parameter %u does not exist", parameter);
+    if (kind < FYX_PARAM_WEIGHT || kind > FYX_PARAM_SAMPLING_POINT) return fail(c, FYX_ERR_INVALID_ARG, "parameter kind %d", kind);
+    Param p;
+    p.kind = kind; p.f0 = f0; p.f1 = f1; p.u = u;
+    if (instance == FYX_ALL_INSTANCES) {
+        A->param_defaults[parameter] = p;
+        for (MachineState& m : A->mstate) m.params[parameter] = p;
+        return FYX_OK;
+    }
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    ensure_machine_state(*A);
+    A->mstate[instance].params[parameter] = p;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_machine_add_layer(fyx_ctx* c, uint64_t animator_id, float weight, uint32_t* out_layer) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (A->layers.size() >= 255) return fail(c, FYX_ERR_UNSUPPORTED, "too many layers");
+    LayerDef L;
+    L.weight = weight;
+    A->layers.push_back(std::move(L));
+    sync_machine_state(*A);
+    A->masks_dirty = true;
+    if (out_layer) *out_layer = (uint32_t)A->layers.size() - 1;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_set_weight(fyx_ctx* c, uint64_t animator_id, uint32_t layer, float weight) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    L->weight = weight;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_set_mask(fyx_ctx* c, uint64_t animator_id, uint32_t layer, const int32_t* excluded, uint32_t n) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (n && !excluded) return fail(c, FYX_ERR_INVALID_ARG, "excluded_nodes is null");
+    L->excluded.assign(excluded, excluded + n);
+    A->masks_dirty = true;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+static int add_node(fyx_ctx* c, Animator* A, LayerDef* L, PoseNodeDef&& n, uint32_t* out_node) {
+    for (const BlendInput& in : n.inputs)
+        if (in.source >= (int32_t)L->nodes.size() + 1)
+            return fail(c, FYX_ERR_INVALID_ARG, "pose source %d does not exist", in.source);
+    L->nodes.push_back(std::move(n));
+    std::vector<int> st(L->nodes.size(), -3);
+    for (size_t h = 0; h < L->nodes.size(); ++h) {
+        const int d = node_depth(*L, (int32_t)h, st);
+        if (d < 0) { L->nodes.pop_back(); return fail(c, FYX_ERR_INVALID_ARG, "pose nodes form a cycle"); }
+        if (d + 1 > kMaxFoldDepth - 1) {
+            L->nodes.pop_back();
+            return fail(c, FYX_ERR_UNSUPPORTED, "pose nodes nest deeper than %d blend levels", kMaxFoldDepth - 2);
+        }
+    }
+    (void)A;
+    if (out_node) *out_node = (uint32_t)L->nodes.size() - 1;
+    return FYX_OK;
+}
+
+int fyx_layer_add_play_animation(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t animation, uint32_t* out_node) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (animation >= A->anims.size())
+        return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist (an invalid handle would leave a stale pose in the reference)", animation);
+    if (animation >= (1u << 24)) return fail(c, FYX_ERR_UNSUPPORTED, "too many animations");
+    PoseNodeDef n;
+    n.type = NODE_PLAY;
+    n.animation = animation;
+    return add_node(c, A, L, std::move(n), out_node);
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_add_blend_animations(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t n_inputs,
+                                   const int32_t* pose_sources, const int32_t* weight_parameters,
+                                   const float* weight_constants, uint32_t* out_node) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (n_inputs && !pose_sources) return fail(c, FYX_ERR_INVALID_ARG, "pose_sources is null");
+    PoseNodeDef n;
+    n.type = NODE_BLEND;
+    n.inputs.resize(n_inputs);
+    for (uint32_t i = 0; i < n_inputs; ++i) {
+        n.inputs[i].source = pose_sources[i];
+        n.inputs[i].weight_param = weight_parameters ? weight_parameters[i] : -1;
+        n.inputs[i].weight_const = weight_constants ? weight_constants[i] : 0.f;
+    }
+    return add_node(c, A, L, std::move(n), out_node);
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_add_blend_animations_by_index(fyx_ctx* c, uint64_t animator_id, uint32_t layer, int32_t index_parameter,
+                                            uint32_t n_inputs, const int32_t* pose_sources,
+                                            const float* blend_times, uint32_t* out_node) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (n_inputs && (!pose_sources || !blend_times)) return fail(c, FYX_ERR_INVALID_ARG, "inputs are null");
+    PoseNodeDef n;
+    n.type = NODE_BY_INDEX;
+    n.param = index_parameter;
+    n.inputs.resize(n_inputs);
+    for (uint32_t i = 0; i < n_inputs; ++i) {
+        n.inputs[i].source = pose_sources[i];
+        n.inputs[i].blend_time = blend_times[i];
+    }
+    n.by_index_slot = L->by_index_count;
+    int rc = add_node(c, A, L, std::move(n), out_node);
+    if (rc) return rc;
+    ++L->by_index_count;
+    sync_machine_state(*A);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_add_blend_space(fyx_ctx* c, uint64_t animator_id, uint32_t layer, int32_t sampling_parameter,
+                              uint32_t n_points, const float* points_xy, const int32_t* pose_sources,
+                              uint32_t n_triangles, const uint32_t* triangles, uint32_t* out_node) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (n_points && (!points_xy || !pose_sources)) return fail(c, FYX_ERR_INVALID_ARG, "points are null");
+    if (n_triangles && !triangles) return fail(c, FYX_ERR_INVALID_ARG, "triangles is null");
+    for (uint32_t i = 0; i < n_triangles * 3; ++i)
+        if (triangles[i] >= n_points) return fail(c, FYX_ERR_INVALID_ARG, "triangle refers to point %u of %u", triangles[i], n_points);
+    PoseNodeDef n;
+    n.type = NODE_BLEND_SPACE;
+    n.param = sampling_parameter;
+    n.inputs.resize(n_points);
+    for (uint32_t i = 0; i < n_points; ++i) n.inputs[i].source = pose_sources[i];
+    n.points.assign(points_xy, points_xy + (size_t)n_points * 2);
+    n.triangles.assign(triangles, triangles + (size_t)n_triangles * 3);
+    return add_node(c, A, L, std::move(n), out_node);
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_add_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, int32_t root_node, uint32_t* out_state) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    StateDef s;
+    s.root = root_node;
+    L->states.push_back(std::move(s));
+    if (L->entry_state < 0) {  // layer.rs:229-235
+        L->entry_state = (int32_t)L->states.size() - 1;
+        sync_machine_state(*A);
+    }
+    if (out_state) *out_state = (uint32_t)L->states.size() - 1;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_set_entry_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t state) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (state >= L->states.size()) return fail(c, FYX_ERR_INVALID_ARG, "state %u does not exist", state);
+    L->entry_state = (int32_t)state;
+    for (MachineState& m : A->mstate) m.layers[layer].active_state = (int32_t)state;  // layer.rs:209-212
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_state_add_action(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t state, int on_enter, int action, uint32_t animation) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (state >= L->states.size()) return fail(c, FYX_ERR_INVALID_ARG, "state %u does not exist", state);
+    if (action < FYX_ACTION_NONE || action > FYX_ACTION_DISABLE_ANIMATION)
+        return fail(c, FYX_ERR_UNSUPPORTED, "state action %d (EnableRandomAnimation draws from the host RNG)", action);
+    (on_enter ? L->states[state].on_enter : L->states[state].on_leave).push_back(Action{action, animation});
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_add_transition(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t source, uint32_t dest,
+                             float transition_time, const int32_t* condition, uint32_t n_condition, uint32_t* out_transition) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (n_condition && !condition) return fail(c, FYX_ERR_INVALID_ARG, "condition is null");
+    TransitionDef t;
+    t.source = source;
+    t.dest = dest;
+    t.time = transition_time;
+    t.logic.assign(condition, condition + n_condition);
+    L->transitions.push_back(std::move(t));
+    sync_machine_state(*A);
+    if (out_transition) *out_transition = (uint32_t)L->transitions.size() - 1;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_get_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance, int32_t* active_state,
+                        int32_t* active_transition) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    int32_t as = L->entry_state, at = -1;
+    if (A->mstate.size() == A->n_instances) {
+        as = A->mstate[instance].layers[layer].active_state;
+        at = A->mstate[instance].layers[layer].active_transition;
+    }
+    if (active_state) *active_state = as;
+    if (active_transition) *active_transition = at;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+// ---- per frame -----------------------------------------------------------------------------
+
+static int update_common(fyx_ctx* c, uint64_t animator_id, int mode, float dt) {
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: no GPU to run the pose kernels on");
+    if (mode == 1 && A->layers.empty()) return fail(c, FYX_ERR_INVALID_ARG, "animator %llu has no machine layers", (unsigned long long)animator_id);
+    if (int rc = plan_frame(c, *A, mode, dt)) return rc;
+    return run_frame(c, *A, true);
+}
+
+int fyx_animation_player_update(fyx_ctx* c, uint64_t animator_id, float dt) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    return update_common(c, animator_id, 0, dt);
+    FYX_GUARD_END(c)
+}
+
+int fyx_absm_update(fyx_ctx* c, uint64_t animator_id, float dt) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    return update_common(c, animator_id, 1, dt);
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_update_transforms(fyx_ctx* c, uint64_t animator_id) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    return run_frame(c, *A, false);
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_palette(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, float* d_out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    auto bit = store(c).bones.find(bones_id);
+    if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
+    if (bit->second.rig_id != A->rig_id) return fail(c, FYX_ERR_INVALID_ARG, "bone list belongs to another rig");
+    if (!d_out) return fail(c, FYX_ERR_INVALID_ARG, "d_out_palette is null");
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, *A)) return rc;
+    FYX_HIP(c, launch_palette_gather(A->d_global, A->rig->d_inv_bind, bit->second.d_bone_nodes, A->rig->n_nodes,
+                                     bit->second.n_bones, A->n_instances, d_out, c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_set_local_trs(fyx_ctx* c, uint64_t animator_id, uint32_t node, uint32_t first_instance,
+                               uint32_t n_instances, const float* trs) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (node >= A->rig->n_nodes) return fail(c, FYX_ERR_INVALID_ARG, "node %u out of range", node);
+    if ((uint64_t)first_instance + n_instances > A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance range out of bounds");
+    if (n_instances == 0) return FYX_OK;
+    if (!trs) return fail(c, FYX_ERR_INVALID_ARG, "trs is null");
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, *A)) return rc;
+    std::vector<float> recs((size_t)n_instances * 12, 0.f);
+    for (uint32_t i = 0; i < n_instances; ++i) {
+        const float* s = trs + (size_t)i * 10;
+        float* d = &recs[(size_t)i * 12];
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+        d[4] = s[3]; d[5] = s[4]; d[6] = s[5]; d[7] = s[6];
+        d[8] = s[7]; d[9] = s[8]; d[10] = s[9];
+    }
+    char* dst = reinterpret_cast<char*>(A->d_node_trs) + ((size_t)first_instance * A->rig->n_nodes + node) * 48;
+    FYX_HIP(c, hipMemcpy2DAsync(dst, (size_t)A->rig->n_nodes * 48, recs.data(), 48, 48, n_instances,
+                                hipMemcpyHostToDevice, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+static int locate(fyx_ctx* c, Animator* A, int what, void** ptr, size_t* bytes) {
+    const size_t in = (size_t)A->n_instances * A->rig->n_nodes;
+    if (int rc = ensure_device_state(c, *A)) return rc;
+    if (what == FYX_READ_LOCAL_TRS) { *ptr = A->d_node_trs; *bytes = in * 48; return FYX_OK; }
+    if (what == FYX_READ_LOCAL_MATRIX) { *ptr = A->d_local; *bytes = in * 64; return FYX_OK; }
+    if (what == FYX_READ_GLOBAL_MATRIX) { *ptr = A->d_global; *bytes = in * 64; return FYX_OK; }
+    if (what >= FYX_READ_ANIMATION_POSE && (size_t)(what - FYX_READ_ANIMATION_POSE) < A->anims.size()) {
+        *ptr = reinterpret_cast<char*>(A->d_anim_pose) + (size_t)(what - FYX_READ_ANIMATION_POSE) * in * 48;
+        *bytes = in * 48;
+        return FYX_OK;
+    }
+    return fail(c, FYX_ERR_INVALID_ARG, "unknown array selector %d", what);
+}
+
+int fyx_animator_read(fyx_ctx* c, uint64_t animator_id, int what, float* host_out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
+    if (int rc = enter_primary(c)) return rc;
+    void* p = nullptr;
+    size_t bytes = 0;
+    if (int rc = locate(c, A, what, &p, &bytes)) return rc;
+    FYX_HIP(c, hipMemcpyAsync(host_out, p, bytes, hipMemcpyDeviceToHost, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_device_ptr(fyx_ctx* c, uint64_t animator_id, int what, void** out) {
+    if (!c || !out) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (int rc = enter_primary(c)) return rc;
+    size_t bytes = 0;
+    return locate(c, A, what, out, &bytes);
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_plan(fyx_ctx* c, uint64_t animator_id, int mode, float dt, float* times, uint8_t* ticked,
+                      uint32_t* program_offset, uint32_t* ops, uint32_t ops_capacity, uint32_t* n_ops) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (mode != 0 && mode != 1) return fail(c, FYX_ERR_INVALID_ARG, "mode %d", mode);
+    if (mode == 1 && A->layers.empty()) return fail(c, FYX_ERR_INVALID_ARG, "animator has no machine layers");
+    if (int rc = plan_frame(c, *A, mode, dt)) return rc;
+    if (times) memcpy(times, A->times.data(), A->times.size() * 4);
+    if (ticked) memcpy(ticked, A->ticked.data(), A->ticked.size());
+    if (program_offset) memcpy(program_offset, A->prog_off.data(), A->prog_off.size() * 4);
+    if (n_ops) *n_ops = (uint32_t)A->ops.size();
+    if (ops) memcpy(ops, A->ops.data(), std::min<size_t>(A->ops.size(), ops_capacity) * 8);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+}  // extern "C"

@@ -1,0 +1,518 @@
+// anim_kernels.hip -- gfx950 kernels of the pose path that feeds the skinning kernel:
+//   pose_sample  : keyframe sampling of every ticked animation of every instance
+//                  (Curve::value_at fyrox-math/src/curve.rs:254-314, TrackDataContainer::fetch
+//                  fyrox-animation/src/container.rs:287-297, Animation::update_pose lib.rs:895-914)
+//   pose_update  : per instance, per node: run the instance's fold program (AnimationPose::
+//                  blend_with semantics, pose.rs:41-101 / value.rs:221-230,438-459; the program is
+//                  the Machine/Layer/PoseNode evaluation order flattened by the host control
+//                  plane), apply the result to the node's local TRS (scene/animation/mod.rs:147-186),
+//                  build the local matrix (scene/transform.rs:421-540) and propagate
+//                  global = parent.global * local (scene/graph/mod.rs:1199-1241)
+//   palette_gather: palette[b] = global[bone_b] * inv_bind[bone_b] (scene/mesh/mod.rs:781-793)
+//
+// Mapping to the hardware.  A pose is tiny next to the vertices it drives (10 floats per bone),
+// so this is latency-/launch-bound work, not bandwidth-bound: the design goal is ONE block per
+// instance that never leaves the chip between "sampled poses" and "global matrices":
+//   * thread = node; the fold program of an instance is block-uniform, so the interpreter has no
+//     divergence and its operands are scalar loads; nested blend accumulators live in VGPRs
+//     (the nesting is unrolled at compile time, kMaxFoldDepth levels -- no scratch, no LDS);
+//   * local and global matrices of the instance stay in LDS across the level-synchronous
+//     hierarchy walk (64 B x 2 per node; 1024 nodes = 128 KiB of the CU's 160 KiB);
+//   * records are float4-packed and node-contiguous, so a wave's loads are dense.
+// Arithmetic: f32, reference operation order, no FMA contraction (-ffp-contract=off), IEEE
+// divide and sqrt -- bit-identical to the CPU path except sin/cos of Euler tracks (computed in
+// f64 and rounded; libm's sinf is not reproducible bit-for-bit on a GPU).
+#include "fyx_internal.h"
+
+#include "../../include/fyrox_hip.h"
+
+namespace fyx {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// fyrox-math leaves
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float lerpf_(float a, float b, float t) { return a + (b - a) * t; }
+
+__device__ __forceinline__ float cubicf_(float p0, float p1, float t, float m0, float m1) {
+    const float t2 = t * t;
+    const float t3 = t2 * t;
+    const float scale = fabsf(p1 - p0);
+    return (2.0f * t3 - 3.0f * t2 + 1.0f) * p0 + (t3 - 2.0f * t2 + t) * m0 * scale +
+           (-2.0f * t3 + 3.0f * t2) * p1 + (t3 - t2) * m1 * scale;
+}
+
+// CurveKey::interpolate (curve.rs:87-132): dispatch on the LEFT key's kind.
+__device__ __forceinline__ float interpolate_keys(const float* __restrict__ loc,
+                                                  const f4* __restrict__ aux, uint32_t l, uint32_t r,
+                                                  float location) {
+    const float ll = loc[l], rl = loc[r];
+    const f4 la = aux[l], ra = aux[r];
+    const float t = (location - ll) / (rl - ll);
+    const uint32_t lk = __float_as_uint(la.y), rk = __float_as_uint(ra.y);
+    if (lk == FYX_KEY_CONSTANT) return t == 1.0f ? ra.x : la.x;
+    if (lk == FYX_KEY_LINEAR) return lerpf_(la.x, ra.x, t);
+    return cubicf_(la.x, ra.x, t, la.w, rk == FYX_KEY_CUBIC ? ra.z : 0.0f);
+}
+
+// Curve::value_at with the caller's span hint (curve.rs:254-314).
+__device__ float curve_value_at(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
+                                float location, uint32_t& hint) {
+    if (n == 0) return 0.0f;
+    if (location <= loc[0]) { hint = 0; return aux[0].x; }
+    if (location >= loc[n - 1]) { hint = n - 1; return aux[n - 1].x; }
+    const uint32_t h = hint, hl = h > 0 ? h - 1 : 0;
+    if (h < n) {
+        if (location >= loc[hl] && location < loc[h]) return interpolate_keys(loc, aux, hl, h, location);
+    }
+    uint32_t lo = 0, hi = n;  // partition_point(|k| k.location < location)
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (loc[mid] < location) lo = mid + 1; else hi = mid;
+    }
+    hint = lo;
+    return interpolate_keys(loc, aux, lo > 0 ? lo - 1 : 0, lo, location);
+}
+
+// nalgebra leaves (operation order restated in oracle/fyrox_oracle.c)
+__device__ __forceinline__ float dot4(f4 a, f4 b) {
+    float x = a.x * b.x, y = a.y * b.y;
+    const float z = a.z * b.z, w = a.w * b.w;
+    x += z;
+    y += w;
+    return x + y;
+}
+__device__ __forceinline__ f4 quat_normalize(f4 q) {
+    const float n = sqrtf(dot4(q, q));
+    return f4{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+__device__ __forceinline__ f4 quat_mul(f4 a, f4 b) {  // Hamilton product, storage (i,j,k,w)
+    const float w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    const float i = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    const float j = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    const float k = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return f4{i, j, k, w};
+}
+// UnitQuaternion::from_axis_angle(unit axis, angle) = (axis * sin(angle/2), cos(angle/2))
+__device__ __forceinline__ f4 quat_axis_angle(int axis, float angle) {
+    const float half = angle / 2.0f;
+    double sd, cd;
+    sincos((double)half, &sd, &cd);
+    const float s = (float)sd, c = (float)cd;
+    const float e0 = axis == 0 ? 1.0f : 0.0f, e1 = axis == 1 ? 1.0f : 0.0f, e2 = axis == 2 ? 1.0f : 0.0f;
+    return f4{e0 * s, e1 * s, e2 * s, c};
+}
+
+// ---------------------------------------------------------------------------------------
+// pose_sample: one thread per (animation, instance, node); it samples the (up to three) tracks
+// of that animation bound to Position / Scale / Rotation of the node and writes the node's
+// pose record {pos, present-mask}{rot}{scale}.  Present bits: 1 Position, 2 Scale, 4 Rotation.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sample_track(const AnimDev& an, int32_t track, float time,
+                                             uint32_t* __restrict__ hints, int want_kind_quat, f4& out) {
+    if (track < 0) return false;
+    const TrackDev tk = an.tracks[track];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int need;
+    switch (tk.kind) {
+        case FYX_KIND_VEC3: need = 3; break;
+        case FYX_KIND_QUAT_EULER: need = 3; break;
+        case FYX_KIND_QUAT: need = 4; break;
+        default: return false;  // rejected at upload; never reached
+    }
+    if ((tk.kind == FYX_KIND_VEC3) == (want_kind_quat != 0)) return false;
+    if ((int)tk.n_curves < need) return false;  // fetch() -> None
+    uint32_t* h = hints + (size_t)track * 4;
+    for (int c = 0; c < need; ++c) {
+        uint32_t hint = h[c];
+        v[c] = curve_value_at(an.key_loc + tk.first_key[c], reinterpret_cast<const f4*>(an.key_aux) + tk.first_key[c], tk.n_keys[c],
+                              time, hint);
+        h[c] = hint;
+    }
+    if (tk.kind == FYX_KIND_VEC3) {
+        out = f4{v[0], v[1], v[2], 0.f};
+    } else if (tk.kind == FYX_KIND_QUAT) {
+        out = quat_normalize(f4{v[0], v[1], v[2], v[3]});  // from_quaternion(Quaternion::new(w,x,y,z))
+    } else {
+        // quat_from_euler(.., XYZ) = qz * qy * qx   (fyrox-math/src/lib.rs:725-740)
+        const f4 qx = quat_axis_angle(0, v[0]), qy = quat_axis_angle(1, v[1]), qz = quat_axis_angle(2, v[2]);
+        out = quat_mul(quat_mul(qz, qy), qx);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
+    const uint32_t per_anim = f.n_instances * f.n_nodes;
+    const uint64_t total = (uint64_t)f.n_anims * per_anim;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+         id += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = (uint32_t)(id / per_anim);
+        const uint32_t rem = (uint32_t)(id - (uint64_t)a * per_anim);
+        const uint32_t inst = rem / f.n_nodes, node = rem - inst * f.n_nodes;
+        if (!f.ticked[(size_t)inst * f.n_anims + a]) continue;
+        const float time = f.times[(size_t)inst * f.n_anims + a];
+        const AnimDev an = f.anims[a];
+        const int32_t* st = an.slot_track + (size_t)node * 3;
+        uint32_t* hints = f.hints + ((size_t)a * f.n_instances + inst) * f.max_tracks * 4;
+        f4 p = f4{0.f, 0.f, 0.f, 0.f}, s = f4{0.f, 0.f, 0.f, 0.f}, r = f4{0.f, 0.f, 0.f, 1.f};
+        uint32_t mask = 0;
+        if (sample_track(an, st[0], time, hints, 0, p)) mask |= 1u;
+        if (sample_track(an, st[1], time, hints, 0, s)) mask |= 2u;
+        if (sample_track(an, st[2], time, hints, 1, r)) mask |= 4u;
+        f4* rec = reinterpret_cast<f4*>(f.anim_pose) + id * 3;
+        rec[0] = f4{p.x, p.y, p.z, __uint_as_float(mask)};
+        rec[1] = r;
+        rec[2] = s;
+    }
+}
+
+hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s) {
+    const uint64_t total = (uint64_t)f.n_anims * f.n_instances * f.n_nodes;
+    if (total == 0) return hipSuccess;
+    uint64_t grid = (total + 255) / 256;
+    if (grid > (uint64_t)kCUs * 16) grid = (uint64_t)kCUs * 16;
+    hipLaunchKernelGGL(pose_sample_kernel, dim3((uint32_t)grid), dim3(256), 0, s, f);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Fold interpreter
+// ---------------------------------------------------------------------------------------
+struct Acc {
+    float px, py, pz, sx, sy, sz;
+    f4 r;
+    uint32_t mask;
+};
+
+__device__ __forceinline__ Acc load_rec(const f4* __restrict__ rec) {
+    const f4 a = rec[0], b = rec[1], c = rec[2];
+    Acc o;
+    o.px = a.x; o.py = a.y; o.pz = a.z;
+    o.mask = __float_as_uint(a.w);
+    o.r = b;
+    o.sx = c.x; o.sy = c.y; o.sz = c.z;
+    return o;
+}
+
+// NodePose::blend_with (pose.rs:41-47): an empty self becomes a copy of other (weight ignored);
+// otherwise every value of self with a same-binding value in other is blended
+// (value.rs:438-444), values only in other are dropped.
+__device__ __forceinline__ void blend(Acc& self, const Acc& o, float w) {
+    if (self.mask == 0) { self = o; return; }
+    const uint32_t both = self.mask & o.mask;
+    const float omw = 1.0f - w;  // nalgebra lerp: self * (1 - t) + rhs * t
+    if (both & 1u) {
+        self.px = self.px * omw + o.px * w;
+        self.py = self.py * omw + o.py * w;
+        self.pz = self.pz * omw + o.pz * w;
+    }
+    if (both & 2u) {
+        self.sx = self.sx * omw + o.sx * w;
+        self.sy = self.sy * omw + o.sy * w;
+        self.sz = self.sz * omw + o.sz * w;
+    }
+    if (both & 4u) {  // value.rs:449-454 nlerp: flip self when dot < 0, then normalize(lerp)
+        f4 a = self.r;
+        if (dot4(a, o.r) < 0.0f) a = f4{-a.x, -a.y, -a.z, -a.w};
+        const f4 l = f4{a.x * omw + o.r.x * w, a.y * omw + o.r.y * w, a.z * omw + o.r.z * w,
+                        a.w * omw + o.r.w * w};
+        self.r = quat_normalize(l);
+    }
+}
+
+struct FoldCtx {
+    const uint2* __restrict__ ops;
+    const f4* __restrict__ anim_pose;     // base of [n_anims][n_instances][n_nodes][3]
+    const uint8_t* __restrict__ layer_masks;
+    size_t anim_stride;                   // records between animations = n_instances * n_nodes
+    size_t rec_index;                     // inst * n_nodes + node
+    uint32_t n_nodes, node;
+    uint32_t pc;
+    float pop_w;
+    bool done;
+    // node transform being written (BoundValueCollectionExt::apply)
+    float tpx, tpy, tpz, tsx, tsy, tsz;
+    f4 tr;
+    bool dirty;
+};
+
+__device__ __forceinline__ void apply_pose(FoldCtx& cx, const Acc& a) {
+    if (a.mask & 1u) { cx.tpx = a.px; cx.tpy = a.py; cx.tpz = a.pz; }
+    if (a.mask & 2u) { cx.tsx = a.sx; cx.tsy = a.sy; cx.tsz = a.sz; }
+    if (a.mask & 4u) cx.tr = a.r;
+    cx.dirty |= a.mask != 0;
+}
+
+template <int D>
+__device__ __forceinline__ void run_fold(FoldCtx& cx, Acc& acc) {
+    for (;;) {
+        const uint2 op = cx.ops[cx.pc++];
+        const uint32_t code = op.x & 0xffu, arg = op.x >> 8;
+        const float w = __uint_as_float(op.y);
+        switch (code) {
+            case OP_BLEND_ANIM: {
+                const Acc o = load_rec(cx.anim_pose + ((size_t)arg * cx.anim_stride + cx.rec_index) * 3);
+                blend(acc, o, w);
+                break;
+            }
+            case OP_PUSH:
+                if constexpr (D + 1 < kMaxFoldDepth) {
+                    Acc child;
+                    child.px = child.py = child.pz = child.sx = child.sy = child.sz = 0.f;
+                    child.r = f4{0.f, 0.f, 0.f, 1.f};
+                    child.mask = 0;
+                    run_fold<D + 1>(cx, child);
+                    if (cx.done) return;
+                    blend(acc, child, cx.pop_w);
+                } else {
+                    cx.done = true;  // deeper than the host ever emits (validated at build time)
+                    return;
+                }
+                break;
+            case OP_POP_BLEND:
+                cx.pop_w = w;
+                return;
+            case OP_RESET:
+                acc.mask = 0;
+                break;
+            case OP_MASK:
+                if (cx.layer_masks[(size_t)arg * cx.n_nodes + cx.node]) acc.mask = 0;
+                break;
+            case OP_APPLY:
+                apply_pose(cx, acc);
+                break;
+            case OP_APPLY_ANIM: {
+                const Acc o = load_rec(cx.anim_pose + ((size_t)arg * cx.anim_stride + cx.rec_index) * 3);
+                apply_pose(cx, o);
+                break;
+            }
+            default:  // OP_END
+                cx.done = true;
+                return;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// local matrix (Transform::calculate_local_transform, scene/transform.rs:421-540) and mat4 product
+// ---------------------------------------------------------------------------------------
+struct M3 { float m[9]; };  // column-major, m[col*3+row]
+
+// UnitQuaternion::to_rotation_matrix
+__device__ __forceinline__ M3 quat_to_m3(f4 q) {
+    const float i = q.x, j = q.y, k = q.z, w = q.w;
+    const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    const float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f;
+    const float ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+    M3 o;
+    o.m[0] = ww + ii - jj - kk; o.m[1] = wk + ij;           o.m[2] = ik - wj;
+    o.m[3] = ij - wk;           o.m[4] = ww - ii + jj - kk; o.m[5] = wi + jk;
+    o.m[6] = wj + ik;           o.m[7] = jk - wi;           o.m[8] = ww - ii - jj + kk;
+    return o;
+}
+
+// Writes the 16 floats of the local matrix (column-major) for one node.
+__device__ __forceinline__ void local_matrix(const float* __restrict__ st, float px, float py, float pz,
+                                             f4 rot, float sx, float sy, float sz, float* out) {
+    const f4 pre = f4{st[0], st[1], st[2], st[3]};
+    const float* por = st + 4;                       // post_rotation_matrix, column-major 3x3
+    const float rox = st[13], roy = st[14], roz = st[15];
+    const float rpx = st[16], rpy = st[17], rpz = st[18];
+    const float sox = st[19], soy = st[20], soz = st[21];
+    const float spx = st[22], spy = st[23], spz = st[24];
+    const M3 pr = quat_to_m3(pre), r = quat_to_m3(rot);
+    float a[9], fm[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)      // a = pr * r (columns of r)
+#pragma unroll
+        for (int row = 0; row < 3; ++row)
+            a[c * 3 + row] = pr.m[row] * r.m[c * 3] + pr.m[3 + row] * r.m[c * 3 + 1] + pr.m[6 + row] * r.m[c * 3 + 2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)      // f = a * por  with por indexed as in the reference (por[3c+k])
+#pragma unroll
+        for (int row = 0; row < 3; ++row)
+            fm[c * 3 + row] = por[c * 3] * a[row] + por[c * 3 + 1] * a[3 + row] + por[c * 3 + 2] * a[6 + row];
+    const float s[3] = {sx, sy, sz};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out[c * 4 + 0] = s[c] * fm[c * 3 + 0];
+        out[c * 4 + 1] = s[c] * fm[c * 3 + 1];
+        out[c * 4 + 2] = s[c] * fm[c * 3 + 2];
+        out[c * 4 + 3] = 0.0f;
+    }
+    const float ro[3] = {rox, roy, roz}, rp[3] = {rpx, rpy, rpz}, t[3] = {px, py, pz};
+#pragma unroll
+    for (int row = 0; row < 3; ++row) {
+        const float f0 = fm[row], f3 = fm[3 + row], f6 = fm[6 + row];
+        const float k0 = spx * f0, k1 = spy * f3, k2 = spz * f6;
+        out[12 + row] = ro[row] + rp[row] + t[row] - rpx * f0 - rpy * f3 - rpz * f6 + sox * f0 + k0 +
+                        soy * f3 + k1 + soz * f6 + k2 - sx * k0 - sy * k1 - sz * k2;
+    }
+    out[15] = 1.0f;
+}
+
+// nalgebra Matrix4 * Matrix4: per result column an axpy chain over k (a_col_k * b_kj + y).
+__device__ __forceinline__ void mat4_mul(const float* a, const float* b, float* out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float y = a[i] * b[j * 4];
+            y = a[4 + i] * b[j * 4 + 1] + y;
+            y = a[8 + i] * b[j * 4 + 2] + y;
+            y = a[12 + i] * b[j * 4 + 3] + y;
+            out[j * 4 + i] = y;
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// pose_update: one workgroup per instance.
+// ---------------------------------------------------------------------------------------
+template <bool PROGRAM>
+__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* l_local = lds;                               // [n_nodes][16]
+    float* l_global = lds + (size_t)rig.n_nodes * 16;   // [n_nodes][16]
+    const uint32_t inst = blockIdx.x;
+    const size_t inst_base = (size_t)inst * rig.n_nodes;
+
+    for (uint32_t node = threadIdx.x; node < rig.n_nodes; node += blockDim.x) {
+        f4* trs = reinterpret_cast<f4*>(f.node_trs) + (inst_base + node) * 3;
+        const f4 t0 = trs[0], t1 = trs[1], t2 = trs[2];
+        FoldCtx cx;
+        cx.tpx = t0.x; cx.tpy = t0.y; cx.tpz = t0.z;
+        cx.tr = t1;
+        cx.tsx = t2.x; cx.tsy = t2.y; cx.tsz = t2.z;
+        cx.dirty = false;
+        if constexpr (PROGRAM) {
+            cx.ops = f.ops + f.prog_off[inst];
+            cx.anim_pose = reinterpret_cast<const f4*>(f.anim_pose);
+            cx.layer_masks = f.layer_masks;
+            cx.anim_stride = (size_t)f.n_instances * f.n_nodes;
+            cx.rec_index = inst_base + node;
+            cx.n_nodes = f.n_nodes;
+            cx.node = node;
+            cx.pc = 0;
+            cx.pop_w = 0.f;
+            cx.done = false;
+            Acc acc;
+            acc.px = acc.py = acc.pz = acc.sx = acc.sy = acc.sz = 0.f;
+            acc.r = f4{0.f, 0.f, 0.f, 1.f};
+            acc.mask = 0;
+            while (!cx.done) run_fold<0>(cx, acc);  // a stray POP at depth 0 is ignored
+            if (cx.dirty) {
+                trs[0] = f4{cx.tpx, cx.tpy, cx.tpz, 0.f};
+                trs[1] = cx.tr;
+                trs[2] = f4{cx.tsx, cx.tsy, cx.tsz, 0.f};
+            }
+        }
+        float m[16];
+        local_matrix(rig.statics + (size_t)node * 28, cx.tpx, cx.tpy, cx.tpz, cx.tr, cx.tsx, cx.tsy, cx.tsz, m);
+        f4* gl = reinterpret_cast<f4*>(f.local + (inst_base + node) * 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f4 col = f4{m[c * 4], m[c * 4 + 1], m[c * 4 + 2], m[c * 4 + 3]};
+            reinterpret_cast<f4*>(l_local + (size_t)node * 16)[c] = col;
+            gl[c] = col;
+        }
+    }
+    __syncthreads();
+
+    // level-synchronous global = parent.global * local; a root multiplies by the identity, as
+    // the reference does for a node without a valid parent.
+    for (uint32_t lv = 0; lv < rig.n_levels; ++lv) {
+        const uint32_t b = rig.level_start[lv], e = rig.level_start[lv + 1];
+        for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+            const uint32_t node = rig.level_nodes[i];
+            const int32_t par = rig.parent[node];
+            float pg[16], lm[16], g[16];
+            if (par >= 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) pg[k] = l_global[(size_t)par * 16 + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) pg[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lm[k] = l_local[(size_t)node * 16 + k];
+            mat4_mul(pg, lm, g);
+            f4* gg = reinterpret_cast<f4*>(f.global + (inst_base + node) * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f4 col = f4{g[c * 4], g[c * 4 + 1], g[c * 4 + 2], g[c * 4 + 3]};
+                reinterpret_cast<f4*>(l_global + (size_t)node * 16)[c] = col;
+                gg[c] = col;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s) {
+    if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;
+    uint32_t block = ((rig.n_nodes + 63) / 64) * 64;
+    if (block > 256) block = 256;
+    const size_t lds = (size_t)rig.n_nodes * 32 * sizeof(float);
+    if (run_program) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_update_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(pose_update_kernel<true>, dim3(f.n_instances), dim3(block), lds, s, f, rig);
+    } else {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_update_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(pose_update_kernel<false>, dim3(f.n_instances), dim3(block), lds, s, f, rig);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// palette[inst][b] = global[inst][bone_b] * inv_bind[bone_b]; one thread per output element.
+// An invalid bone handle (negative node) yields the identity (scene/mesh/mod.rs:789-791).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void palette_gather_kernel(const float* __restrict__ global,
+                                                             const float* __restrict__ inv_bind,
+                                                             const int32_t* __restrict__ bone_nodes,
+                                                             uint32_t n_nodes, uint32_t n_bones,
+                                                             uint32_t n_instances, float* __restrict__ out) {
+    const uint64_t total = (uint64_t)n_instances * n_bones * 16;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(e & 3), j = (uint32_t)((e >> 2) & 3);
+        const uint64_t mb = e >> 4;
+        const uint32_t b = (uint32_t)(mb % n_bones), inst = (uint32_t)(mb / n_bones);
+        const int32_t node = bone_nodes[b];
+        float y;
+        if (node < 0) {
+            y = (i == j) ? 1.0f : 0.0f;
+        } else {
+            const float* a = global + ((size_t)inst * n_nodes + node) * 16;
+            const float* bb = inv_bind + (size_t)node * 16;
+            y = a[i] * bb[j * 4];
+            y = a[4 + i] * bb[j * 4 + 1] + y;
+            y = a[8 + i] * bb[j * 4 + 2] + y;
+            y = a[12 + i] * bb[j * 4 + 3] + y;
+        }
+        out[e] = y;
+    }
+}
+
+hipError_t launch_palette_gather(const float* d_global, const float* d_inv_bind, const int32_t* d_bone_nodes,
+                                 uint32_t n_nodes, uint32_t n_bones, uint32_t n_instances, float* d_out,
+                                 hipStream_t s) {
+    const uint64_t total = (uint64_t)n_instances * n_bones * 16;
+    if (total == 0) return hipSuccess;
+    uint64_t grid = (total + 255) / 256;
+    if (grid > (uint64_t)kCUs * 16) grid = (uint64_t)kCUs * 16;
+    hipLaunchKernelGGL(palette_gather_kernel, dim3((uint32_t)grid), dim3(256), 0, s, d_global, d_inv_bind,
+                       d_bone_nodes, n_nodes, n_bones, n_instances, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace fyx

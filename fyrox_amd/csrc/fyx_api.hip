@@ -1,58 +1,9 @@
 // fyx_api.hip -- the C ABI of libfyrox_hip.so (see include/fyrox_hip.h).
 // Owns: the context (device, stream, options, scratch), the mesh registry (device SoA streams
 // keyed by mesh id) and all argument validation.  No exception ever crosses the boundary.
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <string>
-#include <unordered_map>
+#include "fyx_ctx.h"
 
-#include "../../include/fyrox_hip.h"
-#include "fyx_internal.h"
-
-namespace {
-
-struct Mesh {
-    uint32_t n_verts = 0;
-    uint32_t max_bone_index = 0;
-    void* block = nullptr;  // one allocation, streams carved at 256-byte boundaries
-    float* pos = nullptr;
-    float* nrm = nullptr;
-    float* tan = nullptr;
-    float* wgt = nullptr;
-    uint32_t* idx = nullptr;
-};
-
-}  // namespace
-
-struct fyx_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    fyx::LbsTuning lbs;
-    std::unordered_map<uint64_t, Mesh> meshes;
-    std::string err = "";
-    // scratch: staging for host-variant calls, grown on demand
-    void* scratch = nullptr;
-    size_t scratch_bytes = 0;
-    float* aabb_partials = nullptr;  // 6 * 2048 floats + 8
-    uint32_t* d_u32 = nullptr;       // 1 word
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // Worker streams for independent skinning launches (see "stream semantics" in fyrox_hip.h).
-    static constexpr int kMaxWorkers = 4;
-    int n_workers = 2;  // option "lbs.streams"; 1 = launch on the context stream itself
-    hipStream_t workers[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t worker_done[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
-    bool worker_busy[kMaxWorkers] = {false, false, false, false};
-    uint64_t worker_seen[kMaxWorkers] = {0, 0, 0, 0};
-    hipEvent_t fork_ev = nullptr;
-    uint64_t fork_gen = 0;
-    bool primary_dirty = true;  // context-stream work enqueued since the last fork event
-    int next_worker = 0;
-};
-
-namespace {
+namespace fyx {
 
 int fail(fyx_ctx* c, int code, const char* fmt, ...) {
     if (c) {
@@ -71,12 +22,6 @@ int hip_fail(fyx_ctx* c, hipError_t e, const char* what) {
     return fail(c, code, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
 }
 
-#define FYX_HIP(c, call)                                          \
-    do {                                                          \
-        hipError_t e_ = (call);                                   \
-        if (e_ != hipSuccess) return hip_fail((c), e_, #call);    \
-    } while (0)
-
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Make the context stream wait for every in-flight worker launch (GPU-side join, no host wait).
@@ -92,6 +37,7 @@ int join_workers(fyx_ctx* c) {
 
 // Called by every entry point that enqueues work on (or synchronises) the context stream.
 int enter_primary(fyx_ctx* c) {
+    if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: this call needs a GPU");
     int rc = join_workers(c);
     c->primary_dirty = true;
     return rc;
@@ -139,6 +85,11 @@ int ensure_scratch(fyx_ctx* c, size_t bytes) {
     c->scratch_bytes = want;
     return FYX_OK;
 }
+
+}  // namespace fyx
+
+namespace {
+using namespace fyx;
 
 void free_mesh(Mesh& m) {
     if (m.block) (void)hipFree(m.block);
@@ -213,14 +164,6 @@ fyx::LbsArgs make_args(const Mesh& m, const float* d_palette, uint32_t n_bones, 
 
 }  // namespace
 
-#define FYX_GUARD_BEGIN try {
-#define FYX_GUARD_END(c)                                                        \
-    } catch (const std::bad_alloc&) {                                           \
-        return fail((c), FYX_ERR_OOM, "host allocation failed");                \
-    } catch (...) {                                                             \
-        return fail((c), FYX_ERR_HIP, "unexpected C++ exception");              \
-    }
-
 extern "C" {
 
 const char* fyx_version(void) { return "fyrox_hip 0.1.0 (gfx950)"; }
@@ -249,8 +192,10 @@ int fyx_init(fyx_ctx** out_ctx, int device_ordinal) {
 
 void fyx_shutdown(fyx_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    fyx::anim_store_destroy(c->anim);
+    c->anim = nullptr;
     for (auto& kv : c->meshes) free_mesh(kv.second);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->aabb_partials) (void)hipFree(c->aabb_partials);
@@ -348,6 +293,7 @@ int fyx_malloc(fyx_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return FYX_ERR_INVALID_ARG;
     *out = nullptr;
     if (bytes == 0) return FYX_OK;
+    if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: this call needs a GPU");
     FYX_HIP(c, hipMalloc(out, bytes));
     return FYX_OK;
 }

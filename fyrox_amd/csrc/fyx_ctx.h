@@ -1,0 +1,79 @@
+// fyx_ctx.h -- the context object and the helpers every C-ABI translation unit shares.
+#pragma once
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <unordered_map>
+
+#include "../../include/fyrox_hip.h"
+#include "fyx_internal.h"
+
+namespace fyx {
+struct Mesh {
+    uint32_t n_verts = 0;
+    uint32_t max_bone_index = 0;
+    void* block = nullptr;  // one allocation, streams carved at 256-byte boundaries
+    float* pos = nullptr;
+    float* nrm = nullptr;
+    float* tan = nullptr;
+    float* wgt = nullptr;
+    uint32_t* idx = nullptr;
+};
+struct AnimStore;  // anim_api.hip: tracks data, rigs, animators, bone lists
+void anim_store_destroy(AnimStore*);
+}  // namespace fyx
+using fyx::Mesh;
+
+struct fyx_ctx {
+    int device = 0;          // -1: control-only context (no GPU; data-path calls fail)
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    fyx::LbsTuning lbs;
+    std::unordered_map<uint64_t, Mesh> meshes;
+    std::string err = "";
+    // scratch: staging for host-variant calls, grown on demand
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    float* aabb_partials = nullptr;  // 6 * 2048 floats + 8
+    uint32_t* d_u32 = nullptr;       // 1 word
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Worker streams for independent skinning launches (see "stream semantics" in fyrox_hip.h).
+    static constexpr int kMaxWorkers = 4;
+    int n_workers = 2;  // option "lbs.streams"; 1 = launch on the context stream itself
+    hipStream_t workers[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t worker_done[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
+    bool worker_busy[kMaxWorkers] = {false, false, false, false};
+    uint64_t worker_seen[kMaxWorkers] = {0, 0, 0, 0};
+    hipEvent_t fork_ev = nullptr;
+    uint64_t fork_gen = 0;
+    bool primary_dirty = true;  // context-stream work enqueued since the last fork event
+    int next_worker = 0;
+    fyx::AnimStore* anim = nullptr;
+};
+
+
+namespace fyx {
+int fail(fyx_ctx* c, int code, const char* fmt, ...);
+int hip_fail(fyx_ctx* c, hipError_t e, const char* what);
+size_t align_up(size_t x, size_t a);
+int join_workers(fyx_ctx* c);
+int enter_primary(fyx_ctx* c);
+int ensure_scratch(fyx_ctx* c, size_t bytes);
+}  // namespace fyx
+
+#define FYX_HIP(c, call)                                               \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return fyx::hip_fail((c), e_, #call);    \
+    } while (0)
+
+#define FYX_GUARD_BEGIN try {
+#define FYX_GUARD_END(c)                                                        \
+    } catch (const std::bad_alloc&) {                                           \
+        return fyx::fail((c), FYX_ERR_OOM, "host allocation failed");           \
+    } catch (...) {                                                             \
+        return fyx::fail((c), FYX_ERR_HIP, "unexpected C++ exception");         \
+    }

@@ -61,3 +61,78 @@ hipError_t launch_stream_copy(const float* d_src, float* d_dst, uint32_t units, 
                               hipStream_t stream);
 
 }  // namespace fyx
+
+// ---------------------------------------------------------------------------------------
+// Skeletal-animation pose path (anim_kernels.hip).  All pointers device.
+// ---------------------------------------------------------------------------------------
+namespace fyx {
+
+constexpr int kMaxRigNodes = 1024;   // local+global matrices of one instance live in LDS
+constexpr int kMaxFoldDepth = 8;     // nested pose accumulators held in VGPRs
+
+// One track of an AnimationTracksData: TrackValueKind + up to four curves (key ranges).
+struct TrackDev {
+    int32_t kind;            // FYX_KIND_*
+    uint32_t n_curves;
+    uint32_t first_key[4];
+    uint32_t n_keys[4];
+};
+
+// One animation of an animator (shared by all its instances).
+struct AnimDev {
+    const TrackDev* tracks;
+    const float* key_loc;        // locations of all keys of the tracks data
+    const float4* key_aux;       // {value, kind bits, left tangent, right tangent} per key
+    const int32_t* slot_track;   // [n_nodes][3]: track feeding Position/Scale/Rotation of a node, -1 none
+    uint32_t n_tracks;
+    uint32_t pad;
+};
+
+// Fold program ops (one uint2 each: x = opcode | a << 8, y = float weight bits).
+enum : uint32_t {
+    OP_END = 0,
+    OP_BLEND_ANIM = 1,   // acc.blend_with(animation[a].pose, w)
+    OP_PUSH = 2,         // open a nested, empty accumulator
+    OP_POP_BLEND = 3,    // parent.blend_with(nested, w)
+    OP_RESET = 4,        // acc.reset()
+    OP_MASK = 5,         // drop the node from acc if layer mask a excludes it
+    OP_APPLY = 6,        // write acc to the node's local transform
+    OP_APPLY_ANIM = 7,   // write animation[a].pose to the node's local transform
+};
+
+struct RigDev {
+    const int32_t* parent;       // [n_nodes], parent index < node index or -1
+    const float* statics;        // [n_nodes][28]: pre_rotation(4) post_rotation_matrix(9)
+                                 //   rotation_offset(3) rotation_pivot(3) scaling_offset(3) scaling_pivot(3) pad(3)
+    const uint32_t* level_nodes; // nodes sorted by depth
+    const uint32_t* level_start; // [n_levels + 1]
+    uint32_t n_nodes;
+    uint32_t n_levels;
+};
+
+struct PoseFrameDev {
+    const AnimDev* anims;
+    uint32_t n_anims;
+    uint32_t n_instances;
+    uint32_t n_nodes;
+    const float* times;          // [n_instances][n_anims] sample time of ticked animations
+    const uint8_t* ticked;       // [n_instances][n_anims]
+    const uint2* ops;            // all instances' programs
+    const uint32_t* prog_off;    // [n_instances] offset of each instance's program in ops
+    const uint8_t* layer_masks;  // [n_layers][n_nodes] 1 = excluded
+    uint32_t* hints;             // [n_anims][n_instances][max_tracks][4]
+    uint32_t max_tracks;
+    float4* anim_pose;           // [n_anims][n_instances][n_nodes][3]
+    float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
+    float* local;                // [n_instances][n_nodes][16]
+    float* global;               // [n_instances][n_nodes][16]
+};
+
+hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s);
+hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s);
+// out[inst][b] = global[inst][bone_nodes[b]] * inv_bind[bone_nodes[b]] (identity for a negative node)
+hipError_t launch_palette_gather(const float* d_global, const float* d_inv_bind, const int32_t* d_bone_nodes,
+                                 uint32_t n_nodes, uint32_t n_bones, uint32_t n_instances, float* d_out,
+                                 hipStream_t s);
+
+}  // namespace fyx

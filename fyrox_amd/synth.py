@@ -176,3 +176,97 @@ def make_palette(n_bones: int, seed: int, n_instances: int = 1) -> np.ndarray:
         g, ib = make_bone_transforms(n_bones, seed, i)
         pals.append(mat4_mul_f32(g, ib))
     return np.concatenate(pals, axis=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Rigs, clips and machines: host-side input generation only.
+# ---------------------------------------------------------------------------------------------
+
+def make_rig(n_bones: int, seed: int, chain_depth: int = 8, exotic: bool = False):
+    """A skeleton of n_bones nodes: chains of `chain_depth` bones hanging off node 0.  Local
+    transforms are random rigid (unit scale); inv_bind is the f64 inverse of the bind-pose global,
+    rounded to f32.  exotic=True also fills pre-rotation, post-rotation, pivots and offsets so the
+    whole Transform::calculate_local_transform expression is exercised."""
+    from .anim import Rig, Transform
+    parent = np.full(n_bones, -1, np.int32)
+    for i in range(1, n_bones):
+        parent[i] = 0 if (i - 1) % chain_depth == 0 else i - 1
+    q = normal(seed, "rig.q", 4 * n_bones).reshape(n_bones, 4)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = (uniform(seed, "rig.t", 3 * n_bones) - 0.5).reshape(n_bones, 3)
+    qp = normal(seed, "rig.qpre", 4 * n_bones).reshape(n_bones, 4)
+    qp /= np.linalg.norm(qp, axis=1, keepdims=True)
+    qo = normal(seed, "rig.qpost", 4 * n_bones).reshape(n_bones, 4)
+    qo /= np.linalg.norm(qo, axis=1, keepdims=True)
+    piv = (uniform(seed, "rig.piv", 12 * n_bones) - 0.5).reshape(n_bones, 4, 3) * 0.2
+    transforms = []
+    for i in range(n_bones):
+        tr = Transform.identity()
+        tr.local_position[:] = t[i].astype(np.float32).tolist()
+        tr.local_rotation[:] = q[i].astype(np.float32).tolist()
+        if exotic and i % 3 == 1:
+            tr.pre_rotation[:] = qp[i].astype(np.float32).tolist()
+            # cached inverse of the post-rotation matrix (column-major 3x3), as set_post_rotation stores
+            inv = quat_to_mat3(qo[i:i + 1])[0].T
+            tr.post_rotation_matrix[:] = np.ascontiguousarray(inv.T).reshape(9).astype(np.float32).tolist()
+            tr.rotation_offset[:] = piv[i, 0].astype(np.float32).tolist()
+            tr.rotation_pivot[:] = piv[i, 1].astype(np.float32).tolist()
+            tr.scaling_offset[:] = piv[i, 2].astype(np.float32).tolist()
+            tr.scaling_pivot[:] = piv[i, 3].astype(np.float32).tolist()
+        transforms.append(tr)
+    # bind-pose globals in f64 (plain rigid chain; good enough for an inverse bind matrix input)
+    loc = np.zeros((n_bones, 4, 4))
+    loc[:, :3, :3] = quat_to_mat3(q.astype(np.float32).astype(np.float64))
+    loc[:, :3, 3] = t.astype(np.float32)
+    loc[:, 3, 3] = 1.0
+    glob = np.zeros_like(loc)
+    for i in range(n_bones):
+        glob[i] = loc[i] if parent[i] < 0 else glob[parent[i]] @ loc[i]
+    inv_bind = np.linalg.inv(glob)
+    inv_bind[:, 3, :] = (0.0, 0.0, 0.0, 1.0)
+    inv_bind_cm = np.ascontiguousarray(inv_bind.transpose(0, 2, 1)).reshape(n_bones, 16).astype(np.float32)
+    return Rig(parent=parent, transforms=transforms, inv_bind=inv_bind_cm)
+
+
+def make_clip(n_bones: int, seed: int, clip: int = 0, n_keys: int = 31, fps: float = 30.0,
+              key_kind: int = 1, euler_every: int = 2):
+    """AnimationTracksData with 3 tracks per bone (Position Vec3, Rotation, Scale Vec3), n_keys keys
+    at 1/fps spacing.  Rotation tracks are UnitQuaternion for bones with i % euler_every == 0
+    (glTF-like) and UnitQuaternionEuler otherwise (FBX-like).  Returns (tracks_data, track_target)."""
+    from . import anim as A
+    tag = f"clip{clip}"
+    nk = n_keys
+    times = (np.arange(nk, dtype=np.float64) / fps).astype(np.float32)
+    pos = ((uniform(seed, tag + ".pos", n_bones * nk * 3) - 0.5) * 0.6).reshape(n_bones, nk, 3)
+    scl = (1.0 + (uniform(seed, tag + ".scl", n_bones * nk * 3) - 0.5) * 0.1).reshape(n_bones, nk, 3)
+    quat = normal(seed, tag + ".q", n_bones * nk * 4).reshape(n_bones, nk, 4)
+    # low-frequency drift so neighbouring keys are similar but not equal
+    quat = np.cumsum(quat * 0.15, axis=1) + normal(seed, tag + ".q0", n_bones * 4).reshape(n_bones, 1, 4)
+    quat /= np.linalg.norm(quat, axis=2, keepdims=True)
+    eul = np.cumsum(normal(seed, tag + ".e", n_bones * nk * 3).reshape(n_bones, nk, 3) * 0.2, axis=1)
+    tan = normal(seed, tag + ".tan", n_bones * nk * 10 * 2).reshape(n_bones, nk, 10, 2) * 0.5
+
+    def curve(vals, b, comp):
+        return A.Curve([A.CurveKey(float(times[k]), float(np.float32(vals[k])), key_kind,
+                                   float(np.float32(tan[b, k, comp, 0])), float(np.float32(tan[b, k, comp, 1])))
+                        for k in range(nk)])
+
+    tracks, target = [], []
+    for b in range(n_bones):
+        tracks.append(A.Track(A.BIND_POSITION, A.KIND_VEC3, [curve(pos[b, :, c], b, c) for c in range(3)]))
+        if b % euler_every == 0:
+            tracks.append(A.Track(A.BIND_ROTATION, A.KIND_QUAT, [curve(quat[b, :, c], b, 3 + c) for c in range(4)]))
+        else:
+            tracks.append(A.Track(A.BIND_ROTATION, A.KIND_QUAT_EULER, [curve(eul[b, :, c], b, 3 + c) for c in range(3)]))
+        tracks.append(A.Track(A.BIND_SCALE, A.KIND_VEC3, [curve(scl[b, :, c], b, 7 + c) for c in range(3)]))
+        target += [b, b, b]
+    return A.AnimationTracksData(tracks), np.asarray(target, np.int32)
+
+
+def make_c5_machine():
+    """BASELINE config C5: one layer, one state whose root is BlendAnimations over four PlayAnimation
+    nodes with constant weights (-, 0.5, 0.25, 0.75); animations 0..3."""
+    from . import anim as A
+    nodes = [A.PlayAnimation(a) for a in range(4)]
+    nodes.append(A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, 0.5), A.BlendPose(2, 0.25), A.BlendPose(3, 0.75)]))
+    return A.Machine(parameters=[], layers=[A.MachineLayer(nodes=nodes, states=[A.State(root=4)])])

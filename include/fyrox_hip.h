@@ -159,6 +159,215 @@ int fyx_palette(fyx_ctx* ctx, const float* global, const float* inv_bind, uint32
 int fyx_palette_device(fyx_ctx* ctx, const float* d_global, const float* d_inv_bind, uint32_t n,
                        float* d_out);
 
+/* ====================================================================================== */
+/* Pose path: keyframes -> animation poses -> blending state machine -> node transforms    */
+/* -> global matrices -> bone palettes, for a batch of instances (a crowd) per call.         */
+/*                                                                                          */
+/* Split of work.  The per-instance CONTROL plane (time advance, transitions, parameters,   */
+/* blend weights: a few scalars per instance) runs on the host inside this library and       */
+/* mirrors the reference's Animation / Machine code line by line; it emits, per frame and    */
+/* instance, the sample times and a small fold program.  Every per-BONE operation (curve     */
+/* sampling, pose blending, apply, local matrix, hierarchy, palette) runs in HIP kernels;    */
+/* poses, node transforms, matrices and palettes never leave HBM.                            */
+/* ====================================================================================== */
+
+#define FYX_ALL_INSTANCES 0xffffffffu
+
+/* ValueBinding (fyrox-animation/src/value.rs:355-373).  Property{..} bindings go through
+ * reflection in the reference and are not a per-bone numeric path: FYX_ERR_UNSUPPORTED. */
+enum { FYX_BIND_POSITION = 0, FYX_BIND_SCALE = 1, FYX_BIND_ROTATION = 2 };
+/* TrackValueKind (container.rs:40-62) */
+enum { FYX_KIND_REAL = 0, FYX_KIND_VEC2 = 1, FYX_KIND_VEC3 = 2, FYX_KIND_VEC4 = 3,
+       FYX_KIND_QUAT_EULER = 4, FYX_KIND_QUAT = 5 };
+/* CurveKeyKind (fyrox-math/src/curve.rs:34-45) */
+enum { FYX_KEY_CONSTANT = 0, FYX_KEY_LINEAR = 1, FYX_KEY_CUBIC = 2 };
+
+/* One Track (track.rs:103-107): binding + TrackDataContainer{kind, curves}.  The keys of its
+ * curves follow each other in the key arrays passed to fyx_tracks_data_upload. */
+typedef struct fyx_track_desc {
+    int32_t binding;          /* FYX_BIND_* */
+    int32_t kind;             /* FYX_KIND_*; Position/Scale need VEC3, Rotation QUAT or QUAT_EULER */
+    uint32_t n_curves;        /* curves.len(), 0..4; fewer than the kind needs => the track fetches None */
+    uint32_t curve_n_keys[4]; /* keys per curve, sorted by location as Curve keeps them */
+} fyx_track_desc;
+
+/* AnimationTracksData (fyrox-animation/src/lib.rs:66-110): uploaded once, shared by any number
+ * of animations.  Key arrays hold sum(curve_n_keys) entries in track-major, curve-major order.
+ * Tangents are read only for FYX_KEY_CUBIC keys (CurveKeyKind::Cubic{left_tangent,right_tangent}). */
+int fyx_tracks_data_upload(fyx_ctx* ctx, uint64_t tracks_id, uint32_t n_tracks,
+                           const fyx_track_desc* tracks, uint32_t n_keys,
+                           const float* key_location, const float* key_value,
+                           const uint8_t* key_kind, const float* key_left_tangent,
+                           const float* key_right_tangent);
+int fyx_tracks_data_free(fyx_ctx* ctx, uint64_t tracks_id);
+
+/* The fields of scene::transform::Transform that calculate_local_transform reads
+ * (fyrox-impl/src/scene/transform.rs:96-120, :421-540).  post_rotation_matrix is the cached
+ * Matrix3 (column-major) that set_post_rotation stores. */
+typedef struct fyx_transform {
+    float local_position[3];
+    float local_rotation[4];      /* (i, j, k, w) */
+    float local_scale[3];
+    float pre_rotation[4];
+    float post_rotation_matrix[9];
+    float rotation_offset[3];
+    float rotation_pivot[3];
+    float scaling_offset[3];
+    float scaling_pivot[3];
+} fyx_transform;
+
+/* A rig: the scene nodes one animated model instance consists of (bones and whatever sits
+ * between them), in an order where parent[i] < i (or -1: no parent inside the rig; such a node
+ * multiplies by the identity exactly as Graph::update_global_transform_recursively does for an
+ * invalid parent handle, scene/graph/mod.rs:1210-1216).  `transforms` are the initial local
+ * transforms every instance starts from; inv_bind (n_nodes x 16, NULL = identity) is
+ * Base::inv_bind_pose_transform (scene/base.rs:710-712).  At most 1024 nodes. */
+int fyx_rig_create(fyx_ctx* ctx, uint64_t rig_id, uint32_t n_nodes, const int32_t* parent,
+                   const fyx_transform* transforms, const float* inv_bind);
+int fyx_rig_free(fyx_ctx* ctx, uint64_t rig_id);
+
+/* Surface::bones (scene/mesh/surface.rs:1255): the rig nodes whose matrices form a palette,
+ * in bone-index order.  A negative entry is an invalid handle (identity matrix). */
+int fyx_bone_list_create(fyx_ctx* ctx, uint64_t bones_id, uint64_t rig_id, uint32_t n_bones,
+                         const int32_t* bone_nodes);
+int fyx_bone_list_free(fyx_ctx* ctx, uint64_t bones_id);
+
+/* An animator: n_instances copies of one rig, each with its own AnimationContainer state
+ * (AnimationPlayer, scene/animation/mod.rs:190-346) and optionally its own Machine
+ * (AnimationBlendingStateMachine, scene/animation/absm.rs).  Structure (animations, tracks
+ * bindings, machine graph) is shared by the instances; state (times, speeds, enabled flags,
+ * parameters, active states, transition progress, node transforms) is per instance. */
+int fyx_animator_create(fyx_ctx* ctx, uint64_t animator_id, uint64_t rig_id, uint32_t n_instances);
+int fyx_animator_free(fyx_ctx* ctx, uint64_t animator_id);
+
+/* AnimationContainer::add + Animation::set_tracks_data + track_bindings (lib.rs:860-870):
+ * track_target[t] = rig node the t-th track drives (negative: no TrackBinding for the track),
+ * track_enabled[t] = TrackBinding::enabled (NULL: all enabled).  The new animation has the
+ * reference's defaults: speed 1, looped, enabled, time 0, time_slice 0..0 (lib.rs:928-950).
+ * Two enabled tracks with the same binding on one node are FYX_ERR_UNSUPPORTED. */
+int fyx_animator_add_animation(fyx_ctx* ctx, uint64_t animator_id, uint64_t tracks_id,
+                               const int32_t* track_target, const uint8_t* track_enabled,
+                               uint32_t* out_animation);
+int fyx_animation_set_track_enabled(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                                    uint32_t track, int enabled);
+/* Per-instance Animation state; instance = FYX_ALL_INSTANCES addresses every instance.
+ * Semantics of lib.rs:432-460 (set_time_position wraps or clamps into the time slice;
+ * set_time_slice re-applies it), :695-748. */
+int fyx_animation_set_time_slice(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                                 uint32_t instance, float start, float end);
+int fyx_animation_set_time_position(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                                    uint32_t instance, float time);
+int fyx_animation_set_speed(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                            uint32_t instance, float speed);
+int fyx_animation_set_loop(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                           uint32_t instance, int looped);
+int fyx_animation_set_enabled(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                              uint32_t instance, int enabled);
+int fyx_animation_rewind(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation, uint32_t instance);
+int fyx_animation_get_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                            uint32_t instance, float* time_position, int* enabled, int* has_ended);
+
+/* ---- Machine (fyrox-animation/src/machine) ------------------------------------------- */
+/* Parameter (machine/parameter.rs:37-60) */
+enum { FYX_PARAM_WEIGHT = 0, FYX_PARAM_RULE = 1, FYX_PARAM_INDEX = 2, FYX_PARAM_SAMPLING_POINT = 3 };
+/* StateAction (machine/state.rs:62-80); EnableRandomAnimation needs the host's RNG: unsupported */
+enum { FYX_ACTION_NONE = 0, FYX_ACTION_REWIND_ANIMATION = 1, FYX_ACTION_ENABLE_ANIMATION = 2,
+       FYX_ACTION_DISABLE_ANIMATION = 3 };
+/* LogicNode (machine/transition.rs:107-131), prefix encoded into an int array:
+ * PARAMETER p | AND a b | OR a b | XOR a b | NOT a | IS_ANIMATION_ENDED animation */
+enum { FYX_LOGIC_PARAMETER = 0, FYX_LOGIC_AND = 1, FYX_LOGIC_OR = 2, FYX_LOGIC_XOR = 3,
+       FYX_LOGIC_NOT = 4, FYX_LOGIC_IS_ANIMATION_ENDED = 5 };
+
+/* Parameters are addressed by index instead of name (the shim resolves names once); an index
+ * that is out of range, or holds another kind than the reader expects, behaves like a missing
+ * or mistyped name in the reference (weight 0.0 / rule false / node yields an empty pose). */
+int fyx_machine_add_parameter(fyx_ctx* ctx, uint64_t animator_id, int kind, float f0, float f1,
+                              uint32_t u, uint32_t* out_parameter);
+int fyx_machine_set_parameter(fyx_ctx* ctx, uint64_t animator_id, uint32_t parameter,
+                              uint32_t instance, int kind, float f0, float f1, uint32_t u);
+int fyx_machine_add_layer(fyx_ctx* ctx, uint64_t animator_id, float weight, uint32_t* out_layer);
+int fyx_layer_set_weight(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, float weight);
+/* LayerMask (machine/mask.rs): rig nodes the layer must not animate */
+int fyx_layer_set_mask(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
+                       const int32_t* excluded_nodes, uint32_t n);
+/* PoseNode::PlayAnimation (machine/node/play.rs) */
+int fyx_layer_add_play_animation(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
+                                 uint32_t animation, uint32_t* out_node);
+/* PoseNode::BlendAnimations (node/blend.rs:60-164): weight_parameter[i] < 0 = PoseWeight::Constant */
+int fyx_layer_add_blend_animations(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
+                                   uint32_t n_inputs, const int32_t* pose_sources,
+                                   const int32_t* weight_parameters, const float* weight_constants,
+                                   uint32_t* out_node);
+/* PoseNode::BlendAnimationsByIndex (node/blend.rs:200-361) */
+int fyx_layer_add_blend_animations_by_index(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
+                                            int32_t index_parameter, uint32_t n_inputs,
+                                            const int32_t* pose_sources, const float* blend_times,
+                                            uint32_t* out_node);
+/* PoseNode::BlendSpace (node/blendspace.rs); triangles = the Delaunay triangulation the
+ * reference caches in BlendSpace::triangles (3 point indices each) */
+int fyx_layer_add_blend_space(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
+                              int32_t sampling_parameter, uint32_t n_points, const float* points_xy,
+                              const int32_t* pose_sources, uint32_t n_triangles,
+                              const uint32_t* triangles, uint32_t* out_node);
+/* MachineLayer::add_state (layer.rs:229-235: the first state becomes active) */
+int fyx_layer_add_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, int32_t root_node,
+                        uint32_t* out_state);
+int fyx_layer_set_entry_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t state);
+int fyx_state_add_action(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t state,
+                         int on_enter, int action, uint32_t animation);
+/* Transition (machine/transition.rs:180-323) */
+int fyx_layer_add_transition(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t source,
+                             uint32_t dest, float transition_time, const int32_t* condition,
+                             uint32_t n_condition, uint32_t* out_transition);
+int fyx_layer_get_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance,
+                        int32_t* active_state, int32_t* active_transition);
+
+/* ---- per frame ----------------------------------------------------------------------- */
+/* AnimationPlayer::update = AnimationContainerExt::update_animations (scene/animation/mod.rs:
+ * 83-88, 340-346): every enabled animation ticks (pose sampled at its current time, then the
+ * time advances, lib.rs:471-496) and its pose is applied to the nodes, in container order. */
+int fyx_animation_player_update(fyx_ctx* ctx, uint64_t animator_id, float dt);
+/* AnimationBlendingStateMachine::update (absm.rs:311-326) = Machine::evaluate_pose
+ * (machine/mod.rs:344-382) + AnimationPoseExt::apply_internal. */
+int fyx_absm_update(fyx_ctx* ctx, uint64_t animator_id, float dt);
+/* Both calls also refresh the local and global matrices of every node of every instance
+ * (Transform::matrix + Graph::update_hierarchical_data); this one does only that (after
+ * fyx_animator_set_local_trs, or for a rig nothing animates). */
+int fyx_animator_update_transforms(fyx_ctx* ctx, uint64_t animator_id);
+/* d_out_palette[(i * n_bones + b) * 16 ..] = global(i, bone_b) * inv_bind(bone_b): the
+ * `bone_matrices` of Mesh::collect_render_data (scene/mesh/mod.rs:781-793), ready for
+ * fyx_lbs_skin_device(.., n_instances).  Asynchronous on the context stream. */
+int fyx_animator_palette(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, float* d_out_palette);
+
+/* Transform::set_position / set_rotation / set_scale of one node for a range of instances
+ * (placing the members of a crowd): trs = n_instances x {pos xyz, rot ijkw, scale xyz}. */
+int fyx_animator_set_local_trs(fyx_ctx* ctx, uint64_t animator_id, uint32_t node,
+                               uint32_t first_instance, uint32_t n_instances, const float* trs);
+
+/* Read back per-instance state (synchronous).  Layouts, all [n_instances][n_nodes][..]:
+ * LOCAL_TRS 12 floats {pos xyz, 0, rot ijkw, scale xyz, 0}; LOCAL/GLOBAL_MATRIX 16 floats;
+ * ANIMATION_POSE + animation: the animation's current pose, 12 floats {pos xyz, present-bits
+ * as u32 (1 Position, 2 Scale, 4 Rotation), rot ijkw, scale xyz, 0}. */
+enum { FYX_READ_LOCAL_TRS = 0, FYX_READ_LOCAL_MATRIX = 1, FYX_READ_GLOBAL_MATRIX = 2,
+       FYX_READ_ANIMATION_POSE = 16 };
+int fyx_animator_read(fyx_ctx* ctx, uint64_t animator_id, int what, float* host_out);
+/* Device address of the same arrays (what as above), for consumers on the GPU. */
+int fyx_animator_device_ptr(fyx_ctx* ctx, uint64_t animator_id, int what, void** out_device_ptr);
+
+/* ---- control plane without a GPU ----------------------------------------------------- */
+/* A context with no device: registry and control-plane calls work, every call that would touch
+ * the GPU returns FYX_ERR_NO_DEVICE.  It computes no poses and no vertices -- it exists so the
+ * host logic (time advance, transitions, emitted fold programs) can be unit-tested anywhere. */
+int fyx_init_control_only(fyx_ctx** out_ctx);
+/* Advance the control plane of every instance by one frame exactly as fyx_animation_player_update
+ * (mode 0) / fyx_absm_update (mode 1) would, and copy what they would send to the GPU:
+ * times and ticked are [n_instances][n_animations]; program_offset is [n_instances + 1]; ops are
+ * {opcode | arg << 8, f32 weight bits} pairs (opcodes: 0 END, 1 BLEND_ANIM, 2 PUSH, 3 POP_BLEND,
+ * 4 RESET, 5 MASK, 6 APPLY, 7 APPLY_ANIM).  *n_ops returns the number of pairs needed. */
+int fyx_animator_plan(fyx_ctx* ctx, uint64_t animator_id, int mode, float dt, float* times,
+                      uint8_t* ticked, uint32_t* program_offset, uint32_t* ops,
+                      uint32_t ops_capacity, uint32_t* n_ops);
+
 #ifdef __cplusplus
 }
 #endif

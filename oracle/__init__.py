@@ -268,3 +268,263 @@ def accurate_world_bounding_box(aos, n_verts, stride, off_pos, off_weights, off_
 
 def omp_max_threads() -> int:
     return int(lib().fo_omp_max_threads())
+
+
+# ---- fyrox-animation pose path (fyrox_oracle_anim.c) ----------------------------------------------
+
+BIND_POSITION, BIND_SCALE, BIND_ROTATION = 0, 1, 2
+VAL_REAL, VAL_VEC2, VAL_VEC3, VAL_VEC4, VAL_QUAT = range(5)
+
+
+class _BoundValue(Structure):
+    _fields_ = [("binding", c_int), ("kind", c_int), ("v", c_float * 4)]
+
+
+_anim_bound = False
+
+
+def _alib():
+    global _anim_bound
+    l = lib()
+    if not _anim_bound:
+        for name in ("fo_pose_new", "fo_tracks_new", "fo_animation_new", "fo_machine_new", "fo_animation_pose",
+                     "fo_layer_pose", "fo_machine_pose", "fo_machine_evaluate_pose"):
+            getattr(l, name).restype = c_void_p
+        l.fo_animation_time_position.restype = c_float
+        for name, args in {
+            "fo_pose_free": [c_void_p], "fo_pose_value_count": [c_void_p, c_int],
+            "fo_pose_get_value": [c_void_p, c_int, c_int, POINTER(_BoundValue)],
+            "fo_pose_node_capacity": [c_void_p], "fo_pose_apply": [c_void_p, c_void_p, c_int],
+            "fo_tracks_free": [c_void_p], "fo_tracks_add_track": [c_void_p, c_int, c_int, c_uint32, c_void_p],
+            "fo_animation_new": [c_void_p], "fo_animation_free": [c_void_p],
+            "fo_animation_bind": [c_void_p, c_int, c_int, c_int],
+            "fo_animation_set_time_position": [c_void_p, c_float],
+            "fo_animation_set_time_slice": [c_void_p, c_float, c_float],
+            "fo_animation_set_speed": [c_void_p, c_float], "fo_animation_set_loop": [c_void_p, c_int],
+            "fo_animation_set_enabled": [c_void_p, c_int], "fo_animation_rewind": [c_void_p],
+            "fo_animation_time_position": [c_void_p], "fo_animation_is_enabled": [c_void_p],
+            "fo_animation_has_ended": [c_void_p], "fo_animation_pose": [c_void_p],
+            "fo_animation_tick": [c_void_p, c_float],
+            "fo_machine_free": [c_void_p],
+            "fo_machine_add_parameter": [c_void_p, c_int, c_float, c_float, c_uint32],
+            "fo_machine_set_parameter": [c_void_p, c_int, c_int, c_float, c_float, c_uint32],
+            "fo_machine_add_layer": [c_void_p, c_float], "fo_layer_set_weight": [c_void_p, c_int, c_float],
+            "fo_layer_set_mask": [c_void_p, c_int, c_void_p, c_int],
+            "fo_layer_add_play": [c_void_p, c_int, c_int],
+            "fo_layer_add_blend": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+            "fo_layer_add_blend_by_index": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+            "fo_layer_add_blend_space": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+            "fo_layer_add_state": [c_void_p, c_int, c_int], "fo_layer_set_entry_state": [c_void_p, c_int, c_int],
+            "fo_state_add_action": [c_void_p, c_int, c_int, c_int, c_int, c_int],
+            "fo_layer_add_transition": [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int],
+            "fo_layer_active_state": [c_void_p, c_int], "fo_layer_active_transition": [c_void_p, c_int],
+            "fo_layer_pose": [c_void_p, c_int], "fo_machine_pose": [c_void_p],
+            "fo_machine_evaluate_pose": [c_void_p, c_void_p, c_int, c_float],
+            "fo_blend_space_fetch_weights": [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+        }.items():
+            getattr(l, name).argtypes = args
+        _anim_bound = True
+    return l
+
+
+def blend_space_fetch_weights(points_xy, triangles, sampling_point):
+    """BlendSpace::fetch_weights -> [(index, weight)] * 3 or None."""
+    pts = _f32(points_xy).reshape(-1, 2)
+    tri = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
+    sp = _f32(sampling_point, 2)
+    idx = np.zeros(3, np.int32)
+    w = np.zeros(3, np.float32)
+    ok = _alib().fo_blend_space_fetch_weights(pts.shape[0], _p(pts), tri.shape[0], _p(tri), _p(sp), _p(idx), _p(w))
+    return [(int(idx[i]), float(w[i])) for i in range(3)] if ok else None
+
+
+def _pose_records(pose_ptr, n_nodes: int) -> np.ndarray:
+    """(n_nodes, 12) records in the product's layout {pos, present-bits}{rot}{scale,0}: first value per binding."""
+    l = _alib()
+    out = np.zeros((n_nodes, 12), np.float32)
+    out[:, 7] = 1.0
+    bits = np.zeros(n_nodes, np.uint32)
+    bv = _BoundValue()
+    for n in range(n_nodes):
+        seen = set()
+        for i in range(l.fo_pose_value_count(pose_ptr, n)):
+            l.fo_pose_get_value(pose_ptr, n, i, byref(bv))
+            if bv.binding in seen:
+                continue
+            seen.add(bv.binding)
+            if bv.binding == BIND_POSITION and bv.kind == VAL_VEC3:
+                out[n, 0:3] = bv.v[0:3]; bits[n] |= 1
+            elif bv.binding == BIND_SCALE and bv.kind == VAL_VEC3:
+                out[n, 8:11] = bv.v[0:3]; bits[n] |= 2
+            elif bv.binding == BIND_ROTATION and bv.kind == VAL_QUAT:
+                out[n, 4:8] = bv.v[0:4]; bits[n] |= 4
+    out[:, 3] = bits.view(np.float32)
+    return out
+
+
+class AnimScene:
+    """One instance of: rig nodes + AnimationContainer + optional Machine, evaluated by the oracle.
+    Takes the same descriptions as fyrox_amd.anim (duck-typed; nothing is imported from the product)."""
+
+    def __init__(self, rig):
+        self.l = _alib()
+        self.n_nodes = len(rig.transforms)
+        self.parent = np.ascontiguousarray(rig.parent, dtype=np.int32)
+        self.nodes = (_Transform * self.n_nodes)()
+        for i, t in enumerate(rig.transforms):
+            ctypes.memmove(byref(self.nodes[i]), byref(t), ctypes.sizeof(_Transform))
+        self.inv_bind = (np.tile(np.eye(4, dtype=np.float32).reshape(16), (self.n_nodes, 1))
+                         if rig.inv_bind is None else _f32(rig.inv_bind, (self.n_nodes, 16)))
+        self.tracks = []
+        self.anims = []
+        self.machine = None
+
+    def add_tracks_data(self, td) -> int:
+        h = self.l.fo_tracks_new()
+        for t in td.tracks:
+            cs = [Curve([(k.location, k.value, k.kind, k.left_tangent, k.right_tangent) for k in c.keys]) for c in t.curves]
+            arr = (_Curve * max(len(cs), 1))(*[c._c() for c in cs])
+            self.l.fo_tracks_add_track(h, t.binding, t.kind, len(cs), arr)
+        self.tracks.append(h)
+        return len(self.tracks) - 1
+
+    def add_animation(self, tracks_index: int, track_target, track_enabled=None, *, time_slice=None, speed=None,
+                      looped=None, enabled=None) -> int:
+        a = self.l.fo_animation_new(self.tracks[tracks_index])
+        for t, tgt in enumerate(track_target):
+            self.l.fo_animation_bind(a, t, int(tgt), 1 if track_enabled is None else int(track_enabled[t]))
+        if looped is not None:
+            self.l.fo_animation_set_loop(a, int(bool(looped)))
+        if time_slice is not None:
+            self.l.fo_animation_set_time_slice(a, time_slice[0], time_slice[1])
+        if speed is not None:
+            self.l.fo_animation_set_speed(a, speed)
+        if enabled is not None:
+            self.l.fo_animation_set_enabled(a, int(bool(enabled)))
+        self.anims.append(a)
+        return len(self.anims) - 1
+
+    def set_machine(self, m) -> None:
+        l = self.l
+        h = l.fo_machine_new()
+        for p in m.parameters:
+            f0, f1, u = p.packed()
+            l.fo_machine_add_parameter(h, p.kind, f0, f1, u)
+        for layer in m.layers:
+            li = l.fo_machine_add_layer(h, layer.weight)
+            if layer.mask:
+                mk = np.ascontiguousarray(layer.mask, dtype=np.int32)
+                l.fo_layer_set_mask(h, li, _p(mk), len(mk))
+            for n in layer.nodes:
+                tn = type(n).__name__
+                if tn == "PlayAnimation":
+                    l.fo_layer_add_play(h, li, n.animation)
+                elif tn == "BlendAnimations":
+                    src = np.asarray([b.pose_source for b in n.pose_sources], np.int32)
+                    par = np.asarray([-1 if b.parameter is None else b.parameter for b in n.pose_sources], np.int32)
+                    wc = np.asarray([b.weight for b in n.pose_sources], np.float32)
+                    l.fo_layer_add_blend(h, li, len(src), _p(src), _p(par), _p(wc))
+                elif tn == "BlendAnimationsByIndex":
+                    src = np.asarray([i.pose_source for i in n.inputs], np.int32)
+                    bt = np.asarray([i.blend_time for i in n.inputs], np.float32)
+                    l.fo_layer_add_blend_by_index(h, li, n.index_parameter, len(src), _p(src), _p(bt))
+                elif tn == "BlendSpace":
+                    pts = np.asarray([p.position for p in n.points], np.float32).reshape(-1, 2)
+                    src = np.asarray([p.pose_source for p in n.points], np.int32)
+                    tri = np.asarray(n.triangles, np.uint32).reshape(-1, 3)
+                    l.fo_layer_add_blend_space(h, li, n.sampling_parameter, len(src), _p(pts), _p(src), len(tri), _p(tri))
+                else:
+                    raise TypeError(n)
+            for si, s in enumerate(layer.states):
+                l.fo_layer_add_state(h, li, s.root)
+                for kind, anim in s.on_enter_actions:
+                    l.fo_state_add_action(h, li, si, 1, kind, anim)
+                for kind, anim in s.on_leave_actions:
+                    l.fo_state_add_action(h, li, si, 0, kind, anim)
+            for t in layer.transitions:
+                code = np.asarray(_encode_logic(t.condition), np.int32)
+                l.fo_layer_add_transition(h, li, t.source, t.dest, t.transition_time, _p(code), len(code))
+            if layer.entry_state is not None:
+                l.fo_layer_set_entry_state(h, li, layer.entry_state)
+        self.machine = h
+
+    def set_parameter(self, index, p) -> None:
+        f0, f1, u = p.packed()
+        self.l.fo_machine_set_parameter(self.machine, index, p.kind, f0, f1, u)
+
+    # AnimationContainerExt::update_animations
+    def update_animations(self, dt: float) -> None:
+        for a in self.anims:
+            if self.l.fo_animation_is_enabled(a):
+                self.l.fo_animation_tick(a, dt)
+                self.l.fo_pose_apply(self.l.fo_animation_pose(a), self.nodes, self.n_nodes)
+
+    # AnimationBlendingStateMachine::update
+    def update_machine(self, dt: float) -> None:
+        arr = (c_void_p * max(len(self.anims), 1))(*self.anims)
+        pose = self.l.fo_machine_evaluate_pose(self.machine, arr, len(self.anims), dt)
+        self.l.fo_pose_apply(pose, self.nodes, self.n_nodes)
+
+    def animation_pose(self, a: int) -> np.ndarray:
+        return _pose_records(self.l.fo_animation_pose(self.anims[a]), self.n_nodes)
+
+    def machine_pose(self) -> np.ndarray:
+        return _pose_records(self.l.fo_machine_pose(self.machine), self.n_nodes)
+
+    def animation_state(self, a: int) -> dict:
+        h = self.anims[a]
+        return {"time_position": float(self.l.fo_animation_time_position(h)),
+                "enabled": bool(self.l.fo_animation_is_enabled(h)), "has_ended": bool(self.l.fo_animation_has_ended(h))}
+
+    def layer_state(self, layer: int):
+        return (self.l.fo_layer_active_state(self.machine, layer), self.l.fo_layer_active_transition(self.machine, layer))
+
+    def set_local_trs(self, node: int, trs10) -> None:
+        self.nodes[node].local_position[:] = [float(x) for x in trs10[0:3]]
+        self.nodes[node].local_rotation[:] = [float(x) for x in trs10[3:7]]
+        self.nodes[node].local_scale[:] = [float(x) for x in trs10[7:10]]
+
+    def node_trs(self) -> np.ndarray:
+        out = np.zeros((self.n_nodes, 12), np.float32)
+        for i in range(self.n_nodes):
+            out[i, 0:3] = self.nodes[i].local_position[:]
+            out[i, 4:8] = self.nodes[i].local_rotation[:]
+            out[i, 8:11] = self.nodes[i].local_scale[:]
+        return out
+
+    def local_matrices(self) -> np.ndarray:
+        out = np.empty((self.n_nodes, 16), np.float32)
+        for i in range(self.n_nodes):
+            self.l.fo_calculate_local_transform(byref(self.nodes[i]), _p(out[i]))
+        return out
+
+    def global_matrices(self) -> np.ndarray:
+        return update_global_transforms(self.local_matrices(), self.parent)
+
+    def palette(self, bone_nodes) -> np.ndarray:
+        g = self.global_matrices()
+        out = np.empty((len(bone_nodes), 16), np.float32)
+        ident = np.eye(4, dtype=np.float32).reshape(16)
+        for b, n in enumerate(bone_nodes):
+            out[b] = ident if n < 0 else mat4_mul(g[n], self.inv_bind[n])
+        return out
+
+    def close(self) -> None:
+        if self.machine:
+            self.l.fo_machine_free(self.machine)
+        for a in self.anims:
+            self.l.fo_animation_free(a)
+        for t in self.tracks:
+            self.l.fo_tracks_free(t)
+        self.machine, self.anims, self.tracks = None, [], []
+
+
+def _encode_logic(cond):
+    op = cond[0]
+    if op == "parameter":
+        return [0, int(cond[1])]
+    if op == "ended":
+        return [5, int(cond[1])]
+    if op == "not":
+        return [4] + _encode_logic(cond[1])
+    return [{"and": 1, "or": 2, "xor": 3}[op]] + _encode_logic(cond[1]) + _encode_logic(cond[2])

@@ -124,6 +124,83 @@ uint32_t fo_accurate_world_bounding_box(const uint8_t* aos, uint32_t n_verts, ui
                                         const float* palette, uint32_t n_bones, float aabb[6]);
 int fo_omp_max_threads(void);
 
+/* ---------- fyrox-animation pose path (fyrox_oracle_anim.c) ---------- */
+/* ValueBinding (value.rs:355-373): ids >= FO_BIND_PROPERTY0 stand for distinct Property{name,..} */
+enum { FO_BIND_POSITION = 0, FO_BIND_SCALE = 1, FO_BIND_ROTATION = 2, FO_BIND_PROPERTY0 = 3 };
+/* TrackValue variants (value.rs:199-214) */
+enum { FO_VAL_REAL = 0, FO_VAL_VEC2 = 1, FO_VAL_VEC3 = 2, FO_VAL_VEC4 = 3, FO_VAL_QUAT = 4 };
+typedef struct fo_bound_value { int binding; int kind; float v[4]; } fo_bound_value;
+
+typedef struct fo_pose fo_pose;           /* AnimationPose<T>, T = small non-negative int */
+fo_pose* fo_pose_new(void);
+void fo_pose_free(fo_pose*);
+void fo_pose_reset(fo_pose*);
+void fo_pose_add(fo_pose*, int node, const fo_bound_value*);
+void fo_pose_clone_into(const fo_pose* src, fo_pose* dst);
+void fo_pose_blend_with(fo_pose* self, const fo_pose* other, float weight);
+int fo_pose_node_capacity(const fo_pose*);
+int fo_pose_value_count(const fo_pose*, int node);
+int fo_pose_get_value(const fo_pose*, int node, int i, fo_bound_value* out);
+void fo_pose_apply(const fo_pose*, fo_transform* nodes, int n_nodes);
+
+typedef struct fo_tracks fo_tracks;       /* AnimationTracksData */
+fo_tracks* fo_tracks_new(void);
+void fo_tracks_free(fo_tracks*);
+int fo_tracks_add_track(fo_tracks*, int binding, int kind, uint32_t n_curves, const fo_curve* curves);
+int fo_tracks_count(const fo_tracks*);
+
+typedef struct fo_animation fo_animation; /* Animation<T> */
+fo_animation* fo_animation_new(const fo_tracks*);
+void fo_animation_free(fo_animation*);
+void fo_animation_bind(fo_animation*, int track, int target_node, int enabled);
+void fo_animation_set_time_position(fo_animation*, float);
+void fo_animation_set_time_slice(fo_animation*, float start, float end);
+void fo_animation_set_speed(fo_animation*, float);
+void fo_animation_set_loop(fo_animation*, int);
+void fo_animation_set_enabled(fo_animation*, int);
+void fo_animation_rewind(fo_animation*);
+float fo_animation_time_position(const fo_animation*);
+int fo_animation_is_enabled(const fo_animation*);
+int fo_animation_has_ended(const fo_animation*);
+const fo_pose* fo_animation_pose(const fo_animation*);
+void fo_animation_tick(fo_animation*, float dt);
+
+enum { FO_PARAM_WEIGHT = 0, FO_PARAM_RULE = 1, FO_PARAM_INDEX = 2, FO_PARAM_SAMPLING_POINT = 3 };
+enum { FO_NODE_PLAY = 0, FO_NODE_BLEND = 1, FO_NODE_BLEND_BY_INDEX = 2, FO_NODE_BLEND_SPACE = 3 };
+enum { FO_ACTION_NONE = 0, FO_ACTION_REWIND = 1, FO_ACTION_ENABLE = 2, FO_ACTION_DISABLE = 3 };
+/* LogicNode, prefix encoded: PARAM p | AND a b | OR a b | XOR a b | NOT a | IS_ANIMATION_ENDED anim */
+enum { FO_LOGIC_PARAM = 0, FO_LOGIC_AND = 1, FO_LOGIC_OR = 2, FO_LOGIC_XOR = 3, FO_LOGIC_NOT = 4,
+       FO_LOGIC_IS_ANIMATION_ENDED = 5 };
+
+typedef struct fo_machine fo_machine;     /* Machine<T> */
+fo_machine* fo_machine_new(void);
+void fo_machine_free(fo_machine*);
+int fo_machine_add_parameter(fo_machine*, int kind, float f0, float f1, uint32_t u);
+void fo_machine_set_parameter(fo_machine*, int index, int kind, float f0, float f1, uint32_t u);
+int fo_machine_add_layer(fo_machine*, float weight);
+void fo_layer_set_weight(fo_machine*, int layer, float w);
+void fo_layer_set_mask(fo_machine*, int layer, const int* excluded_nodes, int n);
+int fo_layer_add_play(fo_machine*, int layer, int animation);
+int fo_layer_add_blend(fo_machine*, int layer, int n_inputs, const int* sources,
+                       const int* weight_params /* -1 = constant */, const float* weight_consts);
+int fo_layer_add_blend_by_index(fo_machine*, int layer, int index_param, int n_inputs,
+                                const int* sources, const float* blend_times);
+int fo_layer_add_blend_space(fo_machine*, int layer, int sampling_param, int n_points,
+                             const float* points_xy, const int* sources, int n_tris,
+                             const uint32_t* tris);
+int fo_layer_add_state(fo_machine*, int layer, int root_node);
+void fo_layer_set_entry_state(fo_machine*, int layer, int state);
+void fo_state_add_action(fo_machine*, int layer, int state, int on_enter, int kind, int animation);
+int fo_layer_add_transition(fo_machine*, int layer, int source, int dest, float time,
+                            const int* logic, int n_logic);
+int fo_layer_active_state(const fo_machine*, int layer);
+int fo_layer_active_transition(const fo_machine*, int layer);
+const fo_pose* fo_layer_pose(const fo_machine*, int layer);
+const fo_pose* fo_machine_pose(const fo_machine*);
+int fo_blend_space_fetch_weights(int n_points, const float* pts_xy, int n_tris, const uint32_t* tris,
+                                 const float sampling_point[2], int idx[3], float w[3]);
+const fo_pose* fo_machine_evaluate_pose(fo_machine*, fo_animation* const* anims, int n_anims, float dt);
+
 #ifdef __cplusplus
 }
 #endif

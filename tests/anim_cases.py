@@ -1,0 +1,199 @@
+"""Shared animation scenarios for the pose-path tests: each builds the SAME description for the oracle
+(oracle.AnimScene) and for the product (fyrox_amd.anim.Animator), plus a per-frame script of parameter
+changes.  Test infrastructure only."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from fyrox_amd import anim as A
+from fyrox_amd import synth
+
+
+@dataclass
+class AnimSpec:
+    tracks: int                      # index into Scenario.tracks_data
+    target: np.ndarray
+    enabled_tracks: Optional[np.ndarray] = None
+    time_slice: Tuple[float, float] = (0.0, 1.0)
+    speed: Optional[float] = None
+    looped: Optional[bool] = None
+    enabled: Optional[bool] = None
+
+
+@dataclass
+class Scenario:
+    name: str
+    rig: A.Rig
+    tracks_data: List[A.AnimationTracksData]
+    animations: List[AnimSpec]
+    machine: Optional[A.Machine] = None
+    # frame -> list of (parameter index, Parameter)
+    script: Dict[int, List[Tuple[int, A.Parameter]]] = field(default_factory=dict)
+    n_frames: int = 60
+    dt: float = 1.0 / 60.0
+    has_euler: bool = True
+
+
+def _partial(td: A.AnimationTracksData, target: np.ndarray, keep: Callable[[int, A.Track], bool]):
+    """Drop tracks (by bone / binding) to get clips that animate only part of the skeleton."""
+    tracks, tgt = [], []
+    for t, b in zip(td.tracks, target):
+        if keep(int(b), t):
+            tracks.append(t)
+            tgt.append(int(b))
+    return A.AnimationTracksData(tracks), np.asarray(tgt, np.int32)
+
+
+def c5_blend_tree(n_bones=64, seed=synth.SEED_BASE + 5, euler_every=2) -> Scenario:
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(4):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, euler_every=euler_every)
+        tds.append(td)
+        anims.append(AnimSpec(c, tgt, speed=[1.0, 0.8, 1.3, -0.7][c]))
+    return Scenario("c5_blend_tree", rig, tds, anims, synth.make_c5_machine(), has_euler=euler_every < 10 ** 6)
+
+
+def player_only(n_bones=32, seed=synth.SEED_BASE + 2, euler_every=2, key_kind=A.KEY_LINEAR) -> Scenario:
+    """C2-like: AnimationPlayer with two enabled clips (the second overrides part of the skeleton) and a
+    disabled one."""
+    rig = synth.make_rig(n_bones, seed, exotic=True)
+    td0, t0 = synth.make_clip(n_bones, seed, 0, euler_every=euler_every, key_kind=key_kind)
+    td1, t1 = synth.make_clip(n_bones, seed, 1, euler_every=euler_every, key_kind=key_kind)
+    td1, t1 = _partial(td1, t1, lambda b, t: b % 4 == 0 and t.binding != A.BIND_SCALE)
+    td2, t2 = synth.make_clip(n_bones, seed, 2, euler_every=euler_every, key_kind=key_kind)
+    anims = [AnimSpec(0, t0, speed=1.7), AnimSpec(1, t1, time_slice=(0.2, 0.9), looped=False, speed=2.5),
+             AnimSpec(2, t2, enabled=False)]
+    return Scenario("player_only", rig, [td0, td1, td2], anims, None, has_euler=euler_every < 10 ** 6)
+
+
+def transitions(n_bones=24, seed=synth.SEED_BASE + 7) -> Scenario:
+    """idle <-> walk on a Rule parameter, walk -> attack (one-shot, rewound on enter) on a second rule,
+    attack -> idle when the attack animation has ended."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, tgts = [], []
+    for c in range(3):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, euler_every=10 ** 9)  # quaternion tracks only: bit-exact
+        tds.append(td)
+        tgts.append(tgt)
+    anims = [AnimSpec(0, tgts[0]), AnimSpec(1, tgts[1], speed=1.5),
+             AnimSpec(2, tgts[2], looped=False, speed=4.0, time_slice=(0.0, 0.5))]
+    layer = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2)],
+        states=[A.State(0), A.State(1), A.State(2, on_enter_actions=[(A.ACTION_REWIND, 2)],
+                                               on_leave_actions=[(A.ACTION_DISABLE, 2), (A.ACTION_ENABLE, 2)])],
+        transitions=[A.Transition(0, 1, 0.15, ("parameter", 0)),
+                     A.Transition(1, 0, 0.2, ("not", ("parameter", 0))),
+                     A.Transition(1, 2, 0.1, ("and", ("parameter", 0), ("parameter", 1))),
+                     A.Transition(2, 0, 0.25, ("ended", 2))])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_RULE, False), A.Parameter(A.PARAM_RULE, False)], layers=[layer])
+    script = {5: [(0, A.Parameter(A.PARAM_RULE, True))], 30: [(1, A.Parameter(A.PARAM_RULE, True))],
+              33: [(1, A.Parameter(A.PARAM_RULE, False))], 70: [(0, A.Parameter(A.PARAM_RULE, False))]}
+    return Scenario("transitions", rig, tds, anims, m, script, n_frames=100, has_euler=False)
+
+
+def by_index(n_bones=16, seed=synth.SEED_BASE + 8) -> Scenario:
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(3):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, euler_every=10 ** 9)
+        tds.append(td)
+        anims.append(AnimSpec(c, tgt))
+    layer = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2),
+               A.BlendAnimationsByIndex(0, [A.IndexedBlendInput(0.1, 0), A.IndexedBlendInput(0.25, 1),
+                                            A.IndexedBlendInput(0.05, 2)])],
+        states=[A.State(3)])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_INDEX, 0)], layers=[layer])
+    script = {4: [(0, A.Parameter(A.PARAM_INDEX, 1))], 30: [(0, A.Parameter(A.PARAM_INDEX, 2))],
+              32: [(0, A.Parameter(A.PARAM_INDEX, 0))], 50: [(0, A.Parameter(A.PARAM_INDEX, 7))],
+              55: [(0, A.Parameter(A.PARAM_WEIGHT, 0.5))]}
+    return Scenario("by_index", rig, tds, anims, m, script, n_frames=64, has_euler=False)
+
+
+def blend_space(n_bones=16, seed=synth.SEED_BASE + 9) -> Scenario:
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(4):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, euler_every=10 ** 9)
+        tds.append(td)
+        anims.append(AnimSpec(c, tgt))
+    pts = [A.BlendSpacePoint((0.0, 0.0), 0), A.BlendSpacePoint((1.0, 0.0), 1), A.BlendSpacePoint((1.0, 1.0), 2),
+           A.BlendSpacePoint((0.0, 1.0), 3)]
+    layer = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2), A.PlayAnimation(3),
+               A.BlendSpace(0, pts, [(2, 0, 1), (3, 0, 2)])],   # the triangulation of test_blend_space_triangulation
+        states=[A.State(4)])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_SAMPLING_POINT, (0.25, 0.5))], layers=[layer])
+    script = {}
+    for f in range(0, 48):
+        x = 0.5 + 0.9 * np.cos(f * 0.21)   # wanders outside the unit square: nearest-edge branch
+        y = 0.5 + 0.9 * np.sin(f * 0.13)
+        script[f] = [(0, A.Parameter(A.PARAM_SAMPLING_POINT, (float(np.float32(x)), float(np.float32(y)))))]
+    return Scenario("blend_space", rig, tds, anims, m, script, n_frames=48, has_euler=False)
+
+
+def layered(n_bones=40, seed=synth.SEED_BASE + 10) -> Scenario:
+    """Two layers: full-body locomotion blend (weights from parameters, one of them mistyped) and an
+    upper-body layer (partial clip, layer mask, weight 0.6) -- exercises the copy rule for nodes a
+    pose does not contain, dropped bindings, masks and nested blends."""
+    rig = synth.make_rig(n_bones, seed, exotic=True)
+    td0, t0 = synth.make_clip(n_bones, seed, 0, euler_every=10 ** 9)
+    td1, t1 = synth.make_clip(n_bones, seed, 1, euler_every=10 ** 9)
+    td2, t2 = synth.make_clip(n_bones, seed, 2, euler_every=10 ** 9)
+    td2, t2 = _partial(td2, t2, lambda b, t: b >= n_bones // 2 and t.binding != A.BIND_POSITION)
+    td3, t3 = synth.make_clip(n_bones, seed, 3, euler_every=10 ** 9)
+    td3, t3 = _partial(td3, t3, lambda b, t: b % 3 != 0)
+    anims = [AnimSpec(0, t0), AnimSpec(1, t1, speed=1.2), AnimSpec(2, t2, speed=0.9), AnimSpec(3, t3, speed=-1.0)]
+    base = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(3),
+               A.BlendAnimations([A.BlendPose(2, 1.0), A.BlendPose(1, parameter=0)]),          # 3: partial first
+               A.BlendAnimations([A.BlendPose(0, 0.0), A.BlendPose(3, parameter=1), A.BlendPose(1, parameter=2)])],  # 4
+        states=[A.State(4)])
+    upper = A.MachineLayer(
+        nodes=[A.PlayAnimation(2), A.PlayAnimation(0), A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, 0.3)])],
+        states=[A.State(2)], weight=0.6, mask=list(range(0, n_bones // 2 + 3)))
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_WEIGHT, 0.35), A.Parameter(A.PARAM_WEIGHT, 0.8),
+                              A.Parameter(A.PARAM_RULE, True)],   # parameter 2 is mistyped -> weight 0.0
+                  layers=[base, upper])
+    script = {10: [(0, A.Parameter(A.PARAM_WEIGHT, 0.9))], 20: [(2, A.Parameter(A.PARAM_WEIGHT, 0.45))]}
+    return Scenario("layered", rig, [td0, td1, td2, td3], anims, m, script, n_frames=40, has_euler=False)
+
+
+ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered]
+
+
+# ---- builders -------------------------------------------------------------------------------------
+
+def build_oracle(orc, sc: Scenario):
+    s = orc.AnimScene(sc.rig)
+    for td in sc.tracks_data:
+        s.add_tracks_data(td)
+    for a in sc.animations:
+        s.add_animation(a.tracks, a.target, a.enabled_tracks, time_slice=a.time_slice, speed=a.speed,
+                        looped=a.looped, enabled=a.enabled)
+    if sc.machine is not None:
+        s.set_machine(sc.machine)
+    return s
+
+
+_next_id = [1000]
+
+
+def build_product(ctx, sc: Scenario, n_instances: int = 1) -> A.Animator:
+    base = _next_id[0]
+    _next_id[0] += 100
+    A.create_rig(ctx, base, sc.rig)
+    for i, td in enumerate(sc.tracks_data):
+        A.upload_tracks_data(ctx, base + 1 + i, td)
+    an = A.Animator(ctx, base, base, sc.rig, n_instances)
+    for a in sc.animations:
+        an.add_animation(base + 1 + a.tracks, a.target, a.enabled_tracks, time_slice=a.time_slice, speed=a.speed,
+                         looped=a.looped, enabled=a.enabled)
+    if sc.machine is not None:
+        an.set_machine(sc.machine)
+    an.base_id = base
+    return an
