@@ -75,7 +75,7 @@ __device__ float curve_value_at(const float* __restrict__ loc, const f4* __restr
     return interpolate_keys(loc, aux, lo > 0 ? lo - 1 : 0, lo, location);
 }
 
-// nalgebra leaves (operation order restated in oracle/fyrox_oracle.c)
+// nalgebra leaves, in nalgebra's operation order
 __device__ __forceinline__ float dot4(f4 a, f4 b) {
     float x = a.x * b.x, y = a.y * b.y;
     const float z = a.z * b.z, w = a.w * b.w;

@@ -231,8 +231,8 @@ def make_rig(n_bones: int, seed: int, chain_depth: int = 8, exotic: bool = False
 def make_clip(n_bones: int, seed: int, clip: int = 0, n_keys: int = 31, fps: float = 30.0,
               key_kind: int = 1, euler_every: int = 2):
     """AnimationTracksData with 3 tracks per bone (Position Vec3, Rotation, Scale Vec3), n_keys keys
-    at 1/fps spacing.  Rotation tracks are UnitQuaternion for bones with i % euler_every == 0
-    (glTF-like) and UnitQuaternionEuler otherwise (FBX-like).  Returns (tracks_data, track_target)."""
+    at 1/fps spacing.  Rotation tracks are UnitQuaternionEuler (FBX-like) for bones with
+    i % euler_every == euler_every - 1 and UnitQuaternion (glTF-like) otherwise; a huge euler_every means none.  Returns (tracks_data, track_target)."""
     from . import anim as A
     tag = f"clip{clip}"
     nk = n_keys
@@ -254,7 +254,7 @@ def make_clip(n_bones: int, seed: int, clip: int = 0, n_keys: int = 31, fps: flo
     tracks, target = [], []
     for b in range(n_bones):
         tracks.append(A.Track(A.BIND_POSITION, A.KIND_VEC3, [curve(pos[b, :, c], b, c) for c in range(3)]))
-        if b % euler_every == 0:
+        if euler_every <= 0 or b % euler_every != euler_every - 1:
             tracks.append(A.Track(A.BIND_ROTATION, A.KIND_QUAT, [curve(quat[b, :, c], b, 3 + c) for c in range(4)]))
         else:
             tracks.append(A.Track(A.BIND_ROTATION, A.KIND_QUAT_EULER, [curve(eul[b, :, c], b, 3 + c) for c in range(3)]))

@@ -1,0 +1,261 @@
+"""GPU parity of the pose path (through the C ABI) against the CPU oracle: keyframe sampling, pose
+folding (Machine / layers / transitions / pose nodes), apply, local matrices, hierarchy, palettes, and
+the end-to-end chain into the skinning kernel (BASELINE configs C2, C3-scaled, C5).
+
+Bar.  Everything is BIT-EXACT except values that depend on sin/cos of UnitQuaternionEuler tracks: libm's
+sinf/cosf are not reproducible bit-for-bit on a GPU (the kernel evaluates them in f64 and rounds), so
+Euler-driven rotations -- and what is computed from them -- are held to 1e-5 relative, the tolerance
+BASELINE.json's north_star states; scenarios without Euler tracks must match bit for bit.
+"""
+import numpy as np
+import pytest
+
+import fyrox_amd
+from fyrox_amd import anim as A
+from fyrox_amd import synth
+
+import anim_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+def rel_err(got, ref):
+    scale = max(float(np.abs(ref).max()), 1e-3)
+    return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) / scale
+
+
+def check(got, ref, exact, what):
+    assert got.shape == ref.shape, what
+    if exact:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{what}: max rel err {rel_err(got, ref):.3e}"
+    else:
+        assert rel_err(got, ref) <= REL_TOL, f"{what}: max rel err {rel_err(got, ref):.3e}"
+
+
+def check_pose(got, ref, exact, what):
+    """12-float pose records: present bits must match exactly; values per the bar."""
+    bits = ref[:, 3].view(np.uint32)
+    assert np.array_equal(got[:, 3].view(np.uint32), bits), f"{what}: present bits"
+    g, r = got.copy(), ref.copy()
+    for arr in (g, r):   # values of absent bindings are unspecified
+        arr[:, 3] = 0
+        arr[(bits & 1) == 0, 0:3] = 0
+        arr[(bits & 4) == 0, 4:8] = 0
+        arr[(bits & 2) == 0, 8:12] = 0
+    check(np.ascontiguousarray(g), np.ascontiguousarray(r), exact, what)
+
+
+def run_scenario(ctx, orc, sc, n_instances=1, frames=None, check_every=1):
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, n_instances)
+    exact = not sc.has_euler
+    frames = sc.n_frames if frames is None else frames
+    for f in range(frames):
+        for idx, par in sc.script.get(f, []):
+            o.set_parameter(idx, par)
+            p.set_parameter(idx, par)
+        if sc.machine is None:
+            o.update_animations(sc.dt)
+            p.update_animations(sc.dt)
+        else:
+            o.update_machine(sc.dt)
+            p.update_machine(sc.dt)
+        if f % check_every and f != frames - 1:
+            continue
+        for a in range(len(sc.animations)):
+            got = p.read(A.READ_ANIMATION_POSE + a)
+            ref = o.animation_pose(a)
+            for i in (0, n_instances - 1):
+                check_pose(got[i], ref, exact, f"{sc.name} frame {f} animation {a} pose (instance {i})")
+        trs, loc, glo = p.read(A.READ_LOCAL_TRS), p.read(A.READ_LOCAL_MATRIX), p.read(A.READ_GLOBAL_MATRIX)
+        for i in (0, n_instances - 1):
+            check(trs[i], o.node_trs(), exact, f"{sc.name} frame {f} node TRS")
+            check(loc[i], o.local_matrices(), exact, f"{sc.name} frame {f} local matrices")
+            check(glo[i], o.global_matrices(), exact, f"{sc.name} frame {f} global matrices")
+        if sc.machine is not None:
+            for li in range(len(sc.machine.layers)):
+                assert p.layer_state(li, n_instances - 1) == o.layer_state(li)
+    return o, p
+
+
+@pytest.mark.parametrize("make", cases.ALL, ids=lambda f: f.__name__)
+def test_scenario_matches_oracle(ctx, orc, make):
+    sc = make()
+    o, p = run_scenario(ctx, orc, sc, n_instances=3)
+    o.close()
+    p.free()
+
+
+def test_quaternion_only_blend_tree_is_bit_exact(ctx, orc):
+    sc = cases.c5_blend_tree(euler_every=10 ** 9)
+    assert not sc.has_euler
+    o, p = run_scenario(ctx, orc, sc, n_instances=2, frames=30)
+    o.close()
+    p.free()
+
+
+@pytest.mark.parametrize("kind", [A.KEY_CONSTANT, A.KEY_LINEAR, A.KEY_CUBIC])
+def test_key_kinds_sample_bit_exact(ctx, orc, kind):
+    sc = cases.player_only(euler_every=10 ** 9, key_kind=kind)
+    o, p = run_scenario(ctx, orc, sc, frames=40)
+    o.close()
+    p.free()
+
+
+def test_sampling_hints_with_duplicate_key_locations(ctx, orc):
+    """Duplicate key locations make Curve::value_at depend on the span hint carried between frames
+    (curve.rs:254-314): the device keeps one hint per (instance, animation, track, curve)."""
+    rig = synth.make_rig(4, 77)
+    keys = [A.CurveKey(0.0, 0.0), A.CurveKey(0.25, 1.0), A.CurveKey(0.25, 5.0), A.CurveKey(0.5, 2.0),
+            A.CurveKey(0.5, -3.0, A.KEY_CONSTANT), A.CurveKey(0.75, 4.0, A.KEY_CUBIC, 0.5, -0.25), A.CurveKey(1.0, 0.5)]
+    cv = lambda s: A.Curve([A.CurveKey(k.location, k.value * s, k.kind, k.left_tangent, k.right_tangent) for k in keys])
+    td = A.AnimationTracksData([A.Track(A.BIND_POSITION, A.KIND_VEC3, [cv(1.0), cv(-2.0), cv(0.5)])])
+    sc = cases.Scenario("dup_keys", rig, [td], [cases.AnimSpec(0, np.asarray([2], np.int32), speed=1.0)], None,
+                        n_frames=130, dt=1.0 / 64.0, has_euler=False)   # dt hits the duplicate locations exactly
+    o, p = run_scenario(ctx, orc, sc)
+    # and backwards, crossing the same keys with the hints left by the forward pass
+    p.set_speed(0, -1.0)
+    orc._alib().fo_animation_set_speed(o.anims[0], -1.0)
+    for f in range(70):
+        o.update_animations(sc.dt)
+        p.update_animations(sc.dt)
+        check_pose(p.read(A.READ_ANIMATION_POSE)[0], o.animation_pose(0), True, f"reverse frame {f}")
+    o.close()
+    p.free()
+
+
+def test_instances_diverge(ctx, orc):
+    """Per-instance state: different speeds / parameters per instance vs one oracle scene each."""
+    sc = cases.transitions()
+    n = 4
+    os_ = [cases.build_oracle(orc, sc) for _ in range(n)]
+    p = cases.build_product(ctx, sc, n)
+    for i in range(n):
+        p.set_speed(0, 0.5 + 0.5 * i, instance=i)
+        orc._alib().fo_animation_set_speed(os_[i].anims[0], 0.5 + 0.5 * i)
+    for f in range(60):
+        for i in range(n):
+            if f == 3 + 5 * i:     # each instance starts walking at a different frame
+                par = A.Parameter(A.PARAM_RULE, True)
+                p.set_parameter(0, par, instance=i)
+                os_[i].set_parameter(0, par)
+            os_[i].update_machine(sc.dt)
+        p.update_machine(sc.dt)
+        trs = p.read(A.READ_LOCAL_TRS)
+        for i in range(n):
+            check(trs[i], os_[i].node_trs(), True, f"frame {f} instance {i}")
+            assert p.layer_state(0, i) == os_[i].layer_state(0)
+    for o in os_:
+        o.close()
+    p.free()
+
+
+def test_set_local_trs_places_instances(ctx, orc):
+    sc = cases.by_index()
+    n = 5
+    p = cases.build_product(ctx, sc, n)
+    os_ = [cases.build_oracle(orc, sc) for _ in range(n)]
+    trs = np.zeros((n, 10), np.float32)
+    trs[:, 0] = np.arange(n) * 3.0
+    trs[:, 2] = -np.arange(n)
+    trs[:, 3:7] = (0.0, 0.38268343, 0.0, 0.92387953)
+    trs[:, 7:10] = 1.0
+    node = 1   # by_index animates every node; pick one and re-place it after the update
+    p.update_machine(sc.dt)
+    p.set_local_trs(node, trs[1:], first_instance=1)
+    p.update_transforms()
+    glo = p.read(A.READ_GLOBAL_MATRIX)
+    for i in range(n):
+        os_[i].update_machine(sc.dt)
+        if i >= 1:
+            os_[i].set_local_trs(node, trs[i])
+        check(glo[i], os_[i].global_matrices(), True, f"instance {i}")
+    for o in os_:
+        o.close()
+    p.free()
+
+
+# ---- end to end: pose -> palette -> skinning ---------------------------------------------------
+
+def _skin_chain(ctx, orc, sc, mesh, n_instances, frames, bone_nodes, exact):
+    o, p = run_scenario(ctx, orc, sc, n_instances=n_instances, frames=frames, check_every=10 ** 9)
+    base = p.base_id
+    A.create_bone_list(ctx, base + 50, base, bone_nodes)
+    nb = len(bone_nodes)
+    d_pal = ctx.malloc(n_instances * nb * 64)
+    p.palette(base + 50, d_pal.ptr)
+    pal = d_pal.download(np.float32, n_instances * nb * 16).reshape(n_instances, nb, 16)
+    ref_pal = o.palette(bone_nodes)
+    for i in (0, n_instances - 1):
+        check(pal[i], ref_pal, exact, "palette")
+    ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    nv = mesh.n_verts * n_instances
+    d_pos, d_nrm, d_tan = ctx.malloc(nv * 12), ctx.malloc(nv * 12), ctx.malloc(nv * 16)
+    ctx.lbs_skin_device(base + 60, d_pal.ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+    ctx.join()
+    got = {"pos": d_pos.download(np.float32, nv * 3).reshape(n_instances, -1, 3),
+           "normal": d_nrm.download(np.float32, nv * 3).reshape(n_instances, -1, 3),
+           "tangent": d_tan.download(np.float32, nv * 4).reshape(n_instances, -1, 4)}
+    ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, ref_pal, mesh.normal, mesh.tangent, threads=0)
+    for k in ("pos", "normal", "tangent"):
+        for i in (0, n_instances - 1):
+            check(got[k][i], ref[k], exact, f"skinned {k} (instance {i})")
+    if exact:
+        # the skinning kernel itself is bit-exact given the GPU-built palette
+        ref2 = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal[0], mesh.normal, mesh.tangent, threads=0)
+        assert np.array_equal(got["pos"][0], ref2["pos"])
+    for b in (d_pal, d_pos, d_nrm, d_tan):
+        b.free()
+    ctx.mesh_free(base + 60)
+    o.close()
+    p.free()
+
+
+def test_c2_character_50k_verts_64_bones_one_clip(ctx, orc):
+    """BASELINE C2: one character, 50k verts / 64 bones / 1 clip: player -> palette -> LBS vs CPU (1e-5)."""
+    n_bones = 64
+    rig = synth.make_rig(n_bones, synth.SEED_BASE + 2)
+    td, tgt = synth.make_clip(n_bones, synth.SEED_BASE + 2, 0)
+    sc = cases.Scenario("c2", rig, [td], [cases.AnimSpec(0, tgt)], None, n_frames=20)
+    mesh = synth.make_mesh(50_000, n_bones, synth.SEED_BASE + 2)
+    _skin_chain(ctx, orc, sc, mesh, 1, 20, list(range(n_bones)), exact=False)
+
+
+def test_c5_machine_four_clip_blend_tree_100k_verts(ctx, orc):
+    """BASELINE C5: Machine 4-clip blend tree -> palette -> 100k-vert LBS, end-to-end f32 tolerance vs CPU."""
+    sc = cases.c5_blend_tree(n_bones=64)
+    mesh = synth.make_mesh(100_000, 64, synth.SEED_BASE + 5)
+    _skin_chain(ctx, orc, sc, mesh, 1, 60, list(range(64)), exact=False)
+
+
+def test_c5_quaternion_tracks_end_to_end_bit_exact(ctx, orc):
+    sc = cases.c5_blend_tree(n_bones=64, euler_every=10 ** 9)
+    mesh = synth.make_mesh(20_000, 64, synth.SEED_BASE + 5)
+    _skin_chain(ctx, orc, sc, mesh, 1, 25, list(range(64)), exact=True)
+
+
+def test_c3_crowd_instances_from_pose_to_vertices(ctx, orc):
+    """Scaled C3: 48 instances x 10k verts / 64 bones, per-instance palettes built on the GPU and consumed
+    by the instanced skinning launch without leaving HBM.  Bones are a subset with an invalid handle."""
+    sc = cases.layered(n_bones=64)
+    mesh = synth.make_mesh(10_000, 32, synth.SEED_BASE + 3)
+    bone_nodes = [2 * b for b in range(32)]
+    bone_nodes[5] = -1   # Handle::NONE -> identity matrix (scene/mesh/mod.rs:789-791)
+    _skin_chain(ctx, orc, sc, mesh, 48, 12, bone_nodes, exact=True)
+
+
+def test_large_rig_1024_nodes(ctx, orc):
+    """The LDS-resident hierarchy walk at its upper limit (1024 nodes = 128 KiB of LDS), deep chains."""
+    n = 1024
+    rig = synth.make_rig(n, 99, chain_depth=200, exotic=True)
+    td, tgt = synth.make_clip(n, 99, 0, n_keys=5, euler_every=10 ** 9)
+    sc = cases.Scenario("big", rig, [td], [cases.AnimSpec(0, tgt, time_slice=(0.0, 4 / 30))], None, n_frames=3,
+                        has_euler=False)
+    o, p = run_scenario(ctx, orc, sc, n_instances=2)
+    o.close()
+    p.free()
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        A.create_rig(ctx, 31337, synth.make_rig(1025, 1))
+    assert e.value.code == fyrox_amd._native.FYX_ERR_UNSUPPORTED
