@@ -127,3 +127,28 @@ def test_track_fetch_kinds(orc, kind, ncurves, expect_len):
         assert short is None
     if kind == 5:  # from_quaternion normalises
         assert abs(np.linalg.norm(vals) - 1.0) < 1e-6
+
+
+def test_blend_space_fetch_weights(orc, golden):
+    # machine/node/blendspace.rs:486-537: exact (usize, f32) triples
+    for case in golden["blend_space_fetch_weights"]["cases"]:
+        got = orc.blend_space_fetch_weights(np.asarray(case["points"], np.float32).reshape(-1, 2),
+                                            np.asarray(case["triangles"], np.uint32).reshape(-1, 3),
+                                            case["sampling_point"])
+        want = None if case["expected"] is None else [tuple(x) for x in case["expected"]]
+        assert got == want, case
+
+
+def test_blend_space_triangulated_square(orc, golden):
+    # with the reference's own triangulation of the unit square (blendspace.rs:455-484): barycentric
+    # weights inside a triangle sum to 1, and a point outside projects onto the nearest edge
+    g = golden["blend_space_triangulation"]
+    pts, tri = np.asarray(g["points"], np.float32), np.asarray(g["triangles"], np.uint32)
+    w = orc.blend_space_fetch_weights(pts, tri, (0.75, 0.25))
+    assert [i for i, _ in w] == [2, 0, 1] and abs(sum(x for _, x in w) - 1.0) < 1e-6
+    w = orc.blend_space_fetch_weights(pts, tri, (0.25, 0.75))
+    assert [i for i, _ in w] == [3, 0, 2] and abs(sum(x for _, x in w) - 1.0) < 1e-6
+    w = orc.blend_space_fetch_weights(pts, tri, (0.5, -2.0))   # below the bottom edge 0-1
+    assert sorted((w[0][0], w[1][0])) == [0, 1] and w[2] == (w[1][0], 0.0)
+    assert w[0][1] == 0.5 and w[1][1] == 0.5
+    assert orc.blend_space_fetch_weights(pts, tri, (5.0, 5.0)) is None  # no edge contains the projection

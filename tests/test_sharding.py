@@ -1,0 +1,86 @@
+"""Multi-GPU sharding of the skinning path on CPU: world_size-2 (and 3) `gloo` process groups.
+
+Each rank skins ITS vertex range with the oracle (the checker standing in for the per-GPU kernel; the
+GPU kernel's own parity is tests/test_lbs_gpu.py), the ranks all-gather the skinned streams through
+fyrox_amd.sharding, and every rank must hold exactly the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from fyrox_amd import sharding, synth
+
+
+def test_vertex_ranges_tile_the_mesh():
+    for n in (0, 1, 255, 256, 257, 1000, 50_000, 1_000_000, 1_000_001):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                b, e = sharding.vertex_range(n, r, world)
+                assert b == prev and e >= b
+                assert b % sharding.VERTEX_ALIGN == 0 or b == n
+                prev = e
+            assert prev == n
+    sizes = sharding.shard_sizes(1_000_000, 8)
+    assert sum(sizes) == 1_000_000 and max(sizes) - min(sizes) <= sharding.VERTEX_ALIGN
+    with pytest.raises(ValueError):
+        sharding.vertex_range(10, 2, 2)
+
+
+def test_instance_ranges_tile_the_crowd():
+    for n in (0, 1, 7, 1000):
+        for world in (1, 2, 4, 8):
+            rs = [sharding.instance_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, n_verts: int, n_bones: int, q):
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seed = synth.SEED_BASE + 4
+        mesh = synth.make_mesh(n_verts, n_bones, seed)          # every rank can build the inputs ...
+        pal = torch.from_numpy(synth.make_palette(n_bones, seed) if rank == 0
+                               else np.zeros((n_bones, 16), np.float32))
+        sharding.broadcast_palette(dist, pal, src=0)             # ... but only rank 0 owns the pose
+        b, e = sharding.vertex_range(n_verts, rank, world)       # this rank holds ONLY its slice
+        out = oracle.lbs_skin(mesh.pos[b:e], mesh.weights[b:e], mesh.indices[b:e], pal.numpy(),
+                              mesh.normal[b:e], mesh.tangent[b:e])
+        full = {k: sharding.all_gather_stream(dist, torch.from_numpy(out[k]), n_verts, out[k].shape[1], rank, world).numpy()
+                for k in ("pos", "normal", "tangent")}
+        ref = oracle.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal.numpy(), mesh.normal, mesh.tangent)
+        ok = all(np.array_equal(full[k], ref[k]) for k in ref)
+        q.put((rank, ok, (b, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_verts", [(2, 10_000), (2, 4097), (3, 1000)])
+def test_sharded_skinning_all_gathers_to_the_single_process_result(world, n_verts):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_verts, 64, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in results) == list(range(world))
+    assert all(ok for _, ok, _ in results)
+    ranges = sorted(rg for _, _, rg in results)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n_verts
