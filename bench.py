@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (e.g. lbs.prefetch=0)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity spot-check before timing")
+    ap.add_argument("--no-serialized", action="store_true",
+                    help="skip the extra single-stream timing (roofline.serialized)")
     return ap.parse_args()
 
 
@@ -108,7 +110,9 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    opts = {k: ctx.get_option(k) for k in ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams")}
+    opts = {k: ctx.get_option(k) for k in ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams", "lbs.range_stage")}
+    from fyrox_amd import sharding
+    shard = sharding.vertex_range(world * args.verts, rank, world)   # this rank's slice of the N x 1M scene
 
     # ---- synthetic inputs; each rank owns a different vertex-range shard --------
     seed = synth.SEED_BASE + 4
@@ -181,10 +185,27 @@ def main():
     gpu_ms = ctx.timer_end()                 # second hipEvent after a GPU-side join of all launch streams
     barrier()
     elapsed = time.perf_counter() - t0
+    # Same launches serialized on ONE stream (outside the timed region above): there the HIP-event
+    # average per launch IS the kernel's duration as rocprofv3 --kernel-trace reports it; with the
+    # default two launch streams consecutive kernels overlap pairwise, so the trace shows ~2x longer
+    # kernels while the device retires one launch every `avg_launch_us`.
+    serial_us = None
+    if not args.no_serialized and gathered is None:
+        n_ser = max(200, min(args.steps, 1000))
+        ctx.set_option("lbs.streams", 1)
+        for i in range(50):
+            step(i)
+        ctx.sync()
+        ctx.timer_begin()
+        for i in range(n_ser):
+            step(i)
+        serial_us = ctx.timer_end() * 1e3 / n_ser
+        ctx.set_option("lbs.streams", opts["lbs.streams"])
     if dist is not None:
-        t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, gpu_ms, serial_us or 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, gpu_ms = float(t[0]), float(t[1])
+        serial_us = float(t[2]) or None
 
     if rank == 0:
         total_verts = float(world) * nv * args.steps
@@ -207,11 +228,17 @@ def main():
                                    f"{args.sets} rotating 100 MB buffer sets, "
                                    f"{'random' if args.random_bones else 'spatially coherent'} bone indices",
                        "sharding": "contiguous vertex range per GPU, palette replicated" + (", + RCCL all-gather" if gathered else ""),
+                       "rank0_vertex_range": list(shard),
                        "kernel_options": opts},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": KERNEL_NAME, "avg_launch_us": launch_us,
-                         "algorithmic_bytes_per_launch": BYTES_PER_VERTEX * nv},
+                         "algorithmic_bytes_per_launch": BYTES_PER_VERTEX * nv,
+                         "launch_streams": opts["lbs.streams"],
+                         "serialized": None if serial_us is None else {
+                             "avg_launch_us": serial_us, "achieved": BYTES_PER_VERTEX * nv / (serial_us * 1e-6) / 1e9,
+                             "frac": BYTES_PER_VERTEX * nv / (serial_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                             "note": "one launch stream: kernels do not overlap, avg_launch_us == rocprofv3 kernel duration"}},
             "parity": parity,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -386,7 +386,7 @@ class Animator:
         times = np.zeros((self.n_instances, na), np.float32)
         ticked = np.zeros((self.n_instances, na), np.uint8)
         off = np.zeros(self.n_instances + 1, np.uint32)
-        cap = 4096
+        cap = max(4096, 128 * self.n_instances)
         ops = np.zeros((cap, 2), np.uint32)
         n = c_uint32()
         self._check(self._l.fyx_animator_plan(self._h, self.id, mode, dt, _ptr(times), _ptr(ticked), _ptr(off),

@@ -11,10 +11,10 @@
 // Hardware mapping (HBM-bound stream: 60 B read + 40 B written per vertex, ~300 VALU):
 //   * inputs/outputs are attribute streams in HBM; every lane access is 12- or 16-byte and
 //     lanes are contiguous, so each wave instruction covers one dense 768 B / 1 KiB span;
-//   * the bone palette of the current instance is staged ONCE per workgroup into LDS,
-//     transposed to three float4 rows per bone (48-byte stride: 3 is coprime with the 16
-//     b128 slots, so a random bone gather spreads over all LDS banks) + a separate row-3
-//     array that only the projective (non-affine) path reads;
+//   * the bone palette of the current instance is staged ONCE per workgroup into LDS as
+//     three float4 per bone laid out for packed-f32 math (see stage_palette; 48-byte stride:
+//     3 is coprime with the 16 b128 slots, so a random bone gather spreads over all LDS
+//     banks) + a separate row-3 array that only the projective (non-affine) path reads;
 //   * persistent grid (blocks_per_cu x 256 CUs), each workgroup owns a contiguous range of
 //     vertex chunks, re-staging the palette only when the instance changes (crowds);
 //   * vertex loads of a chunk are issued BEFORE the palette staging barrier so the HBM
@@ -52,17 +52,30 @@ __device__ __forceinline__ void st3(float* p, float x, float y, float z) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Palette staging: global column-major mat4 -> LDS rows.  rows[b*3+r] = (m_r0, m_r1, m_r2, t_r),
-// row3[b] = (m30, m31, m32, m33).  Returns (per thread) whether any staged matrix is projective.
+// Palette staging: global column-major mat4 -> three float4 per bone in LDS, arranged for
+// PACKED f32 math (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 work on register pairs and can
+// broadcast either half of a pair):
+//     A = (m00, m10, m01, m11)   B = (m02, m12, t0, t1)   C = (m20, m21, m22, t2)
+// so the x and y rows of a matrix sit side by side in a 64-bit register pair
+//   (pos.x, pos.y) = ((A.lo*px + A.hi*py) + B.lo*pz) + B.hi           3 pk_mul + 3 pk_add
+// while a single coefficient m_rk is the lo or hi half of one of those pairs, so normal and
+// tangent are transformed together as the pair (n_r, t_r) = (m_r0*(nx,tx) + m_r1*(ny,ty)) +
+// m_r2*(nz,tz) with the coefficient broadcast by op_sel -- no register shuffling.  Every output
+// component keeps exactly the reference's operation order (each pk instruction rounds its two
+// lanes independently), so the packed EXACT path stays bit-identical to the CPU loop while
+// issuing ~half the VALU instructions of the scalar form.
+// row3[b] = (m30, m31, m32, m33) is only read by the projective path.
+// Returns (per thread) whether any staged matrix is projective.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool stage_palette(const float* __restrict__ pal, uint32_t n_bones,
-                                              f32x4* rows, f32x4* row3, int tid, int nthreads) {
+__device__ __forceinline__ bool stage_palette(const float* __restrict__ pal, uint32_t b_begin,
+                                              uint32_t b_end, f32x4* rows, f32x4* row3, int tid,
+                                              int nthreads) {
     bool projective = false;
-    for (uint32_t b = tid; b < n_bones; b += nthreads) {
+    for (uint32_t b = b_begin + tid; b < b_end; b += nthreads) {
         const f32x4* m = reinterpret_cast<const f32x4*>(pal + (size_t)b * 16);
         f32x4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
-        rows[b * 3 + 0] = f32x4{c0.x, c1.x, c2.x, c3.x};
-        rows[b * 3 + 1] = f32x4{c0.y, c1.y, c2.y, c3.y};
+        rows[b * 3 + 0] = f32x4{c0.x, c0.y, c1.x, c1.y};
+        rows[b * 3 + 1] = f32x4{c2.x, c2.y, c3.x, c3.y};
         rows[b * 3 + 2] = f32x4{c0.z, c1.z, c2.z, c3.z};
         row3[b] = f32x4{c0.w, c1.w, c2.w, c3.w};
         projective |= !(c0.w == 0.0f && c1.w == 0.0f && c2.w == 0.0f && c3.w == 1.0f);
@@ -70,69 +83,100 @@ __device__ __forceinline__ bool stage_palette(const float* __restrict__ pal, uin
     return projective;
 }
 
-// mat3 rows * v, reference order.
+// mat3 rows * v, reference order ((m0*x + m1*y) + m2*z); used by the projective normaliser.
 template <bool EXACT>
 __device__ __forceinline__ float dot3(f32x4 r, float x, float y, float z) {
     if constexpr (EXACT) return (r.x * x + r.y * y) + r.z * z;
     else return __builtin_fmaf(r.z, z, __builtin_fmaf(r.y, y, r.x * x));
+}
+
+// (a*x + b*y) + c*z on pairs; fused: fma(c, z, fma(b, y, a*x)).
+template <bool EXACT>
+__device__ __forceinline__ f32x2 dot3p(f32x2 a, f32x2 x, f32x2 b, f32x2 y, f32x2 c, f32x2 z) {
+    if constexpr (EXACT) return (a * x + b * y) + c * z;
+    else return __builtin_elementwise_fma(c, z, __builtin_elementwise_fma(b, y, a * x));
+}
+template <bool EXACT>
+__device__ __forceinline__ f32x2 accp(f32x2 a, f32x2 r, f32x2 w) {
+    if constexpr (EXACT) return a + r * w;
+    else return __builtin_elementwise_fma(r, w, a);
 }
 template <bool EXACT>
 __device__ __forceinline__ float acc(float a, float r, float w) {
     if constexpr (EXACT) return a + r * w;
     else return __builtin_fmaf(r, w, a);
 }
+__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
 
 struct Skinned {
     float px, py, pz, nx, ny, nz, tx, ty, tz;
 };
 
 // One vertex, four influences.  MASK bit0 position, bit1 normal, bit2 tangent.
+template <bool EXACT, int MASK, bool PROJ>
+__device__ __forceinline__ Skinned skin_vertex_impl(const f32x4* __restrict__ rows,
+                                               const f32x4* __restrict__ row3,
+                                               uint32_t id, f32x4 w, float px, float py, float pz,
+                                               float nx, float ny, float nz, float tx, float ty,
+                                               float tz) {
+    f32x2 o_pxy = {0.f, 0.f}, o_x = {0.f, 0.f}, o_y = {0.f, 0.f}, o_z = {0.f, 0.f};  // o_r = (n_r, t_r)
+    float o_pz = 0.f;
+    const f32x2 vx = {nx, tx}, vy = {ny, ty}, vz = {nz, tz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = (id >> (8 * k)) & 0xffu;
+        const float wk = w[k];
+        const f32x4 A = rows[b * 3 + 0];
+        const f32x4 B = rows[b * 3 + 1];
+        const f32x4 C = rows[b * 3 + 2];
+        if constexpr (MASK & 1) {
+            f32x2 xy;
+            float z;
+            if constexpr (EXACT) {
+                xy = dot3p<true>(A.xy, splat(px), A.zw, splat(py), B.xy, splat(pz)) + B.zw;
+                z = ((C.x * px + C.y * py) + C.z * pz) + C.w;
+            } else {
+                xy = __builtin_elementwise_fma(
+                    B.xy, splat(pz),
+                    __builtin_elementwise_fma(A.zw, splat(py), __builtin_elementwise_fma(A.xy, splat(px), B.zw)));
+                z = __builtin_fmaf(C.z, pz, __builtin_fmaf(C.y, py, __builtin_fmaf(C.x, px, C.w)));
+            }
+            if constexpr (PROJ) {
+                const f32x4 r3 = row3[b];
+                const float n = dot3<EXACT>(r3, px, py, pz) + r3.w;
+                if (n != 0.0f) { xy.x = xy.x / n; xy.y = xy.y / n; z = z / n; }
+            }
+            o_pxy = accp<EXACT>(o_pxy, xy, splat(wk));
+            o_pz = acc<EXACT>(o_pz, z, wk);
+        }
+        if constexpr ((MASK & 6) != 0) {
+            // (n_r, t_r) for r = x, y, z; with only one of the two streams present the other lane
+            // carries zeros and is never stored.
+            const f32x2 rx = dot3p<EXACT>(splat(A.x), vx, splat(A.z), vy, splat(B.x), vz);
+            const f32x2 ry = dot3p<EXACT>(splat(A.y), vx, splat(A.w), vy, splat(B.y), vz);
+            const f32x2 rz = dot3p<EXACT>(splat(C.x), vx, splat(C.y), vy, splat(C.z), vz);
+            o_x = accp<EXACT>(o_x, rx, splat(wk));
+            o_y = accp<EXACT>(o_y, ry, splat(wk));
+            o_z = accp<EXACT>(o_z, rz, splat(wk));
+        }
+    }
+    Skinned o;
+    o.px = o_pxy.x; o.py = o_pxy.y; o.pz = o_pz;
+    o.nx = o_x.x; o.ny = o_y.x; o.nz = o_z.x;
+    o.tx = o_x.y; o.ty = o_y.y; o.tz = o_z.y;
+    return o;
+}
+
+// `projective` is workgroup-uniform: the affine path (the only kind of palette Fyrox produces)
+// is one straight-line block of packed math; the homogeneous divide lives in its own copy.
 template <bool EXACT, int MASK>
 __device__ __forceinline__ Skinned skin_vertex(const f32x4* __restrict__ rows,
                                                const f32x4* __restrict__ row3, bool projective,
                                                uint32_t id, f32x4 w, float px, float py, float pz,
                                                float nx, float ny, float nz, float tx, float ty,
                                                float tz) {
-    Skinned o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t b = (id >> (8 * k)) & 0xffu;
-        const float wk = w[k];
-        const f32x4 r0 = rows[b * 3 + 0];
-        const f32x4 r1 = rows[b * 3 + 1];
-        const f32x4 r2 = rows[b * 3 + 2];
-        if constexpr (MASK & 1) {
-            float x, y, z;
-            if constexpr (EXACT) {
-                x = dot3<true>(r0, px, py, pz) + r0.w;
-                y = dot3<true>(r1, px, py, pz) + r1.w;
-                z = dot3<true>(r2, px, py, pz) + r2.w;
-            } else {
-                x = __builtin_fmaf(r0.z, pz, __builtin_fmaf(r0.y, py, __builtin_fmaf(r0.x, px, r0.w)));
-                y = __builtin_fmaf(r1.z, pz, __builtin_fmaf(r1.y, py, __builtin_fmaf(r1.x, px, r1.w)));
-                z = __builtin_fmaf(r2.z, pz, __builtin_fmaf(r2.y, py, __builtin_fmaf(r2.x, px, r2.w)));
-            }
-            if (projective) {  // workgroup-uniform
-                const f32x4 r3 = row3[b];
-                const float n = dot3<EXACT>(r3, px, py, pz) + r3.w;
-                if (n != 0.0f) { x = x / n; y = y / n; z = z / n; }
-            }
-            o.px = acc<EXACT>(o.px, x, wk);
-            o.py = acc<EXACT>(o.py, y, wk);
-            o.pz = acc<EXACT>(o.pz, z, wk);
-        }
-        if constexpr (MASK & 2) {
-            o.nx = acc<EXACT>(o.nx, dot3<EXACT>(r0, nx, ny, nz), wk);
-            o.ny = acc<EXACT>(o.ny, dot3<EXACT>(r1, nx, ny, nz), wk);
-            o.nz = acc<EXACT>(o.nz, dot3<EXACT>(r2, nx, ny, nz), wk);
-        }
-        if constexpr (MASK & 4) {
-            o.tx = acc<EXACT>(o.tx, dot3<EXACT>(r0, tx, ty, tz), wk);
-            o.ty = acc<EXACT>(o.ty, dot3<EXACT>(r1, tx, ty, tz), wk);
-            o.tz = acc<EXACT>(o.tz, dot3<EXACT>(r2, tx, ty, tz), wk);
-        }
-    }
-    return o;
+    if (projective) return skin_vertex_impl<EXACT, MASK, true>(rows, row3, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
+    return skin_vertex_impl<EXACT, MASK, false>(rows, row3, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -172,7 +216,7 @@ __device__ __forceinline__ VertexIn<MASK> load_vertex(const LbsArgs& a, uint32_t
     return r;
 }
 
-template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK>
+template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK, bool RANGE>
 __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_inst,
                                                   uint32_t total_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -200,8 +244,29 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         VertexIn<MASK> cur;
         if (u < seg_e) cur = load_vertex<NT, MASK>(a, v < a.n_verts ? v : 0);
 
+        // Bones this segment's vertices can reference: [lo, hi].  Every wave reduces the (few)
+        // per-unit ranges of the segment on its own -- one tiny coalesced load and a DPP
+        // reduction, no LDS, no barrier -- and all waves arrive at the same answer.
+        uint32_t b_lo = 0, b_hi = a.n_bones;
+        if (RANGE && a.unit_range) {
+            uint32_t lo = 255u, hi = 0u;
+            for (uint32_t uu = seg_b + lane; uu < seg_e; uu += 64) {
+                const uint32_t r = a.unit_range[uu];
+                lo = min(lo, r & 0xffu);
+                hi = max(hi, r >> 8);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+                hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+            }
+            b_lo = lo;
+            b_hi = min(hi + 1u, a.n_bones);
+            if (b_lo > b_hi) b_lo = b_hi;
+        }
+
         if (inst != inst_first) __syncthreads();  // every wave is done with the previous palette
-        const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, rows,
+        const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, b_lo, b_hi, rows,
                                       row3, tid, BLOCK);
         const bool projective = __syncthreads_or(pj) != 0;
 
@@ -246,8 +311,12 @@ static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s
     const uint32_t max_useful = (total + (BLOCK / 64) - 1) / (BLOCK / 64);
     if (grid > max_useful) grid = max_useful;
     const size_t lds = (size_t)a.n_bones * 64;
-    hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
-                       upi, total);
+    if (t.range_stage && a.unit_range)
+        hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK, true>), dim3(grid), dim3(BLOCK), lds,
+                           s, a, upi, total);
+    else
+        hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK, false>), dim3(grid), dim3(BLOCK), lds,
+                           s, a, upi, total);
     return hipGetLastError();
 }
 
@@ -350,6 +419,39 @@ __global__ __launch_bounds__(256) void max_bone_index_kernel(const uint32_t* __r
     if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));  // one per block
 }
 
+// Bone-index range of every 64-vertex unit (computed once per upload): one wave per unit.
+__global__ __launch_bounds__(256) void unit_bone_range_kernel(const uint32_t* __restrict__ idx,
+                                                              uint32_t n_verts, uint32_t n_units,
+                                                              uint16_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t u = blockIdx.x * 4 + (threadIdx.x >> 6); u < n_units; u += gridDim.x * 4) {
+        const uint32_t v = u * 64 + lane;
+        uint32_t lo = 255u, hi = 0u;
+        if (v < n_verts) {
+            const uint32_t id = idx[v];
+            const uint32_t b0 = id & 0xffu, b1 = (id >> 8) & 0xffu, b2 = (id >> 16) & 0xffu, b3 = id >> 24;
+            lo = min(min(b0, b1), min(b2, b3));
+            hi = max(max(b0, b1), max(b2, b3));
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+        }
+        if (lane == 0) out[u] = (uint16_t)(lo | (hi << 8));
+    }
+}
+
+hipError_t launch_unit_bone_range(const uint32_t* d_idx, uint32_t n_verts, uint16_t* d_out,
+                                  hipStream_t stream) {
+    const uint32_t n_units = (n_verts + 63) / 64;
+    if (n_units == 0) return hipSuccess;
+    uint32_t grid = (n_units + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(unit_bone_range_kernel, dim3(grid), dim3(256), 0, stream, d_idx, n_verts, n_units,
+                       d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32_t* d_out,
                                  hipStream_t stream) {
     hipError_t e = hipMemsetAsync(d_out, 0, sizeof(uint32_t), stream);
@@ -400,7 +502,7 @@ __global__ __launch_bounds__(kAabbBlock) void skinned_aabb_kernel(LbsArgs a, flo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
-    const bool pj = stage_palette(a.palette, a.n_bones, rows, row3, threadIdx.x, kAabbBlock);
+    const bool pj = stage_palette(a.palette, 0, a.n_bones, rows, row3, threadIdx.x, kAabbBlock);
     const bool projective = __syncthreads_or(pj) != 0;
     float mn[3] = {__FLT_MAX__, __FLT_MAX__, __FLT_MAX__};
     float mx[3] = {-__FLT_MAX__, -__FLT_MAX__, -__FLT_MAX__};

@@ -13,7 +13,10 @@ for sub, name in (("trace", f"{tag}_bench_streams2_kernel_stats.csv"), ("trace_s
     p = os.path.join(src, sub, "bench_kernel_stats.csv")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))
-for f in ("bench_plain.json", "bench_under_trace.json", "bench_under_trace_s1.json"):
+p = os.path.join(src, "trace_pose", "pose_kernel_stats.csv")
+if os.path.exists(p):
+    shutil.copy(p, os.path.join(dst, f"{tag}_crowd_pose_kernel_stats.csv"))
+for f in ("bench_plain.json", "bench_under_trace.json", "bench_under_trace_s1.json", "pose_plain.json", "pose_under_trace.json"):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
