@@ -103,8 +103,7 @@ int alloc_mesh(fyx_ctx* c, Mesh& m, uint32_t n, bool has_nrm, bool has_tan) {
     const size_t b_pos = align_up(np * 12, 256), b_nrm = has_nrm ? b_pos : 0;
     const size_t b_tan = has_tan ? align_up(np * 16, 256) : 0, b_wgt = align_up(np * 16, 256);
     const size_t b_idx = align_up(np * 4, 256);
-    const size_t b_rng = align_up((np / 64 + 1) * 2, 256);
-    const size_t total = b_pos + b_nrm + b_tan + b_wgt + b_idx + b_rng;
+    const size_t total = b_pos + b_nrm + b_tan + b_wgt + b_idx;
     void* blk = nullptr;
     FYX_HIP(c, hipMalloc(&blk, total));
     hipError_t e = hipMemsetAsync(blk, 0, total, c->stream);
@@ -116,14 +115,12 @@ int alloc_mesh(fyx_ctx* c, Mesh& m, uint32_t n, bool has_nrm, bool has_tan) {
     m.nrm = has_nrm ? reinterpret_cast<float*>(p) : nullptr; p += b_nrm;
     m.tan = has_tan ? reinterpret_cast<float*>(p) : nullptr; p += b_tan;
     m.wgt = reinterpret_cast<float*>(p); p += b_wgt;
-    m.idx = reinterpret_cast<uint32_t*>(p); p += b_idx;
-    m.unit_range = reinterpret_cast<uint16_t*>(p);
+    m.idx = reinterpret_cast<uint32_t*>(p);
     return FYX_OK;
 }
 
 int finish_upload(fyx_ctx* c, uint64_t mesh_id, Mesh& m) {
     hipError_t e = fyx::launch_max_bone_index(m.idx, m.n_verts, c->d_u32, c->stream);
-    if (e == hipSuccess) e = fyx::launch_unit_bone_range(m.idx, m.n_verts, m.unit_range, c->stream);
     if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "max_bone_index"); }
     uint32_t mx = 0;
     e = hipMemcpyAsync(&mx, c->d_u32, 4, hipMemcpyDeviceToHost, c->stream);
@@ -159,7 +156,6 @@ fyx::LbsArgs make_args(const Mesh& m, const float* d_palette, uint32_t n_bones, 
                        float* op, float* on, float* ot) {
     fyx::LbsArgs a;
     a.pos = m.pos; a.nrm = m.nrm; a.tan = m.tan; a.wgt = m.wgt; a.idx = m.idx;
-    a.unit_range = m.unit_range;
     a.palette = d_palette;
     a.out_pos = op; a.out_nrm = on; a.out_tan = ot;
     a.n_verts = m.n_verts; a.n_bones = n_bones; a.n_instances = n_inst;
@@ -263,7 +259,6 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.prefetch")) return &c->lbs.prefetch;
     if (!strcmp(key, "lbs.exact")) return &c->lbs.exact;
     if (!strcmp(key, "lbs.nt")) return &c->lbs.nt;
-    if (!strcmp(key, "lbs.range_stage")) return &c->lbs.range_stage;
     if (!strcmp(key, "lbs.streams")) return &c->n_workers;
     return nullptr;
 }
@@ -466,7 +461,6 @@ int fyx_lbs_skin_streams(fyx_ctx* c, uint32_t n_verts, const float* d_pos, const
     if (d_out_tangent && !d_tangent) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "no Tangent stream");
     fyx::LbsArgs a;
     a.pos = d_pos; a.nrm = d_normal; a.tan = d_tangent; a.wgt = d_weights; a.idx = d_indices;
-    a.unit_range = nullptr;  // raw streams: no upload-time index scan, the whole palette is staged
     a.palette = d_palette;
     a.out_pos = d_out_pos; a.out_nrm = d_out_normal; a.out_tan = d_out_tangent;
     a.n_verts = n_verts; a.n_bones = n_bones; a.n_instances = n_instances;

@@ -21,7 +21,6 @@ struct Mesh {
     float* tan = nullptr;
     float* wgt = nullptr;
     uint32_t* idx = nullptr;
-    uint16_t* unit_range = nullptr;  // bone-index range per 64-vertex unit
 };
 struct AnimStore;  // anim_api.hip: tracks data, rigs, animators, bone lists
 void anim_store_destroy(AnimStore*);

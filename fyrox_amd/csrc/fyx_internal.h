@@ -8,13 +8,11 @@ namespace fyx {
 constexpr int kCUs = 256;  // MI355X
 
 struct LbsTuning {
-    int block = 256;         // threads per workgroup: 256 | 512 | 1024
-    int blocks_per_cu = 5;   // persistent grid = kCUs * blocks_per_cu (capped by the work)
+    int block = 512;         // threads per workgroup: 256 | 512 | 1024
+    int blocks_per_cu = 4;   // persistent grid = kCUs * blocks_per_cu (capped by the work)
     int prefetch = 1;        // software-pipeline each wave (loads of unit i+1 before math of unit i)
     int exact = 1;           // 1: reference operation order, unfused; 0: FMA
     int nt = 1;              // non-temporal streaming loads/stores
-    int range_stage = 0;     // stage only the palette range [min,max] the workgroup's vertices reference
-                             // (measured slower on MI355X: the range load serialises ahead of the staging)
 };
 
 struct LbsArgs {
@@ -23,7 +21,6 @@ struct LbsArgs {
     const float* tan;        // 4N or null
     const float* wgt;        // 4N
     const uint32_t* idx;     // N (4 x u8 packed little-endian: idx0 in the low byte)
-    const uint16_t* unit_range;  // per 64-vertex unit: min | max << 8 of its bone indices, or null
     const float* palette;    // n_instances * n_bones * 16, column-major mat4
     float* out_pos;          // n_instances * 3N or null
     float* out_nrm;
@@ -41,10 +38,6 @@ hipError_t launch_deinterleave(const uint8_t* d_aos, uint32_t n_verts, uint32_t 
                                int off_pos, int off_nrm, int off_tan, int off_wgt, int off_idx,
                                float* d_pos, float* d_nrm, float* d_tan, float* d_wgt,
                                uint32_t* d_idx, hipStream_t stream);
-
-// per 64-vertex unit: (min | max << 8) over the unit's 256 bone-index bytes.
-hipError_t launch_unit_bone_range(const uint32_t* d_idx, uint32_t n_verts, uint16_t* d_out,
-                                  hipStream_t stream);
 
 // max over all 4N index bytes -> *d_out (single uint32).
 hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32_t* d_out,

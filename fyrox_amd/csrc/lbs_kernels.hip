@@ -67,11 +67,38 @@ __device__ __forceinline__ void st3(float* p, float x, float y, float z) {
 // row3[b] = (m30, m31, m32, m33) is only read by the projective path.
 // Returns (per thread) whether any staged matrix is projective.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool stage_palette(const float* __restrict__ pal, uint32_t b_begin,
-                                              uint32_t b_end, f32x4* rows, f32x4* row3, int tid,
-                                              int nthreads) {
+struct PaletteRegs {
+    f32x4 c0, c1, c2, c3;
+};
+
+// Issue the global loads of this thread's bone (n_bones <= 256 <= BLOCK: at most one bone each).
+__device__ __forceinline__ PaletteRegs palette_fetch(const float* __restrict__ pal, uint32_t n_bones,
+                                                     int tid) {
+    // unconditional (clamped) so that no branch sits between these loads, the vertex loads that
+    // follow and the LDS commit: the compiler's vmcnt bookkeeping stays exact only in straight-line code
+    const uint32_t b = (uint32_t)tid < n_bones ? (uint32_t)tid : n_bones - 1;
+    const f32x4* m = reinterpret_cast<const f32x4*>(pal + (size_t)b * 16);
+    PaletteRegs r;
+    r.c0 = m[0]; r.c1 = m[1]; r.c2 = m[2]; r.c3 = m[3];
+    return r;
+}
+
+// Write the fetched bone to LDS in the packed-math layout; true if that matrix is projective.
+__device__ __forceinline__ bool palette_commit(const PaletteRegs& r, uint32_t n_bones, f32x4* rows,
+                                               f32x4* row3, int tid) {
+    if ((uint32_t)tid >= n_bones) return false;
+    rows[tid * 3 + 0] = f32x4{r.c0.x, r.c0.y, r.c1.x, r.c1.y};
+    rows[tid * 3 + 1] = f32x4{r.c2.x, r.c2.y, r.c3.x, r.c3.y};
+    rows[tid * 3 + 2] = f32x4{r.c0.z, r.c1.z, r.c2.z, r.c3.z};
+    row3[tid] = f32x4{r.c0.w, r.c1.w, r.c2.w, r.c3.w};
+    return !(r.c0.w == 0.0f && r.c1.w == 0.0f && r.c2.w == 0.0f && r.c3.w == 1.0f);
+}
+
+// Whole-palette staging by a workgroup of any size (AABB kernel).
+__device__ __forceinline__ bool stage_palette(const float* __restrict__ pal, uint32_t n_bones,
+                                              f32x4* rows, f32x4* row3, int tid, int nthreads) {
     bool projective = false;
-    for (uint32_t b = b_begin + tid; b < b_end; b += nthreads) {
+    for (uint32_t b = tid; b < n_bones; b += nthreads) {
         const f32x4* m = reinterpret_cast<const f32x4*>(pal + (size_t)b * 16);
         f32x4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
         rows[b * 3 + 0] = f32x4{c0.x, c0.y, c1.x, c1.y};
@@ -216,12 +243,19 @@ __device__ __forceinline__ VertexIn<MASK> load_vertex(const LbsArgs& a, uint32_t
     return r;
 }
 
-template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK, bool RANGE>
+template <int MASK>
+__device__ __forceinline__ void pin_vertex(VertexIn<MASK>& r) {
+    asm volatile("" : "+v"(r.px), "+v"(r.py), "+v"(r.pz), "+v"(r.nx), "+v"(r.ny), "+v"(r.nz));
+    asm volatile("" : "+v"(r.t), "+v"(r.w), "+v"(r.id));
+}
+
+template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK>
 __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_inst,
                                                   uint32_t total_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
+    uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);
 
     constexpr uint32_t WPB = BLOCK / 64;
     const int tid = threadIdx.x;
@@ -238,37 +272,27 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         const uint32_t seg_b = (u_begin > inst_u0 ? u_begin : inst_u0) - inst_u0;
         const uint32_t seg_e = (u_end < inst_u0 + units_per_inst ? u_end : inst_u0 + units_per_inst) - inst_u0;
 
-        // first unit of this wave: issue its loads before staging so HBM latency overlaps staging
+        // Order of issue matters: vector-memory loads retire in order (vmcnt), so the palette
+        // fetch goes FIRST and the first unit's vertex loads right behind it.  The LDS commit
+        // below then waits for the (L2-resident, fast) palette only, while the vertex loads --
+        // a cold HBM access at kernel start -- stay in flight across the staging barrier.
+        const PaletteRegs pr = palette_fetch(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, tid);
         uint32_t u = seg_b + wave;
         uint32_t v = u * 64 + lane;
-        VertexIn<MASK> cur;
-        if (u < seg_e) cur = load_vertex<NT, MASK>(a, v < a.n_verts ? v : 0);
-
-        // Bones this segment's vertices can reference: [lo, hi].  Every wave reduces the (few)
-        // per-unit ranges of the segment on its own -- one tiny coalesced load and a DPP
-        // reduction, no LDS, no barrier -- and all waves arrive at the same answer.
-        uint32_t b_lo = 0, b_hi = a.n_bones;
-        if (RANGE && a.unit_range) {
-            uint32_t lo = 255u, hi = 0u;
-            for (uint32_t uu = seg_b + lane; uu < seg_e; uu += 64) {
-                const uint32_t r = a.unit_range[uu];
-                lo = min(lo, r & 0xffu);
-                hi = max(hi, r >> 8);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
-                hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
-            }
-            b_lo = lo;
-            b_hi = min(hi + 1u, a.n_bones);
-            if (b_lo > b_hi) b_lo = b_hi;
-        }
+        VertexIn<MASK> cur = load_vertex<NT, MASK>(a, (u < seg_e && v < a.n_verts) ? v : 0);
 
         if (inst != inst_first) __syncthreads();  // every wave is done with the previous palette
-        const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, b_lo, b_hi, rows,
-                                      row3, tid, BLOCK);
-        const bool projective = __syncthreads_or(pj) != 0;
+        const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
+        // block-wide OR with the single barrier the staging needs anyway: one flag per wave
+        const bool wave_pj = __any(pj) != 0;
+        if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
+        __syncthreads();
+        bool projective = false;
+#pragma unroll
+        for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
+        // Opaque use point: nothing that consumes the first unit's vertex data may be scheduled
+        // above the staging barrier (it would drag the wait for those loads up with it).
+        pin_vertex(cur);
 
         while (u < seg_e) {  // wave-uniform
             const uint32_t un = u + WPB;
@@ -310,13 +334,9 @@ static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s
     uint32_t grid = (uint32_t)kCUs * (uint32_t)(t.blocks_per_cu > 0 ? t.blocks_per_cu : 1);
     const uint32_t max_useful = (total + (BLOCK / 64) - 1) / (BLOCK / 64);
     if (grid > max_useful) grid = max_useful;
-    const size_t lds = (size_t)a.n_bones * 64;
-    if (t.range_stage && a.unit_range)
-        hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK, true>), dim3(grid), dim3(BLOCK), lds,
-                           s, a, upi, total);
-    else
-        hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK, false>), dim3(grid), dim3(BLOCK), lds,
-                           s, a, upi, total);
+    const size_t lds = (size_t)a.n_bones * 64 + 64;  // rows + row3 + one flag per wave
+    hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
+                       upi, total);
     return hipGetLastError();
 }
 
@@ -419,39 +439,6 @@ __global__ __launch_bounds__(256) void max_bone_index_kernel(const uint32_t* __r
     if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));  // one per block
 }
 
-// Bone-index range of every 64-vertex unit (computed once per upload): one wave per unit.
-__global__ __launch_bounds__(256) void unit_bone_range_kernel(const uint32_t* __restrict__ idx,
-                                                              uint32_t n_verts, uint32_t n_units,
-                                                              uint16_t* __restrict__ out) {
-    const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t u = blockIdx.x * 4 + (threadIdx.x >> 6); u < n_units; u += gridDim.x * 4) {
-        const uint32_t v = u * 64 + lane;
-        uint32_t lo = 255u, hi = 0u;
-        if (v < n_verts) {
-            const uint32_t id = idx[v];
-            const uint32_t b0 = id & 0xffu, b1 = (id >> 8) & 0xffu, b2 = (id >> 16) & 0xffu, b3 = id >> 24;
-            lo = min(min(b0, b1), min(b2, b3));
-            hi = max(max(b0, b1), max(b2, b3));
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
-            hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
-        }
-        if (lane == 0) out[u] = (uint16_t)(lo | (hi << 8));
-    }
-}
-
-hipError_t launch_unit_bone_range(const uint32_t* d_idx, uint32_t n_verts, uint16_t* d_out,
-                                  hipStream_t stream) {
-    const uint32_t n_units = (n_verts + 63) / 64;
-    if (n_units == 0) return hipSuccess;
-    uint32_t grid = (n_units + 3) / 4;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(unit_bone_range_kernel, dim3(grid), dim3(256), 0, stream, d_idx, n_verts, n_units,
-                       d_out);
-    return hipGetLastError();
-}
-
 hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32_t* d_out,
                                  hipStream_t stream) {
     hipError_t e = hipMemsetAsync(d_out, 0, sizeof(uint32_t), stream);
@@ -502,7 +489,7 @@ __global__ __launch_bounds__(kAabbBlock) void skinned_aabb_kernel(LbsArgs a, flo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
-    const bool pj = stage_palette(a.palette, 0, a.n_bones, rows, row3, threadIdx.x, kAabbBlock);
+    const bool pj = stage_palette(a.palette, a.n_bones, rows, row3, threadIdx.x, kAabbBlock);
     const bool projective = __syncthreads_or(pj) != 0;
     float mn[3] = {__FLT_MAX__, __FLT_MAX__, __FLT_MAX__};
     float mx[3] = {-__FLT_MAX__, -__FLT_MAX__, -__FLT_MAX__};

@@ -72,8 +72,6 @@ int fyx_join(fyx_ctx* ctx);
  * Unknown keys return FYX_ERR_INVALID_ARG.  Keys: "lbs.block", "lbs.blocks_per_cu", "lbs.prefetch",
  * "lbs.exact" (1 = reference operation order, no FMA contraction: bit-identical to the CPU path;
  * 0 = fused multiply-add, within 1e-5 relative), "lbs.nt" (non-temporal loads/stores),
- * "lbs.range_stage" (1 = each workgroup stages only the palette range its vertices reference, from the
- * per-64-vertex bone ranges computed at mesh upload; 0 = stage the whole palette),
  * "lbs.streams" (1..4 worker streams for independent skinning launches, see fyx_join). */
 int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
 int fyx_get_option(fyx_ctx* ctx, const char* key, int* value);

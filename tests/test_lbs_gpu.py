@@ -46,7 +46,7 @@ def assert_bit_exact(got, ref):
 
 @pytest.fixture(autouse=True)
 def _defaults(ctx):
-    for k, v in (("lbs.block", 256), ("lbs.blocks_per_cu", 5), ("lbs.prefetch", 1), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2), ("lbs.range_stage", 0)):
+    for k, v in (("lbs.block", 512), ("lbs.blocks_per_cu", 4), ("lbs.prefetch", 1), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2)):
         ctx.set_option(k, v)
     yield
 
