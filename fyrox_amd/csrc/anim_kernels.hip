@@ -94,84 +94,102 @@ __device__ __forceinline__ f4 quat_mul(f4 a, f4 b) {  // Hamilton product, stora
     const float k = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
     return f4{i, j, k, w};
 }
-// UnitQuaternion::from_axis_angle(unit axis, angle) = (axis * sin(angle/2), cos(angle/2))
-__device__ __forceinline__ f4 quat_axis_angle(int axis, float angle) {
-    const float half = angle / 2.0f;
-    double sd, cd;
-    sincos((double)half, &sd, &cd);
-    const float s = (float)sd, c = (float)cd;
-    const float e0 = axis == 0 ? 1.0f : 0.0f, e1 = axis == 1 ? 1.0f : 0.0f, e2 = axis == 2 ? 1.0f : 0.0f;
-    return f4{e0 * s, e1 * s, e2 * s, c};
-}
-
 // ---------------------------------------------------------------------------------------
-// pose_sample: one thread per (animation, instance, node); it samples the (up to three) tracks
-// of that animation bound to Position / Scale / Rotation of the node and writes the node's
-// pose record {pos, present-mask}{rot}{scale}.  Present bits: 1 Position, 2 Scale, 4 Rotation.
+// pose_sample: sixteen lanes per (animation, instance, node), ONE LANE PER CURVE.  A curve sample is
+// a chain of dependent loads (hint -> key locations -> key values), so a thread that walked the ten
+// curves of a node one after another would pay that latency ten times; here the ten chains of a node
+// run side by side and the lanes exchange their results with cross-lane shuffles.
+// Lane j of a group owns dword j of the node's 48-byte pose record, so the store is one dense 48-byte
+// span per group (192 B per wave):
+//     j = 0..2  position x,y,z     j = 3  present bits (1 Position, 2 Scale, 4 Rotation)
+//     j = 4..7  rotation i,j,k,w   j = 8..10  scale x,y,z     j = 11  zero      j = 12..15 idle
+// Euler tracks: lanes 4,5,6 each evaluate sin/cos of their own half angle once, every rotation lane
+// then forms qz * qy * qx (fyrox-math/src/lib.rs:725-740) from the shuffled values.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool sample_track(const AnimDev& an, int32_t track, float time,
-                                             uint32_t* __restrict__ hints, int want_kind_quat, f4& out) {
-    if (track < 0) return false;
-    const TrackDev tk = an.tracks[track];
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    int need;
-    switch (tk.kind) {
-        case FYX_KIND_VEC3: need = 3; break;
-        case FYX_KIND_QUAT_EULER: need = 3; break;
-        case FYX_KIND_QUAT: need = 4; break;
-        default: return false;  // rejected at upload; never reached
-    }
-    if ((tk.kind == FYX_KIND_VEC3) == (want_kind_quat != 0)) return false;
-    if ((int)tk.n_curves < need) return false;  // fetch() -> None
-    uint32_t* h = hints + (size_t)track * 4;
-    for (int c = 0; c < need; ++c) {
-        uint32_t hint = h[c];
-        v[c] = curve_value_at(an.key_loc + tk.first_key[c], reinterpret_cast<const f4*>(an.key_aux) + tk.first_key[c], tk.n_keys[c],
-                              time, hint);
-        h[c] = hint;
-    }
-    if (tk.kind == FYX_KIND_VEC3) {
-        out = f4{v[0], v[1], v[2], 0.f};
-    } else if (tk.kind == FYX_KIND_QUAT) {
-        out = quat_normalize(f4{v[0], v[1], v[2], v[3]});  // from_quaternion(Quaternion::new(w,x,y,z))
-    } else {
-        // quat_from_euler(.., XYZ) = qz * qy * qx   (fyrox-math/src/lib.rs:725-740)
-        const f4 qx = quat_axis_angle(0, v[0]), qy = quat_axis_angle(1, v[1]), qz = quat_axis_angle(2, v[2]);
-        out = quat_mul(quat_mul(qz, qy), qx);
-    }
-    return true;
-}
-
 __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
+    const uint32_t lane = threadIdx.x & 63u, j = threadIdx.x & 15u, gbase = lane & ~15u;
     const uint32_t per_anim = f.n_instances * f.n_nodes;
-    const uint64_t total = (uint64_t)f.n_anims * per_anim;
-    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
-         id += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t a = (uint32_t)(id / per_anim);
-        const uint32_t rem = (uint32_t)(id - (uint64_t)a * per_anim);
+    const uint64_t items = (uint64_t)f.n_anims * per_anim;
+    const uint64_t groups_per_pass = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; item < items;
+         item += groups_per_pass) {
+        const uint32_t a = (uint32_t)(item / per_anim);
+        const uint32_t rem = (uint32_t)(item - (uint64_t)a * per_anim);
         const uint32_t inst = rem / f.n_nodes, node = rem - inst * f.n_nodes;
-        if (!f.ticked[(size_t)inst * f.n_anims + a]) continue;
+        if (!f.ticked[(size_t)inst * f.n_anims + a]) continue;  // uniform across the group
         const float time = f.times[(size_t)inst * f.n_anims + a];
         const AnimDev an = f.anims[a];
-        const int32_t* st = an.slot_track + (size_t)node * 3;
-        uint32_t* hints = f.hints + ((size_t)a * f.n_instances + inst) * f.max_tracks * 4;
-        f4 p = f4{0.f, 0.f, 0.f, 0.f}, s = f4{0.f, 0.f, 0.f, 0.f}, r = f4{0.f, 0.f, 0.f, 1.f};
-        uint32_t mask = 0;
-        if (sample_track(an, st[0], time, hints, 0, p)) mask |= 1u;
-        if (sample_track(an, st[1], time, hints, 0, s)) mask |= 2u;
-        if (sample_track(an, st[2], time, hints, 1, r)) mask |= 4u;
-        f4* rec = reinterpret_cast<f4*>(f.anim_pose) + id * 3;
-        rec[0] = f4{p.x, p.y, p.z, __uint_as_float(mask)};
-        rec[1] = r;
-        rec[2] = s;
+
+        // which binding / curve this lane serves
+        int bind = -1, c = 0;
+        if (j < 3) { bind = FYX_BIND_POSITION; c = (int)j; }
+        else if (j >= 4 && j < 8) { bind = FYX_BIND_ROTATION; c = (int)j - 4; }
+        else if (j >= 8 && j < 11) { bind = FYX_BIND_SCALE; c = (int)j - 8; }
+        int32_t track = -1;
+        if (bind >= 0) track = an.slot_track[(size_t)node * 3 + bind];
+        int kind = -1, need = 0;
+        bool valid = false;
+        float v = 0.0f;
+        if (track >= 0) {
+            const TrackDev* tk = an.tracks + track;
+            kind = tk->kind;
+            need = kind == FYX_KIND_QUAT ? 4 : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3 : 0;
+            const bool fits = (bind == FYX_BIND_ROTATION) ? (kind == FYX_KIND_QUAT || kind == FYX_KIND_QUAT_EULER)
+                                                          : (kind == FYX_KIND_VEC3);
+            valid = fits && need > 0 && (int)tk->n_curves >= need;   // else fetch() -> None
+            if (valid && c < need) {
+                uint32_t* hp = f.hints + (((size_t)a * f.n_instances + inst) * f.max_tracks + track) * 4 + c;
+                uint32_t hint = *hp;
+                const uint32_t fk = tk->first_key[c];
+                v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c],
+                                   time, hint);
+                *hp = hint;
+            }
+        }
+        const int has_p = __shfl((int)valid, (int)gbase + 0, 64);
+        const int has_r = __shfl((int)valid, (int)gbase + 4, 64);
+        const int has_s = __shfl((int)valid, (int)gbase + 8, 64);
+        const int rkind = __shfl(kind, (int)gbase + 4, 64);
+
+        // rotation: gather the (up to four) sampled components on every lane of the group
+        const float r0 = __shfl(v, (int)gbase + 4, 64), r1 = __shfl(v, (int)gbase + 5, 64);
+        const float r2 = __shfl(v, (int)gbase + 6, 64), r3 = __shfl(v, (int)gbase + 7, 64);
+        f4 q = f4{0.f, 0.f, 0.f, 1.f};
+        if (__any(has_r && rkind == FYX_KIND_QUAT_EULER)) {
+            // (axis * sin(angle/2), cos(angle/2)) of this lane's own angle; lanes 4,5,6 are x,y,z
+            const float half = v / 2.0f;
+            double sd, cd;
+            sincos((double)half, &sd, &cd);
+            const float sn = (float)sd, cs = (float)cd;
+            const float sx = __shfl(sn, (int)gbase + 4, 64), cx = __shfl(cs, (int)gbase + 4, 64);
+            const float sy = __shfl(sn, (int)gbase + 5, 64), cy = __shfl(cs, (int)gbase + 5, 64);
+            const float sz = __shfl(sn, (int)gbase + 6, 64), cz = __shfl(cs, (int)gbase + 6, 64);
+            if (has_r && rkind == FYX_KIND_QUAT_EULER) {
+                const f4 qx = f4{1.0f * sx, 0.0f * sx, 0.0f * sx, cx};
+                const f4 qy = f4{0.0f * sy, 1.0f * sy, 0.0f * sy, cy};
+                const f4 qz = f4{0.0f * sz, 0.0f * sz, 1.0f * sz, cz};
+                q = quat_mul(quat_mul(qz, qy), qx);
+            }
+        }
+        if (has_r && rkind == FYX_KIND_QUAT) q = quat_normalize(f4{r0, r1, r2, r3});
+
+        float out;
+        if (j < 3 || (j >= 8 && j < 11)) out = v;   // an absent binding sampled nothing: 0
+        else if (j == 3) out = __uint_as_float((has_p ? 1u : 0u) | (has_s ? 2u : 0u) | (has_r ? 4u : 0u));
+        else if (j == 4) out = q.x;
+        else if (j == 5) out = q.y;
+        else if (j == 6) out = q.z;
+        else if (j == 7) out = q.w;
+        else out = 0.0f;
+        if (j < 12) reinterpret_cast<float*>(f.anim_pose)[item * 12 + j] = out;
     }
 }
 
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s) {
-    const uint64_t total = (uint64_t)f.n_anims * f.n_instances * f.n_nodes;
-    if (total == 0) return hipSuccess;
-    uint64_t grid = (total + 255) / 256;
-    if (grid > (uint64_t)kCUs * 16) grid = (uint64_t)kCUs * 16;
+    const uint64_t items = (uint64_t)f.n_anims * f.n_instances * f.n_nodes;
+    if (items == 0) return hipSuccess;
+    uint64_t grid = (items * 16 + 255) / 256;
+    if (grid > (uint64_t)kCUs * 32) grid = (uint64_t)kCUs * 32;
     hipLaunchKernelGGL(pose_sample_kernel, dim3((uint32_t)grid), dim3(256), 0, s, f);
     return hipGetLastError();
 }

@@ -26,9 +26,15 @@ ap.add_argument("--verts", type=int, default=10_000)
 ap.add_argument("--bones", type=int, default=64)
 ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--warmup", type=int, default=20)
+ap.add_argument("--opt", action="append", default=["lbs.streams=1"],
+                help="kernel option key=value; the frame is a dependent chain (pose -> palette -> skin), so the "
+                     "default keeps every launch on the context stream instead of forking to the worker streams")
 args = ap.parse_args()
 
 ctx = fyrox_amd.Context(0)
+for kv in args.opt:
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
 seed = synth.SEED_BASE + 3
 rig = synth.make_rig(args.bones, seed)
 A.create_rig(ctx, 1, rig)
