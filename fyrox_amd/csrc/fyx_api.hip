@@ -260,6 +260,9 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.exact")) return &c->lbs.exact;
     if (!strcmp(key, "lbs.nt")) return &c->lbs.nt;
     if (!strcmp(key, "lbs.streams")) return &c->n_workers;
+    if (!strcmp(key, "lbs.crowd")) return &c->lbs.crowd;
+    if (!strcmp(key, "lbs.crowd_block")) return &c->lbs.crowd_block;
+    if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
     return nullptr;
 }
 
@@ -275,6 +278,12 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         if (int rc = enter_primary(c)) return rc;
         c->next_worker = 0;
     }
+    if (slot == &c->lbs.crowd && (value < -1 || value > 1))
+        return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd must be -1 (auto), 0 or 1");
+    if (slot == &c->lbs.crowd_block && value != 256 && value != 512)
+        return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_block must be 256 or 512");
+    if (slot == &c->lbs.crowd_ipb && (value < 0 || value > 4096))
+        return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_ipb must be 0 (auto) .. 4096");
     if (slot == &c->lbs.blocks_per_cu && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.blocks_per_cu must be 1..64");
     *slot = value;

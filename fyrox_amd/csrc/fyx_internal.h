@@ -13,6 +13,9 @@ struct LbsTuning {
     int prefetch = 1;        // software-pipeline each wave (loads of unit i+1 before math of unit i)
     int exact = 1;           // 1: reference operation order, unfused; 0: FMA
     int nt = 1;              // non-temporal streaming loads/stores
+    int crowd = -1;          // instanced launches: -1 auto (crowd kernel from 4 instances), 0 never, 1 always
+    int crowd_block = 512;   // crowd kernel workgroup = vertex tile: 256 | 512
+    int crowd_ipb = 0;       // instances per workgroup run; 0 = auto
 };
 
 struct LbsArgs {

@@ -322,6 +322,119 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
 }
 
 // ---------------------------------------------------------------------------------------
+// Crowd kernel: many instances of ONE mesh (1000 x 10 k vertices / 64 bones).
+//
+// lbs_skin above re-reads the shared mesh for every instance (60 B/vertex from L2 on top of the
+// 40 B written), which makes a crowd L2/TA-bound.  Here a workgroup owns one tile of BLOCK
+// vertices (one per thread) and a run of `ipb` consecutive instances: the vertex attributes are
+// loaded ONCE into registers and stay there, and only the palette changes per instance.  The
+// palettes are double-buffered in LDS -- the global fetch of palette i+1 is issued before the
+// barrier of instance i and committed to the other buffer after this wave's math -- so there is
+// exactly one barrier per instance and the only per-instance memory traffic is the palette
+// (n_bones * 64 B per BLOCK vertices) and the 40 B/vertex written.
+// blockIdx -> (tile, chunk) with tile fastest: neighbouring workgroups (which round-robin over
+// the XCDs) read the same palettes, so each palette is fetched from HBM about once per XCD.
+// ---------------------------------------------------------------------------------------
+template <int BLOCK, bool EXACT, int MASK>
+__global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tiles, uint32_t ipb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t WPB = BLOCK / 64;
+    const uint32_t buf_f4 = 4 * a.n_bones;  // rows (3 per bone) + row3 (1 per bone)
+    f32x4* const base = reinterpret_cast<f32x4*>(smem);
+    uint32_t* const flags = reinterpret_cast<uint32_t*>(base + 2 * buf_f4);  // [2][WPB]
+
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const uint32_t i0 = chunk * ipb;
+    const uint32_t i1 = (i0 + ipb < a.n_instances) ? i0 + ipb : a.n_instances;
+    if (i0 >= i1) return;
+    const uint32_t v = tile * BLOCK + tid;
+    const bool live = v < a.n_verts;
+
+    PaletteRegs pr = palette_fetch(a.palette + (size_t)i0 * a.n_bones * 16, a.n_bones, tid);
+    // the mesh is shared by every workgroup of the launch: ordinary (cacheable) loads
+    const VertexIn<MASK> vin = load_vertex<false, MASK>(a, live ? v : 0);
+    {
+        const bool pj = palette_commit(pr, a.n_bones, base, base + 3 * a.n_bones, tid);
+        const bool wave_pj = __any(pj) != 0;
+        if (lane == 0) flags[wave] = wave_pj ? 1u : 0u;
+    }
+    uint32_t cur = 0;
+    for (uint32_t inst = i0; inst < i1; ++inst) {  // workgroup-uniform
+        const bool more = inst + 1 < i1;
+        if (more) pr = palette_fetch(a.palette + (size_t)(inst + 1) * a.n_bones * 16, a.n_bones, tid);
+        __syncthreads();  // buffer `cur` is complete; nobody reads buffer `cur ^ 1` any more
+        const f32x4* rows = base + cur * buf_f4;
+        const f32x4* row3 = rows + 3 * a.n_bones;
+        bool projective = false;
+#pragma unroll
+        for (uint32_t wv = 0; wv < WPB; ++wv) projective |= flags[cur * WPB + wv] != 0;
+        const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, vin.id, vin.w, vin.px, vin.py,
+                                                   vin.pz, vin.nx, vin.ny, vin.nz, vin.t.x, vin.t.y, vin.t.z);
+        if (live) {
+            const size_t ov = (size_t)inst * a.n_verts + v;
+            if constexpr (MASK & 1) st3<true>(a.out_pos + ov * 3, o.px, o.py, o.pz);
+            if constexpr (MASK & 2) st3<true>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
+            if constexpr (MASK & 4)
+                stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, vin.t.w});
+        }
+        if (more) {
+            f32x4* nrows = base + (cur ^ 1) * buf_f4;
+            const bool pj = palette_commit(pr, a.n_bones, nrows, nrows + 3 * a.n_bones, tid);
+            const bool wave_pj = __any(pj) != 0;
+            if (lane == 0) flags[(cur ^ 1) * WPB + wave] = wave_pj ? 1u : 0u;
+        }
+        cur ^= 1;
+    }
+}
+
+template <int BLOCK, bool EXACT, int MASK>
+static hipError_t launch_crowd_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    const uint32_t tiles = (a.n_verts + BLOCK - 1) / BLOCK;
+    uint32_t ipb = (uint32_t)(t.crowd_ipb > 0 ? t.crowd_ipb : 0);
+    if (ipb == 0) {
+        // long enough runs to amortise the vertex loads, enough workgroups to fill the chip: the C3
+        // sweep (tools/tune_crowd.py) is flat between 8 and 16 instances per run and loses ~10 % at
+        // 2 and at 32
+        const uint64_t pairs = (uint64_t)tiles * a.n_instances;
+        uint64_t want = pairs / ((uint64_t)kCUs * 4);
+        if (want < 1) want = 1;
+        if (want > 16) want = 16;
+        ipb = (uint32_t)want;
+    }
+    if (ipb > a.n_instances) ipb = a.n_instances;
+    const uint32_t chunks = (a.n_instances + ipb - 1) / ipb;
+    const uint64_t grid = (uint64_t)tiles * chunks;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = (size_t)a.n_bones * 64 * 2 + 2 * (BLOCK / 64) * sizeof(uint32_t);
+    hipLaunchKernelGGL((lbs_skin_crowd<BLOCK, EXACT, MASK>), dim3((uint32_t)grid), dim3(BLOCK), lds, s, a, tiles,
+                       ipb);
+    return hipGetLastError();
+}
+
+template <int BLOCK, bool EXACT>
+static hipError_t launch_crowd_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
+    switch (mask) {
+        case 1: return launch_crowd_one<BLOCK, EXACT, 1>(a, t, s);
+        case 2: return launch_crowd_one<BLOCK, EXACT, 2>(a, t, s);
+        case 3: return launch_crowd_one<BLOCK, EXACT, 3>(a, t, s);
+        case 4: return launch_crowd_one<BLOCK, EXACT, 4>(a, t, s);
+        case 5: return launch_crowd_one<BLOCK, EXACT, 5>(a, t, s);
+        case 6: return launch_crowd_one<BLOCK, EXACT, 6>(a, t, s);
+        case 7: return launch_crowd_one<BLOCK, EXACT, 7>(a, t, s);
+        default: return hipSuccess;
+    }
+}
+
+static hipError_t launch_crowd(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    if (t.crowd_block == 512)
+        return t.exact ? launch_crowd_mask<512, true>(a, t, s) : launch_crowd_mask<512, false>(a, t, s);
+    return t.exact ? launch_crowd_mask<256, true>(a, t, s) : launch_crowd_mask<256, false>(a, t, s);
+}
+
+// ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
 template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK>
@@ -372,6 +485,8 @@ static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t
 
 hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream) {
     if (a.n_verts == 0 || a.n_instances == 0) return hipSuccess;
+    // crowds (one mesh, many palettes) keep the vertices in registers and loop over instances
+    if (t.crowd > 0 || (t.crowd < 0 && a.n_instances >= 4)) return launch_crowd(a, t, stream);
     switch (t.block) {
         case 512: return launch_block<512>(a, t, stream);
         case 1024: return launch_block<1024>(a, t, stream);

@@ -72,7 +72,10 @@ int fyx_join(fyx_ctx* ctx);
  * Unknown keys return FYX_ERR_INVALID_ARG.  Keys: "lbs.block", "lbs.blocks_per_cu", "lbs.prefetch",
  * "lbs.exact" (1 = reference operation order, no FMA contraction: bit-identical to the CPU path;
  * 0 = fused multiply-add, within 1e-5 relative), "lbs.nt" (non-temporal loads/stores),
- * "lbs.streams" (1..4 worker streams for independent skinning launches, see fyx_join). */
+ * "lbs.streams" (1..4 worker streams for independent skinning launches, see fyx_join),
+ * "lbs.crowd" (instanced launches: -1 = crowd kernel from 4 instances on, 0 never, 1 always; the
+ * crowd kernel keeps a tile of vertices in registers and loops over instances), "lbs.crowd_block"
+ * (256 | 512 vertices per tile), "lbs.crowd_ipb" (instances per workgroup, 0 = auto). */
 int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
 int fyx_get_option(fyx_ctx* ctx, const char* key, int* value);
 

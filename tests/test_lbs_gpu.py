@@ -46,7 +46,8 @@ def assert_bit_exact(got, ref):
 
 @pytest.fixture(autouse=True)
 def _defaults(ctx):
-    for k, v in (("lbs.block", 512), ("lbs.blocks_per_cu", 4), ("lbs.prefetch", 1), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2)):
+    for k, v in (("lbs.block", 512), ("lbs.blocks_per_cu", 4), ("lbs.prefetch", 1), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2),
+                 ("lbs.crowd", -1), ("lbs.crowd_block", 512), ("lbs.crowd_ipb", 0)):
         ctx.set_option(k, v)
     yield
 
@@ -130,8 +131,45 @@ def test_instanced_variants(ctx, orc, block, bpcu, n_inst, n_verts):
     m = synth.make_mesh(n_verts, 32, 7)
     pal = synth.make_palette(32, 7, n_instances=n_inst)
     upload(ctx, 7, m)
+    ctx.set_option("lbs.crowd", 0)      # the streaming kernel's per-instance segments
     ctx.set_option("lbs.block", block); ctx.set_option("lbs.blocks_per_cu", bpcu)
     assert_bit_exact(ctx.lbs_skin(7, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst))
+
+
+@pytest.mark.parametrize("cblock,ipb", [(256, 0), (256, 1), (512, 3), (512, 0), (256, 4096)])
+@pytest.mark.parametrize("n_inst,n_verts", [(1, 1000), (3, 1000), (5, 1001), (2, 4096), (7, 13), (300, 65), (2000, 3),
+                                            (33, 10_000)])
+def test_crowd_kernel_variants(ctx, orc, cblock, ipb, n_inst, n_verts):
+    # vertices held in registers, palettes double-buffered in LDS, one barrier per instance
+    m = synth.make_mesh(n_verts, 32, 7)
+    pal = synth.make_palette(32, 7, n_instances=n_inst)
+    upload(ctx, 7, m)
+    ctx.set_option("lbs.crowd", 1); ctx.set_option("lbs.crowd_block", cblock); ctx.set_option("lbs.crowd_ipb", ipb)
+    assert_bit_exact(ctx.lbs_skin(7, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst))
+
+
+def test_crowd_kernel_edge_palettes(ctx, orc):
+    # 256 bones (2 x 16 KiB of LDS), one projective matrix in ONE instance of the run (the flag is
+    # per palette buffer), positions-only and normal-only launches, fused arithmetic within 1e-5
+    n_inst = 9
+    m = synth.make_mesh(3001, 256, 19, coherent=False)
+    pal = synth.make_palette(256, 19, n_instances=n_inst).copy()
+    pal[4 * 256 + 7, 3] = 0.125; pal[4 * 256 + 7, 7] = -0.25; pal[4 * 256 + 7, 15] = 1.5
+    upload(ctx, 19, m)
+    ctx.set_option("lbs.crowd", 1)
+    ref = oracle_skin(orc, m, pal, n_inst)
+    for ipb in (0, 2, 5):
+        ctx.set_option("lbs.crowd_ipb", ipb)
+        assert_bit_exact(ctx.lbs_skin(19, pal, n_instances=n_inst), ref)
+    got = ctx.lbs_skin(19, pal, n_instances=n_inst, want=("pos",))
+    assert set(got) == {"pos"} and np.array_equal(got["pos"], ref["pos"])
+    got = ctx.lbs_skin(19, pal, n_instances=n_inst, want=("normal",))
+    assert np.array_equal(got["normal"], ref["normal"])
+    ctx.set_option("lbs.exact", 0)
+    got = ctx.lbs_skin(19, pal, n_instances=n_inst)
+    for k in ("pos", "normal", "tangent"):
+        assert rel_err(got[k], ref[k]) <= REL_TOL, k
+    assert np.array_equal(got["tangent"][:, 3], np.tile(m.tangent[:, 3], n_inst))
 
 
 # ---- edge cases ---------------------------------------------------------------------------
