@@ -116,6 +116,19 @@ _SIGS = {
     "fyx_animator_read": (c_int, [_P, c_uint64, c_int, _P]),
     "fyx_animator_device_ptr": (c_int, [_P, c_uint64, c_int, POINTER(c_void_p)]),
     "fyx_animator_plan": (c_int, [_P, c_uint64, c_int, c_float, _P, _P, _P, _P, c_uint32, POINTER(c_uint32)]),
+    # signals / events / root motion
+    "fyx_animation_add_signal": (c_int, [_P, c_uint64, c_uint32, c_float, c_int, POINTER(c_uint32)]),
+    "fyx_animation_set_signal_enabled": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int]),
+    "fyx_animation_set_max_event_capacity": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32]),
+    "fyx_animation_pop_event": (c_int, [_P, c_uint64, c_uint32, c_uint32, POINTER(c_int32)]),
+    "fyx_animation_event_count": (c_int, [_P, c_uint64, c_uint32, c_uint32, POINTER(c_uint32)]),
+    "fyx_animation_clear_events": (c_int, [_P, c_uint64, c_uint32, c_uint32]),
+    "fyx_animation_set_root_motion_settings": (c_int, [_P, c_uint64, c_uint32, c_int32, c_int, c_int, c_int, c_int]),
+    "fyx_animator_track_root_motion": (c_int, [_P, c_uint64, c_int]),
+    "fyx_animation_read_root_motion": (c_int, [_P, c_uint64, c_uint32, _P]),
+    "fyx_absm_read_root_motion": (c_int, [_P, c_uint64, c_int32, _P]),
+    "fyx_layer_pop_event": (c_int, [_P, c_uint64, c_uint32, c_uint32, _P, POINTER(c_int)]),
+    "fyx_animator_plan_root_motion": (c_int, [_P, c_uint64, _P, _P, c_uint32, POINTER(c_uint32), POINTER(c_uint32), _P]),
 }
 
 

@@ -25,6 +25,8 @@ LOGIC_PARAMETER, LOGIC_AND, LOGIC_OR, LOGIC_XOR, LOGIC_NOT, LOGIC_IS_ANIMATION_E
 ALL_INSTANCES = 0xFFFFFFFF
 READ_LOCAL_TRS, READ_LOCAL_MATRIX, READ_GLOBAL_MATRIX, READ_ANIMATION_POSE = 0, 1, 2, 16
 OP_NAMES = ("END", "BLEND_ANIM", "PUSH", "POP_BLEND", "RESET", "MASK", "APPLY", "APPLY_ANIM")
+RM_OP_NAMES = ("END", "SET_ANIM", "BLEND", "COPY")
+EVENT_STATE_ENTER, EVENT_STATE_LEAVE, EVENT_ACTIVE_STATE_CHANGED, EVENT_ACTIVE_TRANSITION_CHANGED = range(4)
 
 
 # ---- curves / tracks (fyrox-math/src/curve.rs, fyrox-animation/src/track.rs, container.rs) ----------
@@ -292,6 +294,75 @@ class Animator:
         t, e, d = c_float(), c_int(), c_int()
         self._check(self._l.fyx_animation_get_state(self._h, self.id, a, instance, byref(t), byref(e), byref(d)))
         return {"time_position": t.value, "enabled": bool(e.value), "has_ended": bool(d.value)}
+
+    # -- signals / events ------------------------------------------------------------------------
+    def add_signal(self, a: int, time: float, enabled: bool = True) -> int:
+        """Animation::add_signal; the returned index stands for the signal's {Uuid, name}."""
+        out = c_uint32()
+        self._check(self._l.fyx_animation_add_signal(self._h, self.id, a, time, int(bool(enabled)), byref(out)))
+        return out.value
+
+    def set_signal_enabled(self, a: int, signal: int, enabled: bool) -> None:
+        self._check(self._l.fyx_animation_set_signal_enabled(self._h, self.id, a, signal, int(bool(enabled))))
+
+    def set_max_event_capacity(self, a: int, capacity: int, instance=ALL_INSTANCES) -> None:
+        self._check(self._l.fyx_animation_set_max_event_capacity(self._h, self.id, a, instance, capacity))
+
+    def pop_event(self, a: int, instance: int = 0) -> Optional[int]:
+        """Animation::pop_event -> signal index or None."""
+        out = c_int32()
+        self._check(self._l.fyx_animation_pop_event(self._h, self.id, a, instance, byref(out)))
+        return None if out.value < 0 else out.value
+
+    def event_count(self, a: int, instance: int = 0) -> int:
+        out = c_uint32()
+        self._check(self._l.fyx_animation_event_count(self._h, self.id, a, instance, byref(out)))
+        return out.value
+
+    def clear_events(self, a: int, instance=ALL_INSTANCES) -> None:
+        self._check(self._l.fyx_animation_clear_events(self._h, self.id, a, instance))
+
+    def pop_layer_event(self, layer: int, instance: int = 0) -> Optional[Tuple[int, int, int]]:
+        """MachineLayer::pop_event -> (kind, a, b) or None."""
+        ev = (c_int32 * 3)()
+        has = c_int()
+        self._check(self._l.fyx_layer_pop_event(self._h, self.id, layer, instance, ev, byref(has)))
+        return (ev[0], ev[1], ev[2]) if has.value else None
+
+    # -- root motion -----------------------------------------------------------------------------
+    def set_root_motion_settings(self, a: int, node: Optional[int], ignore_x=False, ignore_y=False, ignore_z=False,
+                                 ignore_rotations=False) -> None:
+        """Animation::set_root_motion_settings (None clears them)."""
+        self._check(self._l.fyx_animation_set_root_motion_settings(
+            self._h, self.id, a, -1 if node is None else int(node), int(bool(ignore_x)), int(bool(ignore_y)),
+            int(bool(ignore_z)), int(bool(ignore_rotations))))
+
+    def track_root_motion(self, enabled: bool = True) -> None:
+        self._check(self._l.fyx_animator_track_root_motion(self._h, self.id, int(bool(enabled))))
+
+    def animation_root_motion(self, a: int) -> np.ndarray:
+        """(n_instances, 8) float32 view of fyx_root_motion: dp xyz, has (u32 bits), dr ijkw."""
+        out = np.zeros((self.n_instances, 8), np.float32)
+        self._check(self._l.fyx_animation_read_root_motion(self._h, self.id, a, _ptr(out)))
+        return out
+
+    def machine_root_motion(self, layer: int = -1) -> np.ndarray:
+        out = np.zeros((self.n_instances, 8), np.float32)
+        self._check(self._l.fyx_absm_read_root_motion(self._h, self.id, layer, _ptr(out)))
+        return out
+
+    def plan_root_motion(self) -> dict:
+        """Test hook: the root-motion program of the frame plan() planned last."""
+        off = np.zeros(self.n_instances + 1, np.uint32)
+        cap = max(4096, 128 * self.n_instances)
+        ops = np.zeros((cap, 4), np.uint32)
+        n, ns = c_uint32(), c_uint32()
+        slices = np.zeros((self.n_instances, max(self.n_animations, 1), 2), np.float32)
+        self._check(self._l.fyx_animator_plan_root_motion(self._h, self.id, _ptr(off), _ptr(ops), cap, byref(n),
+                                                          byref(ns), _ptr(slices)))
+        if n.value > cap:
+            raise RuntimeError("program larger than the wrapper's buffer; plan_root_motion() is a test hook")
+        return {"offsets": off, "ops": ops[:n.value], "n_slots": ns.value, "slices": slices[:, :self.n_animations]}
 
     # -- machine ---------------------------------------------------------------------------------
     def set_machine(self, m: Machine) -> None:

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <deque>
 #include <vector>
 
 #include "fyx_ctx.h"
@@ -56,11 +57,20 @@ struct AnimationDef {
     std::vector<uint8_t> enabled;  // TrackBinding::enabled
     int32_t* d_slot_track = nullptr;
     bool slots_dirty = true;
+    // AnimationSignal (signal.rs): the index stands for the {id, name} pair the shim keeps
+    struct Signal { float time; uint8_t enabled; };
+    std::vector<Signal> signals;
+    // RootMotionSettings (lib.rs:307-319); node < 0: None
+    int32_t rm_node = -1;
+    uint32_t rm_ignore = 0;
+    int32_t rm_pos_track = -1, rm_rot_track = -1;  // first Position / Rotation track of the tracks data
 };
 
 struct AnimState {  // per instance, per animation (Animation's scalar fields)
     float time = 0.f, speed = 1.f, start = 0.f, end = 0.f;
     uint8_t enabled = 1, looped = 1;
+    uint32_t max_event_capacity = 32;   // lib.rs:941
+    std::deque<int32_t> events;         // VecDeque<AnimationEvent>, as signal indices
 };
 
 struct Param {
@@ -109,7 +119,9 @@ struct LayerState {
     int32_t active_state = -1, active_transition = -1;
     std::vector<TransitionState> transitions;
     std::vector<ByIndexState> by_index;
+    std::deque<fyx_layer_event> events;  // FixedEventQueue::new(2048), layer.rs:182
 };
+constexpr size_t kLayerEventLimit = 2048;
 struct MachineState {
     std::vector<Param> params;
     std::vector<LayerState> layers;
@@ -157,6 +169,17 @@ struct Animator {
     std::vector<uint8_t> ticked;
     std::vector<uint2> ops;
     std::vector<uint32_t> prog_off;
+    // root motion (only when rm_enabled): per-frame slices + program, persistent device state
+    bool rm_enabled = false;
+    std::vector<float2> slices;
+    std::vector<uint4> rm_ops;
+    std::vector<uint32_t> rm_prog_off;
+    std::vector<uint32_t> rm_layer_base;   // first slot of each layer; nodes, then the layer's final pose
+    uint32_t n_rm_slots = 0;               // ... and the machine's final pose last
+    RootMotionDev* d_rm_anim = nullptr;
+    uint32_t dev_rm_anim_capacity = 0;
+    float4* d_rm_slots = nullptr;
+    uint32_t dev_rm_slots = 0;
     // scratch of the planner
     std::vector<Recipe> recipes;
     std::vector<RecipeItem> items;
@@ -193,7 +216,7 @@ void free_bones(BoneList& b) { dfree(b.d_bone_nodes); b = BoneList(); }
 void free_animator(Animator& a) {
     for (auto& an : a.anims) dfree(an.d_slot_track);
     dfree(a.d_anims); dfree(a.d_hints); dfree(a.d_anim_pose); dfree(a.d_node_trs); dfree(a.d_local);
-    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_ctrl);
+    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_ctrl); dfree(a.d_rm_anim); dfree(a.d_rm_slots);
     for (int i = 0; i < 2; ++i) {
         if (a.h_ctrl[i]) (void)hipHostFree(a.h_ctrl[i]);
         if (a.h_ctrl_ev[i]) (void)hipEventDestroy(a.h_ctrl_ev[i]);
@@ -282,9 +305,38 @@ struct Planner {
     // Animation::tick (lib.rs:471-496): the pose is sampled at the CURRENT time, then time advances.
     void tick(uint32_t a) {
         AnimState& s = as[a];
+        const AnimationDef& def = A.anims[a];
         A.times[(size_t)inst * n_anims + a] = s.time;
-        A.ticked[(size_t)inst * n_anims + a] = 1;
-        set_time_position(s, s.time + dt * s.speed);
+        const float current = s.time, next = current + dt * s.speed;
+        // signals (lib.rs:476-489).  Precedence exactly as written there: `a || b && cap`, so the
+        // max_event_capacity cap guards only the negative-speed branch.
+        for (size_t i = 0; i < def.signals.size(); ++i) {
+            const AnimationDef::Signal& sg = def.signals[i];
+            if (!sg.enabled) continue;
+            if ((s.speed >= 0.0f && (current < sg.time && next >= sg.time)) ||
+                (s.speed < 0.0f && (current > sg.time && next <= sg.time) && s.events.size() < s.max_event_capacity))
+                s.events.push_back((int32_t)i);
+        }
+        set_time_position(s, next);
+        // what update_root_motion needs besides the sampled pose (lib.rs:539-554)
+        const bool new_loop = s.looped && ((s.speed > 0.0f && s.time < current) || (s.speed < 0.0f && s.time > current));
+        A.ticked[(size_t)inst * n_anims + a] = (uint8_t)(1u | (new_loop ? 2u : 0u) | (s.speed > 0.0f ? 4u : 0u));
+    }
+
+    // ---- root-motion program (pose.rs:73,98-100; play.rs:97) ----
+    bool rm() const { return A.rm_enabled; }
+    uint32_t node_slot(uint32_t li, int32_t h) const { return A.rm_layer_base[li] + (uint32_t)h; }
+    uint32_t layer_slot(uint32_t li) const { return A.rm_layer_base[li] + (uint32_t)A.layers[li].nodes.size(); }
+    uint32_t machine_slot() const { return A.n_rm_slots - 1; }
+    void rm_emit(uint32_t code, uint32_t dst, uint32_t src, float w) {
+        uint4 op;
+        op.x = code; op.y = dst; op.z = src;
+        memcpy(&op.w, &w, 4);
+        A.rm_ops.push_back(op);
+    }
+    uint32_t cur_layer = 0;
+    void layer_event(LayerState& LS, int32_t kind, int32_t a, int32_t b) {  // event.rs:79-83
+        if (LS.events.size() < kLayerEventLimit) LS.events.push_back(fyx_layer_event{kind, a, b});
     }
 
     const Param* param(int32_t idx) const {
@@ -338,6 +390,7 @@ struct Planner {
         switch (n.type) {
             case NODE_PLAY:  // play.rs:86-100
                 out = (int32_t)new_recipe_anim(n.animation);
+                if (rm()) rm_emit(RM_SET_ANIM, node_slot(cur_layer, handle), n.animation, 0.f);
                 break;
             case NODE_BLEND: {  // blend.rs:136-164
                 std::vector<RecipeItem> its;
@@ -350,7 +403,10 @@ struct Planner {
                         w = (p && p->kind == FYX_PARAM_WEIGHT) ? p->f0 : 0.0f;
                     }
                     const int32_t src = eval_node(L, LS, in.source, node_recipe);
-                    if (src >= 0) its.push_back({(uint32_t)src, w});
+                    if (src >= 0) {
+                        its.push_back({(uint32_t)src, w});
+                        if (rm()) rm_emit(RM_BLEND, node_slot(cur_layer, handle), node_slot(cur_layer, in.source), w);
+                    }
                 }
                 out = (int32_t)new_recipe_fold(its.data(), (uint32_t)its.size());
                 break;
@@ -372,9 +428,15 @@ struct Planner {
                             st.blend_time = bt;
                             const float interpolator = st.blend_time / cur_in.blend_time;
                             const int32_t pr = eval_node(L, LS, prev_in.source, node_recipe);
-                            if (pr >= 0) its[cnt++] = {(uint32_t)pr, 1.0f - interpolator};
+                            if (pr >= 0) {
+                                its[cnt++] = {(uint32_t)pr, 1.0f - interpolator};
+                                if (rm()) rm_emit(RM_BLEND, node_slot(cur_layer, handle), node_slot(cur_layer, prev_in.source), 1.0f - interpolator);
+                            }
                             const int32_t cr = eval_node(L, LS, cur_in.source, node_recipe);
-                            if (cr >= 0) its[cnt++] = {(uint32_t)cr, interpolator};
+                            if (cr >= 0) {
+                                its[cnt++] = {(uint32_t)cr, interpolator};
+                                if (rm()) rm_emit(RM_BLEND, node_slot(cur_layer, handle), node_slot(cur_layer, cur_in.source), interpolator);
+                            }
                             if (interpolator >= 1.0f) {
                                 st.prev = current;
                                 st.blend_time = 0.0f;
@@ -389,7 +451,10 @@ struct Planner {
                         st.blend_time = 0.0f;
                         if (current < n.inputs.size()) {
                             const int32_t cr = eval_node(L, LS, n.inputs[current].source, node_recipe);
-                            if (cr >= 0) its[cnt++] = {(uint32_t)cr, 1.0f};  // clone_into an empty pose
+                            if (cr >= 0) {
+                                its[cnt++] = {(uint32_t)cr, 1.0f};  // clone_into an empty pose
+                                if (rm()) rm_emit(RM_COPY, node_slot(cur_layer, handle), node_slot(cur_layer, n.inputs[current].source), 0.f);
+                            }
                         }
                     }
                 }
@@ -409,9 +474,12 @@ struct Planner {
                                       sc = n.inputs[idx[2]].source;
                         auto ok = [&](int32_t h) { return h >= 0 && (size_t)h < L.nodes.size(); };
                         if (ok(sa) && ok(sb) && ok(sc)) {
-                            its[cnt++] = {(uint32_t)eval_node(L, LS, sa, node_recipe), w[0]};
-                            its[cnt++] = {(uint32_t)eval_node(L, LS, sb, node_recipe), w[1]};
-                            its[cnt++] = {(uint32_t)eval_node(L, LS, sc, node_recipe), w[2]};
+                            // blendspace.rs:139-141: evaluate a, blend, evaluate b, blend, evaluate c, blend
+                            const int32_t srcs[3] = {sa, sb, sc};
+                            for (int k = 0; k < 3; ++k) {
+                                its[cnt++] = {(uint32_t)eval_node(L, LS, srcs[k], node_recipe), w[k]};
+                                if (rm()) rm_emit(RM_BLEND, node_slot(cur_layer, handle), node_slot(cur_layer, srcs[k]), w[k]);
+                            }
                         }
                     }
                 }
@@ -526,6 +594,7 @@ struct Planner {
     void plan_layer(uint32_t li) {
         const LayerDef& L = A.layers[li];
         LayerState& LS = ms->layers[li];
+        cur_layer = li;
         if (LS.active_state >= 0 || LS.active_transition >= 0) {
             A.node_recipe.assign(L.nodes.size(), -1);
             int32_t* nr = A.node_recipe.data();
@@ -539,9 +608,12 @@ struct Planner {
                     if (logic(tr.logic, pc)) {
                         if (LS.active_state >= 0 && (size_t)LS.active_state < L.states.size())
                             apply_actions(L.states[LS.active_state].on_leave);
+                        layer_event(LS, FYX_EVENT_STATE_LEAVE, LS.active_state, -1);             // layer.rs:620
                         if (tr.dest < L.states.size()) apply_actions(L.states[tr.dest].on_enter);
+                        layer_event(LS, FYX_EVENT_STATE_ENTER, (int32_t)tr.dest, -1);            // :634
                         LS.active_state = -1;
                         LS.active_transition = (int32_t)t;
+                        layer_event(LS, FYX_EVENT_ACTIVE_TRANSITION_CHANGED, (int32_t)t, -1);    // :645
                         break;
                     }
                 }
@@ -557,8 +629,14 @@ struct Planner {
                 const TransitionDef& tr = L.transitions[LS.active_transition];
                 TransitionState& ts = LS.transitions[LS.active_transition];
                 const int32_t src = root_recipe(tr.source), dst = root_recipe(tr.dest);
-                if (src >= 0) emit_blend((uint32_t)src, 1.0f - ts.blend_factor);
-                if (dst >= 0) emit_blend((uint32_t)dst, ts.blend_factor);
+                if (src >= 0) {
+                    emit_blend((uint32_t)src, 1.0f - ts.blend_factor);
+                    if (rm()) rm_emit(RM_BLEND, layer_slot(li), node_slot(li, L.states[tr.source].root), 1.0f - ts.blend_factor);
+                }
+                if (dst >= 0) {
+                    emit_blend((uint32_t)dst, ts.blend_factor);
+                    if (rm()) rm_emit(RM_BLEND, layer_slot(li), node_slot(li, L.states[tr.dest].root), ts.blend_factor);
+                }
                 ts.elapsed += dt;  // transition.rs:315-321
                 if (ts.elapsed > tr.time) ts.elapsed = tr.time;
                 ts.blend_factor = ts.elapsed / tr.time;
@@ -566,11 +644,16 @@ struct Planner {
                     ts.elapsed = 0.0f;
                     ts.blend_factor = 0.0f;
                     LS.active_transition = -1;
+                    layer_event(LS, FYX_EVENT_ACTIVE_TRANSITION_CHANGED, -1, -1);                 // :673
                     LS.active_state = (int32_t)tr.dest;
+                    layer_event(LS, FYX_EVENT_ACTIVE_STATE_CHANGED, (int32_t)tr.source, (int32_t)tr.dest);  // :677
                 }
             } else {
                 const int32_t r = root_recipe((uint32_t)LS.active_state);
-                if (r >= 0) emit_blend((uint32_t)r, 1.0f);  // clone_into the (reset) final pose
+                if (r >= 0) {
+                    emit_blend((uint32_t)r, 1.0f);  // clone_into the (reset) final pose
+                    if (rm()) rm_emit(RM_COPY, layer_slot(li), node_slot(li, L.states[LS.active_state].root), 0.f);
+                }
             }
         }
         if (!L.excluded.empty()) emit(OP_MASK, li, 0.f);
@@ -600,9 +683,11 @@ struct Planner {
             plan_layer((uint32_t)li);
             depth = 0;
             emit(OP_POP_BLEND, 0, A.layers[li].weight);
+            if (rm()) rm_emit(RM_BLEND, machine_slot(), layer_slot((uint32_t)li), A.layers[li].weight);  // mod.rs:375-378
         }
         emit(OP_APPLY, 0, 0.f);
         emit(OP_END, 0, 0.f);
+        if (rm()) rm_emit(RM_END, 0, 0, 0.f);
     }
 
     // AnimationContainerExt::update_animations (scene/animation/mod.rs:83-88)
@@ -645,13 +730,26 @@ int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
     A.prog_off.assign((size_t)A.n_instances + 1, 0);
     A.seen.assign(na ? na : 1, 0);
     if (mode == 1) ensure_machine_state(A);  // instances get their machine state lazily
+    A.rm_ops.clear();
+    A.rm_prog_off.assign((size_t)A.n_instances + 1, 0);
+    if (A.rm_enabled) {
+        // slots: per layer its pose nodes then its final pose; the machine's final pose last
+        A.rm_layer_base.assign(A.layers.size(), 0);
+        uint32_t n = 0;
+        for (size_t l = 0; l < A.layers.size(); ++l) { A.rm_layer_base[l] = n; n += (uint32_t)A.layers[l].nodes.size() + 1; }
+        A.n_rm_slots = n + 1;
+        A.slices.resize((size_t)A.n_instances * na);
+        for (size_t k = 0; k < A.slices.size(); ++k) A.slices[k] = make_float2(A.anim_state[k].start, A.anim_state[k].end);
+    }
     for (uint32_t i = 0; i < A.n_instances; ++i) {
         A.prog_off[i] = (uint32_t)A.ops.size();
+        A.rm_prog_off[i] = (uint32_t)A.rm_ops.size();
         Planner p(A, i, dt);
         if (mode == 1) p.plan_absm(); else p.plan_player();
         if (p.error) return fail(c, p.error, "pose nodes nest deeper than %d blend levels", kMaxFoldDepth - 2);
     }
     A.prog_off[A.n_instances] = (uint32_t)A.ops.size();
+    A.rm_prog_off[A.n_instances] = (uint32_t)A.rm_ops.size();
     return FYX_OK;
 }
 
@@ -730,12 +828,42 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             hd[a].key_aux = an.td->d_aux;
             hd[a].slot_track = an.d_slot_track;
             hd[a].n_tracks = an.td->n_tracks;
+            hd[a].rm_node = an.rm_node;
+            hd[a].rm_ignore = an.rm_ignore;
+            hd[a].rm_pos_track = an.rm_pos_track;
+            hd[a].rm_rot_track = an.rm_rot_track;
             hd[a].pad = 0;
         }
         dfree(A.d_anims);
         A.d_anims = nullptr;
         if (int rc = upload(c, &A.d_anims, hd.data(), hd.size())) return rc;
         A.anims_dirty = false;
+    }
+    if (A.rm_enabled) {
+        if (A.dev_rm_anim_capacity < A.dev_anim_capacity) {  // [anim][instance]: growing keeps the existing prefix
+            RootMotionDev* nr = nullptr;
+            const size_t nb = (size_t)A.dev_anim_capacity * A.n_instances * sizeof(RootMotionDev);
+            FYX_HIP(c, hipStreamSynchronize(c->stream));
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&nr), std::max<size_t>(nb, 16)));
+            FYX_HIP(c, hipMemset(nr, 0, std::max<size_t>(nb, 16)));
+            if (A.d_rm_anim && A.dev_rm_anim_capacity)
+                FYX_HIP(c, hipMemcpy(nr, A.d_rm_anim, (size_t)A.dev_rm_anim_capacity * A.n_instances * sizeof(RootMotionDev),
+                                     hipMemcpyDeviceToDevice));
+            dfree(A.d_rm_anim);
+            A.d_rm_anim = nr;
+            A.dev_rm_anim_capacity = A.dev_anim_capacity;
+        }
+        uint32_t want = 1;
+        for (const LayerDef& L : A.layers) want += (uint32_t)L.nodes.size() + 1;
+        if (want != A.dev_rm_slots) {  // the machine graph changed: every pose's root motion starts from None again
+            FYX_HIP(c, hipStreamSynchronize(c->stream));
+            dfree(A.d_rm_slots);
+            A.d_rm_slots = nullptr;
+            const size_t nb = (size_t)A.n_instances * want * 32;
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_rm_slots), nb));
+            FYX_HIP(c, hipMemset(A.d_rm_slots, 0, nb));
+            A.dev_rm_slots = want;
+        }
     }
     if (A.masks_dirty || A.dev_mask_layers != A.layers.size()) {
         FYX_HIP(c, hipStreamSynchronize(c->stream));
@@ -783,7 +911,12 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     if (with_program) {
         const size_t b_times = align_up(A.times.size() * 4, 256), b_tick = align_up(A.ticked.size(), 256);
         const size_t b_off = align_up(A.prog_off.size() * 4, 256), b_ops = align_up(A.ops.size() * 8, 256);
-        const size_t total = b_times + b_tick + b_off + b_ops;
+        const bool rm = A.rm_enabled;
+        const size_t b_slices = rm ? align_up(A.slices.size() * 8, 256) : 0;
+        const size_t b_rmoff = rm ? align_up(A.rm_prog_off.size() * 4, 256) : 0;
+        const size_t b_rmops = rm ? align_up(A.rm_ops.size() * 16, 256) : 0;
+        const size_t o_slices = b_times + b_tick + b_off + b_ops, o_rmoff = o_slices + b_slices, o_rmops = o_rmoff + b_rmoff;
+        const size_t total = o_rmops + b_rmops;
         const int slot = A.h_ctrl_next;
         A.h_ctrl_next ^= 1;
         if (A.h_ctrl_busy[slot]) {
@@ -811,6 +944,11 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         memcpy(h + b_times, A.ticked.data(), A.ticked.size());
         memcpy(h + b_times + b_tick, A.prog_off.data(), A.prog_off.size() * 4);
         memcpy(h + b_times + b_tick + b_off, A.ops.data(), A.ops.size() * 8);
+        if (rm) {
+            memcpy(h + o_slices, A.slices.data(), A.slices.size() * 8);
+            memcpy(h + o_rmoff, A.rm_prog_off.data(), A.rm_prog_off.size() * 4);
+            memcpy(h + o_rmops, A.rm_ops.data(), A.rm_ops.size() * 16);
+        }
         FYX_HIP(c, hipMemcpyAsync(A.d_ctrl, h, total, hipMemcpyHostToDevice, c->stream));
         FYX_HIP(c, hipEventRecord(A.h_ctrl_ev[slot], c->stream));
         A.h_ctrl_busy[slot] = true;
@@ -820,6 +958,15 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         f.prog_off = reinterpret_cast<const uint32_t*>(d + b_times + b_tick);
         f.ops = reinterpret_cast<const uint2*>(d + b_times + b_tick + b_off);
         FYX_HIP(c, launch_pose_sample(f, c->stream));
+        if (rm) {
+            f.slices = reinterpret_cast<const float2*>(d + o_slices);
+            f.rm_anim = A.d_rm_anim;
+            f.rm_slots = A.d_rm_slots;
+            f.n_rm_slots = A.dev_rm_slots;
+            f.rm_prog_off = reinterpret_cast<const uint32_t*>(d + o_rmoff);
+            f.rm_ops = reinterpret_cast<const uint4*>(d + o_rmops);
+            FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), c->stream));
+        }
     }
     FYX_HIP(c, launch_pose_update(f, rig_dev(*A.rig), with_program, c->stream));
     return FYX_OK;
@@ -1160,6 +1307,10 @@ int fyx_animator_add_animation(fyx_ctx* c, uint64_t animator_id, uint64_t tracks
             if (u) return fail(c, FYX_ERR_UNSUPPORTED, "two tracks drive the same binding of node %d", track_target[t]);
             u = 1;
         }
+    }
+    for (uint32_t t = 0; t < td.n_tracks; ++t) {  // lib.rs:507-534: the first track with the binding
+        if (an.rm_pos_track < 0 && td.tracks[t].binding == FYX_BIND_POSITION) an.rm_pos_track = (int32_t)t;
+        if (an.rm_rot_track < 0 && td.tracks[t].binding == FYX_BIND_ROTATION) an.rm_rot_track = (int32_t)t;
     }
     const uint32_t na = (uint32_t)A->anims.size();
     // re-layout [inst][anim] state for the new animation count
@@ -1631,6 +1782,182 @@ int fyx_animator_plan(fyx_ctx* c, uint64_t animator_id, int mode, float dt, floa
     if (program_offset) memcpy(program_offset, A->prog_off.data(), A->prog_off.size() * 4);
     if (n_ops) *n_ops = (uint32_t)A->ops.size();
     if (ops) memcpy(ops, A->ops.data(), std::min<size_t>(A->ops.size(), ops_capacity) * 8);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+// ---- signals / events / root motion ----------------------------------------------------------
+
+int fyx_animation_add_signal(fyx_ctx* c, uint64_t animator_id, uint32_t animation, float time, int enabled, uint32_t* out_signal) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    A->anims[animation].signals.push_back(AnimationDef::Signal{time, (uint8_t)(enabled ? 1 : 0)});
+    if (out_signal) *out_signal = (uint32_t)A->anims[animation].signals.size() - 1;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+int fyx_animation_set_signal_enabled(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t signal, int enabled) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (signal >= A->anims[animation].signals.size()) return fail(c, FYX_ERR_INVALID_ARG, "signal %u does not exist", signal);
+    A->anims[animation].signals[signal].enabled = enabled ? 1 : 0;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+int fyx_animation_set_max_event_capacity(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, uint32_t capacity) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { s.max_event_capacity = capacity; });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_pop_event(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, int32_t* out_signal) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    if (!out_signal) return fail(c, FYX_ERR_INVALID_ARG, "out_signal is null");
+    return for_instances(c, A, animation, instance, [&](AnimState& s) {
+        if (s.events.empty()) { *out_signal = -1; return; }
+        *out_signal = s.events.front();
+        s.events.pop_front();
+    });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_event_count(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, uint32_t* out_count) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    if (!out_count) return fail(c, FYX_ERR_INVALID_ARG, "out_count is null");
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { *out_count = (uint32_t)s.events.size(); });
+    FYX_GUARD_END(c)
+}
+int fyx_animation_clear_events(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    return for_instances(c, A, animation, instance, [&](AnimState& s) { s.events.clear(); });
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_track_root_motion(fyx_ctx* c, uint64_t animator_id, int enabled) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!enabled) {
+        for (const AnimationDef& an : A->anims)
+            if (an.rm_node >= 0) return fail(c, FYX_ERR_INVALID_ARG, "an animation still has root motion settings");
+        if (has_device(c) && (A->d_rm_anim || A->d_rm_slots)) {
+            if (int rc = enter_primary(c)) return rc;
+            FYX_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        dfree(A->d_rm_anim); dfree(A->d_rm_slots);
+        A->d_rm_anim = nullptr; A->d_rm_slots = nullptr;
+        A->dev_rm_anim_capacity = 0; A->dev_rm_slots = 0;
+    }
+    A->rm_enabled = enabled != 0;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animation_set_root_motion_settings(fyx_ctx* c, uint64_t animator_id, uint32_t animation, int32_t node,
+                                           int ignore_x, int ignore_y, int ignore_z, int ignore_rotations) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (node >= (int32_t)A->rig->n_nodes) return fail(c, FYX_ERR_INVALID_ARG, "root motion node %d of a %u-node rig", node, A->rig->n_nodes);
+    AnimationDef& an = A->anims[animation];
+    an.rm_node = node < 0 ? -1 : node;
+    an.rm_ignore = (ignore_x ? 1u : 0u) | (ignore_y ? 2u : 0u) | (ignore_z ? 4u : 0u) | (ignore_rotations ? 8u : 0u);
+    A->anims_dirty = true;
+    if (node >= 0) A->rm_enabled = true;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animation_read_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t animation, fyx_root_motion* host_out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
+    if (!A->rm_enabled) return fail(c, FYX_ERR_INVALID_ARG, "root motion is not tracked on this animator");
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, *A)) return rc;
+    static_assert(sizeof(fyx_root_motion) == 32, "fyx_root_motion layout");
+    // the first 32 bytes of a RootMotionDev are exactly a fyx_root_motion
+    FYX_HIP(c, hipMemcpy2DAsync(host_out, sizeof(fyx_root_motion), A->d_rm_anim + (size_t)animation * A->n_instances,
+                                sizeof(RootMotionDev), sizeof(fyx_root_motion), A->n_instances, hipMemcpyDeviceToHost, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < A->n_instances; ++i)
+        if (!host_out[i].has) { memset(&host_out[i], 0, sizeof host_out[i]); host_out[i].delta_rotation[3] = 1.0f; }
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_absm_read_root_motion(fyx_ctx* c, uint64_t animator_id, int32_t layer, fyx_root_motion* host_out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
+    if (!A->rm_enabled) return fail(c, FYX_ERR_INVALID_ARG, "root motion is not tracked on this animator");
+    if (layer >= (int32_t)A->layers.size()) return fail(c, FYX_ERR_INVALID_ARG, "layer %d does not exist", layer);
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, *A)) return rc;
+    uint32_t slot = A->dev_rm_slots - 1;
+    if (layer >= 0) {
+        slot = 0;
+        for (int32_t l = 0; l < layer; ++l) slot += (uint32_t)A->layers[l].nodes.size() + 1;
+        slot += (uint32_t)A->layers[layer].nodes.size();
+    }
+    FYX_HIP(c, hipMemcpy2DAsync(host_out, 32, reinterpret_cast<const char*>(A->d_rm_slots) + (size_t)slot * 32,
+                                (size_t)A->dev_rm_slots * 32, 32, A->n_instances, hipMemcpyDeviceToHost, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < A->n_instances; ++i)
+        if (!host_out[i].has) { memset(&host_out[i], 0, sizeof host_out[i]); host_out[i].delta_rotation[3] = 1.0f; }
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_pop_event(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance, fyx_layer_event* out_event, int* out_has) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    (void)L;
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    if (!out_event || !out_has) return fail(c, FYX_ERR_INVALID_ARG, "out pointers are null");
+    *out_has = 0;
+    if (A->mstate.size() != A->n_instances) return FYX_OK;
+    std::deque<fyx_layer_event>& q = A->mstate[instance].layers[layer].events;
+    if (q.empty()) return FYX_OK;
+    *out_event = q.front();
+    q.pop_front();
+    *out_has = 1;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_plan_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t* program_offset, uint32_t* ops,
+                                  uint32_t ops_capacity, uint32_t* n_ops, uint32_t* n_slots, float* slices) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!A->rm_enabled) return fail(c, FYX_ERR_INVALID_ARG, "root motion is not tracked on this animator");
+    if (A->rm_prog_off.size() != (size_t)A->n_instances + 1) return fail(c, FYX_ERR_INVALID_ARG, "no frame has been planned yet");
+    if (program_offset) memcpy(program_offset, A->rm_prog_off.data(), A->rm_prog_off.size() * 4);
+    if (n_ops) *n_ops = (uint32_t)A->rm_ops.size();
+    if (n_slots) *n_slots = A->n_rm_slots;
+    if (ops) memcpy(ops, A->rm_ops.data(), std::min<size_t>(A->rm_ops.size(), ops_capacity) * 16);
+    if (slices) memcpy(slices, A->slices.data(), A->slices.size() * 8);
     return FYX_OK;
     FYX_GUARD_END(c)
 }

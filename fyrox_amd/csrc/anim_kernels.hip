@@ -94,6 +94,35 @@ __device__ __forceinline__ f4 quat_mul(f4 a, f4 b) {  // Hamilton product, stora
     const float k = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
     return f4{i, j, k, w};
 }
+// Rotation value of a lane group whose lanes base..base+3 sampled the (up to four) curves of a
+// rotation track: UnitQuaternion -> from_quaternion (normalise, container.rs:277-279);
+// UnitQuaternionEuler -> qz * qy * qx (fyrox-math/src/lib.rs:725-740), lanes base..base+2 each
+// evaluating sin/cos of their own half angle once.  has_r / rkind are uniform over the group;
+// every lane of the wave must call this (cross-lane shuffles).
+__device__ __forceinline__ f4 group_rotation(float v, int has_r, int rkind, int base) {
+    const float r0 = __shfl(v, base, 64), r1 = __shfl(v, base + 1, 64);
+    const float r2 = __shfl(v, base + 2, 64), r3 = __shfl(v, base + 3, 64);
+    f4 q = f4{0.f, 0.f, 0.f, 1.f};
+    if (__any(has_r && rkind == FYX_KIND_QUAT_EULER)) {
+        // (axis * sin(angle/2), cos(angle/2)) of this lane's own angle; lanes base.. are x,y,z
+        const float half = v / 2.0f;
+        double sd, cd;
+        sincos((double)half, &sd, &cd);
+        const float sn = (float)sd, cs = (float)cd;
+        const float sx = __shfl(sn, base, 64), cx = __shfl(cs, base, 64);
+        const float sy = __shfl(sn, base + 1, 64), cy = __shfl(cs, base + 1, 64);
+        const float sz = __shfl(sn, base + 2, 64), cz = __shfl(cs, base + 2, 64);
+        if (has_r && rkind == FYX_KIND_QUAT_EULER) {
+            const f4 qx = f4{1.0f * sx, 0.0f * sx, 0.0f * sx, cx};
+            const f4 qy = f4{0.0f * sy, 1.0f * sy, 0.0f * sy, cy};
+            const f4 qz = f4{0.0f * sz, 0.0f * sz, 1.0f * sz, cz};
+            q = quat_mul(quat_mul(qz, qy), qx);
+        }
+    }
+    if (has_r && rkind == FYX_KIND_QUAT) q = quat_normalize(f4{r0, r1, r2, r3});
+    return q;
+}
+
 // ---------------------------------------------------------------------------------------
 // pose_sample: sixteen lanes per (animation, instance, node), ONE LANE PER CURVE.  A curve sample is
 // a chain of dependent loads (hint -> key locations -> key values), so a thread that walked the ten
@@ -116,7 +145,7 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
         const uint32_t a = (uint32_t)(item / per_anim);
         const uint32_t rem = (uint32_t)(item - (uint64_t)a * per_anim);
         const uint32_t inst = rem / f.n_nodes, node = rem - inst * f.n_nodes;
-        if (!f.ticked[(size_t)inst * f.n_anims + a]) continue;  // uniform across the group
+        if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) continue;  // uniform across the group
         const float time = f.times[(size_t)inst * f.n_anims + a];
         const AnimDev an = f.anims[a];
 
@@ -151,27 +180,7 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
         const int has_s = __shfl((int)valid, (int)gbase + 8, 64);
         const int rkind = __shfl(kind, (int)gbase + 4, 64);
 
-        // rotation: gather the (up to four) sampled components on every lane of the group
-        const float r0 = __shfl(v, (int)gbase + 4, 64), r1 = __shfl(v, (int)gbase + 5, 64);
-        const float r2 = __shfl(v, (int)gbase + 6, 64), r3 = __shfl(v, (int)gbase + 7, 64);
-        f4 q = f4{0.f, 0.f, 0.f, 1.f};
-        if (__any(has_r && rkind == FYX_KIND_QUAT_EULER)) {
-            // (axis * sin(angle/2), cos(angle/2)) of this lane's own angle; lanes 4,5,6 are x,y,z
-            const float half = v / 2.0f;
-            double sd, cd;
-            sincos((double)half, &sd, &cd);
-            const float sn = (float)sd, cs = (float)cd;
-            const float sx = __shfl(sn, (int)gbase + 4, 64), cx = __shfl(cs, (int)gbase + 4, 64);
-            const float sy = __shfl(sn, (int)gbase + 5, 64), cy = __shfl(cs, (int)gbase + 5, 64);
-            const float sz = __shfl(sn, (int)gbase + 6, 64), cz = __shfl(cs, (int)gbase + 6, 64);
-            if (has_r && rkind == FYX_KIND_QUAT_EULER) {
-                const f4 qx = f4{1.0f * sx, 0.0f * sx, 0.0f * sx, cx};
-                const f4 qy = f4{0.0f * sy, 1.0f * sy, 0.0f * sy, cy};
-                const f4 qz = f4{0.0f * sz, 0.0f * sz, 1.0f * sz, cz};
-                q = quat_mul(quat_mul(qz, qy), qx);
-            }
-        }
-        if (has_r && rkind == FYX_KIND_QUAT) q = quat_normalize(f4{r0, r1, r2, r3});
+        const f4 q = group_rotation(v, has_r, rkind, (int)gbase + 4);
 
         float out;
         if (j < 3 || (j >= 8 && j < 11)) out = v;   // an absent binding sampled nothing: 0
@@ -192,6 +201,211 @@ hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s) {
     if (grid > (uint64_t)kCUs * 32) grid = (uint64_t)kCUs * 32;
     hipLaunchKernelGGL(pose_sample_kernel, dim3((uint32_t)grid), dim3(256), 0, s, f);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Root motion.
+//
+// root_motion_kernel = Animation::update_root_motion (fyrox-animation/src/lib.rs:498-661) for every
+// ticked animation with RootMotionSettings: sixteen lanes per (animation, instance), ONE LANE PER
+// CURVE SAMPLE as in pose_sample.  The reference fetches the first Position / Rotation track of the
+// tracks data at cycle_start_time, cycle_end_time and time_slice.start, all of which are one of
+// {time_slice.start, time_slice.end}: lanes 0..7 sample at the slice start, lanes 8..15 at the slice
+// end (within each half: 0..2 position xyz, 4..7 rotation), with fresh hints as HintContainer::
+// default() gives.  Lane 0 then runs the scalar update against the root node's sampled pose record,
+// stores the animation's RootMotion and rewrites the record (the root stops moving).
+//
+// root_motion_fold_kernel: one thread per instance runs the instance's root-motion program (the
+// order in which the reference's pose nodes / layers / machine called clone_into and blend_with on
+// each other's poses, recorded by the host control plane) over the persistent slots.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void root_motion_kernel(PoseFrameDev f) {
+    const uint32_t lane = threadIdx.x & 63u, j = threadIdx.x & 15u, gbase = lane & ~15u;
+    const uint32_t items = f.n_anims * f.n_instances;
+    const uint32_t groups_per_pass = (gridDim.x * blockDim.x) >> 4;
+    for (uint32_t item = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; item < items; item += groups_per_pass) {
+        const uint32_t a = item / f.n_instances, inst = item - a * f.n_instances;
+        const uint32_t flags = f.ticked[(size_t)inst * f.n_anims + a];
+        const AnimDev an = f.anims[a];
+        if (!(flags & 1u) || an.rm_node < 0) continue;  // uniform across the group
+        const float2 slice = f.slices[(size_t)inst * f.n_anims + a];
+        const uint32_t half = j >> 3, c8 = j & 7u;
+        const float time = half ? slice.y : slice.x;
+        int32_t track = -1;
+        int c = 0;
+        if (c8 < 3) { track = an.rm_pos_track; c = (int)c8; }
+        else if (c8 >= 4) { track = an.rm_rot_track; c = (int)c8 - 4; }
+        int kind = -1;
+        bool valid = false;
+        float v = 0.0f;
+        if (track >= 0) {
+            const TrackDev* tk = an.tracks + track;
+            kind = tk->kind;
+            const int need = kind == FYX_KIND_QUAT ? 4 : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3 : 0;
+            const bool fits = (c8 >= 4) ? (kind == FYX_KIND_QUAT || kind == FYX_KIND_QUAT_EULER) : (kind == FYX_KIND_VEC3);
+            valid = fits && need > 0 && (int)tk->n_curves >= need;  // else .and_then(..) -> unwrap_or_default()
+            if (valid && c < need) {
+                uint32_t hint = 0;
+                const uint32_t fk = tk->first_key[c];
+                v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], time, hint);
+            }
+        }
+        const int sub = (int)(gbase + half * 8u);
+        const int has_p = __shfl((int)valid, sub, 64);
+        const int has_r = __shfl((int)valid, sub + 4, 64);
+        const int rkind = __shfl(kind, sub + 4, 64);
+        const f4 q = group_rotation(v, has_r, rkind, sub + 4);   // identity when the fetch fails
+        const float pv = has_p ? v : 0.0f;                        // Vector3::default()
+        // gather both halves on every lane
+        float ps[3], pe[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ps[k] = __shfl(pv, (int)gbase + k, 64);
+            pe[k] = __shfl(pv, (int)gbase + 8 + k, 64);
+        }
+        f4 qs, qe;
+        qs.x = __shfl(q.x, (int)gbase, 64); qs.y = __shfl(q.y, (int)gbase, 64);
+        qs.z = __shfl(q.z, (int)gbase, 64); qs.w = __shfl(q.w, (int)gbase, 64);
+        qe.x = __shfl(q.x, (int)gbase + 8, 64); qe.y = __shfl(q.y, (int)gbase + 8, 64);
+        qe.z = __shfl(q.z, (int)gbase + 8, 64); qe.w = __shfl(q.w, (int)gbase + 8, 64);
+        if (j != 0) continue;
+
+        const bool new_loop = (flags & 2u) != 0, fwd = (flags & 4u) != 0;
+        RootMotionDev* st = f.rm_anim + (size_t)a * f.n_instances + inst;
+        RootMotionDev prev = *st;
+        if (!prev.has) {  // self.root_motion.clone().unwrap_or_default()
+            prev = RootMotionDev{};
+            prev.delta_rotation[3] = 1.0f;
+            prev.prev_rotation[3] = 1.0f;
+        }
+        RootMotionDev rm = RootMotionDev{};
+        rm.has = 1u;
+        rm.delta_rotation[3] = 1.0f;
+        rm.prev_rotation[3] = 1.0f;
+        f4* rec = reinterpret_cast<f4*>(f.anim_pose) + ((size_t)a * f.n_instances * f.n_nodes + (size_t)inst * f.n_nodes + (uint32_t)an.rm_node) * 3;
+        f4 r0 = rec[0], r1 = rec[1];
+        const uint32_t present = __float_as_uint(r0.w);
+        if (present & 1u) {  // ValueBinding::Position / TrackValue::Vector3
+            const float p[3] = {r0.x, r0.y, r0.z};
+            const float* cyc_start = fwd ? ps : pe;   // speed > 0 ? time_slice.start : time_slice.end
+            const float* cyc_end = fwd ? pe : ps;
+            if (new_loop) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    rm.prev_position[k] = cyc_start[k];
+                    rm.position_offset_remainder[k] = cyc_end[k] - p[k];
+                }
+                rm.rem_flags |= 1u;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rm.prev_position[k] = p[k];
+            }
+            float delta[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float remainder = (prev.rem_flags & 1u) ? prev.position_offset_remainder[k] : 0.0f;
+                const float current_offset = p[k] - prev.prev_position[k];
+                delta[k] = current_offset + remainder;
+            }
+            rm.delta_position[0] = (an.rm_ignore & 1u) ? 0.0f : delta[0];
+            rm.delta_position[1] = (an.rm_ignore & 2u) ? 0.0f : delta[1];
+            rm.delta_position[2] = (an.rm_ignore & 4u) ? 0.0f : delta[2];
+            r0.x = (an.rm_ignore & 1u) ? p[0] : ps[0];   // start_position = fetch(time_slice.start)
+            r0.y = (an.rm_ignore & 2u) ? p[1] : ps[1];
+            r0.z = (an.rm_ignore & 4u) ? p[2] : ps[2];
+        }
+        if ((present & 4u) && !(an.rm_ignore & 8u)) {  // ValueBinding::Rotation / UnitQuaternion
+            const f4 pose_rotation = r1;
+            const f4 cyc_start = fwd ? qs : qe, cyc_end = fwd ? qe : qs;
+            auto conj = [](f4 x) { return f4{-x.x, -x.y, -x.z, x.w}; };  // UnitQuaternion::inverse
+            if (new_loop) {
+                const f4 rem = quat_mul(conj(cyc_end), pose_rotation);
+                rm.prev_rotation[0] = cyc_start.x; rm.prev_rotation[1] = cyc_start.y;
+                rm.prev_rotation[2] = cyc_start.z; rm.prev_rotation[3] = cyc_start.w;
+                rm.rotation_remainder[0] = rem.x; rm.rotation_remainder[1] = rem.y;
+                rm.rotation_remainder[2] = rem.z; rm.rotation_remainder[3] = rem.w;
+                rm.rem_flags |= 2u;
+            } else {
+                rm.prev_rotation[0] = pose_rotation.x; rm.prev_rotation[1] = pose_rotation.y;
+                rm.prev_rotation[2] = pose_rotation.z; rm.prev_rotation[3] = pose_rotation.w;
+            }
+            const f4 remainder = (prev.rem_flags & 2u)
+                ? f4{prev.rotation_remainder[0], prev.rotation_remainder[1], prev.rotation_remainder[2], prev.rotation_remainder[3]}
+                : f4{0.f, 0.f, 0.f, 1.f};
+            const f4 pp = f4{prev.prev_rotation[0], prev.prev_rotation[1], prev.prev_rotation[2], prev.prev_rotation[3]};
+            const f4 current_relative_rotation = quat_mul(conj(pp), pose_rotation);
+            const f4 d = quat_mul(remainder, current_relative_rotation);
+            rm.delta_rotation[0] = d.x; rm.delta_rotation[1] = d.y; rm.delta_rotation[2] = d.z; rm.delta_rotation[3] = d.w;
+            r1 = qs;
+        }
+        *st = rm;
+        rec[0] = r0;
+        rec[1] = r1;
+    }
+}
+
+// RootMotion::blend_with (lib.rs:340-343) on {delta_position, has}{delta_rotation} slot pairs.
+__device__ __forceinline__ void rm_blend(f4& sp, f4& sr, f4 op, f4 orr, float w) {
+    if (__float_as_uint(sp.w) == 0u) { sp = f4{0.f, 0.f, 0.f, __uint_as_float(1u)}; sr = f4{0.f, 0.f, 0.f, 1.f}; }
+    if (__float_as_uint(op.w) == 0u) { op = f4{0.f, 0.f, 0.f, 0.f}; orr = f4{0.f, 0.f, 0.f, 1.f}; }
+    const float omw = 1.0f - w;
+    sp.x = sp.x * omw + op.x * w;
+    sp.y = sp.y * omw + op.y * w;
+    sp.z = sp.z * omw + op.z * w;
+    f4 a = sr;
+    if (dot4(a, orr) < 0.0f) a = f4{-a.x, -a.y, -a.z, -a.w};
+    sr = quat_normalize(f4{a.x * omw + orr.x * w, a.y * omw + orr.y * w, a.z * omw + orr.z * w, a.w * omw + orr.w * w});
+}
+
+__global__ __launch_bounds__(64) void root_motion_fold_kernel(PoseFrameDev f) {
+    const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= f.n_instances) return;
+    f4* slots = reinterpret_cast<f4*>(f.rm_slots) + (size_t)inst * f.n_rm_slots * 2;
+    uint32_t pc = f.rm_prog_off[inst];
+    const uint32_t end = f.rm_prog_off[inst + 1];
+    if (pc >= end) return;
+    uint4 op = f.rm_ops[pc];
+    while (true) {
+        ++pc;
+        const uint4 next = pc < end ? f.rm_ops[pc] : make_uint4(RM_END, 0, 0, 0);  // fetched ahead of the dependent slot traffic
+        if (op.x == RM_END) break;
+        f4* d = slots + (size_t)op.y * 2;
+        if (op.x == RM_SET_ANIM) {
+            const RootMotionDev* r = f.rm_anim + (size_t)op.z * f.n_instances + inst;
+            const uint32_t has = r->has;
+            d[0] = f4{r->delta_position[0], r->delta_position[1], r->delta_position[2], __uint_as_float(has ? 1u : 0u)};
+            d[1] = f4{r->delta_rotation[0], r->delta_rotation[1], r->delta_rotation[2], r->delta_rotation[3]};
+        } else {
+            const f4* sl = slots + (size_t)op.z * 2;
+            const f4 s0 = sl[0], s1 = sl[1];
+            if (op.x == RM_COPY) {
+                d[0] = s0;
+                d[1] = s1;
+            } else {  // RM_BLEND
+                f4 d0 = d[0], d1 = d[1];
+                rm_blend(d0, d1, s0, s1, __uint_as_float(op.w));
+                d[0] = d0;
+                d[1] = d1;
+            }
+        }
+        op = next;
+    }
+}
+
+hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s) {
+    const uint64_t items = (uint64_t)f.n_anims * f.n_instances;
+    if (items && f.rm_anim) {
+        uint64_t grid = (items * 16 + 255) / 256;
+        if (grid > (uint64_t)kCUs * 16) grid = (uint64_t)kCUs * 16;
+        hipLaunchKernelGGL(root_motion_kernel, dim3((uint32_t)grid), dim3(256), 0, s, f);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (run_program && f.rm_slots && f.rm_ops && f.n_instances) {
+        hipLaunchKernelGGL(root_motion_fold_kernel, dim3((f.n_instances + 63) / 64), dim3(64), 0, s, f);
+        return hipGetLastError();
+    }
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------

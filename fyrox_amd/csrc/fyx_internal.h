@@ -88,7 +88,38 @@ struct AnimDev {
     const float4* key_aux;       // {value, kind bits, left tangent, right tangent} per key
     const int32_t* slot_track;   // [n_nodes][3]: track feeding Position/Scale/Rotation of a node, -1 none
     uint32_t n_tracks;
+    // RootMotionSettings (lib.rs:307-319): rm_node < 0 = None; rm_ignore bits 1 x, 2 y, 4 z, 8 rotations;
+    // rm_pos_track / rm_rot_track: FIRST track of the tracks data bound to Position / Rotation
+    // (fetch_position_at_time / fetch_rotation_at_time, lib.rs:507-534), -1 none
+    int32_t rm_node;
+    uint32_t rm_ignore;
+    int32_t rm_pos_track;
+    int32_t rm_rot_track;
     uint32_t pad;
+};
+
+// Animation::root_motion: Option<RootMotion> (lib.rs:325-336), one per (animation, instance).
+struct RootMotionDev {
+    float delta_position[3];
+    uint32_t has;                     // Option is Some
+    float delta_rotation[4];
+    float prev_position[3];
+    uint32_t rem_flags;               // 1: position_offset_remainder is Some, 2: rotation_remainder is Some
+    float prev_rotation[4];
+    float position_offset_remainder[3];
+    uint32_t pad;
+    float rotation_remainder[4];
+};
+static_assert(sizeof(RootMotionDev) == 96, "RootMotionDev layout");
+
+// Root-motion program ops (one uint4 each: x = opcode, y = dst slot, z = src slot / animation,
+// w = f32 weight bits).  A slot is the root_motion field of one AnimationPose that outlives the
+// frame: every pose node's output, every layer's final pose, the machine's final pose.
+enum : uint32_t {
+    RM_END = 0,
+    RM_SET_ANIM = 1,   // slot[dst] = animation[src].root_motion.clone()        (play.rs:97)
+    RM_BLEND = 2,      // slot[dst].get_or_insert_default().blend_with(slot[src] or default, w)  (pose.rs:98-100)
+    RM_COPY = 3,       // slot[dst] = slot[src].clone()                          (pose.rs:73)
 };
 
 // Fold program ops (one uint2 each: x = opcode | a << 8, y = float weight bits).
@@ -119,7 +150,8 @@ struct PoseFrameDev {
     uint32_t n_instances;
     uint32_t n_nodes;
     const float* times;          // [n_instances][n_anims] sample time of ticked animations
-    const uint8_t* ticked;       // [n_instances][n_anims]
+    const uint8_t* ticked;       // [n_instances][n_anims] bit 0: ticked this frame; bit 1: the tick started a new
+                                 //   loop cycle; bit 2: speed > 0 (root motion, lib.rs:539-554)
     const uint2* ops;            // all instances' programs
     const uint32_t* prog_off;    // [n_instances] offset of each instance's program in ops
     const uint8_t* layer_masks;  // [n_layers][n_nodes] 1 = excluded
@@ -129,10 +161,20 @@ struct PoseFrameDev {
     float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
     float* local;                // [n_instances][n_nodes][16]
     float* global;               // [n_instances][n_nodes][16]
+    // root motion (all null / 0 unless the animator tracks root motion)
+    const float2* slices;        // [n_instances][n_anims] time_slice {start, end}
+    RootMotionDev* rm_anim;      // [n_anims][n_instances]
+    float4* rm_slots;            // [n_instances][n_rm_slots][2]: {delta_position, has}{delta_rotation}
+    uint32_t n_rm_slots;
+    const uint4* rm_ops;         // all instances' root-motion programs
+    const uint32_t* rm_prog_off; // [n_instances + 1]
 };
 
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s);
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s);
+// Animation::update_root_motion for every ticked animation that has settings (after pose_sample:
+// rewrites the root node's pose record), then the per-instance root-motion program (machine mode).
+hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s);
 // out[inst][b] = global[inst][bone_nodes[b]] * inv_bind[bone_nodes[b]] (identity for a negative node)
 hipError_t launch_palette_gather(const float* d_global, const float* d_inv_bind, const int32_t* d_bone_nodes,
                                  uint32_t n_nodes, uint32_t n_bones, uint32_t n_instances, float* d_out,

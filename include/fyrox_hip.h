@@ -270,6 +270,55 @@ int fyx_animation_rewind(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
 int fyx_animation_get_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
                             uint32_t instance, float* time_position, int* enabled, int* has_ended);
 
+/* AnimationSignal + the animation's event queue (fyrox-animation/src/signal.rs, lib.rs:471-496,
+ * :680-700).  A signal is addressed by the index fyx_animation_add_signal returned (the shim keeps
+ * the {Uuid, name} pair per index); signals are shared by the instances, event queues and
+ * max_event_capacity (default 32) are per instance.  During a tick every enabled signal with
+ * time in (t, t + dt*speed] (speed >= 0) resp. [t + dt*speed, t) (speed < 0) pushes its index;
+ * as in the reference the capacity cap applies to the negative-speed case only (the `||`/`&&`
+ * precedence at lib.rs:478-482). */
+int fyx_animation_add_signal(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation, float time,
+                             int enabled, uint32_t* out_signal);
+int fyx_animation_set_signal_enabled(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                                     uint32_t signal, int enabled);
+int fyx_animation_set_max_event_capacity(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                                         uint32_t instance, uint32_t capacity);
+/* Animation::pop_event: *out_signal = front of the queue, or -1 when it is empty */
+int fyx_animation_pop_event(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                            uint32_t instance, int32_t* out_signal);
+int fyx_animation_event_count(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                              uint32_t instance, uint32_t* out_count);
+/* Animation::take_events / events_mut().clear() */
+int fyx_animation_clear_events(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation, uint32_t instance);
+
+/* Root motion (lib.rs:302-343, :498-676).  Settings are shared by the instances; node < 0 = None.
+ * With settings, every tick extracts the root node's frame-to-frame motion into the animation's
+ * RootMotion and rewrites the root node's sampled position / rotation to their value at the start
+ * of the time slice (per ignore_* flag), on the GPU, before the pose is blended or applied.
+ * Setting any settings turns root-motion tracking on for the animator (see below). */
+int fyx_animation_set_root_motion_settings(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                                           int32_t node, int ignore_x_movement, int ignore_y_movement,
+                                           int ignore_z_movement, int ignore_rotations);
+/* Option<RootMotion> as the engine's scripts read it: has == 0 is None (the other fields then
+ * hold RootMotion::default(): zero offset, identity rotation). */
+typedef struct fyx_root_motion {
+    float delta_position[3];
+    uint32_t has;
+    float delta_rotation[4];      /* (i, j, k, w) */
+} fyx_root_motion;
+/* Root-motion tracking also maintains AnimationPose::root_motion of every pose node, layer and
+ * the machine (pose.rs:54-100: clone_into copies it, blend_with lerps / nlerps it, reset() keeps
+ * it -- so a blend node starts each frame from LAST frame's value, which is reproduced).  It can
+ * be switched on without any settings (every pose then carries None / default as in the
+ * reference); switching it off frees the state. */
+int fyx_animator_track_root_motion(fyx_ctx* ctx, uint64_t animator_id, int enabled);
+/* Animation::root_motion() of every instance: host_out[n_instances].  Synchronous. */
+int fyx_animation_read_root_motion(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
+                                   fyx_root_motion* host_out);
+/* Machine::pose().root_motion() (layer < 0) or MachineLayer's final pose (layer >= 0) of every
+ * instance, as of the last fyx_absm_update: host_out[n_instances].  Synchronous. */
+int fyx_absm_read_root_motion(fyx_ctx* ctx, uint64_t animator_id, int32_t layer, fyx_root_motion* host_out);
+
 /* ---- Machine (fyrox-animation/src/machine) ------------------------------------------- */
 /* Parameter (machine/parameter.rs:37-60) */
 enum { FYX_PARAM_WEIGHT = 0, FYX_PARAM_RULE = 1, FYX_PARAM_INDEX = 2, FYX_PARAM_SAMPLING_POINT = 3 };
@@ -324,6 +373,17 @@ int fyx_layer_add_transition(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
                              uint32_t n_condition, uint32_t* out_transition);
 int fyx_layer_get_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance,
                         int32_t* active_state, int32_t* active_transition);
+/* machine::Event (machine/event.rs:30-51) and MachineLayer::pop_event (layer.rs:284-286); the
+ * queue holds at most 2048 events per layer and instance, further ones are dropped
+ * (FixedEventQueue, event.rs:53-90).  Handles are indices, -1 = Handle::NONE. */
+enum { FYX_EVENT_STATE_ENTER = 0,               /* a = state */
+       FYX_EVENT_STATE_LEAVE = 1,               /* a = state */
+       FYX_EVENT_ACTIVE_STATE_CHANGED = 2,      /* a = prev, b = new */
+       FYX_EVENT_ACTIVE_TRANSITION_CHANGED = 3  /* a = transition or -1 */ };
+typedef struct fyx_layer_event { int32_t kind, a, b; } fyx_layer_event;
+/* *out_has = 0 when the queue is empty */
+int fyx_layer_pop_event(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance,
+                        fyx_layer_event* out_event, int* out_has);
 
 /* ---- per frame ----------------------------------------------------------------------- */
 /* AnimationPlayer::update = AnimationContainerExt::update_animations (scene/animation/mod.rs:
@@ -366,10 +426,21 @@ int fyx_init_control_only(fyx_ctx** out_ctx);
  * (mode 0) / fyx_absm_update (mode 1) would, and copy what they would send to the GPU:
  * times and ticked are [n_instances][n_animations]; program_offset is [n_instances + 1]; ops are
  * {opcode | arg << 8, f32 weight bits} pairs (opcodes: 0 END, 1 BLEND_ANIM, 2 PUSH, 3 POP_BLEND,
- * 4 RESET, 5 MASK, 6 APPLY, 7 APPLY_ANIM).  *n_ops returns the number of pairs needed. */
+ * 4 RESET, 5 MASK, 6 APPLY, 7 APPLY_ANIM).  *n_ops returns the number of pairs needed.
+ * ticked: bit 0 = the animation ticked; bit 1 = that tick started a new loop cycle; bit 2 =
+ * speed > 0 (what Animation::update_root_motion derives, lib.rs:539-554). */
 int fyx_animator_plan(fyx_ctx* ctx, uint64_t animator_id, int mode, float dt, float* times,
                       uint8_t* ticked, uint32_t* program_offset, uint32_t* ops,
                       uint32_t ops_capacity, uint32_t* n_ops);
+
+/* The root-motion program of the frame fyx_animator_plan planned last (mode 1, tracking on):
+ * program_offset is [n_instances + 1]; ops are {opcode, dst slot, src slot | animation, f32
+ * weight bits} quadruples (opcodes: 0 END, 1 SET_ANIM, 2 BLEND, 3 COPY).  Slots: for each layer
+ * its pose nodes in handle order, then the layer's final pose; the machine's final pose is the
+ * last slot (*n_slots).  slices is [n_instances][n_animations][2] = time_slice {start, end}. */
+int fyx_animator_plan_root_motion(fyx_ctx* ctx, uint64_t animator_id, uint32_t* program_offset,
+                                  uint32_t* ops, uint32_t ops_capacity, uint32_t* n_ops,
+                                  uint32_t* n_slots, float* slices);
 
 #ifdef __cplusplus
 }

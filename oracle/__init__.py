@@ -321,6 +321,15 @@ def _alib():
             "fo_layer_pose": [c_void_p, c_int], "fo_machine_pose": [c_void_p],
             "fo_machine_evaluate_pose": [c_void_p, c_void_p, c_int, c_float],
             "fo_blend_space_fetch_weights": [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+            "fo_pose_root_motion": [c_void_p, c_void_p, c_void_p],
+            "fo_animation_add_signal": [c_void_p, c_float, c_int],
+            "fo_animation_set_signal_enabled": [c_void_p, c_int, c_int],
+            "fo_animation_set_max_event_capacity": [c_void_p, c_uint32],
+            "fo_animation_event_count": [c_void_p], "fo_animation_pop_event": [c_void_p],
+            "fo_animation_clear_events": [c_void_p],
+            "fo_animation_set_root_motion_settings": [c_void_p, c_int, c_int, c_int, c_int, c_int],
+            "fo_animation_root_motion": [c_void_p, c_void_p, c_void_p],
+            "fo_layer_pop_event": [c_void_p, c_int, c_void_p],
         }.items():
             getattr(l, name).argtypes = args
         _anim_bound = True
@@ -389,8 +398,15 @@ class AnimScene:
         return len(self.tracks) - 1
 
     def add_animation(self, tracks_index: int, track_target, track_enabled=None, *, time_slice=None, speed=None,
-                      looped=None, enabled=None) -> int:
+                      looped=None, enabled=None, signals=(), root_motion=None, max_event_capacity=None) -> int:
         a = self.l.fo_animation_new(self.tracks[tracks_index])
+        for time, en in signals:
+            self.l.fo_animation_add_signal(a, time, int(bool(en)))
+        if root_motion is not None:
+            node, ix, iy, iz, ir = root_motion
+            self.l.fo_animation_set_root_motion_settings(a, int(node), int(ix), int(iy), int(iz), int(ir))
+        if max_event_capacity is not None:
+            self.l.fo_animation_set_max_event_capacity(a, int(max_event_capacity))
         for t, tgt in enumerate(track_target):
             self.l.fo_animation_bind(a, t, int(tgt), 1 if track_enabled is None else int(track_enabled[t]))
         if looped is not None:
@@ -470,6 +486,40 @@ class AnimScene:
 
     def machine_pose(self) -> np.ndarray:
         return _pose_records(self.l.fo_machine_pose(self.machine), self.n_nodes)
+
+    @staticmethod
+    def _rm_record(has, dp, dr) -> np.ndarray:
+        """fyx_root_motion layout as 8 float32: dp xyz, has (u32 bits), dr ijkw."""
+        out = np.zeros(8, np.float32)
+        out[0:3] = dp
+        out[3:4] = np.asarray([1 if has else 0], np.uint32).view(np.float32)
+        out[4:8] = dr
+        return out
+
+    def animation_root_motion(self, a: int) -> np.ndarray:
+        dp, dr = np.zeros(3, np.float32), np.zeros(4, np.float32)
+        has = self.l.fo_animation_root_motion(self.anims[a], _p(dp), _p(dr))
+        return self._rm_record(has, dp, dr)
+
+    def machine_root_motion(self, layer: int = -1) -> np.ndarray:
+        pose = self.l.fo_machine_pose(self.machine) if layer < 0 else self.l.fo_layer_pose(self.machine, layer)
+        dp, dr = np.zeros(3, np.float32), np.zeros(4, np.float32)
+        has = self.l.fo_pose_root_motion(pose, _p(dp), _p(dr))
+        return self._rm_record(has, dp, dr)
+
+    def pop_event(self, a: int):
+        s = self.l.fo_animation_pop_event(self.anims[a])
+        return None if s < 0 else s
+
+    def event_count(self, a: int) -> int:
+        return self.l.fo_animation_event_count(self.anims[a])
+
+    def clear_events(self, a: int) -> None:
+        self.l.fo_animation_clear_events(self.anims[a])
+
+    def pop_layer_event(self, layer: int):
+        ev = (c_int * 3)()
+        return (ev[0], ev[1], ev[2]) if self.l.fo_layer_pop_event(self.machine, layer, ev) else None
 
     def animation_state(self, a: int) -> dict:
         h = self.anims[a]

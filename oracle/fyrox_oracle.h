@@ -142,6 +142,9 @@ int fo_pose_node_capacity(const fo_pose*);
 int fo_pose_value_count(const fo_pose*, int node);
 int fo_pose_get_value(const fo_pose*, int node, int i, fo_bound_value* out);
 void fo_pose_apply(const fo_pose*, fo_transform* nodes, int n_nodes);
+/* pose.rs:78-85; root_motion() returns 0 for None (outputs then hold RootMotion::default()) */
+void fo_pose_set_root_motion(fo_pose*, int has, const float delta_position[3], const float delta_rotation[4]);
+int fo_pose_root_motion(const fo_pose*, float delta_position[3], float delta_rotation[4]);
 
 typedef struct fo_tracks fo_tracks;       /* AnimationTracksData */
 fo_tracks* fo_tracks_new(void);
@@ -164,6 +167,17 @@ int fo_animation_is_enabled(const fo_animation*);
 int fo_animation_has_ended(const fo_animation*);
 const fo_pose* fo_animation_pose(const fo_animation*);
 void fo_animation_tick(fo_animation*, float dt);
+/* signals (index == the {id, name} pair), events queue (lib.rs:471-496, 680-700) */
+int fo_animation_add_signal(fo_animation*, float time, int enabled);
+void fo_animation_set_signal_enabled(fo_animation*, int signal, int enabled);
+void fo_animation_set_max_event_capacity(fo_animation*, uint32_t cap);
+int fo_animation_event_count(const fo_animation*);
+int fo_animation_pop_event(fo_animation*); /* signal index, -1 == None */
+void fo_animation_clear_events(fo_animation*);
+/* root motion (lib.rs:302-343, 498-676); node < 0 == settings None */
+void fo_animation_set_root_motion_settings(fo_animation*, int node, int ignore_x, int ignore_y,
+                                           int ignore_z, int ignore_rotations);
+int fo_animation_root_motion(const fo_animation*, float delta_position[3], float delta_rotation[4]);
 
 enum { FO_PARAM_WEIGHT = 0, FO_PARAM_RULE = 1, FO_PARAM_INDEX = 2, FO_PARAM_SAMPLING_POINT = 3 };
 enum { FO_NODE_PLAY = 0, FO_NODE_BLEND = 1, FO_NODE_BLEND_BY_INDEX = 2, FO_NODE_BLEND_SPACE = 3 };
@@ -171,6 +185,11 @@ enum { FO_ACTION_NONE = 0, FO_ACTION_REWIND = 1, FO_ACTION_ENABLE = 2, FO_ACTION
 /* LogicNode, prefix encoded: PARAM p | AND a b | OR a b | XOR a b | NOT a | IS_ANIMATION_ENDED anim */
 enum { FO_LOGIC_PARAM = 0, FO_LOGIC_AND = 1, FO_LOGIC_OR = 2, FO_LOGIC_XOR = 3, FO_LOGIC_NOT = 4,
        FO_LOGIC_IS_ANIMATION_ENDED = 5 };
+
+/* machine/event.rs:30-51 Event<T>: {kind, a, b}: StateEnter(a) StateLeave(a)
+ * ActiveStateChanged{prev: a, new: b} ActiveTransitionChanged(a) (-1 == Handle::NONE) */
+enum { FO_EVENT_STATE_ENTER = 0, FO_EVENT_STATE_LEAVE = 1, FO_EVENT_ACTIVE_STATE_CHANGED = 2,
+       FO_EVENT_ACTIVE_TRANSITION_CHANGED = 3 };
 
 typedef struct fo_machine fo_machine;     /* Machine<T> */
 fo_machine* fo_machine_new(void);
@@ -193,6 +212,7 @@ void fo_layer_set_entry_state(fo_machine*, int layer, int state);
 void fo_state_add_action(fo_machine*, int layer, int state, int on_enter, int kind, int animation);
 int fo_layer_add_transition(fo_machine*, int layer, int source, int dest, float time,
                             const int* logic, int n_logic);
+int fo_layer_pop_event(fo_machine*, int layer, int out[3]); /* 0 == None */
 int fo_layer_active_state(const fo_machine*, int layer);
 int fo_layer_active_transition(const fo_machine*, int layer);
 const fo_pose* fo_layer_pose(const fo_machine*, int layer);

@@ -8,11 +8,12 @@
  * binding, recursive pose-node evaluation with cached output poses -- NOT the dense
  * batched form the HIP path uses -- so that the two share no structure.
  *
- * Not restated (control-plane features that never touch the per-bone arithmetic, or
- * need unavailable crates): signals/events, root motion (lib.rs:498-661, only when
- * configured), StateAction::EnableRandomAnimation (rand), Property bindings through
- * reflection (value.rs:404-427; Property values still blend here, they are just not
- * applied to nodes), BlendSpace triangulation (spade crate; triangles are inputs).
+ * Signals/events (lib.rs:471-496), root motion (lib.rs:498-661, pose.rs:73-100,
+ * play.rs:97) and the layer event queue (layer.rs:590-706, event.rs:53-90) are restated
+ * too.  Not restated (need unavailable crates or the engine's reflection):
+ * StateAction::EnableRandomAnimation (rand), Property bindings through reflection
+ * (value.rs:404-427; Property values still blend here, they are just not applied to
+ * nodes), BlendSpace triangulation (spade crate; triangles are inputs).
  *
  * file:line citations are relative to /root/reference.
  */
@@ -35,7 +36,17 @@ typedef struct fo_node_pose {
 struct fo_pose {
     int n_nodes; /* node ids are 0..n_nodes-1; "not in the map" == "empty values" (see header) */
     fo_node_pose* nodes;
+    /* pose.rs:54 root_motion: Option<RootMotion>; only the two public fields take part in
+     * pose blending (lib.rs:340-343) */
+    int rm_has;
+    float rm_dp[3]; /* delta_position */
+    float rm_dr[4]; /* delta_rotation (i,j,k,w) */
 };
+
+static void rm_default(float dp[3], float dr[4]) { /* RootMotion::default(): zero offset, identity */
+    dp[0] = dp[1] = dp[2] = 0.0f;
+    dr[0] = dr[1] = dr[2] = 0.0f; dr[3] = 1.0f;
+}
 
 static void pose_reserve_nodes(fo_pose* p, int n_nodes) {
     if (n_nodes <= p->n_nodes) return;
@@ -53,7 +64,9 @@ void fo_pose_free(fo_pose* p) {
     free(p);
 }
 
-/* pose.rs:125-129  reset(): clear every node's values, keep the nodes */
+/* pose.rs:125-129  reset(): clear every node's values, keep the nodes -- and keep root_motion:
+ * a pose node's output (blend.rs:145, blendspace.rs:127, layer.rs:596, mod.rs:352) starts every
+ * frame with LAST frame's root motion still in place */
 void fo_pose_reset(fo_pose* p) {
     for (int i = 0; i < p->n_nodes; ++i) p->nodes[i].n = 0;
 }
@@ -82,6 +95,19 @@ void fo_pose_clone_into(const fo_pose* src, fo_pose* dst) {
     fo_pose_reset(dst);
     pose_reserve_nodes(dst, src->n_nodes);
     for (int i = 0; i < src->n_nodes; ++i) node_copy(&dst->nodes[i], &src->nodes[i]);
+    dst->rm_has = src->rm_has; /* :73 dest.root_motion.clone_from(&self.root_motion) */
+    memcpy(dst->rm_dp, src->rm_dp, sizeof dst->rm_dp);
+    memcpy(dst->rm_dr, src->rm_dr, sizeof dst->rm_dr);
+}
+
+/* pose.rs:78-85 */
+void fo_pose_set_root_motion(fo_pose* p, int has, const float dp[3], const float dr[4]) {
+    p->rm_has = has;
+    if (has) { memcpy(p->rm_dp, dp, 12); memcpy(p->rm_dr, dr, 16); }
+}
+int fo_pose_root_motion(const fo_pose* p, float dp[3], float dr[4]) {
+    if (p->rm_has) { memcpy(dp, p->rm_dp, 12); memcpy(dr, p->rm_dr, 16); } else rm_default(dp, dr);
+    return p->rm_has;
 }
 
 /* value.rs:221-230  TrackValue::blend_with (mismatched variants: no-op) */
@@ -113,10 +139,19 @@ static void node_blend(fo_node_pose* self, const fo_node_pose* other, float w) {
     }
 }
 
-/* pose.rs:89-101 AnimationPose::blend_with (root motion part omitted, see header) */
+/* pose.rs:89-101 AnimationPose::blend_with */
 void fo_pose_blend_with(fo_pose* self, const fo_pose* other, float w) {
     pose_reserve_nodes(self, other->n_nodes);
     for (int i = 0; i < other->n_nodes; ++i) node_blend(&self->nodes[i], &other->nodes[i], w);
+    /* :98-100 self.root_motion.get_or_insert_with(Default::default)
+     *             .blend_with(&other.root_motion.clone().unwrap_or_default(), weight)
+     * lib.rs:340-343: delta_position.lerp (nalgebra a*(1-t)+b*t), delta_rotation value.rs nlerp */
+    if (!self->rm_has) { self->rm_has = 1; rm_default(self->rm_dp, self->rm_dr); }
+    float odp[3], odr[4], dr[4];
+    if (other->rm_has) { memcpy(odp, other->rm_dp, 12); memcpy(odr, other->rm_dr, 16); } else rm_default(odp, odr);
+    fo_vec_lerp(self->rm_dp, odp, w, 3, self->rm_dp);
+    fo_quat_nlerp_shortest(self->rm_dr, odr, w, dr);
+    memcpy(self->rm_dr, dr, sizeof dr);
 }
 
 /* layer.rs:700-702  final_pose.poses_mut().retain(|h,_| mask.should_animate(*h)) */
@@ -252,12 +287,42 @@ typedef struct fo_track_binding { /* track.rs:40-97 TrackBinding: enabled, targe
     size_t hints[4];
 } fo_track_binding;
 
+typedef struct fo_signal { float time; int enabled; } fo_signal; /* signal.rs: AnimationSignal */
+
+typedef struct fo_root_motion { /* lib.rs:325-336 RootMotion */
+    float delta_position[3];
+    float delta_rotation[4];
+    float prev_position[3];
+    int has_position_offset_remainder;
+    float position_offset_remainder[3];
+    float prev_rotation[4];
+    int has_rotation_remainder;
+    float rotation_remainder[4];
+} fo_root_motion;
+
+static void root_motion_default(fo_root_motion* r) {
+    memset(r, 0, sizeof *r);
+    r->delta_rotation[3] = 1.0f; /* UnitQuaternion::default() == identity */
+    r->prev_rotation[3] = 1.0f;
+}
+
 struct fo_animation {
     const fo_tracks* tracks;
     fo_track_binding* bindings; /* one per track (track_bindings map keyed by track id) */
     float speed, time_position, slice_start, slice_end;
     int enabled, looped;
     fo_pose* pose;
+    /* signals: Vec<AnimationSignal>, events: VecDeque<AnimationEvent> (signal index stands for
+     * the {signal_id, name} pair), max_event_capacity (default 32, lib.rs:941) */
+    int n_signals;
+    fo_signal* signals;
+    int n_events, ev_cap, ev_head; /* ring buffer of signal indices */
+    int* events;
+    size_t max_event_capacity;
+    /* root_motion_settings: Option<RootMotionSettings>, root_motion: Option<RootMotion> */
+    int has_rm_settings, rm_node, rm_ignore_x, rm_ignore_y, rm_ignore_z, rm_ignore_rotations;
+    int has_root_motion;
+    fo_root_motion root_motion;
 };
 
 /* lib.rs:928-950 Default: speed 1, time 0, enabled, looped, time_slice 0..0 */
@@ -269,6 +334,7 @@ fo_animation* fo_animation_new(const fo_tracks* td) {
     a->enabled = 1;
     a->looped = 1;
     a->pose = fo_pose_new();
+    a->max_event_capacity = 32;
     return a;
 }
 
@@ -276,7 +342,58 @@ void fo_animation_free(fo_animation* a) {
     if (!a) return;
     fo_pose_free(a->pose);
     free(a->bindings);
+    free(a->signals);
+    free(a->events);
     free(a);
+}
+
+/* lib.rs add_signal / signals_mut */
+int fo_animation_add_signal(fo_animation* a, float time, int enabled) {
+    a->signals = (fo_signal*)realloc(a->signals, (size_t)(a->n_signals + 1) * sizeof(fo_signal));
+    a->signals[a->n_signals].time = time;
+    a->signals[a->n_signals].enabled = enabled;
+    return a->n_signals++;
+}
+void fo_animation_set_signal_enabled(fo_animation* a, int signal, int enabled) {
+    if (signal >= 0 && signal < a->n_signals) a->signals[signal].enabled = enabled;
+}
+void fo_animation_set_max_event_capacity(fo_animation* a, uint32_t cap) { a->max_event_capacity = cap; } /* :380 */
+int fo_animation_event_count(const fo_animation* a) { return a->n_events; }
+static void events_push_back(fo_animation* a, int signal) {
+    if (a->n_events == a->ev_cap) {
+        int ncap = a->ev_cap ? a->ev_cap * 2 : 16;
+        int* ne = (int*)malloc((size_t)ncap * sizeof(int));
+        for (int i = 0; i < a->n_events; ++i) ne[i] = a->events[(a->ev_head + i) % a->ev_cap];
+        free(a->events);
+        a->events = ne; a->ev_cap = ncap; a->ev_head = 0;
+    }
+    a->events[(a->ev_head + a->n_events) % a->ev_cap] = signal;
+    ++a->n_events;
+}
+/* lib.rs:680-682 pop_event: events.pop_front(); -1 == None */
+int fo_animation_pop_event(fo_animation* a) {
+    if (!a->n_events) return -1;
+    int s = a->events[a->ev_head];
+    a->ev_head = (a->ev_head + 1) % a->ev_cap;
+    --a->n_events;
+    return s;
+}
+void fo_animation_clear_events(fo_animation* a) { a->n_events = 0; a->ev_head = 0; } /* take_events / events_mut().clear() */
+
+/* lib.rs:664-666 set_root_motion_settings; node < 0 == None */
+void fo_animation_set_root_motion_settings(fo_animation* a, int node, int ignore_x, int ignore_y,
+                                           int ignore_z, int ignore_rotations) {
+    a->has_rm_settings = node >= 0;
+    a->rm_node = node;
+    a->rm_ignore_x = ignore_x; a->rm_ignore_y = ignore_y; a->rm_ignore_z = ignore_z;
+    a->rm_ignore_rotations = ignore_rotations;
+}
+/* lib.rs:674-676 root_motion(); returns 0 for None */
+int fo_animation_root_motion(const fo_animation* a, float delta_position[3], float delta_rotation[4]) {
+    if (!a->has_root_motion) { rm_default(delta_position, delta_rotation); return 0; }
+    memcpy(delta_position, a->root_motion.delta_position, 12);
+    memcpy(delta_rotation, a->root_motion.delta_rotation, 16);
+    return 1;
 }
 
 /* add_track_with_binding / track_bindings_mut: target < 0 removes the binding */
@@ -334,11 +451,128 @@ static void animation_update_pose(fo_animation* a) {
     }
 }
 
-/* lib.rs:471-496 tick: pose at the OLD time, then advance (signals / root motion omitted) */
+/* lib.rs:507-519 fetch_position_at_time: the FIRST track of the tracks data whose binding is
+ * Position (whatever node it is bound to, enabled or not), fresh hints, Vector3 or default */
+static void rm_fetch_position(const fo_tracks* td, float time, float out[3]) {
+    out[0] = out[1] = out[2] = 0.0f;
+    for (int i = 0; i < td->n; ++i) {
+        if (td->t[i].binding != FO_BIND_POSITION) continue;
+        size_t hints[4] = { 0, 0, 0, 0 };
+        fo_bound_value bv;
+        if (track_fetch(&td->t[i], time, hints, &bv) && bv.kind == FO_VAL_VEC3) memcpy(out, bv.v, 12);
+        return; /* .find() stops at the first Position track even when its fetch fails */
+    }
+}
+/* lib.rs:521-534 fetch_rotation_at_time */
+static void rm_fetch_rotation(const fo_tracks* td, float time, float out[4]) {
+    out[0] = out[1] = out[2] = 0.0f; out[3] = 1.0f;
+    for (int i = 0; i < td->n; ++i) {
+        if (td->t[i].binding != FO_BIND_ROTATION) continue;
+        size_t hints[4] = { 0, 0, 0, 0 };
+        fo_bound_value bv;
+        if (track_fetch(&td->t[i], time, hints, &bv) && bv.kind == FO_VAL_QUAT) memcpy(out, bv.v, 16);
+        return;
+    }
+}
+/* nalgebra UnitQuaternion::inverse() == conjugate: (-i,-j,-k,w) */
+static void quat_conj(const float q[4], float out[4]) { out[0] = -q[0]; out[1] = -q[1]; out[2] = -q[2]; out[3] = q[3]; }
+
+/* lib.rs:498-661 update_root_motion */
+static void animation_update_root_motion(fo_animation* a, float prev_time_position) {
+    if (!a->has_rm_settings) return;
+    const fo_tracks* td = a->tracks;
+    fo_root_motion prev;
+    if (a->has_root_motion) prev = a->root_motion; else root_motion_default(&prev);
+    int new_loop_cycle_started = a->looped
+        && ((a->speed > 0.0f && a->time_position < prev_time_position)
+            || (a->speed < 0.0f && a->time_position > prev_time_position));
+    float cycle_start_time = a->speed > 0.0f ? a->slice_start : a->slice_end;
+    float cycle_end_time = a->speed > 0.0f ? a->slice_end : a->slice_start;
+    fo_root_motion rm;
+    root_motion_default(&rm);
+    if (a->rm_node >= 0 && a->rm_node < a->pose->n_nodes) {
+        fo_node_pose* np = &a->pose->nodes[a->rm_node];
+        for (int i = 0; i < np->n; ++i) {
+            fo_bound_value* bv = &np->vals[i];
+            if (bv->binding == FO_BIND_POSITION) {
+                if (bv->kind != FO_VAL_VEC3) continue;
+                float pose_position[3] = { bv->v[0], bv->v[1], bv->v[2] };
+                if (new_loop_cycle_started) {
+                    float end[3];
+                    rm_fetch_position(td, cycle_start_time, rm.prev_position);
+                    rm_fetch_position(td, cycle_end_time, end);
+                    rm.has_position_offset_remainder = 1;
+                    for (int k = 0; k < 3; ++k) rm.position_offset_remainder[k] = end[k] - pose_position[k];
+                } else {
+                    memcpy(rm.prev_position, pose_position, 12);
+                }
+                float remainder[3] = { 0, 0, 0 };
+                if (prev.has_position_offset_remainder) { /* .take().unwrap_or_default() */
+                    memcpy(remainder, prev.position_offset_remainder, 12);
+                    prev.has_position_offset_remainder = 0;
+                }
+                float delta[3];
+                for (int k = 0; k < 3; ++k) {
+                    float current_offset = pose_position[k] - prev.prev_position[k];
+                    delta[k] = current_offset + remainder[k];
+                }
+                rm.delta_position[0] = a->rm_ignore_x ? 0.0f : delta[0];
+                rm.delta_position[1] = a->rm_ignore_y ? 0.0f : delta[1];
+                rm.delta_position[2] = a->rm_ignore_z ? 0.0f : delta[2];
+                float start_position[3];
+                rm_fetch_position(td, a->slice_start, start_position);
+                bv->v[0] = a->rm_ignore_x ? pose_position[0] : start_position[0];
+                bv->v[1] = a->rm_ignore_y ? pose_position[1] : start_position[1];
+                bv->v[2] = a->rm_ignore_z ? pose_position[2] : start_position[2];
+            } else if (bv->binding == FO_BIND_ROTATION) {
+                if (bv->kind != FO_VAL_QUAT) continue;
+                if (a->rm_ignore_rotations) continue;
+                float pose_rotation[4] = { bv->v[0], bv->v[1], bv->v[2], bv->v[3] };
+                if (new_loop_cycle_started) {
+                    float end[4], inv[4];
+                    rm_fetch_rotation(td, cycle_start_time, rm.prev_rotation);
+                    rm_fetch_rotation(td, cycle_end_time, end);
+                    quat_conj(end, inv);
+                    rm.has_rotation_remainder = 1;
+                    fo_quat_mul(inv, pose_rotation, rm.rotation_remainder);
+                } else {
+                    memcpy(rm.prev_rotation, pose_rotation, 16);
+                }
+                float remainder[4] = { 0, 0, 0, 1 };
+                if (prev.has_rotation_remainder) {
+                    memcpy(remainder, prev.rotation_remainder, 16);
+                    prev.has_rotation_remainder = 0;
+                }
+                float inv_prev[4], current_relative_rotation[4];
+                quat_conj(prev.prev_rotation, inv_prev);
+                fo_quat_mul(inv_prev, pose_rotation, current_relative_rotation);
+                fo_quat_mul(remainder, current_relative_rotation, rm.delta_rotation);
+                rm_fetch_rotation(td, a->slice_start, bv->v);
+            }
+        }
+    }
+    a->root_motion = rm;
+    a->has_root_motion = 1;
+}
+
+/* lib.rs:471-496 tick: pose at the OLD time, signals over (t, t + dt*speed], advance, root motion */
 void fo_animation_tick(fo_animation* a, float dt) {
     animation_update_pose(a);
-    float new_time = a->time_position + dt * a->speed;
-    fo_animation_set_time_position(a, new_time);
+    float current_time_position = a->time_position;
+    float new_time_position = current_time_position + dt * a->speed;
+    for (int i = 0; i < a->n_signals; ++i) {
+        const fo_signal* sg = &a->signals[i];
+        if (!sg->enabled) continue;
+        /* operator precedence as written at :478-482: a || (b && c && cap) -- the capacity cap
+         * binds to the negative-speed branch only */
+        if ((a->speed >= 0.0f && (current_time_position < sg->time && new_time_position >= sg->time))
+            || (a->speed < 0.0f && (current_time_position > sg->time && new_time_position <= sg->time)
+                && (size_t)a->n_events < a->max_event_capacity))
+            events_push_back(a, i);
+    }
+    float prev_time_position = current_time_position;
+    fo_animation_set_time_position(a, new_time_position);
+    animation_update_root_motion(a, prev_time_position);
 }
 
 /* ======================================================================== */
@@ -392,7 +626,22 @@ typedef struct fo_layer {
     int n_excluded;
     int* excluded;
     fo_pose* final_pose;
+    /* layer.rs:117,182 events: FixedEventQueue::new(2048) (event.rs:53-90): push drops the
+     * event when the queue is full, pop takes from the front */
+    int n_events, ev_head;
+    int (*events)[3]; /* {FO_EVENT_*, a, b}, ring of FO_LAYER_EVENT_LIMIT */
 } fo_layer;
+
+#define FO_LAYER_EVENT_LIMIT 2048
+static void layer_push_event(fo_layer* L, int kind, int a, int b) {
+    if (L->n_events >= FO_LAYER_EVENT_LIMIT) return;
+    if (!L->events) L->events = (int(*)[3])malloc(sizeof(int[3]) * FO_LAYER_EVENT_LIMIT);
+    int* e = L->events[(L->ev_head + L->n_events) % FO_LAYER_EVENT_LIMIT];
+    e[0] = kind; e[1] = a; e[2] = b;
+    ++L->n_events;
+}
+/* layer.rs:284-286 pop_event; returns 0 for None */
+int fo_layer_pop_event(fo_machine* m, int layer, int out[3]);
 
 struct fo_machine {
     int n_params, n_layers;
@@ -417,7 +666,7 @@ void fo_machine_free(fo_machine* m) {
         }
         for (int i = 0; i < L->n_states; ++i) { free(L->states[i].enter); free(L->states[i].leave); }
         for (int i = 0; i < L->n_transitions; ++i) free(L->transitions[i].logic);
-        free(L->nodes); free(L->states); free(L->transitions); free(L->excluded);
+        free(L->nodes); free(L->states); free(L->transitions); free(L->excluded); free(L->events);
         fo_pose_free(L->final_pose);
     }
     free(m->layers); free(m->params);
@@ -552,6 +801,14 @@ int fo_layer_add_transition(fo_machine* m, int layer, int source, int dest, floa
     return L->n_transitions++;
 }
 
+int fo_layer_pop_event(fo_machine* m, int layer, int out[3]) {
+    fo_layer* L = &m->layers[layer];
+    if (!L->n_events) return 0;
+    memcpy(out, L->events[L->ev_head], sizeof(int[3]));
+    L->ev_head = (L->ev_head + 1) % FO_LAYER_EVENT_LIMIT;
+    --L->n_events;
+    return 1;
+}
 int fo_layer_active_state(const fo_machine* m, int layer) { return m->layers[layer].active_state; }
 int fo_layer_active_transition(const fo_machine* m, int layer) { return m->layers[layer].active_transition; }
 const fo_pose* fo_layer_pose(const fo_machine* m, int layer) { return m->layers[layer].final_pose; }
@@ -666,8 +923,13 @@ static const fo_pose* node_eval(eval_ctx* c, int handle) {
     fo_pose_node* n = &c->L->nodes[handle];
     switch (n->type) {
     case FO_NODE_PLAY: /* play.rs:86-100: a stale output is kept when the animation handle is invalid */
-        if (n->animation >= 0 && n->animation < c->n_anims && c->anims[n->animation])
-            fo_pose_clone_into(c->anims[n->animation]->pose, n->output);
+        if (n->animation >= 0 && n->animation < c->n_anims && c->anims[n->animation]) {
+            const fo_animation* an = c->anims[n->animation];
+            fo_pose_clone_into(an->pose, n->output);
+            /* :97 output_pose.set_root_motion(animation.root_motion().cloned()) */
+            fo_pose_set_root_motion(n->output, an->has_root_motion, an->root_motion.delta_position,
+                                    an->root_motion.delta_rotation);
+        }
         return n->output;
     case FO_NODE_BLEND: /* blend.rs:136-164 */
         fo_pose_reset(n->output);
@@ -784,10 +1046,13 @@ static const fo_pose* layer_evaluate(fo_machine* m, fo_layer* L, fo_animation* c
                 if (logic_eval(tr->logic, tr->n_logic, &pc, m, anims, n_anims)) {
                     if (L->active_state >= 0 && L->active_state < L->n_states)
                         apply_actions(L->states[L->active_state].leave, L->states[L->active_state].n_leave, anims, n_anims);
+                    layer_push_event(L, FO_EVENT_STATE_LEAVE, L->active_state, -1);      /* :620 */
                     if (tr->dest >= 0 && tr->dest < L->n_states)
                         apply_actions(L->states[tr->dest].enter, L->states[tr->dest].n_enter, anims, n_anims);
+                    layer_push_event(L, FO_EVENT_STATE_ENTER, tr->dest, -1);             /* :634 */
                     L->active_state = -1;
                     L->active_transition = t;
+                    layer_push_event(L, FO_EVENT_ACTIVE_TRANSITION_CHANGED, t, -1);      /* :645 */
                     break;
                 }
             }
@@ -813,7 +1078,9 @@ static const fo_pose* layer_evaluate(fo_machine* m, fo_layer* L, fo_animation* c
                 tr->elapsed_time = 0.0f; /* reset */
                 tr->blend_factor = 0.0f;
                 L->active_transition = -1;
+                layer_push_event(L, FO_EVENT_ACTIVE_TRANSITION_CHANGED, -1, -1);         /* :673 */
                 L->active_state = tr->dest;
+                layer_push_event(L, FO_EVENT_ACTIVE_STATE_CHANGED, tr->source, tr->dest); /* :677 */
             }
         } else {
             if (L->active_state >= 0 && L->active_state < L->n_states) {

@@ -21,6 +21,9 @@ class AnimSpec:
     speed: Optional[float] = None
     looped: Optional[bool] = None
     enabled: Optional[bool] = None
+    signals: List[Tuple[float, bool]] = field(default_factory=list)          # (time, enabled)
+    root_motion: Optional[Tuple[int, bool, bool, bool, bool]] = None         # (node, ignore x, y, z, rotations)
+    max_event_capacity: Optional[int] = None
 
 
 @dataclass
@@ -35,6 +38,7 @@ class Scenario:
     n_frames: int = 60
     dt: float = 1.0 / 60.0
     has_euler: bool = True
+    track_root_motion: bool = False   # compare AnimationPose::root_motion of animations / layers / machine too
 
 
 def _partial(td: A.AnimationTracksData, target: np.ndarray, keep: Callable[[int, A.Track], bool]):
@@ -166,6 +170,60 @@ def layered(n_bones=40, seed=synth.SEED_BASE + 10) -> Scenario:
 ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered]
 
 
+def with_root_motion_and_signals(make) -> Callable[[], Scenario]:
+    """The same scenario with RootMotionSettings on every animation (different root nodes and ignore_*
+    flags, so the root node's pose is rewritten before blending), signals on every animation (one disabled,
+    one at each end of the time slice, a small event capacity on one), and AnimationPose::root_motion
+    tracked through every pose node, layer and the machine."""
+    def build() -> Scenario:
+        sc = make()
+        flags = [(0, False, False, False, False), (0, False, True, False, False), (1, True, False, True, False),
+                 (0, False, False, False, True)]
+        for i, a in enumerate(sc.animations):
+            a.root_motion = flags[i % len(flags)]
+            lo, hi = a.time_slice
+            a.signals = [(lo + (hi - lo) * 0.25, True), (lo + (hi - lo) * 0.5, False), (lo + (hi - lo) * 0.75, True),
+                         (hi, True), (lo, True)]
+            if i % 2 == 1:
+                a.max_event_capacity = 3
+        sc.name += "+rm"
+        sc.track_root_motion = True
+        return sc
+    build.__name__ = make.__name__ + "_rm"
+    return build
+
+
+def looping_root_motion(n_bones=12, seed=synth.SEED_BASE + 11) -> Scenario:
+    """Root motion across loop boundaries in both directions (the position / rotation remainder branch,
+    lib.rs:563-570, :626-633), a non-looping clip that clamps at its end, a clip whose root has no rotation
+    track, two layers folded into the machine pose, and a big dt so that cycles restart every few frames."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(4):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, n_keys=16, euler_every=10 ** 9)
+        if c == 3:
+            td, tgt = _partial(td, tgt, lambda b, t: not (b == 0 and t.binding == A.BIND_ROTATION))
+        tds.append(td)
+        anims.append(AnimSpec(c, tgt, time_slice=(0.05, 0.45), speed=[1.0, -1.3, 2.0, 0.7][c], looped=c != 2,
+                              root_motion=(0, False, False, c == 1, False),
+                              signals=[(0.2, True), (0.4, True)], max_event_capacity=2 if c == 1 else None))
+    base = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2), A.PlayAnimation(3),
+               A.BlendAnimations([A.BlendPose(0, 0.4), A.BlendPose(1, 0.6), A.BlendPose(3, 0.3)]),
+               A.BlendAnimationsByIndex(0, [A.IndexedBlendInput(0.2, 4), A.IndexedBlendInput(0.15, 2)])],
+        states=[A.State(5), A.State(3)],
+        transitions=[A.Transition(0, 1, 0.3, ("parameter", 1)), A.Transition(1, 0, 0.2, ("not", ("parameter", 1)))])
+    upper = A.MachineLayer(nodes=[A.PlayAnimation(1)], states=[A.State(0)], weight=0.35, mask=[0, 1, 2])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_INDEX, 0), A.Parameter(A.PARAM_RULE, False)], layers=[base, upper])
+    script = {6: [(0, A.Parameter(A.PARAM_INDEX, 1))], 20: [(1, A.Parameter(A.PARAM_RULE, True))],
+              26: [(0, A.Parameter(A.PARAM_INDEX, 0))], 40: [(1, A.Parameter(A.PARAM_RULE, False))]}
+    return Scenario("looping_root_motion", rig, tds, anims, m, script, n_frames=60, dt=1.0 / 17.0, has_euler=False,
+                    track_root_motion=True)
+
+
+ALL_RM = [with_root_motion_and_signals(f) for f in ALL] + [looping_root_motion]
+
+
 # ---- builders -------------------------------------------------------------------------------------
 
 def build_oracle(orc, sc: Scenario):
@@ -174,7 +232,8 @@ def build_oracle(orc, sc: Scenario):
         s.add_tracks_data(td)
     for a in sc.animations:
         s.add_animation(a.tracks, a.target, a.enabled_tracks, time_slice=a.time_slice, speed=a.speed,
-                        looped=a.looped, enabled=a.enabled)
+                        looped=a.looped, enabled=a.enabled, signals=a.signals, root_motion=a.root_motion,
+                        max_event_capacity=a.max_event_capacity)
     if sc.machine is not None:
         s.set_machine(sc.machine)
     return s
@@ -191,8 +250,16 @@ def build_product(ctx, sc: Scenario, n_instances: int = 1) -> A.Animator:
         A.upload_tracks_data(ctx, base + 1 + i, td)
     an = A.Animator(ctx, base, base, sc.rig, n_instances)
     for a in sc.animations:
-        an.add_animation(base + 1 + a.tracks, a.target, a.enabled_tracks, time_slice=a.time_slice, speed=a.speed,
-                         looped=a.looped, enabled=a.enabled)
+        idx = an.add_animation(base + 1 + a.tracks, a.target, a.enabled_tracks, time_slice=a.time_slice, speed=a.speed,
+                               looped=a.looped, enabled=a.enabled)
+        for time, en in a.signals:
+            an.add_signal(idx, time, en)
+        if a.root_motion is not None:
+            an.set_root_motion_settings(idx, *a.root_motion)
+        if a.max_event_capacity is not None:
+            an.set_max_event_capacity(idx, a.max_event_capacity)
+    if sc.track_root_motion:
+        an.track_root_motion(True)
     if sc.machine is not None:
         an.set_machine(sc.machine)
     an.base_id = base

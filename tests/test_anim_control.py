@@ -82,7 +82,46 @@ def run_program(orc, ops, anim_poses, layer_excluded, trs):
     return trs
 
 
-@pytest.mark.parametrize("make", cases.ALL, ids=lambda f: f.__name__)
+def run_rm_program(orc, ops, slots, anim_rm):
+    """Execute one instance's root-motion program over persistent slots of 8-float records
+    {dp xyz, has, dr ijkw} (pose.rs:73,98-100, play.rs:97, lib.rs:340-343) with the oracle's primitives."""
+    one = np.asarray([1], np.uint32).view(np.float32)[0]
+
+    def default(has):
+        r = np.zeros(8, np.float32)
+        r[7] = 1.0
+        if has:
+            r[3] = one
+        return r
+
+    for code, dst, src, wbits in ops:
+        name = A.RM_OP_NAMES[int(code)]
+        if name == "END":
+            break
+        if name == "SET_ANIM":
+            slots[dst] = anim_rm[src].copy()
+        elif name == "COPY":
+            slots[dst] = slots[src].copy()
+        else:
+            w = np.float32(np.uint32(wbits).view(np.float32))
+            d = slots[dst].copy() if _bits(slots[dst]) else default(True)
+            o = slots[src] if _bits(slots[src]) else default(False)
+            d[0:3] = orc.vec_lerp(d[0:3], o[0:3], w)
+            d[4:8] = orc.quat_nlerp(d[4:8], o[4:8], w)
+            slots[dst] = d
+    return slots
+
+
+def _drain(pop):
+    out = []
+    while True:
+        e = pop()
+        if e is None:
+            return out
+        out.append(e)
+
+
+@pytest.mark.parametrize("make", cases.ALL + cases.ALL_RM, ids=lambda f: f.__name__)
 def test_control_plane_matches_oracle(orc, cctx, make):
     sc = make()
     o = cases.build_oracle(orc, sc)
@@ -91,6 +130,7 @@ def test_control_plane_matches_oracle(orc, cctx, make):
     excluded = [set(l.mask) for l in sc.machine.layers] if sc.machine else []
     trs = o.node_trs()
     n_frames = min(sc.n_frames, 48)
+    rm_slots = None
     for f in range(n_frames):
         for idx, par in sc.script.get(f, []):
             o.set_parameter(idx, par)
@@ -108,15 +148,40 @@ def test_control_plane_matches_oracle(orc, cctx, make):
         assert np.array_equal(plan["times"][0], plan["times"][1])
         # sample times: a ticked animation is sampled at its time before the tick
         for a in range(len(sc.animations)):
-            if plan["ticked"][0, a]:
+            if plan["ticked"][0, a] & 1:
                 assert plan["times"][0, a] == np.float32(before[a]), (f, a)
             assert p.animation_state(a, 1) == o.animation_state(a), (f, a)
+            # signals -> events (the queues are drained only every third frame, so capacities matter)
+            assert p.event_count(a, 1) == o.event_count(a), (f, a)
+            if f % 3 == 2:
+                ref = _drain(lambda: o.pop_event(a))
+                assert _drain(lambda: p.pop_event(a, 0)) == ref, (f, a)
+                assert _drain(lambda: p.pop_event(a, 1)) == ref, (f, a)
         if sc.machine:
             for li in range(len(sc.machine.layers)):
                 assert p.layer_state(li, 0) == o.layer_state(li), (f, li)
+                ref = _drain(lambda: o.pop_layer_event(li))
+                assert _drain(lambda: p.pop_layer_event(li, 0)) == ref, (f, li)
+                assert _drain(lambda: p.pop_layer_event(li, 1)) == ref, (f, li)
         poses = [o.animation_pose(a) for a in range(len(sc.animations))]
         trs = run_program(orc, plan["ops"][o0:o1], poses, excluded, trs)
         assert np.array_equal(trs.view(np.uint32), o.node_trs().view(np.uint32)), f"{sc.name}: frame {f}"
+        if sc.track_root_motion and sc.machine:
+            rp = p.plan_root_motion()
+            r0, r1, r2 = rp["offsets"]
+            assert np.array_equal(rp["ops"][r0:r1], rp["ops"][r1:r2])
+            if rm_slots is None:
+                rm_slots = [np.zeros(8, np.float32) for _ in range(rp["n_slots"])]
+            anim_rm = [o.animation_root_motion(a) for a in range(len(sc.animations))]
+            rm_slots = run_rm_program(orc, rp["ops"][r0:r1], rm_slots, anim_rm)
+            base = 0
+            for li, layer in enumerate(sc.machine.layers):
+                base += len(layer.nodes)
+                assert np.array_equal(rm_slots[base].view(np.uint32), o.machine_root_motion(li).view(np.uint32)), (f, li)
+                base += 1
+            assert np.array_equal(rm_slots[-1].view(np.uint32), o.machine_root_motion(-1).view(np.uint32)), f
+            for a, spec in enumerate(sc.animations):   # the slices and flags the root-motion kernel receives
+                assert tuple(rp["slices"][0, a]) == tuple(np.float32(x) for x in spec.time_slice)
     o.close()
 
 

@@ -77,13 +77,55 @@ def run_scenario(ctx, orc, sc, n_instances=1, frames=None, check_every=1):
         if sc.machine is not None:
             for li in range(len(sc.machine.layers)):
                 assert p.layer_state(li, n_instances - 1) == o.layer_state(li)
+        if sc.track_root_motion:
+            for a in range(len(sc.animations)):
+                check_root_motion(p.animation_root_motion(a), o.animation_root_motion(a), exact,
+                                  f"{sc.name} frame {f} animation {a} root motion")
+            if sc.machine is not None:
+                for li in range(-1, len(sc.machine.layers)):
+                    check_root_motion(p.machine_root_motion(li), o.machine_root_motion(li), exact,
+                                      f"{sc.name} frame {f} root motion of " + ("the machine" if li < 0 else f"layer {li}"))
     return o, p
+
+
+def check_root_motion(got, ref, exact, what):
+    """(n_instances, 8) fyx_root_motion records against the oracle's single instance."""
+    for i in (0, got.shape[0] - 1):
+        assert got[i, 3].view(np.uint32) == ref[3].view(np.uint32), f"{what}: Option tag (instance {i})"
+        g, r = got[i].copy(), ref.copy()
+        g[3] = r[3] = 0
+        check(g, r, exact, f"{what} (instance {i})")
+
+
+def _drain(pop):
+    out = []
+    while (e := pop()) is not None:
+        out.append(e)
+    return out
 
 
 @pytest.mark.parametrize("make", cases.ALL, ids=lambda f: f.__name__)
 def test_scenario_matches_oracle(ctx, orc, make):
     sc = make()
     o, p = run_scenario(ctx, orc, sc, n_instances=3)
+    o.close()
+    p.free()
+
+
+@pytest.mark.parametrize("make", cases.ALL_RM, ids=lambda f: f.__name__)
+def test_root_motion_and_signals_match_oracle(ctx, orc, make):
+    """Animation::update_root_motion on the GPU (root pose rewritten before blending), AnimationPose::root_motion
+    through pose nodes / layers / machine, signal events and layer events."""
+    sc = make()
+    o, p = run_scenario(ctx, orc, sc, n_instances=3)
+    for a in range(len(sc.animations)):
+        ref = _drain(lambda: o.pop_event(a))
+        assert _drain(lambda: p.pop_event(a, 0)) == ref and _drain(lambda: p.pop_event(a, 2)) == ref
+    if sc.machine is not None:
+        for li in range(len(sc.machine.layers)):
+            ref = _drain(lambda: o.pop_layer_event(li))
+            assert ref or sc.name.startswith(("c5", "by_index", "blend_space", "layered"))
+            assert _drain(lambda: p.pop_layer_event(li, 1)) == ref
     o.close()
     p.free()
 

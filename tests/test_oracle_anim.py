@@ -162,3 +162,130 @@ def test_every_scenario_runs_and_moves_the_skeleton(orc):
         after = o.global_matrices()
         assert np.isfinite(after).all() and not np.array_equal(before, after), sc.name
         o.close()
+
+
+# ---- signals / events (lib.rs:471-496) and root motion (lib.rs:498-661), hand-derived ----------------
+
+def _linear_root_clip(p0, p1, length=1.0, rot0=None, rot1=None):
+    """Root bone (node 0) moving linearly from p0 to p1 over [0, length]; optional rotation keys."""
+    tracks, target = [], []
+    tracks.append(A.Track(A.BIND_POSITION, A.KIND_VEC3,
+                          [A.Curve([A.CurveKey(0.0, float(a)), A.CurveKey(length, float(b))]) for a, b in zip(p0, p1)]))
+    target.append(0)
+    if rot0 is not None:
+        tracks.append(A.Track(A.BIND_ROTATION, A.KIND_QUAT,
+                              [A.Curve([A.CurveKey(0.0, float(a)), A.CurveKey(length, float(b))]) for a, b in zip(rot0, rot1)]))
+        target.append(0)
+    return A.AnimationTracksData(tracks), np.asarray(target, np.int32)
+
+
+def test_signals_fire_once_per_crossing_and_only_when_enabled(orc):
+    td, tgt = _linear_root_clip((0, 0, 0), (1, 0, 0))
+    s = orc.AnimScene(synth.make_rig(2, 5))
+    a = s.add_animation(s.add_tracks_data(td), tgt, time_slice=(0.0, 1.0), looped=True,
+                        signals=[(0.25, True), (0.5, False), (0.75, True), (0.0, True)])
+    fired = []
+    for f in range(16):             # dt = 1/8: t = 0, .125, .25, ... wraps at 1.0
+        s.update_animations(0.125)
+        while (e := s.pop_event(a)) is not None:
+            fired.append((f, e))
+    # signal 0 (t=.25) fires on the tick that goes .125 -> .25 (new >= time), i.e. frame 1, and again one loop later;
+    # signal 1 is disabled; signal 2 (t=.75) on frame 5; signal 3 (t=0.0) never: current < 0.0 is impossible going forward
+    assert fired == [(1, 0), (5, 2), (9, 0), (13, 2)]
+    s.close()
+
+
+def test_event_capacity_caps_only_reverse_playback(orc):
+    # lib.rs:478-482: `fwd && crossing || rev && crossing && len < cap` -- the cap guards the reverse branch only
+    td, tgt = _linear_root_clip((0, 0, 0), (1, 0, 0))
+    for speed, expect in ((1.0, 4), (-1.0, 2)):
+        s = orc.AnimScene(synth.make_rig(2, 5))
+        a = s.add_animation(s.add_tracks_data(td), tgt, time_slice=(0.0, 1.0), looped=True, speed=speed,
+                            signals=[(0.3, True), (0.7, True)], max_event_capacity=2)
+        for _ in range(16):         # two loops, nobody pops
+            s.update_animations(0.125)
+        assert s.event_count(a) == expect
+        s.close()
+
+
+def test_root_motion_extracts_deltas_and_pins_the_root(orc):
+    f32 = np.float32
+    td, tgt = _linear_root_clip((1.0, 2.0, 3.0), (5.0, 2.0, -1.0))
+    s = orc.AnimScene(synth.make_rig(2, 5))
+    a = s.add_animation(s.add_tracks_data(td), tgt, time_slice=(0.0, 1.0), looped=True,
+                        root_motion=(0, False, True, False, False))   # keep Y in the pose
+    assert not s.animation_root_motion(a)[3].view(np.uint32)          # None before the first tick
+    total = np.zeros(3, np.float64)
+    for f in range(20):             # dt = 1/8, 2.5 loops
+        s.update_animations(0.125)
+        rm = s.animation_root_motion(a)
+        assert rm[3].view(np.uint32) == 1
+        total += rm[0:3].astype(np.float64)
+        pose = s.animation_pose(a)[0]
+        # the root no longer moves in X/Z: it sits at the value of the slice start; Y is left alone (ignored axis)
+        assert pose[0] == f32(1.0) and pose[2] == f32(3.0)
+        assert rm[1] == 0.0
+    # frame 0 reports the jump from the default prev_position (0,0,0) to the first sample (1,2,3); after that
+    # every frame reports the distance travelled, loop restarts included (the remainder carries end - last sample)
+    travelled = 19 * 0.125 * np.asarray([4.0, 0.0, -4.0])
+    assert np.allclose(total, np.asarray([1.0, 0.0, 3.0]) + travelled, atol=1e-5)
+    s.close()
+
+
+def test_root_motion_rotation_delta_is_relative_to_previous_frame(orc):
+    h = np.sqrt(0.5)
+    td, tgt = _linear_root_clip((0, 0, 0), (0, 0, 0), rot0=(0, 0, 0, 1), rot1=(0, h, 0, h))   # 0 -> 90 deg about Y (nlerp'd keys)
+    s = orc.AnimScene(synth.make_rig(2, 5))
+    a = s.add_animation(s.add_tracks_data(td), tgt, time_slice=(0.0, 1.0), looped=False, root_motion=(0, 0, 0, 0, 0))
+    prev = np.asarray([0, 0, 0, 1], np.float32)
+    for f in range(6):
+        before = s.animation_state(a)["time_position"]
+        s.update_animations(0.125)
+        cur = orc.quat_normalize(np.asarray([0, h * before, 0, 1 + (h - 1) * before], np.float32))  # sampled at the OLD time
+        conj = prev * np.asarray([-1, -1, -1, 1], np.float32)
+        expect = orc.quat_mul(np.asarray([0, 0, 0, 1], np.float32), orc.quat_mul(conj, cur))
+        rm = s.animation_root_motion(a)
+        assert np.allclose(rm[4:8], expect, atol=1e-6), f
+        assert np.array_equal(s.animation_pose(a)[0, 4:8], np.asarray([0, 0, 0, 1], np.float32))  # pinned to slice start
+        prev = cur
+    s.close()
+
+
+def test_pose_node_root_motion_survives_reset(orc):
+    # pose.rs:125-129 reset() leaves root_motion alone, so a BlendAnimations node blends this frame's inputs INTO
+    # last frame's value (and, unlike node poses, the first input's weight matters): rm = mix(mix(rm_prev, a, w0), b, w1)
+    f32 = np.float32
+    tda, tga = _linear_root_clip((0, 0, 0), (8, 0, 0))
+    tdb, tgb = _linear_root_clip((0, 0, 0), (0, 16, 0))
+    s = orc.AnimScene(synth.make_rig(2, 5))
+    for td, tg in ((tda, tga), (tdb, tgb)):
+        s.add_animation(s.add_tracks_data(td), tg, time_slice=(0.0, 1.0), looped=True, root_motion=(0, 0, 0, 0, 0))
+    nodes = [A.PlayAnimation(0), A.PlayAnimation(1), A.BlendAnimations([A.BlendPose(0, 0.5), A.BlendPose(1, 0.25)])]
+    s.set_machine(A.Machine([], [A.MachineLayer(nodes=nodes, states=[A.State(2)])]))
+    node_rm = np.zeros(3, f32)      # get_or_insert_with(Default)
+    for f in range(5):
+        s.update_machine(0.125)
+        da, db = s.animation_root_motion(0)[0:3], s.animation_root_motion(1)[0:3]
+        node_rm = node_rm * (f32(1) - f32(0.5)) + da * f32(0.5)
+        node_rm = node_rm * (f32(1) - f32(0.25)) + db * f32(0.25)
+        # layer: clone_into (copy); machine: blend_with(layer, weight 1.0) into ITS stale value -> a*(1-1)+b*1
+        assert np.array_equal(s.machine_root_motion(0)[0:3], node_rm), f
+        assert np.array_equal(s.machine_root_motion(-1)[0:3], node_rm * f32(0) + node_rm * f32(1)), f
+    s.close()
+
+
+def test_layer_events_follow_a_transition(orc):
+    sc = cases.transitions()
+    o = cases.build_oracle(orc, sc)
+    log = []
+    for f in range(sc.n_frames):
+        for idx, par in sc.script.get(f, []):
+            o.set_parameter(idx, par)
+        o.update_machine(sc.dt)
+        while (e := o.pop_layer_event(0)) is not None:
+            log.append(e)
+    # first transition idle(0) -> walk(1) is transition 0: leave 0, enter 1, transition changed, ... then done
+    assert log[:3] == [(A.EVENT_STATE_LEAVE, 0, -1), (A.EVENT_STATE_ENTER, 1, -1), (A.EVENT_ACTIVE_TRANSITION_CHANGED, 0, -1)]
+    assert log[3:5] == [(A.EVENT_ACTIVE_TRANSITION_CHANGED, -1, -1), (A.EVENT_ACTIVE_STATE_CHANGED, 0, 1)]
+    assert sum(1 for e in log if e[0] == A.EVENT_ACTIVE_STATE_CHANGED) >= 3
+    o.close()
