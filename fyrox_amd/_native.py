@@ -29,6 +29,15 @@ _STATUS_NAMES = {
 }
 
 
+class SkinDesc(ctypes.Structure):
+    """fyx_skin_desc (include/fyrox_hip.h)."""
+    _fields_ = [("d_palette", c_void_p), ("n_bones", c_uint32), ("n_instances", c_uint32),
+                ("d_blend_shape_weights", c_void_p), ("n_blend_shapes", c_uint32),
+                ("d_out_pos", c_void_p), ("d_out_normal", c_void_p), ("d_out_tangent", c_void_p),
+                ("d_out_vertices", c_void_p), ("out_stride", c_uint32),
+                ("out_off_pos", c_int32), ("out_off_normal", c_int32), ("out_off_tangent", c_int32)]
+
+
 class FyxError(RuntimeError):
     """A non-zero fyx_status returned by the native library."""
 
@@ -71,6 +80,8 @@ _SIGS = {
     "fyx_lbs_skin": (c_int, [_P, c_uint64, _P, c_uint32, c_uint32, _P, _P, _P, _P]),
     "fyx_lbs_skin_device": (c_int, [_P, c_uint64, _P, c_uint32, c_uint32, _P, _P, _P]),
     "fyx_lbs_skin_streams": (c_int, [_P, c_uint32, _P, _P, _P, _P, _P, _P, c_uint32, c_uint32, _P, _P, _P]),
+    "fyx_mesh_set_blend_shapes": (c_int, [_P, c_uint64, c_uint32, _P, c_uint32]),
+    "fyx_lbs_skin_ex": (c_int, [_P, c_uint64, _P]),
     "fyx_skinned_aabb": (c_int, [_P, c_uint64, _P, c_uint32, _P]),
     "fyx_calib_stream_copy": (c_int, [_P, _P, _P, c_uint32]),
     "fyx_palette": (c_int, [_P, _P, _P, c_uint32, _P]),

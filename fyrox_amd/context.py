@@ -202,6 +202,23 @@ class Context:
                                                  n_bones, n_instances, d_out_pos or None,
                                                  d_out_normal or None, d_out_tangent or None))
 
+    def mesh_set_blend_shapes(self, mesh_id: int, storage: Optional[np.ndarray], n_shapes: int, plane_vertices: int) -> None:
+        """storage: the RGB16F volume bytes of BlendShapesContainer (uint16 view), [shape][plane][9]."""
+        st = None if storage is None else np.ascontiguousarray(storage).view(np.uint16)
+        if st is not None:
+            assert st.size >= n_shapes * plane_vertices * 9
+        self._check(self._l.fyx_mesh_set_blend_shapes(self._h, mesh_id, n_shapes, _ptr(st), plane_vertices))
+
+    def lbs_skin_ex(self, mesh_id: int, d_palette: int, n_bones: int, n_instances: int = 1, *,
+                    d_blend_shape_weights: int = 0, n_blend_shapes: int = 0, d_out_pos: int = 0,
+                    d_out_normal: int = 0, d_out_tangent: int = 0, d_out_vertices: int = 0, out_stride: int = 0,
+                    out_off_pos: int = -1, out_off_normal: int = -1, out_off_tangent: int = -1) -> None:
+        """fyx_lbs_skin_ex: blend shapes before skinning and / or interleaved output.  Asynchronous."""
+        d = _native.SkinDesc(d_palette or None, n_bones, n_instances, d_blend_shape_weights or None, n_blend_shapes,
+                             d_out_pos or None, d_out_normal or None, d_out_tangent or None, d_out_vertices or None,
+                             out_stride, out_off_pos, out_off_normal, out_off_tangent)
+        self._check(self._l.fyx_lbs_skin_ex(self._h, mesh_id, byref(d)))
+
     def skinned_aabb(self, mesh_id: int, palette) -> np.ndarray:
         palette = _f32(palette, (-1, 16))
         box = np.empty(6, np.float32)

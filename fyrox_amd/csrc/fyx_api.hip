@@ -93,6 +93,7 @@ using namespace fyx;
 
 void free_mesh(Mesh& m) {
     if (m.block) (void)hipFree(m.block);
+    if (m.shapes) (void)hipFree(m.shapes);
     m = Mesh();
 }
 
@@ -451,6 +452,89 @@ int fyx_lbs_skin_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, ui
     hipStream_t st;
     if (int sr = acquire_launch_stream(c, &st)) return sr;
     FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_mesh_set_blend_shapes(fyx_ctx* c, uint64_t mesh_id, uint32_t n_shapes, const uint16_t* storage,
+                              uint32_t plane_vertices) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    Mesh* m = find_mesh(c, mesh_id);
+    if (!m) return fail(c, FYX_ERR_UNKNOWN_ID, "mesh %llu is not registered", (unsigned long long)mesh_id);
+    if (n_shapes > FYX_MAX_BLEND_SHAPES)
+        return fail(c, FYX_ERR_UNSUPPORTED, "%u blend shapes (the shader's weight array holds %d)", n_shapes, FYX_MAX_BLEND_SHAPES);
+    if (n_shapes && !storage) return fail(c, FYX_ERR_INVALID_ARG, "storage is null");
+    if (n_shapes && plane_vertices < m->n_verts)
+        return fail(c, FYX_ERR_INVALID_ARG, "a %u-texel-triple plane cannot hold %u vertices", plane_vertices, m->n_verts);
+    if (int jr = enter_primary(c)) return jr;
+    FYX_HIP(c, hipStreamSynchronize(c->stream));  // nothing may still read the old offsets
+    if (m->shapes) { FYX_HIP(c, hipFree(m->shapes)); m->shapes = nullptr; }
+    m->n_shapes = 0;
+    if (n_shapes == 0 || m->n_verts == 0) { m->n_shapes = n_shapes; return FYX_OK; }
+    const size_t src_bytes = (size_t)n_shapes * plane_vertices * 18;
+    const uint32_t tiles = (m->n_verts + 63) / 64;
+    const size_t dst_bytes = (size_t)n_shapes * tiles * 9 * 64 * 2;
+    int rc = ensure_scratch(c, src_bytes);
+    if (rc) return rc;
+    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&m->shapes), dst_bytes));
+    FYX_HIP(c, hipMemcpyAsync(c->scratch, storage, src_bytes, hipMemcpyHostToDevice, c->stream));
+    FYX_HIP(c, fyx::launch_retile_blend_shapes(static_cast<const uint16_t*>(c->scratch), m->n_verts, plane_vertices,
+                                               n_shapes, m->shapes, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    m->n_shapes = n_shapes;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_lbs_skin_ex(fyx_ctx* c, uint64_t mesh_id, const fyx_skin_desc* d) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (!d) return fail(c, FYX_ERR_INVALID_ARG, "desc is null");
+    const Mesh* m = find_mesh(c, mesh_id);
+    int rc = check_skin_args(c, m, mesh_id, d->d_palette, d->n_bones, d->n_instances);
+    if (rc) return rc;
+    fyx::LbsExArgs x;
+    memset(&x, 0, sizeof x);
+    x.a = make_args(*m, d->d_palette, d->n_bones, d->n_instances, d->d_out_pos, d->d_out_normal, d->d_out_tangent);
+    if (d->d_out_vertices) {
+        if (d->d_out_pos || d->d_out_normal || d->d_out_tangent)
+            return fail(c, FYX_ERR_INVALID_ARG, "give either the interleaved output or the SoA outputs");
+        if (d->out_stride == 0 || (d->out_stride & 3u)) return fail(c, FYX_ERR_UNSUPPORTED, "out_stride %u is not a multiple of 4", d->out_stride);
+        struct { int off; uint32_t size; const char* name; bool have; } f[] = {
+            {d->out_off_pos, 12, "Position", true}, {d->out_off_normal, 12, "Normal", m->nrm != nullptr},
+            {d->out_off_tangent, 16, "Tangent", m->tan != nullptr}};
+        for (auto& a : f) {
+            if (a.off < 0) continue;
+            if (!a.have) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no %s attribute", a.name);
+            if (a.off & 3) return fail(c, FYX_ERR_UNSUPPORTED, "%s offset %d is not 4-byte aligned", a.name, a.off);
+            if ((uint64_t)a.off + a.size > d->out_stride)
+                return fail(c, FYX_ERR_INVALID_ARG, "%s at offset %d does not fit vertex size %u", a.name, a.off, d->out_stride);
+        }
+        if (reinterpret_cast<uintptr_t>(d->d_out_vertices) & 3u) return fail(c, FYX_ERR_UNSUPPORTED, "output buffer is not 4-byte aligned");
+        x.out_aos = d->d_out_vertices;
+        x.out_stride = d->out_stride;
+        x.off_pos = d->out_off_pos; x.off_nrm = d->out_off_normal; x.off_tan = d->out_off_tangent;
+    } else {
+        if (d->d_out_normal && !m->nrm) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Normal attribute");
+        if (d->d_out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Tangent attribute");
+    }
+    if (d->n_blend_shapes) {
+        if (d->n_blend_shapes != m->n_shapes)
+            return fail(c, FYX_ERR_INVALID_ARG, "%u blend-shape weights for a mesh with %u blend shapes", d->n_blend_shapes, m->n_shapes);
+        if (!d->d_blend_shape_weights) return fail(c, FYX_ERR_INVALID_ARG, "blend-shape weights are null");
+        x.shapes = m->shapes;
+        x.shape_w = d->d_blend_shape_weights;
+        x.n_shapes = m->shapes ? d->n_blend_shapes : 0;
+        x.tiles_per_shape = (m->n_verts + 63) / 64;
+    }
+    hipStream_t st;
+    if (int sr = acquire_launch_stream(c, &st)) return sr;
+    if (!x.out_aos && !x.n_shapes) {
+        FYX_HIP(c, fyx::launch_lbs(x.a, c->lbs, st));   // nothing extended asked for: the plain kernel
+    } else {
+        FYX_HIP(c, fyx::launch_lbs_ex(x, c->lbs, st));
+    }
     return FYX_OK;
     FYX_GUARD_END(c)
 }

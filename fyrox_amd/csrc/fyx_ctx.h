@@ -21,6 +21,9 @@ struct Mesh {
     float* tan = nullptr;
     float* wgt = nullptr;
     uint32_t* idx = nullptr;
+    // BlendShapesContainer offsets, re-tiled (own allocation; replaced by fyx_mesh_set_blend_shapes)
+    uint16_t* shapes = nullptr;
+    uint32_t n_shapes = 0;
 };
 struct AnimStore;  // anim_api.hip: tracks data, rigs, animators, bone lists
 void anim_store_destroy(AnimStore*);

@@ -36,6 +36,22 @@ struct LbsArgs {
 // Launch the skinning kernel.  Returns hipSuccess or the launch error.
 hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream);
 
+// Extended launch: blend shapes before skinning and / or interleaved output (lbs_skin_ex).
+struct LbsExArgs {
+    LbsArgs a;                   // out_* are the SoA outputs (ignored when out_aos is set)
+    const uint16_t* shapes;      // re-tiled f16 offsets [shape][tile][9][64], or null
+    const float* shape_w;        // [n_instances][n_shapes]
+    uint32_t n_shapes;
+    uint32_t tiles_per_shape;
+    unsigned char* out_aos;      // interleaved output [n_instances][n_verts][out_stride], or null
+    uint32_t out_stride;
+    int off_pos, off_nrm, off_tan;   // byte offsets inside a vertex, -1 = do not write
+};
+hipError_t launch_lbs_ex(const LbsExArgs& x, const LbsTuning& t, hipStream_t stream);
+// engine RGB16F volume -> device tile layout (see lbs_kernels.hip)
+hipError_t launch_retile_blend_shapes(const uint16_t* d_src, uint32_t n_verts, uint32_t plane_vertices,
+                                      uint32_t n_shapes, uint16_t* d_dst, hipStream_t stream);
+
 // AoS -> SoA de-interleave (device to device).  off_* in bytes, -1 = absent.
 hipError_t launch_deinterleave(const uint8_t* d_aos, uint32_t n_verts, uint32_t stride,
                                int off_pos, int off_nrm, int off_tan, int off_wgt, int off_idx,

@@ -495,6 +495,175 @@ hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream) 
 }
 
 // ---------------------------------------------------------------------------------------
+// Extended skinning kernel: blend shapes before skinning and/or interleaved (AoS) output.
+//
+//   blend shapes (standard.shader:167-173): for i in 0..blendShapesCount:
+//        p += offsets[i].position * w_i;  n += offsets[i].normal * w_i;  t.xyz += offsets[i].tangent * w_i
+//     with the offsets texelFetch'ed from the RGB16F volume BlendShapesContainer::from_lists builds
+//     (surface.rs:116-217; f16 -> f32 is exact) and w_i = BlendShape::weight / 100 (mesh/mod.rs:794-798).
+//     On the device the volume is re-tiled once per upload to [shape][64-vertex tile][9 components][64 lanes]
+//     f16, so each of the nine loads of a wave is one dense 128-byte span and a shape costs exactly its
+//     18 B/vertex of HBM traffic.  The shape weights of an instance are wave-uniform (scalar loads).
+//   interleaved output: position / normal / tangent.xyzw are stored straight into a vertex buffer with
+//     the renderer's layout (stride and attribute offsets as VertexBuffer's layout gives them,
+//     scene/mesh/buffer.rs:404-415), so the skinned mesh can be drawn (or read back) without a
+//     re-interleave pass; bytes of other attributes (tex coords, ...) are left as the caller put them.
+// Same work split as lbs_skin (persistent grid, contiguous unit ranges, palette staged per instance
+// segment); EXACT keeps the unfused reference order (GLSL leaves contraction to the driver, the CPU
+// restatement does not contract).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float h2f(uint16_t h) {
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+
+template <bool EXACT, bool SHAPES, bool AOS>
+__global__ __launch_bounds__(512) void lbs_skin_ex(LbsExArgs x, uint32_t units_per_inst, uint32_t total_units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LbsArgs& a = x.a;
+    f32x4* rows = reinterpret_cast<f32x4*>(smem);
+    f32x4* row3 = rows + 3 * a.n_bones;
+    uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);
+    constexpr uint32_t WPB = 512 / 64;
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    if (u_begin >= u_end) return;
+    const uint32_t inst_first = u_begin / units_per_inst, inst_last = (u_end - 1) / units_per_inst;
+    const bool has_n = a.nrm != nullptr, has_t = a.tan != nullptr;   // kernel-uniform
+
+    for (uint32_t inst = inst_first; inst <= inst_last; ++inst) {
+        const uint32_t inst_u0 = inst * units_per_inst;
+        const uint32_t seg_b = (u_begin > inst_u0 ? u_begin : inst_u0) - inst_u0;
+        const uint32_t seg_e = (u_end < inst_u0 + units_per_inst ? u_end : inst_u0 + units_per_inst) - inst_u0;
+        const PaletteRegs pr = palette_fetch(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, tid);
+        if (inst != inst_first) __syncthreads();
+        const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
+        const bool wave_pj = __any(pj) != 0;
+        if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
+        __syncthreads();
+        bool projective = false;
+#pragma unroll
+        for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
+        const float* sw = SHAPES ? x.shape_w + (size_t)inst * x.n_shapes : nullptr;
+
+        for (uint32_t u = seg_b + wave; u < seg_e; u += WPB) {  // wave-uniform
+            const uint32_t v = u * 64 + lane;
+            const uint32_t vs = v < a.n_verts ? v : 0;
+            float px, py, pz, nx = 0.f, ny = 0.f, nz = 0.f;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            ld3<true>(a.pos + (size_t)vs * 3, px, py, pz);
+            if (has_n) ld3<true>(a.nrm + (size_t)vs * 3, nx, ny, nz);
+            if (has_t) t = ldg<true>(reinterpret_cast<const f32x4*>(a.tan) + vs);
+            const f32x4 w = ldg<true>(reinterpret_cast<const f32x4*>(a.wgt) + vs);
+            const uint32_t id = ldg<true>(a.idx + vs);
+            if constexpr (SHAPES) {
+                // tile u of every shape: 9 planes of 64 halfs; this lane's column
+                const uint16_t* col = x.shapes + ((size_t)u * 9) * 64 + lane;
+                const size_t shape_stride = (size_t)x.tiles_per_shape * 9 * 64;
+#pragma unroll 2
+                for (uint32_t sidx = 0; sidx < x.n_shapes; ++sidx) {
+                    const uint16_t* c = col + (size_t)sidx * shape_stride;
+                    const float ws = sw[sidx];
+                    uint16_t h[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) h[k] = __builtin_nontemporal_load(c + k * 64);
+                    if constexpr (EXACT) {
+                        px = px + h2f(h[0]) * ws; py = py + h2f(h[1]) * ws; pz = pz + h2f(h[2]) * ws;
+                        nx = nx + h2f(h[3]) * ws; ny = ny + h2f(h[4]) * ws; nz = nz + h2f(h[5]) * ws;
+                        t.x = t.x + h2f(h[6]) * ws; t.y = t.y + h2f(h[7]) * ws; t.z = t.z + h2f(h[8]) * ws;
+                    } else {
+                        px = __builtin_fmaf(h2f(h[0]), ws, px); py = __builtin_fmaf(h2f(h[1]), ws, py);
+                        pz = __builtin_fmaf(h2f(h[2]), ws, pz); nx = __builtin_fmaf(h2f(h[3]), ws, nx);
+                        ny = __builtin_fmaf(h2f(h[4]), ws, ny); nz = __builtin_fmaf(h2f(h[5]), ws, nz);
+                        t.x = __builtin_fmaf(h2f(h[6]), ws, t.x); t.y = __builtin_fmaf(h2f(h[7]), ws, t.y);
+                        t.z = __builtin_fmaf(h2f(h[8]), ws, t.z);
+                    }
+                }
+            }
+            const Skinned o = skin_vertex<EXACT, 7>(rows, row3, projective, id, w, px, py, pz, nx, ny, nz, t.x, t.y, t.z);
+            if (v < a.n_verts) {
+                const size_t ov = (size_t)inst * a.n_verts + v;
+                if constexpr (AOS) {
+                    unsigned char* rec = x.out_aos + ov * x.out_stride;
+                    if (x.off_pos >= 0) st3<true>(reinterpret_cast<float*>(rec + x.off_pos), o.px, o.py, o.pz);
+                    if (has_n && x.off_nrm >= 0) st3<true>(reinterpret_cast<float*>(rec + x.off_nrm), o.nx, o.ny, o.nz);
+                    if (has_t && x.off_tan >= 0) {
+                        float* tp = reinterpret_cast<float*>(rec + x.off_tan);
+                        st3<true>(tp, o.tx, o.ty, o.tz);
+                        stg<true>(tp + 3, t.w);
+                    }
+                } else {
+                    if (a.out_pos) st3<true>(a.out_pos + ov * 3, o.px, o.py, o.pz);
+                    if (a.out_nrm) st3<true>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
+                    if (a.out_tan) stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, t.w});
+                }
+            }
+        }
+    }
+}
+
+template <bool EXACT, bool SHAPES, bool AOS>
+static hipError_t launch_ex_one(const LbsExArgs& x, const LbsTuning& t, hipStream_t s) {
+    const uint32_t upi = (x.a.n_verts + 63) / 64;
+    const uint64_t total64 = (uint64_t)upi * x.a.n_instances;
+    if (total64 == 0) return hipSuccess;
+    if (total64 > 0xffffffffull) return hipErrorInvalidValue;
+    const uint32_t total = (uint32_t)total64;
+    // 88-100 VGPRs: 4-5 waves per SIMD = two resident 512-thread workgroups per CU; a persistent grid
+    // larger than what is resident would run in rounds
+    (void)t;
+    uint32_t grid = (uint32_t)kCUs * 2u;
+    const uint32_t max_useful = (total + 7) / 8;
+    if (grid > max_useful) grid = max_useful;
+    const size_t lds = (size_t)x.a.n_bones * 64 + 64;
+    hipLaunchKernelGGL((lbs_skin_ex<EXACT, SHAPES, AOS>), dim3(grid), dim3(512), lds, s, x, upi, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_lbs_ex(const LbsExArgs& x, const LbsTuning& t, hipStream_t s) {
+    const bool shapes = x.n_shapes > 0, aos = x.out_aos != nullptr;
+    const int key = (t.exact ? 4 : 0) | (shapes ? 2 : 0) | (aos ? 1 : 0);
+    switch (key) {
+        case 7: return launch_ex_one<true, true, true>(x, t, s);
+        case 6: return launch_ex_one<true, true, false>(x, t, s);
+        case 5: return launch_ex_one<true, false, true>(x, t, s);
+        case 4: return launch_ex_one<true, false, false>(x, t, s);
+        case 3: return launch_ex_one<false, true, true>(x, t, s);
+        case 2: return launch_ex_one<false, true, false>(x, t, s);
+        case 1: return launch_ex_one<false, false, true>(x, t, s);
+        default: return launch_ex_one<false, false, false>(x, t, s);
+    }
+}
+
+// RGB16F volume (engine layout: [shape][vertex][texel: position, normal, tangent][rgb], 18 B per vertex,
+// plane_vertices = width * height texel triples per shape) -> [shape][tile][9][64] f16.
+__global__ __launch_bounds__(256) void retile_blend_shapes_kernel(const uint16_t* __restrict__ src, uint32_t n_verts,
+                                                                  uint32_t plane_vertices, uint32_t n_shapes,
+                                                                  uint32_t tiles, uint16_t* __restrict__ dst) {
+    const uint64_t total = (uint64_t)n_shapes * tiles * 9 * 64;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = (uint32_t)(e & 63), k = (uint32_t)((e >> 6) % 9);
+        const uint64_t ts = (e >> 6) / 9;
+        const uint32_t tile = (uint32_t)(ts % tiles), shape = (uint32_t)(ts / tiles);
+        const uint32_t v = tile * 64 + l;
+        dst[e] = v < n_verts ? src[((size_t)shape * plane_vertices + v) * 9 + k] : (uint16_t)0;
+    }
+}
+
+hipError_t launch_retile_blend_shapes(const uint16_t* d_src, uint32_t n_verts, uint32_t plane_vertices,
+                                      uint32_t n_shapes, uint16_t* d_dst, hipStream_t s) {
+    const uint32_t tiles = (n_verts + 63) / 64;
+    const uint64_t total = (uint64_t)n_shapes * tiles * 9 * 64;
+    if (total == 0) return hipSuccess;
+    uint64_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(retile_blend_shapes_kernel, dim3((uint32_t)grid), dim3(256), 0, s, d_src, n_verts,
+                       plane_vertices, n_shapes, tiles, d_dst);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // AoS -> SoA de-interleave.  One thread per vertex; field reads are 4-byte loads at the
 // vertex stride (the AoS source is read once per mesh modification, not per frame).
 // Bytes are reinterpreted as little-endian f32/u8 exactly as VertexReadTrait does

@@ -107,6 +107,32 @@ def make_mesh(n_verts: int, n_bones: int, seed: int, coherent: bool = True) -> S
     return SkinnedMesh(pos, nrm, tangent, w.astype(np.float32), idx, n_bones)
 
 
+def make_blend_shapes(n_verts: int, n_shapes: int, seed: int, density: float = 0.35):
+    """The RGB16F volume BlendShapesContainer::from_lists packs (fyrox-impl/src/scene/mesh/surface.rs:116-217):
+    width = min(n_verts, 512), height = ceil(n_verts / width), per shape one plane of width*height records of
+    nine f16 {position, normal, tangent offset}; vertices a shape does not touch stay zero (the maps are
+    sparse).  Returns (storage uint16 [n_shapes, plane, 9], plane_vertices, weights f32 [n_shapes]) with weights
+    already divided by 100 as Mesh::collect_render_data does (scene/mesh/mod.rs:794-798)."""
+    width = max(min(n_verts, 512), 1)
+    height = -(-n_verts // width) if n_verts else 0
+    plane = width * height
+    st = np.zeros((n_shapes, plane, 9), np.float16)
+    for sidx in range(n_shapes):
+        tag = f"shape{sidx}"
+        touched = uniform(seed, tag + ".mask", n_verts) < density
+        off = ((uniform(seed, tag + ".off", n_verts * 9) - 0.5) * 0.25).reshape(n_verts, 9).astype(np.float16)
+        off[~touched] = 0
+        st[sidx, :n_verts] = off
+    bits = st.view(np.uint16)
+    if n_shapes and n_verts > 8:   # a subnormal, a negative zero and the largest finite half, to pin the f16 decode
+        bits[0, 1, 0] = 0x0001
+        bits[0, 2, 3] = 0x8000
+        bits[0, 3, 6] = 0x7BFF
+        bits[0, 4, 1] = 0x83FF
+    weights = (np.float32(100.0) * (uniform(seed, "shape.w", n_shapes) * 1.2 - 0.1).astype(np.float32)) / np.float32(100.0)
+    return bits.copy(), plane, weights.astype(np.float32)
+
+
 def quat_to_mat3(q: np.ndarray) -> np.ndarray:
     """(n,4) quaternions (i,j,k,w), float64 -> (n,3,3) rotation matrices."""
     i, j, k, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]

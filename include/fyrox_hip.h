@@ -136,6 +136,46 @@ int fyx_lbs_skin(fyx_ctx* ctx, uint64_t mesh_id, const float* palette, uint32_t 
 int fyx_lbs_skin_device(fyx_ctx* ctx, uint64_t mesh_id, const float* d_palette, uint32_t n_bones,
                         uint32_t n_instances, float* d_out_pos, float* d_out_normal,
                         float* d_out_tangent);
+/* Blend shapes (morph targets).  `storage` = the bytes of BlendShapesContainer::blend_shape_storage
+ * (fyrox-impl/src/scene/mesh/surface.rs:116-217): an RGB16F volume of width*3 x height x n_shapes
+ * texels, i.e. per shape `plane_vertices` (= width * height >= n_verts) records of three f16 triples
+ * {position, normal, tangent offset}, vertex v at record v -- exactly what S_FetchBlendShapeOffsets
+ * (fyrox-graphics-gl/src/shaders/shared.glsl:371-378) reads.  Uploaded once per SurfaceData change
+ * (host pointer); n_shapes = 0 removes them.  At most FYX_MAX_BLEND_SHAPES
+ * (ShaderDefinition::MAX_BLEND_SHAPE_WEIGHT_GROUPS * 4, fyrox-material/src/shader/mod.rs:616). */
+#define FYX_MAX_BLEND_SHAPES 128
+int fyx_mesh_set_blend_shapes(fyx_ctx* ctx, uint64_t mesh_id, uint32_t n_shapes, const uint16_t* storage,
+                              uint32_t plane_vertices);
+
+/* Skinning with everything the standard shader's vertex stage does before the world transform
+ * (fyrox-material/src/shader/standard/opengl/standard.shader:157-200): blend-shape offsets are
+ * added to position / normal / tangent.xyz first (for i in 0..n: v += offset_i * weight_i, i
+ * ascending, unfused under lbs.exact=1), then the four-influence blend.  All pointers device.
+ *   d_blend_shape_weights: [n_instances][n_blend_shapes], the values SurfaceInstanceData carries
+ *     (BlendShape::weight / 100, scene/mesh/mod.rs:794-798); n_blend_shapes must be 0 (skip) or the
+ *     mesh's shape count.
+ *   Outputs: either the SoA streams of fyx_lbs_skin_device, or ONE interleaved vertex buffer
+ *     d_out_vertices [n_instances][n_verts][out_stride]: position (12 B), normal (12 B) and tangent
+ *     (xyzw, 16 B, w passed through) are written at their byte offsets (< 0: not written; stride
+ *     and offsets multiples of 4, as every VertexAttributeDataType::F32 layout is); all other bytes
+ *     of a vertex -- tex coords, bone data -- are left untouched, so a buffer initialised once with
+ *     the surface's own VertexBuffer bytes stays a valid render-ready vertex buffer
+ *     (scene/mesh/buffer.rs:404-415; consumer: renderer/cache/geometry.rs:84-93). */
+typedef struct fyx_skin_desc {
+    const float* d_palette;
+    uint32_t n_bones;
+    uint32_t n_instances;
+    const float* d_blend_shape_weights;
+    uint32_t n_blend_shapes;
+    float* d_out_pos;
+    float* d_out_normal;
+    float* d_out_tangent;
+    uint8_t* d_out_vertices;
+    uint32_t out_stride;
+    int32_t out_off_pos, out_off_normal, out_off_tangent;
+} fyx_skin_desc;
+int fyx_lbs_skin_ex(fyx_ctx* ctx, uint64_t mesh_id, const fyx_skin_desc* desc);
+
 /* Raw-stream form (no registry): all pointers device; d_indices is 4 x u8 per vertex. No bone
  * index validation (caller guarantees indices < n_bones). Asynchronous. */
 int fyx_lbs_skin_streams(fyx_ctx* ctx, uint32_t n_verts, const float* d_pos, const float* d_normal,

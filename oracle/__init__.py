@@ -256,6 +256,33 @@ def lbs_skin(pos, weights, indices, palette_, normal=None, tangent=None, *, thre
     return out
 
 
+def half_to_float(h) -> np.ndarray:
+    l = lib()
+    l.fo_half_to_float.restype = c_float
+    l.fo_half_to_float.argtypes = [ctypes.c_uint16]
+    return np.asarray([l.fo_half_to_float(int(x)) for x in np.asarray(h, np.uint16).ravel()], np.float32)
+
+
+def apply_blend_shapes(pos, normal, tangent, storage, plane_vertices: int, weights):
+    """standard.shader:167-173: returns (pos, normal, tangent) with every shape's offsets added."""
+    pos = _f32(pos, (-1, 3))
+    n = pos.shape[0]
+    nrm = None if normal is None else _f32(normal, (n, 3))
+    tan = None if tangent is None else _f32(tangent, (n, 4))
+    st = np.ascontiguousarray(storage).view(np.uint16)
+    w = _f32(weights)
+    op = np.empty_like(pos)
+    on = None if nrm is None else np.empty_like(nrm)
+    ot = None if tan is None else np.empty_like(tan)
+    l = lib()
+    l.fo_apply_blend_shapes.restype = None
+    l.fo_apply_blend_shapes.argtypes = [c_uint32] + [c_void_p] * 4 + [c_uint32, c_uint32] + [c_void_p] * 4
+    l.fo_apply_blend_shapes(n, _p(pos), None if nrm is None else _p(nrm), None if tan is None else _p(tan), _p(st),
+                            plane_vertices, len(w), _p(w), _p(op), None if on is None else _p(on),
+                            None if ot is None else _p(ot))
+    return op, on, ot
+
+
 def accurate_world_bounding_box(aos, n_verts, stride, off_pos, off_weights, off_indices, palette_) -> np.ndarray:
     aos = np.ascontiguousarray(aos, dtype=np.uint8)
     pal = _f32(palette_, (-1, 16))

@@ -501,3 +501,54 @@ uint32_t fo_accurate_world_bounding_box(const uint8_t* aos, uint32_t n_verts, ui
     }
     return v;
 }
+
+/* ======================================================================== */
+/* Blend shapes                                                              */
+/* ======================================================================== */
+
+/* IEEE binary16 -> binary32, exact (what texelFetch on an RGB16F texture returns). */
+float fo_half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) { bits = sign; }
+        else { /* subnormal: normalise */
+            int e = -1;
+            do { ++e; man <<= 1; } while (!(man & 0x400u));
+            bits = sign | (uint32_t)(127 - 15 - e) << 23 | (man & 0x3ffu) << 13;
+        }
+    } else if (exp == 31) { bits = sign | 0x7f800000u | man << 13; }
+    else { bits = sign | (exp + 127 - 15) << 23 | man << 13; }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+/* fyrox-material/src/shader/standard/opengl/standard.shader:167-173 with S_FetchBlendShapeOffsets
+ * (fyrox-graphics-gl/src/shaders/shared.glsl:371-378) over the RGB16F volume that
+ * BlendShapesContainer::from_lists packs (fyrox-impl/src/scene/mesh/surface.rs:116-217):
+ *   texel (3*v + {0,1,2}) of layer i = position / normal / tangent offset of vertex v, shape i;
+ *   for i in 0..n_shapes: p += off.position * w[i]; n += off.normal * w[i]; t.xyz += off.tangent * w[i]
+ * (GLSL may contract a*b+c; this restatement does not -- parity unpinned, see the header).
+ * storage: n_shapes planes of plane_vertices * 9 halfs.  nrm / tan (and their outputs) may be NULL. */
+void fo_apply_blend_shapes(uint32_t n_verts, const float* pos, const float* nrm, const float* tan,
+                           const uint16_t* storage, uint32_t plane_vertices, uint32_t n_shapes,
+                           const float* weights, float* out_pos, float* out_nrm, float* out_tan) {
+    for (uint32_t v = 0; v < n_verts; ++v) {
+        float p[3] = { pos[v * 3], pos[v * 3 + 1], pos[v * 3 + 2] };
+        float n[3] = { 0, 0, 0 }, t[4] = { 0, 0, 0, 0 };
+        if (nrm) memcpy(n, nrm + (size_t)v * 3, 12);
+        if (tan) memcpy(t, tan + (size_t)v * 4, 16);
+        for (uint32_t i = 0; i < n_shapes; ++i) {
+            const uint16_t* rec = storage + ((size_t)i * plane_vertices + v) * 9;
+            float w = weights[i];
+            for (int k = 0; k < 3; ++k) {
+                p[k] = p[k] + fo_half_to_float(rec[k]) * w;
+                n[k] = n[k] + fo_half_to_float(rec[3 + k]) * w;
+                t[k] = t[k] + fo_half_to_float(rec[6 + k]) * w;
+            }
+        }
+        memcpy(out_pos + (size_t)v * 3, p, 12);
+        if (nrm && out_nrm) memcpy(out_nrm + (size_t)v * 3, n, 12);
+        if (tan && out_tan) memcpy(out_tan + (size_t)v * 4, t, 16);
+    }
+}

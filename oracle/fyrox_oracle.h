@@ -123,6 +123,11 @@ uint32_t fo_accurate_world_bounding_box(const uint8_t* aos, uint32_t n_verts, ui
                                         int off_pos, int off_weights, int off_indices,
                                         const float* palette, uint32_t n_bones, float aabb[6]);
 int fo_omp_max_threads(void);
+/* blend shapes ahead of skinning (standard.shader:167-173, surface.rs:116-217) */
+float fo_half_to_float(uint16_t h);
+void fo_apply_blend_shapes(uint32_t n_verts, const float* pos, const float* nrm, const float* tan,
+                           const uint16_t* storage, uint32_t plane_vertices, uint32_t n_shapes,
+                           const float* weights, float* out_pos, float* out_nrm, float* out_tan);
 
 /* ---------- fyrox-animation pose path (fyrox_oracle_anim.c) ---------- */
 /* ValueBinding (value.rs:355-373): ids >= FO_BIND_PROPERTY0 stand for distinct Property{name,..} */

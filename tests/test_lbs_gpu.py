@@ -363,3 +363,145 @@ def test_overlapped_launch_streams_and_join(ctx, orc, streams):
     assert np.array_equal(outs[2][0].download(np.float32, m.n_verts * 3).reshape(-1, 3), oracle_skin(orc, m2, pals[2])["pos"])
     for b in d_pals + [x for o in outs for x in o]:
         b.free()
+
+
+# ---- blend shapes ahead of skinning, interleaved (render-ready) output -------------------------------------
+
+def oracle_skin_shapes(orc, m, pal, storage, plane, weights, n_inst=1):
+    """standard.shader:157-200: per instance, offsets of every shape added first, then the four-bone blend."""
+    nb = pal.shape[0] // n_inst
+    w = np.asarray(weights, np.float32).reshape(n_inst, -1)
+    outs = []
+    for i in range(n_inst):
+        p, n, t = orc.apply_blend_shapes(m.pos, m.normal, m.tangent, storage, plane, w[i])
+        outs.append(orc.lbs_skin(p, m.weights, m.indices, pal[i * nb:(i + 1) * nb], n, t, threads=0))
+    return {k: np.concatenate([o[k] for o in outs]) for k in outs[0]}
+
+
+def run_ex(ctx, mesh_id, m, pal, n_inst, weights=None, aos_layout=None, init_bytes=None):
+    nv = m.n_verts * n_inst
+    d_pal = ctx.to_device(pal)
+    d_w = ctx.to_device(np.asarray(weights, np.float32)) if weights is not None else None
+    ns = 0 if weights is None else np.asarray(weights).size // n_inst
+    try:
+        if aos_layout is None:
+            bufs = [ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)]
+            ctx.lbs_skin_ex(mesh_id, d_pal.ptr, pal.shape[0] // n_inst, n_inst, d_blend_shape_weights=d_w.ptr if d_w else 0,
+                            n_blend_shapes=ns, d_out_pos=bufs[0].ptr, d_out_normal=bufs[1].ptr, d_out_tangent=bufs[2].ptr)
+            ctx.sync()
+            out = {"pos": bufs[0].download(np.float32, nv * 3).reshape(nv, 3),
+                   "normal": bufs[1].download(np.float32, nv * 3).reshape(nv, 3),
+                   "tangent": bufs[2].download(np.float32, nv * 4).reshape(nv, 4)}
+            for b in bufs:
+                b.free()
+            return out
+        stride, op, on, ot = aos_layout
+        buf = ctx.to_device(init_bytes)
+        ctx.lbs_skin_ex(mesh_id, d_pal.ptr, pal.shape[0] // n_inst, n_inst, d_blend_shape_weights=d_w.ptr if d_w else 0,
+                        n_blend_shapes=ns, d_out_vertices=buf.ptr, out_stride=stride, out_off_pos=op, out_off_normal=on,
+                        out_off_tangent=ot)
+        ctx.sync()
+        raw = buf.download(np.uint8, nv * stride).reshape(nv, stride)
+        buf.free()
+        return raw
+    finally:
+        d_pal.free()
+        if d_w:
+            d_w.free()
+
+
+@pytest.mark.parametrize("n_verts,n_shapes,n_inst", [(1000, 1, 1), (4099, 5, 1), (50_000, 3, 2), (777, 128, 1)])
+def test_blend_shapes_then_skinning_bit_exact(ctx, orc, n_verts, n_shapes, n_inst):
+    m = synth.make_mesh(n_verts, 64, synth.SEED_BASE + 20)
+    pal = synth.make_palette(64, synth.SEED_BASE + 20, n_instances=n_inst)
+    storage, plane, w = synth.make_blend_shapes(n_verts, n_shapes, synth.SEED_BASE + 20)
+    weights = np.stack([w * np.float32(1.0 - 0.3 * i) for i in range(n_inst)])
+    upload(ctx, 60, m)
+    ctx.mesh_set_blend_shapes(60, storage, n_shapes, plane)
+    got = run_ex(ctx, 60, m, pal, n_inst, weights)
+    assert_bit_exact(got, oracle_skin_shapes(orc, m, pal, storage, plane, weights, n_inst))
+    # all-zero weights: x + offset*0 == x, so the plain kernel's result
+    zero = run_ex(ctx, 60, m, pal, n_inst, np.zeros_like(weights))
+    assert_bit_exact(zero, oracle_skin(orc, m, pal, n_inst))
+    # removing the shapes again
+    ctx.mesh_set_blend_shapes(60, None, 0, 0)
+    with pytest.raises(fyrox_amd.FyxError):
+        run_ex(ctx, 60, m, pal, n_inst, weights)
+    ctx.mesh_free(60)
+
+
+def test_blend_shapes_fused_mode_within_tolerance(ctx, orc):
+    m = synth.make_mesh(30_011, 64, synth.SEED_BASE + 21)
+    pal = synth.make_palette(64, synth.SEED_BASE + 21)
+    storage, plane, w = synth.make_blend_shapes(m.n_verts, 4, synth.SEED_BASE + 21)
+    upload(ctx, 61, m)
+    ctx.mesh_set_blend_shapes(61, storage, 4, plane)
+    ctx.set_option("lbs.exact", 0)
+    got = run_ex(ctx, 61, m, pal, 1, w)
+    ref = oracle_skin_shapes(orc, m, pal, storage, plane, w)
+    for k in ("pos", "normal", "tangent"):
+        assert rel_err(got[k], ref[k]) <= REL_TOL, k   # tolerance: 1e-5 relative (north_star)
+    ctx.mesh_free(61)
+
+
+@pytest.mark.parametrize("layout", ["animated_vertex", "static_vertex", "pos_only"])
+@pytest.mark.parametrize("shapes", [0, 3])
+def test_interleaved_output_is_a_render_ready_vertex_buffer(ctx, orc, layout, shapes):
+    """Position / normal / tangent land at their offsets of the engine's vertex layout (vertex.rs:139-155 for
+    AnimatedVertex: stride 68; StaticVertex: 48) and every other byte of the buffer is left alone."""
+    n_inst = 2
+    m = synth.make_mesh(9_001, 32, synth.SEED_BASE + 22, coherent=False)
+    pal = synth.make_palette(32, synth.SEED_BASE + 22, n_instances=n_inst)
+    upload(ctx, 62, m, aos=True)
+    weights = None
+    if shapes:
+        storage, plane, w = synth.make_blend_shapes(m.n_verts, shapes, synth.SEED_BASE + 22)
+        ctx.mesh_set_blend_shapes(62, storage, shapes, plane)
+        weights = np.stack([w, w * np.float32(0.5)])
+        ref = oracle_skin_shapes(orc, m, pal, storage, plane, weights, n_inst)
+    else:
+        ref = oracle_skin(orc, m, pal, n_inst)
+    if layout == "animated_vertex":
+        L = synth.ANIMATED_VERTEX
+        stride, op, on, ot = L["stride"], L["off_pos"], L["off_normal"], L["off_tangent"]
+        init = np.tile(m.to_animated_vertex_aos().reshape(m.n_verts, stride), (n_inst, 1))
+    elif layout == "static_vertex":
+        stride, op, on, ot = 48, 0, 20, 32      # position, tex_coord, normal, tangent (vertex.rs:34-44)
+        init = np.full((m.n_verts * n_inst, stride), 0xA5, np.uint8)
+    else:
+        stride, op, on, ot = 16, 4, -1, -1
+        init = np.full((m.n_verts * n_inst, stride), 0x3C, np.uint8)
+    raw = run_ex(ctx, 62, m, pal, n_inst, weights, (stride, op, on, ot), init)
+    touched = np.zeros(stride, bool)
+    for off, size, key in ((op, 12, "pos"), (on, 12, "normal"), (ot, 16, "tangent")):
+        if off < 0:
+            continue
+        got = np.ascontiguousarray(raw[:, off:off + size]).view(np.float32)
+        assert np.array_equal(got.view(np.uint32), ref[key].view(np.uint32)), (layout, key)
+        touched[off:off + size] = True
+    assert np.array_equal(raw[:, ~touched], init[:, ~touched]), "bytes outside the written attributes changed"
+    ctx.mesh_free(62)
+
+
+def test_skin_ex_argument_errors(ctx):
+    from fyrox_amd import _native
+    m = synth.make_mesh(300, 8, 5)
+    upload(ctx, 63, m)
+    pal = ctx.to_device(synth.make_palette(8, 5))
+    out = ctx.malloc(300 * 68)
+    cases = [dict(d_out_vertices=out.ptr, out_stride=70, out_off_pos=0), dict(d_out_vertices=out.ptr, out_stride=68, out_off_pos=2),
+             dict(d_out_vertices=out.ptr, out_stride=68, out_off_pos=60),
+             dict(d_out_vertices=out.ptr, out_stride=68, out_off_pos=0, d_out_pos=out.ptr),
+             dict(d_out_pos=out.ptr, n_blend_shapes=2, d_blend_shape_weights=out.ptr)]
+    codes = []
+    for kw in cases:
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            ctx.lbs_skin_ex(63, pal.ptr, 8, 1, **kw)
+        codes.append(e.value.code)
+    assert codes == [_native.FYX_ERR_UNSUPPORTED, _native.FYX_ERR_UNSUPPORTED, _native.FYX_ERR_INVALID_ARG,
+                     _native.FYX_ERR_INVALID_ARG, _native.FYX_ERR_INVALID_ARG]
+    with pytest.raises(fyrox_amd.FyxError) as e:   # more shapes than the shader's weight array holds
+        ctx.mesh_set_blend_shapes(63, np.zeros((129, 300, 9), np.uint16), 129, 300)
+    assert e.value.code == _native.FYX_ERR_UNSUPPORTED
+    pal.free(); out.free()
+    ctx.mesh_free(63)

@@ -138,3 +138,30 @@ def test_synth_inputs_are_deterministic_and_well_formed():
     r = synth.make_mesh(1000, 64, synth.SEED_BASE + 2, coherent=False)
     assert all(len(set(row)) == 4 for row in r.indices[:100].tolist())  # 4 distinct bones
     assert synth.splitmix64(0, 3).tolist() == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+# ---- blend shapes (standard.shader:167-173; parity unpinned: no reference test covers the shader) ----------
+
+def test_half_decode_matches_ieee_for_every_bit_pattern(orc):
+    bits = np.arange(65536, dtype=np.uint16)
+    ref = bits.view(np.float16).astype(np.float32)
+    got = orc.half_to_float(bits)
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got[~nan].view(np.uint32), ref[~nan].view(np.uint32))
+
+
+def test_blend_shapes_accumulate_in_shape_order_unfused(orc):
+    from fyrox_amd import synth
+    m = synth.make_mesh(257, 4, 9)
+    storage, plane, w = synth.make_blend_shapes(257, 3, 9)
+    p, n, t = orc.apply_blend_shapes(m.pos, m.normal, m.tangent, storage, plane, w)
+    off = storage.view(np.float16).astype(np.float32)           # [shape, plane, 9]
+    ep, en, et = m.pos.copy(), m.normal.copy(), m.tangent.copy()
+    for s in range(3):
+        ep = ep + off[s, :257, 0:3] * w[s]
+        en = en + off[s, :257, 3:6] * w[s]
+        et[:, :3] = et[:, :3] + off[s, :257, 6:9] * w[s]
+    assert np.array_equal(p, ep) and np.array_equal(n, en) and np.array_equal(t, et)
+    assert np.array_equal(t[:, 3], m.tangent[:, 3])            # tangent.w (bitangent sign) is not morphed
+    assert plane >= 257 and plane == min(257, 512) * -(-257 // min(257, 512))
