@@ -94,6 +94,7 @@ using namespace fyx;
 void free_mesh(Mesh& m) {
     if (m.block) (void)hipFree(m.block);
     if (m.shapes) (void)hipFree(m.shapes);
+    if (m.aos) (void)hipFree(m.aos);
     m = Mesh();
 }
 
@@ -359,15 +360,21 @@ int fyx_mesh_upload(fyx_ctx* c, uint64_t mesh_id, const uint8_t* aos, uint32_t n
     int rc = alloc_mesh(c, m, n_verts, off_normal >= 0, off_tangent >= 0);
     if (rc) return rc;
     if (n_verts) {
+        // the interleaved bytes stay resident (padded by a 64-vertex unit so whole-span loads of a ragged tail
+        // stay inside the allocation): fyx_lbs_skin_ex's vertex-buffer output path reads them directly
         const size_t bytes = (size_t)n_verts * stride;
-        rc = ensure_scratch(c, bytes);
-        if (rc) { free_mesh(m); return rc; }
-        hipError_t e = hipMemcpyAsync(c->scratch, aos, bytes, hipMemcpyHostToDevice, c->stream);
+        const size_t padded = (align_up((size_t)n_verts, 64) + 64) * stride;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&m.aos), padded);
+        if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "hipMalloc(vertex buffer)"); }
+        e = hipMemsetAsync(m.aos + bytes, 0, padded - bytes, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(m.aos, aos, bytes, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess)
-            e = fyx::launch_deinterleave(static_cast<const uint8_t*>(c->scratch), n_verts, stride,
+            e = fyx::launch_deinterleave(m.aos, n_verts, stride,
                                          off_pos, off_normal, off_tangent, off_weights, off_indices,
                                          m.pos, m.nrm, m.tan, m.wgt, m.idx, c->stream);
         if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "mesh upload"); }
+        m.stride = stride;
+        m.off_pos = off_pos; m.off_nrm = off_normal; m.off_tan = off_tangent; m.off_wgt = off_weights; m.off_idx = off_indices;
     }
     return finish_upload(c, mesh_id, m);
     FYX_GUARD_END(c)
@@ -497,10 +504,27 @@ int fyx_lbs_skin_ex(fyx_ctx* c, uint64_t mesh_id, const fyx_skin_desc* d) {
     fyx::LbsExArgs x;
     memset(&x, 0, sizeof x);
     x.a = make_args(*m, d->d_palette, d->n_bones, d->n_instances, d->d_out_pos, d->d_out_normal, d->d_out_tangent);
-    if (d->d_out_vertices) {
+    bool whole_spans = false;
+    if (d->d_out_vertices && d->out_stride == 0) {
+        // the mesh's own layout: vertex buffer in, vertex buffer out
         if (d->d_out_pos || d->d_out_normal || d->d_out_tangent)
             return fail(c, FYX_ERR_INVALID_ARG, "give either the interleaved output or the SoA outputs");
-        if (d->out_stride == 0 || (d->out_stride & 3u)) return fail(c, FYX_ERR_UNSUPPORTED, "out_stride %u is not a multiple of 4", d->out_stride);
+        if (!m->aos && m->n_verts)
+            return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "out_stride 0 (the mesh's own vertex layout) needs a mesh uploaded with fyx_mesh_upload");
+        if ((m->stride & 3u) || m->stride > 160 || ((m->off_pos | m->off_wgt | m->off_idx) & 3) ||
+            (m->off_nrm >= 0 && (m->off_nrm & 3)) || (m->off_tan >= 0 && (m->off_tan & 3)))
+            return fail(c, FYX_ERR_UNSUPPORTED, "vertex layout (stride %u) must be 4-byte aligned and at most 160 bytes", m->stride);
+        if (reinterpret_cast<uintptr_t>(d->d_out_vertices) & 3u) return fail(c, FYX_ERR_UNSUPPORTED, "output buffer is not 4-byte aligned");
+        whole_spans = true;
+        x.out_aos = d->d_out_vertices;
+        x.out_stride = m->stride;
+        x.off_pos = m->off_pos; x.off_nrm = m->off_nrm; x.off_tan = m->off_tan;
+        x.in_aos = m->aos;
+        x.in_off_wgt = m->off_wgt; x.in_off_idx = m->off_idx;
+    } else if (d->d_out_vertices) {
+        if (d->d_out_pos || d->d_out_normal || d->d_out_tangent)
+            return fail(c, FYX_ERR_INVALID_ARG, "give either the interleaved output or the SoA outputs");
+        if ((d->out_stride & 3u)) return fail(c, FYX_ERR_UNSUPPORTED, "out_stride %u is not a multiple of 4", d->out_stride);
         struct { int off; uint32_t size; const char* name; bool have; } f[] = {
             {d->out_off_pos, 12, "Position", true}, {d->out_off_normal, 12, "Normal", m->nrm != nullptr},
             {d->out_off_tangent, 16, "Tangent", m->tan != nullptr}};
@@ -530,7 +554,9 @@ int fyx_lbs_skin_ex(fyx_ctx* c, uint64_t mesh_id, const fyx_skin_desc* d) {
     }
     hipStream_t st;
     if (int sr = acquire_launch_stream(c, &st)) return sr;
-    if (!x.out_aos && !x.n_shapes) {
+    if (whole_spans) {
+        FYX_HIP(c, fyx::launch_lbs_aos(x, c->lbs, st));
+    } else if (!x.out_aos && !x.n_shapes) {
         FYX_HIP(c, fyx::launch_lbs(x.a, c->lbs, st));   // nothing extended asked for: the plain kernel
     } else {
         FYX_HIP(c, fyx::launch_lbs_ex(x, c->lbs, st));

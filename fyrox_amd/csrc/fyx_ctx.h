@@ -24,6 +24,11 @@ struct Mesh {
     // BlendShapesContainer offsets, re-tiled (own allocation; replaced by fyx_mesh_set_blend_shapes)
     uint16_t* shapes = nullptr;
     uint32_t n_shapes = 0;
+    // the interleaved VertexBuffer bytes as uploaded by fyx_mesh_upload (padded by one 64-vertex unit), kept for
+    // the vertex-buffer-in / vertex-buffer-out skinning path; null after fyx_mesh_upload_soa
+    unsigned char* aos = nullptr;
+    uint32_t stride = 0;
+    int off_pos = -1, off_nrm = -1, off_tan = -1, off_wgt = -1, off_idx = -1;
 };
 struct AnimStore;  // anim_api.hip: tracks data, rigs, animators, bone lists
 void anim_store_destroy(AnimStore*);

@@ -46,8 +46,14 @@ struct LbsExArgs {
     unsigned char* out_aos;      // interleaved output [n_instances][n_verts][out_stride], or null
     uint32_t out_stride;
     int off_pos, off_nrm, off_tan;   // byte offsets inside a vertex, -1 = do not write
+    // vertex-buffer-in / vertex-buffer-out launch (launch_lbs_aos): the mesh's own interleaved bytes, same
+    // stride and offsets as the output
+    const unsigned char* in_aos;
+    int in_off_wgt, in_off_idx;
 };
 hipError_t launch_lbs_ex(const LbsExArgs& x, const LbsTuning& t, hipStream_t stream);
+// whole-span variant: out = in with position / normal / tangent.xyz replaced; stride <= 160, multiple of 4
+hipError_t launch_lbs_aos(const LbsExArgs& x, const LbsTuning& t, hipStream_t stream);
 // engine RGB16F volume -> device tile layout (see lbs_kernels.hip)
 hipError_t launch_retile_blend_shapes(const uint16_t* d_src, uint32_t n_verts, uint32_t plane_vertices,
                                       uint32_t n_shapes, uint16_t* d_dst, hipStream_t stream);

@@ -636,6 +636,191 @@ hipError_t launch_lbs_ex(const LbsExArgs& x, const LbsTuning& t, hipStream_t s) 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Vertex-buffer-in, vertex-buffer-out skinning (the engine's native interleaved layout on both sides).
+//
+// Scattered 12/16-byte stores at a 68-byte stride only fill parts of every 128-byte line and run at ~1.3 TB/s,
+// so this kernel moves whole spans instead: a wave's unit of 64 vertices is ONE contiguous 64*stride-byte span
+// of the VertexBuffer (4352 B for AnimatedVertex).  The wave
+//   1. loads the span with dense 16-byte lane accesses (the NEXT unit's span is already in registers while the
+//      current one is processed) and parks it in its private LDS slab,
+//   2. every lane reads the fields of its own vertex from LDS (stride/4 is odd for the engine's layouts, so the
+//      64 lanes hit different banks), applies blend-shape offsets, skins, and writes position / normal /
+//      tangent.xyz back in place,
+//   3. streams the slab out again with dense 16-byte stores.
+// HBM traffic is 2 * stride bytes per vertex (136 B for AnimatedVertex: texture coordinates, bone weights and
+// indices pass through, so the output is a complete vertex buffer for the renderer's geometry cache,
+// renderer/cache/geometry.rs:84-93).  No barrier besides the palette staging: a slab belongs to one wave and LDS
+// operations of a wave complete in order.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kAosMaxF4PerLane = 10;   // stride <= 160 bytes
+constexpr int kAosBlock = 256;
+
+// PL = 16-byte accesses per lane and span = ceil(stride / 16): a compile-time bound so that only the registers a
+// layout needs are held for the span in flight (5 for the 68-byte AnimatedVertex)
+template <bool EXACT, bool SHAPES, uint32_t PL>
+__global__ __launch_bounds__(kAosBlock) void lbs_skin_aos(LbsExArgs x, uint32_t units_per_inst, uint32_t total_units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LbsArgs& a = x.a;
+    f32x4* rows = reinterpret_cast<f32x4*>(smem);
+    f32x4* row3 = rows + 3 * a.n_bones;
+    uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);
+    constexpr uint32_t WPB = kAosBlock / 64;
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t stride = x.out_stride;                     // == input stride
+    const uint32_t span_f4 = stride * 4;                      // 64 * stride / 16
+    constexpr uint32_t per_lane = PL;
+    unsigned char* slab = smem + (size_t)a.n_bones * 64 + 64 + (size_t)wave * 64 * stride;
+    f32x4* slab4 = reinterpret_cast<f32x4*>(slab);
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    if (u_begin >= u_end) return;
+    const uint32_t inst_first = u_begin / units_per_inst, inst_last = (u_end - 1) / units_per_inst;
+    const f32x4* in4 = reinterpret_cast<const f32x4*>(x.in_aos);
+
+    for (uint32_t inst = inst_first; inst <= inst_last; ++inst) {
+        const uint32_t inst_u0 = inst * units_per_inst;
+        const uint32_t seg_b = (u_begin > inst_u0 ? u_begin : inst_u0) - inst_u0;
+        const uint32_t seg_e = (u_end < inst_u0 + units_per_inst ? u_end : inst_u0 + units_per_inst) - inst_u0;
+        const PaletteRegs pr = palette_fetch(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, tid);
+        uint32_t u = seg_b + wave;
+        f32x4 cur[PL];
+#pragma unroll
+        for (uint32_t k = 0; k < PL; ++k) {
+            const uint32_t i = lane + 64 * k;
+            // the input buffer is padded by one unit, so a ragged last span may be read in full
+            if (k < per_lane && u < seg_e && i < span_f4) cur[k] = __builtin_nontemporal_load(in4 + (size_t)u * span_f4 + i);
+        }
+        if (inst != inst_first) __syncthreads();
+        const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
+        const bool wave_pj = __any(pj) != 0;
+        if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
+        __syncthreads();
+        bool projective = false;
+#pragma unroll
+        for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
+        const float* sw = SHAPES ? x.shape_w + (size_t)inst * x.n_shapes : nullptr;
+
+        while (u < seg_e) {  // wave-uniform
+#pragma unroll
+            for (uint32_t k = 0; k < PL; ++k) {
+                const uint32_t i = lane + 64 * k;
+                if (k < per_lane && i < span_f4) slab4[i] = cur[k];
+            }
+            const uint32_t un = u + WPB;
+#pragma unroll
+            for (uint32_t k = 0; k < PL; ++k) {
+                const uint32_t i = lane + 64 * k;
+                if (k < per_lane && un < seg_e && i < span_f4) cur[k] = __builtin_nontemporal_load(in4 + (size_t)un * span_f4 + i);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t v = u * 64 + lane;
+            unsigned char* rec = slab + (size_t)lane * stride;
+            float* pp = reinterpret_cast<float*>(rec + x.off_pos);
+            float px = pp[0], py = pp[1], pz = pp[2];
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            float* np_ = x.off_nrm >= 0 ? reinterpret_cast<float*>(rec + x.off_nrm) : nullptr;
+            float* tp = x.off_tan >= 0 ? reinterpret_cast<float*>(rec + x.off_tan) : nullptr;
+            if (np_) { nx = np_[0]; ny = np_[1]; nz = np_[2]; }
+            if (tp) { t.x = tp[0]; t.y = tp[1]; t.z = tp[2]; }
+            const float* wp = reinterpret_cast<const float*>(rec + x.in_off_wgt);
+            const f32x4 w = {wp[0], wp[1], wp[2], wp[3]};
+            const uint32_t id = *reinterpret_cast<const uint32_t*>(rec + x.in_off_idx);
+            if constexpr (SHAPES) {
+                const uint16_t* col = x.shapes + ((size_t)u * 9) * 64 + lane;
+                const size_t shape_stride = (size_t)x.tiles_per_shape * 9 * 64;
+#pragma unroll 2
+                for (uint32_t sidx = 0; sidx < x.n_shapes; ++sidx) {
+                    const uint16_t* c = col + (size_t)sidx * shape_stride;
+                    const float ws = sw[sidx];
+                    uint16_t h[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) h[k] = __builtin_nontemporal_load(c + k * 64);
+                    if constexpr (EXACT) {
+                        px = px + h2f(h[0]) * ws; py = py + h2f(h[1]) * ws; pz = pz + h2f(h[2]) * ws;
+                        nx = nx + h2f(h[3]) * ws; ny = ny + h2f(h[4]) * ws; nz = nz + h2f(h[5]) * ws;
+                        t.x = t.x + h2f(h[6]) * ws; t.y = t.y + h2f(h[7]) * ws; t.z = t.z + h2f(h[8]) * ws;
+                    } else {
+                        px = __builtin_fmaf(h2f(h[0]), ws, px); py = __builtin_fmaf(h2f(h[1]), ws, py);
+                        pz = __builtin_fmaf(h2f(h[2]), ws, pz); nx = __builtin_fmaf(h2f(h[3]), ws, nx);
+                        ny = __builtin_fmaf(h2f(h[4]), ws, ny); nz = __builtin_fmaf(h2f(h[5]), ws, nz);
+                        t.x = __builtin_fmaf(h2f(h[6]), ws, t.x); t.y = __builtin_fmaf(h2f(h[7]), ws, t.y);
+                        t.z = __builtin_fmaf(h2f(h[8]), ws, t.z);
+                    }
+                }
+            }
+            const Skinned o = skin_vertex<EXACT, 7>(rows, row3, projective, id, w, px, py, pz, nx, ny, nz, t.x, t.y, t.z);
+            pp[0] = o.px; pp[1] = o.py; pp[2] = o.pz;
+            if (np_) { np_[0] = o.nx; np_[1] = o.ny; np_[2] = o.nz; }
+            if (tp) { tp[0] = o.tx; tp[1] = o.ty; tp[2] = o.tz; }
+            __builtin_amdgcn_wave_barrier();
+            // stream the slab out; only whole vertices of a ragged last unit
+            const uint32_t n_valid = (a.n_verts - u * 64) < 64u ? (a.n_verts - u * 64) : 64u;
+            unsigned char* out_span = x.out_aos + ((size_t)inst * a.n_verts + (size_t)u * 64) * stride;
+            if (n_valid == 64u && ((reinterpret_cast<uintptr_t>(out_span) & 15u) == 0)) {
+                f32x4* o4 = reinterpret_cast<f32x4*>(out_span);
+#pragma unroll
+                for (uint32_t k = 0; k < PL; ++k) {
+                    const uint32_t i = lane + 64 * k;
+                    if (k < per_lane && i < span_f4) __builtin_nontemporal_store(slab4[i], o4 + i);
+                }
+            } else {
+                const uint32_t n_dw = n_valid * (stride / 4);
+                const uint32_t* s32 = reinterpret_cast<const uint32_t*>(slab);
+                uint32_t* o32 = reinterpret_cast<uint32_t*>(out_span);
+                for (uint32_t i = lane; i < n_dw; i += 64) o32[i] = s32[i];
+            }
+            __builtin_amdgcn_wave_barrier();   // the slab is rewritten at the top of the loop
+            u = un;
+            (void)v;
+        }
+    }
+}
+
+template <bool EXACT, bool SHAPES, uint32_t PL>
+static hipError_t launch_aos_pl(const LbsExArgs& x, hipStream_t s) {
+    const uint32_t upi = (x.a.n_verts + 63) / 64;
+    const uint64_t total64 = (uint64_t)upi * x.a.n_instances;
+    if (total64 == 0) return hipSuccess;
+    if (total64 > 0xffffffffull) return hipErrorInvalidValue;
+    const uint32_t total = (uint32_t)total64;
+    constexpr uint32_t WPB = kAosBlock / 64;
+    const size_t lds = (size_t)x.a.n_bones * 64 + 64 + (size_t)WPB * 64 * x.out_stride;
+    const void* fn = reinterpret_cast<const void*>(&lbs_skin_aos<EXACT, SHAPES, PL>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // persistent grid = exactly what is resident (registers and LDS decide)
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kAosBlock, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    uint32_t grid = (uint32_t)kCUs * (uint32_t)per_cu;
+    const uint32_t max_useful = (total + WPB - 1) / WPB;
+    if (grid > max_useful) grid = max_useful;
+    hipLaunchKernelGGL((lbs_skin_aos<EXACT, SHAPES, PL>), dim3(grid), dim3(kAosBlock), lds, s, x, upi, total);
+    return hipGetLastError();
+}
+
+template <bool EXACT, bool SHAPES>
+static hipError_t launch_aos_one(const LbsExArgs& x, hipStream_t s) {
+    const uint32_t pl = (x.out_stride * 4 + 63) / 64;
+    if (pl <= 4) return launch_aos_pl<EXACT, SHAPES, 4>(x, s);
+    if (pl <= 5) return launch_aos_pl<EXACT, SHAPES, 5>(x, s);
+    if (pl <= 8) return launch_aos_pl<EXACT, SHAPES, 8>(x, s);
+    return launch_aos_pl<EXACT, SHAPES, kAosMaxF4PerLane>(x, s);
+}
+
+hipError_t launch_lbs_aos(const LbsExArgs& x, const LbsTuning& t, hipStream_t s) {
+    if (x.out_stride == 0 || (x.out_stride & 3u) || x.out_stride * 4 > 64 * kAosMaxF4PerLane) return hipErrorInvalidValue;
+    const bool shapes = x.n_shapes > 0;
+    if (t.exact) return shapes ? launch_aos_one<true, true>(x, s) : launch_aos_one<true, false>(x, s);
+    return shapes ? launch_aos_one<false, true>(x, s) : launch_aos_one<false, false>(x, s);
+}
+
 // RGB16F volume (engine layout: [shape][vertex][texel: position, normal, tangent][rgb], 18 B per vertex,
 // plane_vertices = width * height texel triples per shape) -> [shape][tile][9][64] f16.
 __global__ __launch_bounds__(256) void retile_blend_shapes_kernel(const uint16_t* __restrict__ src, uint32_t n_verts,

@@ -155,12 +155,17 @@ int fyx_mesh_set_blend_shapes(fyx_ctx* ctx, uint64_t mesh_id, uint32_t n_shapes,
  *     (BlendShape::weight / 100, scene/mesh/mod.rs:794-798); n_blend_shapes must be 0 (skip) or the
  *     mesh's shape count.
  *   Outputs: either the SoA streams of fyx_lbs_skin_device, or ONE interleaved vertex buffer
- *     d_out_vertices [n_instances][n_verts][out_stride]: position (12 B), normal (12 B) and tangent
- *     (xyzw, 16 B, w passed through) are written at their byte offsets (< 0: not written; stride
- *     and offsets multiples of 4, as every VertexAttributeDataType::F32 layout is); all other bytes
- *     of a vertex -- tex coords, bone data -- are left untouched, so a buffer initialised once with
- *     the surface's own VertexBuffer bytes stays a valid render-ready vertex buffer
- *     (scene/mesh/buffer.rs:404-415; consumer: renderer/cache/geometry.rs:84-93). */
+ *     d_out_vertices [n_instances][n_verts][stride], in one of two forms:
+ *     - out_stride == 0: the mesh's OWN vertex layout (the one given to fyx_mesh_upload, which
+ *       keeps the VertexBuffer bytes resident).  Every output vertex is the input vertex with
+ *       position / normal / tangent.xyz replaced -- texture coordinates, tangent.w, bone weights
+ *       and indices pass through -- i.e. a complete render-ready vertex buffer
+ *       (scene/mesh/buffer.rs:404-415; consumer: renderer/cache/geometry.rs:84-93).  This form
+ *       moves whole 64-vertex spans (2 * stride bytes of HBM traffic per vertex) and is the fast
+ *       one; stride <= 160.  out_off_* are ignored.
+ *     - out_stride > 0: any other layout.  position (12 B), normal (12 B) and tangent (xyzw, 16 B,
+ *       w passed through) are scattered to their byte offsets (< 0: not written; stride and
+ *       offsets multiples of 4); all other bytes of the buffer are left untouched. */
 typedef struct fyx_skin_desc {
     const float* d_palette;
     uint32_t n_bones;

@@ -444,6 +444,64 @@ def test_blend_shapes_fused_mode_within_tolerance(ctx, orc):
     ctx.mesh_free(61)
 
 
+@pytest.mark.parametrize("n_verts,n_inst,shapes", [(9_001, 2, 0), (64, 1, 2), (63, 3, 0), (50_000, 1, 3), (1, 1, 1), (4096, 2, 0)])
+@pytest.mark.parametrize("exact", [1, 0])
+def test_vertex_buffer_in_vertex_buffer_out(ctx, orc, n_verts, n_inst, shapes, exact):
+    """out_stride == 0: the mesh's own AnimatedVertex layout (vertex.rs:139-155).  Every output vertex is the input
+    vertex with position / normal / tangent.xyz replaced; uv, tangent.w, bone weights and indices pass through."""
+    L = synth.ANIMATED_VERTEX
+    m = synth.make_mesh(n_verts, 48, synth.SEED_BASE + 23, coherent=False)
+    pal = synth.make_palette(48, synth.SEED_BASE + 23, n_instances=n_inst)
+    upload(ctx, 64, m, aos=True)
+    weights = None
+    if shapes:
+        storage, plane, w = synth.make_blend_shapes(n_verts, shapes, synth.SEED_BASE + 23)
+        ctx.mesh_set_blend_shapes(64, storage, shapes, plane)
+        weights = np.stack([w * np.float32(1.0 + 0.25 * i) for i in range(n_inst)])
+        ref = oracle_skin_shapes(orc, m, pal, storage, plane, weights, n_inst)
+    else:
+        ref = oracle_skin(orc, m, pal, n_inst)
+    src = m.to_animated_vertex_aos().reshape(n_verts, L["stride"])
+    ctx.set_option("lbs.exact", exact)
+    guard = 256   # bytes after the last vertex must stay untouched (ragged last span)
+    init = np.full(n_verts * n_inst * L["stride"] + guard, 0xEE, np.uint8)
+    d_pal, buf = ctx.to_device(pal), ctx.to_device(init)
+    d_w = ctx.to_device(weights) if shapes else None
+    ctx.lbs_skin_ex(64, d_pal.ptr, 48, n_inst, d_blend_shape_weights=d_w.ptr if d_w else 0, n_blend_shapes=shapes,
+                    d_out_vertices=buf.ptr, out_stride=0)
+    ctx.sync()
+    raw = buf.download(np.uint8, init.size)
+    assert np.all(raw[-guard:] == 0xEE), "wrote past the last vertex"
+    raw = raw[:-guard].reshape(n_verts * n_inst, L["stride"])
+    expect = np.tile(src, (n_inst, 1))
+    skinned = np.zeros(L["stride"], bool)
+    for off, size, key in ((L["off_pos"], 12, "pos"), (L["off_normal"], 12, "normal"), (L["off_tangent"], 12, "tangent")):
+        got = np.ascontiguousarray(raw[:, off:off + size]).view(np.float32)
+        want = ref[key][:, :3]
+        if exact:
+            assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32)), key
+        else:
+            assert rel_err(got, want) <= REL_TOL, key
+        skinned[off:off + size] = True
+    assert np.array_equal(raw[:, ~skinned], expect[:, ~skinned]), "pass-through attributes changed"
+    for b in (d_pal, buf, d_w):
+        if b:
+            b.free()
+    ctx.mesh_free(64)
+
+
+def test_vertex_buffer_output_needs_an_interleaved_upload(ctx):
+    from fyrox_amd import _native
+    m = synth.make_mesh(100, 8, 5)
+    upload(ctx, 65, m, aos=False)
+    pal, out = ctx.to_device(synth.make_palette(8, 5)), ctx.malloc(100 * 68)
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        ctx.lbs_skin_ex(65, pal.ptr, 8, 1, d_out_vertices=out.ptr, out_stride=0)
+    assert e.value.code == _native.FYX_ERR_MISSING_ATTRIBUTE
+    pal.free(); out.free()
+    ctx.mesh_free(65)
+
+
 @pytest.mark.parametrize("layout", ["animated_vertex", "static_vertex", "pos_only"])
 @pytest.mark.parametrize("shapes", [0, 3])
 def test_interleaved_output_is_a_render_ready_vertex_buffer(ctx, orc, layout, shapes):

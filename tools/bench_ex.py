@@ -57,6 +57,15 @@ def main():
     res = {}
     res["plain_soa"] = run("plain", lambda s: ctx.lbs_skin_device(100 + s, pal.ptr, args.bones, 1, sets[s]["pos"].ptr,
                                                                   sets[s]["nrm"].ptr, sets[s]["tan"].ptr), 100)
+    for s in range(args.sets):   # meshes 200+: uploaded interleaved, so the library keeps the vertex buffer resident
+        ctx.mesh_upload(200 + s, aos_init, nv, L["stride"], off_pos=L["off_pos"], off_normal=L["off_normal"],
+                        off_tangent=L["off_tangent"], off_weights=L["off_weights"], off_indices=L["off_indices"])
+        ctx.mesh_set_blend_shapes(200 + s, storage, args.shapes, plane)
+    res["vb_in_vb_out_68B"] = run("vb", lambda s: ctx.lbs_skin_ex(200 + s, pal.ptr, args.bones, 1,
+                                                                 d_out_vertices=sets[s]["aos68"].ptr, out_stride=0), 136)
+    res[f"vb_in_vb_out_68B_{args.shapes}_shapes"] = run("vb_shapes", lambda s: ctx.lbs_skin_ex(
+        200 + s, pal.ptr, args.bones, 1, d_blend_shape_weights=d_w.ptr, n_blend_shapes=args.shapes,
+        d_out_vertices=sets[s]["aos68"].ptr, out_stride=0), 136 + 18 * args.shapes)
     res["ex_aos_animated_vertex_68B"] = run("aos68", lambda s: ctx.lbs_skin_ex(
         100 + s, pal.ptr, args.bones, 1, d_out_vertices=sets[s]["aos68"].ptr, out_stride=L["stride"],
         out_off_pos=L["off_pos"], out_off_normal=L["off_normal"], out_off_tangent=L["off_tangent"]), 100)
