@@ -167,7 +167,115 @@ def layered(n_bones=40, seed=synth.SEED_BASE + 10) -> Scenario:
     return Scenario("layered", rig, [td0, td1, td2, td3], anims, m, script, n_frames=40, has_euler=False)
 
 
-ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered]
+# ---- importer-shaped clips: tracks built the way the engine's asset importers build them -----------------
+
+def _fbx_tracks(n_bones: int, seed: int, fps=24.0, n_keys=13):
+    """fyrox-impl/src/resource/fbx/mod.rs:706-800 (convert_model -> fill_track): per model three tracks in the order
+    translation (Track::new_position, Vector3), rotation (Track::new_rotation = UnitQuaternionEuler with THREE
+    curves of Euler angles, degrees converted with f32::to_radians), scale; every FBX key becomes a Linear key; a
+    component with no FBX curve (or an empty one) gets ONE Constant key at t=0 holding the model's default; a
+    model without the curve node gets such keys on all three components."""
+    f32 = np.float32
+    to_rad = f32(np.pi) / f32(180.0)          # f32::to_radians: self * (PI / 180.0)
+    tracks, target = [], []
+    t = (np.arange(n_keys, dtype=np.float64) / fps).astype(f32)
+    for b in range(n_bones):
+        tag = f"fbx{b}"
+        deflt = {"T": (synth.uniform(seed, tag + ".dT", 3) - 0.5).astype(f32),
+                 "R": ((synth.uniform(seed, tag + ".dR", 3) - 0.5) * 90.0).astype(f32),
+                 "S": (1.0 + (synth.uniform(seed, tag + ".dS", 3) - 0.5) * 0.2).astype(f32)}
+        vals = {"T": (synth.uniform(seed, tag + ".T", n_keys * 3).reshape(n_keys, 3) - 0.5).astype(f32),
+                "R": np.cumsum((synth.uniform(seed, tag + ".R", n_keys * 3).reshape(n_keys, 3) - 0.5) * 40.0, axis=0).astype(f32),
+                "S": (1.0 + (synth.uniform(seed, tag + ".S", n_keys * 3).reshape(n_keys, 3) - 0.5) * 0.3).astype(f32)}
+        for name, binding, kind in (("T", A.BIND_POSITION, A.KIND_VEC3), ("R", A.BIND_ROTATION, A.KIND_QUAT_EULER),
+                                    ("S", A.BIND_SCALE, A.KIND_VEC3)):
+            conv = (lambda v: f32(v) * to_rad) if name == "R" else (lambda v: f32(v))
+            has_node = not (b % 5 == 4 and name == "S")          # some models have no Lcl Scaling curve node
+            curves = []
+            for c in range(3):
+                missing = not has_node or (b % 3 == 1 and c == 1 and name == "T") or (b % 4 == 2 and c == 2 and name == "R")
+                if missing:
+                    # both fill_track's default key (:713-721) and add_vec3_key (:787) store the model's value as-is:
+                    # a default ROTATION stays in degrees -- reproduced, no conversion
+                    curves.append(A.Curve([A.CurveKey(0.0, float(deflt[name][c]), A.KEY_CONSTANT)]))
+                else:
+                    curves.append(A.Curve([A.CurveKey(float(t[k]), float(conv(vals[name][k, c])), A.KEY_LINEAR)
+                                           for k in range(n_keys)]))
+            tracks.append(A.Track(binding, kind, curves))
+            target.append(b)
+    td = A.AnimationTracksData(tracks)
+    length = max(max((c.keys[-1].location if c.keys else 0.0) for c in tr.curves) for tr in tracks)  # fit_length_to_content
+    return td, np.asarray(target, np.int32), float(length)
+
+
+def fbx_like(n_bones=20, seed=synth.SEED_BASE + 12) -> Scenario:
+    """An FBX-imported clip under an AnimationPlayer.  Euler rotation tracks: 1e-5 bar (sin/cos)."""
+    rig = synth.make_rig(n_bones, seed, exotic=True)     # FBX models carry pre/post rotations and pivots
+    td, tgt, length = _fbx_tracks(n_bones, seed)
+    anims = [AnimSpec(0, tgt, time_slice=(0.0, length), speed=1.0)]
+    return Scenario("fbx_like", rig, [td], anims, None, n_frames=50, dt=1.0 / 50.0, has_euler=True)
+
+
+def _gltf_tracks(n_bones: int, seed: int, clip: int):
+    """fyrox-impl/src/resource/gltf/animation.rs:402-670: one track per channel; translation / scale are Vector3,
+    rotation is UnitQuaternion with FOUR curves holding the sampler's xyzw as-is; LINEAR -> Linear keys, STEP ->
+    Constant keys, CUBICSPLINE -> Cubic keys {left_tangent: in-tangent, right_tangent: out-tangent}; channels of a
+    node can have different key times; nodes may lack some channels."""
+    f32 = np.float32
+    tracks, target = [], []
+    lo, hi = np.inf, 0.0
+    for b in range(n_bones):
+        for name, binding, kind, nc in (("translation", A.BIND_POSITION, A.KIND_VEC3, 3),
+                                        ("rotation", A.BIND_ROTATION, A.KIND_QUAT, 4), ("scale", A.BIND_SCALE, A.KIND_VEC3, 3)):
+            tag = f"gltf{clip}.{b}.{name}"
+            if (b + clip) % 6 == 5 and name == "scale":
+                continue                                            # no such channel for this node
+            nk = 5 + int(synth.uniform(seed, tag + ".nk", 1)[0] * 8)
+            times = np.cumsum(0.02 + synth.uniform(seed, tag + ".t", nk) * 0.12).astype(f32)
+            interp = (b + clip + {"translation": 0, "rotation": 1, "scale": 2}[name]) % 3   # LINEAR, STEP, CUBICSPLINE
+            if name == "rotation":
+                v = synth.normal(seed, tag + ".v", nk * 4).reshape(nk, 4)
+                v = np.cumsum(v * 0.2, axis=0) + synth.normal(seed, tag + ".v0", 4)
+                v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(f32)
+            elif name == "scale":
+                v = (1.0 + (synth.uniform(seed, tag + ".v", nk * 3).reshape(nk, 3) - 0.5) * 0.2).astype(f32)
+            else:
+                v = ((synth.uniform(seed, tag + ".v", nk * 3).reshape(nk, 3) - 0.5) * 0.8).astype(f32)
+            tin = (synth.normal(seed, tag + ".in", nk * nc).reshape(nk, nc) * 0.6).astype(f32)
+            tout = (synth.normal(seed, tag + ".out", nk * nc).reshape(nk, nc) * 0.6).astype(f32)
+            curves = []
+            for c in range(nc):
+                if interp == 2:
+                    keys = [A.CurveKey(float(times[k]), float(v[k, c]), A.KEY_CUBIC, float(tin[k, c]), float(tout[k, c]))
+                            for k in range(nk)]
+                else:
+                    keys = [A.CurveKey(float(times[k]), float(v[k, c]), A.KEY_LINEAR if interp == 0 else A.KEY_CONSTANT)
+                            for k in range(nk)]
+                curves.append(A.Curve(keys))
+            tracks.append(A.Track(binding, kind, curves))
+            target.append(b)
+            lo, hi = min(lo, float(times[0])), max(hi, float(times[-1]))
+    return A.AnimationTracksData(tracks), np.asarray(target, np.int32), (lo, hi)
+
+
+def gltf_like(n_bones=18, seed=synth.SEED_BASE + 13) -> Scenario:
+    """Two glTF-imported clips cross-faded by a machine (quaternion tracks only: bit-exact), every sampler
+    interpolation mode, ragged key times, missing channels."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(2):
+        td, tgt, (lo, hi) = _gltf_tracks(n_bones, seed, c)
+        tds.append(td)
+        anims.append(AnimSpec(c, tgt, time_slice=(lo, hi), speed=[1.0, -0.8][c]))   # set_time_slice(start..end), :227
+    layer = A.MachineLayer(nodes=[A.PlayAnimation(0), A.PlayAnimation(1),
+                                  A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, parameter=0)])],
+                           states=[A.State(2)])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_WEIGHT, 0.0)], layers=[layer])
+    script = {f: [(0, A.Parameter(A.PARAM_WEIGHT, float(np.float32(min(1.0, f / 30.0)))))] for f in range(0, 45)}
+    return Scenario("gltf_like", rig, tds, anims, m, script, n_frames=45, dt=1.0 / 45.0, has_euler=False)
+
+
+ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like]
 
 
 def with_root_motion_and_signals(make) -> Callable[[], Scenario]:
