@@ -15,7 +15,13 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "fyx_ctx.h"
@@ -134,6 +140,18 @@ struct Recipe {
 };
 struct RecipeItem { uint32_t recipe; float w; };
 
+// What planning a range of instances produces; one per planner thread, merged in instance order.
+struct PlanScratch {
+    std::vector<uint2> ops;
+    std::vector<uint4> rm_ops;
+    std::vector<uint32_t> prog_len, rm_prog_len;   // per instance of the range
+    std::vector<Recipe> recipes;
+    std::vector<RecipeItem> items;
+    std::vector<int32_t> node_recipe;
+    std::vector<uint8_t> seen;
+    int error = 0;
+};
+
 struct Animator {
     uint64_t rig_id = 0;
     Rig* rig = nullptr;
@@ -180,11 +198,8 @@ struct Animator {
     uint32_t dev_rm_anim_capacity = 0;
     float4* d_rm_slots = nullptr;
     uint32_t dev_rm_slots = 0;
-    // scratch of the planner
-    std::vector<Recipe> recipes;
-    std::vector<RecipeItem> items;
-    std::vector<int32_t> node_recipe;
-    std::vector<uint8_t> seen;
+    // scratch of the planner threads
+    std::vector<PlanScratch> scratch;
 };
 
 }  // namespace
@@ -281,6 +296,7 @@ bool has_ended(const AnimState& s) { return !s.looped && fabsf(s.time - s.end) <
 // ------------------------------------------------------------------------------------------
 struct Planner {
     Animator& A;
+    PlanScratch& S;
     uint32_t inst;
     float dt;
     uint32_t n_anims;
@@ -289,7 +305,7 @@ struct Planner {
     int error = 0;       // FYX_ERR_UNSUPPORTED when the fold nests too deep
     int depth = 0;
 
-    Planner(Animator& a, uint32_t i, float dt_) : A(a), inst(i), dt(dt_) {
+    Planner(Animator& a, PlanScratch& sc, uint32_t i, float dt_) : A(a), S(sc), inst(i), dt(dt_) {
         n_anims = (uint32_t)a.anims.size();
         as = a.anim_state.data() + (size_t)i * n_anims;
         ms = a.mstate.empty() ? nullptr : &a.mstate[i];
@@ -299,7 +315,7 @@ struct Planner {
         uint2 op;
         op.x = code | (arg << 8);
         memcpy(&op.y, &w, 4);
-        A.ops.push_back(op);
+        S.ops.push_back(op);
     }
 
     // Animation::tick (lib.rs:471-496): the pose is sampled at the CURRENT time, then time advances.
@@ -332,7 +348,7 @@ struct Planner {
         uint4 op;
         op.x = code; op.y = dst; op.z = src;
         memcpy(&op.w, &w, 4);
-        A.rm_ops.push_back(op);
+        S.rm_ops.push_back(op);
     }
     uint32_t cur_layer = 0;
     void layer_event(LayerState& LS, int32_t kind, int32_t a, int32_t b) {  // event.rs:79-83
@@ -346,16 +362,16 @@ struct Planner {
     uint32_t new_recipe_anim(uint32_t a) {
         Recipe r;
         r.anim = (int32_t)a;
-        A.recipes.push_back(r);
-        return (uint32_t)A.recipes.size() - 1;
+        S.recipes.push_back(r);
+        return (uint32_t)S.recipes.size() - 1;
     }
     uint32_t new_recipe_fold(const RecipeItem* it, uint32_t n) {
         Recipe r;
-        r.first = (uint32_t)A.items.size();
+        r.first = (uint32_t)S.items.size();
         r.count = n;
-        for (uint32_t i = 0; i < n; ++i) A.items.push_back(it[i]);
-        A.recipes.push_back(r);
-        return (uint32_t)A.recipes.size() - 1;
+        for (uint32_t i = 0; i < n; ++i) S.items.push_back(it[i]);
+        S.recipes.push_back(r);
+        return (uint32_t)S.recipes.size() - 1;
     }
 
     // transition.rs:141-173
@@ -393,7 +409,11 @@ struct Planner {
                 if (rm()) rm_emit(RM_SET_ANIM, node_slot(cur_layer, handle), n.animation, 0.f);
                 break;
             case NODE_BLEND: {  // blend.rs:136-164
-                std::vector<RecipeItem> its;
+                RecipeItem small[16];                      // no heap traffic for the usual fan-in
+                std::vector<RecipeItem> big;
+                RecipeItem* its = small;
+                if (n.inputs.size() > 16) { big.resize(n.inputs.size()); its = big.data(); }
+                uint32_t cnt = 0;
                 for (const BlendInput& in : n.inputs) {
                     float w;
                     if (in.weight_param < 0) {
@@ -404,11 +424,11 @@ struct Planner {
                     }
                     const int32_t src = eval_node(L, LS, in.source, node_recipe);
                     if (src >= 0) {
-                        its.push_back({(uint32_t)src, w});
+                        its[cnt++] = {(uint32_t)src, w};
                         if (rm()) rm_emit(RM_BLEND, node_slot(cur_layer, handle), node_slot(cur_layer, in.source), w);
                     }
                 }
-                out = (int32_t)new_recipe_fold(its.data(), (uint32_t)its.size());
+                out = (int32_t)new_recipe_fold(its, cnt);
                 break;
             }
             case NODE_BY_INDEX: {  // blend.rs:306-361
@@ -555,14 +575,14 @@ struct Planner {
 
     // acc.blend_with(<pose described by recipe r>, w)
     void emit_blend(uint32_t r, float w) {
-        const Recipe rc = A.recipes[r];
+        const Recipe rc = S.recipes[r];
         if (rc.anim >= 0) { emit(OP_BLEND_ANIM, (uint32_t)rc.anim, w); return; }
         if (rc.count == 0) return;  // blending with an empty pose changes nothing
         if (depth + 1 >= kMaxFoldDepth) { error = FYX_ERR_UNSUPPORTED; return; }
         emit(OP_PUSH, 0, 0.f);
         ++depth;
         for (uint32_t i = 0; i < rc.count; ++i) {
-            const RecipeItem it = A.items[rc.first + i];
+            const RecipeItem it = S.items[rc.first + i];
             emit_blend(it.recipe, it.w);
         }
         --depth;
@@ -572,7 +592,7 @@ struct Planner {
     void collect(const LayerDef& L, int32_t handle) {  // node/mod.rs:116-150
         if (handle < 0 || (size_t)handle >= L.nodes.size()) return;
         const PoseNodeDef& n = L.nodes[handle];
-        if (n.type == NODE_PLAY) { A.seen[n.animation] = 1; return; }
+        if (n.type == NODE_PLAY) { S.seen[n.animation] = 1; return; }
         for (const BlendInput& in : n.inputs) collect(L, in.source);
     }
 
@@ -596,8 +616,8 @@ struct Planner {
         LayerState& LS = ms->layers[li];
         cur_layer = li;
         if (LS.active_state >= 0 || LS.active_transition >= 0) {
-            A.node_recipe.assign(L.nodes.size(), -1);
-            int32_t* nr = A.node_recipe.data();
+            S.node_recipe.assign(L.nodes.size(), -1);
+            int32_t* nr = S.node_recipe.data();
             for (const StateDef& s : L.states) eval_node(L, LS, s.root, nr);  // state.update
 
             if (LS.active_transition < 0) {
@@ -661,7 +681,7 @@ struct Planner {
 
     // Machine::evaluate_pose (machine/mod.rs:344-382) + apply
     void plan_absm() {
-        std::fill(A.seen.begin(), A.seen.end(), 0);
+        std::fill(S.seen.begin(), S.seen.end(), 0);
         for (size_t li = 0; li < A.layers.size(); ++li) {
             const LayerDef& L = A.layers[li];
             const LayerState& LS = ms->layers[li];
@@ -674,9 +694,9 @@ struct Planner {
                 if (check[k] >= 0 && (size_t)check[k] < L.states.size()) collect(L, L.states[check[k]].root);
         }
         for (uint32_t a = 0; a < n_anims; ++a)
-            if (A.seen[a] && as[a].enabled) tick(a);
-        A.recipes.clear();
-        A.items.clear();
+            if (S.seen[a] && as[a].enabled) tick(a);
+        S.recipes.clear();
+        S.items.clear();
         for (size_t li = 0; li < A.layers.size(); ++li) {
             emit(OP_PUSH, 0, 0.f);
             depth = 1;
@@ -722,13 +742,72 @@ void ensure_machine_state(Animator& A) {
     sync_machine_state(A);
 }
 
+}  // namespace
+
+// A small persistent pool for planning a crowd: instances are independent (own animation states, own machine
+// state, own event queues), so a frame's planning splits into contiguous instance ranges.
+class PlanPool {
+public:
+    explicit PlanPool(unsigned n) {
+        for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this, i] { loop(i); });
+    }
+    ~PlanPool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    unsigned size() const { return (unsigned)workers_.size(); }
+    // runs fn(k) for k in 0..n_tasks; the caller does task 0 itself, workers 1.. (n_tasks - 1 <= size()).
+    // Workers sleep on a condition variable between frames (no spinning: measured, spinning workers starve the
+    // calling thread on hosts with a CPU quota); waking them costs tens of microseconds, which is why plan_frame
+    // only splits crowds whose planning takes much longer than that.
+    void run(unsigned n_tasks, const std::function<void(unsigned)>& fn) {
+        if (n_tasks <= 1) { if (n_tasks) fn(0); return; }
+        { std::lock_guard<std::mutex> g(m_); fn_ = &fn; tasks_ = n_tasks; pending_ = n_tasks - 1; ++gen_; }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void loop(unsigned idx) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (idx + 1 < tasks_) fn = fn_;
+            }
+            if (fn) {
+                (*fn)(idx + 1);
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)>* fn_ = nullptr;
+    unsigned tasks_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+void plan_pool_destroy(PlanPool* p) { delete p; }
+
+namespace {
+
 int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
     const uint32_t na = (uint32_t)A.anims.size();
     A.times.assign((size_t)A.n_instances * na, 0.f);
     A.ticked.assign((size_t)A.n_instances * na, 0);
     A.ops.clear();
     A.prog_off.assign((size_t)A.n_instances + 1, 0);
-    A.seen.assign(na ? na : 1, 0);
     if (mode == 1) ensure_machine_state(A);  // instances get their machine state lazily
     A.rm_ops.clear();
     A.rm_prog_off.assign((size_t)A.n_instances + 1, 0);
@@ -741,12 +820,48 @@ int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
         A.slices.resize((size_t)A.n_instances * na);
         for (size_t k = 0; k < A.slices.size(); ++k) A.slices[k] = make_float2(A.anim_state[k].start, A.anim_state[k].end);
     }
-    for (uint32_t i = 0; i < A.n_instances; ++i) {
-        A.prog_off[i] = (uint32_t)A.ops.size();
-        A.rm_prog_off[i] = (uint32_t)A.rm_ops.size();
-        Planner p(A, i, dt);
-        if (mode == 1) p.plan_absm(); else p.plan_player();
-        if (p.error) return fail(c, p.error, "pose nodes nest deeper than %d blend levels", kMaxFoldDepth - 2);
+    // Planning costs ~0.1 us per instance and waking the pool tens of microseconds: split only big crowds, one
+    // task per `anim.split` instances (default 2048), at most anim.threads of them
+    unsigned n_tasks = 1;
+    const uint32_t split = (uint32_t)std::max(c->plan_split, 1);
+    if (c->plan_threads > 1 && A.n_instances >= 2 * split) {
+        n_tasks = std::min<unsigned>((unsigned)c->plan_threads, A.n_instances / split);
+        if (!c->plan_pool || c->plan_pool->size() + 1 < n_tasks) {
+            delete c->plan_pool;
+            c->plan_pool = new PlanPool(n_tasks - 1);
+        }
+    }
+    if (A.scratch.size() < n_tasks) A.scratch.resize(n_tasks);
+    auto work = [&](unsigned k) {
+        PlanScratch& S = A.scratch[k];
+        const uint32_t i0 = (uint32_t)((uint64_t)A.n_instances * k / n_tasks);
+        const uint32_t i1 = (uint32_t)((uint64_t)A.n_instances * (k + 1) / n_tasks);
+        S.ops.clear(); S.rm_ops.clear(); S.prog_len.clear(); S.rm_prog_len.clear();
+        S.seen.assign(na ? na : 1, 0);
+        S.error = 0;
+        for (uint32_t i = i0; i < i1; ++i) {
+            const size_t o0 = S.ops.size(), r0 = S.rm_ops.size();
+            Planner p(A, S, i, dt);
+            if (mode == 1) p.plan_absm(); else p.plan_player();
+            if (p.error) S.error = p.error;
+            S.prog_len.push_back((uint32_t)(S.ops.size() - o0));
+            S.rm_prog_len.push_back((uint32_t)(S.rm_ops.size() - r0));
+        }
+    };
+    if (n_tasks > 1) c->plan_pool->run(n_tasks, work); else work(0);
+    uint32_t inst = 0;
+    for (unsigned k = 0; k < n_tasks; ++k) {  // merge in instance order
+        const PlanScratch& S = A.scratch[k];
+        if (S.error) return fail(c, S.error, "pose nodes nest deeper than %d blend levels", kMaxFoldDepth - 2);
+        uint32_t o = (uint32_t)A.ops.size(), r = (uint32_t)A.rm_ops.size();
+        for (size_t j = 0; j < S.prog_len.size(); ++j, ++inst) {
+            A.prog_off[inst] = o;
+            A.rm_prog_off[inst] = r;
+            o += S.prog_len[j];
+            r += S.rm_prog_len[j];
+        }
+        A.ops.insert(A.ops.end(), S.ops.begin(), S.ops.end());
+        A.rm_ops.insert(A.rm_ops.end(), S.rm_ops.begin(), S.rm_ops.end());
     }
     A.prog_off[A.n_instances] = (uint32_t)A.ops.size();
     A.rm_prog_off[A.n_instances] = (uint32_t)A.rm_ops.size();

@@ -20,8 +20,8 @@
 //     hierarchy walk (64 B x 2 per node; 1024 nodes = 128 KiB of the CU's 160 KiB);
 //   * records are float4-packed and node-contiguous, so a wave's loads are dense.
 // Arithmetic: f32, reference operation order, no FMA contraction (-ffp-contract=off), IEEE
-// divide and sqrt -- bit-identical to the CPU path except sin/cos of Euler tracks (computed in
-// f64 and rounded; libm's sinf is not reproducible bit-for-bit on a GPU).
+// divide and sqrt -- bit-identical to the CPU path except sin/cos of Euler tracks (<= 1 ulp f32
+// sincosf; libm's sinf is not reproducible bit-for-bit on a GPU).
 #include "fyx_internal.h"
 
 #include "../../include/fyrox_hip.h"
@@ -44,27 +44,35 @@ __device__ __forceinline__ float cubicf_(float p0, float p1, float t, float m0, 
 }
 
 // CurveKey::interpolate (curve.rs:87-132): dispatch on the LEFT key's kind.
-__device__ __forceinline__ float interpolate_keys(const float* __restrict__ loc,
-                                                  const f4* __restrict__ aux, uint32_t l, uint32_t r,
-                                                  float location) {
-    const float ll = loc[l], rl = loc[r];
-    const f4 la = aux[l], ra = aux[r];
+__device__ __forceinline__ float interpolate_loaded(float ll, float rl, f4 la, f4 ra, float location) {
     const float t = (location - ll) / (rl - ll);
     const uint32_t lk = __float_as_uint(la.y), rk = __float_as_uint(ra.y);
     if (lk == FYX_KEY_CONSTANT) return t == 1.0f ? ra.x : la.x;
     if (lk == FYX_KEY_LINEAR) return lerpf_(la.x, ra.x, t);
     return cubicf_(la.x, ra.x, t, la.w, rk == FYX_KEY_CUBIC ? ra.z : 0.0f);
 }
+__device__ __forceinline__ float interpolate_keys(const float* __restrict__ loc,
+                                                  const f4* __restrict__ aux, uint32_t l, uint32_t r,
+                                                  float location) {
+    return interpolate_loaded(loc[l], loc[r], aux[l], aux[r], location);
+}
 
 // Curve::value_at with the caller's span hint (curve.rs:254-314).
+// A sample is a chain of dependent loads, and this kernel is bound by that latency, not by bytes: everything the
+// common outcomes need -- the first and last key (clamping) and the two keys of the hinted span -- is therefore
+// fetched in ONE round trip right after the hint is known (eight independent loads), and only a hint miss pays
+// for the binary search.  The decisions are taken in the reference's order on the same values.
 __device__ float curve_value_at(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
                                 float location, uint32_t& hint) {
     if (n == 0) return 0.0f;
-    if (location <= loc[0]) { hint = 0; return aux[0].x; }
-    if (location >= loc[n - 1]) { hint = n - 1; return aux[n - 1].x; }
-    const uint32_t h = hint, hl = h > 0 ? h - 1 : 0;
+    const uint32_t h = hint;
+    const uint32_t hc = h < n ? h : n - 1, hl = hc > 0 ? hc - 1 : 0;   // clamped: addresses stay inside the curve
+    const float l_first = loc[0], l_last = loc[n - 1], l_hl = loc[hl], l_h = loc[hc];
+    const f4 a_first = aux[0], a_last = aux[n - 1], a_hl = aux[hl], a_h = aux[hc];
+    if (location <= l_first) { hint = 0; return a_first.x; }
+    if (location >= l_last) { hint = n - 1; return a_last.x; }
     if (h < n) {
-        if (location >= loc[hl] && location < loc[h]) return interpolate_keys(loc, aux, hl, h, location);
+        if (location >= l_hl && location < l_h) return interpolate_loaded(l_hl, l_h, a_hl, a_h, location);
     }
     uint32_t lo = 0, hi = n;  // partition_point(|k| k.location < location)
     while (lo < hi) {
@@ -105,10 +113,11 @@ __device__ __forceinline__ f4 group_rotation(float v, int has_r, int rkind, int 
     f4 q = f4{0.f, 0.f, 0.f, 1.f};
     if (__any(has_r && rkind == FYX_KIND_QUAT_EULER)) {
         // (axis * sin(angle/2), cos(angle/2)) of this lane's own angle; lanes base.. are x,y,z
+        // f32 sin/cos (<= 1 ulp each): libm's sinf/cosf cannot be matched bit for bit on a GPU anyway (DESIGN.md
+        // section 2), and the f64 evaluation used before cost more than the whole rest of the sample
         const float half = v / 2.0f;
-        double sd, cd;
-        sincos((double)half, &sd, &cd);
-        const float sn = (float)sd, cs = (float)cd;
+        float sn, cs;
+        sincosf(half, &sn, &cs);
         const float sx = __shfl(sn, base, 64), cx = __shfl(cs, base, 64);
         const float sy = __shfl(sn, base + 1, 64), cy = __shfl(cs, base + 1, 64);
         const float sz = __shfl(sn, base + 2, 64), cz = __shfl(cs, base + 2, 64);

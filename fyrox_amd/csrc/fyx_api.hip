@@ -198,6 +198,8 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     fyx::anim_store_destroy(c->anim);
     c->anim = nullptr;
+    fyx::plan_pool_destroy(c->plan_pool);
+    c->plan_pool = nullptr;
     for (auto& kv : c->meshes) free_mesh(kv.second);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->aabb_partials) (void)hipFree(c->aabb_partials);
@@ -265,6 +267,8 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd")) return &c->lbs.crowd;
     if (!strcmp(key, "lbs.crowd_block")) return &c->lbs.crowd_block;
     if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
+    if (!strcmp(key, "anim.threads")) return &c->plan_threads;
+    if (!strcmp(key, "anim.split")) return &c->plan_split;
     return nullptr;
 }
 
@@ -286,6 +290,9 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_block must be 256 or 512");
     if (slot == &c->lbs.crowd_ipb && (value < 0 || value > 4096))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_ipb must be 0 (auto) .. 4096");
+    if (slot == &c->plan_split && value < 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.split must be >= 1");
+    if (slot == &c->plan_threads && (value < 1 || value > 64))
+        return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");
     if (slot == &c->lbs.blocks_per_cu && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.blocks_per_cu must be 1..64");
     *slot = value;

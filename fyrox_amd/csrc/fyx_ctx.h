@@ -32,6 +32,9 @@ struct Mesh {
 };
 struct AnimStore;  // anim_api.hip: tracks data, rigs, animators, bone lists
 void anim_store_destroy(AnimStore*);
+class PlanPool;     // anim_api.hip: host threads that plan a crowd's frame
+void plan_pool_destroy(PlanPool*);
+
 }  // namespace fyx
 using fyx::Mesh;
 
@@ -60,6 +63,9 @@ struct fyx_ctx {
     bool primary_dirty = true;  // context-stream work enqueued since the last fork event
     int next_worker = 0;
     fyx::AnimStore* anim = nullptr;
+    int plan_threads = 8;    // option "anim.threads": host threads planning a crowd's frame (1 = the calling thread only)
+    int plan_split = 2048;   // option "anim.split": instances per planning task
+    fyx::PlanPool* plan_pool = nullptr;
 };
 
 

@@ -252,3 +252,43 @@ def test_builder_validation(cctx):
     bad = A.Rig(parent=np.asarray([1, -1], np.int32), transforms=[A.Transform.identity()] * 2)
     with pytest.raises(fyrox_amd.FyxError):
         A.create_rig(cctx, 999, bad)
+
+
+def test_threaded_crowd_planner_equals_the_serial_one():
+    """A crowd's frame is planned by several host threads over instance ranges (option anim.threads); the merged
+    programs, sample times, root-motion programs, layer states and event queues must equal the single-threaded
+    plan exactly, with every instance in its own state."""
+    n = 777
+    ctxs = [fyrox_amd.Context(control_only=True) for _ in range(2)]
+    ctxs[0].set_option("anim.threads", 1)
+    ctxs[1].set_option("anim.threads", 6)
+    ctxs[1].set_option("anim.split", 100)
+    sc = cases.ALL_RM[2]()            # transitions + root motion + signals
+    ps = [cases.build_product(c, sc, n_instances=n) for c in ctxs]
+    for p in ps:
+        for i in range(n):
+            for a in range(len(sc.animations)):
+                p.set_time_position(a, (i * 0.0137 + a * 0.31) % 0.5, instance=i)
+    for f in range(40):
+        for idx, par in sc.script.get(f, []):
+            for p in ps:
+                for i in range(0, n, 3):                       # a third of the crowd follows the script ...
+                    p.set_parameter(idx, par, instance=i)
+        if f == 12:
+            for p in ps:
+                for i in range(1, n, 3):                       # ... another third switches later
+                    p.set_parameter(0, A.Parameter(A.PARAM_RULE, True), instance=i)
+        plans = [p.plan(1, sc.dt) for p in ps]
+        for k in ("times", "ticked", "offsets", "ops"):
+            assert np.array_equal(plans[0][k], plans[1][k]), (f, k)
+        rms = [p.plan_root_motion() for p in ps]
+        for k in ("offsets", "ops", "slices"):
+            assert np.array_equal(rms[0][k], rms[1][k]), (f, k)
+        for i in (0, 1, 2, 128, 129, 500, n - 1):
+            assert ps[0].layer_state(0, i) == ps[1].layer_state(0, i)
+            for a in range(len(sc.animations)):
+                assert ps[0].event_count(a, i) == ps[1].event_count(a, i)
+    states = {ps[0].layer_state(0, i) for i in range(n)}
+    assert len(states) > 1, "the crowd should have diverged"
+    for c in ctxs:
+        c.close()

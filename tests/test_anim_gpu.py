@@ -3,7 +3,7 @@ folding (Machine / layers / transitions / pose nodes), apply, local matrices, hi
 the end-to-end chain into the skinning kernel (BASELINE configs C2, C3-scaled, C5).
 
 Bar.  Everything is BIT-EXACT except values that depend on sin/cos of UnitQuaternionEuler tracks: libm's
-sinf/cosf are not reproducible bit-for-bit on a GPU (the kernel evaluates them in f64 and rounds), so
+sinf/cosf are not reproducible bit-for-bit on a GPU (the kernel uses the device's <= 1 ulp sincosf), so
 Euler-driven rotations -- and what is computed from them -- are held to 1e-5 relative, the tolerance
 BASELINE.json's north_star states; scenarios without Euler tracks must match bit for bit.
 """

@@ -29,6 +29,8 @@ ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--opt", action="append", default=["lbs.streams=1"],
                 help="kernel option key=value; the frame is a dependent chain (pose -> palette -> skin), so the "
                      "default keeps every launch on the context stream instead of forking to the worker streams")
+ap.add_argument("--root-motion", action="store_true",
+                help="RootMotionSettings on every clip (root = node 0) + AnimationPose::root_motion tracking")
 args = ap.parse_args()
 
 ctx = fyrox_amd.Context(0)
@@ -44,6 +46,9 @@ for c in range(4):
     A.upload_tracks_data(ctx, 10 + c, td)
     an.add_animation(10 + c, tgt, time_slice=(0.0, 1.0), speed=[1.0, 0.8, 1.3, -0.7][c])
 an.set_machine(synth.make_c5_machine())
+if args.root_motion:
+    for c in range(4):
+        an.set_root_motion_settings(c, 0)
 # desynchronise the crowd: every instance starts at its own phase and stands at its own place
 for i in range(args.instances):
     for c in range(4):
