@@ -1373,6 +1373,7 @@ int fyx_animator_create(fyx_ctx* c, uint64_t animator_id, uint64_t rig_id, uint3
     auto rit = store(c).rigs.find(rig_id);
     if (rit == store(c).rigs.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "rig %llu is not registered", (unsigned long long)rig_id);
     if (n_instances == 0) return fail(c, FYX_ERR_INVALID_ARG, "n_instances is 0");
+    if (n_instances > 65535u) return fail(c, FYX_ERR_UNSUPPORTED, "n_instances=%u: at most 65535 instances per animator (split the crowd)", n_instances);
     if (store(c).animators.count(animator_id))
         return fail(c, FYX_ERR_INVALID_ARG, "animator %llu already exists", (unsigned long long)animator_id);
     std::unique_ptr<Animator> a(new Animator());

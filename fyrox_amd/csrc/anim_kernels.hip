@@ -144,17 +144,16 @@ __device__ __forceinline__ f4 group_rotation(float v, int has_r, int rkind, int 
 // Euler tracks: lanes 4,5,6 each evaluate sin/cos of their own half angle once, every rotation lane
 // then forms qz * qy * qx (fyrox-math/src/lib.rs:725-740) from the shuffled values.
 // ---------------------------------------------------------------------------------------
+// Grid: x = 16-node slices of one instance, y = instance, z = animation -- no index arithmetic beyond shifts
+// (the kernel is VALU-issue bound: ~64 K waves of a few hundred instructions each for the C3 crowd).
 __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
     const uint32_t lane = threadIdx.x & 63u, j = threadIdx.x & 15u, gbase = lane & ~15u;
-    const uint32_t per_anim = f.n_instances * f.n_nodes;
-    const uint64_t items = (uint64_t)f.n_anims * per_anim;
-    const uint64_t groups_per_pass = ((uint64_t)gridDim.x * blockDim.x) >> 4;
-    for (uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; item < items;
-         item += groups_per_pass) {
-        const uint32_t a = (uint32_t)(item / per_anim);
-        const uint32_t rem = (uint32_t)(item - (uint64_t)a * per_anim);
-        const uint32_t inst = rem / f.n_nodes, node = rem - inst * f.n_nodes;
-        if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) continue;  // uniform across the group
+    const uint32_t a = blockIdx.z, inst = blockIdx.y;
+    const uint32_t node = (blockIdx.x * 256u + threadIdx.x) >> 4;
+    {
+        if (node >= f.n_nodes) return;                                   // uniform across the group
+        if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      // uniform across the block
+        const size_t item = ((size_t)a * f.n_instances + inst) * f.n_nodes + node;
         const float time = f.times[(size_t)inst * f.n_anims + a];
         const AnimDev an = f.anims[a];
 
@@ -204,11 +203,9 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
 }
 
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s) {
-    const uint64_t items = (uint64_t)f.n_anims * f.n_instances * f.n_nodes;
-    if (items == 0) return hipSuccess;
-    uint64_t grid = (items * 16 + 255) / 256;
-    if (grid > (uint64_t)kCUs * 32) grid = (uint64_t)kCUs * 32;
-    hipLaunchKernelGGL(pose_sample_kernel, dim3((uint32_t)grid), dim3(256), 0, s, f);
+    if (f.n_anims == 0 || f.n_instances == 0 || f.n_nodes == 0) return hipSuccess;
+    if (f.n_instances > 65535u || f.n_anims > 65535u) return hipErrorInvalidValue;   // grid y / z limits
+    hipLaunchKernelGGL(pose_sample_kernel, dim3((f.n_nodes * 16 + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f);
     return hipGetLastError();
 }
 

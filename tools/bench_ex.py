@@ -79,6 +79,17 @@ def main():
         100 + s, pal.ptr, args.bones, 1, d_blend_shape_weights=d_w.ptr, n_blend_shapes=args.shapes,
         d_out_vertices=sets[s]["aos68"].ptr, out_stride=L["stride"], out_off_pos=L["off_pos"],
         out_off_normal=L["off_normal"], out_off_tangent=L["off_tangent"]), 100 + 18 * args.shapes)
+    # host-pointer variant (fyx_lbs_skin): 16 KB palette H2D + 40 MB D2H per call, synchronous -- the PCIe-inclusive rate
+    import time
+    palh = synth.make_palette(args.bones, seed)
+    ctx.lbs_skin(100, palh)
+    t0 = time.perf_counter()
+    n_host = 10
+    for _ in range(n_host):
+        ctx.lbs_skin(100, palh)
+    dt = (time.perf_counter() - t0) / n_host
+    res["host_pointer_variant_pcie_inclusive"] = {"ms_per_call": dt * 1e3, "vertices_per_s": nv / dt,
+                                                  "note": "fyx_lbs_skin: palette H2D, kernel, 40 MB D2H into pageable host memory, sync"}
     print(json.dumps({"workload": f"{nv} verts / {args.bones} bones, {args.sets} rotating sets, {args.streams} launch streams",
                       "results": res}))
     ctx.close()
