@@ -110,7 +110,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    opts = {k: ctx.get_option(k) for k in ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams")}
+    opts = {k: ctx.get_option(k) for k in ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams",
+                                           "lbs.split")}
     from fyrox_amd import sharding
     shard = sharding.vertex_range(world * args.verts, rank, world)   # this rank's slice of the N x 1M scene
 

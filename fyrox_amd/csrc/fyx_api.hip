@@ -204,6 +204,7 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->aabb_partials) (void)hipFree(c->aabb_partials);
     if (c->d_u32) (void)hipFree(c->d_u32);
+    if (c->lbs.probe_buf) (void)hipFree(c->lbs.probe_buf);
     for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
         if (c->workers[w]) { (void)hipStreamSynchronize(c->workers[w]); (void)hipStreamDestroy(c->workers[w]); }
         if (c->worker_done[w]) (void)hipEventDestroy(c->worker_done[w]);
@@ -267,6 +268,8 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd")) return &c->lbs.crowd;
     if (!strcmp(key, "lbs.crowd_block")) return &c->lbs.crowd_block;
     if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
+    if (!strcmp(key, "lbs.probe")) return &c->lbs.probe;
+    if (!strcmp(key, "lbs.split")) return &c->lbs.split;
     if (!strcmp(key, "anim.threads")) return &c->plan_threads;
     if (!strcmp(key, "anim.split")) return &c->plan_split;
     return nullptr;
@@ -295,7 +298,24 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");
     if (slot == &c->lbs.blocks_per_cu && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.blocks_per_cu must be 1..64");
+    if (slot == &c->lbs.probe && value && !c->lbs.probe_buf) {
+        if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+        c->lbs.probe_words = (size_t)65536 * 4;
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->lbs.probe_buf), c->lbs.probe_words * 8));
+    }
     *slot = value;
+    return FYX_OK;
+}
+
+// Debug: copy the per-wave timeline the last lbs.probe=1 launch wrote ({entry, staged, last store issued, last
+// store done} in 10 ns ticks per wave).  Allocates the probe buffer on first use (64 K waves).
+int fyx_debug_read_probe(fyx_ctx* c, uint64_t* host_out, uint32_t n_waves) {
+    if (!c || !host_out) return FYX_ERR_INVALID_ARG;
+    if (int rc = enter_primary(c)) return rc;
+    if (!c->lbs.probe_buf) return fail(c, FYX_ERR_INVALID_ARG, "no probe buffer: set lbs.probe=1 first");
+    if ((size_t)n_waves * 4 > c->lbs.probe_words) return fail(c, FYX_ERR_INVALID_ARG, "n_waves too large");
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    FYX_HIP(c, hipMemcpy(host_out, c->lbs.probe_buf, (size_t)n_waves * 32, hipMemcpyDeviceToHost));
     return FYX_OK;
 }
 

@@ -249,9 +249,13 @@ __device__ __forceinline__ void pin_vertex(VertexIn<MASK>& r) {
     asm volatile("" : "+v"(r.t), "+v"(r.w), "+v"(r.id));
 }
 
-template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK>
+// PROBE (debug, option lbs.probe): every wave records s_memrealtime (100 MHz) at kernel entry, after the palette
+// staging barrier, after its last store was issued and after that store completed -- the launch's timeline.
+template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK, bool PROBE = false>
 __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_inst,
-                                                  uint32_t total_units) {
+                                                  uint32_t total_units, uint32_t split, uint64_t* probe = nullptr) {
+    uint64_t pt0 = 0, pt1 = 0;
+    if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
@@ -277,9 +281,29 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         // below then waits for the (L2-resident, fast) palette only, while the vertex loads --
         // a cold HBM access at kernel start -- stay in flight across the staging barrier.
         const PaletteRegs pr = palette_fetch(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, tid);
-        uint32_t u = seg_b + wave;
-        uint32_t v = u * 64 + lane;
-        VertexIn<MASK> cur = load_vertex<NT, MASK>(a, (u < seg_e && v < a.n_verts) ? v : 0);
+        // This wave's vertices of the segment: [vb, ve) visited in 64-vertex steps of stride `vstep`.
+        //   split == 0: whole units dealt round-robin to the waves (unit k of the segment -> wave k % WPB);
+        //   split == 1: the segment's vertex range cut into WPB equal contiguous shares (16-vertex aligned), so every
+        //               wave of every workgroup has the same number of bytes to move (units are too coarse for that:
+        //               3 or 4 per wave on the 1 M-vertex workload) and runs the same number of iterations.
+        uint32_t vb, ve, vstep;
+        {
+            const uint32_t s0 = seg_b * 64;
+            const uint32_t s1 = seg_e * 64 < a.n_verts ? seg_e * 64 : a.n_verts;
+            if (split) {
+                const uint32_t len = s1 - s0;
+                vb = s0 + (uint32_t)(((uint64_t)len * wave / WPB) & ~15ull);
+                ve = wave + 1 == WPB ? s1 : s0 + (uint32_t)(((uint64_t)len * (wave + 1) / WPB) & ~15ull);
+                vstep = 64;
+            } else {
+                vb = (seg_b + wave) * 64;
+                ve = s1;
+                vstep = WPB * 64;
+            }
+        }
+        uint32_t base = vb;
+        uint32_t v = base + lane;
+        VertexIn<MASK> cur = load_vertex<NT, MASK>(a, v < ve ? v : 0);
 
         if (inst != inst_first) __syncthreads();  // every wave is done with the previous palette
         const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
@@ -293,18 +317,19 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         // Opaque use point: nothing that consumes the first unit's vertex data may be scheduled
         // above the staging barrier (it would drag the wait for those loads up with it).
         pin_vertex(cur);
+        if constexpr (PROBE) { if (inst == inst_first) pt1 = __builtin_amdgcn_s_memrealtime(); }
 
-        while (u < seg_e) {  // wave-uniform
-            const uint32_t un = u + WPB;
-            const uint32_t vn = un * 64 + lane;
+        while (base < ve) {  // wave-uniform
+            const uint32_t bn = base + vstep;
+            const uint32_t vn = bn + lane;
             VertexIn<MASK> nxt;
             if constexpr (PREFETCH) {
-                if (un < seg_e) nxt = load_vertex<NT, MASK>(a, vn < a.n_verts ? vn : 0);
+                if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
             }
             const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.px,
                                                        cur.py, cur.pz, cur.nx, cur.ny, cur.nz,
                                                        cur.t.x, cur.t.y, cur.t.z);
-            if (v < a.n_verts) {
+            if (v < ve) {
                 const size_t ov = (size_t)inst * a.n_verts + v;
                 if constexpr (MASK & 1) st3<NT>(a.out_pos + ov * 3, o.px, o.py, o.pz);
                 if constexpr (MASK & 2) st3<NT>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
@@ -312,11 +337,20 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
                     stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, cur.t.w});
             }
             if constexpr (!PREFETCH) {
-                if (un < seg_e) nxt = load_vertex<NT, MASK>(a, vn < a.n_verts ? vn : 0);
+                if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
             }
             cur = nxt;
-            u = un;
+            base = bn;
             v = vn;
+        }
+    }
+    if constexpr (PROBE) {
+        const uint64_t pt2 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t pt3 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            uint64_t* r = probe + ((size_t)blockIdx.x * WPB + wave) * 4;
+            r[0] = pt0; r[1] = pt1; r[2] = pt2; r[3] = pt3;
         }
     }
 }
@@ -448,8 +482,16 @@ static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s
     const uint32_t max_useful = (total + (BLOCK / 64) - 1) / (BLOCK / 64);
     if (grid > max_useful) grid = max_useful;
     const size_t lds = (size_t)a.n_bones * 64 + 64;  // rows + row3 + one flag per wave
+    if constexpr (BLOCK == 512 && EXACT && NT && PREFETCH && MASK == 7) {
+        if (t.probe && t.probe_buf) {   // debug timeline, only for the default variant
+            if ((size_t)grid * (BLOCK / 64) * 4 > t.probe_words) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a,
+                               upi, total, (uint32_t)(t.split ? 1 : 0), t.probe_buf);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
-                       upi, total);
+                       upi, total, (uint32_t)(t.split ? 1 : 0), (uint64_t*)nullptr);
     return hipGetLastError();
 }
 

@@ -77,6 +77,9 @@ int fyx_join(fyx_ctx* ctx);
  * crowd kernel keeps a tile of vertices in registers and loops over instances), "lbs.crowd_block"
  * (256 | 512 vertices per tile), "lbs.crowd_ipb" (instances per workgroup, 0 = auto). */
 int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
+/* Debug aid (option "lbs.probe" = 1): per-wave timeline of the last default-variant skinning launch, four
+ * uint64 per wave {kernel entry, palette staged, last store issued, last store completed} in 10 ns ticks. */
+int fyx_debug_read_probe(fyx_ctx* ctx, uint64_t* host_out, uint32_t n_waves);
 int fyx_get_option(fyx_ctx* ctx, const char* key, int* value);
 
 /* GPU-side timing on the context's stream (hipEvent pair): begin records an event, end records

@@ -47,7 +47,7 @@ def assert_bit_exact(got, ref):
 @pytest.fixture(autouse=True)
 def _defaults(ctx):
     for k, v in (("lbs.block", 512), ("lbs.blocks_per_cu", 4), ("lbs.prefetch", 1), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2),
-                 ("lbs.crowd", -1), ("lbs.crowd_block", 512), ("lbs.crowd_ipb", 0)):
+                 ("lbs.crowd", -1), ("lbs.crowd_block", 512), ("lbs.crowd_ipb", 0), ("lbs.split", 0)):
         ctx.set_option(k, v)
     yield
 
@@ -104,13 +104,24 @@ def test_c4_1m_verts_256_bones(ctx, orc):
 @pytest.mark.parametrize("block", [256, 512, 1024])
 @pytest.mark.parametrize("prefetch", [0, 1])
 @pytest.mark.parametrize("nt", [0, 1])
-def test_every_kernel_variant_is_bit_exact(ctx, orc, block, prefetch, nt):
+@pytest.mark.parametrize("split", [0, 1])
+def test_every_kernel_variant_is_bit_exact(ctx, orc, block, prefetch, nt, split):
     m = synth.make_mesh(70_001, 200, 99, coherent=False)   # ragged: not a multiple of 4 or 256
     pal = synth.make_palette(200, 99)
     upload(ctx, 5, m)
     ctx.set_option("lbs.block", block); ctx.set_option("lbs.prefetch", prefetch); ctx.set_option("lbs.nt", nt)
-    ctx.set_option("lbs.blocks_per_cu", 2)
+    ctx.set_option("lbs.blocks_per_cu", 2); ctx.set_option("lbs.split", split)
     assert_bit_exact(ctx.lbs_skin(5, pal), oracle_skin(orc, m, pal))
+
+
+@pytest.mark.parametrize("n_inst,n_verts", [(1, 1), (1, 15), (1, 17), (3, 1001), (2, 4096), (1, 1_000_003), (5, 70)])
+def test_equal_share_split_covers_every_vertex_once(ctx, orc, n_inst, n_verts):
+    """lbs.split=1: a workgroup's range is cut into per-wave contiguous shares (16-vertex aligned)."""
+    m = synth.make_mesh(n_verts, 16, 7)
+    pal = synth.make_palette(16, 7, n_instances=n_inst)
+    upload(ctx, 9, m)
+    ctx.set_option("lbs.split", 1); ctx.set_option("lbs.crowd", 0)
+    assert_bit_exact(ctx.lbs_skin(9, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst))
 
 
 @pytest.mark.parametrize("prefetch", [0, 1])
