@@ -140,6 +140,10 @@ _SIGS = {
     "fyx_animation_read_root_motion": (c_int, [_P, c_uint64, c_uint32, _P]),
     "fyx_absm_read_root_motion": (c_int, [_P, c_uint64, c_int32, _P]),
     "fyx_layer_pop_event": (c_int, [_P, c_uint64, c_uint32, c_uint32, _P, POINTER(c_int)]),
+    "fyx_animator_property_count": (c_int, [_P, c_uint64, POINTER(c_uint32)]),
+    "fyx_animator_property_slot": (c_int, [_P, c_uint64, c_int32, c_int32, POINTER(c_int32)]),
+    "fyx_animator_read_properties": (c_int, [_P, c_uint64, c_int32, _P]),
+    "fyx_animator_blend_shape_weights": (c_int, [_P, c_uint64, c_uint32, _P, _P, _P]),
     "fyx_animator_plan_root_motion": (c_int, [_P, c_uint64, _P, _P, c_uint32, POINTER(c_uint32), POINTER(c_uint32), _P]),
 }
 

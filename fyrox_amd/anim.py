@@ -17,6 +17,7 @@ import numpy as np
 
 # ValueBinding / TrackValueKind / CurveKeyKind (values of include/fyrox_hip.h)
 BIND_POSITION, BIND_SCALE, BIND_ROTATION = 0, 1, 2
+BIND_PROPERTY0 = 3   # ValueBinding::Property{name, ..}: BIND_PROPERTY0 + id (Real tracks only)
 KIND_REAL, KIND_VEC2, KIND_VEC3, KIND_VEC4, KIND_QUAT_EULER, KIND_QUAT = range(6)
 KEY_CONSTANT, KEY_LINEAR, KEY_CUBIC = 0, 1, 2
 PARAM_WEIGHT, PARAM_RULE, PARAM_INDEX, PARAM_SAMPLING_POINT = range(4)
@@ -363,6 +364,29 @@ class Animator:
         if n.value > cap:
             raise RuntimeError("program larger than the wrapper's buffer; plan_root_motion() is a test hook")
         return {"offsets": off, "ops": ops[:n.value], "n_slots": ns.value, "slices": slices[:, :self.n_animations]}
+
+    # -- Property{..} slots ------------------------------------------------------------------------
+    def property_count(self) -> int:
+        out = c_uint32()
+        self._check(self._l.fyx_animator_property_count(self._h, self.id, byref(out)))
+        return out.value
+
+    def property_slot(self, node: int, property_id: int) -> int:
+        out = c_int32()
+        self._check(self._l.fyx_animator_property_slot(self._h, self.id, node, property_id, byref(out)))
+        return out.value
+
+    def read_properties(self, animation: int = -1) -> np.ndarray:
+        """(n_instances, n_slots, 2) float32: value, flag bits.  animation < 0: applied values."""
+        out = np.zeros((self.n_instances, self.property_count(), 2), np.float32)
+        self._check(self._l.fyx_animator_read_properties(self._h, self.id, animation, _ptr(out)))
+        return out
+
+    def blend_shape_weights(self, slots, default_weights, d_out: int) -> None:
+        sl = _i32(slots)
+        dw = np.ascontiguousarray(default_weights, dtype=np.float32)
+        assert len(sl) == len(dw)
+        self._check(self._l.fyx_animator_blend_shape_weights(self._h, self.id, len(sl), _ptr(sl), _ptr(dw), d_out))
 
     # -- machine ---------------------------------------------------------------------------------
     def set_machine(self, m: Machine) -> None:

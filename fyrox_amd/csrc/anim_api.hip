@@ -62,6 +62,8 @@ struct AnimationDef {
     std::vector<int32_t> target;   // per track, <0: no TrackBinding
     std::vector<uint8_t> enabled;  // TrackBinding::enabled
     int32_t* d_slot_track = nullptr;
+    int32_t* d_prop_track = nullptr;   // [animator's property slots]
+    uint32_t dev_prop_slots = 0;
     bool slots_dirty = true;
     // AnimationSignal (signal.rs): the index stands for the {id, name} pair the shim keeps
     struct Signal { float time; uint8_t enabled; };
@@ -192,6 +194,12 @@ struct Animator {
     std::vector<float2> slices;
     std::vector<uint4> rm_ops;
     std::vector<uint32_t> rm_prog_off;
+    // Property{..} slots: one per distinct (node, property id) any animation of the animator drives
+    std::vector<std::pair<int32_t, int32_t>> prop_slots;
+    int32_t* d_prop_node = nullptr;
+    float2* d_prop_pose = nullptr;     // [anim capacity][instance][slot]
+    float2* d_prop_out = nullptr;      // [instance][slot]
+    uint32_t dev_prop_slots = 0, dev_prop_anims = 0;
     std::vector<uint32_t> rm_layer_base;   // first slot of each layer; nodes, then the layer's final pose
     uint32_t n_rm_slots = 0;               // ... and the machine's final pose last
     RootMotionDev* d_rm_anim = nullptr;
@@ -229,7 +237,8 @@ void free_rig(Rig& r) {
 }
 void free_bones(BoneList& b) { dfree(b.d_bone_nodes); b = BoneList(); }
 void free_animator(Animator& a) {
-    for (auto& an : a.anims) dfree(an.d_slot_track);
+    for (auto& an : a.anims) { dfree(an.d_slot_track); dfree(an.d_prop_track); }
+    dfree(a.d_prop_node); dfree(a.d_prop_pose); dfree(a.d_prop_out);
     dfree(a.d_anims); dfree(a.d_hints); dfree(a.d_anim_pose); dfree(a.d_node_trs); dfree(a.d_local);
     dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_ctrl); dfree(a.d_rm_anim); dfree(a.d_rm_slots);
     for (int i = 0; i < 2; ++i) {
@@ -926,13 +935,29 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         for (uint32_t a = 0; a < na; ++a) {
             AnimationDef& an = A.anims[a];
             if (an.slots_dirty) {
-                std::vector<int32_t> slots((size_t)rig.n_nodes * 3, -1);
+                std::vector<int32_t> slots((size_t)rig.n_nodes * 4, -1);
+                std::vector<int32_t> ptrack(std::max<size_t>(A.prop_slots.size(), 1), -1);
                 for (uint32_t t = 0; t < an.td->n_tracks; ++t) {
                     if (an.target[t] < 0 || !an.enabled[t]) continue;
                     const int b = an.td->tracks[t].binding;
-                    int32_t& s = slots[(size_t)an.target[t] * 3 + b];
+                    if (b >= FYX_BIND_PROPERTY0) {
+                        if (an.td->tracks[t].n_curves < 1) continue;   // fetch() -> None
+                        const std::pair<int32_t, int32_t> key(an.target[t], b - FYX_BIND_PROPERTY0);
+                        const size_t sl = std::find(A.prop_slots.begin(), A.prop_slots.end(), key) - A.prop_slots.begin();
+                        if (sl < ptrack.size()) ptrack[sl] = (int32_t)t;
+                        slots[(size_t)an.target[t] * 4 + 3] = (int32_t)t;   // the node's pose is not empty
+                        continue;
+                    }
+                    int32_t& s = slots[(size_t)an.target[t] * 4 + b];
                     if (s < 0) s = (int32_t)t;
                 }
+                if (an.dev_prop_slots < ptrack.size()) {
+                    dfree(an.d_prop_track);
+                    an.d_prop_track = nullptr;
+                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_prop_track), std::max<size_t>(ptrack.size() * 4, 16)));
+                    an.dev_prop_slots = (uint32_t)ptrack.size();
+                }
+                FYX_HIP(c, hipMemcpy(an.d_prop_track, ptrack.data(), ptrack.size() * 4, hipMemcpyHostToDevice));
                 if (!an.d_slot_track)
                     FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_slot_track), std::max<size_t>(slots.size() * 4, 16)));
                 FYX_HIP(c, hipMemcpy(an.d_slot_track, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
@@ -942,6 +967,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             hd[a].key_loc = an.td->d_loc;
             hd[a].key_aux = an.td->d_aux;
             hd[a].slot_track = an.d_slot_track;
+            hd[a].prop_track = an.d_prop_track;
             hd[a].n_tracks = an.td->n_tracks;
             hd[a].rm_node = an.rm_node;
             hd[a].rm_ignore = an.rm_ignore;
@@ -953,6 +979,33 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         A.d_anims = nullptr;
         if (int rc = upload(c, &A.d_anims, hd.data(), hd.size())) return rc;
         A.anims_dirty = false;
+    }
+    const uint32_t nps = (uint32_t)A.prop_slots.size();
+    if (nps && (A.dev_prop_slots != nps || A.dev_prop_anims < A.dev_anim_capacity)) {
+        // property storage is re-created when slots or animations are added (values applied so far are kept per slot)
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<int32_t> nodes(nps);
+        for (uint32_t k = 0; k < nps; ++k) nodes[k] = A.prop_slots[k].first;
+        dfree(A.d_prop_node);
+        A.d_prop_node = nullptr;
+        if (int rc = upload(c, &A.d_prop_node, nodes.data(), nodes.size())) return rc;
+        float2* np = nullptr;
+        float2* no = nullptr;
+        const size_t pb = (size_t)A.dev_anim_capacity * A.n_instances * nps * sizeof(float2);
+        const size_t ob = (size_t)A.n_instances * nps * sizeof(float2);
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&np), std::max<size_t>(pb, 16)));
+        FYX_HIP(c, hipMemset(np, 0, std::max<size_t>(pb, 16)));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&no), std::max<size_t>(ob, 16)));
+        FYX_HIP(c, hipMemset(no, 0, std::max<size_t>(ob, 16)));
+        if (A.d_prop_out && A.dev_prop_slots)   // slots only ever get appended: old slot k is new slot k
+            FYX_HIP(c, hipMemcpy2D(no, (size_t)nps * sizeof(float2), A.d_prop_out, (size_t)A.dev_prop_slots * sizeof(float2),
+                                   (size_t)A.dev_prop_slots * sizeof(float2), A.n_instances, hipMemcpyDeviceToDevice));
+        dfree(A.d_prop_pose);
+        dfree(A.d_prop_out);
+        A.d_prop_pose = np;
+        A.d_prop_out = no;
+        A.dev_prop_slots = nps;
+        A.dev_prop_anims = A.dev_anim_capacity;
     }
     if (A.rm_enabled) {
         if (A.dev_rm_anim_capacity < A.dev_anim_capacity) {  // [anim][instance]: growing keeps the existing prefix
@@ -1023,6 +1076,10 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     f.node_trs = A.d_node_trs;
     f.local = A.d_local;
     f.global = A.d_global;
+    f.n_prop_slots = A.dev_prop_slots;
+    f.prop_node = A.d_prop_node;
+    f.prop_pose = A.d_prop_pose;
+    f.prop_out = A.d_prop_out;
     if (with_program) {
         const size_t b_times = align_up(A.times.size() * 4, 256), b_tick = align_up(A.ticked.size(), 256);
         const size_t b_off = align_up(A.prog_off.size() * 4, 256), b_ops = align_up(A.ops.size() * 8, 256);
@@ -1073,6 +1130,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         f.prog_off = reinterpret_cast<const uint32_t*>(d + b_times + b_tick);
         f.ops = reinterpret_cast<const uint2*>(d + b_times + b_tick + b_off);
         FYX_HIP(c, launch_pose_sample(f, c->stream));
+        FYX_HIP(c, launch_property_sample(f, c->stream));
         if (rm) {
             f.slices = reinterpret_cast<const float2*>(d + o_slices);
             f.rm_anim = A.d_rm_anim;
@@ -1084,6 +1142,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         }
     }
     FYX_HIP(c, launch_pose_update(f, rig_dev(*A.rig), with_program, c->stream));
+    if (with_program) FYX_HIP(c, launch_property_update(f, c->stream));
     return FYX_OK;
 }
 
@@ -1168,9 +1227,16 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
     uint64_t total = 0;
     for (uint32_t t = 0; t < n_tracks; ++t) {
         const fyx_track_desc& d = tracks[t];
+        if (d.binding >= FYX_BIND_PROPERTY0) {
+            // Property{name, value_type}: the id stands for the name; Real values only (morph weights and the like)
+            if (d.kind != FYX_KIND_REAL)
+                return fail(c, FYX_ERR_UNSUPPORTED, "track %u: Property bindings are supported for TrackValueKind::Real only", t);
+            if (d.n_curves > 4) return fail(c, FYX_ERR_INVALID_ARG, "track %u has %u curves", t, d.n_curves);
+            for (uint32_t k = 0; k < d.n_curves; ++k) total += d.curve_n_keys[k];
+            continue;
+        }
         if (d.binding != FYX_BIND_POSITION && d.binding != FYX_BIND_SCALE && d.binding != FYX_BIND_ROTATION)
-            return fail(c, FYX_ERR_UNSUPPORTED,
-                        "track %u: only Position/Scale/Rotation bindings run on the GPU (Property bindings use reflection)", t);
+            return fail(c, FYX_ERR_INVALID_ARG, "track %u: binding %d", t, d.binding);
         const bool vec3 = d.kind == FYX_KIND_VEC3;
         const bool quat = d.kind == FYX_KIND_QUAT || d.kind == FYX_KIND_QUAT_EULER;
         if ((d.binding == FYX_BIND_ROTATION && !quat) || (d.binding != FYX_BIND_ROTATION && !vec3))
@@ -1413,16 +1479,28 @@ int fyx_animator_add_animation(fyx_ctx* c, uint64_t animator_id, uint64_t tracks
     an.target.assign(td.n_tracks, -1);
     an.enabled.assign(td.n_tracks, 1);
     std::vector<uint8_t> used((size_t)A->rig->n_nodes * 3, 0);
+    std::vector<std::pair<int32_t, int32_t>> new_slots = A->prop_slots, seen_props;
     for (uint32_t t = 0; t < td.n_tracks; ++t) {
         an.target[t] = track_target[t];
         if (track_enabled) an.enabled[t] = track_enabled[t] ? 1 : 0;
         if (track_target[t] >= (int32_t)A->rig->n_nodes)
             return fail(c, FYX_ERR_INVALID_ARG, "track %u targets node %d of a %u-node rig", t, track_target[t], A->rig->n_nodes);
-        if (track_target[t] >= 0) {
+        if (track_target[t] >= 0 && td.tracks[t].binding >= FYX_BIND_PROPERTY0) {
+            const std::pair<int32_t, int32_t> key(track_target[t], td.tracks[t].binding - FYX_BIND_PROPERTY0);
+            if (std::find(seen_props.begin(), seen_props.end(), key) != seen_props.end())
+                return fail(c, FYX_ERR_UNSUPPORTED, "two tracks drive the same property of node %d", track_target[t]);
+            seen_props.push_back(key);
+            if (std::find(new_slots.begin(), new_slots.end(), key) == new_slots.end()) new_slots.push_back(key);
+        } else if (track_target[t] >= 0) {
             uint8_t& u = used[(size_t)track_target[t] * 3 + td.tracks[t].binding];
             if (u) return fail(c, FYX_ERR_UNSUPPORTED, "two tracks drive the same binding of node %d", track_target[t]);
             u = 1;
         }
+    }
+    if (new_slots.size() > 65535) return fail(c, FYX_ERR_UNSUPPORTED, "more than 65535 animated properties");
+    if (new_slots.size() != A->prop_slots.size()) {
+        A->prop_slots.swap(new_slots);
+        for (AnimationDef& o : A->anims) o.slots_dirty = true;   // their slot tables grow
     }
     for (uint32_t t = 0; t < td.n_tracks; ++t) {  // lib.rs:507-534: the first track with the binding
         if (an.rm_pos_track < 0 && td.tracks[t].binding == FYX_BIND_POSITION) an.rm_pos_track = (int32_t)t;
@@ -2074,6 +2152,69 @@ int fyx_animator_plan_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t* pr
     if (n_slots) *n_slots = A->n_rm_slots;
     if (ops) memcpy(ops, A->rm_ops.data(), std::min<size_t>(A->rm_ops.size(), ops_capacity) * 16);
     if (slices) memcpy(slices, A->slices.data(), A->slices.size() * 8);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+// ---- Property{..} slots ----------------------------------------------------------------------
+
+int fyx_animator_property_count(fyx_ctx* c, uint64_t animator_id, uint32_t* out_count) {
+    if (!c || !out_count) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    *out_count = (uint32_t)A->prop_slots.size();
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_property_slot(fyx_ctx* c, uint64_t animator_id, int32_t node, int32_t property_id, int32_t* out_slot) {
+    if (!c || !out_slot) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    const std::pair<int32_t, int32_t> key(node, property_id);
+    const auto it = std::find(A->prop_slots.begin(), A->prop_slots.end(), key);
+    *out_slot = it == A->prop_slots.end() ? -1 : (int32_t)(it - A->prop_slots.begin());
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_read_properties(fyx_ctx* c, uint64_t animator_id, int32_t animation, float* host_out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
+    if (animation >= (int32_t)A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %d does not exist", animation);
+    if (A->prop_slots.empty()) return FYX_OK;
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, *A)) return rc;
+    const size_t per = (size_t)A->n_instances * A->dev_prop_slots;
+    const float2* src = animation < 0 ? A->d_prop_out : A->d_prop_pose + (size_t)animation * per;
+    FYX_HIP(c, hipMemcpyAsync(host_out, src, per * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_blend_shape_weights(fyx_ctx* c, uint64_t animator_id, uint32_t n_shapes, const int32_t* slots,
+                                     const float* default_weights, float* d_out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (n_shapes == 0) return FYX_OK;
+    if (n_shapes > FYX_MAX_BLEND_SHAPES) return fail(c, FYX_ERR_UNSUPPORTED, "%u blend shapes", n_shapes);
+    if (!slots || !default_weights || !d_out) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, *A)) return rc;
+    // slots + defaults travel as one small block through the scratch buffer
+    if (int rc = ensure_scratch(c, (size_t)n_shapes * 8 + 64)) return rc;
+    int32_t* d_slots = static_cast<int32_t*>(c->scratch);
+    float* d_def = reinterpret_cast<float*>(d_slots + n_shapes);
+    FYX_HIP(c, hipMemcpyAsync(d_slots, slots, (size_t)n_shapes * 4, hipMemcpyHostToDevice, c->stream));
+    FYX_HIP(c, hipMemcpyAsync(d_def, default_weights, (size_t)n_shapes * 4, hipMemcpyHostToDevice, c->stream));
+    FYX_HIP(c, launch_blend_shape_weights(A->d_prop_out, A->dev_prop_slots, A->n_instances, d_slots, d_def, n_shapes, d_out,
+                                          c->stream));
     return FYX_OK;
     FYX_GUARD_END(c)
 }

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
         else if (j >= 4 && j < 8) { bind = FYX_BIND_ROTATION; c = (int)j - 4; }
         else if (j >= 8 && j < 11) { bind = FYX_BIND_SCALE; c = (int)j - 8; }
         int32_t track = -1;
-        if (bind >= 0) track = an.slot_track[(size_t)node * 3 + bind];
+        if (bind >= 0) track = an.slot_track[(size_t)node * 4 + bind];
+        const bool has_prop = j == 3 && an.slot_track[(size_t)node * 4 + 3] >= 0;   // lane 3 writes the present bits
         int kind = -1, need = 0;
         bool valid = false;
         float v = 0.0f;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
 
         float out;
         if (j < 3 || (j >= 8 && j < 11)) out = v;   // an absent binding sampled nothing: 0
-        else if (j == 3) out = __uint_as_float((has_p ? 1u : 0u) | (has_s ? 2u : 0u) | (has_r ? 4u : 0u));
+        else if (j == 3) out = __uint_as_float((has_p ? 1u : 0u) | (has_s ? 2u : 0u) | (has_r ? 4u : 0u) | (has_prop ? 8u : 0u));
         else if (j == 4) out = q.x;
         else if (j == 5) out = q.y;
         else if (j == 6) out = q.z;
@@ -530,6 +531,173 @@ __device__ __forceinline__ void run_fold(FoldCtx& cx, Acc& acc) {
                 return;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Property{..} bindings of kind Real (morph-target weights and the like).
+//
+// In the reference such a value is one more BoundValue in its node's pose (pose.rs:107-121), blended by
+// TrackValue::Real => lerpf (value.rs:221-230) and applied through reflection (value.rs:404-427).  Here every
+// (node, property) pair of an animator is a SLOT with its own thread.  What couples a slot to the rest of its node
+// is NodePose::blend_with's rule "an empty node pose becomes a copy of the other" (pose.rs:41-47): emptiness is a
+// property of the whole node, so bit 3 of a pose record's present bits says "this animation holds a Property value
+// for the node" (the node threads of pose_update see it in their mask), and a slot thread carries the node's mask
+// along with its own {value, present} through the same fold program.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void property_sample_kernel(PoseFrameDev f) {
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x, inst = blockIdx.y, a = blockIdx.z;
+    if (slot >= f.n_prop_slots) return;
+    if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;
+    const AnimDev an = f.anims[a];
+    const int32_t track = an.prop_track[slot];
+    float2 out = make_float2(0.0f, 0.0f);
+    if (track >= 0) {
+        const TrackDev* tk = an.tracks + track;
+        if (tk->kind == FYX_KIND_REAL && tk->n_curves >= 1) {   // curves.first()? else None (container.rs:289-291)
+            uint32_t* hp = f.hints + (((size_t)a * f.n_instances + inst) * f.max_tracks + track) * 4;
+            uint32_t hint = *hp;
+            const uint32_t fk = tk->first_key[0];
+            out.x = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[0],
+                                   f.times[(size_t)inst * f.n_anims + a], hint);
+            *hp = hint;
+            out.y = __uint_as_float(1u);
+        }
+    }
+    f.prop_pose[((size_t)a * f.n_instances + inst) * f.n_prop_slots + slot] = out;
+}
+
+hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s) {
+    if (!f.n_prop_slots || !f.n_anims || !f.n_instances) return hipSuccess;
+    hipLaunchKernelGGL(property_sample_kernel, dim3((f.n_prop_slots + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f);
+    return hipGetLastError();
+}
+
+struct PAcc {
+    float v;
+    uint32_t present;     // this slot holds a value
+    uint32_t node_mask;   // present bits of the whole node (0 == the node's pose is empty)
+};
+
+__device__ __forceinline__ void pblend(PAcc& self, const PAcc& o, float w) {
+    if (self.node_mask == 0) { self = o; return; }                      // copy, weight ignored
+    if (self.present && o.present) self.v = lerpf_(self.v, o.v, w);      // Real: a + (b - a) * w
+}
+
+struct PFoldCtx {
+    const uint2* __restrict__ ops;
+    const float2* __restrict__ prop_pose;      // [n_anims][n_instances][n_slots]
+    const f4* __restrict__ anim_pose;          // node records (for the node's present bits)
+    const uint8_t* __restrict__ layer_masks;
+    size_t prop_stride, prop_index;            // n_instances * n_slots, inst * n_slots + slot
+    size_t rec_stride, rec_index;              // n_instances * n_nodes, inst * n_nodes + node
+    uint32_t n_nodes, node, pc;
+    float pop_w;
+    bool done;
+    float out_v;
+    bool out_set;
+};
+
+__device__ __forceinline__ PAcc pload(const PFoldCtx& cx, uint32_t a) {
+    const float2 p = cx.prop_pose[(size_t)a * cx.prop_stride + cx.prop_index];
+    PAcc o;
+    o.v = p.x;
+    o.present = __float_as_uint(p.y);
+    o.node_mask = __float_as_uint(cx.anim_pose[((size_t)a * cx.rec_stride + cx.rec_index) * 3].w);
+    return o;
+}
+
+template <int D>
+__device__ __forceinline__ void run_fold_prop(PFoldCtx& cx, PAcc& acc) {
+    for (;;) {
+        const uint2 op = cx.ops[cx.pc++];
+        const uint32_t code = op.x & 0xffu, arg = op.x >> 8;
+        const float w = __uint_as_float(op.y);
+        switch (code) {
+            case OP_BLEND_ANIM: pblend(acc, pload(cx, arg), w); break;
+            case OP_PUSH:
+                if constexpr (D + 1 < kMaxFoldDepth) {
+                    PAcc child{0.0f, 0u, 0u};
+                    run_fold_prop<D + 1>(cx, child);
+                    if (cx.done) return;
+                    pblend(acc, child, cx.pop_w);
+                } else {
+                    cx.done = true;
+                    return;
+                }
+                break;
+            case OP_POP_BLEND: cx.pop_w = w; return;
+            case OP_RESET: acc = PAcc{0.0f, 0u, 0u}; break;
+            case OP_MASK:
+                if (cx.layer_masks[(size_t)arg * cx.n_nodes + cx.node]) acc = PAcc{0.0f, 0u, 0u};
+                break;
+            case OP_APPLY:
+                if (acc.present) { cx.out_v = acc.v; cx.out_set = true; }
+                break;
+            case OP_APPLY_ANIM: {
+                const PAcc o = pload(cx, arg);
+                if (o.present) { cx.out_v = o.v; cx.out_set = true; }
+                break;
+            }
+            default: cx.done = true; return;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void property_update_kernel(PoseFrameDev f) {
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x, inst = blockIdx.y;
+    if (slot >= f.n_prop_slots) return;
+    PFoldCtx cx;
+    cx.ops = f.ops + f.prog_off[inst];
+    cx.prop_pose = f.prop_pose;
+    cx.anim_pose = reinterpret_cast<const f4*>(f.anim_pose);
+    cx.layer_masks = f.layer_masks;
+    cx.prop_stride = (size_t)f.n_instances * f.n_prop_slots;
+    cx.prop_index = (size_t)inst * f.n_prop_slots + slot;
+    cx.n_nodes = f.n_nodes;
+    cx.node = (uint32_t)f.prop_node[slot];
+    cx.rec_stride = (size_t)f.n_instances * f.n_nodes;
+    cx.rec_index = (size_t)inst * f.n_nodes + cx.node;
+    cx.pc = 0;
+    cx.pop_w = 0.f;
+    cx.done = false;
+    cx.out_v = 0.f;
+    cx.out_set = false;
+    PAcc acc{0.0f, 0u, 0u};
+    while (!cx.done) run_fold_prop<0>(cx, acc);
+    if (cx.out_set) f.prop_out[(size_t)inst * f.n_prop_slots + slot] = make_float2(cx.out_v, __uint_as_float(1u));
+}
+
+hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s) {
+    if (!f.n_prop_slots || !f.n_instances) return hipSuccess;
+    hipLaunchKernelGGL(property_update_kernel, dim3((f.n_prop_slots + 63) / 64, f.n_instances), dim3(64), 0, s, f);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void blend_shape_weights_kernel(const float2* __restrict__ prop_out, uint32_t n_prop_slots,
+                                                                  uint32_t n_instances, const int32_t* __restrict__ slots,
+                                                                  const float* __restrict__ defaults, uint32_t n_shapes,
+                                                                  float* __restrict__ out) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n_instances * n_shapes) return;
+    const uint32_t inst = e / n_shapes, k = e - inst * n_shapes;
+    float w = defaults[k];
+    const int32_t sl = slots[k];
+    if (sl >= 0 && (uint32_t)sl < n_prop_slots) {
+        const float2 p = prop_out[(size_t)inst * n_prop_slots + sl];
+        if (__float_as_uint(p.y)) w = p.x;
+    }
+    out[e] = w / 100.0f;   // bs.weight / 100.0 (scene/mesh/mod.rs:797)
+}
+
+hipError_t launch_blend_shape_weights(const float2* prop_out, uint32_t n_prop_slots, uint32_t n_instances,
+                                      const int32_t* d_slots, const float* d_defaults, uint32_t n_shapes, float* d_out,
+                                      hipStream_t s) {
+    const uint64_t total = (uint64_t)n_instances * n_shapes;
+    if (!total) return hipSuccess;
+    if (total > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(blend_shape_weights_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, prop_out,
+                       n_prop_slots, n_instances, d_slots, d_defaults, n_shapes, d_out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------

@@ -112,7 +112,9 @@ struct AnimDev {
     const TrackDev* tracks;
     const float* key_loc;        // locations of all keys of the tracks data
     const float4* key_aux;       // {value, kind bits, left tangent, right tangent} per key
-    const int32_t* slot_track;   // [n_nodes][3]: track feeding Position/Scale/Rotation of a node, -1 none
+    const int32_t* slot_track;   // [n_nodes][4]: track feeding Position/Scale/Rotation of a node (-1 none); entry 3 is
+                                 //   >= 0 when the animation holds a Property value for the node
+    const int32_t* prop_track;   // [n_prop_slots]: Real track feeding a (node, property) slot of the animator, -1 none
     uint32_t n_tracks;
     // RootMotionSettings (lib.rs:307-319): rm_node < 0 = None; rm_ignore bits 1 x, 2 y, 4 z, 8 rotations;
     // rm_pos_track / rm_rot_track: FIRST track of the tracks data bound to Position / Rotation
@@ -187,6 +189,11 @@ struct PoseFrameDev {
     float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
     float* local;                // [n_instances][n_nodes][16]
     float* global;               // [n_instances][n_nodes][16]
+    // Property{..} bindings of kind Real (value.rs:355-373, :404-427): one slot per (node, property) of the animator
+    uint32_t n_prop_slots;
+    const int32_t* prop_node;    // [n_prop_slots] node of each slot
+    float2* prop_pose;           // [n_anims][n_instances][n_prop_slots] {value, present bits}
+    float2* prop_out;            // [n_instances][n_prop_slots] {applied value, has-been-applied bits}
     // root motion (all null / 0 unless the animator tracks root motion)
     const float2* slices;        // [n_instances][n_anims] time_slice {start, end}
     RootMotionDev* rm_anim;      // [n_anims][n_instances]
@@ -201,6 +208,13 @@ hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run
 // Animation::update_root_motion for every ticked animation that has settings (after pose_sample:
 // rewrites the root node's pose record), then the per-instance root-motion program (machine mode).
 hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s);
+// Property slots: sample the Real tracks of every ticked animation / run the instance's fold program on them
+hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s);
+hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s);
+// out[inst][k] = (has(inst, slots[k]) ? value(inst, slots[k]) : defaults[k]) / 100  (mesh/mod.rs:794-798)
+hipError_t launch_blend_shape_weights(const float2* prop_out, uint32_t n_prop_slots, uint32_t n_instances,
+                                      const int32_t* d_slots, const float* d_defaults, uint32_t n_shapes, float* d_out,
+                                      hipStream_t s);
 // out[inst][b] = global[inst][bone_nodes[b]] * inv_bind[bone_nodes[b]] (identity for a negative node)
 hipError_t launch_palette_gather(const float* d_global, const float* d_inv_bind, const int32_t* d_bone_nodes,
                                  uint32_t n_nodes, uint32_t n_bones, uint32_t n_instances, float* d_out,

@@ -224,9 +224,11 @@ int fyx_palette_device(fyx_ctx* ctx, const float* d_global, const float* d_inv_b
 
 #define FYX_ALL_INSTANCES 0xffffffffu
 
-/* ValueBinding (fyrox-animation/src/value.rs:355-373).  Property{..} bindings go through
- * reflection in the reference and are not a per-bone numeric path: FYX_ERR_UNSUPPORTED. */
-enum { FYX_BIND_POSITION = 0, FYX_BIND_SCALE = 1, FYX_BIND_ROTATION = 2 };
+/* ValueBinding (fyrox-animation/src/value.rs:355-373). */
+enum { FYX_BIND_POSITION = 0, FYX_BIND_SCALE = 1, FYX_BIND_ROTATION = 2,
+       /* ValueBinding::Property{name, value_type}: FYX_BIND_PROPERTY0 + id, the id standing for the name
+        * (bindings compare by name and type, value.rs:355-373).  TrackValueKind::Real only. */
+       FYX_BIND_PROPERTY0 = 3 };
 /* TrackValueKind (container.rs:40-62) */
 enum { FYX_KIND_REAL = 0, FYX_KIND_VEC2 = 1, FYX_KIND_VEC3 = 2, FYX_KIND_VEC4 = 3,
        FYX_KIND_QUAT_EULER = 4, FYX_KIND_QUAT = 5 };
@@ -366,6 +368,30 @@ int fyx_animation_read_root_motion(fyx_ctx* ctx, uint64_t animator_id, uint32_t 
 /* Machine::pose().root_motion() (layer < 0) or MachineLayer's final pose (layer >= 0) of every
  * instance, as of the last fyx_absm_update: host_out[n_instances].  Synchronous. */
 int fyx_absm_read_root_motion(fyx_ctx* ctx, uint64_t animator_id, int32_t layer, fyx_root_motion* host_out);
+
+/* Property{..} bindings of kind Real (value.rs:355-373, applied through reflection at :404-427; the glTF
+ * importer animates BlendShape weights this way, resource/gltf/animation.rs:395-420).  A track with
+ * binding FYX_BIND_PROPERTY0 + id bound to node n animates the (n, id) "slot" of the animator; slots
+ * are created by fyx_animator_add_animation in order of first appearance.  Such a value is part of its
+ * node's pose exactly as in the reference: it is blended with lerpf (value.rs:221-230), dropped when
+ * only the other pose holds it, copied -- weight ignored -- when the node's own pose is empty, removed
+ * by a layer mask on the node, and it makes the node's pose non-empty for the node's Position /
+ * Rotation / Scale values too.  The applied values stay on the device; the shim reads them back
+ * (and writes them through reflection) or feeds them to the skinning kernel directly. */
+int fyx_animator_property_count(fyx_ctx* ctx, uint64_t animator_id, uint32_t* out_count);
+/* *out_slot = slot of (node, property id), or -1 when no animation drives it */
+int fyx_animator_property_slot(fyx_ctx* ctx, uint64_t animator_id, int32_t node, int32_t property_id,
+                               int32_t* out_slot);
+/* host_out[n_instances][n_slots][2]: {value, flag as u32 bits}.  animation < 0: the values applied so
+ * far (flag = the property has been written at least once); animation >= 0: that animation's current
+ * pose (flag = the pose holds the value).  Synchronous. */
+int fyx_animator_read_properties(fyx_ctx* ctx, uint64_t animator_id, int32_t animation, float* host_out);
+/* d_out[n_instances][n_shapes] = (applied value of slots[k], or default_weights[k] when slots[k] < 0 or
+ * nothing has been applied yet) / 100 -- the `blend_shapes_weights` Mesh::collect_render_data hands to
+ * the renderer (scene/mesh/mod.rs:794-798), ready for fyx_lbs_skin_ex.  slots / default_weights are
+ * host arrays of n_shapes entries; asynchronous on the context stream. */
+int fyx_animator_blend_shape_weights(fyx_ctx* ctx, uint64_t animator_id, uint32_t n_shapes,
+                                     const int32_t* slots, const float* default_weights, float* d_out);
 
 /* ---- Machine (fyrox-animation/src/machine) ------------------------------------------- */
 /* Parameter (machine/parameter.rs:37-60) */

@@ -394,6 +394,8 @@ def _pose_records(pose_ptr, n_nodes: int) -> np.ndarray:
                 out[n, 8:11] = bv.v[0:3]; bits[n] |= 2
             elif bv.binding == BIND_ROTATION and bv.kind == VAL_QUAT:
                 out[n, 4:8] = bv.v[0:4]; bits[n] |= 4
+            elif bv.binding >= 3:
+                bits[n] |= 8          # a Property value: the node's pose is not empty
     out[:, 3] = bits.view(np.float32)
     return out
 
@@ -414,6 +416,7 @@ class AnimScene:
         self.tracks = []
         self.anims = []
         self.machine = None
+        self.props = {}      # (node, property id) -> value applied last (Property{..} bindings of kind Real)
 
     def add_tracks_data(self, td) -> int:
         h = self.l.fo_tracks_new()
@@ -495,18 +498,37 @@ class AnimScene:
         f0, f1, u = p.packed()
         self.l.fo_machine_set_parameter(self.machine, index, p.kind, f0, f1, u)
 
+    def _pose_properties(self, pose_ptr) -> dict:
+        """{(node, property id): value} of the Real Property values a pose holds (first value per binding)."""
+        out = {}
+        bv = _BoundValue()
+        for n in range(min(self.l.fo_pose_node_capacity(pose_ptr), self.n_nodes)):
+            for i in range(self.l.fo_pose_value_count(pose_ptr, n)):
+                self.l.fo_pose_get_value(pose_ptr, n, i, byref(bv))
+                if bv.binding >= 3 and bv.kind == VAL_REAL and (n, bv.binding - 3) not in out:
+                    out[(n, bv.binding - 3)] = np.float32(bv.v[0])
+        return out
+
+    def _apply_properties(self, pose_ptr) -> None:   # value.rs:404-427: written through reflection
+        self.props.update(self._pose_properties(pose_ptr))
+
+    def animation_properties(self, a: int) -> dict:
+        return self._pose_properties(self.l.fo_animation_pose(self.anims[a]))
+
     # AnimationContainerExt::update_animations
     def update_animations(self, dt: float) -> None:
         for a in self.anims:
             if self.l.fo_animation_is_enabled(a):
                 self.l.fo_animation_tick(a, dt)
                 self.l.fo_pose_apply(self.l.fo_animation_pose(a), self.nodes, self.n_nodes)
+                self._apply_properties(self.l.fo_animation_pose(a))
 
     # AnimationBlendingStateMachine::update
     def update_machine(self, dt: float) -> None:
         arr = (c_void_p * max(len(self.anims), 1))(*self.anims)
         pose = self.l.fo_machine_evaluate_pose(self.machine, arr, len(self.anims), dt)
         self.l.fo_pose_apply(pose, self.nodes, self.n_nodes)
+        self._apply_properties(pose)
 
     def animation_pose(self, a: int) -> np.ndarray:
         return _pose_records(self.l.fo_animation_pose(self.anims[a]), self.n_nodes)

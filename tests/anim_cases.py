@@ -275,7 +275,60 @@ def gltf_like(n_bones=18, seed=synth.SEED_BASE + 13) -> Scenario:
     return Scenario("gltf_like", rig, tds, anims, m, script, n_frames=45, dt=1.0 / 45.0, has_euler=False)
 
 
-ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like]
+def morph_weights(n_bones=10, seed=synth.SEED_BASE + 14) -> Scenario:
+    """glTF morph-target animation (resource/gltf/animation.rs:395-420): Real tracks bound to Property bindings
+    (BlendShape weights, values x100) on a mesh node, next to ordinary TRS tracks.  Clip 0 animates weights 0-3 of
+    node 4 (which has NO transform tracks there: a pose holding only Property values), clip 1 weights 2-5 plus a
+    position track on node 4, clip 2 weight 1 on another node; blended, cross-faded by a transition, the second layer
+    masks node 4.  Exercises lerpf blending, dropped / copied values and the node-level emptiness rule."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+
+    def weight_track(tag, prop, kind=A.KEY_LINEAR, nk=9):
+        t = (np.arange(nk) / 8.0).astype(np.float32)
+        v = (synth.uniform(seed, tag, nk) * np.float32(100.0)).astype(np.float32)     # importer stores weight * 100
+        tan = (synth.normal(seed, tag + ".t", nk * 2).reshape(nk, 2) * 20).astype(np.float32)
+        return A.Track(A.BIND_PROPERTY0 + prop, A.KIND_REAL,
+                       [A.Curve([A.CurveKey(float(t[k]), float(v[k]), kind, float(tan[k, 0]), float(tan[k, 1])) for k in range(nk)])])
+
+    for c in range(3):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, n_keys=9, fps=8.0, euler_every=10 ** 9)
+        keep = (lambda b, t: b != 4) if c == 0 else (lambda b, t: b != 4 or t.binding == A.BIND_POSITION) if c == 1 else (lambda b, t: True)
+        td, tgt = _partial(td, tgt, keep)
+        tracks, target = list(td.tracks), list(tgt)
+        if c == 0:
+            for p_ in range(4):
+                tracks.append(weight_track(f"w0.{p_}", p_, [A.KEY_LINEAR, A.KEY_CUBIC, A.KEY_CONSTANT, A.KEY_LINEAR][p_])); target.append(4)
+        elif c == 1:
+            for p_ in range(2, 6):
+                tracks.append(weight_track(f"w1.{p_}", p_)); target.append(4)
+        else:
+            tracks.append(weight_track("w2.1", 1)); target.append(7)
+            tracks.append(weight_track("w2.0", 0)); target.append(4)
+        tds.append(A.AnimationTracksData(tracks))
+        anims.append(AnimSpec(c, np.asarray(target, np.int32), speed=[1.0, 0.7, -1.1][c]))
+    base = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2),
+               A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, parameter=0)]),
+               A.BlendAnimations([A.BlendPose(2, 1.0), A.BlendPose(3, 0.6)])],
+        states=[A.State(3), A.State(4)],
+        transitions=[A.Transition(0, 1, 0.25, ("parameter", 1)), A.Transition(1, 0, 0.2, ("not", ("parameter", 1)))])
+    upper = A.MachineLayer(nodes=[A.PlayAnimation(1)], states=[A.State(0)], weight=0.4, mask=[4, 5])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_WEIGHT, 0.3), A.Parameter(A.PARAM_RULE, False)], layers=[base, upper])
+    script = {8: [(0, A.Parameter(A.PARAM_WEIGHT, 0.85))], 14: [(1, A.Parameter(A.PARAM_RULE, True))],
+              36: [(1, A.Parameter(A.PARAM_RULE, False))]}
+    return Scenario("morph_weights", rig, tds, anims, m, script, n_frames=56, dt=1.0 / 40.0, has_euler=False)
+
+
+def morph_weights_player(n_bones=6, seed=synth.SEED_BASE + 15) -> Scenario:
+    """The same kind of tracks under a plain AnimationPlayer: later animations overwrite earlier ones per property."""
+    sc = morph_weights(n_bones=max(n_bones, 8), seed=seed)
+    sc.machine, sc.script, sc.name = None, {}, "morph_weights_player"
+    return sc
+
+
+ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like, morph_weights,
+       morph_weights_player]
 
 
 def with_root_motion_and_signals(make) -> Callable[[], Scenario]:

@@ -223,11 +223,19 @@ def test_builder_validation(cctx):
     sc = cases.by_index()
     p = cases.build_product(cctx, sc)
     l, h = cctx._l, cctx._h
-    # unsupported: Property-like binding, mismatched kind, duplicate binding on a node
-    td = A.AnimationTracksData([A.Track(3, A.KIND_REAL, [A.Curve([A.CurveKey(0, 1)])])])
+    # unsupported: Property binding of a non-Real kind, mismatched kind, duplicate binding on a node
+    td = A.AnimationTracksData([A.Track(A.BIND_PROPERTY0 + 2, A.KIND_VEC3, [A.Curve([A.CurveKey(0, 1)])] * 3)])
     with pytest.raises(fyrox_amd.FyxError) as e:
         A.upload_tracks_data(cctx, 1, td)
     assert e.value.code == _native.FYX_ERR_UNSUPPORTED
+    real = [A.Curve([A.CurveKey(0, 1)])]
+    td = A.AnimationTracksData([A.Track(A.BIND_PROPERTY0 + 2, A.KIND_REAL, real), A.Track(A.BIND_PROPERTY0 + 2, A.KIND_REAL, real)])
+    A.upload_tracks_data(cctx, 2, td)
+    with pytest.raises(fyrox_amd.FyxError) as e:      # the same property of the same node twice
+        p.add_animation(2, [1, 1])
+    assert e.value.code == _native.FYX_ERR_UNSUPPORTED
+    p.add_animation(2, [1, 3])
+    assert p.property_count() == 2 and p.property_slot(1, 2) == 0 and p.property_slot(3, 2) == 1 and p.property_slot(2, 2) == -1
     td = A.AnimationTracksData([A.Track(A.BIND_POSITION, A.KIND_QUAT, [A.Curve()] * 4)])
     with pytest.raises(fyrox_amd.FyxError) as e:
         A.upload_tracks_data(cctx, 1, td)

@@ -77,6 +77,8 @@ def run_scenario(ctx, orc, sc, n_instances=1, frames=None, check_every=1):
         if sc.machine is not None:
             for li in range(len(sc.machine.layers)):
                 assert p.layer_state(li, n_instances - 1) == o.layer_state(li)
+        if p.property_count():
+            check_properties(p, o, sc, exact, f"{sc.name} frame {f}")
         if sc.track_root_motion:
             for a in range(len(sc.animations)):
                 check_root_motion(p.animation_root_motion(a), o.animation_root_motion(a), exact,
@@ -86,6 +88,32 @@ def run_scenario(ctx, orc, sc, n_instances=1, frames=None, check_every=1):
                     check_root_motion(p.machine_root_motion(li), o.machine_root_motion(li), exact,
                                       f"{sc.name} frame {f} root motion of " + ("the machine" if li < 0 else f"layer {li}"))
     return o, p
+
+
+def check_properties(p, o, sc, exact, what):
+    """Property{..} slots: every animation's pose values (with their presence) and the values applied so far."""
+    slots = {}
+    for node in range(sc.rig.n_nodes):
+        for prop in range(8):
+            s = p.property_slot(node, prop)
+            if s >= 0:
+                slots[(node, prop)] = s
+    assert len(slots) == p.property_count() and sorted(slots.values()) == list(range(len(slots)))
+    for a in range(len(sc.animations)):
+        got, ref = p.read_properties(a), o.animation_properties(a)
+        for i in (0, got.shape[0] - 1):
+            for key, s in slots.items():
+                present = bool(got[i, s, 1].view(np.uint32))
+                assert present == (key in ref), f"{what}: animation {a} property {key} presence"
+                if present:
+                    check(got[i, s, 0:1], np.asarray([ref[key]], np.float32), exact, f"{what}: animation {a} property {key}")
+    got = p.read_properties(-1)
+    for i in (0, got.shape[0] - 1):
+        for key, s in slots.items():
+            applied = bool(got[i, s, 1].view(np.uint32))
+            assert applied == (key in o.props), f"{what}: property {key} applied"
+            if applied:
+                check(got[i, s, 0:1], np.asarray([o.props[key]], np.float32), exact, f"{what}: applied property {key}")
 
 
 def check_root_motion(got, ref, exact, what):

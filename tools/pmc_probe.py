@@ -31,4 +31,32 @@ for i in range(N):
     s = i % SETS
     ctx.lbs_skin_device(s, d_pal.ptr, NB, 1, outs[s][0].ptr, outs[s][1].ptr, outs[s][2].ptr)
 ctx.sync()
+# extended launches: 4 blend shapes -> SoA, vertex buffer in -> vertex buffer out (AnimatedVertex, 68 B), and the crowd kernel
+L = synth.ANIMATED_VERTEX
+storage, plane, w = synth.make_blend_shapes(NV, 4, synth.SEED_BASE + 4)
+d_w = ctx.to_device(w)
+aos = mesh.to_animated_vertex_aos()
+vbs = []
+for s in range(SETS):
+    ctx.mesh_set_blend_shapes(s, storage, 4, plane)
+    ctx.mesh_upload(100 + s, aos, NV, L["stride"], off_pos=L["off_pos"], off_normal=L["off_normal"], off_tangent=L["off_tangent"],
+                    off_weights=L["off_weights"], off_indices=L["off_indices"])
+    vbs.append(ctx.malloc(NV * L["stride"]))
+for i in range(N):
+    s = i % SETS
+    ctx.lbs_skin_ex(s, d_pal.ptr, NB, 1, d_blend_shape_weights=d_w.ptr, n_blend_shapes=4, d_out_pos=outs[s][0].ptr,
+                    d_out_normal=outs[s][1].ptr, d_out_tangent=outs[s][2].ptr)
+ctx.sync()
+for i in range(N):
+    s = i % SETS
+    ctx.lbs_skin_ex(100 + s, d_pal.ptr, NB, 1, d_out_vertices=vbs[s].ptr, out_stride=0)
+ctx.sync()
+# crowd: 100 instances x 10 k vertices / 64 bones (10 MB of palettes + mesh read, 40 MB written per launch)
+cm = synth.make_mesh(10_000, 64, synth.SEED_BASE + 3)
+cp = ctx.to_device(synth.make_palette(64, synth.SEED_BASE + 3, n_instances=100))
+ctx.mesh_upload_soa(300, cm.pos, cm.weights, cm.indices, cm.normal, cm.tangent)
+for i in range(N):
+    s = i % SETS
+    ctx.lbs_skin_device(300, cp.ptr, 64, 100, outs[s][0].ptr, outs[s][1].ptr, outs[s][2].ptr)
+ctx.sync()
 print("done")

@@ -31,7 +31,7 @@ def trace_summary(sub):
     p = os.path.join(src, sub, "bench_kernel_trace.csv")
     if not os.path.exists(p):
         return None
-    rows = [r for r in csv.DictReader(open(p)) if "lbs_skin" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(p)) if "lbs_skin<" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[-1000:]  # the timed region (after warm-up)
     st = [int(r["Start_Timestamp"]) for r in rows]
@@ -48,7 +48,10 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_lds"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
-        k = "lbs_skin" if "lbs_skin" in r["Kernel_Name"] else "stream_copy" if "stream_copy" in r["Kernel_Name"] else None
+        n = r["Kernel_Name"]
+        k = ("lbs_skin_aos" if "lbs_skin_aos<" in n else "lbs_skin_ex" if "lbs_skin_ex<" in n else
+             "lbs_skin_crowd" if "lbs_skin_crowd<" in n else "lbs_skin" if "lbs_skin<" in n else
+             "stream_copy" if "stream_copy" in n else None)
         if k:
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in agg.items():
@@ -66,6 +69,12 @@ if "stream_copy" in pmc and "FETCH_SIZE" in pmc["stream_copy"] and "lbs_skin" in
     out["calibration"] = {"known_copy_read_bytes": copy_rd_known, "known_copy_write_bytes": copy_wr_known,
                           "fetch_size_correction": f_rd, "write_size_correction": f_wr}
     out["lbs_hbm_bytes_per_launch"] = {"read": rd, "write": wr, "total": rd + wr, "algorithmic": 100_000_000}
+    algo = {"lbs_skin_ex": ("4 blend shapes -> SoA", 172_000_000), "lbs_skin_aos": ("vertex buffer in -> out, 68 B", 136_000_000),
+            "lbs_skin_crowd": ("100 instances x 10 k vertices / 64 bones: unique bytes", 600_000 + 100 * 4096 + 40_000_000)}
+    for k, (what, ab) in algo.items():
+        if k in pmc and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]:
+            r_, w_ = pmc[k]["FETCH_SIZE"]["median"] * KB * f_rd, pmc[k]["WRITE_SIZE"]["median"] * KB * f_wr
+            out[k + "_hbm_bytes_per_launch"] = {"what": what, "read": r_, "write": w_, "total": r_ + w_, "algorithmic": ab}
     json.dump({"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr,
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile.sh), KB units, corrected by "
                          "the factors measured on fyx_calib_stream_copy's known 60 MB read / 40 MB written in the same run "
