@@ -315,6 +315,52 @@ def test_c3_crowd_instances_from_pose_to_vertices(ctx, orc):
     _skin_chain(ctx, orc, sc, mesh, 48, 12, bone_nodes, exact=True)
 
 
+def test_animated_morph_weights_drive_blend_shapes_into_a_vertex_buffer(ctx, orc):
+    """glTF-style chain, all on the device: Real Property tracks -> blended weights -> fyx_animator_blend_shape_weights
+    (x / 100, defaults for shapes nothing animated yet) -> blend shapes + skinning with GPU-built palettes -> a complete
+    AnimatedVertex vertex buffer.  The oracle does the same steps with the reference's formulas."""
+    sc = cases.morph_weights(n_bones=16)
+    n_inst, n_shapes, mesh_node = 3, 7, 4
+    o, p = run_scenario(ctx, orc, sc, n_instances=n_inst, frames=30, check_every=10 ** 9)
+    base = p.base_id
+    bone_nodes = list(range(16))
+    A.create_bone_list(ctx, base + 50, base, bone_nodes)
+    d_pal = ctx.malloc(n_inst * 16 * 64)
+    p.palette(base + 50, d_pal.ptr)
+    # shape k of the mesh is property k of the mesh node; shape 6 is animated by nothing: its default weight applies
+    slots = [p.property_slot(mesh_node, k) for k in range(n_shapes)]
+    assert slots[6] == -1 and all(s >= 0 for s in slots[:6])
+    defaults = np.asarray([10.0, 20.0, 30.0, 40.0, 50.0, 60.0, 35.0], np.float32)
+    d_w = ctx.malloc(n_inst * n_shapes * 4)
+    p.blend_shape_weights(slots, defaults, d_w.ptr)
+    got_w = d_w.download(np.float32, n_inst * n_shapes).reshape(n_inst, n_shapes)
+    ref_w = np.asarray([o.props.get((mesh_node, k), defaults[k]) for k in range(n_shapes)], np.float32) / np.float32(100.0)
+    assert np.array_equal(got_w[0], ref_w) and np.array_equal(got_w[-1], ref_w)
+    mesh = synth.make_mesh(5_003, 16, synth.SEED_BASE + 14, coherent=False)
+    L = synth.ANIMATED_VERTEX
+    ctx.mesh_upload(base + 60, mesh.to_animated_vertex_aos(), mesh.n_verts, L["stride"], off_pos=L["off_pos"],
+                    off_normal=L["off_normal"], off_tangent=L["off_tangent"], off_weights=L["off_weights"],
+                    off_indices=L["off_indices"])
+    storage, plane, _ = synth.make_blend_shapes(mesh.n_verts, n_shapes, synth.SEED_BASE + 14)
+    ctx.mesh_set_blend_shapes(base + 60, storage, n_shapes, plane)
+    vb = ctx.malloc(n_inst * mesh.n_verts * L["stride"])
+    ctx.lbs_skin_ex(base + 60, d_pal.ptr, 16, n_inst, d_blend_shape_weights=d_w.ptr, n_blend_shapes=n_shapes,
+                    d_out_vertices=vb.ptr, out_stride=0)
+    ctx.join()
+    raw = vb.download(np.uint8, n_inst * mesh.n_verts * L["stride"]).reshape(n_inst, mesh.n_verts, L["stride"])
+    bp, bn, bt = orc.apply_blend_shapes(mesh.pos, mesh.normal, mesh.tangent, storage, plane, ref_w)
+    ref = orc.lbs_skin(bp, mesh.weights, mesh.indices, o.palette(bone_nodes), bn, bt, threads=0)
+    for i in (0, n_inst - 1):
+        for off, key in ((L["off_pos"], "pos"), (L["off_normal"], "normal"), (L["off_tangent"], "tangent")):
+            got = np.ascontiguousarray(raw[i][:, off:off + 12]).view(np.float32)
+            check(got, np.ascontiguousarray(ref[key][:, :3]), True, f"vertex buffer {key} (instance {i})")
+    for b in (d_pal, d_w, vb):
+        b.free()
+    ctx.mesh_free(base + 60)
+    o.close()
+    p.free()
+
+
 def test_large_rig_1024_nodes(ctx, orc):
     """The LDS-resident hierarchy walk at its upper limit (1024 nodes = 128 KiB of LDS), deep chains."""
     n = 1024
