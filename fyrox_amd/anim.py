@@ -27,6 +27,7 @@ ALL_INSTANCES = 0xFFFFFFFF
 READ_LOCAL_TRS, READ_LOCAL_MATRIX, READ_GLOBAL_MATRIX, READ_ANIMATION_POSE = 0, 1, 2, 16
 OP_NAMES = ("END", "BLEND_ANIM", "PUSH", "POP_BLEND", "RESET", "MASK", "APPLY", "APPLY_ANIM")
 RM_OP_NAMES = ("END", "SET_ANIM", "BLEND", "COPY")
+EVENTS_ALL, EVENTS_MAX_WEIGHT, EVENTS_MIN_WEIGHT = range(3)
 EVENT_STATE_ENTER, EVENT_STATE_LEAVE, EVENT_ACTIVE_STATE_CHANGED, EVENT_ACTIVE_TRANSITION_CHANGED = range(4)
 
 
@@ -329,6 +330,17 @@ class Animator:
         has = c_int()
         self._check(self._l.fyx_layer_pop_event(self._h, self.id, layer, instance, ev, byref(has)))
         return (ev[0], ev[1], ev[2]) if has.value else None
+
+    def collect_active_animations_events(self, layer: int, strategy: int = 0, instance: int = 0):
+        """MachineLayer::collect_active_animations_events -> (source tuple, [(animation, signal), ...])."""
+        cap = 256
+        ev = np.zeros((cap, 2), np.int32)
+        n = c_uint32()
+        src = (c_int32 * 4)()
+        self._check(self._l.fyx_layer_collect_active_animations_events(self._h, self.id, layer, instance, strategy, _ptr(ev),
+                                                                       cap, byref(n), src))
+        assert n.value <= cap
+        return tuple(src), [(int(a), int(s_)) for a, s_ in ev[:n.value]]
 
     # -- root motion -----------------------------------------------------------------------------
     def set_root_motion_settings(self, a: int, node: Optional[int], ignore_x=False, ignore_y=False, ignore_z=False,

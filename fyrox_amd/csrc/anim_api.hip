@@ -2219,4 +2219,131 @@ int fyx_animator_blend_shape_weights(fyx_ctx* c, uint64_t animator_id, uint32_t 
     FYX_GUARD_END(c)
 }
 
+// ---- MachineLayer::collect_active_animations_events (layer.rs:308-401) -----------------------
+
+namespace {
+struct EventCollector {
+    const Animator& A;
+    const LayerDef& L;
+    const MachineState& ms;
+    const LayerState& LS;
+    const AnimState* as;
+    int strategy;
+    fyx_animation_event* out;
+    uint32_t cap, n = 0;
+
+    const Param* param(int32_t idx) const { return (idx >= 0 && (size_t)idx < ms.params.size()) ? &ms.params[idx] : nullptr; }
+    void push(uint32_t anim, int32_t sig) {
+        if (n < cap) { out[n].animation = anim; out[n].signal = sig; }
+        ++n;
+    }
+    void node(int32_t h) {
+        if (h < 0 || (size_t)h >= L.nodes.size()) return;
+        const PoseNodeDef& nd = L.nodes[h];
+        switch (nd.type) {
+            case NODE_PLAY:  // play.rs:106-122: the animation's queued events, in order, not removed
+                if (nd.animation < A.anims.size())
+                    for (int32_t sgn : as[nd.animation].events) push(nd.animation, sgn);
+                return;
+            case NODE_BLEND: {  // blend.rs:172-222
+                if (strategy == FYX_EVENTS_ALL) { for (const BlendInput& in : nd.inputs) node(in.source); return; }
+                int best = -1;
+                float bw = 0.f;
+                for (size_t i = 0; i < nd.inputs.size(); ++i) {
+                    float w;
+                    if (nd.inputs[i].weight_param < 0) w = nd.inputs[i].weight_const;
+                    else {
+                        const Param* p = param(nd.inputs[i].weight_param);
+                        if (!p || p->kind != FYX_PARAM_WEIGHT) continue;  // PoseWeight::value -> None
+                        w = p->f0;
+                    }
+                    if (best < 0) { best = (int)i; bw = w; continue; }
+                    // Iterator::max_by keeps the LAST of equal maxima, min_by the FIRST of equal minima
+                    if (strategy == FYX_EVENTS_MAX_WEIGHT) { if (!(w < bw)) { best = (int)i; bw = w; } }
+                    else if (w < bw) { best = (int)i; bw = w; }
+                }
+                if (best >= 0) node(nd.inputs[best].source);
+                return;
+            }
+            case NODE_BY_INDEX: {  // blend.rs:370-438
+                const Param* p = param(nd.param);
+                const ByIndexState& st = LS.by_index[nd.by_index_slot];
+                if (!p || p->kind != FYX_PARAM_INDEX || !st.has_prev) return;
+                const uint32_t cur = p->u;
+                if (st.prev != cur) {
+                    if (st.prev < nd.inputs.size() && cur < nd.inputs.size()) {
+                        const BlendInput& pi = nd.inputs[st.prev];
+                        const BlendInput& ci = nd.inputs[cur];
+                        const float interpolator = st.blend_time / ci.blend_time;
+                        if (strategy == FYX_EVENTS_ALL) { node(pi.source); node(ci.source); }
+                        else if (strategy == FYX_EVENTS_MAX_WEIGHT) node((interpolator < 0.5f ? pi : ci).source);
+                        else node((interpolator < 0.5f ? ci : pi).source);
+                    }
+                } else if (cur < nd.inputs.size()) {
+                    node(nd.inputs[cur].source);
+                }
+                return;
+            }
+            case NODE_BLEND_SPACE: {  // blendspace.rs:157-218
+                const Param* p = param(nd.param);
+                if (!p || p->kind != FYX_PARAM_SAMPLING_POINT) return;
+                int idx[3];
+                float w[3];
+                const float sp[2] = {p->f0, p->f1};
+                if (!Planner::blend_space_weights(nd, sp, idx, w)) return;
+                const int32_t src[3] = {nd.inputs[idx[0]].source, nd.inputs[idx[1]].source, nd.inputs[idx[2]].source};
+                for (int k = 0; k < 3; ++k)
+                    if (src[k] < 0 || (size_t)src[k] >= L.nodes.size()) return;
+                if (strategy == FYX_EVENTS_ALL) { for (int k = 0; k < 3; ++k) node(src[k]); return; }
+                int best = 0;
+                for (int k = 1; k < 3; ++k) {
+                    if (strategy == FYX_EVENTS_MAX_WEIGHT) { if (!(w[k] < w[best])) best = k; }
+                    else if (w[k] < w[best]) best = k;
+                }
+                node(src[best]);
+                return;
+            }
+        }
+    }
+};
+}  // namespace
+
+int fyx_layer_collect_active_animations_events(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance,
+                                               int strategy, fyx_animation_event* out_events, uint32_t capacity,
+                                               uint32_t* n_events, fyx_events_source* out_source) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    if (strategy < FYX_EVENTS_ALL || strategy > FYX_EVENTS_MIN_WEIGHT) return fail(c, FYX_ERR_INVALID_ARG, "strategy %d", strategy);
+    if (capacity && !out_events) return fail(c, FYX_ERR_INVALID_ARG, "out_events is null");
+    ensure_machine_state(*A);
+    const MachineState& ms = A->mstate[instance];
+    const LayerState& LS = ms.layers[layer];
+    EventCollector ec{*A, *L, ms, LS, A->anim_state.data() + (size_t)instance * A->anims.size(), strategy, out_events, capacity};
+    fyx_events_source src{0, -1, -1, -1};
+    if (LS.active_state >= 0 && (size_t)LS.active_state < L->states.size()) {
+        src = fyx_events_source{1, LS.active_state, -1, -1};
+        ec.node(L->states[LS.active_state].root);
+    } else if (LS.active_transition >= 0 && (size_t)LS.active_transition < L->transitions.size()) {
+        const TransitionDef& tr = L->transitions[LS.active_transition];
+        if (tr.source < L->states.size() && tr.dest < L->states.size()) {
+            src = fyx_events_source{2, LS.active_transition, (int32_t)tr.source, (int32_t)tr.dest};
+            const float bf = LS.transitions[LS.active_transition].blend_factor;
+            if (strategy == FYX_EVENTS_ALL) {
+                ec.node(L->states[tr.source].root);
+                ec.node(L->states[tr.dest].root);
+            } else {
+                const bool pick_source = strategy == FYX_EVENTS_MAX_WEIGHT ? bf < 0.5f : !(bf < 0.5f);
+                ec.node(L->states[pick_source ? tr.source : tr.dest].root);
+            }
+        }
+    }
+    if (n_events) *n_events = ec.n;
+    if (out_source) *out_source = src;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
 }  // extern "C"

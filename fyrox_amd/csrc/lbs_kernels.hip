@@ -194,15 +194,60 @@ __device__ __forceinline__ Skinned skin_vertex_impl(const f32x4* __restrict__ ro
     return o;
 }
 
+// Fused mode for VALU-bound launches (crowds): blend the four matrices first, M = sum_k w_k M_k, then transform
+// position / normal / tangent once.  For affine palettes this is the same linear map as sum_k (M_k v) w_k -- only
+// the rounding differs (a few 1e-7 relative, inside the 1e-5 bar of lbs.exact=0) -- and costs ~40 packed VALU
+// instead of ~138: 24 for the blend (three float4 per bone, two pk-FMAs each) and 15 for the three transforms.
+template <int MASK>
+__device__ __forceinline__ Skinned skin_vertex_blended(const f32x4* __restrict__ rows, uint32_t id, f32x4 w, float px,
+                                                       float py, float pz, float nx, float ny, float nz, float tx,
+                                                       float ty, float tz) {
+    f32x2 a_lo, a_hi, b_lo, b_hi, c_lo, c_hi;
+    {
+        const uint32_t b0 = id & 0xffu;
+        const f32x4 A = rows[b0 * 3 + 0], B = rows[b0 * 3 + 1], C = rows[b0 * 3 + 2];
+        const f32x2 ww = splat(w[0]);
+        a_lo = A.xy * ww; a_hi = A.zw * ww; b_lo = B.xy * ww; b_hi = B.zw * ww; c_lo = C.xy * ww; c_hi = C.zw * ww;
+    }
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const uint32_t b = (id >> (8 * k)) & 0xffu;
+        const f32x4 A = rows[b * 3 + 0], B = rows[b * 3 + 1], C = rows[b * 3 + 2];
+        const f32x2 ww = splat(w[k]);
+        a_lo = __builtin_elementwise_fma(A.xy, ww, a_lo); a_hi = __builtin_elementwise_fma(A.zw, ww, a_hi);
+        b_lo = __builtin_elementwise_fma(B.xy, ww, b_lo); b_hi = __builtin_elementwise_fma(B.zw, ww, b_hi);
+        c_lo = __builtin_elementwise_fma(C.xy, ww, c_lo); c_hi = __builtin_elementwise_fma(C.zw, ww, c_hi);
+    }
+    // blended rows: (m00,m10) (m01,m11) (m02,m12) (t0,t1) (m20,m21) (m22,t2)
+    Skinned o;
+    o.px = o.py = o.pz = o.nx = o.ny = o.nz = o.tx = o.ty = o.tz = 0.f;
+    if constexpr (MASK & 1) {
+        const f32x2 xy = __builtin_elementwise_fma(b_lo, splat(pz), __builtin_elementwise_fma(a_hi, splat(py),
+                         __builtin_elementwise_fma(a_lo, splat(px), b_hi)));
+        o.px = xy.x; o.py = xy.y;
+        o.pz = __builtin_fmaf(c_hi.x, pz, __builtin_fmaf(c_lo.y, py, __builtin_fmaf(c_lo.x, px, c_hi.y)));
+    }
+    if constexpr ((MASK & 6) != 0) {
+        const f32x2 vx = {nx, tx}, vy = {ny, ty}, vz = {nz, tz};
+        const f32x2 rx = __builtin_elementwise_fma(splat(b_lo.x), vz, __builtin_elementwise_fma(splat(a_hi.x), vy, splat(a_lo.x) * vx));
+        const f32x2 ry = __builtin_elementwise_fma(splat(b_lo.y), vz, __builtin_elementwise_fma(splat(a_hi.y), vy, splat(a_lo.y) * vx));
+        const f32x2 rz = __builtin_elementwise_fma(splat(c_hi.x), vz, __builtin_elementwise_fma(splat(c_lo.y), vy, splat(c_lo.x) * vx));
+        o.nx = rx.x; o.ny = ry.x; o.nz = rz.x;
+        o.tx = rx.y; o.ty = ry.y; o.tz = rz.y;
+    }
+    return o;
+}
+
 // `projective` is workgroup-uniform: the affine path (the only kind of palette Fyrox produces)
 // is one straight-line block of packed math; the homogeneous divide lives in its own copy.
-template <bool EXACT, int MASK>
+template <bool EXACT, int MASK, bool BLEND_FIRST = false>
 __device__ __forceinline__ Skinned skin_vertex(const f32x4* __restrict__ rows,
                                                const f32x4* __restrict__ row3, bool projective,
                                                uint32_t id, f32x4 w, float px, float py, float pz,
                                                float nx, float ny, float nz, float tx, float ty,
                                                float tz) {
     if (projective) return skin_vertex_impl<EXACT, MASK, true>(rows, row3, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
+    if constexpr (!EXACT && BLEND_FIRST) return skin_vertex_blended<MASK>(rows, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
     return skin_vertex_impl<EXACT, MASK, false>(rows, row3, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
 }
 
@@ -404,8 +449,9 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
         bool projective = false;
 #pragma unroll
         for (uint32_t wv = 0; wv < WPB; ++wv) projective |= flags[cur * WPB + wv] != 0;
-        const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, vin.id, vin.w, vin.px, vin.py,
-                                                   vin.pz, vin.nx, vin.ny, vin.nz, vin.t.x, vin.t.y, vin.t.z);
+        // the crowd kernel is VALU-bound, so its fused mode blends the matrices first (see skin_vertex_blended)
+        const Skinned o = skin_vertex<EXACT, MASK, true>(rows, row3, projective, vin.id, vin.w, vin.px, vin.py,
+                                                         vin.pz, vin.nx, vin.ny, vin.nz, vin.t.x, vin.t.y, vin.t.z);
         if (live) {
             const size_t ov = (size_t)inst * a.n_verts + v;
             if constexpr (MASK & 1) st3<true>(a.out_pos + ov * 3, o.px, o.py, o.pz);

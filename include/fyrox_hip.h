@@ -455,6 +455,19 @@ enum { FYX_EVENT_STATE_ENTER = 0,               /* a = state */
        FYX_EVENT_ACTIVE_STATE_CHANGED = 2,      /* a = prev, b = new */
        FYX_EVENT_ACTIVE_TRANSITION_CHANGED = 3  /* a = transition or -1 */ };
 typedef struct fyx_layer_event { int32_t kind, a, b; } fyx_layer_event;
+/* MachineLayer::collect_active_animations_events (layer.rs:308-401): the queued events of the animations behind the
+ * active state (or the active transition's states), filtered by AnimationEventCollectionStrategy (node/mod.rs:
+ * 177-184; blend nodes pick the source with the largest / smallest weight, Iterator::max_by / min_by tie rules
+ * included).  Nothing is removed from the animations' queues.  *n_events = number found (out_events holds at most
+ * `capacity`); signal = the index fyx_animation_add_signal returned. */
+enum { FYX_EVENTS_ALL = 0, FYX_EVENTS_MAX_WEIGHT = 1, FYX_EVENTS_MIN_WEIGHT = 2 };
+typedef struct fyx_animation_event { uint32_t animation; int32_t signal; } fyx_animation_event;
+/* AnimationEventsSource: kind 0 Invalid, 1 State{handle}, 2 Transition{handle, source_state, dest_state} */
+typedef struct fyx_events_source { int32_t kind, handle, source_state, dest_state; } fyx_events_source;
+int fyx_layer_collect_active_animations_events(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
+                                               uint32_t instance, int strategy,
+                                               fyx_animation_event* out_events, uint32_t capacity,
+                                               uint32_t* n_events, fyx_events_source* out_source);
 /* *out_has = 0 when the queue is empty */
 int fyx_layer_pop_event(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance,
                         fyx_layer_event* out_event, int* out_has);

@@ -357,6 +357,7 @@ def _alib():
             "fo_animation_set_root_motion_settings": [c_void_p, c_int, c_int, c_int, c_int, c_int],
             "fo_animation_root_motion": [c_void_p, c_void_p, c_void_p],
             "fo_layer_pop_event": [c_void_p, c_int, c_void_p],
+            "fo_layer_collect_active_animations_events": [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
         }.items():
             getattr(l, name).argtypes = args
         _anim_bound = True
@@ -569,6 +570,14 @@ class AnimScene:
     def pop_layer_event(self, layer: int):
         ev = (c_int * 3)()
         return (ev[0], ev[1], ev[2]) if self.l.fo_layer_pop_event(self.machine, layer, ev) else None
+
+    def collect_active_animations_events(self, layer: int, strategy: int = 0):
+        arr = (c_void_p * max(len(self.anims), 1))(*self.anims)
+        pairs = np.zeros((256, 2), np.int32)
+        src = (c_int * 4)()
+        n = self.l.fo_layer_collect_active_animations_events(self.machine, layer, arr, len(self.anims), strategy, _p(pairs), 256, src)
+        assert n <= 256
+        return tuple(src), [(int(a), int(s)) for a, s in pairs[:n]]
 
     def animation_state(self, a: int) -> dict:
         h = self.anims[a]

@@ -218,6 +218,10 @@ void fo_state_add_action(fo_machine*, int layer, int state, int on_enter, int ki
 int fo_layer_add_transition(fo_machine*, int layer, int source, int dest, float time,
                             const int* logic, int n_logic);
 int fo_layer_pop_event(fo_machine*, int layer, int out[3]); /* 0 == None */
+/* AnimationEventCollectionStrategy (node/mod.rs:177-184) and MachineLayer::collect_active_animations_events */
+enum { FO_EVENTS_ALL = 0, FO_EVENTS_MAX_WEIGHT = 1, FO_EVENTS_MIN_WEIGHT = 2 };
+int fo_layer_collect_active_animations_events(const fo_machine*, int layer, fo_animation* const* anims, int n_anims,
+                                              int strategy, int* pairs, int cap, int source[4]);
 int fo_layer_active_state(const fo_machine*, int layer);
 int fo_layer_active_transition(const fo_machine*, int layer);
 const fo_pose* fo_layer_pose(const fo_machine*, int layer);

@@ -1006,6 +1006,120 @@ static const fo_pose* node_eval(eval_ctx* c, int handle) {
     }
 }
 
+/* ---- collect_animation_events (node/play.rs:106-122, blend.rs:172-222, :370-438, blendspace.rs:157-218) ---- */
+typedef struct ev_out { int* pairs; int cap, n; } ev_out; /* (animation, signal index) pairs */
+
+static void ev_push(ev_out* o, int anim, int sig) {
+    if (o->n < o->cap) { o->pairs[o->n * 2] = anim; o->pairs[o->n * 2 + 1] = sig; }
+    ++o->n;
+}
+
+static void node_collect_events(const fo_machine* m, const fo_layer* L, int handle, fo_animation* const* anims,
+                                int n_anims, int strategy, ev_out* out) {
+    if (handle < 0 || handle >= L->n_nodes) return; /* nodes.try_borrow failed */
+    const fo_pose_node* n = &L->nodes[handle];
+    switch (n->type) {
+    case FO_NODE_PLAY: /* every queued event of the animation, in queue order; nothing is removed */
+        if (n->animation >= 0 && n->animation < n_anims && anims[n->animation]) {
+            const fo_animation* a = anims[n->animation];
+            for (int i = 0; i < a->n_events; ++i) ev_push(out, n->animation, a->events[(a->ev_head + i) % a->ev_cap]);
+        }
+        return;
+    case FO_NODE_BLEND: {
+        if (strategy == FO_EVENTS_ALL) {
+            for (int i = 0; i < n->n_inputs; ++i) node_collect_events(m, L, n->inputs[i].source, anims, n_anims, strategy, out);
+            return;
+        }
+        /* filter_map(weight.value(params)) then max_by (LAST of equal maxima) / min_by (FIRST of equal minima),
+         * partial_cmp().unwrap_or(Equal) */
+        int best = -1; float bw = 0.0f;
+        for (int i = 0; i < n->n_inputs; ++i) {
+            float w;
+            if (n->inputs[i].weight_param < 0) w = n->inputs[i].weight_const;
+            else {
+                const fo_param* p = get_param(m, n->inputs[i].weight_param);
+                if (!p || p->kind != FO_PARAM_WEIGHT) continue; /* value() -> None */
+                w = p->f[0];
+            }
+            if (best < 0) { best = i; bw = w; continue; }
+            if (strategy == FO_EVENTS_MAX_WEIGHT) { if (!(w < bw)) { best = i; bw = w; } } /* >= or unordered: later wins */
+            else { if (w < bw) { best = i; bw = w; } }                                      /* strictly smaller: first wins */
+        }
+        if (best >= 0) node_collect_events(m, L, n->inputs[best].source, anims, n_anims, strategy, out);
+        return;
+    }
+    case FO_NODE_BLEND_BY_INDEX: {
+        const fo_param* p = get_param(m, n->param);
+        if (!p || p->kind != FO_PARAM_INDEX || !n->has_prev_index) return;
+        uint32_t cur = p->u;
+        if (n->prev_index != cur) {
+            if (n->prev_index < (uint32_t)n->n_inputs && cur < (uint32_t)n->n_inputs) {
+                const fo_blend_input* pi = &n->inputs[n->prev_index];
+                const fo_blend_input* ci = &n->inputs[cur];
+                float interpolator = n->blend_time / ci->blend_time;
+                if (strategy == FO_EVENTS_ALL) {
+                    node_collect_events(m, L, pi->source, anims, n_anims, strategy, out);
+                    node_collect_events(m, L, ci->source, anims, n_anims, strategy, out);
+                } else if (strategy == FO_EVENTS_MAX_WEIGHT) {
+                    node_collect_events(m, L, (interpolator < 0.5f ? pi : ci)->source, anims, n_anims, strategy, out);
+                } else {
+                    node_collect_events(m, L, (interpolator < 0.5f ? ci : pi)->source, anims, n_anims, strategy, out);
+                }
+            }
+        } else if (cur < (uint32_t)n->n_inputs) {
+            node_collect_events(m, L, n->inputs[cur].source, anims, n_anims, strategy, out);
+        }
+        return;
+    }
+    case FO_NODE_BLEND_SPACE: {
+        const fo_param* p = get_param(m, n->param);
+        if (!p || p->kind != FO_PARAM_SAMPLING_POINT) return;
+        int idx[3]; float w[3];
+        if (!fo_blend_space_fetch_weights(n->n_inputs, n->points, n->n_tris, n->tris, p->f, idx, w)) return;
+        int src[3] = { n->inputs[idx[0]].source, n->inputs[idx[1]].source, n->inputs[idx[2]].source };
+        for (int k = 0; k < 3; ++k) if (src[k] < 0 || src[k] >= L->n_nodes) return;
+        if (strategy == FO_EVENTS_ALL) {
+            for (int k = 0; k < 3; ++k) node_collect_events(m, L, src[k], anims, n_anims, strategy, out);
+            return;
+        }
+        int best = 0;
+        for (int k = 1; k < 3; ++k) {
+            if (strategy == FO_EVENTS_MAX_WEIGHT) { if (!(w[k] < w[best])) best = k; }
+            else { if (w[k] < w[best]) best = k; }
+        }
+        node_collect_events(m, L, src[best], anims, n_anims, strategy, out);
+        return;
+    }
+    default: return;
+    }
+}
+
+/* layer.rs:308-401 MachineLayer::collect_active_animations_events.  source[4] = {kind 0 Invalid / 1 State /
+ * 2 Transition, handle, source state, dest state}; returns the number of events (pairs hold at most cap). */
+int fo_layer_collect_active_animations_events(const fo_machine* m, int layer, fo_animation* const* anims, int n_anims,
+                                              int strategy, int* pairs, int cap, int source[4]) {
+    const fo_layer* L = &m->layers[layer];
+    ev_out out = { pairs, cap, 0 };
+    source[0] = 0; source[1] = source[2] = source[3] = -1;
+    if (L->active_state >= 0 && L->active_state < L->n_states) {
+        source[0] = 1; source[1] = L->active_state;
+        node_collect_events(m, L, L->states[L->active_state].root, anims, n_anims, strategy, &out);
+    } else if (L->active_transition >= 0 && L->active_transition < L->n_transitions) {
+        const fo_transition* tr = &L->transitions[L->active_transition];
+        if (tr->source >= 0 && tr->source < L->n_states && tr->dest >= 0 && tr->dest < L->n_states) {
+            source[0] = 2; source[1] = L->active_transition; source[2] = tr->source; source[3] = tr->dest;
+            if (strategy == FO_EVENTS_ALL) {
+                node_collect_events(m, L, L->states[tr->source].root, anims, n_anims, strategy, &out);
+                node_collect_events(m, L, L->states[tr->dest].root, anims, n_anims, strategy, &out);
+            } else {
+                int pick_source = strategy == FO_EVENTS_MAX_WEIGHT ? tr->blend_factor < 0.5f : !(tr->blend_factor < 0.5f);
+                node_collect_events(m, L, L->states[pick_source ? tr->source : tr->dest].root, anims, n_anims, strategy, &out);
+            }
+        }
+    }
+    return out.n;
+}
+
 /* node/mod.rs:116-150 collect_animations (set semantics via the `seen` array) */
 static void node_collect(const fo_layer* L, int handle, unsigned char* seen, int n_anims) {
     if (handle < 0 || handle >= L->n_nodes) return;

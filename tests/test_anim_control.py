@@ -160,6 +160,9 @@ def test_control_plane_matches_oracle(orc, cctx, make):
         if sc.machine:
             for li in range(len(sc.machine.layers)):
                 assert p.layer_state(li, 0) == o.layer_state(li), (f, li)
+                for strategy in (A.EVENTS_ALL, A.EVENTS_MAX_WEIGHT, A.EVENTS_MIN_WEIGHT):   # a query: nothing is consumed
+                    assert p.collect_active_animations_events(li, strategy, 1) == o.collect_active_animations_events(li, strategy), \
+                        (f, li, strategy)
                 ref = _drain(lambda: o.pop_layer_event(li))
                 assert _drain(lambda: p.pop_layer_event(li, 0)) == ref, (f, li)
                 assert _drain(lambda: p.pop_layer_event(li, 1)) == ref, (f, li)

@@ -124,6 +124,25 @@ def test_equal_share_split_covers_every_vertex_once(ctx, orc, n_inst, n_verts):
     assert_bit_exact(ctx.lbs_skin(9, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst))
 
 
+@pytest.mark.parametrize("n_inst,block", [(24, 512), (7, 256), (4, 512)])
+def test_crowd_fused_mode_blends_matrices_first_within_1e5(ctx, orc, n_inst, block):
+    """lbs.exact=0 on the crowd kernel: M = sum_k w_k M_k, then one transform (tolerance 1e-5 relative, north_star);
+    a projective palette still takes the per-bone path with the homogeneous divide."""
+    m = synth.make_mesh(10_007, 64, 321, coherent=False)
+    pal = synth.make_palette(64, 321, n_instances=n_inst)
+    upload(ctx, 7, m)
+    ctx.set_option("lbs.exact", 0); ctx.set_option("lbs.crowd", 1); ctx.set_option("lbs.crowd_block", block)
+    got, ref = ctx.lbs_skin(7, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst)
+    for k in ("pos", "normal", "tangent"):
+        assert rel_err(got[k], ref[k]) <= REL_TOL, k
+    assert np.array_equal(got["tangent"][:, 3], np.tile(m.tangent[:, 3], n_inst))
+    proj = pal.copy()
+    proj[5::64, 3] = 0.25; proj[5::64, 15] = 1.5      # bone 5 of every instance: a projective row
+    got, ref = ctx.lbs_skin(7, proj, n_instances=n_inst), oracle_skin(orc, m, proj, n_inst)
+    for k in ("pos", "normal", "tangent"):
+        assert rel_err(got[k], ref[k]) <= REL_TOL, k
+
+
 @pytest.mark.parametrize("prefetch", [0, 1])
 def test_fused_mode_within_1e5(ctx, orc, prefetch):
     m = synth.make_mesh(100_000, 64, 123)

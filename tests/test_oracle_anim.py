@@ -289,3 +289,25 @@ def test_layer_events_follow_a_transition(orc):
     assert log[3:5] == [(A.EVENT_ACTIVE_TRANSITION_CHANGED, -1, -1), (A.EVENT_ACTIVE_STATE_CHANGED, 0, 1)]
     assert sum(1 for e in log if e[0] == A.EVENT_ACTIVE_STATE_CHANGED) >= 3
     o.close()
+
+
+def test_collect_active_animations_events_strategies(orc):
+    # layer.rs:308-401 + blend.rs:172-222: All concatenates the sources in order; MaxWeight uses Iterator::max_by (the LAST of
+    # equal maxima), MinWeight Iterator::min_by (the FIRST of equal minima); a source whose weight parameter is missing or
+    # mistyped (PoseWeight::value -> None) does not take part; events stay in the animations' queues
+    td, tgt = _linear_root_clip((0, 0, 0), (1, 0, 0))
+    s = orc.AnimScene(synth.make_rig(2, 5))
+    for _ in range(4):
+        s.add_animation(s.add_tracks_data(td), tgt, time_slice=(0.0, 1.0), looped=True, signals=[(0.05, True), (0.1, True)])
+    nodes = [A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2), A.PlayAnimation(3),
+             A.BlendAnimations([A.BlendPose(0, 0.2), A.BlendPose(1, 0.7), A.BlendPose(2, 0.7), A.BlendPose(3, parameter=0)])]
+    s.set_machine(A.Machine([A.Parameter(A.PARAM_RULE, True)],      # parameter 0 is not a Weight: source 3 has no weight
+                            [A.MachineLayer(nodes=nodes, states=[A.State(4)])]))
+    s.update_machine(0.125)      # every animation crosses both signals
+    src, ev = s.collect_active_animations_events(0, A.EVENTS_ALL)
+    assert src == (1, 0, -1, -1)
+    assert ev == [(a, sg) for a in range(4) for sg in (0, 1)]
+    assert s.collect_active_animations_events(0, A.EVENTS_MAX_WEIGHT)[1] == [(2, 0), (2, 1)]
+    assert s.collect_active_animations_events(0, A.EVENTS_MIN_WEIGHT)[1] == [(0, 0), (0, 1)]
+    assert s.event_count(1) == 2                                       # a query: nothing was consumed
+    s.close()
