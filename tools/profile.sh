@@ -20,5 +20,9 @@ python $ROOT/tools/bench_pose.py --root-motion > "$ROOT/$OUT/pose_root_motion.js
 # extended launches: blend shapes, vertex-buffer-in / vertex-buffer-out
 python $ROOT/tools/bench_ex.py > "$ROOT/$OUT/bench_ex.json" 2> "$ROOT/$OUT/bench_ex.err"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_ex" -o ex -- python $ROOT/tools/bench_ex.py --streams 1 --steps 300 > "$ROOT/$OUT/bench_ex_under_trace.json" 2> "$ROOT/$OUT/trace_ex.err" )
+python $ROOT/tools/bench_pose.py --opt lbs.streams=1 --opt lbs.exact=0 > "$ROOT/$OUT/pose_fused.json" 2> "$ROOT/$OUT/pose_fused.err"
+python $ROOT/tools/probe_timeline.py --opt lbs.blocks_per_cu=2 > "$ROOT/$OUT/timeline.json" 2> "$ROOT/$OUT/timeline.err"
+python $ROOT/tools/write_ceiling.py > "$ROOT/$OUT/write_ceiling.json" 2> "$ROOT/$OUT/write_ceiling.err"
+python $ROOT/tools/calib.py --rounds 2 > "$ROOT/$OUT/calibration_stream.json" 2> "$ROOT/$OUT/calib.err"
 find "$OUT" -name "*.csv" | head -40
 du -sh "$OUT"
