@@ -177,8 +177,10 @@ struct Animator {
     bool masks_dirty = true;
     uint32_t dev_mask_layers = 0;
     // per-frame control (device + pinned staging)
-    void* d_ctrl = nullptr;
-    size_t d_ctrl_bytes = 0;
+    void* d_ctrl[2] = {nullptr, nullptr};     // double-buffered like the staging: frame k+1 uploads while frame k runs
+    size_t d_ctrl_bytes[2] = {0, 0};
+    hipEvent_t d_ctrl_consumed[2] = {nullptr, nullptr};   // the kernels that read d_ctrl[slot] have finished
+    bool d_ctrl_in_use[2] = {false, false};
     void* h_ctrl[2] = {nullptr, nullptr};
     size_t h_ctrl_bytes[2] = {0, 0};
     hipEvent_t h_ctrl_ev[2] = {nullptr, nullptr};
@@ -240,7 +242,9 @@ void free_animator(Animator& a) {
     for (auto& an : a.anims) { dfree(an.d_slot_track); dfree(an.d_prop_track); }
     dfree(a.d_prop_node); dfree(a.d_prop_pose); dfree(a.d_prop_out);
     dfree(a.d_anims); dfree(a.d_hints); dfree(a.d_anim_pose); dfree(a.d_node_trs); dfree(a.d_local);
-    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_ctrl); dfree(a.d_rm_anim); dfree(a.d_rm_slots);
+    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_ctrl[0]); dfree(a.d_ctrl[1]); dfree(a.d_rm_anim); dfree(a.d_rm_slots);
+    for (int i = 0; i < 2; ++i)
+        if (a.d_ctrl_consumed[i]) (void)hipEventDestroy(a.d_ctrl_consumed[i]);
     for (int i = 0; i < 2; ++i) {
         if (a.h_ctrl[i]) (void)hipHostFree(a.h_ctrl[i]);
         if (a.h_ctrl_ev[i]) (void)hipEventDestroy(a.h_ctrl_ev[i]);
@@ -1080,6 +1084,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     f.prop_node = A.d_prop_node;
     f.prop_pose = A.d_prop_pose;
     f.prop_out = A.d_prop_out;
+    int ctrl_slot = 0;
     if (with_program) {
         const size_t b_times = align_up(A.times.size() * 4, 256), b_tick = align_up(A.ticked.size(), 256);
         const size_t b_off = align_up(A.prog_off.size() * 4, 256), b_ops = align_up(A.ops.size() * 8, 256);
@@ -1103,14 +1108,17 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
             A.h_ctrl_bytes[slot] = want;
         }
         if (!A.h_ctrl_ev[slot]) FYX_HIP(c, hipEventCreateWithFlags(&A.h_ctrl_ev[slot], hipEventDisableTiming));
-        if (total > A.d_ctrl_bytes) {
+        if (total > A.d_ctrl_bytes[slot]) {
             FYX_HIP(c, hipStreamSynchronize(c->stream));
-            dfree(A.d_ctrl);
-            A.d_ctrl = nullptr;
+            dfree(A.d_ctrl[slot]);
+            A.d_ctrl[slot] = nullptr;
             const size_t want = align_up(total + total / 2, 4096);
-            FYX_HIP(c, hipMalloc(&A.d_ctrl, want));
-            A.d_ctrl_bytes = want;
+            FYX_HIP(c, hipMalloc(&A.d_ctrl[slot], want));
+            A.d_ctrl_bytes[slot] = want;
+            A.d_ctrl_in_use[slot] = false;
         }
+        if (!A.d_ctrl_consumed[slot]) FYX_HIP(c, hipEventCreateWithFlags(&A.d_ctrl_consumed[slot], hipEventDisableTiming));
+        if (!c->upload_stream) FYX_HIP(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
         char* h = static_cast<char*>(A.h_ctrl[slot]);
         memcpy(h, A.times.data(), A.times.size() * 4);
         memcpy(h + b_times, A.ticked.data(), A.ticked.size());
@@ -1121,10 +1129,16 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
             memcpy(h + o_rmoff, A.rm_prog_off.data(), A.rm_prog_off.size() * 4);
             memcpy(h + o_rmops, A.rm_ops.data(), A.rm_ops.size() * 16);
         }
-        FYX_HIP(c, hipMemcpyAsync(A.d_ctrl, h, total, hipMemcpyHostToDevice, c->stream));
-        FYX_HIP(c, hipEventRecord(A.h_ctrl_ev[slot], c->stream));
+        // The control block has no dependence on the kernels already queued on the context stream (the previous
+        // frame's skinning, typically ~100 us of work), so it travels on its own stream and only the frame's first
+        // kernel waits for it; in-stream it would sit behind that work and add its ~25 us to every frame.
+        if (A.d_ctrl_in_use[slot]) FYX_HIP(c, hipStreamWaitEvent(c->upload_stream, A.d_ctrl_consumed[slot], 0));
+        FYX_HIP(c, hipMemcpyAsync(A.d_ctrl[slot], h, total, hipMemcpyHostToDevice, c->upload_stream));
+        FYX_HIP(c, hipEventRecord(A.h_ctrl_ev[slot], c->upload_stream));
+        FYX_HIP(c, hipStreamWaitEvent(c->stream, A.h_ctrl_ev[slot], 0));
         A.h_ctrl_busy[slot] = true;
-        char* d = static_cast<char*>(A.d_ctrl);
+        ctrl_slot = slot;
+        char* d = static_cast<char*>(A.d_ctrl[slot]);
         f.times = reinterpret_cast<const float*>(d);
         f.ticked = reinterpret_cast<const uint8_t*>(d + b_times);
         f.prog_off = reinterpret_cast<const uint32_t*>(d + b_times + b_tick);
@@ -1142,7 +1156,11 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         }
     }
     FYX_HIP(c, launch_pose_update(f, rig_dev(*A.rig), with_program, c->stream));
-    if (with_program) FYX_HIP(c, launch_property_update(f, c->stream));
+    if (with_program) {
+        FYX_HIP(c, launch_property_update(f, c->stream));
+        FYX_HIP(c, hipEventRecord(A.d_ctrl_consumed[ctrl_slot], c->stream));
+        A.d_ctrl_in_use[ctrl_slot] = true;
+    }
     return FYX_OK;
 }
 

@@ -212,6 +212,7 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->upload_stream) { (void)hipStreamSynchronize(c->upload_stream); (void)hipStreamDestroy(c->upload_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

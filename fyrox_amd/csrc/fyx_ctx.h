@@ -41,6 +41,7 @@ using fyx::Mesh;
 struct fyx_ctx {
     int device = 0;          // -1: control-only context (no GPU; data-path calls fail)
     hipStream_t own_stream = nullptr;
+    hipStream_t upload_stream = nullptr;   // per-frame control blocks of the pose path (anim_api.hip)
     hipStream_t stream = nullptr;
     fyx::LbsTuning lbs;
     std::unordered_map<uint64_t, Mesh> meshes;
