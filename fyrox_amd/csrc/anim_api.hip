@@ -913,14 +913,10 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         if (A.d_anim_pose && A.dev_anim_capacity)
             FYX_HIP(c, hipMemcpy(np, A.d_anim_pose, (size_t)A.dev_anim_capacity * in * 48, hipMemcpyDeviceToDevice));
         if (A.d_hints && A.dev_anim_capacity && A.dev_track_capacity) {
-            if (new_tracks == A.dev_track_capacity) {
-                FYX_HIP(c, hipMemcpy(nh, A.d_hints, (size_t)A.dev_anim_capacity * A.n_instances * new_tracks * 16,
-                                     hipMemcpyDeviceToDevice));
-            } else {
-                FYX_HIP(c, hipMemcpy2D(nh, (size_t)new_tracks * 16, A.d_hints, (size_t)A.dev_track_capacity * 16,
-                                       (size_t)A.dev_track_capacity * 16,
-                                       (size_t)A.dev_anim_capacity * A.n_instances, hipMemcpyDeviceToDevice));
-            }
+            // layout [anim][track][curve][instance]: one row per animation, old rows are a prefix of the new ones
+            const size_t old_row = (size_t)A.dev_track_capacity * 16 * A.n_instances;
+            const size_t new_row = (size_t)new_tracks * 16 * A.n_instances;
+            FYX_HIP(c, hipMemcpy2D(nh, new_row, A.d_hints, old_row, old_row, A.dev_anim_capacity, hipMemcpyDeviceToDevice));
         }
         dfree(A.d_anim_pose);
         dfree(A.d_hints);
@@ -1076,6 +1072,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     f.layer_masks = A.d_layer_masks;
     f.hints = A.d_hints;
     f.max_tracks = A.dev_track_capacity;
+    f.sample_form = (uint32_t)c->sample_form;
     f.anim_pose = A.d_anim_pose;
     f.node_trs = A.d_node_trs;
     f.local = A.d_local;

@@ -62,17 +62,30 @@ __device__ __forceinline__ float interpolate_keys(const float* __restrict__ loc,
 // common outcomes need -- the first and last key (clamping) and the two keys of the hinted span -- is therefore
 // fetched in ONE round trip right after the hint is known (eight independent loads), and only a hint miss pays
 // for the binary search.  The decisions are taken in the reference's order on the same values.
-__device__ float curve_value_at(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
-                                float location, uint32_t& hint) {
+struct CurveKeys {   // the eight values the common outcomes of value_at need, fetched in one round trip
+    float l_first, l_last, l_hl, l_h;
+    f4 a_first, a_last, a_hl, a_h;
+};
+
+__device__ __forceinline__ CurveKeys curve_fetch(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
+                                                 uint32_t h) {
+    CurveKeys k;
+    const uint32_t nn = n ? n : 1;                                    // an empty curve reads key 0 of its successor, unused
+    const uint32_t hc = h < nn ? h : nn - 1, hl = hc > 0 ? hc - 1 : 0;   // clamped: addresses stay inside the curve
+    k.l_first = loc[0]; k.l_last = loc[nn - 1]; k.l_hl = loc[hl]; k.l_h = loc[hc];
+    k.a_first = aux[0]; k.a_last = aux[nn - 1]; k.a_hl = aux[hl]; k.a_h = aux[hc];
+    return k;
+}
+
+// The decisions of value_at, in the reference's order, on values fetched earlier.
+__device__ __forceinline__ float curve_eval(const CurveKeys& k, const float* __restrict__ loc, const f4* __restrict__ aux,
+                                            uint32_t n, float location, uint32_t& hint) {
     if (n == 0) return 0.0f;
     const uint32_t h = hint;
-    const uint32_t hc = h < n ? h : n - 1, hl = hc > 0 ? hc - 1 : 0;   // clamped: addresses stay inside the curve
-    const float l_first = loc[0], l_last = loc[n - 1], l_hl = loc[hl], l_h = loc[hc];
-    const f4 a_first = aux[0], a_last = aux[n - 1], a_hl = aux[hl], a_h = aux[hc];
-    if (location <= l_first) { hint = 0; return a_first.x; }
-    if (location >= l_last) { hint = n - 1; return a_last.x; }
+    if (location <= k.l_first) { hint = 0; return k.a_first.x; }
+    if (location >= k.l_last) { hint = n - 1; return k.a_last.x; }
     if (h < n) {
-        if (location >= l_hl && location < l_h) return interpolate_loaded(l_hl, l_h, a_hl, a_h, location);
+        if (location >= k.l_hl && location < k.l_h) return interpolate_loaded(k.l_hl, k.l_h, k.a_hl, k.a_h, location);
     }
     uint32_t lo = 0, hi = n;  // partition_point(|k| k.location < location)
     while (lo < hi) {
@@ -81,6 +94,18 @@ __device__ float curve_value_at(const float* __restrict__ loc, const f4* __restr
     }
     hint = lo;
     return interpolate_keys(loc, aux, lo > 0 ? lo - 1 : 0, lo, location);
+}
+
+__device__ float curve_value_at(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
+                                float location, uint32_t& hint) {
+    if (n == 0) return 0.0f;
+    const CurveKeys k = curve_fetch(loc, aux, n, hint);
+    return curve_eval(k, loc, aux, n, location, hint);
+}
+
+// Span hint of (animation a, track, curve c, instance): Curve::value_at's `&mut usize`.
+__device__ __forceinline__ uint32_t* hint_ptr(const PoseFrameDev& f, uint32_t a, uint32_t track, uint32_t c, uint32_t inst) {
+    return f.hints + (((size_t)a * f.max_tracks + track) * 4 + c) * f.n_instances + inst;
 }
 
 // nalgebra leaves, in nalgebra's operation order
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
                                                           : (kind == FYX_KIND_VEC3);
             valid = fits && need > 0 && (int)tk->n_curves >= need;   // else fetch() -> None
             if (valid && c < need) {
-                uint32_t* hp = f.hints + (((size_t)a * f.n_instances + inst) * f.max_tracks + track) * 4 + c;
+                uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
                 uint32_t hint = *hp;
                 const uint32_t fk = tk->first_key[c];
                 v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c],
@@ -203,10 +228,96 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Crowd form of pose_sample: the lanes of a wave are 64 INSTANCES of one (animation, node).
+//
+// The form above puts the curves of one instance side by side, so the lanes of every key load hit up to 64 different
+// cache lines (ten scattered requests per curve sample -- the texture-addresser, not VALU or HBM, sets its 51 us on
+// the C3 crowd).  A crowd samples the SAME curves at different times: with instances on the lanes, a load of a
+// curve's keys touches the few lines around the instances' playback positions, the span hints (instance-minor) are
+// one dense span, and the only scattered access left is the 16-byte store of the wave's part of the pose record.
+// Same arithmetic, same order: bit-identical to the form above.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pose_sample_crowd_kernel(PoseFrameDev f) {
+    // One wave = 64 instances of one (animation, node, BINDING): the position, scale and rotation tracks of a node
+    // are sampled by three different waves, so a thread walks at most four curves (the chain of dependent loads
+    // is what bounds this kernel) and the three 16-byte parts of the pose record have one writer each.
+    const uint32_t inst = blockIdx.x * 64u + threadIdx.x, a = blockIdx.z;
+    const uint32_t node = blockIdx.y / 3u;
+    const int bind = (int)(blockIdx.y - node * 3u);           // FYX_BIND_POSITION, _SCALE, _ROTATION
+    if (inst >= f.n_instances) return;
+    if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;
+    const float time = f.times[(size_t)inst * f.n_anims + a];
+    const AnimDev an = f.anims[a];
+    const int32_t* st = an.slot_track + (size_t)node * 4;     // wave-uniform: scalar loads
+    // which bindings the animation provides for this node (all three: the position wave writes the present bits)
+    bool valid[3];
+    int kinds[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        valid[b] = false;
+        kinds[b] = -1;
+        if (st[b] < 0) continue;
+        const TrackDev* tk = an.tracks + st[b];
+        const int kind = tk->kind;
+        const int need = kind == FYX_KIND_QUAT ? 4 : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3 : 0;
+        const bool fits = (b == FYX_BIND_ROTATION) ? (kind == FYX_KIND_QUAT || kind == FYX_KIND_QUAT_EULER)
+                                                   : (kind == FYX_KIND_VEC3);
+        valid[b] = fits && need > 0 && (int)tk->n_curves >= need;   // else fetch() -> None
+        kinds[b] = kind;
+    }
+    float val[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (valid[bind]) {
+        // (fetching the hints and keys of all four curves up front was measured slower: 44 vs 37 us on C3)
+        const int32_t track = st[bind];
+        const TrackDev* tk = an.tracks + track;
+        const int need = kinds[bind] == FYX_KIND_QUAT ? 4 : 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= need) break;
+            uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
+            uint32_t hint = *hp;
+            const uint32_t h0 = hint;
+            const uint32_t fk = tk->first_key[c];
+            val[c] = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], time, hint);
+            if (hint != h0) *hp = hint;
+        }
+    }
+    f4* rec = reinterpret_cast<f4*>(f.anim_pose) + (((size_t)a * f.n_instances + inst) * f.n_nodes + node) * 3;
+    if (bind == FYX_BIND_POSITION) {
+        const uint32_t bits = (valid[FYX_BIND_POSITION] ? 1u : 0u) | (valid[FYX_BIND_SCALE] ? 2u : 0u) |
+                              (valid[FYX_BIND_ROTATION] ? 4u : 0u) | (st[3] >= 0 ? 8u : 0u);
+        rec[0] = f4{val[0], val[1], val[2], __uint_as_float(bits)};
+    } else if (bind == FYX_BIND_SCALE) {
+        rec[2] = f4{val[0], val[1], val[2], 0.0f};
+    } else {
+        f4 q = f4{0.f, 0.f, 0.f, 1.f};
+        if (valid[FYX_BIND_ROTATION]) {
+            if (kinds[FYX_BIND_ROTATION] == FYX_KIND_QUAT) {
+                q = quat_normalize(f4{val[0], val[1], val[2], val[3]});
+            } else {   // (axis * sin(angle/2), cos(angle/2)) per axis, then qz * qy * qx (fyrox-math/src/lib.rs:725-740)
+                float sx, cx, sy, cy, sz, cz;
+                sincosf(val[0] / 2.0f, &sx, &cx);
+                sincosf(val[1] / 2.0f, &sy, &cy);
+                sincosf(val[2] / 2.0f, &sz, &cz);
+                const f4 qx = f4{1.0f * sx, 0.0f * sx, 0.0f * sx, cx};
+                const f4 qy = f4{0.0f * sy, 1.0f * sy, 0.0f * sy, cy};
+                const f4 qz = f4{0.0f * sz, 0.0f * sz, 1.0f * sz, cz};
+                q = quat_mul(quat_mul(qz, qy), qx);
+            }
+        }
+        rec[1] = q;
+    }
+}
+
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s) {
     if (f.n_anims == 0 || f.n_instances == 0 || f.n_nodes == 0) return hipSuccess;
-    if (f.n_instances > 65535u || f.n_anims > 65535u) return hipErrorInvalidValue;   // grid y / z limits
-    hipLaunchKernelGGL(pose_sample_kernel, dim3((f.n_nodes * 16 + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f);
+    if (f.n_instances > 65535u || f.n_anims > 65535u || f.n_nodes * 3u > 65535u) return hipErrorInvalidValue;   // grid limits
+    if (f.sample_form == 2 || (f.sample_form == 0 && f.n_instances >= 32)) {
+        hipLaunchKernelGGL(pose_sample_crowd_kernel, dim3((f.n_instances + 63) / 64, f.n_nodes * 3, f.n_anims), dim3(64), 0, s, f);
+    } else {
+        hipLaunchKernelGGL(pose_sample_kernel, dim3((f.n_nodes * 16 + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f);
+    }
     return hipGetLastError();
 }
 
@@ -554,7 +665,7 @@ __global__ __launch_bounds__(256) void property_sample_kernel(PoseFrameDev f) {
     if (track >= 0) {
         const TrackDev* tk = an.tracks + track;
         if (tk->kind == FYX_KIND_REAL && tk->n_curves >= 1) {   // curves.first()? else None (container.rs:289-291)
-            uint32_t* hp = f.hints + (((size_t)a * f.n_instances + inst) * f.max_tracks + track) * 4;
+            uint32_t* hp = hint_ptr(f, a, (uint32_t)track, 0, inst);
             uint32_t hint = *hp;
             const uint32_t fk = tk->first_key[0];
             out.x = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[0],

@@ -273,6 +273,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.split")) return &c->lbs.split;
     if (!strcmp(key, "anim.threads")) return &c->plan_threads;
     if (!strcmp(key, "anim.split")) return &c->plan_split;
+    if (!strcmp(key, "anim.sample_form")) return &c->sample_form;
     return nullptr;
 }
 
@@ -294,6 +295,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_block must be 256 or 512");
     if (slot == &c->lbs.crowd_ipb && (value < 0 || value > 4096))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_ipb must be 0 (auto) .. 4096");
+    if (slot == &c->sample_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.sample_form must be 0, 1 or 2");
     if (slot == &c->plan_split && value < 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.split must be >= 1");
     if (slot == &c->plan_threads && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");

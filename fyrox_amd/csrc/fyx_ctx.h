@@ -65,6 +65,7 @@ struct fyx_ctx {
     int next_worker = 0;
     fyx::AnimStore* anim = nullptr;
     int plan_threads = 8;    // option "anim.threads": host threads planning a crowd's frame (1 = the calling thread only)
+    int sample_form = 0;     // option "anim.sample_form": 0 auto, 1 curves on the lanes, 2 instances on the lanes
     int plan_split = 2048;   // option "anim.split": instances per planning task
     fyx::PlanPool* plan_pool = nullptr;
 };

@@ -183,8 +183,10 @@ struct PoseFrameDev {
     const uint2* ops;            // all instances' programs
     const uint32_t* prog_off;    // [n_instances] offset of each instance's program in ops
     const uint8_t* layer_masks;  // [n_layers][n_nodes] 1 = excluded
-    uint32_t* hints;             // [n_anims][n_instances][max_tracks][4]
+    uint32_t* hints;             // [n_anims][max_tracks][4 curves][n_instances]: instance-minor, so the crowd sampler's
+                                 //   lanes (= instances of one curve) touch one dense span
     uint32_t max_tracks;
+    uint32_t sample_form;        // 0 auto (instances on the lanes from 32 instances), 1 curves on the lanes, 2 instances on the lanes
     float4* anim_pose;           // [n_anims][n_instances][n_nodes][3]
     float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
     float* local;                // [n_instances][n_nodes][16]

@@ -132,10 +132,29 @@ def _drain(pop):
     return out
 
 
+@pytest.fixture(autouse=True)
+def _anim_defaults(ctx):
+    ctx.set_option("anim.sample_form", 0)
+    yield
+    ctx.set_option("anim.sample_form", 0)
+
+
 @pytest.mark.parametrize("make", cases.ALL, ids=lambda f: f.__name__)
 def test_scenario_matches_oracle(ctx, orc, make):
     sc = make()
     o, p = run_scenario(ctx, orc, sc, n_instances=3)
+    o.close()
+    p.free()
+
+
+@pytest.mark.parametrize("make", cases.ALL, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("n_instances", [2, 70])
+def test_scenario_with_instances_on_the_lanes(ctx, orc, make, n_instances):
+    """The crowd form of the sampler (anim.sample_form = 2: 64 instances of one (animation, node) per wave, instance-minor
+    span hints) must give the same bits as the per-instance form; 70 instances = one full and one ragged wave."""
+    sc = make()
+    ctx.set_option("anim.sample_form", 2)
+    o, p = run_scenario(ctx, orc, sc, n_instances=n_instances, frames=min(sc.n_frames, 30), check_every=3)
     o.close()
     p.free()
 
