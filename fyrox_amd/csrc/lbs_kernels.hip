@@ -296,7 +296,9 @@ __device__ __forceinline__ void pin_vertex(VertexIn<MASK>& r) {
 
 // PROBE (debug, option lbs.probe): every wave records s_memrealtime (100 MHz) at kernel entry, after the palette
 // staging barrier, after its last store was issued and after that store completed -- the launch's timeline.
-template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK, bool PROBE = false>
+// PREFETCH: 0 = none, 1 = the next unit's loads are issued before the math of the current one, 2 = two units ahead
+// (three units in flight per wave: what lets the half-empty CUs of a launch's tail still fill their share of HBM).
+template <int BLOCK, bool EXACT, bool NT, int PREFETCH, int MASK, bool PROBE = false>
 __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_inst,
                                                   uint32_t total_units, uint32_t split, uint64_t* probe = nullptr) {
     uint64_t pt0 = 0, pt1 = 0;
@@ -335,7 +337,13 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         {
             const uint32_t s0 = seg_b * 64;
             const uint32_t s1 = seg_e * 64 < a.n_verts ? seg_e * 64 : a.n_verts;
-            if (split) {
+            if (split == 2 && a.n_instances == 1) {
+                // units interleaved over ALL waves of the grid (wave g takes units g, g + G, g + 2G, ...): every wave
+                // sweeps the whole address range in step with the others
+                vb = (blockIdx.x * WPB + wave) * 64;
+                ve = a.n_verts;
+                vstep = gridDim.x * WPB * 64;
+            } else if (split) {
                 const uint32_t len = s1 - s0;
                 vb = s0 + (uint32_t)(((uint64_t)len * wave / WPB) & ~15ull);
                 ve = wave + 1 == WPB ? s1 : s0 + (uint32_t)(((uint64_t)len * (wave + 1) / WPB) & ~15ull);
@@ -349,6 +357,11 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         uint32_t base = vb;
         uint32_t v = base + lane;
         VertexIn<MASK> cur = load_vertex<NT, MASK>(a, v < ve ? v : 0);
+        VertexIn<MASK> nx1;
+        if constexpr (PREFETCH == 2) {
+            const uint32_t v1 = base + vstep + lane;
+            nx1 = load_vertex<NT, MASK>(a, v1 < ve ? v1 : 0);
+        }
 
         if (inst != inst_first) __syncthreads();  // every wave is done with the previous palette
         const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
@@ -362,14 +375,21 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         // Opaque use point: nothing that consumes the first unit's vertex data may be scheduled
         // above the staging barrier (it would drag the wait for those loads up with it).
         pin_vertex(cur);
+        if constexpr (PREFETCH == 2) pin_vertex(nx1);
         if constexpr (PROBE) { if (inst == inst_first) pt1 = __builtin_amdgcn_s_memrealtime(); }
 
         while (base < ve) {  // wave-uniform
             const uint32_t bn = base + vstep;
             const uint32_t vn = bn + lane;
             VertexIn<MASK> nxt;
-            if constexpr (PREFETCH) {
+            if constexpr (PREFETCH == 1) {
                 if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
+            }
+            if constexpr (PREFETCH == 2) {
+                const uint32_t b2 = bn + vstep;
+                const uint32_t v2 = b2 + lane;
+                nxt = nx1;                                  // loaded one iteration ago
+                if (b2 < ve) nx1 = load_vertex<NT, MASK>(a, v2 < ve ? v2 : 0);
             }
             const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.px,
                                                        cur.py, cur.pz, cur.nx, cur.ny, cur.nz,
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
                 if constexpr (MASK & 4)
                     stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, cur.t.w});
             }
-            if constexpr (!PREFETCH) {
+            if constexpr (PREFETCH == 0) {
                 if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
             }
             cur = nxt;
@@ -517,7 +537,7 @@ static hipError_t launch_crowd(const LbsArgs& a, const LbsTuning& t, hipStream_t
 // ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, bool NT, bool PREFETCH, int MASK>
+template <int BLOCK, bool EXACT, bool NT, int PREFETCH, int MASK>
 static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     const uint32_t upi = (a.n_verts + 63) / 64;
     const uint64_t total64 = (uint64_t)upi * a.n_instances;
@@ -528,20 +548,20 @@ static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s
     const uint32_t max_useful = (total + (BLOCK / 64) - 1) / (BLOCK / 64);
     if (grid > max_useful) grid = max_useful;
     const size_t lds = (size_t)a.n_bones * 64 + 64;  // rows + row3 + one flag per wave
-    if constexpr (BLOCK == 512 && EXACT && NT && PREFETCH && MASK == 7) {
+    if constexpr (BLOCK == 512 && EXACT && NT && PREFETCH == 1 && MASK == 7) {
         if (t.probe && t.probe_buf) {   // debug timeline, only for the default variant
             if ((size_t)grid * (BLOCK / 64) * 4 > t.probe_words) return hipErrorInvalidValue;
             hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a,
-                               upi, total, (uint32_t)(t.split ? 1 : 0), t.probe_buf);
+                               upi, total, (uint32_t)t.split, t.probe_buf);
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
-                       upi, total, (uint32_t)(t.split ? 1 : 0), (uint64_t*)nullptr);
+                       upi, total, (uint32_t)t.split, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool EXACT, bool NT, bool PREFETCH>
+template <int BLOCK, bool EXACT, bool NT, int PREFETCH>
 static hipError_t launch_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
     switch (mask) {
@@ -558,16 +578,20 @@ static hipError_t launch_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t 
 
 template <int BLOCK>
 static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    if constexpr (BLOCK != 1024) {
+        if (t.prefetch >= 2 && t.nt)   // two units ahead: streaming variants of the 256 / 512 workgroups only
+            return t.exact ? launch_mask<BLOCK, true, true, 2>(a, t, s) : launch_mask<BLOCK, false, true, 2>(a, t, s);
+    }
     const int key = (t.exact ? 4 : 0) | (t.nt ? 2 : 0) | (t.prefetch ? 1 : 0);
     switch (key) {
-        case 7: return launch_mask<BLOCK, true, true, true>(a, t, s);
-        case 6: return launch_mask<BLOCK, true, true, false>(a, t, s);
-        case 5: return launch_mask<BLOCK, true, false, true>(a, t, s);
-        case 4: return launch_mask<BLOCK, true, false, false>(a, t, s);
-        case 3: return launch_mask<BLOCK, false, true, true>(a, t, s);
-        case 2: return launch_mask<BLOCK, false, true, false>(a, t, s);
-        case 1: return launch_mask<BLOCK, false, false, true>(a, t, s);
-        default: return launch_mask<BLOCK, false, false, false>(a, t, s);
+        case 7: return launch_mask<BLOCK, true, true, 1>(a, t, s);
+        case 6: return launch_mask<BLOCK, true, true, 0>(a, t, s);
+        case 5: return launch_mask<BLOCK, true, false, 1>(a, t, s);
+        case 4: return launch_mask<BLOCK, true, false, 0>(a, t, s);
+        case 3: return launch_mask<BLOCK, false, true, 1>(a, t, s);
+        case 2: return launch_mask<BLOCK, false, true, 0>(a, t, s);
+        case 1: return launch_mask<BLOCK, false, false, 1>(a, t, s);
+        default: return launch_mask<BLOCK, false, false, 0>(a, t, s);
     }
 }
 

@@ -102,9 +102,9 @@ def test_c4_1m_verts_256_bones(ctx, orc):
 # ---- kernel variants ----------------------------------------------------------------------
 
 @pytest.mark.parametrize("block", [256, 512, 1024])
-@pytest.mark.parametrize("prefetch", [0, 1])
+@pytest.mark.parametrize("prefetch", [0, 1, 2])
 @pytest.mark.parametrize("nt", [0, 1])
-@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("split", [0, 1, 2])
 def test_every_kernel_variant_is_bit_exact(ctx, orc, block, prefetch, nt, split):
     m = synth.make_mesh(70_001, 200, 99, coherent=False)   # ragged: not a multiple of 4 or 256
     pal = synth.make_palette(200, 99)
