@@ -385,6 +385,118 @@ def looping_root_motion(n_bones=12, seed=synth.SEED_BASE + 11) -> Scenario:
 ALL_RM = [with_root_motion_and_signals(f) for f in ALL] + [looping_root_motion]
 
 
+# ---- randomly generated machines ------------------------------------------------------------------------
+
+def random_machine(seed: int, n_bones: int = 7) -> Scenario:
+    """A random but valid animation set-up: 3-5 partial clips (some with Real Property tracks, signals, root motion,
+    reverse / zero speed, non-looping, sub-range time slices, disabled), 1-3 layers of random pose-node DAGs (all four
+    node types, invalid handles, shared sub-trees, nested blends up to depth 4), random states / transitions with
+    random condition trees and actions, masks, mistyped parameter references, and a script that rewrites parameters
+    (sometimes with another kind) every few frames.  Quaternion rotation tracks only, so everything must be
+    bit-exact."""
+    rng = np.random.default_rng(seed)
+    f32 = lambda x: float(np.float32(x))
+    rig = synth.make_rig(n_bones, 1000 + seed, exotic=bool(rng.integers(2)))
+    n_clips = int(rng.integers(3, 6))
+    tds, anims = [], []
+    for c in range(n_clips):
+        td, tgt = synth.make_clip(n_bones, 1000 + seed, clip=c, n_keys=int(rng.integers(2, 9)), fps=8.0,
+                                  key_kind=int(rng.integers(0, 3)), euler_every=10 ** 9)
+        drop = rng.random(len(td.tracks)) < 0.25
+        tracks = [t for t, d in zip(td.tracks, drop) if not d]
+        target = [int(b) for b, d in zip(tgt, drop) if not d]
+        for p_ in range(int(rng.integers(0, 3))):                    # Real Property tracks on nodes 2 / 3
+            nk = int(rng.integers(1, 6))
+            ts = np.sort(rng.random(nk)).astype(np.float32)
+            tracks.append(A.Track(A.BIND_PROPERTY0 + p_, A.KIND_REAL,
+                                  [A.Curve([A.CurveKey(f32(ts[k]), f32(rng.random() * 100), int(rng.integers(0, 3)),
+                                                       f32(rng.normal()), f32(rng.normal())) for k in range(nk)])]))
+            target.append(2 + (c + p_) % 2)
+        tds.append(A.AnimationTracksData(tracks))
+        lo = f32(rng.random() * 0.3)
+        hi = f32(lo + 0.2 + rng.random() * 0.6)
+        spec = AnimSpec(c, np.asarray(target, np.int32), time_slice=(lo, hi),
+                        speed=f32(rng.choice([1.0, 0.6, 1.7, -0.9, -2.0, 0.0])), looped=bool(rng.random() < 0.7),
+                        enabled=bool(rng.random() < 0.9))
+        spec.signals = [(f32(lo + (hi - lo) * rng.random()), bool(rng.random() < 0.8)) for _ in range(int(rng.integers(0, 4)))]
+        if rng.random() < 0.5:
+            spec.root_motion = (int(rng.integers(0, 2)), bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2)),
+                                bool(rng.integers(2)))
+        if rng.random() < 0.3:
+            spec.max_event_capacity = int(rng.integers(0, 4))
+        anims.append(spec)
+    n_params = int(rng.integers(2, 6))
+
+    def rand_param():
+        k = int(rng.integers(0, 4))
+        if k == A.PARAM_WEIGHT:
+            return A.Parameter(k, f32(rng.random() * 1.2 - 0.1))
+        if k == A.PARAM_RULE:
+            return A.Parameter(k, bool(rng.integers(2)))
+        if k == A.PARAM_INDEX:
+            return A.Parameter(k, int(rng.integers(0, 4)))
+        return A.Parameter(k, (f32(rng.random() * 1.6 - 0.3), f32(rng.random() * 1.6 - 0.3)))
+
+    params = [rand_param() for _ in range(n_params)]
+    pref = lambda: int(rng.integers(-1, n_params + 1))              # includes missing parameters
+
+    def cond(depth=0):
+        r = rng.random()
+        if depth >= 2 or r < 0.4:
+            return ("parameter", pref()) if rng.random() < 0.7 else ("ended", int(rng.integers(-1, n_clips + 1)))
+        if r < 0.55:
+            return ("not", cond(depth + 1))
+        return (str(rng.choice(["and", "or", "xor"])), cond(depth + 1), cond(depth + 1))
+
+    layers = []
+    for li in range(int(rng.integers(1, 4))):
+        nodes, depth = [], []
+        for a in rng.permutation(n_clips)[:int(rng.integers(1, n_clips + 1))]:
+            nodes.append(A.PlayAnimation(int(a))); depth.append(0)
+
+        def src(max_depth):
+            if rng.random() < 0.07:
+                return -1                                           # Handle::NONE: try_borrow fails
+            ok = [i for i, d in enumerate(depth) if d <= max_depth]
+            return int(rng.choice(ok))
+
+        for _ in range(int(rng.integers(1, 6))):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                ins = [A.BlendPose(src(2), f32(rng.random())) if rng.random() < 0.6 else A.BlendPose(src(2), parameter=pref())
+                       for _ in range(int(rng.integers(1, 5)))]
+                node = A.BlendAnimations(ins)
+                srcs = [b.pose_source for b in ins]
+            elif kind == 1:
+                ins = [A.IndexedBlendInput(f32(0.05 + rng.random() * 0.3), src(2)) for _ in range(int(rng.integers(1, 5)))]
+                node = A.BlendAnimationsByIndex(pref(), ins)
+                srcs = [b.pose_source for b in ins]
+            else:
+                npts = int(rng.integers(1, 5))
+                pts = [A.BlendSpacePoint((f32(rng.random()), f32(rng.random())), src(2)) for _ in range(npts)]
+                tris = [] if npts < 3 else ([(0, 1, 2)] if npts == 3 else [(0, 1, 2), (0, 2, 3)])
+                node = A.BlendSpace(pref(), pts, tris)
+                srcs = [p_.pose_source for p_ in pts]
+            nodes.append(node)
+            depth.append(1 + max([depth[s_] for s_ in srcs if s_ >= 0], default=0))
+        n_states = int(rng.integers(1, 4))
+        acts = lambda: [(int(rng.integers(0, 4)), int(rng.integers(0, n_clips))) for _ in range(int(rng.integers(0, 3)))]
+        states = [A.State(int(rng.integers(0, len(nodes))), acts(), acts()) for _ in range(n_states)]
+        trans = [A.Transition(int(rng.integers(0, n_states)), int(rng.integers(0, n_states)), f32(0.04 + rng.random() * 0.3), cond())
+                 for _ in range(int(rng.integers(0, 5)))]
+        mask = [int(x) for x in rng.permutation(n_bones)[:int(rng.integers(0, 4))]] if rng.random() < 0.5 else []
+        layers.append(A.MachineLayer(nodes=nodes, states=states, transitions=trans, weight=f32(rng.random() * 1.1), mask=mask,
+                                     entry_state=int(rng.integers(0, n_states)) if rng.random() < 0.5 else None))
+    n_frames = 36
+    script = {}
+    for f in range(n_frames):
+        if rng.random() < 0.35:
+            script[f] = [(int(rng.integers(0, n_params)), rand_param()) for _ in range(int(rng.integers(1, 3)))]
+    return Scenario(f"random_machine[{seed}]", rig, tds, anims, A.Machine(parameters=params, layers=layers), script,
+                    n_frames=n_frames, dt=f32(rng.choice([1 / 60, 1 / 24, 0.11])), has_euler=False,
+                    track_root_motion=any(a.root_motion is not None for a in anims) or bool(rng.integers(2)))
+
+
 # ---- builders -------------------------------------------------------------------------------------
 
 def build_oracle(orc, sc: Scenario):

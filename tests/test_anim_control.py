@@ -121,9 +121,17 @@ def _drain(pop):
         out.append(e)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_control_plane_matches_oracle_on_random_machines(orc, cctx, seed):
+    _check_control_plane(orc, cctx, cases.random_machine(seed))
+
+
 @pytest.mark.parametrize("make", cases.ALL + cases.ALL_RM, ids=lambda f: f.__name__)
 def test_control_plane_matches_oracle(orc, cctx, make):
-    sc = make()
+    _check_control_plane(orc, cctx, make())
+
+
+def _check_control_plane(orc, cctx, sc):
     o = cases.build_oracle(orc, sc)
     p = cases.build_product(cctx, sc, n_instances=2)
     mode = 0 if sc.machine is None else 1
@@ -177,12 +185,18 @@ def test_control_plane_matches_oracle(orc, cctx, make):
                 rm_slots = [np.zeros(8, np.float32) for _ in range(rp["n_slots"])]
             anim_rm = [o.animation_root_motion(a) for a in range(len(sc.animations))]
             rm_slots = run_rm_program(orc, rp["ops"][r0:r1], rm_slots, anim_rm)
+            def norm(rec):   # None reads back as RootMotion::default()
+                if _bits(rec):
+                    return rec
+                r = np.zeros(8, np.float32)
+                r[7] = 1.0
+                return r
             base = 0
             for li, layer in enumerate(sc.machine.layers):
                 base += len(layer.nodes)
-                assert np.array_equal(rm_slots[base].view(np.uint32), o.machine_root_motion(li).view(np.uint32)), (f, li)
+                assert np.array_equal(norm(rm_slots[base]).view(np.uint32), o.machine_root_motion(li).view(np.uint32)), (f, li)
                 base += 1
-            assert np.array_equal(rm_slots[-1].view(np.uint32), o.machine_root_motion(-1).view(np.uint32)), f
+            assert np.array_equal(norm(rm_slots[-1]).view(np.uint32), o.machine_root_motion(-1).view(np.uint32)), f
             for a, spec in enumerate(sc.animations):   # the slices and flags the root-motion kernel receives
                 assert tuple(rp["slices"][0, a]) == tuple(np.float32(x) for x in spec.time_slice)
     o.close()

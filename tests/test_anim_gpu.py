@@ -159,6 +159,21 @@ def test_scenario_with_instances_on_the_lanes(ctx, orc, make, n_instances):
     p.free()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_machines_match_oracle(ctx, orc, seed):
+    """Randomly generated clips / machines / scripts (tests/anim_cases.py::random_machine): poses, transforms, matrices,
+    property values, root motion and event queues, bit for bit; odd seeds use the crowd form of the sampler."""
+    sc = cases.random_machine(seed)
+    ctx.set_option("anim.sample_form", 2 if seed % 2 else 1)
+    o, p = run_scenario(ctx, orc, sc, n_instances=2 + seed % 3)
+    for a in range(len(sc.animations)):
+        assert _drain(lambda: p.pop_event(a, 0)) == _drain(lambda: o.pop_event(a))
+    for li in range(len(sc.machine.layers)):
+        assert _drain(lambda: p.pop_layer_event(li, 1)) == _drain(lambda: o.pop_layer_event(li))
+    o.close()
+    p.free()
+
+
 @pytest.mark.parametrize("make", cases.ALL_RM, ids=lambda f: f.__name__)
 def test_root_motion_and_signals_match_oracle(ctx, orc, make):
     """Animation::update_root_motion on the GPU (root pose rewritten before blending), AnimationPose::root_motion
