@@ -593,3 +593,69 @@ def test_skin_ex_argument_errors(ctx):
     assert e.value.code == _native.FYX_ERR_UNSUPPORTED
     pal.free(); out.free()
     ctx.mesh_free(63)
+
+
+# ---- vertex-buffer-in / vertex-buffer-out on other vertex layouts -------------------------------------------
+
+def _custom_aos(m, stride, offs, fill=0x5A):
+    """Interleave a mesh into an arbitrary layout; bytes no attribute covers are `fill`."""
+    n = m.n_verts
+    aos = np.full((n, stride), fill, np.uint8)
+    parts = {"pos": (m.pos, 12), "normal": (m.normal, 12), "tangent": (m.tangent, 16), "weights": (m.weights, 16)}
+    for key, (arr, size) in parts.items():
+        if offs.get(key, -1) >= 0:
+            aos[:, offs[key]:offs[key] + size] = np.ascontiguousarray(arr).view(np.uint8).reshape(n, size)
+    aos[:, offs["indices"]:offs["indices"] + 4] = m.indices
+    return aos
+
+
+@pytest.mark.parametrize("stride,offs", [
+    (32, dict(pos=0, weights=12, indices=28)),                                   # position only: smallest skinnable vertex
+    (48, dict(pos=4, weights=16, indices=32, normal=36)),                        # no tangent
+    (64, dict(weights=0, indices=16, pos=20, normal=32, tangent=44)),            # attributes in another order
+    (80, dict(pos=0, normal=12, tangent=24, weights=40, indices=56)),            # padded vertex
+    (128, dict(pos=64, normal=76, tangent=88, weights=104, indices=120)),        # a second UV set etc. in front
+    (160, dict(pos=0, normal=140, tangent=100, weights=60, indices=156)),        # the largest supported stride
+], ids=lambda v: str(v) if isinstance(v, int) else "")
+@pytest.mark.parametrize("n_verts", [1000, 129])
+def test_vertex_buffer_path_handles_any_f32_layout(ctx, orc, stride, offs, n_verts):
+    """out_stride == 0 for layouts other than AnimatedVertex: every per-lane span count the kernel is instantiated for
+    (strides up to 64, 80, 128 and 160 bytes), attributes in any order, optional normal / tangent."""
+    m = synth.make_mesh(n_verts, 24, synth.SEED_BASE + 40 + stride, coherent=False)
+    pal = synth.make_palette(24, synth.SEED_BASE + 40)
+    src = _custom_aos(m, stride, offs)
+    ctx.mesh_upload(66, src.reshape(-1), n_verts, stride, off_pos=offs["pos"], off_normal=offs.get("normal", -1),
+                    off_tangent=offs.get("tangent", -1), off_weights=offs["weights"], off_indices=offs["indices"])
+    ref = orc.lbs_skin(m.pos, m.weights, m.indices, pal, m.normal if "normal" in offs else None,
+                       m.tangent if "tangent" in offs else None, threads=0)
+    guard = 192
+    d_pal, buf = ctx.to_device(pal), ctx.to_device(np.full(n_verts * stride + guard, 0xEE, np.uint8))
+    ctx.lbs_skin_ex(66, d_pal.ptr, 24, 1, d_out_vertices=buf.ptr, out_stride=0)
+    ctx.sync()
+    raw = buf.download(np.uint8, n_verts * stride + guard)
+    assert np.all(raw[-guard:] == 0xEE)
+    raw = raw[:-guard].reshape(n_verts, stride)
+    skinned = np.zeros(stride, bool)
+    for key, size in (("pos", 12), ("normal", 12), ("tangent", 12)):
+        if key in offs:
+            got = np.ascontiguousarray(raw[:, offs[key]:offs[key] + size]).view(np.float32)
+            assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref[key][:, :3]).view(np.uint32)), key
+            skinned[offs[key]:offs[key] + size] = True
+    assert np.array_equal(raw[:, ~skinned], src[:, ~skinned]), "pass-through bytes changed"
+    d_pal.free(); buf.free()
+    ctx.mesh_free(66)
+
+
+def test_vertex_buffer_path_rejects_oversized_or_unaligned_layouts(ctx):
+    from fyrox_amd import _native
+    m = synth.make_mesh(64, 8, 5)
+    pal, out = ctx.to_device(synth.make_palette(8, 5)), ctx.malloc(64 * 200)
+    for stride, offs in ((164, dict(pos=0, weights=12, indices=28)), (34, dict(pos=0, weights=14, indices=30))):
+        src = _custom_aos(m, stride, offs)
+        ctx.mesh_upload(67, src.reshape(-1), 64, stride, off_pos=offs["pos"], off_weights=offs["weights"], off_indices=offs["indices"])
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            ctx.lbs_skin_ex(67, pal.ptr, 8, 1, d_out_vertices=out.ptr, out_stride=0)
+        assert e.value.code == _native.FYX_ERR_UNSUPPORTED
+        assert ctx.lbs_skin(67, synth.make_palette(8, 5), want=("pos",))["pos"].shape == (64, 3)   # the SoA path still serves it
+        ctx.mesh_free(67)
+    pal.free(); out.free()
