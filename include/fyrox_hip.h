@@ -75,7 +75,16 @@ int fyx_join(fyx_ctx* ctx);
  * "lbs.streams" (1..4 worker streams for independent skinning launches, see fyx_join),
  * "lbs.crowd" (instanced launches: -1 = crowd kernel from 4 instances on, 0 never, 1 always; the
  * crowd kernel keeps a tile of vertices in registers and loops over instances), "lbs.crowd_block"
- * (256 | 512 vertices per tile), "lbs.crowd_ipb" (instances per workgroup, 0 = auto). */
+ * (256 | 512 vertices per tile), "lbs.crowd_ipb" (instances per workgroup, 0 = auto),
+ * "lbs.prefetch" (0 | 1 | 2 units of loads ahead), "lbs.split" (how a launch's 64-vertex units are
+ * dealt to the waves: 0 contiguous range per workgroup, units round-robin inside it; 1 equal
+ * contiguous vertex shares per wave; 2 units interleaved over all waves), "lbs.probe" (debug
+ * timeline, fyx_debug_read_probe); pose path: "anim.threads" / "anim.split" (host threads that
+ * plan a crowd's frame and instances per planning task; crowds below 2 x anim.split stay on the
+ * calling thread), "anim.sample_form" (0 auto, 1 curves of one instance on the lanes, 2
+ * instances of one curve on the lanes -- same results, the crowd form is picked from 32
+ * instances on).  With lbs.exact = 0 the crowd kernel blends the four matrices first and
+ * transforms once (the same linear map, different rounding, inside the 1e-5 bar). */
 int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
 /* Debug aid (option "lbs.probe" = 1): per-wave timeline of the last default-variant skinning launch, four
  * uint64 per wave {kernel entry, palette staged, last store issued, last store completed} in 10 ns ticks. */
