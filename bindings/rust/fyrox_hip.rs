@@ -1,0 +1,227 @@
+//! Safe layer over `fyrox_hip_sys` (the generated `extern "C"` block): what sits behind the unchanged public
+//! signatures of Fyrox on the skeletal-animation path.  Delivered as source for a Fyrox maintainer
+//! (`fyrox-impl/src/scene/mesh/hip.rs`, cargo feature `hip-skinning`); the Rust toolchain is not part of this
+//! repository's build image, so this file is not compiled or tested here -- the C ABI it calls is exercised
+//! call for call by `tests/` through ctypes (`fyrox_amd/_native.py` declares the same prototypes).
+//!
+//! File:line references are to the Fyrox tree.
+#![allow(dead_code)]
+
+use super::hip_sys::*; // bindings/rust/fyrox_hip_sys.rs
+use crate::core::algebra::{Matrix4, UnitQuaternion, Vector3};
+use crate::scene::mesh::buffer::{VertexAttributeUsage, VertexBuffer};
+use std::{ffi::CStr, ptr};
+
+/// `fyx_status` as a Rust error.  `BoneIndex` is the slice-index panic of `scene/mesh/mod.rs:514`,
+/// `MissingAttribute` is `VertexFetchError::NoSuchAttribute` (`scene/mesh/buffer.rs:1279`).
+#[derive(Debug)]
+pub enum HipError {
+    InvalidArg(String),
+    NoDevice,
+    Hip(String),
+    OutOfMemory,
+    UnknownId,
+    BoneIndex(String),
+    MissingAttribute(String),
+    Unsupported(String),
+}
+
+/// One per engine thread: the raw pointer makes it `!Send + !Sync`, as the C side requires
+/// (`fyrox-impl/src/engine/mod.rs:1634-1733` is the only caller).
+pub struct HipSkinning {
+    ctx: *mut FyxCtx,
+}
+
+impl HipSkinning {
+    pub fn new(device: i32) -> Result<Self, HipError> {
+        let mut ctx = ptr::null_mut();
+        match unsafe { fyx_init(&mut ctx, device) } {
+            FYX_OK => Ok(Self { ctx }),
+            _ => Err(HipError::NoDevice),
+        }
+    }
+
+    fn check(&self, rc: i32) -> Result<(), HipError> {
+        if rc == FYX_OK {
+            return Ok(());
+        }
+        let msg = unsafe { CStr::from_ptr(fyx_last_error(self.ctx)) }.to_string_lossy().into_owned();
+        Err(match rc {
+            FYX_ERR_INVALID_ARG => HipError::InvalidArg(msg),
+            FYX_ERR_NO_DEVICE => HipError::NoDevice,
+            FYX_ERR_OOM => HipError::OutOfMemory,
+            FYX_ERR_UNKNOWN_ID => HipError::UnknownId,
+            FYX_ERR_BONE_INDEX => HipError::BoneIndex(msg),
+            FYX_ERR_MISSING_ATTRIBUTE => HipError::MissingAttribute(msg),
+            FYX_ERR_UNSUPPORTED => HipError::Unsupported(msg),
+            _ => HipError::Hip(msg),
+        })
+    }
+
+    /// Upload (or re-upload) a surface's vertex buffer; call when `VertexBuffer::modifications_count()`
+    /// (`buffer.rs:909`) changed.  The library de-interleaves on the GPU and keeps the interleaved bytes too.
+    pub fn upload_vertex_buffer(&mut self, key: u64, vb: &VertexBuffer) -> Result<(), HipError> {
+        let off = |u| vb.find_attribute(u).map(|a| a.offset as i32).unwrap_or(-1); // buffer.rs:175-190
+        self.check(unsafe {
+            fyx_mesh_upload(
+                self.ctx,
+                key,
+                vb.raw_data().as_ptr(),
+                vb.vertex_count(),
+                vb.vertex_size() as u32,
+                off(VertexAttributeUsage::Position),
+                off(VertexAttributeUsage::Normal),
+                off(VertexAttributeUsage::Tangent),
+                off(VertexAttributeUsage::BoneWeight),
+                off(VertexAttributeUsage::BoneIndices),
+            )
+        })
+    }
+
+    /// `Mesh::accurate_world_bounding_box`, skinned branch (`scene/mesh/mod.rs:487-522`): min / max of the skinned
+    /// positions, reduced on the GPU.  `Matrix4<f32>` is column-major `[f32; 16]`: the palette is passed as is.
+    pub fn skinned_aabb(&mut self, key: u64, bone_matrices: &[Matrix4<f32>]) -> Result<[f32; 6], HipError> {
+        let mut b = [0f32; 6];
+        self.check(unsafe {
+            fyx_skinned_aabb(self.ctx, key, bone_matrices.as_ptr() as *const f32, bone_matrices.len() as u32, b.as_mut_ptr())
+        })?;
+        Ok(b)
+    }
+
+    /// Additive API next to `SurfaceData` (`scene/mesh/surface.rs:265`): skin every vertex into host vectors.
+    pub fn skin_into(&mut self, key: u64, palette: &[Matrix4<f32>], out: &mut SkinnedVertices) -> Result<(), HipError> {
+        let n = out.positions.len();
+        debug_assert!(out.normals.len() == n && out.tangents.len() == n);
+        self.check(unsafe {
+            fyx_lbs_skin(
+                self.ctx,
+                key,
+                palette.as_ptr() as *const f32,
+                palette.len() as u32,
+                1,
+                out.positions.as_mut_ptr() as *mut f32,
+                out.normals.as_mut_ptr() as *mut f32,
+                out.tangents.as_mut_ptr() as *mut f32,
+                out.aabb.as_mut_ptr(),
+            )
+        })
+    }
+
+    /// Device-resident form: blend shapes (weights as `Mesh::collect_render_data` computes them,
+    /// `scene/mesh/mod.rs:794-798`) and skinning straight into a vertex buffer with the surface's own layout,
+    /// ready for the renderer's geometry cache (`renderer/cache/geometry.rs:84-93`).  Asynchronous; `join()`
+    /// before the draw.
+    pub fn skin_into_vertex_buffer(
+        &mut self,
+        key: u64,
+        d_palette: *const f32,
+        n_bones: u32,
+        n_instances: u32,
+        d_blend_shape_weights: *const f32,
+        n_blend_shapes: u32,
+        d_out_vertices: *mut u8,
+    ) -> Result<(), HipError> {
+        let desc = FyxSkinDesc {
+            d_palette,
+            n_bones,
+            n_instances,
+            d_blend_shape_weights,
+            n_blend_shapes,
+            d_out_pos: ptr::null_mut(),
+            d_out_normal: ptr::null_mut(),
+            d_out_tangent: ptr::null_mut(),
+            d_out_vertices,
+            out_stride: 0, // the surface's own vertex layout
+            out_off_pos: -1,
+            out_off_normal: -1,
+            out_off_tangent: -1,
+        };
+        self.check(unsafe { fyx_lbs_skin_ex(self.ctx, key, &desc) })
+    }
+
+    /// GPU-side join of every in-flight skinning launch with the context stream.
+    pub fn join(&mut self) -> Result<(), HipError> {
+        self.check(unsafe { fyx_join(self.ctx) })
+    }
+}
+
+impl Drop for HipSkinning {
+    fn drop(&mut self) {
+        unsafe { fyx_shutdown(self.ctx) }
+    }
+}
+
+/// Output of `skin_into`.
+pub struct SkinnedVertices {
+    pub positions: Vec<Vector3<f32>>,
+    pub normals: Vec<Vector3<f32>>,
+    pub tangents: Vec<[f32; 4]>,
+    pub aabb: [f32; 6],
+}
+
+/// N instances of one animated model: `AnimationPlayer` (`scene/animation/mod.rs:190-346`) and, optionally, the
+/// `Machine` of an `AnimationBlendingStateMachine` (`scene/animation/absm.rs`), evaluated on the GPU.
+/// Built once by flattening the engine's own objects (see INTEGRATION.md section 3 for the field-by-field mapping).
+pub struct HipAnimator<'a> {
+    hip: &'a mut HipSkinning,
+    id: u64,
+    n_instances: u32,
+    /// signal index -> (Uuid, name), per animation: what `fyx_animation_pop_event` indices resolve to
+    pub signal_names: Vec<Vec<(crate::core::uuid::Uuid, String)>>,
+}
+
+/// `Option<RootMotion>` as scripts read it (`fyrox-animation/src/lib.rs:325-336`).
+pub struct HipRootMotion {
+    pub delta_position: Vector3<f32>,
+    pub delta_rotation: UnitQuaternion<f32>,
+}
+
+impl<'a> HipAnimator<'a> {
+    /// `AnimationPlayer::update` with `auto_apply` (`scene/animation/mod.rs:340-346`).
+    pub fn update_animations(&mut self, dt: f32) -> Result<(), HipError> {
+        let rc = unsafe { fyx_animation_player_update(self.hip.ctx, self.id, dt) };
+        self.hip.check(rc)
+    }
+
+    /// `AnimationBlendingStateMachine::update` (`scene/animation/absm.rs:311-326`).
+    pub fn update_machine(&mut self, dt: f32) -> Result<(), HipError> {
+        let rc = unsafe { fyx_absm_update(self.hip.ctx, self.id, dt) };
+        self.hip.check(rc)
+    }
+
+    /// `Mesh::collect_render_data`'s `bone_matrices` (`scene/mesh/mod.rs:781-793`) for every instance, on the device.
+    pub fn palette(&mut self, bones_id: u64, d_out: *mut f32) -> Result<(), HipError> {
+        let rc = unsafe { fyx_animator_palette(self.hip.ctx, self.id, bones_id, d_out) };
+        self.hip.check(rc)
+    }
+
+    /// `Animation::pop_event` (`fyrox-animation/src/lib.rs:680-682`).
+    pub fn pop_event(&mut self, animation: u32, instance: u32) -> Result<Option<(crate::core::uuid::Uuid, String)>, HipError> {
+        let mut signal = -1i32;
+        let rc = unsafe { fyx_animation_pop_event(self.hip.ctx, self.id, animation, instance, &mut signal) };
+        self.hip.check(rc)?;
+        Ok(if signal < 0 { None } else { Some(self.signal_names[animation as usize][signal as usize].clone()) })
+    }
+
+    /// `machine.pose().root_motion()` of every instance after `update_machine`.
+    pub fn machine_root_motion(&mut self) -> Result<Vec<Option<HipRootMotion>>, HipError> {
+        let mut raw = vec![FyxRootMotion { delta_position: [0.0; 3], has: 0, delta_rotation: [0.0, 0.0, 0.0, 1.0] }; self.n_instances as usize];
+        let rc = unsafe { fyx_absm_read_root_motion(self.hip.ctx, self.id, -1, raw.as_mut_ptr()) };
+        self.hip.check(rc)?;
+        Ok(raw
+            .iter()
+            .map(|r| {
+                (r.has != 0).then(|| HipRootMotion {
+                    delta_position: Vector3::new(r.delta_position[0], r.delta_position[1], r.delta_position[2]),
+                    // nalgebra storage order (i, j, k, w); the library returns unit quaternions
+                    delta_rotation: UnitQuaternion::new_unchecked(crate::core::algebra::Quaternion::new(
+                        r.delta_rotation[3],
+                        r.delta_rotation[0],
+                        r.delta_rotation[1],
+                        r.delta_rotation[2],
+                    )),
+                })
+            })
+            .collect())
+    }
+}

@@ -74,3 +74,16 @@ def test_null_context_is_rejected_not_crashing():
     assert l.fyx_lbs_skin(None, 1, None, 1, 1, None, None, None, None) == _native.FYX_ERR_INVALID_ARG
     assert l.fyx_last_error(None) == b"null context"
     l.fyx_shutdown(None)
+
+
+def test_rust_ffi_matches_header():
+    """bindings/rust/fyrox_hip_sys.rs (the `extern "C"` block a Fyrox maintainer adds) is generated from
+    include/fyrox_hip.h; it must be current and declare every exported symbol."""
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"]) == 0, \
+        "bindings/rust/fyrox_hip_sys.rs is stale: run python tools/gen_rust_ffi.py"
+    rs = open(os.path.join(ROOT, "bindings", "rust", "fyrox_hip_sys.rs")).read()
+    assert set(re.findall(r"pub fn (fyx_[a-z0-9_]+)", rs)) == _declared_symbols()
+    for st in ("FyxSkinDesc", "FyxTransform", "FyxTrackDesc", "FyxRootMotion", "FyxLayerEvent"):
+        assert f"pub struct {st} " in rs
