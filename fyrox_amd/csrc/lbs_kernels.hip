@@ -901,15 +901,22 @@ static hipError_t launch_aos_pl(const LbsExArgs& x, hipStream_t s) {
     constexpr uint32_t WPB = kAosBlock / 64;
     const size_t lds = (size_t)x.a.n_bones * 64 + 64 + (size_t)WPB * 64 * x.out_stride;
     const void* fn = reinterpret_cast<const void*>(&lbs_skin_aos<EXACT, SHAPES, PL>);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // persistent grid = exactly what is resident (registers and LDS decide); asked once per LDS size, not per launch
+    // (per host thread: a fyx_ctx is single-threaded; every context runs the same code object)
+    static thread_local size_t cached_lds = ~size_t(0);
+    static thread_local int cached_per_cu = 0;
+    if (lds != cached_lds) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        int q = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, kAosBlock, lds);
         if (e != hipSuccess) return e;
+        cached_per_cu = q < 1 ? 1 : q;
+        cached_lds = lds;
     }
-    // persistent grid = exactly what is resident (registers and LDS decide)
-    int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kAosBlock, lds);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    const int per_cu = cached_per_cu;
     uint32_t grid = (uint32_t)kCUs * (uint32_t)per_cu;
     const uint32_t max_useful = (total + WPB - 1) / WPB;
     if (grid > max_useful) grid = max_useful;
