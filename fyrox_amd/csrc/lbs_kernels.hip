@@ -437,10 +437,9 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
 template <int BLOCK, bool EXACT, int MASK>
 __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tiles, uint32_t ipb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr uint32_t WPB = BLOCK / 64;
     const uint32_t buf_f4 = 4 * a.n_bones;  // rows (3 per bone) + row3 (1 per bone)
     f32x4* const base = reinterpret_cast<f32x4*>(smem);
-    uint32_t* const flags = reinterpret_cast<uint32_t*>(base + 2 * buf_f4);  // [2][WPB]
+    uint32_t* const flags = reinterpret_cast<uint32_t*>(base + 2 * buf_f4);  // [2][4]
 
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -451,24 +450,27 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
     const uint32_t v = tile * BLOCK + tid;
     const bool live = v < a.n_verts;
 
-    PaletteRegs pr = palette_fetch(a.palette + (size_t)i0 * a.n_bones * 16, a.n_bones, tid);
+    // Only the waves whose threads own a bone (n_bones <= 256: waves 0..3) take part in the palette traffic; each
+    // of those four waves owns one flag word per buffer (a wave without bones writes 0 there).
+    const bool owner = wave * 64 < a.n_bones;   // wave-uniform
+    PaletteRegs pr;
+    if (owner) pr = palette_fetch(a.palette + (size_t)i0 * a.n_bones * 16, a.n_bones, tid);
     // the mesh is shared by every workgroup of the launch: ordinary (cacheable) loads
     const VertexIn<MASK> vin = load_vertex<false, MASK>(a, live ? v : 0);
-    {
-        const bool pj = palette_commit(pr, a.n_bones, base, base + 3 * a.n_bones, tid);
-        const bool wave_pj = __any(pj) != 0;
+    if (wave < 4) {
+        bool wave_pj = false;
+        if (owner) wave_pj = __any(palette_commit(pr, a.n_bones, base, base + 3 * a.n_bones, tid)) != 0;
         if (lane == 0) flags[wave] = wave_pj ? 1u : 0u;
     }
     uint32_t cur = 0;
     for (uint32_t inst = i0; inst < i1; ++inst) {  // workgroup-uniform
         const bool more = inst + 1 < i1;
-        if (more) pr = palette_fetch(a.palette + (size_t)(inst + 1) * a.n_bones * 16, a.n_bones, tid);
+        if (more && owner) pr = palette_fetch(a.palette + (size_t)(inst + 1) * a.n_bones * 16, a.n_bones, tid);
         __syncthreads();  // buffer `cur` is complete; nobody reads buffer `cur ^ 1` any more
         const f32x4* rows = base + cur * buf_f4;
         const f32x4* row3 = rows + 3 * a.n_bones;
-        bool projective = false;
-#pragma unroll
-        for (uint32_t wv = 0; wv < WPB; ++wv) projective |= flags[cur * WPB + wv] != 0;
+        const u32x4 fl = *reinterpret_cast<const u32x4*>(flags + cur * 4);
+        const bool projective = (fl.x | fl.y | fl.z | fl.w) != 0;
         // the crowd kernel is VALU-bound, so its fused mode blends the matrices first (see skin_vertex_blended)
         const Skinned o = skin_vertex<EXACT, MASK, true>(rows, row3, projective, vin.id, vin.w, vin.px, vin.py,
                                                          vin.pz, vin.nx, vin.ny, vin.nz, vin.t.x, vin.t.y, vin.t.z);
@@ -479,11 +481,11 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
             if constexpr (MASK & 4)
                 stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, vin.t.w});
         }
-        if (more) {
+        if (more && wave < 4) {
             f32x4* nrows = base + (cur ^ 1) * buf_f4;
-            const bool pj = palette_commit(pr, a.n_bones, nrows, nrows + 3 * a.n_bones, tid);
-            const bool wave_pj = __any(pj) != 0;
-            if (lane == 0) flags[(cur ^ 1) * WPB + wave] = wave_pj ? 1u : 0u;
+            bool wave_pj = false;
+            if (owner) wave_pj = __any(palette_commit(pr, a.n_bones, nrows, nrows + 3 * a.n_bones, tid)) != 0;
+            if (lane == 0) flags[(cur ^ 1) * 4 + wave] = wave_pj ? 1u : 0u;
         }
         cur ^= 1;
     }
