@@ -46,6 +46,7 @@ struct Rig {
     float* d_statics = nullptr;
     uint32_t* d_level_nodes = nullptr;
     uint32_t* d_level_start = nullptr;
+    uint32_t* d_node_level = nullptr;
     float* d_inv_bind = nullptr;
 };
 
@@ -234,7 +235,7 @@ void dfree(void* p) { if (p) (void)hipFree(p); }
 
 void free_tracks(TracksData& t) { dfree(t.d_tracks); dfree(t.d_loc); dfree(t.d_aux); t = TracksData(); }
 void free_rig(Rig& r) {
-    dfree(r.d_parent); dfree(r.d_statics); dfree(r.d_level_nodes); dfree(r.d_level_start); dfree(r.d_inv_bind);
+    dfree(r.d_parent); dfree(r.d_statics); dfree(r.d_level_nodes); dfree(r.d_level_start); dfree(r.d_node_level); dfree(r.d_inv_bind);
     r = Rig();
 }
 void free_bones(BoneList& b) { dfree(b.d_bone_nodes); b = BoneList(); }
@@ -1054,6 +1055,7 @@ RigDev rig_dev(const Rig& r) {
     d.statics = r.d_statics;
     d.level_nodes = r.d_level_nodes;
     d.level_start = r.d_level_start;
+    d.node_level = r.d_node_level;
     d.n_nodes = r.n_nodes;
     d.n_levels = r.n_levels;
     return d;
@@ -1386,6 +1388,7 @@ int fyx_rig_create(fyx_ctx* c, uint64_t rig_id, uint32_t n_nodes, const int32_t*
         if (!rc) rc = upload(c, &r.d_statics, statics.data(), statics.size());
         if (!rc) rc = upload(c, &r.d_level_nodes, level_nodes.data(), level_nodes.size());
         if (!rc) rc = upload(c, &r.d_level_start, level_start.data(), level_start.size());
+        if (!rc) rc = upload(c, &r.d_node_level, depth.data(), depth.size());
         if (!rc) rc = upload(c, &r.d_inv_bind, ib.data(), ib.size());
         if (rc) { free_rig(r); return rc; }
     }

@@ -168,6 +168,7 @@ struct RigDev {
                                  //   rotation_offset(3) rotation_pivot(3) scaling_offset(3) scaling_pivot(3) pad(3)
     const uint32_t* level_nodes; // nodes sorted by depth
     const uint32_t* level_start; // [n_levels + 1]
+    const uint32_t* node_level;  // [n_nodes] depth of each node
     uint32_t n_nodes;
     uint32_t n_levels;
 };
