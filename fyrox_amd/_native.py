@@ -124,6 +124,7 @@ _SIGS = {
     "fyx_absm_update": (c_int, [_P, c_uint64, c_float]),
     "fyx_animator_update_transforms": (c_int, [_P, c_uint64]),
     "fyx_animator_palette": (c_int, [_P, c_uint64, c_uint64, _P]),
+    "fyx_animator_set_palette_output": (c_int, [_P, c_uint64, c_uint64, _P]),
     "fyx_animator_set_local_trs": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, _P]),
     "fyx_animator_read": (c_int, [_P, c_uint64, c_int, _P]),
     "fyx_animator_device_ptr": (c_int, [_P, c_uint64, c_int, POINTER(c_void_p)]),

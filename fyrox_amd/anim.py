@@ -472,6 +472,10 @@ class Animator:
     def palette(self, bones_id: int, d_out: int) -> None:
         self._check(self._l.fyx_animator_palette(self._h, self.id, bones_id, d_out))
 
+    def set_palette_output(self, bones_id: int, d_out: int) -> None:
+        """The update calls write this palette themselves from now on (d_out = 0 unregisters)."""
+        self._check(self._l.fyx_animator_set_palette_output(self._h, self.id, bones_id, d_out or None))
+
     def set_local_trs(self, node: int, trs, first_instance: int = 0) -> None:
         trs = np.ascontiguousarray(trs, dtype=np.float32).reshape(-1, 10)
         self._check(self._l.fyx_animator_set_local_trs(self._h, self.id, node, first_instance, trs.shape[0], _ptr(trs)))

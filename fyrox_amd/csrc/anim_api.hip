@@ -197,6 +197,9 @@ struct Animator {
     std::vector<float2> slices;
     std::vector<uint4> rm_ops;
     std::vector<uint32_t> rm_prog_off;
+    // palettes the update kernel writes itself (fyx_animator_set_palette_output)
+    struct PaletteOut { uint64_t bones_id; float* d_out; };
+    std::vector<PaletteOut> palette_outputs;
     // Property{..} slots: one per distinct (node, property id) any animation of the animator drives
     std::vector<std::pair<int32_t, int32_t>> prop_slots;
     int32_t* d_prop_node = nullptr;
@@ -1056,6 +1059,8 @@ RigDev rig_dev(const Rig& r) {
     d.level_nodes = r.d_level_nodes;
     d.level_start = r.d_level_start;
     d.node_level = r.d_node_level;
+    d.inv_bind = r.d_inv_bind;
+    d.n_pal = 0;
     d.n_nodes = r.n_nodes;
     d.n_levels = r.n_levels;
     return d;
@@ -1154,7 +1159,17 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
             FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), c->stream));
         }
     }
-    FYX_HIP(c, launch_pose_update(f, rig_dev(*A.rig), with_program, c->stream));
+    RigDev rd = rig_dev(*A.rig);
+    for (const Animator::PaletteOut& po : A.palette_outputs) {
+        auto bit = store(c).bones.find(po.bones_id);
+        if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu of a palette output was freed", (unsigned long long)po.bones_id);
+        PaletteOutDev& d = rd.pal[rd.n_pal++];
+        d.bone_nodes = bit->second.d_bone_nodes;
+        d.out = po.d_out;
+        d.n_bones = bit->second.n_bones;
+        d.pad = 0;
+    }
+    FYX_HIP(c, launch_pose_update(f, rd, with_program, c->stream));
     if (with_program) {
         FYX_HIP(c, launch_property_update(f, c->stream));
         FYX_HIP(c, hipEventRecord(A.d_ctrl_consumed[ctrl_slot], c->stream));
@@ -1442,6 +1457,10 @@ int fyx_bone_list_free(fyx_ctx* c, uint64_t bones_id) {
     auto& m = store(c).bones;
     auto it = m.find(bones_id);
     if (it == m.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
+    for (auto& kv : store(c).animators)
+        for (const Animator::PaletteOut& po : kv.second->palette_outputs)
+            if (po.bones_id == bones_id)
+                return fail(c, FYX_ERR_INVALID_ARG, "bone list %llu is a palette output of an animator", (unsigned long long)bones_id);
     if (has_device(c)) { if (int rc = enter_primary(c)) return rc; FYX_HIP(c, hipStreamSynchronize(c->stream)); }
     free_bones(it->second);
     m.erase(it);
@@ -1908,6 +1927,27 @@ int fyx_animator_palette(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, fl
     if (int rc = ensure_device_state(c, *A)) return rc;
     FYX_HIP(c, launch_palette_gather(A->d_global, A->rig->d_inv_bind, bit->second.d_bone_nodes, A->rig->n_nodes,
                                      bit->second.n_bones, A->n_instances, d_out, c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_set_palette_output(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, float* d_out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    auto bit = store(c).bones.find(bones_id);
+    if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
+    if (bit->second.rig_id != A->rig_id) return fail(c, FYX_ERR_INVALID_ARG, "bone list belongs to another rig");
+    auto& v = A->palette_outputs;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].bones_id == bones_id) {
+            if (d_out) v[i].d_out = d_out; else v.erase(v.begin() + (long)i);
+            return FYX_OK;
+        }
+    if (!d_out) return FYX_OK;
+    if (v.size() >= (size_t)kMaxPaletteOutputs)
+        return fail(c, FYX_ERR_UNSUPPORTED, "at most %d palette outputs per animator (use fyx_animator_palette for more)", kMaxPaletteOutputs);
+    v.push_back(Animator::PaletteOut{bones_id, d_out});
     return FYX_OK;
     FYX_GUARD_END(c)
 }

@@ -985,6 +985,29 @@ __global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev
         gout[i] = gin[i];
         lout[i] = lin[i];
     }
+    // Registered palettes (Surface::bones of the meshes this rig drives): bone_matrices[b] = global(bone_b) *
+    // inv_bind(bone_b) (scene/mesh/mod.rs:781-793) straight from the matrices still in LDS -- no separate gather
+    // launch, no re-read of the global matrices.  One thread per output element, nalgebra's column-axpy order.
+    for (uint32_t p = 0; p < rig.n_pal; ++p) {
+        const PaletteOutDev po = rig.pal[p];
+        float* out = po.out + (size_t)inst * po.n_bones * 16;
+        for (uint32_t e = threadIdx.x; e < po.n_bones * 16; e += blockDim.x) {
+            const uint32_t i = e & 3, j = (e >> 2) & 3, b = e >> 4;
+            const int32_t node = po.bone_nodes[b];
+            float y;
+            if (node < 0) {
+                y = (i == j) ? 1.0f : 0.0f;
+            } else {
+                const float* a = l_global + (size_t)node * 16;
+                const float* bb = rig.inv_bind + (size_t)node * 16;
+                y = a[i] * bb[j * 4];
+                y = a[4 + i] * bb[j * 4 + 1] + y;
+                y = a[8 + i] * bb[j * 4 + 2] + y;
+                y = a[12 + i] * bb[j * 4 + 3] + y;
+            }
+            out[e] = y;
+        }
+    }
 }
 
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s) {

@@ -162,7 +162,19 @@ enum : uint32_t {
     OP_APPLY_ANIM = 7,   // write animation[a].pose to the node's local transform
 };
 
+// A palette the update kernel writes by itself at the end of every frame (fyx_animator_set_palette_output).
+struct PaletteOutDev {
+    const int32_t* bone_nodes;   // [n_bones] rig node of each bone, < 0: invalid handle (identity)
+    float* out;                  // [n_instances][n_bones][16]
+    uint32_t n_bones;
+    uint32_t pad;
+};
+constexpr int kMaxPaletteOutputs = 4;
+
 struct RigDev {
+    const float* inv_bind;       // [n_nodes][16]
+    PaletteOutDev pal[kMaxPaletteOutputs];
+    uint32_t n_pal;
     const int32_t* parent;       // [n_nodes], parent index < node index or -1
     const float* statics;        // [n_nodes][28]: pre_rotation(4) post_rotation_matrix(9)
                                  //   rotation_offset(3) rotation_pivot(3) scaling_offset(3) scaling_pivot(3) pad(3)

@@ -395,6 +395,43 @@ def test_animated_morph_weights_drive_blend_shapes_into_a_vertex_buffer(ctx, orc
     p.free()
 
 
+def test_palette_outputs_written_by_the_update_itself(ctx, orc):
+    """fyx_animator_set_palette_output: the update kernel multiplies global * inv_bind while the matrices are still in
+    LDS; the result must equal the separate gather (and the oracle) bit for bit, for two bone lists at once, one with an
+    invalid handle, over several frames and after unregistering."""
+    sc = cases.layered(n_bones=40)
+    o, p = run_scenario(ctx, orc, sc, n_instances=5, frames=6, check_every=10 ** 9)
+    base = p.base_id
+    lists = {base + 51: list(range(40)), base + 52: [39, -1, 7, 3, 3, 0]}
+    bufs = {}
+    for bid, nodes in lists.items():
+        A.create_bone_list(ctx, bid, base, nodes)
+        bufs[bid] = ctx.malloc(5 * len(nodes) * 64)
+        p.set_palette_output(bid, bufs[bid].ptr)
+    for f in range(6, 10):
+        for idx, par in sc.script.get(f, []):
+            o.set_parameter(idx, par); p.set_parameter(idx, par)
+        o.update_machine(sc.dt); p.update_machine(sc.dt)
+        for bid, nodes in lists.items():
+            got = bufs[bid].download(np.float32, 5 * len(nodes) * 16).reshape(5, len(nodes), 16)
+            sep = ctx.malloc(5 * len(nodes) * 64)
+            p.palette(bid, sep.ptr)
+            ref_gpu = sep.download(np.float32, 5 * len(nodes) * 16).reshape(5, len(nodes), 16)
+            sep.free()
+            assert np.array_equal(got.view(np.uint32), ref_gpu.view(np.uint32))
+            check(got[0], o.palette(nodes), True, f"frame {f} palette output")
+            check(got[4], o.palette(nodes), True, f"frame {f} palette output (last instance)")
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx._check(ctx._l.fyx_bone_list_free(ctx._h, base + 52))       # still registered as an output
+    p.set_palette_output(base + 52, 0)
+    ctx._check(ctx._l.fyx_bone_list_free(ctx._h, base + 52))
+    p.update_machine(sc.dt)                                            # the remaining output still works
+    for b in bufs.values():
+        b.free()
+    o.close()
+    p.free()
+
+
 def test_large_rig_1024_nodes(ctx, orc):
     """The LDS-resident hierarchy walk at its upper limit (1024 nodes = 128 KiB of LDS), deep chains."""
     n = 1024

@@ -29,6 +29,8 @@ ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--opt", action="append", default=["lbs.streams=1"],
                 help="kernel option key=value; the frame is a dependent chain (pose -> palette -> skin), so the "
                      "default keeps every launch on the context stream instead of forking to the worker streams")
+ap.add_argument("--palette-output", action="store_true",
+                help="let the update kernel write the palettes itself (fyx_animator_set_palette_output) instead of a separate gather launch")
 ap.add_argument("--root-motion", action="store_true",
                 help="RootMotionSettings on every clip (root = node 0) + AnimationPose::root_motion tracking")
 args = ap.parse_args()
@@ -68,9 +70,14 @@ d_pos, d_nrm, d_tan = ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.ma
 dt = 1.0 / 60.0
 
 
+if args.palette_output:
+    an.set_palette_output(2, d_pal.ptr)
+
+
 def frame(skin=True):
     an.update_machine(dt)
-    an.palette(2, d_pal.ptr)
+    if not args.palette_output:
+        an.palette(2, d_pal.ptr)
     if skin:
         ctx.lbs_skin_device(3, d_pal.ptr, args.bones, args.instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
 
