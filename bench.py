@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--verts", type=int, default=N_VERTS)
     ap.add_argument("--bones", type=int, default=N_BONES)
     ap.add_argument("--random-bones", action="store_true", help="fully random bone indices (worst-case LDS gather)")
-    ap.add_argument("--allgather", action="store_true", help="N>1: add the RCCL all-gather of the skinned buffers")
+    ap.add_argument("--allgather", action="store_true", help="N>1: add the RCCL all-gather of the skinned buffers (fyx_allgather_f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (e.g. lbs.prefetch=0)")
@@ -132,6 +132,10 @@ def main():
         gathered = [torch.empty(world * (nv * 3 + 16), dtype=torch.float32, device="cuda"),
                     torch.empty(world * (nv * 3 + 16), dtype=torch.float32, device="cuda"),
                     torch.empty(world * (nv * 4 + 16), dtype=torch.float32, device="cuda")]
+        # the library's own communicator (fyx_comm_init): rank 0's unique id travels over the process group
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
 
     # One foreign call per step: fyx_lbs_skin_device(ctx, mesh_id, d_palette, n_bones, 1, out...) with
     # the ctypes arguments converted once, so the Python side costs ~1 us per launch.
@@ -147,10 +151,9 @@ def main():
         rc = calls[i % n_sets]()
         if rc:
             ctx._check(rc)
-        if gathered is not None:
-            ctx.sync()                       # skinned shard complete before RCCL reads it
+        if gathered is not None:             # fyx_allgather_f32 is ordered after the launch on the GPU: no host sync
             for g, o in zip(gathered, outs[i % n_sets]):
-                dist.all_gather_into_tensor(g, o)
+                ctx.allgather_f32(o.data_ptr(), o.numel(), g.data_ptr())
 
     # ---- parity spot-check against the oracle before timing (checker only) -------------------
     parity = None

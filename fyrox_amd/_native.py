@@ -146,6 +146,10 @@ _SIGS = {
     "fyx_animator_read_properties": (c_int, [_P, c_uint64, c_int32, _P]),
     "fyx_animator_blend_shape_weights": (c_int, [_P, c_uint64, c_uint32, _P, _P, _P]),
     "fyx_layer_collect_active_animations_events": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int, _P, c_uint32, POINTER(c_uint32), _P]),
+    "fyx_comm_unique_id": (c_int, [_P, _P]),
+    "fyx_comm_init": (c_int, [_P, _P, c_int, c_int]),
+    "fyx_comm_shutdown": (c_int, [_P]),
+    "fyx_allgather_f32": (c_int, [_P, _P, c_size_t, _P]),
     "fyx_animator_plan_root_motion": (c_int, [_P, c_uint64, _P, _P, c_uint32, POINTER(c_uint32), POINTER(c_uint32), _P]),
 }
 

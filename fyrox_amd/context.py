@@ -132,6 +132,23 @@ class Context:
         host = np.ascontiguousarray(host)
         return DeviceBuffer(self, max(host.nbytes, 16)).upload(host)
 
+    # -- multi-GPU exchange (RCCL all-gather behind the C ABI) ----------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = (ctypes.c_uint8 * 128)()
+        self._check(self._l.fyx_comm_unique_id(self._h, buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int) -> None:
+        assert len(unique_id) == 128
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._l.fyx_comm_init(self._h, buf, rank, n_ranks))
+
+    def comm_shutdown(self) -> None:
+        self._check(self._l.fyx_comm_shutdown(self._h))
+
+    def allgather_f32(self, d_send: int, count: int, d_recv: int) -> None:
+        self._check(self._l.fyx_allgather_f32(self._h, d_send, count, d_recv))
+
     # -- mesh registry -------------------------------------------------------------------
     def mesh_upload(self, mesh_id: int, aos: np.ndarray, n_verts: int, stride: int, *, off_pos: int,
                     off_normal: int = -1, off_tangent: int = -1, off_weights: int, off_indices: int) -> None:

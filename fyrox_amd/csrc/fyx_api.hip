@@ -198,6 +198,8 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     fyx::anim_store_destroy(c->anim);
     c->anim = nullptr;
+    fyx::comm_destroy(c->comm);
+    c->comm = nullptr;
     fyx::plan_pool_destroy(c->plan_pool);
     c->plan_pool = nullptr;
     for (auto& kv : c->meshes) free_mesh(kv.second);

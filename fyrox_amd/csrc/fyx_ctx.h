@@ -32,6 +32,8 @@ struct Mesh {
 };
 struct AnimStore;  // anim_api.hip: tracks data, rigs, animators, bone lists
 void anim_store_destroy(AnimStore*);
+struct Comm;        // comm_api.hip: RCCL communicator (dlopen'ed on first use)
+void comm_destroy(Comm*);
 class PlanPool;     // anim_api.hip: host threads that plan a crowd's frame
 void plan_pool_destroy(PlanPool*);
 
@@ -63,6 +65,7 @@ struct fyx_ctx {
     uint64_t fork_gen = 0;
     bool primary_dirty = true;  // context-stream work enqueued since the last fork event
     int next_worker = 0;
+    fyx::Comm* comm = nullptr;
     fyx::AnimStore* anim = nullptr;
     int plan_threads = 8;    // option "anim.threads": host threads planning a crowd's frame (1 = the calling thread only)
     int sample_form = 0;     // option "anim.sample_form": 0 auto, 1 curves on the lanes, 2 instances on the lanes

@@ -518,6 +518,24 @@ int fyx_animator_read(fyx_ctx* ctx, uint64_t animator_id, int what, float* host_
 /* Device address of the same arrays (what as above), for consumers on the GPU. */
 int fyx_animator_device_ptr(fyx_ctx* ctx, uint64_t animator_id, int what, void** out_device_ptr);
 
+/* ---- multi-GPU: the one exchange step of the path --------------------------------------
+ * A scene larger than one GPU is sharded by contiguous vertex range (each GPU holds and skins only its
+ * slice; the <= 16 KiB palette is replicated); crowds shard by instance range.  Neither needs any
+ * communication to skin.  Only a consumer that wants the WHOLE skinned buffer on every GPU pays one
+ * all-gather (RCCL over xGMI), which these calls provide without any other framework in the process:
+ * one process (or thread) per GPU, each with its own fyx_ctx; rank 0 calls fyx_comm_unique_id and the
+ * host application hands the 128 bytes to the other ranks (a file, a pipe, MPI, ...); every rank then
+ * calls fyx_comm_init (collective: returns when all n_ranks have joined).  librccl.so is opened on
+ * first use; without it these calls return FYX_ERR_UNSUPPORTED and nothing else is affected. */
+#define FYX_COMM_ID_BYTES 128
+int fyx_comm_unique_id(fyx_ctx* ctx, uint8_t out_id[FYX_COMM_ID_BYTES]);
+int fyx_comm_init(fyx_ctx* ctx, const uint8_t id[FYX_COMM_ID_BYTES], int rank, int n_ranks);
+int fyx_comm_shutdown(fyx_ctx* ctx);
+/* d_recv[r * count .. (r + 1) * count) = rank r's d_send[0 .. count): ncclAllGather on the context stream,
+ * ordered after every skinning launch in flight (it starts with the GPU-side join of fyx_join).  Equal
+ * counts on all ranks (pad the last shard).  Asynchronous. */
+int fyx_allgather_f32(fyx_ctx* ctx, const float* d_send, size_t count, float* d_recv);
+
 /* ---- control plane without a GPU ----------------------------------------------------- */
 /* A context with no device: registry and control-plane calls work, every call that would touch
  * the GPU returns FYX_ERR_NO_DEVICE.  It computes no poses and no vertices -- it exists so the

@@ -234,6 +234,17 @@ def test_control_only_context_refuses_data_path(cctx):
         cctx.sync()
     assert e.value.code == _native.FYX_ERR_NO_DEVICE
     assert l.fyx_lbs_skin(cctx._h, 1, None, 1, 1, None, None, None, None) != 0
+    # the exchange step needs a device too, and an all-gather needs a communicator first
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        cctx.comm_unique_id()
+    assert e.value.code == _native.FYX_ERR_NO_DEVICE
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        cctx.comm_init(bytes(128), 0, 1)
+    assert e.value.code == _native.FYX_ERR_NO_DEVICE
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        cctx.allgather_f32(0, 16, 0)
+    assert e.value.code == _native.FYX_ERR_INVALID_ARG
+    cctx.comm_shutdown()   # nothing to shut down: a no-op, not an error
 
 
 def test_builder_validation(cctx):

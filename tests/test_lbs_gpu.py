@@ -659,3 +659,40 @@ def test_vertex_buffer_path_rejects_oversized_or_unaligned_layouts(ctx):
         assert ctx.lbs_skin(67, synth.make_palette(8, 5), want=("pos",))["pos"].shape == (64, 3)   # the SoA path still serves it
         ctx.mesh_free(67)
     pal.free(); out.free()
+
+
+def test_single_rank_communicator_all_gathers_a_skinned_shard(ctx, orc):
+    """The exchange step behind the C ABI (fyx_comm_* / fyx_allgather_f32) with a communicator of one rank: the gathered
+    buffer is this rank's skinned shard, bit for bit, and the collective is ordered after the skinning launches without
+    a host sync in between.  The multi-rank layout (rank r's shard at r * count) is covered on CPU by
+    tests/test_sharding.py with the same sharding arithmetic."""
+    from fyrox_amd.sharding import vertex_range
+    m = synth.make_mesh(20_000, 64, synth.SEED_BASE + 41)
+    pal = synth.make_palette(64, synth.SEED_BASE + 41)
+    b, e = vertex_range(m.n_verts, 1, 3)          # the middle shard of a three-way split
+    ctx.mesh_upload_soa(7101, m.pos[b:e], m.weights[b:e], m.indices[b:e], m.normal[b:e], m.tangent[b:e])
+    n = e - b
+    d_pal = ctx.to_device(pal)
+    d_p, d_n, d_t = ctx.malloc(n * 12), ctx.malloc(n * 12), ctx.malloc(n * 16)
+    d_g = ctx.malloc(n * 12)
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx.allgather_f32(d_p.ptr, n * 3, d_g.ptr)     # no communicator yet
+    try:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    except fyrox_amd.FyxError as err:
+        if err.code == fyrox_amd._native.FYX_ERR_UNSUPPORTED:
+            pytest.skip("librccl.so not present")
+        raise
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx.comm_init(bytes(128), 0, 1)                # one communicator per context
+    ctx.lbs_skin_device(7101, d_pal.ptr, 64, 1, d_p.ptr, d_n.ptr, d_t.ptr)
+    ctx.allgather_f32(d_p.ptr, n * 3, d_g.ptr)
+    ctx.sync()
+    ref = orc.lbs_skin(m.pos[b:e], m.weights[b:e], m.indices[b:e], pal, m.normal[b:e], m.tangent[b:e], threads=0)
+    got = d_g.download(np.float32, n * 3).reshape(n, 3)
+    assert np.array_equal(got.view(np.uint32), ref["pos"].view(np.uint32))
+    ctx.comm_shutdown()
+    ctx.comm_shutdown()                                # idempotent
+    for d in (d_pal, d_p, d_n, d_t, d_g):
+        d.free()
+    ctx.mesh_free(7101)
