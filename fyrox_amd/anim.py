@@ -511,6 +511,13 @@ class Animator:
         self._check(self._l.fyx_animator_free(self._h, self.id))
 
 
+def scene_update(ctx, animators: Sequence["Animator"], dt: float) -> None:
+    """fyx_scene_update: one frame of every listed animator (machine update where it has a machine, player update
+    otherwise) -- same results as updating them one by one, one kernel launch per stage for all of them."""
+    ids = np.asarray([a.id for a in animators], np.uint64)
+    ctx._check(ctx._l.fyx_scene_update(ctx._h, _ptr(ids) if len(ids) else None, len(ids), dt))
+
+
 def upload_tracks_data(ctx, tracks_id: int, td: AnimationTracksData) -> None:
     descs, loc, val, kind, lt, rt = td.flatten()
     ctx._check(ctx._l.fyx_tracks_data_upload(ctx._h, tracks_id, len(td.tracks), descs, len(loc), _ptr(loc), _ptr(val),

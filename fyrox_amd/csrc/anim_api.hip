@@ -22,6 +22,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "fyx_ctx.h"
@@ -155,6 +156,20 @@ struct PlanScratch {
     int error = 0;
 };
 
+// Double-buffered pinned staging + device block for per-frame control data: frame k+1 is written and uploaded while
+// frame k's kernels run.  Used per animator (run_frame) and per scene (fyx_scene_update).
+struct CtrlBuffers {
+    void* d[2] = {nullptr, nullptr};
+    size_t d_bytes[2] = {0, 0};
+    hipEvent_t d_consumed[2] = {nullptr, nullptr};   // the kernels that read d[slot] have finished
+    bool d_in_use[2] = {false, false};
+    void* h[2] = {nullptr, nullptr};
+    size_t h_bytes[2] = {0, 0};
+    hipEvent_t h_ev[2] = {nullptr, nullptr};
+    bool h_busy[2] = {false, false};
+    int next = 0;
+};
+
 struct Animator {
     uint64_t rig_id = 0;
     Rig* rig = nullptr;
@@ -177,16 +192,7 @@ struct Animator {
     uint8_t* d_layer_masks = nullptr;
     bool masks_dirty = true;
     uint32_t dev_mask_layers = 0;
-    // per-frame control (device + pinned staging)
-    void* d_ctrl[2] = {nullptr, nullptr};     // double-buffered like the staging: frame k+1 uploads while frame k runs
-    size_t d_ctrl_bytes[2] = {0, 0};
-    hipEvent_t d_ctrl_consumed[2] = {nullptr, nullptr};   // the kernels that read d_ctrl[slot] have finished
-    bool d_ctrl_in_use[2] = {false, false};
-    void* h_ctrl[2] = {nullptr, nullptr};
-    size_t h_ctrl_bytes[2] = {0, 0};
-    hipEvent_t h_ctrl_ev[2] = {nullptr, nullptr};
-    bool h_ctrl_busy[2] = {false, false};
-    int h_ctrl_next = 0;
+    CtrlBuffers ctrl;   // per-frame control (device + pinned staging)
     // frame plan (host)
     std::vector<float> times;
     std::vector<uint8_t> ticked;
@@ -218,7 +224,30 @@ struct Animator {
 
 }  // namespace
 
+// The per-frame control block of an animator (what plan_frame produced), as it travels to the GPU: 256-byte aligned
+// sections {times, ticked, prog_off, ops [, slices, rm_prog_off, rm_ops]}.
+struct CtrlLayout {
+    size_t o_tick = 0, o_off = 0, o_ops = 0, o_slices = 0, o_rmoff = 0, o_rmops = 0, total = 0;
+    bool rm = false;
+};
+
+// fyx_scene_update's cached state: the block tables of the scene it last ran (they depend on the animators' shapes
+// only) and the scene-wide control buffers.
+struct SceneBatch {
+    std::vector<uint64_t> signature;
+    uint4* d_tables = nullptr;
+    size_t table_off[kSceneStages] = {};
+    uint32_t n_blocks[kSceneStages] = {};
+    size_t lds_bytes[kSceneStages] = {};
+    CtrlBuffers ctrl;
+    std::vector<Animator*> animators;   // scratch of the current call
+    std::vector<CtrlLayout> layouts;
+    std::vector<size_t> offsets;
+    std::vector<int> errors;
+};
+
 struct AnimStore {
+    SceneBatch scene;
     std::unordered_map<uint64_t, TracksData> tracks;
     std::unordered_map<uint64_t, Rig> rigs;
     std::unordered_map<uint64_t, BoneList> bones;
@@ -236,6 +265,16 @@ AnimStore& store(fyx_ctx* c) {
 
 void dfree(void* p) { if (p) (void)hipFree(p); }
 
+void free_ctrl(CtrlBuffers& B) {
+    for (int i = 0; i < 2; ++i) {
+        dfree(B.d[i]);
+        if (B.d_consumed[i]) (void)hipEventDestroy(B.d_consumed[i]);
+        if (B.h[i]) (void)hipHostFree(B.h[i]);
+        if (B.h_ev[i]) (void)hipEventDestroy(B.h_ev[i]);
+    }
+    B = CtrlBuffers();
+}
+
 void free_tracks(TracksData& t) { dfree(t.d_tracks); dfree(t.d_loc); dfree(t.d_aux); t = TracksData(); }
 void free_rig(Rig& r) {
     dfree(r.d_parent); dfree(r.d_statics); dfree(r.d_level_nodes); dfree(r.d_level_start); dfree(r.d_node_level); dfree(r.d_inv_bind);
@@ -246,13 +285,8 @@ void free_animator(Animator& a) {
     for (auto& an : a.anims) { dfree(an.d_slot_track); dfree(an.d_prop_track); }
     dfree(a.d_prop_node); dfree(a.d_prop_pose); dfree(a.d_prop_out);
     dfree(a.d_anims); dfree(a.d_hints); dfree(a.d_anim_pose); dfree(a.d_node_trs); dfree(a.d_local);
-    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_ctrl[0]); dfree(a.d_ctrl[1]); dfree(a.d_rm_anim); dfree(a.d_rm_slots);
-    for (int i = 0; i < 2; ++i)
-        if (a.d_ctrl_consumed[i]) (void)hipEventDestroy(a.d_ctrl_consumed[i]);
-    for (int i = 0; i < 2; ++i) {
-        if (a.h_ctrl[i]) (void)hipHostFree(a.h_ctrl[i]);
-        if (a.h_ctrl_ev[i]) (void)hipEventDestroy(a.h_ctrl_ev[i]);
-    }
+    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_rm_anim); dfree(a.d_rm_slots);
+    free_ctrl(a.ctrl);
 }
 
 template <typename T>
@@ -819,7 +853,9 @@ void plan_pool_destroy(PlanPool* p) { delete p; }
 
 namespace {
 
-int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
+// Plans one frame of every instance of A.  Touches nothing but A (fyx_scene_update plans different animators on
+// different threads); n_tasks > 1 splits the instances over `pool`.  Returns 0 or the planner's error code.
+int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool* pool) {
     const uint32_t na = (uint32_t)A.anims.size();
     A.times.assign((size_t)A.n_instances * na, 0.f);
     A.ticked.assign((size_t)A.n_instances * na, 0);
@@ -836,17 +872,6 @@ int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
         A.n_rm_slots = n + 1;
         A.slices.resize((size_t)A.n_instances * na);
         for (size_t k = 0; k < A.slices.size(); ++k) A.slices[k] = make_float2(A.anim_state[k].start, A.anim_state[k].end);
-    }
-    // Planning costs ~0.1 us per instance and waking the pool tens of microseconds: split only big crowds, one
-    // task per `anim.split` instances (default 2048), at most anim.threads of them
-    unsigned n_tasks = 1;
-    const uint32_t split = (uint32_t)std::max(c->plan_split, 1);
-    if (c->plan_threads > 1 && A.n_instances >= 2 * split) {
-        n_tasks = std::min<unsigned>((unsigned)c->plan_threads, A.n_instances / split);
-        if (!c->plan_pool || c->plan_pool->size() + 1 < n_tasks) {
-            delete c->plan_pool;
-            c->plan_pool = new PlanPool(n_tasks - 1);
-        }
     }
     if (A.scratch.size() < n_tasks) A.scratch.resize(n_tasks);
     auto work = [&](unsigned k) {
@@ -865,11 +890,11 @@ int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
             S.rm_prog_len.push_back((uint32_t)(S.rm_ops.size() - r0));
         }
     };
-    if (n_tasks > 1) c->plan_pool->run(n_tasks, work); else work(0);
+    if (n_tasks > 1) pool->run(n_tasks, work); else work(0);
     uint32_t inst = 0;
     for (unsigned k = 0; k < n_tasks; ++k) {  // merge in instance order
         const PlanScratch& S = A.scratch[k];
-        if (S.error) return fail(c, S.error, "pose nodes nest deeper than %d blend levels", kMaxFoldDepth - 2);
+        if (S.error) return S.error;
         uint32_t o = (uint32_t)A.ops.size(), r = (uint32_t)A.rm_ops.size();
         for (size_t j = 0; j < S.prog_len.size(); ++j, ++inst) {
             A.prog_off[inst] = o;
@@ -882,6 +907,29 @@ int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
     }
     A.prog_off[A.n_instances] = (uint32_t)A.ops.size();
     A.rm_prog_off[A.n_instances] = (uint32_t)A.rm_ops.size();
+    return FYX_OK;
+}
+
+PlanPool* plan_pool(fyx_ctx* c, unsigned n_tasks) {
+    if (!c->plan_pool || c->plan_pool->size() + 1 < n_tasks) {
+        delete c->plan_pool;
+        c->plan_pool = new PlanPool(n_tasks - 1);
+    }
+    return c->plan_pool;
+}
+
+// Planning costs ~0.1 us per instance and waking the pool tens of microseconds: split only big crowds, one task per
+// `anim.split` instances (default 2048), at most anim.threads of them
+unsigned plan_tasks(const fyx_ctx* c, const Animator& A) {
+    const uint32_t split = (uint32_t)std::max(c->plan_split, 1);
+    if (c->plan_threads > 1 && A.n_instances >= 2 * split) return std::min<unsigned>((unsigned)c->plan_threads, A.n_instances / split);
+    return 1;
+}
+
+int plan_frame(fyx_ctx* c, Animator& A, int mode, float dt) {
+    const unsigned n_tasks = plan_tasks(c, A);
+    if (int e = plan_frame_core(A, mode, dt, n_tasks, n_tasks > 1 ? plan_pool(c, n_tasks) : nullptr))
+        return fail(c, e, "pose nodes nest deeper than %d blend levels", kMaxFoldDepth - 2);
     return FYX_OK;
 }
 
@@ -1066,11 +1114,8 @@ RigDev rig_dev(const Rig& r) {
     return d;
 }
 
-// Send the planned frame to the GPU and run sample + update.
-int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
-    if (int rc = enter_primary(c)) return rc;
-    if (int rc = ensure_device_state(c, A)) return rc;
-    PoseFrameDev f;
+// The persistent part of an animator's kernel parameters.
+void frame_static(const fyx_ctx* c, const Animator& A, PoseFrameDev& f) {
     memset(&f, 0, sizeof f);
     f.anims = A.d_anims;
     f.n_anims = (uint32_t)A.anims.size();
@@ -1088,78 +1133,52 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     f.prop_node = A.d_prop_node;
     f.prop_pose = A.d_prop_pose;
     f.prop_out = A.d_prop_out;
-    int ctrl_slot = 0;
-    if (with_program) {
-        const size_t b_times = align_up(A.times.size() * 4, 256), b_tick = align_up(A.ticked.size(), 256);
-        const size_t b_off = align_up(A.prog_off.size() * 4, 256), b_ops = align_up(A.ops.size() * 8, 256);
-        const bool rm = A.rm_enabled;
-        const size_t b_slices = rm ? align_up(A.slices.size() * 8, 256) : 0;
-        const size_t b_rmoff = rm ? align_up(A.rm_prog_off.size() * 4, 256) : 0;
-        const size_t b_rmops = rm ? align_up(A.rm_ops.size() * 16, 256) : 0;
-        const size_t o_slices = b_times + b_tick + b_off + b_ops, o_rmoff = o_slices + b_slices, o_rmops = o_rmoff + b_rmoff;
-        const size_t total = o_rmops + b_rmops;
-        const int slot = A.h_ctrl_next;
-        A.h_ctrl_next ^= 1;
-        if (A.h_ctrl_busy[slot]) {
-            FYX_HIP(c, hipEventSynchronize(A.h_ctrl_ev[slot]));
-            A.h_ctrl_busy[slot] = false;
-        }
-        if (total > A.h_ctrl_bytes[slot]) {
-            if (A.h_ctrl[slot]) FYX_HIP(c, hipHostFree(A.h_ctrl[slot]));
-            A.h_ctrl[slot] = nullptr;
-            const size_t want = align_up(total + total / 2, 4096);
-            FYX_HIP(c, hipHostMalloc(&A.h_ctrl[slot], want, hipHostMallocDefault));
-            A.h_ctrl_bytes[slot] = want;
-        }
-        if (!A.h_ctrl_ev[slot]) FYX_HIP(c, hipEventCreateWithFlags(&A.h_ctrl_ev[slot], hipEventDisableTiming));
-        if (total > A.d_ctrl_bytes[slot]) {
-            FYX_HIP(c, hipStreamSynchronize(c->stream));
-            dfree(A.d_ctrl[slot]);
-            A.d_ctrl[slot] = nullptr;
-            const size_t want = align_up(total + total / 2, 4096);
-            FYX_HIP(c, hipMalloc(&A.d_ctrl[slot], want));
-            A.d_ctrl_bytes[slot] = want;
-            A.d_ctrl_in_use[slot] = false;
-        }
-        if (!A.d_ctrl_consumed[slot]) FYX_HIP(c, hipEventCreateWithFlags(&A.d_ctrl_consumed[slot], hipEventDisableTiming));
-        if (!c->upload_stream) FYX_HIP(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
-        char* h = static_cast<char*>(A.h_ctrl[slot]);
-        memcpy(h, A.times.data(), A.times.size() * 4);
-        memcpy(h + b_times, A.ticked.data(), A.ticked.size());
-        memcpy(h + b_times + b_tick, A.prog_off.data(), A.prog_off.size() * 4);
-        memcpy(h + b_times + b_tick + b_off, A.ops.data(), A.ops.size() * 8);
-        if (rm) {
-            memcpy(h + o_slices, A.slices.data(), A.slices.size() * 8);
-            memcpy(h + o_rmoff, A.rm_prog_off.data(), A.rm_prog_off.size() * 4);
-            memcpy(h + o_rmops, A.rm_ops.data(), A.rm_ops.size() * 16);
-        }
-        // The control block has no dependence on the kernels already queued on the context stream (the previous
-        // frame's skinning, typically ~100 us of work), so it travels on its own stream and only the frame's first
-        // kernel waits for it; in-stream it would sit behind that work and add its ~25 us to every frame.
-        if (A.d_ctrl_in_use[slot]) FYX_HIP(c, hipStreamWaitEvent(c->upload_stream, A.d_ctrl_consumed[slot], 0));
-        FYX_HIP(c, hipMemcpyAsync(A.d_ctrl[slot], h, total, hipMemcpyHostToDevice, c->upload_stream));
-        FYX_HIP(c, hipEventRecord(A.h_ctrl_ev[slot], c->upload_stream));
-        FYX_HIP(c, hipStreamWaitEvent(c->stream, A.h_ctrl_ev[slot], 0));
-        A.h_ctrl_busy[slot] = true;
-        ctrl_slot = slot;
-        char* d = static_cast<char*>(A.d_ctrl[slot]);
-        f.times = reinterpret_cast<const float*>(d);
-        f.ticked = reinterpret_cast<const uint8_t*>(d + b_times);
-        f.prog_off = reinterpret_cast<const uint32_t*>(d + b_times + b_tick);
-        f.ops = reinterpret_cast<const uint2*>(d + b_times + b_tick + b_off);
-        FYX_HIP(c, launch_pose_sample(f, c->stream));
-        FYX_HIP(c, launch_property_sample(f, c->stream));
-        if (rm) {
-            f.slices = reinterpret_cast<const float2*>(d + o_slices);
-            f.rm_anim = A.d_rm_anim;
-            f.rm_slots = A.d_rm_slots;
-            f.n_rm_slots = A.dev_rm_slots;
-            f.rm_prog_off = reinterpret_cast<const uint32_t*>(d + o_rmoff);
-            f.rm_ops = reinterpret_cast<const uint4*>(d + o_rmops);
-            FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), c->stream));
-        }
+}
+
+CtrlLayout ctrl_layout(const Animator& A) {
+    CtrlLayout L;
+    L.rm = A.rm_enabled;
+    L.o_tick = align_up(A.times.size() * 4, 256);
+    L.o_off = L.o_tick + align_up(A.ticked.size(), 256);
+    L.o_ops = L.o_off + align_up(A.prog_off.size() * 4, 256);
+    L.o_slices = L.o_ops + align_up(A.ops.size() * 8, 256);
+    L.o_rmoff = L.o_slices + (L.rm ? align_up(A.slices.size() * 8, 256) : 0);
+    L.o_rmops = L.o_rmoff + (L.rm ? align_up(A.rm_prog_off.size() * 4, 256) : 0);
+    L.total = L.o_rmops + (L.rm ? align_up(A.rm_ops.size() * 16, 256) : 0);
+    return L;
+}
+
+void ctrl_write(const Animator& A, const CtrlLayout& L, char* h) {
+    memcpy(h, A.times.data(), A.times.size() * 4);
+    memcpy(h + L.o_tick, A.ticked.data(), A.ticked.size());
+    memcpy(h + L.o_off, A.prog_off.data(), A.prog_off.size() * 4);
+    memcpy(h + L.o_ops, A.ops.data(), A.ops.size() * 8);
+    if (L.rm) {
+        memcpy(h + L.o_slices, A.slices.data(), A.slices.size() * 8);
+        memcpy(h + L.o_rmoff, A.rm_prog_off.data(), A.rm_prog_off.size() * 4);
+        memcpy(h + L.o_rmops, A.rm_ops.data(), A.rm_ops.size() * 16);
     }
-    RigDev rd = rig_dev(*A.rig);
+}
+
+// Point the frame's parameters at the device copy of the control block.
+void ctrl_bind(const Animator& A, const CtrlLayout& L, const char* d, PoseFrameDev& f) {
+    f.times = reinterpret_cast<const float*>(d);
+    f.ticked = reinterpret_cast<const uint8_t*>(d + L.o_tick);
+    f.prog_off = reinterpret_cast<const uint32_t*>(d + L.o_off);
+    f.ops = reinterpret_cast<const uint2*>(d + L.o_ops);
+    if (L.rm) {
+        f.slices = reinterpret_cast<const float2*>(d + L.o_slices);
+        f.rm_anim = A.d_rm_anim;
+        f.rm_slots = A.d_rm_slots;
+        f.n_rm_slots = A.dev_rm_slots;
+        f.rm_prog_off = reinterpret_cast<const uint32_t*>(d + L.o_rmoff);
+        f.rm_ops = reinterpret_cast<const uint4*>(d + L.o_rmops);
+    }
+}
+
+// The rig's parameters plus the palettes the update kernel writes itself.
+int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
+    rd = rig_dev(*A.rig);
     for (const Animator::PaletteOut& po : A.palette_outputs) {
         auto bit = store(c).bones.find(po.bones_id);
         if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu of a palette output was freed", (unsigned long long)po.bones_id);
@@ -1169,13 +1188,205 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         d.n_bones = bit->second.n_bones;
         d.pad = 0;
     }
+    return FYX_OK;
+}
+
+// Claims the next slot with room for `total` bytes; *h / *d are its staging and device blocks.
+int ctrl_acquire(fyx_ctx* c, CtrlBuffers& B, size_t total, int* slot_out, char** h, char** d) {
+    const int slot = B.next;
+    B.next ^= 1;
+    if (B.h_busy[slot]) {
+        FYX_HIP(c, hipEventSynchronize(B.h_ev[slot]));
+        B.h_busy[slot] = false;
+    }
+    if (total > B.h_bytes[slot]) {
+        if (B.h[slot]) FYX_HIP(c, hipHostFree(B.h[slot]));
+        B.h[slot] = nullptr;
+        const size_t want = align_up(total + total / 2, 4096);
+        FYX_HIP(c, hipHostMalloc(&B.h[slot], want, hipHostMallocDefault));
+        B.h_bytes[slot] = want;
+    }
+    if (!B.h_ev[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.h_ev[slot], hipEventDisableTiming));
+    if (total > B.d_bytes[slot]) {
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        dfree(B.d[slot]);
+        B.d[slot] = nullptr;
+        const size_t want = align_up(total + total / 2, 4096);
+        FYX_HIP(c, hipMalloc(&B.d[slot], want));
+        B.d_bytes[slot] = want;
+        B.d_in_use[slot] = false;
+    }
+    if (!B.d_consumed[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.d_consumed[slot], hipEventDisableTiming));
+    if (!c->upload_stream) FYX_HIP(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+    *slot_out = slot;
+    *h = static_cast<char*>(B.h[slot]);
+    *d = static_cast<char*>(B.d[slot]);
+    return FYX_OK;
+}
+
+// The control block has no dependence on the kernels already queued on the context stream (the previous frame's
+// skinning, typically ~100 us of work), so it travels on its own stream and only the frame's first kernel waits for
+// it; in-stream it would sit behind that work and add its ~25 us to every frame.
+int ctrl_upload(fyx_ctx* c, CtrlBuffers& B, int slot, size_t total) {
+    if (B.d_in_use[slot]) FYX_HIP(c, hipStreamWaitEvent(c->upload_stream, B.d_consumed[slot], 0));
+    FYX_HIP(c, hipMemcpyAsync(B.d[slot], B.h[slot], total, hipMemcpyHostToDevice, c->upload_stream));
+    FYX_HIP(c, hipEventRecord(B.h_ev[slot], c->upload_stream));
+    FYX_HIP(c, hipStreamWaitEvent(c->stream, B.h_ev[slot], 0));
+    B.h_busy[slot] = true;
+    return FYX_OK;
+}
+
+int ctrl_consumed(fyx_ctx* c, CtrlBuffers& B, int slot) {
+    FYX_HIP(c, hipEventRecord(B.d_consumed[slot], c->stream));
+    B.d_in_use[slot] = true;
+    return FYX_OK;
+}
+
+// Send the planned frame to the GPU and run sample + update.
+int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, A)) return rc;
+    PoseFrameDev f;
+    frame_static(c, A, f);
+    int slot = 0;
+    if (with_program) {
+        const CtrlLayout L = ctrl_layout(A);
+        char *h = nullptr, *d = nullptr;
+        if (int rc = ctrl_acquire(c, A.ctrl, L.total, &slot, &h, &d)) return rc;
+        ctrl_write(A, L, h);
+        if (int rc = ctrl_upload(c, A.ctrl, slot, L.total)) return rc;
+        ctrl_bind(A, L, d, f);
+        FYX_HIP(c, launch_pose_sample(f, c->stream));
+        FYX_HIP(c, launch_property_sample(f, c->stream));
+        if (L.rm) FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), c->stream));
+    }
+    RigDev rd;
+    if (int rc = rig_params(c, A, rd)) return rc;
     FYX_HIP(c, launch_pose_update(f, rd, with_program, c->stream));
     if (with_program) {
         FYX_HIP(c, launch_property_update(f, c->stream));
-        FYX_HIP(c, hipEventRecord(A.d_ctrl_consumed[ctrl_slot], c->stream));
-        A.d_ctrl_in_use[ctrl_slot] = true;
+        if (int rc = ctrl_consumed(c, A.ctrl, slot)) return rc;
     }
     return FYX_OK;
+}
+
+// One frame of MANY animators (fyx_scene_update): every animator is planned exactly as plan_frame does (different
+// animators on different host threads), the control blocks travel in ONE upload, and each stage of the frame is ONE
+// kernel launch over all of them.  Results are those of run_frame on each animator in turn: the animators share no
+// device state, and the kernels' bodies are the same functions.
+int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
+    const size_t n = S.animators.size();
+    // 1. host control plane.  Crowds big enough to be split go first, one after another, each over the whole pool;
+    //    the rest are dealt out to the pool in contiguous runs of about equal instance counts.
+    S.errors.assign(n, 0);
+    std::vector<size_t> small;
+    uint64_t small_instances = 0;
+    for (size_t k = 0; k < n; ++k) {
+        Animator& A = *S.animators[k];
+        const unsigned nt = plan_tasks(c, A);
+        if (nt > 1) S.errors[k] = plan_frame_core(A, A.layers.empty() ? 0 : 1, dt, nt, plan_pool(c, nt));
+        else { small.push_back(k); small_instances += A.n_instances; }
+    }
+    unsigned n_tasks = 1;
+    if (c->plan_threads > 1 && small.size() >= 32) n_tasks = std::min<unsigned>((unsigned)c->plan_threads, (unsigned)(small.size() / 16));
+    if (n_tasks > 1) {
+        std::vector<size_t> cut(n_tasks + 1, small.size());   // task t plans small[cut[t] .. cut[t + 1])
+        cut[0] = 0;
+        uint64_t acc = 0;
+        unsigned t = 1;
+        for (size_t j = 0; j < small.size() && t < n_tasks; ++j) {
+            acc += S.animators[small[j]]->n_instances;
+            if (acc * n_tasks >= small_instances * t) cut[t++] = j + 1;
+        }
+        plan_pool(c, n_tasks)->run(n_tasks, [&](unsigned task) {
+            for (size_t j = cut[task]; j < cut[task + 1]; ++j) {
+                Animator& A = *S.animators[small[j]];
+                S.errors[small[j]] = plan_frame_core(A, A.layers.empty() ? 0 : 1, dt, 1, nullptr);
+            }
+        });
+    } else {
+        for (size_t k : small) {
+            Animator& A = *S.animators[k];
+            S.errors[k] = plan_frame_core(A, A.layers.empty() ? 0 : 1, dt, 1, nullptr);
+        }
+    }
+    for (size_t k = 0; k < n; ++k)
+        if (S.errors[k]) return fail(c, S.errors[k], "animator %zu of the scene: pose nodes nest deeper than %d blend levels", k, kMaxFoldDepth - 2);
+
+    // 2. device state, and the block tables if the scene's shape changed
+    if (int rc = enter_primary(c)) return rc;
+    std::vector<uint64_t> sig;
+    sig.reserve(n * 3 + 1);
+    sig.push_back((uint64_t)c->sample_form);
+    for (size_t k = 0; k < n; ++k) {
+        Animator& A = *S.animators[k];
+        if (int rc = ensure_device_state(c, A)) return rc;
+        sig.push_back(((uint64_t)A.anims.size() << 32) | A.n_instances);
+        sig.push_back(((uint64_t)A.rig->n_nodes << 32) | A.dev_prop_slots);
+        sig.push_back(A.rm_enabled ? 1 : 0);
+    }
+    if (sig != S.signature) {
+        std::vector<uint4> tables[kSceneStages];
+        size_t lds[kSceneStages] = {};
+        for (size_t k = 0; k < n; ++k) {
+            const Animator& A = *S.animators[k];
+            SceneJobShape sh;
+            sh.n_anims = (uint32_t)A.anims.size();
+            sh.n_instances = A.n_instances;
+            sh.n_nodes = A.rig->n_nodes;
+            sh.n_prop_slots = A.dev_prop_slots;
+            sh.sample_form = (uint32_t)c->sample_form;
+            sh.root_motion = sh.root_motion_program = A.rm_enabled;
+            scene_blocks((uint32_t)k, sh, tables);
+            const int stage = kStageUpdate64 + (int)std::min<uint32_t>((sh.n_nodes + 63) / 64, 4) - 1;
+            lds[stage] = std::max(lds[stage], (size_t)sh.n_nodes * 32 * sizeof(float));
+        }
+        size_t total = 0;
+        for (int k = 0; k < kSceneStages; ++k) {
+            if (tables[k].size() > 0x7fffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "scene too large for one launch per stage");
+            S.table_off[k] = total;
+            S.n_blocks[k] = (uint32_t)tables[k].size();
+            S.lds_bytes[k] = lds[k];
+            total += tables[k].size();
+        }
+        FYX_HIP(c, hipStreamSynchronize(c->stream));   // the previous scene's launches still read the old tables
+        dfree(S.d_tables);
+        S.d_tables = nullptr;
+        S.signature.clear();
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&S.d_tables), std::max<size_t>(total, 1) * sizeof(uint4)));
+        for (int k = 0; k < kSceneStages; ++k)
+            if (!tables[k].empty())
+                FYX_HIP(c, hipMemcpy(S.d_tables + S.table_off[k], tables[k].data(), tables[k].size() * sizeof(uint4), hipMemcpyHostToDevice));
+        S.signature = sig;
+    }
+
+    // 3. one control block: the job array, then every animator's sections
+    S.layouts.resize(n);
+    S.offsets.resize(n);
+    size_t total = align_up(n * sizeof(SceneJobDev), 256);
+    for (size_t k = 0; k < n; ++k) {
+        S.layouts[k] = ctrl_layout(*S.animators[k]);
+        S.offsets[k] = total;
+        total += S.layouts[k].total;
+    }
+    int slot = 0;
+    char *h = nullptr, *d = nullptr;
+    if (int rc = ctrl_acquire(c, S.ctrl, total, &slot, &h, &d)) return rc;
+    SceneJobDev* jobs = reinterpret_cast<SceneJobDev*>(h);
+    for (size_t k = 0; k < n; ++k) {
+        const Animator& A = *S.animators[k];
+        ctrl_write(A, S.layouts[k], h + S.offsets[k]);
+        frame_static(c, A, jobs[k].f);
+        ctrl_bind(A, S.layouts[k], d + S.offsets[k], jobs[k].f);
+        if (int rc = rig_params(c, A, jobs[k].rig)) return rc;
+    }
+    if (int rc = ctrl_upload(c, S.ctrl, slot, total)) return rc;
+
+    // 4. one launch per stage
+    const uint4* tabs[kSceneStages];
+    for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
+    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(d), tabs, S.n_blocks, S.lds_bytes, c->stream));
+    return ctrl_consumed(c, S.ctrl, slot);
 }
 
 template <typename F>
@@ -1221,6 +1432,8 @@ int node_depth(const LayerDef& L, int32_t h, std::vector<int>& state) {
 
 void anim_store_destroy(AnimStore* s) {
     if (!s) return;
+    dfree(s->scene.d_tables);
+    free_ctrl(s->scene.ctrl);
     for (auto& kv : s->animators) free_animator(*kv.second);
     for (auto& kv : s->bones) free_bones(kv.second);
     for (auto& kv : s->rigs) free_rig(kv.second);
@@ -1902,6 +2115,26 @@ int fyx_absm_update(fyx_ctx* c, uint64_t animator_id, float dt) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     return update_common(c, animator_id, 1, dt);
+    FYX_GUARD_END(c)
+}
+
+int fyx_scene_update(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animators, float dt) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (n_animators && !animator_ids) return fail(c, FYX_ERR_INVALID_ARG, "null animator list");
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: no GPU to run the pose kernels on");
+    if (n_animators == 0) return FYX_OK;
+    SceneBatch& S = store(c).scene;
+    S.animators.clear();
+    std::unordered_set<uint64_t> seen;
+    for (uint32_t k = 0; k < n_animators; ++k) {
+        auto it = store(c).animators.find(animator_ids[k]);
+        if (it == store(c).animators.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "animator %llu", (unsigned long long)animator_ids[k]);
+        if (!seen.insert(animator_ids[k]).second)
+            return fail(c, FYX_ERR_INVALID_ARG, "animator %llu is listed twice", (unsigned long long)animator_ids[k]);
+        S.animators.push_back(it->second.get());
+    }
+    return scene_frame(c, S, dt);
     FYX_GUARD_END(c)
 }
 

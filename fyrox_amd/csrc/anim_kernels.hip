@@ -171,10 +171,10 @@ __device__ __forceinline__ f4 group_rotation(float v, int has_r, int rkind, int 
 // ---------------------------------------------------------------------------------------
 // Grid: x = 16-node slices of one instance, y = instance, z = animation -- no index arithmetic beyond shifts
 // (the kernel is VALU-issue bound: ~64 K waves of a few hundred instructions each for the C3 crowd).
-__global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
+__device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
     const uint32_t lane = threadIdx.x & 63u, j = threadIdx.x & 15u, gbase = lane & ~15u;
-    const uint32_t a = blockIdx.z, inst = blockIdx.y;
-    const uint32_t node = (blockIdx.x * 256u + threadIdx.x) >> 4;
+    const uint32_t a = bz, inst = by;
+    const uint32_t node = (bx * 256u + threadIdx.x) >> 4;
     {
         if (node >= f.n_nodes) return;                                   // uniform across the group
         if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      // uniform across the block
@@ -228,6 +228,18 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
     }
 }
 
+__global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) { pose_sample_body(f, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Scene forms of the kernels in this file (fyx_scene_update): ONE launch covers the same stage of MANY animators.
+// Block b of the launch looks up (job, x, y, z) in a table that depends only on the scene's shape -- which animator
+// it works for and which block of that animator's own grid it stands for -- copies the job's parameter block out of
+// HBM (uniform address, loaded before any store: scalar loads, exactly like kernel arguments) and runs the body above.
+__global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+    const uint4 b = blocks[blockIdx.x];
+    const PoseFrameDev f = jobs[b.x].f;
+    pose_sample_body(f, b.y, b.z, b.w);
+}
+
 // ---------------------------------------------------------------------------------------
 // Crowd form of pose_sample: the lanes of a wave are 64 INSTANCES of one (animation, node).
 //
@@ -238,13 +250,13 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) {
 // one dense span, and the only scattered access left is the 16-byte store of the wave's part of the pose record.
 // Same arithmetic, same order: bit-identical to the form above.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pose_sample_crowd_kernel(PoseFrameDev f) {
+__device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
     // One wave = 64 instances of one (animation, node, BINDING): the position, scale and rotation tracks of a node
     // are sampled by three different waves, so a thread walks at most four curves (the chain of dependent loads
     // is what bounds this kernel) and the three 16-byte parts of the pose record have one writer each.
-    const uint32_t inst = blockIdx.x * 64u + threadIdx.x, a = blockIdx.z;
-    const uint32_t node = blockIdx.y / 3u;
-    const int bind = (int)(blockIdx.y - node * 3u);           // FYX_BIND_POSITION, _SCALE, _ROTATION
+    const uint32_t inst = bx * 64u + threadIdx.x, a = bz;
+    const uint32_t node = by / 3u;
+    const int bind = (int)(by - node * 3u);           // FYX_BIND_POSITION, _SCALE, _ROTATION
     if (inst >= f.n_instances) return;
     if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;
     const float time = f.times[(size_t)inst * f.n_anims + a];
@@ -310,6 +322,14 @@ __global__ __launch_bounds__(64) void pose_sample_crowd_kernel(PoseFrameDev f) {
     }
 }
 
+__global__ __launch_bounds__(64) void pose_sample_crowd_kernel(PoseFrameDev f) { pose_sample_crowd_body(f, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+__global__ __launch_bounds__(64) void pose_sample_crowd_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+    const uint4 b = blocks[blockIdx.x];
+    const PoseFrameDev f = jobs[b.x].f;
+    pose_sample_crowd_body(f, b.y, b.z, b.w);
+}
+
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s) {
     if (f.n_anims == 0 || f.n_instances == 0 || f.n_nodes == 0) return hipSuccess;
     if (f.n_instances > 65535u || f.n_anims > 65535u || f.n_nodes * 3u > 65535u) return hipErrorInvalidValue;   // grid limits
@@ -337,11 +357,11 @@ hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s) {
 // order in which the reference's pose nodes / layers / machine called clone_into and blend_with on
 // each other's poses, recorded by the host control plane) over the persistent slots.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void root_motion_kernel(PoseFrameDev f) {
+__device__ __forceinline__ void root_motion_body(const PoseFrameDev& f, uint32_t bx, uint32_t n_blocks) {
     const uint32_t lane = threadIdx.x & 63u, j = threadIdx.x & 15u, gbase = lane & ~15u;
     const uint32_t items = f.n_anims * f.n_instances;
-    const uint32_t groups_per_pass = (gridDim.x * blockDim.x) >> 4;
-    for (uint32_t item = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; item < items; item += groups_per_pass) {
+    const uint32_t groups_per_pass = (n_blocks * blockDim.x) >> 4;
+    for (uint32_t item = (bx * blockDim.x + threadIdx.x) >> 4; item < items; item += groups_per_pass) {
         const uint32_t a = item / f.n_instances, inst = item - a * f.n_instances;
         const uint32_t flags = f.ticked[(size_t)inst * f.n_anims + a];
         const AnimDev an = f.anims[a];
@@ -475,8 +495,8 @@ __device__ __forceinline__ void rm_blend(f4& sp, f4& sr, f4 op, f4 orr, float w)
     sr = quat_normalize(f4{a.x * omw + orr.x * w, a.y * omw + orr.y * w, a.z * omw + orr.z * w, a.w * omw + orr.w * w});
 }
 
-__global__ __launch_bounds__(64) void root_motion_fold_kernel(PoseFrameDev f) {
-    const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void root_motion_fold_body(const PoseFrameDev& f, uint32_t bx) {
+    const uint32_t inst = bx * blockDim.x + threadIdx.x;
     if (inst >= f.n_instances) return;
     f4* slots = reinterpret_cast<f4*>(f.rm_slots) + (size_t)inst * f.n_rm_slots * 2;
     uint32_t pc = f.rm_prog_off[inst];
@@ -508,6 +528,20 @@ __global__ __launch_bounds__(64) void root_motion_fold_kernel(PoseFrameDev f) {
         }
         op = next;
     }
+}
+
+__global__ __launch_bounds__(256) void root_motion_kernel(PoseFrameDev f) { root_motion_body(f, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void root_motion_fold_kernel(PoseFrameDev f) { root_motion_fold_body(f, blockIdx.x); }
+
+__global__ __launch_bounds__(256) void root_motion_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+    const uint4 b = blocks[blockIdx.x];          // {job, block of the job, blocks of the job, -}
+    const PoseFrameDev f = jobs[b.x].f;
+    root_motion_body(f, b.y, b.z);
+}
+__global__ __launch_bounds__(64) void root_motion_fold_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+    const uint4 b = blocks[blockIdx.x];
+    const PoseFrameDev f = jobs[b.x].f;
+    root_motion_fold_body(f, b.y);
 }
 
 hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s) {
@@ -655,8 +689,8 @@ __device__ __forceinline__ void run_fold(FoldCtx& cx, Acc& acc) {
 // for the node" (the node threads of pose_update see it in their mask), and a slot thread carries the node's mask
 // along with its own {value, present} through the same fold program.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void property_sample_kernel(PoseFrameDev f) {
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x, inst = blockIdx.y, a = blockIdx.z;
+__device__ __forceinline__ void property_sample_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
+    const uint32_t slot = bx * 256u + threadIdx.x, inst = by, a = bz;
     if (slot >= f.n_prop_slots) return;
     if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;
     const AnimDev an = f.anims[a];
@@ -675,6 +709,13 @@ __global__ __launch_bounds__(256) void property_sample_kernel(PoseFrameDev f) {
         }
     }
     f.prop_pose[((size_t)a * f.n_instances + inst) * f.n_prop_slots + slot] = out;
+}
+
+__global__ __launch_bounds__(256) void property_sample_kernel(PoseFrameDev f) { property_sample_body(f, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256) void property_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+    const uint4 b = blocks[blockIdx.x];
+    const PoseFrameDev f = jobs[b.x].f;
+    property_sample_body(f, b.y, b.z, b.w);
 }
 
 hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s) {
@@ -754,8 +795,8 @@ __device__ __forceinline__ void run_fold_prop(PFoldCtx& cx, PAcc& acc) {
     }
 }
 
-__global__ __launch_bounds__(64) void property_update_kernel(PoseFrameDev f) {
-    const uint32_t slot = blockIdx.x * 64u + threadIdx.x, inst = blockIdx.y;
+__device__ __forceinline__ void property_update_body(const PoseFrameDev& f, uint32_t bx, uint32_t by) {
+    const uint32_t slot = bx * 64u + threadIdx.x, inst = by;
     if (slot >= f.n_prop_slots) return;
     PFoldCtx cx;
     cx.ops = f.ops + f.prog_off[inst];
@@ -776,6 +817,13 @@ __global__ __launch_bounds__(64) void property_update_kernel(PoseFrameDev f) {
     PAcc acc{0.0f, 0u, 0u};
     while (!cx.done) run_fold_prop<0>(cx, acc);
     if (cx.out_set) f.prop_out[(size_t)inst * f.n_prop_slots + slot] = make_float2(cx.out_v, __uint_as_float(1u));
+}
+
+__global__ __launch_bounds__(64) void property_update_kernel(PoseFrameDev f) { property_update_body(f, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(64) void property_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+    const uint4 b = blocks[blockIdx.x];
+    const PoseFrameDev f = jobs[b.x].f;
+    property_update_body(f, b.y, b.z);
 }
 
 hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s) {
@@ -887,11 +935,10 @@ __device__ __forceinline__ void mat4_mul(const float* a, const float* b, float* 
 // pose_update: one workgroup per instance.
 // ---------------------------------------------------------------------------------------
 template <bool PROGRAM>
-__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) {
+__device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* l_local = lds;                               // [n_nodes][16]
     float* l_global = lds + (size_t)rig.n_nodes * 16;   // [n_nodes][16]
-    const uint32_t inst = blockIdx.x;
     const size_t inst_base = (size_t)inst * rig.n_nodes;
 
     for (uint32_t node = threadIdx.x; node < rig.n_nodes; node += blockDim.x) {
@@ -1010,6 +1057,17 @@ __global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev
     }
 }
 
+template <bool PROGRAM>
+__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) { pose_update_body<PROGRAM>(f, rig, blockIdx.x); }
+
+// Scene form: every job of one launch has the same block size; the dynamic LDS is sized for the largest rig among them.
+__global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+    const uint4 b = blocks[blockIdx.x];
+    const PoseFrameDev f = jobs[b.x].f;
+    const RigDev rig = jobs[b.x].rig;
+    pose_update_body<true>(f, rig, b.y);
+}
+
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s) {
     if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;
     uint32_t block = ((rig.n_nodes + 63) / 64) * 64;
@@ -1073,6 +1131,73 @@ hipError_t launch_palette_gather(const float* d_global, const float* d_inv_bind,
     if (grid > (uint64_t)kCUs * 16) grid = (uint64_t)kCUs * 16;
     hipLaunchKernelGGL(palette_gather_kernel, dim3((uint32_t)grid), dim3(256), 0, s, d_global, d_inv_bind,
                        d_bone_nodes, n_nodes, n_bones, n_instances, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Scene launches (fyx_scene_update): the grids of launch_pose_sample / _property_sample / _root_motion / _pose_update /
+// _property_update, flattened into per-stage block tables so that one launch serves every animator of a scene.
+// ---------------------------------------------------------------------------------------
+void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[kSceneStages]) {
+    if (s.n_instances == 0 || s.n_nodes == 0) return;
+    if (s.n_anims) {
+        if (s.sample_form == 2 || (s.sample_form == 0 && s.n_instances >= 32)) {
+            const uint32_t gx = (s.n_instances + 63) / 64;
+            for (uint32_t a = 0; a < s.n_anims; ++a)
+                for (uint32_t y = 0; y < s.n_nodes * 3; ++y)
+                    for (uint32_t x = 0; x < gx; ++x) t[kStageSampleCrowd].push_back(make_uint4(job, x, y, a));
+        } else {
+            const uint32_t gx = (s.n_nodes * 16 + 255) / 256;
+            for (uint32_t a = 0; a < s.n_anims; ++a)
+                for (uint32_t i = 0; i < s.n_instances; ++i)
+                    for (uint32_t x = 0; x < gx; ++x) t[kStageSample].push_back(make_uint4(job, x, i, a));
+        }
+        if (s.n_prop_slots) {
+            const uint32_t gx = (s.n_prop_slots + 255) / 256;
+            for (uint32_t a = 0; a < s.n_anims; ++a)
+                for (uint32_t i = 0; i < s.n_instances; ++i)
+                    for (uint32_t x = 0; x < gx; ++x) t[kStagePropSample].push_back(make_uint4(job, x, i, a));
+        }
+        if (s.root_motion) {
+            const uint64_t items = (uint64_t)s.n_anims * s.n_instances;
+            uint64_t grid = (items * 16 + 255) / 256;
+            if (grid > (uint64_t)kCUs * 16) grid = (uint64_t)kCUs * 16;
+            for (uint32_t x = 0; x < (uint32_t)grid; ++x) t[kStageRootMotion].push_back(make_uint4(job, x, (uint32_t)grid, 0));
+        }
+    }
+    if (s.root_motion_program)
+        for (uint32_t x = 0; x < (s.n_instances + 63) / 64; ++x) t[kStageRootMotionFold].push_back(make_uint4(job, x, 0, 0));
+    uint32_t block = (s.n_nodes + 63) / 64;
+    if (block > 4) block = 4;
+    for (uint32_t i = 0; i < s.n_instances; ++i) t[kStageUpdate64 + (int)block - 1].push_back(make_uint4(job, i, 0, 0));
+    if (s.n_prop_slots) {
+        const uint32_t gx = (s.n_prop_slots + 63) / 64;
+        for (uint32_t i = 0; i < s.n_instances; ++i)
+            for (uint32_t x = 0; x < gx; ++x) t[kStagePropUpdate].push_back(make_uint4(job, x, i, 0));
+    }
+}
+
+hipError_t launch_scene(const SceneJobDev* d_jobs, const uint4* const (&d_tables)[kSceneStages],
+                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], hipStream_t s) {
+    auto go = [&](int stage, auto kernel, uint32_t block, size_t lds) {
+        if (n_blocks[stage]) hipLaunchKernelGGL(kernel, dim3(n_blocks[stage]), dim3(block), lds, s, d_jobs, d_tables[stage]);
+    };
+    go(kStageSample, pose_sample_scene_kernel, 256, 0);
+    go(kStageSampleCrowd, pose_sample_crowd_scene_kernel, 64, 0);
+    go(kStagePropSample, property_sample_scene_kernel, 256, 0);
+    go(kStageRootMotion, root_motion_scene_kernel, 256, 0);
+    go(kStageRootMotionFold, root_motion_fold_scene_kernel, 64, 0);
+    size_t max_lds = 0;
+    for (int k = kStageUpdate64; k <= kStageUpdate256; ++k)
+        if (n_blocks[k]) max_lds = std::max(max_lds, lds_bytes[k]);
+    if (max_lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_update_scene_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+        if (e != hipSuccess) return e;
+    }
+    for (int k = kStageUpdate64; k <= kStageUpdate256; ++k)
+        go(k, pose_update_scene_kernel, 64u * (uint32_t)(k - kStageUpdate64 + 1), lds_bytes[k]);
+    go(kStagePropUpdate, property_update_scene_kernel, 64, 0);
     return hipGetLastError();
 }
 

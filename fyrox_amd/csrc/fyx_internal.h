@@ -1,6 +1,8 @@
 // Internal declarations shared by the HIP translation units of libfyrox_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <stdint.h>
 
 namespace fyx {
@@ -217,6 +219,39 @@ struct PoseFrameDev {
     const uint4* rm_ops;         // all instances' root-motion programs
     const uint32_t* rm_prog_off; // [n_instances + 1]
 };
+
+// fyx_scene_update: one parameter block per animator of the scene, rewritten every frame (it points into the frame's
+// control block) and read by the *_scene_kernel forms, whose block tables say which job a block works for.
+struct SceneJobDev {
+    PoseFrameDev f;
+    RigDev rig;
+};
+
+// The stages of a scene frame.  Each has a table of {job, x, y, z} per block (uint4), built by scene_blocks() from the
+// jobs' shapes alone (so it is uploaded once per scene, not per frame) in the order the launch runs them.
+enum SceneStage : int {
+    kStageSample = 0,      // pose_sample, curves on the lanes      {job, node slice, instance, animation}
+    kStageSampleCrowd,     // pose_sample, instances on the lanes   {job, instance slice, node * 3 + binding, animation}
+    kStagePropSample,      //                                       {job, slot slice, instance, animation}
+    kStageRootMotion,      //                                       {job, block, blocks of the job, -}
+    kStageRootMotionFold,  //                                       {job, instance slice, -, -}
+    kStageUpdate64,        // pose_update with 64 / 128 / 192 / 256 threads: {job, instance, -, -}
+    kStageUpdate128,
+    kStageUpdate192,
+    kStageUpdate256,
+    kStagePropUpdate,      //                                       {job, slot slice, instance, -}
+    kSceneStages
+};
+struct SceneJobShape {   // what the tables depend on
+    uint32_t n_anims, n_instances, n_nodes, n_prop_slots, sample_form;
+    bool root_motion, root_motion_program;
+};
+// Appends job `job`'s blocks to the per-stage tables.
+void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&tables)[kSceneStages]);
+// One launch per non-empty stage.  d_tables[k] / n_blocks[k]: the device copy of stage k's table; lds_bytes[k]: dynamic
+// LDS of the update stages (the largest rig of the stage).
+hipError_t launch_scene(const SceneJobDev* d_jobs, const uint4* const (&d_tables)[kSceneStages],
+                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], hipStream_t s);
 
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s);
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s);

@@ -489,7 +489,16 @@ int fyx_animation_player_update(fyx_ctx* ctx, uint64_t animator_id, float dt);
 /* AnimationBlendingStateMachine::update (absm.rs:311-326) = Machine::evaluate_pose
  * (machine/mod.rs:344-382) + AnimationPoseExt::apply_internal. */
 int fyx_absm_update(fyx_ctx* ctx, uint64_t animator_id, float dt);
-/* Both calls also refresh the local and global matrices of every node of every instance
+/* Graph::update ticks EVERY node of a scene (scene/graph/mod.rs:1459-1502 -> update_node :1415-1440: `node.update(ctx)` for every pool slot), i.e.
+ * every AnimationPlayer and every AnimationBlendingStateMachine once per frame.  Batch form of the two calls
+ * above for a scene of many animators: each listed animator gets fyx_absm_update if it has a machine,
+ * fyx_animation_player_update otherwise, with results identical to calling them one by one in list order -- but the
+ * host control planes run on the planner threads side by side, all control data travels in one upload, and each
+ * stage of the frame is ONE kernel launch over all animators (a scene of 256 distinct characters costs what one
+ * costs in launches).  An id may appear once.  Palettes registered with fyx_animator_set_palette_output are
+ * written as usual. */
+int fyx_scene_update(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t n_animators, float dt);
+/* All three calls also refresh the local and global matrices of every node of every instance
  * (Transform::matrix + Graph::update_hierarchical_data); this one does only that (after
  * fyx_animator_set_local_trs, or for a rig nothing animates). */
 int fyx_animator_update_transforms(fyx_ctx* ctx, uint64_t animator_id);

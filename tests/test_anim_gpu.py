@@ -47,10 +47,37 @@ def check_pose(got, ref, exact, what):
     check(np.ascontiguousarray(g), np.ascontiguousarray(r), exact, what)
 
 
+def check_frame(p, o, sc, n_instances, f):
+    """Everything the product can read back after frame f against the oracle's single instance."""
+    exact = not sc.has_euler
+    for a in range(len(sc.animations)):
+        got = p.read(A.READ_ANIMATION_POSE + a)
+        ref = o.animation_pose(a)
+        for i in (0, n_instances - 1):
+            check_pose(got[i], ref, exact, f"{sc.name} frame {f} animation {a} pose (instance {i})")
+    trs, loc, glo = p.read(A.READ_LOCAL_TRS), p.read(A.READ_LOCAL_MATRIX), p.read(A.READ_GLOBAL_MATRIX)
+    for i in (0, n_instances - 1):
+        check(trs[i], o.node_trs(), exact, f"{sc.name} frame {f} node TRS")
+        check(loc[i], o.local_matrices(), exact, f"{sc.name} frame {f} local matrices")
+        check(glo[i], o.global_matrices(), exact, f"{sc.name} frame {f} global matrices")
+    if sc.machine is not None:
+        for li in range(len(sc.machine.layers)):
+            assert p.layer_state(li, n_instances - 1) == o.layer_state(li)
+    if p.property_count():
+        check_properties(p, o, sc, exact, f"{sc.name} frame {f}")
+    if sc.track_root_motion:
+        for a in range(len(sc.animations)):
+            check_root_motion(p.animation_root_motion(a), o.animation_root_motion(a), exact,
+                              f"{sc.name} frame {f} animation {a} root motion")
+        if sc.machine is not None:
+            for li in range(-1, len(sc.machine.layers)):
+                check_root_motion(p.machine_root_motion(li), o.machine_root_motion(li), exact,
+                                  f"{sc.name} frame {f} root motion of " + ("the machine" if li < 0 else f"layer {li}"))
+
+
 def run_scenario(ctx, orc, sc, n_instances=1, frames=None, check_every=1):
     o = cases.build_oracle(orc, sc)
     p = cases.build_product(ctx, sc, n_instances)
-    exact = not sc.has_euler
     frames = sc.n_frames if frames is None else frames
     for f in range(frames):
         for idx, par in sc.script.get(f, []):
@@ -64,29 +91,7 @@ def run_scenario(ctx, orc, sc, n_instances=1, frames=None, check_every=1):
             p.update_machine(sc.dt)
         if f % check_every and f != frames - 1:
             continue
-        for a in range(len(sc.animations)):
-            got = p.read(A.READ_ANIMATION_POSE + a)
-            ref = o.animation_pose(a)
-            for i in (0, n_instances - 1):
-                check_pose(got[i], ref, exact, f"{sc.name} frame {f} animation {a} pose (instance {i})")
-        trs, loc, glo = p.read(A.READ_LOCAL_TRS), p.read(A.READ_LOCAL_MATRIX), p.read(A.READ_GLOBAL_MATRIX)
-        for i in (0, n_instances - 1):
-            check(trs[i], o.node_trs(), exact, f"{sc.name} frame {f} node TRS")
-            check(loc[i], o.local_matrices(), exact, f"{sc.name} frame {f} local matrices")
-            check(glo[i], o.global_matrices(), exact, f"{sc.name} frame {f} global matrices")
-        if sc.machine is not None:
-            for li in range(len(sc.machine.layers)):
-                assert p.layer_state(li, n_instances - 1) == o.layer_state(li)
-        if p.property_count():
-            check_properties(p, o, sc, exact, f"{sc.name} frame {f}")
-        if sc.track_root_motion:
-            for a in range(len(sc.animations)):
-                check_root_motion(p.animation_root_motion(a), o.animation_root_motion(a), exact,
-                                  f"{sc.name} frame {f} animation {a} root motion")
-            if sc.machine is not None:
-                for li in range(-1, len(sc.machine.layers)):
-                    check_root_motion(p.machine_root_motion(li), o.machine_root_motion(li), exact,
-                                      f"{sc.name} frame {f} root motion of " + ("the machine" if li < 0 else f"layer {li}"))
+        check_frame(p, o, sc, n_instances, f)
     return o, p
 
 
@@ -445,3 +450,115 @@ def test_large_rig_1024_nodes(ctx, orc):
     with pytest.raises(fyrox_amd.FyxError) as e:
         A.create_rig(ctx, 31337, synth.make_rig(1025, 1))
     assert e.value.code == fyrox_amd._native.FYX_ERR_UNSUPPORTED
+
+
+# ---- fyx_scene_update: many animators, one launch per stage ----------------------------------------------------
+
+def _scene_members():
+    """Every scenario of the suite (blend trees, transitions, layers, Euler and quaternion tracks, properties, root motion
+    with signals, random machines), with instance counts that put some on the curves-on-the-lanes sampler and some on
+    the instances-on-the-lanes one."""
+    makes = list(cases.ALL) + list(cases.ALL_RM) + [lambda s=s: cases.random_machine(s) for s in (3, 11, 19)]
+    counts = [1, 3, 40, 1, 2, 70, 1, 5]
+    return [(mk(), counts[k % len(counts)]) for k, mk in enumerate(makes)]
+
+
+def test_scene_update_matches_the_oracle_for_every_member(ctx, orc):
+    members = _scene_members()
+    dt = 1.0 / 48.0     # one step for the whole scene, as Graph::update passes one dt to every node
+    os_ = [cases.build_oracle(orc, sc) for sc, _ in members]
+    ps = [cases.build_product(ctx, sc, n) for sc, n in members]
+    frames = 48
+    for f in range(frames):
+        for (sc, _), o, p in zip(members, os_, ps):
+            for idx, par in sc.script.get(f, []):
+                o.set_parameter(idx, par)
+                p.set_parameter(idx, par)
+            if sc.machine is None:
+                o.update_animations(dt)
+            else:
+                o.update_machine(dt)
+        A.scene_update(ctx, ps, dt)
+        if f % 6 == 0 or f == frames - 1:
+            for (sc, n), o, p in zip(members, os_, ps):
+                check_frame(p, o, sc, n, f)
+    # events raised by the host control plane arrive as they do one by one
+    for (sc, n), o, p in zip(members, os_, ps):
+        for a in range(len(sc.animations)):
+            assert _drain(lambda: p.pop_event(a, n - 1)) == _drain(lambda: o.pop_event(a)), f"{sc.name}: events of animation {a}"
+
+
+def test_scene_update_is_bit_identical_to_one_by_one_updates(ctx, orc):
+    """Two copies of the same scene, one stepped by fyx_scene_update and one animator by animator: every read-back is
+    identical bit for bit (Euler scenarios included -- same kernels' bodies, same order), across a change of the
+    scene's membership and order."""
+    members = _scene_members()
+    dt = 1.0 / 48.0
+    pa = [cases.build_product(ctx, sc, n) for sc, n in members]
+    pb = [cases.build_product(ctx, sc, n) for sc, n in members]
+    order = list(range(len(members)))
+    for f in range(30):
+        if f == 10:
+            order = order[::-1]             # same members, other order: other tables, same results
+        if f == 20:
+            order = order[::2]              # a smaller scene; the rest keep their state
+        for k in order:
+            sc = members[k][0]
+            for idx, par in sc.script.get(f, []):
+                pa[k].set_parameter(idx, par)
+                pb[k].set_parameter(idx, par)
+            if sc.machine is None:
+                pb[k].update_animations(dt)
+            else:
+                pb[k].update_machine(dt)
+        A.scene_update(ctx, [pa[k] for k in order], dt)
+        if f % 5 == 4:
+            for k in range(len(members)):
+                sc = members[k][0]
+                for what in [A.READ_LOCAL_TRS, A.READ_LOCAL_MATRIX, A.READ_GLOBAL_MATRIX] + [A.READ_ANIMATION_POSE + a for a in range(len(sc.animations))]:
+                    ga, gb = pa[k].read(what), pb[k].read(what)
+                    assert np.array_equal(ga.view(np.uint32), gb.view(np.uint32)), f"{sc.name} frame {f} read {what}"
+                if pa[k].property_count():
+                    assert np.array_equal(pa[k].read_properties(-1).view(np.uint32), pb[k].read_properties(-1).view(np.uint32))
+                if sc.track_root_motion and sc.machine is not None:
+                    assert np.array_equal(pa[k].machine_root_motion(-1).view(np.uint32), pb[k].machine_root_motion(-1).view(np.uint32))
+
+
+def test_scene_update_writes_registered_palettes_and_feeds_skinning(ctx, orc):
+    """Palette outputs of several rigs written by the one update launch; then skinning from them."""
+    specs = [(cases.c5_blend_tree(), 3), (cases.transitions(), 1), (cases.layered(), 2)]
+    os_ = [cases.build_oracle(orc, sc) for sc, _ in specs]
+    ps = [cases.build_product(ctx, sc, n) for sc, n in specs]
+    pals = []
+    for k, ((sc, n), p) in enumerate(zip(specs, ps)):
+        bones = list(range(sc.rig.n_nodes))[::-1]
+        A.create_bone_list(ctx, 9100 + k, p.base_id, bones)
+        d = ctx.malloc(n * len(bones) * 64)
+        p.set_palette_output(9100 + k, d.ptr)
+        pals.append((bones, d))
+    for f in range(12):
+        for (sc, _), o in zip(specs, os_):
+            for idx, par in sc.script.get(f, []):
+                o.set_parameter(idx, par)
+            o.update_machine(1 / 30) if sc.machine is not None else o.update_animations(1 / 30)
+        for (sc, _), p in zip(specs, ps):
+            for idx, par in sc.script.get(f, []):
+                p.set_parameter(idx, par)
+        A.scene_update(ctx, ps, 1 / 30)
+    ctx.sync()
+    for (sc, n), o, (bones, d) in zip(specs, os_, pals):
+        got = d.download(np.float32, n * len(bones) * 16).reshape(n, len(bones), 16)
+        ref = o.palette(bones)
+        for i in range(n):
+            check(got[i], ref, not sc.has_euler, f"{sc.name} palette (instance {i})")
+
+
+def test_scene_update_argument_errors(ctx):
+    sc = cases.by_index()
+    p = cases.build_product(ctx, sc)
+    A.scene_update(ctx, [], 1 / 60)     # an empty scene is fine
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        A.scene_update(ctx, [p, p], 1 / 60)
+    assert e.value.code == fyrox_amd._native.FYX_ERR_INVALID_ARG
+    ids = np.asarray([p.id, 0xdead], np.uint64)
+    assert ctx._l.fyx_scene_update(ctx._h, ids.ctypes.data_as(__import__("ctypes").c_void_p), 2, 1 / 60) == fyrox_amd._native.FYX_ERR_UNKNOWN_ID

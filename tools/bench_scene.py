@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""A heterogeneous scene on one MI355X: K distinct characters (each its own rig, clips, state machine and mesh --
+one AnimationPlayer + AnimationBlendingStateMachine + Mesh per character in the reference's scene graph,
+`fyrox-impl/src/scene/animation/absm.rs:311-326`), N instances of each.  Per frame and per character:
+    fyx_scene_update (all characters at once; `one_by_one` = fyx_absm_update per character) -> palettes (written by the
+    update kernel) -> fyx_lbs_skin_device per character
+Many small dependent chains: launch-bound rather than bandwidth-bound.  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fyrox_amd
+from fyrox_amd import anim as A
+from fyrox_amd import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--characters", type=int, default=64)
+ap.add_argument("--instances", type=int, default=4)
+ap.add_argument("--verts", type=int, default=20_000)
+ap.add_argument("--bones", type=int, default=64)
+ap.add_argument("--frames", type=int, default=100)
+ap.add_argument("--warmup", type=int, default=10)
+ap.add_argument("--opt", action="append", default=[])
+args = ap.parse_args()
+
+ctx = fyrox_amd.Context(0)
+for kv in args.opt:
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
+K, N = args.characters, args.instances
+chars = []
+for k in range(K):
+    seed = synth.SEED_BASE + 100 + k
+    rig = synth.make_rig(args.bones, seed)
+    rid, aid, bid, mid = 1000 + k, 2000 + k, 3000 + k, 4000 + k
+    A.create_rig(ctx, rid, rig)
+    an = A.Animator(ctx, aid, rid, rig, N)
+    for c in range(4):
+        td, tgt = synth.make_clip(args.bones, seed, clip=c)
+        A.upload_tracks_data(ctx, 10_000 + 4 * k + c, td)
+        an.add_animation(10_000 + 4 * k + c, tgt, time_slice=(0.0, 1.0), speed=[1.0, 0.8, 1.3, -0.7][c])
+    an.set_machine(synth.make_c5_machine())
+    for i in range(N):
+        for c in range(4):
+            an.set_time_position(c, (i * 0.37 + c * 0.11 + k * 0.05) % 1.0, instance=i)
+    A.create_bone_list(ctx, bid, rid, list(range(args.bones)))
+    mesh = synth.make_mesh(args.verts, args.bones, seed)
+    ctx.mesh_upload_soa(mid, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    nv = args.verts * N
+    d_pal = ctx.malloc(N * args.bones * 64)
+    outs = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+    an.set_palette_output(bid, d_pal.ptr)
+    chars.append((an, mid, d_pal, outs))
+dt = 1.0 / 60.0
+
+
+animators = [c[0] for c in chars]
+
+
+def frame(skin=True, pose=True, batched=True):
+    if pose and batched:
+        A.scene_update(ctx, animators, dt)           # one launch per stage for the whole scene
+    for an, mid, d_pal, o in chars:
+        if pose and not batched:
+            an.update_machine(dt)                    # one by one: what the batched call replaces
+        if skin:
+            ctx.lbs_skin_device(mid, d_pal.ptr, args.bones, N, o[0].ptr, o[1].ptr, o[2].ptr)
+
+
+def timed(**kw):
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.timer_begin()
+    for _ in range(args.frames):
+        frame(**kw)
+    gpu = ctx.timer_end()
+    return gpu / args.frames, (time.perf_counter() - t0) * 1e3 / args.frames
+
+
+for _ in range(args.warmup):
+    frame()
+f_gpu, f_wall = timed()
+p_gpu, p_wall = timed(skin=False)
+s_gpu, s_wall = timed(pose=False)
+f1_gpu, f1_wall = timed(batched=False)
+p1_gpu, p1_wall = timed(skin=False, batched=False)
+t0 = time.perf_counter()
+for _ in range(args.frames):
+    for an, *_ in chars:
+        an.plan(1, dt)
+plan = (time.perf_counter() - t0) * 1e3 / args.frames
+total_verts = K * N * args.verts
+print(json.dumps({
+    "workload": f"{K} distinct characters x {N} instances x {args.verts} verts / {args.bones} bones, 4-clip blend-tree machine each",
+    "options": {k: ctx.get_option(k) for k in ("lbs.streams", "anim.threads")},
+    "frame_ms_gpu": f_gpu, "frame_ms_wall": f_wall, "pose_ms_gpu": p_gpu, "pose_ms_wall": p_wall,
+    "one_by_one": {"frame_ms_wall": f1_wall, "pose_ms_gpu": p1_gpu, "pose_ms_wall": p1_wall},
+    "skin_ms_gpu": s_gpu, "skin_ms_wall": s_wall, "host_control_plane_ms": plan,
+    "per_character_us_wall": f_wall * 1e3 / K, "skinned_vertices_per_s": total_verts / (f_wall * 1e-3),
+    "scene_frames_per_s": 1e3 / f_wall}), flush=True)
+ctx.close()
