@@ -29,6 +29,12 @@ _STATUS_NAMES = {
 }
 
 
+class SkinJob(ctypes.Structure):
+    """fyx_skin_job"""
+    _fields_ = [("mesh_id", c_uint64), ("d_palette", c_void_p), ("n_bones", c_uint32), ("n_instances", c_uint32),
+                ("d_out_pos", c_void_p), ("d_out_normal", c_void_p), ("d_out_tangent", c_void_p)]
+
+
 class SkinDesc(ctypes.Structure):
     """fyx_skin_desc (include/fyrox_hip.h)."""
     _fields_ = [("d_palette", c_void_p), ("n_bones", c_uint32), ("n_instances", c_uint32),
@@ -146,6 +152,7 @@ _SIGS = {
     "fyx_animator_read_properties": (c_int, [_P, c_uint64, c_int32, _P]),
     "fyx_animator_blend_shape_weights": (c_int, [_P, c_uint64, c_uint32, _P, _P, _P]),
     "fyx_layer_collect_active_animations_events": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int, _P, c_uint32, POINTER(c_uint32), _P]),
+    "fyx_lbs_skin_batch": (c_int, [_P, _P, c_uint32]),
     "fyx_scene_update": (c_int, [_P, _P, c_uint32, c_float]),
     "fyx_comm_unique_id": (c_int, [_P, _P]),
     "fyx_comm_init": (c_int, [_P, _P, c_int, c_int]),

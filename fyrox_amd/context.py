@@ -219,6 +219,17 @@ class Context:
                                                  n_bones, n_instances, d_out_pos or None,
                                                  d_out_normal or None, d_out_tangent or None))
 
+    def lbs_skin_batch(self, jobs) -> None:
+        """jobs: sequence of (mesh_id, d_palette, n_bones, n_instances, d_out_pos, d_out_normal, d_out_tangent) or a
+        prebuilt (SkinJob * n) array (fyx_lbs_skin_batch)."""
+        from ._native import SkinJob
+        if not isinstance(jobs, ctypes.Array):
+            arr = (SkinJob * len(jobs))()
+            for k, j in enumerate(jobs):
+                arr[k] = SkinJob(*[(v or None) if i in (1, 4, 5, 6) else v for i, v in enumerate(j)])
+            jobs = arr
+        self._check(self._l.fyx_lbs_skin_batch(self._h, jobs, len(jobs)))
+
     def mesh_set_blend_shapes(self, mesh_id: int, storage: Optional[np.ndarray], n_shapes: int, plane_vertices: int) -> None:
         """storage: the RGB16F volume bytes of BlendShapesContainer (uint16 view), [shape][plane][9]."""
         st = None if storage is None else np.ascontiguousarray(storage).view(np.uint16)

@@ -156,20 +156,6 @@ struct PlanScratch {
     int error = 0;
 };
 
-// Double-buffered pinned staging + device block for per-frame control data: frame k+1 is written and uploaded while
-// frame k's kernels run.  Used per animator (run_frame) and per scene (fyx_scene_update).
-struct CtrlBuffers {
-    void* d[2] = {nullptr, nullptr};
-    size_t d_bytes[2] = {0, 0};
-    hipEvent_t d_consumed[2] = {nullptr, nullptr};   // the kernels that read d[slot] have finished
-    bool d_in_use[2] = {false, false};
-    void* h[2] = {nullptr, nullptr};
-    size_t h_bytes[2] = {0, 0};
-    hipEvent_t h_ev[2] = {nullptr, nullptr};
-    bool h_busy[2] = {false, false};
-    int next = 0;
-};
-
 struct Animator {
     uint64_t rig_id = 0;
     Rig* rig = nullptr;
@@ -264,16 +250,6 @@ AnimStore& store(fyx_ctx* c) {
 }
 
 void dfree(void* p) { if (p) (void)hipFree(p); }
-
-void free_ctrl(CtrlBuffers& B) {
-    for (int i = 0; i < 2; ++i) {
-        dfree(B.d[i]);
-        if (B.d_consumed[i]) (void)hipEventDestroy(B.d_consumed[i]);
-        if (B.h[i]) (void)hipHostFree(B.h[i]);
-        if (B.h_ev[i]) (void)hipEventDestroy(B.h_ev[i]);
-    }
-    B = CtrlBuffers();
-}
 
 void free_tracks(TracksData& t) { dfree(t.d_tracks); dfree(t.d_loc); dfree(t.d_aux); t = TracksData(); }
 void free_rig(Rig& r) {
@@ -1188,57 +1164,6 @@ int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
         d.n_bones = bit->second.n_bones;
         d.pad = 0;
     }
-    return FYX_OK;
-}
-
-// Claims the next slot with room for `total` bytes; *h / *d are its staging and device blocks.
-int ctrl_acquire(fyx_ctx* c, CtrlBuffers& B, size_t total, int* slot_out, char** h, char** d) {
-    const int slot = B.next;
-    B.next ^= 1;
-    if (B.h_busy[slot]) {
-        FYX_HIP(c, hipEventSynchronize(B.h_ev[slot]));
-        B.h_busy[slot] = false;
-    }
-    if (total > B.h_bytes[slot]) {
-        if (B.h[slot]) FYX_HIP(c, hipHostFree(B.h[slot]));
-        B.h[slot] = nullptr;
-        const size_t want = align_up(total + total / 2, 4096);
-        FYX_HIP(c, hipHostMalloc(&B.h[slot], want, hipHostMallocDefault));
-        B.h_bytes[slot] = want;
-    }
-    if (!B.h_ev[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.h_ev[slot], hipEventDisableTiming));
-    if (total > B.d_bytes[slot]) {
-        FYX_HIP(c, hipStreamSynchronize(c->stream));
-        dfree(B.d[slot]);
-        B.d[slot] = nullptr;
-        const size_t want = align_up(total + total / 2, 4096);
-        FYX_HIP(c, hipMalloc(&B.d[slot], want));
-        B.d_bytes[slot] = want;
-        B.d_in_use[slot] = false;
-    }
-    if (!B.d_consumed[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.d_consumed[slot], hipEventDisableTiming));
-    if (!c->upload_stream) FYX_HIP(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
-    *slot_out = slot;
-    *h = static_cast<char*>(B.h[slot]);
-    *d = static_cast<char*>(B.d[slot]);
-    return FYX_OK;
-}
-
-// The control block has no dependence on the kernels already queued on the context stream (the previous frame's
-// skinning, typically ~100 us of work), so it travels on its own stream and only the frame's first kernel waits for
-// it; in-stream it would sit behind that work and add its ~25 us to every frame.
-int ctrl_upload(fyx_ctx* c, CtrlBuffers& B, int slot, size_t total) {
-    if (B.d_in_use[slot]) FYX_HIP(c, hipStreamWaitEvent(c->upload_stream, B.d_consumed[slot], 0));
-    FYX_HIP(c, hipMemcpyAsync(B.d[slot], B.h[slot], total, hipMemcpyHostToDevice, c->upload_stream));
-    FYX_HIP(c, hipEventRecord(B.h_ev[slot], c->upload_stream));
-    FYX_HIP(c, hipStreamWaitEvent(c->stream, B.h_ev[slot], 0));
-    B.h_busy[slot] = true;
-    return FYX_OK;
-}
-
-int ctrl_consumed(fyx_ctx* c, CtrlBuffers& B, int slot) {
-    FYX_HIP(c, hipEventRecord(B.d_consumed[slot], c->stream));
-    B.d_in_use[slot] = true;
     return FYX_OK;
 }
 

@@ -72,6 +72,80 @@ int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
     return FYX_OK;
 }
 
+void free_ctrl(CtrlBuffers& B) {
+    for (int i = 0; i < 2; ++i) {
+        if (B.d[i]) (void)hipFree(B.d[i]);
+        if (B.d_consumed[i]) (void)hipEventDestroy(B.d_consumed[i]);
+        if (B.h[i]) (void)hipHostFree(B.h[i]);
+        if (B.h_ev[i]) (void)hipEventDestroy(B.h_ev[i]);
+    }
+    B = CtrlBuffers();
+}
+
+int ctrl_acquire(fyx_ctx* c, CtrlBuffers& B, size_t total, int* slot_out, char** h, char** d) {
+    const int slot = B.next;
+    B.next ^= 1;
+    if (B.h_busy[slot]) {
+        FYX_HIP(c, hipEventSynchronize(B.h_ev[slot]));
+        B.h_busy[slot] = false;
+    }
+    if (total > B.h_bytes[slot]) {
+        if (B.h[slot]) FYX_HIP(c, hipHostFree(B.h[slot]));
+        B.h[slot] = nullptr;
+        const size_t want = align_up(total + total / 2, 4096);
+        FYX_HIP(c, hipHostMalloc(&B.h[slot], want, hipHostMallocDefault));
+        B.h_bytes[slot] = want;
+    }
+    if (!B.h_ev[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.h_ev[slot], hipEventDisableTiming));
+    if (total > B.d_bytes[slot]) {
+        if (int rc = enter_primary(c)) return rc;            // whoever still reads the old block, on any launch stream
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        if (B.d[slot]) (void)hipFree(B.d[slot]);
+        B.d[slot] = nullptr;
+        const size_t want = align_up(total + total / 2, 4096);
+        FYX_HIP(c, hipMalloc(&B.d[slot], want));
+        B.d_bytes[slot] = want;
+        B.d_in_use[slot] = false;
+    }
+    if (!B.d_consumed[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.d_consumed[slot], hipEventDisableTiming));
+    if (!c->upload_stream) FYX_HIP(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+    *slot_out = slot;
+    *h = static_cast<char*>(B.h[slot]);
+    *d = static_cast<char*>(B.d[slot]);
+    return FYX_OK;
+}
+
+// The control block has no dependence on the kernels already queued on the context stream (the previous frame's
+// skinning, typically ~100 us of work), so it travels on its own stream and only the frame's first kernel waits for
+// it; in-stream it would sit behind that work and add its ~25 us to every frame.
+int ctrl_upload(fyx_ctx* c, CtrlBuffers& B, int slot, size_t total, hipStream_t consumer) {
+    if (B.d_in_use[slot]) FYX_HIP(c, hipStreamWaitEvent(c->upload_stream, B.d_consumed[slot], 0));
+    FYX_HIP(c, hipMemcpyAsync(B.d[slot], B.h[slot], total, hipMemcpyHostToDevice, c->upload_stream));
+    FYX_HIP(c, hipEventRecord(B.h_ev[slot], c->upload_stream));
+    FYX_HIP(c, hipStreamWaitEvent(consumer ? consumer : c->stream, B.h_ev[slot], 0));
+    B.h_busy[slot] = true;
+    return FYX_OK;
+}
+
+int ctrl_consumed(fyx_ctx* c, CtrlBuffers& B, int slot, hipStream_t consumer) {
+    FYX_HIP(c, hipEventRecord(B.d_consumed[slot], consumer ? consumer : c->stream));
+    B.d_in_use[slot] = true;
+    return FYX_OK;
+}
+
+// fyx_lbs_skin_batch: the tables of the last batch (a scene sends the same one every frame: no re-upload then)
+struct SkinBatch {
+    CtrlBuffers ctrl;
+    std::vector<char> last;     // bytes of the last uploaded tables
+    int last_slot = -1;
+    std::vector<char> build;    // scratch of the current call
+};
+void skin_batch_destroy(SkinBatch* b) {
+    if (!b) return;
+    free_ctrl(b->ctrl);
+    delete b;
+}
+
 int ensure_scratch(fyx_ctx* c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return FYX_OK;
     if (c->scratch) {
@@ -201,6 +275,7 @@ void fyx_shutdown(fyx_ctx* c) {
     fyx::comm_destroy(c->comm);
     c->comm = nullptr;
     fyx::plan_pool_destroy(c->plan_pool);
+    fyx::skin_batch_destroy(c->skin_batch);
     c->plan_pool = nullptr;
     for (auto& kv : c->meshes) free_mesh(kv.second);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -491,6 +566,115 @@ int fyx_lbs_skin_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, ui
     hipStream_t st;
     if (int sr = acquire_launch_stream(c, &st)) return sr;
     FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_lbs_skin_batch(fyx_ctx* c, const fyx_skin_job* jobs, uint32_t n_jobs) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (n_jobs && !jobs) return fail(c, FYX_ERR_INVALID_ARG, "jobs is null");
+    if (n_jobs == 0) return FYX_OK;
+    // validate everything before anything is launched
+    constexpr uint32_t kCrowdFrom = 16;   // jobs with this many instances go to the crowd kernel (vertices in registers)
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        const fyx_skin_job& J = jobs[j];
+        const Mesh* m = find_mesh(c, J.mesh_id);
+        if (int rc = check_skin_args(c, m, J.mesh_id, J.d_palette, J.n_bones, J.n_instances)) return rc;
+        if (J.d_out_normal && !m->nrm) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "job %u: mesh has no Normal attribute", j);
+        if (J.d_out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "job %u: mesh has no Tangent attribute", j);
+    }
+    if (!c->skin_batch) c->skin_batch = new SkinBatch();
+    SkinBatch& B = *c->skin_batch;
+    // segments grouped by output mask (one launch per mask; a scene normally has one)
+    struct Group { std::vector<fyx::LbsSegDev> segs; uint32_t units = 0, max_bones = 0; };
+    Group groups[8];
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        const fyx_skin_job& J = jobs[j];
+        const Mesh& m = *find_mesh(c, J.mesh_id);
+        if (m.n_verts == 0 || J.n_instances >= kCrowdFrom) continue;
+        const int mask = (J.d_out_pos ? 1 : 0) | (J.d_out_normal ? 2 : 0) | (J.d_out_tangent ? 4 : 0);
+        if (!mask) continue;
+        Group& G = groups[mask];
+        const uint32_t upi = (m.n_verts + 63) / 64;
+        for (uint32_t i = 0; i < J.n_instances; ++i) {
+            if ((uint64_t)G.units + upi > 0xffffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "batch too large for one launch");
+            fyx::LbsSegDev sg;
+            sg.pos = m.pos; sg.nrm = m.nrm; sg.tan = m.tan; sg.wgt = m.wgt; sg.idx = m.idx;
+            sg.palette = J.d_palette + (size_t)i * J.n_bones * 16;
+            sg.out_pos = J.d_out_pos ? J.d_out_pos + (size_t)i * m.n_verts * 3 : nullptr;
+            sg.out_nrm = J.d_out_normal ? J.d_out_normal + (size_t)i * m.n_verts * 3 : nullptr;
+            sg.out_tan = J.d_out_tangent ? J.d_out_tangent + (size_t)i * m.n_verts * 4 : nullptr;
+            sg.n_verts = m.n_verts;
+            sg.n_bones = J.n_bones;
+            sg.unit0 = G.units;
+            sg.pad = 0;
+            G.segs.push_back(sg);
+            G.units += upi;
+            G.max_bones = std::max(G.max_bones, J.n_bones);
+        }
+    }
+    // tables: per group its segments, then the first segment of every workgroup
+    struct Placed { size_t o_segs, o_blocks; uint32_t grid; };
+    Placed placed[8] = {};
+    size_t total = 0;
+    for (int k = 1; k < 8; ++k) {
+        Group& G = groups[k];
+        if (G.segs.empty()) continue;
+        placed[k].grid = fyx::lbs_batch_grid(G.units, c->lbs);
+        placed[k].o_segs = total;
+        total += align_up(G.segs.size() * sizeof(fyx::LbsSegDev), 256);
+        placed[k].o_blocks = total;
+        total += align_up((size_t)placed[k].grid * 4, 256);
+    }
+    // One launch that fills the chip: nothing to gain from a worker stream, and on the context stream the table
+    // buffers have a single consumer to order their reuse against.
+    if (int sr = enter_primary(c)) return sr;
+    const hipStream_t st = c->stream;
+    if (total) {
+        B.build.assign(total, 0);
+        for (int k = 1; k < 8; ++k) {
+            Group& G = groups[k];
+            if (G.segs.empty()) continue;
+            memcpy(B.build.data() + placed[k].o_segs, G.segs.data(), G.segs.size() * sizeof(fyx::LbsSegDev));
+            uint32_t* bs = reinterpret_cast<uint32_t*>(B.build.data() + placed[k].o_blocks);
+            uint32_t sg = 0;
+            for (uint32_t b = 0; b < placed[k].grid; ++b) {
+                const uint32_t u = (uint32_t)(((uint64_t)b * G.units) / placed[k].grid);
+                while (sg + 1 < G.segs.size() && G.segs[sg + 1].unit0 <= u) ++sg;
+                bs[b] = sg;
+            }
+        }
+        int slot = B.last_slot;
+        const bool same = slot >= 0 && B.last.size() == total && memcmp(B.last.data(), B.build.data(), total) == 0;
+        if (!same) {
+            char *h = nullptr, *d = nullptr;
+            if (int rc = ctrl_acquire(c, B.ctrl, total, &slot, &h, &d)) return rc;
+            memcpy(h, B.build.data(), total);
+            if (int rc = ctrl_upload(c, B.ctrl, slot, total, st)) return rc;
+            B.last.swap(B.build);
+            B.last_slot = slot;
+        } else if (B.ctrl.h_busy[slot]) {
+            FYX_HIP(c, hipStreamWaitEvent(st, B.ctrl.h_ev[slot], 0));   // a borrowed stream may have changed since the upload
+        }
+        const char* d = static_cast<const char*>(B.ctrl.d[slot]);
+        for (int k = 1; k < 8; ++k) {
+            const Group& G = groups[k];
+            if (G.segs.empty()) continue;
+            FYX_HIP(c, fyx::launch_lbs_batch(reinterpret_cast<const fyx::LbsSegDev*>(d + placed[k].o_segs), (uint32_t)G.segs.size(),
+                                             reinterpret_cast<const uint32_t*>(d + placed[k].o_blocks), placed[k].grid, G.units,
+                                             G.max_bones, k, c->lbs, st));
+        }
+        if (int rc = ctrl_consumed(c, B.ctrl, slot, st)) return rc;
+    }
+    // crowds: one launch each, vertices held in registers across the instances
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        const fyx_skin_job& J = jobs[j];
+        if (J.n_instances < kCrowdFrom) continue;
+        const Mesh& m = *find_mesh(c, J.mesh_id);
+        const fyx::LbsArgs a = make_args(m, J.d_palette, J.n_bones, J.n_instances, J.d_out_pos, J.d_out_normal, J.d_out_tangent);
+        FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
+    }
     return FYX_OK;
     FYX_GUARD_END(c)
 }

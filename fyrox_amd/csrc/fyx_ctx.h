@@ -34,6 +34,24 @@ struct AnimStore;  // anim_api.hip: tracks data, rigs, animators, bone lists
 void anim_store_destroy(AnimStore*);
 struct Comm;        // comm_api.hip: RCCL communicator (dlopen'ed on first use)
 void comm_destroy(Comm*);
+// Double-buffered pinned staging + device block for per-frame control data (the pose path's per-animator and
+// per-scene control blocks, the job tables of fyx_lbs_skin_batch): frame k+1 is written and uploaded while frame k's
+// kernels run.
+struct CtrlBuffers {
+    void* d[2] = {nullptr, nullptr};
+    size_t d_bytes[2] = {0, 0};
+    hipEvent_t d_consumed[2] = {nullptr, nullptr};   // the kernels that read d[slot] have finished
+    bool d_in_use[2] = {false, false};
+    void* h[2] = {nullptr, nullptr};
+    size_t h_bytes[2] = {0, 0};
+    hipEvent_t h_ev[2] = {nullptr, nullptr};
+    bool h_busy[2] = {false, false};
+    int next = 0;
+};
+
+struct SkinBatch;   // fyx_api.hip: cached tables of fyx_lbs_skin_batch
+void skin_batch_destroy(SkinBatch*);
+
 class PlanPool;     // anim_api.hip: host threads that plan a crowd's frame
 void plan_pool_destroy(PlanPool*);
 
@@ -71,6 +89,7 @@ struct fyx_ctx {
     int sample_form = 0;     // option "anim.sample_form": 0 auto, 1 curves on the lanes, 2 instances on the lanes
     int plan_split = 2048;   // option "anim.split": instances per planning task
     fyx::PlanPool* plan_pool = nullptr;
+    fyx::SkinBatch* skin_batch = nullptr;
 };
 
 
@@ -81,6 +100,13 @@ size_t align_up(size_t x, size_t a);
 int join_workers(fyx_ctx* c);
 int enter_primary(fyx_ctx* c);
 int ensure_scratch(fyx_ctx* c, size_t bytes);
+void free_ctrl(CtrlBuffers& B);
+// Claims the next slot with room for `total` bytes; *h / *d are its staging and device blocks.
+int ctrl_acquire(fyx_ctx* c, CtrlBuffers& B, size_t total, int* slot_out, char** h, char** d);
+// Sends slot's staging block to its device block on the upload stream; `consumer` (default: the context stream) waits for it.
+int ctrl_upload(fyx_ctx* c, CtrlBuffers& B, int slot, size_t total, hipStream_t consumer = nullptr);
+// Marks the point on `consumer` after which the device block may be overwritten.
+int ctrl_consumed(fyx_ctx* c, CtrlBuffers& B, int slot, hipStream_t consumer = nullptr);
 }  // namespace fyx
 
 #define FYX_HIP(c, call)                                               \

@@ -42,6 +42,31 @@ struct LbsArgs {
 // Launch the skinning kernel.  Returns hipSuccess or the launch error.
 hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream);
 
+// Batched launch (fyx_lbs_skin_batch): ONE launch skins many (mesh, palette) pairs.  A segment is one instance of one
+// job; segments are laid end to end in a common numbering of 64-vertex units and the workgroups of the launch take
+// equal contiguous unit ranges of the whole batch, exactly as lbs_skin does for the instances of one mesh.
+struct LbsSegDev {
+    const float* pos;
+    const float* nrm;
+    const float* tan;
+    const float* wgt;
+    const uint32_t* idx;
+    const float* palette;    // this instance's n_bones matrices
+    float* out_pos;          // this instance's outputs (null where the launch's mask has no bit)
+    float* out_nrm;
+    float* out_tan;
+    uint32_t n_verts;
+    uint32_t n_bones;
+    uint32_t unit0;          // first unit of the segment in the batch
+    uint32_t pad;
+};
+// grid for a batch of total_units units
+uint32_t lbs_batch_grid(uint32_t total_units, const LbsTuning& t);
+// d_block_seg[b] = the segment that holds workgroup b's first unit.  mask: bit 0 position, 1 normal, 2 tangent (the
+// same for every segment of the launch); max_bones sizes the LDS.
+hipError_t launch_lbs_batch(const LbsSegDev* d_segs, uint32_t n_segs, const uint32_t* d_block_seg, uint32_t grid,
+                            uint32_t total_units, uint32_t max_bones, int mask, const LbsTuning& t, hipStream_t stream);
+
 // Extended launch: blend shapes before skinning and / or interleaved output (lbs_skin_ex).
 struct LbsExArgs {
     LbsArgs a;                   // out_* are the SoA outputs (ignored when out_aos is set)

@@ -609,6 +609,119 @@ hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream) 
 }
 
 // ---------------------------------------------------------------------------------------
+// Batched skinning: many (mesh, palette) pairs in one launch (fyx_lbs_skin_batch).
+//
+// A scene of a few hundred distinct characters is a few hundred launches of a few microseconds of work each; the
+// GPU idles between them (measured: 256 meshes of 5 k vertices, 1.0 ms of launches for 13 us of HBM traffic).  Here
+// the jobs' instances ("segments") are laid end to end in one numbering of 64-vertex units and the launch splits
+// THAT evenly over its workgroups, as lbs_skin does for the instances of one mesh: a workgroup walks its unit range
+// segment by segment, restaging the palette at each boundary.  The segment's pointers come from a table in HBM read
+// through the constant address space (uniform address => scalar loads into SGPRs, as kernel arguments would be).
+// Same per-vertex code as lbs_skin (load_vertex / skin_vertex / the stores): bit-identical results.
+// ---------------------------------------------------------------------------------------
+#define FYX_CONSTANT __attribute__((address_space(4)))
+
+template <bool EXACT, int MASK>
+__global__ __launch_bounds__(512) void lbs_skin_batch(const LbsSegDev* __restrict__ segs_g, uint32_t n_segs,
+                                                     const uint32_t* __restrict__ block_seg, uint32_t total_units) {
+    constexpr uint32_t WPB = 8;
+    constexpr bool NT = true;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FYX_CONSTANT LbsSegDev* segs = (const FYX_CONSTANT LbsSegDev*)segs_g;
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    if (u_begin >= u_end) return;
+    bool first = true;
+    for (uint32_t seg = block_seg[blockIdx.x]; seg < n_segs; ++seg) {   // workgroup-uniform
+        const uint32_t s_u0 = segs[seg].unit0;
+        if (s_u0 >= u_end) break;
+        LbsArgs a;
+        a.pos = segs[seg].pos; a.nrm = segs[seg].nrm; a.tan = segs[seg].tan; a.wgt = segs[seg].wgt; a.idx = segs[seg].idx;
+        a.palette = segs[seg].palette;
+        a.out_pos = segs[seg].out_pos; a.out_nrm = segs[seg].out_nrm; a.out_tan = segs[seg].out_tan;
+        a.n_verts = segs[seg].n_verts; a.n_bones = segs[seg].n_bones; a.n_instances = 1;
+        const uint32_t upi = (a.n_verts + 63) / 64;
+        if (s_u0 + upi <= u_begin) continue;
+        const uint32_t seg_b = (u_begin > s_u0 ? u_begin : s_u0) - s_u0;
+        const uint32_t seg_e = (u_end < s_u0 + upi ? u_end : s_u0 + upi) - s_u0;
+
+        f32x4* rows = reinterpret_cast<f32x4*>(smem);
+        f32x4* row3 = rows + 3 * a.n_bones;
+        uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);
+        // palette fetch first, the first unit's vertex loads right behind it (see lbs_skin)
+        const PaletteRegs pr = palette_fetch(a.palette, a.n_bones, tid);
+        const uint32_t vb = (seg_b + wave) * 64;
+        const uint32_t ve = seg_e * 64 < a.n_verts ? seg_e * 64 : a.n_verts;
+        constexpr uint32_t vstep = WPB * 64;
+        uint32_t base = vb;
+        uint32_t v = base + lane;
+        VertexIn<MASK> cur = load_vertex<NT, MASK>(a, v < ve ? v : 0);
+
+        if (!first) __syncthreads();  // every wave is done with the previous palette
+        first = false;
+        const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
+        const bool wave_pj = __any(pj) != 0;
+        if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
+        __syncthreads();
+        bool projective = false;
+#pragma unroll
+        for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
+        pin_vertex(cur);
+
+        while (base < ve) {  // wave-uniform
+            const uint32_t bn = base + vstep;
+            const uint32_t vn = bn + lane;
+            VertexIn<MASK> nxt;
+            if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
+            const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.px,
+                                                       cur.py, cur.pz, cur.nx, cur.ny, cur.nz,
+                                                       cur.t.x, cur.t.y, cur.t.z);
+            if (v < ve) {
+                if constexpr (MASK & 1) st3<NT>(a.out_pos + (size_t)v * 3, o.px, o.py, o.pz);
+                if constexpr (MASK & 2) st3<NT>(a.out_nrm + (size_t)v * 3, o.nx, o.ny, o.nz);
+                if constexpr (MASK & 4)
+                    stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + v, f32x4{o.tx, o.ty, o.tz, cur.t.w});
+            }
+            cur = nxt;
+            base = bn;
+            v = vn;
+        }
+    }
+}
+
+uint32_t lbs_batch_grid(uint32_t total_units, const LbsTuning& t) {
+    uint32_t grid = (uint32_t)kCUs * (uint32_t)(t.blocks_per_cu > 0 ? t.blocks_per_cu : 1);
+    const uint32_t max_useful = (total_units + 7) / 8;
+    return grid > max_useful ? max_useful : grid;
+}
+
+template <bool EXACT>
+static hipError_t launch_batch_mask(const LbsSegDev* d_segs, uint32_t n_segs, const uint32_t* d_block_seg, uint32_t grid,
+                                    uint32_t total_units, size_t lds, int mask, hipStream_t s) {
+#define FYX_BATCH_CASE(M)                                                                                          \
+    case M:                                                                                                        \
+        hipLaunchKernelGGL((lbs_skin_batch<EXACT, M>), dim3(grid), dim3(512), lds, s, d_segs, n_segs, d_block_seg, \
+                           total_units);                                                                           \
+        break;
+    switch (mask) {
+        FYX_BATCH_CASE(1) FYX_BATCH_CASE(2) FYX_BATCH_CASE(3) FYX_BATCH_CASE(4) FYX_BATCH_CASE(5) FYX_BATCH_CASE(6) FYX_BATCH_CASE(7)
+        default: return hipSuccess;
+    }
+#undef FYX_BATCH_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_lbs_batch(const LbsSegDev* d_segs, uint32_t n_segs, const uint32_t* d_block_seg, uint32_t grid,
+                            uint32_t total_units, uint32_t max_bones, int mask, const LbsTuning& t, hipStream_t stream) {
+    if (n_segs == 0 || total_units == 0 || grid == 0) return hipSuccess;
+    const size_t lds = (size_t)max_bones * 64 + 64;
+    return t.exact ? launch_batch_mask<true>(d_segs, n_segs, d_block_seg, grid, total_units, lds, mask, stream)
+                   : launch_batch_mask<false>(d_segs, n_segs, d_block_seg, grid, total_units, lds, mask, stream);
+}
+
+// ---------------------------------------------------------------------------------------
 // Extended skinning kernel: blend shapes before skinning and/or interleaved (AoS) output.
 //
 //   blend shapes (standard.shader:167-173): for i in 0..blendShapesCount:

@@ -148,6 +148,23 @@ int fyx_lbs_skin(fyx_ctx* ctx, uint64_t mesh_id, const float* palette, uint32_t 
 int fyx_lbs_skin_device(fyx_ctx* ctx, uint64_t mesh_id, const float* d_palette, uint32_t n_bones,
                         uint32_t n_instances, float* d_out_pos, float* d_out_normal,
                         float* d_out_tangent);
+
+/* Batch form for a scene of many skinned meshes (Engine::render collects every Mesh's surfaces per frame,
+ * scene/mesh/mod.rs:774-802): jobs[k] means fyx_lbs_skin_device(ctx, mesh_id, d_palette, n_bones, n_instances,
+ * d_out_pos, d_out_normal, d_out_tangent) with identical results, but all jobs are skinned by ONE kernel launch
+ * whose workgroups split the whole batch's vertices evenly (jobs of 16 or more instances keep their own crowd launch).
+ * Every job is validated before anything is launched; asynchronous, like the single form.  The job table is kept on
+ * the device and only re-sent when it differs from the previous call's. */
+typedef struct fyx_skin_job {
+    uint64_t mesh_id;
+    const float* d_palette;      /* n_instances * n_bones column-major mat4 */
+    uint32_t n_bones;
+    uint32_t n_instances;
+    float* d_out_pos;            /* n_instances * n_verts * 3, or NULL */
+    float* d_out_normal;         /* n_instances * n_verts * 3, or NULL */
+    float* d_out_tangent;        /* n_instances * n_verts * 4, or NULL */
+} fyx_skin_job;
+int fyx_lbs_skin_batch(fyx_ctx* ctx, const fyx_skin_job* jobs, uint32_t n_jobs);
 /* Blend shapes (morph targets).  `storage` = the bytes of BlendShapesContainer::blend_shape_storage
  * (fyrox-impl/src/scene/mesh/surface.rs:116-217): an RGB16F volume of width*3 x height x n_shapes
  * texels, i.e. per shape `plane_vertices` (= width * height >= n_verts) records of three f16 triples

@@ -696,3 +696,108 @@ def test_single_rank_communicator_all_gathers_a_skinned_shard(ctx, orc):
     for d in (d_pal, d_p, d_n, d_t, d_g):
         d.free()
     ctx.mesh_free(7101)
+
+
+# ---- fyx_lbs_skin_batch: many (mesh, palette) pairs, one launch -------------------------------------------------
+
+def _batch_scene(ctx, base_id, specs, seed0):
+    """specs: (n_verts, n_bones, n_instances, want) per job.  Uploads the meshes and returns per job
+    (mesh, palette, device palette, outputs dict)."""
+    scene = []
+    for k, (nv, nb, ni, want) in enumerate(specs):
+        m = synth.make_mesh(nv, nb, seed0 + k, coherent=bool(k % 2)) if nv else synth.make_mesh(0, nb, seed0 + k)
+        pal = synth.make_palette(nb, seed0 + 100 + k, n_instances=ni)
+        ctx.mesh_upload_soa(base_id + k, m.pos, m.weights, m.indices, m.normal, m.tangent)
+        outs = {"pos": ctx.malloc(max(ni * nv * 12, 16)) if "pos" in want else None,
+                "normal": ctx.malloc(max(ni * nv * 12, 16)) if "normal" in want else None,
+                "tangent": ctx.malloc(max(ni * nv * 16, 16)) if "tangent" in want else None}
+        scene.append((m, pal, ctx.to_device(pal), outs))
+    return scene
+
+
+def _batch_jobs(base_id, specs, scene):
+    return [(base_id + k, dp.ptr, nb, ni, o["pos"].ptr if o["pos"] else 0, o["normal"].ptr if o["normal"] else 0,
+             o["tangent"].ptr if o["tangent"] else 0)
+            for k, ((nv, nb, ni, want), (m, pal, dp, o)) in enumerate(zip(specs, scene))]
+
+
+def _check_batch(ctx, orc, specs, scene, exact):
+    width = {"pos": 3, "normal": 3, "tangent": 4}
+    for (nv, nb, ni, want), (m, pal, dp, o) in zip(specs, scene):
+        if nv == 0:
+            continue
+        ref = oracle_skin(orc, m, pal, ni)
+        for key in want:
+            got = o[key].download(np.float32, ni * nv * width[key]).reshape(ni * nv, width[key])
+            if exact:
+                assert np.array_equal(got.view(np.uint32), ref[key].view(np.uint32)), f"{nv} verts / {nb} bones x {ni}: {key}"
+            else:
+                assert rel_err(got, ref[key]) <= REL_TOL
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+def test_batch_of_many_meshes_is_bit_exact(ctx, orc, exact):
+    """Ragged sizes (1 vertex, just under / over a unit, just over a workgroup's share), different bone counts,
+    instanced jobs, an empty mesh, one job big enough to take the crowd launch -- all in one call."""
+    ALL3 = ("pos", "normal", "tangent")
+    specs = [(1, 4, 1, ALL3), (63, 8, 2, ALL3), (65, 64, 1, ALL3), (5000, 64, 1, ALL3), (4097, 256, 3, ALL3),
+             (0, 16, 1, ALL3), (20_000, 96, 1, ALL3), (777, 33, 5, ALL3), (300, 12, 17, ALL3), (12_345, 200, 1, ALL3)]
+    ctx.set_option("lbs.exact", exact)
+    try:
+        scene = _batch_scene(ctx, 7300, specs, synth.SEED_BASE + 300)
+        ctx.lbs_skin_batch(_batch_jobs(7300, specs, scene))
+        ctx.sync()
+        _check_batch(ctx, orc, specs, scene, bool(exact))
+    finally:
+        ctx.set_option("lbs.exact", 1)
+
+
+def test_batch_with_different_output_sets_and_repeated_calls(ctx, orc):
+    """Jobs asking for different attribute sets are split into one launch per set; the same batch sent again re-uses the
+    device table, a changed batch replaces it, and the single-job form still agrees."""
+    specs = [(3000, 32, 1, ("pos",)), (3000, 32, 2, ("pos", "normal")), (900, 16, 1, ("tangent",)),
+             (2500, 48, 1, ("pos", "normal", "tangent")), (70, 5, 3, ("normal", "tangent")), (4000, 64, 1, ("pos", "tangent"))]
+    scene = _batch_scene(ctx, 7400, specs, synth.SEED_BASE + 340)
+    jobs = _batch_jobs(7400, specs, scene)
+    for rep in range(3):
+        ctx.lbs_skin_batch(jobs)
+    ctx.sync()
+    _check_batch(ctx, orc, specs, scene, True)
+    # another scene right behind it (other table), then the first again
+    specs2 = [(1500, 20, 2, ("pos", "normal", "tangent")), (640, 64, 1, ("pos", "normal", "tangent"))]
+    scene2 = _batch_scene(ctx, 7450, specs2, synth.SEED_BASE + 360)
+    ctx.lbs_skin_batch(_batch_jobs(7450, specs2, scene2))
+    ctx.lbs_skin_batch(jobs[::-1])
+    ctx.sync()
+    _check_batch(ctx, orc, specs2, scene2, True)
+    _check_batch(ctx, orc, specs, scene, True)
+    # and against the one-mesh entry point, bit for bit
+    m, pal, dp, o = scene[3]
+    one = ctx.malloc(2500 * 12)
+    ctx.lbs_skin_device(7403, dp.ptr, 48, 1, one.ptr, 0, 0)
+    ctx.sync()
+    assert np.array_equal(one.download(np.uint32, 2500 * 3), o["pos"].download(np.uint32, 2500 * 3))
+
+
+def test_batch_argument_errors_launch_nothing(ctx):
+    specs = [(500, 16, 1, ("pos",)), (500, 16, 1, ("pos",))]
+    scene = _batch_scene(ctx, 7500, specs, synth.SEED_BASE + 380)
+    for _, _, _, o in scene:
+        o["pos"].upload(np.full(500 * 3, 7.0, np.float32))
+    jobs = _batch_jobs(7500, specs, scene)
+    ctx.lbs_skin_batch([])                                   # an empty batch is fine
+    bad = list(jobs)
+    bad[1] = (9_999_999,) + jobs[1][1:]                       # unknown mesh in the LAST job
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        ctx.lbs_skin_batch(bad)
+    assert e.value.code == fyrox_amd._native.FYX_ERR_UNKNOWN_ID
+    bad[1] = jobs[1][:2] + (8,) + jobs[1][3:]                 # palette too small for the mesh's bone indices
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        ctx.lbs_skin_batch(bad)
+    assert e.value.code == fyrox_amd._native.FYX_ERR_BONE_INDEX
+    bad[1] = jobs[1][:1] + (0,) + jobs[1][2:]                 # null palette
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx.lbs_skin_batch(bad)
+    ctx.sync()
+    for _, _, _, o in scene:                                  # the valid first job was not launched either
+        assert np.all(o["pos"].download(np.float32, 500 * 3) == 7.0)

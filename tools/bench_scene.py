@@ -3,7 +3,7 @@
 one AnimationPlayer + AnimationBlendingStateMachine + Mesh per character in the reference's scene graph,
 `fyrox-impl/src/scene/animation/absm.rs:311-326`), N instances of each.  Per frame and per character:
     fyx_scene_update (all characters at once; `one_by_one` = fyx_absm_update per character) -> palettes (written by the
-    update kernel) -> fyx_lbs_skin_device per character
+    update kernel) -> fyx_lbs_skin_batch (`one_by_one`: fyx_lbs_skin_device per character)
 Many small dependent chains: launch-bound rather than bandwidth-bound.  Prints one JSON line."""
 import argparse
 import json
@@ -64,12 +64,20 @@ dt = 1.0 / 60.0
 animators = [c[0] for c in chars]
 
 
+from fyrox_amd._native import SkinJob
+skin_jobs = (SkinJob * K)(*[SkinJob(mid, d_pal.ptr, args.bones, N, o[0].ptr, o[1].ptr, o[2].ptr) for _, mid, d_pal, o in chars])
+
+
 def frame(skin=True, pose=True, batched=True):
-    if pose and batched:
-        A.scene_update(ctx, animators, dt)           # one launch per stage for the whole scene
-    for an, mid, d_pal, o in chars:
-        if pose and not batched:
-            an.update_machine(dt)                    # one by one: what the batched call replaces
+    if batched:
+        if pose:
+            A.scene_update(ctx, animators, dt)       # one launch per stage for the whole scene
+        if skin:
+            ctx.lbs_skin_batch(skin_jobs)            # one launch for every mesh of the scene
+        return
+    for an, mid, d_pal, o in chars:                  # one by one: what the batched calls replace
+        if pose:
+            an.update_machine(dt)
         if skin:
             ctx.lbs_skin_device(mid, d_pal.ptr, args.bones, N, o[0].ptr, o[1].ptr, o[2].ptr)
 
@@ -91,6 +99,7 @@ p_gpu, p_wall = timed(skin=False)
 s_gpu, s_wall = timed(pose=False)
 f1_gpu, f1_wall = timed(batched=False)
 p1_gpu, p1_wall = timed(skin=False, batched=False)
+s1_gpu, s1_wall = timed(pose=False, batched=False)
 t0 = time.perf_counter()
 for _ in range(args.frames):
     for an, *_ in chars:
@@ -101,7 +110,8 @@ print(json.dumps({
     "workload": f"{K} distinct characters x {N} instances x {args.verts} verts / {args.bones} bones, 4-clip blend-tree machine each",
     "options": {k: ctx.get_option(k) for k in ("lbs.streams", "anim.threads")},
     "frame_ms_gpu": f_gpu, "frame_ms_wall": f_wall, "pose_ms_gpu": p_gpu, "pose_ms_wall": p_wall,
-    "one_by_one": {"frame_ms_wall": f1_wall, "pose_ms_gpu": p1_gpu, "pose_ms_wall": p1_wall},
+    "one_by_one": {"frame_ms_wall": f1_wall, "pose_ms_gpu": p1_gpu, "pose_ms_wall": p1_wall, "skin_ms_gpu": s1_gpu, "skin_ms_wall": s1_wall},
+    "skin_algorithmic_GBps": total_verts * 100 / (s_gpu * 1e-3) / 1e9,
     "skin_ms_gpu": s_gpu, "skin_ms_wall": s_wall, "host_control_plane_ms": plan,
     "per_character_us_wall": f_wall * 1e3 / K, "skinned_vertices_per_s": total_verts / (f_wall * 1e-3),
     "scene_frames_per_s": 1e3 / f_wall}), flush=True)
