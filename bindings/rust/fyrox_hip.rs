@@ -139,6 +139,20 @@ impl HipSkinning {
         self.check(unsafe { fyx_lbs_skin_ex(self.ctx, key, &desc) })
     }
 
+    /// One frame of every animated node of a scene (`Graph::update` -> `update_node`, `scene/graph/mod.rs:1415-1502`):
+    /// `animators` are the ids of the `HipAnimator`s registered for the scene's `AnimationPlayer` /
+    /// `AnimationBlendingStateMachine` nodes.  Same results as updating them one by one; one kernel launch per stage.
+    pub fn update_scene(&mut self, animators: &[u64], dt: f32) -> Result<(), HipError> {
+        self.check(unsafe { fyx_scene_update(self.ctx, animators.as_ptr(), animators.len() as u32, dt) })
+    }
+
+    /// Every skinned surface of a frame in one launch per layout class (`Mesh::collect_render_data`,
+    /// `scene/mesh/mod.rs:774-802`, collects one `FyxSkinDesc` per surface instead of launching).
+    pub fn skin_scene(&mut self, keys: &[u64], descs: &[FyxSkinDesc]) -> Result<(), HipError> {
+        debug_assert_eq!(keys.len(), descs.len());
+        self.check(unsafe { fyx_lbs_skin_ex_batch(self.ctx, keys.as_ptr(), descs.as_ptr(), keys.len() as u32) })
+    }
+
     /// GPU-side join of every in-flight skinning launch with the context stream.
     pub fn join(&mut self) -> Result<(), HipError> {
         self.check(unsafe { fyx_join(self.ctx) })

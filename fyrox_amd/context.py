@@ -247,6 +247,21 @@ class Context:
                              out_stride, out_off_pos, out_off_normal, out_off_tangent)
         self._check(self._l.fyx_lbs_skin_ex(self._h, mesh_id, byref(d)))
 
+    def lbs_skin_ex_batch(self, jobs) -> None:
+        """fyx_lbs_skin_ex_batch.  jobs: sequence of (mesh_id, kwargs) with lbs_skin_ex's arguments
+        (d_palette, n_bones, n_instances, d_blend_shape_weights, ...)."""
+        n = len(jobs)
+        ids = (ctypes.c_uint64 * max(n, 1))()
+        descs = (_native.SkinDesc * max(n, 1))()
+        for k, (mesh_id, kw) in enumerate(jobs):
+            ids[k] = mesh_id
+            descs[k] = _native.SkinDesc(kw.get("d_palette") or None, kw.get("n_bones", 0), kw.get("n_instances", 1),
+                                        kw.get("d_blend_shape_weights") or None, kw.get("n_blend_shapes", 0),
+                                        kw.get("d_out_pos") or None, kw.get("d_out_normal") or None, kw.get("d_out_tangent") or None,
+                                        kw.get("d_out_vertices") or None, kw.get("out_stride", 0), kw.get("out_off_pos", -1),
+                                        kw.get("out_off_normal", -1), kw.get("out_off_tangent", -1))
+        self._check(self._l.fyx_lbs_skin_ex_batch(self._h, ids, descs, n))
+
     def skinned_aabb(self, mesh_id: int, palette) -> np.ndarray:
         palette = _f32(palette, (-1, 16))
         box = np.empty(6, np.float32)

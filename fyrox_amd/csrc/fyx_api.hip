@@ -238,6 +238,224 @@ fyx::LbsArgs make_args(const Mesh& m, const float* d_palette, uint32_t n_bones, 
     return a;
 }
 
+// Validation and kernel arguments of one extended skinning job (fyx_lbs_skin_ex and its batch form).
+int build_ex_args(fyx_ctx* c, uint64_t mesh_id, const fyx_skin_desc* d, fyx::LbsExArgs& x, bool& whole_spans) {
+    if (!d) return fail(c, FYX_ERR_INVALID_ARG, "desc is null");
+    const Mesh* m = find_mesh(c, mesh_id);
+    int rc = check_skin_args(c, m, mesh_id, d->d_palette, d->n_bones, d->n_instances);
+    if (rc) return rc;
+    memset(&x, 0, sizeof x);
+    x.a = make_args(*m, d->d_palette, d->n_bones, d->n_instances, d->d_out_pos, d->d_out_normal, d->d_out_tangent);
+    whole_spans = false;
+    if (d->d_out_vertices && d->out_stride == 0) {
+        // the mesh's own layout: vertex buffer in, vertex buffer out
+        if (d->d_out_pos || d->d_out_normal || d->d_out_tangent)
+            return fail(c, FYX_ERR_INVALID_ARG, "give either the interleaved output or the SoA outputs");
+        if (!m->aos && m->n_verts)
+            return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "out_stride 0 (the mesh's own vertex layout) needs a mesh uploaded with fyx_mesh_upload");
+        if ((m->stride & 3u) || m->stride > 160 || ((m->off_pos | m->off_wgt | m->off_idx) & 3) ||
+            (m->off_nrm >= 0 && (m->off_nrm & 3)) || (m->off_tan >= 0 && (m->off_tan & 3)))
+            return fail(c, FYX_ERR_UNSUPPORTED, "vertex layout (stride %u) must be 4-byte aligned and at most 160 bytes", m->stride);
+        if (reinterpret_cast<uintptr_t>(d->d_out_vertices) & 3u) return fail(c, FYX_ERR_UNSUPPORTED, "output buffer is not 4-byte aligned");
+        whole_spans = true;
+        x.out_aos = d->d_out_vertices;
+        x.out_stride = m->stride;
+        x.off_pos = m->off_pos; x.off_nrm = m->off_nrm; x.off_tan = m->off_tan;
+        x.in_aos = m->aos;
+        x.in_off_wgt = m->off_wgt; x.in_off_idx = m->off_idx;
+    } else if (d->d_out_vertices) {
+        if (d->d_out_pos || d->d_out_normal || d->d_out_tangent)
+            return fail(c, FYX_ERR_INVALID_ARG, "give either the interleaved output or the SoA outputs");
+        if ((d->out_stride & 3u)) return fail(c, FYX_ERR_UNSUPPORTED, "out_stride %u is not a multiple of 4", d->out_stride);
+        struct { int off; uint32_t size; const char* name; bool have; } f[] = {
+            {d->out_off_pos, 12, "Position", true}, {d->out_off_normal, 12, "Normal", m->nrm != nullptr},
+            {d->out_off_tangent, 16, "Tangent", m->tan != nullptr}};
+        for (auto& a : f) {
+            if (a.off < 0) continue;
+            if (!a.have) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no %s attribute", a.name);
+            if (a.off & 3) return fail(c, FYX_ERR_UNSUPPORTED, "%s offset %d is not 4-byte aligned", a.name, a.off);
+            if ((uint64_t)a.off + a.size > d->out_stride)
+                return fail(c, FYX_ERR_INVALID_ARG, "%s at offset %d does not fit vertex size %u", a.name, a.off, d->out_stride);
+        }
+        if (reinterpret_cast<uintptr_t>(d->d_out_vertices) & 3u) return fail(c, FYX_ERR_UNSUPPORTED, "output buffer is not 4-byte aligned");
+        x.out_aos = d->d_out_vertices;
+        x.out_stride = d->out_stride;
+        x.off_pos = d->out_off_pos; x.off_nrm = d->out_off_normal; x.off_tan = d->out_off_tangent;
+    } else {
+        if (d->d_out_normal && !m->nrm) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Normal attribute");
+        if (d->d_out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Tangent attribute");
+    }
+    if (d->n_blend_shapes) {
+        if (d->n_blend_shapes != m->n_shapes)
+            return fail(c, FYX_ERR_INVALID_ARG, "%u blend-shape weights for a mesh with %u blend shapes", d->n_blend_shapes, m->n_shapes);
+        if (!d->d_blend_shape_weights) return fail(c, FYX_ERR_INVALID_ARG, "blend-shape weights are null");
+        x.shapes = m->shapes;
+        x.shape_w = d->d_blend_shape_weights;
+        x.n_shapes = m->shapes ? d->n_blend_shapes : 0;
+        x.tiles_per_shape = (m->n_verts + 63) / 64;
+    }
+    return FYX_OK;
+}
+
+enum ExKind { kExWholeSpans, kExPlain, kExGeneral };
+ExKind ex_kind(const fyx::LbsExArgs& x, bool whole_spans) {
+    if (whole_spans) return kExWholeSpans;
+    return (!x.out_aos && !x.n_shapes) ? kExPlain : kExGeneral;   // nothing extended asked for: the plain kernel
+}
+
+// Everything a batch call launches: segments for the batched kernels, the rest one launch each.
+struct BatchPlan {
+    struct SoaGroup { std::vector<fyx::LbsSegDev> segs; uint32_t units = 0, max_bones = 0; };
+    struct AosGroup { std::vector<fyx::LbsExSegDev> segs; uint32_t units = 0, max_bones = 0, max_stride = 0; };
+    SoaGroup soa[8];                 // by output mask
+    AosGroup aos[8];                 // by (layout bucket, blend shapes)
+    std::vector<fyx::LbsArgs> crowds;     // instanced jobs big enough for the crowd kernel
+    std::vector<fyx::LbsExArgs> general;  // blend shapes into SoA, scattered interleaved output
+    static constexpr uint32_t kCrowdFrom = 16;
+
+    static int aos_slot(uint32_t bucket, bool shapes) { return (bucket == 4 ? 0 : bucket == 5 ? 1 : bucket == 8 ? 2 : 3) * 2 + (shapes ? 1 : 0); }
+    static uint32_t aos_bucket_of(int slot) { static const uint32_t b[4] = {4, 5, 8, 10}; return b[slot / 2]; }
+
+    int add_soa(fyx_ctx* c, const fyx::LbsArgs& a) {
+        if (a.n_verts == 0) return FYX_OK;
+        if (a.n_instances >= kCrowdFrom) { crowds.push_back(a); return FYX_OK; }
+        const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
+        if (!mask) return FYX_OK;
+        SoaGroup& G = soa[mask];
+        const uint32_t upi = (a.n_verts + 63) / 64;
+        for (uint32_t i = 0; i < a.n_instances; ++i) {
+            if ((uint64_t)G.units + upi > 0xffffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "batch too large for one launch");
+            fyx::LbsSegDev sg;
+            sg.pos = a.pos; sg.nrm = a.nrm; sg.tan = a.tan; sg.wgt = a.wgt; sg.idx = a.idx;
+            sg.palette = a.palette + (size_t)i * a.n_bones * 16;
+            sg.out_pos = a.out_pos ? a.out_pos + (size_t)i * a.n_verts * 3 : nullptr;
+            sg.out_nrm = a.out_nrm ? a.out_nrm + (size_t)i * a.n_verts * 3 : nullptr;
+            sg.out_tan = a.out_tan ? a.out_tan + (size_t)i * a.n_verts * 4 : nullptr;
+            sg.n_verts = a.n_verts;
+            sg.n_bones = a.n_bones;
+            sg.unit0 = G.units;
+            sg.pad = 0;
+            G.segs.push_back(sg);
+            G.units += upi;
+            G.max_bones = std::max(G.max_bones, a.n_bones);
+        }
+        return FYX_OK;
+    }
+
+    int add_aos(fyx_ctx* c, const fyx::LbsExArgs& x) {
+        if (x.a.n_verts == 0) return FYX_OK;
+        const uint32_t bucket = fyx::lbs_aos_bucket(x.out_stride);
+        if (!bucket) return fail(c, FYX_ERR_UNSUPPORTED, "vertex layout (stride %u)", x.out_stride);
+        AosGroup& G = aos[aos_slot(bucket, x.n_shapes > 0)];
+        const uint32_t upi = (x.a.n_verts + 63) / 64;
+        for (uint32_t i = 0; i < x.a.n_instances; ++i) {
+            if ((uint64_t)G.units + upi > 0xffffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "batch too large for one launch");
+            fyx::LbsExSegDev sg;
+            sg.in_aos = x.in_aos;
+            sg.out_aos = x.out_aos + (size_t)i * x.a.n_verts * x.out_stride;
+            sg.palette = x.a.palette + (size_t)i * x.a.n_bones * 16;
+            sg.shapes = x.shapes;
+            sg.shape_w = x.n_shapes ? x.shape_w + (size_t)i * x.n_shapes : nullptr;
+            sg.n_verts = x.a.n_verts; sg.n_bones = x.a.n_bones; sg.n_shapes = x.n_shapes; sg.tiles_per_shape = x.tiles_per_shape;
+            sg.stride = x.out_stride;
+            sg.off_pos = x.off_pos; sg.off_nrm = x.off_nrm; sg.off_tan = x.off_tan;
+            sg.in_off_wgt = x.in_off_wgt; sg.in_off_idx = x.in_off_idx;
+            sg.unit0 = G.units;
+            sg.pad = 0;
+            G.segs.push_back(sg);
+            G.units += upi;
+            G.max_bones = std::max(G.max_bones, x.a.n_bones);
+            G.max_stride = std::max(G.max_stride, x.out_stride);
+        }
+        return FYX_OK;
+    }
+};
+
+// d_block_seg[b] = the segment holding workgroup b's first unit
+template <typename Seg>
+void fill_block_segs(uint32_t* bs, uint32_t grid, uint32_t units, const std::vector<Seg>& segs) {
+    uint32_t sg = 0;
+    for (uint32_t b = 0; b < grid; ++b) {
+        const uint32_t u = (uint32_t)(((uint64_t)b * units) / grid);
+        while (sg + 1 < segs.size() && segs[sg + 1].unit0 <= u) ++sg;
+        bs[b] = sg;
+    }
+}
+
+// Tables to the device (unless they are the previous call's), then one launch per non-empty group and per leftover job.
+int run_batch_plan(fyx_ctx* c, BatchPlan& P) {
+    if (!c->skin_batch) c->skin_batch = new SkinBatch();
+    SkinBatch& B = *c->skin_batch;
+    // One launch that fills the chip: nothing to gain from a worker stream, and on the context stream the table
+    // buffers have a single consumer to order their reuse against.
+    if (int sr = enter_primary(c)) return sr;
+    const hipStream_t st = c->stream;
+    struct Placed { size_t o_segs = 0, o_blocks = 0; uint32_t grid = 0; };
+    Placed ps[8], pa[8];
+    size_t total = 0;
+    for (int k = 1; k < 8; ++k) {
+        if (P.soa[k].segs.empty()) continue;
+        ps[k].grid = fyx::lbs_batch_grid(P.soa[k].units, c->lbs);
+        ps[k].o_segs = total;
+        total += align_up(P.soa[k].segs.size() * sizeof(fyx::LbsSegDev), 256);
+        ps[k].o_blocks = total;
+        total += align_up((size_t)ps[k].grid * 4, 256);
+    }
+    for (int k = 0; k < 8; ++k) {
+        BatchPlan::AosGroup& G = P.aos[k];
+        if (G.segs.empty()) continue;
+        FYX_HIP(c, fyx::lbs_aos_batch_grid(G.units, G.max_bones, G.max_stride, BatchPlan::aos_bucket_of(k), (k & 1) != 0, c->lbs, &pa[k].grid));
+        pa[k].o_segs = total;
+        total += align_up(G.segs.size() * sizeof(fyx::LbsExSegDev), 256);
+        pa[k].o_blocks = total;
+        total += align_up((size_t)pa[k].grid * 4, 256);
+    }
+    if (total) {
+        B.build.assign(total, 0);
+        for (int k = 1; k < 8; ++k) {
+            if (P.soa[k].segs.empty()) continue;
+            memcpy(B.build.data() + ps[k].o_segs, P.soa[k].segs.data(), P.soa[k].segs.size() * sizeof(fyx::LbsSegDev));
+            fill_block_segs(reinterpret_cast<uint32_t*>(B.build.data() + ps[k].o_blocks), ps[k].grid, P.soa[k].units, P.soa[k].segs);
+        }
+        for (int k = 0; k < 8; ++k) {
+            if (P.aos[k].segs.empty()) continue;
+            memcpy(B.build.data() + pa[k].o_segs, P.aos[k].segs.data(), P.aos[k].segs.size() * sizeof(fyx::LbsExSegDev));
+            fill_block_segs(reinterpret_cast<uint32_t*>(B.build.data() + pa[k].o_blocks), pa[k].grid, P.aos[k].units, P.aos[k].segs);
+        }
+        int slot = B.last_slot;
+        const bool same = slot >= 0 && B.last.size() == total && memcmp(B.last.data(), B.build.data(), total) == 0;
+        if (!same) {
+            char *h = nullptr, *d = nullptr;
+            if (int rc = ctrl_acquire(c, B.ctrl, total, &slot, &h, &d)) return rc;
+            memcpy(h, B.build.data(), total);
+            if (int rc = ctrl_upload(c, B.ctrl, slot, total, st)) return rc;
+            B.last.swap(B.build);
+            B.last_slot = slot;
+        } else if (B.ctrl.h_busy[slot]) {
+            FYX_HIP(c, hipStreamWaitEvent(st, B.ctrl.h_ev[slot], 0));   // a borrowed stream may have changed since the upload
+        }
+        const char* d = static_cast<const char*>(B.ctrl.d[slot]);
+        for (int k = 1; k < 8; ++k) {
+            const BatchPlan::SoaGroup& G = P.soa[k];
+            if (G.segs.empty()) continue;
+            FYX_HIP(c, fyx::launch_lbs_batch(reinterpret_cast<const fyx::LbsSegDev*>(d + ps[k].o_segs), (uint32_t)G.segs.size(),
+                                             reinterpret_cast<const uint32_t*>(d + ps[k].o_blocks), ps[k].grid, G.units, G.max_bones,
+                                             k, c->lbs, st));
+        }
+        for (int k = 0; k < 8; ++k) {
+            const BatchPlan::AosGroup& G = P.aos[k];
+            if (G.segs.empty()) continue;
+            FYX_HIP(c, fyx::launch_lbs_aos_batch(reinterpret_cast<const fyx::LbsExSegDev*>(d + pa[k].o_segs), (uint32_t)G.segs.size(),
+                                                 reinterpret_cast<const uint32_t*>(d + pa[k].o_blocks), pa[k].grid, G.units,
+                                                 G.max_bones, G.max_stride, BatchPlan::aos_bucket_of(k), (k & 1) != 0, c->lbs, st));
+        }
+        if (int rc = ctrl_consumed(c, B.ctrl, slot, st)) return rc;
+    }
+    for (const fyx::LbsArgs& a : P.crowds) FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));   // vertices held in registers across the instances
+    for (const fyx::LbsExArgs& x : P.general) FYX_HIP(c, fyx::launch_lbs_ex(x, c->lbs, st));
+    return FYX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -575,107 +793,16 @@ int fyx_lbs_skin_batch(fyx_ctx* c, const fyx_skin_job* jobs, uint32_t n_jobs) {
     FYX_GUARD_BEGIN
     if (n_jobs && !jobs) return fail(c, FYX_ERR_INVALID_ARG, "jobs is null");
     if (n_jobs == 0) return FYX_OK;
-    // validate everything before anything is launched
-    constexpr uint32_t kCrowdFrom = 16;   // jobs with this many instances go to the crowd kernel (vertices in registers)
-    for (uint32_t j = 0; j < n_jobs; ++j) {
+    BatchPlan P;
+    for (uint32_t j = 0; j < n_jobs; ++j) {   // every job is validated before anything is launched
         const fyx_skin_job& J = jobs[j];
         const Mesh* m = find_mesh(c, J.mesh_id);
         if (int rc = check_skin_args(c, m, J.mesh_id, J.d_palette, J.n_bones, J.n_instances)) return rc;
         if (J.d_out_normal && !m->nrm) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "job %u: mesh has no Normal attribute", j);
         if (J.d_out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "job %u: mesh has no Tangent attribute", j);
+        if (int rc = P.add_soa(c, make_args(*m, J.d_palette, J.n_bones, J.n_instances, J.d_out_pos, J.d_out_normal, J.d_out_tangent))) return rc;
     }
-    if (!c->skin_batch) c->skin_batch = new SkinBatch();
-    SkinBatch& B = *c->skin_batch;
-    // segments grouped by output mask (one launch per mask; a scene normally has one)
-    struct Group { std::vector<fyx::LbsSegDev> segs; uint32_t units = 0, max_bones = 0; };
-    Group groups[8];
-    for (uint32_t j = 0; j < n_jobs; ++j) {
-        const fyx_skin_job& J = jobs[j];
-        const Mesh& m = *find_mesh(c, J.mesh_id);
-        if (m.n_verts == 0 || J.n_instances >= kCrowdFrom) continue;
-        const int mask = (J.d_out_pos ? 1 : 0) | (J.d_out_normal ? 2 : 0) | (J.d_out_tangent ? 4 : 0);
-        if (!mask) continue;
-        Group& G = groups[mask];
-        const uint32_t upi = (m.n_verts + 63) / 64;
-        for (uint32_t i = 0; i < J.n_instances; ++i) {
-            if ((uint64_t)G.units + upi > 0xffffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "batch too large for one launch");
-            fyx::LbsSegDev sg;
-            sg.pos = m.pos; sg.nrm = m.nrm; sg.tan = m.tan; sg.wgt = m.wgt; sg.idx = m.idx;
-            sg.palette = J.d_palette + (size_t)i * J.n_bones * 16;
-            sg.out_pos = J.d_out_pos ? J.d_out_pos + (size_t)i * m.n_verts * 3 : nullptr;
-            sg.out_nrm = J.d_out_normal ? J.d_out_normal + (size_t)i * m.n_verts * 3 : nullptr;
-            sg.out_tan = J.d_out_tangent ? J.d_out_tangent + (size_t)i * m.n_verts * 4 : nullptr;
-            sg.n_verts = m.n_verts;
-            sg.n_bones = J.n_bones;
-            sg.unit0 = G.units;
-            sg.pad = 0;
-            G.segs.push_back(sg);
-            G.units += upi;
-            G.max_bones = std::max(G.max_bones, J.n_bones);
-        }
-    }
-    // tables: per group its segments, then the first segment of every workgroup
-    struct Placed { size_t o_segs, o_blocks; uint32_t grid; };
-    Placed placed[8] = {};
-    size_t total = 0;
-    for (int k = 1; k < 8; ++k) {
-        Group& G = groups[k];
-        if (G.segs.empty()) continue;
-        placed[k].grid = fyx::lbs_batch_grid(G.units, c->lbs);
-        placed[k].o_segs = total;
-        total += align_up(G.segs.size() * sizeof(fyx::LbsSegDev), 256);
-        placed[k].o_blocks = total;
-        total += align_up((size_t)placed[k].grid * 4, 256);
-    }
-    // One launch that fills the chip: nothing to gain from a worker stream, and on the context stream the table
-    // buffers have a single consumer to order their reuse against.
-    if (int sr = enter_primary(c)) return sr;
-    const hipStream_t st = c->stream;
-    if (total) {
-        B.build.assign(total, 0);
-        for (int k = 1; k < 8; ++k) {
-            Group& G = groups[k];
-            if (G.segs.empty()) continue;
-            memcpy(B.build.data() + placed[k].o_segs, G.segs.data(), G.segs.size() * sizeof(fyx::LbsSegDev));
-            uint32_t* bs = reinterpret_cast<uint32_t*>(B.build.data() + placed[k].o_blocks);
-            uint32_t sg = 0;
-            for (uint32_t b = 0; b < placed[k].grid; ++b) {
-                const uint32_t u = (uint32_t)(((uint64_t)b * G.units) / placed[k].grid);
-                while (sg + 1 < G.segs.size() && G.segs[sg + 1].unit0 <= u) ++sg;
-                bs[b] = sg;
-            }
-        }
-        int slot = B.last_slot;
-        const bool same = slot >= 0 && B.last.size() == total && memcmp(B.last.data(), B.build.data(), total) == 0;
-        if (!same) {
-            char *h = nullptr, *d = nullptr;
-            if (int rc = ctrl_acquire(c, B.ctrl, total, &slot, &h, &d)) return rc;
-            memcpy(h, B.build.data(), total);
-            if (int rc = ctrl_upload(c, B.ctrl, slot, total, st)) return rc;
-            B.last.swap(B.build);
-            B.last_slot = slot;
-        } else if (B.ctrl.h_busy[slot]) {
-            FYX_HIP(c, hipStreamWaitEvent(st, B.ctrl.h_ev[slot], 0));   // a borrowed stream may have changed since the upload
-        }
-        const char* d = static_cast<const char*>(B.ctrl.d[slot]);
-        for (int k = 1; k < 8; ++k) {
-            const Group& G = groups[k];
-            if (G.segs.empty()) continue;
-            FYX_HIP(c, fyx::launch_lbs_batch(reinterpret_cast<const fyx::LbsSegDev*>(d + placed[k].o_segs), (uint32_t)G.segs.size(),
-                                             reinterpret_cast<const uint32_t*>(d + placed[k].o_blocks), placed[k].grid, G.units,
-                                             G.max_bones, k, c->lbs, st));
-        }
-        if (int rc = ctrl_consumed(c, B.ctrl, slot, st)) return rc;
-    }
-    // crowds: one launch each, vertices held in registers across the instances
-    for (uint32_t j = 0; j < n_jobs; ++j) {
-        const fyx_skin_job& J = jobs[j];
-        if (J.n_instances < kCrowdFrom) continue;
-        const Mesh& m = *find_mesh(c, J.mesh_id);
-        const fyx::LbsArgs a = make_args(m, J.d_palette, J.n_bones, J.n_instances, J.d_out_pos, J.d_out_normal, J.d_out_tangent);
-        FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
-    }
-    return FYX_OK;
+    return run_batch_plan(c, P);
     FYX_GUARD_END(c)
 }
 
@@ -713,71 +840,39 @@ int fyx_mesh_set_blend_shapes(fyx_ctx* c, uint64_t mesh_id, uint32_t n_shapes, c
 int fyx_lbs_skin_ex(fyx_ctx* c, uint64_t mesh_id, const fyx_skin_desc* d) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    if (!d) return fail(c, FYX_ERR_INVALID_ARG, "desc is null");
-    const Mesh* m = find_mesh(c, mesh_id);
-    int rc = check_skin_args(c, m, mesh_id, d->d_palette, d->n_bones, d->n_instances);
-    if (rc) return rc;
     fyx::LbsExArgs x;
-    memset(&x, 0, sizeof x);
-    x.a = make_args(*m, d->d_palette, d->n_bones, d->n_instances, d->d_out_pos, d->d_out_normal, d->d_out_tangent);
     bool whole_spans = false;
-    if (d->d_out_vertices && d->out_stride == 0) {
-        // the mesh's own layout: vertex buffer in, vertex buffer out
-        if (d->d_out_pos || d->d_out_normal || d->d_out_tangent)
-            return fail(c, FYX_ERR_INVALID_ARG, "give either the interleaved output or the SoA outputs");
-        if (!m->aos && m->n_verts)
-            return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "out_stride 0 (the mesh's own vertex layout) needs a mesh uploaded with fyx_mesh_upload");
-        if ((m->stride & 3u) || m->stride > 160 || ((m->off_pos | m->off_wgt | m->off_idx) & 3) ||
-            (m->off_nrm >= 0 && (m->off_nrm & 3)) || (m->off_tan >= 0 && (m->off_tan & 3)))
-            return fail(c, FYX_ERR_UNSUPPORTED, "vertex layout (stride %u) must be 4-byte aligned and at most 160 bytes", m->stride);
-        if (reinterpret_cast<uintptr_t>(d->d_out_vertices) & 3u) return fail(c, FYX_ERR_UNSUPPORTED, "output buffer is not 4-byte aligned");
-        whole_spans = true;
-        x.out_aos = d->d_out_vertices;
-        x.out_stride = m->stride;
-        x.off_pos = m->off_pos; x.off_nrm = m->off_nrm; x.off_tan = m->off_tan;
-        x.in_aos = m->aos;
-        x.in_off_wgt = m->off_wgt; x.in_off_idx = m->off_idx;
-    } else if (d->d_out_vertices) {
-        if (d->d_out_pos || d->d_out_normal || d->d_out_tangent)
-            return fail(c, FYX_ERR_INVALID_ARG, "give either the interleaved output or the SoA outputs");
-        if ((d->out_stride & 3u)) return fail(c, FYX_ERR_UNSUPPORTED, "out_stride %u is not a multiple of 4", d->out_stride);
-        struct { int off; uint32_t size; const char* name; bool have; } f[] = {
-            {d->out_off_pos, 12, "Position", true}, {d->out_off_normal, 12, "Normal", m->nrm != nullptr},
-            {d->out_off_tangent, 16, "Tangent", m->tan != nullptr}};
-        for (auto& a : f) {
-            if (a.off < 0) continue;
-            if (!a.have) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no %s attribute", a.name);
-            if (a.off & 3) return fail(c, FYX_ERR_UNSUPPORTED, "%s offset %d is not 4-byte aligned", a.name, a.off);
-            if ((uint64_t)a.off + a.size > d->out_stride)
-                return fail(c, FYX_ERR_INVALID_ARG, "%s at offset %d does not fit vertex size %u", a.name, a.off, d->out_stride);
-        }
-        if (reinterpret_cast<uintptr_t>(d->d_out_vertices) & 3u) return fail(c, FYX_ERR_UNSUPPORTED, "output buffer is not 4-byte aligned");
-        x.out_aos = d->d_out_vertices;
-        x.out_stride = d->out_stride;
-        x.off_pos = d->out_off_pos; x.off_nrm = d->out_off_normal; x.off_tan = d->out_off_tangent;
-    } else {
-        if (d->d_out_normal && !m->nrm) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Normal attribute");
-        if (d->d_out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Tangent attribute");
-    }
-    if (d->n_blend_shapes) {
-        if (d->n_blend_shapes != m->n_shapes)
-            return fail(c, FYX_ERR_INVALID_ARG, "%u blend-shape weights for a mesh with %u blend shapes", d->n_blend_shapes, m->n_shapes);
-        if (!d->d_blend_shape_weights) return fail(c, FYX_ERR_INVALID_ARG, "blend-shape weights are null");
-        x.shapes = m->shapes;
-        x.shape_w = d->d_blend_shape_weights;
-        x.n_shapes = m->shapes ? d->n_blend_shapes : 0;
-        x.tiles_per_shape = (m->n_verts + 63) / 64;
-    }
+    if (int rc = build_ex_args(c, mesh_id, d, x, whole_spans)) return rc;
     hipStream_t st;
     if (int sr = acquire_launch_stream(c, &st)) return sr;
-    if (whole_spans) {
-        FYX_HIP(c, fyx::launch_lbs_aos(x, c->lbs, st));
-    } else if (!x.out_aos && !x.n_shapes) {
-        FYX_HIP(c, fyx::launch_lbs(x.a, c->lbs, st));   // nothing extended asked for: the plain kernel
-    } else {
-        FYX_HIP(c, fyx::launch_lbs_ex(x, c->lbs, st));
+    switch (ex_kind(x, whole_spans)) {
+        case kExWholeSpans: FYX_HIP(c, fyx::launch_lbs_aos(x, c->lbs, st)); break;
+        case kExPlain: FYX_HIP(c, fyx::launch_lbs(x.a, c->lbs, st)); break;
+        default: FYX_HIP(c, fyx::launch_lbs_ex(x, c->lbs, st)); break;
     }
     return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_lbs_skin_ex_batch(fyx_ctx* c, const uint64_t* mesh_ids, const fyx_skin_desc* descs, uint32_t n_jobs) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (n_jobs && (!mesh_ids || !descs)) return fail(c, FYX_ERR_INVALID_ARG, "null job arrays");
+    if (n_jobs == 0) return FYX_OK;
+    BatchPlan P;
+    for (uint32_t j = 0; j < n_jobs; ++j) {   // every job is validated before anything is launched
+        fyx::LbsExArgs x;
+        bool whole_spans = false;
+        if (int rc = build_ex_args(c, mesh_ids[j], &descs[j], x, whole_spans)) return rc;
+        int rc = FYX_OK;
+        switch (ex_kind(x, whole_spans)) {
+            case kExWholeSpans: rc = P.add_aos(c, x); break;
+            case kExPlain: rc = P.add_soa(c, x.a); break;
+            default: if (x.a.n_verts) P.general.push_back(x); break;
+        }
+        if (rc) return rc;
+    }
+    return run_batch_plan(c, P);
     FYX_GUARD_END(c)
 }
 

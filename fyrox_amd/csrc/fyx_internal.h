@@ -83,6 +83,29 @@ struct LbsExArgs {
     int in_off_wgt, in_off_idx;
 };
 hipError_t launch_lbs_ex(const LbsExArgs& x, const LbsTuning& t, hipStream_t stream);
+
+// Batched whole-span launches (vertex buffer in -> vertex buffer out, optional blend shapes): one segment per
+// (job, instance), as LbsSegDev.
+struct LbsExSegDev {
+    const unsigned char* in_aos;
+    unsigned char* out_aos;      // this instance's output vertex buffer
+    const float* palette;        // this instance's matrices
+    const uint16_t* shapes;
+    const float* shape_w;        // this instance's weights
+    uint32_t n_verts, n_bones, n_shapes, tiles_per_shape;
+    uint32_t stride;
+    int32_t off_pos, off_nrm, off_tan, in_off_wgt, in_off_idx;
+    uint32_t unit0, pad;
+};
+// The kernel variant is picked by the layout bucket (16-byte accesses per lane and span: 4, 5, 8 or 10 -- see
+// lbs_aos_bucket) and whether any blend shapes are applied; every segment of a launch shares both.
+uint32_t lbs_aos_bucket(uint32_t stride);   // 0 = unsupported stride
+// Persistent grid of a batch launch (what is resident for its LDS footprint, capped by the work).
+hipError_t lbs_aos_batch_grid(uint32_t total_units, uint32_t max_bones, uint32_t max_stride, uint32_t bucket, bool shapes,
+                              const LbsTuning& t, uint32_t* grid);
+hipError_t launch_lbs_aos_batch(const LbsExSegDev* d_segs, uint32_t n_segs, const uint32_t* d_block_seg, uint32_t grid,
+                                uint32_t total_units, uint32_t max_bones, uint32_t max_stride, uint32_t bucket, bool shapes,
+                                const LbsTuning& t, hipStream_t stream);
 // whole-span variant: out = in with position / normal / tangent.xyz replaced; stride <= 160, multiple of 4
 hipError_t launch_lbs_aos(const LbsExArgs& x, const LbsTuning& t, hipStream_t stream);
 // engine RGB16F volume -> device tile layout (see lbs_kernels.hip)

@@ -885,9 +885,13 @@ constexpr int kAosBlock = 256;
 
 // PL = 16-byte accesses per lane and span = ceil(stride / 16): a compile-time bound so that only the registers a
 // layout needs are held for the span in flight (5 for the 68-byte AnimatedVertex)
+// One segment (= the units [seg_b, seg_e) of one instance of one mesh) of the whole-span kernel: shared by the
+// single-mesh launch (segments = the instances of x) and the batched one (segments = the batch's table).
+// palette / sw / out_inst: this instance's matrices, blend-shape weights and output vertex buffer.
 template <bool EXACT, bool SHAPES, uint32_t PL>
-__global__ __launch_bounds__(kAosBlock) void lbs_skin_aos(LbsExArgs x, uint32_t units_per_inst, uint32_t total_units) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void aos_segment(const LbsExArgs& x, const float* __restrict__ palette, const float* __restrict__ sw,
+                                            unsigned char* __restrict__ out_inst, uint32_t seg_b, uint32_t seg_e, bool first,
+                                            unsigned char* smem) {
     const LbsArgs& a = x.a;
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
@@ -900,127 +904,156 @@ __global__ __launch_bounds__(kAosBlock) void lbs_skin_aos(LbsExArgs x, uint32_t 
     constexpr uint32_t per_lane = PL;
     unsigned char* slab = smem + (size_t)a.n_bones * 64 + 64 + (size_t)wave * 64 * stride;
     f32x4* slab4 = reinterpret_cast<f32x4*>(slab);
-    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
-    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
-    if (u_begin >= u_end) return;
-    const uint32_t inst_first = u_begin / units_per_inst, inst_last = (u_end - 1) / units_per_inst;
     const f32x4* in4 = reinterpret_cast<const f32x4*>(x.in_aos);
-
-    for (uint32_t inst = inst_first; inst <= inst_last; ++inst) {
-        const uint32_t inst_u0 = inst * units_per_inst;
-        const uint32_t seg_b = (u_begin > inst_u0 ? u_begin : inst_u0) - inst_u0;
-        const uint32_t seg_e = (u_end < inst_u0 + units_per_inst ? u_end : inst_u0 + units_per_inst) - inst_u0;
-        const PaletteRegs pr = palette_fetch(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, tid);
-        uint32_t u = seg_b + wave;
-        f32x4 cur[PL];
+    const PaletteRegs pr = palette_fetch(palette, a.n_bones, tid);
+    uint32_t u = seg_b + wave;
+    f32x4 cur[PL];
+#pragma unroll
+    for (uint32_t k = 0; k < PL; ++k) {
+        const uint32_t i = lane + 64 * k;
+        // the input buffer is padded by one unit, so a ragged last span may be read in full
+        if (k < per_lane && u < seg_e && i < span_f4) cur[k] = __builtin_nontemporal_load(in4 + (size_t)u * span_f4 + i);
+    }
+    if (!first) __syncthreads();   // every wave is done with the previous palette
+    const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
+    const bool wave_pj = __any(pj) != 0;
+    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
+    __syncthreads();
+    bool projective = false;
+#pragma unroll
+    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
+    
+    while (u < seg_e) {  // wave-uniform
 #pragma unroll
         for (uint32_t k = 0; k < PL; ++k) {
             const uint32_t i = lane + 64 * k;
-            // the input buffer is padded by one unit, so a ragged last span may be read in full
-            if (k < per_lane && u < seg_e && i < span_f4) cur[k] = __builtin_nontemporal_load(in4 + (size_t)u * span_f4 + i);
+            if (k < per_lane && i < span_f4) slab4[i] = cur[k];
         }
-        if (inst != inst_first) __syncthreads();
-        const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
-        const bool wave_pj = __any(pj) != 0;
-        if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
-        __syncthreads();
-        bool projective = false;
+        const uint32_t un = u + WPB;
 #pragma unroll
-        for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
-        const float* sw = SHAPES ? x.shape_w + (size_t)inst * x.n_shapes : nullptr;
-
-        while (u < seg_e) {  // wave-uniform
-#pragma unroll
-            for (uint32_t k = 0; k < PL; ++k) {
-                const uint32_t i = lane + 64 * k;
-                if (k < per_lane && i < span_f4) slab4[i] = cur[k];
-            }
-            const uint32_t un = u + WPB;
-#pragma unroll
-            for (uint32_t k = 0; k < PL; ++k) {
-                const uint32_t i = lane + 64 * k;
-                if (k < per_lane && un < seg_e && i < span_f4) cur[k] = __builtin_nontemporal_load(in4 + (size_t)un * span_f4 + i);
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t v = u * 64 + lane;
-            unsigned char* rec = slab + (size_t)lane * stride;
-            float* pp = reinterpret_cast<float*>(rec + x.off_pos);
-            float px = pp[0], py = pp[1], pz = pp[2];
-            float nx = 0.f, ny = 0.f, nz = 0.f;
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            float* np_ = x.off_nrm >= 0 ? reinterpret_cast<float*>(rec + x.off_nrm) : nullptr;
-            float* tp = x.off_tan >= 0 ? reinterpret_cast<float*>(rec + x.off_tan) : nullptr;
-            if (np_) { nx = np_[0]; ny = np_[1]; nz = np_[2]; }
-            if (tp) { t.x = tp[0]; t.y = tp[1]; t.z = tp[2]; }
-            const float* wp = reinterpret_cast<const float*>(rec + x.in_off_wgt);
-            const f32x4 w = {wp[0], wp[1], wp[2], wp[3]};
-            const uint32_t id = *reinterpret_cast<const uint32_t*>(rec + x.in_off_idx);
-            if constexpr (SHAPES) {
-                const uint16_t* col = x.shapes + ((size_t)u * 9) * 64 + lane;
-                const size_t shape_stride = (size_t)x.tiles_per_shape * 9 * 64;
+        for (uint32_t k = 0; k < PL; ++k) {
+            const uint32_t i = lane + 64 * k;
+            if (k < per_lane && un < seg_e && i < span_f4) cur[k] = __builtin_nontemporal_load(in4 + (size_t)un * span_f4 + i);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t v = u * 64 + lane;
+        unsigned char* rec = slab + (size_t)lane * stride;
+        float* pp = reinterpret_cast<float*>(rec + x.off_pos);
+        float px = pp[0], py = pp[1], pz = pp[2];
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        float* np_ = x.off_nrm >= 0 ? reinterpret_cast<float*>(rec + x.off_nrm) : nullptr;
+        float* tp = x.off_tan >= 0 ? reinterpret_cast<float*>(rec + x.off_tan) : nullptr;
+        if (np_) { nx = np_[0]; ny = np_[1]; nz = np_[2]; }
+        if (tp) { t.x = tp[0]; t.y = tp[1]; t.z = tp[2]; }
+        const float* wp = reinterpret_cast<const float*>(rec + x.in_off_wgt);
+        const f32x4 w = {wp[0], wp[1], wp[2], wp[3]};
+        const uint32_t id = *reinterpret_cast<const uint32_t*>(rec + x.in_off_idx);
+        if constexpr (SHAPES) {
+            const uint16_t* col = x.shapes + ((size_t)u * 9) * 64 + lane;
+            const size_t shape_stride = (size_t)x.tiles_per_shape * 9 * 64;
 #pragma unroll 2
-                for (uint32_t sidx = 0; sidx < x.n_shapes; ++sidx) {
-                    const uint16_t* c = col + (size_t)sidx * shape_stride;
-                    const float ws = sw[sidx];
-                    uint16_t h[9];
+            for (uint32_t sidx = 0; sidx < x.n_shapes; ++sidx) {
+                const uint16_t* c = col + (size_t)sidx * shape_stride;
+                const float ws = sw[sidx];
+                uint16_t h[9];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) h[k] = __builtin_nontemporal_load(c + k * 64);
-                    if constexpr (EXACT) {
-                        px = px + h2f(h[0]) * ws; py = py + h2f(h[1]) * ws; pz = pz + h2f(h[2]) * ws;
-                        nx = nx + h2f(h[3]) * ws; ny = ny + h2f(h[4]) * ws; nz = nz + h2f(h[5]) * ws;
-                        t.x = t.x + h2f(h[6]) * ws; t.y = t.y + h2f(h[7]) * ws; t.z = t.z + h2f(h[8]) * ws;
-                    } else {
-                        px = __builtin_fmaf(h2f(h[0]), ws, px); py = __builtin_fmaf(h2f(h[1]), ws, py);
-                        pz = __builtin_fmaf(h2f(h[2]), ws, pz); nx = __builtin_fmaf(h2f(h[3]), ws, nx);
-                        ny = __builtin_fmaf(h2f(h[4]), ws, ny); nz = __builtin_fmaf(h2f(h[5]), ws, nz);
-                        t.x = __builtin_fmaf(h2f(h[6]), ws, t.x); t.y = __builtin_fmaf(h2f(h[7]), ws, t.y);
-                        t.z = __builtin_fmaf(h2f(h[8]), ws, t.z);
-                    }
+                for (int k = 0; k < 9; ++k) h[k] = __builtin_nontemporal_load(c + k * 64);
+                if constexpr (EXACT) {
+                    px = px + h2f(h[0]) * ws; py = py + h2f(h[1]) * ws; pz = pz + h2f(h[2]) * ws;
+                    nx = nx + h2f(h[3]) * ws; ny = ny + h2f(h[4]) * ws; nz = nz + h2f(h[5]) * ws;
+                    t.x = t.x + h2f(h[6]) * ws; t.y = t.y + h2f(h[7]) * ws; t.z = t.z + h2f(h[8]) * ws;
+                } else {
+                    px = __builtin_fmaf(h2f(h[0]), ws, px); py = __builtin_fmaf(h2f(h[1]), ws, py);
+                    pz = __builtin_fmaf(h2f(h[2]), ws, pz); nx = __builtin_fmaf(h2f(h[3]), ws, nx);
+                    ny = __builtin_fmaf(h2f(h[4]), ws, ny); nz = __builtin_fmaf(h2f(h[5]), ws, nz);
+                    t.x = __builtin_fmaf(h2f(h[6]), ws, t.x); t.y = __builtin_fmaf(h2f(h[7]), ws, t.y);
+                    t.z = __builtin_fmaf(h2f(h[8]), ws, t.z);
                 }
             }
-            const Skinned o = skin_vertex<EXACT, 7>(rows, row3, projective, id, w, px, py, pz, nx, ny, nz, t.x, t.y, t.z);
-            pp[0] = o.px; pp[1] = o.py; pp[2] = o.pz;
-            if (np_) { np_[0] = o.nx; np_[1] = o.ny; np_[2] = o.nz; }
-            if (tp) { tp[0] = o.tx; tp[1] = o.ty; tp[2] = o.tz; }
-            __builtin_amdgcn_wave_barrier();
-            // stream the slab out; only whole vertices of a ragged last unit
-            const uint32_t n_valid = (a.n_verts - u * 64) < 64u ? (a.n_verts - u * 64) : 64u;
-            unsigned char* out_span = x.out_aos + ((size_t)inst * a.n_verts + (size_t)u * 64) * stride;
-            if (n_valid == 64u && ((reinterpret_cast<uintptr_t>(out_span) & 15u) == 0)) {
-                f32x4* o4 = reinterpret_cast<f32x4*>(out_span);
-#pragma unroll
-                for (uint32_t k = 0; k < PL; ++k) {
-                    const uint32_t i = lane + 64 * k;
-                    if (k < per_lane && i < span_f4) __builtin_nontemporal_store(slab4[i], o4 + i);
-                }
-            } else {
-                const uint32_t n_dw = n_valid * (stride / 4);
-                const uint32_t* s32 = reinterpret_cast<const uint32_t*>(slab);
-                uint32_t* o32 = reinterpret_cast<uint32_t*>(out_span);
-                for (uint32_t i = lane; i < n_dw; i += 64) o32[i] = s32[i];
-            }
-            __builtin_amdgcn_wave_barrier();   // the slab is rewritten at the top of the loop
-            u = un;
-            (void)v;
         }
+        const Skinned o = skin_vertex<EXACT, 7>(rows, row3, projective, id, w, px, py, pz, nx, ny, nz, t.x, t.y, t.z);
+        pp[0] = o.px; pp[1] = o.py; pp[2] = o.pz;
+        if (np_) { np_[0] = o.nx; np_[1] = o.ny; np_[2] = o.nz; }
+        if (tp) { tp[0] = o.tx; tp[1] = o.ty; tp[2] = o.tz; }
+        __builtin_amdgcn_wave_barrier();
+        // stream the slab out; only whole vertices of a ragged last unit
+        const uint32_t n_valid = (a.n_verts - u * 64) < 64u ? (a.n_verts - u * 64) : 64u;
+        unsigned char* out_span = out_inst + (size_t)u * 64 * stride;
+        if (n_valid == 64u && ((reinterpret_cast<uintptr_t>(out_span) & 15u) == 0)) {
+            f32x4* o4 = reinterpret_cast<f32x4*>(out_span);
+#pragma unroll
+            for (uint32_t k = 0; k < PL; ++k) {
+                const uint32_t i = lane + 64 * k;
+                if (k < per_lane && i < span_f4) __builtin_nontemporal_store(slab4[i], o4 + i);
+            }
+        } else {
+            const uint32_t n_dw = n_valid * (stride / 4);
+            const uint32_t* s32 = reinterpret_cast<const uint32_t*>(slab);
+            uint32_t* o32 = reinterpret_cast<uint32_t*>(out_span);
+            for (uint32_t i = lane; i < n_dw; i += 64) o32[i] = s32[i];
+        }
+        __builtin_amdgcn_wave_barrier();   // the slab is rewritten at the top of the loop
+        u = un;
+        (void)v;
     }
 }
 
 template <bool EXACT, bool SHAPES, uint32_t PL>
-static hipError_t launch_aos_pl(const LbsExArgs& x, hipStream_t s) {
-    const uint32_t upi = (x.a.n_verts + 63) / 64;
-    const uint64_t total64 = (uint64_t)upi * x.a.n_instances;
-    if (total64 == 0) return hipSuccess;
-    if (total64 > 0xffffffffull) return hipErrorInvalidValue;
-    const uint32_t total = (uint32_t)total64;
-    constexpr uint32_t WPB = kAosBlock / 64;
-    const size_t lds = (size_t)x.a.n_bones * 64 + 64 + (size_t)WPB * 64 * x.out_stride;
-    const void* fn = reinterpret_cast<const void*>(&lbs_skin_aos<EXACT, SHAPES, PL>);
-    // persistent grid = exactly what is resident (registers and LDS decide); asked once per LDS size, not per launch
-    // (per host thread: a fyx_ctx is single-threaded; every context runs the same code object)
+__global__ __launch_bounds__(kAosBlock) void lbs_skin_aos(LbsExArgs x, uint32_t units_per_inst, uint32_t total_units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LbsArgs& a = x.a;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    if (u_begin >= u_end) return;
+    const uint32_t inst_first = u_begin / units_per_inst, inst_last = (u_end - 1) / units_per_inst;
+    for (uint32_t inst = inst_first; inst <= inst_last; ++inst) {
+        const uint32_t inst_u0 = inst * units_per_inst;
+        const uint32_t seg_b = (u_begin > inst_u0 ? u_begin : inst_u0) - inst_u0;
+        const uint32_t seg_e = (u_end < inst_u0 + units_per_inst ? u_end : inst_u0 + units_per_inst) - inst_u0;
+        aos_segment<EXACT, SHAPES, PL>(x, a.palette + (size_t)inst * a.n_bones * 16,
+                                       SHAPES ? x.shape_w + (size_t)inst * x.n_shapes : nullptr,
+                                       x.out_aos + (size_t)inst * a.n_verts * x.out_stride, seg_b, seg_e, inst == inst_first, smem);
+    }
+}
+
+// Batched form (fyx_lbs_skin_ex_batch): the segments of many meshes in one unit numbering, as lbs_skin_batch.
+template <bool EXACT, bool SHAPES, uint32_t PL>
+__global__ __launch_bounds__(kAosBlock) void lbs_skin_aos_batch(const LbsExSegDev* __restrict__ segs_g, uint32_t n_segs,
+                                                               const uint32_t* __restrict__ block_seg, uint32_t total_units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FYX_CONSTANT LbsExSegDev* segs = (const FYX_CONSTANT LbsExSegDev*)segs_g;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    if (u_begin >= u_end) return;
+    bool first = true;
+    for (uint32_t seg = block_seg[blockIdx.x]; seg < n_segs; ++seg) {   // workgroup-uniform
+        const uint32_t s_u0 = segs[seg].unit0;
+        if (s_u0 >= u_end) break;
+        LbsExArgs x;
+        x.a.n_verts = segs[seg].n_verts; x.a.n_bones = segs[seg].n_bones;
+        x.in_aos = segs[seg].in_aos;
+        x.shapes = segs[seg].shapes; x.n_shapes = segs[seg].n_shapes; x.tiles_per_shape = segs[seg].tiles_per_shape;
+        x.out_stride = segs[seg].stride;
+        x.off_pos = segs[seg].off_pos; x.off_nrm = segs[seg].off_nrm; x.off_tan = segs[seg].off_tan;
+        x.in_off_wgt = segs[seg].in_off_wgt; x.in_off_idx = segs[seg].in_off_idx;
+        const uint32_t upi = (x.a.n_verts + 63) / 64;
+        if (s_u0 + upi <= u_begin) continue;
+        const uint32_t seg_b = (u_begin > s_u0 ? u_begin : s_u0) - s_u0;
+        const uint32_t seg_e = (u_end < s_u0 + upi ? u_end : s_u0 + upi) - s_u0;
+        aos_segment<EXACT, SHAPES, PL>(x, segs[seg].palette, segs[seg].shape_w, segs[seg].out_aos, seg_b, seg_e, first, smem);
+        first = false;
+    }
+}
+
+// persistent grid = exactly what is resident (registers and LDS decide); asked once per LDS size, not per launch
+// (per host thread: a fyx_ctx is single-threaded; every context runs the same code object)
+template <typename K>
+static hipError_t aos_blocks_per_cu(K kernel, size_t lds, int* per_cu) {
     static thread_local size_t cached_lds = ~size_t(0);
     static thread_local int cached_per_cu = 0;
     if (lds != cached_lds) {
+        const void* fn = reinterpret_cast<const void*>(kernel);
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
@@ -1031,7 +1064,25 @@ static hipError_t launch_aos_pl(const LbsExArgs& x, hipStream_t s) {
         cached_per_cu = q < 1 ? 1 : q;
         cached_lds = lds;
     }
-    const int per_cu = cached_per_cu;
+    *per_cu = cached_per_cu;
+    return hipSuccess;
+}
+
+static size_t aos_lds_bytes(uint32_t n_bones, uint32_t stride) {
+    return (size_t)n_bones * 64 + 64 + (size_t)(kAosBlock / 64) * 64 * stride;
+}
+
+template <bool EXACT, bool SHAPES, uint32_t PL>
+static hipError_t launch_aos_pl(const LbsExArgs& x, hipStream_t s) {
+    const uint32_t upi = (x.a.n_verts + 63) / 64;
+    const uint64_t total64 = (uint64_t)upi * x.a.n_instances;
+    if (total64 == 0) return hipSuccess;
+    if (total64 > 0xffffffffull) return hipErrorInvalidValue;
+    const uint32_t total = (uint32_t)total64;
+    constexpr uint32_t WPB = kAosBlock / 64;
+    const size_t lds = aos_lds_bytes(x.a.n_bones, x.out_stride);
+    int per_cu = 1;
+    if (hipError_t e = aos_blocks_per_cu(&lbs_skin_aos<EXACT, SHAPES, PL>, lds, &per_cu); e != hipSuccess) return e;
     uint32_t grid = (uint32_t)kCUs * (uint32_t)per_cu;
     const uint32_t max_useful = (total + WPB - 1) / WPB;
     if (grid > max_useful) grid = max_useful;
@@ -1039,20 +1090,76 @@ static hipError_t launch_aos_pl(const LbsExArgs& x, hipStream_t s) {
     return hipGetLastError();
 }
 
+uint32_t lbs_aos_bucket(uint32_t stride) {
+    if (stride == 0 || (stride & 3u) || stride * 4 > 64 * kAosMaxF4PerLane) return 0;
+    const uint32_t pl = (stride * 4 + 63) / 64;
+    return pl <= 4 ? 4 : pl <= 5 ? 5 : pl <= 8 ? 8 : kAosMaxF4PerLane;
+}
+
 template <bool EXACT, bool SHAPES>
 static hipError_t launch_aos_one(const LbsExArgs& x, hipStream_t s) {
-    const uint32_t pl = (x.out_stride * 4 + 63) / 64;
-    if (pl <= 4) return launch_aos_pl<EXACT, SHAPES, 4>(x, s);
-    if (pl <= 5) return launch_aos_pl<EXACT, SHAPES, 5>(x, s);
-    if (pl <= 8) return launch_aos_pl<EXACT, SHAPES, 8>(x, s);
-    return launch_aos_pl<EXACT, SHAPES, kAosMaxF4PerLane>(x, s);
+    switch (lbs_aos_bucket(x.out_stride)) {
+        case 4: return launch_aos_pl<EXACT, SHAPES, 4>(x, s);
+        case 5: return launch_aos_pl<EXACT, SHAPES, 5>(x, s);
+        case 8: return launch_aos_pl<EXACT, SHAPES, 8>(x, s);
+        default: return launch_aos_pl<EXACT, SHAPES, kAosMaxF4PerLane>(x, s);
+    }
 }
 
 hipError_t launch_lbs_aos(const LbsExArgs& x, const LbsTuning& t, hipStream_t s) {
-    if (x.out_stride == 0 || (x.out_stride & 3u) || x.out_stride * 4 > 64 * kAosMaxF4PerLane) return hipErrorInvalidValue;
+    if (!lbs_aos_bucket(x.out_stride)) return hipErrorInvalidValue;
     const bool shapes = x.n_shapes > 0;
     if (t.exact) return shapes ? launch_aos_one<true, true>(x, s) : launch_aos_one<true, false>(x, s);
     return shapes ? launch_aos_one<false, true>(x, s) : launch_aos_one<false, false>(x, s);
+}
+
+// The batched launches: `op` is "how many workgroups per CU are resident" (grid != nullptr) or "launch".
+template <bool EXACT, bool SHAPES, uint32_t PL>
+static hipError_t aos_batch_pl(size_t lds, int* per_cu, const LbsExSegDev* d_segs, uint32_t n_segs, const uint32_t* d_block_seg,
+                               uint32_t grid, uint32_t total_units, hipStream_t s) {
+    if (per_cu) return aos_blocks_per_cu(&lbs_skin_aos_batch<EXACT, SHAPES, PL>, lds, per_cu);
+    hipLaunchKernelGGL((lbs_skin_aos_batch<EXACT, SHAPES, PL>), dim3(grid), dim3(kAosBlock), lds, s, d_segs, n_segs, d_block_seg,
+                       total_units);
+    return hipGetLastError();
+}
+
+template <bool EXACT, bool SHAPES>
+static hipError_t aos_batch_bucket(uint32_t bucket, size_t lds, int* per_cu, const LbsExSegDev* d_segs, uint32_t n_segs,
+                                   const uint32_t* d_block_seg, uint32_t grid, uint32_t total_units, hipStream_t s) {
+    switch (bucket) {
+        case 4: return aos_batch_pl<EXACT, SHAPES, 4>(lds, per_cu, d_segs, n_segs, d_block_seg, grid, total_units, s);
+        case 5: return aos_batch_pl<EXACT, SHAPES, 5>(lds, per_cu, d_segs, n_segs, d_block_seg, grid, total_units, s);
+        case 8: return aos_batch_pl<EXACT, SHAPES, 8>(lds, per_cu, d_segs, n_segs, d_block_seg, grid, total_units, s);
+        case kAosMaxF4PerLane: return aos_batch_pl<EXACT, SHAPES, kAosMaxF4PerLane>(lds, per_cu, d_segs, n_segs, d_block_seg, grid, total_units, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static hipError_t aos_batch_any(bool exact, bool shapes, uint32_t bucket, size_t lds, int* per_cu, const LbsExSegDev* d_segs,
+                                uint32_t n_segs, const uint32_t* d_block_seg, uint32_t grid, uint32_t total_units, hipStream_t s) {
+    if (exact) return shapes ? aos_batch_bucket<true, true>(bucket, lds, per_cu, d_segs, n_segs, d_block_seg, grid, total_units, s)
+                             : aos_batch_bucket<true, false>(bucket, lds, per_cu, d_segs, n_segs, d_block_seg, grid, total_units, s);
+    return shapes ? aos_batch_bucket<false, true>(bucket, lds, per_cu, d_segs, n_segs, d_block_seg, grid, total_units, s)
+                  : aos_batch_bucket<false, false>(bucket, lds, per_cu, d_segs, n_segs, d_block_seg, grid, total_units, s);
+}
+
+hipError_t lbs_aos_batch_grid(uint32_t total_units, uint32_t max_bones, uint32_t max_stride, uint32_t bucket, bool shapes,
+                              const LbsTuning& t, uint32_t* grid) {
+    int per_cu = 1;
+    if (hipError_t e = aos_batch_any(t.exact != 0, shapes, bucket, aos_lds_bytes(max_bones, max_stride), &per_cu, nullptr, 0,
+                                     nullptr, 0, 0, nullptr); e != hipSuccess) return e;
+    uint32_t g = (uint32_t)kCUs * (uint32_t)per_cu;
+    const uint32_t max_useful = (total_units + (kAosBlock / 64) - 1) / (kAosBlock / 64);
+    *grid = g > max_useful ? max_useful : g;
+    return hipSuccess;
+}
+
+hipError_t launch_lbs_aos_batch(const LbsExSegDev* d_segs, uint32_t n_segs, const uint32_t* d_block_seg, uint32_t grid,
+                                uint32_t total_units, uint32_t max_bones, uint32_t max_stride, uint32_t bucket, bool shapes,
+                                const LbsTuning& t, hipStream_t stream) {
+    if (n_segs == 0 || total_units == 0 || grid == 0) return hipSuccess;
+    return aos_batch_any(t.exact != 0, shapes, bucket, aos_lds_bytes(max_bones, max_stride), nullptr, d_segs, n_segs, d_block_seg,
+                         grid, total_units, stream);
 }
 
 // RGB16F volume (engine layout: [shape][vertex][texel: position, normal, tangent][rgb], 18 B per vertex,

@@ -209,6 +209,11 @@ typedef struct fyx_skin_desc {
     int32_t out_off_pos, out_off_normal, out_off_tangent;
 } fyx_skin_desc;
 int fyx_lbs_skin_ex(fyx_ctx* ctx, uint64_t mesh_id, const fyx_skin_desc* desc);
+/* Batch form of fyx_lbs_skin_ex, as fyx_lbs_skin_batch is of fyx_lbs_skin_device: job k = fyx_lbs_skin_ex(ctx,
+ * mesh_ids[k], &descs[k]), identical results.  Jobs that write vertex buffers in the mesh's own layout (out_stride 0,
+ * with or without blend shapes) are skinned by one launch per layout class; plain SoA jobs by one launch per output
+ * set; the remaining forms (blend shapes into SoA, custom interleaved layouts) keep one launch each. */
+int fyx_lbs_skin_ex_batch(fyx_ctx* ctx, const uint64_t* mesh_ids, const fyx_skin_desc* descs, uint32_t n_jobs);
 
 /* Raw-stream form (no registry): all pointers device; d_indices is 4 x u8 per vertex. No bone
  * index validation (caller guarantees indices < n_bones). Asynchronous. */

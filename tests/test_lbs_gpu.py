@@ -801,3 +801,100 @@ def test_batch_argument_errors_launch_nothing(ctx):
     ctx.sync()
     for _, _, _, o in scene:                                  # the valid first job was not launched either
         assert np.all(o["pos"].download(np.float32, 500 * 3) == 7.0)
+
+
+def _aos_expect(orc, m, pal, n_inst, layout_stride, offs, shapes=None):
+    """Reference output vertex buffer bytes: input vertices with position / normal / tangent.xyz replaced."""
+    if shapes:
+        storage, plane, weights = shapes
+        ref = oracle_skin_shapes(orc, m, pal, storage, plane, weights, n_inst)
+    else:
+        ref = oracle_skin(orc, m, pal, n_inst)
+    src = m.to_animated_vertex_aos().reshape(m.n_verts, layout_stride)
+    out = np.tile(src, (n_inst, 1)).copy()
+    for off, key in zip(offs, ("pos", "normal", "tangent")):
+        out[:, off:off + 12] = np.ascontiguousarray(ref[key][:, :3]).view(np.uint8).reshape(-1, 12)
+    return out
+
+
+def test_ex_batch_vertex_buffers_blend_shapes_and_plain_jobs_in_one_call(ctx, orc):
+    """fyx_lbs_skin_ex_batch: vertex-buffer jobs without and with blend shapes (two launches), plain SoA jobs (the
+    batched SoA launch), a blend-shapes-into-SoA job (its own launch) -- every output equals the oracle bit for bit
+    and equals what fyx_lbs_skin_ex writes for the same job."""
+    L = synth.ANIMATED_VERTEX
+    offs = (L["off_pos"], L["off_normal"], L["off_tangent"])
+    seed = synth.SEED_BASE + 400
+    jobs, checks = [], []
+    # (n_verts, n_bones, n_instances, n_shapes) vertex-buffer jobs
+    for k, (nv, nb, ni, ns) in enumerate([(3000, 40, 1, 0), (65, 8, 3, 0), (10_000, 64, 2, 0), (2222, 30, 1, 2), (640, 16, 2, 3), (1, 4, 1, 0)]):
+        mid = 7600 + k
+        m = synth.make_mesh(nv, nb, seed + k, coherent=bool(k % 2))
+        pal = synth.make_palette(nb, seed + 50 + k, n_instances=ni)
+        upload(ctx, mid, m, aos=True)
+        kw = dict(d_palette=ctx.to_device(pal).ptr, n_bones=nb, n_instances=ni)
+        shapes = None
+        if ns:
+            storage, plane, w = synth.make_blend_shapes(nv, ns, seed + k)
+            ctx.mesh_set_blend_shapes(mid, storage, ns, plane)
+            weights = np.stack([w * np.float32(1.0 + 0.5 * i) for i in range(ni)])
+            kw.update(d_blend_shape_weights=ctx.to_device(weights).ptr, n_blend_shapes=ns)
+            shapes = (storage, plane, weights)
+        buf = ctx.to_device(np.full(nv * ni * L["stride"] + 64, 0xEE, np.uint8))
+        kw.update(d_out_vertices=buf.ptr, out_stride=0)
+        jobs.append((mid, kw))
+        checks.append(("aos", m, pal, ni, shapes, buf))
+    # plain SoA jobs and one with blend shapes into SoA
+    for k, (nv, nb, ni, ns) in enumerate([(4000, 32, 1, 0), (500, 12, 2, 0), (3000, 24, 1, 2)]):
+        mid = 7650 + k
+        m = synth.make_mesh(nv, nb, seed + 20 + k)
+        pal = synth.make_palette(nb, seed + 70 + k, n_instances=ni)
+        upload(ctx, mid, m)
+        outs = (ctx.malloc(nv * ni * 12), ctx.malloc(nv * ni * 12), ctx.malloc(nv * ni * 16))
+        kw = dict(d_palette=ctx.to_device(pal).ptr, n_bones=nb, n_instances=ni, d_out_pos=outs[0].ptr, d_out_normal=outs[1].ptr,
+                  d_out_tangent=outs[2].ptr)
+        shapes = None
+        if ns:
+            storage, plane, w = synth.make_blend_shapes(nv, ns, seed + 20 + k)
+            ctx.mesh_set_blend_shapes(mid, storage, ns, plane)
+            weights = w[None, :]
+            kw.update(d_blend_shape_weights=ctx.to_device(weights).ptr, n_blend_shapes=ns)
+            shapes = (storage, plane, weights)
+        jobs.append((mid, kw))
+        checks.append(("soa", m, pal, ni, shapes, outs))
+    ctx.lbs_skin_ex_batch(jobs)
+    ctx.lbs_skin_ex_batch(jobs)      # the same table again: no re-upload, same result
+    ctx.sync()
+    for (mid, kw), (kind, m, pal, ni, shapes, out) in zip(jobs, checks):
+        nv = m.n_verts
+        if kind == "aos":
+            raw = out.download(np.uint8, nv * ni * L["stride"] + 64)
+            assert np.all(raw[-64:] == 0xEE), "wrote past the last vertex"
+            got = raw[:-64].reshape(nv * ni, L["stride"])
+            assert np.array_equal(got, _aos_expect(orc, m, pal, ni, L["stride"], offs, shapes)), f"mesh {mid}"
+            one = ctx.to_device(np.full(nv * ni * L["stride"] + 64, 0xEE, np.uint8))
+            ctx.lbs_skin_ex(mid, **{**kw, "d_out_vertices": one.ptr})
+            ctx.sync()
+            assert np.array_equal(one.download(np.uint8, raw.size), raw), f"mesh {mid}: batch != single launch"
+            one.free()
+        else:
+            ref = oracle_skin_shapes(orc, m, pal, *shapes, ni) if shapes else oracle_skin(orc, m, pal, ni)
+            for o, key, wdt in zip(out, ("pos", "normal", "tangent"), (3, 3, 4)):
+                got = o.download(np.float32, nv * ni * wdt).reshape(-1, wdt)
+                assert np.array_equal(got.view(np.uint32), ref[key].view(np.uint32)), f"mesh {mid} {key}"
+
+
+def test_ex_batch_validates_every_job_first(ctx):
+    L = synth.ANIMATED_VERTEX
+    m = synth.make_mesh(300, 8, 77)
+    upload(ctx, 7700, m, aos=True)
+    upload(ctx, 7701, m, aos=False)
+    pal = ctx.to_device(synth.make_palette(8, 77))
+    buf = ctx.to_device(np.full(300 * L["stride"], 0x11, np.uint8))
+    good = (7700, dict(d_palette=pal.ptr, n_bones=8, d_out_vertices=buf.ptr, out_stride=0))
+    bad = (7701, dict(d_palette=pal.ptr, n_bones=8, d_out_vertices=buf.ptr, out_stride=0))   # no interleaved upload
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        ctx.lbs_skin_ex_batch([good, bad])
+    assert e.value.code == fyrox_amd._native.FYX_ERR_MISSING_ATTRIBUTE
+    ctx.sync()
+    assert np.all(buf.download(np.uint8, 300 * L["stride"]) == 0x11)      # the good job was not launched either
+    ctx.lbs_skin_ex_batch([])
