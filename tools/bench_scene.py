@@ -28,6 +28,7 @@ ap.add_argument("--bones", type=int, default=64)
 ap.add_argument("--frames", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--batched-only", action="store_true", help="skip the one-by-one legs (short runs under a profiler)")
 args = ap.parse_args()
 
 ctx = fyrox_amd.Context(0)
@@ -97,9 +98,12 @@ for _ in range(args.warmup):
 f_gpu, f_wall = timed()
 p_gpu, p_wall = timed(skin=False)
 s_gpu, s_wall = timed(pose=False)
-f1_gpu, f1_wall = timed(batched=False)
-p1_gpu, p1_wall = timed(skin=False, batched=False)
-s1_gpu, s1_wall = timed(pose=False, batched=False)
+if args.batched_only:
+    f1_gpu = f1_wall = p1_gpu = p1_wall = s1_gpu = s1_wall = None
+else:
+    f1_gpu, f1_wall = timed(batched=False)
+    p1_gpu, p1_wall = timed(skin=False, batched=False)
+    s1_gpu, s1_wall = timed(pose=False, batched=False)
 t0 = time.perf_counter()
 for _ in range(args.frames):
     for an, *_ in chars:

@@ -20,6 +20,10 @@ python $ROOT/tools/bench_pose.py --root-motion > "$ROOT/$OUT/pose_root_motion.js
 # extended launches: blend shapes, vertex-buffer-in / vertex-buffer-out
 python $ROOT/tools/bench_ex.py > "$ROOT/$OUT/bench_ex.json" 2> "$ROOT/$OUT/bench_ex.err"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_ex" -o ex -- python $ROOT/tools/bench_ex.py --streams 1 --steps 300 > "$ROOT/$OUT/bench_ex_under_trace.json" 2> "$ROOT/$OUT/trace_ex.err" )
+# heterogeneous scenes: many animators / meshes per frame, batched vs one by one
+python $ROOT/tools/bench_scene.py > "$ROOT/$OUT/scene_64x4.json" 2> "$ROOT/$OUT/scene_64x4.err"
+python $ROOT/tools/bench_scene.py --characters 256 --instances 1 --verts 5000 > "$ROOT/$OUT/scene_256x1.json" 2> "$ROOT/$OUT/scene_256x1.err"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_scene" -o scene -- python $ROOT/tools/bench_scene.py --characters 256 --instances 1 --verts 5000 --frames 50 --batched-only > "$ROOT/$OUT/scene_under_trace.json" 2> "$ROOT/$OUT/trace_scene.err" )
 python $ROOT/tools/bench_pose.py --opt lbs.streams=1 --opt lbs.exact=0 > "$ROOT/$OUT/pose_fused.json" 2> "$ROOT/$OUT/pose_fused.err"
 python $ROOT/tools/probe_timeline.py --opt lbs.blocks_per_cu=2 > "$ROOT/$OUT/timeline.json" 2> "$ROOT/$OUT/timeline.err"
 python $ROOT/tools/write_ceiling.py > "$ROOT/$OUT/write_ceiling.json" 2> "$ROOT/$OUT/write_ceiling.err"
