@@ -240,6 +240,10 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+PROPERTY_VALUE = np.dtype([("value", np.float32, (4,)), ("present", np.uint32), ("kind", np.uint32), ("reserved", np.uint32, (2,))])
+VALUE_REAL, VALUE_VEC2, VALUE_VEC3, VALUE_VEC4, VALUE_QUAT = 0, 1, 2, 3, 4   # FYX_VALUE_*: TrackValue variants
+
+
 class Animator:
     """n_instances copies of one rig + its AnimationPlayer animations (+ optionally a Machine)."""
 
@@ -389,8 +393,9 @@ class Animator:
         return out.value
 
     def read_properties(self, animation: int = -1) -> np.ndarray:
-        """(n_instances, n_slots, 2) float32: value, flag bits.  animation < 0: applied values."""
-        out = np.zeros((self.n_instances, self.property_count(), 2), np.float32)
+        """(n_instances, n_slots) records of PROPERTY_VALUE (fyx_property_value): value[4], present, kind.
+        animation < 0: applied values."""
+        out = np.zeros((self.n_instances, self.property_count()), PROPERTY_VALUE)
         self._check(self._l.fyx_animator_read_properties(self._h, self.id, animation, _ptr(out)))
         return out
 

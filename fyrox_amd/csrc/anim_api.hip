@@ -195,8 +195,8 @@ struct Animator {
     // Property{..} slots: one per distinct (node, property id) any animation of the animator drives
     std::vector<std::pair<int32_t, int32_t>> prop_slots;
     int32_t* d_prop_node = nullptr;
-    float2* d_prop_pose = nullptr;     // [anim capacity][instance][slot]
-    float2* d_prop_out = nullptr;      // [instance][slot]
+    PropRec* d_prop_pose = nullptr;    // [anim capacity][instance][slot]
+    PropRec* d_prop_out = nullptr;     // [instance][slot]
     uint32_t dev_prop_slots = 0, dev_prop_anims = 0;
     std::vector<uint32_t> rm_layer_base;   // first slot of each layer; nodes, then the layer's final pose
     uint32_t n_rm_slots = 0;               // ... and the machine's final pose last
@@ -1017,17 +1017,17 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         dfree(A.d_prop_node);
         A.d_prop_node = nullptr;
         if (int rc = upload(c, &A.d_prop_node, nodes.data(), nodes.size())) return rc;
-        float2* np = nullptr;
-        float2* no = nullptr;
-        const size_t pb = (size_t)A.dev_anim_capacity * A.n_instances * nps * sizeof(float2);
-        const size_t ob = (size_t)A.n_instances * nps * sizeof(float2);
+        PropRec* np = nullptr;
+        PropRec* no = nullptr;
+        const size_t pb = (size_t)A.dev_anim_capacity * A.n_instances * nps * sizeof(PropRec);
+        const size_t ob = (size_t)A.n_instances * nps * sizeof(PropRec);
         FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&np), std::max<size_t>(pb, 16)));
         FYX_HIP(c, hipMemset(np, 0, std::max<size_t>(pb, 16)));
         FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&no), std::max<size_t>(ob, 16)));
         FYX_HIP(c, hipMemset(no, 0, std::max<size_t>(ob, 16)));
         if (A.d_prop_out && A.dev_prop_slots)   // slots only ever get appended: old slot k is new slot k
-            FYX_HIP(c, hipMemcpy2D(no, (size_t)nps * sizeof(float2), A.d_prop_out, (size_t)A.dev_prop_slots * sizeof(float2),
-                                   (size_t)A.dev_prop_slots * sizeof(float2), A.n_instances, hipMemcpyDeviceToDevice));
+            FYX_HIP(c, hipMemcpy2D(no, (size_t)nps * sizeof(PropRec), A.d_prop_out, (size_t)A.dev_prop_slots * sizeof(PropRec),
+                                   (size_t)A.dev_prop_slots * sizeof(PropRec), A.n_instances, hipMemcpyDeviceToDevice));
         dfree(A.d_prop_pose);
         dfree(A.d_prop_out);
         A.d_prop_pose = np;
@@ -1398,9 +1398,9 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
     for (uint32_t t = 0; t < n_tracks; ++t) {
         const fyx_track_desc& d = tracks[t];
         if (d.binding >= FYX_BIND_PROPERTY0) {
-            // Property{name, value_type}: the id stands for the name; Real values only (morph weights and the like)
-            if (d.kind != FYX_KIND_REAL)
-                return fail(c, FYX_ERR_UNSUPPORTED, "track %u: Property bindings are supported for TrackValueKind::Real only", t);
+            // Property{name, value_type}: the id stands for the name; every TrackValueKind
+            if (d.kind < FYX_KIND_REAL || d.kind > FYX_KIND_QUAT)
+                return fail(c, FYX_ERR_INVALID_ARG, "track %u: value kind %d", t, d.kind);
             if (d.n_curves > 4) return fail(c, FYX_ERR_INVALID_ARG, "track %u has %u curves", t, d.n_curves);
             for (uint32_t k = 0; k < d.n_curves; ++k) total += d.curve_n_keys[k];
             continue;
@@ -2394,7 +2394,7 @@ int fyx_animator_property_slot(fyx_ctx* c, uint64_t animator_id, int32_t node, i
     FYX_GUARD_END(c)
 }
 
-int fyx_animator_read_properties(fyx_ctx* c, uint64_t animator_id, int32_t animation, float* host_out) {
+int fyx_animator_read_properties(fyx_ctx* c, uint64_t animator_id, int32_t animation, fyx_property_value* host_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     FYX_ANIMATOR(c, A, animator_id);
@@ -2405,8 +2405,9 @@ int fyx_animator_read_properties(fyx_ctx* c, uint64_t animator_id, int32_t anima
     if (int rc = enter_primary(c)) return rc;
     if (int rc = ensure_device_state(c, *A)) return rc;
     const size_t per = (size_t)A->n_instances * A->dev_prop_slots;
-    const float2* src = animation < 0 ? A->d_prop_out : A->d_prop_pose + (size_t)animation * per;
-    FYX_HIP(c, hipMemcpyAsync(host_out, src, per * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    static_assert(sizeof(fyx_property_value) == sizeof(PropRec), "same record on both sides of the boundary");
+    const PropRec* src = animation < 0 ? A->d_prop_out : A->d_prop_pose + (size_t)animation * per;
+    FYX_HIP(c, hipMemcpyAsync(host_out, src, per * sizeof(PropRec), hipMemcpyDeviceToHost, c->stream));
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     return FYX_OK;
     FYX_GUARD_END(c)

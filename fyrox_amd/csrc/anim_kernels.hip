@@ -679,15 +679,17 @@ __device__ __forceinline__ void run_fold(FoldCtx& cx, Acc& acc) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Property{..} bindings of kind Real (morph-target weights and the like).
+// Property{..} bindings (morph-target weights, and any other numeric property the animation editor can key).
 //
 // In the reference such a value is one more BoundValue in its node's pose (pose.rs:107-121), blended by
-// TrackValue::Real => lerpf (value.rs:221-230) and applied through reflection (value.rs:404-427).  Here every
+// TrackValue::blend_with -- Real => lerpf, Vector2/3/4 => nalgebra lerp, UnitQuaternion => nlerp, different variants
+// => no-op (value.rs:221-230) -- and written through reflection after a numeric cast to the property's machine type
+// (value.rs:232-427; the cast is the Rust shim's: it gets the f32 lanes and the value's variant).  Here every
 // (node, property) pair of an animator is a SLOT with its own thread.  What couples a slot to the rest of its node
 // is NodePose::blend_with's rule "an empty node pose becomes a copy of the other" (pose.rs:41-47): emptiness is a
 // property of the whole node, so bit 3 of a pose record's present bits says "this animation holds a Property value
 // for the node" (the node threads of pose_update see it in their mask), and a slot thread carries the node's mask
-// along with its own {value, present} through the same fold program.
+// along with its own {value[4], variant, present} through the same fold program.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void property_sample_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
     const uint32_t slot = bx * 256u + threadIdx.x, inst = by, a = bz;
@@ -695,17 +697,44 @@ __device__ __forceinline__ void property_sample_body(const PoseFrameDev& f, uint
     if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;
     const AnimDev an = f.anims[a];
     const int32_t track = an.prop_track[slot];
-    float2 out = make_float2(0.0f, 0.0f);
+    PropRec out;
+    out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0.0f;
+    out.present = out.kind = out.pad[0] = out.pad[1] = 0u;
     if (track >= 0) {
+        // TrackDataContainer::fetch (container.rs:182-297): 1 / 2 / 3 / 4 curves for Real / Vector2 / Vector3 / Vector4,
+        // 3 Euler angles -> qz * qy * qx, 4 components -> normalised quaternion; None when curves are missing
         const TrackDev* tk = an.tracks + track;
-        if (tk->kind == FYX_KIND_REAL && tk->n_curves >= 1) {   // curves.first()? else None (container.rs:289-291)
-            uint32_t* hp = hint_ptr(f, a, (uint32_t)track, 0, inst);
-            uint32_t hint = *hp;
-            const uint32_t fk = tk->first_key[0];
-            out.x = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[0],
-                                   f.times[(size_t)inst * f.n_anims + a], hint);
-            *hp = hint;
-            out.y = __uint_as_float(1u);
+        const int kind = tk->kind;
+        const int need = kind == FYX_KIND_REAL ? 1 : kind == FYX_KIND_VEC2 ? 2 : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3 : 4;
+        if ((int)tk->n_curves >= need) {
+            const float time = f.times[(size_t)inst * f.n_anims + a];
+            float val[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= need) break;
+                uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
+                uint32_t hint = *hp;
+                const uint32_t fk = tk->first_key[c];
+                val[c] = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], time, hint);
+                *hp = hint;
+            }
+            if (kind == FYX_KIND_QUAT) {
+                const f4 q = quat_normalize(f4{val[0], val[1], val[2], val[3]});
+                val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
+            } else if (kind == FYX_KIND_QUAT_EULER) {
+                float sx, cx, sy, cy, sz, cz;
+                sincosf(val[0] / 2.0f, &sx, &cx);
+                sincosf(val[1] / 2.0f, &sy, &cy);
+                sincosf(val[2] / 2.0f, &sz, &cz);
+                const f4 qx = f4{1.0f * sx, 0.0f * sx, 0.0f * sx, cx};
+                const f4 qy = f4{0.0f * sy, 1.0f * sy, 0.0f * sy, cy};
+                const f4 qz = f4{0.0f * sz, 0.0f * sz, 1.0f * sz, cz};
+                const f4 q = quat_mul(quat_mul(qz, qy), qx);
+                val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
+            }
+            out.v[0] = val[0]; out.v[1] = val[1]; out.v[2] = val[2]; out.v[3] = val[3];
+            out.present = 1u;
+            out.kind = kind == FYX_KIND_QUAT_EULER || kind == FYX_KIND_QUAT ? (uint32_t)FYX_VALUE_QUAT : (uint32_t)kind;   // TrackValue variant
         }
     }
     f.prop_pose[((size_t)a * f.n_instances + inst) * f.n_prop_slots + slot] = out;
@@ -725,19 +754,43 @@ hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s) {
 }
 
 struct PAcc {
-    float v;
+    f4 v;
+    uint32_t kind;        // TrackValue variant (FYX_VALUE_*)
     uint32_t present;     // this slot holds a value
     uint32_t node_mask;   // present bits of the whole node (0 == the node's pose is empty)
 };
 
+__device__ __forceinline__ PAcc pacc_empty() { return PAcc{f4{0.0f, 0.0f, 0.0f, 0.0f}, 0u, 0u, 0u}; }
+
+// TrackValue::blend_with (value.rs:221-230)
 __device__ __forceinline__ void pblend(PAcc& self, const PAcc& o, float w) {
     if (self.node_mask == 0) { self = o; return; }                      // copy, weight ignored
-    if (self.present && o.present) self.v = lerpf_(self.v, o.v, w);      // Real: a + (b - a) * w
+    if (!(self.present && o.present) || self.kind != o.kind) return;     // different variants: no-op
+    const float omw = 1.0f - w;                                          // nalgebra lerp: self * (1 - t) + rhs * t
+    switch (self.kind) {
+        case FYX_VALUE_REAL: self.v.x = lerpf_(self.v.x, o.v.x, w); break;    // a + (b - a) * w
+        case FYX_VALUE_VEC2:
+            self.v.x = self.v.x * omw + o.v.x * w; self.v.y = self.v.y * omw + o.v.y * w;
+            break;
+        case FYX_VALUE_VEC3:
+            self.v.x = self.v.x * omw + o.v.x * w; self.v.y = self.v.y * omw + o.v.y * w; self.v.z = self.v.z * omw + o.v.z * w;
+            break;
+        case FYX_VALUE_VEC4:
+            self.v.x = self.v.x * omw + o.v.x * w; self.v.y = self.v.y * omw + o.v.y * w;
+            self.v.z = self.v.z * omw + o.v.z * w; self.v.w = self.v.w * omw + o.v.w * w;
+            break;
+        default: {   // value.rs:449-454 nlerp: flip self when dot < 0, then normalize(lerp)
+            f4 a = self.v;
+            if (dot4(a, o.v) < 0.0f) a = f4{-a.x, -a.y, -a.z, -a.w};
+            self.v = quat_normalize(f4{a.x * omw + o.v.x * w, a.y * omw + o.v.y * w, a.z * omw + o.v.z * w, a.w * omw + o.v.w * w});
+            break;
+        }
+    }
 }
 
 struct PFoldCtx {
     const uint2* __restrict__ ops;
-    const float2* __restrict__ prop_pose;      // [n_anims][n_instances][n_slots]
+    const PropRec* __restrict__ prop_pose;     // [n_anims][n_instances][n_slots]
     const f4* __restrict__ anim_pose;          // node records (for the node's present bits)
     const uint8_t* __restrict__ layer_masks;
     size_t prop_stride, prop_index;            // n_instances * n_slots, inst * n_slots + slot
@@ -745,15 +798,18 @@ struct PFoldCtx {
     uint32_t n_nodes, node, pc;
     float pop_w;
     bool done;
-    float out_v;
+    f4 out_v;
+    uint32_t out_kind;
     bool out_set;
 };
 
 __device__ __forceinline__ PAcc pload(const PFoldCtx& cx, uint32_t a) {
-    const float2 p = cx.prop_pose[(size_t)a * cx.prop_stride + cx.prop_index];
+    const f4* p = reinterpret_cast<const f4*>(cx.prop_pose + (size_t)a * cx.prop_stride + cx.prop_index);
+    const f4 v = p[0], m = p[1];
     PAcc o;
-    o.v = p.x;
-    o.present = __float_as_uint(p.y);
+    o.v = v;
+    o.present = __float_as_uint(m.x);
+    o.kind = __float_as_uint(m.y);
     o.node_mask = __float_as_uint(cx.anim_pose[((size_t)a * cx.rec_stride + cx.rec_index) * 3].w);
     return o;
 }
@@ -768,7 +824,7 @@ __device__ __forceinline__ void run_fold_prop(PFoldCtx& cx, PAcc& acc) {
             case OP_BLEND_ANIM: pblend(acc, pload(cx, arg), w); break;
             case OP_PUSH:
                 if constexpr (D + 1 < kMaxFoldDepth) {
-                    PAcc child{0.0f, 0u, 0u};
+                    PAcc child = pacc_empty();
                     run_fold_prop<D + 1>(cx, child);
                     if (cx.done) return;
                     pblend(acc, child, cx.pop_w);
@@ -778,16 +834,16 @@ __device__ __forceinline__ void run_fold_prop(PFoldCtx& cx, PAcc& acc) {
                 }
                 break;
             case OP_POP_BLEND: cx.pop_w = w; return;
-            case OP_RESET: acc = PAcc{0.0f, 0u, 0u}; break;
+            case OP_RESET: acc = pacc_empty(); break;
             case OP_MASK:
-                if (cx.layer_masks[(size_t)arg * cx.n_nodes + cx.node]) acc = PAcc{0.0f, 0u, 0u};
+                if (cx.layer_masks[(size_t)arg * cx.n_nodes + cx.node]) acc = pacc_empty();
                 break;
             case OP_APPLY:
-                if (acc.present) { cx.out_v = acc.v; cx.out_set = true; }
+                if (acc.present) { cx.out_v = acc.v; cx.out_kind = acc.kind; cx.out_set = true; }
                 break;
             case OP_APPLY_ANIM: {
                 const PAcc o = pload(cx, arg);
-                if (o.present) { cx.out_v = o.v; cx.out_set = true; }
+                if (o.present) { cx.out_v = o.v; cx.out_kind = o.kind; cx.out_set = true; }
                 break;
             }
             default: cx.done = true; return;
@@ -812,11 +868,16 @@ __device__ __forceinline__ void property_update_body(const PoseFrameDev& f, uint
     cx.pc = 0;
     cx.pop_w = 0.f;
     cx.done = false;
-    cx.out_v = 0.f;
+    cx.out_v = f4{0.f, 0.f, 0.f, 0.f};
+    cx.out_kind = 0u;
     cx.out_set = false;
-    PAcc acc{0.0f, 0u, 0u};
+    PAcc acc = pacc_empty();
     while (!cx.done) run_fold_prop<0>(cx, acc);
-    if (cx.out_set) f.prop_out[(size_t)inst * f.n_prop_slots + slot] = make_float2(cx.out_v, __uint_as_float(1u));
+    if (cx.out_set) {
+        f4* o = reinterpret_cast<f4*>(f.prop_out + (size_t)inst * f.n_prop_slots + slot);
+        o[0] = cx.out_v;
+        o[1] = f4{__uint_as_float(1u), __uint_as_float(cx.out_kind), 0.0f, 0.0f};
+    }
 }
 
 __global__ __launch_bounds__(64) void property_update_kernel(PoseFrameDev f) { property_update_body(f, blockIdx.x, blockIdx.y); }
@@ -832,7 +893,7 @@ hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s) {
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void blend_shape_weights_kernel(const float2* __restrict__ prop_out, uint32_t n_prop_slots,
+__global__ __launch_bounds__(256) void blend_shape_weights_kernel(const PropRec* __restrict__ prop_out, uint32_t n_prop_slots,
                                                                   uint32_t n_instances, const int32_t* __restrict__ slots,
                                                                   const float* __restrict__ defaults, uint32_t n_shapes,
                                                                   float* __restrict__ out) {
@@ -842,13 +903,13 @@ __global__ __launch_bounds__(256) void blend_shape_weights_kernel(const float2* 
     float w = defaults[k];
     const int32_t sl = slots[k];
     if (sl >= 0 && (uint32_t)sl < n_prop_slots) {
-        const float2 p = prop_out[(size_t)inst * n_prop_slots + sl];
-        if (__float_as_uint(p.y)) w = p.x;
+        const PropRec p = prop_out[(size_t)inst * n_prop_slots + sl];
+        if (p.present && p.kind == FYX_VALUE_REAL) w = p.v[0];   // BlendShape::weight is an f32: only a Real value casts to it
     }
     out[e] = w / 100.0f;   // bs.weight / 100.0 (scene/mesh/mod.rs:797)
 }
 
-hipError_t launch_blend_shape_weights(const float2* prop_out, uint32_t n_prop_slots, uint32_t n_instances,
+hipError_t launch_blend_shape_weights(const PropRec* prop_out, uint32_t n_prop_slots, uint32_t n_instances,
                                       const int32_t* d_slots, const float* d_defaults, uint32_t n_shapes, float* d_out,
                                       hipStream_t s) {
     const uint64_t total = (uint64_t)n_instances * n_shapes;

@@ -235,6 +235,15 @@ struct RigDev {
     uint32_t n_levels;
 };
 
+// One Property{..} value: the TrackValue's f32 lanes, its variant and whether it is there (== fyx_property_value)
+struct PropRec {
+    float v[4];
+    uint32_t present;
+    uint32_t kind;       // FYX_VALUE_*
+    uint32_t pad[2];
+};
+static_assert(sizeof(PropRec) == 32, "two 16-byte halves");
+
 struct PoseFrameDev {
     const AnimDev* anims;
     uint32_t n_anims;
@@ -254,11 +263,11 @@ struct PoseFrameDev {
     float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
     float* local;                // [n_instances][n_nodes][16]
     float* global;               // [n_instances][n_nodes][16]
-    // Property{..} bindings of kind Real (value.rs:355-373, :404-427): one slot per (node, property) of the animator
+    // Property{..} bindings (value.rs:221-230, :404-427): one slot per (node, property) of the animator
     uint32_t n_prop_slots;
     const int32_t* prop_node;    // [n_prop_slots] node of each slot
-    float2* prop_pose;           // [n_anims][n_instances][n_prop_slots] {value, present bits}
-    float2* prop_out;            // [n_instances][n_prop_slots] {applied value, has-been-applied bits}
+    PropRec* prop_pose;          // [n_anims][n_instances][n_prop_slots]
+    PropRec* prop_out;           // [n_instances][n_prop_slots] value applied last (present = has been applied)
     // root motion (all null / 0 unless the animator tracks root motion)
     const float2* slices;        // [n_instances][n_anims] time_slice {start, end}
     RootMotionDev* rm_anim;      // [n_anims][n_instances]
@@ -310,7 +319,7 @@ hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream
 hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s);
 hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s);
 // out[inst][k] = (has(inst, slots[k]) ? value(inst, slots[k]) : defaults[k]) / 100  (mesh/mod.rs:794-798)
-hipError_t launch_blend_shape_weights(const float2* prop_out, uint32_t n_prop_slots, uint32_t n_instances,
+hipError_t launch_blend_shape_weights(const PropRec* prop_out, uint32_t n_prop_slots, uint32_t n_instances,
                                       const int32_t* d_slots, const float* d_defaults, uint32_t n_shapes, float* d_out,
                                       hipStream_t s);
 // out[inst][b] = global[inst][bone_nodes[b]] * inv_bind[bone_nodes[b]] (identity for a negative node)

@@ -400,23 +400,34 @@ int fyx_animation_read_root_motion(fyx_ctx* ctx, uint64_t animator_id, uint32_t 
  * instance, as of the last fyx_absm_update: host_out[n_instances].  Synchronous. */
 int fyx_absm_read_root_motion(fyx_ctx* ctx, uint64_t animator_id, int32_t layer, fyx_root_motion* host_out);
 
-/* Property{..} bindings of kind Real (value.rs:355-373, applied through reflection at :404-427; the glTF
- * importer animates BlendShape weights this way, resource/gltf/animation.rs:395-420).  A track with
+/* Property{..} bindings (value.rs:355-373, applied through reflection at :404-427; the glTF importer animates
+ * BlendShape weights this way, resource/gltf/animation.rs:395-420, and the animation editor keys any numeric
+ * property).  Tracks of every TrackValueKind are taken: Real, Vector2/3/4, UnitQuaternion, UnitQuaternionEuler.  A track with
  * binding FYX_BIND_PROPERTY0 + id bound to node n animates the (n, id) "slot" of the animator; slots
  * are created by fyx_animator_add_animation in order of first appearance.  Such a value is part of its
- * node's pose exactly as in the reference: it is blended with lerpf (value.rs:221-230), dropped when
+ * node's pose exactly as in the reference: it is blended by TrackValue::blend_with (value.rs:221-230: lerpf, vector
+ * lerp or nlerp by variant; values of different variants do not blend), dropped when
  * only the other pose holds it, copied -- weight ignored -- when the node's own pose is empty, removed
  * by a layer mask on the node, and it makes the node's pose non-empty for the node's Position /
- * Rotation / Scale values too.  The applied values stay on the device; the shim reads them back
- * (and writes them through reflection) or feeds them to the skinning kernel directly. */
+ * Rotation / Scale values too.  The applied values stay on the device as f32 lanes + variant; the shim reads them
+ * back and writes them through reflection -- the numeric cast to the property's machine type (bool, integers, f64,
+ * vectors of those: value.rs:232-352) is the shim's, `as` conversions of the lanes -- or feeds them to the
+ * skinning kernel directly. */
+enum { FYX_VALUE_REAL = 0, FYX_VALUE_VEC2 = 1, FYX_VALUE_VEC3 = 2, FYX_VALUE_VEC4 = 3, FYX_VALUE_QUAT = 4 };  /* TrackValue variants */
+typedef struct fyx_property_value {
+    float value[4];      /* Real: [0]; Vector2/3/4: xy / xyz / xyzw; UnitQuaternion: i, j, k, w */
+    uint32_t present;    /* 0: no value (the other fields are then 0) */
+    uint32_t kind;       /* FYX_VALUE_* */
+    uint32_t reserved[2];
+} fyx_property_value;
 int fyx_animator_property_count(fyx_ctx* ctx, uint64_t animator_id, uint32_t* out_count);
 /* *out_slot = slot of (node, property id), or -1 when no animation drives it */
 int fyx_animator_property_slot(fyx_ctx* ctx, uint64_t animator_id, int32_t node, int32_t property_id,
                                int32_t* out_slot);
-/* host_out[n_instances][n_slots][2]: {value, flag as u32 bits}.  animation < 0: the values applied so
- * far (flag = the property has been written at least once); animation >= 0: that animation's current
- * pose (flag = the pose holds the value).  Synchronous. */
-int fyx_animator_read_properties(fyx_ctx* ctx, uint64_t animator_id, int32_t animation, float* host_out);
+/* host_out[n_instances][n_slots].  animation < 0: the values applied so far (present = the property has been
+ * written at least once); animation >= 0: that animation's current pose (present = the pose holds the value).
+ * Synchronous. */
+int fyx_animator_read_properties(fyx_ctx* ctx, uint64_t animator_id, int32_t animation, fyx_property_value* host_out);
 /* d_out[n_instances][n_shapes] = (applied value of slots[k], or default_weights[k] when slots[k] < 0 or
  * nothing has been applied yet) / 100 -- the `blend_shapes_weights` Mesh::collect_render_data hands to
  * the renderer (scene/mesh/mod.rs:794-798), ready for fyx_lbs_skin_ex.  slots / default_weights are

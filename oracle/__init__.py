@@ -417,7 +417,7 @@ class AnimScene:
         self.tracks = []
         self.anims = []
         self.machine = None
-        self.props = {}      # (node, property id) -> value applied last (Property{..} bindings of kind Real)
+        self.props = {}      # (node, property id) -> (variant, lanes) applied last (Property{..} bindings)
 
     def add_tracks_data(self, td) -> int:
         h = self.l.fo_tracks_new()
@@ -500,14 +500,18 @@ class AnimScene:
         self.l.fo_machine_set_parameter(self.machine, index, p.kind, f0, f1, u)
 
     def _pose_properties(self, pose_ptr) -> dict:
-        """{(node, property id): value} of the Real Property values a pose holds (first value per binding)."""
+        """{(node, property id): (TrackValue variant, its f32 lanes)} of the Property values a pose holds (first value per
+        binding, as BoundValueCollection's lookups find it)."""
         out = {}
         bv = _BoundValue()
+        lanes = {VAL_REAL: 1, VAL_VEC2: 2, VAL_VEC3: 3, VAL_VEC4: 4, VAL_QUAT: 4}
         for n in range(min(self.l.fo_pose_node_capacity(pose_ptr), self.n_nodes)):
             for i in range(self.l.fo_pose_value_count(pose_ptr, n)):
                 self.l.fo_pose_get_value(pose_ptr, n, i, byref(bv))
-                if bv.binding >= 3 and bv.kind == VAL_REAL and (n, bv.binding - 3) not in out:
-                    out[(n, bv.binding - 3)] = np.float32(bv.v[0])
+                if bv.binding >= 3 and (n, bv.binding - 3) not in out:
+                    v = np.zeros(4, np.float32)
+                    v[:lanes[bv.kind]] = np.asarray(bv.v[:lanes[bv.kind]], np.float32)
+                    out[(n, bv.binding - 3)] = (int(bv.kind), v)
         return out
 
     def _apply_properties(self, pose_ptr) -> None:   # value.rs:404-427: written through reflection

@@ -327,8 +327,69 @@ def morph_weights_player(n_bones=6, seed=synth.SEED_BASE + 15) -> Scenario:
     return sc
 
 
+def property_kinds(n_bones=10, seed=synth.SEED_BASE + 16, euler=False) -> Scenario:
+    """Property{..} tracks of every TrackValueKind (value.rs:221-230): Real, Vector2/3/4 and UnitQuaternion values under
+    the same blend tree / transition / masked layer as morph_weights.  Property 2 of node 4 is a Vector3 in clip 0 and a
+    Vector2 in clip 1 (different variants do not blend: the value of the pose that is blended INTO stays); property 3
+    is a quaternion in both (nlerp with the sign flip); with euler=True clip 1 drives it by Euler angles instead (the
+    same TrackValue variant after fetch, so the two still blend)."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    curves_of = {A.KIND_REAL: 1, A.KIND_VEC2: 2, A.KIND_VEC3: 3, A.KIND_VEC4: 4, A.KIND_QUAT: 4, A.KIND_QUAT_EULER: 3}
+
+    def prop_track(tag, prop, kind, key_kind=A.KEY_LINEAR, nk=9):
+        t = (np.arange(nk) / 8.0).astype(np.float32)
+        curves = []
+        for c in range(curves_of[kind]):
+            v = (synth.normal(seed, f"{tag}.{c}", nk) * np.float32(2.0)).astype(np.float32)
+            tan = (synth.normal(seed, f"{tag}.{c}.t", nk * 2).reshape(nk, 2) * 3).astype(np.float32)
+            curves.append(A.Curve([A.CurveKey(float(t[k]), float(v[k]), key_kind, float(tan[k, 0]), float(tan[k, 1])) for k in range(nk)]))
+        return A.Track(A.BIND_PROPERTY0 + prop, kind, curves)
+
+    plan = {
+        0: [(4, 0, A.KIND_REAL, A.KEY_CUBIC), (4, 1, A.KIND_VEC2, A.KEY_LINEAR), (4, 2, A.KIND_VEC3, A.KEY_LINEAR),
+            (4, 3, A.KIND_QUAT, A.KEY_LINEAR), (4, 4, A.KIND_VEC4, A.KEY_CONSTANT)],
+        1: [(4, 1, A.KIND_VEC2, A.KEY_CUBIC), (4, 2, A.KIND_VEC2, A.KEY_LINEAR),
+            (4, 3, A.KIND_QUAT_EULER if euler else A.KIND_QUAT, A.KEY_LINEAR), (4, 4, A.KIND_VEC4, A.KEY_LINEAR),
+            (4, 5, A.KIND_VEC3, A.KEY_LINEAR)],
+        2: [(7, 0, A.KIND_QUAT, A.KEY_CUBIC), (4, 0, A.KIND_REAL, A.KEY_LINEAR), (4, 4, A.KIND_VEC4, A.KEY_LINEAR),
+            (2, 6, A.KIND_VEC3, A.KEY_LINEAR)],
+    }
+    for c in range(3):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, n_keys=9, fps=8.0, euler_every=10 ** 9)
+        keep = (lambda b, t: b != 4) if c == 0 else (lambda b, t: b != 4 or t.binding == A.BIND_POSITION) if c == 1 else (lambda b, t: True)
+        td, tgt = _partial(td, tgt, keep)
+        tracks, target = list(td.tracks), list(tgt)
+        for node, prop, kind, kk in plan[c]:
+            tracks.append(prop_track(f"p{c}.{node}.{prop}", prop, kind, kk)); target.append(node)
+        tds.append(A.AnimationTracksData(tracks))
+        anims.append(AnimSpec(c, np.asarray(target, np.int32), speed=[1.0, 0.7, -1.1][c]))
+    base = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2),
+               A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, parameter=0)]),
+               A.BlendAnimations([A.BlendPose(2, 1.0), A.BlendPose(3, 0.6)])],
+        states=[A.State(3), A.State(4)],
+        transitions=[A.Transition(0, 1, 0.25, ("parameter", 1)), A.Transition(1, 0, 0.2, ("not", ("parameter", 1)))])
+    upper = A.MachineLayer(nodes=[A.PlayAnimation(1)], states=[A.State(0)], weight=0.4, mask=[7, 5])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_WEIGHT, 0.3), A.Parameter(A.PARAM_RULE, False)], layers=[base, upper])
+    script = {8: [(0, A.Parameter(A.PARAM_WEIGHT, 0.85))], 14: [(1, A.Parameter(A.PARAM_RULE, True))],
+              36: [(1, A.Parameter(A.PARAM_RULE, False))]}
+    return Scenario("property_kinds_euler" if euler else "property_kinds", rig, tds, anims, m, script, n_frames=56, dt=1.0 / 40.0,
+                    has_euler=euler)
+
+
+def property_kinds_euler() -> Scenario:
+    return property_kinds(euler=True)
+
+
+def property_kinds_player() -> Scenario:
+    sc = property_kinds()
+    sc.machine, sc.script, sc.name = None, {}, "property_kinds_player"
+    return sc
+
+
 ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like, morph_weights,
-       morph_weights_player]
+       morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player]
 
 
 def with_root_motion_and_signals(make) -> Callable[[], Scenario]:

@@ -251,11 +251,14 @@ def test_builder_validation(cctx):
     sc = cases.by_index()
     p = cases.build_product(cctx, sc)
     l, h = cctx._l, cctx._h
-    # unsupported: Property binding of a non-Real kind, mismatched kind, duplicate binding on a node
+    # Property bindings take every value kind (an unknown kind is an argument error); unsupported: a kind that does not
+    # fit a transform binding, duplicate binding on a node
     td = A.AnimationTracksData([A.Track(A.BIND_PROPERTY0 + 2, A.KIND_VEC3, [A.Curve([A.CurveKey(0, 1)])] * 3)])
+    A.upload_tracks_data(cctx, 1, td)
+    td = A.AnimationTracksData([A.Track(A.BIND_PROPERTY0 + 2, 9, [A.Curve([A.CurveKey(0, 1)])])])
     with pytest.raises(fyrox_amd.FyxError) as e:
         A.upload_tracks_data(cctx, 1, td)
-    assert e.value.code == _native.FYX_ERR_UNSUPPORTED
+    assert e.value.code == _native.FYX_ERR_INVALID_ARG
     real = [A.Curve([A.CurveKey(0, 1)])]
     td = A.AnimationTracksData([A.Track(A.BIND_PROPERTY0 + 2, A.KIND_REAL, real), A.Track(A.BIND_PROPERTY0 + 2, A.KIND_REAL, real)])
     A.upload_tracks_data(cctx, 2, td)

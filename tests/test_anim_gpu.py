@@ -96,7 +96,7 @@ def run_scenario(ctx, orc, sc, n_instances=1, frames=None, check_every=1):
 
 
 def check_properties(p, o, sc, exact, what):
-    """Property{..} slots: every animation's pose values (with their presence) and the values applied so far."""
+    """Property{..} slots: every animation's pose values (variant, lanes, presence) and the values applied so far."""
     slots = {}
     for node in range(sc.rig.n_nodes):
         for prop in range(8):
@@ -104,21 +104,28 @@ def check_properties(p, o, sc, exact, what):
             if s >= 0:
                 slots[(node, prop)] = s
     assert len(slots) == p.property_count() and sorted(slots.values()) == list(range(len(slots)))
+
+    def compare(rec, ref, ctx_):
+        kind, lanes = ref
+        assert int(rec["kind"]) == kind, f"{ctx_}: TrackValue variant"
+        assert np.all(rec["reserved"] == 0)
+        check(rec["value"], lanes, exact, ctx_)
+
     for a in range(len(sc.animations)):
         got, ref = p.read_properties(a), o.animation_properties(a)
         for i in (0, got.shape[0] - 1):
             for key, s in slots.items():
-                present = bool(got[i, s, 1].view(np.uint32))
+                present = bool(got[i, s]["present"])
                 assert present == (key in ref), f"{what}: animation {a} property {key} presence"
                 if present:
-                    check(got[i, s, 0:1], np.asarray([ref[key]], np.float32), exact, f"{what}: animation {a} property {key}")
+                    compare(got[i, s], ref[key], f"{what}: animation {a} property {key}")
     got = p.read_properties(-1)
     for i in (0, got.shape[0] - 1):
         for key, s in slots.items():
-            applied = bool(got[i, s, 1].view(np.uint32))
+            applied = bool(got[i, s]["present"])
             assert applied == (key in o.props), f"{what}: property {key} applied"
             if applied:
-                check(got[i, s, 0:1], np.asarray([o.props[key]], np.float32), exact, f"{what}: applied property {key}")
+                compare(got[i, s], o.props[key], f"{what}: applied property {key}")
 
 
 def check_root_motion(got, ref, exact, what):
@@ -373,7 +380,7 @@ def test_animated_morph_weights_drive_blend_shapes_into_a_vertex_buffer(ctx, orc
     d_w = ctx.malloc(n_inst * n_shapes * 4)
     p.blend_shape_weights(slots, defaults, d_w.ptr)
     got_w = d_w.download(np.float32, n_inst * n_shapes).reshape(n_inst, n_shapes)
-    ref_w = np.asarray([o.props.get((mesh_node, k), defaults[k]) for k in range(n_shapes)], np.float32) / np.float32(100.0)
+    ref_w = np.asarray([o.props[(mesh_node, k)][1][0] if (mesh_node, k) in o.props else defaults[k] for k in range(n_shapes)], np.float32) / np.float32(100.0)
     assert np.array_equal(got_w[0], ref_w) and np.array_equal(got_w[-1], ref_w)
     mesh = synth.make_mesh(5_003, 16, synth.SEED_BASE + 14, coherent=False)
     L = synth.ANIMATED_VERTEX
