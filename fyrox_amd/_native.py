@@ -155,6 +155,7 @@ _SIGS = {
     "fyx_lbs_skin_batch": (c_int, [_P, _P, c_uint32]),
     "fyx_lbs_skin_ex_batch": (c_int, [_P, _P, _P, c_uint32]),
     "fyx_scene_update": (c_int, [_P, _P, c_uint32, c_float]),
+    "fyx_scene_plan": (c_int, [_P, _P, c_uint32, c_float]),
     "fyx_comm_unique_id": (c_int, [_P, _P]),
     "fyx_comm_init": (c_int, [_P, _P, c_int, c_int]),
     "fyx_comm_shutdown": (c_int, [_P]),

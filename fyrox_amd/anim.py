@@ -523,6 +523,13 @@ def scene_update(ctx, animators: Sequence["Animator"], dt: float) -> None:
     ctx._check(ctx._l.fyx_scene_update(ctx._h, _ptr(ids) if len(ids) else None, len(ids), dt))
 
 
+def scene_plan(ctx, animators: Sequence["Animator"], dt: float) -> None:
+    """fyx_scene_plan: the host half of scene_update (works on a control-only context); read each animator's frame with
+    Animator.plan(-1, 0.0)."""
+    ids = np.asarray([a.id for a in animators], np.uint64)
+    ctx._check(ctx._l.fyx_scene_plan(ctx._h, _ptr(ids) if len(ids) else None, len(ids), dt))
+
+
 def upload_tracks_data(ctx, tracks_id: int, td: AnimationTracksData) -> None:
     descs, loc, val, kind, lt, rt = td.flatten()
     ctx._check(ctx._l.fyx_tracks_data_upload(ctx._h, tracks_id, len(td.tracks), descs, len(loc), _ptr(loc), _ptr(val),

@@ -790,12 +790,14 @@ public:
     // only splits crowds whose planning takes much longer than that.
     void run(unsigned n_tasks, const std::function<void(unsigned)>& fn) {
         if (n_tasks <= 1) { if (n_tasks) fn(0); return; }
-        { std::lock_guard<std::mutex> g(m_); fn_ = &fn; tasks_ = n_tasks; pending_ = n_tasks - 1; ++gen_; }
+        { std::lock_guard<std::mutex> g(m_); fn_ = &fn; tasks_ = n_tasks; pending_ = n_tasks - 1; failed_ = false; ++gen_; }
         cv_.notify_all();
-        fn(0);
+        bool threw = false;
+        try { fn(0); } catch (...) { threw = true; }   // the workers still hold &fn: wait for them before unwinding
         std::unique_lock<std::mutex> l(m_);
         done_.wait(l, [this] { return pending_ == 0; });
         fn_ = nullptr;
+        if (threw || failed_) throw std::bad_alloc();   // the only thing planning throws; the C ABI maps it to FYX_ERR_OOM
     }
 private:
     void loop(unsigned idx) {
@@ -810,8 +812,10 @@ private:
                 if (idx + 1 < tasks_) fn = fn_;
             }
             if (fn) {
-                (*fn)(idx + 1);
+                bool threw = false;
+                try { (*fn)(idx + 1); } catch (...) { threw = true; }   // nothing may unwind out of a worker thread
                 std::lock_guard<std::mutex> g(m_);
+                failed_ |= threw;
                 if (--pending_ == 0) done_.notify_one();
             }
         }
@@ -822,7 +826,7 @@ private:
     const std::function<void(unsigned)>* fn_ = nullptr;
     unsigned tasks_ = 0, pending_ = 0;
     uint64_t gen_ = 0;
-    bool stop_ = false;
+    bool stop_ = false, failed_ = false;
 };
 
 void plan_pool_destroy(PlanPool* p) { delete p; }
@@ -1199,10 +1203,10 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
 // animators on different host threads), the control blocks travel in ONE upload, and each stage of the frame is ONE
 // kernel launch over all of them.  Results are those of run_frame on each animator in turn: the animators share no
 // device state, and the kernels' bodies are the same functions.
-int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
+// Host control plane of a scene frame.  Crowds big enough to be split go first, one after another, each over the
+// whole pool; the rest are dealt out to the pool in contiguous runs of about equal instance counts.
+int scene_plan(fyx_ctx* c, SceneBatch& S, float dt) {
     const size_t n = S.animators.size();
-    // 1. host control plane.  Crowds big enough to be split go first, one after another, each over the whole pool;
-    //    the rest are dealt out to the pool in contiguous runs of about equal instance counts.
     S.errors.assign(n, 0);
     std::vector<size_t> small;
     uint64_t small_instances = 0;
@@ -1237,6 +1241,13 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     }
     for (size_t k = 0; k < n; ++k)
         if (S.errors[k]) return fail(c, S.errors[k], "animator %zu of the scene: pose nodes nest deeper than %d blend levels", k, kMaxFoldDepth - 2);
+    return FYX_OK;
+}
+
+int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
+    const size_t n = S.animators.size();
+    // 1. host control plane
+    if (int rc = scene_plan(c, S, dt)) return rc;
 
     // 2. device state, and the block tables if the scene's shape changed
     if (int rc = enter_primary(c)) return rc;
@@ -2043,13 +2054,8 @@ int fyx_absm_update(fyx_ctx* c, uint64_t animator_id, float dt) {
     FYX_GUARD_END(c)
 }
 
-int fyx_scene_update(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animators, float dt) {
-    if (!c) return FYX_ERR_INVALID_ARG;
-    FYX_GUARD_BEGIN
+static int scene_members(fyx_ctx* c, SceneBatch& S, const uint64_t* animator_ids, uint32_t n_animators) {
     if (n_animators && !animator_ids) return fail(c, FYX_ERR_INVALID_ARG, "null animator list");
-    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: no GPU to run the pose kernels on");
-    if (n_animators == 0) return FYX_OK;
-    SceneBatch& S = store(c).scene;
     S.animators.clear();
     std::unordered_set<uint64_t> seen;
     for (uint32_t k = 0; k < n_animators; ++k) {
@@ -2059,7 +2065,26 @@ int fyx_scene_update(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animat
             return fail(c, FYX_ERR_INVALID_ARG, "animator %llu is listed twice", (unsigned long long)animator_ids[k]);
         S.animators.push_back(it->second.get());
     }
+    return FYX_OK;
+}
+
+int fyx_scene_update(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animators, float dt) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: no GPU to run the pose kernels on");
+    SceneBatch& S = store(c).scene;
+    if (int rc = scene_members(c, S, animator_ids, n_animators)) return rc;
+    if (n_animators == 0) return FYX_OK;
     return scene_frame(c, S, dt);
+    FYX_GUARD_END(c)
+}
+
+int fyx_scene_plan(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animators, float dt) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    SceneBatch& S = store(c).scene;
+    if (int rc = scene_members(c, S, animator_ids, n_animators)) return rc;
+    return scene_plan(c, S, dt);
     FYX_GUARD_END(c)
 }
 
@@ -2184,9 +2209,11 @@ int fyx_animator_plan(fyx_ctx* c, uint64_t animator_id, int mode, float dt, floa
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     FYX_ANIMATOR(c, A, animator_id);
-    if (mode != 0 && mode != 1) return fail(c, FYX_ERR_INVALID_ARG, "mode %d", mode);
+    if (mode != 0 && mode != 1 && mode != -1) return fail(c, FYX_ERR_INVALID_ARG, "mode %d", mode);
     if (mode == 1 && A->layers.empty()) return fail(c, FYX_ERR_INVALID_ARG, "animator has no machine layers");
-    if (int rc = plan_frame(c, *A, mode, dt)) return rc;
+    if (mode >= 0) {
+        if (int rc = plan_frame(c, *A, mode, dt)) return rc;
+    }
     if (times) memcpy(times, A->times.data(), A->times.size() * 4);
     if (ticked) memcpy(ticked, A->ticked.data(), A->ticked.size());
     if (program_offset) memcpy(program_offset, A->prog_off.data(), A->prog_off.size() * 4);

@@ -593,6 +593,11 @@ int fyx_init_control_only(fyx_ctx** out_ctx);
 int fyx_animator_plan(fyx_ctx* ctx, uint64_t animator_id, int mode, float dt, float* times,
                       uint8_t* ticked, uint32_t* program_offset, uint32_t* ops,
                       uint32_t ops_capacity, uint32_t* n_ops);
+/* mode -1: do not advance anything, copy what was planned last (e.g. by fyx_scene_plan).
+ *
+ * The host half of fyx_scene_update: every listed animator is planned (machine mode where it has a machine) on
+ * the planner threads, nothing is sent to a GPU; read the results with fyx_animator_plan(.., mode -1, ..). */
+int fyx_scene_plan(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t n_animators, float dt);
 
 /* The root-motion program of the frame fyx_animator_plan planned last (mode 1, tracking on):
  * program_offset is [n_instances + 1]; ops are {opcode, dst slot, src slot | animation, f32

@@ -331,3 +331,51 @@ def test_threaded_crowd_planner_equals_the_serial_one():
     assert len(states) > 1, "the crowd should have diverged"
     for c in ctxs:
         c.close()
+
+
+def test_scene_planner_on_many_threads_equals_one_by_one_plans():
+    """fyx_scene_plan (the host half of fyx_scene_update): 70 animators of every scenario kind and different crowd sizes,
+    dealt out to the planner threads in runs -- one of them a crowd large enough to be split over the pool itself --
+    must produce for every animator exactly the frame fyx_animator_plan produces alone: programs, sample times,
+    root-motion programs, machine states, event queues."""
+    ctxs = [fyrox_amd.Context(control_only=True) for _ in range(2)]
+    ctxs[0].set_option("anim.threads", 1)
+    ctxs[1].set_option("anim.threads", 5)
+    ctxs[1].set_option("anim.split", 64)
+    makes = list(cases.ALL) + list(cases.ALL_RM) + [lambda s=s: cases.random_machine(s) for s in range(12)]
+    members = []
+    for k in range(70):
+        sc = makes[k % len(makes)]()
+        members.append((sc, 300 if k == 7 else 1 + (k * 7) % 11))
+    sets = [[cases.build_product(c, sc, n) for sc, n in members] for c in ctxs]
+    for ps in sets:
+        for (sc, n), p in zip(members, ps):
+            for i in range(n):
+                for a in range(len(sc.animations)):
+                    p.set_time_position(a, (i * 0.0137 + a * 0.31) % 0.5, instance=i)
+    dt = 1.0 / 50.0
+    for f in range(24):
+        for ps in sets:
+            for (sc, n), p in zip(members, ps):
+                for idx, par in sc.script.get(f, []):
+                    p.set_parameter(idx, par, instance=n // 2)
+        one_by_one = [p.plan(0 if sc.machine is None else 1, dt) for (sc, _), p in zip(members, sets[0])]
+        A.scene_plan(ctxs[1], sets[1], dt)
+        for k, ((sc, n), p0, p1) in enumerate(zip(members, sets[0], sets[1])):
+            got = p1.plan(-1, 0.0)
+            for key in ("times", "ticked", "offsets", "ops"):
+                assert np.array_equal(one_by_one[k][key], got[key]), (f, sc.name, key)
+            if sc.track_root_motion and sc.machine is not None:
+                r0, r1 = p0.plan_root_motion(), p1.plan_root_motion()
+                for key in ("offsets", "ops", "slices"):
+                    assert np.array_equal(r0[key], r1[key]), (f, sc.name, key)
+            for i in {0, n // 2, n - 1}:
+                if sc.machine is not None:
+                    for li in range(len(sc.machine.layers)):
+                        assert p0.layer_state(li, i) == p1.layer_state(li, i)
+                for a in range(len(sc.animations)):
+                    assert p0.event_count(a, i) == p1.event_count(a, i)
+    with pytest.raises(fyrox_amd.FyxError):
+        A.scene_plan(ctxs[1], [sets[1][0], sets[1][0]], dt)       # listed twice
+    for c in ctxs:
+        c.close()
