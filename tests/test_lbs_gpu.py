@@ -898,3 +898,46 @@ def test_ex_batch_validates_every_job_first(ctx):
     ctx.sync()
     assert np.all(buf.download(np.uint8, 300 * L["stride"]) == 0x11)      # the good job was not launched either
     ctx.lbs_skin_ex_batch([])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_batch_of_hundreds_of_tiny_meshes_equals_per_mesh_launches(ctx, seed):
+    """Workgroups whose unit range spans many segments (meshes of 1..200 vertices, so most segments are 1-3 units):
+    both batched kernels against the per-mesh launches, bit for bit, guard bytes behind every output."""
+    rng = np.random.default_rng(seed)
+    L = synth.ANIMATED_VERTEX
+    n_jobs = 300
+    jobs_soa, jobs_aos, singles = [], [], []
+    for k in range(n_jobs):
+        nv = int(rng.integers(1, 200)) if k % 17 else int(rng.integers(400, 3000))
+        nb = int(rng.integers(1, 40))
+        ni = int(rng.integers(1, 4))
+        m = synth.make_mesh(nv, nb, 9000 + seed * 1000 + k, coherent=bool(k % 2))
+        pal = ctx.to_device(synth.make_palette(nb, 9500 + k, n_instances=ni))
+        mid = 20_000 + k
+        upload(ctx, mid, m, aos=True)
+        bytes_soa = [nv * ni * 12, nv * ni * 12, nv * ni * 16]
+        a = [ctx.to_device(np.full(b + 32, 0xAB, np.uint8)) for b in bytes_soa]
+        b_ = [ctx.to_device(np.full(b + 32, 0xAB, np.uint8)) for b in bytes_soa]
+        va = ctx.to_device(np.full(nv * ni * L["stride"] + 32, 0xAB, np.uint8))
+        vb = ctx.to_device(np.full(nv * ni * L["stride"] + 32, 0xAB, np.uint8))
+        jobs_soa.append((mid, pal.ptr, nb, ni, a[0].ptr, a[1].ptr, a[2].ptr))
+        jobs_aos.append((mid, dict(d_palette=pal.ptr, n_bones=nb, n_instances=ni, d_out_vertices=va.ptr, out_stride=0)))
+        singles.append((mid, pal, nb, ni, a, b_, va, vb, bytes_soa, nv * ni * L["stride"]))
+    ctx.lbs_skin_batch(jobs_soa)
+    ctx.lbs_skin_ex_batch(jobs_aos)
+    for mid, pal, nb, ni, a, b_, va, vb, bytes_soa, bytes_aos in singles:
+        ctx.lbs_skin_device(mid, pal.ptr, nb, ni, b_[0].ptr, b_[1].ptr, b_[2].ptr)
+        ctx.lbs_skin_ex(mid, pal.ptr, nb, ni, d_out_vertices=vb.ptr, out_stride=0)
+    ctx.sync()
+    for mid, pal, nb, ni, a, b_, va, vb, bytes_soa, bytes_aos in singles:
+        for x, y, nbytes in zip(a, b_, bytes_soa):
+            gx, gy = x.download(np.uint8, nbytes + 32), y.download(np.uint8, nbytes + 32)
+            assert np.array_equal(gx, gy), f"mesh {mid}"
+            assert np.all(gx[-32:] == 0xAB)
+        gx, gy = va.download(np.uint8, bytes_aos + 32), vb.download(np.uint8, bytes_aos + 32)
+        assert np.array_equal(gx, gy), f"mesh {mid} (vertex buffer)"
+        assert np.all(gx[-32:] == 0xAB)
+        for d in [pal, va, vb] + a + b_:
+            d.free()
+        ctx.mesh_free(mid)
