@@ -21,7 +21,7 @@ BIND_PROPERTY0 = 3   # ValueBinding::Property{name, ..}: BIND_PROPERTY0 + id (Re
 KIND_REAL, KIND_VEC2, KIND_VEC3, KIND_VEC4, KIND_QUAT_EULER, KIND_QUAT = range(6)
 KEY_CONSTANT, KEY_LINEAR, KEY_CUBIC = 0, 1, 2
 PARAM_WEIGHT, PARAM_RULE, PARAM_INDEX, PARAM_SAMPLING_POINT = range(4)
-ACTION_NONE, ACTION_REWIND, ACTION_ENABLE, ACTION_DISABLE = range(4)
+ACTION_NONE, ACTION_REWIND, ACTION_ENABLE, ACTION_DISABLE, ACTION_ENABLE_RANDOM = range(5)   # ENABLE_RANDOM: (kind, [handles])
 LOGIC_PARAMETER, LOGIC_AND, LOGIC_OR, LOGIC_XOR, LOGIC_NOT, LOGIC_IS_ANIMATION_ENDED = range(6)
 ALL_INSTANCES = 0xFFFFFFFF
 READ_LOCAL_TRS, READ_LOCAL_MATRIX, READ_GLOBAL_MATRIX, READ_ANIMATION_POSE = 0, 1, 2, 16
@@ -392,6 +392,10 @@ class Animator:
         self._check(self._l.fyx_animator_property_slot(self._h, self.id, node, property_id, byref(out)))
         return out.value
 
+    def set_random_seed(self, seed: int, instance: int = ALL_INSTANCES) -> None:
+        """State of the EnableRandomAnimation generator: `seed` for one instance; for all, seed + (i + 1) * golden."""
+        self._check(self._l.fyx_animator_set_random_seed(self._h, self.id, instance, ctypes.c_uint64(seed & (2 ** 64 - 1))))
+
     def read_properties(self, animation: int = -1) -> np.ndarray:
         """(n_instances, n_slots) records of PROPERTY_VALUE (fyx_property_value): value[4], present, kind.
         animation < 0: applied values."""
@@ -442,10 +446,13 @@ class Animator:
                     raise TypeError(n)
             for si, s in enumerate(layer.states):
                 self._check(L.fyx_layer_add_state(self._h, self.id, li, s.root, None))
-                for kind, anim in s.on_enter_actions:
-                    self._check(L.fyx_state_add_action(self._h, self.id, li, si, 1, kind, anim))
-                for kind, anim in s.on_leave_actions:
-                    self._check(L.fyx_state_add_action(self._h, self.id, li, si, 0, kind, anim))
+                for on_enter, actions in ((1, s.on_enter_actions), (0, s.on_leave_actions)):
+                    for kind, anim in actions:
+                        if kind == ACTION_ENABLE_RANDOM:
+                            ch = np.asarray(anim, np.int64).astype(np.uint32)   # -1 = Handle::NONE -> an invalid index
+                            self._check(L.fyx_state_add_random_action(self._h, self.id, li, si, on_enter, _ptr(ch), len(ch)))
+                        else:
+                            self._check(L.fyx_state_add_action(self._h, self.id, li, si, on_enter, kind, anim))
             for t in layer.transitions:
                 code = _i32(encode_logic(t.condition))
                 self._check(L.fyx_layer_add_transition(self._h, self.id, li, t.source, t.dest, t.transition_time,

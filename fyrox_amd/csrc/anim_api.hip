@@ -108,7 +108,7 @@ struct PoseNodeDef {
     uint32_t by_index_slot = 0;      // index into per-instance ByIndex state
 };
 
-struct Action { int kind; uint32_t animation; };
+struct Action { int kind; uint32_t animation; std::vector<uint32_t> choices; };   // choices: EnableRandomAnimation's handles
 struct StateDef { int32_t root = -1; std::vector<Action> on_enter, on_leave; };
 struct TransitionDef { uint32_t source = 0, dest = 0; float time = 0.f; std::vector<int32_t> logic; };
 
@@ -165,6 +165,7 @@ struct Animator {
     std::vector<Param> param_defaults;
     std::vector<LayerDef> layers;
     std::vector<MachineState> mstate;   // [inst]
+    std::vector<uint64_t> rng;          // [inst] StateAction::EnableRandomAnimation's generator state (lazily sized)
     uint32_t max_tracks = 0;
     // device state
     AnimDev* d_anims = nullptr;
@@ -321,6 +322,25 @@ bool has_ended(const AnimState& s) { return !s.looped && fabsf(s.time - s.end) <
 // ------------------------------------------------------------------------------------------
 // Planner
 // ------------------------------------------------------------------------------------------
+// The generator behind StateAction::EnableRandomAnimation.  The reference draws from rand::thread_rng(), which no
+// one can reproduce; here every instance owns a splitmix64 stream (documented in fyrox_hip.h, restated by the oracle)
+// so that a run is repeatable and instances can be given the same or different streams.
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+inline uint64_t splitmix64(uint64_t& state) {
+    uint64_t z = (state += kGolden);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint32_t random_index(uint64_t& state, uint32_t n) {   // uniform in 0..n: the high word of draw * n
+    return (uint32_t)(((unsigned __int128)splitmix64(state) * n) >> 64);
+}
+void ensure_rng(Animator& A) {
+    if (A.rng.size() == A.n_instances) return;
+    A.rng.resize(A.n_instances);
+    for (uint32_t i = 0; i < A.n_instances; ++i) A.rng[i] = kGolden * (uint64_t)(i + 1);   // distinct default streams
+}
+
 struct Planner {
     Animator& A;
     PlanScratch& S;
@@ -625,6 +645,12 @@ struct Planner {
 
     void apply_actions(const std::vector<Action>& acts) {  // state.rs:48-80
         for (const Action& a : acts) {
+            if (a.kind == FYX_ACTION_ENABLE_RANDOM_ANIMATION) {   // state.rs:108-114: handles.iter().choose(rng), then enable
+                if (a.choices.empty()) continue;                  // choose() on an empty iterator: None, nothing drawn
+                const uint32_t pick = a.choices[random_index(A.rng[inst], (uint32_t)a.choices.size())];
+                if (pick < n_anims) as[pick].enabled = 1;
+                continue;
+            }
             if (a.animation >= n_anims) continue;
             AnimState& s = as[a.animation];
             switch (a.kind) {
@@ -764,6 +790,7 @@ void sync_machine_state(Animator& A) {
 }
 
 void ensure_machine_state(Animator& A) {
+    ensure_rng(A);
     if (A.mstate.size() == A.n_instances) return;
     A.mstate.assign(A.n_instances, MachineState());
     sync_machine_state(A);
@@ -1987,8 +2014,38 @@ int fyx_state_add_action(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint3
     FYX_LAYER(c, A, L, layer);
     if (state >= L->states.size()) return fail(c, FYX_ERR_INVALID_ARG, "state %u does not exist", state);
     if (action < FYX_ACTION_NONE || action > FYX_ACTION_DISABLE_ANIMATION)
-        return fail(c, FYX_ERR_UNSUPPORTED, "state action %d (EnableRandomAnimation draws from the host RNG)", action);
-    (on_enter ? L->states[state].on_enter : L->states[state].on_leave).push_back(Action{action, animation});
+        return fail(c, FYX_ERR_INVALID_ARG, "state action %d (EnableRandomAnimation has its own call)", action);
+    (on_enter ? L->states[state].on_enter : L->states[state].on_leave).push_back(Action{action, animation, {}});
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_state_add_random_action(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t state, int on_enter,
+                                const uint32_t* animations, uint32_t n_animations) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (state >= L->states.size()) return fail(c, FYX_ERR_INVALID_ARG, "state %u does not exist", state);
+    if (n_animations && !animations) return fail(c, FYX_ERR_INVALID_ARG, "animations is null");
+    Action a{FYX_ACTION_ENABLE_RANDOM_ANIMATION, 0, {}};
+    a.choices.assign(animations, animations + n_animations);
+    (on_enter ? L->states[state].on_enter : L->states[state].on_leave).push_back(std::move(a));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_set_random_seed(fyx_ctx* c, uint64_t animator_id, uint32_t instance, uint64_t seed) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    ensure_rng(*A);
+    if (instance == FYX_ALL_INSTANCES) {
+        for (uint32_t i = 0; i < A->n_instances; ++i) A->rng[i] = seed + kGolden * (uint64_t)(i + 1);
+        return FYX_OK;
+    }
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    A->rng[instance] = seed;
     return FYX_OK;
     FYX_GUARD_END(c)
 }

@@ -438,9 +438,9 @@ int fyx_animator_blend_shape_weights(fyx_ctx* ctx, uint64_t animator_id, uint32_
 /* ---- Machine (fyrox-animation/src/machine) ------------------------------------------- */
 /* Parameter (machine/parameter.rs:37-60) */
 enum { FYX_PARAM_WEIGHT = 0, FYX_PARAM_RULE = 1, FYX_PARAM_INDEX = 2, FYX_PARAM_SAMPLING_POINT = 3 };
-/* StateAction (machine/state.rs:62-80); EnableRandomAnimation needs the host's RNG: unsupported */
+/* StateAction (machine/state.rs:62-116) */
 enum { FYX_ACTION_NONE = 0, FYX_ACTION_REWIND_ANIMATION = 1, FYX_ACTION_ENABLE_ANIMATION = 2,
-       FYX_ACTION_DISABLE_ANIMATION = 3 };
+       FYX_ACTION_DISABLE_ANIMATION = 3, FYX_ACTION_ENABLE_RANDOM_ANIMATION = 4 /* fyx_state_add_random_action */ };
 /* LogicNode (machine/transition.rs:107-131), prefix encoded into an int array:
  * PARAMETER p | AND a b | OR a b | XOR a b | NOT a | IS_ANIMATION_ENDED animation */
 enum { FYX_LOGIC_PARAMETER = 0, FYX_LOGIC_AND = 1, FYX_LOGIC_OR = 2, FYX_LOGIC_XOR = 3,
@@ -483,6 +483,17 @@ int fyx_layer_add_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, int3
 int fyx_layer_set_entry_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t state);
 int fyx_state_add_action(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t state,
                          int on_enter, int action, uint32_t animation);
+/* StateAction::EnableRandomAnimation(handles) (state.rs:85, :108-114): one of `animations`, chosen uniformly, is
+ * enabled (an invalid handle chosen enables nothing; an empty list draws nothing).  The reference draws from
+ * rand::thread_rng(), which is not reproducible; this library gives every instance its own splitmix64 stream:
+ *     state += 0x9E3779B97F4A7C15; z = state; z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9;
+ *     z = (z ^ z >> 27) * 0x94D049BB133111EB; draw = z ^ z >> 31;   index = (draw * n) >> 64
+ * so a run can be repeated.  fyx_animator_set_random_seed sets an instance's state to `seed`; with
+ * FYX_ALL_INSTANCES instance i gets seed + (i + 1) * 0x9E3779B97F4A7C15 (distinct streams; with seed 0 that is
+ * the default). */
+int fyx_state_add_random_action(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t state, int on_enter,
+                                const uint32_t* animations, uint32_t n_animations);
+int fyx_animator_set_random_seed(fyx_ctx* ctx, uint64_t animator_id, uint32_t instance, uint64_t seed);
 /* Transition (machine/transition.rs:180-323) */
 int fyx_layer_add_transition(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t source,
                              uint32_t dest, float transition_time, const int32_t* condition,

@@ -343,6 +343,8 @@ def _alib():
             "fo_layer_add_blend_space": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
             "fo_layer_add_state": [c_void_p, c_int, c_int], "fo_layer_set_entry_state": [c_void_p, c_int, c_int],
             "fo_state_add_action": [c_void_p, c_int, c_int, c_int, c_int, c_int],
+            "fo_state_add_random_action": [c_void_p, c_int, c_int, c_int, c_void_p, c_int],
+            "fo_machine_set_random_state": [c_void_p, ctypes.c_uint64],
             "fo_layer_add_transition": [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int],
             "fo_layer_active_state": [c_void_p, c_int], "fo_layer_active_transition": [c_void_p, c_int],
             "fo_layer_pose": [c_void_p, c_int], "fo_machine_pose": [c_void_p],
@@ -484,16 +486,23 @@ class AnimScene:
                     raise TypeError(n)
             for si, s in enumerate(layer.states):
                 l.fo_layer_add_state(h, li, s.root)
-                for kind, anim in s.on_enter_actions:
-                    l.fo_state_add_action(h, li, si, 1, kind, anim)
-                for kind, anim in s.on_leave_actions:
-                    l.fo_state_add_action(h, li, si, 0, kind, anim)
+                for on_enter, actions in ((1, s.on_enter_actions), (0, s.on_leave_actions)):
+                    for kind, anim in actions:
+                        if kind == 4:   # EnableRandomAnimation: `anim` is the list of handles
+                            ch = np.asarray(anim, np.int32)
+                            l.fo_state_add_random_action(h, li, si, on_enter, _p(ch), len(ch))
+                        else:
+                            l.fo_state_add_action(h, li, si, on_enter, kind, anim)
             for t in layer.transitions:
                 code = np.asarray(_encode_logic(t.condition), np.int32)
                 l.fo_layer_add_transition(h, li, t.source, t.dest, t.transition_time, _p(code), len(code))
             if layer.entry_state is not None:
                 l.fo_layer_set_entry_state(h, li, layer.entry_state)
         self.machine = h
+
+    def set_random_state(self, state: int) -> None:
+        """The EnableRandomAnimation generator's state (the product's fyx_animator_set_random_seed for one instance)."""
+        self.l.fo_machine_set_random_state(self.machine, ctypes.c_uint64(state & (2 ** 64 - 1)))
 
     def set_parameter(self, index, p) -> None:
         f0, f1, u = p.packed()

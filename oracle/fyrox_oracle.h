@@ -186,7 +186,7 @@ int fo_animation_root_motion(const fo_animation*, float delta_position[3], float
 
 enum { FO_PARAM_WEIGHT = 0, FO_PARAM_RULE = 1, FO_PARAM_INDEX = 2, FO_PARAM_SAMPLING_POINT = 3 };
 enum { FO_NODE_PLAY = 0, FO_NODE_BLEND = 1, FO_NODE_BLEND_BY_INDEX = 2, FO_NODE_BLEND_SPACE = 3 };
-enum { FO_ACTION_NONE = 0, FO_ACTION_REWIND = 1, FO_ACTION_ENABLE = 2, FO_ACTION_DISABLE = 3 };
+enum { FO_ACTION_NONE = 0, FO_ACTION_REWIND = 1, FO_ACTION_ENABLE = 2, FO_ACTION_DISABLE = 3, FO_ACTION_ENABLE_RANDOM = 4 };
 /* LogicNode, prefix encoded: PARAM p | AND a b | OR a b | XOR a b | NOT a | IS_ANIMATION_ENDED anim */
 enum { FO_LOGIC_PARAM = 0, FO_LOGIC_AND = 1, FO_LOGIC_OR = 2, FO_LOGIC_XOR = 3, FO_LOGIC_NOT = 4,
        FO_LOGIC_IS_ANIMATION_ENDED = 5 };
@@ -215,6 +215,8 @@ int fo_layer_add_blend_space(fo_machine*, int layer, int sampling_param, int n_p
 int fo_layer_add_state(fo_machine*, int layer, int root_node);
 void fo_layer_set_entry_state(fo_machine*, int layer, int state);
 void fo_state_add_action(fo_machine*, int layer, int state, int on_enter, int kind, int animation);
+void fo_state_add_random_action(fo_machine*, int layer, int state, int on_enter, const int* animations, int n);
+void fo_machine_set_random_state(fo_machine*, uint64_t state);
 int fo_layer_add_transition(fo_machine*, int layer, int source, int dest, float time,
                             const int* logic, int n_logic);
 int fo_layer_pop_event(fo_machine*, int layer, int out[3]); /* 0 == None */

@@ -602,7 +602,7 @@ typedef struct fo_pose_node {
     fo_pose* output;
 } fo_pose_node;
 
-typedef struct fo_action { int kind; int animation; } fo_action;
+typedef struct fo_action { int kind; int animation; int n_choices; int* choices; } fo_action;
 typedef struct fo_state {
     int root;
     int n_enter, n_leave;
@@ -644,6 +644,7 @@ static void layer_push_event(fo_layer* L, int kind, int a, int b) {
 int fo_layer_pop_event(fo_machine* m, int layer, int out[3]);
 
 struct fo_machine {
+    uint64_t rng; /* StateAction::EnableRandomAnimation: see apply_actions */
     int n_params, n_layers;
     fo_param* params;
     fo_layer* layers;
@@ -664,7 +665,11 @@ void fo_machine_free(fo_machine* m) {
             free(L->nodes[i].inputs); free(L->nodes[i].points); free(L->nodes[i].tris);
             fo_pose_free(L->nodes[i].output);
         }
-        for (int i = 0; i < L->n_states; ++i) { free(L->states[i].enter); free(L->states[i].leave); }
+        for (int i = 0; i < L->n_states; ++i) {
+            for (int k = 0; k < L->states[i].n_enter; ++k) free(L->states[i].enter[k].choices);
+            for (int k = 0; k < L->states[i].n_leave; ++k) free(L->states[i].leave[k].choices);
+            free(L->states[i].enter); free(L->states[i].leave);
+        }
         for (int i = 0; i < L->n_transitions; ++i) free(L->transitions[i].logic);
         free(L->nodes); free(L->states); free(L->transitions); free(L->excluded); free(L->events);
         fo_pose_free(L->final_pose);
@@ -786,8 +791,22 @@ void fo_state_add_action(fo_machine* m, int layer, int state, int on_enter, int 
     *arr = (fo_action*)realloc(*arr, (size_t)(*cnt + 1) * sizeof(fo_action));
     (*arr)[*cnt].kind = kind;
     (*arr)[*cnt].animation = animation;
+    (*arr)[*cnt].n_choices = 0;
+    (*arr)[*cnt].choices = NULL;
     ++*cnt;
 }
+
+/* state.rs:85 StateAction::EnableRandomAnimation(Vec<Handle>) */
+void fo_state_add_random_action(fo_machine* m, int layer, int state, int on_enter, const int* animations, int n) {
+    fo_state_add_action(m, layer, state, on_enter, FO_ACTION_ENABLE_RANDOM, -1);
+    fo_state* s = &m->layers[layer].states[state];
+    fo_action* a = on_enter ? &s->enter[s->n_enter - 1] : &s->leave[s->n_leave - 1];
+    a->n_choices = n;
+    a->choices = (int*)malloc((size_t)(n ? n : 1) * sizeof(int));
+    if (n) memcpy(a->choices, animations, (size_t)n * sizeof(int));
+}
+
+void fo_machine_set_random_state(fo_machine* m, uint64_t state) { m->rng = state; }
 
 int fo_layer_add_transition(fo_machine* m, int layer, int source, int dest, float time,
                             const int* logic, int n_logic) {
@@ -1131,9 +1150,26 @@ static void node_collect(const fo_layer* L, int handle, unsigned char* seen, int
     for (int i = 0; i < n->n_inputs; ++i) node_collect(L, n->inputs[i].source, seen, n_anims);
 }
 
-/* state.rs:48-80 StateAction::apply */
-static void apply_actions(const fo_action* acts, int n, fo_animation* const* anims, int n_anims) {
+/* The reference's EnableRandomAnimation draws from rand::thread_rng() (state.rs:109), which cannot be restated: what
+ * is restated is everything around the draw (which handles, when, what an invalid or absent choice does) with the
+ * generator the product documents in fyrox_hip.h -- splitmix64, index = high word of draw * n. */
+static uint64_t splitmix64_next(uint64_t* state) {
+    uint64_t z = (*state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* state.rs:88-116 StateAction::apply */
+static void apply_actions(fo_machine* m, const fo_action* acts, int n, fo_animation* const* anims, int n_anims) {
     for (int i = 0; i < n; ++i) {
+        if (acts[i].kind == FO_ACTION_ENABLE_RANDOM) {
+            if (acts[i].n_choices <= 0) continue; /* choose() of an empty iterator: None */
+            const uint64_t draw = splitmix64_next(&m->rng);
+            const int pick = acts[i].choices[(uint32_t)(((unsigned __int128)draw * (uint32_t)acts[i].n_choices) >> 64)];
+            if (pick >= 0 && pick < n_anims && anims[pick]) fo_animation_set_enabled(anims[pick], 1);
+            continue;
+        }
         int a = acts[i].animation;
         if (a < 0 || a >= n_anims || !anims[a]) continue;
         switch (acts[i].kind) {
@@ -1159,10 +1195,10 @@ static const fo_pose* layer_evaluate(fo_machine* m, fo_layer* L, fo_animation* c
                 int pc = 0;
                 if (logic_eval(tr->logic, tr->n_logic, &pc, m, anims, n_anims)) {
                     if (L->active_state >= 0 && L->active_state < L->n_states)
-                        apply_actions(L->states[L->active_state].leave, L->states[L->active_state].n_leave, anims, n_anims);
+                        apply_actions(m, L->states[L->active_state].leave, L->states[L->active_state].n_leave, anims, n_anims);
                     layer_push_event(L, FO_EVENT_STATE_LEAVE, L->active_state, -1);      /* :620 */
                     if (tr->dest >= 0 && tr->dest < L->n_states)
-                        apply_actions(L->states[tr->dest].enter, L->states[tr->dest].n_enter, anims, n_anims);
+                        apply_actions(m, L->states[tr->dest].enter, L->states[tr->dest].n_enter, anims, n_anims);
                     layer_push_event(L, FO_EVENT_STATE_ENTER, tr->dest, -1);             /* :634 */
                     L->active_state = -1;
                     L->active_transition = t;

@@ -39,6 +39,7 @@ class Scenario:
     dt: float = 1.0 / 60.0
     has_euler: bool = True
     track_root_motion: bool = False   # compare AnimationPose::root_motion of animations / layers / machine too
+    random_seed: Optional[int] = None  # state of the EnableRandomAnimation generator (every instance gets the same)
 
 
 def _partial(td: A.AnimationTracksData, target: np.ndarray, keep: Callable[[int, A.Track], bool]):
@@ -388,8 +389,33 @@ def property_kinds_player() -> Scenario:
     return sc
 
 
+def random_attacks(n_bones=12, seed=synth.SEED_BASE + 17) -> Scenario:
+    """StateAction::EnableRandomAnimation (state.rs:85, :108-114): an idle state and an attack state whose root blends
+    three attack clips that are all disabled; entering `attack` enables one of them at random (and rewinds all three),
+    leaving it disables them again.  One list holds an invalid handle (chosen: nothing is enabled) and one action has
+    an empty list (nothing is drawn).  A rule parameter flips every few frames, so the generator is consulted many
+    times; which clip plays is visible in every pose."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(4):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, n_keys=9, fps=8.0, euler_every=10 ** 9)
+        tds.append(td)
+        anims.append(AnimSpec(c, tgt, speed=[1.0, 1.3, 0.8, 1.7][c], enabled=(c == 0), looped=(c == 0)))
+    layer = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2), A.PlayAnimation(3),
+               A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, 0.7), A.BlendPose(2, 0.7), A.BlendPose(3, 0.7)])],
+        states=[A.State(0),
+                A.State(4, on_enter_actions=[(A.ACTION_REWIND, 1), (A.ACTION_REWIND, 2), (A.ACTION_REWIND, 3),
+                                             (A.ACTION_ENABLE_RANDOM, []), (A.ACTION_ENABLE_RANDOM, [1, 2, 3, 99])],
+                        on_leave_actions=[(A.ACTION_DISABLE, 1), (A.ACTION_DISABLE, 2), (A.ACTION_DISABLE, 3)])],
+        transitions=[A.Transition(0, 1, 0.05, ("parameter", 0)), A.Transition(1, 0, 0.05, ("not", ("parameter", 0)))])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_RULE, False)], layers=[layer])
+    script = {f: [(0, A.Parameter(A.PARAM_RULE, (f // 6) % 2 == 0))] for f in range(2, 120, 6)}
+    return Scenario("random_attacks", rig, tds, anims, m, script, n_frames=120, dt=1.0 / 40.0, has_euler=False, random_seed=0x5EED1234)
+
+
 ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like, morph_weights,
-       morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player]
+       morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player, random_attacks]
 
 
 def with_root_motion_and_signals(make) -> Callable[[], Scenario]:
@@ -541,7 +567,16 @@ def random_machine(seed: int, n_bones: int = 7) -> Scenario:
             nodes.append(node)
             depth.append(1 + max([depth[s_] for s_ in srcs if s_ >= 0], default=0))
         n_states = int(rng.integers(1, 4))
-        acts = lambda: [(int(rng.integers(0, 4)), int(rng.integers(0, n_clips))) for _ in range(int(rng.integers(0, 3)))]
+        def acts():
+            out = []
+            for _ in range(int(rng.integers(0, 3))):
+                kind = int(rng.integers(0, 5))
+                if kind == A.ACTION_ENABLE_RANDOM:      # handles incl. invalid ones; sometimes an empty list
+                    out.append((kind, [int(x) for x in rng.integers(-1, n_clips + 1, int(rng.integers(0, 4)))]))
+                else:
+                    out.append((kind, int(rng.integers(0, n_clips))))
+            return out
+
         states = [A.State(int(rng.integers(0, len(nodes))), acts(), acts()) for _ in range(n_states)]
         trans = [A.Transition(int(rng.integers(0, n_states)), int(rng.integers(0, n_states)), f32(0.04 + rng.random() * 0.3), cond())
                  for _ in range(int(rng.integers(0, 5)))]
@@ -555,7 +590,8 @@ def random_machine(seed: int, n_bones: int = 7) -> Scenario:
             script[f] = [(int(rng.integers(0, n_params)), rand_param()) for _ in range(int(rng.integers(1, 3)))]
     return Scenario(f"random_machine[{seed}]", rig, tds, anims, A.Machine(parameters=params, layers=layers), script,
                     n_frames=n_frames, dt=f32(rng.choice([1 / 60, 1 / 24, 0.11])), has_euler=False,
-                    track_root_motion=any(a.root_motion is not None for a in anims) or bool(rng.integers(2)))
+                    track_root_motion=any(a.root_motion is not None for a in anims) or bool(rng.integers(2)),
+                    random_seed=seed * 7919 + 13)
 
 
 # ---- builders -------------------------------------------------------------------------------------
@@ -570,6 +606,8 @@ def build_oracle(orc, sc: Scenario):
                         max_event_capacity=a.max_event_capacity)
     if sc.machine is not None:
         s.set_machine(sc.machine)
+        if sc.random_seed is not None:
+            s.set_random_state(sc.random_seed)
     return s
 
 
@@ -596,5 +634,8 @@ def build_product(ctx, sc: Scenario, n_instances: int = 1) -> A.Animator:
         an.track_root_motion(True)
     if sc.machine is not None:
         an.set_machine(sc.machine)
+        if sc.random_seed is not None:       # the same stream for every instance: the tests compare them with ONE oracle
+            for i in range(n_instances):
+                an.set_random_seed(sc.random_seed, instance=i)
     an.base_id = base
     return an

@@ -311,3 +311,37 @@ def test_collect_active_animations_events_strategies(orc):
     assert s.collect_active_animations_events(0, A.EVENTS_MIN_WEIGHT)[1] == [(0, 0), (0, 1)]
     assert s.event_count(1) == 2                                       # a query: nothing was consumed
     s.close()
+
+
+def test_enable_random_animation_picks_one_handle_per_entry():
+    """StateAction::EnableRandomAnimation (state.rs:108-114), hand-derived expectations on the restatement: every entry
+    into the attack state enables AT MOST one of the listed clips (none when the invalid handle is drawn, none for the
+    empty list), leaving disables them, different entries pick different clips, and the choice depends on the
+    generator state only."""
+    import oracle as orc
+    from tests import anim_cases as cases
+
+    def run(seed):
+        sc = cases.random_attacks()
+        sc.random_seed = seed
+        o = cases.build_oracle(orc, sc)
+        picks, prev = [], False
+        for f in range(sc.n_frames):
+            for idx, par in sc.script.get(f, []):
+                o.set_parameter(idx, par)
+            o.update_machine(sc.dt)
+            en = [a for a in (1, 2, 3) if o.animation_state(a)["enabled"]]
+            assert len(en) <= 1
+            in_attack = o.layer_state(0) == (1, -1) or (o.layer_state(0)[1] == 0)
+            if in_attack and not prev:
+                picks.append(tuple(en))
+            prev = in_attack
+        o.close()
+        return picks
+
+    a, b, c = run(0x5EED1234), run(0x5EED1234), run(99)
+    assert a == b, "same generator state, same choices"
+    assert len(a) >= 8
+    assert len({p for p in a if p}) >= 2, "several different clips were picked"
+    assert a != c, "another stream picks differently"
+    assert () in a + c + run(7) + run(8), "the invalid handle was drawn at least once: nothing enabled"
