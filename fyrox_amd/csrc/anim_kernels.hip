@@ -1002,9 +1002,37 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     float* l_global = lds + (size_t)rig.n_nodes * 16;   // [n_nodes][16]
     const size_t inst_base = (size_t)inst * rig.n_nodes;
 
+    // Everything that does not depend on the fold is requested FIRST, so that its (cold) latency runs under the
+    // fold's chain of dependent loads instead of after it: what this thread will do in the hierarchy walk (its <= 4
+    // entries of the depth-sorted node list: node, level, parent -- so a level of the walk costs LDS traffic and a
+    // barrier only) and, per node, the 112 bytes of the rig's static transform parts.
+    constexpr int kEntries = kMaxRigNodes / 256;   // launch_pose_update: block = min(256, n_nodes rounded up to 64)
+    uint32_t w_node[kEntries], w_level[kEntries];
+    int32_t w_par[kEntries];
+#pragma unroll
+    for (int k = 0; k < kEntries; ++k) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
+        w_level[k] = 0xffffffffu;
+        w_node[k] = 0;
+        w_par[k] = -1;
+        if (i < rig.n_nodes) {
+            w_node[k] = rig.level_nodes[i];
+            w_level[k] = rig.node_level[w_node[k]];
+            w_par[k] = rig.parent[w_node[k]];
+        }
+    }
     for (uint32_t node = threadIdx.x; node < rig.n_nodes; node += blockDim.x) {
         f4* trs = reinterpret_cast<f4*>(f.node_trs) + (inst_base + node) * 3;
         const f4 t0 = trs[0], t1 = trs[1], t2 = trs[2];
+        float st[28];
+        {
+            const f4* sp = reinterpret_cast<const f4*>(rig.statics + (size_t)node * 28);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const f4 v = sp[q];
+                st[q * 4] = v.x; st[q * 4 + 1] = v.y; st[q * 4 + 2] = v.z; st[q * 4 + 3] = v.w;
+            }
+        }
         FoldCtx cx;
         cx.tpx = t0.x; cx.tpy = t0.y; cx.tpz = t0.z;
         cx.tr = t1;
@@ -1033,7 +1061,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             }
         }
         float m[16];
-        local_matrix(rig.statics + (size_t)node * 28, cx.tpx, cx.tpy, cx.tpz, cx.tr, cx.tsx, cx.tsy, cx.tsz, m);
+        local_matrix(st, cx.tpx, cx.tpy, cx.tpz, cx.tr, cx.tsx, cx.tsy, cx.tsz, m);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             reinterpret_cast<f4*>(l_local + (size_t)node * 16)[c] = f4{m[c * 4], m[c * 4 + 1], m[c * 4 + 2], m[c * 4 + 3]};
@@ -1041,24 +1069,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     __syncthreads();
 
     // level-synchronous global = parent.global * local; a root multiplies by the identity, as
-    // the reference does for a node without a valid parent.
-    // What each thread will do in the walk is fetched up front (its <= 4 entries of the depth-sorted node list: node,
-    // parent, level), so a level costs LDS traffic and a barrier only -- no global load sits inside the walk.
-    constexpr int kEntries = kMaxRigNodes / 256;   // launch_pose_update: block = min(256, n_nodes rounded up to 64)
-    uint32_t w_node[kEntries], w_level[kEntries];
-    int32_t w_par[kEntries];
-#pragma unroll
-    for (int k = 0; k < kEntries; ++k) {
-        const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
-        w_level[k] = 0xffffffffu;
-        w_node[k] = 0;
-        w_par[k] = -1;
-        if (i < rig.n_nodes) {
-            w_node[k] = rig.level_nodes[i];
-            w_level[k] = rig.node_level[w_node[k]];
-            w_par[k] = rig.parent[w_node[k]];
-        }
-    }
+    // the reference does for a node without a valid parent.  What each thread does in the walk was fetched at the top.
     for (uint32_t lv = 0; lv < rig.n_levels; ++lv) {
 #pragma unroll
         for (int k = 0; k < kEntries; ++k) {
@@ -1095,23 +1106,25 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     }
     // Registered palettes (Surface::bones of the meshes this rig drives): bone_matrices[b] = global(bone_b) *
     // inv_bind(bone_b) (scene/mesh/mod.rs:781-793) straight from the matrices still in LDS -- no separate gather
-    // launch, no re-read of the global matrices.  One thread per output element, nalgebra's column-axpy order.
+    // launch, no re-read of the global matrices.  One thread per output COLUMN (four 16-byte LDS reads, one 16-byte
+    // load of inv_bind's column, one 16-byte store), nalgebra's column-axpy order per component.
     for (uint32_t p = 0; p < rig.n_pal; ++p) {
         const PaletteOutDev po = rig.pal[p];
-        float* out = po.out + (size_t)inst * po.n_bones * 16;
-        for (uint32_t e = threadIdx.x; e < po.n_bones * 16; e += blockDim.x) {
-            const uint32_t i = e & 3, j = (e >> 2) & 3, b = e >> 4;
+        f4* out = reinterpret_cast<f4*>(po.out + (size_t)inst * po.n_bones * 16);
+        for (uint32_t e = threadIdx.x; e < po.n_bones * 4; e += blockDim.x) {
+            const uint32_t j = e & 3, b = e >> 2;
             const int32_t node = po.bone_nodes[b];
-            float y;
+            f4 y;
             if (node < 0) {
-                y = (i == j) ? 1.0f : 0.0f;
+                y = f4{j == 0 ? 1.0f : 0.0f, j == 1 ? 1.0f : 0.0f, j == 2 ? 1.0f : 0.0f, j == 3 ? 1.0f : 0.0f};
             } else {
-                const float* a = l_global + (size_t)node * 16;
-                const float* bb = rig.inv_bind + (size_t)node * 16;
-                y = a[i] * bb[j * 4];
-                y = a[4 + i] * bb[j * 4 + 1] + y;
-                y = a[8 + i] * bb[j * 4 + 2] + y;
-                y = a[12 + i] * bb[j * 4 + 3] + y;
+                const f4 bb = reinterpret_cast<const f4*>(rig.inv_bind)[(size_t)node * 4 + j];
+                const f4* a = reinterpret_cast<const f4*>(l_global) + (size_t)node * 4;
+                const f4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+                y.x = a0.x * bb.x; y.x = a1.x * bb.y + y.x; y.x = a2.x * bb.z + y.x; y.x = a3.x * bb.w + y.x;
+                y.y = a0.y * bb.x; y.y = a1.y * bb.y + y.y; y.y = a2.y * bb.z + y.y; y.y = a3.y * bb.w + y.y;
+                y.z = a0.z * bb.x; y.z = a1.z * bb.y + y.z; y.z = a2.z * bb.z + y.z; y.z = a3.z * bb.w + y.z;
+                y.w = a0.w * bb.x; y.w = a1.w * bb.y + y.w; y.w = a2.w * bb.z + y.w; y.w = a3.w * bb.w + y.w;
             }
             out[e] = y;
         }

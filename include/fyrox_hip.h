@@ -553,7 +553,8 @@ int fyx_animator_palette(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, 
 /* The same palette, written by the update calls themselves: after fyx_animation_player_update /
  * fyx_absm_update / fyx_animator_update_transforms the buffer holds the frame's palettes (the matrices are
  * multiplied while still on chip; no extra launch).  d_out_palette = NULL unregisters.  At most 4 outputs per
- * animator (one per skinned surface of the model, typically 1); the bone list must stay registered. */
+ * animator (one per skinned surface of the model, typically 1); the bone list must stay registered; the buffer
+ * must be 16-byte aligned (matrix columns are stored as 16-byte words). */
 int fyx_animator_set_palette_output(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, float* d_out_palette);
 
 /* Transform::set_position / set_rotation / set_scale of one node for a range of instances
