@@ -60,8 +60,9 @@ __device__ __forceinline__ float interpolate_keys(const float* __restrict__ loc,
 // Curve::value_at with the caller's span hint (curve.rs:254-314).
 // A sample is a chain of dependent loads, and this kernel is bound by that latency, not by bytes: everything the
 // common outcomes need -- the first and last key (clamping) and the two keys of the hinted span -- is therefore
-// fetched in ONE round trip right after the hint is known (eight independent loads), and only a hint miss pays
-// for the binary search.  The decisions are taken in the reference's order on the same values.
+// fetched in ONE round trip right after the hint is known (eight independent loads); a hint that is off by one
+// span costs one more round trip, and only a hint further off pays for the binary search.  The decisions are taken
+// in the reference's order on the same values.
 struct CurveKeys {   // the eight values the common outcomes of value_at need, fetched in one round trip
     float l_first, l_last, l_hl, l_h;
     f4 a_first, a_last, a_hl, a_h;
@@ -78,6 +79,10 @@ __device__ __forceinline__ CurveKeys curve_fetch(const float* __restrict__ loc, 
 }
 
 // The decisions of value_at, in the reference's order, on values fetched earlier.
+// NEIGHBOURS: resolve a hint that is off by one span without the binary search (one extra round trip instead of
+// ~five).  Worth it where a round trip is a cold HBM access (many animators with their own key data: -5 %); on a
+// crowd, whose few curves sit in L2 and whose bound is the number of memory instructions, it measured 6 % slower.
+template <bool NEIGHBOURS>
 __device__ __forceinline__ float curve_eval(const CurveKeys& k, const float* __restrict__ loc, const f4* __restrict__ aux,
                                             uint32_t n, float location, uint32_t& hint) {
     if (n == 0) return 0.0f;
@@ -86,6 +91,28 @@ __device__ __forceinline__ float curve_eval(const CurveKeys& k, const float* __r
     if (location >= k.l_last) { hint = n - 1; return k.a_last.x; }
     if (h < n) {
         if (location >= k.l_hl && location < k.l_h) return interpolate_loaded(k.l_hl, k.l_h, k.a_hl, k.a_h, location);
+        // The hint missed.  The reference now runs partition_point(|k| k.location < location) = the first key at or
+        // after `location`.  Keys are sorted, so if key i - 1 lies before `location` and key i at or after it, that
+        // index IS i -- no search needed.  Playback is continuous (curve.rs:293-297 has this as a TODO): i is almost
+        // always the hinted index itself (location sits exactly on its right key), the next one (forward playback
+        // crossed a key) or the previous one (reverse playback).  Same hint, same two keys, same arithmetic.
+        if (h >= 1 && k.l_hl < location && location <= k.l_h)
+            return interpolate_loaded(k.l_hl, k.l_h, k.a_hl, k.a_h, location);                       // i == h
+        if constexpr (NEIGHBOURS) {
+            if (h + 1 < n && k.l_h < location) {
+                const float l_n = loc[h + 1];
+                if (location <= l_n) {
+                    hint = h + 1;
+                    return interpolate_loaded(k.l_h, l_n, k.a_h, aux[h + 1], location);              // i == h + 1
+                }
+            } else if (h >= 2 && location <= k.l_hl) {
+                const float l_p = loc[h - 2];
+                if (l_p < location) {
+                    hint = h - 1;
+                    return interpolate_loaded(l_p, k.l_hl, aux[h - 2], k.a_hl, location);            // i == h - 1
+                }
+            }
+        }
     }
     uint32_t lo = 0, hi = n;  // partition_point(|k| k.location < location)
     while (lo < hi) {
@@ -96,11 +123,12 @@ __device__ __forceinline__ float curve_eval(const CurveKeys& k, const float* __r
     return interpolate_keys(loc, aux, lo > 0 ? lo - 1 : 0, lo, location);
 }
 
+template <bool NEIGHBOURS = true>
 __device__ float curve_value_at(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
                                 float location, uint32_t& hint) {
     if (n == 0) return 0.0f;
     const CurveKeys k = curve_fetch(loc, aux, n, hint);
-    return curve_eval(k, loc, aux, n, location, hint);
+    return curve_eval<NEIGHBOURS>(k, loc, aux, n, location, hint);
 }
 
 // Span hint of (animation a, track, curve c, instance): Curve::value_at's `&mut usize`.
@@ -291,7 +319,7 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
             uint32_t hint = *hp;
             const uint32_t h0 = hint;
             const uint32_t fk = tk->first_key[c];
-            val[c] = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], time, hint);
+            val[c] = curve_value_at<false>(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], time, hint);
             if (hint != h0) *hp = hint;
         }
     }
