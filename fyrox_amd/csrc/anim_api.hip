@@ -1469,9 +1469,14 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
             hd[t].kind = tracks[t].kind;
             hd[t].n_curves = tracks[t].n_curves;
             for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t nk = k < tracks[t].n_curves ? tracks[t].curve_n_keys[k] : 0;
                 hd[t].first_key[k] = key;
-                hd[t].n_keys[k] = k < tracks[t].n_curves ? tracks[t].curve_n_keys[k] : 0;
-                key += hd[t].n_keys[k];
+                hd[t].n_keys[k] = nk;
+                hd[t].first_loc[k] = nk ? key_location[key] : 0.f;
+                hd[t].last_loc[k] = nk ? key_location[key + nk - 1] : 0.f;
+                hd[t].first_val[k] = nk ? key_value[key] : 0.f;
+                hd[t].last_val[k] = nk ? key_value[key + nk - 1] : 0.f;
+                key += nk;
             }
         }
         std::vector<float4> aux(n_keys);

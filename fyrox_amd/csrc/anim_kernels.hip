@@ -58,23 +58,28 @@ __device__ __forceinline__ float interpolate_keys(const float* __restrict__ loc,
 }
 
 // Curve::value_at with the caller's span hint (curve.rs:254-314).
-// A sample is a chain of dependent loads, and this kernel is bound by that latency, not by bytes: everything the
-// common outcomes need -- the first and last key (clamping) and the two keys of the hinted span -- is therefore
-// fetched in ONE round trip right after the hint is known (eight independent loads); a hint that is off by one
-// span costs one more round trip, and only a hint further off pays for the binary search.  The decisions are taken
-// in the reference's order on the same values.
-struct CurveKeys {   // the eight values the common outcomes of value_at need, fetched in one round trip
-    float l_first, l_last, l_hl, l_h;
-    f4 a_first, a_last, a_hl, a_h;
+// A sample is a chain of dependent loads, and this kernel is bound by that latency and by the number of cache lines
+// it touches, not by bytes: the first and last key (clamping) come with the track record (TrackDev, one line per
+// track), the two keys of the hinted span are fetched in ONE round trip right after the hint is known (four
+// independent loads); a hint that is off by one span costs one more round trip, and only a hint further off pays
+// for the binary search.  The decisions are taken in the reference's order on the same values.
+struct CurveEnds { float l_first, l_last, v_first, v_last; };   // first / last key of the curve: location, value
+struct CurveKeys {   // the two keys of the hinted span
+    float l_hl, l_h;
+    f4 a_hl, a_h;
 };
+
+__device__ __forceinline__ CurveEnds curve_ends(const TrackDev* tk, int c) {
+    return CurveEnds{tk->first_loc[c], tk->last_loc[c], tk->first_val[c], tk->last_val[c]};
+}
 
 __device__ __forceinline__ CurveKeys curve_fetch(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
                                                  uint32_t h) {
     CurveKeys k;
     const uint32_t nn = n ? n : 1;                                    // an empty curve reads key 0 of its successor, unused
     const uint32_t hc = h < nn ? h : nn - 1, hl = hc > 0 ? hc - 1 : 0;   // clamped: addresses stay inside the curve
-    k.l_first = loc[0]; k.l_last = loc[nn - 1]; k.l_hl = loc[hl]; k.l_h = loc[hc];
-    k.a_first = aux[0]; k.a_last = aux[nn - 1]; k.a_hl = aux[hl]; k.a_h = aux[hc];
+    k.l_hl = loc[hl]; k.l_h = loc[hc];
+    k.a_hl = aux[hl]; k.a_h = aux[hc];
     return k;
 }
 
@@ -83,12 +88,12 @@ __device__ __forceinline__ CurveKeys curve_fetch(const float* __restrict__ loc, 
 // ~five).  Worth it where a round trip is a cold HBM access (many animators with their own key data: -5 %); on a
 // crowd, whose few curves sit in L2 and whose bound is the number of memory instructions, it measured 6 % slower.
 template <bool NEIGHBOURS>
-__device__ __forceinline__ float curve_eval(const CurveKeys& k, const float* __restrict__ loc, const f4* __restrict__ aux,
-                                            uint32_t n, float location, uint32_t& hint) {
+__device__ __forceinline__ float curve_eval(const CurveKeys& k, const CurveEnds& e, const float* __restrict__ loc,
+                                            const f4* __restrict__ aux, uint32_t n, float location, uint32_t& hint) {
     if (n == 0) return 0.0f;
     const uint32_t h = hint;
-    if (location <= k.l_first) { hint = 0; return k.a_first.x; }
-    if (location >= k.l_last) { hint = n - 1; return k.a_last.x; }
+    if (location <= e.l_first) { hint = 0; return e.v_first; }
+    if (location >= e.l_last) { hint = n - 1; return e.v_last; }
     if (h < n) {
         if (location >= k.l_hl && location < k.l_h) return interpolate_loaded(k.l_hl, k.l_h, k.a_hl, k.a_h, location);
         // The hint missed.  The reference now runs partition_point(|k| k.location < location) = the first key at or
@@ -124,11 +129,11 @@ __device__ __forceinline__ float curve_eval(const CurveKeys& k, const float* __r
 }
 
 template <bool NEIGHBOURS = true>
-__device__ float curve_value_at(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
+__device__ float curve_value_at(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n, const CurveEnds& ends,
                                 float location, uint32_t& hint) {
     if (n == 0) return 0.0f;
     const CurveKeys k = curve_fetch(loc, aux, n, hint);
-    return curve_eval<NEIGHBOURS>(k, loc, aux, n, location, hint);
+    return curve_eval<NEIGHBOURS>(k, ends, loc, aux, n, location, hint);
 }
 
 // Span hint of (animation a, track, curve c, instance): Curve::value_at's `&mut usize`.
@@ -233,7 +238,7 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
                 uint32_t hint = *hp;
                 const uint32_t fk = tk->first_key[c];
                 v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c],
-                                   time, hint);
+                                   curve_ends(tk, (int)c), time, hint);
                 *hp = hint;
             }
         }
@@ -312,15 +317,18 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
         const int32_t track = st[bind];
         const TrackDev* tk = an.tracks + track;
         const int need = kinds[bind] == FYX_KIND_QUAT ? 4 : 3;
+        // the hints of the track's curves are independent of each other: one round trip for all of them
+        uint32_t h0[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < need) h0[c] = *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c >= need) break;
-            uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
-            uint32_t hint = *hp;
-            const uint32_t h0 = hint;
+            uint32_t hint = h0[c];
             const uint32_t fk = tk->first_key[c];
-            val[c] = curve_value_at<false>(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], time, hint);
-            if (hint != h0) *hp = hint;
+            val[c] = curve_value_at<false>(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], curve_ends(tk, c), time, hint);
+            if (hint != h0[c]) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = hint;
         }
     }
     f4* rec = reinterpret_cast<f4*>(f.anim_pose) + (((size_t)a * f.n_instances + inst) * f.n_nodes + node) * 3;
@@ -413,7 +421,7 @@ __device__ __forceinline__ void root_motion_body(const PoseFrameDev& f, uint32_t
             if (valid && c < need) {
                 uint32_t hint = 0;
                 const uint32_t fk = tk->first_key[c];
-                v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], time, hint);
+                v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], curve_ends(tk, c), time, hint);
             }
         }
         const int sub = (int)(gbase + half * 8u);
@@ -743,7 +751,7 @@ __device__ __forceinline__ void property_sample_body(const PoseFrameDev& f, uint
                 uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
                 uint32_t hint = *hp;
                 const uint32_t fk = tk->first_key[c];
-                val[c] = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], time, hint);
+                val[c] = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], curve_ends(tk, c), time, hint);
                 *hp = hint;
             }
             if (kind == FYX_KIND_QUAT) {

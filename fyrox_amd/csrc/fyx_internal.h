@@ -150,12 +150,17 @@ constexpr int kMaxRigNodes = 1024;   // local+global matrices of one instance li
 constexpr int kMaxFoldDepth = 8;     // nested pose accumulators held in VGPRs
 
 // One track of an AnimationTracksData: TrackValueKind + up to four curves (key ranges).
-struct TrackDev {
+// The first and last key of every curve ride along: Curve::value_at clamps against them on every sample, and here
+// they come with the cache line the sample reads anyway instead of from four more lines of the key arrays.
+struct alignas(128) TrackDev {
     int32_t kind;            // FYX_KIND_*
     uint32_t n_curves;
     uint32_t first_key[4];
     uint32_t n_keys[4];
+    float first_loc[4], last_loc[4];   // location of each curve's first / last key (0 for an empty curve)
+    float first_val[4], last_val[4];   // and their values
 };
+static_assert(sizeof(TrackDev) == 128, "one cache line per track");
 
 // One animation of an animator (shared by all its instances).
 struct AnimDev {
