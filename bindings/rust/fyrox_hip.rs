@@ -184,6 +184,27 @@ pub struct HipAnimator<'a> {
     pub signal_names: Vec<Vec<(crate::core::uuid::Uuid, String)>>,
 }
 
+/// One `Property{..}` value as it comes back from `fyx_animator_read_properties`: the f32 lanes and the `TrackValue`
+/// variant.  Re-wrapped into the engine's own `TrackValue`, so the numeric cast to the property's `ValueType`
+/// (`TrackValue::apply_to_any`, `fyrox-animation/src/value.rs:234-352`) and the write through reflection
+/// (`BoundValue::apply_to_object`, `value.rs:404-427`) are the engine's unchanged code.
+pub fn track_value(v: &FyxPropertyValue) -> Option<crate::generic_animation::value::TrackValue> {
+    use crate::core::algebra::{Quaternion, Vector2, Vector4};
+    use crate::generic_animation::value::TrackValue;
+    if v.present == 0 {
+        return None;
+    }
+    let l = v.value;
+    Some(match v.kind as i32 {
+        FYX_VALUE_REAL => TrackValue::Real(l[0]),
+        FYX_VALUE_VEC2 => TrackValue::Vector2(Vector2::new(l[0], l[1])),
+        FYX_VALUE_VEC3 => TrackValue::Vector3(Vector3::new(l[0], l[1], l[2])),
+        FYX_VALUE_VEC4 => TrackValue::Vector4(Vector4::new(l[0], l[1], l[2], l[3])),
+        // lanes are (i, j, k, w); the library returns unit quaternions
+        _ => TrackValue::UnitQuaternion(UnitQuaternion::new_unchecked(Quaternion::new(l[3], l[0], l[1], l[2]))),
+    })
+}
+
 /// `Option<RootMotion>` as scripts read it (`fyrox-animation/src/lib.rs:325-336`).
 pub struct HipRootMotion {
     pub delta_position: Vector3<f32>,
