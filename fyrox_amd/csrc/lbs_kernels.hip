@@ -1046,25 +1046,27 @@ __global__ __launch_bounds__(kAosBlock) void lbs_skin_aos_batch(const LbsExSegDe
     }
 }
 
-// persistent grid = exactly what is resident (registers and LDS decide); asked once per LDS size, not per launch
-// (per host thread: a fyx_ctx is single-threaded; every context runs the same code object)
+// persistent grid = exactly what is resident (registers and LDS decide); asked once per (kernel, LDS size), not per
+// launch (per host thread: a fyx_ctx is single-threaded; every context runs the same code object)
 template <typename K>
 static hipError_t aos_blocks_per_cu(K kernel, size_t lds, int* per_cu) {
-    static thread_local size_t cached_lds = ~size_t(0);
-    static thread_local int cached_per_cu = 0;
-    if (lds != cached_lds) {
-        const void* fn = reinterpret_cast<const void*>(kernel);
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        int q = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, kAosBlock, lds);
+    struct Entry { const void* fn; size_t lds; int per_cu; };
+    constexpr int kEntries = 16;
+    static thread_local Entry cache[kEntries] = {};
+    static thread_local int next = 0;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    for (const Entry& e : cache)
+        if (e.fn == fn && e.lds == lds) { *per_cu = e.per_cu; return hipSuccess; }
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        cached_per_cu = q < 1 ? 1 : q;
-        cached_lds = lds;
     }
-    *per_cu = cached_per_cu;
+    int q = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, kAosBlock, lds);
+    if (e != hipSuccess) return e;
+    cache[next] = Entry{fn, lds, q < 1 ? 1 : q};
+    next = (next + 1) % kEntries;
+    *per_cu = q < 1 ? 1 : q;
     return hipSuccess;
 }
 
