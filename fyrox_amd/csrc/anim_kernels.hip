@@ -643,6 +643,8 @@ __device__ __forceinline__ void blend(Acc& self, const Acc& o, float w) {
 
 struct FoldCtx {
     const uint2* __restrict__ ops;
+    uint2 my_op;                          // op `lane` of the program (END beyond its end): ops 0..63 come from registers
+    uint32_t n_ops;
     const f4* __restrict__ anim_pose;     // base of [n_anims][n_instances][n_nodes][3]
     const uint8_t* __restrict__ layer_masks;
     size_t anim_stride;                   // records between animations = n_instances * n_nodes
@@ -664,10 +666,22 @@ __device__ __forceinline__ void apply_pose(FoldCtx& cx, const Acc& a) {
     cx.dirty |= a.mask != 0;
 }
 
+// The program is the same for every thread of the workgroup (one instance), so its first 64 ops sit in the lanes of a
+// register pair (one load at kernel start) and op k is a v_readlane away -- no dependent scalar load per op.
+__device__ __forceinline__ uint2 fold_op(const FoldCtx& cx, uint32_t pc) {
+    if (pc < 64u) {
+        uint2 op;
+        op.x = (uint32_t)__builtin_amdgcn_readlane((int)cx.my_op.x, (int)pc);
+        op.y = (uint32_t)__builtin_amdgcn_readlane((int)cx.my_op.y, (int)pc);
+        return op;
+    }
+    return pc < cx.n_ops ? cx.ops[pc] : make_uint2(OP_END, 0u);
+}
+
 template <int D>
 __device__ __forceinline__ void run_fold(FoldCtx& cx, Acc& acc) {
     for (;;) {
-        const uint2 op = cx.ops[cx.pc++];
+        const uint2 op = fold_op(cx, cx.pc++);
         const uint32_t code = op.x & 0xffu, arg = op.x >> 8;
         const float w = __uint_as_float(op.y);
         switch (code) {
@@ -1057,6 +1071,18 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             w_par[k] = rig.parent[w_node[k]];
         }
     }
+    // the instance's fold program: op `lane` into every wave's registers while ALL lanes are still active (v_readlane
+    // reads a lane's register whatever EXEC says, but only active lanes load)
+    const uint2* prog = nullptr;
+    uint32_t n_ops = 0;
+    uint2 my_op = make_uint2(OP_END, 0u);
+    if constexpr (PROGRAM) {
+        const uint32_t p0 = f.prog_off[inst];
+        prog = f.ops + p0;
+        n_ops = f.prog_off[inst + 1] - p0;
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane < n_ops) my_op = prog[lane];
+    }
     for (uint32_t node = threadIdx.x; node < rig.n_nodes; node += blockDim.x) {
         f4* trs = reinterpret_cast<f4*>(f.node_trs) + (inst_base + node) * 3;
         const f4 t0 = trs[0], t1 = trs[1], t2 = trs[2];
@@ -1075,7 +1101,9 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         cx.tsx = t2.x; cx.tsy = t2.y; cx.tsz = t2.z;
         cx.dirty = false;
         if constexpr (PROGRAM) {
-            cx.ops = f.ops + f.prog_off[inst];
+            cx.ops = prog;
+            cx.n_ops = n_ops;
+            cx.my_op = my_op;
             cx.anim_pose = reinterpret_cast<const f4*>(f.anim_pose);
             cx.layer_masks = f.layer_masks;
             cx.anim_stride = (size_t)f.n_instances * f.n_nodes;
@@ -1089,6 +1117,8 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             acc.px = acc.py = acc.pz = acc.sx = acc.sy = acc.sz = 0.f;
             acc.r = f4{0.f, 0.f, 0.f, 1.f};
             acc.mask = 0;
+            // (touching all operand records ahead of the fold, so that its loads find them in flight, measured slower:
+            // 19.1 vs 17.7 us on the C3 crowd)
             while (!cx.done) run_fold<0>(cx, acc);  // a stray POP at depth 0 is ignored
             if (cx.dirty) {
                 trs[0] = f4{cx.tpx, cx.tpy, cx.tpz, 0.f};
