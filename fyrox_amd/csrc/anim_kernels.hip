@@ -51,9 +51,10 @@ __device__ __forceinline__ float interpolate_loaded(float ll, float rl, f4 la, f
     if (lk == FYX_KEY_LINEAR) return lerpf_(la.x, ra.x, t);
     return cubicf_(la.x, ra.x, t, la.w, rk == FYX_KEY_CUBIC ? ra.z : 0.0f);
 }
-__device__ __forceinline__ float interpolate_keys(const float* __restrict__ loc,
-                                                  const f4* __restrict__ aux, uint32_t l, uint32_t r,
-                                                  float location) {
+// (LP / AP: pointers to the key locations / {value, kind, tangents} records -- global memory, or LDS where the crowd
+// sampler has staged the curve)
+template <typename LP, typename AP>
+__device__ __forceinline__ float interpolate_keys(LP loc, AP aux, uint32_t l, uint32_t r, float location) {
     return interpolate_loaded(loc[l], loc[r], aux[l], aux[r], location);
 }
 
@@ -73,8 +74,8 @@ __device__ __forceinline__ CurveEnds curve_ends(const TrackDev* tk, int c) {
     return CurveEnds{tk->first_loc[c], tk->last_loc[c], tk->first_val[c], tk->last_val[c]};
 }
 
-__device__ __forceinline__ CurveKeys curve_fetch(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n,
-                                                 uint32_t h) {
+template <typename LP, typename AP>
+__device__ __forceinline__ CurveKeys curve_fetch(LP loc, AP aux, uint32_t n, uint32_t h) {
     CurveKeys k;
     const uint32_t nn = n ? n : 1;                                    // an empty curve reads key 0 of its successor, unused
     const uint32_t hc = h < nn ? h : nn - 1, hl = hc > 0 ? hc - 1 : 0;   // clamped: addresses stay inside the curve
@@ -87,9 +88,9 @@ __device__ __forceinline__ CurveKeys curve_fetch(const float* __restrict__ loc, 
 // NEIGHBOURS: resolve a hint that is off by one span without the binary search (one extra round trip instead of
 // ~five).  Worth it where a round trip is a cold HBM access (many animators with their own key data: -5 %); on a
 // crowd, whose few curves sit in L2 and whose bound is the number of memory instructions, it measured 6 % slower.
-template <bool NEIGHBOURS>
-__device__ __forceinline__ float curve_eval(const CurveKeys& k, const CurveEnds& e, const float* __restrict__ loc,
-                                            const f4* __restrict__ aux, uint32_t n, float location, uint32_t& hint) {
+template <bool NEIGHBOURS, typename LP, typename AP>
+__device__ __forceinline__ float curve_eval(const CurveKeys& k, const CurveEnds& e, LP loc, AP aux, uint32_t n, float location,
+                                            uint32_t& hint) {
     if (n == 0) return 0.0f;
     const uint32_t h = hint;
     if (location <= e.l_first) { hint = 0; return e.v_first; }
@@ -128,9 +129,8 @@ __device__ __forceinline__ float curve_eval(const CurveKeys& k, const CurveEnds&
     return interpolate_keys(loc, aux, lo > 0 ? lo - 1 : 0, lo, location);
 }
 
-template <bool NEIGHBOURS = true>
-__device__ float curve_value_at(const float* __restrict__ loc, const f4* __restrict__ aux, uint32_t n, const CurveEnds& ends,
-                                float location, uint32_t& hint) {
+template <bool NEIGHBOURS = true, typename LP, typename AP>
+__device__ __forceinline__ float curve_value_at(LP loc, AP aux, uint32_t n, const CurveEnds& ends, float location, uint32_t& hint) {
     if (n == 0) return 0.0f;
     const CurveKeys k = curve_fetch(loc, aux, n, hint);
     return curve_eval<NEIGHBOURS>(k, ends, loc, aux, n, location, hint);
@@ -283,6 +283,8 @@ __global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDe
 // one dense span, and the only scattered access left is the 16-byte store of the wave's part of the pose record.
 // Same arithmetic, same order: bit-identical to the form above.
 // ---------------------------------------------------------------------------------------
+constexpr uint32_t kCurveLdsKeys = 128;   // curves up to this many keys are staged in LDS by the crowd sampler (2.5 KB per wave)
+
 __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
     // One wave = 64 instances of one (animation, node, BINDING): the position, scale and rotation tracks of a node
     // are sampled by three different waves, so a thread walks at most four curves (the chain of dependent loads
@@ -290,9 +292,11 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
     const uint32_t inst = bx * 64u + threadIdx.x, a = bz;
     const uint32_t node = by / 3u;
     const int bind = (int)(by - node * 3u);           // FYX_BIND_POSITION, _SCALE, _ROTATION
-    if (inst >= f.n_instances) return;
-    if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;
-    const float time = f.times[(size_t)inst * f.n_anims + a];
+    // a lane without work (past the crowd, or an animation that did not tick for its instance) still helps to stage
+    // the curves below
+    const bool active = inst < f.n_instances && (f.ticked[(size_t)(inst < f.n_instances ? inst : 0) * f.n_anims + a] & 1u);
+    if (!__any(active)) return;
+    const float time = active ? f.times[(size_t)inst * f.n_anims + a] : 0.0f;
     const AnimDev an = f.anims[a];
     const int32_t* st = an.slot_track + (size_t)node * 4;     // wave-uniform: scalar loads
     // which bindings the animation provides for this node (all three: the position wave writes the present bits)
@@ -321,16 +325,35 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
         uint32_t h0[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (c < need) h0[c] = *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
+            if (c < need && active) h0[c] = *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
+        // The 64 instances of the wave sit at 64 different playback positions, so a key load from global memory is a
+        // gather of 64 different addresses -- and the texture addresser takes about a cycle per address (measured:
+        // ~58 cycles per such instruction and CU, five of them per curve, is what this kernel's time was made of).
+        // A curve is small (20 B per key), so the wave copies the WHOLE curve into LDS with dense loads instead and
+        // gathers from there, where 64 different addresses cost a few cycles.  Longer curves keep the global path.
+        __shared__ float s_loc[kCurveLdsKeys];
+        __shared__ __attribute__((aligned(16))) f4 s_aux[kCurveLdsKeys];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c >= need) break;
             uint32_t hint = h0[c];
-            const uint32_t fk = tk->first_key[c];
-            val[c] = curve_value_at<false>(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], curve_ends(tk, c), time, hint);
-            if (hint != h0[c]) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = hint;
+            const uint32_t fk = tk->first_key[c], nk = tk->n_keys[c];
+            const float* gl = an.key_loc + fk;
+            const f4* ga = reinterpret_cast<const f4*>(an.key_aux) + fk;
+            if (nk <= kCurveLdsKeys) {   // wave-uniform
+                __builtin_amdgcn_wave_barrier();                // every lane is done with the previous curve
+                for (uint32_t i = threadIdx.x; i < nk; i += 64u) { s_loc[i] = gl[i]; s_aux[i] = ga[i]; }
+                __builtin_amdgcn_wave_barrier();
+                if (active)
+                    val[c] = curve_value_at<false>((const __attribute__((address_space(3))) float*)s_loc,
+                                                   (const __attribute__((address_space(3))) f4*)s_aux, nk, curve_ends(tk, c), time, hint);
+            } else if (active) {
+                val[c] = curve_value_at<false>(gl, ga, nk, curve_ends(tk, c), time, hint);
+            }
+            if (active && hint != h0[c]) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = hint;
         }
     }
+    if (!active) return;
     f4* rec = reinterpret_cast<f4*>(f.anim_pose) + (((size_t)a * f.n_instances + inst) * f.n_nodes + node) * 3;
     if (bind == FYX_BIND_POSITION) {
         const uint32_t bits = (valid[FYX_BIND_POSITION] ? 1u : 0u) | (valid[FYX_BIND_SCALE] ? 2u : 0u) |
