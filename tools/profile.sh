@@ -16,6 +16,7 @@ python $ROOT/bench.py --steps 2000 --warmup 100 --cpu-seconds 3 > "$ROOT/$OUT/be
 # C3 crowd, pose path + instanced skinning (kernel-trace only)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_pose" -o pose -- python $ROOT/tools/bench_pose.py --frames 200 > "$ROOT/$OUT/pose_under_trace.json" 2> "$ROOT/$OUT/trace_pose.err" )
 python $ROOT/tools/bench_pose.py > "$ROOT/$OUT/pose_plain.json" 2> "$ROOT/$OUT/pose_plain.err"
+python $ROOT/tools/bench_pose.py --palette-output > "$ROOT/$OUT/pose_palette_output.json" 2> "$ROOT/$OUT/pose_palette_output.err"
 python $ROOT/tools/bench_pose.py --root-motion > "$ROOT/$OUT/pose_root_motion.json" 2> "$ROOT/$OUT/pose_root_motion.err"
 # extended launches: blend shapes, vertex-buffer-in / vertex-buffer-out
 python $ROOT/tools/bench_ex.py > "$ROOT/$OUT/bench_ex.json" 2> "$ROOT/$OUT/bench_ex.err"

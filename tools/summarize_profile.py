@@ -23,7 +23,7 @@ p = os.path.join(src, "trace_ex", "ex_kernel_stats.csv")
 if os.path.exists(p):
     shutil.copy(p, os.path.join(dst, f"{tag}_bench_ex_kernel_stats.csv"))
 for f in ("bench_plain.json", "bench_under_trace.json", "bench_under_trace_s1.json", "pose_plain.json", "pose_under_trace.json",
-          "pose_root_motion.json", "pose_fused.json", "bench_ex.json", "bench_ex_under_trace.json", "timeline.json",
+          "pose_root_motion.json", "pose_fused.json", "pose_palette_output.json", "bench_ex.json", "bench_ex_under_trace.json", "timeline.json",
           "write_ceiling.json", "calibration_stream.json", "scene_64x4.json", "scene_256x1.json", "scene_under_trace.json"):
     p = os.path.join(src, f)
     if os.path.exists(p):
