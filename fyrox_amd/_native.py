@@ -156,6 +156,7 @@ _SIGS = {
     "fyx_lbs_skin_ex_batch": (c_int, [_P, _P, _P, c_uint32]),
     "fyx_state_add_random_action": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int, _P, c_uint32]),
     "fyx_animator_set_random_seed": (c_int, [_P, c_uint64, c_uint32, c_uint64]),
+    "fyx_animator_remove_animation": (c_int, [_P, c_uint64, c_uint32]),
     "fyx_scene_update": (c_int, [_P, _P, c_uint32, c_float]),
     "fyx_scene_plan": (c_int, [_P, _P, c_uint32, c_float]),
     "fyx_comm_unique_id": (c_int, [_P, _P]),

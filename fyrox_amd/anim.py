@@ -275,6 +275,10 @@ class Animator:
             self.set_enabled(a, enabled)
         return a
 
+    def remove_animation(self, a: int) -> None:
+        """AnimationContainer::remove: the index no longer resolves (see fyx_animator_remove_animation)."""
+        self._check(self._l.fyx_animator_remove_animation(self._h, self.id, a))
+
     def set_time_slice(self, a, start, end, instance=ALL_INSTANCES):
         self._check(self._l.fyx_animation_set_time_slice(self._h, self.id, a, instance, start, end))
 

@@ -74,6 +74,10 @@ struct AnimationDef {
     int32_t rm_node = -1;
     uint32_t rm_ignore = 0;
     int32_t rm_pos_track = -1, rm_rot_track = -1;  // first Position / Rotation track of the tracks data
+    // AnimationContainer::remove (lib.rs:1007): the handle is invalid from then on.  Nothing ticks it, conditions see
+    // "ended" (is_none_or), actions skip it -- and a PlayAnimation node that still names it keeps the pose it copied
+    // last (play.rs:93-99 only overwrites its output when the handle resolves), which is the record the device holds.
+    bool removed = false;
 };
 
 struct AnimState {  // per instance, per animation (Animation's scalar fields)
@@ -437,7 +441,7 @@ struct Planner {
             case FYX_LOGIC_NOT: return !logic(code, pc);
             case FYX_LOGIC_IS_ANIMATION_ENDED: {
                 const int32_t a = pc < code.size() ? code[pc++] : -1;
-                if (a < 0 || (uint32_t)a >= n_anims) return true;  // invalid handle: is_none_or -> true
+                if (a < 0 || (uint32_t)a >= n_anims || A.anims[a].removed) return true;  // invalid handle: is_none_or -> true
                 return has_ended(as[a]);
             }
             default: return false;
@@ -452,8 +456,8 @@ struct Planner {
         int32_t out = -1;
         switch (n.type) {
             case NODE_PLAY:  // play.rs:86-100
-                out = (int32_t)new_recipe_anim(n.animation);
-                if (rm()) rm_emit(RM_SET_ANIM, node_slot(cur_layer, handle), n.animation, 0.f);
+                out = (int32_t)new_recipe_anim(n.animation);   // of a removed animation: the pose it had last (see AnimationDef)
+                if (rm() && !A.anims[n.animation].removed) rm_emit(RM_SET_ANIM, node_slot(cur_layer, handle), n.animation, 0.f);
                 break;
             case NODE_BLEND: {  // blend.rs:136-164
                 RecipeItem small[16];                      // no heap traffic for the usual fan-in
@@ -648,10 +652,10 @@ struct Planner {
             if (a.kind == FYX_ACTION_ENABLE_RANDOM_ANIMATION) {   // state.rs:108-114: handles.iter().choose(rng), then enable
                 if (a.choices.empty()) continue;                  // choose() on an empty iterator: None, nothing drawn
                 const uint32_t pick = a.choices[random_index(A.rng[inst], (uint32_t)a.choices.size())];
-                if (pick < n_anims) as[pick].enabled = 1;
+                if (pick < n_anims && !A.anims[pick].removed) as[pick].enabled = 1;
                 continue;
             }
-            if (a.animation >= n_anims) continue;
+            if (a.animation >= n_anims || A.anims[a.animation].removed) continue;
             AnimState& s = as[a.animation];
             switch (a.kind) {
                 case FYX_ACTION_REWIND_ANIMATION: set_time_position(s, s.start); break;
@@ -1354,7 +1358,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
 
 template <typename F>
 int for_instances(fyx_ctx* c, Animator* A, uint32_t animation, uint32_t instance, F fn) {
-    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
     const uint32_t na = (uint32_t)A->anims.size();
     if (instance == FYX_ALL_INSTANCES) {
         for (uint32_t i = 0; i < A->n_instances; ++i) fn(A->anim_state[(size_t)i * na + animation]);
@@ -1742,7 +1746,7 @@ int fyx_animation_set_track_enabled(fyx_ctx* c, uint64_t animator_id, uint32_t a
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     FYX_ANIMATOR(c, A, animator_id);
-    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
     AnimationDef& an = A->anims[animation];
     if (track >= an.enabled.size()) return fail(c, FYX_ERR_INVALID_ARG, "track %u does not exist", track);
     an.enabled[track] = enabled ? 1 : 0;
@@ -1906,7 +1910,7 @@ int fyx_layer_add_play_animation(fyx_ctx* c, uint64_t animator_id, uint32_t laye
     FYX_GUARD_BEGIN
     FYX_ANIMATOR(c, A, animator_id);
     FYX_LAYER(c, A, L, layer);
-    if (animation >= A->anims.size())
+    if (animation >= A->anims.size() || A->anims[animation].removed)
         return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist (an invalid handle would leave a stale pose in the reference)", animation);
     if (animation >= (1u << 24)) return fail(c, FYX_ERR_UNSUPPORTED, "too many animations");
     PoseNodeDef n;
@@ -2008,6 +2012,22 @@ int fyx_layer_set_entry_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, 
     if (state >= L->states.size()) return fail(c, FYX_ERR_INVALID_ARG, "state %u does not exist", state);
     L->entry_state = (int32_t)state;
     for (MachineState& m : A->mstate) m.layers[layer].active_state = (int32_t)state;  // layer.rs:209-212
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_remove_animation(fyx_ctx* c, uint64_t animator_id, uint32_t animation) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    A->anims[animation].removed = true;
+    const uint32_t na = (uint32_t)A->anims.size();
+    for (uint32_t i = 0; i < A->n_instances; ++i) {
+        AnimState& st = A->anim_state[(size_t)i * na + animation];
+        st.enabled = 0;          // nothing ticks it any more
+        st.events.clear();
+    }
     return FYX_OK;
     FYX_GUARD_END(c)
 }
@@ -2292,7 +2312,7 @@ int fyx_animation_add_signal(fyx_ctx* c, uint64_t animator_id, uint32_t animatio
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     FYX_ANIMATOR(c, A, animator_id);
-    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
     A->anims[animation].signals.push_back(AnimationDef::Signal{time, (uint8_t)(enabled ? 1 : 0)});
     if (out_signal) *out_signal = (uint32_t)A->anims[animation].signals.size() - 1;
     return FYX_OK;
@@ -2302,7 +2322,7 @@ int fyx_animation_set_signal_enabled(fyx_ctx* c, uint64_t animator_id, uint32_t 
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     FYX_ANIMATOR(c, A, animator_id);
-    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
     if (signal >= A->anims[animation].signals.size()) return fail(c, FYX_ERR_INVALID_ARG, "signal %u does not exist", signal);
     A->anims[animation].signals[signal].enabled = enabled ? 1 : 0;
     return FYX_OK;
@@ -2370,7 +2390,7 @@ int fyx_animation_set_root_motion_settings(fyx_ctx* c, uint64_t animator_id, uin
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     FYX_ANIMATOR(c, A, animator_id);
-    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
     if (node >= (int32_t)A->rig->n_nodes) return fail(c, FYX_ERR_INVALID_ARG, "root motion node %d of a %u-node rig", node, A->rig->n_nodes);
     AnimationDef& an = A->anims[animation];
     an.rm_node = node < 0 ? -1 : node;
@@ -2386,7 +2406,7 @@ int fyx_animation_read_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t an
     FYX_GUARD_BEGIN
     FYX_ANIMATOR(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
-    if (animation >= A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
     if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
     if (!A->rm_enabled) return fail(c, FYX_ERR_INVALID_ARG, "root motion is not tracked on this animator");
     if (int rc = enter_primary(c)) return rc;
@@ -2490,7 +2510,8 @@ int fyx_animator_read_properties(fyx_ctx* c, uint64_t animator_id, int32_t anima
     FYX_ANIMATOR(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
-    if (animation >= (int32_t)A->anims.size()) return fail(c, FYX_ERR_INVALID_ARG, "animation %d does not exist", animation);
+    if (animation >= (int32_t)A->anims.size() || (animation >= 0 && A->anims[animation].removed))
+        return fail(c, FYX_ERR_INVALID_ARG, "animation %d does not exist", animation);
     if (A->prop_slots.empty()) return FYX_OK;
     if (int rc = enter_primary(c)) return rc;
     if (int rc = ensure_device_state(c, *A)) return rc;
@@ -2549,7 +2570,7 @@ struct EventCollector {
         const PoseNodeDef& nd = L.nodes[h];
         switch (nd.type) {
             case NODE_PLAY:  // play.rs:106-122: the animation's queued events, in order, not removed
-                if (nd.animation < A.anims.size())
+                if (nd.animation < A.anims.size() && !A.anims[nd.animation].removed)
                     for (int32_t sgn : as[nd.animation].events) push(nd.animation, sgn);
                 return;
             case NODE_BLEND: {  // blend.rs:172-222

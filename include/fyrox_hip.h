@@ -332,6 +332,11 @@ int fyx_animator_free(fyx_ctx* ctx, uint64_t animator_id);
 int fyx_animator_add_animation(fyx_ctx* ctx, uint64_t animator_id, uint64_t tracks_id,
                                const int32_t* track_target, const uint8_t* track_enabled,
                                uint32_t* out_animation);
+/* AnimationContainer::remove (lib.rs:1007): the index stays taken (indices of other animations do not move, as pool
+ * handles do not) but no longer resolves: nothing ticks it, IsAnimationEnded conditions on it are true, state actions
+ * skip it, per-animation calls answer FYX_ERR_INVALID_ARG -- and a PlayAnimation node that still names it keeps
+ * handing out the pose it copied last, exactly as play.rs:93-99 does for a handle that stopped resolving. */
+int fyx_animator_remove_animation(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation);
 int fyx_animation_set_track_enabled(fyx_ctx* ctx, uint64_t animator_id, uint32_t animation,
                                     uint32_t track, int enabled);
 /* Per-instance Animation state; instance = FYX_ALL_INSTANCES addresses every instance.

@@ -527,12 +527,23 @@ class AnimScene:
         self.props.update(self._pose_properties(pose_ptr))
 
     def animation_properties(self, a: int) -> dict:
-        return self._pose_properties(self.l.fo_animation_pose(self.anims[a]))
+        return self._pose_properties(self.l.fo_animation_pose(self._anim(a)))
+
+    def _anim(self, a: int):
+        h = self.anims[a]
+        if not h:
+            raise KeyError(f"animation {a} was removed")
+        return h
+
+    def remove_animation(self, a: int) -> None:
+        """AnimationContainer::remove (lib.rs:1007): the handle stops resolving; other handles keep their index."""
+        self.l.fo_animation_free(self._anim(a))
+        self.anims[a] = None
 
     # AnimationContainerExt::update_animations
     def update_animations(self, dt: float) -> None:
         for a in self.anims:
-            if self.l.fo_animation_is_enabled(a):
+            if a and self.l.fo_animation_is_enabled(a):
                 self.l.fo_animation_tick(a, dt)
                 self.l.fo_pose_apply(self.l.fo_animation_pose(a), self.nodes, self.n_nodes)
                 self._apply_properties(self.l.fo_animation_pose(a))
@@ -545,7 +556,7 @@ class AnimScene:
         self._apply_properties(pose)
 
     def animation_pose(self, a: int) -> np.ndarray:
-        return _pose_records(self.l.fo_animation_pose(self.anims[a]), self.n_nodes)
+        return _pose_records(self.l.fo_animation_pose(self._anim(a)), self.n_nodes)
 
     def machine_pose(self) -> np.ndarray:
         return _pose_records(self.l.fo_machine_pose(self.machine), self.n_nodes)
@@ -561,7 +572,7 @@ class AnimScene:
 
     def animation_root_motion(self, a: int) -> np.ndarray:
         dp, dr = np.zeros(3, np.float32), np.zeros(4, np.float32)
-        has = self.l.fo_animation_root_motion(self.anims[a], _p(dp), _p(dr))
+        has = self.l.fo_animation_root_motion(self._anim(a), _p(dp), _p(dr))
         return self._rm_record(has, dp, dr)
 
     def machine_root_motion(self, layer: int = -1) -> np.ndarray:
@@ -571,14 +582,14 @@ class AnimScene:
         return self._rm_record(has, dp, dr)
 
     def pop_event(self, a: int):
-        s = self.l.fo_animation_pop_event(self.anims[a])
+        s = self.l.fo_animation_pop_event(self._anim(a))
         return None if s < 0 else s
 
     def event_count(self, a: int) -> int:
-        return self.l.fo_animation_event_count(self.anims[a])
+        return self.l.fo_animation_event_count(self._anim(a))
 
     def clear_events(self, a: int) -> None:
-        self.l.fo_animation_clear_events(self.anims[a])
+        self.l.fo_animation_clear_events(self._anim(a))
 
     def pop_layer_event(self, layer: int):
         ev = (c_int * 3)()
@@ -593,7 +604,7 @@ class AnimScene:
         return tuple(src), [(int(a), int(s)) for a, s in pairs[:n]]
 
     def animation_state(self, a: int) -> dict:
-        h = self.anims[a]
+        h = self._anim(a)
         return {"time_position": float(self.l.fo_animation_time_position(h)),
                 "enabled": bool(self.l.fo_animation_is_enabled(h)), "has_ended": bool(self.l.fo_animation_has_ended(h))}
 
@@ -634,7 +645,8 @@ class AnimScene:
         if self.machine:
             self.l.fo_machine_free(self.machine)
         for a in self.anims:
-            self.l.fo_animation_free(a)
+            if a:
+                self.l.fo_animation_free(a)
         for t in self.tracks:
             self.l.fo_tracks_free(t)
         self.machine, self.anims, self.tracks = None, [], []

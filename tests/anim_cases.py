@@ -40,6 +40,7 @@ class Scenario:
     has_euler: bool = True
     track_root_motion: bool = False   # compare AnimationPose::root_motion of animations / layers / machine too
     random_seed: Optional[int] = None  # state of the EnableRandomAnimation generator (every instance gets the same)
+    removals: Dict[int, List[int]] = field(default_factory=dict)   # frame -> animations removed before that frame's update
 
 
 def _partial(td: A.AnimationTracksData, target: np.ndarray, keep: Callable[[int, A.Track], bool]):
@@ -414,8 +415,35 @@ def random_attacks(n_bones=12, seed=synth.SEED_BASE + 17) -> Scenario:
     return Scenario("random_attacks", rig, tds, anims, m, script, n_frames=120, dt=1.0 / 40.0, has_euler=False, random_seed=0x5EED1234)
 
 
+def removed_clips(n_bones=14, seed=synth.SEED_BASE + 18) -> Scenario:
+    """AnimationContainer::remove while a machine still names the animation (lib.rs:1007, play.rs:93-99): state 0 blends
+    clips 0 and 1, state 1 plays clip 2, state 2 blends clips 0, 1 and 3.  Clip 1 is removed at frame 9: its
+    PlayAnimation node keeps handing out the pose it copied last (the blend goes on with a frozen clip), the
+    `ended(1)` condition becomes true (is_none_or) and fires the transition to state 1, whose enter actions on the
+    removed clip do nothing.  Clip 3 is removed at frame 30, while state 2 is blending it."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(4):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, n_keys=9, fps=8.0, euler_every=10 ** 9)
+        tds.append(td)
+        anims.append(AnimSpec(c, tgt, speed=[1.0, 0.9, 1.4, -0.6][c]))
+    layer = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2), A.PlayAnimation(3),
+               A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, 0.4)]),
+               A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, 0.3), A.BlendPose(3, 0.5)])],
+        states=[A.State(4), A.State(2, on_enter_actions=[(A.ACTION_REWIND, 1), (A.ACTION_ENABLE, 1), (A.ACTION_ENABLE_RANDOM, [1, 1])]),
+                A.State(5)],
+        transitions=[A.Transition(0, 1, 0.2, ("and", ("ended", 1), ("not", ("parameter", 0)))),
+                     A.Transition(1, 2, 0.15, ("parameter", 0)),
+                     A.Transition(2, 0, 0.1, ("and", ("ended", 3), ("not", ("parameter", 0))))])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_RULE, False)], layers=[layer])
+    script = {20: [(0, A.Parameter(A.PARAM_RULE, True))], 38: [(0, A.Parameter(A.PARAM_RULE, False))]}
+    return Scenario("removed_clips", rig, tds, anims, m, script, n_frames=60, dt=1.0 / 30.0, has_euler=False, random_seed=5,
+                    removals={9: [1], 30: [3]})
+
+
 ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like, morph_weights,
-       morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player, random_attacks]
+       morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player, random_attacks, removed_clips]
 
 
 def with_root_motion_and_signals(make) -> Callable[[], Scenario]:

@@ -139,12 +139,21 @@ def _check_control_plane(orc, cctx, sc):
     trs = o.node_trs()
     n_frames = min(sc.n_frames, 48)
     rm_slots = None
+    alive = [True] * len(sc.animations)
+    poses = [o.animation_pose(a) for a in range(len(sc.animations))]
+    anim_rm = [None] * len(sc.animations)
     for f in range(n_frames):
         for idx, par in sc.script.get(f, []):
             o.set_parameter(idx, par)
             p.set_parameter(idx, par)
+        for a in sc.removals.get(f, []):     # AnimationContainer::remove: the handle stops resolving from here on
+            o.remove_animation(a)
+            p.remove_animation(a)
+            alive[a] = False
+            with pytest.raises(fyrox_amd.FyxError):
+                p.set_enabled(a, True)
         # what the oracle's animations hold BEFORE this frame (stale poses of animations that do not tick)
-        before = [o.animation_state(a)["time_position"] for a in range(len(sc.animations))]
+        before = [o.animation_state(a)["time_position"] if alive[a] else 0.0 for a in range(len(sc.animations))]
         plan = p.plan(mode, sc.dt)
         if mode:
             o.update_machine(sc.dt)
@@ -156,6 +165,9 @@ def _check_control_plane(orc, cctx, sc):
         assert np.array_equal(plan["times"][0], plan["times"][1])
         # sample times: a ticked animation is sampled at its time before the tick
         for a in range(len(sc.animations)):
+            if not alive[a]:
+                assert not plan["ticked"][0, a] & 1, (f, a)
+                continue
             if plan["ticked"][0, a] & 1:
                 assert plan["times"][0, a] == np.float32(before[a]), (f, a)
             assert p.animation_state(a, 1) == o.animation_state(a), (f, a)
@@ -174,7 +186,8 @@ def _check_control_plane(orc, cctx, sc):
                 ref = _drain(lambda: o.pop_layer_event(li))
                 assert _drain(lambda: p.pop_layer_event(li, 0)) == ref, (f, li)
                 assert _drain(lambda: p.pop_layer_event(li, 1)) == ref, (f, li)
-        poses = [o.animation_pose(a) for a in range(len(sc.animations))]
+        # a removed animation's pose is the one its PlayAnimation node copied last (play.rs:93-99)
+        poses = [o.animation_pose(a) if alive[a] else poses[a] for a in range(len(sc.animations))]
         trs = run_program(orc, plan["ops"][o0:o1], poses, excluded, trs)
         assert np.array_equal(trs.view(np.uint32), o.node_trs().view(np.uint32)), f"{sc.name}: frame {f}"
         if sc.track_root_motion and sc.machine:
@@ -183,7 +196,7 @@ def _check_control_plane(orc, cctx, sc):
             assert np.array_equal(rp["ops"][r0:r1], rp["ops"][r1:r2])
             if rm_slots is None:
                 rm_slots = [np.zeros(8, np.float32) for _ in range(rp["n_slots"])]
-            anim_rm = [o.animation_root_motion(a) for a in range(len(sc.animations))]
+            anim_rm = [o.animation_root_motion(a) if alive[a] else anim_rm[a] for a in range(len(sc.animations))]
             rm_slots = run_rm_program(orc, rp["ops"][r0:r1], rm_slots, anim_rm)
             def norm(rec):   # None reads back as RootMotion::default()
                 if _bits(rec):

@@ -50,7 +50,10 @@ def check_pose(got, ref, exact, what):
 def check_frame(p, o, sc, n_instances, f):
     """Everything the product can read back after frame f against the oracle's single instance."""
     exact = not sc.has_euler
+    gone = {a for fr, lst in sc.removals.items() if fr <= f for a in lst}   # AnimationContainer::remove'd by now
     for a in range(len(sc.animations)):
+        if a in gone:      # its record stays what it was (the pose PlayAnimation nodes keep using); nothing to compare with
+            continue
         got = p.read(A.READ_ANIMATION_POSE + a)
         ref = o.animation_pose(a)
         for i in (0, n_instances - 1):
@@ -67,6 +70,8 @@ def check_frame(p, o, sc, n_instances, f):
         check_properties(p, o, sc, exact, f"{sc.name} frame {f}")
     if sc.track_root_motion:
         for a in range(len(sc.animations)):
+            if a in gone:
+                continue
             check_root_motion(p.animation_root_motion(a), o.animation_root_motion(a), exact,
                               f"{sc.name} frame {f} animation {a} root motion")
         if sc.machine is not None:
@@ -83,6 +88,9 @@ def run_scenario(ctx, orc, sc, n_instances=1, frames=None, check_every=1):
         for idx, par in sc.script.get(f, []):
             o.set_parameter(idx, par)
             p.set_parameter(idx, par)
+        for a in sc.removals.get(f, []):
+            o.remove_animation(a)
+            p.remove_animation(a)
         if sc.machine is None:
             o.update_animations(sc.dt)
             p.update_animations(sc.dt)
@@ -192,7 +200,10 @@ def test_root_motion_and_signals_match_oracle(ctx, orc, make):
     through pose nodes / layers / machine, signal events and layer events."""
     sc = make()
     o, p = run_scenario(ctx, orc, sc, n_instances=3)
+    gone = {a for lst in sc.removals.values() for a in lst}
     for a in range(len(sc.animations)):
+        if a in gone:
+            continue
         ref = _drain(lambda: o.pop_event(a))
         assert _drain(lambda: p.pop_event(a, 0)) == ref and _drain(lambda: p.pop_event(a, 2)) == ref
     if sc.machine is not None:
@@ -481,6 +492,9 @@ def test_scene_update_matches_the_oracle_for_every_member(ctx, orc):
             for idx, par in sc.script.get(f, []):
                 o.set_parameter(idx, par)
                 p.set_parameter(idx, par)
+            for a in sc.removals.get(f, []):
+                o.remove_animation(a)
+                p.remove_animation(a)
             if sc.machine is None:
                 o.update_animations(dt)
             else:
@@ -491,8 +505,10 @@ def test_scene_update_matches_the_oracle_for_every_member(ctx, orc):
                 check_frame(p, o, sc, n, f)
     # events raised by the host control plane arrive as they do one by one
     for (sc, n), o, p in zip(members, os_, ps):
+        gone = {a for lst in sc.removals.values() for a in lst}
         for a in range(len(sc.animations)):
-            assert _drain(lambda: p.pop_event(a, n - 1)) == _drain(lambda: o.pop_event(a)), f"{sc.name}: events of animation {a}"
+            if a not in gone:
+                assert _drain(lambda: p.pop_event(a, n - 1)) == _drain(lambda: o.pop_event(a)), f"{sc.name}: events of animation {a}"
 
 
 def test_scene_update_is_bit_identical_to_one_by_one_updates(ctx, orc):
@@ -514,6 +530,9 @@ def test_scene_update_is_bit_identical_to_one_by_one_updates(ctx, orc):
             for idx, par in sc.script.get(f, []):
                 pa[k].set_parameter(idx, par)
                 pb[k].set_parameter(idx, par)
+            for a in sc.removals.get(f, []):
+                pa[k].remove_animation(a)
+                pb[k].remove_animation(a)
             if sc.machine is None:
                 pb[k].update_animations(dt)
             else:
@@ -522,7 +541,9 @@ def test_scene_update_is_bit_identical_to_one_by_one_updates(ctx, orc):
         if f % 5 == 4:
             for k in range(len(members)):
                 sc = members[k][0]
-                for what in [A.READ_LOCAL_TRS, A.READ_LOCAL_MATRIX, A.READ_GLOBAL_MATRIX] + [A.READ_ANIMATION_POSE + a for a in range(len(sc.animations))]:
+                gone = {a for fr, lst in sc.removals.items() if fr <= f for a in lst}
+                for what in [A.READ_LOCAL_TRS, A.READ_LOCAL_MATRIX, A.READ_GLOBAL_MATRIX] + \
+                        [A.READ_ANIMATION_POSE + a for a in range(len(sc.animations)) if a not in gone]:
                     ga, gb = pa[k].read(what), pb[k].read(what)
                     assert np.array_equal(ga.view(np.uint32), gb.view(np.uint32)), f"{sc.name} frame {f} read {what}"
                 if pa[k].property_count():
