@@ -159,6 +159,7 @@ _SIGS = {
     "fyx_animator_remove_animation": (c_int, [_P, c_uint64, c_uint32]),
     "fyx_scene_update": (c_int, [_P, _P, c_uint32, c_float]),
     "fyx_scene_plan": (c_int, [_P, _P, c_uint32, c_float]),
+    "fyx_debug_scene_tables": (c_int, [_P, _P, c_uint32, c_int, _P, c_uint32, _P]),
     "fyx_comm_unique_id": (c_int, [_P, _P]),
     "fyx_comm_init": (c_int, [_P, _P, c_int, c_int]),
     "fyx_comm_shutdown": (c_int, [_P]),

@@ -541,6 +541,16 @@ def scene_plan(ctx, animators: Sequence["Animator"], dt: float) -> None:
     ctx._check(ctx._l.fyx_scene_plan(ctx._h, _ptr(ids) if len(ids) else None, len(ids), dt))
 
 
+def scene_tables(ctx, animators: Sequence["Animator"], stage: int) -> np.ndarray:
+    """fyx_debug_scene_tables: (n_blocks, 4) uint32 {job, x, y, z} of one stage of the scene launch."""
+    ids = np.asarray([a.id for a in animators], np.uint64)
+    n = c_uint32()
+    ctx._check(ctx._l.fyx_debug_scene_tables(ctx._h, _ptr(ids), len(ids), stage, None, 0, byref(n)))
+    out = np.zeros((max(n.value, 1), 4), np.uint32)
+    ctx._check(ctx._l.fyx_debug_scene_tables(ctx._h, _ptr(ids), len(ids), stage, _ptr(out), n.value, byref(n)))
+    return out[:n.value]
+
+
 def upload_tracks_data(ctx, tracks_id: int, td: AnimationTracksData) -> None:
     descs, loc, val, kind, lt, rt = td.flatten()
     ctx._check(ctx._l.fyx_tracks_data_upload(ctx._h, tracks_id, len(td.tracks), descs, len(loc), _ptr(loc), _ptr(val),

@@ -1275,6 +1275,17 @@ int scene_plan(fyx_ctx* c, SceneBatch& S, float dt) {
     return FYX_OK;
 }
 
+SceneJobShape scene_shape(const fyx_ctx* c, const Animator& A, uint32_t n_prop_slots) {
+    SceneJobShape sh;
+    sh.n_anims = (uint32_t)A.anims.size();
+    sh.n_instances = A.n_instances;
+    sh.n_nodes = A.rig->n_nodes;
+    sh.n_prop_slots = n_prop_slots;
+    sh.sample_form = (uint32_t)c->sample_form;
+    sh.root_motion = sh.root_motion_program = A.rm_enabled;
+    return sh;
+}
+
 int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     const size_t n = S.animators.size();
     // 1. host control plane
@@ -1297,13 +1308,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         size_t lds[kSceneStages] = {};
         for (size_t k = 0; k < n; ++k) {
             const Animator& A = *S.animators[k];
-            SceneJobShape sh;
-            sh.n_anims = (uint32_t)A.anims.size();
-            sh.n_instances = A.n_instances;
-            sh.n_nodes = A.rig->n_nodes;
-            sh.n_prop_slots = A.dev_prop_slots;
-            sh.sample_form = (uint32_t)c->sample_form;
-            sh.root_motion = sh.root_motion_program = A.rm_enabled;
+            const SceneJobShape sh = scene_shape(c, A, A.dev_prop_slots);
             scene_blocks((uint32_t)k, sh, tables);
             const int stage = kStageUpdate64 + (int)std::min<uint32_t>((sh.n_nodes + 63) / 64, 4) - 1;
             lds[stage] = std::max(lds[stage], (size_t)sh.n_nodes * 32 * sizeof(float));
@@ -2158,6 +2163,22 @@ int fyx_scene_update(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animat
     if (int rc = scene_members(c, S, animator_ids, n_animators)) return rc;
     if (n_animators == 0) return FYX_OK;
     return scene_frame(c, S, dt);
+    FYX_GUARD_END(c)
+}
+
+int fyx_debug_scene_tables(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animators, int stage, uint32_t* out_blocks,
+                           uint32_t capacity, uint32_t* n_blocks) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (stage < 0 || stage >= kSceneStages) return fail(c, FYX_ERR_INVALID_ARG, "stage %d", stage);
+    SceneBatch& S = store(c).scene;
+    if (int rc = scene_members(c, S, animator_ids, n_animators)) return rc;
+    std::vector<uint4> tables[kSceneStages];
+    for (size_t k = 0; k < S.animators.size(); ++k)
+        scene_blocks((uint32_t)k, scene_shape(c, *S.animators[k], (uint32_t)S.animators[k]->prop_slots.size()), tables);
+    if (n_blocks) *n_blocks = (uint32_t)tables[stage].size();
+    if (out_blocks) memcpy(out_blocks, tables[stage].data(), std::min<size_t>(tables[stage].size(), capacity) * sizeof(uint4));
+    return FYX_OK;
     FYX_GUARD_END(c)
 }
 

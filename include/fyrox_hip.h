@@ -615,6 +615,12 @@ int fyx_animator_plan(fyx_ctx* ctx, uint64_t animator_id, int mode, float dt, fl
  * The host half of fyx_scene_update: every listed animator is planned (machine mode where it has a machine) on
  * the planner threads, nothing is sent to a GPU; read the results with fyx_animator_plan(.., mode -1, ..). */
 int fyx_scene_plan(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t n_animators, float dt);
+/* The block table fyx_scene_update would use for one stage of this scene (stages in launch order: 0 sample, curves on
+ * the lanes; 1 sample, instances on the lanes; 2 property sample; 3 root motion; 4 root-motion fold; 5-8 update with
+ * 64 / 128 / 192 / 256 threads; 9 property update): {job, x, y, z} per workgroup, *n_blocks = how many there are.
+ * Depends on the animators' shapes only; needs no GPU (a test hook, like fyx_animator_plan). */
+int fyx_debug_scene_tables(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t n_animators, int stage,
+                           uint32_t* out_blocks, uint32_t capacity, uint32_t* n_blocks);
 
 /* The root-motion program of the frame fyx_animator_plan planned last (mode 1, tracking on):
  * program_offset is [n_instances + 1]; ops are {opcode, dst slot, src slot | animation, f32

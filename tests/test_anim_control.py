@@ -392,3 +392,50 @@ def test_scene_planner_on_many_threads_equals_one_by_one_plans():
         A.scene_plan(ctxs[1], [sets[1][0], sets[1][0]], dt)       # listed twice
     for c in ctxs:
         c.close()
+
+
+def test_scene_block_tables_cover_every_animators_own_grid_exactly_once():
+    """The tables behind fyx_scene_update's one-launch-per-stage: for every stage, the entries of job k are exactly the
+    workgroups the per-animator launch of that stage would start for animator k -- each once, nothing else -- for
+    animators on both sampler forms, with and without properties and root motion, rigs from 6 to 300 nodes."""
+    ctx = fyrox_amd.Context(control_only=True)
+    members = [(cases.c5_blend_tree(), 1), (cases.c5_blend_tree(), 40), (cases.morph_weights(), 3), (cases.property_kinds(), 70),
+               (cases.ALL_RM[2](), 2), (cases.ALL_RM[0](), 33), (cases.player_only(), 5), (cases.removed_clips(), 1)]
+    big = cases.c5_blend_tree(n_bones=300)
+    members.append((big, 2))
+    ps = [cases.build_product(ctx, sc, n) for sc, n in members]
+    S_SAMPLE, S_CROWD, S_PSAMPLE, S_RM, S_RMFOLD, S_U64, S_U128, S_U192, S_U256, S_PUPD = range(10)
+    tables = {st: A.scene_tables(ctx, ps, st) for st in range(10)}
+
+    def of(st, k):
+        t = tables[st]
+        return [tuple(int(v) for v in r[1:]) for r in t[t[:, 0] == k]]
+
+    for k, ((sc, n), p) in enumerate(zip(members, ps)):
+        na, nn, nps = len(sc.animations), sc.rig.n_nodes, p.property_count()
+        crowd = n >= 32
+        want = {(x, y, a) for a in range(na) for y in range(nn * 3) for x in range((n + 63) // 64)} if crowd else set()
+        got = of(S_CROWD, k)
+        assert len(got) == len(set(got)) and set(got) == want, (sc.name, "crowd sampler")
+        want = set() if crowd else {(x, i, a) for a in range(na) for i in range(n) for x in range((nn * 16 + 255) // 256)}
+        got = of(S_SAMPLE, k)
+        assert len(got) == len(set(got)) and set(got) == want, (sc.name, "sampler")
+        want = {(x, i, a) for a in range(na) for i in range(n) for x in range((nps + 255) // 256)} if nps else set()
+        got = of(S_PSAMPLE, k)
+        assert len(got) == len(set(got)) and set(got) == want, (sc.name, "property sampler")
+        got = of(S_RM, k)
+        if sc.track_root_motion:
+            g = min((na * n * 16 + 255) // 256, 256 * 16)
+            assert sorted(got) == [(x, g, 0) for x in range(g)], (sc.name, "root motion")
+            assert sorted(of(S_RMFOLD, k)) == [(x, 0, 0) for x in range((n + 63) // 64)]
+        else:
+            assert got == [] and of(S_RMFOLD, k) == []
+        stage = S_U64 + min((nn + 63) // 64, 4) - 1
+        for st in (S_U64, S_U128, S_U192, S_U256):
+            assert sorted(of(st, k)) == ([(i, 0, 0) for i in range(n)] if st == stage else []), (sc.name, "update", st)
+        want = {(x, i, 0) for i in range(n) for x in range((nps + 63) // 64)} if nps else set()
+        got = of(S_PUPD, k)
+        assert len(got) == len(set(got)) and set(got) == want, (sc.name, "property update")
+    # job indices are positions in the list
+    assert set(int(j) for st in range(10) for j in tables[st][:, 0]) <= set(range(len(members)))
+    ctx.close()
