@@ -439,3 +439,49 @@ def test_scene_block_tables_cover_every_animators_own_grid_exactly_once():
     # job indices are positions in the list
     assert set(int(j) for st in range(10) for j in tables[st][:, 0]) <= set(range(len(members)))
     ctx.close()
+
+
+def test_entry_points_reject_bad_arguments_without_crashing(cctx):
+    """Nothing throws or aborts across the boundary: null pointers, unknown ids, out-of-range indices and a null context
+    come back as error codes from the batch / scene / removal / random-action entry points too."""
+    l, h = cctx._l, cctx._h
+    E = _native
+    sc = cases.by_index()
+    p = cases.build_product(cctx, sc)
+    ids = np.asarray([p.id], np.uint64)
+    bad = np.asarray([0xdeadbeef], np.uint64)
+    pi, pb = ids.ctypes.data_as(A.c_void_p), bad.ctypes.data_as(A.c_void_p)
+    assert l.fyx_scene_plan(None, pi, 1, 0.1) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_scene_plan(h, None, 1, 0.1) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_scene_plan(h, pb, 1, 0.1) == E.FYX_ERR_UNKNOWN_ID
+    assert l.fyx_scene_plan(h, None, 0, 0.1) == 0
+    assert l.fyx_scene_update(h, pi, 1, 0.1) == E.FYX_ERR_NO_DEVICE
+    assert l.fyx_scene_update(None, pi, 1, 0.1) == E.FYX_ERR_INVALID_ARG
+    n = A.c_uint32()
+    assert l.fyx_debug_scene_tables(h, pi, 1, 99, None, 0, A.byref(n)) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_debug_scene_tables(h, pb, 1, 0, None, 0, A.byref(n)) == E.FYX_ERR_UNKNOWN_ID
+    assert l.fyx_debug_scene_tables(h, pi, 1, 0, None, 0, None) == 0
+    assert l.fyx_animator_remove_animation(h, p.id, 99) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_animator_remove_animation(h, 0xdeadbeef, 0) == E.FYX_ERR_UNKNOWN_ID
+    assert l.fyx_animator_remove_animation(None, p.id, 0) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_state_add_random_action(h, p.id, 0, 0, 1, None, 3) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_state_add_random_action(h, p.id, 0, 99, 1, None, 0) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_state_add_random_action(h, p.id, 9, 0, 1, None, 0) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_state_add_random_action(h, p.id, 0, 0, 1, None, 0) == 0          # an empty list is legal (and draws nothing)
+    assert l.fyx_animator_set_random_seed(h, p.id, 99, 1) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_animator_set_random_seed(h, p.id, A.ALL_INSTANCES, 1) == 0
+    assert l.fyx_state_add_action(h, p.id, 0, 0, 1, 4, 0) == E.FYX_ERR_INVALID_ARG   # EnableRandomAnimation has its own call
+    assert l.fyx_lbs_skin_batch(h, None, 2) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_lbs_skin_batch(h, None, 0) == 0
+    assert l.fyx_lbs_skin_batch(None, None, 0) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_lbs_skin_ex_batch(h, None, None, 1) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_lbs_skin_ex_batch(h, None, None, 0) == 0
+    job = (_native.SkinJob * 1)(_native.SkinJob(12345, None, 4, 1, None, None, None))
+    assert l.fyx_lbs_skin_batch(h, job, 1) == E.FYX_ERR_UNKNOWN_ID                # validated before any device is needed
+    assert l.fyx_comm_init(h, None, 0, 1) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_comm_unique_id(h, None) == E.FYX_ERR_INVALID_ARG
+    assert l.fyx_allgather_f32(None, None, 0, None) == E.FYX_ERR_INVALID_ARG
+    # plan mode -1 on an animator that never planned: empty frame, no crash
+    fresh = cases.build_product(cctx, cases.player_only())
+    got = fresh.plan(-1, 0.0)
+    assert got["ops"].shape[0] == 0
