@@ -1,0 +1,479 @@
+// anim_device.h -- device side of an animator: persistent state, the per-frame control block and its upload, the
+// per-animator frame (run_frame) and the scene frame (scene_plan / scene_frame).  Included by anim_api.hip only, after
+// anim_planner.h.
+#pragma once
+
+namespace fyx {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Device side of an animator
+// ------------------------------------------------------------------------------------------
+int ensure_device_state(fyx_ctx* c, Animator& A) {
+    const Rig& rig = *A.rig;
+    const size_t in = (size_t)A.n_instances * rig.n_nodes;
+    if (!A.d_node_trs) {
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_node_trs), std::max<size_t>(in * 48, 16)));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_local), std::max<size_t>(in * 64, 16)));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_global), std::max<size_t>(in * 64, 16)));
+        for (uint32_t i = 0; i < A.n_instances; ++i)  // every instance starts from the rig's transforms
+            FYX_HIP(c, hipMemcpyAsync(reinterpret_cast<char*>(A.d_node_trs) + (size_t)i * rig.n_nodes * 48,
+                                      rig.init_trs.data(), (size_t)rig.n_nodes * 48, hipMemcpyHostToDevice,
+                                      c->stream));
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    const uint32_t na = (uint32_t)A.anims.size();
+    if (na > A.dev_anim_capacity || A.max_tracks > A.dev_track_capacity) {
+        // grow pose records / hints; existing contents are preserved
+        const uint32_t new_cap = std::max(na, A.dev_anim_capacity);
+        const uint32_t new_tracks = std::max(A.max_tracks, A.dev_track_capacity);
+        float4* np = nullptr;
+        uint32_t* nh = nullptr;
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&np), std::max<size_t>((size_t)new_cap * in * 48, 16)));
+        FYX_HIP(c, hipMemset(np, 0, std::max<size_t>((size_t)new_cap * in * 48, 16)));
+        const size_t hb = std::max<size_t>((size_t)new_cap * A.n_instances * std::max(new_tracks, 1u) * 16, 16);
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&nh), hb));
+        FYX_HIP(c, hipMemset(nh, 0, hb));
+        if (A.d_anim_pose && A.dev_anim_capacity)
+            FYX_HIP(c, hipMemcpy(np, A.d_anim_pose, (size_t)A.dev_anim_capacity * in * 48, hipMemcpyDeviceToDevice));
+        if (A.d_hints && A.dev_anim_capacity && A.dev_track_capacity) {
+            // layout [anim][track][curve][instance]: one row per animation, old rows are a prefix of the new ones
+            const size_t old_row = (size_t)A.dev_track_capacity * 16 * A.n_instances;
+            const size_t new_row = (size_t)new_tracks * 16 * A.n_instances;
+            FYX_HIP(c, hipMemcpy2D(nh, new_row, A.d_hints, old_row, old_row, A.dev_anim_capacity, hipMemcpyDeviceToDevice));
+        }
+        dfree(A.d_anim_pose);
+        dfree(A.d_hints);
+        A.d_anim_pose = np;
+        A.d_hints = nh;
+        A.dev_anim_capacity = new_cap;
+        A.dev_track_capacity = new_tracks;
+        A.anims_dirty = true;
+    }
+    // slot tables + animation descriptors
+    bool any_slots = false;
+    for (AnimationDef& an : A.anims) any_slots |= an.slots_dirty;
+    if (any_slots || A.anims_dirty) {
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<AnimDev> hd(na);
+        for (uint32_t a = 0; a < na; ++a) {
+            AnimationDef& an = A.anims[a];
+            if (an.slots_dirty) {
+                std::vector<int32_t> slots((size_t)rig.n_nodes * 4, -1);
+                std::vector<int32_t> ptrack(std::max<size_t>(A.prop_slots.size(), 1), -1);
+                for (uint32_t t = 0; t < an.td->n_tracks; ++t) {
+                    if (an.target[t] < 0 || !an.enabled[t]) continue;
+                    const int b = an.td->tracks[t].binding;
+                    if (b >= FYX_BIND_PROPERTY0) {
+                        if (an.td->tracks[t].n_curves < 1) continue;   // fetch() -> None
+                        const std::pair<int32_t, int32_t> key(an.target[t], b - FYX_BIND_PROPERTY0);
+                        const size_t sl = std::find(A.prop_slots.begin(), A.prop_slots.end(), key) - A.prop_slots.begin();
+                        if (sl < ptrack.size()) ptrack[sl] = (int32_t)t;
+                        slots[(size_t)an.target[t] * 4 + 3] = (int32_t)t;   // the node's pose is not empty
+                        continue;
+                    }
+                    int32_t& s = slots[(size_t)an.target[t] * 4 + b];
+                    if (s < 0) s = (int32_t)t;
+                }
+                if (an.dev_prop_slots < ptrack.size()) {
+                    dfree(an.d_prop_track);
+                    an.d_prop_track = nullptr;
+                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_prop_track), std::max<size_t>(ptrack.size() * 4, 16)));
+                    an.dev_prop_slots = (uint32_t)ptrack.size();
+                }
+                FYX_HIP(c, hipMemcpy(an.d_prop_track, ptrack.data(), ptrack.size() * 4, hipMemcpyHostToDevice));
+                if (!an.d_slot_track)
+                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_slot_track), std::max<size_t>(slots.size() * 4, 16)));
+                FYX_HIP(c, hipMemcpy(an.d_slot_track, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+                an.slots_dirty = false;
+            }
+            hd[a].tracks = an.td->d_tracks;
+            hd[a].key_loc = an.td->d_loc;
+            hd[a].key_aux = an.td->d_aux;
+            hd[a].slot_track = an.d_slot_track;
+            hd[a].prop_track = an.d_prop_track;
+            hd[a].n_tracks = an.td->n_tracks;
+            hd[a].rm_node = an.rm_node;
+            hd[a].rm_ignore = an.rm_ignore;
+            hd[a].rm_pos_track = an.rm_pos_track;
+            hd[a].rm_rot_track = an.rm_rot_track;
+            hd[a].pad = 0;
+        }
+        dfree(A.d_anims);
+        A.d_anims = nullptr;
+        if (int rc = upload(c, &A.d_anims, hd.data(), hd.size())) return rc;
+        A.anims_dirty = false;
+    }
+    const uint32_t nps = (uint32_t)A.prop_slots.size();
+    if (nps && (A.dev_prop_slots != nps || A.dev_prop_anims < A.dev_anim_capacity)) {
+        // property storage is re-created when slots or animations are added (values applied so far are kept per slot)
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<int32_t> nodes(nps);
+        for (uint32_t k = 0; k < nps; ++k) nodes[k] = A.prop_slots[k].first;
+        dfree(A.d_prop_node);
+        A.d_prop_node = nullptr;
+        if (int rc = upload(c, &A.d_prop_node, nodes.data(), nodes.size())) return rc;
+        PropRec* np = nullptr;
+        PropRec* no = nullptr;
+        const size_t pb = (size_t)A.dev_anim_capacity * A.n_instances * nps * sizeof(PropRec);
+        const size_t ob = (size_t)A.n_instances * nps * sizeof(PropRec);
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&np), std::max<size_t>(pb, 16)));
+        FYX_HIP(c, hipMemset(np, 0, std::max<size_t>(pb, 16)));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&no), std::max<size_t>(ob, 16)));
+        FYX_HIP(c, hipMemset(no, 0, std::max<size_t>(ob, 16)));
+        if (A.d_prop_out && A.dev_prop_slots)   // slots only ever get appended: old slot k is new slot k
+            FYX_HIP(c, hipMemcpy2D(no, (size_t)nps * sizeof(PropRec), A.d_prop_out, (size_t)A.dev_prop_slots * sizeof(PropRec),
+                                   (size_t)A.dev_prop_slots * sizeof(PropRec), A.n_instances, hipMemcpyDeviceToDevice));
+        dfree(A.d_prop_pose);
+        dfree(A.d_prop_out);
+        A.d_prop_pose = np;
+        A.d_prop_out = no;
+        A.dev_prop_slots = nps;
+        A.dev_prop_anims = A.dev_anim_capacity;
+    }
+    if (A.rm_enabled) {
+        if (A.dev_rm_anim_capacity < A.dev_anim_capacity) {  // [anim][instance]: growing keeps the existing prefix
+            RootMotionDev* nr = nullptr;
+            const size_t nb = (size_t)A.dev_anim_capacity * A.n_instances * sizeof(RootMotionDev);
+            FYX_HIP(c, hipStreamSynchronize(c->stream));
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&nr), std::max<size_t>(nb, 16)));
+            FYX_HIP(c, hipMemset(nr, 0, std::max<size_t>(nb, 16)));
+            if (A.d_rm_anim && A.dev_rm_anim_capacity)
+                FYX_HIP(c, hipMemcpy(nr, A.d_rm_anim, (size_t)A.dev_rm_anim_capacity * A.n_instances * sizeof(RootMotionDev),
+                                     hipMemcpyDeviceToDevice));
+            dfree(A.d_rm_anim);
+            A.d_rm_anim = nr;
+            A.dev_rm_anim_capacity = A.dev_anim_capacity;
+        }
+        uint32_t want = 1;
+        for (const LayerDef& L : A.layers) want += (uint32_t)L.nodes.size() + 1;
+        if (want != A.dev_rm_slots) {  // the machine graph changed: every pose's root motion starts from None again
+            FYX_HIP(c, hipStreamSynchronize(c->stream));
+            dfree(A.d_rm_slots);
+            A.d_rm_slots = nullptr;
+            const size_t nb = (size_t)A.n_instances * want * 32;
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_rm_slots), nb));
+            FYX_HIP(c, hipMemset(A.d_rm_slots, 0, nb));
+            A.dev_rm_slots = want;
+        }
+    }
+    if (A.masks_dirty || A.dev_mask_layers != A.layers.size()) {
+        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<uint8_t> m(std::max<size_t>(A.layers.size() * rig.n_nodes, 1), 0);
+        for (size_t l = 0; l < A.layers.size(); ++l)
+            for (int32_t n : A.layers[l].excluded)
+                if (n >= 0 && (uint32_t)n < rig.n_nodes) m[l * rig.n_nodes + n] = 1;
+        dfree(A.d_layer_masks);
+        A.d_layer_masks = nullptr;
+        if (int rc = upload(c, &A.d_layer_masks, m.data(), m.size())) return rc;
+        A.masks_dirty = false;
+        A.dev_mask_layers = (uint32_t)A.layers.size();
+    }
+    return FYX_OK;
+}
+
+RigDev rig_dev(const Rig& r) {
+    RigDev d;
+    d.parent = r.d_parent;
+    d.statics = r.d_statics;
+    d.level_nodes = r.d_level_nodes;
+    d.level_start = r.d_level_start;
+    d.node_level = r.d_node_level;
+    d.inv_bind = r.d_inv_bind;
+    d.n_pal = 0;
+    d.n_nodes = r.n_nodes;
+    d.n_levels = r.n_levels;
+    return d;
+}
+
+// The persistent part of an animator's kernel parameters.
+void frame_static(const fyx_ctx* c, const Animator& A, PoseFrameDev& f) {
+    memset(&f, 0, sizeof f);
+    f.anims = A.d_anims;
+    f.n_anims = (uint32_t)A.anims.size();
+    f.n_instances = A.n_instances;
+    f.n_nodes = A.rig->n_nodes;
+    f.layer_masks = A.d_layer_masks;
+    f.hints = A.d_hints;
+    f.max_tracks = A.dev_track_capacity;
+    f.sample_form = (uint32_t)c->sample_form;
+    f.anim_pose = A.d_anim_pose;
+    f.node_trs = A.d_node_trs;
+    f.local = A.d_local;
+    f.global = A.d_global;
+    f.n_prop_slots = A.dev_prop_slots;
+    f.prop_node = A.d_prop_node;
+    f.prop_pose = A.d_prop_pose;
+    f.prop_out = A.d_prop_out;
+}
+
+CtrlLayout ctrl_layout(const Animator& A) {
+    CtrlLayout L;
+    L.rm = A.rm_enabled;
+    L.o_tick = align_up(A.times.size() * 4, 256);
+    L.o_off = L.o_tick + align_up(A.ticked.size(), 256);
+    L.o_ops = L.o_off + align_up(A.prog_off.size() * 4, 256);
+    L.o_slices = L.o_ops + align_up(A.ops.size() * 8, 256);
+    L.o_rmoff = L.o_slices + (L.rm ? align_up(A.slices.size() * 8, 256) : 0);
+    L.o_rmops = L.o_rmoff + (L.rm ? align_up(A.rm_prog_off.size() * 4, 256) : 0);
+    L.total = L.o_rmops + (L.rm ? align_up(A.rm_ops.size() * 16, 256) : 0);
+    return L;
+}
+
+void ctrl_write(const Animator& A, const CtrlLayout& L, char* h) {
+    memcpy(h, A.times.data(), A.times.size() * 4);
+    memcpy(h + L.o_tick, A.ticked.data(), A.ticked.size());
+    memcpy(h + L.o_off, A.prog_off.data(), A.prog_off.size() * 4);
+    memcpy(h + L.o_ops, A.ops.data(), A.ops.size() * 8);
+    if (L.rm) {
+        memcpy(h + L.o_slices, A.slices.data(), A.slices.size() * 8);
+        memcpy(h + L.o_rmoff, A.rm_prog_off.data(), A.rm_prog_off.size() * 4);
+        memcpy(h + L.o_rmops, A.rm_ops.data(), A.rm_ops.size() * 16);
+    }
+}
+
+// Point the frame's parameters at the device copy of the control block.
+void ctrl_bind(const Animator& A, const CtrlLayout& L, const char* d, PoseFrameDev& f) {
+    f.times = reinterpret_cast<const float*>(d);
+    f.ticked = reinterpret_cast<const uint8_t*>(d + L.o_tick);
+    f.prog_off = reinterpret_cast<const uint32_t*>(d + L.o_off);
+    f.ops = reinterpret_cast<const uint2*>(d + L.o_ops);
+    if (L.rm) {
+        f.slices = reinterpret_cast<const float2*>(d + L.o_slices);
+        f.rm_anim = A.d_rm_anim;
+        f.rm_slots = A.d_rm_slots;
+        f.n_rm_slots = A.dev_rm_slots;
+        f.rm_prog_off = reinterpret_cast<const uint32_t*>(d + L.o_rmoff);
+        f.rm_ops = reinterpret_cast<const uint4*>(d + L.o_rmops);
+    }
+}
+
+// The rig's parameters plus the palettes the update kernel writes itself.
+int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
+    rd = rig_dev(*A.rig);
+    for (const Animator::PaletteOut& po : A.palette_outputs) {
+        auto bit = store(c).bones.find(po.bones_id);
+        if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu of a palette output was freed", (unsigned long long)po.bones_id);
+        PaletteOutDev& d = rd.pal[rd.n_pal++];
+        d.bone_nodes = bit->second.d_bone_nodes;
+        d.out = po.d_out;
+        d.n_bones = bit->second.n_bones;
+        d.pad = 0;
+    }
+    return FYX_OK;
+}
+
+// Send the planned frame to the GPU and run sample + update.
+int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
+    if (int rc = enter_primary(c)) return rc;
+    if (int rc = ensure_device_state(c, A)) return rc;
+    PoseFrameDev f;
+    frame_static(c, A, f);
+    int slot = 0;
+    if (with_program) {
+        const CtrlLayout L = ctrl_layout(A);
+        char *h = nullptr, *d = nullptr;
+        if (int rc = ctrl_acquire(c, A.ctrl, L.total, &slot, &h, &d)) return rc;
+        ctrl_write(A, L, h);
+        if (int rc = ctrl_upload(c, A.ctrl, slot, L.total)) return rc;
+        ctrl_bind(A, L, d, f);
+        FYX_HIP(c, launch_pose_sample(f, c->stream));
+        FYX_HIP(c, launch_property_sample(f, c->stream));
+        if (L.rm) FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), c->stream));
+    }
+    RigDev rd;
+    if (int rc = rig_params(c, A, rd)) return rc;
+    FYX_HIP(c, launch_pose_update(f, rd, with_program, c->stream));
+    if (with_program) {
+        FYX_HIP(c, launch_property_update(f, c->stream));
+        if (int rc = ctrl_consumed(c, A.ctrl, slot)) return rc;
+    }
+    return FYX_OK;
+}
+
+// One frame of MANY animators (fyx_scene_update): every animator is planned exactly as plan_frame does (different
+// animators on different host threads), the control blocks travel in ONE upload, and each stage of the frame is ONE
+// kernel launch over all of them.  Results are those of run_frame on each animator in turn: the animators share no
+// device state, and the kernels' bodies are the same functions.
+// Host control plane of a scene frame.  Crowds big enough to be split go first, one after another, each over the
+// whole pool; the rest are dealt out to the pool in contiguous runs of about equal instance counts.
+int scene_plan(fyx_ctx* c, SceneBatch& S, float dt) {
+    const size_t n = S.animators.size();
+    S.errors.assign(n, 0);
+    std::vector<size_t> small;
+    uint64_t small_instances = 0;
+    for (size_t k = 0; k < n; ++k) {
+        Animator& A = *S.animators[k];
+        const unsigned nt = plan_tasks(c, A);
+        if (nt > 1) S.errors[k] = plan_frame_core(A, A.layers.empty() ? 0 : 1, dt, nt, plan_pool(c, nt));
+        else { small.push_back(k); small_instances += A.n_instances; }
+    }
+    unsigned n_tasks = 1;
+    if (c->plan_threads > 1 && small.size() >= 32) n_tasks = std::min<unsigned>((unsigned)c->plan_threads, (unsigned)(small.size() / 16));
+    if (n_tasks > 1) {
+        std::vector<size_t> cut(n_tasks + 1, small.size());   // task t plans small[cut[t] .. cut[t + 1])
+        cut[0] = 0;
+        uint64_t acc = 0;
+        unsigned t = 1;
+        for (size_t j = 0; j < small.size() && t < n_tasks; ++j) {
+            acc += S.animators[small[j]]->n_instances;
+            if (acc * n_tasks >= small_instances * t) cut[t++] = j + 1;
+        }
+        plan_pool(c, n_tasks)->run(n_tasks, [&](unsigned task) {
+            for (size_t j = cut[task]; j < cut[task + 1]; ++j) {
+                Animator& A = *S.animators[small[j]];
+                S.errors[small[j]] = plan_frame_core(A, A.layers.empty() ? 0 : 1, dt, 1, nullptr);
+            }
+        });
+    } else {
+        for (size_t k : small) {
+            Animator& A = *S.animators[k];
+            S.errors[k] = plan_frame_core(A, A.layers.empty() ? 0 : 1, dt, 1, nullptr);
+        }
+    }
+    for (size_t k = 0; k < n; ++k)
+        if (S.errors[k]) return fail(c, S.errors[k], "animator %zu of the scene: pose nodes nest deeper than %d blend levels", k, kMaxFoldDepth - 2);
+    return FYX_OK;
+}
+
+SceneJobShape scene_shape(const fyx_ctx* c, const Animator& A, uint32_t n_prop_slots) {
+    SceneJobShape sh;
+    sh.n_anims = (uint32_t)A.anims.size();
+    sh.n_instances = A.n_instances;
+    sh.n_nodes = A.rig->n_nodes;
+    sh.n_prop_slots = n_prop_slots;
+    sh.sample_form = (uint32_t)c->sample_form;
+    sh.root_motion = sh.root_motion_program = A.rm_enabled;
+    return sh;
+}
+
+int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
+    const size_t n = S.animators.size();
+    // 1. host control plane
+    if (int rc = scene_plan(c, S, dt)) return rc;
+
+    // 2. device state, and the block tables if the scene's shape changed
+    if (int rc = enter_primary(c)) return rc;
+    std::vector<uint64_t> sig;
+    sig.reserve(n * 3 + 1);
+    sig.push_back((uint64_t)c->sample_form);
+    for (size_t k = 0; k < n; ++k) {
+        Animator& A = *S.animators[k];
+        if (int rc = ensure_device_state(c, A)) return rc;
+        sig.push_back(((uint64_t)A.anims.size() << 32) | A.n_instances);
+        sig.push_back(((uint64_t)A.rig->n_nodes << 32) | A.dev_prop_slots);
+        sig.push_back(A.rm_enabled ? 1 : 0);
+    }
+    if (sig != S.signature) {
+        std::vector<uint4> tables[kSceneStages];
+        size_t lds[kSceneStages] = {};
+        for (size_t k = 0; k < n; ++k) {
+            const Animator& A = *S.animators[k];
+            const SceneJobShape sh = scene_shape(c, A, A.dev_prop_slots);
+            scene_blocks((uint32_t)k, sh, tables);
+            const int stage = kStageUpdate64 + (int)std::min<uint32_t>((sh.n_nodes + 63) / 64, 4) - 1;
+            lds[stage] = std::max(lds[stage], (size_t)sh.n_nodes * 32 * sizeof(float));
+        }
+        size_t total = 0;
+        for (int k = 0; k < kSceneStages; ++k) {
+            if (tables[k].size() > 0x7fffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "scene too large for one launch per stage");
+            S.table_off[k] = total;
+            S.n_blocks[k] = (uint32_t)tables[k].size();
+            S.lds_bytes[k] = lds[k];
+            total += tables[k].size();
+        }
+        FYX_HIP(c, hipStreamSynchronize(c->stream));   // the previous scene's launches still read the old tables
+        dfree(S.d_tables);
+        S.d_tables = nullptr;
+        S.signature.clear();
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&S.d_tables), std::max<size_t>(total, 1) * sizeof(uint4)));
+        for (int k = 0; k < kSceneStages; ++k)
+            if (!tables[k].empty())
+                FYX_HIP(c, hipMemcpy(S.d_tables + S.table_off[k], tables[k].data(), tables[k].size() * sizeof(uint4), hipMemcpyHostToDevice));
+        S.signature = sig;
+    }
+
+    // 3. one control block: the job array, then every animator's sections
+    S.layouts.resize(n);
+    S.offsets.resize(n);
+    size_t total = align_up(n * sizeof(SceneJobDev), 256);
+    for (size_t k = 0; k < n; ++k) {
+        S.layouts[k] = ctrl_layout(*S.animators[k]);
+        S.offsets[k] = total;
+        total += S.layouts[k].total;
+    }
+    int slot = 0;
+    char *h = nullptr, *d = nullptr;
+    if (int rc = ctrl_acquire(c, S.ctrl, total, &slot, &h, &d)) return rc;
+    SceneJobDev* jobs = reinterpret_cast<SceneJobDev*>(h);
+    for (size_t k = 0; k < n; ++k) {
+        const Animator& A = *S.animators[k];
+        ctrl_write(A, S.layouts[k], h + S.offsets[k]);
+        frame_static(c, A, jobs[k].f);
+        ctrl_bind(A, S.layouts[k], d + S.offsets[k], jobs[k].f);
+        if (int rc = rig_params(c, A, jobs[k].rig)) return rc;
+    }
+    if (int rc = ctrl_upload(c, S.ctrl, slot, total)) return rc;
+
+    // 4. one launch per stage
+    const uint4* tabs[kSceneStages];
+    for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
+    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(d), tabs, S.n_blocks, S.lds_bytes, c->stream));
+    return ctrl_consumed(c, S.ctrl, slot);
+}
+
+template <typename F>
+int for_instances(fyx_ctx* c, Animator* A, uint32_t animation, uint32_t instance, F fn) {
+    if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
+    const uint32_t na = (uint32_t)A->anims.size();
+    if (instance == FYX_ALL_INSTANCES) {
+        for (uint32_t i = 0; i < A->n_instances; ++i) fn(A->anim_state[(size_t)i * na + animation]);
+        return FYX_OK;
+    }
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    fn(A->anim_state[(size_t)instance * na + animation]);
+    return FYX_OK;
+}
+
+LayerDef* find_layer(Animator* A, uint32_t layer) { return layer < A->layers.size() ? &A->layers[layer] : nullptr; }
+
+#define FYX_LAYER(c, A, L, layer)                                                                \
+    LayerDef* L = find_layer((A), (layer));                                                      \
+    if (!L) return fail((c), FYX_ERR_INVALID_ARG, "layer %u does not exist", (layer))
+
+// Longest chain of nested blends below a node; -1 on a cycle (the reference would recurse forever).
+int node_depth(const LayerDef& L, int32_t h, std::vector<int>& state) {
+    if (h < 0 || (size_t)h >= L.nodes.size()) return 0;
+    if (state[h] == -2) return -1;
+    if (state[h] >= 0) return state[h];
+    state[h] = -2;
+    int d = 0;
+    const PoseNodeDef& n = L.nodes[h];
+    if (n.type != NODE_PLAY) {
+        for (const BlendInput& in : n.inputs) {
+            const int cd = node_depth(L, in.source, state);
+            if (cd < 0) return -1;
+            d = std::max(d, cd);
+        }
+        d += 1;
+    }
+    state[h] = d;
+    return d;
+}
+
+}  // namespace
+
+void anim_store_destroy(AnimStore* s) {
+    if (!s) return;
+    dfree(s->scene.d_tables);
+    free_ctrl(s->scene.ctrl);
+    for (auto& kv : s->animators) free_animator(*kv.second);
+    for (auto& kv : s->bones) free_bones(kv.second);
+    for (auto& kv : s->rigs) free_rig(kv.second);
+    for (auto& kv : s->tracks) free_tracks(kv.second);
+    delete s;
+}
+
+}  // namespace fyx

@@ -1,0 +1,223 @@
+// anim_model.h -- host-side model of the pose path: tracks data, rigs, the structure of an animator (animations, machine
+// layers, pose nodes), per-instance state, and the context's registries.  Included by anim_api.hip only.
+#pragma once
+
+namespace fyx {
+
+namespace {
+
+struct TracksData {
+    uint32_t n_tracks = 0;
+    std::vector<fyx_track_desc> tracks;
+    TrackDev* d_tracks = nullptr;
+    float* d_loc = nullptr;
+    float4* d_aux = nullptr;
+};
+
+struct Rig {
+    uint32_t n_nodes = 0, n_levels = 0;
+    std::vector<int32_t> parent;
+    std::vector<float> init_trs;  // [n_nodes][12]
+    int32_t* d_parent = nullptr;
+    float* d_statics = nullptr;
+    uint32_t* d_level_nodes = nullptr;
+    uint32_t* d_level_start = nullptr;
+    uint32_t* d_node_level = nullptr;
+    float* d_inv_bind = nullptr;
+};
+
+struct BoneList {
+    uint64_t rig_id = 0;
+    uint32_t n_bones = 0;
+    int32_t* d_bone_nodes = nullptr;
+};
+
+// ---- shared structure of an animator ----
+struct AnimationDef {
+    uint64_t tracks_id = 0;
+    const TracksData* td = nullptr;
+    std::vector<int32_t> target;   // per track, <0: no TrackBinding
+    std::vector<uint8_t> enabled;  // TrackBinding::enabled
+    int32_t* d_slot_track = nullptr;
+    int32_t* d_prop_track = nullptr;   // [animator's property slots]
+    uint32_t dev_prop_slots = 0;
+    bool slots_dirty = true;
+    // AnimationSignal (signal.rs): the index stands for the {id, name} pair the shim keeps
+    struct Signal { float time; uint8_t enabled; };
+    std::vector<Signal> signals;
+    // RootMotionSettings (lib.rs:307-319); node < 0: None
+    int32_t rm_node = -1;
+    uint32_t rm_ignore = 0;
+    int32_t rm_pos_track = -1, rm_rot_track = -1;  // first Position / Rotation track of the tracks data
+    // AnimationContainer::remove (lib.rs:1007): the handle is invalid from then on.  Nothing ticks it, conditions see
+    // "ended" (is_none_or), actions skip it -- and a PlayAnimation node that still names it keeps the pose it copied
+    // last (play.rs:93-99 only overwrites its output when the handle resolves), which is the record the device holds.
+    bool removed = false;
+};
+
+struct AnimState {  // per instance, per animation (Animation's scalar fields)
+    float time = 0.f, speed = 1.f, start = 0.f, end = 0.f;
+    uint8_t enabled = 1, looped = 1;
+    uint32_t max_event_capacity = 32;   // lib.rs:941
+    std::deque<int32_t> events;         // VecDeque<AnimationEvent>, as signal indices
+};
+
+struct Param {
+    int kind = FYX_PARAM_WEIGHT;
+    float f0 = 0.f, f1 = 0.f;
+    uint32_t u = 0;
+};
+
+struct BlendInput {
+    int32_t source = -1;
+    int32_t weight_param = -1;
+    float weight_const = 0.f;
+    float blend_time = 0.f;
+};
+
+enum NodeType { NODE_PLAY, NODE_BLEND, NODE_BY_INDEX, NODE_BLEND_SPACE };
+
+struct PoseNodeDef {
+    NodeType type = NODE_PLAY;
+    uint32_t animation = 0;
+    int32_t param = -1;
+    std::vector<BlendInput> inputs;
+    std::vector<float> points;       // BlendSpace xy
+    std::vector<uint32_t> triangles;
+    uint32_t by_index_slot = 0;      // index into per-instance ByIndex state
+};
+
+struct Action { int kind; uint32_t animation; std::vector<uint32_t> choices; };   // choices: EnableRandomAnimation's handles
+struct StateDef { int32_t root = -1; std::vector<Action> on_enter, on_leave; };
+struct TransitionDef { uint32_t source = 0, dest = 0; float time = 0.f; std::vector<int32_t> logic; };
+
+struct LayerDef {
+    float weight = 1.f;
+    std::vector<PoseNodeDef> nodes;
+    std::vector<StateDef> states;
+    std::vector<TransitionDef> transitions;
+    int32_t entry_state = -1;
+    std::vector<int32_t> excluded;
+    uint32_t by_index_count = 0;
+};
+
+// ---- per-instance machine state ----
+struct TransitionState { float elapsed = 0.f, blend_factor = 0.f; };
+struct ByIndexState { bool has_prev = false; uint32_t prev = 0; float blend_time = 0.f; };
+struct LayerState {
+    int32_t active_state = -1, active_transition = -1;
+    std::vector<TransitionState> transitions;
+    std::vector<ByIndexState> by_index;
+    std::deque<fyx_layer_event> events;  // FixedEventQueue::new(2048), layer.rs:182
+};
+constexpr size_t kLayerEventLimit = 2048;
+struct MachineState {
+    std::vector<Param> params;
+    std::vector<LayerState> layers;
+};
+
+// A recipe: what a pose node's output pose was made of at one evaluation.
+struct Recipe {
+    int32_t anim = -1;                  // >= 0: a copy of that animation's pose
+    uint32_t first = 0, count = 0;      // else: fold of items[first .. first+count)
+};
+struct RecipeItem { uint32_t recipe; float w; };
+
+// What planning a range of instances produces; one per planner thread, merged in instance order.
+struct PlanScratch {
+    std::vector<uint2> ops;
+    std::vector<uint4> rm_ops;
+    std::vector<uint32_t> prog_len, rm_prog_len;   // per instance of the range
+    std::vector<Recipe> recipes;
+    std::vector<RecipeItem> items;
+    std::vector<int32_t> node_recipe;
+    std::vector<uint8_t> seen;
+    int error = 0;
+};
+
+struct Animator {
+    uint64_t rig_id = 0;
+    Rig* rig = nullptr;
+    uint32_t n_instances = 0;
+    std::vector<AnimationDef> anims;
+    std::vector<AnimState> anim_state;  // [inst][anim]
+    std::vector<Param> param_defaults;
+    std::vector<LayerDef> layers;
+    std::vector<MachineState> mstate;   // [inst]
+    std::vector<uint64_t> rng;          // [inst] StateAction::EnableRandomAnimation's generator state (lazily sized)
+    uint32_t max_tracks = 0;
+    // device state
+    AnimDev* d_anims = nullptr;
+    bool anims_dirty = true;
+    uint32_t* d_hints = nullptr;
+    float4* d_anim_pose = nullptr;
+    uint32_t dev_anim_capacity = 0, dev_track_capacity = 0;
+    float4* d_node_trs = nullptr;
+    float* d_local = nullptr;
+    float* d_global = nullptr;
+    uint8_t* d_layer_masks = nullptr;
+    bool masks_dirty = true;
+    uint32_t dev_mask_layers = 0;
+    CtrlBuffers ctrl;   // per-frame control (device + pinned staging)
+    // frame plan (host)
+    std::vector<float> times;
+    std::vector<uint8_t> ticked;
+    std::vector<uint2> ops;
+    std::vector<uint32_t> prog_off;
+    // root motion (only when rm_enabled): per-frame slices + program, persistent device state
+    bool rm_enabled = false;
+    std::vector<float2> slices;
+    std::vector<uint4> rm_ops;
+    std::vector<uint32_t> rm_prog_off;
+    // palettes the update kernel writes itself (fyx_animator_set_palette_output)
+    struct PaletteOut { uint64_t bones_id; float* d_out; };
+    std::vector<PaletteOut> palette_outputs;
+    // Property{..} slots: one per distinct (node, property id) any animation of the animator drives
+    std::vector<std::pair<int32_t, int32_t>> prop_slots;
+    int32_t* d_prop_node = nullptr;
+    PropRec* d_prop_pose = nullptr;    // [anim capacity][instance][slot]
+    PropRec* d_prop_out = nullptr;     // [instance][slot]
+    uint32_t dev_prop_slots = 0, dev_prop_anims = 0;
+    std::vector<uint32_t> rm_layer_base;   // first slot of each layer; nodes, then the layer's final pose
+    uint32_t n_rm_slots = 0;               // ... and the machine's final pose last
+    RootMotionDev* d_rm_anim = nullptr;
+    uint32_t dev_rm_anim_capacity = 0;
+    float4* d_rm_slots = nullptr;
+    uint32_t dev_rm_slots = 0;
+    // scratch of the planner threads
+    std::vector<PlanScratch> scratch;
+};
+
+}  // namespace
+
+// The per-frame control block of an animator (what plan_frame produced), as it travels to the GPU: 256-byte aligned
+// sections {times, ticked, prog_off, ops [, slices, rm_prog_off, rm_ops]}.
+struct CtrlLayout {
+    size_t o_tick = 0, o_off = 0, o_ops = 0, o_slices = 0, o_rmoff = 0, o_rmops = 0, total = 0;
+    bool rm = false;
+};
+
+// fyx_scene_update's cached state: the block tables of the scene it last ran (they depend on the animators' shapes
+// only) and the scene-wide control buffers.
+struct SceneBatch {
+    std::vector<uint64_t> signature;
+    uint4* d_tables = nullptr;
+    size_t table_off[kSceneStages] = {};
+    uint32_t n_blocks[kSceneStages] = {};
+    size_t lds_bytes[kSceneStages] = {};
+    CtrlBuffers ctrl;
+    std::vector<Animator*> animators;   // scratch of the current call
+    std::vector<CtrlLayout> layouts;
+    std::vector<size_t> offsets;
+    std::vector<int> errors;
+};
+
+struct AnimStore {
+    SceneBatch scene;
+    std::unordered_map<uint64_t, TracksData> tracks;
+    std::unordered_map<uint64_t, Rig> rigs;
+    std::unordered_map<uint64_t, BoneList> bones;
+    std::unordered_map<uint64_t, std::unique_ptr<Animator>> animators;
+};
+
+}  // namespace fyx
