@@ -29,6 +29,7 @@ namespace fyx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT, typename T>
@@ -268,9 +269,12 @@ __device__ __forceinline__ Skinned skin_vertex(const f32x4* __restrict__ rows,
 // the memory system while it computes (all waves start in lock-step at kernel launch, so
 // without this the whole chip alternates between a load phase and a compute phase).
 // ---------------------------------------------------------------------------------------
+// p and n are kept as whole 96-bit values (one register triple each): a loop that carries a vertex from one
+// iteration to the next then carries the triple a dwordx3 load fills, instead of six scalars the register allocator
+// is free to scatter (and has to gather again with moves that wait for the load).
 template <int MASK>
 struct VertexIn {
-    float px, py, pz, nx, ny, nz;
+    f32x3 p, n;
     f32x4 t, w;
     uint32_t id;
 };
@@ -278,10 +282,11 @@ struct VertexIn {
 template <bool NT, int MASK>
 __device__ __forceinline__ VertexIn<MASK> load_vertex(const LbsArgs& a, uint32_t vs) {
     VertexIn<MASK> r;
-    r.px = r.py = r.pz = r.nx = r.ny = r.nz = 0.f;
+    r.p = r.n = f32x3{0.f, 0.f, 0.f};
     r.t = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (MASK & 1) ld3<NT>(a.pos + (size_t)vs * 3, r.px, r.py, r.pz);
-    if constexpr (MASK & 2) ld3<NT>(a.nrm + (size_t)vs * 3, r.nx, r.ny, r.nz);
+    float x, y, z;
+    if constexpr (MASK & 1) { ld3<NT>(a.pos + (size_t)vs * 3, x, y, z); r.p = f32x3{x, y, z}; }
+    if constexpr (MASK & 2) { ld3<NT>(a.nrm + (size_t)vs * 3, x, y, z); r.n = f32x3{x, y, z}; }
     if constexpr (MASK & 4) r.t = ldg<NT>(reinterpret_cast<const f32x4*>(a.tan) + vs);
     r.w = ldg<NT>(reinterpret_cast<const f32x4*>(a.wgt) + vs);
     r.id = ldg<NT>(a.idx + vs);
@@ -290,7 +295,7 @@ __device__ __forceinline__ VertexIn<MASK> load_vertex(const LbsArgs& a, uint32_t
 
 template <int MASK>
 __device__ __forceinline__ void pin_vertex(VertexIn<MASK>& r) {
-    asm volatile("" : "+v"(r.px), "+v"(r.py), "+v"(r.pz), "+v"(r.nx), "+v"(r.ny), "+v"(r.nz));
+    asm volatile("" : "+v"(r.p), "+v"(r.n));
     asm volatile("" : "+v"(r.t), "+v"(r.w), "+v"(r.id));
 }
 
@@ -300,7 +305,8 @@ __device__ __forceinline__ void pin_vertex(VertexIn<MASK>& r) {
 // (three units in flight per wave: what lets the half-empty CUs of a launch's tail still fill their share of HBM).
 template <int BLOCK, bool EXACT, bool NT, int PREFETCH, int MASK, bool PROBE = false>
 __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_inst,
-                                                  uint32_t total_units, uint32_t split, uint64_t* probe = nullptr) {
+                                                  uint32_t total_units, uint32_t split, uint64_t* probe = nullptr,
+                                                  uint32_t asym = 0, uint32_t young_prio = 0) {
     uint64_t pt0 = 0, pt1 = 0;
     if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -311,8 +317,24 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
     constexpr uint32_t WPB = BLOCK / 64;
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
-    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    if (asym) {
+        // Two workgroups per CU (grid = 2 x CUs): the first-dispatched one (block < CUs; observed, not promised --
+        // a matter of speed only) wins the arbitration inside its CU and finishes early, so it takes asym/64 of the
+        // pair's contiguous range.
+        const uint32_t half = gridDim.x / 2, pair = blockIdx.x % half;
+        const uint32_t p0 = (uint32_t)(((uint64_t)pair * total_units) / half);
+        const uint32_t p1 = (uint32_t)(((uint64_t)(pair + 1) * total_units) / half);
+        const uint32_t cut = p0 + (uint32_t)(((uint64_t)(p1 - p0) * asym) / 64);
+        u_begin = blockIdx.x < half ? p0 : cut;
+        u_end = blockIdx.x < half ? cut : p1;
+    }
+    if (young_prio && blockIdx.x >= gridDim.x / 2) {
+        if (young_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (young_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
     if (u_begin >= u_end) return;
 
     const uint32_t inst_first = u_begin / units_per_inst;
@@ -356,7 +378,8 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         }
         uint32_t base = vb;
         uint32_t v = base + lane;
-        VertexIn<MASK> cur = load_vertex<NT, MASK>(a, v < ve ? v : 0);
+        // (PREFETCH == 3: a lane past the end of the wave's range works on the range's last vertex, see below)
+        VertexIn<MASK> cur = load_vertex<NT, MASK>(a, v < ve ? v : (PREFETCH == 3 && base < ve ? ve - 1 : 0));
         VertexIn<MASK> nx1;
         if constexpr (PREFETCH == 2) {
             const uint32_t v1 = base + vstep + lane;
@@ -378,6 +401,43 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         if constexpr (PREFETCH == 2) pin_vertex(nx1);
         if constexpr (PROBE) { if (inst == inst_first) pt1 = __builtin_amdgcn_s_memrealtime(); }
 
+        if constexpr (PREFETCH == 3) {
+            // Two vertex buffers that swap roles (no register copies: a copy needs every outstanding load AND store to
+            // have landed, which drains the wave's memory pipeline once per unit).  The body is straight-line
+            // vector-memory code -- five loads, three stores, always: a lane past the end of the wave's range works on
+            // the range's LAST vertex instead (same inputs, same arithmetic, same bytes stored to the same address as
+            // the lane that owns it) -- so the compiler's vmcnt bookkeeping is exact and the math waits for its own
+            // unit's loads only, with the previous unit's stores and the next unit's loads still in flight.
+            const uint32_t v_last = ve - 1;
+            auto half = [&](VertexIn<MASK>& c_, uint32_t v_c, VertexIn<MASK>& n_, uint32_t v_n) {
+                n_ = load_vertex<NT, MASK>(a, v_n);
+                pin_vertex(c_);   // the math's first touch of the loaded registers is here, not on the back edge
+                const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
+                                                           c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
+                const size_t ov = (size_t)inst * a.n_verts + v_c;
+                if constexpr (MASK & 1) st3<NT>(a.out_pos + ov * 3, o.px, o.py, o.pz);
+                if constexpr (MASK & 2) st3<NT>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
+                if constexpr (MASK & 4)
+                    stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, c_.t.w});
+            };
+            if (base < ve) {   // wave-uniform
+                VertexIn<MASK> other;
+                uint32_t vc = v < v_last ? v : v_last;   // what `cur` was loaded from
+                for (;;) {
+                    uint32_t vn = v + vstep;
+                    vn = vn < v_last ? vn : v_last;
+                    half(cur, vc, other, vn);
+                    base += vstep; v += vstep;
+                    if (base >= ve) break;
+                    uint32_t vm = v + vstep;
+                    vm = vm < v_last ? vm : v_last;
+                    half(other, vn, cur, vm);
+                    base += vstep; v += vstep;
+                    vc = vm;
+                    if (base >= ve) break;
+                }
+            }
+        } else
         while (base < ve) {  // wave-uniform
             const uint32_t bn = base + vstep;
             const uint32_t vn = bn + lane;
@@ -391,8 +451,8 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
                 nxt = nx1;                                  // loaded one iteration ago
                 if (b2 < ve) nx1 = load_vertex<NT, MASK>(a, v2 < ve ? v2 : 0);
             }
-            const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.px,
-                                                       cur.py, cur.pz, cur.nx, cur.ny, cur.nz,
+            const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.p.x,
+                                                       cur.p.y, cur.p.z, cur.n.x, cur.n.y, cur.n.z,
                                                        cur.t.x, cur.t.y, cur.t.z);
             if (v < ve) {
                 const size_t ov = (size_t)inst * a.n_verts + v;
@@ -407,6 +467,205 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
             cur = nxt;
             base = bn;
             v = vn;
+        }
+    }
+    if constexpr (PROBE) {
+        const uint64_t pt2 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t pt3 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            uint64_t* r = probe + ((size_t)blockIdx.x * WPB + wave) * 4;
+            r[0] = pt0; r[1] = pt1; r[2] = pt2; r[3] = pt3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// lbs_skin_dyn: the single-instance kernel with its work drawn at run time.
+//
+// Why: a 1 M-vertex launch lasts ~16 us and gives a wave only ~4 units of 64 vertices, so with equal static shares
+// the launch ends when its unluckiest wave does -- the measured timeline (profiles/r01_timeline.json) has the
+// first-dispatched workgroup of every CU done at 12-13 us, the second at ~16.8 us, whole CUs anywhere between 13.3 and
+// 19 us, for a launch that would take ~16 us if everything ended together.  Here
+//   * the units are grouped into chunks of C = 2^c consecutive units (C * 6.4 KB of traffic);
+//   * every workgroup owns `n_static` chunks up front (no synchronisation on the bulk of the stream), the rest sits in
+//     kSchedHeads pools, each a device-scope counter on its own cache line (one counter retires ~88 draws/us; the
+//     tail needs ~250/us);
+//   * inside a workgroup, waves draw UNITS with an LDS atomic (ticket t -> chunk slot t / C, unit t % C of it), so a
+//     wave that is served faster simply takes more; the wave that draws the first unit of slot s requests the chunk
+//     of slot s + L from the pools (one lane, one returning global atomic, issued ahead of the wave's own vertex loads
+//     and consumed behind them) and publishes it in an LDS ring -- the ~1 us of the global atomic is hidden L chunks
+//     ahead of its use;
+//   * an exhausted pool sends the workgroup on to the next one (so a slow XCD's pool is finished by the others);
+//     the last workgroup to leave zeroes the counters for the next launch (launches that may overlap use different
+//     counter sets).
+// Which workgroup skins a unit changes nothing in the arithmetic: results stay bit-identical to lbs_skin.
+// Nothing here depends on dispatch order or placement for correctness.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kDynRing = 8;        // published chunk slots per workgroup
+constexpr uint32_t kDynAhead = 2;       // a slot's chunk is requested this many slots before its first unit is drawn
+constexpr uint32_t kNoChunk = 0xffffffffu;
+
+struct DynLds {
+    uint32_t ticket;      // next unit ticket of the workgroup
+    uint32_t exited;      // waves that have left
+    uint32_t head;        // pool this workgroup draws from next
+    uint32_t exhausted;   // every pool has been seen empty
+    unsigned long long ring[kDynRing];   // {chunk, slot + 1}
+};
+
+struct DynParams {
+    uint32_t total_units, c_log2, n_static, n_chunks;   // n_static chunks per workgroup are its own; gridDim.x * n_static <= n_chunks
+    uint32_t* sched;                                    // kSchedWords words of this launch's counter set
+};
+
+// One lane: take a chunk from the pools, or kNoChunk.
+__device__ __forceinline__ uint32_t dyn_pool_draw(const DynParams& d, DynLds* q, uint32_t h, uint32_t first) {
+    const uint32_t pool0 = gridDim.x * d.n_static;
+    const uint32_t n_dyn = d.n_chunks - pool0;
+    uint32_t c = first;     // the draw that was issued ahead, from pool h
+    for (uint32_t tries = 0;; ++tries) {
+        const uint32_t b0 = (uint32_t)(((uint64_t)n_dyn * h) / kSchedHeads);
+        const uint32_t b1 = (uint32_t)(((uint64_t)n_dyn * (h + 1)) / kSchedHeads);
+        if (c < b1 - b0) return pool0 + b0 + c;
+        if (tries + 1 == kSchedHeads) break;
+        h = (h + 1) % kSchedHeads;
+        __hip_atomic_store(&q->head, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = __hip_atomic_fetch_add(d.sched + h * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(&q->exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return kNoChunk;
+}
+
+template <int BLOCK, bool EXACT, int MASK, bool PROBE = false>
+__global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, DynParams d, uint64_t* probe = nullptr) {
+    uint64_t pt0 = 0, pt1 = 0;
+    if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* rows = reinterpret_cast<f32x4*>(smem);
+    f32x4* row3 = rows + 3 * a.n_bones;
+    uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);   // 16 words
+    DynLds* q = reinterpret_cast<DynLds*>(wave_flag + 16);
+
+    constexpr uint32_t WPB = BLOCK / 64;
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t cmask = (1u << d.c_log2) - 1;
+    const uint32_t slots_at_start = (WPB - 1) >> d.c_log2;   // the waves' first units are tickets 0 .. WPB-1
+
+    // A ticket's unit, or kNoChunk when the work is finished (wave-uniform; lane 0's view is broadcast).
+    auto resolve = [&](uint32_t t) -> uint32_t {
+        const uint32_t slot = t >> d.c_log2;
+        uint32_t chunk;
+        if (slot < d.n_static) {
+            chunk = blockIdx.x * d.n_static + slot;
+        } else {
+            const uint32_t k = slot - d.n_static;
+            unsigned long long e;
+            do {   // published kDynAhead slots ago: normally there already
+                e = __hip_atomic_load(&q->ring[k % kDynRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } while ((uint32_t)(e >> 32) != k + 1);
+            chunk = (uint32_t)e;
+            if (chunk == kNoChunk) return kNoChunk;
+        }
+        return (chunk << d.c_log2) + (t & cmask);
+    };
+    auto publish = [&](uint32_t slot, uint32_t chunk) {
+        const uint32_t k = slot - d.n_static;
+        __hip_atomic_store(&q->ring[k % kDynRing], ((unsigned long long)(k + 1) << 32) | chunk, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    const PaletteRegs pr = palette_fetch(a.palette, a.n_bones, tid);
+    // Every drawn unit costs five loads and three stores, always: a lane past the end of the mesh (the last unit, or a
+    // ticket of the last chunk that has no unit behind it) works on the LAST vertex instead -- same inputs, same
+    // arithmetic, the same bytes stored to the same address as the lane that owns it.  The loop body is therefore
+    // straight-line vector-memory code and the compiler's vmcnt bookkeeping is exact: the math waits for its own unit's
+    // loads only, with the previous unit's stores and the next unit's loads still in flight.
+    const uint32_t v_last = a.n_verts - 1;
+    const bool have = wave < (d.n_static << d.c_log2);   // static by construction (host); otherwise nothing to do
+    uint32_t v = (have ? resolve(wave) : 0u) * 64 + lane;
+    v = v < v_last ? v : v_last;
+    VertexIn<MASK> cur = load_vertex<true, MASK>(a, v);
+
+    if (tid == 0) {
+        q->ticket = WPB;
+        q->exited = 0;
+        q->head = blockIdx.x % kSchedHeads;
+        q->exhausted = 0;
+        for (uint32_t i = 0; i < kDynRing; ++i) q->ring[i] = 0;
+        // chunks whose requesting draw is one of the implicit first tickets (only when n_static is very small)
+        for (uint32_t slot = d.n_static; slot <= slots_at_start + kDynAhead; ++slot) {
+            const uint32_t c0 = __hip_atomic_fetch_add(d.sched + (blockIdx.x % kSchedHeads) * 32, 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+            publish(slot, dyn_pool_draw(d, q, blockIdx.x % kSchedHeads, c0));
+        }
+    }
+    const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
+    const bool wave_pj = __any(pj) != 0;
+    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
+    __syncthreads();
+    bool projective = false;
+#pragma unroll
+    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
+    pin_vertex(cur);
+    if constexpr (PROBE) pt1 = __builtin_amdgcn_s_memrealtime();
+
+    // One pipeline step: draw the next unit and issue its loads into `nxt` (always: a wave without a next unit reads
+    // the first unit once more), skin `cur`, store it.  The two vertex buffers swap roles from step to step -- no
+    // register copies, which would need every load to have landed.  Returns false when the work is finished.
+    auto step = [&](VertexIn<MASK>& c_, uint32_t v_cur, VertexIn<MASK>& nxt_, uint32_t& v_nxt) -> bool {
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&q->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        t = __builtin_amdgcn_readfirstlane(t);
+        // the first draw of a slot requests the chunk kDynAhead slots on: the pool draw is issued now, ahead of this
+        // wave's own loads (returns come back in order), and consumed after they are issued
+        const uint32_t want = (t >> d.c_log2) + kDynAhead;
+        const bool requester = (t & cmask) == 0 && want >= d.n_static && (t >> d.c_log2) > slots_at_start;
+        uint32_t drawn = 0, drawn_from = 0;
+        bool pool_open = false;
+        if (requester && lane == 0) {
+            pool_open = __hip_atomic_load(&q->exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+            if (pool_open) {
+                drawn_from = __hip_atomic_load(&q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                drawn = __hip_atomic_fetch_add(d.sched + drawn_from * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        const uint32_t un = __builtin_amdgcn_readfirstlane(resolve(t));
+        uint32_t vn = (un != kNoChunk ? un : 0u) * 64 + lane;   // finished: one more (unused) load of the first unit
+        vn = vn < v_last ? vn : v_last;
+        nxt_ = load_vertex<true, MASK>(a, vn);
+        v_nxt = vn;
+        if (requester && lane == 0) publish(want, pool_open ? dyn_pool_draw(d, q, drawn_from, drawn) : kNoChunk);
+
+        // opaque use point: whatever the math does to the loaded registers first (pairing them up for the packed
+        // instructions) happens HERE, behind the issue of the next unit's loads, not on the loop's back edge
+        pin_vertex(c_);
+        const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
+                                                   c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
+        if constexpr (MASK & 1) st3<true>(a.out_pos + (size_t)v_cur * 3, o.px, o.py, o.pz);
+        if constexpr (MASK & 2) st3<true>(a.out_nrm + (size_t)v_cur * 3, o.nx, o.ny, o.nz);
+        if constexpr (MASK & 4)
+            stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + v_cur, f32x4{o.tx, o.ty, o.tz, c_.t.w});
+        return un != kNoChunk;
+    };
+    if (have) {   // wave-uniform
+        VertexIn<MASK> other;
+        uint32_t v_other;
+        for (;;) {
+            if (!step(cur, v, other, v_other)) break;
+            if (!step(other, v_other, cur, v)) break;
+        }
+    }
+    // leave: the last wave of the last workgroup zeroes the counters for the next launch that uses this set
+    if (lane == 0) {
+        const uint32_t e = __hip_atomic_fetch_add(&q->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (e == WPB - 1) {
+            const uint32_t g = __hip_atomic_fetch_add(d.sched + kSchedHeads * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == gridDim.x - 1) {
+                for (uint32_t h = 0; h <= kSchedHeads; ++h)
+                    __hip_atomic_store(d.sched + h * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if constexpr (PROBE) {
@@ -472,8 +731,8 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
         const u32x4 fl = *reinterpret_cast<const u32x4*>(flags + cur * 4);
         const bool projective = (fl.x | fl.y | fl.z | fl.w) != 0;
         // the crowd kernel is VALU-bound, so its fused mode blends the matrices first (see skin_vertex_blended)
-        const Skinned o = skin_vertex<EXACT, MASK, true>(rows, row3, projective, vin.id, vin.w, vin.px, vin.py,
-                                                         vin.pz, vin.nx, vin.ny, vin.nz, vin.t.x, vin.t.y, vin.t.z);
+        const Skinned o = skin_vertex<EXACT, MASK, true>(rows, row3, projective, vin.id, vin.w, vin.p.x, vin.p.y,
+                                                         vin.p.z, vin.n.x, vin.n.y, vin.n.z, vin.t.x, vin.t.y, vin.t.z);
         if (live) {
             const size_t ov = (size_t)inst * a.n_verts + v;
             if constexpr (MASK & 1) st3<true>(a.out_pos + ov * 3, o.px, o.py, o.pz);
@@ -553,13 +812,15 @@ static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s
     if constexpr (BLOCK == 512 && EXACT && NT && PREFETCH == 1 && MASK == 7) {
         if (t.probe && t.probe_buf) {   // debug timeline, only for the default variant
             if ((size_t)grid * (BLOCK / 64) * 4 > t.probe_words) return hipErrorInvalidValue;
+            const uint32_t asym_p = (t.asym > 0 && t.asym < 64 && grid == 2u * kCUs) ? (uint32_t)t.asym : 0u;
             hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a,
-                               upi, total, (uint32_t)t.split, t.probe_buf);
+                               upi, total, (uint32_t)t.split, t.probe_buf, asym_p, (uint32_t)t.young_prio);
             return hipGetLastError();
         }
     }
+    const uint32_t asym = (t.asym > 0 && t.asym < 64 && grid == 2u * kCUs) ? (uint32_t)t.asym : 0u;
     hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
-                       upi, total, (uint32_t)t.split, (uint64_t*)nullptr);
+                       upi, total, (uint32_t)t.split, (uint64_t*)nullptr, asym, (uint32_t)t.young_prio);
     return hipGetLastError();
 }
 
@@ -580,8 +841,10 @@ static hipError_t launch_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t 
 
 template <int BLOCK>
 static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    if (t.prefetch == 3 && t.nt)   // one unit ahead, two register sets that swap roles
+        return t.exact ? launch_mask<BLOCK, true, true, 3>(a, t, s) : launch_mask<BLOCK, false, true, 3>(a, t, s);
     if constexpr (BLOCK != 1024) {
-        if (t.prefetch >= 2 && t.nt)   // two units ahead: streaming variants of the 256 / 512 workgroups only
+        if (t.prefetch == 2 && t.nt)   // two units ahead: streaming variants of the 256 / 512 workgroups only
             return t.exact ? launch_mask<BLOCK, true, true, 2>(a, t, s) : launch_mask<BLOCK, false, true, 2>(a, t, s);
     }
     const int key = (t.exact ? 4 : 0) | (t.nt ? 2 : 0) | (t.prefetch ? 1 : 0);
@@ -597,8 +860,63 @@ static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t
     }
 }
 
+// lbs_skin_dyn launch: the grid is what is resident (16 waves per CU at the kernel's register budget), the counter
+// set rotates per launch.  Returns hipErrorNotReady when the launch does not qualify (the caller takes the static kernel).
+template <int BLOCK, bool EXACT, int MASK>
+static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    constexpr uint32_t WPB = BLOCK / 64;
+    const uint32_t total = (a.n_verts + 63) / 64;
+    const uint32_t c_log2 = (uint32_t)t.dyn_chunk_log2;
+    const uint32_t n_chunks = (total + (1u << c_log2) - 1) >> c_log2;
+    const uint32_t resident = 1024 / BLOCK;
+    const uint32_t grid = (uint32_t)kCUs * ((t.dyn_bpc > 0 && (uint32_t)t.dyn_bpc < resident) ? (uint32_t)t.dyn_bpc : resident);
+    const uint32_t n_static = (uint32_t)(((uint64_t)n_chunks * (uint32_t)t.dyn_static_pct / 100) / grid);
+    if (n_static == 0 || (n_static << c_log2) < WPB) return hipErrorNotReady;   // too small to be worth drawing
+    DynParams d;
+    d.total_units = total; d.c_log2 = c_log2; d.n_static = n_static; d.n_chunks = n_chunks;
+    d.sched = t.sched + (size_t)(t.sched_seq++ % kSchedSets) * kSchedWords;
+    const size_t lds = (size_t)a.n_bones * 64 + 64 + sizeof(DynLds);
+    if constexpr (EXACT && MASK == 7) {
+        if (t.probe && t.probe_buf) {
+            if ((size_t)grid * WPB * 4 > t.probe_words) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a, d, t.probe_buf);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a, d, (uint64_t*)nullptr);
+    return hipGetLastError();
+}
+
+template <int BLOCK, bool EXACT>
+static hipError_t launch_dyn_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
+    switch (mask) {
+        case 1: return launch_dyn_one<BLOCK, EXACT, 1>(a, t, s);
+        case 2: return launch_dyn_one<BLOCK, EXACT, 2>(a, t, s);
+        case 3: return launch_dyn_one<BLOCK, EXACT, 3>(a, t, s);
+        case 4: return launch_dyn_one<BLOCK, EXACT, 4>(a, t, s);
+        case 5: return launch_dyn_one<BLOCK, EXACT, 5>(a, t, s);
+        case 6: return launch_dyn_one<BLOCK, EXACT, 6>(a, t, s);
+        case 7: return launch_dyn_one<BLOCK, EXACT, 7>(a, t, s);
+        default: return hipSuccess;
+    }
+}
+
+static hipError_t launch_dyn(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    if (!t.sched || a.n_instances != 1 || t.dyn_chunk_log2 < 0 || t.dyn_chunk_log2 > 6) return hipErrorNotReady;
+    switch (t.block) {
+        case 1024: return t.exact ? launch_dyn_mask<1024, true>(a, t, s) : launch_dyn_mask<1024, false>(a, t, s);
+        case 512: return t.exact ? launch_dyn_mask<512, true>(a, t, s) : launch_dyn_mask<512, false>(a, t, s);
+        default: return t.exact ? launch_dyn_mask<256, true>(a, t, s) : launch_dyn_mask<256, false>(a, t, s);
+    }
+}
+
 hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream) {
     if (a.n_verts == 0 || a.n_instances == 0) return hipSuccess;
+    if (t.dyn && a.n_instances == 1 && t.nt && t.prefetch) {
+        const hipError_t e = launch_dyn(a, t, stream);
+        if (e != hipErrorNotReady) return e;
+    }
     // crowds (one mesh, many palettes) keep the vertices in registers and loop over instances
     if (t.crowd > 0 || (t.crowd < 0 && a.n_instances >= 4)) return launch_crowd(a, t, stream);
     switch (t.block) {
@@ -675,8 +993,8 @@ __global__ __launch_bounds__(512) void lbs_skin_batch(const LbsSegDev* __restric
             const uint32_t vn = bn + lane;
             VertexIn<MASK> nxt;
             if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
-            const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.px,
-                                                       cur.py, cur.pz, cur.nx, cur.ny, cur.nz,
+            const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.p.x,
+                                                       cur.p.y, cur.p.z, cur.n.x, cur.n.y, cur.n.z,
                                                        cur.t.x, cur.t.y, cur.t.z);
             if (v < ve) {
                 if constexpr (MASK & 1) st3<NT>(a.out_pos + (size_t)v * 3, o.px, o.py, o.pz);
