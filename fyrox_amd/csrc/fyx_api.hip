@@ -474,9 +474,7 @@ int fyx_init(fyx_ctx** out_ctx, int device_ordinal) {
     c->device = device_ordinal;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->aabb_partials), (6 * 2048 + 8) * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_u32), 64) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->lbs.sched), fyx::kSchedSets * fyx::kSchedWords * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(c->lbs.sched, 0, fyx::kSchedSets * fyx::kSchedWords * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&c->d_u32), 64) != hipSuccess) {
         fyx_shutdown(c);
         return FYX_ERR_HIP;
     }
@@ -502,7 +500,6 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->aabb_partials) (void)hipFree(c->aabb_partials);
     if (c->d_u32) (void)hipFree(c->d_u32);
     if (c->lbs.probe_buf) (void)hipFree(c->lbs.probe_buf);
-    if (c->lbs.sched) (void)hipFree(c->lbs.sched);
     for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
         if (c->workers[w]) { (void)hipStreamSynchronize(c->workers[w]); (void)hipStreamDestroy(c->workers[w]); }
         if (c->worker_done[w]) (void)hipEventDestroy(c->worker_done[w]);
@@ -570,8 +567,6 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.probe")) return &c->lbs.probe;
     if (!strcmp(key, "lbs.split")) return &c->lbs.split;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
-    if (!strcmp(key, "lbs.dyn_chunk_log2")) return &c->lbs.dyn_chunk_log2;
-    if (!strcmp(key, "lbs.dyn_static_pct")) return &c->lbs.dyn_static_pct;
     if (!strcmp(key, "lbs.dyn_bpc")) return &c->lbs.dyn_bpc;
     if (!strcmp(key, "lbs.asym")) return &c->lbs.asym;
     if (!strcmp(key, "lbs.young_prio")) return &c->lbs.young_prio;
@@ -605,10 +600,6 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");
     if (slot == &c->lbs.blocks_per_cu && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.blocks_per_cu must be 1..64");
-    if (slot == &c->lbs.dyn_chunk_log2 && (value < 0 || value > 6))
-        return fail(c, FYX_ERR_INVALID_ARG, "lbs.dyn_chunk_log2 must be 0..6");
-    if (slot == &c->lbs.dyn_static_pct && (value < 0 || value > 100))
-        return fail(c, FYX_ERR_INVALID_ARG, "lbs.dyn_static_pct must be 0..100");
     if (slot == &c->lbs.dyn_bpc && (value < 0 || value > 4)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.dyn_bpc must be 0..4");
     if (slot == &c->lbs.asym && (value < 0 || value > 63)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.asym must be 0..63");
     if (slot == &c->lbs.young_prio && (value < 0 || value > 3)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.young_prio must be 0..3");

@@ -22,19 +22,12 @@ struct LbsTuning {
     int probe = 0;           // debug: per-wave timeline of the default lbs_skin variant into probe_buf
     uint64_t* probe_buf = nullptr;
     size_t probe_words = 0;
-    // Work distribution of single-instance launches (lbs_skin_dyn, see lbs_kernels.hip):
-    int dyn = 0;             // 1: chunks of 64-vertex units are drawn at run time (static head, shared tail pools)
-    int dyn_chunk_log2 = 2;  // units per chunk = 1 << dyn_chunk_log2
-    int dyn_bpc = 0;         // workgroups per CU of the drawn launch; 0 = what is resident (1024 / block)
-    int dyn_static_pct = 60; // share of the chunks that is dealt out statically (the rest is drawn from the pools)
-    int asym = 0;            // static kernel, 2 workgroups per CU: the first-dispatched one owns asym/64 of the pair's units (0 = halves)
-    int young_prio = 0;      // static kernel: s_setprio for the second-dispatched half of the grid
-    uint32_t* sched = nullptr;       // kSchedSets x kSchedWords words of pool heads, zero between launches
-    mutable uint32_t sched_seq = 0;  // launches so far: picks the set
+    // Large single-instance launches (lbs_skin_dyn, see lbs_kernels.hip):
+    int dyn = 0;             // 1: one workgroup per resident CU slot, units drawn from an LDS ticket counter
+    int dyn_bpc = 0;         // workgroups per CU of that launch; 0 = what is resident (1024 / block)
+    int asym = 0;            // lbs_skin, 2 workgroups per CU: the first-dispatched one owns asym/64 of the pair's units (0 = halves)
+    int young_prio = 0;      // lbs_skin: s_setprio for the second-dispatched half of the grid
 };
-constexpr uint32_t kSchedSets = 8;     // more than the launches that can overlap (<= 4 launch streams)
-constexpr uint32_t kSchedHeads = 8;
-constexpr uint32_t kSchedWords = 32 * (kSchedHeads + 1);   // every head and the exit counter on a 128-byte line of its own
 
 struct LbsArgs {
     const float* pos;        // 3N packed xyz

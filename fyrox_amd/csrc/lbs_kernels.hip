@@ -481,192 +481,114 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
 }
 
 // ---------------------------------------------------------------------------------------
-// lbs_skin_dyn: the single-instance kernel with its work drawn at run time.
+// lbs_skin_dyn: the single-instance kernel for large meshes, built around how a LONE launch spends its ~18 us
+// (timeline: tools/probe_timeline.py, profiles/r01_timeline.json for lbs_skin).
 //
-// Why: a 1 M-vertex launch lasts ~16 us and gives a wave only ~4 units of 64 vertices, so with equal static shares
-// the launch ends when its unluckiest wave does -- the measured timeline (profiles/r01_timeline.json) has the
-// first-dispatched workgroup of every CU done at 12-13 us, the second at ~16.8 us, whole CUs anywhere between 13.3 and
-// 19 us, for a launch that would take ~16 us if everything ended together.  Here
-//   * the units are grouped into chunks of C = 2^c consecutive units (C * 6.4 KB of traffic);
-//   * every workgroup owns `n_static` chunks up front (no synchronisation on the bulk of the stream), the rest sits in
-//     kSchedHeads pools, each a device-scope counter on its own cache line (one counter retires ~88 draws/us; the
-//     tail needs ~250/us);
-//   * inside a workgroup, waves draw UNITS with an LDS atomic (ticket t -> chunk slot t / C, unit t % C of it), so a
-//     wave that is served faster simply takes more; the wave that draws the first unit of slot s requests the chunk
-//     of slot s + L from the pools (one lane, one returning global atomic, issued ahead of the wave's own vertex loads
-//     and consumed behind them) and publishes it in an LDS ring -- the ~1 us of the global atomic is hidden L chunks
-//     ahead of its use;
-//   * an exhausted pool sends the workgroup on to the next one (so a slow XCD's pool is finished by the others);
-//     the last workgroup to leave zeroes the counters for the next launch (launches that may overlap use different
-//     counter sets).
-// Which workgroup skins a unit changes nothing in the arithmetic: results stay bit-identical to lbs_skin.
-// Nothing here depends on dispatch order or placement for correctness.
+//   * One workgroup per CU slot that is resident anyway (1024 threads = all 16 waves of a CU at this register budget,
+//     or two of 512), each owning one contiguous range of 64-vertex units.  Inside the workgroup the waves DRAW their
+//     units from an LDS ticket counter (one ds_add_rtn per unit) instead of taking every WPB-th one: a wave that is
+//     served faster takes more, so the workgroup ends when its work does, not when the wave that happened to get 4
+//     units instead of 3 does (measured spread inside a workgroup of lbs_skin: 1.9 us of a 16 us launch), and with one
+//     workgroup per CU the whole CU's share is balanced over its 16 waves -- lbs_skin's second-dispatched workgroup
+//     loses the arbitration inside its CU and finishes 3.4 us after the first.  (Drawing chunks from device-scope
+//     counters shared by all CUs was measured too: a returning global atomic queues behind the CU's own streaming
+//     loads, several us each -- 27 us per launch at best.  Nothing here leaves the CU.)
+//   * The palette goes first and wide: every thread fetches 16-byte columns of the palette (one dense 1 KB request
+//     per wave, the wave's FIRST vector-memory instruction), so the palette of the whole workgroup sits at the head of
+//     the CU's memory queue instead of behind other waves' vertex loads (lbs_skin: staged after 3.1 us median, 6.8 us
+//     worst, and until then a wave has nothing but its first unit in flight).
+//   * Two units per wave are requested before the staging barrier, and the loop keeps two in flight: a register set
+//     is refilled as soon as its math is done, while the other set's loads have had a whole unit's time to land.
+//   * Every unit costs five loads and three stores, always: a lane past the end of the mesh works on the LAST vertex
+//     (same inputs, same arithmetic, the same bytes stored to the same address as the lane that owns it), so the loop
+//     body is straight-line vector-memory code and the compiler's vmcnt bookkeeping is exact.
+// Which wave skins a unit changes nothing in the arithmetic: results are bit-identical to lbs_skin's.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t kDynRing = 8;        // published chunk slots per workgroup
-constexpr uint32_t kDynAhead = 2;       // a slot's chunk is requested this many slots before its first unit is drawn
-constexpr uint32_t kNoChunk = 0xffffffffu;
-
-struct DynLds {
-    uint32_t ticket;      // next unit ticket of the workgroup
-    uint32_t exited;      // waves that have left
-    uint32_t head;        // pool this workgroup draws from next
-    uint32_t exhausted;   // every pool has been seen empty
-    unsigned long long ring[kDynRing];   // {chunk, slot + 1}
-};
-
-struct DynParams {
-    uint32_t total_units, c_log2, n_static, n_chunks;   // n_static chunks per workgroup are its own; gridDim.x * n_static <= n_chunks
-    uint32_t* sched;                                    // kSchedWords words of this launch's counter set
-};
-
-// One lane: take a chunk from the pools, or kNoChunk.
-__device__ __forceinline__ uint32_t dyn_pool_draw(const DynParams& d, DynLds* q, uint32_t h, uint32_t first) {
-    const uint32_t pool0 = gridDim.x * d.n_static;
-    const uint32_t n_dyn = d.n_chunks - pool0;
-    uint32_t c = first;     // the draw that was issued ahead, from pool h
-    for (uint32_t tries = 0;; ++tries) {
-        const uint32_t b0 = (uint32_t)(((uint64_t)n_dyn * h) / kSchedHeads);
-        const uint32_t b1 = (uint32_t)(((uint64_t)n_dyn * (h + 1)) / kSchedHeads);
-        if (c < b1 - b0) return pool0 + b0 + c;
-        if (tries + 1 == kSchedHeads) break;
-        h = (h + 1) % kSchedHeads;
-        __hip_atomic_store(&q->head, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        c = __hip_atomic_fetch_add(d.sched + h * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __hip_atomic_store(&q->exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return kNoChunk;
-}
-
 template <int BLOCK, bool EXACT, int MASK, bool PROBE = false>
-__global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, DynParams d, uint64_t* probe = nullptr) {
+__global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint64_t* probe = nullptr) {
     uint64_t pt0 = 0, pt1 = 0;
     if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
     uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);   // 16 words
-    DynLds* q = reinterpret_cast<DynLds*>(wave_flag + 16);
+    uint32_t* ticket = wave_flag + 16;
 
     constexpr uint32_t WPB = BLOCK / 64;
+    constexpr int PIECES = 1024 / BLOCK;     // 16-byte palette columns per thread (n_bones <= 256)
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    const uint32_t cmask = (1u << d.c_log2) - 1;
-    const uint32_t slots_at_start = (WPB - 1) >> d.c_log2;   // the waves' first units are tickets 0 .. WPB-1
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t n_units = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x) - u_begin;
 
-    // A ticket's unit, or kNoChunk when the work is finished (wave-uniform; lane 0's view is broadcast).
-    auto resolve = [&](uint32_t t) -> uint32_t {
-        const uint32_t slot = t >> d.c_log2;
-        uint32_t chunk;
-        if (slot < d.n_static) {
-            chunk = blockIdx.x * d.n_static + slot;
-        } else {
-            const uint32_t k = slot - d.n_static;
-            unsigned long long e;
-            do {   // published kDynAhead slots ago: normally there already
-                e = __hip_atomic_load(&q->ring[k % kDynRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } while ((uint32_t)(e >> 32) != k + 1);
-            chunk = (uint32_t)e;
-            if (chunk == kNoChunk) return kNoChunk;
-        }
-        return (chunk << d.c_log2) + (t & cmask);
-    };
-    auto publish = [&](uint32_t slot, uint32_t chunk) {
-        const uint32_t k = slot - d.n_static;
-        __hip_atomic_store(&q->ring[k % kDynRing], ((unsigned long long)(k + 1) << 32) | chunk, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
-    const PaletteRegs pr = palette_fetch(a.palette, a.n_bones, tid);
-    // Every drawn unit costs five loads and three stores, always: a lane past the end of the mesh (the last unit, or a
-    // ticket of the last chunk that has no unit behind it) works on the LAST vertex instead -- same inputs, same
-    // arithmetic, the same bytes stored to the same address as the lane that owns it.  The loop body is therefore
-    // straight-line vector-memory code and the compiler's vmcnt bookkeeping is exact: the math waits for its own unit's
-    // loads only, with the previous unit's stores and the next unit's loads still in flight.
+    // palette columns first: column c of bone b is piece 4 b + c
+    const uint32_t n_pieces = a.n_bones * 4;
+    f32x4 col[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
+        col[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
+    }
+    // the wave's first two units (tickets wave and WPB + wave; the launcher guarantees n_units >= 2 WPB)
     const uint32_t v_last = a.n_verts - 1;
-    const bool have = wave < (d.n_static << d.c_log2);   // static by construction (host); otherwise nothing to do
-    uint32_t v = (have ? resolve(wave) : 0u) * 64 + lane;
-    v = v < v_last ? v : v_last;
-    VertexIn<MASK> cur = load_vertex<true, MASK>(a, v);
+    auto vertex_of = [&](uint32_t t) -> uint32_t {
+        const uint32_t v = (u_begin + t) * 64 + lane;
+        return v < v_last ? v : v_last;
+    };
+    uint32_t vA = vertex_of(wave), vB = vertex_of(WPB + wave);
+    VertexIn<MASK> A = load_vertex<true, MASK>(a, vA);
+    VertexIn<MASK> B = load_vertex<true, MASK>(a, vB);
 
-    if (tid == 0) {
-        q->ticket = WPB;
-        q->exited = 0;
-        q->head = blockIdx.x % kSchedHeads;
-        q->exhausted = 0;
-        for (uint32_t i = 0; i < kDynRing; ++i) q->ring[i] = 0;
-        // chunks whose requesting draw is one of the implicit first tickets (only when n_static is very small)
-        for (uint32_t slot = d.n_static; slot <= slots_at_start + kDynAhead; ++slot) {
-            const uint32_t c0 = __hip_atomic_fetch_add(d.sched + (blockIdx.x % kSchedHeads) * 32, 1u, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-            publish(slot, dyn_pool_draw(d, q, blockIdx.x % kSchedHeads, c0));
+    if (tid == 0) *ticket = 2 * WPB;
+    bool pj = false;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
+        if (piece < n_pieces) {
+            // packed-math layout (see stage_palette): A = (m00, m10, m01, m11)  B = (m02, m12, t0, t1)
+            // C = (m20, m21, m22, t2)  row3 = (m30, m31, m32, m33); column c = (m0c, m1c, m2c, m3c)
+            const uint32_t b = piece >> 2, c = piece & 3;
+            float* r = reinterpret_cast<float*>(rows + b * 3);
+            *reinterpret_cast<f32x2*>(r + 2 * c) = f32x2{col[i].x, col[i].y};
+            r[8 + c] = col[i].z;
+            reinterpret_cast<float*>(row3 + b)[c] = col[i].w;
+            pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);
         }
     }
-    const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
     const bool wave_pj = __any(pj) != 0;
     if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
     __syncthreads();
     bool projective = false;
 #pragma unroll
     for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
-    pin_vertex(cur);
+    pin_vertex(A);
+    pin_vertex(B);
     if constexpr (PROBE) pt1 = __builtin_amdgcn_s_memrealtime();
 
-    // One pipeline step: draw the next unit and issue its loads into `nxt` (always: a wave without a next unit reads
-    // the first unit once more), skin `cur`, store it.  The two vertex buffers swap roles from step to step -- no
-    // register copies, which would need every load to have landed.  Returns false when the work is finished.
-    auto step = [&](VertexIn<MASK>& c_, uint32_t v_cur, VertexIn<MASK>& nxt_, uint32_t& v_nxt) -> bool {
-        uint32_t t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(&q->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        t = __builtin_amdgcn_readfirstlane(t);
-        // the first draw of a slot requests the chunk kDynAhead slots on: the pool draw is issued now, ahead of this
-        // wave's own loads (returns come back in order), and consumed after they are issued
-        const uint32_t want = (t >> d.c_log2) + kDynAhead;
-        const bool requester = (t & cmask) == 0 && want >= d.n_static && (t >> d.c_log2) > slots_at_start;
-        uint32_t drawn = 0, drawn_from = 0;
-        bool pool_open = false;
-        if (requester && lane == 0) {
-            pool_open = __hip_atomic_load(&q->exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
-            if (pool_open) {
-                drawn_from = __hip_atomic_load(&q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                drawn = __hip_atomic_fetch_add(d.sched + drawn_from * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        const uint32_t un = __builtin_amdgcn_readfirstlane(resolve(t));
-        uint32_t vn = (un != kNoChunk ? un : 0u) * 64 + lane;   // finished: one more (unused) load of the first unit
-        vn = vn < v_last ? vn : v_last;
-        nxt_ = load_vertex<true, MASK>(a, vn);
-        v_nxt = vn;
-        if (requester && lane == 0) publish(want, pool_open ? dyn_pool_draw(d, q, drawn_from, drawn) : kNoChunk);
-
-        // opaque use point: whatever the math does to the loaded registers first (pairing them up for the packed
-        // instructions) happens HERE, behind the issue of the next unit's loads, not on the loop's back edge
-        pin_vertex(c_);
+    auto process = [&](VertexIn<MASK>& c_, uint32_t v_c) {
+        pin_vertex(c_);   // the math's first touch of the loaded registers is here
         const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
                                                    c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
-        if constexpr (MASK & 1) st3<true>(a.out_pos + (size_t)v_cur * 3, o.px, o.py, o.pz);
-        if constexpr (MASK & 2) st3<true>(a.out_nrm + (size_t)v_cur * 3, o.nx, o.ny, o.nz);
+        if constexpr (MASK & 1) st3<true>(a.out_pos + (size_t)v_c * 3, o.px, o.py, o.pz);
+        if constexpr (MASK & 2) st3<true>(a.out_nrm + (size_t)v_c * 3, o.nx, o.ny, o.nz);
         if constexpr (MASK & 4)
-            stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + v_cur, f32x4{o.tx, o.ty, o.tz, c_.t.w});
-        return un != kNoChunk;
+            stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + v_c, f32x4{o.tx, o.ty, o.tz, c_.t.w});
     };
-    if (have) {   // wave-uniform
-        VertexIn<MASK> other;
-        uint32_t v_other;
-        for (;;) {
-            if (!step(cur, v, other, v_other)) break;
-            if (!step(other, v_other, cur, v)) break;
-        }
-    }
-    // leave: the last wave of the last workgroup zeroes the counters for the next launch that uses this set
-    if (lane == 0) {
-        const uint32_t e = __hip_atomic_fetch_add(&q->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (e == WPB - 1) {
-            const uint32_t g = __hip_atomic_fetch_add(d.sched + kSchedHeads * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g == gridDim.x - 1) {
-                for (uint32_t h = 0; h <= kSchedHeads; ++h)
-                    __hip_atomic_store(d.sched + h * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+    // draw the next unit into a register set whose math is done; false when the workgroup's range is used up
+    auto refill = [&](VertexIn<MASK>& n_, uint32_t& v_n) -> bool {
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= n_units) return false;
+        v_n = vertex_of(t);
+        n_ = load_vertex<true, MASK>(a, v_n);
+        return true;
+    };
+    for (;;) {   // wave-uniform
+        process(A, vA);
+        if (!refill(A, vA)) { process(B, vB); break; }
+        process(B, vB);
+        if (!refill(B, vB)) { process(A, vA); break; }
     }
     if constexpr (PROBE) {
         const uint64_t pt2 = __builtin_amdgcn_s_memrealtime();
@@ -860,30 +782,24 @@ static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t
     }
 }
 
-// lbs_skin_dyn launch: the grid is what is resident (16 waves per CU at the kernel's register budget), the counter
-// set rotates per launch.  Returns hipErrorNotReady when the launch does not qualify (the caller takes the static kernel).
+// lbs_skin_dyn launch: the grid is what is resident (16 waves per CU at the kernel's register budget).  Returns
+// hipErrorNotReady when the launch does not qualify (the caller takes lbs_skin).
 template <int BLOCK, bool EXACT, int MASK>
 static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     constexpr uint32_t WPB = BLOCK / 64;
     const uint32_t total = (a.n_verts + 63) / 64;
-    const uint32_t c_log2 = (uint32_t)t.dyn_chunk_log2;
-    const uint32_t n_chunks = (total + (1u << c_log2) - 1) >> c_log2;
     const uint32_t resident = 1024 / BLOCK;
     const uint32_t grid = (uint32_t)kCUs * ((t.dyn_bpc > 0 && (uint32_t)t.dyn_bpc < resident) ? (uint32_t)t.dyn_bpc : resident);
-    const uint32_t n_static = (uint32_t)(((uint64_t)n_chunks * (uint32_t)t.dyn_static_pct / 100) / grid);
-    if (n_static == 0 || (n_static << c_log2) < WPB) return hipErrorNotReady;   // too small to be worth drawing
-    DynParams d;
-    d.total_units = total; d.c_log2 = c_log2; d.n_static = n_static; d.n_chunks = n_chunks;
-    d.sched = t.sched + (size_t)(t.sched_seq++ % kSchedSets) * kSchedWords;
-    const size_t lds = (size_t)a.n_bones * 64 + 64 + sizeof(DynLds);
+    if (total / grid < 2 * WPB) return hipErrorNotReady;   // every wave starts with two units of its own
+    const size_t lds = (size_t)a.n_bones * 64 + 64 + 16;
     if constexpr (EXACT && MASK == 7) {
         if (t.probe && t.probe_buf) {
             if ((size_t)grid * WPB * 4 > t.probe_words) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a, d, t.probe_buf);
+            hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a, total, t.probe_buf);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a, d, (uint64_t*)nullptr);
+    hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a, total, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -903,7 +819,7 @@ static hipError_t launch_dyn_mask(const LbsArgs& a, const LbsTuning& t, hipStrea
 }
 
 static hipError_t launch_dyn(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    if (!t.sched || a.n_instances != 1 || t.dyn_chunk_log2 < 0 || t.dyn_chunk_log2 > 6) return hipErrorNotReady;
+    if (a.n_instances != 1 || a.n_bones > 256) return hipErrorNotReady;
     switch (t.block) {
         case 1024: return t.exact ? launch_dyn_mask<1024, true>(a, t, s) : launch_dyn_mask<1024, false>(a, t, s);
         case 512: return t.exact ? launch_dyn_mask<512, true>(a, t, s) : launch_dyn_mask<512, false>(a, t, s);

@@ -38,8 +38,7 @@ for s in range(args.sets):
     outs.append((ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)))
 
 BASE = {"lbs.block": 512, "lbs.blocks_per_cu": 4, "lbs.prefetch": 1, "lbs.exact": 1, "lbs.nt": 1, "lbs.split": 0,
-        "lbs.dyn": 0, "lbs.dyn_chunk_log2": 2, "lbs.dyn_static_pct": 60, "lbs.dyn_bpc": 0, "lbs.asym": 0,
-        "lbs.young_prio": 0}
+        "lbs.dyn": 0, "lbs.dyn_bpc": 0, "lbs.asym": 0, "lbs.young_prio": 0}
 
 
 def configure(opts, streams):
@@ -78,12 +77,11 @@ for a in (36, 40, 44):
 variants.append(("static p3 bpc2 asym40", {"lbs.blocks_per_cu": 2, "lbs.asym": 40, "lbs.prefetch": 3}))
 for pr in (1, 3):
     variants.append((f"static p1 bpc2 prio{pr}", {"lbs.blocks_per_cu": 2, "lbs.young_prio": pr}))
-for blk in (512, 1024, 256):
-    for c in ((0, 1, 2, 3) if not args.quick else (1, 2)):
-        for pct in ((40, 60, 75, 90) if not args.quick else (60,)):
-            variants.append((f"dyn b{blk} c{1 << c} s{pct}", {"lbs.block": blk, "lbs.dyn": 1, "lbs.dyn_chunk_log2": c,
-                                                              "lbs.dyn_static_pct": pct}))
-variants.append(("dyn b512 c4 s60 exact0", {"lbs.dyn": 1, "lbs.exact": 0}))
+for blk in (1024, 512, 256):
+    variants.append((f"dyn b{blk}", {"lbs.block": blk, "lbs.dyn": 1}))
+    variants.append((f"dyn b{blk} exact0", {"lbs.block": blk, "lbs.dyn": 1, "lbs.exact": 0}))
+variants.append(("dyn b256 bpc2", {"lbs.block": 256, "lbs.dyn": 1, "lbs.dyn_bpc": 2}))
+variants.append(("dyn b512 bpc1", {"lbs.block": 512, "lbs.dyn": 1, "lbs.dyn_bpc": 1}))
 variants.append(("static p1 bpc4 exact0", {"lbs.exact": 0}))
 
 # ---- correctness: every variant against the plain static kernel, bit for bit ---------------------------------------
@@ -101,8 +99,8 @@ for name, o in variants:
     got = snapshot()
     if not all(np.array_equal(a, b) for a, b in zip(ref, got)):
         bad.append(name)
-# the drawn kernel again over a few launches in a row on two streams (counter sets rotate, the last workgroup resets them)
-configure({"lbs.dyn": 1}, 2)
+# the drawn kernel again over a few launches in a row on two streams
+configure({"lbs.dyn": 1, "lbs.block": 1024}, 2)
 for rep in range(3):
     clear()
     for i in range(args.sets * 2 + 1):
