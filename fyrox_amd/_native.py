@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfyrox_hip.so")
+# FYX_LIB_PATH: another build of the SAME library (kernel experiments, tools/exp/build_variants.sh); never a fallback
+LIB_PATH = os.environ.get("FYX_LIB_PATH") or os.path.join(_HERE, "libfyrox_hip.so")
 
 FYX_OK = 0
 FYX_ERR_INVALID_ARG = -1

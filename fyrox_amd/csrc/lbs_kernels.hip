@@ -37,10 +37,27 @@ __device__ __forceinline__ T ldg(const T* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
 }
+// FYX_EXP_ST (experiments only, tools/exp/build_variants.sh): cache policy of the streaming stores.
+//   0 nt (default)   1 plain   2 sc1   3 sc0 sc1   4 nt sc1
+#ifndef FYX_EXP_ST
+#define FYX_EXP_ST 0
+#endif
+#ifndef FYX_EXP_STAGE
+#define FYX_EXP_STAGE 0   // lbs_skin_dyn staging experiments, see the kernel
+#endif
 template <bool NT, typename T>
 __device__ __forceinline__ void stg(T* p, T v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+    if constexpr (!NT || FYX_EXP_ST == 1) *p = v;
+    else if constexpr (FYX_EXP_ST == 0) __builtin_nontemporal_store(v, p);
+    else if constexpr (sizeof(T) == 16) {
+        if constexpr (FYX_EXP_ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (FYX_EXP_ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    } else {
+        if constexpr (FYX_EXP_ST == 2) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (FYX_EXP_ST == 3) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    }
 }
 
 template <bool NT>
@@ -49,7 +66,15 @@ __device__ __forceinline__ void ld3(const float* p, float& x, float& y, float& z
 }
 template <bool NT>
 __device__ __forceinline__ void st3(float* p, float x, float y, float z) {
-    stg<NT>(p, x); stg<NT>(p + 1, y); stg<NT>(p + 2, z);
+    if constexpr (NT && FYX_EXP_ST >= 2) {
+        typedef float f3 __attribute__((ext_vector_type(3)));
+        const f3 v = {x, y, z};
+        if constexpr (FYX_EXP_ST == 2) asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (FYX_EXP_ST == 3) asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx3 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    } else {
+        stg<NT>(p, x); stg<NT>(p + 1, y); stg<NT>(p + 2, z);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -523,12 +548,28 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
 
     // palette columns first: column c of bone b is piece 4 b + c
     const uint32_t n_pieces = a.n_bones * 4;
+#if FYX_EXP_STAGE == 2
+    // experiment: the workgroup's first wave fetches the whole palette (16 x 1 KB), everybody else goes straight to its vertices
+    constexpr int WPIECES = 16;
+    f32x4 wcol[WPIECES];
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < WPIECES; ++i) {
+            const uint32_t piece = lane + (uint32_t)i * 64;
+            wcol[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
+        }
+    }
+#else
     f32x4 col[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
         col[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
     }
+#endif
+#if FYX_EXP_STAGE == 1
+    __syncthreads();   // experiment: every wave's palette request is queued before any vertex request of the workgroup
+#endif
     // the wave's first two units (tickets wave and WPB + wave; the launcher guarantees n_units >= 2 WPB)
     const uint32_t v_last = a.n_verts - 1;
     auto vertex_of = [&](uint32_t t) -> uint32_t {
@@ -537,10 +578,30 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
     };
     uint32_t vA = vertex_of(wave), vB = vertex_of(WPB + wave);
     VertexIn<MASK> A = load_vertex<true, MASK>(a, vA);
+#if FYX_EXP_STAGE == 3
+    VertexIn<MASK> B;   // experiment: the second unit is requested after the staging barrier
+#else
     VertexIn<MASK> B = load_vertex<true, MASK>(a, vB);
+#endif
 
     if (tid == 0) *ticket = 2 * WPB;
     bool pj = false;
+#if FYX_EXP_STAGE == 2
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < WPIECES; ++i) {
+            const uint32_t piece = lane + (uint32_t)i * 64;
+            if (piece < n_pieces) {
+                const uint32_t b = piece >> 2, c = piece & 3;
+                float* r = reinterpret_cast<float*>(rows + b * 3);
+                *reinterpret_cast<f32x2*>(r + 2 * c) = f32x2{wcol[i].x, wcol[i].y};
+                r[8 + c] = wcol[i].z;
+                reinterpret_cast<float*>(row3 + b)[c] = wcol[i].w;
+                pj |= wcol[i].w != (c == 3 ? 1.0f : 0.0f);
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
@@ -555,6 +616,7 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
             pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);
         }
     }
+#endif
     const bool wave_pj = __any(pj) != 0;
     if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
     __syncthreads();
@@ -562,7 +624,11 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
 #pragma unroll
     for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
     pin_vertex(A);
+#if FYX_EXP_STAGE == 3
+    B = load_vertex<true, MASK>(a, vB);
+#else
     pin_vertex(B);
+#endif
     if constexpr (PROBE) pt1 = __builtin_amdgcn_s_memrealtime();
 
     auto process = [&](VertexIn<MASK>& c_, uint32_t v_c) {

@@ -25,6 +25,8 @@ ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--streams", default="1,2")
+ap.add_argument("--only", default="", help="comma-separated variant names to keep")
+ap.add_argument("--tag", default="")
 args = ap.parse_args()
 
 ctx = fyrox_amd.Context(0)
@@ -84,6 +86,10 @@ variants.append(("dyn b256 bpc2", {"lbs.block": 256, "lbs.dyn": 1, "lbs.dyn_bpc"
 variants.append(("dyn b512 bpc1", {"lbs.block": 512, "lbs.dyn": 1, "lbs.dyn_bpc": 1}))
 variants.append(("static p1 bpc4 exact0", {"lbs.exact": 0}))
 
+if args.only:
+    keep = set(args.only.split(","))
+    variants = [v for v in variants if v[0] in keep]
+
 # ---- correctness: every variant against the plain static kernel, bit for bit ---------------------------------------
 configure({}, 1)
 clear()
@@ -125,6 +131,6 @@ for (name, streams), ts in results.items():
     rows.append({"variant": name, "streams": streams, "us_median": us, "us_min": float(min(ts)),
                  "frac_of_8TBps": 100.0 * nv / us / 1e3 / 8000.0})
 rows.sort(key=lambda r: (r["streams"], r["us_median"]))
-print(json.dumps({"verts": nv, "bones": args.bones, "mismatching": bad, "rows": rows}, indent=1))
+print(json.dumps({"tag": args.tag, "lib": os.environ.get("FYX_LIB_PATH", ""), "verts": nv, "bones": args.bones, "mismatching": bad, "rows": rows}, indent=1))
 for r in rows:
     print("#", r, file=sys.stderr)
