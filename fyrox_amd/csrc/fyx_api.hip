@@ -569,6 +569,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
     if (!strcmp(key, "lbs.dyn_bpc")) return &c->lbs.dyn_bpc;
     if (!strcmp(key, "lbs.asym")) return &c->lbs.asym;
+    if (!strcmp(key, "lbs.policy")) return &c->lbs.policy;
     if (!strcmp(key, "lbs.young_prio")) return &c->lbs.young_prio;
     if (!strcmp(key, "anim.threads")) return &c->plan_threads;
     if (!strcmp(key, "anim.split")) return &c->plan_split;

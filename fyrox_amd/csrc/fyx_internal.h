@@ -27,6 +27,7 @@ struct LbsTuning {
     int dyn_bpc = 0;         // workgroups per CU of that launch; 0 = what is resident (1024 / block)
     int asym = 0;            // lbs_skin, 2 workgroups per CU: the first-dispatched one owns asym/64 of the pair's units (0 = halves)
     int young_prio = 0;      // lbs_skin: s_setprio for the second-dispatched half of the grid
+    int policy = 0;          // experiment builds only (FYX_EXP_POLICY): cache policy of lbs_skin_dyn's streams
 };
 
 struct LbsArgs {

@@ -42,6 +42,9 @@ __device__ __forceinline__ T ldg(const T* p) {
 #ifndef FYX_EXP_ST
 #define FYX_EXP_ST 0
 #endif
+#ifndef FYX_EXP_POLICY
+#define FYX_EXP_POLICY 0
+#endif
 #ifndef FYX_EXP_STAGE
 #define FYX_EXP_STAGE 0   // lbs_skin_dyn staging experiments, see the kernel
 #endif
@@ -506,6 +509,54 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
 }
 
 // ---------------------------------------------------------------------------------------
+// Vertex streams as buffer resources (lbs_skin_dyn): buffer_load / buffer_store carry the cache policy in the
+// instruction (aux bits below), the compiler knows them (exact vmcnt counts, hazards), and an access past the
+// stream's last byte is dropped by the hardware (loads return 0) -- no per-lane bounds test.
+//   aux: 1 = sc0, 2 = nt, 16 = sc1   (gfx940+ cache-policy bits of the raw-buffer builtins)
+// ---------------------------------------------------------------------------------------
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+struct VtxBuffers {
+    __amdgpu_buffer_rsrc_t pos, nrm, tan, wgt, idx, out_pos, out_nrm, out_tan;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_stream(const void* p, uint32_t bytes) {
+    // null stream -> zero records: every access is out of range
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0u, 0x00020000);
+}
+__device__ __forceinline__ VtxBuffers make_vtx_buffers(const LbsArgs& a) {
+    VtxBuffers b;
+    b.pos = make_stream(a.pos, a.n_verts * 12u);
+    b.nrm = make_stream(a.nrm, a.n_verts * 12u);
+    b.tan = make_stream(a.tan, a.n_verts * 16u);
+    b.wgt = make_stream(a.wgt, a.n_verts * 16u);
+    b.idx = make_stream(a.idx, a.n_verts * 4u);
+    b.out_pos = make_stream(a.out_pos, a.n_verts * 12u);
+    b.out_nrm = make_stream(a.out_nrm, a.n_verts * 12u);
+    b.out_tan = make_stream(a.out_tan, a.n_verts * 16u);
+    return b;
+}
+template <int MASK, int AUX>
+__device__ __forceinline__ VertexIn<MASK> load_vertex_buf(const VtxBuffers& b, uint32_t v) {
+    VertexIn<MASK> r;
+    r.p = r.n = f32x3{0.f, 0.f, 0.f};
+    r.t = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (MASK & 1) r.p = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(b.pos, v * 12u, 0, AUX));
+    if constexpr (MASK & 2) r.n = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(b.nrm, v * 12u, 0, AUX));
+    if constexpr (MASK & 4) r.t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.tan, v * 16u, 0, AUX));
+    r.w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.wgt, v * 16u, 0, AUX));
+    r.id = __builtin_amdgcn_raw_buffer_load_b32(b.idx, v * 4u, 0, AUX);
+    return r;
+}
+template <int MASK, int AUX>
+__device__ __forceinline__ void store_vertex_buf(const VtxBuffers& b, uint32_t v, const Skinned& o, float tw) {
+    if constexpr (MASK & 1)
+        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f32x3{o.px, o.py, o.pz}), b.out_pos, v * 12u, 0, AUX);
+    if constexpr (MASK & 2)
+        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f32x3{o.nx, o.ny, o.nz}), b.out_nrm, v * 12u, 0, AUX);
+    if constexpr (MASK & 4)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{o.tx, o.ty, o.tz, tw}), b.out_tan, v * 16u, 0, AUX);
+}
+
+// ---------------------------------------------------------------------------------------
 // lbs_skin_dyn: the single-instance kernel for large meshes, built around how a LONE launch spends its ~18 us
 // (timeline: tools/probe_timeline.py, profiles/r01_timeline.json for lbs_skin).
 //
@@ -524,12 +575,12 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
 //     worst, and until then a wave has nothing but its first unit in flight).
 //   * Two units per wave are requested before the staging barrier, and the loop keeps two in flight: a register set
 //     is refilled as soon as its math is done, while the other set's loads have had a whole unit's time to land.
-//   * Every unit costs five loads and three stores, always: a lane past the end of the mesh works on the LAST vertex
-//     (same inputs, same arithmetic, the same bytes stored to the same address as the lane that owns it), so the loop
-//     body is straight-line vector-memory code and the compiler's vmcnt bookkeeping is exact.
+//   * Every unit costs five loads and three stores, always: the streams are buffer resources, so a lane past the end
+//     of the mesh loads zeros and its stores are dropped by the hardware -- the loop body is straight-line
+//     vector-memory code and the compiler's vmcnt bookkeeping is exact.
 // Which wave skins a unit changes nothing in the arithmetic: results are bit-identical to lbs_skin's.
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, int MASK, bool PROBE = false>
+template <int BLOCK, bool EXACT, int MASK, bool PROBE = false, int LD_AUX = 2, int ST_AUX = 2>
 __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint64_t* probe = nullptr) {
     uint64_t pt0 = 0, pt1 = 0;
     if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
@@ -571,17 +622,14 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
     __syncthreads();   // experiment: every wave's palette request is queued before any vertex request of the workgroup
 #endif
     // the wave's first two units (tickets wave and WPB + wave; the launcher guarantees n_units >= 2 WPB)
-    const uint32_t v_last = a.n_verts - 1;
-    auto vertex_of = [&](uint32_t t) -> uint32_t {
-        const uint32_t v = (u_begin + t) * 64 + lane;
-        return v < v_last ? v : v_last;
-    };
+    const VtxBuffers vb = make_vtx_buffers(a);
+    auto vertex_of = [&](uint32_t t) -> uint32_t { return (u_begin + t) * 64 + lane; };
     uint32_t vA = vertex_of(wave), vB = vertex_of(WPB + wave);
-    VertexIn<MASK> A = load_vertex<true, MASK>(a, vA);
+    VertexIn<MASK> A = load_vertex_buf<MASK, LD_AUX>(vb, vA);
 #if FYX_EXP_STAGE == 3
     VertexIn<MASK> B;   // experiment: the second unit is requested after the staging barrier
 #else
-    VertexIn<MASK> B = load_vertex<true, MASK>(a, vB);
+    VertexIn<MASK> B = load_vertex_buf<MASK, LD_AUX>(vb, vB);
 #endif
 
     if (tid == 0) *ticket = 2 * WPB;
@@ -625,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
     for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
     pin_vertex(A);
 #if FYX_EXP_STAGE == 3
-    B = load_vertex<true, MASK>(a, vB);
+    B = load_vertex_buf<MASK, LD_AUX>(vb, vB);
 #else
     pin_vertex(B);
 #endif
@@ -635,10 +683,7 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
         pin_vertex(c_);   // the math's first touch of the loaded registers is here
         const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
                                                    c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
-        if constexpr (MASK & 1) st3<true>(a.out_pos + (size_t)v_c * 3, o.px, o.py, o.pz);
-        if constexpr (MASK & 2) st3<true>(a.out_nrm + (size_t)v_c * 3, o.nx, o.ny, o.nz);
-        if constexpr (MASK & 4)
-            stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + v_c, f32x4{o.tx, o.ty, o.tz, c_.t.w});
+        store_vertex_buf<MASK, ST_AUX>(vb, v_c, o, c_.t.w);
     };
     // draw the next unit into a register set whose math is done; false when the workgroup's range is used up
     auto refill = [&](VertexIn<MASK>& n_, uint32_t& v_n) -> bool {
@@ -647,7 +692,7 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= n_units) return false;
         v_n = vertex_of(t);
-        n_ = load_vertex<true, MASK>(a, v_n);
+        n_ = load_vertex_buf<MASK, LD_AUX>(vb, v_n);
         return true;
     };
     for (;;) {   // wave-uniform
@@ -848,6 +893,7 @@ static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t
     }
 }
 
+constexpr int kPolAux[5] = {0, 2, 16, 17, 18};   // plain, nt, sc1, sc0 sc1, sc1 nt
 // lbs_skin_dyn launch: the grid is what is resident (16 waves per CU at the kernel's register budget).  Returns
 // hipErrorNotReady when the launch does not qualify (the caller takes lbs_skin).
 template <int BLOCK, bool EXACT, int MASK>
@@ -865,6 +911,22 @@ static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream
             return hipGetLastError();
         }
     }
+#if FYX_EXP_POLICY
+    if constexpr (BLOCK == 512 && EXACT && MASK == 7) {   // experiment: cache policy of the streams, lbs.policy = 1 + 5 * load + store
+        if (t.policy > 0) {
+            const int ld = (t.policy - 1) / 5, st = (t.policy - 1) % 5;
+#define FYX_POL(L, S) if (ld == L && st == S) { \
+                hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK, false, kPolAux[L], kPolAux[S]>), dim3(grid), dim3(BLOCK), lds, s, a, total, (uint64_t*)nullptr); \
+                return hipGetLastError(); }
+            FYX_POL(0,0) FYX_POL(0,1) FYX_POL(0,2) FYX_POL(0,3) FYX_POL(0,4)
+            FYX_POL(1,0) FYX_POL(1,1) FYX_POL(1,2) FYX_POL(1,3) FYX_POL(1,4)
+            FYX_POL(2,0) FYX_POL(2,1) FYX_POL(2,2) FYX_POL(2,3) FYX_POL(2,4)
+            FYX_POL(3,0) FYX_POL(3,1) FYX_POL(3,2) FYX_POL(3,3) FYX_POL(3,4)
+            FYX_POL(4,0) FYX_POL(4,1) FYX_POL(4,2) FYX_POL(4,3) FYX_POL(4,4)
+#undef FYX_POL
+        }
+    }
+#endif
     hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a, total, (uint64_t*)nullptr);
     return hipGetLastError();
 }
