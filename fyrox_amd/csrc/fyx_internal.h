@@ -23,7 +23,7 @@ struct LbsTuning {
     uint64_t* probe_buf = nullptr;
     size_t probe_words = 0;
     // Large single-instance launches (lbs_skin_dyn, see lbs_kernels.hip):
-    int dyn = 0;             // 1: one workgroup per resident CU slot, units drawn from an LDS ticket counter
+    int dyn = 1;             // 1: one workgroup per resident CU slot, units drawn from an LDS ticket counter
     int dyn_bpc = 0;         // workgroups per CU of that launch; 0 = what is resident (1024 / block)
     int asym = 0;            // lbs_skin, 2 workgroups per CU: the first-dispatched one owns asym/64 of the pair's units (0 = halves)
     int young_prio = 0;      // lbs_skin: s_setprio for the second-dispatched half of the grid

@@ -37,31 +37,17 @@ __device__ __forceinline__ T ldg(const T* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
 }
-// FYX_EXP_ST (experiments only, tools/exp/build_variants.sh): cache policy of the streaming stores.
-//   0 nt (default)   1 plain   2 sc1   3 sc0 sc1   4 nt sc1
-#ifndef FYX_EXP_ST
-#define FYX_EXP_ST 0
-#endif
+template <bool NT, typename T>
+__device__ __forceinline__ void stg(T* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// FYX_EXP_POLICY (experiment builds only, tools/exp/build_variants.sh): instantiates lbs_skin_dyn for every pair of
+// load / store cache policies, selected at run time by the option lbs.policy (tools/exp/policy_sweep.py).
 #ifndef FYX_EXP_POLICY
 #define FYX_EXP_POLICY 0
 #endif
-#ifndef FYX_EXP_STAGE
-#define FYX_EXP_STAGE 0   // lbs_skin_dyn staging experiments, see the kernel
-#endif
-template <bool NT, typename T>
-__device__ __forceinline__ void stg(T* p, T v) {
-    if constexpr (!NT || FYX_EXP_ST == 1) *p = v;
-    else if constexpr (FYX_EXP_ST == 0) __builtin_nontemporal_store(v, p);
-    else if constexpr (sizeof(T) == 16) {
-        if constexpr (FYX_EXP_ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-        else if constexpr (FYX_EXP_ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
-    } else {
-        if constexpr (FYX_EXP_ST == 2) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-        else if constexpr (FYX_EXP_ST == 3) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        else asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
-    }
-}
 
 template <bool NT>
 __device__ __forceinline__ void ld3(const float* p, float& x, float& y, float& z) {
@@ -69,15 +55,7 @@ __device__ __forceinline__ void ld3(const float* p, float& x, float& y, float& z
 }
 template <bool NT>
 __device__ __forceinline__ void st3(float* p, float x, float y, float z) {
-    if constexpr (NT && FYX_EXP_ST >= 2) {
-        typedef float f3 __attribute__((ext_vector_type(3)));
-        const f3 v = {x, y, z};
-        if constexpr (FYX_EXP_ST == 2) asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-        else if constexpr (FYX_EXP_ST == 3) asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        else asm volatile("global_store_dwordx3 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
-    } else {
-        stg<NT>(p, x); stg<NT>(p + 1, y); stg<NT>(p + 2, z);
-    }
+    stg<NT>(p, x); stg<NT>(p + 1, y); stg<NT>(p + 2, z);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -570,17 +548,21 @@ __device__ __forceinline__ void store_vertex_buf(const VtxBuffers& b, uint32_t v
 //     counters shared by all CUs was measured too: a returning global atomic queues behind the CU's own streaming
 //     loads, several us each -- 27 us per launch at best.  Nothing here leaves the CU.)
 //   * The palette goes first and wide: every thread fetches 16-byte columns of the palette (one dense 1 KB request
-//     per wave, the wave's FIRST vector-memory instruction), so the palette of the whole workgroup sits at the head of
-//     the CU's memory queue instead of behind other waves' vertex loads (lbs_skin: staged after 3.1 us median, 6.8 us
-//     worst, and until then a wave has nothing but its first unit in flight).
-//   * Two units per wave are requested before the staging barrier, and the loop keeps two in flight: a register set
-//     is refilled as soon as its math is done, while the other set's loads have had a whole unit's time to land.
-//   * Every unit costs five loads and three stores, always: the streams are buffer resources, so a lane past the end
-//     of the mesh loads zeros and its stores are dropped by the hardware -- the loop body is straight-line
-//     vector-memory code and the compiler's vmcnt bookkeeping is exact.
+//     per wave, the wave's FIRST vector-memory instruction) and the first unit's vertex loads right behind it; the
+//     second unit is requested as soon as the staging barrier is passed.  (Requesting both units ahead of the barrier
+//     was measured slower, 20.0 vs 19.5 us: the CU's memory queue is served in order, so the palette columns of the
+//     later waves then wait behind twice as many vertex requests of the earlier ones.)
+//   * The loop keeps two units in flight per wave: a register set is refilled as soon as its math is done, while the
+//     other set's loads have had a whole unit's time to land.
+//   * The streams are buffer resources: a lane past the end of the mesh loads zeros and its stores are dropped by the
+//     hardware, so every unit is five loads and three stores of straight-line vector-memory code, and the cache
+//     policy rides in the instruction: loads `nt` (read once), stores `sc1` (written through, the line is not kept
+//     dirty in the XCD's L2).  Measured over all 25 load / store policy pairs (tools/exp/policy_sweep.py,
+//     profiles/r02_policy_sweep.json): sc1 stores are 0.5 us faster than nt stores on a lone launch and 1.0 us
+//     (6 %) faster when launches overlap on two streams -- 15.2 us per 100 MB, 6.6 TB/s.
 // Which wave skins a unit changes nothing in the arithmetic: results are bit-identical to lbs_skin's.
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, int MASK, bool PROBE = false, int LD_AUX = 2, int ST_AUX = 2>
+template <int BLOCK, bool EXACT, int MASK, bool PROBE = false, int LD_AUX = 2, int ST_AUX = 16>
 __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint64_t* probe = nullptr) {
     uint64_t pt0 = 0, pt1 = 0;
     if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
@@ -599,57 +581,21 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
 
     // palette columns first: column c of bone b is piece 4 b + c
     const uint32_t n_pieces = a.n_bones * 4;
-#if FYX_EXP_STAGE == 2
-    // experiment: the workgroup's first wave fetches the whole palette (16 x 1 KB), everybody else goes straight to its vertices
-    constexpr int WPIECES = 16;
-    f32x4 wcol[WPIECES];
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < WPIECES; ++i) {
-            const uint32_t piece = lane + (uint32_t)i * 64;
-            wcol[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
-        }
-    }
-#else
     f32x4 col[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
         col[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
     }
-#endif
-#if FYX_EXP_STAGE == 1
-    __syncthreads();   // experiment: every wave's palette request is queued before any vertex request of the workgroup
-#endif
     // the wave's first two units (tickets wave and WPB + wave; the launcher guarantees n_units >= 2 WPB)
     const VtxBuffers vb = make_vtx_buffers(a);
     auto vertex_of = [&](uint32_t t) -> uint32_t { return (u_begin + t) * 64 + lane; };
     uint32_t vA = vertex_of(wave), vB = vertex_of(WPB + wave);
     VertexIn<MASK> A = load_vertex_buf<MASK, LD_AUX>(vb, vA);
-#if FYX_EXP_STAGE == 3
-    VertexIn<MASK> B;   // experiment: the second unit is requested after the staging barrier
-#else
-    VertexIn<MASK> B = load_vertex_buf<MASK, LD_AUX>(vb, vB);
-#endif
+    VertexIn<MASK> B;   // requested behind the staging barrier (see above)
 
     if (tid == 0) *ticket = 2 * WPB;
     bool pj = false;
-#if FYX_EXP_STAGE == 2
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < WPIECES; ++i) {
-            const uint32_t piece = lane + (uint32_t)i * 64;
-            if (piece < n_pieces) {
-                const uint32_t b = piece >> 2, c = piece & 3;
-                float* r = reinterpret_cast<float*>(rows + b * 3);
-                *reinterpret_cast<f32x2*>(r + 2 * c) = f32x2{wcol[i].x, wcol[i].y};
-                r[8 + c] = wcol[i].z;
-                reinterpret_cast<float*>(row3 + b)[c] = wcol[i].w;
-                pj |= wcol[i].w != (c == 3 ? 1.0f : 0.0f);
-            }
-        }
-    }
-#else
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
@@ -664,7 +610,6 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
             pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);
         }
     }
-#endif
     const bool wave_pj = __any(pj) != 0;
     if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
     __syncthreads();
@@ -672,11 +617,7 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
 #pragma unroll
     for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
     pin_vertex(A);
-#if FYX_EXP_STAGE == 3
     B = load_vertex_buf<MASK, LD_AUX>(vb, vB);
-#else
-    pin_vertex(B);
-#endif
     if constexpr (PROBE) pt1 = __builtin_amdgcn_s_memrealtime();
 
     auto process = [&](VertexIn<MASK>& c_, uint32_t v_c) {
@@ -912,7 +853,7 @@ static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream
         }
     }
 #if FYX_EXP_POLICY
-    if constexpr (BLOCK == 512 && EXACT && MASK == 7) {   // experiment: cache policy of the streams, lbs.policy = 1 + 5 * load + store
+    if constexpr (EXACT && MASK == 7) {   // experiment: cache policy of the streams, lbs.policy = 1 + 5 * load + store
         if (t.policy > 0) {
             const int ld = (t.policy - 1) / 5, st = (t.policy - 1) % 5;
 #define FYX_POL(L, S) if (ld == L && st == S) { \
@@ -947,7 +888,7 @@ static hipError_t launch_dyn_mask(const LbsArgs& a, const LbsTuning& t, hipStrea
 }
 
 static hipError_t launch_dyn(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    if (a.n_instances != 1 || a.n_bones > 256) return hipErrorNotReady;
+    if (a.n_instances != 1 || a.n_bones == 0 || a.n_bones > 256 || a.n_verts > 0x0fffffffu) return hipErrorNotReady;
     switch (t.block) {
         case 1024: return t.exact ? launch_dyn_mask<1024, true>(a, t, s) : launch_dyn_mask<1024, false>(a, t, s);
         case 512: return t.exact ? launch_dyn_mask<512, true>(a, t, s) : launch_dyn_mask<512, false>(a, t, s);

@@ -47,7 +47,8 @@ def assert_bit_exact(got, ref):
 @pytest.fixture(autouse=True)
 def _defaults(ctx):
     for k, v in (("lbs.block", 512), ("lbs.blocks_per_cu", 4), ("lbs.prefetch", 1), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2),
-                 ("lbs.crowd", -1), ("lbs.crowd_block", 512), ("lbs.crowd_ipb", 0), ("lbs.split", 0)):
+                 ("lbs.crowd", -1), ("lbs.crowd_block", 512), ("lbs.crowd_ipb", 0), ("lbs.split", 0), ("lbs.dyn", 1),
+                 ("lbs.dyn_bpc", 0), ("lbs.asym", 0), ("lbs.young_prio", 0)):
         ctx.set_option(k, v)
     yield
 
@@ -102,7 +103,7 @@ def test_c4_1m_verts_256_bones(ctx, orc):
 # ---- kernel variants ----------------------------------------------------------------------
 
 @pytest.mark.parametrize("block", [256, 512, 1024])
-@pytest.mark.parametrize("prefetch", [0, 1, 2])
+@pytest.mark.parametrize("prefetch", [0, 1, 2, 3])
 @pytest.mark.parametrize("nt", [0, 1])
 @pytest.mark.parametrize("split", [0, 1, 2])
 def test_every_kernel_variant_is_bit_exact(ctx, orc, block, prefetch, nt, split):
@@ -112,6 +113,125 @@ def test_every_kernel_variant_is_bit_exact(ctx, orc, block, prefetch, nt, split)
     ctx.set_option("lbs.block", block); ctx.set_option("lbs.prefetch", prefetch); ctx.set_option("lbs.nt", nt)
     ctx.set_option("lbs.blocks_per_cu", 2); ctx.set_option("lbs.split", split)
     assert_bit_exact(ctx.lbs_skin(5, pal), oracle_skin(orc, m, pal))
+
+
+@pytest.mark.parametrize("prefetch", [1, 3])
+@pytest.mark.parametrize("asym,prio", [(0, 0), (40, 0), (0, 2), (23, 3)])
+def test_static_kernel_options_at_full_size(ctx, orc, prefetch, asym, prio):
+    """lbs.dyn=0 keeps lbs_skin for large meshes too; its two-register-set form (prefetch=3), asymmetric shares and
+    priorities change who does what, never the bytes."""
+    m = synth.make_mesh(300_001, 64, 55)
+    pal = synth.make_palette(64, 55)
+    upload(ctx, 5, m)
+    for k, v in (("lbs.dyn", 0), ("lbs.blocks_per_cu", 2), ("lbs.prefetch", prefetch), ("lbs.asym", asym), ("lbs.young_prio", prio)):
+        ctx.set_option(k, v)
+    assert_bit_exact(ctx.lbs_skin(5, pal), oracle_skin(orc, m, pal))
+
+
+# ---- lbs_skin_dyn: the large single-instance launch (units drawn from an LDS ticket counter, buffer-resource streams) ----
+
+def _skin_device_masked(ctx, mesh_id, m, pal, want, guard=64):
+    """fyx_lbs_skin_device into guarded device buffers; returns the outputs and whether the guard bytes survived."""
+    nb = pal.shape[0]
+    d_pal = ctx.to_device(pal)
+    spec = {"pos": 3, "normal": 3, "tangent": 4}
+    bufs = {}
+    for k in want:
+        n = m.n_verts * spec[k]
+        b = ctx.malloc((n + guard) * 4)
+        b.upload(np.full(n + guard, 0x7FC0DEAD, np.uint32))
+        bufs[k] = b
+    ctx.lbs_skin_device(mesh_id, d_pal.ptr, nb, 1, bufs["pos"].ptr if "pos" in bufs else 0,
+                        bufs["normal"].ptr if "normal" in bufs else 0, bufs["tangent"].ptr if "tangent" in bufs else 0)
+    ctx.sync()
+    out, guards_ok = {}, True
+    for k, b in bufs.items():
+        n = m.n_verts * spec[k]
+        raw = b.download(np.uint32, n + guard)
+        guards_ok &= bool((raw[n:] == 0x7FC0DEAD).all())
+        out[k] = raw[:n].view(np.float32).reshape(-1, spec[k])
+        b.free()
+    d_pal.free()
+    return out, guards_ok
+
+
+@pytest.mark.parametrize("block", [256, 512, 1024])
+@pytest.mark.parametrize("n_verts", [1_048_576, 1_000_003, 530_001])
+def test_drawn_kernel_ragged_sizes_bit_exact(ctx, orc, block, n_verts):
+    """The launch qualifies for lbs_skin_dyn from 2 units per wave and workgroup on; the last unit is ragged (the
+    buffer resources drop what lies past the end: the guard words behind every output must survive)."""
+    m = synth.make_mesh(n_verts, 200, 1234 + block, coherent=False)
+    pal = synth.make_palette(200, 1234)
+    upload(ctx, 6, m)
+    ctx.set_option("lbs.block", block)
+    ref = oracle_skin(orc, m, pal)
+    got, guards_ok = _skin_device_masked(ctx, 6, m, pal, ("pos", "normal", "tangent"))
+    assert guards_ok
+    assert_bit_exact(got, ref)
+    ctx.set_option("lbs.dyn", 0)                    # and the static kernel agrees
+    got0, _ = _skin_device_masked(ctx, 6, m, pal, ("pos", "normal", "tangent"))
+    assert_bit_exact(got0, ref)
+    ctx.mesh_free(6)
+
+
+@pytest.mark.parametrize("want", [("pos",), ("normal",), ("pos", "normal"), ("tangent",), ("pos", "tangent"),
+                                  ("normal", "tangent"), ("pos", "normal", "tangent")])
+@pytest.mark.parametrize("exact", [1, 0])
+def test_drawn_kernel_every_output_set(ctx, orc, want, exact):
+    m = synth.make_mesh(600_037, 64, 4321)
+    pal = synth.make_palette(64, 4321)
+    upload(ctx, 6, m)
+    ctx.set_option("lbs.exact", exact)
+    ref = oracle_skin(orc, m, pal)
+    got, guards_ok = _skin_device_masked(ctx, 6, m, pal, want)
+    assert guards_ok
+    for k in want:
+        if exact:
+            assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
+        else:
+            assert rel_err(got[k][:, :3], ref[k][:, :3]) <= REL_TOL, k      # tolerance: north_star's 1e-5 relative
+    ctx.mesh_free(6)
+
+
+def test_drawn_kernel_projective_palette_and_nan_propagation(ctx, orc):
+    m = synth.make_mesh(700_001, 16, 777)
+    pal = synth.make_palette(16, 777).copy()
+    pal[3, 3] = 0.125; pal[3, 7] = -0.25; pal[3, 15] = 1.5      # bone 3 is projective: the divide path
+    upload(ctx, 6, m)
+    got, _ = _skin_device_masked(ctx, 6, m, pal, ("pos", "normal", "tangent"))
+    assert_bit_exact(got, oracle_skin(orc, m, pal))
+    pal2 = synth.make_palette(16, 777).copy()
+    pal2[5, 12] = np.inf                                         # inf * 0 = NaN must come through
+    got, _ = _skin_device_masked(ctx, 6, m, pal2, ("pos", "normal", "tangent"))
+    ref = oracle_skin(orc, m, pal2)
+    assert np.isnan(ref["pos"]).any()
+    assert np.array_equal(np.isnan(got["pos"]), np.isnan(ref["pos"]))
+    ok = ~np.isnan(ref["pos"])
+    assert np.array_equal(got["pos"][ok], ref["pos"][ok]) and np.array_equal(got["normal"], ref["normal"])
+    ctx.mesh_free(6)
+
+
+def test_drawn_kernel_repeated_overlapping_launches(ctx, orc):
+    """Launches dealt over the worker streams overlap; every one must produce the same bytes."""
+    m = synth.make_mesh(1_000_000, 256, synth.SEED_BASE + 4)
+    pal = synth.make_palette(256, synth.SEED_BASE + 4)
+    upload(ctx, 6, m)
+    ref = oracle_skin(orc, m, pal)
+    d_pal = ctx.to_device(pal)
+    outs = [(ctx.malloc(m.n_verts * 12), ctx.malloc(m.n_verts * 12), ctx.malloc(m.n_verts * 16)) for _ in range(4)]
+    for rep in range(3):
+        for o in outs:
+            ctx.lbs_skin_device(6, d_pal.ptr, 256, 1, o[0].ptr, o[1].ptr, o[2].ptr)
+    ctx.sync()
+    for o in outs:
+        assert np.array_equal(o[0].download(np.float32, m.n_verts * 3).reshape(-1, 3), ref["pos"])
+        assert np.array_equal(o[1].download(np.float32, m.n_verts * 3).reshape(-1, 3), ref["normal"])
+        assert np.array_equal(o[2].download(np.float32, m.n_verts * 4).reshape(-1, 4), ref["tangent"])
+    for o in outs:
+        for b in o:
+            b.free()
+    d_pal.free()
+    ctx.mesh_free(6)
 
 
 @pytest.mark.parametrize("n_inst,n_verts", [(1, 1), (1, 15), (1, 17), (3, 1001), (2, 4096), (1, 1_000_003), (5, 70)])

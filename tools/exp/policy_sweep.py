@@ -36,30 +36,38 @@ def clear():
         b.upload(z[: b.nbytes // 4])
 
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--policies", default="0,7,8,6,9")
+ap.add_argument("--blocks", default="512,256,1024")
+ap.add_argument("--rounds", type=int, default=5)
+args = ap.parse_args()
 names = ["plain", "nt", "sc1", "sc0sc1", "sc1nt"]
 ctx.set_option("lbs.streams", 1)
 ctx.set_option("lbs.blocks_per_cu", 2)
 run(1); ref = snapshot()
-ctx.set_option("lbs.dyn", 1)
-rows = []
-for pol in range(0, 26):
-    ctx.set_option("lbs.policy", pol)
+cfgs = [("static bpc2", {"lbs.dyn": 0, "lbs.block": 512, "lbs.blocks_per_cu": 2, "lbs.policy": 0}),
+        ("static bpc4", {"lbs.dyn": 0, "lbs.block": 512, "lbs.blocks_per_cu": 4, "lbs.policy": 0})]
+for blk in [int(x) for x in args.blocks.split(",")]:
+    for pol in [int(x) for x in args.policies.split(",")]:
+        label = "default(nt,nt)" if pol == 0 else f"ld={names[(pol - 1) // 5]} st={names[(pol - 1) % 5]}"
+        cfgs.append((f"dyn b{blk} {label}", {"lbs.dyn": 1, "lbs.block": blk, "lbs.blocks_per_cu": 2, "lbs.policy": pol}))
+res = {}
+for name, o in cfgs:
+    for k, v in o.items():
+        ctx.set_option(k, v)
     ctx.set_option("lbs.streams", 1)
     clear(); run(1)
-    ok = all(np.array_equal(a, b) for a, b in zip(ref, snapshot()))
-    t1 = []
-    t2 = []
-    for r in range(3):
-        ctx.set_option("lbs.streams", 1); run(20); t1.append(run(300))
-        ctx.set_option("lbs.streams", 2); run(20); t2.append(run(300))
-    label = "default" if pol == 0 else f"ld={names[(pol - 1) // 5]} st={names[(pol - 1) % 5]}"
-    rows.append({"policy": pol, "label": label, "bit_identical": ok, "lone_us": float(np.median(t1)), "two_stream_us": float(np.median(t2))})
-    print("# %2d %-28s ok=%s lone %6.2f  2-stream %6.2f" % (pol, label, ok, rows[-1]["lone_us"], rows[-1]["two_stream_us"]), file=sys.stderr)
-ctx.set_option("lbs.dyn", 0); ctx.set_option("lbs.policy", 0)
-for bpc in (2, 4):
-    ctx.set_option("lbs.blocks_per_cu", bpc)
-    ctx.set_option("lbs.streams", 1); run(20); a = run(300)
-    ctx.set_option("lbs.streams", 2); run(20); b = run(300)
-    rows.append({"policy": -bpc, "label": f"static bpc{bpc}", "bit_identical": True, "lone_us": a, "two_stream_us": b})
-    print("# static bpc%d lone %6.2f 2-stream %6.2f" % (bpc, a, b), file=sys.stderr)
+    res[name] = {"ok": all(np.array_equal(a, b) for a, b in zip(ref, snapshot())), "t1": [], "t2": []}
+for r in range(args.rounds):
+    for name, o in cfgs:
+        for k, v in o.items():
+            ctx.set_option(k, v)
+        ctx.set_option("lbs.streams", 1); run(20); res[name]["t1"].append(run(300))
+        ctx.set_option("lbs.streams", 2); run(20); res[name]["t2"].append(run(300))
+rows = []
+for name, r in res.items():
+    rows.append({"config": name, "bit_identical": r["ok"], "lone_us": float(np.median(r["t1"])), "lone_min": float(min(r["t1"])),
+                 "two_stream_us": float(np.median(r["t2"]))})
+    print("# %-36s ok=%s lone %6.2f (min %6.2f)  2-stream %6.2f" % (name, r["ok"], rows[-1]["lone_us"], rows[-1]["lone_min"], rows[-1]["two_stream_us"]), file=sys.stderr)
 print(json.dumps(rows))
