@@ -149,6 +149,17 @@ class Context:
     def allgather_f32(self, d_send: int, count: int, d_recv: int) -> None:
         self._check(self._l.fyx_allgather_f32(self._h, d_send, count, d_recv))
 
+    def comm_info(self):
+        """(rank, n_ranks) as RCCL reports them."""
+        r, n = c_int(), c_int()
+        self._check(self._l.fyx_comm_info(self._h, byref(r), byref(n)))
+        return r.value, n.value
+
+    def allgather_skinned(self, n_verts: int, d_pos_all: int = 0, d_normal_all: int = 0, d_tangent_all: int = 0) -> None:
+        """fyx_allgather_skinned: every rank wrote its own (ragged) shard in place; afterwards all hold all."""
+        self._check(self._l.fyx_allgather_skinned(self._h, n_verts, d_pos_all or None, d_normal_all or None,
+                                                  d_tangent_all or None))
+
     # -- mesh registry -------------------------------------------------------------------
     def mesh_upload(self, mesh_id: int, aos: np.ndarray, n_verts: int, stride: int, *, off_pos: int,
                     off_normal: int = -1, off_tangent: int = -1, off_weights: int, off_indices: int) -> None:

@@ -18,6 +18,11 @@ struct Comm {
     int (*comm_init_rank)(RcclComm*, int, RcclId, int) = nullptr;
     int (*comm_destroy)(RcclComm) = nullptr;
     int (*all_gather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*broadcast)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    int (*comm_count)(RcclComm, int*) = nullptr;
+    int (*comm_user_rank)(RcclComm, int*) = nullptr;
     const char* (*get_error_string)(int) = nullptr;
     RcclComm comm = nullptr;
     int rank = 0, n_ranks = 0;
@@ -35,7 +40,13 @@ int load_rccl(fyx_ctx* c, Comm& k) {
     k.comm_destroy = reinterpret_cast<int (*)(RcclComm)>(dlsym(h, "ncclCommDestroy"));
     k.all_gather = reinterpret_cast<int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t)>(dlsym(h, "ncclAllGather"));
     k.get_error_string = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
-    if (!k.get_unique_id || !k.comm_init_rank || !k.comm_destroy || !k.all_gather) {
+    k.broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t)>(dlsym(h, "ncclBroadcast"));
+    k.group_start = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupStart"));
+    k.group_end = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupEnd"));
+    k.comm_count = reinterpret_cast<int (*)(RcclComm, int*)>(dlsym(h, "ncclCommCount"));
+    k.comm_user_rank = reinterpret_cast<int (*)(RcclComm, int*)>(dlsym(h, "ncclCommUserRank"));
+    if (!k.get_unique_id || !k.comm_init_rank || !k.comm_destroy || !k.all_gather || !k.broadcast || !k.group_start ||
+        !k.group_end || !k.comm_count || !k.comm_user_rank) {
         dlclose(h);
         return fail(c, FYX_ERR_UNSUPPORTED, "librccl.so lacks the expected entry points");
     }
@@ -50,6 +61,14 @@ Comm& comm_of(fyx_ctx* c) {
 
 int rccl_fail(fyx_ctx* c, const Comm& k, int rc, const char* what) {
     return fail(c, FYX_ERR_HIP, "%s: %s (%d)", what, k.get_error_string ? k.get_error_string(rc) : "RCCL error", rc);
+}
+
+// [g * groups / n_ranks] groups of kShardAlign vertices each: the same cut as fyrox_amd/sharding.py::vertex_range
+constexpr uint32_t kShardAlign = 256;
+uint32_t shard_cut(uint32_t n_verts, uint64_t g, uint64_t n_ranks) {
+    const uint64_t groups = ((uint64_t)n_verts + kShardAlign - 1) / kShardAlign;
+    const uint64_t v = (g * groups / n_ranks) * kShardAlign;
+    return v < n_verts ? (uint32_t)v : n_verts;
 }
 
 }  // namespace
@@ -124,6 +143,56 @@ int fyx_allgather_f32(fyx_ctx* c, const float* d_send, size_t count, float* d_re
     constexpr int kNcclFloat32 = 7;   // rccl.h: ncclFloat32
     const int rc = c->comm->all_gather(d_send, d_recv, count, kNcclFloat32, c->comm->comm, c->stream);
     if (rc) return rccl_fail(c, *c->comm, rc, "ncclAllGather");
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_shard_vertex_range(uint32_t n_verts, int rank, int n_ranks, uint32_t* begin, uint32_t* end) {
+    if (!begin || !end || n_ranks < 1 || rank < 0 || rank >= n_ranks) return FYX_ERR_INVALID_ARG;
+    *begin = shard_cut(n_verts, (uint64_t)rank, (uint64_t)n_ranks);
+    *end = shard_cut(n_verts, (uint64_t)rank + 1, (uint64_t)n_ranks);
+    return FYX_OK;
+}
+
+int fyx_comm_info(fyx_ctx* c, int* rank, int* n_ranks) {
+    if (!c || !rank || !n_ranks) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (!c->comm || !c->comm->comm) return fail(c, FYX_ERR_INVALID_ARG, "no communicator: call fyx_comm_init first");
+    Comm& k = *c->comm;
+    int rc = k.comm_user_rank(k.comm, rank);
+    if (rc) return rccl_fail(c, k, rc, "ncclCommUserRank");
+    rc = k.comm_count(k.comm, n_ranks);
+    if (rc) return rccl_fail(c, k, rc, "ncclCommCount");
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_allgather_skinned(fyx_ctx* c, uint32_t n_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (!c->comm || !c->comm->comm) return fail(c, FYX_ERR_INVALID_ARG, "no communicator: call fyx_comm_init first");
+    if (n_verts == 0 || (!d_pos_all && !d_normal_all && !d_tangent_all)) return FYX_OK;
+    Comm& k = *c->comm;
+    // on the context stream, after every skinning launch in flight (the shard must be complete before it is sent)
+    if (int rc = enter_primary(c)) return rc;
+    constexpr int kNcclFloat32 = 7;   // rccl.h: ncclFloat32
+    struct { float* p; uint32_t width; } streams[3] = {{d_pos_all, 3}, {d_normal_all, 3}, {d_tangent_all, 4}};
+    int rc = k.group_start();
+    if (rc) return rccl_fail(c, k, rc, "ncclGroupStart");
+    int first_err = 0;
+    for (const auto& s : streams) {
+        if (!s.p) continue;
+        for (int r = 0; r < k.n_ranks && !first_err; ++r) {
+            const uint32_t b = shard_cut(n_verts, (uint64_t)r, (uint64_t)k.n_ranks);
+            const uint32_t e = shard_cut(n_verts, (uint64_t)r + 1, (uint64_t)k.n_ranks);
+            if (e == b) continue;
+            float* at = s.p + (size_t)b * s.width;      // rank r's shard: sent from there by r, received there by all
+            first_err = k.broadcast(at, at, (size_t)(e - b) * s.width, kNcclFloat32, r, k.comm, c->stream);
+        }
+    }
+    rc = k.group_end();     // always closed, also after a failed call inside the group
+    if (first_err) return rccl_fail(c, k, first_err, "ncclBroadcast");
+    if (rc) return rccl_fail(c, k, rc, "ncclGroupEnd");
     return FYX_OK;
     FYX_GUARD_END(c)
 }

@@ -25,6 +25,17 @@ def vertex_range(n_verts: int, rank: int, world: int, align: int = VERTEX_ALIGN)
     return cut(rank), cut(rank + 1)
 
 
+def vertex_range_native(n_verts: int, rank: int, world: int) -> Tuple[int, int]:
+    """The same cut computed by the library (fyx_shard_vertex_range), which fyx_allgather_skinned uses."""
+    from ctypes import byref, c_uint32
+    from . import _native
+    b, e = c_uint32(), c_uint32()
+    rc = _native.lib().fyx_shard_vertex_range(n_verts, rank, world, byref(b), byref(e))
+    if rc:
+        raise ValueError(f"fyx_shard_vertex_range({n_verts}, {rank}, {world}) -> {rc}")
+    return b.value, e.value
+
+
 def instance_range(n_instances: int, rank: int, world: int) -> Tuple[int, int]:
     """[begin, end) of rank's instances of a crowd (zero communication)."""
     if not (0 <= rank < world):

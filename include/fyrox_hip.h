@@ -594,6 +594,21 @@ int fyx_comm_shutdown(fyx_ctx* ctx);
  * ordered after every skinning launch in flight (it starts with the GPU-side join of fyx_join).  Equal
  * counts on all ranks (pad the last shard).  Asynchronous. */
 int fyx_allgather_f32(fyx_ctx* ctx, const float* d_send, size_t count, float* d_recv);
+/* The cut BASELINE config 4 names ("1 M verts / 256 bones, vertex-range sharded across 8 GPUs"): rank r of n_ranks owns
+ * the contiguous vertices [*begin, *end) of an n_verts mesh; boundaries fall on whole 256-vertex groups (four 64-vertex
+ * work units), groups are dealt as evenly as integers allow, so shards are RAGGED (1 000 000 over 8 GPUs: 124 928 /
+ * 124 928 / 125 184 / ... / 124 992 vertices).  Pure function: no context, no GPU.  The reference has no counterpart
+ * (one process, one GPU); this replaces nothing and exists for the all-gather below. */
+int fyx_shard_vertex_range(uint32_t n_verts, int rank, int n_ranks, uint32_t* begin, uint32_t* end);
+/* rank and size of the context's communicator as RCCL reports them (ncclCommUserRank / ncclCommCount). */
+int fyx_comm_info(fyx_ctx* ctx, int* rank, int* n_ranks);
+/* The exchange step, once per frame: every non-null d_*_all is a FULL skinned stream of the n_verts mesh (3 / 3 / 4
+ * floats per vertex) of which this rank has written its own shard IN PLACE (give fyx_lbs_skin_device the addresses
+ * d_pos_all + 3 * begin, ...); on return (stream-ordered) every rank holds every shard.  ONE grouped RCCL operation
+ * for all streams and all (ragged) shards -- ncclGroupStart, one ncclBroadcast per (stream, rank) rooted at the shard's
+ * owner, ncclGroupEnd -- on the context stream, after the GPU-side join of the skinning launches in flight.  All ranks
+ * must pass the same n_verts and the same set of non-null streams. */
+int fyx_allgather_skinned(fyx_ctx* ctx, uint32_t n_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all);
 
 /* ---- control plane without a GPU ----------------------------------------------------- */
 /* A context with no device: registry and control-plane calls work, every call that would touch

@@ -815,8 +815,22 @@ def test_single_rank_communicator_all_gathers_a_skinned_shard(ctx, orc):
     ref = orc.lbs_skin(m.pos[b:e], m.weights[b:e], m.indices[b:e], pal, m.normal[b:e], m.tangent[b:e], threads=0)
     got = d_g.download(np.float32, n * 3).reshape(n, 3)
     assert np.array_equal(got.view(np.uint32), ref["pos"].view(np.uint32))
+    # the in-place form (fyx_allgather_skinned): with one rank the shard is the whole mesh, written where it belongs;
+    # the grouped broadcasts rooted at rank 0 leave every byte as the skinning launch wrote it
+    assert ctx.comm_info() == (0, 1)
+    for d in (d_p, d_n, d_t):
+        d.upload(np.zeros(d.nbytes // 4, np.uint32))
+    ctx.lbs_skin_device(7101, d_pal.ptr, 64, 1, d_p.ptr, d_n.ptr, d_t.ptr)
+    ctx.allgather_skinned(n, d_p.ptr, d_n.ptr, d_t.ptr)
+    ctx.allgather_skinned(n, d_p.ptr, 0, 0)            # any subset of the streams
+    ctx.sync()
+    assert np.array_equal(d_p.download(np.float32, n * 3).reshape(n, 3), ref["pos"])
+    assert np.array_equal(d_n.download(np.float32, n * 3).reshape(n, 3), ref["normal"])
+    assert np.array_equal(d_t.download(np.float32, n * 4).reshape(n, 4), ref["tangent"])
     ctx.comm_shutdown()
     ctx.comm_shutdown()                                # idempotent
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx.allgather_skinned(n, d_p.ptr, d_n.ptr, d_t.ptr)   # the communicator is gone
     for d in (d_pal, d_p, d_n, d_t, d_g):
         d.free()
     ctx.mesh_free(7101)

@@ -28,6 +28,23 @@ def test_vertex_ranges_tile_the_mesh():
         sharding.vertex_range(10, 2, 2)
 
 
+def test_library_cut_equals_the_python_cut():
+    """fyx_shard_vertex_range (what fyx_allgather_skinned places the shards by) against fyrox_amd.sharding, and the
+    BASELINE config-4 cut spelled out: 1 M vertices over 8 GPUs is ragged."""
+    for n in (0, 1, 255, 256, 257, 1000, 4097, 50_000, 999_999, 1_000_000, 1_000_001, 4_000_000_000):
+        for world in (1, 2, 3, 4, 5, 7, 8, 16):
+            for r in range(world):
+                assert sharding.vertex_range_native(n, r, world) == sharding.vertex_range(n, r, world), (n, r, world)
+    cuts = [sharding.vertex_range_native(1_000_000, r, 8) for r in range(8)]
+    assert [e - b for b, e in cuts] == [124928, 124928, 125184, 124928, 124928, 125184, 124928, 124992]
+    assert [b for b, _ in cuts] == [0, 124928, 249856, 375040, 499968, 624896, 750080, 875008]
+    assert [e - b for b, e in cuts] == sharding.shard_sizes(1_000_000, 8)
+    with pytest.raises(ValueError):
+        sharding.vertex_range_native(10, 2, 2)
+    with pytest.raises(ValueError):
+        sharding.vertex_range_native(10, 0, 0)
+
+
 def test_instance_ranges_tile_the_crowd():
     for n in (0, 1, 7, 1000):
         for world in (1, 2, 4, 8):
@@ -65,6 +82,54 @@ def _worker(rank: int, world: int, port: int, n_verts: int, n_bones: int, q):
         q.put((rank, ok, (b, e)))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_in_place(rank: int, world: int, port: int, n_verts: int, n_bones: int, q):
+    """The schedule of fyx_allgather_skinned with gloo standing in for RCCL: every rank skins its shard INTO its place
+    of the full streams (the library's own cut), then one broadcast per (stream, owner) over that owner's slice."""
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seed = synth.SEED_BASE + 4
+        mesh = synth.make_mesh(n_verts, n_bones, seed)
+        pal = synth.make_palette(n_bones, seed)
+        b, e = sharding.vertex_range_native(n_verts, rank, world)
+        out = oracle.lbs_skin(mesh.pos[b:e], mesh.weights[b:e], mesh.indices[b:e], pal, mesh.normal[b:e], mesh.tangent[b:e])
+        full = {k: torch.full((n_verts, w), float("nan")) for k, w in (("pos", 3), ("normal", 3), ("tangent", 4))}
+        for k in full:
+            full[k][b:e] = torch.from_numpy(out[k])
+        for k in ("pos", "normal", "tangent"):
+            for r in range(world):
+                rb, re = sharding.vertex_range_native(n_verts, r, world)
+                if re > rb:
+                    piece = full[k][rb:re]            # a view: received in place
+                    dist.broadcast(piece, src=r)
+        ref = oracle.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal, mesh.normal, mesh.tangent)
+        q.put((rank, all(np.array_equal(full[k].numpy(), ref[k]) for k in ref), (b, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_verts", [(2, 4097), (3, 1000), (2, 300)])
+def test_in_place_ragged_gather_schedule(world, n_verts):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_in_place, args=(r, world, port, n_verts, 16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results)
+    ranges = sorted(rg for _, _, rg in results)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n_verts
 
 
 @pytest.mark.parametrize("world,n_verts", [(2, 10_000), (2, 4097), (3, 1000)])
