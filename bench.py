@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- skinned vertices/s of the HIP linear-blend-skinning hot path on MI355X.
 
-A "step" = one pass of the hot path over one batch: ONE launch of the skinning kernel over the
-C4 workload (1 M vertices / 256 bones; position + normal + tangent, 4 influences) through the
-C ABI (fyx_lbs_skin_device), inputs resident in HBM.  Steps rotate through `--sets` disjoint
-buffer sets (default 8 x 100 MB > 2 x the 256 MiB Infinity Cache) so the stream comes from HBM.
+A "step" = one pass of the hot path over one batch: ONE launch of the skinning kernel over the C4 workload
+(1 M vertices / 256 bones; position + normal + tangent, 4 influences) through the C ABI (fyx_lbs_skin_device),
+inputs resident in HBM.  Steps rotate through `--sets` disjoint buffer sets (default 8 x 100 MB > 2 x the 256 MiB
+Infinity Cache) so the stream comes from HBM.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; every rank skins its own 1 M-vertex shard of an N x 1 M-vertex scene
-(vertex-range sharding, weak scaling, no data-path collective; `--allgather` adds the RCCL
-all-gather of the skinned buffers that a consumer needing the whole scene on every GPU would pay).
-Rank 0 prints ONE JSON line.
+What the one JSON line says (rank 0 prints it):
+  value / ms_per_step   K steps timed between barrier + device sync on both sides, max over ranks.  K steps of a 16 us
+                        kernel are shorter than the closing sync is noisy, so the K-step region is repeated (`timed_regions`)
+                        and the MEDIAN region is reported: the number does not depend on K.
+  roofline.frac         follows from ONE kernel: algorithmic bytes / the kernel's own duration (launches serialized on
+                        one stream, HIP events: what rocprofv3 --kernel-trace reports per dispatch).
+  roofline.overlapped   the same bytes / the time per launch of the timed region, where independent launches overlap on
+                        the library's launch streams (head of one launch under the tail of the previous one).
+  roofline.copy_ceiling a no-math 60 MB-in / 40 MB-out copy kernel on the same buffers' sizes, same run, same box.
+  extra.c2 / c3 / c5    the other BASELINE configs end to end (pose -> palette -> skinning), N = 1 only.
+  extra.strong_scaling  N > 1: the SAME 1 M-vertex mesh cut by vertex range over the N GPUs (BASELINE config 4), compute
+                        only and with the RCCL exchange (fyx_allgather_skinned).  The headline stays weak scaling (N x 1 M).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
 import time
+from functools import partial
 
 import numpy as np
 
@@ -31,7 +41,7 @@ N_VERTS = 1_000_000
 N_BONES = 256
 BYTES_PER_VERTEX = 100          # 60 read + 40 written
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-KERNEL_NAME = "lbs_skin"
+MIN_REGION_MS = 20.0            # a timed region shorter than this is repeated (see module docstring)
 
 
 def parse():
@@ -43,13 +53,16 @@ def parse():
     ap.add_argument("--verts", type=int, default=N_VERTS)
     ap.add_argument("--bones", type=int, default=N_BONES)
     ap.add_argument("--random-bones", action="store_true", help="fully random bone indices (worst-case LDS gather)")
-    ap.add_argument("--allgather", action="store_true", help="N>1: add the RCCL all-gather of the skinned buffers (fyx_allgather_f32)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N>1: weak = every GPU skins its own 1 M-vertex shard of an N x 1 M scene (headline); "
+                         "strong = the 1 M-vertex mesh itself is cut over the N GPUs (BASELINE config 4)")
+    ap.add_argument("--allgather", action="store_true", help="strong scaling: include the RCCL exchange in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (e.g. lbs.prefetch=0)")
+    ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (e.g. lbs.dyn=0)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity spot-check before timing")
-    ap.add_argument("--no-serialized", action="store_true",
-                    help="skip the extra single-stream timing (roofline.serialized)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C3 / C5 sub-records")
+    ap.add_argument("--max-regions", type=int, default=25)
     return ap.parse_args()
 
 
@@ -84,6 +97,142 @@ def cpu_baseline(mesh, pal, seconds: float) -> dict:
             "omp_note": "OpenMP over vertices; not present in the reference (no rayon on this path)"}
 
 
+def lbs_parity(ctx, mesh, pal, d_out, n_chk: int) -> dict:
+    """Skinned position / normal / tangent of the first n_chk vertices against the oracle (checker only)."""
+    import oracle
+    ref = oracle.lbs_skin(mesh.pos[:n_chk], mesh.weights[:n_chk], mesh.indices[:n_chk], pal,
+                          mesh.normal[:n_chk], mesh.tangent[:n_chk], threads=0)
+    got = {"pos": d_out[0][:n_chk * 3].cpu().numpy().reshape(-1, 3), "normal": d_out[1][:n_chk * 3].cpu().numpy().reshape(-1, 3),
+           "tangent": d_out[2][:n_chk * 4].cpu().numpy().reshape(-1, 4)}
+    err = max(float(np.abs(got[k] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-3)) for k in ref)
+    return {"max_rel_err": err, "bit_exact": bool(all(np.array_equal(got[k], ref[k]) for k in ref)),
+            "streams_checked": ["pos", "normal", "tangent"], "checked_vertices": n_chk}
+
+
+# ---- the other BASELINE configs, end to end (N = 1) -------------------------------------------------------------------
+
+def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_instances):
+    """pose (AnimationPlayer / Machine) -> palette (written by the update kernel) -> instanced skinning, all resident.
+    Timing: HIP events over `frames` frames on ONE stream (the frame is a dependent chain).  Parity: the whole chain
+    against the oracle stepped in lock-step (tests/anim_cases.py builds both sides from one description)."""
+    import oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import anim_cases as cases
+    from fyrox_amd import anim as A
+
+    nb = sc.rig.n_nodes
+    p = cases.build_product(ctx, sc, n_instances)
+    base = p.base_id
+    bone_nodes = list(range(nb))
+    A.create_bone_list(ctx, base + 50, base, bone_nodes)
+    d_pal = ctx.malloc(n_instances * nb * 64)
+    p.set_palette_output(base + 50, d_pal.ptr)
+    ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    nv = mesh.n_verts * n_instances
+    d_pos, d_nrm, d_tan = ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)
+    oracles = {}
+    if desync:      # every instance at its own phase (a crowd); the sampled ones get an oracle of their own
+        for i in range(n_instances):
+            for a in range(len(sc.animations)):
+                p.set_time_position(a, (i * 0.37 + a * 0.11) % 1.0, instance=i)
+    for i in parity_instances:
+        o = cases.build_oracle(orc, sc)
+        if desync:
+            for a in range(len(sc.animations)):
+                orc._alib().fo_animation_set_time_position(o.anims[a], (i * 0.37 + a * 0.11) % 1.0)
+        oracles[i] = o
+    update = p.update_machine if sc.machine is not None else p.update_animations
+
+    def frame(skin=True):
+        update(sc.dt)
+        if skin:
+            ctx.lbs_skin_device(base + 60, d_pal.ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+
+    # parity: a few frames in lock-step with the oracle, then the whole chain compared
+    n_par = 5
+    for f in range(n_par):
+        for o in oracles.values():
+            (o.update_machine if sc.machine is not None else o.update_animations)(sc.dt)
+        frame()
+    ctx.sync()
+    pal = d_pal.download(np.float32, n_instances * nb * 16).reshape(n_instances, nb, 16)
+    got = {"pos": d_pos.download(np.float32, nv * 3).reshape(n_instances, -1, 3),
+           "normal": d_nrm.download(np.float32, nv * 3).reshape(n_instances, -1, 3),
+           "tangent": d_tan.download(np.float32, nv * 4).reshape(n_instances, -1, 4)}
+    chain_err, lbs_exact, chain_exact = 0.0, True, True
+    for i, o in oracles.items():
+        ref_pal = o.palette(bone_nodes)
+        ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, ref_pal, mesh.normal, mesh.tangent, threads=0)
+        ref_gpu_pal = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal[i], mesh.normal, mesh.tangent, threads=0)
+        for k in ref:
+            chain_err = max(chain_err, float(np.abs(got[k][i] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-3)))
+            chain_exact &= bool(np.array_equal(got[k][i], ref[k]))
+            lbs_exact &= bool(np.array_equal(got[k][i], ref_gpu_pal[k]))     # the skinning stage given the GPU's palettes
+        o.close()
+    if chain_err > 1e-5:
+        raise SystemExit(f"{name}: end-to-end parity failed: max rel err {chain_err:.3e} > 1e-5")
+    if not lbs_exact:
+        raise SystemExit(f"{name}: skinning stage is not bit-exact against the oracle on the GPU-built palettes")
+
+    for _ in range(10):
+        frame()
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(frames):
+        frame()
+    frame_ms = ctx.timer_end() / frames
+    ctx.timer_begin()
+    for _ in range(frames):
+        frame(skin=False)
+    pose_ms = ctx.timer_end() / frames
+    ctx.timer_begin()
+    for _ in range(frames):
+        ctx.lbs_skin_device(base + 60, d_pal.ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+    skin_ms = ctx.timer_end() / frames
+    unique = mesh.n_verts * 60 + n_instances * nb * 64 + nv * 40     # mesh read once, palettes, outputs
+    rec = {"workload": name, "frame_ms": frame_ms, "pose_ms": pose_ms, "skin_ms": skin_ms,
+           "skinned_vertices_per_s_frame": nv / (frame_ms * 1e-3), "skinned_vertices_per_s_skin": nv / (skin_ms * 1e-3),
+           "roofline": {"bound": "hbm", "kernel": "lbs_skin_crowd" if n_instances >= 4 else "lbs_skin",
+                        "unique_bytes_per_launch": unique, "achieved": unique / (skin_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": unique / (skin_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "avg_launch_us": skin_ms * 1e3},
+           "parity": {"instances_checked": sorted(oracles), "frames_in_lock_step": n_par,
+                      "end_to_end_max_rel_err": chain_err, "end_to_end_bit_exact": chain_exact,
+                      "bit_exact": lbs_exact,
+                      "note": "bit_exact = skinning stage vs oracle on the GPU-built palettes; end_to_end = pose -> palette -> "
+                              "skin vs the oracle's whole chain (Euler tracks use device sincosf: <= 1e-5, not bit-exact)"}}
+    for b in (d_pal, d_pos, d_nrm, d_tan):
+        b.free()
+    ctx.mesh_free(base + 60)
+    p.free()
+    return rec
+
+
+def extras(ctx) -> dict:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import anim_cases as cases
+    from fyrox_amd import synth
+    streams = ctx.get_option("lbs.streams")
+    ctx.set_option("lbs.streams", 1)
+    out = {}
+    try:
+        rig2 = synth.make_rig(64, synth.SEED_BASE + 2)
+        td, tgt = synth.make_clip(64, synth.SEED_BASE + 2, 0)
+        c2 = cases.Scenario("c2", rig2, [td], [cases.AnimSpec(0, tgt)], None, n_frames=20)
+        out["c2"] = _chain_record(ctx, "C2: one character, 50k verts / 64 bones / 1 clip (AnimationPlayer -> palette -> LBS)",
+                                  c2, synth.make_mesh(50_000, 64, synth.SEED_BASE + 2), 1, 400, False, [0])
+        out["c3"] = _chain_record(ctx, "C3: crowd of 1000 instances x 10k verts / 64 bones, 4-clip blend-tree machine per instance",
+                                  cases.c5_blend_tree(n_bones=64, seed=synth.SEED_BASE + 3), synth.make_mesh(10_000, 64, synth.SEED_BASE + 3),
+                                  1000, 100, True, [0, 1, 15, 16, 17, 999])
+        out["c5"] = _chain_record(ctx, "C5: Machine 4-clip blend tree -> palette -> 100k-vert LBS",
+                                  cases.c5_blend_tree(n_bones=64), synth.make_mesh(100_000, 64, synth.SEED_BASE + 5), 1, 400, False, [0])
+    finally:
+        ctx.set_option("lbs.streams", streams)
+    return out
+
+
+# ---- main ---------------------------------------------------------------------------------------------------------------
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +243,7 @@ def main():
 
     import torch
     import fyrox_amd
-    from fyrox_amd import synth
+    from fyrox_amd import sharding, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -103,45 +252,73 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    ctx = fyrox_amd.Context(local_rank)    # owns its launch streams; torch is only used for RCCL + barriers
+    ctx = fyrox_amd.Context(local_rank)    # owns its launch streams; torch is only used for barriers and buffers
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    opts = {k: ctx.get_option(k) for k in ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams",
-                                           "lbs.split")}
-    from fyrox_amd import sharding
-    shard = sharding.vertex_range(world * args.verts, rank, world)   # this rank's slice of the N x 1M scene
+    opt_keys = ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams", "lbs.split", "lbs.dyn")
+    opts = {k: ctx.get_option(k) for k in opt_keys}
+    n_ranks_rccl = None
+    if world > 1:      # the library's own communicator (fyx_comm_init): rank 0's unique id travels over the process group
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+        n_ranks_rccl = ctx.comm_info()[1]
 
-    # ---- synthetic inputs; each rank owns a different vertex-range shard --------
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def timed_regions(step, steps, warmup, first_index=0):
+        """`steps` launches between barrier + sync, repeated while the regions are shorter than MIN_REGION_MS; returns the
+        per-region wall seconds (max over ranks) and GPU milliseconds (HIP events on the context stream)."""
+        for i in range(warmup):
+            step(first_index + i)
+        walls, gpus = [], []
+        n = first_index + warmup
+        while True:
+            barrier()
+            t0 = time.perf_counter()
+            ctx.timer_begin()
+            for i in range(steps):
+                step(n + i)
+            g = ctx.timer_end()
+            barrier()
+            walls.append(max_over_ranks(time.perf_counter() - t0))
+            gpus.append(max_over_ranks(g))
+            n += steps
+            need = int(np.ceil(MIN_REGION_MS / max(np.median(walls) * 1e3, 1e-3)))
+            target = 1 if np.median(walls) * 1e3 >= MIN_REGION_MS else min(args.max_regions, max(5, need))
+            if len(walls) >= target:
+                return walls, gpus
+
     seed = synth.SEED_BASE + 4
-    mesh = synth.make_mesh(args.verts, args.bones, seed + 1000 * rank, coherent=not args.random_bones)
     pal = synth.make_palette(args.bones, seed)
-    nv = mesh.n_verts
     d_pal = torch.from_numpy(pal).cuda()
+    fn = ctx._l.fyx_lbs_skin_device
+
+    # ---- headline: every rank skins its own 1 M-vertex shard (weak); N = 1: THE C4 workload ----------------------------
+    shard = sharding.vertex_range(world * args.verts, rank, world)
+    mesh = synth.make_mesh(args.verts, args.bones, seed + 1000 * rank, coherent=not args.random_bones)
+    nv = mesh.n_verts
     outs = []
     for s in range(args.sets):
         ctx.mesh_upload_soa(s, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
         outs.append((torch.empty(nv * 3 + 16, dtype=torch.float32, device="cuda"),
                      torch.empty(nv * 3 + 16, dtype=torch.float32, device="cuda"),
                      torch.empty(nv * 4 + 16, dtype=torch.float32, device="cuda")))
-    gathered = None
-    if world > 1 and args.allgather:
-        gathered = [torch.empty(world * (nv * 3 + 16), dtype=torch.float32, device="cuda"),
-                    torch.empty(world * (nv * 3 + 16), dtype=torch.float32, device="cuda"),
-                    torch.empty(world * (nv * 4 + 16), dtype=torch.float32, device="cuda")]
-        # the library's own communicator (fyx_comm_init): rank 0's unique id travels over the process group
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
-
-    # One foreign call per step: fyx_lbs_skin_device(ctx, mesh_id, d_palette, n_bones, 1, out...) with
-    # the ctypes arguments converted once, so the Python side costs ~1 us per launch.
-    import ctypes
-    from functools import partial
-    fn = ctx._l.fyx_lbs_skin_device
+    # One foreign call per step with the ctypes arguments converted once: ~1 us of Python per launch.
     calls = [partial(fn, ctx._h, ctypes.c_uint64(s), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones),
                      ctypes.c_uint32(1), ctypes.c_void_p(o[0].data_ptr()), ctypes.c_void_p(o[1].data_ptr()),
                      ctypes.c_void_p(o[2].data_ptr())) for s, o in enumerate(outs)]
@@ -151,104 +328,166 @@ def main():
         rc = calls[i % n_sets]()
         if rc:
             ctx._check(rc)
-        if gathered is not None:             # fyx_allgather_f32 is ordered after the launch on the GPU: no host sync
-            for g, o in zip(gathered, outs[i % n_sets]):
-                ctx.allgather_f32(o.data_ptr(), o.numel(), g.data_ptr())
 
-    # ---- parity spot-check against the oracle before timing (checker only) -------------------
     parity = None
     if not args.no_check and rank == 0:
-        import oracle
+        for o in outs[0]:
+            o.zero_()
         step(0)
         ctx.sync()
-        n_chk = min(nv, 50_000)
-        ref = oracle.lbs_skin(mesh.pos[:n_chk], mesh.weights[:n_chk], mesh.indices[:n_chk], pal,
-                              mesh.normal[:n_chk], mesh.tangent[:n_chk], threads=0)
-        got_p = outs[0][0][:n_chk * 3].cpu().numpy().reshape(-1, 3)
-        got_t = outs[0][2][:n_chk * 4].cpu().numpy().reshape(-1, 4)
-        err = max(float(np.abs(got_p - ref["pos"]).max() / max(np.abs(ref["pos"]).max(), 1e-3)),
-                  float(np.abs(got_t - ref["tangent"]).max() / max(np.abs(ref["tangent"]).max(), 1e-3)))
-        parity = {"max_rel_err": err, "bit_exact": bool(np.array_equal(got_p, ref["pos"]) and np.array_equal(got_t, ref["tangent"])),
-                  "checked_vertices": n_chk}
-        if err > 1e-5:
-            raise SystemExit(f"parity check failed before timing: max rel err {err:.3e} > 1e-5")
+        parity = lbs_parity(ctx, mesh, pal, outs[0], min(nv, 50_000))
+        if parity["max_rel_err"] > 1e-5:
+            raise SystemExit(f"parity check failed before timing: max rel err {parity['max_rel_err']:.3e} > 1e-5")
 
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
+    strong = None
+    if args.scaling == "weak":
+        walls, gpus = timed_regions(step, args.steps, args.warmup)
+    # ---- the kernel alone: launches serialized on ONE stream (HIP-event average per launch == rocprofv3 kernel duration) --
+    n_ser = max(500, min(args.steps, 2000))
+    ctx.set_option("lbs.streams", 1)
+    for i in range(50):
         step(i)
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_begin()                        # hipEvent on the context stream (joins the launch streams)
-    for i in range(args.steps):
-        step(args.warmup + i)
-    gpu_ms = ctx.timer_end()                 # second hipEvent after a GPU-side join of all launch streams
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # Same launches serialized on ONE stream (outside the timed region above): there the HIP-event
-    # average per launch IS the kernel's duration as rocprofv3 --kernel-trace reports it; with the
-    # default two launch streams consecutive kernels overlap pairwise, so the trace shows ~2x longer
-    # kernels while the device retires one launch every `avg_launch_us`.
-    serial_us = None
-    if not args.no_serialized and gathered is None:
-        n_ser = max(200, min(args.steps, 1000))
-        ctx.set_option("lbs.streams", 1)
-        for i in range(50):
-            step(i)
+    ser = []
+    for _ in range(3):
         ctx.sync()
         ctx.timer_begin()
         for i in range(n_ser):
             step(i)
-        serial_us = ctx.timer_end() * 1e3 / n_ser
-        ctx.set_option("lbs.streams", opts["lbs.streams"])
-    if dist is not None:
-        t = torch.tensor([elapsed, gpu_ms, serial_us or 0.0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, gpu_ms = float(t[0]), float(t[1])
-        serial_us = float(t[2]) or None
+        ser.append(ctx.timer_end() * 1e3 / n_ser)
+    kernel_us = max_over_ranks(float(np.median(ser)))
+    ctx.set_option("lbs.streams", opts["lbs.streams"])
+    # ---- no-math copy of the same bytes (60 MB in, 40 MB out per launch), same run: what a 100 MB launch can do here ----
+    copy_us = None
+    if rank == 0:
+        units = 1_250_000
+        srcs = [torch.full((units * 12,), float(s), dtype=torch.float32, device="cuda") for s in range(n_sets)]
+        dsts = [torch.empty(units * 8, dtype=torch.float32, device="cuda") for _ in range(n_sets)]
+        for i in range(40):
+            ctx.calib_stream_copy(srcs[i % n_sets].data_ptr(), dsts[i % n_sets].data_ptr(), units)
+        cs = []
+        for _ in range(3):
+            ctx.sync()
+            ctx.timer_begin()
+            for i in range(500):
+                ctx.calib_stream_copy(srcs[i % n_sets].data_ptr(), dsts[i % n_sets].data_ptr(), units)
+            cs.append(ctx.timer_end() * 1e3 / 500)
+        copy_us = float(np.median(cs))
+        del srcs, dsts
+
+    # ---- BASELINE config 4 as written: the 1 M-vertex mesh cut by vertex range over the ranks ---------------------------
+    if world > 1 or args.scaling == "strong":
+        full = synth.make_mesh(args.verts, args.bones, seed, coherent=not args.random_bones)     # same mesh on every rank
+        b, e = sharding.vertex_range_native(full.n_verts, rank, world)
+        sets2 = min(n_sets, 4)
+        alls = []
+        for s in range(sets2):
+            ctx.mesh_upload_soa(100 + s, full.pos[b:e], full.weights[b:e], full.indices[b:e], full.normal[b:e], full.tangent[b:e])
+            alls.append((torch.zeros(full.n_verts * 3 + 16, dtype=torch.float32, device="cuda"),
+                         torch.zeros(full.n_verts * 3 + 16, dtype=torch.float32, device="cuda"),
+                         torch.zeros(full.n_verts * 4 + 16, dtype=torch.float32, device="cuda")))
+        scalls = [partial(fn, ctx._h, ctypes.c_uint64(100 + s), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones),
+                          ctypes.c_uint32(1), ctypes.c_void_p(o[0].data_ptr() + 12 * b), ctypes.c_void_p(o[1].data_ptr() + 12 * b),
+                          ctypes.c_void_p(o[2].data_ptr() + 16 * b)) for s, o in enumerate(alls)]
+        gather = ctx._l.fyx_allgather_skinned
+        gcalls = [partial(gather, ctx._h, ctypes.c_uint32(full.n_verts), ctypes.c_void_p(o[0].data_ptr()),
+                          ctypes.c_void_p(o[1].data_ptr()), ctypes.c_void_p(o[2].data_ptr())) for o in alls]
+
+        def sstep(i: int, with_gather: bool):
+            rc = scalls[i % sets2]()
+            if rc:
+                ctx._check(rc)
+            if with_gather and world > 1:
+                rc = gcalls[i % sets2]()
+                if rc:
+                    ctx._check(rc)
+
+        # every rank must end up holding the WHOLE skinned mesh: checked on rank 0 against the oracle, head and tail
+        gathered_ok = None
+        sstep(0, True)
+        ctx.sync()
+        if rank == 0 and not args.no_check:
+            import oracle
+            n_chk = 20_000
+            tail = slice(full.n_verts - n_chk, full.n_verts)
+            ref = oracle.lbs_skin(full.pos[tail], full.weights[tail], full.indices[tail], pal, full.normal[tail], full.tangent[tail], threads=0)
+            got = alls[0][0][(full.n_verts - n_chk) * 3:full.n_verts * 3].cpu().numpy().reshape(-1, 3)
+            head = lbs_parity(ctx, full, pal, alls[0], n_chk)
+            gathered_ok = bool(head["bit_exact"] and np.array_equal(got, ref["pos"]))
+            if not gathered_ok:
+                raise SystemExit("strong scaling: the gathered buffer differs from the oracle")
+        w_c, g_c = timed_regions(lambda i: sstep(i, False), args.steps, args.warmup)
+        w_g, g_g = (timed_regions(lambda i: sstep(i, True), args.steps, args.warmup) if world > 1 else (w_c, g_c))
+        sizes = [sharding.vertex_range_native(full.n_verts, r, world) for r in range(world)]
+        strong = {"workload": f"C4 as written: {full.n_verts} verts / {args.bones} bones cut by contiguous vertex range over {world} GPU(s), "
+                              "palette replicated; every rank writes its shard in place into the full buffers",
+                  "scaling": "strong", "n_ranks": n_ranks_rccl if n_ranks_rccl is not None else 1,
+                  "shard_vertices": [e_ - b_ for b_, e_ in sizes],
+                  "compute_only": {"value": full.n_verts * args.steps / float(np.median(w_c)), "unit": "vertices/s",
+                                   "ms_per_step": float(np.median(w_c)) * 1e3 / args.steps, "timed_regions": len(w_c)},
+                  "with_allgather": {"value": full.n_verts * args.steps / float(np.median(w_g)), "unit": "vertices/s",
+                                     "ms_per_step": float(np.median(w_g)) * 1e3 / args.steps, "timed_regions": len(w_g),
+                                     "collective": "fyx_allgather_skinned: one grouped RCCL op per frame (ragged shards, 40 B/vertex)"},
+                  "gathered_equals_oracle": gathered_ok}
+        if args.scaling == "strong":
+            walls, gpus = (w_g, g_g) if args.allgather else (w_c, g_c)
 
     if rank == 0:
-        total_verts = float(world) * nv * args.steps
-        value = total_verts / elapsed
-        launch_us = gpu_ms * 1e3 / args.steps           # average per launch, HIP events
-        achieved = BYTES_PER_VERTEX * nv / (launch_us * 1e-6) / 1e9
-        traffic = None
+        region = float(np.median(walls))
+        per_rank_verts = nv if args.scaling == "weak" else args.verts / world
+        total_verts = (float(world) * nv if args.scaling == "weak" else float(args.verts)) * args.steps
+        value = total_verts / region
+        launch_us = float(np.median(gpus)) * 1e3 / args.steps           # per launch in the timed region (launches overlap)
+        bytes_launch = BYTES_PER_VERTEX * nv
+        achieved = bytes_launch / (kernel_us * 1e-6) / 1e9
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):                        # PMC-derived HBM bytes per launch (see profiles/README.md)
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, builder run; not measured in this run)"
             except Exception:
                 traffic = None
+        kname = "lbs_skin_dyn" if opts["lbs.dyn"] and nv >= 524_288 else "lbs_skin"
         out = {
             "metric": "skinned vertices/sec at 1M verts/256 bones; achieved HBM GB/s vs peak",
             "value": value, "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": region * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timed_regions": len(walls), "region_ms": [w * 1e3 for w in walls],
             "config": {"workload": f"C4: {nv} verts / {args.bones} bones per GPU, 4-influence LBS of position+normal+tangent, "
                                    f"{args.sets} rotating 100 MB buffer sets, "
-                                   f"{'random' if args.random_bones else 'spatially coherent'} bone indices",
-                       "sharding": "contiguous vertex range per GPU, palette replicated" + (", + RCCL all-gather" if gathered else ""),
-                       "rank0_vertex_range": list(shard),
+                                   f"{'random' if args.random_bones else 'spatially coherent'} bone indices"
+                                   if args.scaling == "weak" else strong["workload"],
+                       "sharding": "contiguous vertex range per GPU, palette replicated",
+                       "rank0_vertex_range": list(shard), "n_ranks": n_ranks_rccl if n_ranks_rccl is not None else 1,
                        "kernel_options": opts},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": KERNEL_NAME, "avg_launch_us": launch_us,
-                         "algorithmic_bytes_per_launch": BYTES_PER_VERTEX * nv,
-                         "launch_streams": opts["lbs.streams"],
-                         "serialized": None if serial_us is None else {
-                             "avg_launch_us": serial_us, "achieved": BYTES_PER_VERTEX * nv / (serial_us * 1e-6) / 1e9,
-                             "frac": BYTES_PER_VERTEX * nv / (serial_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                             "note": "one launch stream: kernels do not overlap, avg_launch_us == rocprofv3 kernel duration"}},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "kernel_us": kernel_us,
+                         "kernel_us_note": "one launch stream: HIP-event average per launch == rocprofv3 --kernel-trace duration",
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "overlapped": {"avg_launch_us": launch_us, "achieved": bytes_launch / (launch_us * 1e-6) / 1e9,
+                                        "frac": bytes_launch / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                        "launch_streams": opts["lbs.streams"],
+                                        "note": "time per launch of the timed region: consecutive launches overlap on the launch streams"},
+                         "copy_ceiling": None if copy_us is None else {
+                             "kernel_us": copy_us, "achieved": bytes_launch / (copy_us * 1e-6) / 1e9,
+                             "frac": bytes_launch / (copy_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                             "note": "stream_copy_kernel: 60 MB read + 40 MB written, no math, one stream, same run"}},
             "parity": parity,
         }
+        extra = {}
+        if strong is not None:
+            extra["strong_scaling"] = strong
+        if world == 1 and not args.no_extras and args.scaling == "weak":
+            extra.update(extras(ctx))
+        if extra:
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mesh, pal, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
+    barrier()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
