@@ -10,9 +10,10 @@ Infinity Cache) so the stream comes from HBM.
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 What the one JSON line says (rank 0 prints it):
-  value / ms_per_step   K steps timed between barrier + device sync on both sides, max over ranks.  K steps of a 16 us
-                        kernel are shorter than the closing sync is noisy, so the K-step region is repeated (`timed_regions`)
-                        and the MEDIAN region is reported: the number does not depend on K.
+  value / ms_per_step   steps timed between barrier + device sync on both sides, max over ranks.  K = 20 steps of a 16 us
+                        kernel last 0.3 ms, of which opening and closing the region is ~15 %, so a timed region is `repeats`
+                        back-to-back passes of K steps (no sync inside; `timed_steps` = K x repeats >= 20 ms) and the median
+                        of five regions is reported: the per-step number does not depend on K.
   roofline.frac         follows from ONE kernel: algorithmic bytes / the kernel's own duration (launches serialized on
                         one stream, HIP events: what rocprofv3 --kernel-trace reports per dispatch).
   roofline.overlapped   the same bytes / the time per launch of the timed region, where independent launches overlap on
@@ -62,7 +63,7 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (e.g. lbs.dyn=0)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity spot-check before timing")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C3 / C5 sub-records")
-    ap.add_argument("--max-regions", type=int, default=25)
+    ap.add_argument("--max-repeats", type=int, default=4000)
     return ap.parse_args()
 
 
@@ -281,27 +282,34 @@ def main():
         return float(t[0])
 
     def timed_regions(step, steps, warmup, first_index=0):
-        """`steps` launches between barrier + sync, repeated while the regions are shorter than MIN_REGION_MS; returns the
-        per-region wall seconds (max over ranks) and GPU milliseconds (HIP events on the context stream)."""
+        """One timed region = `repeats` back-to-back passes of `steps` launches between barrier + device sync (no sync
+        inside); `repeats` is 1 when `steps` launches already last MIN_REGION_MS, otherwise what makes the region that
+        long (from an untimed pilot pass), so that the fixed cost of opening and closing a region (~50 us) does not
+        decide a number quoted per step.  Returns (repeats, per-region wall seconds (max over ranks), GPU ms)."""
         for i in range(warmup):
             step(first_index + i)
-        walls, gpus = [], []
         n = first_index + warmup
-        while True:
+
+        def region(count):
+            nonlocal n
             barrier()
             t0 = time.perf_counter()
             ctx.timer_begin()
-            for i in range(steps):
+            for i in range(count):
                 step(n + i)
             g = ctx.timer_end()
             barrier()
-            walls.append(max_over_ranks(time.perf_counter() - t0))
-            gpus.append(max_over_ranks(g))
-            n += steps
-            need = int(np.ceil(MIN_REGION_MS / max(np.median(walls) * 1e3, 1e-3)))
-            target = 1 if np.median(walls) * 1e3 >= MIN_REGION_MS else min(args.max_regions, max(5, need))
-            if len(walls) >= target:
-                return walls, gpus
+            n += count
+            return max_over_ranks(time.perf_counter() - t0), max_over_ranks(g)
+
+        pilot, _ = region(steps)
+        repeats = max(1, min(args.max_repeats, int(np.ceil(MIN_REGION_MS * 1e-3 / max(pilot, 1e-6)))))
+        walls, gpus = [], []
+        for _ in range(5 if repeats > 1 else 1):
+            w, g = region(steps * repeats)
+            walls.append(w)
+            gpus.append(g)
+        return repeats, walls, gpus
 
     seed = synth.SEED_BASE + 4
     pal = synth.make_palette(args.bones, seed)
@@ -341,7 +349,7 @@ def main():
 
     strong = None
     if args.scaling == "weak":
-        walls, gpus = timed_regions(step, args.steps, args.warmup)
+        repeats, walls, gpus = timed_regions(step, args.steps, args.warmup)
     # ---- the kernel alone: launches serialized on ONE stream (HIP-event average per launch == rocprofv3 kernel duration) --
     n_ser = max(500, min(args.steps, 2000))
     ctx.set_option("lbs.streams", 1)
@@ -415,28 +423,29 @@ def main():
             gathered_ok = bool(head["bit_exact"] and np.array_equal(got, ref["pos"]))
             if not gathered_ok:
                 raise SystemExit("strong scaling: the gathered buffer differs from the oracle")
-        w_c, g_c = timed_regions(lambda i: sstep(i, False), args.steps, args.warmup)
-        w_g, g_g = (timed_regions(lambda i: sstep(i, True), args.steps, args.warmup) if world > 1 else (w_c, g_c))
+        r_c, w_c, g_c = timed_regions(lambda i: sstep(i, False), args.steps, args.warmup)
+        r_g, w_g, g_g = (timed_regions(lambda i: sstep(i, True), args.steps, args.warmup) if world > 1 else (r_c, w_c, g_c))
         sizes = [sharding.vertex_range_native(full.n_verts, r, world) for r in range(world)]
         strong = {"workload": f"C4 as written: {full.n_verts} verts / {args.bones} bones cut by contiguous vertex range over {world} GPU(s), "
                               "palette replicated; every rank writes its shard in place into the full buffers",
                   "scaling": "strong", "n_ranks": n_ranks_rccl if n_ranks_rccl is not None else 1,
                   "shard_vertices": [e_ - b_ for b_, e_ in sizes],
-                  "compute_only": {"value": full.n_verts * args.steps / float(np.median(w_c)), "unit": "vertices/s",
-                                   "ms_per_step": float(np.median(w_c)) * 1e3 / args.steps, "timed_regions": len(w_c)},
-                  "with_allgather": {"value": full.n_verts * args.steps / float(np.median(w_g)), "unit": "vertices/s",
-                                     "ms_per_step": float(np.median(w_g)) * 1e3 / args.steps, "timed_regions": len(w_g),
+                  "compute_only": {"value": full.n_verts * args.steps * r_c / float(np.median(w_c)), "unit": "vertices/s",
+                                   "ms_per_step": float(np.median(w_c)) * 1e3 / (args.steps * r_c), "timed_steps": args.steps * r_c},
+                  "with_allgather": {"value": full.n_verts * args.steps * r_g / float(np.median(w_g)), "unit": "vertices/s",
+                                     "ms_per_step": float(np.median(w_g)) * 1e3 / (args.steps * r_g), "timed_steps": args.steps * r_g,
                                      "collective": "fyx_allgather_skinned: one grouped RCCL op per frame (ragged shards, 40 B/vertex)"},
                   "gathered_equals_oracle": gathered_ok}
         if args.scaling == "strong":
-            walls, gpus = (w_g, g_g) if args.allgather else (w_c, g_c)
+            repeats, walls, gpus = (r_g, w_g, g_g) if args.allgather else (r_c, w_c, g_c)
 
     if rank == 0:
         region = float(np.median(walls))
         per_rank_verts = nv if args.scaling == "weak" else args.verts / world
-        total_verts = (float(world) * nv if args.scaling == "weak" else float(args.verts)) * args.steps
+        timed_steps = args.steps * repeats
+        total_verts = (float(world) * nv if args.scaling == "weak" else float(args.verts)) * timed_steps
         value = total_verts / region
-        launch_us = float(np.median(gpus)) * 1e3 / args.steps           # per launch in the timed region (launches overlap)
+        launch_us = float(np.median(gpus)) * 1e3 / timed_steps          # per launch in the timed region (launches overlap)
         bytes_launch = BYTES_PER_VERTEX * nv
         achieved = bytes_launch / (kernel_us * 1e-6) / 1e9
         traffic, traffic_src = None, None
@@ -451,9 +460,11 @@ def main():
         out = {
             "metric": "skinned vertices/sec at 1M verts/256 bones; achieved HBM GB/s vs peak",
             "value": value, "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": region * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": region * 1e3 / timed_steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "timed_regions": len(walls), "region_ms": [w * 1e3 for w in walls],
+            "timed_steps": timed_steps, "repeats": repeats, "timed_regions": len(walls), "region_ms": [w * 1e3 for w in walls],
+            "timing_note": f"a timed region = {repeats} back-to-back passes of --steps {args.steps} launches between barrier + sync "
+                           f"(no sync inside), so that it lasts >= {MIN_REGION_MS:.0f} ms; median of {len(walls)} regions",
             "config": {"workload": f"C4: {nv} verts / {args.bones} bones per GPU, 4-influence LBS of position+normal+tangent, "
                                    f"{args.sets} rotating 100 MB buffer sets, "
                                    f"{'random' if args.random_bones else 'spatially coherent'} bone indices"

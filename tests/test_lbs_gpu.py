@@ -80,6 +80,42 @@ def test_c3_crowd_instances_share_one_mesh(ctx, orc):
     assert_bit_exact(ctx.lbs_skin(3, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst))
 
 
+def _download_at(ctx, buf, byte_offset, dtype, count):
+    out = np.empty(count, dtype=dtype)
+    ctx._check(ctx._l.fyx_memcpy_d2h(ctx._h, out.ctypes.data, buf.ptr + byte_offset, out.nbytes))
+    return out
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+def test_c3_full_size_crowd_1000_instances(ctx, orc, exact):
+    """BASELINE C3 at its full size: 1000 instances x 10k verts / 64 bones in one instanced launch.  The crowd kernel's
+    automatic instances-per-workgroup run differs with the crowd's size (16 here, 1-2 for a few dozen instances), so
+    the shipped configuration is the one under test: instances at the start, across the first run boundary (15 | 16,
+    17) and at the very end against the oracle, bit for bit (fused mode: 1e-5)."""
+    n_inst, nv, nb = 1000, 10_000, 64
+    m = synth.make_mesh(nv, nb, synth.SEED_BASE + 3)
+    pal = synth.make_palette(nb, synth.SEED_BASE + 3, n_instances=n_inst)
+    upload(ctx, 3, m)
+    ctx.set_option("lbs.exact", exact)
+    d_pal = ctx.to_device(pal)
+    d_p, d_n, d_t = ctx.malloc(n_inst * nv * 12), ctx.malloc(n_inst * nv * 12), ctx.malloc(n_inst * nv * 16)
+    ctx.lbs_skin_device(3, d_pal.ptr, nb, n_inst, d_p.ptr, d_n.ptr, d_t.ptr)
+    ctx.sync()
+    for i in (0, 1, 15, 16, 17, 500, 999):
+        ref = orc.lbs_skin(m.pos, m.weights, m.indices, pal[i * nb:(i + 1) * nb], m.normal, m.tangent, threads=0)
+        got = {"pos": _download_at(ctx, d_p, i * nv * 12, np.float32, nv * 3).reshape(-1, 3),
+               "normal": _download_at(ctx, d_n, i * nv * 12, np.float32, nv * 3).reshape(-1, 3),
+               "tangent": _download_at(ctx, d_t, i * nv * 16, np.float32, nv * 4).reshape(-1, 4)}
+        if exact:
+            assert_bit_exact(got, ref)
+        else:
+            for k in ref:
+                assert rel_err(got[k], ref[k]) <= REL_TOL, (i, k)
+    for d in (d_pal, d_p, d_n, d_t):
+        d.free()
+    ctx.mesh_free(3)
+
+
 def test_c4_1m_verts_256_bones(ctx, orc):
     m = synth.make_mesh(1_000_000, 256, synth.SEED_BASE + 4)
     pal = synth.make_palette(256, synth.SEED_BASE + 4)
