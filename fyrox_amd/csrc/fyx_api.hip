@@ -568,6 +568,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.split")) return &c->lbs.split;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
     if (!strcmp(key, "lbs.dyn_bpc")) return &c->lbs.dyn_bpc;
+    if (!strcmp(key, "lbs.dyn_block")) return &c->lbs.dyn_block;
     if (!strcmp(key, "lbs.asym")) return &c->lbs.asym;
     if (!strcmp(key, "lbs.policy")) return &c->lbs.policy;
     if (!strcmp(key, "lbs.young_prio")) return &c->lbs.young_prio;
@@ -581,8 +582,8 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (!c) return FYX_ERR_INVALID_ARG;
     int* slot = option_slot(c, key);
     if (!slot) return fail(c, FYX_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
-    if (slot == &c->lbs.block && value != 256 && value != 512 && value != 1024)
-        return fail(c, FYX_ERR_INVALID_ARG, "lbs.block must be 256, 512 or 1024");
+    if ((slot == &c->lbs.block || slot == &c->lbs.dyn_block) && value != 256 && value != 512 && value != 1024)
+        return fail(c, FYX_ERR_INVALID_ARG, "%s must be 256, 512 or 1024", key);
     if (slot == &c->n_workers) {
         if (value < 1 || value > fyx_ctx::kMaxWorkers)
             return fail(c, FYX_ERR_INVALID_ARG, "lbs.streams must be 1..%d", fyx_ctx::kMaxWorkers);

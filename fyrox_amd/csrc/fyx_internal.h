@@ -24,7 +24,9 @@ struct LbsTuning {
     size_t probe_words = 0;
     // Large single-instance launches (lbs_skin_dyn, see lbs_kernels.hip):
     int dyn = 1;             // 1: one workgroup per resident CU slot, units drawn from an LDS ticket counter
-    int dyn_bpc = 0;         // workgroups per CU of that launch; 0 = what is resident (1024 / block)
+    int dyn_block = 256;     // its workgroup size: 256 | 512 | 1024 (four small workgroups per CU end at more staggered times than two
+                             //   large ones: the most robust lone-launch time over the boxes of the pool, profiles/r02_policy_sweep*.json)
+    int dyn_bpc = 0;         // workgroups per CU of that launch; 0 = what is resident (1024 / dyn_block)
     int asym = 0;            // lbs_skin, 2 workgroups per CU: the first-dispatched one owns asym/64 of the pair's units (0 = halves)
     int young_prio = 0;      // lbs_skin: s_setprio for the second-dispatched half of the grid
     int policy = 0;          // experiment builds only (FYX_EXP_POLICY): cache policy of lbs_skin_dyn's streams

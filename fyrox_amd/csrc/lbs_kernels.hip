@@ -889,7 +889,7 @@ static hipError_t launch_dyn_mask(const LbsArgs& a, const LbsTuning& t, hipStrea
 
 static hipError_t launch_dyn(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     if (a.n_instances != 1 || a.n_bones == 0 || a.n_bones > 256 || a.n_verts > 0x0fffffffu) return hipErrorNotReady;
-    switch (t.block) {
+    switch (t.dyn_block) {
         case 1024: return t.exact ? launch_dyn_mask<1024, true>(a, t, s) : launch_dyn_mask<1024, false>(a, t, s);
         case 512: return t.exact ? launch_dyn_mask<512, true>(a, t, s) : launch_dyn_mask<512, false>(a, t, s);
         default: return t.exact ? launch_dyn_mask<256, true>(a, t, s) : launch_dyn_mask<256, false>(a, t, s);

@@ -48,7 +48,7 @@ def assert_bit_exact(got, ref):
 def _defaults(ctx):
     for k, v in (("lbs.block", 512), ("lbs.blocks_per_cu", 4), ("lbs.prefetch", 1), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2),
                  ("lbs.crowd", -1), ("lbs.crowd_block", 512), ("lbs.crowd_ipb", 0), ("lbs.split", 0), ("lbs.dyn", 1),
-                 ("lbs.dyn_bpc", 0), ("lbs.asym", 0), ("lbs.young_prio", 0)):
+                 ("lbs.dyn_bpc", 0), ("lbs.dyn_block", 256), ("lbs.asym", 0), ("lbs.young_prio", 0)):
         ctx.set_option(k, v)
     yield
 
@@ -199,7 +199,7 @@ def test_drawn_kernel_ragged_sizes_bit_exact(ctx, orc, block, n_verts):
     m = synth.make_mesh(n_verts, 200, 1234 + block, coherent=False)
     pal = synth.make_palette(200, 1234)
     upload(ctx, 6, m)
-    ctx.set_option("lbs.block", block)
+    ctx.set_option("lbs.dyn_block", block)
     ref = oracle_skin(orc, m, pal)
     got, guards_ok = _skin_device_masked(ctx, 6, m, pal, ("pos", "normal", "tangent"))
     assert guards_ok

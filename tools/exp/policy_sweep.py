@@ -51,7 +51,7 @@ cfgs = [("static bpc2", {"lbs.dyn": 0, "lbs.block": 512, "lbs.blocks_per_cu": 2,
 for blk in [int(x) for x in args.blocks.split(",")]:
     for pol in [int(x) for x in args.policies.split(",")]:
         label = "default(nt,nt)" if pol == 0 else f"ld={names[(pol - 1) // 5]} st={names[(pol - 1) % 5]}"
-        cfgs.append((f"dyn b{blk} {label}", {"lbs.dyn": 1, "lbs.block": blk, "lbs.blocks_per_cu": 2, "lbs.policy": pol}))
+        cfgs.append((f"dyn b{blk} {label}", {"lbs.dyn": 1, "lbs.dyn_block": blk, "lbs.blocks_per_cu": 2, "lbs.policy": pol}))
 res = {}
 for name, o in cfgs:
     for k, v in o.items():

@@ -40,7 +40,7 @@ for s in range(args.sets):
     outs.append((ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)))
 
 BASE = {"lbs.block": 512, "lbs.blocks_per_cu": 4, "lbs.prefetch": 1, "lbs.exact": 1, "lbs.nt": 1, "lbs.split": 0,
-        "lbs.dyn": 0, "lbs.dyn_bpc": 0, "lbs.asym": 0, "lbs.young_prio": 0}
+        "lbs.dyn": 0, "lbs.dyn_bpc": 0, "lbs.dyn_block": 256, "lbs.asym": 0, "lbs.young_prio": 0}
 
 
 def configure(opts, streams):
@@ -80,10 +80,10 @@ variants.append(("static p3 bpc2 asym40", {"lbs.blocks_per_cu": 2, "lbs.asym": 4
 for pr in (1, 3):
     variants.append((f"static p1 bpc2 prio{pr}", {"lbs.blocks_per_cu": 2, "lbs.young_prio": pr}))
 for blk in (1024, 512, 256):
-    variants.append((f"dyn b{blk}", {"lbs.block": blk, "lbs.dyn": 1}))
-    variants.append((f"dyn b{blk} exact0", {"lbs.block": blk, "lbs.dyn": 1, "lbs.exact": 0}))
-variants.append(("dyn b256 bpc2", {"lbs.block": 256, "lbs.dyn": 1, "lbs.dyn_bpc": 2}))
-variants.append(("dyn b512 bpc1", {"lbs.block": 512, "lbs.dyn": 1, "lbs.dyn_bpc": 1}))
+    variants.append((f"dyn b{blk}", {"lbs.dyn_block": blk, "lbs.dyn": 1}))
+    variants.append((f"dyn b{blk} exact0", {"lbs.dyn_block": blk, "lbs.dyn": 1, "lbs.exact": 0}))
+variants.append(("dyn b256 bpc2", {"lbs.dyn_block": 256, "lbs.dyn": 1, "lbs.dyn_bpc": 2}))
+variants.append(("dyn b512 bpc1", {"lbs.dyn_block": 512, "lbs.dyn": 1, "lbs.dyn_bpc": 1}))
 variants.append(("static p1 bpc4 exact0", {"lbs.exact": 0}))
 
 if args.only:
@@ -106,7 +106,7 @@ for name, o in variants:
     if not all(np.array_equal(a, b) for a, b in zip(ref, got)):
         bad.append(name)
 # the drawn kernel again over a few launches in a row on two streams
-configure({"lbs.dyn": 1, "lbs.block": 1024}, 2)
+configure({"lbs.dyn": 1, "lbs.dyn_block": 1024}, 2)
 for rep in range(3):
     clear()
     for i in range(args.sets * 2 + 1):
