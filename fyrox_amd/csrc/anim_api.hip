@@ -38,7 +38,7 @@ extern "C" {
 int fyx_init_control_only(fyx_ctx** out_ctx) {
     if (!out_ctx) return FYX_ERR_INVALID_ARG;
     *out_ctx = nullptr;
-    FYX_GUARD_BEGIN
+    FYX_GUARD_BEGIN_NOCTX
     fyx_ctx* c = new fyx_ctx();
     c->device = -1;
     *out_ctx = c;
@@ -83,6 +83,24 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
         return fail(c, FYX_ERR_INVALID_ARG, "tracks describe %llu keys but n_keys = %u", (unsigned long long)total, n_keys);
     for (uint32_t k = 0; k < n_keys; ++k)
         if (key_kind[k] > FYX_KEY_CUBIC) return fail(c, FYX_ERR_INVALID_ARG, "key %u has kind %u", k, key_kind[k]);
+    // Curve keeps its keys sorted by location (Curve::from / add_key sort them, fyrox-math/src/curve.rs:176-200, 215-236)
+    // and value_at's partition_point, span hints and end clamps rely on it: keys arrive here as the Curve holds them.
+    // Anything else (unsorted, NaN / infinite locations) would sample silently different values: refused.
+    {
+        uint32_t key = 0;
+        for (uint32_t t = 0; t < n_tracks; ++t)
+            for (uint32_t k = 0; k < tracks[t].n_curves; ++k) {
+                const uint32_t nk = tracks[t].curve_n_keys[k];
+                for (uint32_t i = 0; i < nk; ++i) {
+                    const float loc = key_location[key + i];
+                    if (!(loc - loc == 0.0f))
+                        return fail(c, FYX_ERR_INVALID_ARG, "track %u curve %u: key %u has a non-finite location", t, k, i);
+                    if (i && loc < key_location[key + i - 1])
+                        return fail(c, FYX_ERR_INVALID_ARG, "track %u curve %u: key locations are not sorted (key %u)", t, k, i);
+                }
+                key += nk;
+            }
+    }
     TracksData td;
     td.n_tracks = n_tracks;
     td.tracks.assign(tracks, tracks + n_tracks);

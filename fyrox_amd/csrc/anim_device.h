@@ -7,6 +7,17 @@ namespace fyx {
 
 namespace {
 
+// A device allocation that is freed again unless released: the grow paths below allocate, fill and copy in several steps,
+// any of which may fail and return early.
+struct DevGuard {
+    void* p = nullptr;
+    DevGuard() = default;
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+    ~DevGuard() { if (p) (void)hipFree(p); }
+    void* release() { void* r = p; p = nullptr; return r; }
+};
+
 // ------------------------------------------------------------------------------------------
 // Device side of an animator
 // ------------------------------------------------------------------------------------------
@@ -28,26 +39,25 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         // grow pose records / hints; existing contents are preserved
         const uint32_t new_cap = std::max(na, A.dev_anim_capacity);
         const uint32_t new_tracks = std::max(A.max_tracks, A.dev_track_capacity);
-        float4* np = nullptr;
-        uint32_t* nh = nullptr;
+        DevGuard np, nh;
         FYX_HIP(c, hipStreamSynchronize(c->stream));
-        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&np), std::max<size_t>((size_t)new_cap * in * 48, 16)));
-        FYX_HIP(c, hipMemset(np, 0, std::max<size_t>((size_t)new_cap * in * 48, 16)));
+        FYX_HIP(c, hipMalloc(&np.p, std::max<size_t>((size_t)new_cap * in * 48, 16)));
+        FYX_HIP(c, hipMemset(np.p, 0, std::max<size_t>((size_t)new_cap * in * 48, 16)));
         const size_t hb = std::max<size_t>((size_t)new_cap * A.n_instances * std::max(new_tracks, 1u) * 16, 16);
-        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&nh), hb));
-        FYX_HIP(c, hipMemset(nh, 0, hb));
+        FYX_HIP(c, hipMalloc(&nh.p, hb));
+        FYX_HIP(c, hipMemset(nh.p, 0, hb));
         if (A.d_anim_pose && A.dev_anim_capacity)
-            FYX_HIP(c, hipMemcpy(np, A.d_anim_pose, (size_t)A.dev_anim_capacity * in * 48, hipMemcpyDeviceToDevice));
+            FYX_HIP(c, hipMemcpy(np.p, A.d_anim_pose, (size_t)A.dev_anim_capacity * in * 48, hipMemcpyDeviceToDevice));
         if (A.d_hints && A.dev_anim_capacity && A.dev_track_capacity) {
             // layout [anim][track][curve][instance]: one row per animation, old rows are a prefix of the new ones
             const size_t old_row = (size_t)A.dev_track_capacity * 16 * A.n_instances;
             const size_t new_row = (size_t)new_tracks * 16 * A.n_instances;
-            FYX_HIP(c, hipMemcpy2D(nh, new_row, A.d_hints, old_row, old_row, A.dev_anim_capacity, hipMemcpyDeviceToDevice));
+            FYX_HIP(c, hipMemcpy2D(nh.p, new_row, A.d_hints, old_row, old_row, A.dev_anim_capacity, hipMemcpyDeviceToDevice));
         }
         dfree(A.d_anim_pose);
         dfree(A.d_hints);
-        A.d_anim_pose = np;
-        A.d_hints = nh;
+        A.d_anim_pose = static_cast<float4*>(np.release());
+        A.d_hints = static_cast<uint32_t*>(nh.release());
         A.dev_anim_capacity = new_cap;
         A.dev_track_capacity = new_tracks;
         A.anims_dirty = true;
@@ -115,36 +125,44 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         dfree(A.d_prop_node);
         A.d_prop_node = nullptr;
         if (int rc = upload(c, &A.d_prop_node, nodes.data(), nodes.size())) return rc;
-        PropRec* np = nullptr;
-        PropRec* no = nullptr;
+        DevGuard np, no;    // freed again if anything below fails
         const size_t pb = (size_t)A.dev_anim_capacity * A.n_instances * nps * sizeof(PropRec);
         const size_t ob = (size_t)A.n_instances * nps * sizeof(PropRec);
-        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&np), std::max<size_t>(pb, 16)));
-        FYX_HIP(c, hipMemset(np, 0, std::max<size_t>(pb, 16)));
-        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&no), std::max<size_t>(ob, 16)));
-        FYX_HIP(c, hipMemset(no, 0, std::max<size_t>(ob, 16)));
-        if (A.d_prop_out && A.dev_prop_slots)   // slots only ever get appended: old slot k is new slot k
-            FYX_HIP(c, hipMemcpy2D(no, (size_t)nps * sizeof(PropRec), A.d_prop_out, (size_t)A.dev_prop_slots * sizeof(PropRec),
-                                   (size_t)A.dev_prop_slots * sizeof(PropRec), A.n_instances, hipMemcpyDeviceToDevice));
+        FYX_HIP(c, hipMalloc(&np.p, std::max<size_t>(pb, 16)));
+        FYX_HIP(c, hipMemset(np.p, 0, std::max<size_t>(pb, 16)));
+        FYX_HIP(c, hipMalloc(&no.p, std::max<size_t>(ob, 16)));
+        FYX_HIP(c, hipMemset(no.p, 0, std::max<size_t>(ob, 16)));
+        // Slots only ever get appended (old slot k is new slot k) and animations too, so the old arrays are the top-left
+        // corner of the new ones, row by row ((animation, instance) rows of dev_prop_slots records).  Both are kept: what
+        // `apply` wrote last, AND every animation's sampled Property values -- in the reference an animation that does
+        // not tick keeps its pose, and PlayAnimation nodes go on blending it (pose.rs:107-121).
+        if (A.dev_prop_slots) {
+            const size_t old_row = (size_t)A.dev_prop_slots * sizeof(PropRec), new_row = (size_t)nps * sizeof(PropRec);
+            if (A.d_prop_out)
+                FYX_HIP(c, hipMemcpy2D(no.p, new_row, A.d_prop_out, old_row, old_row, A.n_instances, hipMemcpyDeviceToDevice));
+            if (A.d_prop_pose && A.dev_prop_anims)
+                FYX_HIP(c, hipMemcpy2D(np.p, new_row, A.d_prop_pose, old_row, old_row, (size_t)A.dev_prop_anims * A.n_instances,
+                                       hipMemcpyDeviceToDevice));
+        }
         dfree(A.d_prop_pose);
         dfree(A.d_prop_out);
-        A.d_prop_pose = np;
-        A.d_prop_out = no;
+        A.d_prop_pose = static_cast<PropRec*>(np.release());
+        A.d_prop_out = static_cast<PropRec*>(no.release());
         A.dev_prop_slots = nps;
         A.dev_prop_anims = A.dev_anim_capacity;
     }
     if (A.rm_enabled) {
         if (A.dev_rm_anim_capacity < A.dev_anim_capacity) {  // [anim][instance]: growing keeps the existing prefix
-            RootMotionDev* nr = nullptr;
+            DevGuard nr;
             const size_t nb = (size_t)A.dev_anim_capacity * A.n_instances * sizeof(RootMotionDev);
             FYX_HIP(c, hipStreamSynchronize(c->stream));
-            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&nr), std::max<size_t>(nb, 16)));
-            FYX_HIP(c, hipMemset(nr, 0, std::max<size_t>(nb, 16)));
+            FYX_HIP(c, hipMalloc(&nr.p, std::max<size_t>(nb, 16)));
+            FYX_HIP(c, hipMemset(nr.p, 0, std::max<size_t>(nb, 16)));
             if (A.d_rm_anim && A.dev_rm_anim_capacity)
-                FYX_HIP(c, hipMemcpy(nr, A.d_rm_anim, (size_t)A.dev_rm_anim_capacity * A.n_instances * sizeof(RootMotionDev),
+                FYX_HIP(c, hipMemcpy(nr.p, A.d_rm_anim, (size_t)A.dev_rm_anim_capacity * A.n_instances * sizeof(RootMotionDev),
                                      hipMemcpyDeviceToDevice));
             dfree(A.d_rm_anim);
-            A.d_rm_anim = nr;
+            A.d_rm_anim = static_cast<RootMotionDev*>(nr.release());
             A.dev_rm_anim_capacity = A.dev_anim_capacity;
         }
         uint32_t want = 1;

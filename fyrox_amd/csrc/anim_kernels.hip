@@ -1106,7 +1106,13 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         const uint32_t lane = threadIdx.x & 63u;
         if (lane < n_ops) my_op = prog[lane];
     }
-    for (uint32_t node = threadIdx.x; node < rig.n_nodes; node += blockDim.x) {
+    // Every lane of every wave walks the fold, also the lanes past the last node (they redo the last node and store
+    // nothing): fold_op reads the program out of the lanes' registers with v_readlane, and a lane that is inactive when
+    // its register is read is undefined by the LLVM contract -- with a rig of 24 nodes and a program of 40 ops the ops
+    // 24..39 would sit in lanes that a `node < n_nodes` loop has switched off.
+    for (uint32_t node_base = 0; node_base < rig.n_nodes; node_base += blockDim.x) {   // workgroup-uniform trip count
+        const bool live = node_base + threadIdx.x < rig.n_nodes;
+        const uint32_t node = live ? node_base + threadIdx.x : rig.n_nodes - 1;
         f4* trs = reinterpret_cast<f4*>(f.node_trs) + (inst_base + node) * 3;
         const f4 t0 = trs[0], t1 = trs[1], t2 = trs[2];
         float st[28];
@@ -1143,7 +1149,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             // (touching all operand records ahead of the fold, so that its loads find them in flight, measured slower:
             // 19.1 vs 17.7 us on the C3 crowd)
             while (!cx.done) run_fold<0>(cx, acc);  // a stray POP at depth 0 is ignored
-            if (cx.dirty) {
+            if (cx.dirty && live) {
                 trs[0] = f4{cx.tpx, cx.tpy, cx.tpz, 0.f};
                 trs[1] = cx.tr;
                 trs[2] = f4{cx.tsx, cx.tsy, cx.tsz, 0.f};
@@ -1151,9 +1157,11 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         }
         float m[16];
         local_matrix(st, cx.tpx, cx.tpy, cx.tpz, cx.tr, cx.tsx, cx.tsy, cx.tsz, m);
+        if (live) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            reinterpret_cast<f4*>(l_local + (size_t)node * 16)[c] = f4{m[c * 4], m[c * 4 + 1], m[c * 4 + 2], m[c * 4 + 3]};
+            for (int c = 0; c < 4; ++c)
+                reinterpret_cast<f4*>(l_local + (size_t)node * 16)[c] = f4{m[c * 4], m[c * 4 + 1], m[c * 4 + 2], m[c * 4 + 3]};
+        }
     }
     __syncthreads();
 

@@ -89,7 +89,7 @@ extern "C" {
 int fyx_comm_unique_id(fyx_ctx* c, uint8_t out_id[FYX_COMM_ID_BYTES]) {
     if (!c || !out_id) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (int rc = bind_device(c)) return rc;
     Comm& k = comm_of(c);
     if (int rc = load_rccl(c, k)) return rc;
     RcclId id;

@@ -35,9 +35,18 @@ int join_workers(fyx_ctx* c) {
     return FYX_OK;
 }
 
+// The calling thread's current HIP device becomes the context's: allocations, launches and event calls all act on
+// "the current device", and nothing says that the thread that calls in is the one that called fyx_init, or that it has
+// not used another context (another GPU) in between.  hipSetDevice is a thread-local store when nothing changes.
+int bind_device(fyx_ctx* c) {
+    if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: this call needs a GPU");
+    FYX_HIP(c, hipSetDevice(c->device));
+    return FYX_OK;
+}
+
 // Called by every entry point that enqueues work on (or synchronises) the context stream.
 int enter_primary(fyx_ctx* c) {
-    if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: this call needs a GPU");
+    if (int rc = bind_device(c)) return rc;
     int rc = join_workers(c);
     c->primary_dirty = true;
     return rc;
@@ -51,6 +60,7 @@ int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
         *out = c->stream;
         return rc;
     }
+    if (int rc = bind_device(c)) return rc;
     const int w = c->next_worker;
     c->next_worker = (w + 1) % c->n_workers;
     if (!c->workers[w]) {
@@ -465,7 +475,7 @@ const char* fyx_version(void) { return "fyrox_hip 0.1.0 (gfx950)"; }
 int fyx_init(fyx_ctx** out_ctx, int device_ordinal) {
     if (!out_ctx) return FYX_ERR_INVALID_ARG;
     *out_ctx = nullptr;
-    FYX_GUARD_BEGIN
+    FYX_GUARD_BEGIN_NOCTX
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FYX_ERR_NO_DEVICE;
     if (device_ordinal < 0 || device_ordinal >= n) return FYX_ERR_NO_DEVICE;
@@ -638,7 +648,7 @@ int fyx_malloc(fyx_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return FYX_ERR_INVALID_ARG;
     *out = nullptr;
     if (bytes == 0) return FYX_OK;
-    if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: this call needs a GPU");
+    if (int rc = bind_device(c)) return rc;
     FYX_HIP(c, hipMalloc(out, bytes));
     return FYX_OK;
 }

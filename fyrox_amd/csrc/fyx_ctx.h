@@ -98,6 +98,7 @@ int fail(fyx_ctx* c, int code, const char* fmt, ...);
 int hip_fail(fyx_ctx* c, hipError_t e, const char* what);
 size_t align_up(size_t x, size_t a);
 int join_workers(fyx_ctx* c);
+int bind_device(fyx_ctx* c);      // hipSetDevice(ctx's device) for the calling thread
 int enter_primary(fyx_ctx* c);
 int ensure_scratch(fyx_ctx* c, size_t bytes);
 void free_ctrl(CtrlBuffers& B);
@@ -115,7 +116,10 @@ int ctrl_consumed(fyx_ctx* c, CtrlBuffers& B, int slot, hipStream_t consumer = n
         if (e_ != hipSuccess) return fyx::hip_fail((c), e_, #call);    \
     } while (0)
 
-#define FYX_GUARD_BEGIN try {
+// Entry points whose context is called `c` bind the calling thread to the context's GPU first (see bind_device);
+// fyx_init / fyx_init_control_only, which have no context yet, use FYX_GUARD_BEGIN_NOCTX.
+#define FYX_GUARD_BEGIN_NOCTX try {
+#define FYX_GUARD_BEGIN try { if ((c) && (c)->device >= 0) (void)hipSetDevice((c)->device);
 #define FYX_GUARD_END(c)                                                        \
     } catch (const std::bad_alloc&) {                                           \
         return fyx::fail((c), FYX_ERR_OOM, "host allocation failed");           \

@@ -277,7 +277,10 @@ typedef struct fyx_track_desc {
 
 /* AnimationTracksData (fyrox-animation/src/lib.rs:66-110): uploaded once, shared by any number
  * of animations.  Key arrays hold sum(curve_n_keys) entries in track-major, curve-major order.
- * Tangents are read only for FYX_KEY_CUBIC keys (CurveKeyKind::Cubic{left_tangent,right_tangent}). */
+ * Tangents are read only for FYX_KEY_CUBIC keys (CurveKeyKind::Cubic{left_tangent,right_tangent}).
+ * Key locations must be finite and non-decreasing within each curve, as Curve keeps them (Curve::from and add_key sort,
+ * curve.rs:176-236): value_at's search, its span hints and the end clamps rely on the order.  Unsorted or non-finite
+ * locations are refused with FYX_ERR_INVALID_ARG (they are not sorted here: a caller that sends them has bypassed Curve). */
 int fyx_tracks_data_upload(fyx_ctx* ctx, uint64_t tracks_id, uint32_t n_tracks,
                            const fyx_track_desc* tracks, uint32_t n_keys,
                            const float* key_location, const float* key_value,
@@ -545,7 +548,13 @@ int fyx_absm_update(fyx_ctx* ctx, uint64_t animator_id, float dt);
  * host control planes run on the planner threads side by side, all control data travels in one upload, and each
  * stage of the frame is ONE kernel launch over all animators (a scene of 256 distinct characters costs what one
  * costs in launches).  An id may appear once.  Palettes registered with fyx_animator_set_palette_output are
- * written as usual. */
+ * written as usual.
+ * Failure: arguments (unknown or repeated ids) are checked before anything changes.  After that the host control plane of
+ * EVERY listed animator advances by dt (clocks, transitions, event queues, random draws) before the first GPU call, so an
+ * error returned from there on -- a HIP error: allocation, upload, launch -- leaves the host state one frame ahead of the
+ * device's poses, exactly as a failure inside fyx_absm_update does for one animator; the context's device state is
+ * suspect after a HIP error anyway.  The control plane itself cannot fail at this point: its only error (pose nodes
+ * nested deeper than the fold interpreter's accumulators) is refused when the node is added (fyx_layer_add_*). */
 int fyx_scene_update(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t n_animators, float dt);
 /* All three calls also refresh the local and global matrices of every node of every instance
  * (Transform::matrix + Graph::update_hierarchical_data); this one does only that (after

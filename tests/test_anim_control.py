@@ -291,6 +291,17 @@ def test_builder_validation(cctx):
         p.add_animation(7, [1, 1])
     assert e.value.code == _native.FYX_ERR_UNSUPPORTED
     p.add_animation(7, [1, 2])  # distinct nodes are fine
+    # key locations as Curve keeps them: sorted (duplicates allowed) and finite; anything else has bypassed Curve
+    def raw_upload(locs):
+        curve = A.Curve()
+        curve.keys = [A.CurveKey(float(x), 1.0) for x in locs]       # NOT sorted by the constructor
+        td = A.AnimationTracksData([A.Track(A.BIND_PROPERTY0, A.KIND_REAL, [curve])])
+        A.upload_tracks_data(cctx, 8, td)
+    raw_upload([0.0, 0.5, 0.5, 1.0])
+    for bad_locs in ([0.0, 1.0, 0.5], [0.0, float("nan"), 1.0], [float("inf")], [1.0, -1.0]):
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            raw_upload(bad_locs)
+        assert e.value.code == _native.FYX_ERR_INVALID_ARG
     # a pose-node cycle is rejected (the reference would recurse forever)
     li = A.c_uint32()
     assert l.fyx_machine_add_layer(h, p.id, 1.0, A.byref(li)) == 0
