@@ -418,6 +418,36 @@ def test_animated_morph_weights_drive_blend_shapes_into_a_vertex_buffer(ctx, orc
     p.free()
 
 
+def test_property_values_survive_a_new_slot_and_a_new_animation(ctx, orc):
+    """Adding an animation (and with it a property slot) after frames have run re-creates the property storage on the
+    device; what every animation sampled so far, and what was applied last, must still be there -- in the reference an
+    animation that does not tick keeps its pose and PlayAnimation nodes keep blending it (pose.rs:107-121)."""
+    sc = cases.morph_weights(n_bones=10)
+    n_inst = 3
+    o, p = run_scenario(ctx, orc, sc, n_instances=n_inst, frames=12, check_every=10 ** 9)
+    n_before = p.property_count()
+    assert n_before > 0
+    poses = [p.read_properties(a) for a in range(len(sc.animations))]
+    applied = p.read_properties(-1)
+    assert any(int(r["present"].sum()) for r in poses)
+    # a clip that animates a property nobody had so far (a new slot) and is a new animation (a new row block)
+    tr = A.Track(A.BIND_PROPERTY0 + 9, A.KIND_REAL, [A.Curve([A.CurveKey(0.0, 5.0), A.CurveKey(1.0, 50.0)])])
+    A.upload_tracks_data(ctx, p.base_id + 40, A.AnimationTracksData([tr]))
+    new_anim = p.add_animation(p.base_id + 40, [2], enabled=False)
+    assert p.property_count() == n_before + 1
+    for a, before in enumerate(poses):
+        after = p.read_properties(a)
+        for name in before.dtype.names:
+            assert np.array_equal(after[name][:, :n_before], before[name]), (a, name)
+        assert not after["present"][:, n_before:].any()
+    after = p.read_properties(-1)
+    for name in applied.dtype.names:
+        assert np.array_equal(after[name][:, :n_before], applied[name]), name
+    assert not p.read_properties(new_anim)["present"].any()
+    o.close()
+    p.free()
+
+
 def test_palette_outputs_written_by_the_update_itself(ctx, orc):
     """fyx_animator_set_palette_output: the update kernel multiplies global * inv_bind while the matrices are still in
     LDS; the result must equal the separate gather (and the oracle) bit for bit, for two bone lists at once, one with an
