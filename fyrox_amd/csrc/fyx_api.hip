@@ -574,7 +574,6 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd")) return &c->lbs.crowd;
     if (!strcmp(key, "lbs.crowd_block")) return &c->lbs.crowd_block;
     if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
-    if (!strcmp(key, "lbs.crowd_form")) return &c->lbs.crowd_form;
     if (!strcmp(key, "lbs.probe")) return &c->lbs.probe;
     if (!strcmp(key, "lbs.split")) return &c->lbs.split;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
@@ -605,7 +604,6 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd must be -1 (auto), 0 or 1");
     if (slot == &c->lbs.crowd_block && value != 256 && value != 512)
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_block must be 256 or 512");
-    if (slot == &c->lbs.crowd_form && value != 1 && value != 2) return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_form must be 1 or 2");
     if (slot == &c->lbs.crowd_ipb && (value < 0 || value > 4096))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_ipb must be 0 (auto) .. 4096");
     if (slot == &c->sample_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.sample_form must be 0, 1 or 2");

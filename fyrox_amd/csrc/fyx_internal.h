@@ -18,7 +18,6 @@ struct LbsTuning {
     int crowd = -1;          // instanced launches: -1 auto (crowd kernel from 4 instances), 0 never, 1 always
     int crowd_block = 512;   // crowd kernel workgroup = vertex tile: 256 | 512
     int crowd_ipb = 0;       // instances per workgroup run; 0 = auto
-    int crowd_form = 2;      // 2: lbs_skin_crowd2 (two instances per barrier, columns staged by all threads, sc1 stores); 1: lbs_skin_crowd
     int split = 0;           // 1: equal contiguous vertex shares per wave instead of whole 64-vertex units round-robin
     int probe = 0;           // debug: per-wave timeline of the default lbs_skin variant into probe_buf
     uint64_t* probe_buf = nullptr;

@@ -666,6 +666,15 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
 // (n_bones * 64 B per BLOCK vertices) and the 40 B/vertex written.
 // blockIdx -> (tile, chunk) with tile fastest: neighbouring workgroups (which round-robin over
 // the XCDs) read the same palettes, so each palette is fetched from HBM about once per XCD.
+//
+// What bounds it (C3, 1000 x 10 k / 64 bones; ISA count of the affine path: 69 v_pk_mul + 55 v_pk_add + 22 scalar
+// mul / add + ~20 moves and address updates per vertex-instance = ~165 VALU at 4 cycles each): 42 us of VALU issue per
+// CU beside 64 us of stores at 6.3 TB/s.  In the fused mode (~45 VALU) the launch IS the stores: 66 - 68 us, 0.75 of
+// peak.  In the exact mode the two do not hide each other completely: 77 - 80 us.  Measured and rejected in round 2
+// (profiles/r02_crowd_forms_sweep.jsonl, tools/exp/crowd_sweep.py in the history): a second form with two (or four)
+// instances per barrier, the palette fetched as matrix columns by every thread instead of by the bone-owning threads,
+// outputs as per-instance buffer resources so that no wave ever waits for a store (exact vmcnt counts), `sc1` or `nt`
+// stores -- 79 - 83 us exact (sc1: 84 - 95), 66 - 68 us fused: no better, the exact mode's floor is its arithmetic.
 // ---------------------------------------------------------------------------------------
 template <int BLOCK, bool EXACT, int MASK>
 __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tiles, uint32_t ipb) {
@@ -724,165 +733,6 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Crowd kernel, second form (default): the same tile / run decomposition as lbs_skin_crowd, restructured around what
-// bounded it -- VALU issue of the exact-order math (~265 unfused mul / add per vertex-instance: ~35 us of the C3 crowd)
-// beside 400 MB of stores, with one barrier per instance keeping the eight waves of a tile in lock-step, and the whole
-// palette traffic of a 64-bone rig on ONE wave (threads own bones):
-//   * STEP instances per barrier (two): a wave runs straight from one instance's math and stores into the next one's,
-//     so its stores drain under the following math and waves drift apart by up to a whole instance;
-//   * the palettes of the next step are fetched as 16-byte matrix columns by ALL threads (one dense request per
-//     wave) before the math and committed to the other LDS buffer after it -- no wave is the designated stager;
-//   * the outputs are buffer resources rebased per instance (any crowd size), stored `sc1` (written through, not left
-//     dirty in L2), the policy that won the sweep of lbs_skin_dyn's streams.
-// PPT = palette columns per thread and step (template: the registers they occupy during the math are real).
-// ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, int MASK, int PPT, int STEP>
-__global__ __launch_bounds__(BLOCK) void lbs_skin_crowd2(LbsArgs a, uint32_t tiles, uint32_t ipb) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr uint32_t WPB = BLOCK / 64;
-    const uint32_t pal_f4 = 4 * a.n_bones;             // rows (3 per bone) + row3 (1 per bone) of ONE palette
-    f32x4* const base = reinterpret_cast<f32x4*>(smem);           // [2 buffers][STEP palettes][pal_f4]
-    uint32_t* const flags = reinterpret_cast<uint32_t*>(base + 2 * STEP * pal_f4);   // [2][STEP][WPB]: projective, per wave
-
-    const int tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
-    const uint32_t i0 = chunk * ipb;
-    const uint32_t i1 = (i0 + ipb < a.n_instances) ? i0 + ipb : a.n_instances;
-    if (i0 >= i1) return;
-    const uint32_t v = tile * BLOCK + tid;
-    const bool live = v < a.n_verts;
-    const uint32_t n_pieces = a.n_bones * 4;            // 16-byte columns of one palette
-
-    // columns of the palettes of the step that starts at instance `first`: piece q of the step = column (q % n_pieces)
-    // of instance first + q / n_pieces; pieces past the run's last instance are skipped at commit time
-    f32x4 col[PPT];
-    auto fetch = [&](uint32_t first) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.palette) + (size_t)first * n_pieces;
-        const uint32_t avail = (i1 - first < (uint32_t)STEP ? i1 - first : (uint32_t)STEP) * n_pieces;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const uint32_t q = (uint32_t)tid + (uint32_t)k * BLOCK;
-            col[k] = src[q < avail ? q : avail - 1];
-        }
-    };
-    auto commit = [&](uint32_t first, uint32_t buf) {
-        const uint32_t avail = (i1 - first < (uint32_t)STEP ? i1 - first : (uint32_t)STEP) * n_pieces;
-        bool pj[STEP];
-#pragma unroll
-        for (int j = 0; j < STEP; ++j) pj[j] = false;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const uint32_t q = (uint32_t)tid + (uint32_t)k * BLOCK;
-            if (q < avail) {
-                const uint32_t j = q / n_pieces, piece = q - j * n_pieces;
-                const uint32_t b = piece >> 2, c = piece & 3;
-                f32x4* rows = base + (buf * STEP + j) * pal_f4;
-                float* r = reinterpret_cast<float*>(rows + b * 3);
-                *reinterpret_cast<f32x2*>(r + 2 * c) = f32x2{col[k].x, col[k].y};
-                r[8 + c] = col[k].z;
-                reinterpret_cast<float*>(rows + 3 * a.n_bones + b)[c] = col[k].w;
-                const bool p = col[k].w != (c == 3 ? 1.0f : 0.0f);
-#pragma unroll
-                for (int jj = 0; jj < STEP; ++jj) pj[jj] |= p && (uint32_t)jj == j;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < STEP; ++j) {
-            const bool any = __any(pj[j]) != 0;
-            if (lane == 0) flags[(buf * STEP + j) * WPB + wave] = any ? 1u : 0u;
-        }
-    };
-
-    fetch(i0);
-    // the mesh is shared by every workgroup of the launch: ordinary (cacheable) loads
-    const VertexIn<MASK> vin = load_vertex<false, MASK>(a, live ? v : 0);
-    commit(i0, 0);
-    uint32_t cur = 0;
-    for (uint32_t first = i0; first < i1; first += STEP) {  // workgroup-uniform
-        const bool more = first + STEP < i1;
-        __syncthreads();   // buffer `cur` is complete; nobody reads buffer `cur ^ 1` any more
-        if (more) fetch(first + STEP);
-#pragma unroll
-        for (int j = 0; j < STEP; ++j) {
-            const uint32_t inst = first + (uint32_t)j;
-            if (inst >= i1) break;   // workgroup-uniform
-            const f32x4* rows = base + (cur * STEP + j) * pal_f4;
-            const f32x4* row3 = rows + 3 * a.n_bones;
-            bool projective = false;
-#pragma unroll
-            for (uint32_t wv = 0; wv < WPB; ++wv) projective |= flags[(cur * STEP + j) * WPB + wv] != 0;
-            // the crowd kernel is VALU-bound, so its fused mode blends the matrices first (see skin_vertex_blended)
-            const Skinned o = skin_vertex<EXACT, MASK, true>(rows, row3, projective, vin.id, vin.w, vin.p.x, vin.p.y,
-                                                             vin.p.z, vin.n.x, vin.n.y, vin.n.z, vin.t.x, vin.t.y, vin.t.z);
-            // this instance's outputs as buffer resources (a vertex past the end of the mesh is dropped by the hardware)
-            const size_t ofs = (size_t)inst * a.n_verts;
-            VtxBuffers ob;
-            ob.out_pos = make_stream(a.out_pos ? a.out_pos + ofs * 3 : nullptr, a.n_verts * 12u);
-            ob.out_nrm = make_stream(a.out_nrm ? a.out_nrm + ofs * 3 : nullptr, a.n_verts * 12u);
-            ob.out_tan = make_stream(a.out_tan ? a.out_tan + ofs * 4 : nullptr, a.n_verts * 16u);
-            store_vertex_buf<MASK, 16>(ob, v, o, vin.t.w);
-        }
-        if (more) commit(first + STEP, cur ^ 1);
-        cur ^= 1;
-    }
-}
-
-template <int BLOCK, bool EXACT, int MASK, int PPT>
-static hipError_t launch_crowd2_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    constexpr int STEP = 2;
-    const uint32_t tiles = (a.n_verts + BLOCK - 1) / BLOCK;
-    uint32_t ipb = (uint32_t)(t.crowd_ipb > 0 ? t.crowd_ipb : 0);
-    if (ipb == 0) {   // as launch_crowd_one: runs long enough to amortise the vertex loads, enough workgroups to fill the chip
-        const uint64_t pairs = (uint64_t)tiles * a.n_instances;
-        uint64_t want = pairs / ((uint64_t)kCUs * 4);
-        if (want < 2) want = 2;
-        if (want > 16) want = 16;
-        ipb = (uint32_t)want;
-    }
-    if (ipb > a.n_instances) ipb = a.n_instances;
-    const uint32_t chunks = (a.n_instances + ipb - 1) / ipb;
-    const uint64_t grid = (uint64_t)tiles * chunks;
-    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (size_t)a.n_bones * 64 * 2 * STEP + 2 * STEP * (BLOCK / 64) * sizeof(uint32_t);
-    if (lds > 64 * 1024) {   // four 256-bone palettes: above the default dynamic-LDS limit
-        static bool raised = false;   // per instantiation
-        if (!raised) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_skin_crowd2<BLOCK, EXACT, MASK, PPT, STEP>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
-    }
-    hipLaunchKernelGGL((lbs_skin_crowd2<BLOCK, EXACT, MASK, PPT, STEP>), dim3((uint32_t)grid), dim3(BLOCK), lds, s, a, tiles, ipb);
-    return hipGetLastError();
-}
-
-template <int BLOCK, bool EXACT, int MASK>
-static hipError_t launch_crowd2_ppt(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    const uint32_t need = (2u * a.n_bones * 4u + BLOCK - 1) / BLOCK;     // columns per thread and step of two instances
-    if (need <= 1) return launch_crowd2_one<BLOCK, EXACT, MASK, 1>(a, t, s);
-    if (need <= 2) return launch_crowd2_one<BLOCK, EXACT, MASK, 2>(a, t, s);
-    if (need <= 4) return launch_crowd2_one<BLOCK, EXACT, MASK, 4>(a, t, s);
-    return launch_crowd2_one<BLOCK, EXACT, MASK, 8>(a, t, s);
-}
-
-template <int BLOCK, bool EXACT>
-static hipError_t launch_crowd2_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
-    switch (mask) {
-        case 1: return launch_crowd2_ppt<BLOCK, EXACT, 1>(a, t, s);
-        case 2: return launch_crowd2_ppt<BLOCK, EXACT, 2>(a, t, s);
-        case 3: return launch_crowd2_ppt<BLOCK, EXACT, 3>(a, t, s);
-        case 4: return launch_crowd2_ppt<BLOCK, EXACT, 4>(a, t, s);
-        case 5: return launch_crowd2_ppt<BLOCK, EXACT, 5>(a, t, s);
-        case 6: return launch_crowd2_ppt<BLOCK, EXACT, 6>(a, t, s);
-        case 7: return launch_crowd2_ppt<BLOCK, EXACT, 7>(a, t, s);
-        default: return hipSuccess;
-    }
-}
-
 template <int BLOCK, bool EXACT, int MASK>
 static hipError_t launch_crowd_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     const uint32_t tiles = (a.n_verts + BLOCK - 1) / BLOCK;
@@ -923,11 +773,6 @@ static hipError_t launch_crowd_mask(const LbsArgs& a, const LbsTuning& t, hipStr
 }
 
 static hipError_t launch_crowd(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    if (t.crowd_form == 2 && a.n_verts <= 0x0fffffffu) {
-        if (t.crowd_block == 512)
-            return t.exact ? launch_crowd2_mask<512, true>(a, t, s) : launch_crowd2_mask<512, false>(a, t, s);
-        return t.exact ? launch_crowd2_mask<256, true>(a, t, s) : launch_crowd2_mask<256, false>(a, t, s);
-    }
     if (t.crowd_block == 512)
         return t.exact ? launch_crowd_mask<512, true>(a, t, s) : launch_crowd_mask<512, false>(a, t, s);
     return t.exact ? launch_crowd_mask<256, true>(a, t, s) : launch_crowd_mask<256, false>(a, t, s);

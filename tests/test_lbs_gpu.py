@@ -44,13 +44,18 @@ def assert_bit_exact(got, ref):
             f"{k}: max rel err {rel_err(got[k], ref[k]):.3e}"
 
 
-@pytest.fixture(autouse=True)
-def _defaults(ctx):
+def _set_defaults(ctx):
     for k, v in (("lbs.block", 512), ("lbs.blocks_per_cu", 4), ("lbs.prefetch", 1), ("lbs.exact", 1), ("lbs.nt", 1), ("lbs.streams", 2),
-                 ("lbs.crowd", -1), ("lbs.crowd_block", 512), ("lbs.crowd_ipb", 0), ("lbs.crowd_form", 2), ("lbs.split", 0), ("lbs.dyn", 1),
+                 ("lbs.crowd", -1), ("lbs.crowd_block", 512), ("lbs.crowd_ipb", 0), ("lbs.split", 0), ("lbs.dyn", 1),
                  ("lbs.dyn_bpc", 0), ("lbs.dyn_block", 256), ("lbs.asym", 0), ("lbs.young_prio", 0)):
         ctx.set_option(k, v)
+
+
+@pytest.fixture(autouse=True)
+def _defaults(ctx):
+    _set_defaults(ctx)
     yield
+    _set_defaults(ctx)      # the context is shared by the whole session: leave it as it was found
 
 
 # ---- BASELINE configs ---------------------------------------------------------------------
@@ -322,26 +327,23 @@ def test_instanced_variants(ctx, orc, block, bpcu, n_inst, n_verts):
     assert_bit_exact(ctx.lbs_skin(7, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst))
 
 
-@pytest.mark.parametrize("form", [2, 1])
 @pytest.mark.parametrize("cblock,ipb", [(256, 0), (256, 1), (512, 3), (512, 0), (256, 4096)])
 @pytest.mark.parametrize("n_inst,n_verts", [(1, 1000), (3, 1000), (5, 1001), (2, 4096), (7, 13), (300, 65), (2000, 3),
                                             (33, 10_000)])
-def test_crowd_kernel_variants(ctx, orc, form, cblock, ipb, n_inst, n_verts):
-    # vertices held in registers, palettes double-buffered in LDS; form 1: one barrier per instance, bone-owning threads
-    # stage the palette; form 2 (default): two instances per barrier, every thread stages matrix columns
+def test_crowd_kernel_variants(ctx, orc, cblock, ipb, n_inst, n_verts):
+    # vertices held in registers, palettes double-buffered in LDS, one barrier per instance
     m = synth.make_mesh(n_verts, 32, 7)
     pal = synth.make_palette(32, 7, n_instances=n_inst)
     upload(ctx, 7, m)
     ctx.set_option("lbs.crowd", 1); ctx.set_option("lbs.crowd_block", cblock); ctx.set_option("lbs.crowd_ipb", ipb)
-    ctx.set_option("lbs.crowd_form", form)
     assert_bit_exact(ctx.lbs_skin(7, pal, n_instances=n_inst), oracle_skin(orc, m, pal, n_inst))
 
 
-@pytest.mark.parametrize("form,cblock", [(2, 512), (2, 256), (1, 512)])
-def test_crowd_kernel_edge_palettes(ctx, orc, form, cblock):
-    # 256 bones (form 2: four palettes = 64 KiB of LDS, above the default dynamic limit), one projective matrix in ONE
-    # instance of the run (the flag is per palette), positions-only and normal-only launches, fused arithmetic within 1e-5
-    ctx.set_option("lbs.crowd_form", form); ctx.set_option("lbs.crowd_block", cblock)
+@pytest.mark.parametrize("cblock", [512, 256])
+def test_crowd_kernel_edge_palettes(ctx, orc, cblock):
+    # 256 bones (2 x 16 KiB of LDS), one projective matrix in ONE instance of the run (the flag is
+    # per palette buffer), positions-only and normal-only launches, fused arithmetic within 1e-5
+    ctx.set_option("lbs.crowd_block", cblock)
     n_inst = 9
     m = synth.make_mesh(3001, 256, 19, coherent=False)
     pal = synth.make_palette(256, 19, n_instances=n_inst).copy()

@@ -49,8 +49,7 @@ def run(label, **opts):
 
 run("stream", crowd=0)
 for exact in (1, 0):
-    for form in (1, 2):
-        for cb in (256, 512):
-            for ipb in (0, 2, 4, 8, 16, 32, 64):
-                run("crowd", crowd=1, crowd_form=form, crowd_block=cb, crowd_ipb=ipb, exact=exact)
+    for cb in (256, 512):
+        for ipb in (0, 2, 4, 8, 16, 32, 64):
+            run("crowd", crowd=1, crowd_block=cb, crowd_ipb=ipb, exact=exact)
 ctx.close()
