@@ -1,0 +1,804 @@
+"""fyrox-animation restated (test infrastructure, see __init__): Track / Animation / AnimationPose / Machine.
+
+Values are tagged tuples ("real" | "v2" | "v3" | "v4" | "quat", components); a node pose is an ordered list of
+(binding, value); an animation pose is {node: [..]} plus an optional root motion -- the shapes of the Rust types
+(value.rs, pose.rs), kept as Python containers.  Descriptions are duck-typed fyrox_amd.anim dataclasses (nothing is
+imported from the product)."""
+from collections import deque
+
+import numpy as np
+
+from . import na
+from .curve import Curve, Key, clampf, lerpf, wrapf
+from .na import F, ONE, Q_IDENTITY, ZERO
+from .scene import global_matrices, local_matrix, palette as _palette
+
+BIND_POSITION, BIND_SCALE, BIND_ROTATION, BIND_PROPERTY0 = 0, 1, 2, 3
+KIND_REAL, KIND_VEC2, KIND_VEC3, KIND_VEC4, KIND_QUAT_EULER, KIND_QUAT = range(6)
+EPSILON = F(np.finfo(np.float32).eps)
+X_AXIS, Y_AXIS, Z_AXIS = (ONE, ZERO, ZERO), (ZERO, ONE, ZERO), (ZERO, ZERO, ONE)
+
+
+# ---- value.rs ------------------------------------------------------------------------------------------------------------
+def nlerp(a, b, w):
+    """value.rs:449-454: flip `a` when the dot product is negative, then nalgebra's nlerp"""
+    if na.dot4(a, b) < ZERO:
+        a = na.q_neg(a)
+    return na.q_nlerp(a, b, w)
+
+
+def blend_value(a, b, w):
+    """TrackValue::blend_with (value.rs:221-230): same variants only"""
+    ka, va = a
+    kb, vb = b
+    if ka != kb:
+        return a
+    if ka == "real":
+        return (ka, (lerpf(va[0], vb[0], w),))
+    if ka == "quat":
+        return (ka, nlerp(va, vb, w))
+    return (ka, na.vlerp(va, vb, w))
+
+
+def blend_node_values(mine, other, w):
+    """NodePose::blend_with (pose.rs:41-47) + BoundValueCollection::blend_with (value.rs:438-444), in place on `mine`"""
+    if not mine:
+        mine[:] = list(other)
+        return
+    for idx, (binding, value) in enumerate(mine):
+        for ob, ov in other:
+            if ob == binding:
+                mine[idx] = (binding, blend_value(value, ov, w))
+                break
+
+
+class RootMotion:
+    """lib.rs:325-343"""
+
+    def __init__(self):
+        self.delta_position = (ZERO, ZERO, ZERO)
+        self.delta_rotation = Q_IDENTITY
+        self.prev_position = (ZERO, ZERO, ZERO)
+        self.position_offset_remainder = None
+        self.prev_rotation = Q_IDENTITY
+        self.rotation_remainder = None
+
+    def clone(self):
+        r = RootMotion()
+        r.__dict__.update(self.__dict__)
+        return r
+
+    def blend_with(self, other, w):
+        self.delta_position = na.vlerp(self.delta_position, other.delta_position, w)
+        self.delta_rotation = nlerp(self.delta_rotation, other.delta_rotation, w)
+
+
+class Pose:
+    """AnimationPose (pose.rs:50-135)"""
+
+    def __init__(self):
+        self.poses = {}
+        self.root_motion = None
+
+    def reset(self):
+        for v in self.poses.values():
+            del v[:]
+
+    def clone_into(self, dest: "Pose"):
+        dest.reset()
+        for node, values in self.poses.items():
+            dest.poses[node] = list(values)
+        dest.root_motion = None if self.root_motion is None else self.root_motion.clone()
+
+    def blend_with(self, other: "Pose", w):
+        for node, values in other.poses.items():
+            if node in self.poses:
+                blend_node_values(self.poses[node], values, w)
+            else:
+                self.poses[node] = list(values)
+        if self.root_motion is None:
+            self.root_motion = RootMotion()
+        self.root_motion.blend_with(other.root_motion.clone() if other.root_motion is not None else RootMotion(), w)
+
+    def add(self, node, bound_value):
+        self.poses.setdefault(node, []).append(bound_value)
+
+
+# ---- container.rs / track.rs ----------------------------------------------------------------------------------------------
+class Track:
+    def __init__(self, binding, kind, curves):
+        self.binding, self.kind, self.curves = int(binding), int(kind), curves
+
+    def fetch(self, time, hints):
+        """TrackDataContainer::fetch (container.rs:182-297) -> value or None; `hints` is the binding's [usize; 4]"""
+        need = {KIND_REAL: 1, KIND_VEC2: 2, KIND_VEC3: 3, KIND_VEC4: 4, KIND_QUAT_EULER: 3, KIND_QUAT: 4}[self.kind]
+        if len(self.curves) < need:
+            return None
+        c = []
+        for i in range(need):
+            v, hints[i] = self.curves[i].value_at(time, hints[i])
+            c.append(v)
+        if self.kind == KIND_REAL:
+            return ("real", (c[0],))
+        if self.kind == KIND_VEC2:
+            return ("v2", tuple(c))
+        if self.kind == KIND_VEC3:
+            return ("v3", tuple(c))
+        if self.kind == KIND_VEC4:
+            return ("v4", tuple(c))
+        if self.kind == KIND_QUAT_EULER:
+            # quat_from_euler(.., XYZ) = qz * qy * qx (fyrox-math/src/lib.rs:725-740)
+            qx = na.q_from_axis_angle(X_AXIS, c[0])
+            qy = na.q_from_axis_angle(Y_AXIS, c[1])
+            qz = na.q_from_axis_angle(Z_AXIS, c[2])
+            return ("quat", na.q_mul(na.q_mul(qz, qy), qx))
+        # UnitQuaternion::from_quaternion(Quaternion::new(w, x, y, z)): curves are x, y, z, w
+        return ("quat", na.q_normalize((c[0], c[1], c[2], c[3])))
+
+
+def make_tracks(td):
+    out = []
+    for t in td.tracks:
+        curves = [Curve([Key(k.location, k.value, k.kind, k.left_tangent, k.right_tangent) for k in c.keys]) for c in t.curves]
+        out.append(Track(t.binding, t.kind, curves))
+    return out
+
+
+# ---- lib.rs: Animation -----------------------------------------------------------------------------------------------------
+class Animation:
+    def __init__(self, tracks):
+        self.tracks = tracks
+        self.bindings = [None] * len(tracks)      # per track: [target, enabled, hints]
+        self.time_position = ZERO
+        self.slice_start, self.slice_end = ZERO, ZERO
+        self.speed = ONE
+        self.looped = True
+        self.enabled = True
+        self.signals = []                          # [time, enabled]
+        self.events = deque()
+        self.max_event_capacity = 32
+        self.rm_settings = None                    # (node, ignore x, y, z, rotations)
+        self.root_motion = None
+        self.pose = Pose()
+
+    def set_time_position(self, t):
+        """lib.rs:432-440"""
+        t = F(t)
+        if self.looped:
+            self.time_position = wrapf(t, self.slice_start, self.slice_end)
+        else:
+            self.time_position = clampf(t, self.slice_start, self.slice_end)
+
+    def set_time_slice(self, start, end):
+        self.slice_start, self.slice_end = F(start), F(end)
+        self.set_time_position(self.time_position)
+
+    def rewind(self):
+        self.set_time_position(self.slice_start)
+
+    def has_ended(self):
+        """lib.rs:736-738"""
+        return (not self.looped) and abs(self.time_position - self.slice_end) <= EPSILON
+
+    def update_pose(self):
+        """lib.rs:895-914"""
+        self.pose.reset()
+        for track, b in zip(self.tracks, self.bindings):
+            if b is None or not b[1]:
+                continue
+            v = track.fetch(self.time_position, b[2])
+            if v is not None:
+                self.pose.add(b[0], (track.binding, v))
+
+    def tick(self, dt):
+        """lib.rs:471-496: sample at the CURRENT time, raise signals for the step, advance, root motion"""
+        dt = F(dt)
+        self.update_pose()
+        cur = self.time_position
+        new = cur + dt * self.speed
+        for sid, (time, enabled) in enumerate(self.signals):
+            if not enabled:
+                continue
+            # `a && b || c && d && e`: the capacity test belongs to the reverse-playback arm only (lib.rs:478-482)
+            if (self.speed >= ZERO and (cur < time and new >= time)) or \
+               (self.speed < ZERO and (cur > time and new <= time) and len(self.events) < self.max_event_capacity):
+                self.events.append(sid)
+        prev = cur
+        self.set_time_position(new)
+        self.update_root_motion(prev)
+
+    def _fetch_first(self, binding, want, time, default):
+        """fetch_position_at_time / fetch_rotation_at_time (lib.rs:507-534): FIRST track of the data with that binding"""
+        for t in self.tracks:
+            if t.binding == binding:
+                v = t.fetch(time, [0, 0, 0, 0])
+                if v is not None and v[0] == want:
+                    return v[1]
+                return default
+        return default
+
+    def update_root_motion(self, prev_time):
+        """lib.rs:498-661"""
+        if self.rm_settings is None:
+            return
+        node, ign_x, ign_y, ign_z, ign_rot = self.rm_settings
+        prev_rm = self.root_motion.clone() if self.root_motion is not None else RootMotion()
+        new_cycle = self.looped and ((self.speed > ZERO and self.time_position < prev_time) or
+                                     (self.speed < ZERO and self.time_position > prev_time))
+        cycle_start = self.slice_start if self.speed > ZERO else self.slice_end
+        cycle_end = self.slice_end if self.speed > ZERO else self.slice_start
+        zero3 = (ZERO, ZERO, ZERO)
+        rm = RootMotion()
+        values = self.pose.poses.get(node)
+        if values is not None:
+            for idx, (binding, value) in enumerate(values):
+                if binding == BIND_POSITION and value[0] == "v3":
+                    p = value[1]
+                    if new_cycle:
+                        rm.prev_position = self._fetch_first(BIND_POSITION, "v3", cycle_start, zero3)
+                        rm.position_offset_remainder = na.vsub(self._fetch_first(BIND_POSITION, "v3", cycle_end, zero3), p)
+                    else:
+                        rm.prev_position = p
+                    remainder = prev_rm.position_offset_remainder if prev_rm.position_offset_remainder is not None else zero3
+                    prev_rm.position_offset_remainder = None
+                    delta = na.vadd(na.vsub(p, prev_rm.prev_position), remainder)
+                    rm.delta_position = (ZERO if ign_x else delta[0], ZERO if ign_y else delta[1], ZERO if ign_z else delta[2])
+                    start = self._fetch_first(BIND_POSITION, "v3", self.slice_start, zero3)
+                    values[idx] = (binding, ("v3", (p[0] if ign_x else start[0], p[1] if ign_y else start[1],
+                                                    p[2] if ign_z else start[2])))
+                elif binding == BIND_ROTATION and value[0] == "quat":
+                    if ign_rot:
+                        continue
+                    r = value[1]
+                    if new_cycle:
+                        rm.prev_rotation = self._fetch_first(BIND_ROTATION, "quat", cycle_start, Q_IDENTITY)
+                        rm.rotation_remainder = na.q_mul(na.q_inverse(self._fetch_first(BIND_ROTATION, "quat", cycle_end, Q_IDENTITY)), r)
+                    else:
+                        rm.prev_rotation = r
+                    remainder = prev_rm.rotation_remainder if prev_rm.rotation_remainder is not None else Q_IDENTITY
+                    prev_rm.rotation_remainder = None
+                    rel = na.q_mul(na.q_inverse(prev_rm.prev_rotation), r)
+                    rm.delta_rotation = na.q_mul(remainder, rel)
+                    values[idx] = (binding, ("quat", self._fetch_first(BIND_ROTATION, "quat", self.slice_start, Q_IDENTITY)))
+        self.root_motion = rm
+
+
+# ---- machine/node/*.rs ------------------------------------------------------------------------------------------------------
+class _Ctx:
+    """what every eval_pose receives: the layer's node pool, the parameters, the animation container, dt"""
+
+    def __init__(self, nodes, params, animations, dt, rng=None):
+        self.nodes, self.params, self.animations, self.dt, self.rng = nodes, params, animations, dt, rng
+
+    def node(self, h):
+        return self.nodes[h] if 0 <= h < len(self.nodes) else None
+
+    def anim(self, h):
+        return self.animations[h] if 0 <= h < len(self.animations) else None
+
+    def param(self, h, kind):
+        if 0 <= h < len(self.params) and self.params[h][0] == kind:
+            return self.params[h][1]
+        return None
+
+
+PARAM_WEIGHT, PARAM_RULE, PARAM_INDEX, PARAM_SAMPLING_POINT = range(4)
+
+
+class PlayNode:
+    """play.rs:86-100"""
+
+    def __init__(self, d):
+        self.animation = d.animation
+        self.out = Pose()
+
+    def eval(self, cx):
+        a = cx.anim(self.animation)
+        if a is not None:
+            a.pose.clone_into(self.out)
+            self.out.root_motion = None if a.root_motion is None else a.root_motion.clone()
+        return self.out
+
+    def collect(self, cx, acc):
+        acc.append(self.animation)
+
+
+class BlendNode:
+    """blend.rs:136-164: out.reset(); for every source: out.blend_with(source.eval_pose(), weight)"""
+
+    def __init__(self, d):
+        self.sources = [(b.pose_source, F(b.weight), b.parameter) for b in d.pose_sources]
+        self.out = Pose()
+
+    def eval(self, cx):
+        self.out.reset()
+        for src, const_w, par in self.sources:
+            if par is None:
+                w = const_w
+            else:
+                pv = cx.param(par, PARAM_WEIGHT)
+                w = pv if pv is not None else ZERO
+            n = cx.node(src)
+            if n is not None:
+                self.out.blend_with(n.eval(cx), w)
+        return self.out
+
+    def collect(self, cx, acc):
+        for src, _, _ in self.sources:
+            n = cx.node(src)
+            if n is not None:
+                n.collect(cx, acc)
+
+
+class ByIndexNode:
+    """blend.rs:306-361"""
+
+    def __init__(self, d):
+        self.index_parameter = d.index_parameter
+        self.inputs = [(F(i.blend_time), i.pose_source) for i in d.inputs]
+        self.prev_index = None
+        self.blend_time = ZERO
+        self.out = Pose()
+
+    def eval(self, cx):
+        self.out.reset()
+        cur = cx.param(self.index_parameter, PARAM_INDEX)
+        if cur is not None:
+            applied = False
+            if self.prev_index is not None:
+                if self.prev_index != cur:
+                    if self.prev_index < len(self.inputs) and cur < len(self.inputs):
+                        prev_in, cur_in = self.inputs[self.prev_index], self.inputs[cur]
+                        self.blend_time = min(self.blend_time + cx.dt, cur_in[0])     # f32::min
+                        k = self.blend_time / cur_in[0]
+                        self.out.blend_with(cx.nodes[prev_in[1]].eval(cx), ONE - k)
+                        self.out.blend_with(cx.nodes[cur_in[1]].eval(cx), k)
+                        if k >= ONE:
+                            self.prev_index = cur
+                            self.blend_time = ZERO
+                        applied = True
+            else:
+                self.prev_index = cur
+            if not applied:
+                self.blend_time = ZERO
+                if cur < len(self.inputs):
+                    cx.nodes[self.inputs[cur][1]].eval(cx).clone_into(self.out)
+        return self.out
+
+    def collect(self, cx, acc):
+        for _, src in self.inputs:
+            n = cx.node(src)
+            if n is not None:
+                n.collect(cx, acc)
+
+
+class BlendSpaceNode:
+    """blendspace.rs:118-150, fetch_weights :338-414"""
+
+    def __init__(self, d):
+        self.sampling_parameter = d.sampling_parameter
+        self.points = [((F(p.position[0]), F(p.position[1])), p.pose_source) for p in d.points]
+        self.triangles = [tuple(int(x) for x in t) for t in d.triangles]
+        self.out = Pose()
+
+    def fetch_weights(self, sp):
+        pts = self.points
+        if not pts:
+            return None
+        if len(pts) == 1:
+            return [(0, ONE), (0, ZERO), (0, ZERO)]
+        if len(pts) == 2:
+            edge = na.vsub(pts[1][0], pts[0][0])
+            to_point = na.vsub(sp, pts[0][0])
+            t = na.dot2(to_point, edge) / na.dot2(edge, edge)
+            if ZERO <= t <= ONE:
+                return [(0, ONE - t), (1, t), (0, ZERO)]
+        for ia, ib, ic in self.triangles:
+            a, b, c = pts[ia][0], pts[ib][0], pts[ic][0]
+            # get_barycentric_coords_2d (fyrox-math/src/lib.rs:291-313)
+            v0, v1, v2 = na.vsub(b, a), na.vsub(c, a), na.vsub(sp, a)
+            d00, d01, d11 = na.dot2(v0, v0), na.dot2(v0, v1), na.dot2(v1, v1)
+            d20, d21 = na.dot2(v2, v0), na.dot2(v2, v1)
+            inv_denom = ONE / (d00 * d11 - d01 * d01)
+            v = (d11 * d20 - d01 * d21) * inv_denom
+            w = (d00 * d21 - d01 * d20) * inv_denom
+            u = ONE - v - w
+            if u >= ZERO and v >= ZERO and u + v < ONE:      # barycentric_is_inside (:326-328)
+                return [(ia, u), (ib, v), (ic, w)]
+        best, weights = F(np.finfo(np.float32).max), None
+        for tri in self.triangles:
+            for a, b in ((tri[0], tri[1]), (tri[1], tri[2]), (tri[2], tri[0])):
+                pa, pb = pts[a][0], pts[b][0]
+                edge = na.vsub(pb, pa)
+                to_point = na.vsub(sp, pa)
+                t = na.dot2(to_point, edge) / na.dot2(edge, edge)
+                if ZERO <= t <= ONE:
+                    proj = na.vadd(pa, na.vscale(edge, t))
+                    dist = na.norm(na.vsub(sp, proj))
+                    if dist < best:
+                        best = dist
+                        weights = [(a, ONE - t), (b, t), (b, ZERO)]
+        return weights
+
+    def eval(self, cx):
+        self.out.reset()
+        sp = cx.param(self.sampling_parameter, PARAM_SAMPLING_POINT)
+        if sp is not None:
+            ws = self.fetch_weights(sp)
+            if ws is not None:
+                ns = [cx.node(self.points[i][1]) for i, _ in ws]
+                if all(n is not None for n in ns):
+                    for n, (_, w) in zip(ns, ws):
+                        self.out.blend_with(n.eval(cx), w)
+        return self.out
+
+    def collect(self, cx, acc):
+        for _, src in self.points:
+            n = cx.node(src)
+            if n is not None:
+                n.collect(cx, acc)
+
+
+def _make_node(d):
+    name = type(d).__name__
+    return {"PlayAnimation": PlayNode, "BlendAnimations": BlendNode, "BlendAnimationsByIndex": ByIndexNode,
+            "BlendSpace": BlendSpaceNode}[name](d)
+
+
+# ---- machine/{state,transition,layer,mask,mod}.rs ------------------------------------------------------------------------------
+def _logic(cond, cx):
+    """LogicNode::calculate_value (transition.rs:141-173)"""
+    op = cond[0]
+    if op == "parameter":
+        v = cx.param(cond[1], PARAM_RULE)
+        return bool(v) if v is not None else False
+    if op == "ended":
+        a = cx.anim(cond[1])
+        return True if a is None else a.has_ended()
+    if op == "not":
+        return not _logic(cond[1], cx)
+    lhs, rhs = _logic(cond[1], cx), _logic(cond[2], cx)
+    return {"and": lhs and rhs, "or": lhs or rhs, "xor": lhs != rhs}[op]
+
+
+ACTION_NONE, ACTION_REWIND, ACTION_ENABLE, ACTION_DISABLE, ACTION_ENABLE_RANDOM = range(5)
+EVENT_STATE_ENTER, EVENT_STATE_LEAVE, EVENT_ACTIVE_STATE_CHANGED, EVENT_ACTIVE_TRANSITION_CHANGED = range(4)
+
+
+MASK64 = (1 << 64) - 1
+
+
+def _apply_action(action, cx):
+    """StateAction::apply (state.rs:86-116).  EnableRandomAnimation draws from rand::thread_rng() in the reference, which
+    nobody can reproduce; the PRODUCT documents its own generator (include/fyrox_hip.h, fyx_state_add_random_action:
+    one splitmix64 step per draw, index = (draw * n) >> 64, nothing drawn for an empty list) and that documented stream
+    is what is restated here -- what an invalid or absent choice does is the reference's."""
+    kind, anim = action
+    if kind == ACTION_ENABLE_RANDOM:
+        handles = list(anim)
+        if not handles:
+            return
+        st = cx.rng
+        st[0] = (st[0] + 0x9E3779B97F4A7C15) & MASK64
+        z = st[0]
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        draw = z ^ (z >> 31)
+        a = cx.anim(handles[(draw * len(handles)) >> 64])
+        if a is not None:
+            a.enabled = True
+        return
+    a = cx.anim(anim) if kind in (ACTION_REWIND, ACTION_ENABLE, ACTION_DISABLE) else None
+    if a is None:
+        return
+    if kind == ACTION_REWIND:
+        a.rewind()
+    elif kind == ACTION_ENABLE:
+        a.enabled = True
+    elif kind == ACTION_DISABLE:
+        a.enabled = False
+
+
+class Layer:
+    def __init__(self, d):
+        self.nodes = [_make_node(n) for n in d.nodes]
+        self.states = [(s.root, list(s.on_enter_actions), list(s.on_leave_actions)) for s in d.states]
+        # [source, dest, transition_time, condition, elapsed, blend_factor]
+        self.transitions = [[t.source, t.dest, F(t.transition_time), t.condition, ZERO, ZERO] for t in d.transitions]
+        self.weight = F(d.weight)
+        self.mask = set(int(x) for x in d.mask)
+        self.active_state = 0 if self.states else -1        # add_state: the first state becomes active (layer.rs:229-235)
+        if d.entry_state is not None:
+            self.active_state = d.entry_state
+        self.active_transition = -1
+        self.final = Pose()
+        self.events = []
+
+    def _state(self, h):
+        return self.states[h] if 0 <= h < len(self.states) else None
+
+    def _state_pose(self, h, cx):
+        s = self._state(h)
+        if s is None:
+            return None
+        n = cx.node(s[0])
+        return None if n is None else n.out
+
+    def evaluate(self, cx):
+        """MachineLayer::evaluate_pose (layer.rs:590-706)"""
+        self.final.reset()
+        if self.active_state >= 0 or self.active_transition >= 0:
+            for root, _, _ in self.states:
+                n = cx.node(root)
+                if n is not None:
+                    n.eval(cx)
+            if self.active_transition < 0:
+                for h, tr in enumerate(self.transitions):
+                    if tr[1] == self.active_state or tr[0] != self.active_state:
+                        continue
+                    if _logic(tr[3], cx):
+                        s = self._state(self.active_state)
+                        if s is not None:
+                            for act in s[2]:
+                                _apply_action(act, cx)
+                        self.events.append((EVENT_STATE_LEAVE, self.active_state, -1))
+                        d = self._state(tr[1])
+                        if d is not None:
+                            for act in d[1]:
+                                _apply_action(act, cx)
+                        self.events.append((EVENT_STATE_ENTER, tr[1], -1))
+                        self.active_state = -1
+                        self.active_transition = h
+                        self.events.append((EVENT_ACTIVE_TRANSITION_CHANGED, h, -1))
+                        break
+            if self.active_transition >= 0:
+                tr = self.transitions[self.active_transition]
+                src = self._state_pose(tr[0], cx)
+                if src is not None:
+                    self.final.blend_with(src, ONE - tr[5])
+                dst = self._state_pose(tr[1], cx)
+                if dst is not None:
+                    self.final.blend_with(dst, tr[5])
+                # Transition::update (transition.rs:314-320)
+                tr[4] = tr[4] + cx.dt
+                if tr[4] > tr[2]:
+                    tr[4] = tr[2]
+                tr[5] = tr[4] / tr[2]
+                if abs(tr[2] - tr[4]) <= EPSILON:                     # is_done
+                    tr[4], tr[5] = ZERO, ZERO
+                    self.active_transition = -1
+                    self.events.append((EVENT_ACTIVE_TRANSITION_CHANGED, -1, -1))
+                    self.active_state = tr[1]
+                    self.events.append((EVENT_ACTIVE_STATE_CHANGED, tr[0], tr[1]))
+            else:
+                p = self._state_pose(self.active_state, cx)
+                if p is not None:
+                    p.clone_into(self.final)
+        for node in [n for n in self.final.poses if n in self.mask]:     # retain(|h, _| mask.should_animate(h))
+            del self.final.poses[node]
+        return self.final
+
+
+class Machine:
+    def __init__(self, d):
+        self.params = []
+        for p in d.parameters:
+            self.params.append(self._param(p))
+        self.layers = [Layer(l) for l in d.layers]
+        self.final = Pose()
+        self.rng = [0]           # state of the documented EnableRandomAnimation stream
+
+    @staticmethod
+    def _param(p):
+        if p.kind == PARAM_WEIGHT:
+            return (PARAM_WEIGHT, F(p.value))
+        if p.kind == PARAM_RULE:
+            return (PARAM_RULE, bool(p.value))
+        if p.kind == PARAM_INDEX:
+            return (PARAM_INDEX, int(p.value))
+        return (PARAM_SAMPLING_POINT, (F(p.value[0]), F(p.value[1])))
+
+    def evaluate(self, animations, dt):
+        """Machine::evaluate_pose (machine/mod.rs:344-382)"""
+        dt = F(dt)
+        self.final.reset()
+        cache = []
+        for layer in self.layers:
+            cx = _Ctx(layer.nodes, self.params, animations, dt)
+            check = [layer.active_state]
+            if 0 <= layer.active_transition < len(layer.transitions):
+                tr = layer.transitions[layer.active_transition]
+                check += [tr[0], tr[1]]
+            for s in check:
+                st = layer._state(s)
+                if st is not None:
+                    n = cx.node(st[0])
+                    if n is not None:
+                        n.collect(cx, cache)
+        seen = set()
+        for h in cache:                      # a set in the Rust: every animation ticks once, in no order that matters
+            if h in seen:
+                continue
+            seen.add(h)
+            a = animations[h] if 0 <= h < len(animations) else None
+            if a is not None and a.enabled:
+                a.tick(dt)
+        for layer in self.layers:
+            cx = _Ctx(layer.nodes, self.params, animations, dt, self.rng)
+            self.final.blend_with(layer.evaluate(cx), layer.weight)
+        return self.final
+
+
+# ---- the scene around it: nodes' transforms, apply, matrices ----------------------------------------------------------------
+def _records(pose: Pose, n_nodes: int) -> np.ndarray:
+    """(n_nodes, 12) float32: pos xyz, present bits (1 position, 2 scale, 4 rotation, 8 a property value), rot ijkw,
+    scale xyz, 0 -- the layout tests compare poses in"""
+    out = np.zeros((n_nodes, 12), np.float32)
+    out[:, 7] = 1.0                                   # an absent rotation reads as the identity
+    bits = np.zeros(n_nodes, np.uint32)
+    for node, values in pose.poses.items():
+        if not (0 <= node < n_nodes):
+            continue
+        seen = set()
+        for binding, (kind, v) in values:
+            if binding in seen:                       # lookups by binding find the first value
+                continue
+            seen.add(binding)
+            if binding == BIND_POSITION and kind == "v3":
+                out[node, 0:3] = v; bits[node] |= 1
+            elif binding == BIND_SCALE and kind == "v3":
+                out[node, 8:11] = v; bits[node] |= 2
+            elif binding == BIND_ROTATION and kind == "quat":
+                out[node, 4:8] = v; bits[node] |= 4
+            elif binding >= BIND_PROPERTY0:
+                bits[node] |= 8
+    out[:, 3] = bits.view(np.float32)
+    return out
+
+
+class AnimScene:
+    """One instance of: rig nodes + AnimationContainer + optional Machine (the interface of oracle.AnimScene)."""
+
+    def __init__(self, rig):
+        self.n_nodes = len(rig.transforms)
+        self.parent = [int(p) for p in rig.parent]
+        f3 = lambda a: tuple(F(x) for x in a)
+        self.nodes = []
+        for t in rig.transforms:
+            self.nodes.append({"position": f3(t.local_position), "rotation": f3(t.local_rotation), "scale": f3(t.local_scale),
+                               "pre_rotation": f3(t.pre_rotation), "post_rotation_matrix": f3(t.post_rotation_matrix),
+                               "rotation_offset": f3(t.rotation_offset), "rotation_pivot": f3(t.rotation_pivot),
+                               "scaling_offset": f3(t.scaling_offset), "scaling_pivot": f3(t.scaling_pivot)})
+        self.inv_bind = (np.tile(np.eye(4, dtype=np.float32).reshape(16), (self.n_nodes, 1)) if rig.inv_bind is None
+                         else np.ascontiguousarray(rig.inv_bind, dtype=np.float32).reshape(self.n_nodes, 16))
+        self.tracks = []
+        self.anims = []
+        self.machine = None
+        self.props = {}
+
+    def add_tracks_data(self, td) -> int:
+        self.tracks.append(make_tracks(td))
+        return len(self.tracks) - 1
+
+    def add_animation(self, tracks_index, track_target, track_enabled=None, *, time_slice=None, speed=None, looped=None,
+                      enabled=None, signals=(), root_motion=None, max_event_capacity=None) -> int:
+        a = Animation(self.tracks[tracks_index])
+        for time, en in signals:
+            a.signals.append((F(time), bool(en)))
+        if root_motion is not None:
+            node, ix, iy, iz, ir = root_motion
+            a.rm_settings = (int(node), bool(ix), bool(iy), bool(iz), bool(ir))
+        if max_event_capacity is not None:
+            a.max_event_capacity = int(max_event_capacity)
+        for t, tgt in enumerate(track_target):
+            a.bindings[t] = [int(tgt), True if track_enabled is None else bool(track_enabled[t]), [0, 0, 0, 0]]
+        if looped is not None:
+            a.looped = bool(looped)
+        if time_slice is not None:
+            a.set_time_slice(time_slice[0], time_slice[1])
+        if speed is not None:
+            a.speed = F(speed)
+        if enabled is not None:
+            a.enabled = bool(enabled)
+        self.anims.append(a)
+        return len(self.anims) - 1
+
+    def set_machine(self, m) -> None:
+        self.machine = Machine(m)
+
+    def set_parameter(self, index, p) -> None:
+        self.machine.params[index] = Machine._param(p)
+
+    def set_random_state(self, state: int) -> None:
+        self.machine.rng[0] = state & MASK64
+
+    def remove_animation(self, a: int) -> None:
+        self.anims[a] = None
+
+    # BoundValueCollectionExt::apply (scene/animation/mod.rs:147-186): Transform::set_* store the value
+    def _apply(self, pose: Pose) -> None:
+        for node, values in pose.poses.items():
+            if not (0 <= node < self.n_nodes):
+                continue
+            for binding, (kind, v) in values:
+                if binding == BIND_POSITION and kind == "v3":
+                    self.nodes[node]["position"] = v
+                elif binding == BIND_SCALE and kind == "v3":
+                    self.nodes[node]["scale"] = v
+                elif binding == BIND_ROTATION and kind == "quat":
+                    self.nodes[node]["rotation"] = v
+                elif binding >= BIND_PROPERTY0:
+                    self.props[(node, binding - BIND_PROPERTY0)] = (kind, v)
+
+    def update_animations(self, dt) -> None:
+        """AnimationContainerExt::update_animations (scene/animation/mod.rs:83-88): enabled animations tick and apply"""
+        for a in self.anims:
+            if a is not None and a.enabled:
+                a.tick(dt)
+                self._apply(a.pose)
+
+    def update_machine(self, dt) -> None:
+        """AnimationBlendingStateMachine::update (absm.rs:311-326)"""
+        self._apply(self.machine.evaluate(self.anims, dt))
+
+    def animation_pose(self, a: int) -> np.ndarray:
+        return _records(self.anims[a].pose, self.n_nodes)
+
+    def machine_pose(self) -> np.ndarray:
+        return _records(self.machine.final, self.n_nodes)
+
+    def layer_state(self, layer: int):
+        l = self.machine.layers[layer]
+        return (l.active_state, l.active_transition)
+
+    def animation_state(self, a: int) -> dict:
+        an = self.anims[a]
+        return {"time_position": float(an.time_position), "enabled": bool(an.enabled), "has_ended": bool(an.has_ended())}
+
+    def pop_event(self, a: int):
+        ev = self.anims[a].events
+        return ev.popleft() if ev else None
+
+    def pop_layer_event(self, layer: int):
+        ev = self.machine.layers[layer].events
+        return ev.pop(0) if ev else None
+
+    @staticmethod
+    def _rm_record(rm) -> np.ndarray:
+        out = np.zeros(8, np.float32)         # None reads as RootMotion::default() with the `has` word clear
+        out[7] = 1.0
+        if rm is not None:
+            out[0:3] = rm.delta_position
+            out[3:4] = np.asarray([1], np.uint32).view(np.float32)
+            out[4:8] = rm.delta_rotation
+        return out
+
+    def animation_root_motion(self, a: int) -> np.ndarray:
+        return self._rm_record(self.anims[a].root_motion)
+
+    def machine_root_motion(self, layer: int = -1) -> np.ndarray:
+        pose = self.machine.final if layer < 0 else self.machine.layers[layer].final
+        return self._rm_record(pose.root_motion)
+
+    def set_local_trs(self, node: int, trs10) -> None:
+        self.nodes[node]["position"] = tuple(F(x) for x in trs10[0:3])
+        self.nodes[node]["rotation"] = tuple(F(x) for x in trs10[3:7])
+        self.nodes[node]["scale"] = tuple(F(x) for x in trs10[7:10])
+
+    def node_trs(self) -> np.ndarray:
+        out = np.zeros((self.n_nodes, 12), np.float32)
+        for i, n in enumerate(self.nodes):
+            out[i, 0:3] = n["position"]; out[i, 4:8] = n["rotation"]; out[i, 8:11] = n["scale"]
+        return out
+
+    def local_matrices(self) -> np.ndarray:
+        return np.stack([local_matrix(n).T.reshape(16) for n in self.nodes])      # rows of 16 = column-major
+
+    def global_matrices(self) -> np.ndarray:
+        return global_matrices(self.local_matrices(), self.parent)
+
+    def palette(self, bone_nodes) -> np.ndarray:
+        return _palette(self.global_matrices(), self.inv_bind, bone_nodes)
+
+    def close(self) -> None:
+        pass
