@@ -41,27 +41,40 @@ impl HipSkinning {
         }
     }
 
-    fn check(&self, rc: i32) -> Result<(), HipError> {
-        if rc == FYX_OK {
-            return Ok(());
-        }
-        let msg = unsafe { CStr::from_ptr(fyx_last_error(self.ctx)) }.to_string_lossy().into_owned();
-        Err(match rc {
-            FYX_ERR_INVALID_ARG => HipError::InvalidArg(msg),
-            FYX_ERR_NO_DEVICE => HipError::NoDevice,
-            FYX_ERR_OOM => HipError::OutOfMemory,
-            FYX_ERR_UNKNOWN_ID => HipError::UnknownId,
-            FYX_ERR_BONE_INDEX => HipError::BoneIndex(msg),
-            FYX_ERR_MISSING_ATTRIBUTE => HipError::MissingAttribute(msg),
-            FYX_ERR_UNSUPPORTED => HipError::Unsupported(msg),
-            _ => HipError::Hip(msg),
-        })
+    /// The raw context for the other files of the shim (`fyrox_hip_flatten.rs`).
+    pub(super) fn raw(&self) -> *mut FyxCtx {
+        self.ctx
     }
 
+    fn check(&self, rc: i32) -> Result<(), HipError> {
+        check_rc(self.ctx, rc)
+    }
+}
+
+/// `fyx_status` -> `Result`, with the context's last message.
+pub(super) fn check_rc(ctx: *mut FyxCtx, rc: i32) -> Result<(), HipError> {
+    if rc == FYX_OK {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(fyx_last_error(ctx)) }.to_string_lossy().into_owned();
+    Err(match rc {
+        FYX_ERR_INVALID_ARG => HipError::InvalidArg(msg),
+        FYX_ERR_NO_DEVICE => HipError::NoDevice,
+        FYX_ERR_OOM => HipError::OutOfMemory,
+        FYX_ERR_UNKNOWN_ID => HipError::UnknownId,
+        FYX_ERR_BONE_INDEX => HipError::BoneIndex(msg),
+        FYX_ERR_MISSING_ATTRIBUTE => HipError::MissingAttribute(msg),
+        FYX_ERR_UNSUPPORTED => HipError::Unsupported(msg),
+        _ => HipError::Hip(msg),
+    })
+}
+
+impl HipSkinning {
     /// Upload (or re-upload) a surface's vertex buffer; call when `VertexBuffer::modifications_count()`
     /// (`buffer.rs:909`) changed.  The library de-interleaves on the GPU and keeps the interleaved bytes too.
     pub fn upload_vertex_buffer(&mut self, key: u64, vb: &VertexBuffer) -> Result<(), HipError> {
-        let off = |u| vb.find_attribute(u).map(|a| a.offset as i32).unwrap_or(-1); // buffer.rs:175-190
+        // VertexBuffer::layout() (buffer.rs:980-982): the dense list of VertexAttribute {usage, offset, ..} (buffer.rs:175-202)
+        let off = |u: VertexAttributeUsage| vb.layout().iter().find(|a| a.usage == u).map(|a| a.offset as i32).unwrap_or(-1);
         self.check(unsafe {
             fyx_mesh_upload(
                 self.ctx,
@@ -175,7 +188,8 @@ pub struct SkinnedVertices {
 
 /// N instances of one animated model: `AnimationPlayer` (`scene/animation/mod.rs:190-346`) and, optionally, the
 /// `Machine` of an `AnimationBlendingStateMachine` (`scene/animation/absm.rs`), evaluated on the GPU.
-/// Built once by flattening the engine's own objects (see INTEGRATION.md section 3 for the field-by-field mapping).
+/// Built once by flattening the engine's own objects: `HipAnimator::from_player` + `attach_machine` in
+/// `fyrox_hip_flatten.rs`.
 pub struct HipAnimator<'a> {
     hip: &'a mut HipSkinning,
     id: u64,
@@ -212,6 +226,19 @@ pub struct HipRootMotion {
 }
 
 impl<'a> HipAnimator<'a> {
+    /// Built by `HipAnimator::from_player` (`fyrox_hip_flatten.rs`), which flattens an `AnimationContainer`.
+    pub(super) fn from_parts(hip: &'a mut HipSkinning, id: u64, n_instances: u32, signal_names: Vec<Vec<(crate::core::uuid::Uuid, String)>>) -> Self {
+        Self { hip, id, n_instances, signal_names }
+    }
+
+    pub(super) fn raw(&self) -> *mut FyxCtx {
+        self.hip.ctx
+    }
+
+    pub fn id(&self) -> u64 {
+        self.id
+    }
+
     /// `AnimationPlayer::update` with `auto_apply` (`scene/animation/mod.rs:340-346`).
     pub fn update_animations(&mut self, dt: f32) -> Result<(), HipError> {
         let rc = unsafe { fyx_animation_player_update(self.hip.ctx, self.id, dt) };

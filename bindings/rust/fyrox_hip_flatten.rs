@@ -1,0 +1,487 @@
+//! Flatteners: the engine's own animation objects -> the builder calls of the C ABI (`include/fyrox_hip.h`, second half).
+//! Part of the shim of `fyrox_hip.rs` (`fyrox-impl/src/scene/mesh/hip_flatten.rs`, same cargo feature).  Like that file it
+//! has never met a compiler in this repository's build image (no rustc); `tools/lint_rust_shim.py` (run by the CPU test
+//! suite) checks every method, field, variant and path used here on a reference type against the Fyrox sources instead.
+//!
+//! What is flattened, and from where (file:line in the Fyrox tree):
+//!   * the nodes of one animated model -> `fyx_rig_create`              (scene/base.rs:552,678,710; scene/transform.rs:196-407)
+//!   * `AnimationTracksData`             -> `fyx_tracks_data_upload`      (fyrox-animation/src/lib.rs:71-110, track.rs:104-205, container.rs:103-160)
+//!   * `AnimationContainer`              -> `fyx_animator_add_animation` + per-animation state  (lib.rs:269-291, :855, :951-1110)
+//!   * `Machine`                         -> `fyx_machine_*` / `fyx_layer_*` / `fyx_state_*`      (machine/mod.rs:192-310, layer.rs:86-560)
+//! Handles become dense indices: pools may have holes, so every pool is walked with `pair_iter()` and the handle -> index
+//! maps are kept (`animation_index`, per-layer node / state maps) for the calls that take handles later.
+#![allow(dead_code)]
+
+use super::hip::{check_rc, HipAnimator, HipError, HipSkinning}; // bindings/rust/fyrox_hip.rs
+use super::hip_sys::*; // bindings/rust/fyrox_hip_sys.rs
+use crate::core::{algebra::Matrix3, math::curve::CurveKeyKind, pool::Handle};
+use crate::generic_animation::{
+    container::TrackValueKind,
+    machine::{Parameter, PoseWeight},
+    value::ValueBinding,
+    AnimationTracksData,
+};
+use crate::scene::{
+    animation::{
+        absm::{LogicNode, Machine, PoseNode, StateAction},
+        Animation, AnimationContainer,
+    },
+    graph::Graph,
+    node::Node,
+};
+use fxhash::FxHashMap;
+
+/// Scene node handle -> index inside the rig registered with `fyx_rig_create`.
+pub struct RigMap {
+    pub rig_id: u64,
+    pub index_of: FxHashMap<Handle<Node>, i32>,
+}
+
+impl RigMap {
+    /// -1 for a handle outside the rig: the library treats a negative node as "no binding" / "invalid bone".
+    pub fn node(&self, h: Handle<Node>) -> i32 {
+        self.index_of.get(&h).copied().unwrap_or(-1)
+    }
+}
+
+fn v3(v: &crate::core::algebra::Vector3<f32>) -> [f32; 3] {
+    [v.x, v.y, v.z]
+}
+
+fn quat(q: &crate::core::algebra::UnitQuaternion<f32>) -> [f32; 4] {
+    // nalgebra storage order (i, j, k, w)
+    [q.coords.x, q.coords.y, q.coords.z, q.coords.w]
+}
+
+impl HipSkinning {
+    /// `nodes`: the model's nodes parent-first (e.g. a depth-first walk from the model root); a node whose parent is not
+    /// in the list gets parent -1 and multiplies by the identity, as `update_global_transform_recursively` does for an
+    /// invalid parent handle (scene/graph/mod.rs:1210-1216).
+    pub fn create_rig(&mut self, rig_id: u64, graph: &Graph, nodes: &[Handle<Node>]) -> Result<RigMap, HipError> {
+        let mut index_of = FxHashMap::default();
+        for (i, h) in nodes.iter().enumerate() {
+            index_of.insert(*h, i as i32);
+        }
+        let mut parent = Vec::with_capacity(nodes.len());
+        let mut transforms = Vec::with_capacity(nodes.len());
+        let mut inv_bind = Vec::with_capacity(nodes.len() * 16);
+        for h in nodes {
+            let node = graph.try_get_node(*h).map_err(|_| HipError::InvalidArg(format!("node {h} is not in the graph")))?;
+            parent.push(index_of.get(&node.parent()).copied().unwrap_or(-1));
+            let t = node.local_transform();
+            // Transform keeps the INVERSE of the post-rotation's matrix (build_post_rotation_matrix, transform.rs:160-172);
+            // the field is private, so it is rebuilt here with the same nalgebra calls
+            let por: Matrix3<f32> = t
+                .post_rotation()
+                .to_rotation_matrix()
+                .matrix()
+                .try_inverse()
+                .unwrap_or_else(Matrix3::identity);
+            let mut post = [0f32; 9];
+            post.copy_from_slice(por.as_slice()); // column-major, as calculate_local_transform indexes it
+            transforms.push(FyxTransform {
+                local_position: v3(t.position()),
+                local_rotation: quat(t.rotation()),
+                local_scale: v3(t.scale()),
+                pre_rotation: quat(t.pre_rotation()),
+                post_rotation_matrix: post,
+                rotation_offset: v3(t.rotation_offset()),
+                rotation_pivot: v3(t.rotation_pivot()),
+                scaling_offset: v3(t.scaling_offset()),
+                scaling_pivot: v3(t.scaling_pivot()),
+            });
+            inv_bind.extend_from_slice(node.inv_bind_pose_transform().as_slice()); // Matrix4<f32>: column-major [f32; 16]
+        }
+        let rc = unsafe { fyx_rig_create(self.raw(), rig_id, nodes.len() as u32, parent.as_ptr(), transforms.as_ptr(), inv_bind.as_ptr()) };
+        check_rc(self.raw(), rc)?;
+        Ok(RigMap { rig_id, index_of })
+    }
+
+    /// `Surface::bones` (scene/mesh/surface.rs:1255) as a bone list of the rig; an invalid handle becomes -1 (identity
+    /// matrix, scene/mesh/mod.rs:789-791).
+    pub fn create_bone_list(&mut self, bones_id: u64, rig: &RigMap, bones: &[Handle<Node>]) -> Result<(), HipError> {
+        let idx: Vec<i32> = bones.iter().map(|b| rig.node(*b)).collect();
+        let rc = unsafe { fyx_bone_list_create(self.raw(), bones_id, rig.rig_id, idx.len() as u32, idx.as_ptr()) };
+        check_rc(self.raw(), rc)
+    }
+
+    /// One `AnimationTracksData` resource (shared by any number of animations).  Keys are sent in the order the `Curve`s
+    /// hold them: sorted by location (`Curve::from` / `add_key`, fyrox-math/src/curve.rs:170-236) -- the library refuses
+    /// anything else.
+    pub fn upload_tracks(&mut self, tracks_id: u64, data: &AnimationTracksData) -> Result<(), HipError> {
+        let mut descs = Vec::with_capacity(data.tracks.len());
+        let (mut loc, mut val, mut kind, mut lt, mut rt) = (Vec::new(), Vec::new(), Vec::new(), Vec::new(), Vec::new());
+        let mut property_ids: FxHashMap<String, i32> = FxHashMap::default();
+        for track in data.tracks() {
+            let binding = match track.value_binding() {
+                ValueBinding::Position => FYX_BIND_POSITION,
+                ValueBinding::Scale => FYX_BIND_SCALE,
+                ValueBinding::Rotation => FYX_BIND_ROTATION,
+                // a property is addressed by a small integer id; the shim owns the name <-> id table of the tracks data
+                ValueBinding::Property { name, .. } => {
+                    let next = property_ids.len() as i32;
+                    FYX_BIND_PROPERTY0 + *property_ids.entry(name.to_string()).or_insert(next)
+                }
+            };
+            let container = track.data_container();
+            let k = match container.value_kind() {
+                TrackValueKind::Real => FYX_KIND_REAL,
+                TrackValueKind::Vector2 => FYX_KIND_VEC2,
+                TrackValueKind::Vector3 => FYX_KIND_VEC3,
+                TrackValueKind::Vector4 => FYX_KIND_VEC4,
+                TrackValueKind::UnitQuaternionEuler => FYX_KIND_QUAT_EULER,
+                TrackValueKind::UnitQuaternion => FYX_KIND_QUAT,
+            };
+            let curves = container.curves_ref();
+            if curves.len() > 4 {
+                return Err(HipError::Unsupported("a track with more than four curves".into()));
+            }
+            let mut n_keys = [0u32; 4];
+            for (c, curve) in curves.iter().enumerate() {
+                n_keys[c] = curve.keys().len() as u32;
+                for key in curve.keys() {
+                    loc.push(key.location);
+                    val.push(key.value);
+                    match key.kind {
+                        CurveKeyKind::Constant => {
+                            kind.push(FYX_KEY_CONSTANT as u8);
+                            lt.push(0.0);
+                            rt.push(0.0);
+                        }
+                        CurveKeyKind::Linear => {
+                            kind.push(FYX_KEY_LINEAR as u8);
+                            lt.push(0.0);
+                            rt.push(0.0);
+                        }
+                        CurveKeyKind::Cubic { left_tangent, right_tangent } => {
+                            kind.push(FYX_KEY_CUBIC as u8);
+                            lt.push(left_tangent);
+                            rt.push(right_tangent);
+                        }
+                    }
+                }
+            }
+            descs.push(FyxTrackDesc { binding, kind: k, n_curves: curves.len() as u32, curve_n_keys: n_keys });
+        }
+        let rc = unsafe {
+            fyx_tracks_data_upload(
+                self.raw(),
+                tracks_id,
+                descs.len() as u32,
+                descs.as_ptr(),
+                loc.len() as u32,
+                loc.as_ptr(),
+                val.as_ptr(),
+                kind.as_ptr(),
+                lt.as_ptr(),
+                rt.as_ptr(),
+            )
+        };
+        check_rc(self.raw(), rc)
+    }
+}
+
+/// What `from_player` returns besides the animator: the handle -> index tables the per-frame calls need.
+pub struct AnimatorMaps {
+    /// `Handle<Animation>` -> animation index inside the library (pool slots may be empty: indices are dense)
+    pub animation_index: FxHashMap<Handle<Animation>, u32>,
+    /// machine parameter name -> parameter index (filled by `attach_machine`)
+    pub parameter_index: FxHashMap<String, u32>,
+}
+
+impl<'a> HipAnimator<'a> {
+    /// `AnimationPlayer`'s container (scene/animation/mod.rs:285) -> an animator of `n_instances` copies of the rig.
+    /// `tracks_id_of`: resource key of an animation's tracks data; every distinct key is uploaded once.
+    pub fn from_player(
+        hip: &'a mut HipSkinning,
+        animator_id: u64,
+        rig: &RigMap,
+        animations: &AnimationContainer,
+        n_instances: u32,
+        mut tracks_id_of: impl FnMut(&Animation) -> u64,
+    ) -> Result<(Self, AnimatorMaps), HipError> {
+        let rc = unsafe { fyx_animator_create(hip.raw(), animator_id, rig.rig_id, n_instances) };
+        check_rc(hip.raw(), rc)?;
+        let mut uploaded: FxHashMap<u64, ()> = FxHashMap::default();
+        let mut animation_index = FxHashMap::default();
+        let mut signal_names = Vec::new();
+        for (handle, animation) in animations.pair_iter() {
+            let tracks_id = tracks_id_of(animation);
+            let state = animation.tracks_data().state();
+            let Some(data) = state.data_ref() else {
+                continue; // not loaded: the reference's update_pose returns early too (lib.rs:896-899)
+            };
+            if uploaded.insert(tracks_id, ()).is_none() {
+                hip.upload_tracks(tracks_id, data)?;
+            }
+            // TrackBinding per track id (lib.rs:855): target node and enabled flag; a track without a binding is skipped
+            // by update_pose (lib.rs:903-905) -> target -1
+            let mut target = Vec::with_capacity(data.tracks.len());
+            let mut enabled = Vec::with_capacity(data.tracks.len());
+            for track in data.tracks() {
+                match animation.track_bindings().get(&track.id()) {
+                    Some(b) => {
+                        target.push(rig.node(b.target()));
+                        enabled.push(b.is_enabled() as u8);
+                    }
+                    None => {
+                        target.push(-1);
+                        enabled.push(0);
+                    }
+                }
+            }
+            let mut index = 0u32;
+            let rc = unsafe { fyx_animator_add_animation(hip.raw(), animator_id, tracks_id, target.as_ptr(), enabled.as_ptr(), &mut index) };
+            check_rc(hip.raw(), rc)?;
+            animation_index.insert(handle, index);
+            // per-animation state, every instance alike (lib.rs:432-460, :713-748)
+            let slice = animation.time_slice();
+            unsafe {
+                check_rc(hip.raw(), fyx_animation_set_loop(hip.raw(), animator_id, index, FYX_ALL_INSTANCES, animation.is_loop() as i32))?;
+                check_rc(hip.raw(), fyx_animation_set_time_slice(hip.raw(), animator_id, index, FYX_ALL_INSTANCES, slice.start, slice.end))?;
+                check_rc(hip.raw(), fyx_animation_set_time_position(hip.raw(), animator_id, index, FYX_ALL_INSTANCES, animation.time_position()))?;
+                check_rc(hip.raw(), fyx_animation_set_speed(hip.raw(), animator_id, index, FYX_ALL_INSTANCES, animation.speed()))?;
+                check_rc(hip.raw(), fyx_animation_set_enabled(hip.raw(), animator_id, index, FYX_ALL_INSTANCES, animation.is_enabled() as i32))?;
+                check_rc(hip.raw(), fyx_animation_set_max_event_capacity(
+                    hip.raw(),
+                    animator_id,
+                    index,
+                    FYX_ALL_INSTANCES,
+                    animation.get_max_event_capacity() as u32,
+                ))?;
+            }
+            let mut names = Vec::new();
+            for signal in animation.signals() {
+                let mut s = 0u32;
+                let rc = unsafe { fyx_animation_add_signal(hip.raw(), animator_id, index, signal.time, signal.enabled as i32, &mut s) };
+                check_rc(hip.raw(), rc)?;
+                names.push((signal.id, signal.name.clone()));
+            }
+            signal_names.push(names);
+            if let Some(rm) = animation.root_motion_settings_ref() {
+                let rc = unsafe {
+                    fyx_animation_set_root_motion_settings(
+                        hip.raw(),
+                        animator_id,
+                        index,
+                        rig.node(rm.node),
+                        rm.ignore_x_movement as i32,
+                        rm.ignore_y_movement as i32,
+                        rm.ignore_z_movement as i32,
+                        rm.ignore_rotations as i32,
+                    )
+                };
+                check_rc(hip.raw(), rc)?;
+            }
+        }
+        let animator = HipAnimator::from_parts(hip, animator_id, n_instances, signal_names);
+        Ok((animator, AnimatorMaps { animation_index, parameter_index: FxHashMap::default() }))
+    }
+
+    /// The `Machine` of an `AnimationBlendingStateMachine` (scene/animation/absm.rs:240) on top of `from_player`.
+    pub fn attach_machine(&mut self, machine: &Machine, rig: &RigMap, maps: &mut AnimatorMaps) -> Result<(), HipError> {
+        let (ctx, id) = (self.raw(), self.id());
+        for layer in machine.layers() {
+            let mut li = 0u32;
+            check_rc(ctx, unsafe { fyx_machine_add_layer(ctx, id, layer.weight(), &mut li) })?;
+            let excluded: Vec<i32> = layer.mask().inner().iter().map(|h| rig.node(*h)).filter(|i| *i >= 0).collect();
+            if !excluded.is_empty() {
+                check_rc(ctx, unsafe { fyx_layer_set_mask(ctx, id, li, excluded.as_ptr(), excluded.len() as u32) })?;
+            }
+            // pose nodes: the pool is walked in slot order; children are referred to by handle, so the handle -> index map
+            // is complete before any node is sent
+            let mut node_index: FxHashMap<Handle<PoseNode>, i32> = FxHashMap::default();
+            for (n, (h, _)) in layer.nodes().pair_iter().enumerate() {
+                node_index.insert(h, n as i32);
+            }
+            for (_, node) in layer.nodes().pair_iter() {
+                let mut out = 0u32;
+                let rc = match node {
+                    PoseNode::PlayAnimation(play) => {
+                        // a handle that does not resolve: the node keeps an empty pose (play.rs:93-99) -- an animation index
+                        // past the end says the same to the library
+                        let a = maps.animation_index.get(&play.animation).copied().unwrap_or(u32::MAX);
+                        unsafe { fyx_layer_add_play_animation(ctx, id, li, a, &mut out) }
+                    }
+                    PoseNode::BlendAnimations(blend) => {
+                        let mut sources = Vec::with_capacity(blend.pose_sources.len());
+                        let mut wp = Vec::with_capacity(blend.pose_sources.len());
+                        let mut wc = Vec::with_capacity(blend.pose_sources.len());
+                        for p in blend.pose_sources.iter() {
+                            sources.push(node_index.get(&p.pose_source).copied().unwrap_or(-1));
+                            match &p.weight {
+                                PoseWeight::Constant(w) => {
+                                    wp.push(-1);
+                                    wc.push(*w);
+                                }
+                                PoseWeight::Parameter(name) => {
+                                    // a name that does not resolve weighs 0.0 (blend.rs:147-153)
+                                    wp.push(resolve_parameter(ctx, id, machine, maps, name)?);
+                                    wc.push(0.0);
+                                }
+                            }
+                        }
+                        unsafe { fyx_layer_add_blend_animations(ctx, id, li, sources.len() as u32, sources.as_ptr(), wp.as_ptr(), wc.as_ptr(), &mut out) }
+                    }
+                    PoseNode::BlendAnimationsByIndex(by_index) => {
+                        let sources: Vec<i32> = by_index.inputs.iter().map(|i| node_index.get(&i.pose_source).copied().unwrap_or(-1)).collect();
+                        let times: Vec<f32> = by_index.inputs.iter().map(|i| i.blend_time).collect();
+                        let p = resolve_parameter(ctx, id, machine, maps, &by_index.index_parameter)?;
+                        unsafe { fyx_layer_add_blend_animations_by_index(ctx, id, li, p, sources.len() as u32, sources.as_ptr(), times.as_ptr(), &mut out) }
+                    }
+                    PoseNode::BlendSpace(space) => {
+                        let mut pts = Vec::with_capacity(space.points().len() * 2);
+                        let mut sources = Vec::with_capacity(space.points().len());
+                        for p in space.points() {
+                            pts.push(p.position.x);
+                            pts.push(p.position.y);
+                            sources.push(node_index.get(&p.pose_source).copied().unwrap_or(-1));
+                        }
+                        // the Delaunay triangulation the engine caches on every point edit (blendspace.rs:246-270, :416-447)
+                        let mut tris = Vec::with_capacity(space.triangles().len() * 3);
+                        for t in space.triangles() {
+                            tris.extend_from_slice(&[t[0], t[1], t[2]]);
+                        }
+                        let p = resolve_parameter(ctx, id, machine, maps, space.sampling_parameter())?;
+                        unsafe {
+                            fyx_layer_add_blend_space(
+                                ctx,
+                                id,
+                                li,
+                                p,
+                                sources.len() as u32,
+                                pts.as_ptr(),
+                                sources.as_ptr(),
+                                (tris.len() / 3) as u32,
+                                tris.as_ptr(),
+                                &mut out,
+                            )
+                        }
+                    }
+                };
+                check_rc(ctx, rc)?;
+            }
+            // states, in slot order; the first one added becomes active (layer.rs:229-235), the entry state is set afterwards
+            let mut state_index = FxHashMap::default();
+            for (n, (h, _)) in layer.states().pair_iter().enumerate() {
+                state_index.insert(h, n as u32);
+            }
+            for (_, state) in layer.states().pair_iter() {
+                let mut si = 0u32;
+                let root = node_index.get(&state.root).copied().unwrap_or(-1);
+                check_rc(ctx, unsafe { fyx_layer_add_state(ctx, id, li, root, &mut si) })?;
+                for (on_enter, actions) in [(1, &state.on_enter_actions), (0, &state.on_leave_actions)] {
+                    for action in actions.iter() {
+                        let index_of = |h: &Handle<Animation>| maps.animation_index.get(h).copied().unwrap_or(u32::MAX);
+                        let rc = match &action.0 {
+                            StateAction::None => FYX_OK,
+                            StateAction::RewindAnimation(h) => unsafe {
+                                fyx_state_add_action(ctx, id, li, si, on_enter, FYX_ACTION_REWIND_ANIMATION, index_of(h))
+                            },
+                            StateAction::EnableAnimation(h) => unsafe {
+                                fyx_state_add_action(ctx, id, li, si, on_enter, FYX_ACTION_ENABLE_ANIMATION, index_of(h))
+                            },
+                            StateAction::DisableAnimation(h) => unsafe {
+                                fyx_state_add_action(ctx, id, li, si, on_enter, FYX_ACTION_DISABLE_ANIMATION, index_of(h))
+                            },
+                            StateAction::EnableRandomAnimation(handles) => {
+                                let list: Vec<u32> = handles.iter().map(index_of).collect();
+                                unsafe { fyx_state_add_random_action(ctx, id, li, si, on_enter, list.as_ptr(), list.len() as u32) }
+                            }
+                        };
+                        check_rc(ctx, rc)?;
+                    }
+                }
+            }
+            if let Some(e) = state_index.get(&layer.entry_state()) {
+                check_rc(ctx, unsafe { fyx_layer_set_entry_state(ctx, id, li, *e) })?;
+            }
+            for (_, transition) in layer.transitions().pair_iter() {
+                let (Some(s), Some(d)) = (state_index.get(&transition.source()), state_index.get(&transition.dest())) else {
+                    continue; // a transition between states that do not exist can never fire (layer.rs:606-611)
+                };
+                let mut code = Vec::new();
+                encode_logic(transition.condition(), &mut code, ctx, id, machine, maps)?;
+                let mut ti = 0u32;
+                check_rc(ctx, unsafe {
+                    fyx_layer_add_transition(ctx, id, li, *s, *d, transition.transition_time(), code.as_ptr(), code.len() as u32, &mut ti)
+                })?;
+            }
+        }
+        Ok(())
+    }
+
+    /// Game code changes parameters between frames (`machine.parameters_mut().get_mut(name)`): push the current values
+    /// before `update_machine`.  One small call per parameter the graph uses; the values are host scalars.
+    pub fn sync_parameters(&mut self, machine: &Machine, maps: &AnimatorMaps) -> Result<(), HipError> {
+        for (name, index) in maps.parameter_index.iter() {
+            if let Some(p) = machine.parameters().get(name) {
+                let (kind, f0, f1, u) = parameter_words(p);
+                check_rc(self.raw(), unsafe { fyx_machine_set_parameter(self.raw(), self.id(), *index, FYX_ALL_INSTANCES, kind, f0, f1, u) })?;
+            }
+        }
+        Ok(())
+    }
+}
+
+/// `Parameter` (machine/parameter.rs:36-50) as the (kind, f0, f1, u) words of `fyx_machine_add_parameter`.
+fn parameter_words(p: &Parameter) -> (i32, f32, f32, u32) {
+    match p {
+        Parameter::Weight(w) => (FYX_PARAM_WEIGHT, *w, 0.0, 0),
+        Parameter::Rule(r) => (FYX_PARAM_RULE, 0.0, 0.0, *r as u32),
+        Parameter::Index(i) => (FYX_PARAM_INDEX, 0.0, 0.0, *i),
+        Parameter::SamplingPoint(v) => (FYX_PARAM_SAMPLING_POINT, v.x, v.y, 0),
+    }
+}
+
+/// ParameterContainer has no public iteration (machine/parameter.rs:136-200: `add` / `get` / `get_mut` by name), and the
+/// library does not need one: every name the graph refers to is resolved through `get` and registered once.  -1 for a
+/// name that does not exist: it behaves like a missing parameter in the reference.
+fn resolve_parameter(ctx: *mut FyxCtx, id: u64, machine: &Machine, maps: &mut AnimatorMaps, name: &str) -> Result<i32, HipError> {
+    if let Some(i) = maps.parameter_index.get(name) {
+        return Ok(*i as i32);
+    }
+    let Some(p) = machine.parameters().get(name) else {
+        return Ok(-1);
+    };
+    let (kind, f0, f1, u) = parameter_words(p);
+    let mut index = 0u32;
+    check_rc(ctx, unsafe { fyx_machine_add_parameter(ctx, id, kind, f0, f1, u, &mut index) })?;
+    maps.parameter_index.insert(name.to_string(), index);
+    Ok(index as i32)
+}
+
+/// `LogicNode` (machine/transition.rs:118-131) -> the prefix code of `fyx_layer_add_transition`.
+fn encode_logic(node: &LogicNode, out: &mut Vec<i32>, ctx: *mut FyxCtx, id: u64, machine: &Machine, maps: &mut AnimatorMaps) -> Result<(), HipError> {
+    match node {
+        LogicNode::Parameter(name) => {
+            out.push(FYX_LOGIC_PARAMETER);
+            out.push(resolve_parameter(ctx, id, machine, maps, name)?);
+        }
+        LogicNode::And(n) => {
+            out.push(FYX_LOGIC_AND);
+            encode_logic(&n.lhs, out, ctx, id, machine, maps)?;
+            encode_logic(&n.rhs, out, ctx, id, machine, maps)?;
+        }
+        LogicNode::Or(n) => {
+            out.push(FYX_LOGIC_OR);
+            encode_logic(&n.lhs, out, ctx, id, machine, maps)?;
+            encode_logic(&n.rhs, out, ctx, id, machine, maps)?;
+        }
+        LogicNode::Xor(n) => {
+            out.push(FYX_LOGIC_XOR);
+            encode_logic(&n.lhs, out, ctx, id, machine, maps)?;
+            encode_logic(&n.rhs, out, ctx, id, machine, maps)?;
+        }
+        LogicNode::Not(n) => {
+            out.push(FYX_LOGIC_NOT);
+            encode_logic(&n.lhs, out, ctx, id, machine, maps)?;
+        }
+        LogicNode::IsAnimationEnded(h) => {
+            out.push(FYX_LOGIC_IS_ANIMATION_ENDED);
+            // a handle that does not resolve is "ended" (transition.rs:167-170): -1 says so to the library
+            out.push(maps.animation_index.get(h).map(|a| *a as i32).unwrap_or(-1));
+        }
+    }
+    Ok(())
+}
