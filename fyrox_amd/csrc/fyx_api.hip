@@ -179,6 +179,7 @@ void free_mesh(Mesh& m) {
     if (m.block) (void)hipFree(m.block);
     if (m.shapes) (void)hipFree(m.shapes);
     if (m.aos) (void)hipFree(m.aos);
+    if (m.tiled) (void)hipFree(m.tiled);
     m = Mesh();
 }
 
@@ -206,7 +207,15 @@ int alloc_mesh(fyx_ctx* c, Mesh& m, uint32_t n, bool has_nrm, bool has_tan) {
 }
 
 int finish_upload(fyx_ctx* c, uint64_t mesh_id, Mesh& m) {
-    hipError_t e = fyx::launch_max_bone_index(m.idx, m.n_verts, c->d_u32, c->stream);
+    hipError_t e = hipSuccess;
+    if ((c->lbs.dyn_knobs & 0x2000) && m.n_verts >= fyx::kTiledFromVerts && m.nrm && m.tan) {   // experiment: unit-tiled inputs for lbs_skin_dyn
+        const size_t units = ((size_t)m.n_verts + 63) / 64 + 2;
+        e = hipMalloc(reinterpret_cast<void**>(&m.tiled), units * fyx::kTiledDwordsPerUnit * 4);
+        if (e == hipSuccess) e = hipMemsetAsync(m.tiled, 0, units * fyx::kTiledDwordsPerUnit * 4, c->stream);
+        if (e == hipSuccess) e = fyx::launch_retile_units(m.pos, m.nrm, m.tan, m.wgt, m.idx, m.n_verts, m.tiled, c->stream);
+        if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "unit-tiled copy"); }
+    }
+    e = fyx::launch_max_bone_index(m.idx, m.n_verts, c->d_u32, c->stream);
     if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "max_bone_index"); }
     uint32_t mx = 0;
     e = hipMemcpyAsync(&mx, c->d_u32, 4, hipMemcpyDeviceToHost, c->stream);
@@ -245,6 +254,7 @@ fyx::LbsArgs make_args(const Mesh& m, const float* d_palette, uint32_t n_bones, 
     a.palette = d_palette;
     a.out_pos = op; a.out_nrm = on; a.out_tan = ot;
     a.n_verts = m.n_verts; a.n_bones = n_bones; a.n_instances = n_inst;
+    a.tiled = m.tiled;
     return a;
 }
 
@@ -510,6 +520,8 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->aabb_partials) (void)hipFree(c->aabb_partials);
     if (c->d_u32) (void)hipFree(c->d_u32);
     if (c->lbs.probe_buf) (void)hipFree(c->lbs.probe_buf);
+    if (c->lbs.pool_buf) (void)hipFree(c->lbs.pool_buf);
+    delete c->lbs.pool_seq;
     for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
         if (c->workers[w]) { (void)hipStreamSynchronize(c->workers[w]); (void)hipStreamDestroy(c->workers[w]); }
         if (c->worker_done[w]) (void)hipEventDestroy(c->worker_done[w]);
@@ -579,6 +591,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
     if (!strcmp(key, "lbs.dyn_bpc")) return &c->lbs.dyn_bpc;
     if (!strcmp(key, "lbs.dyn_block")) return &c->lbs.dyn_block;
+    if (!strcmp(key, "lbs.dyn_knobs")) return &c->lbs.dyn_knobs;
     if (!strcmp(key, "lbs.asym")) return &c->lbs.asym;
     if (!strcmp(key, "lbs.policy")) return &c->lbs.policy;
     if (!strcmp(key, "lbs.young_prio")) return &c->lbs.young_prio;
@@ -615,6 +628,13 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->lbs.dyn_bpc && (value < 0 || value > 4)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.dyn_bpc must be 0..4");
     if (slot == &c->lbs.asym && (value < 0 || value > 63)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.asym must be 0..63");
     if (slot == &c->lbs.young_prio && (value < 0 || value > 3)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.young_prio must be 0..3");
+    if (slot == &c->lbs.dyn_knobs && ((value >> 16) & 63) && !c->lbs.pool_buf) {
+        if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+        if (int rc = enter_primary(c)) return rc;
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->lbs.pool_buf), 4 * 64 * 256));
+        FYX_HIP(c, hipMemset(c->lbs.pool_buf, 0, 4 * 64 * 256));
+        c->lbs.pool_seq = new uint32_t(0);
+    }
     if (slot == &c->lbs.probe && value && !c->lbs.probe_buf) {
         if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
         c->lbs.probe_words = (size_t)65536 * 4;

@@ -27,6 +27,9 @@ struct LbsTuning {
     int dyn_block = 256;     // its workgroup size: 256 | 512 | 1024 (four small workgroups per CU end at more staggered times than two
                              //   large ones: the most robust lone-launch time over the boxes of the pool, profiles/r02_policy_sweep*.json)
     int dyn_bpc = 0;         // workgroups per CU of that launch; 0 = what is resident (1024 / dyn_block)
+    uint32_t* pool_buf = nullptr;   // lbs_skin_dyn's unit pool counters (4 sets x 64, 256 bytes apart)
+    uint32_t* pool_seq = nullptr;   // launches so far (host word): which set a launch uses
+    int dyn_knobs = 0;       // experiment switches of lbs_skin_dyn (see the kernel)
     int asym = 0;            // lbs_skin, 2 workgroups per CU: the first-dispatched one owns asym/64 of the pair's units (0 = halves)
     int young_prio = 0;      // lbs_skin: s_setprio for the second-dispatched half of the grid
     int policy = 0;          // experiment builds only (FYX_EXP_POLICY): cache policy of lbs_skin_dyn's streams
@@ -45,7 +48,17 @@ struct LbsArgs {
     uint32_t n_verts;
     uint32_t n_bones;
     uint32_t n_instances;
+    const uint32_t* tiled = nullptr;   // the same inputs, one contiguous 3840-byte span per 64-vertex unit (or null)
 };
+
+// Unit-tiled copy of the five input streams (library-owned layout): per 64-vertex unit 960 dwords --
+//   [0,256)   lane l: px py pz nx     [256,512) lane l: ny nz tx ty     [512,768) lane l: tz tw w0 w1
+//   [768,960) lane l: w2 w3 idx (3 dwords)
+// so a wave reads its unit with three 16-byte and one 12-byte access per lane out of ONE span.
+constexpr uint32_t kTiledDwordsPerUnit = 960;
+constexpr uint32_t kTiledFromVerts = 524288;   // smaller meshes never take lbs_skin_dyn
+hipError_t launch_retile_units(const float* pos, const float* nrm, const float* tan, const float* wgt, const uint32_t* idx,
+                               uint32_t n_verts, uint32_t* tiled, hipStream_t stream);
 
 // Launch the skinning kernel.  Returns hipSuccess or the launch error.
 hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream);

@@ -48,6 +48,11 @@ __device__ __forceinline__ void stg(T* p, T v) {
 #ifndef FYX_EXP_POLICY
 #define FYX_EXP_POLICY 0
 #endif
+// FYX_EXP_KNOBS (experiment builds only): the start-up / work-distribution / ablation switches of lbs_skin_dyn
+// (option lbs.dyn_knobs, tools/exp/dyn_knobs.py).
+#ifndef FYX_EXP_KNOBS
+#define FYX_EXP_KNOBS 0
+#endif
 
 template <bool NT>
 __device__ __forceinline__ void ld3(const float* p, float& x, float& y, float& z) {
@@ -524,6 +529,23 @@ __device__ __forceinline__ VertexIn<MASK> load_vertex_buf(const VtxBuffers& b, u
     r.id = __builtin_amdgcn_raw_buffer_load_b32(b.idx, v * 4u, 0, AUX);
     return r;
 }
+// The same vertex out of the unit-tiled copy (MASK 7 only): v = unit * 64 + lane.
+template <int AUX>
+__device__ __forceinline__ VertexIn<7> load_vertex_tiled(__amdgpu_buffer_rsrc_t tiled, uint32_t v) {
+    const uint32_t unit = v >> 6, l = v & 63u;
+    const uint32_t b = unit * (kTiledDwordsPerUnit * 4u);
+    const f32x4 q0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tiled, b + l * 16u, 0, AUX));
+    const f32x4 q1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tiled, b + 1024u + l * 16u, 0, AUX));
+    const f32x4 q2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tiled, b + 2048u + l * 16u, 0, AUX));
+    const u32x3 q3 = __builtin_amdgcn_raw_buffer_load_b96(tiled, b + 3072u + l * 12u, 0, AUX);
+    VertexIn<7> r;
+    r.p = f32x3{q0.x, q0.y, q0.z};
+    r.n = f32x3{q0.w, q1.x, q1.y};
+    r.t = f32x4{q1.z, q1.w, q2.x, q2.y};
+    r.w = f32x4{q2.z, q2.w, __uint_as_float(q3.x), __uint_as_float(q3.y)};
+    r.id = q3.z;
+    return r;
+}
 template <int MASK, int AUX>
 __device__ __forceinline__ void store_vertex_buf(const VtxBuffers& b, uint32_t v, const Skinned& o, float tw) {
     if constexpr (MASK & 1)
@@ -563,7 +585,13 @@ __device__ __forceinline__ void store_vertex_buf(const VtxBuffers& b, uint32_t v
 // Which wave skins a unit changes nothing in the arithmetic: results are bit-identical to lbs_skin's.
 // ---------------------------------------------------------------------------------------
 template <int BLOCK, bool EXACT, int MASK, bool PROBE = false, int LD_AUX = 2, int ST_AUX = 16>
-__global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint64_t* probe = nullptr) {
+__global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint64_t* probe = nullptr,
+                                                      uint32_t knobs_arg = 0, uint32_t* pool_arg = nullptr,
+                                                      uint32_t* pool_zero = nullptr) {
+    // Experiment switches (tools/exp/dyn_knobs.py; findings in DESIGN.md 5): compiled in only with -DFYX_EXP_KNOBS=1
+    // (tools/exp/build_variants.sh).  In the product build `knobs` is the constant 0 and every branch on it is gone.
+    const uint32_t knobs = FYX_EXP_KNOBS ? knobs_arg : 0u;
+    uint32_t* const pool = FYX_EXP_KNOBS ? pool_arg : nullptr;
     uint64_t pt0 = 0, pt1 = 0;
     if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -576,8 +604,33 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
     constexpr int PIECES = 1024 / BLOCK;     // 16-byte palette columns per thread (n_bones <= 256)
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
-    const uint32_t n_units = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x) - u_begin;
+    // experiment (knobs bits 16-21 = pool share in 1/64 of the units, 22-23 = pool groups 8 / 32 / 64, 24 = partner steal):
+    // the last `pool_units` units are not dealt out but drawn by the waves that run out of their own, from the counter of
+    // their hardware neighbourhood (XCD / XCD x SE / ...), with a scalar-memory atomic (its return does not queue behind
+    // the wave's vector loads).
+    const uint32_t pool_units = pool ? (uint32_t)(((uint64_t)total_units * ((knobs >> 16) & 63u)) >> 6) : 0u;
+    const uint32_t static_units = total_units - pool_units;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * static_units) / gridDim.x);
+    const uint32_t n_units = (uint32_t)(((uint64_t)(blockIdx.x + 1) * static_units) / gridDim.x) - u_begin;
+    uint32_t grp = 0, n_grp = 8, grp2 = 0;
+    if (pool_units) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508) & 7u;
+        const uint32_t se = (hw >> 13) & 3u, cu = (hw >> 8) & 15u, mode = (knobs >> 22) & 3u;
+        if (mode == 0) { n_grp = 8; grp = xcc; grp2 = xcc ^ 1u; }
+        else if (mode == 1) { n_grp = 32; grp = xcc * 4 + se; grp2 = (xcc ^ 1u) * 4 + se; }
+        else { n_grp = 64; grp = (xcc * 4 + se) * 2 + (cu >= 4 ? 1u : 0u); grp2 = grp ^ 1u; }
+        if (blockIdx.x == 0 && tid < 64 && pool_zero) pool_zero[tid * 64] = 0;   // the counters of the launch after next
+    }
+    // knobs bits 25-27 = d: the pools of the odd XCDs are (8 - d) / 8 of the even ones' (8 + d) / 8 -- they run dry earlier
+    const uint32_t pool_d = (knobs >> 25) & 7u;
+    auto pool_range = [&](uint32_t g, uint32_t& base, uint32_t& len) {
+        const uint32_t sub = n_grp >> 3, x = g / sub, j = g % sub;
+        const uint32_t w = (x & 1u) ? 8u - pool_d : 8u + pool_d;
+        const uint32_t W = sub * (((x + 1) >> 1) * (8u + pool_d) + (x >> 1) * (8u - pool_d)) + j * w;
+        base = (uint32_t)(((uint64_t)W * pool_units) / (sub * 64u));
+        len = (uint32_t)(((uint64_t)(W + w) * pool_units) / (sub * 64u)) - base;
+        base += static_units;
+    };
 
     // palette columns first: column c of bone b is piece 4 b + c
     const uint32_t n_pieces = a.n_bones * 4;
@@ -585,21 +638,37 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
-        col[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
+        col[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(knobs & 0x400u)) col[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
     }
     // the wave's first two units (tickets wave and WPB + wave; the launcher guarantees n_units >= 2 WPB)
     const VtxBuffers vb = make_vtx_buffers(a);
+    const bool use_tiled = MASK == 7 && a.tiled != nullptr && (knobs & 0x2000u) && total_units < 1000000u;   // 32-bit buffer offsets
+    const __amdgpu_buffer_rsrc_t tiled = make_stream(a.tiled, total_units * (kTiledDwordsPerUnit * 4u));
+    auto load_unit = [&](uint32_t v) -> VertexIn<MASK> {
+        if constexpr (MASK == 7) {
+            if (use_tiled) return load_vertex_tiled<LD_AUX>(tiled, v);
+        }
+        return load_vertex_buf<MASK, LD_AUX>(vb, v);
+    };
     auto vertex_of = [&](uint32_t t) -> uint32_t { return (u_begin + t) * 64 + lane; };
     uint32_t vA = vertex_of(wave), vB = vertex_of(WPB + wave);
-    VertexIn<MASK> A = load_vertex_buf<MASK, LD_AUX>(vb, vA);
+    // experiment knobs (lbs.dyn_knobs): bits 0-7 = pause (x64 clocks) between the palette request and the vertex requests,
+    // bit 8 = wait for the palette columns to land first, bit 9 = request the second unit ahead of the barrier too
+    if (knobs & 0x100u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (knobs & 0x1000u) __syncthreads();   // nobody requests vertices before every wave of the workgroup has requested its columns
+    for (uint32_t i = knobs & 0xffu; i > 0; --i) __builtin_amdgcn_s_sleep(1);
+    VertexIn<MASK> A = load_unit(vA);
     VertexIn<MASK> B;   // requested behind the staging barrier (see above)
+    const bool early2 = (knobs & 0x200u) != 0;
+    if (early2) B = load_unit(vB);
 
     if (tid == 0) *ticket = 2 * WPB;
     bool pj = false;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
-        if (piece < n_pieces) {
+        if (piece < n_pieces && !(knobs & 0x400u)) {
             // packed-math layout (see stage_palette): A = (m00, m10, m01, m11)  B = (m02, m12, t0, t1)
             // C = (m20, m21, m22, t2)  row3 = (m30, m31, m32, m33); column c = (m0c, m1c, m2c, m3c)
             const uint32_t b = piece >> 2, c = piece & 3;
@@ -617,13 +686,19 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
 #pragma unroll
     for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
     pin_vertex(A);
-    B = load_vertex_buf<MASK, LD_AUX>(vb, vB);
+    if (!early2) B = load_unit(vB);
     if constexpr (PROBE) pt1 = __builtin_amdgcn_s_memrealtime();
 
-    auto process = [&](VertexIn<MASK>& c_, uint32_t v_c) {
+    auto process = [&](VertexIn<MASK>& c_, uint32_t v_c, bool drain = false) {
         pin_vertex(c_);   // the math's first touch of the loaded registers is here
-        const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
-                                                   c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
+        Skinned o;
+        if ((knobs & 0x800u) || (drain && (knobs & 0x4000u)) || (!drain && (knobs & 0x8000u))) {   // ablation (wrong results): no math
+            o.px = c_.p.x + c_.w.x; o.py = c_.p.y + c_.w.y; o.pz = c_.p.z + c_.w.z; o.nx = c_.n.x + c_.w.w; o.ny = c_.n.y; o.nz = c_.n.z;
+            o.tx = c_.t.x; o.ty = c_.t.y; o.tz = c_.t.z + __uint_as_float(c_.id) * 0.f;
+        } else {
+            o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
+                                         c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
+        }
         store_vertex_buf<MASK, ST_AUX>(vb, v_c, o, c_.t.w);
     };
     // draw the next unit into a register set whose math is done; false when the workgroup's range is used up
@@ -631,24 +706,41 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
         uint32_t t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= n_units) return false;
-        v_n = vertex_of(t);
-        n_ = load_vertex_buf<MASK, LD_AUX>(vb, v_n);
+        if (t < n_units) {
+            v_n = vertex_of(t);
+        } else {
+            if (!pool_units) return false;
+            uint32_t base, len, p = 1;
+            pool_range(grp, base, len);
+            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(p) : "s"(pool + grp * 64) : "memory");
+            if (p >= len) {
+                if (!(knobs & 0x1000000u)) return false;
+                pool_range(grp2, base, len);
+                p = 1;
+                asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(p) : "s"(pool + grp2 * 64) : "memory");
+                if (p >= len) return false;
+            }
+            v_n = (base + p) * 64 + lane;
+        }
+        n_ = load_unit(v_n);
         return true;
     };
     for (;;) {   // wave-uniform
         process(A, vA);
-        if (!refill(A, vA)) { process(B, vB); break; }
+        if (!refill(A, vA)) { process(B, vB, true); break; }
         process(B, vB);
-        if (!refill(B, vB)) { process(A, vA); break; }
+        if (!refill(B, vB)) { process(A, vA, true); break; }
     }
     if constexpr (PROBE) {
         const uint64_t pt2 = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint64_t pt3 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
+            // where the wave ran: HW_ID (wave, simd, pipe, cu, sh, se in the low 16 bits) and XCC_ID ride in the unused top bits
+            const uint64_t hw = (uint64_t)(__builtin_amdgcn_s_getreg(63492) & 0xffffu);
+            const uint64_t xcc = (uint64_t)(__builtin_amdgcn_s_getreg(63508) & 0xfu);
             uint64_t* r = probe + ((size_t)blockIdx.x * WPB + wave) * 4;
-            r[0] = pt0; r[1] = pt1; r[2] = pt2; r[3] = pt3;
+            r[0] = pt0; r[1] = pt1 | (xcc << 56); r[2] = pt2 | (hw << 48); r[3] = pt3;
         }
     }
 }
@@ -854,10 +946,18 @@ static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream
     const uint32_t grid = (uint32_t)kCUs * ((t.dyn_bpc > 0 && (uint32_t)t.dyn_bpc < resident) ? (uint32_t)t.dyn_bpc : resident);
     if (total / grid < 2 * WPB) return hipErrorNotReady;   // every wave starts with two units of its own
     const size_t lds = (size_t)a.n_bones * 64 + 64 + 16;
+    uint32_t *pool = nullptr, *pool_zero = nullptr;
+    if (t.pool_buf && ((t.dyn_knobs >> 16) & 63)) {
+        const uint32_t share = (uint32_t)((t.dyn_knobs >> 16) & 63);
+        if ((uint64_t)(total - (uint32_t)(((uint64_t)total * share) >> 6)) / grid < 2 * WPB) return hipErrorNotReady;
+        const uint32_t seq = (*t.pool_seq)++;
+        pool = t.pool_buf + (size_t)(seq & 3u) * 64 * 64;          // four sets of 64 counters, 256 bytes apart
+        pool_zero = t.pool_buf + (size_t)((seq + 2) & 3u) * 64 * 64;
+    }
     if constexpr (EXACT && MASK == 7) {
         if (t.probe && t.probe_buf) {
             if ((size_t)grid * WPB * 4 > t.probe_words) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a, total, t.probe_buf);
+            hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a, total, t.probe_buf, (uint32_t)t.dyn_knobs, pool, pool_zero);
             return hipGetLastError();
         }
     }
@@ -877,7 +977,8 @@ static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream
         }
     }
 #endif
-    hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a, total, (uint64_t*)nullptr);
+    hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a, total, (uint64_t*)nullptr,
+                       (uint32_t)t.dyn_knobs, pool, pool_zero);
     return hipGetLastError();
 }
 
@@ -1561,6 +1662,30 @@ __global__ __launch_bounds__(256) void max_bone_index_kernel(const uint32_t* __r
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));  // one per block
+}
+
+__global__ __launch_bounds__(256) void retile_units_kernel(const float* __restrict__ pos, const float* __restrict__ nrm,
+                                                           const float* __restrict__ tan, const float* __restrict__ wgt,
+                                                           const uint32_t* __restrict__ idx, uint32_t n_verts,
+                                                           uint32_t* __restrict__ tiled) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_verts) return;   // the rest of the last unit stays zero (memset by the caller)
+    const uint32_t l = v & 63u;
+    uint32_t* d = tiled + (size_t)(v >> 6) * kTiledDwordsPerUnit;
+    const f32x4 t = reinterpret_cast<const f32x4*>(tan)[v], w = reinterpret_cast<const f32x4*>(wgt)[v];
+    reinterpret_cast<f32x4*>(d)[l] = f32x4{pos[(size_t)v * 3], pos[(size_t)v * 3 + 1], pos[(size_t)v * 3 + 2], nrm[(size_t)v * 3]};
+    reinterpret_cast<f32x4*>(d + 256)[l] = f32x4{nrm[(size_t)v * 3 + 1], nrm[(size_t)v * 3 + 2], t.x, t.y};
+    reinterpret_cast<f32x4*>(d + 512)[l] = f32x4{t.z, t.w, w.x, w.y};
+    d[768 + l * 3] = __float_as_uint(w.z);
+    d[768 + l * 3 + 1] = __float_as_uint(w.w);
+    d[768 + l * 3 + 2] = idx[v];
+}
+
+hipError_t launch_retile_units(const float* pos, const float* nrm, const float* tan, const float* wgt, const uint32_t* idx,
+                               uint32_t n_verts, uint32_t* tiled, hipStream_t stream) {
+    if (n_verts == 0) return hipSuccess;
+    hipLaunchKernelGGL(retile_units_kernel, dim3((n_verts + 255) / 256), dim3(256), 0, stream, pos, nrm, tan, wgt, idx, n_verts, tiled);
+    return hipGetLastError();
 }
 
 hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32_t* d_out,
