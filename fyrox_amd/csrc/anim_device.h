@@ -285,7 +285,7 @@ int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
 
 // Send the planned frame to the GPU and run sample + update.
 int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
-    if (int rc = enter_primary(c)) return rc;
+    if (int rc = enter_pose(c)) return rc;
     if (int rc = ensure_device_state(c, A)) return rc;
     PoseFrameDev f;
     frame_static(c, A, f);
@@ -373,7 +373,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     if (int rc = scene_plan(c, S, dt)) return rc;
 
     // 2. device state, and the block tables if the scene's shape changed
-    if (int rc = enter_primary(c)) return rc;
+    if (int rc = enter_pose(c)) return rc;
     std::vector<uint64_t> sig;
     sig.reserve(n * 3 + 1);
     sig.push_back((uint64_t)c->sample_form);

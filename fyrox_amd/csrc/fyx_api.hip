@@ -52,6 +52,13 @@ int enter_primary(fyx_ctx* c) {
     return rc;
 }
 
+int enter_pose(fyx_ctx* c) {
+    if (!c->pose_overlap) return enter_primary(c);
+    if (int rc = bind_device(c)) return rc;
+    c->primary_dirty = true;
+    return FYX_OK;
+}
+
 // Pick the stream for an independent skinning launch: a worker, ordered after everything that
 // was on the context stream at this moment (one fork event per batch of context-stream work).
 int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
@@ -597,6 +604,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.young_prio")) return &c->lbs.young_prio;
     if (!strcmp(key, "anim.threads")) return &c->plan_threads;
     if (!strcmp(key, "anim.split")) return &c->plan_split;
+    if (!strcmp(key, "anim.overlap")) return &c->pose_overlap;
     if (!strcmp(key, "anim.sample_form")) return &c->sample_form;
     return nullptr;
 }
@@ -620,6 +628,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->lbs.crowd_ipb && (value < 0 || value > 4096))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_ipb must be 0 (auto) .. 4096");
     if (slot == &c->sample_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.sample_form must be 0, 1 or 2");
+    if (slot == &c->pose_overlap && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.overlap must be 0 or 1");
     if (slot == &c->plan_split && value < 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.split must be >= 1");
     if (slot == &c->plan_threads && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");

@@ -88,6 +88,7 @@ struct fyx_ctx {
     fyx::AnimStore* anim = nullptr;
     int plan_threads = 8;    // option "anim.threads": host threads planning a crowd's frame (1 = the calling thread only)
     int sample_form = 0;     // option "anim.sample_form": 0 auto, 1 curves on the lanes, 2 instances on the lanes
+    int pose_overlap = 0;    // option "anim.overlap": 1 = pose updates do not wait for in-flight skinning launches (see enter_pose)
     int plan_split = 2048;   // option "anim.split": instances per planning task
     fyx::PlanPool* plan_pool = nullptr;
     fyx::SkinBatch* skin_batch = nullptr;
@@ -101,6 +102,11 @@ size_t align_up(size_t x, size_t a);
 int join_workers(fyx_ctx* c);
 int bind_device(fyx_ctx* c);      // hipSetDevice(ctx's device) for the calling thread
 int enter_primary(fyx_ctx* c);
+// Entry of the pose path (fyx_*_update, fyx_scene_update, fyx_animator_palette).  Default: enter_primary.  With option
+// anim.overlap = 1 the in-flight skinning launches of the worker streams are NOT joined first, so frame n+1's pose
+// kernels (latency-bound, a few waves per CU) run under frame n's skinning (bandwidth-bound); the pose path touches
+// nothing a skinning launch reads except the palette buffers it is told to write, which the caller then alternates.
+int enter_pose(fyx_ctx* c);
 int ensure_scratch(fyx_ctx* c, size_t bytes);
 void free_ctrl(CtrlBuffers& B);
 // Claims the next slot with room for `total` bytes; *h / *d are its staging and device blocks.

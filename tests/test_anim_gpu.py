@@ -372,6 +372,62 @@ def test_c3_crowd_instances_from_pose_to_vertices(ctx, orc):
     _skin_chain(ctx, orc, sc, mesh, 48, 12, bone_nodes, exact=True)
 
 
+def test_pipelined_frames_are_bit_identical_to_one_stream_frames(ctx, orc):
+    """Option anim.overlap: frame n+1's pose kernels run under frame n's skinning (worker streams, two palette buffers).
+    Same kernels, same inputs: the skinned vertices of EVERY frame equal those of the one-stream frame loop bit for bit
+    (each frame's output lands in its own buffer, compared after the loop), and the last frame equals the oracle."""
+    n_inst, n_frames, nb = 40, 14, 64
+    mesh = synth.make_mesh(10_000, nb, synth.SEED_BASE + 3)
+    results = []
+    for overlap in (0, 1):
+        sc = cases.c5_blend_tree(n_bones=nb, seed=synth.SEED_BASE + 3, euler_every=10 ** 9)
+        p = cases.build_product(ctx, sc, n_inst)
+        base = p.base_id
+        for i in range(n_inst):
+            for a in range(len(sc.animations)):
+                p.set_time_position(a, (i * 0.37 + a * 0.11) % 1.0, instance=i)
+        A.create_bone_list(ctx, base + 50, base, list(range(nb)))
+        pals = [ctx.malloc(n_inst * nb * 64) for _ in range(2)]
+        ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+        nv = mesh.n_verts * n_inst
+        outs = [(ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)) for _ in range(n_frames)]
+        ctx.set_option("anim.overlap", overlap)
+        ctx.set_option("lbs.streams", 2 if overlap else 1)
+        try:
+            for f in range(n_frames):
+                dp = pals[f & 1]
+                p.set_palette_output(base + 50, dp.ptr)
+                p.update_machine(sc.dt)
+                ctx.lbs_skin_device(base + 60, dp.ptr, nb, n_inst, outs[f][0].ptr, outs[f][1].ptr, outs[f][2].ptr)
+            ctx.join()
+            ctx.sync()
+        finally:
+            ctx.set_option("anim.overlap", 0)
+            ctx.set_option("lbs.streams", 2)
+        results.append([[b.download(np.uint32, nv * w) for b, w in zip(o, (3, 3, 4))] for o in outs])
+        last_pal = pals[(n_frames - 1) & 1].download(np.float32, n_inst * nb * 16).reshape(n_inst, nb, 16)
+        if overlap:   # the last frame against the oracle (instance 0 and the last one, each at its own phase)
+            for i in (0, n_inst - 1):
+                o = cases.build_oracle(orc, sc)
+                for a in range(len(sc.animations)):
+                    orc._alib().fo_animation_set_time_position(o.anims[a], (i * 0.37 + a * 0.11) % 1.0)
+                for f in range(n_frames):
+                    o.update_machine(sc.dt)
+                ref_pal = o.palette(list(range(nb)))
+                assert np.array_equal(last_pal[i].view(np.uint32), ref_pal.view(np.uint32)), f"palette of instance {i}"
+                ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, ref_pal, mesh.normal, mesh.tangent, threads=0)
+                got = results[-1][-1][0].view(np.float32).reshape(n_inst, -1, 3)[i]
+                assert np.array_equal(got, ref["pos"]), f"skinned positions of instance {i}"
+                o.close()
+        for b in pals + [x for o in outs for x in o]:
+            b.free()
+        ctx.mesh_free(base + 60)
+        p.free()
+    for f in range(n_frames):
+        for k in range(3):
+            assert np.array_equal(results[0][f][k], results[1][f][k]), f"frame {f}, stream {k}: pipelined != one-stream"
+
+
 def test_animated_morph_weights_drive_blend_shapes_into_a_vertex_buffer(ctx, orc):
     """glTF-style chain, all on the device: Real Property tracks -> blended weights -> fyx_animator_blend_shape_weights
     (x / 100, defaults for shapes nothing animated yet) -> blend shapes + skinning with GPU-built palettes -> a complete

@@ -59,4 +59,16 @@ for i in range(N):
     s = i % SETS
     ctx.lbs_skin_device(300, cp.ptr, 64, 100, outs[s][0].ptr, outs[s][1].ptr, outs[s][2].ptr)
 ctx.sync()
+# batched launch: 64 meshes x 20 k vertices / 64 bones, one instance each, ONE lbs_skin_batch launch (128 MB algorithmic)
+jobs = []
+for k in range(64):
+    bm = synth.make_mesh(20_000, 64, synth.SEED_BASE + 400 + k)
+    ctx.mesh_upload_soa(400 + k, bm.pos, bm.weights, bm.indices, bm.normal, bm.tangent)
+    bp = ctx.to_device(synth.make_palette(64, synth.SEED_BASE + 400 + k))
+    bo = (ctx.malloc(20_000 * 12 + 64), ctx.malloc(20_000 * 12 + 64), ctx.malloc(20_000 * 16 + 64))
+    jobs.append((400 + k, bp.ptr, 64, 1, bo[0].ptr, bo[1].ptr, bo[2].ptr))
+    vbs.append(bp); vbs.extend(bo)     # keep alive
+for i in range(N):
+    ctx.lbs_skin_batch(jobs)
+ctx.sync()
 print("done")

@@ -12,7 +12,10 @@ BENCH="python $ROOT/bench.py --steps 1000 --warmup 100 --no-cpu-baseline"
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_fetch" -o pmc -- python $ROOT/tools/pmc_probe.py > /dev/null 2> "$ROOT/$OUT/pmc_fetch.err" )
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_write" -o pmc -- python $ROOT/tools/pmc_probe.py > /dev/null 2> "$ROOT/$OUT/pmc_write.err" )
 ( cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_lds" -o pmc -- python $ROOT/tools/pmc_probe.py > /dev/null 2> "$ROOT/$OUT/pmc_lds.err" )
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_scene_fetch" -o pmc -- python $ROOT/tools/bench_scene.py --characters 256 --instances 1 --verts 5000 --frames 20 --batched-only > /dev/null 2> "$ROOT/$OUT/pmc_scene_fetch.err" )
+( cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_scene_write" -o pmc -- python $ROOT/tools/bench_scene.py --characters 256 --instances 1 --verts 5000 --frames 20 --batched-only > /dev/null 2> "$ROOT/$OUT/pmc_scene_write.err" )
 python $ROOT/bench.py --steps 2000 --warmup 100 --cpu-seconds 3 > "$ROOT/$OUT/bench_plain.json" 2> "$ROOT/$OUT/bench_plain.err"
+python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > "$ROOT/$OUT/bench_driver_args.json" 2> "$ROOT/$OUT/bench_driver_args.err"
 # C3 crowd, pose path + instanced skinning (kernel-trace only)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_pose" -o pose -- python $ROOT/tools/bench_pose.py --frames 200 > "$ROOT/$OUT/pose_under_trace.json" 2> "$ROOT/$OUT/trace_pose.err" )
 python $ROOT/tools/bench_pose.py > "$ROOT/$OUT/pose_plain.json" 2> "$ROOT/$OUT/pose_plain.err"
@@ -29,5 +32,6 @@ python $ROOT/tools/bench_pose.py --opt lbs.streams=1 --opt lbs.exact=0 > "$ROOT/
 python $ROOT/tools/probe_timeline.py --opt lbs.blocks_per_cu=2 > "$ROOT/$OUT/timeline.json" 2> "$ROOT/$OUT/timeline.err"
 python $ROOT/tools/write_ceiling.py > "$ROOT/$OUT/write_ceiling.json" 2> "$ROOT/$OUT/write_ceiling.err"
 python $ROOT/tools/calib.py --rounds 2 > "$ROOT/$OUT/calibration_stream.json" 2> "$ROOT/$OUT/calib.err"
+find "$OUT" -name "*_kernel_trace.csv" -size +8M -delete   # raw per-dispatch traces of the long runs do not travel back
 find "$OUT" -name "*.csv" | head -40
 du -sh "$OUT"
