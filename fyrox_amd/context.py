@@ -117,6 +117,13 @@ class Context:
         self._check(self._l.fyx_timer_end(self._h, byref(ms)))
         return ms.value
 
+    def kernel_time(self):
+        """(sum of the kernel durations in us, number of launches) of the fyx_lbs_skin_device launches made under option
+        lbs.timing = 1 since the last call."""
+        us, n = ctypes.c_double(), ctypes.c_uint32()
+        self._check(self._l.fyx_debug_kernel_time(self._h, byref(us), byref(n)))
+        return us.value, n.value
+
     def set_option(self, key: str, value: int) -> None:
         self._check(self._l.fyx_set_option(self._h, key.encode(), int(value)))
 

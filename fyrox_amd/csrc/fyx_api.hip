@@ -526,6 +526,8 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->aabb_partials) (void)hipFree(c->aabb_partials);
     if (c->d_u32) (void)hipFree(c->d_u32);
+    for (hipEvent_t e : c->timing_ev) (void)hipEventDestroy(e);
+    c->timing_ev.clear();
     if (c->lbs.probe_buf) (void)hipFree(c->lbs.probe_buf);
     if (c->lbs.pool_buf) (void)hipFree(c->lbs.pool_buf);
     delete c->lbs.pool_seq;
@@ -594,6 +596,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd_block")) return &c->lbs.crowd_block;
     if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
     if (!strcmp(key, "lbs.probe")) return &c->lbs.probe;
+    if (!strcmp(key, "lbs.timing")) return &c->timing;
     if (!strcmp(key, "lbs.split")) return &c->lbs.split;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
     if (!strcmp(key, "lbs.dyn_bpc")) return &c->lbs.dyn_bpc;
@@ -831,7 +834,41 @@ int fyx_lbs_skin_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, ui
     const fyx::LbsArgs a = make_args(*m, d_palette, n_bones, n_instances, d_out_pos, d_out_normal, d_out_tangent);
     hipStream_t st;
     if (int sr = acquire_launch_stream(c, &st)) return sr;
+    if (c->timing) {   // this launch's own start / stop events
+        if (c->timing_used + 2 > c->timing_ev.size()) {
+            if (c->timing_ev.size() >= 2 * 8192) return fail(c, FYX_ERR_INVALID_ARG, "lbs.timing: read the times (fyx_debug_kernel_time) every 8192 launches");
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t e = nullptr;
+                FYX_HIP(c, hipEventCreate(&e));
+                c->timing_ev.push_back(e);
+            }
+        }
+        fyx::LbsTuning t = c->lbs;
+        t.ev_start = c->timing_ev[c->timing_used];
+        t.ev_stop = c->timing_ev[c->timing_used + 1];
+        c->timing_used += 2;
+        FYX_HIP(c, fyx::launch_lbs(a, t, st));
+        return FYX_OK;
+    }
     FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_debug_kernel_time(fyx_ctx* c, double* total_us, uint32_t* n_launches) {
+    if (!c || !total_us || !n_launches) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (int rc = enter_primary(c)) return rc;
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (size_t k = 0; k + 1 < c->timing_used; k += 2) {
+        float ms = 0.f;
+        FYX_HIP(c, hipEventElapsedTime(&ms, c->timing_ev[k], c->timing_ev[k + 1]));
+        sum += (double)ms * 1e3;
+    }
+    *total_us = sum;
+    *n_launches = (uint32_t)(c->timing_used / 2);
+    c->timing_used = 0;
     return FYX_OK;
     FYX_GUARD_END(c)
 }

@@ -75,6 +75,9 @@ struct fyx_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // Worker streams for independent skinning launches (see "stream semantics" in fyrox_hip.h).
     static constexpr int kMaxWorkers = 4;
+    int timing = 0;     // option "lbs.timing": fyx_lbs_skin_device launches carry their own start / stop events
+    std::vector<hipEvent_t> timing_ev;   // pairs, in launch order (fyx_debug_kernel_time sums and clears)
+    size_t timing_used = 0;
     int n_workers = 2;  // option "lbs.streams"; 1 = launch on the context stream itself
     hipStream_t workers[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t worker_done[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};

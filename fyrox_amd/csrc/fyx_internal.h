@@ -29,6 +29,7 @@ struct LbsTuning {
     int dyn_bpc = 0;         // workgroups per CU of that launch; 0 = what is resident (1024 / dyn_block)
     uint32_t* pool_buf = nullptr;   // lbs_skin_dyn's unit pool counters (4 sets x 64, 256 bytes apart)
     uint32_t* pool_seq = nullptr;   // launches so far (host word): which set a launch uses
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // option lbs.timing: this launch's own start / stop events (dispatch timestamps)
     int dyn_knobs = 0;       // experiment switches of lbs_skin_dyn (see the kernel)
     int asym = 0;            // lbs_skin, 2 workgroups per CU: the first-dispatched one owns asym/64 of the pair's units (0 = halves)
     int young_prio = 0;      // lbs_skin: s_setprio for the second-dispatched half of the grid

@@ -24,6 +24,15 @@
 //     uses explicit FMAs (<= 1e-5 relative).  f32 VALU only -- no MFMA: this is not a dense
 //     contraction (2.6 FLOP/B).
 #include "fyx_internal.h"
+#include <hip/hip_ext.h>
+
+// A launch that carries its own start / stop events when the caller asked for per-dispatch timing (option lbs.timing:
+// the events take the dispatch's begin / end timestamps, what rocprofv3 --kernel-trace reports), a plain launch otherwise.
+#define FYX_LAUNCH(t, kernel, grid, block, lds, s, ...)                                                          \
+    do {                                                                                                          \
+        if ((t).ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, (t).ev_start, (t).ev_stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                                        \
+    } while (0)
 
 namespace fyx {
 
@@ -725,6 +734,13 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
         n_ = load_unit(v_n);
         return true;
     };
+    if (knobs & 0x10000000u) {   // experiment: one unit in flight per wave (B is processed first, then A alone)
+        process(B, vB);
+        for (;;) {
+            process(A, vA);
+            if (!refill(A, vA)) break;
+        }
+    } else
     for (;;) {   // wave-uniform
         process(A, vA);
         if (!refill(A, vA)) { process(B, vB, true); break; }
@@ -844,8 +860,7 @@ static hipError_t launch_crowd_one(const LbsArgs& a, const LbsTuning& t, hipStre
     const uint64_t grid = (uint64_t)tiles * chunks;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = (size_t)a.n_bones * 64 * 2 + 2 * (BLOCK / 64) * sizeof(uint32_t);
-    hipLaunchKernelGGL((lbs_skin_crowd<BLOCK, EXACT, MASK>), dim3((uint32_t)grid), dim3(BLOCK), lds, s, a, tiles,
-                       ipb);
+    FYX_LAUNCH(t, (lbs_skin_crowd<BLOCK, EXACT, MASK>), dim3((uint32_t)grid), dim3(BLOCK), (uint32_t)lds, s, a, tiles, ipb);
     return hipGetLastError();
 }
 
@@ -894,8 +909,8 @@ static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s
         }
     }
     const uint32_t asym = (t.asym > 0 && t.asym < 64 && grid == 2u * kCUs) ? (uint32_t)t.asym : 0u;
-    hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), lds, s, a,
-                       upi, total, (uint32_t)t.split, (uint64_t*)nullptr, asym, (uint32_t)t.young_prio);
+    FYX_LAUNCH(t, (lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), (uint32_t)lds, s, a,
+               upi, total, (uint32_t)t.split, (uint64_t*)nullptr, asym, (uint32_t)t.young_prio);
     return hipGetLastError();
 }
 
@@ -977,8 +992,8 @@ static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream
         }
     }
 #endif
-    hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), lds, s, a, total, (uint64_t*)nullptr,
-                       (uint32_t)t.dyn_knobs, pool, pool_zero);
+    FYX_LAUNCH(t, (lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), (uint32_t)lds, s, a, total, (uint64_t*)nullptr,
+               (uint32_t)t.dyn_knobs, pool, pool_zero);
     return hipGetLastError();
 }
 

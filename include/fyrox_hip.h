@@ -79,7 +79,7 @@ int fyx_join(fyx_ctx* ctx);
  * "lbs.prefetch" (0 | 1 | 2 units of loads ahead), "lbs.split" (how a launch's 64-vertex units are
  * dealt to the waves: 0 contiguous range per workgroup, units round-robin inside it; 1 equal
  * contiguous vertex shares per wave; 2 units interleaved over all waves), "lbs.probe" (debug
- * timeline, fyx_debug_read_probe); pose path: "anim.threads" / "anim.split" (host threads that
+ * timeline, fyx_debug_read_probe), "lbs.timing" (per-launch events, fyx_debug_kernel_time); pose path: "anim.threads" / "anim.split" (host threads that
  * plan a crowd's frame and instances per planning task; crowds below 2 x anim.split stay on the
  * calling thread), "anim.sample_form" (0 auto, 1 curves of one instance on the lanes, 2
  * instances of one curve on the lanes -- same results, the crowd form is picked from 32
@@ -89,6 +89,12 @@ int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
 /* Debug aid (option "lbs.probe" = 1): per-wave timeline of the last default-variant skinning launch, four
  * uint64 per wave {kernel entry, palette staged, last store issued, last store completed} in 10 ns ticks. */
 int fyx_debug_read_probe(fyx_ctx* ctx, uint64_t* host_out, uint32_t n_waves);
+/* Measurement aid (option "lbs.timing" = 1): every fyx_lbs_skin_device launch carries its own start / stop events
+ * (hipExtLaunchKernel: the dispatch's begin / end timestamps, i.e. the kernel's own duration as a kernel trace
+ * reports it, without the gap between dependent launches).  Waits for the work in flight, returns the sum of the
+ * durations of the launches made since the last call and their number, and starts over.  At most 8192 launches
+ * between two calls.  Replaces nothing in the reference. */
+int fyx_debug_kernel_time(fyx_ctx* ctx, double* total_us, uint32_t* n_launches);
 int fyx_get_option(fyx_ctx* ctx, const char* key, int* value);
 
 /* GPU-side timing on the context's stream (hipEvent pair): begin records an event, end records
