@@ -43,7 +43,7 @@ for i in range(args.launches):
     ctx.sync()
     buf = np.zeros((n_waves, 4), np.uint64)
     ctx._check(ctx._l.fyx_debug_read_probe(ctx._h, buf.ctypes.data, n_waves))
-    t = buf.astype(np.int64)
+    t = (buf & np.uint64((1 << 48) - 1)).astype(np.int64)    # the top bits carry the wave's hardware position (lbs_skin_dyn)
     t0 = t[:, 0].min()
     us = (t - t0) / 100.0           # 100 MHz ticks -> microseconds
     rows.append({"entry_last_us": float(us[:, 0].max()), "entry_p50_us": float(np.median(us[:, 0])),
