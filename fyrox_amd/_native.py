@@ -177,6 +177,8 @@ def _preload_hip_runtime() -> None:
     """If torch is importable, import it first so that libfyrox_hip.so binds to the SAME
     libamdhip64.so.7 torch uses (one HIP runtime per process: device pointers and streams are
     then interchangeable between torch tensors / RCCL and this library)."""
+    if os.environ.get("FYX_TEST_NO_TORCH"):   # sanitizer runs (tools/asan_gpu.sh): the system's HIP runtime, no torch
+        return
     try:
         import torch  # noqa: F401
     except Exception:

@@ -223,11 +223,70 @@ static int gpu() {
         std::printf("FAIL: animated palette differs from the oracle\n");
         return 1;
     }
+    // ---- a frame loop as the engine would drive it: scene update with registered (alternating) palette outputs, skinning
+    // launches on the worker streams, a batch whose job table changes, pipelined and joined frames, per-launch timing.
+    // Every batch result must equal the single-mesh call's bytes; under tools/asan_gpu.sh this is the part that walks
+    // the stream / event / control-block bookkeeping of the library with AddressSanitizer watching.
+    {
+        const uint32_t sizes[3] = {700, 5003, 20000};
+        std::vector<std::vector<float>> want(3);
+        std::vector<void*> d_out(3, nullptr);
+        void* d_static_pal = nullptr;
+        CHECK(fyx_malloc(ctx, nb * 64, &d_static_pal));
+        CHECK(fyx_memcpy_h2d(ctx, d_static_pal, pal.data(), nb * 64));
+        for (int m = 0; m < 3; ++m) {
+            const uint32_t n = sizes[m];
+            std::vector<uint8_t> a((size_t)n * stride, 0);
+            for (uint32_t v = 0; v < n; ++v) std::memcpy(&a[(size_t)v * stride], &aos[(size_t)(v % nv) * stride], stride);
+            CHECK(fyx_mesh_upload(ctx, 100 + m, a.data(), n, stride, 0, 20, 32, 48, 64));
+            want[m].resize((size_t)n * 3);
+            CHECK(fyx_lbs_skin(ctx, 100 + m, pal.data(), nb, 1, want[m].data(), nullptr, nullptr, nullptr));
+            CHECK(fyx_malloc(ctx, (size_t)n * 12 + 64, &d_out[m]));
+        }
+        void *d_pal_ring[2] = {nullptr, nullptr}, *d_inst_out = nullptr;
+        for (auto& q : d_pal_ring) CHECK(fyx_malloc(ctx, 2 * 4 * 64, &q));
+        CHECK(fyx_malloc(ctx, 2 * (size_t)sizes[1] * 12 + 64, &d_inst_out));
+        const uint64_t ids[1] = {2};
+        for (int frame = 0; frame < 16; ++frame) {
+            CHECK(fyx_set_option(ctx, "lbs.streams", 1 + (frame / 4) % 2));
+            CHECK(fyx_set_option(ctx, "anim.overlap", (frame / 2) % 2));
+            CHECK(fyx_set_option(ctx, "lbs.timing", frame % 2));
+            CHECK(fyx_animator_set_palette_output(ctx, 2, 3, (float*)d_pal_ring[frame & 1]));
+            CHECK(fyx_scene_update(ctx, ids, 1, 1.0f / 24.0f));
+            CHECK(fyx_lbs_skin_device(ctx, 101, (const float*)d_pal_ring[frame & 1], 4, 2, (float*)d_inst_out, nullptr, nullptr));
+            fyx_skin_job jobs[3];
+            uint32_t n_jobs = 0;
+            for (int m = 0; m < 3; ++m) {
+                if (frame % 3 == 1 && m == 0) continue;   // the job table changes from frame to frame
+                CHECK(fyx_memcpy_h2d(ctx, d_out[m], std::vector<float>((size_t)sizes[m] * 3, -1.0f).data(), (size_t)sizes[m] * 12));
+                jobs[n_jobs++] = fyx_skin_job{(uint64_t)(100 + m), (const float*)d_static_pal, nb, 1, (float*)d_out[m], nullptr, nullptr};
+            }
+            CHECK(fyx_lbs_skin_batch(ctx, jobs, n_jobs));
+            if (frame % 2) CHECK(fyx_join(ctx));
+            for (uint32_t j = 0; j < n_jobs; ++j) {
+                const int m = (int)jobs[j].mesh_id - 100;
+                std::vector<float> back((size_t)sizes[m] * 3);
+                CHECK(fyx_memcpy_d2h(ctx, back.data(), d_out[m], back.size() * 4));
+                if (std::memcmp(back.data(), want[m].data(), back.size() * 4)) { std::printf("FAIL: frame %d, batch job of mesh %d differs from the single-mesh call\n", frame, m); return 1; }
+            }
+            if (frame % 2) {
+                double us = 0; uint32_t n = 0;
+                CHECK(fyx_debug_kernel_time(ctx, &us, &n));
+                if (n != 1 || !(us > 0.0)) { std::printf("FAIL: fyx_debug_kernel_time -> %u launches, %f us\n", n, us); return 1; }
+            }
+        }
+        CHECK(fyx_set_option(ctx, "lbs.streams", 2)); CHECK(fyx_set_option(ctx, "anim.overlap", 0)); CHECK(fyx_set_option(ctx, "lbs.timing", 0));
+        CHECK(fyx_animator_set_palette_output(ctx, 2, 3, nullptr));
+        CHECK(fyx_sync(ctx));
+        for (int m = 0; m < 3; ++m) { CHECK(fyx_mesh_free(ctx, 100 + m)); CHECK(fyx_free(ctx, d_out[m])); }
+        for (auto& q : d_pal_ring) CHECK(fyx_free(ctx, q));
+        CHECK(fyx_free(ctx, d_inst_out)); CHECK(fyx_free(ctx, d_static_pal));
+    }
     CHECK(fyx_free(ctx, d_pal));
     fo_animation_free(oa);
     fo_tracks_free(td);
     fyx_shutdown(ctx);
-    std::printf("gpu ok: C1 skinning + AABB bit-exact, 25-frame clip -> palette bit-exact\n");
+    std::printf("gpu ok: C1 skinning + AABB bit-exact, 25-frame clip -> palette bit-exact, 16-frame engine-style loop (scene update, worker streams, batches, pipelining, timing) consistent\n");
     return 0;
 }
 
