@@ -284,12 +284,26 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # FYX_BENCH_DEVICE: test hook -- every rank on this device (exercises the N > 1 code on a one-GPU box; RCCL refuses
+    # two ranks on one GPU, so it also exercises the fall-backs below)
+    if os.environ.get("FYX_BENCH_DEVICE"):
+        local_rank = int(os.environ["FYX_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    dist = None
+    dist, dist_backend, dist_cuda = None, None, True
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # the process group only carries barriers, the max over ranks and the 128-byte unique id; RCCL when it comes up,
+        # gloo otherwise (the decision is each rank's own: a failing RCCL start-up fails on every rank)
+        try:
+            if os.environ.get("FYX_BENCH_DEVICE"):
+                raise RuntimeError("ranks share a device")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist_backend = "nccl"
+        except Exception as e:     # noqa: BLE001
+            print(f"# rank {rank}: process group on RCCL failed ({e!r}); using gloo for the control collectives", file=sys.stderr)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist_backend, dist_cuda = "gloo", False
 
     ctx = fyrox_amd.Context(local_rank)    # owns its launch streams; torch is only used for barriers and buffers
     for kv in args.opt:
@@ -297,12 +311,29 @@ def main():
         ctx.set_option(k, int(v))
     opt_keys = ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams", "lbs.split", "lbs.dyn", "lbs.dyn_block")
     opts = {k: ctx.get_option(k) for k in opt_keys}
-    n_ranks_rccl = None
+    n_ranks_rccl, comm_error = None, None
     if world > 1:      # the library's own communicator (fyx_comm_init): rank 0's unique id travels over the process group
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        ok = 1
+        try:
+            uid = [ctx.comm_unique_id() if rank == 0 else None]
+        except Exception as e:     # noqa: BLE001
+            uid, ok, comm_error = [None], 0, repr(e)
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
-        n_ranks_rccl = ctx.comm_info()[1]
+        if uid[0] is None:
+            ok = 0
+        else:
+            try:
+                ctx.comm_init(uid[0], rank, world)
+                n_ranks_rccl = ctx.comm_info()[1]
+            except Exception as e:     # noqa: BLE001
+                ok, comm_error = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist_cuda else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # all ranks take the same path
+        if int(flag[0]) == 0:
+            n_ranks_rccl = None
+            comm_error = comm_error or "another rank could not join the communicator"
+            print(f"# rank {rank}: fyx_comm_init failed ({comm_error}); the exchange leg is skipped", file=sys.stderr)
+    have_comm = n_ranks_rccl is not None
 
     def barrier():
         ctx.sync()
@@ -313,7 +344,7 @@ def main():
     def max_over_ranks(x: float) -> float:
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist_cuda else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
 
@@ -409,6 +440,34 @@ def main():
     kernel_us = max_over_ranks(float(np.median(ker)))          # the kernel's own duration, averaged over n_ser launches
     period_us = max_over_ranks(float(np.median(ser)))          # launch to launch on one stream (adds the dependent-launch gap)
     ctx.set_option("lbs.streams", opts["lbs.streams"])
+    # ---- position only: what the reference's CPU loop computes (mesh/mod.rs:501-522): 32 B read + 12 B written per vertex ----
+    pos_only = None
+    if rank == 0:
+        pcalls = [partial(fn, ctx._h, ctypes.c_uint64(s), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones),
+                          ctypes.c_uint32(1), ctypes.c_void_p(o[0].data_ptr()), ctypes.c_void_p(None), ctypes.c_void_p(None))
+                  for s, o in enumerate(outs)]
+        ctx.set_option("lbs.streams", 1)
+        for i in range(50):
+            pcalls[i % n_sets]()
+        ctx.set_option("lbs.timing", 1)
+        ctx.kernel_time()
+        for i in range(n_ser):
+            pcalls[i % n_sets]()
+        us, n = ctx.kernel_time()
+        ctx.set_option("lbs.timing", 0)
+        ctx.set_option("lbs.streams", opts["lbs.streams"])
+        for i in range(50):
+            pcalls[i % n_sets]()
+        ctx.sync()
+        ctx.timer_begin()
+        for i in range(n_ser):
+            pcalls[i % n_sets]()
+        ov = ctx.timer_end() * 1e3 / n_ser
+        pk = us / max(n, 1)
+        pos_only = {"workload": "C4, position stream only (the reference's CPU loop): 44 B/vertex", "algorithmic_bytes_per_launch": 44 * nv,
+                    "kernel_us": pk, "frac": 44 * nv / (pk * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "overlapped_us": ov, "overlapped_frac": 44 * nv / (ov * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "vertices_per_s_overlapped": nv / (ov * 1e-6)}
     # ---- no-math copy of the same bytes (60 MB in, 40 MB out per launch), same run: what a 100 MB launch can do here ----
     copy_us = None
     if rank == 0:
@@ -449,7 +508,7 @@ def main():
             rc = scalls[i % sets2]()
             if rc:
                 ctx._check(rc)
-            if with_gather and world > 1:
+            if with_gather and have_comm:
                 rc = gcalls[i % sets2]()
                 if rc:
                     ctx._check(rc)
@@ -464,12 +523,15 @@ def main():
             tail = slice(full.n_verts - n_chk, full.n_verts)
             ref = oracle.lbs_skin(full.pos[tail], full.weights[tail], full.indices[tail], pal, full.normal[tail], full.tangent[tail], threads=0)
             got = alls[0][0][(full.n_verts - n_chk) * 3:full.n_verts * 3].cpu().numpy().reshape(-1, 3)
-            head = lbs_parity(ctx, full, pal, alls[0], n_chk)
-            gathered_ok = bool(head["bit_exact"] and np.array_equal(got, ref["pos"]))
-            if not gathered_ok:
-                raise SystemExit("strong scaling: the gathered buffer differs from the oracle")
+            head = lbs_parity(ctx, full, pal, alls[0], n_chk)        # rank 0's own shard starts at vertex 0
+            if have_comm or world == 1:
+                gathered_ok = bool(head["bit_exact"] and np.array_equal(got, ref["pos"]))
+                if not gathered_ok:
+                    raise SystemExit("strong scaling: the gathered buffer differs from the oracle")
+            elif not head["bit_exact"]:
+                raise SystemExit("strong scaling: rank 0's shard differs from the oracle")
         r_c, w_c, g_c = timed_regions(lambda i: sstep(i, False), args.steps, args.warmup)
-        r_g, w_g, g_g = (timed_regions(lambda i: sstep(i, True), args.steps, args.warmup) if world > 1 else (r_c, w_c, g_c))
+        r_g, w_g, g_g = (timed_regions(lambda i: sstep(i, True), args.steps, args.warmup) if have_comm else (r_c, w_c, g_c))
         sizes = [sharding.vertex_range_native(full.n_verts, r, world) for r in range(world)]
         strong = {"workload": f"C4 as written: {full.n_verts} verts / {args.bones} bones cut by contiguous vertex range over {world} GPU(s), "
                               "palette replicated; every rank writes its shard in place into the full buffers",
@@ -480,7 +542,9 @@ def main():
                   "with_allgather": {"value": full.n_verts * args.steps * r_g / float(np.median(w_g)), "unit": "vertices/s",
                                      "ms_per_step": float(np.median(w_g)) * 1e3 / (args.steps * r_g), "timed_steps": args.steps * r_g,
                                      "collective": "fyx_allgather_skinned: one grouped RCCL op per frame (ragged shards, 40 B/vertex)"},
-                  "gathered_equals_oracle": gathered_ok}
+                  "gathered_equals_oracle": gathered_ok, "comm_error": comm_error}
+        if not have_comm and world > 1:
+            strong["with_allgather"] = {"value": None, "note": "no communicator (see comm_error): the exchange leg did not run"}
         if args.scaling == "strong":
             repeats, walls, gpus = (r_g, w_g, g_g) if args.allgather else (r_c, w_c, g_c)
 
@@ -516,6 +580,7 @@ def main():
                                    if args.scaling == "weak" else strong["workload"],
                        "sharding": "contiguous vertex range per GPU, palette replicated",
                        "rank0_vertex_range": list(shard), "n_ranks": n_ranks_rccl if n_ranks_rccl is not None else 1,
+                       "process_group": dist_backend,
                        "kernel_options": opts},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -531,7 +596,8 @@ def main():
                          "copy_ceiling": None if copy_us is None else {
                              "kernel_us": copy_us, "achieved": bytes_launch / (copy_us * 1e-6) / 1e9,
                              "frac": bytes_launch / (copy_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                             "note": "stream_copy_kernel: 60 MB read + 40 MB written, no math, one stream, same run"}},
+                             "note": "stream_copy_kernel: 60 MB read + 40 MB written, no math, one stream, same run"},
+                         "position_only": pos_only},
             "parity": parity,
         }
         extra = {}
