@@ -26,7 +26,7 @@ ap.add_argument("--instances", type=int, default=4)
 ap.add_argument("--verts", type=int, default=20_000)
 ap.add_argument("--bones", type=int, default=64)
 ap.add_argument("--frames", type=int, default=100)
-ap.add_argument("--warmup", type=int, default=10)
+ap.add_argument("--warmup", type=int, default=60)
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--batched-only", action="store_true", help="skip the one-by-one legs (short runs under a profiler)")
 args = ap.parse_args()
@@ -63,6 +63,11 @@ dt = 1.0 / 60.0
 
 
 animators = [c[0] for c in chars]
+# the id array is built once: a Python list comprehension over 256 objects per frame costs more than the library's whole host path
+import ctypes
+_ids = np.asarray([a.id for a in animators], np.uint64)
+_scene_update = ctx._l.fyx_scene_update
+_ids_p, _n_ids, _dt = _ids.ctypes.data_as(ctypes.c_void_p), len(_ids), ctypes.c_float(1.0 / 60.0)
 
 
 from fyrox_amd._native import SkinJob
@@ -72,7 +77,7 @@ skin_jobs = (SkinJob * K)(*[SkinJob(mid, d_pal.ptr, args.bones, N, o[0].ptr, o[1
 def frame(skin=True, pose=True, batched=True):
     if batched:
         if pose:
-            A.scene_update(ctx, animators, dt)       # one launch per stage for the whole scene
+            ctx._check(_scene_update(ctx._h, _ids_p, _n_ids, _dt))   # one launch per stage for the whole scene
         if skin:
             ctx.lbs_skin_batch(skin_jobs)            # one launch for every mesh of the scene
         return
@@ -104,10 +109,10 @@ else:
     f1_gpu, f1_wall = timed(batched=False)
     p1_gpu, p1_wall = timed(skin=False, batched=False)
     s1_gpu, s1_wall = timed(pose=False, batched=False)
+_scene_plan = ctx._l.fyx_scene_plan
 t0 = time.perf_counter()
 for _ in range(args.frames):
-    for an, *_ in chars:
-        an.plan(1, dt)
+    ctx._check(_scene_plan(ctx._h, _ids_p, _n_ids, _dt))      # the host half of fyx_scene_update alone (planner threads included)
 plan = (time.perf_counter() - t0) * 1e3 / args.frames
 total_verts = K * N * args.verts
 print(json.dumps({
