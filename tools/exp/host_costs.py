@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import fyrox_amd
 from fyrox_amd import anim as A, synth
-N = 1000
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 ctx = fyrox_amd.Context(0)
 ctx.set_option("lbs.streams", 1)
 seed = synth.SEED_BASE + 3

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 mkdir -p gpurun_out/ab
 for v in "$@"; do
-  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/ab/$opt$v" -o p -- python $ROOT/tools/bench_pose.py --frames 150 --opt lbs.streams=1 --opt $opt=$v > "$ROOT/gpurun_out/ab/$opt$v.json" 2> /dev/null )
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/ab/$opt$v" -o p -- python $ROOT/tools/bench_pose.py --instances ${INSTANCES:-1000} --frames 150 --opt lbs.streams=1 --opt $opt=$v > "$ROOT/gpurun_out/ab/$opt$v.json" 2> /dev/null )
   echo "== $opt=$v"; grep -E "pose_|palette" gpurun_out/ab/$opt$v/p_kernel_stats.csv | python3 -c "import csv,sys; [print(r[0][:70], r[1], round(float(r[3])/1000,2)) for r in csv.reader(sys.stdin)]"
   find gpurun_out/ab -name "*kernel_trace.csv" -delete
 done
