@@ -20,6 +20,7 @@ What the one JSON line says (rank 0 prints it):
                         the library's launch streams (head of one launch under the tail of the previous one).
   roofline.copy_ceiling a no-math 60 MB-in / 40 MB-out copy kernel on the same buffers' sizes, same run, same box.
   extra.c2 / c3 / c5    the other BASELINE configs end to end (pose -> palette -> skinning), N = 1 only.
+  extra.scene_*         the scene tick: many distinct characters per frame, one fyx_scene_update + one fyx_lbs_skin_batch.
   extra.strong_scaling  N > 1: the SAME 1 M-vertex mesh cut by vertex range over the N GPUs (BASELINE config 4), compute
                         only and with the RCCL exchange (fyx_allgather_skinned).  The headline stays weak scaling (N x 1 M).
 """
@@ -245,6 +246,99 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     return rec
 
 
+def _scene_record(ctx, n_chars: int, n_inst: int, n_verts: int, id_base: int, frames: int = 150) -> dict:
+    """The scene tick: n_chars DISTINCT characters (own rig, four clips, blend-tree machine, mesh), n_inst instances
+    each; per frame ONE fyx_scene_update (one launch per stage for all animators, palettes written by the update kernel) and ONE
+    fyx_lbs_skin_batch.  Parity: two characters against the oracle after a few frames (skinning stage bit-exact)."""
+    import ctypes as ct
+    import oracle as orc
+    from fyrox_amd import anim as A, synth
+    from fyrox_amd._native import SkinJob
+    nb, dt = 64, 1.0 / 60.0
+    chars, frees = [], []
+    for k in range(n_chars):
+        seed = synth.SEED_BASE + 700 + k
+        rig = synth.make_rig(nb, seed)
+        rid, aid, bid, mid, tid = (id_base + j * 10_000 + k for j in range(5))
+        tid = id_base + 100_000 + 4 * k
+        A.create_rig(ctx, rid, rig)
+        an = A.Animator(ctx, aid, rid, rig, n_inst)
+        for c in range(4):
+            td, tgt = synth.make_clip(nb, seed, clip=c, euler_every=10 ** 9)
+            A.upload_tracks_data(ctx, tid + c, td)
+            an.add_animation(tid + c, tgt, time_slice=(0.0, 1.0), speed=[1.0, 0.8, 1.3, -0.7][c])
+        an.set_machine(synth.make_c5_machine())
+        A.create_bone_list(ctx, bid, rid, list(range(nb)))
+        mesh = synth.make_mesh(n_verts, nb, seed)
+        ctx.mesh_upload_soa(mid, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+        nv = n_verts * n_inst
+        d_pal = ctx.malloc(n_inst * nb * 64)
+        outs = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+        an.set_palette_output(bid, d_pal.ptr)
+        chars.append((an, mid, d_pal, outs, mesh, rig, seed))
+        frees += [d_pal, *outs]
+    ids = np.asarray([c[0].id for c in chars], np.uint64)
+    ids_p, cdt = ids.ctypes.data_as(ct.c_void_p), ct.c_float(dt)
+    jobs = (SkinJob * n_chars)(*[SkinJob(mid, d_pal.ptr, nb, n_inst, o[0].ptr, o[1].ptr, o[2].ptr) for _, mid, d_pal, o, *_ in chars])
+    upd, batch = ctx._l.fyx_scene_update, ctx._l.fyx_lbs_skin_batch
+
+    def frame(pose=True, skin=True):
+        if pose:
+            ctx._check(upd(ctx._h, ids_p, n_chars, cdt))
+        if skin:
+            ctx._check(batch(ctx._h, jobs, n_chars))
+
+    n_par = 4
+    for _ in range(n_par):
+        frame()
+    ctx.sync()
+    exact = True
+    for k in (0, n_chars - 1):       # the oracle steps the same machine (all instances start in phase); skinning on the GPU's palette
+        an, mid, d_pal, outs, mesh, rig, seed = chars[k]
+        pal = d_pal.download(np.float32, n_inst * nb * 16).reshape(n_inst, nb, 16)
+        o = orc.AnimScene(rig)
+        for c in range(4):
+            td, tgt = synth.make_clip(nb, seed, clip=c, euler_every=10 ** 9)
+            o.add_animation(o.add_tracks_data(td), tgt, time_slice=(0.0, 1.0), speed=[1.0, 0.8, 1.3, -0.7][c])
+        o.set_machine(synth.make_c5_machine())
+        for _ in range(n_par):
+            o.update_machine(dt)
+        ref_pal = o.palette(list(range(nb)))
+        exact &= bool(np.array_equal(pal[0].view(np.uint32), ref_pal.view(np.uint32)))
+        ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, ref_pal, mesh.normal, mesh.tangent, threads=0)
+        got = outs[0].download(np.float32, n_verts * 3).reshape(-1, 3)
+        exact &= bool(np.array_equal(got, ref["pos"]))
+        o.close()
+    if not exact:
+        raise SystemExit("scene record: palettes / skinned vertices differ from the oracle")
+    for _ in range(60):
+        frame()
+
+    def timed(**kw):
+        ctx.sync()
+        ctx.timer_begin()
+        for _ in range(frames):
+            frame(**kw)
+        return ctx.timer_end() / frames
+
+    f_ms, p_ms, s_ms = timed(), timed(skin=False), timed(pose=False)
+    total = n_chars * n_inst * n_verts
+    rec = {"workload": f"scene tick: {n_chars} distinct characters x {n_inst} instance(s) x {n_verts} verts / {nb} bones, 4-clip blend-tree machine each; "
+                       "one fyx_scene_update + one fyx_lbs_skin_batch per frame",
+           "frame_ms": f_ms, "pose_ms": p_ms, "skin_ms": s_ms, "scene_frames_per_s": 1e3 / f_ms, "skinned_vertices_per_s": total / (f_ms * 1e-3),
+           "skin_roofline": {"bound": "hbm", "kernel": "lbs_skin_batch", "algorithmic_bytes_per_launch": total * 100,
+                             "achieved": total * 100 / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": total * 100 / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launch_period_us": s_ms * 1e3},
+           "parity": {"characters_checked": [0, n_chars - 1], "frames_in_lock_step": n_par, "bit_exact": exact,
+                      "note": "quaternion tracks: palettes and skinned positions bit-identical to the oracle"}}
+    for an, mid, *_ in chars:
+        an.free()
+        ctx.mesh_free(mid)
+    for b in frees:
+        b.free()
+    return rec
+
+
 def extras(ctx) -> dict:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import anim_cases as cases
@@ -265,6 +359,8 @@ def extras(ctx) -> dict:
                                   cases.c5_blend_tree(n_bones=64), synth.make_mesh(100_000, 64, synth.SEED_BASE + 5), 1, 400, False, [0])
     finally:
         ctx.set_option("lbs.streams", streams)
+    out["scene_64x4"] = _scene_record(ctx, 64, 4, 20_000, 1_000_000)
+    out["scene_256x1"] = _scene_record(ctx, 256, 1, 5_000, 2_000_000)
     return out
 
 
