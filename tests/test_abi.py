@@ -99,3 +99,28 @@ def test_rust_shim_uses_only_names_the_reference_has():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_rust_shim.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_options_are_validated_and_readable_without_a_gpu():
+    """fyx_set_option / fyx_get_option on a control-only context: known keys round-trip, out-of-range values and unknown
+    keys are error codes (the header lists the keys), and nothing needs a device."""
+    import fyrox_amd
+    c = fyrox_amd.Context(control_only=True)
+    try:
+        for key, good, bad in (("lbs.exact", 0, None), ("lbs.streams", 1, 9), ("lbs.crowd", -1, 2), ("lbs.crowd_block", 256, 300),
+                               ("lbs.dyn_block", 1024, 100), ("lbs.dyn_bpc", 2, 9), ("anim.threads", 3, 0), ("anim.split", 64, 0),
+                               ("anim.sample_form", 2, 3), ("anim.overlap", 1, 2), ("lbs.timing", 1, None)):
+            if key == "lbs.streams":
+                continue      # binds the device when it changes: a data-path option
+            c.set_option(key, good)
+            assert c.get_option(key) == good, key
+            if bad is not None:
+                with pytest.raises(fyrox_amd.FyxError):
+                    c.set_option(key, bad)
+                assert c.get_option(key) == good, key
+        with pytest.raises(fyrox_amd.FyxError):
+            c.set_option("no.such.option", 1)
+        with pytest.raises(fyrox_amd.FyxError):
+            c.get_option("no.such.option")
+    finally:
+        c.close()

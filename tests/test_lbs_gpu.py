@@ -1122,3 +1122,34 @@ def test_batch_of_hundreds_of_tiny_meshes_equals_per_mesh_launches(ctx, seed):
         for d in [pal, va, vb] + a + b_:
             d.free()
         ctx.mesh_free(mid)
+
+
+@pytest.mark.gpu
+def test_per_launch_timing_reports_every_launch_once(ctx):
+    """Option lbs.timing: each fyx_lbs_skin_device launch carries its own start / stop events; fyx_debug_kernel_time returns
+    the sum of the kernels' durations and their number since the last call and starts over.  Results are unaffected."""
+    mesh = synth.make_mesh(30_000, 32, synth.SEED_BASE + 77)
+    pal = synth.make_palette(32, synth.SEED_BASE + 77)
+    ctx.mesh_upload_soa(9100, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    d_pal = ctx.to_device(pal)
+    out = ctx.malloc(mesh.n_verts * 12 + 64)
+    ctx.lbs_skin_device(9100, d_pal.ptr, 32, 1, out.ptr)
+    ctx.sync()
+    ref = out.download(np.uint32, mesh.n_verts * 3)
+    ctx.set_option("lbs.timing", 1)
+    try:
+        ctx.kernel_time()
+        for streams in (1, 2):
+            ctx.set_option("lbs.streams", streams)
+            for _ in range(7):
+                ctx.lbs_skin_device(9100, d_pal.ptr, 32, 1, out.ptr)
+            us, n = ctx.kernel_time()
+            assert n == 7 and 7 * 0.5 < us < 7 * 500.0, (us, n)
+        assert ctx.kernel_time() == (0.0, 0)
+    finally:
+        ctx.set_option("lbs.timing", 0)
+        ctx.set_option("lbs.streams", 2)
+    ctx.lbs_skin_device(9100, d_pal.ptr, 32, 1, out.ptr)
+    ctx.sync()
+    assert np.array_equal(out.download(np.uint32, mesh.n_verts * 3), ref)
+    out.free(); d_pal.free(); ctx.mesh_free(9100)

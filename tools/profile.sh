@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$(pwd)
-BENCH="python $ROOT/bench.py --steps 1000 --warmup 100 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-extras"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace" -o bench -- $BENCH > "$ROOT/$OUT/bench_under_trace.json" 2> "$ROOT/$OUT/trace.err" )
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_s1" -o bench -- $BENCH --opt lbs.streams=1 > "$ROOT/$OUT/bench_under_trace_s1.json" 2> "$ROOT/$OUT/trace_s1.err" )
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_fetch" -o pmc -- python $ROOT/tools/pmc_probe.py > /dev/null 2> "$ROOT/$OUT/pmc_fetch.err" )
