@@ -44,6 +44,17 @@ N_BONES = 256
 BYTES_PER_VERTEX = 100          # 60 read + 40 written
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MIN_REGION_MS = 20.0            # a timed region shorter than this is repeated (see module docstring)
+EXCHANGE_TIMEOUT_S = 120        # N > 1: the RCCL exchange leg may take this long before the line is printed without it
+
+
+def emit(line: str) -> None:
+    """Rank 0's ONE JSON line, as the last thing on stdout: whatever native libraries have buffered in C stdio (RCCL prints
+    a version banner through it, which would otherwise come out at exit, after the line) is flushed first."""
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:     # noqa: BLE001
+        pass
+    print(line, flush=True)
 
 
 def parse():
@@ -429,6 +440,10 @@ def main():
             n_ranks_rccl = None
             comm_error = comm_error or "another rank could not join the communicator"
             print(f"# rank {rank}: fyx_comm_init failed ({comm_error}); the exchange leg is skipped", file=sys.stderr)
+    force_exchange = world == 1 and bool(os.environ.get("FYX_BENCH_FORCE_EXCHANGE"))   # test hook: single-rank communicator
+    if force_exchange:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        n_ranks_rccl = ctx.comm_info()[1]
     have_comm = n_ranks_rccl is not None
 
     def barrier():
@@ -609,25 +624,14 @@ def main():
                 if rc:
                     ctx._check(rc)
 
-        # every rank must end up holding the WHOLE skinned mesh: checked on rank 0 against the oracle, head and tail
-        gathered_ok = None
-        sstep(0, True)
+        # compute only first; the exchange (RCCL with more than one rank) runs LAST, under a watchdog, see exchange_leg
+        sstep(0, False)
         ctx.sync()
         if rank == 0 and not args.no_check:
-            import oracle
-            n_chk = 20_000
-            tail = slice(full.n_verts - n_chk, full.n_verts)
-            ref = oracle.lbs_skin(full.pos[tail], full.weights[tail], full.indices[tail], pal, full.normal[tail], full.tangent[tail], threads=0)
-            got = alls[0][0][(full.n_verts - n_chk) * 3:full.n_verts * 3].cpu().numpy().reshape(-1, 3)
-            head = lbs_parity(ctx, full, pal, alls[0], n_chk)        # rank 0's own shard starts at vertex 0
-            if have_comm or world == 1:
-                gathered_ok = bool(head["bit_exact"] and np.array_equal(got, ref["pos"]))
-                if not gathered_ok:
-                    raise SystemExit("strong scaling: the gathered buffer differs from the oracle")
-            elif not head["bit_exact"]:
+            head = lbs_parity(ctx, full, pal, alls[0], 20_000)        # rank 0's own shard starts at vertex 0
+            if not head["bit_exact"]:
                 raise SystemExit("strong scaling: rank 0's shard differs from the oracle")
         r_c, w_c, g_c = timed_regions(lambda i: sstep(i, False), args.steps, args.warmup)
-        r_g, w_g, g_g = (timed_regions(lambda i: sstep(i, True), args.steps, args.warmup) if have_comm else (r_c, w_c, g_c))
         sizes = [sharding.vertex_range_native(full.n_verts, r, world) for r in range(world)]
         strong = {"workload": f"C4 as written: {full.n_verts} verts / {args.bones} bones cut by contiguous vertex range over {world} GPU(s), "
                               "palette replicated; every rank writes its shard in place into the full buffers",
@@ -635,14 +639,33 @@ def main():
                   "shard_vertices": [e_ - b_ for b_, e_ in sizes],
                   "compute_only": {"value": full.n_verts * args.steps * r_c / float(np.median(w_c)), "unit": "vertices/s",
                                    "ms_per_step": float(np.median(w_c)) * 1e3 / (args.steps * r_c), "timed_steps": args.steps * r_c},
-                  "with_allgather": {"value": full.n_verts * args.steps * r_g / float(np.median(w_g)), "unit": "vertices/s",
-                                     "ms_per_step": float(np.median(w_g)) * 1e3 / (args.steps * r_g), "timed_steps": args.steps * r_g,
-                                     "collective": "fyx_allgather_skinned: one grouped RCCL op per frame (ragged shards, 40 B/vertex)"},
-                  "gathered_equals_oracle": gathered_ok, "comm_error": comm_error}
-        if not have_comm and world > 1:
-            strong["with_allgather"] = {"value": None, "note": "no communicator (see comm_error): the exchange leg did not run"}
+                  "with_allgather": {"value": None, "note": "world size 1: nothing to exchange" if world == 1 else
+                                     "no communicator (see comm_error): the exchange leg did not run"},
+                  "gathered_equals_oracle": None, "comm_error": comm_error}
+
+        def exchange_leg():
+            """Every rank ends up holding the WHOLE skinned mesh (checked on rank 0 against the oracle, head and tail), then the
+            timed regions with the exchange in them.  Returns (record, regions) on rank 0's behalf; all ranks take part."""
+            for o in alls[0]:
+                o.zero_()
+            sstep(0, True)
+            ctx.sync()
+            ok = None
+            if rank == 0 and not args.no_check:
+                import oracle
+                n_chk = 20_000
+                tail = slice(full.n_verts - n_chk, full.n_verts)
+                ref = oracle.lbs_skin(full.pos[tail], full.weights[tail], full.indices[tail], pal, full.normal[tail], full.tangent[tail], threads=0)
+                got = alls[0][0][(full.n_verts - n_chk) * 3:full.n_verts * 3].cpu().numpy().reshape(-1, 3)
+                ok = bool(lbs_parity(ctx, full, pal, alls[0], n_chk)["bit_exact"] and np.array_equal(got, ref["pos"]))
+            r_g, w_g, g_g = timed_regions(lambda i: sstep(i, True), args.steps, args.warmup)
+            rec = {"value": full.n_verts * args.steps * r_g / float(np.median(w_g)), "unit": "vertices/s",
+                   "ms_per_step": float(np.median(w_g)) * 1e3 / (args.steps * r_g), "timed_steps": args.steps * r_g,
+                   "collective": "fyx_allgather_skinned: one grouped RCCL op per frame (ragged shards, 40 B/vertex)"}
+            return rec, ok, (r_g, w_g, g_g)
+
         if args.scaling == "strong":
-            repeats, walls, gpus = (r_g, w_g, g_g) if args.allgather else (r_c, w_c, g_c)
+            repeats, walls, gpus = r_c, w_c, g_c
 
     if rank == 0:
         region = float(np.median(walls))
@@ -705,7 +728,44 @@ def main():
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mesh, pal, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
+
+    # ---- the exchange, last: RCCL with more than one rank has never run before the driver's multi-GPU job, so a hang in it
+    # must not cost the line -- after EXCHANGE_TIMEOUT_S rank 0 prints what it has and every rank leaves ----------------------
+    if strong is not None and have_comm and (world > 1 or force_exchange):
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["extra"]["strong_scaling"]["with_allgather"] = {"value": None, "note": f"the exchange did not finish within {EXCHANGE_TIMEOUT_S} s"}
+                emit(json.dumps(out))
+            os._exit(0)
+
+        watchdog = threading.Timer(EXCHANGE_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            rec, ok, regions = exchange_leg()
+            err = None
+        except Exception as e:     # noqa: BLE001
+            rec, ok, regions, err = None, None, None, repr(e)
+        watchdog.cancel()
+        if rank == 0:
+            st = out["extra"]["strong_scaling"]
+            if rec is not None:
+                st["with_allgather"], st["gathered_equals_oracle"] = rec, ok
+                if ok is False:
+                    st["with_allgather"]["note"] = "THE GATHERED BUFFER DIFFERS FROM THE ORACLE"
+                if args.scaling == "strong" and args.allgather:
+                    r_g, w_g, _ = regions
+                    out["value"] = float(args.verts) * args.steps * r_g / float(np.median(w_g))
+                    out["ms_per_step"] = float(np.median(w_g)) * 1e3 / (args.steps * r_g)
+                    out["timed_steps"], out["repeats"], out["region_ms"] = args.steps * r_g, r_g, [w * 1e3 for w in w_g]
+            else:
+                st["with_allgather"] = {"value": None, "note": f"the exchange failed: {err}"}
+    if rank == 0:
+        emit(json.dumps(out))
 
     barrier()
     ctx.close()
