@@ -131,9 +131,16 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
             aux[k] = make_float4(key_value[k], kb, cubic && key_left_tangent ? key_left_tangent[k] : 0.f,
                                  cubic && key_right_tangent ? key_right_tangent[k] : 0.f);
         }
+        std::vector<KeyRec> recs(n_keys);
+        for (uint32_t k = 0; k < n_keys; ++k) {
+            recs[k].aux = aux[k];
+            recs[k].loc = key_location[k];
+            recs[k].pad[0] = recs[k].pad[1] = recs[k].pad[2] = 0.f;
+        }
         int rc = upload(c, &td.d_tracks, hd.data(), hd.size());
         if (!rc) rc = upload(c, &td.d_loc, key_location, (size_t)n_keys);
         if (!rc) rc = upload(c, &td.d_aux, aux.data(), aux.size());
+        if (!rc) rc = upload(c, &td.d_rec, recs.data(), recs.size());
         if (rc) { free_tracks(td); return rc; }
     }
     auto& m = store(c).tracks;

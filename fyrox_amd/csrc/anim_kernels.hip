@@ -190,6 +190,22 @@ __device__ __forceinline__ f4 group_rotation(float v, int has_r, int rkind, int 
     return q;
 }
 
+// Key records as the `loc[i]` / `aux[i]` the curve functions index (pose_sample: one line per span instead of two).
+#ifndef FYX_KEYREC
+#define FYX_KEYREC 1
+#endif
+struct RecLoc {
+    const KeyRec* p;
+    __device__ __forceinline__ float operator[](uint32_t i) const { return p[i].loc; }
+};
+struct RecAux {
+    const KeyRec* p;
+    __device__ __forceinline__ f4 operator[](uint32_t i) const {
+        const float4 a = p[i].aux;
+        return f4{a.x, a.y, a.z, a.w};
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // pose_sample: sixteen lanes per (animation, instance, node), ONE LANE PER CURVE.  A curve sample is
 // a chain of dependent loads (hint -> key locations -> key values), so a thread that walked the ten
@@ -237,8 +253,12 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
                 uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
                 uint32_t hint = *hp;
                 const uint32_t fk = tk->first_key[c];
+#if FYX_KEYREC
+                v = curve_value_at(RecLoc{an.key_rec + fk}, RecAux{an.key_rec + fk}, tk->n_keys[c], curve_ends(tk, (int)c), time, hint);
+#else
                 v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c],
                                    curve_ends(tk, (int)c), time, hint);
+#endif
                 *hp = hint;
             }
         }

@@ -12,6 +12,7 @@ struct TracksData {
     TrackDev* d_tracks = nullptr;
     float* d_loc = nullptr;
     float4* d_aux = nullptr;
+    KeyRec* d_rec = nullptr;
 };
 
 struct Rig {
