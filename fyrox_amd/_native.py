@@ -92,6 +92,7 @@ _SIGS = {
     "fyx_mesh_set_blend_shapes": (c_int, [_P, c_uint64, c_uint32, _P, c_uint32]),
     "fyx_lbs_skin_ex": (c_int, [_P, c_uint64, _P]),
     "fyx_skinned_aabb": (c_int, [_P, c_uint64, _P, c_uint32, _P]),
+    "fyx_skinned_aabb_device": (c_int, [_P, c_uint64, _P, c_uint32, c_uint32, _P]),
     "fyx_calib_stream_copy": (c_int, [_P, _P, _P, c_uint32]),
     "fyx_palette": (c_int, [_P, _P, _P, c_uint32, _P]),
     "fyx_palette_device": (c_int, [_P, _P, _P, c_uint32, _P]),

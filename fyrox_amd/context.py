@@ -286,6 +286,10 @@ class Context:
         self._check(self._l.fyx_skinned_aabb(self._h, mesh_id, _ptr(palette), palette.shape[0], _ptr(box)))
         return box
 
+    def skinned_aabb_device(self, mesh_id: int, d_palette: int, n_bones: int, n_instances: int, d_out_aabb: int) -> None:
+        """Per-instance boxes of an instanced mesh, device to device (asynchronous)."""
+        self._check(self._l.fyx_skinned_aabb_device(self._h, mesh_id, d_palette, n_bones, n_instances, d_out_aabb))
+
     def calib_stream_copy(self, d_src: int, d_dst: int, units: int) -> None:
         self._check(self._l.fyx_calib_stream_copy(self._h, d_src, d_dst, units))
 

@@ -1048,6 +1048,29 @@ int fyx_skinned_aabb(fyx_ctx* c, uint64_t mesh_id, const float* palette, uint32_
     FYX_GUARD_END(c)
 }
 
+int fyx_skinned_aabb_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, uint32_t n_bones, uint32_t n_instances,
+                            float* d_out_aabb) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (!d_out_aabb) return fail(c, FYX_ERR_INVALID_ARG, "d_out_aabb is null");
+    const Mesh* m = find_mesh(c, mesh_id);
+    int rc = check_skin_args(c, m, mesh_id, d_palette, n_bones, n_instances);
+    if (rc) return rc;
+    if (n_instances > 65535u) return fail(c, FYX_ERR_UNSUPPORTED, "at most 65535 instances per call");
+    if (int jr = enter_primary(c)) return jr;
+    const uint32_t slices = fyx::aabb_inst_slices(m->n_verts, n_instances);
+    float* d_partials = nullptr;
+    if (slices > 1) {
+        rc = ensure_scratch(c, (size_t)slices * n_instances * 24);
+        if (rc) return rc;
+        d_partials = static_cast<float*>(c->scratch);
+    }
+    const fyx::LbsArgs a = make_args(*m, d_palette, n_bones, n_instances, nullptr, nullptr, nullptr);
+    FYX_HIP(c, fyx::launch_skinned_aabb_inst(a, d_partials, d_out_aabb, c->stream));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
 // ---- calibration --------------------------------------------------------------------------
 
 int fyx_calib_stream_copy(fyx_ctx* c, const float* d_src, float* d_dst, uint32_t units) {

@@ -147,6 +147,10 @@ hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32
 // skinned-position AABB. d_partials: scratch of 6 * n_blocks floats (n_blocks returned by
 // aabb_partial_blocks()).  Result in d_out[6] = {min xyz, max xyz}.
 uint32_t aabb_partial_blocks(uint32_t n_verts);
+// Per-instance boxes of an instanced mesh (a.palette = n_instances palettes): d_out[n_instances][6]; d_partials holds
+// aabb_inst_slices() * n_instances * 6 floats when there is more than one slice.
+uint32_t aabb_inst_slices(uint32_t n_verts, uint32_t n_instances);
+hipError_t launch_skinned_aabb_inst(const LbsArgs& a, float* d_partials, float* d_out, hipStream_t s);
 hipError_t launch_skinned_aabb(const LbsArgs& a, float* d_partials, float* d_out,
                                hipStream_t stream);
 // min/max over an already skinned packed xyz stream of n points.

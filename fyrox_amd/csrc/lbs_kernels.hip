@@ -1805,6 +1805,71 @@ __global__ __launch_bounds__(kAabbBlock) void aabb_final_kernel(const float* par
     block_minmax_store(mn, mx, out);
 }
 
+// Instanced form: the box of EVERY instance of a crowd in one launch (palettes and boxes stay on the device).  Block
+// (x, y) skins slice x of instance y's vertices with instance y's palette; with one slice per instance the block writes
+// the instance's box itself, otherwise a second launch folds the slices.
+__global__ __launch_bounds__(kAabbBlock) void skinned_aabb_inst_kernel(LbsArgs a, float* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* rows = reinterpret_cast<f32x4*>(smem);
+    f32x4* row3 = rows + 3 * a.n_bones;
+    const uint32_t inst = blockIdx.y;
+    const bool pj = stage_palette(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, rows, row3, threadIdx.x, kAabbBlock);
+    const bool projective = __syncthreads_or(pj) != 0;
+    float mn[3] = {__FLT_MAX__, __FLT_MAX__, __FLT_MAX__};
+    float mx[3] = {-__FLT_MAX__, -__FLT_MAX__, -__FLT_MAX__};
+    for (uint32_t v = blockIdx.x * kAabbBlock + threadIdx.x; v < a.n_verts; v += gridDim.x * kAabbBlock) {
+        float px, py, pz;
+        ld3<false>(a.pos + (size_t)v * 3, px, py, pz);
+        const f32x4 w = reinterpret_cast<const f32x4*>(a.wgt)[v];
+        const Skinned o = skin_vertex<true, 1>(rows, row3, projective, a.idx[v], w, px, py, pz, 0, 0, 0, 0, 0, 0);
+        if (o.px < mn[0]) mn[0] = o.px;
+        if (o.py < mn[1]) mn[1] = o.py;
+        if (o.pz < mn[2]) mn[2] = o.pz;
+        if (o.px > mx[0]) mx[0] = o.px;
+        if (o.py > mx[1]) mx[1] = o.py;
+        if (o.pz > mx[2]) mx[2] = o.pz;
+    }
+    block_minmax_store(mn, mx, out + ((size_t)inst * gridDim.x + blockIdx.x) * 6);
+}
+
+__global__ __launch_bounds__(64) void aabb_final_inst_kernel(const float* partials, uint32_t slices, float* out) {
+    const uint32_t inst = blockIdx.x;
+    float mn[3] = {__FLT_MAX__, __FLT_MAX__, __FLT_MAX__};
+    float mx[3] = {-__FLT_MAX__, -__FLT_MAX__, -__FLT_MAX__};
+    for (uint32_t b = threadIdx.x; b < slices; b += 64)
+        for (int i = 0; i < 3; ++i) {
+            mn[i] = fminf(mn[i], partials[((size_t)inst * slices + b) * 6 + i]);
+            mx[i] = fmaxf(mx[i], partials[((size_t)inst * slices + b) * 6 + 3 + i]);
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[i] = fminf(mn[i], __shfl_xor(mn[i], o, 64));
+            mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o, 64));
+        }
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 3; ++i) { out[(size_t)inst * 6 + i] = mn[i]; out[(size_t)inst * 6 + 3 + i] = mx[i]; }
+}
+
+uint32_t aabb_inst_slices(uint32_t n_verts, uint32_t n_instances) {
+    // enough blocks to fill the chip when the instances alone do not, at most 64 slices per instance
+    uint32_t want = (uint32_t)((4ull * kCUs + n_instances - 1) / n_instances);
+    const uint32_t cap = (n_verts + kAabbBlock - 1) / kAabbBlock;
+    if (want > cap) want = cap;
+    if (want > 64) want = 64;
+    return want ? want : 1;
+}
+
+hipError_t launch_skinned_aabb_inst(const LbsArgs& a, float* d_partials, float* d_out, hipStream_t s) {
+    if (a.n_instances == 0) return hipSuccess;
+    if (a.n_instances > 65535u) return hipErrorInvalidValue;
+    const uint32_t slices = aabb_inst_slices(a.n_verts, a.n_instances);
+    hipLaunchKernelGGL(skinned_aabb_inst_kernel, dim3(slices, a.n_instances), dim3(kAabbBlock), (size_t)a.n_bones * 64, s, a,
+                       slices == 1 ? d_out : d_partials);
+    if (slices > 1) hipLaunchKernelGGL(aabb_final_inst_kernel, dim3(a.n_instances), dim3(64), 0, s, d_partials, slices, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_skinned_aabb(const LbsArgs& a, float* d_partials, float* d_out, hipStream_t s) {
     const uint32_t grid = aabb_partial_blocks(a.n_verts);
     hipLaunchKernelGGL(skinned_aabb_kernel, dim3(grid), dim3(kAabbBlock), (size_t)a.n_bones * 64, s, a,

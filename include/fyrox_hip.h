@@ -231,6 +231,14 @@ int fyx_lbs_skin_streams(fyx_ctx* ctx, uint32_t n_verts, const float* d_pos, con
  * Replaces the body of Mesh::accurate_world_bounding_box, scene/mesh/mod.rs:470-526. */
 int fyx_skinned_aabb(fyx_ctx* ctx, uint64_t mesh_id, const float* palette, uint32_t n_bones,
                      float out_aabb[6]);
+/* The same box for EVERY instance of an instanced mesh, device to device: d_palette holds n_instances palettes
+ * (n_bones column-major mat4 each, e.g. written by fyx_animator_set_palette_output), d_out_aabb receives
+ * n_instances x {min xyz, max xyz}.  One launch (two when an instance's vertices are cut in slices) on the context
+ * stream, asynchronous, nothing visits the host: what a culling pass over a crowd needs of
+ * Mesh::accurate_world_bounding_box (scene/mesh/mod.rs:470-526), which the reference would call once per instance.
+ * An empty mesh gives the reference's default box (+MAX, -MAX) (fyrox-math/src/aabb.rs:33-40).  At most 65535 instances. */
+int fyx_skinned_aabb_device(fyx_ctx* ctx, uint64_t mesh_id, const float* d_palette, uint32_t n_bones,
+                            uint32_t n_instances, float* d_out_aabb);
 
 /* ---- calibration ---------------------------------------------------------------------- */
 

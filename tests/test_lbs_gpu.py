@@ -1153,3 +1153,50 @@ def test_per_launch_timing_reports_every_launch_once(ctx):
     ctx.sync()
     assert np.array_equal(out.download(np.uint32, mesh.n_verts * 3), ref)
     out.free(); d_pal.free(); ctx.mesh_free(9100)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_verts,n_bones,n_inst", [(5003, 64, 37), (300_017, 32, 2), (64, 4, 1), (10_000, 64, 1000)])
+def test_instanced_aabb_on_the_device_matches_the_cpu_loop_per_instance(ctx, orc, n_verts, n_bones, n_inst):
+    """fyx_skinned_aabb_device: Mesh::accurate_world_bounding_box (scene/mesh/mod.rs:470-526) of every instance of an
+    instanced mesh in one call, palettes and boxes on the device: min / max of the oracle's skinned positions, bit for bit
+    (single-slice and multi-slice launches, a crowd of C3's size on sampled instances)."""
+    mesh = synth.make_mesh(n_verts, n_bones, synth.SEED_BASE + 91)
+    pal = synth.make_palette(n_bones, synth.SEED_BASE + 91, n_instances=n_inst)
+    ctx.mesh_upload_soa(9200, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    d_pal = ctx.to_device(pal)
+    d_box = ctx.malloc(n_inst * 24)
+    d_box.upload(np.full(n_inst * 6, 123.0, np.float32))
+    ctx.skinned_aabb_device(9200, d_pal.ptr, n_bones, n_inst, d_box.ptr)
+    ctx.sync()
+    got = d_box.download(np.float32, n_inst * 6).reshape(n_inst, 6)
+    pal = pal.reshape(n_inst, n_bones, 16)
+    for i in sorted({0, min(1, n_inst - 1), n_inst // 2, n_inst - 1}):
+        ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal[i], threads=0)["pos"]
+        box = np.concatenate([ref.min(0), ref.max(0)])
+        assert np.array_equal(got[i].view(np.uint32), box.view(np.uint32)), f"instance {i}"
+    if n_inst == 1:   # and the host-pointer single-instance entry point gives the same box
+        assert np.array_equal(ctx.skinned_aabb(9200, pal[0]), got[0])
+    d_pal.free(); d_box.free(); ctx.mesh_free(9200)
+
+
+@pytest.mark.gpu
+def test_instanced_aabb_argument_errors_and_empty_mesh(ctx):
+    mesh = synth.make_mesh(100, 8, synth.SEED_BASE + 92)
+    ctx.mesh_upload_soa(9201, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    d_pal = ctx.to_device(synth.make_palette(8, synth.SEED_BASE + 92, n_instances=3))
+    d_box = ctx.malloc(3 * 24)
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx.skinned_aabb_device(9201, d_pal.ptr, 8, 3, 0)             # no output
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx.skinned_aabb_device(9201, d_pal.ptr, 4, 3, d_box.ptr)     # the mesh references bone 7
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx.skinned_aabb_device(424242, d_pal.ptr, 8, 3, d_box.ptr)   # unknown mesh
+    ctx.mesh_upload_soa(9202, np.zeros((0, 3), np.float32), np.zeros((0, 4), np.float32), np.zeros((0, 4), np.uint8),
+                        np.zeros((0, 3), np.float32), np.zeros((0, 4), np.float32))
+    ctx.skinned_aabb_device(9202, d_pal.ptr, 8, 3, d_box.ptr)
+    ctx.sync()
+    got = d_box.download(np.float32, 18).reshape(3, 6)
+    fmax = np.finfo(np.float32).max
+    assert np.array_equal(got, np.tile(np.asarray([fmax] * 3 + [-fmax] * 3, np.float32), (3, 1)))   # AxisAlignedBoundingBox::default()
+    d_pal.free(); d_box.free(); ctx.mesh_free(9201); ctx.mesh_free(9202)
