@@ -89,13 +89,18 @@ def frame(skin=True, pose=True, batched=True):
 
 
 def timed(**kw):
-    ctx.sync()
-    t0 = time.perf_counter()
-    ctx.timer_begin()
-    for _ in range(args.frames):
-        frame(**kw)
-    gpu = ctx.timer_end()
-    return gpu / args.frames, (time.perf_counter() - t0) * 1e3 / args.frames
+    """Median of three passes of `frames` frames (a single 10 - 15 ms pass right after set-up is not always at speed)."""
+    res = []
+    for _ in range(3):
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.timer_begin()
+        for _ in range(args.frames):
+            frame(**kw)
+        gpu = ctx.timer_end()
+        res.append((gpu / args.frames, (time.perf_counter() - t0) * 1e3 / args.frames))
+    res.sort(key=lambda r: r[1])
+    return res[1]
 
 
 for _ in range(args.warmup):
