@@ -793,7 +793,15 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
 
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in blockIdx order, and all `tiles`
+    // workgroups of an instance run read the same palettes: ranked by (XCD, order within the XCD) instead of by blockIdx,
+    // consecutive ranks -- hence the workgroups of one instance run -- sit on ONE XCD, and a palette comes out of HBM
+    // once instead of once per XCD (PMC: 33 MB fetched per C3 launch for 4.7 MB of mesh and palettes).  Any permutation
+    // of the workgroups computes the same thing; only the placement is a guess about the hardware.
+    const uint32_t G = gridDim.x, x = blockIdx.x & 7u;
+    uint32_t rank = blockIdx.x >> 3;
+    for (uint32_t q = 0; q < x; ++q) rank += (G - q + 7u) >> 3;     // workgroups on the XCDs before this one
+    const uint32_t tile = rank % tiles, chunk = rank / tiles;
     const uint32_t i0 = chunk * ipb;
     const uint32_t i1 = (i0 + ipb < a.n_instances) ? i0 + ipb : a.n_instances;
     if (i0 >= i1) return;
