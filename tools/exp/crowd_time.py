@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import fyrox_amd
 from fyrox_amd import synth
-inst, verts, bones = 1000, 10_000, 64
+inst, verts, bones = 1000, int(os.environ.get("VERTS", "10000")), 64
 ctx = fyrox_amd.Context(0)
 ctx.set_option("lbs.streams", 1)
 seed = synth.SEED_BASE + 3
