@@ -200,6 +200,7 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     # launch streams, two palette buffers) -- nothing else changes, the same kernels compute the same values
     ctx.set_option("anim.overlap", 1)
     ctx.set_option("lbs.streams", 2)
+    ctx.set_option("lbs.crowd_lean", 1)      # the crowd kernel leaves register room for the pose kernels it runs beside
     pals = (d_pal, d_pal2)
 
     def frame_pipelined(k):
@@ -217,6 +218,7 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     frame_ms = ctx.timer_end() / frames
     ctx.set_option("anim.overlap", 0)
     ctx.set_option("lbs.streams", 1)
+    ctx.set_option("lbs.crowd_lean", 0)
     p.set_palette_output(base + 50, d_pal.ptr)
     ctx.sync()
     ctx.timer_begin()

@@ -595,6 +595,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd")) return &c->lbs.crowd;
     if (!strcmp(key, "lbs.crowd_block")) return &c->lbs.crowd_block;
     if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
+    if (!strcmp(key, "lbs.crowd_lean")) return &c->lbs.crowd_lean;
     if (!strcmp(key, "lbs.probe")) return &c->lbs.probe;
     if (!strcmp(key, "lbs.timing")) return &c->timing;
     if (!strcmp(key, "lbs.split")) return &c->lbs.split;

@@ -17,6 +17,7 @@ struct LbsTuning {
     int nt = 1;              // non-temporal streaming loads/stores
     int crowd = -1;          // instanced launches: -1 auto (crowd kernel from 4 instances), 0 never, 1 always
     int crowd_block = 512;   // crowd kernel workgroup = vertex tile: 256 | 512
+    int crowd_lean = 0;      // 1: register-lean crowd kernel at two workgroups per CU (leaves room for other kernels' waves, see lbs_kernels.hip)
     int crowd_ipb = 0;       // instances per workgroup run; 0 = auto
     int split = 0;           // 1: equal contiguous vertex shares per wave instead of whole 64-vertex units round-robin
     int probe = 0;           // debug: per-wave timeline of the default lbs_skin variant into probe_buf

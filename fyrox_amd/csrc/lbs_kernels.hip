@@ -161,7 +161,9 @@ struct Skinned {
 };
 
 // One vertex, four influences.  MASK bit0 position, bit1 normal, bit2 tangent.
-template <bool EXACT, int MASK, bool PROJ>
+// SEQ: the four influences one after another (three LDS rows live at a time instead of twelve: ~74 instead of ~112 VGPRs in
+// the crowd kernel) -- the same operations in the same order per output component, so the same bits.
+template <bool EXACT, int MASK, bool PROJ, bool SEQ = false>
 __device__ __forceinline__ Skinned skin_vertex_impl(const f32x4* __restrict__ rows,
                                                const f32x4* __restrict__ row3,
                                                uint32_t id, f32x4 w, float px, float py, float pz,
@@ -170,10 +172,10 @@ __device__ __forceinline__ Skinned skin_vertex_impl(const f32x4* __restrict__ ro
     f32x2 o_pxy = {0.f, 0.f}, o_x = {0.f, 0.f}, o_y = {0.f, 0.f}, o_z = {0.f, 0.f};  // o_r = (n_r, t_r)
     float o_pz = 0.f;
     const f32x2 vx = {nx, tx}, vy = {ny, ty}, vz = {nz, tz};
-#pragma unroll
+#pragma unroll(SEQ ? 1 : 4)
     for (int k = 0; k < 4; ++k) {
         const uint32_t b = (id >> (8 * k)) & 0xffu;
-        const float wk = w[k];
+        const float wk = k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w;
         const f32x4 A = rows[b * 3 + 0];
         const f32x4 B = rows[b * 3 + 1];
         const f32x4 C = rows[b * 3 + 2];
@@ -261,15 +263,15 @@ __device__ __forceinline__ Skinned skin_vertex_blended(const f32x4* __restrict__
 
 // `projective` is workgroup-uniform: the affine path (the only kind of palette Fyrox produces)
 // is one straight-line block of packed math; the homogeneous divide lives in its own copy.
-template <bool EXACT, int MASK, bool BLEND_FIRST = false>
+template <bool EXACT, int MASK, bool BLEND_FIRST = false, bool SEQ = false>
 __device__ __forceinline__ Skinned skin_vertex(const f32x4* __restrict__ rows,
                                                const f32x4* __restrict__ row3, bool projective,
                                                uint32_t id, f32x4 w, float px, float py, float pz,
                                                float nx, float ny, float nz, float tx, float ty,
                                                float tz) {
-    if (projective) return skin_vertex_impl<EXACT, MASK, true>(rows, row3, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
+    if (projective) return skin_vertex_impl<EXACT, MASK, true, SEQ>(rows, row3, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
     if constexpr (!EXACT && BLEND_FIRST) return skin_vertex_blended<MASK>(rows, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
-    return skin_vertex_impl<EXACT, MASK, false>(rows, row3, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
+    return skin_vertex_impl<EXACT, MASK, false, SEQ>(rows, row3, id, w, px, py, pz, nx, ny, nz, tx, ty, tz);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -784,7 +786,11 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
 // outputs as per-instance buffer resources so that no wave ever waits for a store (exact vmcnt counts), `sc1` or `nt`
 // stores -- 79 - 83 us exact (sc1: 84 - 95), 66 - 68 us fused: no better, the exact mode's floor is its arithmetic.
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, int MASK>
+// LEAN (option lbs.crowd_lean): the arithmetic walks the influences one by one (SEQ above: ~74 VGPRs) and the launch asks
+// for enough LDS that only two workgroups share a CU -- four waves per SIMD holding ~320 of its 512 VGPRs, which leaves
+// room for the waves of OTHER kernels: what lets the next frame's pose kernels run under this frame's skinning
+// (anim.overlap) instead of trickling in as the skinning drains.
+template <int BLOCK, bool EXACT, int MASK, bool LEAN = false>
 __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tiles, uint32_t ipb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t buf_f4 = 4 * a.n_bones;  // rows (3 per bone) + row3 (1 per bone)
@@ -830,8 +836,8 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
         const u32x4 fl = *reinterpret_cast<const u32x4*>(flags + cur * 4);
         const bool projective = (fl.x | fl.y | fl.z | fl.w) != 0;
         // the crowd kernel is VALU-bound, so its fused mode blends the matrices first (see skin_vertex_blended)
-        const Skinned o = skin_vertex<EXACT, MASK, true>(rows, row3, projective, vin.id, vin.w, vin.p.x, vin.p.y,
-                                                         vin.p.z, vin.n.x, vin.n.y, vin.n.z, vin.t.x, vin.t.y, vin.t.z);
+        const Skinned o = skin_vertex<EXACT, MASK, true, LEAN>(rows, row3, projective, vin.id, vin.w, vin.p.x, vin.p.y,
+                                                               vin.p.z, vin.n.x, vin.n.y, vin.n.z, vin.t.x, vin.t.y, vin.t.z);
         if (live) {
             const size_t ov = (size_t)inst * a.n_verts + v;
             if constexpr (MASK & 1) st3<true>(a.out_pos + ov * 3, o.px, o.py, o.pz);
@@ -868,6 +874,13 @@ static hipError_t launch_crowd_one(const LbsArgs& a, const LbsTuning& t, hipStre
     const uint64_t grid = (uint64_t)tiles * chunks;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = (size_t)a.n_bones * 64 * 2 + 2 * (BLOCK / 64) * sizeof(uint32_t);
+    if constexpr (BLOCK == 512 && EXACT) {
+        if (t.crowd_lean) {   // two workgroups per CU: more than a third of the CU's 160 KB of LDS each
+            const size_t lean_lds = std::max<size_t>(lds, 56 * 1024);
+            FYX_LAUNCH(t, (lbs_skin_crowd<BLOCK, EXACT, MASK, true>), dim3((uint32_t)grid), dim3(BLOCK), (uint32_t)lean_lds, s, a, tiles, ipb);
+            return hipGetLastError();
+        }
+    }
     FYX_LAUNCH(t, (lbs_skin_crowd<BLOCK, EXACT, MASK>), dim3((uint32_t)grid), dim3(BLOCK), (uint32_t)lds, s, a, tiles, ipb);
     return hipGetLastError();
 }

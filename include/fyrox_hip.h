@@ -76,6 +76,8 @@ int fyx_join(fyx_ctx* ctx);
  * "lbs.crowd" (instanced launches: -1 = crowd kernel from 4 instances on, 0 never, 1 always; the
  * crowd kernel keeps a tile of vertices in registers and loops over instances), "lbs.crowd_block"
  * (256 | 512 vertices per tile), "lbs.crowd_ipb" (instances per workgroup, 0 = auto),
+ * "lbs.crowd_lean" (1 = the crowd kernel in its register-lean form at two workgroups per CU: ~6 % slower alone, but it
+ * leaves register room for the next frame's pose kernels to run beside it -- use with "anim.overlap"),
  * "lbs.prefetch" (0 | 1 | 2 units of loads ahead), "lbs.split" (how a launch's 64-vertex units are
  * dealt to the waves: 0 contiguous range per workgroup, units round-robin inside it; 1 equal
  * contiguous vertex shares per wave; 2 units interleaved over all waves), "lbs.probe" (debug

@@ -1200,3 +1200,42 @@ def test_instanced_aabb_argument_errors_and_empty_mesh(ctx):
     fmax = np.finfo(np.float32).max
     assert np.array_equal(got, np.tile(np.asarray([fmax] * 3 + [-fmax] * 3, np.float32), (3, 1)))   # AxisAlignedBoundingBox::default()
     d_pal.free(); d_box.free(); ctx.mesh_free(9201); ctx.mesh_free(9202)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_verts,n_bones,n_inst,projective", [(10_000, 64, 200, False), (4097, 256, 9, False), (1500, 32, 17, True)])
+def test_lean_crowd_kernel_is_bit_identical(ctx, orc, n_verts, n_bones, n_inst, projective):
+    """Option lbs.crowd_lean: the crowd kernel with the influences walked one by one (fewer registers) at two workgroups per
+    CU -- the form that leaves room for the pose kernels of the next frame (anim.overlap).  Same operations in the same order:
+    every byte equals the default crowd kernel's output, and the oracle's on sampled instances."""
+    mesh = synth.make_mesh(n_verts, n_bones, synth.SEED_BASE + 95)
+    pal = synth.make_palette(n_bones, synth.SEED_BASE + 95, n_instances=n_inst).reshape(n_inst, n_bones, 16).copy()
+    if projective:
+        pal[n_inst // 2, 3, 3] = 0.25      # one non-affine matrix: that instance takes the projective path
+        pal[n_inst // 2, 3, 7] = -0.5
+    ctx.mesh_upload_soa(9300, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    d_pal = ctx.to_device(pal.reshape(-1, 16))
+    nv = n_verts * n_inst
+    outs = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+    res = []
+    try:
+        for lean in (0, 1):
+            ctx.set_option("lbs.crowd_lean", lean)
+            ctx.set_option("lbs.crowd", 1)
+            for b in outs:
+                b.upload(np.zeros(16, np.uint32))
+            ctx.lbs_skin_device(9300, d_pal.ptr, n_bones, n_inst, outs[0].ptr, outs[1].ptr, outs[2].ptr)
+            ctx.join(); ctx.sync()
+            res.append([b.download(np.uint32, nv * w) for b, w in zip(outs, (3, 3, 4))])
+    finally:
+        ctx.set_option("lbs.crowd_lean", 0)
+        ctx.set_option("lbs.crowd", -1)
+    for k in range(3):
+        assert np.array_equal(res[0][k], res[1][k]), f"stream {k}: lean != default"
+    for i in sorted({0, n_inst // 2, n_inst - 1}):
+        ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal[i], mesh.normal, mesh.tangent, threads=0)
+        got = res[1][0].view(np.float32).reshape(n_inst, n_verts, 3)[i]
+        assert np.array_equal(got.view(np.uint32), ref["pos"].view(np.uint32)), f"instance {i} vs oracle"
+    for b in outs:
+        b.free()
+    d_pal.free(); ctx.mesh_free(9300)

@@ -9,6 +9,8 @@ from fyrox_amd import synth
 inst, verts, bones = 1000, int(os.environ.get("VERTS", "10000")), 64
 ctx = fyrox_amd.Context(0)
 ctx.set_option("lbs.streams", 1)
+for kv in os.environ.get("OPTS", "").split():
+    k, v = kv.split("="); ctx.set_option(k, int(v))
 seed = synth.SEED_BASE + 3
 mesh = synth.make_mesh(verts, bones, seed)
 pal = synth.make_palette(bones, seed, n_instances=inst)
