@@ -870,6 +870,9 @@ int fyx_debug_kernel_time(fyx_ctx* c, double* total_us, uint32_t* n_launches) {
     *total_us = sum;
     *n_launches = (uint32_t)(c->timing_used / 2);
     c->timing_used = 0;
+    // the events go back to the runtime (a measurement leg may have made thousands)
+    for (hipEvent_t e : c->timing_ev) (void)hipEventDestroy(e);
+    c->timing_ev.clear();
     return FYX_OK;
     FYX_GUARD_END(c)
 }
