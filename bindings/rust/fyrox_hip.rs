@@ -101,6 +101,29 @@ impl HipSkinning {
         Ok(b)
     }
 
+    /// The same box for EVERY instance of an instanced surface, device to device (`d_palettes`: `n_instances` palettes
+    /// of `n_bones` matrices, e.g. what `HipAnimator::set_palette_output` registered; `d_out_boxes`: `n_instances` x
+    /// `{min xyz, max xyz}`): what a culling pass over a crowd needs of `Mesh::accurate_world_bounding_box`
+    /// (`scene/mesh/mod.rs:470-526`) without one call and one host round trip per instance.  Asynchronous.
+    pub fn skinned_aabbs_device(
+        &mut self,
+        key: u64,
+        d_palettes: *const f32,
+        n_bones: u32,
+        n_instances: u32,
+        d_out_boxes: *mut f32,
+    ) -> Result<(), HipError> {
+        self.check(unsafe { fyx_skinned_aabb_device(self.ctx, key, d_palettes, n_bones, n_instances, d_out_boxes) })
+    }
+
+    /// Pipelined frames: let frame n+1's pose kernels run beside frame n's skinning.  The caller then alternates two
+    /// palette buffers per animator ("Pipelined frames"); `lean_crowd` selects the crowd kernel's
+    /// register-lean form, which leaves the pose kernels room on the chip.
+    pub fn set_pipelined(&mut self, on: bool, lean_crowd: bool) -> Result<(), HipError> {
+        self.check(unsafe { fyx_set_option(self.ctx, b"anim.overlap\0".as_ptr() as *const _, on as i32) })?;
+        self.check(unsafe { fyx_set_option(self.ctx, b"lbs.crowd_lean\0".as_ptr() as *const _, (on && lean_crowd) as i32) })
+    }
+
     /// Additive API next to `SurfaceData` (`scene/mesh/surface.rs:265`): skin every vertex into host vectors.
     pub fn skin_into(&mut self, key: u64, palette: &[Matrix4<f32>], out: &mut SkinnedVertices) -> Result<(), HipError> {
         let n = out.positions.len();
