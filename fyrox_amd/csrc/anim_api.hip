@@ -448,7 +448,7 @@ int fyx_animation_get_state(fyx_ctx* c, uint64_t animator_id, uint32_t animation
                             float* time_position, int* enabled, int* ended) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
     return for_instances(c, A, animation, instance, [&](AnimState& s) {
         if (time_position) *time_position = s.time;
@@ -744,7 +744,7 @@ int fyx_layer_get_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32
                         int32_t* active_transition) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     FYX_LAYER(c, A, L, layer);
     if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
     int32_t as = L->entry_state, at = -1;
@@ -761,7 +761,7 @@ int fyx_layer_get_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32
 // ---- per frame -----------------------------------------------------------------------------
 
 static int update_common(fyx_ctx* c, uint64_t animator_id, int mode, float dt) {
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context: no GPU to run the pose kernels on");
     if (mode == 1 && A->layers.empty()) return fail(c, FYX_ERR_INVALID_ARG, "animator %llu has no machine layers", (unsigned long long)animator_id);
     if (int rc = plan_frame(c, *A, mode, dt)) return rc;
@@ -835,7 +835,7 @@ int fyx_scene_plan(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animator
 int fyx_animator_update_transforms(fyx_ctx* c, uint64_t animator_id) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     return run_frame(c, *A, false);
     FYX_GUARD_END(c)
@@ -844,7 +844,7 @@ int fyx_animator_update_transforms(fyx_ctx* c, uint64_t animator_id) {
 int fyx_animator_palette(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, float* d_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     auto bit = store(c).bones.find(bones_id);
     if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
@@ -861,7 +861,7 @@ int fyx_animator_palette(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, fl
 int fyx_animator_set_palette_output(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, float* d_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     auto bit = store(c).bones.find(bones_id);
     if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
     if (bit->second.rig_id != A->rig_id) return fail(c, FYX_ERR_INVALID_ARG, "bone list belongs to another rig");
@@ -884,7 +884,7 @@ int fyx_animator_set_local_trs(fyx_ctx* c, uint64_t animator_id, uint32_t node, 
                                uint32_t n_instances, const float* trs) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     if (node >= A->rig->n_nodes) return fail(c, FYX_ERR_INVALID_ARG, "node %u out of range", node);
     if ((uint64_t)first_instance + n_instances > A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance range out of bounds");
@@ -925,7 +925,7 @@ static int locate(fyx_ctx* c, Animator* A, int what, void** ptr, size_t* bytes) 
 int fyx_animator_read(fyx_ctx* c, uint64_t animator_id, int what, float* host_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
     if (int rc = enter_primary(c)) return rc;
@@ -941,7 +941,7 @@ int fyx_animator_read(fyx_ctx* c, uint64_t animator_id, int what, float* host_ou
 int fyx_animator_device_ptr(fyx_ctx* c, uint64_t animator_id, int what, void** out) {
     if (!c || !out) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     if (int rc = enter_primary(c)) return rc;
     size_t bytes = 0;
@@ -953,7 +953,7 @@ int fyx_animator_plan(fyx_ctx* c, uint64_t animator_id, int mode, float dt, floa
                       uint32_t* program_offset, uint32_t* ops, uint32_t ops_capacity, uint32_t* n_ops) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (mode != 0 && mode != 1 && mode != -1) return fail(c, FYX_ERR_INVALID_ARG, "mode %d", mode);
     if (mode == 1 && A->layers.empty()) return fail(c, FYX_ERR_INVALID_ARG, "animator has no machine layers");
     if (mode >= 0) {
@@ -1000,7 +1000,7 @@ int fyx_animation_set_max_event_capacity(fyx_ctx* c, uint64_t animator_id, uint3
 int fyx_animation_pop_event(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, int32_t* out_signal) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
     if (!out_signal) return fail(c, FYX_ERR_INVALID_ARG, "out_signal is null");
     return for_instances(c, A, animation, instance, [&](AnimState& s) {
@@ -1013,7 +1013,7 @@ int fyx_animation_pop_event(fyx_ctx* c, uint64_t animator_id, uint32_t animation
 int fyx_animation_event_count(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance, uint32_t* out_count) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
     if (!out_count) return fail(c, FYX_ERR_INVALID_ARG, "out_count is null");
     return for_instances(c, A, animation, instance, [&](AnimState& s) { *out_count = (uint32_t)s.events.size(); });
@@ -1022,7 +1022,7 @@ int fyx_animation_event_count(fyx_ctx* c, uint64_t animator_id, uint32_t animati
 int fyx_animation_clear_events(fyx_ctx* c, uint64_t animator_id, uint32_t animation, uint32_t instance) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     return for_instances(c, A, animation, instance, [&](AnimState& s) { s.events.clear(); });
     FYX_GUARD_END(c)
 }
@@ -1066,7 +1066,7 @@ int fyx_animation_set_root_motion_settings(fyx_ctx* c, uint64_t animator_id, uin
 int fyx_animation_read_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t animation, fyx_root_motion* host_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     if (animation >= A->anims.size() || A->anims[animation].removed) return fail(c, FYX_ERR_INVALID_ARG, "animation %u does not exist", animation);
     if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
@@ -1087,7 +1087,7 @@ int fyx_animation_read_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t an
 int fyx_absm_read_root_motion(fyx_ctx* c, uint64_t animator_id, int32_t layer, fyx_root_motion* host_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
     if (!A->rm_enabled) return fail(c, FYX_ERR_INVALID_ARG, "root motion is not tracked on this animator");
@@ -1112,7 +1112,7 @@ int fyx_absm_read_root_motion(fyx_ctx* c, uint64_t animator_id, int32_t layer, f
 int fyx_layer_pop_event(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance, fyx_layer_event* out_event, int* out_has) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     FYX_LAYER(c, A, L, layer);
     (void)L;
     if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
@@ -1132,7 +1132,7 @@ int fyx_animator_plan_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t* pr
                                   uint32_t ops_capacity, uint32_t* n_ops, uint32_t* n_slots, float* slices) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!A->rm_enabled) return fail(c, FYX_ERR_INVALID_ARG, "root motion is not tracked on this animator");
     if (A->rm_prog_off.size() != (size_t)A->n_instances + 1) return fail(c, FYX_ERR_INVALID_ARG, "no frame has been planned yet");
     if (program_offset) memcpy(program_offset, A->rm_prog_off.data(), A->rm_prog_off.size() * 4);
@@ -1149,7 +1149,7 @@ int fyx_animator_plan_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t* pr
 int fyx_animator_property_count(fyx_ctx* c, uint64_t animator_id, uint32_t* out_count) {
     if (!c || !out_count) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     *out_count = (uint32_t)A->prop_slots.size();
     return FYX_OK;
     FYX_GUARD_END(c)
@@ -1158,7 +1158,7 @@ int fyx_animator_property_count(fyx_ctx* c, uint64_t animator_id, uint32_t* out_
 int fyx_animator_property_slot(fyx_ctx* c, uint64_t animator_id, int32_t node, int32_t property_id, int32_t* out_slot) {
     if (!c || !out_slot) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     const std::pair<int32_t, int32_t> key(node, property_id);
     const auto it = std::find(A->prop_slots.begin(), A->prop_slots.end(), key);
     *out_slot = it == A->prop_slots.end() ? -1 : (int32_t)(it - A->prop_slots.begin());
@@ -1169,7 +1169,7 @@ int fyx_animator_property_slot(fyx_ctx* c, uint64_t animator_id, int32_t node, i
 int fyx_animator_read_properties(fyx_ctx* c, uint64_t animator_id, int32_t animation, fyx_property_value* host_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     if (!host_out) return fail(c, FYX_ERR_INVALID_ARG, "host_out is null");
     if (animation >= (int32_t)A->anims.size() || (animation >= 0 && A->anims[animation].removed))
@@ -1190,7 +1190,7 @@ int fyx_animator_blend_shape_weights(fyx_ctx* c, uint64_t animator_id, uint32_t 
                                      const float* default_weights, float* d_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
     if (n_shapes == 0) return FYX_OK;
     if (n_shapes > FYX_MAX_BLEND_SHAPES) return fail(c, FYX_ERR_UNSUPPORTED, "%u blend shapes", n_shapes);
@@ -1303,7 +1303,7 @@ int fyx_layer_collect_active_animations_events(fyx_ctx* c, uint64_t animator_id,
                                                uint32_t* n_events, fyx_events_source* out_source) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    FYX_ANIMATOR_RO(c, A, animator_id);
     FYX_LAYER(c, A, L, layer);
     if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
     if (strategy < FYX_EVENTS_ALL || strategy > FYX_EVENTS_MIN_WEIGHT) return fail(c, FYX_ERR_INVALID_ARG, "strategy %d", strategy);

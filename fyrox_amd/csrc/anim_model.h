@@ -107,6 +107,7 @@ struct TransitionState { float elapsed = 0.f, blend_factor = 0.f; };
 struct ByIndexState { bool has_prev = false; uint32_t prev = 0; float blend_time = 0.f; };
 struct LayerState {
     int32_t active_state = -1, active_transition = -1;
+    int32_t memo_state = -2;             // active_state the instance's memoised fold program was planned in (see MachineState)
     std::vector<TransitionState> transitions;
     std::vector<ByIndexState> by_index;
     std::deque<fyx_layer_event> events;  // FixedEventQueue::new(2048), layer.rs:182
@@ -115,6 +116,12 @@ constexpr size_t kLayerEventLimit = 2048;
 struct MachineState {
     std::vector<Param> params;
     std::vector<LayerState> layers;
+    // Fold-program memo: the program planned last frame is this frame's too when nothing it depends on has changed --
+    // same active states, no transition active then or now and none firing now, no API call on the animator in between
+    // (Animator::edit_gen), no pose node with state of its own (BlendAnimationsByIndex).  Then planning the instance is
+    // its animations' ticks, the transition conditions and a copy of last frame's ops.
+    uint64_t memo_gen = 0;
+    bool memo_valid = false;
 };
 
 // A recipe: what a pose node's output pose was made of at one evaluation.
@@ -165,6 +172,11 @@ struct Animator {
     std::vector<uint8_t> ticked;
     std::vector<uint2> ops;
     std::vector<uint32_t> prog_off;
+    std::vector<uint2> prev_ops;            // last frame's programs (the memo's source)
+    std::vector<uint32_t> prev_prog_off;
+    int prev_mode = -2;                     // mode of the frame planned last
+    uint64_t edit_gen = 1;                  // bumped by every API call on the animator other than update / plan
+    bool memo_static_ok = false;            // no layer has a BlendAnimationsByIndex node, no root motion (set per frame)
     // root motion (only when rm_enabled): per-frame slices + program, persistent device state
     bool rm_enabled = false;
     std::vector<float2> slices;

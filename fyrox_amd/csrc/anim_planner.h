@@ -45,9 +45,15 @@ Animator* find_animator(fyx_ctx* c, uint64_t id) {
     return it == c->anim->animators.end() ? nullptr : it->second.get();
 }
 
-#define FYX_ANIMATOR(c, a, id)                                                                   \
+// Every entry point that names an animator may change what its fold programs depend on (parameters, structure, clocks,
+// removed clips ...): it invalidates the instances' memoised programs wholesale.  Only the per-frame calls (update, plan)
+// use the _RO form.
+#define FYX_ANIMATOR_RO(c, a, id)                                                                \
     Animator* a = find_animator((c), (id));                                                      \
     if (!a) return fail((c), FYX_ERR_UNKNOWN_ID, "animator %llu is not registered", (unsigned long long)(id))
+#define FYX_ANIMATOR(c, a, id)                                                                   \
+    FYX_ANIMATOR_RO(c, a, id);                                                                   \
+    ++a->edit_gen
 
 // ------------------------------------------------------------------------------------------
 // Animation scalars
@@ -162,6 +168,7 @@ struct Planner {
         S.rm_ops.push_back(op);
     }
     uint32_t cur_layer = 0;
+    bool unstable = false;   // this frame's program was planned inside a transition: not next frame's
     void layer_event(LayerState& LS, int32_t kind, int32_t a, int32_t b) {  // event.rs:79-83
         if (LS.events.size() < kLayerEventLimit) LS.events.push_back(fyx_layer_event{kind, a, b});
     }
@@ -463,6 +470,7 @@ struct Planner {
             };
 
             if (LS.active_transition >= 0) {
+                unstable = true;
                 const TransitionDef& tr = L.transitions[LS.active_transition];
                 TransitionState& ts = LS.transitions[LS.active_transition];
                 const int32_t src = root_recipe(tr.source), dst = root_recipe(tr.dest);
@@ -496,6 +504,35 @@ struct Planner {
         if (!L.excluded.empty()) emit(OP_MASK, li, 0.f);
     }
 
+    // The memo (MachineState): true when last frame's program of this instance was appended instead of planning a new one.
+    bool try_reuse() {
+        if (!A.memo_static_ok || !ms->memo_valid || ms->memo_gen != A.edit_gen) return false;
+        if (A.prev_prog_off.size() != (size_t)A.n_instances + 1) return false;
+        for (size_t li = 0; li < A.layers.size(); ++li) {
+            const LayerDef& L = A.layers[li];
+            const LayerState& LS = ms->layers[li];
+            if (LS.active_transition >= 0 || LS.active_state != LS.memo_state) return false;
+            if (LS.active_state < 0) continue;
+            for (const TransitionDef& tr : L.transitions) {     // would one fire? (layer.rs:605-651; conditions have no side effects)
+                if ((int32_t)tr.dest == LS.active_state || (int32_t)tr.source != LS.active_state) continue;
+                size_t pc = 0;
+                if (logic(tr.logic, pc)) return false;
+            }
+        }
+        const uint32_t o0 = A.prev_prog_off[inst], o1 = A.prev_prog_off[inst + 1];
+        S.ops.insert(S.ops.end(), A.prev_ops.begin() + o0, A.prev_ops.begin() + o1);
+        return true;
+    }
+    void remember() {
+        bool stable = A.memo_static_ok && !unstable && !error;
+        for (LayerState& LS : ms->layers) {
+            stable = stable && LS.active_transition < 0;
+            LS.memo_state = LS.active_state;
+        }
+        ms->memo_valid = stable;
+        ms->memo_gen = A.edit_gen;
+    }
+
     // Machine::evaluate_pose (machine/mod.rs:344-382) + apply
     void plan_absm() {
         std::fill(S.seen.begin(), S.seen.end(), 0);
@@ -512,6 +549,7 @@ struct Planner {
         }
         for (uint32_t a = 0; a < n_anims; ++a)
             if (S.seen[a] && as[a].enabled) tick(a);
+        if (try_reuse()) return;
         S.recipes.clear();
         S.items.clear();
         for (size_t li = 0; li < A.layers.size(); ++li) {
@@ -525,6 +563,7 @@ struct Planner {
         emit(OP_APPLY, 0, 0.f);
         emit(OP_END, 0, 0.f);
         if (rm()) rm_emit(RM_END, 0, 0, 0.f);
+        remember();
     }
 
     // AnimationContainerExt::update_animations (scene/animation/mod.rs:83-88)
@@ -630,6 +669,13 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
     const uint32_t na = (uint32_t)A.anims.size();
     A.times.assign((size_t)A.n_instances * na, 0.f);
     A.ticked.assign((size_t)A.n_instances * na, 0);
+    // last frame's programs become the memo's source; a frame of another kind in between invalidates it
+    A.ops.swap(A.prev_ops);
+    A.prog_off.swap(A.prev_prog_off);
+    if (mode != 1 || A.prev_mode != 1) ++A.edit_gen;
+    A.prev_mode = mode;
+    A.memo_static_ok = mode == 1 && !A.rm_enabled;
+    for (const LayerDef& L : A.layers) A.memo_static_ok = A.memo_static_ok && L.by_index_count == 0;
     A.ops.clear();
     A.prog_off.assign((size_t)A.n_instances + 1, 0);
     if (mode == 1) ensure_machine_state(A);  // instances get their machine state lazily
