@@ -496,3 +496,44 @@ def test_entry_points_reject_bad_arguments_without_crashing(cctx):
     fresh = cases.build_product(cctx, cases.player_only())
     got = fresh.plan(-1, 0.0)
     assert got["ops"].shape[0] == 0
+
+
+@pytest.mark.parametrize("make", [cases.c5_blend_tree, cases.transitions, cases.layered, cases.blend_space, cases.removed_clips,
+                                  cases.random_attacks] + [lambda s=s: cases.random_machine(s) for s in range(6)],
+                         ids=lambda f: getattr(f, "__name__", "random_machine"))
+def test_memoised_fold_programs_equal_programs_planned_from_scratch(make):
+    """The planner reuses an instance's fold program of the last frame when nothing it depends on changed (MachineState's
+    memo).  Two control-only contexts run the same scenario -- scripts, removals, per-instance parameter changes and all --
+    one of them with the memo defeated by a no-op setter before every frame (any non-read API call on the animator
+    invalidates): sample times, tick flags, offsets and programs must be equal on every frame, and so must the machine
+    states and event counts.  (Both are separately held to the oracle by the tests above.)"""
+    sc = make()
+    if sc.machine is None:
+        pytest.skip("player-only scenario: no fold program to memoise")
+    ctxs = [fyrox_amd.Context(control_only=True) for _ in range(2)]
+    n = 5
+    ps = [cases.build_product(c, sc, n) for c in ctxs]
+    for p in ps:
+        for i in range(n):
+            for a in range(len(sc.animations)):
+                p.set_time_position(a, (i * 0.173 + a * 0.29) % 0.9, instance=i)
+    for f in range(max(sc.n_frames, 30)):
+        for p in ps:
+            for idx, par in sc.script.get(f, []):
+                p.set_parameter(idx, par, instance=(f % n) if f % 3 else A.ALL_INSTANCES)
+            for a in sc.removals.get(f, []):
+                p.remove_animation(a)
+        keep = next(a for a in range(len(sc.animations)) if all(a not in lst for lst in sc.removals.values()))
+        ps[1].set_loop(keep, True if sc.animations[keep].looped is None else sc.animations[keep].looped)   # same value: only invalidates
+        got = [p.plan(1, sc.dt) for p in ps]
+        for key in ("times", "ticked", "offsets", "ops"):
+            assert np.array_equal(got[0][key], got[1][key]), (sc.name, f, key)
+        for i in range(n):
+            for li in range(len(sc.machine.layers)):
+                assert ps[0].layer_state(li, i) == ps[1].layer_state(li, i), (sc.name, f, i)
+            gone = {a for fr, lst in sc.removals.items() if fr <= f for a in lst}
+            for a in range(len(sc.animations)):
+                if a not in gone:
+                    assert ps[0].event_count(a, i) == ps[1].event_count(a, i)
+    for c in ctxs:
+        c.close()
