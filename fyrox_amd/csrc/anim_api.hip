@@ -478,19 +478,26 @@ int fyx_machine_set_parameter(fyx_ctx* c, uint64_t animator_id, uint32_t paramet
                               float f0, float f1, uint32_t u) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
-    FYX_ANIMATOR(c, A, animator_id);
+    // games set parameters every frame, mostly to the value they already have: only an instance whose parameter really
+    // changes loses its memoised fold program (MachineState), not the whole animator (hence the _RO form)
+    FYX_ANIMATOR_RO(c, A, animator_id);
     if (parameter >= A->param_defaults.size()) return fail(c, FYX_ERR_INVALID_ARG, "parameter %u does not exist", parameter);
     if (kind < FYX_PARAM_WEIGHT || kind > FYX_PARAM_SAMPLING_POINT) return fail(c, FYX_ERR_INVALID_ARG, "parameter kind %d", kind);
     Param p;
     p.kind = kind; p.f0 = f0; p.f1 = f1; p.u = u;
+    auto assign = [&](MachineState& m) {
+        Param& q = m.params[parameter];
+        if (q.kind != p.kind || memcmp(&q.f0, &p.f0, 4) || memcmp(&q.f1, &p.f1, 4) || q.u != p.u) m.memo_valid = false;
+        q = p;
+    };
     if (instance == FYX_ALL_INSTANCES) {
         A->param_defaults[parameter] = p;
-        for (MachineState& m : A->mstate) m.params[parameter] = p;
+        for (MachineState& m : A->mstate) assign(m);
         return FYX_OK;
     }
     if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
     ensure_machine_state(*A);
-    A->mstate[instance].params[parameter] = p;
+    assign(A->mstate[instance]);
     return FYX_OK;
     FYX_GUARD_END(c)
 }
