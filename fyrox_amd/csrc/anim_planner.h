@@ -545,7 +545,8 @@ struct Planner {
                 check[2] = (int32_t)L.transitions[LS.active_transition].dest;
             }
             for (int k = 0; k < 3; ++k)
-                if (check[k] >= 0 && (size_t)check[k] < L.states.size()) collect(L, L.states[check[k]].root);
+                if (check[k] >= 0 && (size_t)check[k] < L.states.size())
+                    for (uint32_t a : A.state_anims[li][check[k]]) S.seen[a] = 1;   // collect(), done once per frame and state (plan_frame_core)
         }
         for (uint32_t a = 0; a < n_anims; ++a)
             if (S.seen[a] && as[a].enabled) tick(a);
@@ -674,6 +675,25 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
     A.prog_off.swap(A.prev_prog_off);
     if (mode != 1 || A.prev_mode != 1) ++A.edit_gen;
     A.prev_mode = mode;
+    if (mode == 1) {   // which animations a state's pose tree plays (node/mod.rs:116-150): the same for every instance
+        struct Walk {
+            static void go(const LayerDef& L, int32_t h, std::vector<uint32_t>& out, int depth) {
+                if (h < 0 || (size_t)h >= L.nodes.size() || depth > 64) return;
+                const PoseNodeDef& n = L.nodes[h];
+                if (n.type == NODE_PLAY) { out.push_back(n.animation); return; }
+                for (const BlendInput& in : n.inputs) go(L, in.source, out, depth + 1);
+            }
+        };
+        A.state_anims.resize(A.layers.size());
+        for (size_t li = 0; li < A.layers.size(); ++li) {
+            const LayerDef& L = A.layers[li];
+            A.state_anims[li].resize(L.states.size());
+            for (size_t st = 0; st < L.states.size(); ++st) {
+                A.state_anims[li][st].clear();
+                Walk::go(L, L.states[st].root, A.state_anims[li][st], 0);
+            }
+        }
+    }
     A.memo_static_ok = mode == 1 && !A.rm_enabled;
     for (const LayerDef& L : A.layers) A.memo_static_ok = A.memo_static_ok && L.by_index_count == 0;
     A.ops.clear();
@@ -719,8 +739,13 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
             o += S.prog_len[j];
             r += S.rm_prog_len[j];
         }
-        A.ops.insert(A.ops.end(), S.ops.begin(), S.ops.end());
-        A.rm_ops.insert(A.rm_ops.end(), S.rm_ops.begin(), S.rm_ops.end());
+        if (n_tasks == 1) {          // one task: its vectors ARE the result (no second copy of every program)
+            A.ops.swap(A.scratch[k].ops);
+            A.rm_ops.swap(A.scratch[k].rm_ops);
+        } else {
+            A.ops.insert(A.ops.end(), S.ops.begin(), S.ops.end());
+            A.rm_ops.insert(A.rm_ops.end(), S.rm_ops.begin(), S.rm_ops.end());
+        }
     }
     A.prog_off[A.n_instances] = (uint32_t)A.ops.size();
     A.rm_prog_off[A.n_instances] = (uint32_t)A.rm_ops.size();
