@@ -85,7 +85,11 @@ int fyx_join(fyx_ctx* ctx);
  * plan a crowd's frame and instances per planning task; crowds below 2 x anim.split stay on the
  * calling thread), "anim.sample_form" (0 auto, 1 curves of one instance on the lanes, 2
  * instances of one curve on the lanes -- same results, the crowd form is picked from 32
- * instances on).  With lbs.exact = 0 the crowd kernel blends the four matrices first and
+ * instances on), "anim.overlap" (1 = pose updates do not wait for the skinning launches in flight, so frame
+ * n + 1's pose kernels run beside frame n's skinning; the caller then alternates two palette buffers per animator,
+ * see INTEGRATION.md), "lbs.dyn" / "lbs.dyn_block" (single-instance launches from 512 K vertices: 1 = the kernel
+ * whose waves draw their 64-vertex units from a per-workgroup ticket counter, workgroups of 256 | 512 | 1024
+ * threads; 0 = lbs_skin's fixed deal).  With lbs.exact = 0 the crowd kernel blends the four matrices first and
  * transforms once (the same linear map, different rounding, inside the 1e-5 bar). */
 int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
 /* Debug aid (option "lbs.probe" = 1): per-wave timeline of the last default-variant skinning launch, four
