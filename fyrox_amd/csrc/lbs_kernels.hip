@@ -971,7 +971,7 @@ static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t
     }
 }
 
-constexpr int kPolAux[5] = {0, 2, 16, 17, 18};   // plain, nt, sc1, sc0 sc1, sc1 nt
+[[maybe_unused]] constexpr int kPolAux[5] = {0, 2, 16, 17, 18};   // plain, nt, sc1, sc0 sc1, sc1 nt
 // lbs_skin_dyn launch: the grid is what is resident (16 waves per CU at the kernel's register budget).  Returns
 // hipErrorNotReady when the launch does not qualify (the caller takes lbs_skin).
 template <int BLOCK, bool EXACT, int MASK>
