@@ -62,6 +62,17 @@ __device__ __forceinline__ void stg(T* p, T v) {
 #ifndef FYX_EXP_KNOBS
 #define FYX_EXP_KNOBS 0
 #endif
+// FYX_EXP_DYN_WAVES (experiment builds only): lbs_skin_dyn with the influences walked one by one (SEQ) and the register
+// budget of that many waves per SIMD (5 -> 96 VGPRs, 6 -> 80); the launcher sizes the resident grid to match.
+// 0 = the product form (four waves per SIMD).
+#ifndef FYX_EXP_DYN_WAVES
+#define FYX_EXP_DYN_WAVES 0
+#endif
+#if FYX_EXP_DYN_WAVES
+#define FYX_DYN_ATTR __attribute__((amdgpu_waves_per_eu(FYX_EXP_DYN_WAVES, FYX_EXP_DYN_WAVES)))
+#else
+#define FYX_DYN_ATTR
+#endif
 
 template <bool NT>
 __device__ __forceinline__ void ld3(const float* p, float& x, float& y, float& z) {
@@ -596,7 +607,7 @@ __device__ __forceinline__ void store_vertex_buf(const VtxBuffers& b, uint32_t v
 // Which wave skins a unit changes nothing in the arithmetic: results are bit-identical to lbs_skin's.
 // ---------------------------------------------------------------------------------------
 template <int BLOCK, bool EXACT, int MASK, bool PROBE = false, int LD_AUX = 2, int ST_AUX = 16>
-__global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint64_t* probe = nullptr,
+__global__ __launch_bounds__(BLOCK) FYX_DYN_ATTR void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint64_t* probe = nullptr,
                                                       uint32_t knobs_arg = 0, uint32_t* pool_arg = nullptr,
                                                       uint32_t* pool_zero = nullptr) {
     // Experiment switches (tools/exp/dyn_knobs.py; findings in DESIGN.md 5): compiled in only with -DFYX_EXP_KNOBS=1
@@ -707,8 +718,8 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_dyn(LbsArgs a, uint32_t total_
             o.px = c_.p.x + c_.w.x; o.py = c_.p.y + c_.w.y; o.pz = c_.p.z + c_.w.z; o.nx = c_.n.x + c_.w.w; o.ny = c_.n.y; o.nz = c_.n.z;
             o.tx = c_.t.x; o.ty = c_.t.y; o.tz = c_.t.z + __uint_as_float(c_.id) * 0.f;
         } else {
-            o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
-                                         c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
+            o = skin_vertex<EXACT, MASK, false, FYX_EXP_DYN_WAVES != 0>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
+                                                                        c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
         }
         store_vertex_buf<MASK, ST_AUX>(vb, v_c, o, c_.t.w);
     };
@@ -978,7 +989,7 @@ template <int BLOCK, bool EXACT, int MASK>
 static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     constexpr uint32_t WPB = BLOCK / 64;
     const uint32_t total = (a.n_verts + 63) / 64;
-    const uint32_t resident = 1024 / BLOCK;
+    const uint32_t resident = (FYX_EXP_DYN_WAVES ? 256u * FYX_EXP_DYN_WAVES : 1024u) / BLOCK;
     const uint32_t grid = (uint32_t)kCUs * ((t.dyn_bpc > 0 && (uint32_t)t.dyn_bpc < resident) ? (uint32_t)t.dyn_bpc : resident);
     if (total / grid < 2 * WPB) return hipErrorNotReady;   // every wave starts with two units of its own
     const size_t lds = (size_t)a.n_bones * 64 + 64 + 16;

@@ -7,7 +7,7 @@ make -s
 mkdir -p ../../tools/exp/libs build/exp
 while [ $# -ge 2 ]; do
   tag=$1; defs=$2; shift 2
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function $defs -c lbs_kernels.hip -o build/exp/lbs_kernels_$tag.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-cuda-compat $defs -c lbs_kernels.hip -o build/exp/lbs_kernels_$tag.o &
 done
 wait
 for o in build/exp/lbs_kernels_*.o; do
