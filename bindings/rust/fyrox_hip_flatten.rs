@@ -23,7 +23,7 @@ use crate::generic_animation::{
 };
 use crate::scene::{
     animation::{
-        absm::{LogicNode, Machine, PoseNode, StateAction},
+        absm::{LogicNode, Machine, PoseNode, State, StateAction, Transition},
         Animation, AnimationContainer,
     },
     graph::Graph,
@@ -187,6 +187,21 @@ pub struct AnimatorMaps {
     pub animation_index: FxHashMap<Handle<Animation>, u32>,
     /// machine parameter name -> parameter index (filled by `attach_machine`)
     pub parameter_index: FxHashMap<String, u32>,
+    /// per machine layer: the handle -> index tables of its three pools (filled by `attach_machine`); what
+    /// `rebuild_machine` translates the run-time state through, and what turns the indices of `fyx_layer_get_state` and of
+    /// the layer events back into handles
+    pub layers: Vec<LayerMaps>,
+}
+
+/// The dense indices the library knows one layer's pool entries by.
+#[derive(Default)]
+pub struct LayerMaps {
+    pub node_index: FxHashMap<Handle<PoseNode>, i32>,
+    pub state_index: FxHashMap<Handle<State>, u32>,
+    /// only transitions between two existing states are sent (see `attach_machine`)
+    pub transition_index: FxHashMap<Handle<Transition>, u32>,
+    /// the `BlendAnimationsByIndex` nodes: the only pose nodes with state of their own (node/blend.rs:260-264)
+    pub by_index_nodes: Vec<Handle<PoseNode>>,
 }
 
 impl<'a> HipAnimator<'a> {
@@ -275,7 +290,7 @@ impl<'a> HipAnimator<'a> {
             }
         }
         let animator = HipAnimator::from_parts(hip, animator_id, n_instances, signal_names);
-        Ok((animator, AnimatorMaps { animation_index, parameter_index: FxHashMap::default() }))
+        Ok((animator, AnimatorMaps { animation_index, parameter_index: FxHashMap::default(), layers: Vec::new() }))
     }
 
     /// The `Machine` of an `AnimationBlendingStateMachine` (scene/animation/absm.rs:240) on top of `from_player`.
@@ -291,8 +306,12 @@ impl<'a> HipAnimator<'a> {
             // pose nodes: the pool is walked in slot order; children are referred to by handle, so the handle -> index map
             // is complete before any node is sent
             let mut node_index: FxHashMap<Handle<PoseNode>, i32> = FxHashMap::default();
-            for (n, (h, _)) in layer.nodes().pair_iter().enumerate() {
+            let mut by_index_nodes = Vec::new();
+            for (n, (h, node)) in layer.nodes().pair_iter().enumerate() {
                 node_index.insert(h, n as i32);
+                if let PoseNode::BlendAnimationsByIndex(_) = node {
+                    by_index_nodes.push(h);
+                }
             }
             for (_, node) in layer.nodes().pair_iter() {
                 let mut out = 0u32;
@@ -396,7 +415,8 @@ impl<'a> HipAnimator<'a> {
             if let Some(e) = state_index.get(&layer.entry_state()) {
                 check_rc(ctx, unsafe { fyx_layer_set_entry_state(ctx, id, li, *e) })?;
             }
-            for (_, transition) in layer.transitions().pair_iter() {
+            let mut transition_index = FxHashMap::default();
+            for (th, transition) in layer.transitions().pair_iter() {
                 let (Some(s), Some(d)) = (state_index.get(&transition.source()), state_index.get(&transition.dest())) else {
                     continue; // a transition between states that do not exist can never fire (layer.rs:606-611)
                 };
@@ -406,9 +426,95 @@ impl<'a> HipAnimator<'a> {
                 check_rc(ctx, unsafe {
                     fyx_layer_add_transition(ctx, id, li, *s, *d, transition.transition_time(), code.as_ptr(), code.len() as u32, &mut ti)
                 })?;
+                transition_index.insert(th, ti);
+            }
+            maps.layers.push(LayerMaps { node_index, state_index, transition_index, by_index_nodes });
+        }
+        Ok(())
+    }
+
+    /// After the game has edited the `Machine` in place -- `layers_mut`, `nodes_mut`, `transitions_mut`, `states_mut`,
+    /// `Transition::set_condition`, `BlendSpace::set_points`, a pool entry freed ... (machine/mod.rs:280-312,
+    /// layer.rs:412-525): the next `evaluate_pose` of the reference sees the edit with every other piece of run-time
+    /// state untouched.  Here the definition is sent again and the run-time state -- which lives in the library, it is
+    /// the library that evaluates -- is carried over BY HANDLE: active state / transition of every layer
+    /// (layer.rs:103-109), `elapsed_time` / `blend_factor` of every transition (transition.rs:188-201), `prev_index` /
+    /// `blend_time` of every `BlendAnimationsByIndex` node (node/blend.rs:260-264); the parameter values are the
+    /// `ParameterContainer`'s own.  A handle that no longer resolves drops its state; an active state that is gone becomes
+    /// `Handle::NONE`.  Layers are matched by position.  Pending layer events (`fyx_layer_pop_event`) should be drained
+    /// first: they do not survive.  What edit happened is the game's knowledge: call this when it says so (the editor's
+    /// commands, a script that rewires the graph) -- not every frame.
+    pub fn rebuild_machine(&mut self, machine: &Machine, rig: &RigMap, maps: &mut AnimatorMaps, n_instances: u32) -> Result<(), HipError> {
+        let (ctx, id) = (self.raw(), self.id());
+        struct SavedLayer {
+            active_state: Option<Handle<State>>,
+            active_transition: Option<Handle<Transition>>,
+            transitions: Vec<(Handle<Transition>, f32, f32)>,
+            by_index: Vec<(Handle<PoseNode>, i32, u32, f32)>,
+        }
+        let mut saved: Vec<Vec<SavedLayer>> = Vec::new(); // [instance][layer]
+        for instance in 0..n_instances {
+            let mut per_layer = Vec::new();
+            for (li, lm) in maps.layers.iter().enumerate() {
+                let li = li as u32;
+                let (mut s, mut t) = (-1i32, -1i32);
+                check_rc(ctx, unsafe { fyx_layer_get_state(ctx, id, li, instance, &mut s, &mut t) })?;
+                let mut transitions = Vec::new();
+                for (h, index) in lm.transition_index.iter() {
+                    let (mut elapsed, mut factor) = (0.0f32, 0.0f32);
+                    check_rc(ctx, unsafe { fyx_layer_get_transition_state(ctx, id, li, instance, *index, &mut elapsed, &mut factor) })?;
+                    transitions.push((*h, elapsed, factor));
+                }
+                let mut by_index = Vec::new();
+                for h in lm.by_index_nodes.iter() {
+                    let (mut has_prev, mut prev, mut time) = (0i32, 0u32, 0.0f32);
+                    let node = lm.node_index[h] as u32;
+                    check_rc(ctx, unsafe { fyx_layer_get_node_state(ctx, id, li, instance, node, &mut has_prev, &mut prev, &mut time) })?;
+                    by_index.push((*h, has_prev, prev, time));
+                }
+                per_layer.push(SavedLayer {
+                    active_state: lm.state_index.iter().find(|(_, i)| **i as i32 == s).map(|(h, _)| *h),
+                    active_transition: lm.transition_index.iter().find(|(_, i)| **i as i32 == t).map(|(h, _)| *h),
+                    transitions,
+                    by_index,
+                });
+            }
+            saved.push(per_layer);
+        }
+        check_rc(ctx, unsafe { fyx_machine_clear(ctx, id) })?;
+        maps.parameter_index.clear();
+        maps.layers.clear();
+        self.attach_machine(machine, rig, maps)?;
+        for (instance, per_layer) in saved.iter().enumerate() {
+            let instance = instance as u32;
+            for (li, old) in per_layer.iter().enumerate() {
+                let Some(lm) = maps.layers.get(li) else {
+                    continue; // the layer is gone
+                };
+                let li = li as u32;
+                let s = old.active_state.and_then(|h| lm.state_index.get(&h)).map(|i| *i as i32).unwrap_or(-1);
+                let t = old.active_transition.and_then(|h| lm.transition_index.get(&h)).map(|i| *i as i32).unwrap_or(-1);
+                check_rc(ctx, unsafe { fyx_layer_set_state(ctx, id, li, instance, s, t) })?;
+                for (h, elapsed, factor) in old.transitions.iter() {
+                    if let Some(index) = lm.transition_index.get(h) {
+                        check_rc(ctx, unsafe { fyx_layer_set_transition_state(ctx, id, li, instance, *index, *elapsed, *factor) })?;
+                    }
+                }
+                for (h, has_prev, prev, time) in old.by_index.iter() {
+                    // still a BlendAnimationsByIndex node?  (a freed slot may have been reused by a node of another kind)
+                    if lm.by_index_nodes.contains(h) {
+                        let node = lm.node_index[h] as u32;
+                        check_rc(ctx, unsafe { fyx_layer_set_node_state(ctx, id, li, instance, node, *has_prev, *prev, *time) })?;
+                    }
+                }
             }
         }
         Ok(())
+    }
+
+    /// `MachineLayer::reset` (layer.rs:288-296) for every instance.
+    pub fn reset_layer(&mut self, layer: u32) -> Result<(), HipError> {
+        check_rc(self.raw(), unsafe { fyx_layer_reset(self.raw(), self.id(), layer, FYX_ALL_INSTANCES) })
     }
 
     /// Game code changes parameters between frames (`machine.parameters_mut().get_mut(name)`): push the current values

@@ -129,6 +129,14 @@ _SIGS = {
     "fyx_state_add_action": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int, c_int, c_uint32]),
     "fyx_layer_add_transition": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, c_float, _P, c_uint32, POINTER(c_uint32)]),
     "fyx_layer_get_state": (c_int, [_P, c_uint64, c_uint32, c_uint32, POINTER(c_int32), POINTER(c_int32)]),
+    "fyx_machine_clear": (c_int, [_P, c_uint64]),
+    "fyx_machine_get_parameter": (c_int, [_P, c_uint64, c_uint32, c_uint32, POINTER(c_int), POINTER(c_float), POINTER(c_float), POINTER(c_uint32)]),
+    "fyx_layer_set_state": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_int32, c_int32]),
+    "fyx_layer_get_transition_state": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, POINTER(c_float), POINTER(c_float)]),
+    "fyx_layer_set_transition_state": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, c_float, c_float]),
+    "fyx_layer_get_node_state": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, POINTER(c_int), POINTER(c_uint32), POINTER(c_float)]),
+    "fyx_layer_set_node_state": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, c_int, c_uint32, c_float]),
+    "fyx_layer_reset": (c_int, [_P, c_uint64, c_uint32, c_uint32]),
     "fyx_animation_player_update": (c_int, [_P, c_uint64, c_float]),
     "fyx_absm_update": (c_int, [_P, c_uint64, c_float]),
     "fyx_animator_update_transforms": (c_int, [_P, c_uint64]),

@@ -473,6 +473,93 @@ class Animator:
         self._check(self._l.fyx_layer_get_state(self._h, self.id, layer, instance, byref(s), byref(t)))
         return s.value, t.value
 
+    # -- run-time edits: the definition is re-sent, the run-time state carried over (fyrox_hip.h) -------------
+    def machine_clear(self) -> None:
+        self._check(self._l.fyx_machine_clear(self._h, self.id))
+
+    def get_parameter(self, index: int, instance: int = 0) -> Parameter:
+        k, f0, f1, u = c_int(), c_float(), c_float(), c_uint32()
+        self._check(self._l.fyx_machine_get_parameter(self._h, self.id, index, instance, byref(k), byref(f0), byref(f1), byref(u)))
+        if k.value == PARAM_WEIGHT:
+            return Parameter(PARAM_WEIGHT, f0.value)
+        if k.value == PARAM_RULE:
+            return Parameter(PARAM_RULE, bool(u.value))
+        if k.value == PARAM_INDEX:
+            return Parameter(PARAM_INDEX, int(u.value))
+        return Parameter(PARAM_SAMPLING_POINT, (f0.value, f1.value))
+
+    def set_layer_state(self, layer: int, active_state: int, active_transition: int, instance=ALL_INSTANCES) -> None:
+        self._check(self._l.fyx_layer_set_state(self._h, self.id, layer, instance, active_state, active_transition))
+
+    def transition_state(self, layer: int, transition: int, instance: int = 0) -> Tuple[float, float]:
+        e, b = c_float(), c_float()
+        self._check(self._l.fyx_layer_get_transition_state(self._h, self.id, layer, instance, transition, byref(e), byref(b)))
+        return e.value, b.value
+
+    def set_transition_state(self, layer: int, transition: int, elapsed: float, blend_factor: float, instance=ALL_INSTANCES) -> None:
+        self._check(self._l.fyx_layer_set_transition_state(self._h, self.id, layer, instance, transition, elapsed, blend_factor))
+
+    def node_state(self, layer: int, node: int, instance: int = 0) -> Tuple[Optional[int], float]:
+        """BlendAnimationsByIndex: (prev_index or None, blend_time)"""
+        h, p, t = c_int(), c_uint32(), c_float()
+        self._check(self._l.fyx_layer_get_node_state(self._h, self.id, layer, instance, node, byref(h), byref(p), byref(t)))
+        return (p.value if h.value else None), t.value
+
+    def set_node_state(self, layer: int, node: int, prev_index: Optional[int], blend_time: float, instance=ALL_INSTANCES) -> None:
+        self._check(self._l.fyx_layer_set_node_state(self._h, self.id, layer, instance, node, 0 if prev_index is None else 1,
+                                                     0 if prev_index is None else prev_index, blend_time))
+
+    def reset_layer(self, layer: int, instance=ALL_INSTANCES) -> None:
+        """MachineLayer::reset (layer.rs:288-296)"""
+        self._check(self._l.fyx_layer_reset(self._h, self.id, layer, instance))
+
+    def rebuild_machine(self, old: Machine, new: Machine, layer_map=None, state_maps=None, transition_maps=None,
+                        node_maps=None, parameter_map=None) -> None:
+        """What the engine-side shim does after the game has edited its Machine in place: read the run-time state of
+        every instance, clear, re-send the definition, put the state back.  The maps translate OLD indices to NEW ones
+        (the shim derives them from its handle -> index tables): `layer_map[old_layer]`, `state_maps[old_layer][old_state]`
+        ...; a missing map is the identity, an entry of None (or an index past the new definition) means the item is gone
+        and its state is dropped -- an active state that is gone becomes Handle::NONE."""
+        def m(maps, key, i, limit):
+            if i is None or i < 0:
+                return -1
+            mp = None if maps is None else (maps.get(key) if isinstance(maps, dict) else maps[key])
+            j = i if mp is None else (mp.get(i) if isinstance(mp, dict) else (mp[i] if i < len(mp) else None))
+            return -1 if j is None or j < 0 or j >= limit else j
+
+        saved = []
+        for inst in range(self.n_instances):
+            rec = {"params": [self.get_parameter(p, inst) for p in range(len(old.parameters))], "layers": []}
+            for li, layer in enumerate(old.layers):
+                rec["layers"].append({
+                    "state": self.layer_state(li, inst),
+                    "transitions": [self.transition_state(li, t, inst) for t in range(len(layer.transitions))],
+                    "nodes": {n: self.node_state(li, n, inst) for n, nd in enumerate(layer.nodes)
+                              if isinstance(nd, BlendAnimationsByIndex)}})
+            saved.append(rec)
+        self.machine_clear()
+        self.set_machine(new)
+        for inst, rec in enumerate(saved):
+            for p_old, val in enumerate(rec["params"]):
+                p_new = m({0: parameter_map} if parameter_map is not None else None, 0, p_old, len(new.parameters))
+                if p_new >= 0:      # Machine::set_parameter replaces the value, kind included (machine/mod.rs:233-245)
+                    self.set_parameter(p_new, val, inst)
+            for li_old, lrec in enumerate(rec["layers"]):
+                li = m({0: layer_map} if layer_map is not None else None, 0, li_old, len(new.layers))
+                if li < 0:
+                    continue
+                nl = new.layers[li]
+                s, t = lrec["state"]
+                self.set_layer_state(li, m(state_maps, li_old, s, len(nl.states)), m(transition_maps, li_old, t, len(nl.transitions)), inst)
+                for t_old, (el, bf) in enumerate(lrec["transitions"]):
+                    t_new = m(transition_maps, li_old, t_old, len(nl.transitions))
+                    if t_new >= 0:
+                        self.set_transition_state(li, t_new, el, bf, inst)
+                for n_old, (prev, bt) in lrec["nodes"].items():
+                    n_new = m(node_maps, li_old, n_old, len(nl.nodes))
+                    if n_new >= 0 and isinstance(nl.nodes[n_new], BlendAnimationsByIndex):
+                        self.set_node_state(li, n_new, prev, bt, inst)
+
     # -- per frame -------------------------------------------------------------------------------
     def update_animations(self, dt: float) -> None:
         """AnimationPlayer::update"""

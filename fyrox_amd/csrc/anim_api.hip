@@ -765,6 +765,138 @@ int fyx_layer_get_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32
     FYX_GUARD_END(c)
 }
 
+// ---- run-time edits of a machine: the definition is re-sent, the run-time state carried over (fyrox_hip.h) ----
+
+int fyx_machine_clear(fyx_ctx* c, uint64_t animator_id) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    // the root-motion records on the device stay: the next frame re-lays them out by position (anim_device.h)
+    A->param_defaults.clear();
+    A->layers.clear();
+    for (MachineState& m : A->mstate) {
+        m.params.clear();
+        m.layers.clear();
+        m.memo_valid = false;
+    }
+    A->state_anims.clear();
+    A->rm_layer_base.clear();
+    A->n_rm_slots = 0;
+    A->masks_dirty = true;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_machine_get_parameter(fyx_ctx* c, uint64_t animator_id, uint32_t parameter, uint32_t instance, int* kind, float* f0,
+                              float* f1, uint32_t* u) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR_RO(c, A, animator_id);
+    if (parameter >= A->param_defaults.size()) return fail(c, FYX_ERR_INVALID_ARG, "parameter %u does not exist", parameter);
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    const Param& p = A->mstate.size() == A->n_instances ? A->mstate[instance].params[parameter] : A->param_defaults[parameter];
+    if (kind) *kind = p.kind;
+    if (f0) *f0 = p.f0;
+    if (f1) *f1 = p.f1;
+    if (u) *u = p.u;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_set_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance, int32_t active_state,
+                        int32_t active_transition) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (active_state < -1 || active_state >= (int32_t)L->states.size()) return fail(c, FYX_ERR_INVALID_ARG, "state %d does not exist", active_state);
+    if (active_transition < -1 || active_transition >= (int32_t)L->transitions.size())
+        return fail(c, FYX_ERR_INVALID_ARG, "transition %d does not exist", active_transition);
+    return for_layer_states(c, A, layer, instance, [&](LayerState& S) {
+        S.active_state = active_state;
+        S.active_transition = active_transition;
+    });
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_get_transition_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance, uint32_t transition,
+                                   float* elapsed_time, float* blend_factor) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR_RO(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (transition >= L->transitions.size()) return fail(c, FYX_ERR_INVALID_ARG, "transition %u does not exist", transition);
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    TransitionState t;
+    if (A->mstate.size() == A->n_instances) t = A->mstate[instance].layers[layer].transitions[transition];
+    if (elapsed_time) *elapsed_time = t.elapsed;
+    if (blend_factor) *blend_factor = t.blend_factor;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_set_transition_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance, uint32_t transition,
+                                   float elapsed_time, float blend_factor) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (transition >= L->transitions.size()) return fail(c, FYX_ERR_INVALID_ARG, "transition %u does not exist", transition);
+    return for_layer_states(c, A, layer, instance, [&](LayerState& S) {
+        S.transitions[transition].elapsed = elapsed_time;
+        S.transitions[transition].blend_factor = blend_factor;
+    });
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_get_node_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance, uint32_t node, int* has_prev,
+                             uint32_t* prev_index, float* blend_time) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR_RO(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (node >= L->nodes.size() || L->nodes[node].type != NODE_BY_INDEX)
+        return fail(c, FYX_ERR_INVALID_ARG, "node %u is not a BlendAnimationsByIndex node", node);
+    if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    ByIndexState b;
+    if (A->mstate.size() == A->n_instances) b = A->mstate[instance].layers[layer].by_index[L->nodes[node].by_index_slot];
+    if (has_prev) *has_prev = b.has_prev ? 1 : 0;
+    if (prev_index) *prev_index = b.prev;
+    if (blend_time) *blend_time = b.blend_time;
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_set_node_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance, uint32_t node, int has_prev,
+                             uint32_t prev_index, float blend_time) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    if (node >= L->nodes.size() || L->nodes[node].type != NODE_BY_INDEX)
+        return fail(c, FYX_ERR_INVALID_ARG, "node %u is not a BlendAnimationsByIndex node", node);
+    const uint32_t slot = L->nodes[node].by_index_slot;
+    return for_layer_states(c, A, layer, instance, [&](LayerState& S) {
+        S.by_index[slot].has_prev = has_prev != 0;
+        S.by_index[slot].prev = prev_index;
+        S.by_index[slot].blend_time = blend_time;
+    });
+    FYX_GUARD_END(c)
+}
+
+int fyx_layer_reset(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32_t instance) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR(c, A, animator_id);
+    FYX_LAYER(c, A, L, layer);
+    const int32_t entry = L->entry_state;
+    return for_layer_states(c, A, layer, instance, [&](LayerState& S) {   // layer.rs:290-296
+        for (TransitionState& t : S.transitions) t = TransitionState();
+        S.active_state = entry;
+    });
+    FYX_GUARD_END(c)
+}
+
 // ---- per frame -----------------------------------------------------------------------------
 
 static int update_common(fyx_ctx* c, uint64_t animator_id, int mode, float dt) {
@@ -1048,6 +1180,7 @@ int fyx_animator_track_root_motion(fyx_ctx* c, uint64_t animator_id, int enabled
         dfree(A->d_rm_anim); dfree(A->d_rm_slots);
         A->d_rm_anim = nullptr; A->d_rm_slots = nullptr;
         A->dev_rm_anim_capacity = 0; A->dev_rm_slots = 0;
+        A->dev_rm_layer_nodes.clear();
     }
     A->rm_enabled = enabled != 0;
     return FYX_OK;

@@ -166,16 +166,42 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             A.d_rm_anim = static_cast<RootMotionDev*>(nr.release());
             A.dev_rm_anim_capacity = A.dev_anim_capacity;
         }
+        // Slots: per layer its pose nodes then the layer's final pose; the machine's final pose last.  The records persist
+        // from frame to frame (AnimationPose::reset keeps root_motion, pose.rs:125-129), so when the graph changes
+        // (nodes / layers appended between frames, or the definition re-sent after an edit: fyx_machine_clear) every
+        // record that still has a place keeps its value BY POSITION -- node n of layer l, layer l's final pose, the
+        // machine's -- and the new ones start from None.
         uint32_t want = 1;
-        for (const LayerDef& L : A.layers) want += (uint32_t)L.nodes.size() + 1;
-        if (want != A.dev_rm_slots) {  // the machine graph changed: every pose's root motion starts from None again
+        std::vector<uint32_t> nodes_now(A.layers.size());
+        for (size_t l = 0; l < A.layers.size(); ++l) { nodes_now[l] = (uint32_t)A.layers[l].nodes.size(); want += nodes_now[l] + 1; }
+        if (want != A.dev_rm_slots || nodes_now != A.dev_rm_layer_nodes) {
             FYX_HIP(c, hipStreamSynchronize(c->stream));
-            dfree(A.d_rm_slots);
-            A.d_rm_slots = nullptr;
+            DevGuard ns;
             const size_t nb = (size_t)A.n_instances * want * 32;
-            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_rm_slots), nb));
-            FYX_HIP(c, hipMemset(A.d_rm_slots, 0, nb));
+            FYX_HIP(c, hipMalloc(&ns.p, nb));
+            FYX_HIP(c, hipMemset(ns.p, 0, nb));
+            if (A.d_rm_slots && A.dev_rm_slots) {
+                const size_t old_pitch = (size_t)A.dev_rm_slots * 32, new_pitch = (size_t)want * 32;
+                auto keep = [&](uint32_t new_first, uint32_t old_first, uint32_t count) -> hipError_t {
+                    if (!count) return hipSuccess;
+                    return hipMemcpy2D(static_cast<char*>(ns.p) + (size_t)new_first * 32, new_pitch,
+                                       reinterpret_cast<const char*>(A.d_rm_slots) + (size_t)old_first * 32, old_pitch,
+                                       (size_t)count * 32, A.n_instances, hipMemcpyDeviceToDevice);
+                };
+                uint32_t ob = 0, nbase = 0;
+                for (size_t l = 0; l < std::min(nodes_now.size(), A.dev_rm_layer_nodes.size()); ++l) {
+                    const uint32_t on = A.dev_rm_layer_nodes[l], nn = nodes_now[l];
+                    FYX_HIP(c, keep(nbase, ob, std::min(on, nn)));
+                    FYX_HIP(c, keep(nbase + nn, ob + on, 1));      // the layer's final pose
+                    ob += on + 1;
+                    nbase += nn + 1;
+                }
+                FYX_HIP(c, keep(want - 1, A.dev_rm_slots - 1, 1));   // the machine's
+            }
+            dfree(A.d_rm_slots);
+            A.d_rm_slots = static_cast<float4*>(ns.release());
             A.dev_rm_slots = want;
+            A.dev_rm_layer_nodes = nodes_now;
         }
     }
     if (A.masks_dirty || A.dev_mask_layers != A.layers.size()) {
@@ -463,6 +489,20 @@ int for_instances(fyx_ctx* c, Animator* A, uint32_t animation, uint32_t instance
 }
 
 LayerDef* find_layer(Animator* A, uint32_t layer) { return layer < A->layers.size() ? &A->layers[layer] : nullptr; }
+
+// Runs fn(LayerState&) on one instance's state of `layer`, or on every instance's.
+template <typename F>
+int for_layer_states(fyx_ctx* c, Animator* A, uint32_t layer, uint32_t instance, F&& fn) {
+    if (instance != FYX_ALL_INSTANCES && instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
+    ensure_machine_state(*A);
+    if (instance == FYX_ALL_INSTANCES) {
+        for (MachineState& m : A->mstate) { fn(m.layers[layer]); m.memo_valid = false; }
+    } else {
+        fn(A->mstate[instance].layers[layer]);
+        A->mstate[instance].memo_valid = false;
+    }
+    return FYX_OK;
+}
 
 #define FYX_LAYER(c, A, L, layer)                                                                \
     LayerDef* L = find_layer((A), (layer));                                                      \

@@ -198,6 +198,7 @@ struct Animator {
     uint32_t dev_rm_anim_capacity = 0;
     float4* d_rm_slots = nullptr;
     uint32_t dev_rm_slots = 0;
+    std::vector<uint32_t> dev_rm_layer_nodes;   // pose nodes per layer of the layout d_rm_slots was made for
     // scratch of the planner threads
     std::vector<PlanScratch> scratch;
 };

@@ -528,6 +528,47 @@ int fyx_layer_add_transition(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
                              uint32_t n_condition, uint32_t* out_transition);
 int fyx_layer_get_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance,
                         int32_t* active_state, int32_t* active_transition);
+/* ---- run-time edits of a machine -------------------------------------------------------
+ * The engine edits a Machine IN PLACE between two frames -- Machine::add_layer / remove_layer / insert_layer /
+ * pop_layer / layers_mut (machine/mod.rs:280-312), MachineLayer::node_mut / nodes_mut / transition_mut /
+ * transitions_mut / state_mut / states_mut (layer.rs:412-525), Transition::set_condition (transition.rs:290),
+ * BlendSpace::set_points / points_mut / set_sampling_parameter (node/blendspace.rs:246-310), the public fields of the
+ * blend nodes -- and the next evaluate_pose sees the edit with every other piece of run-time state untouched.  The
+ * builder calls above only append (which already works between frames: the per-instance state grows with the
+ * definition).  Every other edit is made by re-sending the definition:
+ *     read the run-time state (fyx_layer_get_state, fyx_layer_get_transition_state, fyx_layer_get_node_state,
+ *     fyx_machine_get_parameter)  ->  fyx_machine_clear  ->  builder calls for the edited machine  ->  put the state
+ *     back (fyx_layer_set_state, ..._set_transition_state, ..._set_node_state), translated through the caller's
+ *     handle -> index maps (a state / transition / node whose handle no longer resolves is simply not restored).
+ * What the reference keeps in the objects, and therefore what there is to carry over: MachineLayer::active_state /
+ * active_transition (layer.rs:103-109), Transition::elapsed_time / blend_factor (transition.rs:188-201),
+ * BlendAnimationsByIndex::prev_index / blend_time (node/blend.rs:260-264) and the parameter values.  Animations, their
+ * clocks, event queues and sampled poses belong to the AnimationContainer and are not touched by any of this. */
+/* Drops the parameters, the layers and the per-instance machine state (pending layer events included: pop them first).
+ * The root-motion records of the poses (AnimationPose::root_motion persists from frame to frame: reset() keeps it,
+ * pose.rs:125-129) stay on the device and are matched to the re-sent definition BY POSITION -- node n of layer l, layer
+ * l's final pose, the machine's -- so they carry over exactly as long as the surviving pose nodes keep their indices
+ * (a definition flattened in pool order does, unless a node in the middle of a pool was freed). */
+int fyx_machine_clear(fyx_ctx* ctx, uint64_t animator_id);
+int fyx_machine_get_parameter(fyx_ctx* ctx, uint64_t animator_id, uint32_t parameter, uint32_t instance, int* kind,
+                              float* f0, float* f1, uint32_t* u);
+/* Sets MachineLayer::active_state / active_transition (-1 = Handle::NONE); no actions run, no events are queued.
+ * instance may be FYX_ALL_INSTANCES. */
+int fyx_layer_set_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance, int32_t active_state,
+                        int32_t active_transition);
+int fyx_layer_get_transition_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance,
+                                   uint32_t transition, float* elapsed_time, float* blend_factor);
+int fyx_layer_set_transition_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance,
+                                   uint32_t transition, float elapsed_time, float blend_factor);
+/* BlendAnimationsByIndex's prev_index (has_prev = 0: None) and blend_time; `node` must be such a node. */
+int fyx_layer_get_node_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance, uint32_t node,
+                             int* has_prev, uint32_t* prev_index, float* blend_time);
+int fyx_layer_set_node_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance, uint32_t node,
+                             int has_prev, uint32_t prev_index, float blend_time);
+/* MachineLayer::reset (layer.rs:288-296): every transition's elapsed_time and blend_factor return to 0 and
+ * active_state = entry_state; active_transition is left as it is, as in the reference.  instance may be
+ * FYX_ALL_INSTANCES. */
+int fyx_layer_reset(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance);
 /* machine::Event (machine/event.rs:30-51) and MachineLayer::pop_event (layer.rs:284-286); the
  * queue holds at most 2048 events per layer and instance, further ones are dropped
  * (FixedEventQueue, event.rs:53-90).  Handles are indices, -1 = Handle::NONE. */

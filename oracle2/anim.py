@@ -510,12 +510,69 @@ class Layer:
         self.active_state = 0 if self.states else -1        # add_state: the first state becomes active (layer.rs:229-235)
         if d.entry_state is not None:
             self.active_state = d.entry_state
+        self.entry_state = self.active_state
         self.active_transition = -1
         self.final = Pose()
         self.events = []
 
     def _state(self, h):
-        return self.states[h] if 0 <= h < len(self.states) else None
+        return self.states[h] if 0 <= h < len(self.states) else None       # a freed pool entry is None as well
+
+    # ---- edits in place, as a game makes them between two frames (layer.rs:202-283, 412-525; the pools' free() leaves a
+    # hole and every other handle keeps its meaning; run-time fields -- elapsed_time, blend_factor, prev_index, blend_time,
+    # the cached output poses, active_state / active_transition -- are not touched by any of them) ----
+    def reset(self):
+        """MachineLayer::reset (layer.rs:288-296): transitions reset, active_state = entry_state; active_transition is NOT
+        cleared by the reference."""
+        for tr in self.transitions:
+            if tr is not None:
+                tr[4], tr[5] = ZERO, ZERO
+        self.active_state = self.entry_state
+
+    def add_node(self, d):
+        self.nodes.append(_make_node(d))
+        return len(self.nodes) - 1
+
+    def add_state(self, d):
+        self.states.append((d.root, list(d.on_enter_actions), list(d.on_leave_actions)))
+        if self.entry_state < 0:                     # layer.rs:229-235
+            self.entry_state = self.active_state = len(self.states) - 1
+        return len(self.states) - 1
+
+    def add_transition(self, d):
+        self.transitions.append([d.source, d.dest, F(d.transition_time), d.condition, ZERO, ZERO])
+        return len(self.transitions) - 1
+
+    def edit_transition(self, h, *, transition_time=None, condition=None, source=None, dest=None):
+        tr = self.transitions[h]
+        if transition_time is not None:
+            tr[2] = F(transition_time)
+        if condition is not None:
+            tr[3] = condition
+        if source is not None:
+            tr[0] = source
+        if dest is not None:
+            tr[1] = dest
+
+    def edit_state(self, h, *, root=None, on_enter_actions=None, on_leave_actions=None):
+        r, en, le = self.states[h]
+        self.states[h] = (r if root is None else root, en if on_enter_actions is None else list(on_enter_actions),
+                          le if on_leave_actions is None else list(on_leave_actions))
+
+    def edit_node(self, h, d):
+        """the definition fields of a node replaced through node_mut(); what the node keeps between frames stays"""
+        old, new = self.nodes[h], _make_node(d)
+        assert type(old) is type(new)
+        new.out = old.out
+        if isinstance(old, ByIndexNode):
+            new.prev_index, new.blend_time = old.prev_index, old.blend_time
+        self.nodes[h] = new
+
+    def remove_transition(self, h):
+        self.transitions[h] = None
+
+    def remove_state(self, h):
+        self.states[h] = None
 
     def _state_pose(self, h, cx):
         s = self._state(h)
@@ -528,13 +585,15 @@ class Layer:
         """MachineLayer::evaluate_pose (layer.rs:590-706)"""
         self.final.reset()
         if self.active_state >= 0 or self.active_transition >= 0:
-            for root, _, _ in self.states:
-                n = cx.node(root)
+            for st in self.states:
+                if st is None:
+                    continue
+                n = cx.node(st[0])
                 if n is not None:
                     n.eval(cx)
             if self.active_transition < 0:
                 for h, tr in enumerate(self.transitions):
-                    if tr[1] == self.active_state or tr[0] != self.active_state:
+                    if tr is None or tr[1] == self.active_state or tr[0] != self.active_state:
                         continue
                     if _logic(tr[3], cx):
                         s = self._state(self.active_state)
@@ -606,7 +665,7 @@ class Machine:
         for layer in self.layers:
             cx = _Ctx(layer.nodes, self.params, animations, dt)
             check = [layer.active_state]
-            if 0 <= layer.active_transition < len(layer.transitions):
+            if 0 <= layer.active_transition < len(layer.transitions) and layer.transitions[layer.active_transition] is not None:
                 tr = layer.transitions[layer.active_transition]
                 check += [tr[0], tr[1]]
             for s in check:

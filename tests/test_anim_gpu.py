@@ -289,6 +289,66 @@ def test_root_motion_and_signals_match_oracle(ctx, orc, make):
     p.free()
 
 
+# ---- run-time edits of a machine (fyx_machine_clear + builder calls + state restore; tests/test_machine_edits.py has the
+# control plane's side of it on the CPU) ----
+
+@pytest.mark.parametrize("make", [cases.transitions, cases.by_index, cases.layered, cases.looping_root_motion,
+                                  cases.with_root_motion_and_signals(cases.transitions)],
+                         ids=["transitions", "by_index", "layered", "looping_root_motion", "transitions_rm"])
+def test_machine_resent_between_frames_is_invisible_on_the_device(ctx, orc, make):
+    """The same definition sent again every third frame (inside transitions and cross-fades too): poses, matrices,
+    layer states and root motion keep matching the oracle, whose machine is never touched."""
+    sc = make()
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, 3)
+    for f in range(min(sc.n_frames, 48)):
+        for idx, par in sc.script.get(f, []):
+            o.set_parameter(idx, par)
+            p.set_parameter(idx, par)
+        if f % 3 == 2:
+            for li in range(len(sc.machine.layers)):
+                ref = _drain(lambda: o.pop_layer_event(li))
+                assert _drain(lambda: p.pop_layer_event(li, 2)) == ref and _drain(lambda: p.pop_layer_event(li, 0)) == ref
+                _drain(lambda: p.pop_layer_event(li, 1))
+            p.rebuild_machine(sc.machine, sc.machine)
+        o.update_machine(sc.dt)
+        p.update_machine(sc.dt)
+        check_frame(p, o, sc, 3, f)
+    o.close()
+    p.free()
+
+
+def test_machine_edited_between_frames_matches_the_edit_in_place(ctx):
+    """A real edit (transition times, then a state added with its transitions, then a blend node's weights) made in place
+    on oracle2's machine objects and through fyx_machine_clear + builder calls + the state restore on the device."""
+    import oracle2
+    import test_machine_edits as E
+    for make, edits in ((cases.transitions, {8: E.edit_retime, 12: E.edit_grow, 34: E.edit_recondition}),
+                        (cases.layered, {9: E.edit_reweight, 21: E.edit_layer_weight_and_mask, 26: E.edit_swap_clip}),
+                        (cases.by_index, {6: E.edit_by_index_times, 31: E.edit_grow})):
+        sc = make()
+        o = cases.build_oracle(oracle2, sc)
+        p = cases.build_product(ctx, sc, 2)
+        desc = sc.machine
+        for f in range(min(sc.n_frames, 48)):
+            for idx, par in sc.script.get(f, []):
+                o.set_parameter(idx, par)
+                p.set_parameter(idx, par)
+            if f in edits:
+                new, in_place, maps = edits[f](desc)
+                for li in range(len(desc.layers)):
+                    _drain(lambda: o.pop_layer_event(li))
+                in_place(o.machine)
+                p.rebuild_machine(desc, new, **maps)
+                desc = new
+            o.update_machine(sc.dt)
+            p.update_machine(sc.dt)
+            sc.machine = desc                     # check_frame walks the current definition's layers
+            check_frame(p, o, sc, 2, f)
+        o.close()
+        p.free()
+
+
 def test_quaternion_only_blend_tree_is_bit_exact(ctx, orc):
     sc = cases.c5_blend_tree(euler_every=10 ** 9)
     assert not sc.has_euler

@@ -29,7 +29,7 @@ is_none is_some insert get get_mut entry or_insert push extend_from_slice as_ptr
 to_string_lossy into_owned into clone then copy_from_slice is_empty with_capacity flat_map and_then contains default
 to_rotation_matrix matrix try_inverse identity new new_unchecked from_ptr null null_mut keys values
 """.split())
-SHIM_OWN = set("raw id check node from_parts upload_tracks create_rig create_bone_list from_player attach_machine sync_parameters".split())
+SHIM_OWN = set("raw id check node from_parts upload_tracks create_rig create_bone_list from_player attach_machine sync_parameters rebuild_machine reset_layer".split())
 
 
 def ref_sources():
@@ -167,7 +167,10 @@ def main():
             if fld in pub_fields or fld in ("x", "y", "z", "w", "coords", "0", "start", "end", "ctx", "hip", "id", "n_instances",
                                             "signal_names", "index_of", "rig_id", "animation_index", "parameter_index", "positions",
                                             "normals", "tangents", "aabb", "has", "delta_position", "delta_rotation", "present", "kind",
-                                            "value", "len"):
+                                            "value", "len",
+                                            # LayerMaps / SavedLayer of fyrox_hip_flatten.rs (the shim's own structs)
+                                            "layers", "node_index", "state_index", "transition_index", "by_index_nodes",
+                                            "active_state", "active_transition", "transitions", "by_index"):
                 continue
             if fld in pub_fns or fld in trait_fns:        # a method reference passed as a value
                 continue
