@@ -2,7 +2,7 @@
 # Host-side memory check of the control plane (no GPU needed): builds an AddressSanitizer variant of libfyrox_hip.so
 # into /tmp (device code is not instrumented), swaps it in for the run and puts the real library back afterwards,
 # then runs the control-only tests -- planners (threaded crowd / scene planning included), event queues, builders,
-# 40 fuzzed machines -- under it.
+# 40 fuzzed machines, run-time edits of machines (clear + rebuild + state restore) -- under it.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=/tmp/fyx_asan; mkdir -p $OUT
@@ -16,4 +16,4 @@ RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | he
 cp $ROOT/fyrox_amd/libfyrox_hip.so $OUT/libfyrox_hip.real.so
 trap 'cp $OUT/libfyrox_hip.real.so $ROOT/fyrox_amd/libfyrox_hip.so' EXIT
 cp $OUT/libfyrox_hip.so $ROOT/fyrox_amd/libfyrox_hip.so
-cd $ROOT && LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 python -m pytest tests/test_anim_control.py tests/test_abi.py -x -q -p no:cacheprovider
+cd $ROOT && LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 python -m pytest tests/test_anim_control.py tests/test_machine_edits.py tests/test_abi.py -x -q -p no:cacheprovider
