@@ -41,6 +41,29 @@ impl HipSkinning {
         }
     }
 
+    /// One engine process, several GPUs: a context per device, joined into one RCCL communicator (`fyx_comm_init_all`;
+    /// contexts[i] is rank i).  Every later call on them comes from this same thread, as the engine's update does.
+    pub fn new_on_devices(devices: &[i32]) -> Result<Vec<Self>, HipError> {
+        let mut all = Vec::with_capacity(devices.len());
+        for d in devices {
+            all.push(Self::new(*d)?);
+        }
+        let raw: Vec<*mut FyxCtx> = all.iter().map(|h| h.ctx).collect();
+        let rc = unsafe { fyx_comm_init_all(raw.as_ptr(), raw.len() as i32) };
+        check_rc(raw[0], rc)?;
+        Ok(all)
+    }
+
+    /// The exchange step of a mesh sharded by vertex range over the GPUs of `new_on_devices` (`fyx_shard_vertex_range`):
+    /// every GPU has skinned its shard in place into its own full-size streams; afterwards every GPU holds every shard.
+    /// `pos` / `normal` / `tangent`: one device address per GPU, or an empty slice for a stream that is not exchanged.
+    pub fn allgather_skinned_all(all: &mut [Self], n_verts: u32, pos: &[*mut f32], normal: &[*mut f32], tangent: &[*mut f32]) -> Result<(), HipError> {
+        let raw: Vec<*mut FyxCtx> = all.iter().map(|h| h.ctx).collect();
+        let p = |s: &[*mut f32]| if s.is_empty() { ptr::null() } else { s.as_ptr() };
+        let rc = unsafe { fyx_allgather_skinned_all(raw.as_ptr(), raw.len() as i32, n_verts, p(pos), p(normal), p(tangent)) };
+        check_rc(raw[0], rc)
+    }
+
     /// The raw context for the other files of the shim (`fyrox_hip_flatten.rs`).
     pub(super) fn raw(&self) -> *mut FyxCtx {
         self.ctx

@@ -178,6 +178,8 @@ _SIGS = {
     "fyx_shard_vertex_range": (c_int, [c_uint32, c_int, c_int, POINTER(c_uint32), POINTER(c_uint32)]),
     "fyx_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int)]),
     "fyx_allgather_skinned": (c_int, [_P, c_uint32, _P, _P, _P]),
+    "fyx_comm_init_all": (c_int, [_P, c_int]),
+    "fyx_allgather_skinned_all": (c_int, [_P, c_int, c_uint32, _P, _P, _P]),
     "fyx_animator_plan_root_motion": (c_int, [_P, c_uint64, _P, _P, c_uint32, POINTER(c_uint32), POINTER(c_uint32), _P]),
 }
 

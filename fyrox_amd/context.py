@@ -167,6 +167,26 @@ class Context:
         self._check(self._l.fyx_allgather_skinned(self._h, n_verts, d_pos_all or None, d_normal_all or None,
                                                   d_tangent_all or None))
 
+    # -- one process, several GPUs (every call from one thread) ---------------------------
+    @staticmethod
+    def comm_init_all(contexts) -> None:
+        """fyx_comm_init_all: contexts[i] (each on its own GPU) becomes rank i of len(contexts)."""
+        arr = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
+        contexts[0]._check(contexts[0]._l.fyx_comm_init_all(arr, len(contexts)))
+
+    @staticmethod
+    def allgather_skinned_all(contexts, n_verts: int, d_pos_all=None, d_normal_all=None, d_tangent_all=None) -> None:
+        """fyx_allgather_skinned_all: d_*_all[i] = device address of context i's FULL stream (None: the stream is not
+        exchanged); every context has written its own shard in place."""
+        def arr(ptrs):
+            if ptrs is None:
+                return None
+            assert len(ptrs) == len(contexts)
+            return (ctypes.c_void_p * len(ptrs))(*[int(p) if p else None for p in ptrs])
+        h = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
+        contexts[0]._check(contexts[0]._l.fyx_allgather_skinned_all(h, len(contexts), n_verts, arr(d_pos_all), arr(d_normal_all),
+                                                                    arr(d_tangent_all)))
+
     # -- mesh registry -------------------------------------------------------------------
     def mesh_upload(self, mesh_id: int, aos: np.ndarray, n_verts: int, stride: int, *, off_pos: int,
                     off_normal: int = -1, off_tangent: int = -1, off_weights: int, off_indices: int) -> None:

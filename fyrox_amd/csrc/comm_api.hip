@@ -197,4 +197,99 @@ int fyx_allgather_skinned(fyx_ctx* c, uint32_t n_verts, float* d_pos_all, float*
     FYX_GUARD_END(c)
 }
 
+// ---- one process, several GPUs: every collective of the process is issued by one thread inside one RCCL group ----
+
+int fyx_comm_init_all(fyx_ctx* const* ctxs, int n) {
+    if (!ctxs || n < 1) return FYX_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]) return FYX_ERR_INVALID_ARG;
+    fyx_ctx* c = ctxs[0];
+    FYX_GUARD_BEGIN
+    for (int i = 0; i < n; ++i) {
+        if (ctxs[i]->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "context %d is control-only", i);
+        if (ctxs[i]->comm && ctxs[i]->comm->comm) return fail(c, FYX_ERR_INVALID_ARG, "context %d already has a communicator", i);
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i] || ctxs[j]->device == ctxs[i]->device)
+                return fail(c, FYX_ERR_INVALID_ARG, "contexts %d and %d are on the same GPU (one rank per GPU)", j, i);
+    }
+    Comm& k0 = comm_of(c);
+    if (int rc = load_rccl(c, k0)) return rc;
+    for (int i = 1; i < n; ++i)
+        if (int rc = load_rccl(ctxs[i], comm_of(ctxs[i]))) return fail(c, rc, "context %d: %s", i, ctxs[i]->err.c_str());
+    FYX_HIP(c, hipSetDevice(c->device));
+    RcclId id;
+    int rc = k0.get_unique_id(&id);
+    if (rc) return rccl_fail(c, k0, rc, "ncclGetUniqueId");
+    rc = k0.group_start();
+    if (rc) return rccl_fail(c, k0, rc, "ncclGroupStart");
+    int first_err = 0;
+    for (int i = 0; i < n && !first_err; ++i) {
+        Comm& k = *ctxs[i]->comm;
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) { first_err = -1; break; }
+        first_err = k.comm_init_rank(&k.comm, n, id, i);
+    }
+    rc = k0.group_end();
+    (void)hipSetDevice(c->device);
+    if (first_err || rc) {
+        for (int i = 0; i < n; ++i) {      // no half-made communicator is left behind
+            Comm& k = *ctxs[i]->comm;
+            if (k.comm) { (void)k.comm_destroy(k.comm); k.comm = nullptr; }
+        }
+        if (first_err == -1) return fail(c, FYX_ERR_HIP, "hipSetDevice failed while joining the communicator");
+        return rccl_fail(c, k0, first_err ? first_err : rc, first_err ? "ncclCommInitRank" : "ncclGroupEnd");
+    }
+    for (int i = 0; i < n; ++i) { ctxs[i]->comm->rank = i; ctxs[i]->comm->n_ranks = n; }
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, float* const* d_pos_all, float* const* d_normal_all,
+                              float* const* d_tangent_all) {
+    if (!ctxs || n < 1) return FYX_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]) return FYX_ERR_INVALID_ARG;
+    fyx_ctx* c = ctxs[0];
+    FYX_GUARD_BEGIN
+    for (int i = 0; i < n; ++i) {
+        const Comm* k = ctxs[i]->comm;
+        if (!k || !k->comm) return fail(c, FYX_ERR_INVALID_ARG, "context %d has no communicator: call fyx_comm_init_all first", i);
+        if (k->n_ranks != n || k->rank != i) return fail(c, FYX_ERR_INVALID_ARG, "context %d is rank %d of %d: pass the contexts of fyx_comm_init_all, in order", i, k->rank, k->n_ranks);
+    }
+    if (n_verts == 0 || (!d_pos_all && !d_normal_all && !d_tangent_all)) return FYX_OK;
+    float* const* sets[3] = {d_pos_all, d_normal_all, d_tangent_all};
+    for (int s = 0; s < 3; ++s)
+        if (sets[s])
+            for (int i = 0; i < n; ++i)
+                if (!sets[s][i]) return fail(c, FYX_ERR_INVALID_ARG, "stream %d is null on context %d (every GPU holds the same set of streams)", s, i);
+    // every GPU's shard must be complete before it is sent: the GPU-side join of its skinning launches, on its own stream
+    for (int i = 0; i < n; ++i)
+        if (int rc = enter_primary(ctxs[i])) return i == 0 ? rc : fail(c, rc, "context %d: %s", i, ctxs[i]->err.c_str());
+    Comm& k0 = *c->comm;
+    constexpr int kNcclFloat32 = 7;   // rccl.h: ncclFloat32
+    const uint32_t widths[3] = {3, 3, 4};
+    int rc = k0.group_start();
+    if (rc) return rccl_fail(c, k0, rc, "ncclGroupStart");
+    int first_err = 0;
+    for (int i = 0; i < n && !first_err; ++i) {
+        Comm& k = *ctxs[i]->comm;
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) { first_err = -1; break; }
+        for (int s = 0; s < 3 && !first_err; ++s) {
+            if (!sets[s]) continue;
+            for (int r = 0; r < n && !first_err; ++r) {
+                const uint32_t b = shard_cut(n_verts, (uint64_t)r, (uint64_t)n), e = shard_cut(n_verts, (uint64_t)r + 1, (uint64_t)n);
+                if (e == b) continue;
+                float* at = sets[s][i] + (size_t)b * widths[s];
+                first_err = k.broadcast(at, at, (size_t)(e - b) * widths[s], kNcclFloat32, r, k.comm, ctxs[i]->stream);
+            }
+        }
+    }
+    rc = k0.group_end();
+    (void)hipSetDevice(c->device);
+    if (first_err == -1) return fail(c, FYX_ERR_HIP, "hipSetDevice failed inside the exchange");
+    if (first_err) return rccl_fail(c, k0, first_err, "ncclBroadcast");
+    if (rc) return rccl_fail(c, k0, rc, "ncclGroupEnd");
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
 }  // extern "C"

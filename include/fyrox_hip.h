@@ -679,6 +679,21 @@ int fyx_comm_info(fyx_ctx* ctx, int* rank, int* n_ranks);
  * owner, ncclGroupEnd -- on the context stream, after the GPU-side join of the skinning launches in flight.  All ranks
  * must pass the same n_verts and the same set of non-null streams. */
 int fyx_allgather_skinned(fyx_ctx* ctx, uint32_t n_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all);
+/* ONE PROCESS driving several GPUs -- the engine is one process with one update thread, so this is the
+ * form its shim uses: contexts ctxs[0..n) made by fyx_init on n different devices, every call from the same thread.
+ * RCCL requires a thread that drives several communicators to issue each collective for all of them inside one group,
+ * hence the array forms:
+ *   fyx_comm_init_all       ncclGetUniqueId + one grouped ncclCommInitRank per context: ctxs[i] becomes rank i of n
+ *                           (no id to hand around).  Fails as a whole: no context keeps a half-made communicator.
+ *   fyx_allgather_skinned_all   fyx_allgather_skinned for every GPU at once: d_*_all[i] is context i's FULL stream on its
+ *                           own device, of which it has written shard i (fyx_shard_vertex_range(n_verts, i, n)) in
+ *                           place; a stream is either null (the array pointer) for all GPUs or non-null for all.  Each
+ *                           GPU's part is ordered on its own context stream after its skinning launches in flight.
+ * Errors are reported on ctxs[0] (fyx_last_error).  The per-context calls above stay the form for one process (or thread)
+ * per GPU; the two must not be mixed on one communicator. */
+int fyx_comm_init_all(fyx_ctx* const* ctxs, int n);
+int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, float* const* d_pos_all,
+                              float* const* d_normal_all, float* const* d_tangent_all);
 
 /* ---- control plane without a GPU ----------------------------------------------------- */
 /* A context with no device: registry and control-plane calls work, every call that would touch

@@ -124,3 +124,26 @@ def test_options_are_validated_and_readable_without_a_gpu():
             c.get_option("no.such.option")
     finally:
         c.close()
+
+
+def test_one_process_exchange_refuses_contexts_without_a_gpu():
+    """fyx_comm_init_all / fyx_allgather_skinned_all: argument errors are error codes on ctxs[0], nothing needs a device."""
+    import ctypes
+    import fyrox_amd
+    from fyrox_amd import _native
+    a, b = fyrox_amd.Context(control_only=True), fyrox_amd.Context(control_only=True)
+    try:
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            fyrox_amd.Context.comm_init_all([a, b])
+        assert e.value.code == _native.FYX_ERR_NO_DEVICE
+        with pytest.raises(fyrox_amd.FyxError):
+            fyrox_amd.Context.allgather_skinned_all([a], 100, [0], None, None)       # no communicator
+        lib = _native.lib()
+        assert lib.fyx_comm_init_all(None, 1) == _native.FYX_ERR_INVALID_ARG
+        arr = (ctypes.c_void_p * 2)(a._h, None)
+        assert lib.fyx_comm_init_all(arr, 2) == _native.FYX_ERR_INVALID_ARG
+        assert lib.fyx_comm_init_all(arr, 0) == _native.FYX_ERR_INVALID_ARG
+        assert lib.fyx_allgather_skinned_all(arr, 2, 10, None, None, None) == _native.FYX_ERR_INVALID_ARG
+    finally:
+        a.close()
+        b.close()

@@ -879,6 +879,56 @@ def test_single_rank_communicator_all_gathers_a_skinned_shard(ctx, orc):
     ctx.mesh_free(7101)
 
 
+def test_one_process_form_of_the_exchange(ctx, orc):
+    """fyx_comm_init_all / fyx_allgather_skinned_all -- one process (one thread) driving every GPU, the engine's shape --
+    as far as one GPU can take them: a communicator of one context, the in-place exchange ordered after the skinning
+    launches, and the refusals (two contexts on one GPU, contexts out of order, a stream missing on one GPU).  With more
+    GPUs the same calls issue one grouped RCCL operation over all communicators; that has not run here."""
+    m = synth.make_mesh(30_011, 32, synth.SEED_BASE + 43)
+    pal = synth.make_palette(32, synth.SEED_BASE + 43)
+    other = fyrox_amd.Context(0)                       # a second context on the same GPU
+    try:
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            fyrox_amd.Context.comm_init_all([ctx, other])
+        assert "same GPU" in str(e.value)
+        for c in (ctx, other):                         # and nobody keeps half a communicator
+            with pytest.raises(fyrox_amd.FyxError):
+                c.comm_info()
+        try:
+            fyrox_amd.Context.comm_init_all([ctx])
+        except fyrox_amd.FyxError as err:
+            if err.code == fyrox_amd._native.FYX_ERR_UNSUPPORTED or "ncclGetUniqueId" in str(err) or "ncclCommInitRank" in str(err):
+                pytest.skip(f"RCCL could not initialise here: {err}")
+            raise
+        assert ctx.comm_info() == (0, 1)
+        with pytest.raises(fyrox_amd.FyxError):
+            fyrox_amd.Context.comm_init_all([ctx])     # one communicator per context
+        ctx.mesh_upload_soa(7102, m.pos, m.weights, m.indices, m.normal, m.tangent)
+        d_pal = ctx.to_device(pal)
+        n = m.n_verts
+        d_p, d_n, d_t = ctx.malloc(n * 12), ctx.malloc(n * 12), ctx.malloc(n * 16)
+        ctx.lbs_skin_device(7102, d_pal.ptr, 32, 1, d_p.ptr, d_n.ptr, d_t.ptr)
+        fyrox_amd.Context.allgather_skinned_all([ctx], n, [d_p.ptr], [d_n.ptr], [d_t.ptr])
+        fyrox_amd.Context.allgather_skinned_all([ctx], n, [d_p.ptr], None, [d_t.ptr])     # any subset of the streams
+        ctx.sync()
+        ref = orc.lbs_skin(m.pos, m.weights, m.indices, pal, m.normal, m.tangent, threads=0)
+        assert np.array_equal(d_p.download(np.float32, n * 3).reshape(n, 3), ref["pos"])
+        assert np.array_equal(d_n.download(np.float32, n * 3).reshape(n, 3), ref["normal"])
+        assert np.array_equal(d_t.download(np.float32, n * 4).reshape(n, 4), ref["tangent"])
+        with pytest.raises(fyrox_amd.FyxError):
+            fyrox_amd.Context.allgather_skinned_all([ctx], n, [0], None, None)            # a stream missing on a GPU
+        with pytest.raises(fyrox_amd.FyxError):
+            fyrox_amd.Context.allgather_skinned_all([ctx, other], n, [d_p.ptr, d_p.ptr], None, None)   # not the communicator's contexts
+        with pytest.raises(fyrox_amd.FyxError):
+            fyrox_amd.Context.allgather_skinned_all([other], n, [d_p.ptr], None, None)    # no communicator there
+        ctx.comm_shutdown()
+        for d in (d_pal, d_p, d_n, d_t):
+            d.free()
+        ctx.mesh_free(7102)
+    finally:
+        other.close()
+
+
 # ---- fyx_lbs_skin_batch: many (mesh, palette) pairs, one launch -------------------------------------------------
 
 def _batch_scene(ctx, base_id, specs, seed0):

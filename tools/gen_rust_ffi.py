@@ -31,24 +31,21 @@ def rust_name(c_struct: str) -> str:
 
 
 def map_type(ctype: str, structs) -> str:
-    t = ctype.strip()
-    const = False
-    ptr = t.count("*")
-    t = t.replace("*", " ").split()
-    if "const" in t:
-        const = True
-        t = [x for x in t if x != "const"]
-    t = [x for x in t if x != "struct"]
-    base = " ".join(t)
+    """C declarator -> Rust: the qualifiers are read level by level (`const T*` / `T const*` qualify the pointee,
+    `T* const*` the inner pointer): `const float*` -> *const f32, `fyx_ctx**` -> *mut *mut FyxCtx,
+    `fyx_ctx* const*` -> *const *mut FyxCtx, `float* const*` -> *const *mut f32."""
+    levels = [lv.split() for lv in ctype.strip().split("*")]       # [base tokens][qualifiers after the 1st *][after the 2nd] ...
+    base_tokens = [x for x in levels[0] if x not in ("const", "struct")]
+    consts = ["const" in lv for lv in levels]                      # consts[i]: what the (i+1)-th pointer points at is const
+    base = " ".join(base_tokens)
     if base in SCALARS:
         r = SCALARS[base]
     elif base in structs or base == "fyx_ctx":
         r = rust_name(base)
     else:
         raise ValueError(f"unmapped C type {ctype!r}")
-    for i in range(ptr):
-        # `const T*` -> *const T ; `T**` (out parameters) -> *mut *mut T
-        r = ("*const " if (const and i == 0) else "*mut ") + r
+    for i in range(len(levels) - 1):
+        r = ("*const " if consts[i] else "*mut ") + r
     return r
 
 
