@@ -3,7 +3,10 @@
 //
 //   host_parity --control-only   no GPU needed: builds an AnimationPlayer-style animator, plans frames through the
 //                                host control plane and compares the sample times / clocks with the oracle's
-//                                Animation::tick; every data-path call must answer FYX_ERR_NO_DEVICE.
+//                                Animation::tick; a two-state Machine re-sent four times (fyx_machine_clear + builder
+//                                calls + run-time state put back), three of them inside a transition, stays in step
+//                                with the oracle's untouched machine; every data-path call must answer
+//                                FYX_ERR_NO_DEVICE.
 //   host_parity                  BASELINE config C1 on the GPU: one SurfaceData of 1 k AnimatedVertex vertices /
 //                                4 bones, fyx_mesh_upload + fyx_lbs_skin + fyx_skinned_aabb, bit-exact vs the oracle;
 //                                then a 4-bone clip through fyx_animation_player_update -> fyx_animator_palette.
@@ -105,6 +108,112 @@ static int build_animator(fyx_ctx* ctx, const Clip& clip, int n_bones, uint32_t 
     return 0;
 }
 
+// idle <-> walk on a Rule parameter (0.2 s transitions), the way an engine-side shim sends a Machine -- and sends it AGAIN
+// after the game has edited it (fyx_machine_clear + builder calls + the run-time state put back): here the definition is
+// unchanged and re-sent in the middle of a transition, so the oracle's untouched machine must stay in step.
+static int send_machine(fyx_ctx* ctx, uint64_t id) {
+    uint32_t par = 0, layer = 0, n0 = 0, n1 = 0, s0 = 0, s1 = 0, t = 0;
+    CHECK(fyx_machine_add_parameter(ctx, id, FYX_PARAM_RULE, 0.0f, 0.0f, 0, &par));
+    CHECK(fyx_machine_add_layer(ctx, id, 1.0f, &layer));
+    CHECK(fyx_layer_add_play_animation(ctx, id, layer, 0, &n0));
+    CHECK(fyx_layer_add_play_animation(ctx, id, layer, 1, &n1));
+    CHECK(fyx_layer_add_state(ctx, id, layer, (int32_t)n0, &s0));
+    CHECK(fyx_layer_add_state(ctx, id, layer, (int32_t)n1, &s1));
+    const int32_t go[2] = {FYX_LOGIC_PARAMETER, (int32_t)par}, back[3] = {FYX_LOGIC_NOT, FYX_LOGIC_PARAMETER, (int32_t)par};
+    CHECK(fyx_layer_add_transition(ctx, id, layer, s0, s1, 0.2f, go, 2, &t));
+    CHECK(fyx_layer_add_transition(ctx, id, layer, s1, s0, 0.2f, back, 3, &t));
+    return 0;
+}
+
+static int machine_rebuilt_mid_transition(fyx_ctx* ctx, const Clip& clip, fo_tracks* td) {
+    const uint64_t id = 3;
+    const uint32_t n_inst = 2;
+    CHECK(fyx_animator_create(ctx, id, 1, n_inst));
+    fo_animation* oa[2];
+    for (int a = 0; a < 2; ++a) {
+        uint32_t index = 0;
+        CHECK(fyx_animator_add_animation(ctx, id, 10, clip.target.data(), nullptr, &index));
+        CHECK(fyx_animation_set_speed(ctx, id, index, FYX_ALL_INSTANCES, a ? 2.5f : 0.75f));
+        oa[a] = fo_animation_new(td);
+        for (size_t t = 0; t < clip.target.size(); ++t) fo_animation_bind(oa[a], (int)t, clip.target[t], 1);
+        fo_animation_set_speed(oa[a], a ? 2.5f : 0.75f);
+    }
+    if (send_machine(ctx, id)) return 1;
+    fo_machine* om = fo_machine_new();
+    fo_machine_add_parameter(om, FYX_PARAM_RULE, 0.0f, 0.0f, 0);
+    fo_machine_add_layer(om, 1.0f);
+    fo_layer_add_play(om, 0, 0);
+    fo_layer_add_play(om, 0, 1);
+    fo_layer_add_state(om, 0, 0);
+    fo_layer_add_state(om, 0, 1);
+    const int go[2] = {FYX_LOGIC_PARAMETER, 0}, back[3] = {FYX_LOGIC_NOT, FYX_LOGIC_PARAMETER, 0};
+    fo_layer_add_transition(om, 0, 0, 1, 0.2f, go, 2);
+    fo_layer_add_transition(om, 0, 1, 0, 0.2f, back, 3);
+    int rebuilt_in_transition = 0;
+    for (int frame = 0; frame < 40; ++frame) {
+        if (frame == 5 || frame == 22) {
+            const uint32_t on = frame == 5 ? 1u : 0u;
+            CHECK(fyx_machine_set_parameter(ctx, id, 0, FYX_ALL_INSTANCES, FYX_PARAM_RULE, 0.0f, 0.0f, on));
+            fo_machine_set_parameter(om, 0, FYX_PARAM_RULE, 0.0f, 0.0f, on);
+        }
+        if (frame == 7 || frame == 8 || frame == 25 || frame == 31) {     // the game edited its Machine: send it again
+            int32_t st[2][2];
+            float tr[2][2][2];
+            int kind[2];
+            float f0[2], f1[2];
+            uint32_t u[2];
+            for (uint32_t i = 0; i < n_inst; ++i) {
+                CHECK(fyx_layer_get_state(ctx, id, 0, i, &st[i][0], &st[i][1]));
+                for (uint32_t t = 0; t < 2; ++t) CHECK(fyx_layer_get_transition_state(ctx, id, 0, i, t, &tr[i][t][0], &tr[i][t][1]));
+                CHECK(fyx_machine_get_parameter(ctx, id, 0, i, &kind[i], &f0[i], &f1[i], &u[i]));
+                fyx_layer_event ev;
+                int has = 1;
+                while (has) CHECK(fyx_layer_pop_event(ctx, id, 0, i, &ev, &has));      // they do not survive the clear
+            }
+            if (st[0][1] >= 0) ++rebuilt_in_transition;
+            CHECK(fyx_machine_clear(ctx, id));
+            int32_t dummy = 0;
+            if (fyx_layer_get_state(ctx, id, 0, 0, &dummy, &dummy) == 0) { std::printf("FAIL: a layer survived fyx_machine_clear\n"); return 1; }
+            if (send_machine(ctx, id)) return 1;
+            for (uint32_t i = 0; i < n_inst; ++i) {
+                CHECK(fyx_machine_set_parameter(ctx, id, 0, i, kind[i], f0[i], f1[i], u[i]));
+                CHECK(fyx_layer_set_state(ctx, id, 0, i, st[i][0], st[i][1]));
+                for (uint32_t t = 0; t < 2; ++t) CHECK(fyx_layer_set_transition_state(ctx, id, 0, i, t, tr[i][t][0], tr[i][t][1]));
+            }
+        }
+        float times[4];
+        uint8_t ticked[4];
+        uint32_t off[3], n_ops = 0;
+        std::vector<uint32_t> ops(2 * 256);
+        CHECK(fyx_animator_plan(ctx, id, 1, 1.0f / 30.0f, times, ticked, off, ops.data(), 256, &n_ops));
+        fo_machine_evaluate_pose(om, oa, 2, 1.0f / 30.0f);
+        for (uint32_t i = 0; i < n_inst; ++i) {
+            int32_t s = 0, t = 0;
+            CHECK(fyx_layer_get_state(ctx, id, 0, i, &s, &t));
+            float c0 = 0.0f, c1 = 0.0f;
+            CHECK(fyx_animation_get_state(ctx, id, 0, i, &c0, nullptr, nullptr));
+            CHECK(fyx_animation_get_state(ctx, id, 1, i, &c1, nullptr, nullptr));
+            if (s != fo_layer_active_state(om, 0) || t != fo_layer_active_transition(om, 0) || c0 != fo_animation_time_position(oa[0]) ||
+                c1 != fo_animation_time_position(oa[1])) {
+                std::printf("FAIL machine frame %d instance %u: state %d / transition %d (oracle %d / %d), clocks %.9g %.9g (oracle %.9g %.9g)\n",
+                            frame, i, s, t, fo_layer_active_state(om, 0), fo_layer_active_transition(om, 0), c0, c1,
+                            fo_animation_time_position(oa[0]), fo_animation_time_position(oa[1]));
+                return 1;
+            }
+        }
+        if (std::memcmp(ops.data() + 2 * off[0], ops.data() + 2 * off[1], (size_t)(off[1] - off[0]) * 8) != 0) {
+            std::printf("FAIL machine frame %d: the two instances planned different programs\n", frame);
+            return 1;
+        }
+    }
+    if (rebuilt_in_transition < 2) { std::printf("FAIL: the test no longer re-sends the machine inside a transition\n"); return 1; }
+    fo_machine_free(om);
+    fo_animation_free(oa[0]);
+    fo_animation_free(oa[1]);
+    std::printf("machine re-sent 4 times (%d inside a transition): states, transitions and clocks equal the oracle's\n", rebuilt_in_transition);
+    return 0;
+}
+
 static int control_only() {
     fyx_ctx* ctx = nullptr;
     if (fyx_init_control_only(&ctx) != 0) { std::printf("FAIL fyx_init_control_only\n"); return 1; }
@@ -131,6 +240,7 @@ static int control_only() {
             return 1;
         }
     }
+    if (machine_rebuilt_mid_transition(ctx, clip, td)) return 1;
     // no GPU behind this context: the data path must refuse, not fall back
     if (fyx_animation_player_update(ctx, 2, 0.1f) != FYX_ERR_NO_DEVICE || fyx_sync(ctx) != FYX_ERR_NO_DEVICE) {
         std::printf("FAIL: a control-only context ran a data-path call\n");
