@@ -174,7 +174,8 @@ struct Animator {
     std::vector<uint32_t> prog_off;
     std::vector<uint2> prev_ops;            // last frame's programs (the memo's source)
     std::vector<uint32_t> prev_prog_off;
-    std::vector<std::vector<std::vector<uint32_t>>> state_anims;   // [layer][state]: animations its pose tree plays (per frame)
+    std::vector<std::vector<std::vector<uint32_t>>> state_anims;   // [layer][state]: animations its pose tree plays
+    uint64_t state_anims_gen = 0;           // edit_gen the lists were made at
     int prev_mode = -2;                     // mode of the frame planned last
     uint64_t edit_gen = 1;                  // bumped by every API call on the animator other than update / plan
     bool memo_static_ok = false;            // no layer has a BlendAnimationsByIndex node, no root motion (set per frame)

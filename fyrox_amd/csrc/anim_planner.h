@@ -675,7 +675,10 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
     A.prog_off.swap(A.prev_prog_off);
     if (mode != 1 || A.prev_mode != 1) ++A.edit_gen;
     A.prev_mode = mode;
-    if (mode == 1) {   // which animations a state's pose tree plays (node/mod.rs:116-150): the same for every instance
+    // which animations a state's pose tree plays (node/mod.rs:116-150): the same for every instance, and the same as last
+    // frame unless an API call touched the animator in between (edit_gen)
+    if (mode == 1 && A.state_anims_gen != A.edit_gen) {
+        A.state_anims_gen = A.edit_gen;
         struct Walk {
             static void go(const LayerDef& L, int32_t h, std::vector<uint32_t>& out, int depth) {
                 if (h < 0 || (size_t)h >= L.nodes.size() || depth > 64) return;
