@@ -391,7 +391,72 @@ def extras(ctx) -> dict:
         ctx.set_option("lbs.streams", streams)
     out["scene_64x4"] = _scene_record(ctx, 64, 4, 20_000, 1_000_000)
     out["scene_256x1"] = _scene_record(ctx, 256, 1, 5_000, 2_000_000)
+    out["host_control_plane"] = _host_control_plane_record()
     return out
+
+
+def _host_control_plane_record(frames: int = 200) -> dict:
+    """The host half of the pose path ALONE, on this box's cores (a control-only context: no GPU involved): microseconds
+    per frame to plan C3's 1000 machines (with the fold-program memo and from scratch) and a scene of 256 single-instance
+    characters -- what tools/bench_planner.py and tools/bench_scene_planner.py measure.  Never fails the line."""
+    try:
+        import fyrox_amd
+        from fyrox_amd import anim as A, synth
+        c = fyrox_amd.Context(control_only=True)
+        try:
+            seed = synth.SEED_BASE + 3
+            rig = synth.make_rig(64, seed)
+            A.create_rig(c, 1, rig)
+            tgts = []
+            for k in range(4):
+                td, tgt = synth.make_clip(64, seed, clip=k)
+                A.upload_tracks_data(c, 10 + k, td)
+                tgts.append(tgt)
+
+            def character(animator_id, n_instances):
+                an = A.Animator(c, animator_id, 1, rig, n_instances)
+                for k in range(4):
+                    an.add_animation(10 + k, tgts[k], time_slice=(0.0, 1.0), speed=[1.0, 0.8, 1.3, -0.7][k])
+                an.set_machine(synth.make_c5_machine())
+                return an
+
+            crowd = character(50, 1000)
+            for i in range(1000):
+                for k in range(4):
+                    crowd.set_time_position(k, (i * 0.37 + k * 0.11) % 1.0, instance=i)
+            plan, setloop, splan = c._l.fyx_animator_plan, c._l.fyx_animation_set_loop, c._l.fyx_scene_plan
+            n, dt = ctypes.c_uint32(), ctypes.c_float(1 / 60)
+
+            def best(fn):
+                for _ in range(30):
+                    fn()
+                b = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for _ in range(frames):
+                        fn()
+                    b = min(b, (time.perf_counter() - t0) / frames)
+                return b * 1e6
+
+            memo = best(lambda: plan(c._h, 50, 1, dt, None, None, None, None, 0, ctypes.byref(n)))
+
+            def scratch_frame():
+                setloop(c._h, 50, 0, 0xFFFFFFFF, 1)       # the value it has: only invalidates the memo
+                plan(c._h, 50, 1, dt, None, None, None, None, 0, ctypes.byref(n))
+            scratch = best(scratch_frame)
+            ids = np.arange(100, 356, dtype=np.uint64)
+            for k in ids:
+                character(int(k), 1)
+            p = ids.ctypes.data_as(ctypes.c_void_p)
+            scene = best(lambda: splan(c._h, p, len(ids), dt))
+            return {"workload": "fyx_animator_plan over 1000 instances of the C5 machine (C3's control plane); fyx_scene_plan over 256 "
+                                "single-instance characters; control-only context, calling thread only",
+                    "c3_plan_us_with_memo": memo, "c3_plan_us_from_scratch": scratch, "scene_256x1_plan_us": scene,
+                    "host_threads_available": os.cpu_count()}
+        finally:
+            c.close()
+    except Exception as e:     # noqa: BLE001
+        return {"error": repr(e)}
 
 
 # ---- main ---------------------------------------------------------------------------------------------------------------
