@@ -428,6 +428,38 @@ impl<'a> HipAnimator<'a> {
                 })?;
                 transition_index.insert(th, ti);
             }
+            // The run-time state the objects carry (a scene loaded from a save file is in the middle of whatever it was
+            // doing; from here on the library's copy is the one that moves): active state / transition (layer.rs:432-441),
+            // every transition's blend factor (transition.rs:307; `elapsed_time` has no getter: blend_factor *
+            // transition_time reproduces it to an ulp), prev_index / blend_time of the by-index nodes (node/blend.rs:260-264).
+            let s = state_index.get(&layer.active_state()).map(|i| *i as i32).unwrap_or(-1);
+            let t = transition_index.get(&layer.active_transition()).map(|i| *i as i32).unwrap_or(-1);
+            check_rc(ctx, unsafe { fyx_layer_set_state(ctx, id, li, FYX_ALL_INSTANCES, s, t) })?;
+            for (th, transition) in layer.transitions().pair_iter() {
+                if let Some(ti) = transition_index.get(&th) {
+                    let factor = transition.blend_factor();
+                    check_rc(ctx, unsafe {
+                        fyx_layer_set_transition_state(ctx, id, li, FYX_ALL_INSTANCES, *ti, factor * transition.transition_time(), factor)
+                    })?;
+                }
+            }
+            for h in by_index_nodes.iter() {
+                if let PoseNode::BlendAnimationsByIndex(by_index) = &layer.nodes()[*h] {
+                    let prev = by_index.prev_index.get();
+                    check_rc(ctx, unsafe {
+                        fyx_layer_set_node_state(
+                            ctx,
+                            id,
+                            li,
+                            FYX_ALL_INSTANCES,
+                            node_index[h] as u32,
+                            prev.is_some() as i32,
+                            prev.unwrap_or(0),
+                            by_index.blend_time.get(),
+                        )
+                    })?;
+                }
+            }
             maps.layers.push(LayerMaps { node_index, state_index, transition_index, by_index_nodes });
         }
         Ok(())
@@ -447,6 +479,7 @@ impl<'a> HipAnimator<'a> {
     pub fn rebuild_machine(&mut self, machine: &Machine, rig: &RigMap, maps: &mut AnimatorMaps, n_instances: u32) -> Result<(), HipError> {
         let (ctx, id) = (self.raw(), self.id());
         struct SavedLayer {
+            known_states: Vec<Handle<State>>,
             active_state: Option<Handle<State>>,
             active_transition: Option<Handle<Transition>>,
             transitions: Vec<(Handle<Transition>, f32, f32)>,
@@ -473,6 +506,7 @@ impl<'a> HipAnimator<'a> {
                     by_index.push((*h, has_prev, prev, time));
                 }
                 per_layer.push(SavedLayer {
+                    known_states: lm.state_index.keys().copied().collect(),
                     active_state: lm.state_index.iter().find(|(_, i)| **i as i32 == s).map(|(h, _)| *h),
                     active_transition: lm.transition_index.iter().find(|(_, i)| **i as i32 == t).map(|(h, _)| *h),
                     transitions,
@@ -492,7 +526,15 @@ impl<'a> HipAnimator<'a> {
                     continue; // the layer is gone
                 };
                 let li = li as u32;
-                let s = old.active_state.and_then(|h| lm.state_index.get(&h)).map(|i| *i as i32).unwrap_or(-1);
+                let mut s = old.active_state.and_then(|h| lm.state_index.get(&h)).map(|i| *i as i32).unwrap_or(-1);
+                if old.active_state.is_none() {
+                    // MachineLayer::add_state makes a state active whenever none is (layer.rs:229-235) -- also while a
+                    // transition is in flight: the first state this edit ADDED takes the place
+                    let added = layer_states_added(machine, li as usize, &old.known_states);
+                    if let Some(h) = added {
+                        s = lm.state_index.get(&h).map(|i| *i as i32).unwrap_or(-1);
+                    }
+                }
                 let t = old.active_transition.and_then(|h| lm.transition_index.get(&h)).map(|i| *i as i32).unwrap_or(-1);
                 check_rc(ctx, unsafe { fyx_layer_set_state(ctx, id, li, instance, s, t) })?;
                 for (h, elapsed, factor) in old.transitions.iter() {
@@ -528,6 +570,12 @@ impl<'a> HipAnimator<'a> {
         }
         Ok(())
     }
+}
+
+/// The first state (in pool order) of layer `li` that the shim did not know before the edit.
+fn layer_states_added(machine: &Machine, li: usize, known: &[Handle<State>]) -> Option<Handle<State>> {
+    let layer = machine.layers().get(li)?;
+    layer.states().pair_iter().map(|(h, _)| h).find(|h| !known.contains(h))
 }
 
 /// `Parameter` (machine/parameter.rs:36-50) as the (kind, f0, f1, u) words of `fyx_machine_add_parameter`.

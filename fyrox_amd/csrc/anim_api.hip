@@ -648,11 +648,14 @@ int fyx_layer_add_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, int32_
     StateDef s;
     s.root = root_node;
     L->states.push_back(std::move(s));
-    if (L->entry_state < 0) {  // layer.rs:229-235
-        L->entry_state = (int32_t)L->states.size() - 1;
-        sync_machine_state(*A);
-    }
-    if (out_state) *out_state = (uint32_t)L->states.size() - 1;
+    // layer.rs:229-235: `if self.active_state.is_none() { self.active_state = state }` -- the entry state is NOT touched, and
+    // the test is on active_state alone: a state added while a transition is in flight (active_state is NONE then) becomes
+    // the active one, as in the reference
+    const int32_t idx = (int32_t)L->states.size() - 1;
+    if (L->initial_active < 0) L->initial_active = idx;
+    for (MachineState& m : A->mstate)
+        if (layer < m.layers.size() && m.layers[layer].active_state < 0) { m.layers[layer].active_state = idx; m.memo_valid = false; }
+    if (out_state) *out_state = (uint32_t)idx;
     return FYX_OK;
     FYX_GUARD_END(c)
 }
@@ -663,7 +666,7 @@ int fyx_layer_set_entry_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, 
     FYX_ANIMATOR(c, A, animator_id);
     FYX_LAYER(c, A, L, layer);
     if (state >= L->states.size()) return fail(c, FYX_ERR_INVALID_ARG, "state %u does not exist", state);
-    L->entry_state = (int32_t)state;
+    L->entry_state = L->initial_active = (int32_t)state;
     for (MachineState& m : A->mstate) m.layers[layer].active_state = (int32_t)state;  // layer.rs:209-212
     return FYX_OK;
     FYX_GUARD_END(c)
@@ -754,7 +757,7 @@ int fyx_layer_get_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, uint32
     FYX_ANIMATOR_RO(c, A, animator_id);
     FYX_LAYER(c, A, L, layer);
     if (instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
-    int32_t as = L->entry_state, at = -1;
+    int32_t as = L->initial_active, at = -1;
     if (A->mstate.size() == A->n_instances) {
         as = A->mstate[instance].layers[layer].active_state;
         at = A->mstate[instance].layers[layer].active_transition;

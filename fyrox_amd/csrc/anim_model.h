@@ -97,7 +97,9 @@ struct LayerDef {
     std::vector<PoseNodeDef> nodes;
     std::vector<StateDef> states;
     std::vector<TransitionDef> transitions;
-    int32_t entry_state = -1;
+    int32_t entry_state = -1;       // MachineLayer::entry_state: set by set_entry_state ONLY (layer.rs:209-212); reset() returns to it
+    int32_t initial_active = -1;    // what active_state is on a machine that has only been built: add_state makes the first
+                                    // state active when none is (layer.rs:229-235), set_entry_state overrides
     std::vector<int32_t> excluded;
     uint32_t by_index_count = 0;
 };

@@ -583,10 +583,11 @@ struct Planner {
 void sync_machine_state(Animator& A) {
     for (MachineState& m : A.mstate) {
         while (m.params.size() < A.param_defaults.size()) m.params.push_back(A.param_defaults[m.params.size()]);
+        const size_t had = m.layers.size();
         m.layers.resize(A.layers.size());
         for (size_t l = 0; l < A.layers.size(); ++l) {
             LayerState& LS = m.layers[l];
-            if (LS.active_state < 0 && LS.active_transition < 0) LS.active_state = A.layers[l].entry_state;
+            if (l >= had) LS.active_state = A.layers[l].initial_active;   // a state of its own from here on
             LS.transitions.resize(A.layers[l].transitions.size());
             LS.by_index.resize(A.layers[l].by_index_count);
         }

@@ -505,7 +505,10 @@ int fyx_layer_add_blend_space(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer
                               int32_t sampling_parameter, uint32_t n_points, const float* points_xy,
                               const int32_t* pose_sources, uint32_t n_triangles,
                               const uint32_t* triangles, uint32_t* out_node);
-/* MachineLayer::add_state (layer.rs:229-235: the first state becomes active) */
+/* MachineLayer::add_state (layer.rs:229-235): the state becomes the ACTIVE one of every instance that has no active
+ * state -- the first state of a new layer, but also a state added while a transition is in flight (active_state is NONE
+ * then), exactly as in the reference.  It does not become the ENTRY state: only fyx_layer_set_entry_state sets that
+ * (layer.rs:209-212: active_state and entry_state of every instance), and fyx_layer_reset returns to it. */
 int fyx_layer_add_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, int32_t root_node,
                         uint32_t* out_state);
 int fyx_layer_set_entry_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t state);
@@ -566,8 +569,8 @@ int fyx_layer_get_node_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer,
 int fyx_layer_set_node_state(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance, uint32_t node,
                              int has_prev, uint32_t prev_index, float blend_time);
 /* MachineLayer::reset (layer.rs:288-296): every transition's elapsed_time and blend_factor return to 0 and
- * active_state = entry_state; active_transition is left as it is, as in the reference.  instance may be
- * FYX_ALL_INSTANCES. */
+ * active_state = entry_state (Handle::NONE on a layer whose entry state was never set: add_state does not set it);
+ * active_transition is left as it is, as in the reference.  instance may be FYX_ALL_INSTANCES. */
 int fyx_layer_reset(fyx_ctx* ctx, uint64_t animator_id, uint32_t layer, uint32_t instance);
 /* machine::Event (machine/event.rs:30-51) and MachineLayer::pop_event (layer.rs:284-286); the
  * queue holds at most 2048 events per layer and instance, further ones are dropped

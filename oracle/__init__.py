@@ -342,6 +342,7 @@ def _alib():
             "fo_layer_add_blend_by_index": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
             "fo_layer_add_blend_space": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
             "fo_layer_add_state": [c_void_p, c_int, c_int], "fo_layer_set_entry_state": [c_void_p, c_int, c_int],
+            "fo_layer_reset": [c_void_p, c_int],
             "fo_state_add_action": [c_void_p, c_int, c_int, c_int, c_int, c_int],
             "fo_state_add_random_action": [c_void_p, c_int, c_int, c_int, c_void_p, c_int],
             "fo_machine_set_random_state": [c_void_p, ctypes.c_uint64],
@@ -610,6 +611,10 @@ class AnimScene:
 
     def layer_state(self, layer: int):
         return (self.l.fo_layer_active_state(self.machine, layer), self.l.fo_layer_active_transition(self.machine, layer))
+
+    def reset_layer(self, layer: int) -> None:
+        """MachineLayer::reset (layer.rs:288-296)"""
+        self.l.fo_layer_reset(self.machine, layer)
 
     def set_local_trs(self, node: int, trs10) -> None:
         self.nodes[node].local_position[:] = [float(x) for x in trs10[0:3]]

@@ -214,6 +214,7 @@ int fo_layer_add_blend_space(fo_machine*, int layer, int sampling_param, int n_p
                              const uint32_t* tris);
 int fo_layer_add_state(fo_machine*, int layer, int root_node);
 void fo_layer_set_entry_state(fo_machine*, int layer, int state);
+void fo_layer_reset(fo_machine*, int layer); /* MachineLayer::reset, layer.rs:288-296 */
 void fo_state_add_action(fo_machine*, int layer, int state, int on_enter, int kind, int animation);
 void fo_state_add_random_action(fo_machine*, int layer, int state, int on_enter, const int* animations, int n);
 void fo_machine_set_random_state(fo_machine*, uint64_t state);

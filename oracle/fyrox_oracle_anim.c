@@ -623,6 +623,7 @@ typedef struct fo_layer {
     fo_state* states;
     fo_transition* transitions;
     int active_state, active_transition; /* -1 == Handle::NONE */
+    int entry_state;                     /* layer.rs:105: set by set_entry_state only */
     int n_excluded;
     int* excluded;
     fo_pose* final_pose;
@@ -699,6 +700,7 @@ int fo_machine_add_layer(fo_machine* m, float weight) {
     L->weight = weight;
     L->active_state = -1;
     L->active_transition = -1;
+    L->entry_state = -1;
     L->final_pose = fo_pose_new();
     return m->n_layers++;
 }
@@ -782,7 +784,17 @@ int fo_layer_add_state(fo_machine* m, int layer, int root_node) {
     return L->n_states++;
 }
 /* layer.rs:209-212 */
-void fo_layer_set_entry_state(fo_machine* m, int layer, int state) { m->layers[layer].active_state = state; }
+void fo_layer_set_entry_state(fo_machine* m, int layer, int state) {
+    m->layers[layer].active_state = state;
+    m->layers[layer].entry_state = state;
+}
+/* layer.rs:288-296 reset: every transition's elapsed_time and blend_factor return to 0 (transition.rs:311-314) and
+ * active_state = entry_state -- which is NONE unless set_entry_state was called; active_transition is NOT cleared */
+void fo_layer_reset(fo_machine* m, int layer) {
+    fo_layer* L = &m->layers[layer];
+    for (int t = 0; t < L->n_transitions; ++t) L->transitions[t].elapsed_time = L->transitions[t].blend_factor = 0.0f;
+    L->active_state = L->entry_state;
+}
 
 void fo_state_add_action(fo_machine* m, int layer, int state, int on_enter, int kind, int animation) {
     fo_state* s = &m->layers[layer].states[state];

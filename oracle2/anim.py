@@ -508,9 +508,9 @@ class Layer:
         self.weight = F(d.weight)
         self.mask = set(int(x) for x in d.mask)
         self.active_state = 0 if self.states else -1        # add_state: the first state becomes active (layer.rs:229-235)
-        if d.entry_state is not None:
-            self.active_state = d.entry_state
-        self.entry_state = self.active_state
+        self.entry_state = -1                               # ... and leaves entry_state alone: only set_entry_state sets it
+        if d.entry_state is not None:                       # layer.rs:209-212
+            self.active_state = self.entry_state = d.entry_state
         self.active_transition = -1
         self.final = Pose()
         self.events = []
@@ -522,8 +522,8 @@ class Layer:
     # hole and every other handle keeps its meaning; run-time fields -- elapsed_time, blend_factor, prev_index, blend_time,
     # the cached output poses, active_state / active_transition -- are not touched by any of them) ----
     def reset(self):
-        """MachineLayer::reset (layer.rs:288-296): transitions reset, active_state = entry_state; active_transition is NOT
-        cleared by the reference."""
+        """MachineLayer::reset (layer.rs:288-296): transitions reset, active_state = entry_state -- NONE unless
+        set_entry_state was called --; active_transition is NOT cleared by the reference."""
         for tr in self.transitions:
             if tr is not None:
                 tr[4], tr[5] = ZERO, ZERO
@@ -535,8 +535,8 @@ class Layer:
 
     def add_state(self, d):
         self.states.append((d.root, list(d.on_enter_actions), list(d.on_leave_actions)))
-        if self.entry_state < 0:                     # layer.rs:229-235
-            self.entry_state = self.active_state = len(self.states) - 1
+        if self.active_state < 0:                    # layer.rs:229-235: also true while a transition is in flight
+            self.active_state = len(self.states) - 1
         return len(self.states) - 1
 
     def add_transition(self, d):
@@ -809,6 +809,9 @@ class AnimScene:
     def layer_state(self, layer: int):
         l = self.machine.layers[layer]
         return (l.active_state, l.active_transition)
+
+    def reset_layer(self, layer: int) -> None:
+        self.machine.layers[layer].reset()
 
     def animation_state(self, a: int) -> dict:
         an = self.anims[a]

@@ -361,14 +361,22 @@ def test_removed_state_and_transitions_are_compacted_away(cctx):
         smap = {s: (s if s < ns else None) for s in range(len(m.layers[0].states))}
         return new, in_place, {"state_maps": {0: smap}, "transition_maps": {0: tmap}}
 
-    assert _run(cctx, sc, {6: grow, 9: shrink, 31: edit_retime}) == 3
+    # grown before the first transition fires (a state added DURING a transition would become the active one, see
+    # test_state_added_while_a_transition_is_in_flight_becomes_active), shrunk inside it
+    assert _run(cctx, sc, {3: grow, 9: shrink, 31: edit_retime}) == 3
 
 
-def test_layer_reset_keeps_the_active_transition_like_the_reference(cctx):
-    """MachineLayer::reset (layer.rs:288-296): transitions reset, active_state = entry_state, active_transition untouched."""
-    sc = cases.transitions()
+@pytest.mark.parametrize("orc_mod", [oracle, oracle2], ids=["oracle", "oracle2"])
+@pytest.mark.parametrize("explicit_entry", [None, 0, 1], ids=["entry_never_set", "entry_0", "entry_1"])
+def test_layer_reset_is_the_references(cctx, orc_mod, explicit_entry):
+    """MachineLayer::reset (layer.rs:288-296): transitions reset, active_state = entry_state, active_transition untouched.
+    add_state makes the first state ACTIVE but does not make it the ENTRY state (layer.rs:229-235 vs :209-212), so on a
+    layer whose entry state was never set, reset() leaves no active state: the layer goes quiet unless a transition is
+    still active -- both restatements and the product agree, frame by frame."""
     for reset_at in (3, 6, 7, 8, 12, 35):
-        o = cases.build_oracle(oracle2, sc)
+        sc = cases.transitions()
+        sc.machine.layers[0].entry_state = explicit_entry
+        o = cases.build_oracle(orc_mod, sc)
         p = cases.build_product(cctx, sc, n_instances=2)
         trs = o.node_trs()
         for f in range(50):
@@ -376,8 +384,10 @@ def test_layer_reset_keeps_the_active_transition_like_the_reference(cctx):
                 o.set_parameter(idx, par)
                 p.set_parameter(idx, par)
             if f == reset_at:
-                o.machine.layers[0].reset()
+                o.reset_layer(0)
                 p.reset_layer(0)
+                if explicit_entry is None:
+                    assert p.layer_state(0, 0)[0] == -1
             plan = p.plan(1, sc.dt)
             o.update_machine(sc.dt)
             assert p.layer_state(0, 1) == o.layer_state(0), (reset_at, f)
@@ -385,6 +395,52 @@ def test_layer_reset_keeps_the_active_transition_like_the_reference(cctx):
             o0, o1 = plan["offsets"][:2]
             trs = run_program(oracle, plan["ops"][o0:o1], poses, [set()], trs)
             assert np.array_equal(trs.view(np.uint32), o.node_trs().view(np.uint32)), (reset_at, f)
+        o.close()
+        p.free()
+
+
+def test_state_added_while_a_transition_is_in_flight_becomes_active(cctx):
+    """layer.rs:229-235 tests active_state alone, and active_state is NONE while a transition runs: a state added then
+    becomes the active one under the running transition (which overwrites it when it completes).  The append-only
+    builder call does the same per instance; so does a rebuild, for the first state it finds added."""
+    sc = cases.transitions()
+    for via_rebuild in (False, True):
+        o = cases.build_oracle(oracle2, sc)
+        p = cases.build_product(cctx, sc, n_instances=2)
+        desc, trs, seen = sc.machine, o.node_trs(), False
+        for f in range(40):
+            for idx, par in sc.script.get(f, []):
+                o.set_parameter(idx, par)
+                p.set_parameter(idx, par)
+            if f == 8:
+                assert o.layer_state(0) == (-1, 0)                   # inside idle -> walk
+                new, in_place, _ = edit_grow(desc)
+                in_place(o.machine)
+                assert o.layer_state(0) == (3, 0)                    # the added state is active, the transition goes on
+                if via_rebuild:
+                    p.rebuild_machine(desc, new)
+                else:                                                # the same calls the in-place edit made, appended
+                    l_new = new.layers[0]
+                    p._check(p._l.fyx_layer_add_play_animation(p._h, p.id, 0, l_new.nodes[-1].animation, None))
+                    p._check(p._l.fyx_layer_add_state(p._h, p.id, 0, l_new.states[-1].root, None))
+                    for kind, anim in l_new.states[-1].on_enter_actions:
+                        p._check(p._l.fyx_state_add_action(p._h, p.id, 0, 3, 1, kind, anim))
+                    for t in l_new.transitions[len(desc.layers[0].transitions):]:
+                        code = A._i32(A.encode_logic(t.condition))
+                        p._check(p._l.fyx_layer_add_transition(p._h, p.id, 0, t.source, t.dest, t.transition_time, A._ptr(code), len(code), None))
+                desc = new
+                assert p.layer_state(0, 0) == (3, 0) and p.layer_state(0, 1) == (3, 0)
+                seen = True
+            plan = p.plan(1, sc.dt)
+            o.update_machine(sc.dt)
+            assert p.layer_state(0, 1) == o.layer_state(0), (via_rebuild, f)
+            for a in range(len(sc.animations)):
+                assert p.animation_state(a, 0) == o.animation_state(a), (via_rebuild, f, a)
+            poses = [o.animation_pose(a) for a in range(len(sc.animations))]
+            o0, o1 = plan["offsets"][:2]
+            trs = run_program(oracle, plan["ops"][o0:o1], poses, [set()], trs)
+            assert np.array_equal(trs.view(np.uint32), o.node_trs().view(np.uint32)), (via_rebuild, f)
+        assert seen
         o.close()
         p.free()
 

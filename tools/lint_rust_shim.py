@@ -170,7 +170,7 @@ def main():
                                             "value", "len",
                                             # LayerMaps / SavedLayer of fyrox_hip_flatten.rs (the shim's own structs)
                                             "layers", "node_index", "state_index", "transition_index", "by_index_nodes",
-                                            "active_state", "active_transition", "transitions", "by_index"):
+                                            "active_state", "active_transition", "transitions", "by_index", "known_states"):
                 continue
             if fld in pub_fns or fld in trait_fns:        # a method reference passed as a value
                 continue
