@@ -191,6 +191,8 @@ pub struct AnimatorMaps {
     /// `rebuild_machine` translates the run-time state through, and what turns the indices of `fyx_layer_get_state` and of
     /// the layer events back into handles
     pub layers: Vec<LayerMaps>,
+    /// `machine_signature` of the definition that was sent last
+    pub signature: u64,
 }
 
 /// The dense indices the library knows one layer's pool entries by.
@@ -290,7 +292,7 @@ impl<'a> HipAnimator<'a> {
             }
         }
         let animator = HipAnimator::from_parts(hip, animator_id, n_instances, signal_names);
-        Ok((animator, AnimatorMaps { animation_index, parameter_index: FxHashMap::default(), layers: Vec::new() }))
+        Ok((animator, AnimatorMaps { animation_index, parameter_index: FxHashMap::default(), layers: Vec::new(), signature: 0 }))
     }
 
     /// The `Machine` of an `AnimationBlendingStateMachine` (scene/animation/absm.rs:240) on top of `from_player`.
@@ -462,7 +464,19 @@ impl<'a> HipAnimator<'a> {
             }
             maps.layers.push(LayerMaps { node_index, state_index, transition_index, by_index_nodes });
         }
+        maps.signature = machine_signature(machine);
         Ok(())
+    }
+
+    /// Every frame, before `update_machine`: the definition again if the game has edited the `Machine` since it was sent
+    /// (`machine_signature` differs -- nothing for the game to announce), then the parameter values.  With this the
+    /// engine's own `AnimationBlendingStateMachine::update` body is the three calls `sync_machine`, `update_machine`
+    /// and whatever reads the results.
+    pub fn sync_machine(&mut self, machine: &Machine, rig: &RigMap, maps: &mut AnimatorMaps, n_instances: u32) -> Result<(), HipError> {
+        if machine_signature(machine) != maps.signature {
+            self.rebuild_machine(machine, rig, maps, n_instances)?;
+        }
+        self.sync_parameters(machine, maps)
     }
 
     /// After the game has edited the `Machine` in place -- `layers_mut`, `nodes_mut`, `transitions_mut`, `states_mut`,
@@ -570,6 +584,127 @@ impl<'a> HipAnimator<'a> {
         }
         Ok(())
     }
+}
+
+/// A hash of everything `attach_machine` sends: when it differs from the one taken at the last attach, the game has edited
+/// the `Machine` in place and `sync_machine` re-sends it.  Walks the pools once (a few hundred nanoseconds for a machine
+/// of a dozen nodes); run-time fields (active state, elapsed times, cached poses) and parameter VALUES are not part of it.
+pub fn machine_signature(machine: &Machine) -> u64 {
+    use std::hash::{Hash, Hasher};
+    let mut k = std::collections::hash_map::DefaultHasher::new();
+    fn logic(node: &LogicNode, k: &mut std::collections::hash_map::DefaultHasher) {
+        match node {
+            LogicNode::Parameter(name) => {
+                0u8.hash(k);
+                name.hash(k);
+            }
+            LogicNode::And(n) => {
+                1u8.hash(k);
+                logic(&n.lhs, k);
+                logic(&n.rhs, k);
+            }
+            LogicNode::Or(n) => {
+                2u8.hash(k);
+                logic(&n.lhs, k);
+                logic(&n.rhs, k);
+            }
+            LogicNode::Xor(n) => {
+                3u8.hash(k);
+                logic(&n.lhs, k);
+                logic(&n.rhs, k);
+            }
+            LogicNode::Not(n) => {
+                4u8.hash(k);
+                logic(&n.lhs, k);
+            }
+            LogicNode::IsAnimationEnded(h) => {
+                5u8.hash(k);
+                h.hash(k);
+            }
+        }
+    }
+    machine.layers().len().hash(&mut k);
+    for layer in machine.layers() {
+        layer.weight().to_bits().hash(&mut k);
+        for h in layer.mask().inner().iter() {
+            h.hash(&mut k);
+        }
+        layer.entry_state().hash(&mut k);
+        for (h, node) in layer.nodes().pair_iter() {
+            h.hash(&mut k);
+            match node {
+                PoseNode::PlayAnimation(play) => {
+                    0u8.hash(&mut k);
+                    play.animation.hash(&mut k);
+                }
+                PoseNode::BlendAnimations(blend) => {
+                    1u8.hash(&mut k);
+                    for p in blend.pose_sources.iter() {
+                        p.pose_source.hash(&mut k);
+                        match &p.weight {
+                            PoseWeight::Constant(w) => w.to_bits().hash(&mut k),
+                            PoseWeight::Parameter(name) => name.hash(&mut k),
+                        }
+                    }
+                }
+                PoseNode::BlendAnimationsByIndex(by_index) => {
+                    2u8.hash(&mut k);
+                    by_index.index_parameter.hash(&mut k);
+                    for i in by_index.inputs.iter() {
+                        i.pose_source.hash(&mut k);
+                        i.blend_time.to_bits().hash(&mut k);
+                    }
+                }
+                PoseNode::BlendSpace(space) => {
+                    3u8.hash(&mut k);
+                    space.sampling_parameter().hash(&mut k);
+                    for p in space.points() {
+                        p.position.x.to_bits().hash(&mut k);
+                        p.position.y.to_bits().hash(&mut k);
+                        p.pose_source.hash(&mut k);
+                    }
+                }
+            }
+        }
+        for (h, state) in layer.states().pair_iter() {
+            h.hash(&mut k);
+            state.root.hash(&mut k);
+            for actions in [&state.on_enter_actions, &state.on_leave_actions] {
+                actions.len().hash(&mut k);
+                for action in actions.iter() {
+                    match &action.0 {
+                        StateAction::None => 0u8.hash(&mut k),
+                        StateAction::RewindAnimation(a) => {
+                            1u8.hash(&mut k);
+                            a.hash(&mut k);
+                        }
+                        StateAction::EnableAnimation(a) => {
+                            2u8.hash(&mut k);
+                            a.hash(&mut k);
+                        }
+                        StateAction::DisableAnimation(a) => {
+                            3u8.hash(&mut k);
+                            a.hash(&mut k);
+                        }
+                        StateAction::EnableRandomAnimation(list) => {
+                            4u8.hash(&mut k);
+                            for a in list.iter() {
+                                a.hash(&mut k);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        for (h, transition) in layer.transitions().pair_iter() {
+            h.hash(&mut k);
+            transition.source().hash(&mut k);
+            transition.dest().hash(&mut k);
+            transition.transition_time().to_bits().hash(&mut k);
+            logic(transition.condition(), &mut k);
+        }
+    }
+    k.finish()
 }
 
 /// The first state (in pool order) of layer `li` that the shim did not know before the edit.

@@ -513,6 +513,22 @@ class Animator:
         """MachineLayer::reset (layer.rs:288-296)"""
         self._check(self._l.fyx_layer_reset(self._h, self.id, layer, instance))
 
+    def sync_machine(self, m: Machine) -> bool:
+        """What the shim calls every frame before the update: the definition again if it differs from the one sent last
+        (the game edited its Machine in place), run-time state carried over.  True when it re-sent.  Descriptions here are
+        dense lists, so indices keep their meaning (identity maps); the Rust shim compares `machine_signature`s and maps
+        through its handle tables."""
+        import copy
+        sent = getattr(self, "_sent_machine", None)
+        if sent is None:
+            self.set_machine(m)
+        elif sent != m:
+            self.rebuild_machine(sent, m)
+        else:
+            return False
+        self._sent_machine = copy.deepcopy(m)
+        return True
+
     def rebuild_machine(self, old: Machine, new: Machine, layer_map=None, state_maps=None, transition_maps=None,
                         node_maps=None, parameter_map=None) -> None:
         """What the engine-side shim does after the game has edited its Machine in place: read the run-time state of

@@ -476,3 +476,35 @@ def test_state_accessors_round_trip_and_validate(cctx):
     q.plan(1, sc2.dt)
     p.free()
     q.free()
+
+
+def test_sync_machine_re_sends_only_when_the_definition_changed(cctx):
+    """The shim's per-frame call: nothing when the game left its Machine alone (parameter VALUES are not the
+    definition: Machine::set_parameter travels through fyx_machine_set_parameter), the definition again after an edit."""
+    sc = cases.transitions()
+    o = cases.build_oracle(oracle2, sc)
+    sc_nomachine = copy.copy(sc)
+    sc_nomachine.machine = None
+    p = cases.build_product(cctx, sc_nomachine, n_instances=1)
+    desc = copy.deepcopy(sc.machine)
+    assert p.sync_machine(desc) is True                 # first time: sent
+    trs, sent = o.node_trs(), 1
+    for f in range(40):
+        for idx, par in sc.script.get(f, []):
+            o.set_parameter(idx, par)
+            p.set_parameter(idx, par)
+        if f in (8, 20):                                # the game edits its machine in place ...
+            new, in_place, _ = (edit_retime if f == 8 else edit_recondition)(desc)
+            in_place(o.machine)
+            desc = new
+        sent += p.sync_machine(desc)                    # ... and the shim notices on its own
+        plan = p.plan(1, sc.dt)
+        o.update_machine(sc.dt)
+        assert p.layer_state(0, 0) == o.layer_state(0), f
+        poses = [o.animation_pose(a) for a in range(len(sc.animations))]
+        o0, o1 = plan["offsets"][:2]
+        trs = run_program(oracle, plan["ops"][o0:o1], poses, [set()], trs)
+        assert np.array_equal(trs.view(np.uint32), o.node_trs().view(np.uint32)), f
+    assert sent == 3
+    o.close()
+    p.free()
