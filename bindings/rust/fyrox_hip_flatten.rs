@@ -181,6 +181,29 @@ impl HipSkinning {
     }
 }
 
+/// The scalar state of one `Animation` as the shim last saw it (see `push_animations` / `pull_animations`).
+#[derive(Clone, Copy, PartialEq)]
+pub struct AnimationShadow {
+    pub speed: f32,
+    pub looped: bool,
+    pub enabled: bool,
+    pub slice: (f32, f32),
+    pub time: f32,
+}
+
+impl AnimationShadow {
+    pub fn of(animation: &Animation) -> Self {
+        let slice = animation.time_slice();
+        Self {
+            speed: animation.speed(),
+            looped: animation.is_loop(),
+            enabled: animation.is_enabled(),
+            slice: (slice.start, slice.end),
+            time: animation.time_position(),
+        }
+    }
+}
+
 /// What `from_player` returns besides the animator: the handle -> index tables the per-frame calls need.
 pub struct AnimatorMaps {
     /// `Handle<Animation>` -> animation index inside the library (pool slots may be empty: indices are dense)
@@ -293,6 +316,60 @@ impl<'a> HipAnimator<'a> {
         }
         let animator = HipAnimator::from_parts(hip, animator_id, n_instances, signal_names);
         Ok((animator, AnimatorMaps { animation_index, parameter_index: FxHashMap::default(), layers: Vec::new(), signature: 0 }))
+    }
+
+    /// Before the update: what game code did to the `Animation` objects since the last frame -- `set_speed`, `set_loop`,
+    /// `set_enabled`, `set_time_slice`, `set_time_position` / `rewind` (lib.rs:432-470, :713-748) -- reaches the library.
+    /// The library's copy is the one that ticks, so the objects are compared with `shadow` (what `pull_animations`
+    /// wrote into them after the previous update, or what `from_player` sent): a field that differs was changed by the
+    /// game.  Animations added to or removed from the container since `from_player` are the caller's to announce
+    /// (`fyx_animator_add_animation` / `fyx_animator_remove_animation`); instance 0 is the engine's one instance.
+    pub fn push_animations(&mut self, animations: &AnimationContainer, maps: &AnimatorMaps, shadow: &mut FxHashMap<Handle<Animation>, AnimationShadow>) -> Result<(), HipError> {
+        let (ctx, id) = (self.raw(), self.id());
+        for (h, animation) in animations.pair_iter() {
+            let Some(index) = maps.animation_index.get(&h).copied() else {
+                continue;
+            };
+            let now = AnimationShadow::of(animation);
+            let was = shadow.get(&h).copied().unwrap_or(now);
+            unsafe {
+                if now.speed != was.speed {
+                    check_rc(ctx, fyx_animation_set_speed(ctx, id, index, FYX_ALL_INSTANCES, now.speed))?;
+                }
+                if now.looped != was.looped {
+                    check_rc(ctx, fyx_animation_set_loop(ctx, id, index, FYX_ALL_INSTANCES, now.looped as i32))?;
+                }
+                if now.slice != was.slice {
+                    check_rc(ctx, fyx_animation_set_time_slice(ctx, id, index, FYX_ALL_INSTANCES, now.slice.0, now.slice.1))?;
+                }
+                if now.time != was.time {
+                    check_rc(ctx, fyx_animation_set_time_position(ctx, id, index, FYX_ALL_INSTANCES, now.time))?;
+                }
+                if now.enabled != was.enabled {
+                    check_rc(ctx, fyx_animation_set_enabled(ctx, id, index, FYX_ALL_INSTANCES, now.enabled as i32))?;
+                }
+            }
+            shadow.insert(h, now);
+        }
+        Ok(())
+    }
+
+    /// After the update: the clocks and enabled flags the library advanced (ticks, `StateAction`s) go back into the
+    /// objects, so game code that reads `animation.time_position()` / `is_enabled()` / `has_ended()` sees what the
+    /// reference would show it.
+    pub fn pull_animations(&mut self, animations: &mut AnimationContainer, maps: &AnimatorMaps, shadow: &mut FxHashMap<Handle<Animation>, AnimationShadow>) -> Result<(), HipError> {
+        let (ctx, id) = (self.raw(), self.id());
+        for (h, index) in maps.animation_index.iter() {
+            let Some(animation) = animations.try_get_mut(*h).ok() else {
+                continue;
+            };
+            let (mut time, mut enabled, mut ended) = (0.0f32, 0i32, 0i32);
+            check_rc(ctx, unsafe { fyx_animation_get_state(ctx, id, *index, 0, &mut time, &mut enabled, &mut ended) })?;
+            animation.set_time_position(time);
+            animation.set_enabled(enabled != 0);
+            shadow.insert(*h, AnimationShadow::of(animation));
+        }
+        Ok(())
     }
 
     /// The `Machine` of an `AnimationBlendingStateMachine` (scene/animation/absm.rs:240) on top of `from_player`.
