@@ -1,0 +1,91 @@
+"""Parity invariants that can be read off the compiled gfx950 code without a GPU (tools/isa_stats.py).
+
+The reference computes in unfused IEEE f32; the kernels that promise bit-exact results are compiled with
+-ffp-contract=off and written without fmaf.  A lost compiler flag (the Makefile, __graft_entry__.build) or a compiler
+that starts contracting would show up as wrong LAST BITS on the GPU only -- this test shows it in the instruction
+stream, wherever the library was built."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "fyrox_amd", "libfyrox_hip.so")
+
+
+@pytest.fixture(scope="module")
+def stats():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_stats
+    if not os.path.exists(isa_stats.OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain is not here")
+    s = isa_stats.kernel_stats(LIB)
+    assert len(s) > 300, "the library's kernels were not found in the offload bundles"
+    return s
+
+
+def _targs(name):
+    m = re.search(r"<(.*)>", name)
+    return [a.strip() for a in m.group(1).split(",")] if m else []
+
+
+# position of the EXACT template argument in each skinning kernel
+EXACT_ARG = {"fyx::lbs_skin": 1, "fyx::lbs_skin_dyn": 1, "fyx::lbs_skin_crowd": 1, "fyx::lbs_skin_batch": 0, "fyx::lbs_skin_ex": 0,
+             "fyx::lbs_skin_aos": 0, "fyx::lbs_skin_aos_batch": 0}
+
+
+def _no_contraction(name, c, sqrt_fma=2, slack_fma=0, slack_fmac=2):
+    """every fused operation of the kernel is accounted for by the compiler's IEEE division / square-root expansions"""
+    div, sq = c["v_div_fixup_f32"], c["v_sqrt_f32"]
+    assert c["v_pk_fma_f32"] == 0 and c["v_mad_f32"] == 0 and c["v_mac_f32"] == 0 and c["v_fma_mix_f32"] == 0, (name, dict(c))
+    assert c["v_fma_f32"] <= 3 * div + sqrt_fma * sq + slack_fma, (name, dict(c))
+    assert c["v_fmac_f32"] <= 2 * div + slack_fmac, (name, dict(c))      # + integer-division expansions of the index math
+
+
+def test_exact_skinning_kernels_contain_no_contracted_multiply_add(stats):
+    seen = {"exact": 0, "fused": 0}
+    for name, c in stats.items():
+        family = name.split("<")[0]
+        if family not in EXACT_ARG:
+            continue
+        exact = _targs(name)[EXACT_ARG[family]] == "true"
+        if exact:
+            _no_contraction(name, c)
+            seen["exact"] += 1
+        else:
+            seen["fused"] += 1
+            assert c["v_pk_fma_f32"] > 0, (name, "the fused variant is expected to use packed FMA")
+    assert seen["exact"] > 150 and seen["fused"] > 100, seen
+
+
+def test_pose_and_palette_kernels_contain_no_contracted_multiply_add(stats):
+    """Always exact: sampling (sinf / cosf of Euler tracks bring their own polynomial FMAs: <= 1e-5 by contract, see
+    DESIGN 2), the fold interpreter (nlerp: one sqrt and four divisions per blend), hierarchy, palettes, AABBs."""
+    exact_everywhere = ("fyx::pose_update_kernel", "fyx::pose_update_scene_kernel", "fyx::property_update_kernel",
+                        "fyx::property_update_scene_kernel", "fyx::root_motion_fold_kernel", "fyx::root_motion_fold_scene_kernel",
+                        "fyx::palette_kernel", "fyx::palette_gather_kernel", "fyx::skinned_aabb_kernel", "fyx::skinned_aabb_inst_kernel",
+                        "fyx::points_aabb_kernel", "fyx::aabb_final_kernel", "fyx::aabb_final_inst_kernel", "fyx::blend_shape_weights_kernel")
+    found = 0
+    for name, c in stats.items():
+        if name.split("<")[0] in exact_everywhere:
+            _no_contraction(name, c)
+            found += 1
+    assert found >= len(exact_everywhere)
+    for name, c in stats.items():          # samplers: the only fused operations besides the expansions are sincosf's
+        if "sample" in name or name.startswith("fyx::root_motion_kernel") or name.startswith("fyx::root_motion_scene_kernel"):
+            assert c["v_pk_fma_f32"] == 0 and c["v_mad_f32"] == 0 and c["v_mac_f32"] == 0, (name, dict(c))
+            assert c["v_fma_f32"] - 3 * c["v_div_fixup_f32"] - 2 * c["v_sqrt_f32"] <= 12, (name, dict(c))
+
+
+def test_kernels_do_not_spill(stats):
+    """No kernel keeps registers in scratch memory -- with one known exception: the scene form of the update kernel
+    (pose_update_scene_kernel: the fold interpreter's 256 VGPRs plus the job record it reads from memory instead of from
+    kernel arguments) reloads a few values (168 bytes of scratch, a handful of loads outside the per-op loop).  The
+    exception is pinned so that it cannot grow unnoticed."""
+    for name, c in stats.items():
+        n = c["scratch"]
+        if name == "fyx::pose_update_scene_kernel":
+            assert n <= 24, (name, n)
+        else:
+            assert n == 0, (name, "register spills")
