@@ -89,3 +89,28 @@ def test_kernels_do_not_spill(stats):
             assert n <= 24, (name, n)
         else:
             assert n == 0, (name, "register spills")
+
+
+def test_register_budgets_behind_the_measured_occupancies():
+    """What DESIGN's occupancy statements rest on (512 VGPRs per SIMD lane: waves per SIMD = 512 // allocated, allocation
+    in steps of 8): four waves per SIMD for the streaming kernels (<= 128), six for the lean crowd form (<= 80) -- the
+    launchers size their resident grids and LDS for these."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_stats
+    if not os.path.exists(isa_stats.READELF):
+        pytest.skip("llvm-readelf of the ROCm toolchain is not here")
+    res = isa_stats.kernel_resources(LIB)
+    budget = {"fyx::lbs_skin_dyn<256, true, 7, false, 2, 16>": 128, "fyx::lbs_skin<512, true, true, 3, 7, false>": 128,
+              "fyx::lbs_skin_batch<true, 7>": 128, "fyx::lbs_skin_crowd<512, true, 7, false>": 128,
+              "fyx::lbs_skin_crowd<512, true, 7, true>": 80, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel": 64}
+    for name, limit in budget.items():
+        assert name in res, name
+        assert res[name]["vgpr"] + res[name]["agpr"] <= limit, (name, res[name])
+        assert res[name]["scratch_bytes"] == 0, (name, res[name])
+    for name, r in res.items():        # every skinning kernel fits four waves per SIMD and uses no scratch ...
+        if name.startswith("fyx::lbs_skin"):
+            # ... except the vertex-buffer-out kernels with 32- and 40-byte output vertices, which hold a whole output
+            # vertex per lane on top of the inputs: three waves per SIMD (<= 168)
+            wide = name.startswith("fyx::lbs_skin_aos") and _targs(name)[2] in ("8u", "10u")
+            assert r["vgpr"] + r["agpr"] <= (168 if wide else 128) and r["scratch_bytes"] == 0, (name, r)

@@ -53,9 +53,43 @@ def kernel_stats(lib_path: str) -> dict:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def kernel_resources(lib_path: str) -> dict:
+    """{demangled kernel name: {"vgpr": .., "agpr": .., "sgpr": .., "scratch_bytes": .., "lds_bytes": ..}} from the code
+    objects' metadata notes (what the runtime allocates per wave / workgroup; LDS: the static part only)"""
+    tmp = tempfile.mkdtemp(prefix="fyx_isa_")
+    try:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(lib_path, so)
+        subprocess.run([OBJDUMP, "--offloading", so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = {}
+        for obj in glob.glob(so + ".*gfx950"):
+            text = subprocess.run([READELF, "--notes", obj], check=True, capture_output=True, text=True).stdout
+            for block in re.split(r"\n  - \.agpr_count:", "\n" + text)[1:]:
+                def field(key, block=block):
+                    m = re.search(r"\." + key + r":\s+(\S+)", block)
+                    return m.group(1) if m else None
+                name = field("name")
+                if name is None:
+                    continue
+                out[name] = {"agpr": int(block.split()[0]), "vgpr": int(field("vgpr_count")), "sgpr": int(field("sgpr_count")),
+                             "scratch_bytes": int(field("private_segment_fixed_size")), "lds_bytes": int(field("group_segment_fixed_size"))}
+        names = sorted(out)
+        dem = subprocess.run(["c++filt"] + names, check=True, capture_output=True, text=True).stdout.splitlines()
+        return {d.split("(")[0].replace("void ", ""): out[n] for n, d in zip(names, dem)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     stats = kernel_stats(sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "fyrox_amd", "libfyrox_hip.so"))
-    print(f"{'kernel':70s} " + " ".join(f"{c.replace('v_', '').replace('_f32', ''):>9s}" for c in COUNTED))
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "fyrox_amd", "libfyrox_hip.so")
+    res = kernel_resources(lib)
+    print(f"{'kernel':70s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'scr B':>6s} " + " ".join(f"{c.replace('v_', '').replace('_f32', ''):>9s}" for c in COUNTED))
     for k in sorted(stats):
-        print(f"{k[:70]:70s} " + " ".join(f"{stats[k][c]:9d}" for c in COUNTED))
+        r = res.get(k, {})
+        print(f"{k[:70]:70s} {r.get('vgpr', -1):5d} {r.get('agpr', -1):5d} {r.get('sgpr', -1):5d} {r.get('scratch_bytes', -1):6d} "
+              + " ".join(f"{stats[k][c]:9d}" for c in COUNTED))
