@@ -487,7 +487,7 @@ int run_batch_plan(fyx_ctx* c, BatchPlan& P) {
 
 extern "C" {
 
-const char* fyx_version(void) { return "fyrox_hip 0.1.0 (gfx950)"; }
+const char* fyx_version(void) { return "fyrox_hip 0.2.0 (gfx950)"; }
 
 int fyx_init(fyx_ctx** out_ctx, int device_ordinal) {
     if (!out_ctx) return FYX_ERR_INVALID_ARG;
