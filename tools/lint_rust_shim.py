@@ -7,7 +7,8 @@ that sank the first version of the shim: names that do not exist in the referenc
   * every `.method(` called on a value and every `Type::function(` must exist as a `pub fn` somewhere in the reference
     crates the path touches (or be a std / nalgebra / shim-own name from the allow-lists below);
   * every `Enum::Variant` used in a pattern must be a variant of that reference enum;
-  * every extern function called (`fyx_*`) must be declared in bindings/rust/fyrox_hip_sys.rs (generated from the header).
+  * every extern function called (`fyx_*`) must be declared in bindings/rust/fyrox_hip_sys.rs (generated from the header)
+    and be called with as many arguments as it is declared with.
 
 It is a grep-level check, not a type checker: it cannot see a wrong receiver type or a borrow error.  It reads
 /root/reference, so it only runs where the reference is (the build container), and the CPU test that calls it skips
@@ -30,6 +31,28 @@ to_string_lossy into_owned into clone then copy_from_slice is_empty with_capacit
 to_rotation_matrix matrix try_inverse identity new new_unchecked from_ptr null null_mut keys values to_bits finish hash ok
 """.split())
 SHIM_OWN = set("raw id check node from_parts upload_tracks create_rig create_bone_list from_player attach_machine sync_parameters rebuild_machine reset_layer sync_machine push_animations pull_animations of".split())
+
+
+def count_args(src: str, open_paren: int):
+    """arguments of the call whose `(` is at src[open_paren]; None when the brackets do not balance"""
+    depth, n, seen = 0, 0, False
+    for i in range(open_paren, len(src)):
+        ch = src[i]
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                return n + (1 if seen else 0)
+        elif depth == 1:
+            if ch == ",":
+                n += 1
+                seen = False
+            elif not ch.isspace():
+                seen = True
+        if depth > 1 and not ch.isspace():
+            seen = True
+    return None
 
 
 def ref_sources():
@@ -119,6 +142,10 @@ def main():
         body = re.sub(r"//[^\n]*", "", body)
         enums.setdefault(m.group(1), set()).update(re.findall(r"^\s{4}([A-Z][A-Za-z0-9_]*)", body, flags=re.M))
     sys_fns = set(re.findall(r"pub fn (fyx_[a-z0-9_]+)", open(SYS).read()))
+    sys_arity = {}
+    for m in re.finditer(r"pub fn (fyx_[a-z0-9_]+)\(([^)]*)\)", open(SYS).read()):
+        args = [a for a in m.group(2).split(",") if a.strip()]
+        sys_arity[m.group(1)] = len(args)
     sys_consts = set(re.findall(r"pub const (FYX_[A-Z0-9_]+)", open(SYS).read()))
     sys_structs = set(re.findall(r"pub struct (Fyx[A-Za-z0-9]+)", open(SYS).read()))
     findings = []
@@ -193,6 +220,12 @@ def main():
         for m in re.finditer(r"\b(fyx_[a-z0-9_]+)\s*\(", src):
             if m.group(1) not in sys_fns:
                 findings.append(f"{name}: extern `{m.group(1)}` is not declared in fyrox_hip_sys.rs")
+                continue
+            # the number of arguments of the call against the declaration (top-level commas inside balanced brackets)
+            n_call = count_args(src, m.end() - 1)
+            if n_call is not None and n_call != sys_arity[m.group(1)]:
+                line = src[:m.start()].count("\n") + 1
+                findings.append(f"{name}:{line}: `{m.group(1)}` is called with {n_call} argument(s), declared with {sys_arity[m.group(1)]}")
         for m in re.finditer(r"\b(FYX_[A-Z0-9_]+)\b", src):
             if m.group(1) not in sys_consts:
                 findings.append(f"{name}: constant `{m.group(1)}` is not declared in fyrox_hip_sys.rs")
