@@ -216,6 +216,21 @@ def main():
             if en in enums:
                 line = src[:m.start()].count("\n") + 1
                 findings.append(f"{name}:{line}: `{en}::{var}`: `{var}` is not a variant of the reference's enum {en} ({sorted(enums[en])})")
+        # ---- brackets balance (the cheapest syntax check there is; char literals and lifetimes are not brackets)
+        flat = re.sub(r"'(\\.|[^'\\])'", "' '", src)
+        stack = []
+        pairs = {")": "(", "]": "[", "}": "{"}
+        for i, ch in enumerate(flat):
+            if ch in "([{":
+                stack.append((ch, i))
+            elif ch in ")]}":
+                if not stack or stack[-1][0] != pairs[ch]:
+                    findings.append(f"{name}:{flat[:i].count(chr(10)) + 1}: unbalanced `{ch}`")
+                    break
+                stack.pop()
+        else:
+            if stack:
+                findings.append(f"{name}:{flat[:stack[-1][1]].count(chr(10)) + 1}: `{stack[-1][0]}` is never closed")
         # ---- FFI
         for m in re.finditer(r"\b(fyx_[a-z0-9_]+)\s*\(", src):
             if m.group(1) not in sys_fns:
