@@ -321,7 +321,7 @@ def test_edits_at_every_frame_of_a_cross_fade(cctx):
         _run(cctx, cases.by_index(), {f: edit_by_index_times, f + 2: edit_grow, f + 3: edit_permute}, n_frames=40, n_instances=1)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_machines_survive_a_sequence_of_edits(cctx, seed):
     sc = cases.random_machine(seed)
     rng = np.random.default_rng(seed)
