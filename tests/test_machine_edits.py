@@ -508,3 +508,45 @@ def test_sync_machine_re_sends_only_when_the_definition_changed(cctx):
     assert sent == 3
     o.close()
     p.free()
+
+
+def test_rebuild_carries_every_instances_own_state(cctx):
+    """Two instances of one animator in different states (one has walked through a transition, the other is inside
+    another one): the definition re-sent between frames, each instance keeps ITS run-time state and ITS parameter values
+    -- every instance against its own oracle."""
+    sc = cases.transitions()
+    scripts = [sc.script, {12: [(0, A.Parameter(A.PARAM_RULE, True))], 26: [(1, A.Parameter(A.PARAM_RULE, True))]}]
+    os_ = [cases.build_oracle(oracle2, sc) for _ in scripts]
+    p = cases.build_product(cctx, sc, n_instances=2)
+    desc = sc.machine
+    trs = [o.node_trs() for o in os_]
+    states_seen = set()
+    for f in range(48):
+        for i, script in enumerate(scripts):
+            for idx, par in script.get(f, []):
+                os_[i].set_parameter(idx, par)
+                p.set_parameter(idx, par, instance=i)
+        if f in (9, 14, 15, 30):
+            new, in_place, _ = (edit_retime if f != 30 else edit_grow)(desc)
+            for o in os_:
+                in_place(o.machine)
+            for li in range(len(desc.layers)):
+                for i, o in enumerate(os_):
+                    assert _drain(lambda: p.pop_layer_event(li, i)) == _drain(lambda: o.pop_layer_event(li))
+            p.rebuild_machine(desc, new)
+            desc = new
+        plan = p.plan(1, sc.dt)
+        offs = plan["offsets"]
+        for i, o in enumerate(os_):
+            o.update_machine(sc.dt)
+            assert p.layer_state(0, i) == o.layer_state(0), (f, i)
+            for a in range(len(sc.animations)):
+                assert p.animation_state(a, i) == o.animation_state(a), (f, i, a)
+            poses = [o.animation_pose(a) for a in range(len(sc.animations))]
+            trs[i] = run_program(oracle, plan["ops"][offs[i]:offs[i + 1]], poses, [set()], trs[i])
+            assert np.array_equal(trs[i].view(np.uint32), o.node_trs().view(np.uint32)), (f, i)
+        states_seen.add((p.layer_state(0, 0), p.layer_state(0, 1)))
+    assert any(a != b for a, b in states_seen)          # the instances really were in different states
+    for o in os_:
+        o.close()
+    p.free()
