@@ -23,7 +23,7 @@ use crate::generic_animation::{
 };
 use crate::scene::{
     animation::{
-        absm::{LogicNode, Machine, PoseNode, State, StateAction, Transition},
+        absm::{Event, LogicNode, Machine, PoseNode, State, StateAction, Transition},
         Animation, AnimationContainer,
     },
     graph::Graph,
@@ -216,6 +216,9 @@ pub struct AnimatorMaps {
     pub layers: Vec<LayerMaps>,
     /// `machine_signature` of the definition that was sent last
     pub signature: u64,
+    /// layer events (instance 0) that were still queued in the library when the definition was re-sent: `pop_layer_event`
+    /// serves them first, so an edit loses none (the reference's queue lives in the layer object and survives edits)
+    pub pending_layer_events: Vec<std::collections::VecDeque<Event>>,
 }
 
 /// The dense indices the library knows one layer's pool entries by.
@@ -315,7 +318,7 @@ impl<'a> HipAnimator<'a> {
             }
         }
         let animator = HipAnimator::from_parts(hip, animator_id, n_instances, signal_names);
-        Ok((animator, AnimatorMaps { animation_index, parameter_index: FxHashMap::default(), layers: Vec::new(), signature: 0 }))
+        Ok((animator, AnimatorMaps { animation_index, parameter_index: FxHashMap::default(), layers: Vec::new(), signature: 0, pending_layer_events: Vec::new() }))
     }
 
     /// Before the update: what game code did to the `Animation` objects since the last frame -- `set_speed`, `set_loop`,
@@ -564,8 +567,8 @@ impl<'a> HipAnimator<'a> {
     /// (layer.rs:103-109), `elapsed_time` / `blend_factor` of every transition (transition.rs:188-201), `prev_index` /
     /// `blend_time` of every `BlendAnimationsByIndex` node (node/blend.rs:260-264); the parameter values are the
     /// `ParameterContainer`'s own.  A handle that no longer resolves drops its state; an active state that is gone becomes
-    /// `Handle::NONE`.  Layers are matched by position.  Pending layer events (`fyx_layer_pop_event`) should be drained
-    /// first: they do not survive.  What edit happened is the game's knowledge: call this when it says so (the editor's
+    /// `Handle::NONE`.  Layers are matched by position.  Layer events still queued in the library are moved into
+    /// `maps.pending_layer_events` (as handles) and served by `pop_layer_event` first.  What edit happened is the game's knowledge: call this when it says so (the editor's
     /// commands, a script that rewires the graph) -- not every frame.
     pub fn rebuild_machine(&mut self, machine: &Machine, rig: &RigMap, maps: &mut AnimatorMaps, n_instances: u32) -> Result<(), HipError> {
         let (ctx, id) = (self.raw(), self.id());
@@ -606,6 +609,18 @@ impl<'a> HipAnimator<'a> {
             }
             saved.push(per_layer);
         }
+        // events still queued: out of the library (they do not survive the clear), into the shim's own queue, as handles
+        for li in 0..maps.layers.len() {
+            while let Some(e) = self.pop_layer_event_raw(li as u32, 0, maps)? {
+                if maps.pending_layer_events.len() <= li {
+                    maps.pending_layer_events.resize_with(li + 1, Default::default);
+                }
+                maps.pending_layer_events[li].push_back(e);
+            }
+            for instance in 1..n_instances {
+                while self.pop_layer_event_raw(li as u32, instance, maps)?.is_some() {}
+            }
+        }
         check_rc(ctx, unsafe { fyx_machine_clear(ctx, id) })?;
         maps.parameter_index.clear();
         maps.layers.clear();
@@ -643,6 +658,37 @@ impl<'a> HipAnimator<'a> {
             }
         }
         Ok(())
+    }
+
+    /// `MachineLayer::pop_event` (layer.rs:284-286) of instance 0: events kept across a rebuild first, then the library's.
+    pub fn pop_layer_event(&mut self, layer: u32, maps: &mut AnimatorMaps) -> Result<Option<Event>, HipError> {
+        if let Some(q) = maps.pending_layer_events.get_mut(layer as usize) {
+            if let Some(e) = q.pop_front() {
+                return Ok(Some(e));
+            }
+        }
+        self.pop_layer_event_raw(layer, 0, maps)
+    }
+
+    /// One `fyx_layer_pop_event`, its indices turned back into the handles of `maps` (machine/event.rs:33-51).
+    fn pop_layer_event_raw(&mut self, layer: u32, instance: u32, maps: &AnimatorMaps) -> Result<Option<Event>, HipError> {
+        let mut ev = FyxLayerEvent { kind: 0, a: -1, b: -1 };
+        let mut has = 0i32;
+        check_rc(self.raw(), unsafe { fyx_layer_pop_event(self.raw(), self.id(), layer, instance, &mut ev, &mut has) })?;
+        if has == 0 {
+            return Ok(None);
+        }
+        let Some(lm) = maps.layers.get(layer as usize) else {
+            return Ok(None);
+        };
+        let state = |i: i32| lm.state_index.iter().find(|(_, k)| **k as i32 == i).map(|(h, _)| *h).unwrap_or_default();
+        let transition = |i: i32| lm.transition_index.iter().find(|(_, k)| **k as i32 == i).map(|(h, _)| *h).unwrap_or_default();
+        Ok(Some(match ev.kind {
+            FYX_EVENT_STATE_ENTER => Event::StateEnter(state(ev.a)),
+            FYX_EVENT_STATE_LEAVE => Event::StateLeave(state(ev.a)),
+            FYX_EVENT_ACTIVE_STATE_CHANGED => Event::ActiveStateChanged { prev: state(ev.a), new: state(ev.b) },
+            _ => Event::ActiveTransitionChanged(transition(ev.a)),
+        }))
     }
 
     /// `MachineLayer::reset` (layer.rs:288-296) for every instance.

@@ -28,9 +28,9 @@ STD_METHODS = set("""
 len iter iter_mut enumerate map filter collect copied cloned unwrap_or unwrap_or_else unwrap_or_default map_err ok_or
 is_none is_some insert get get_mut entry or_insert push extend_from_slice as_ptr as_mut_ptr as_slice as_ref as_mut to_string
 to_string_lossy into_owned into clone then copy_from_slice is_empty with_capacity flat_map and_then contains default
-to_rotation_matrix matrix try_inverse identity new new_unchecked from_ptr null null_mut keys values to_bits finish hash ok
+to_rotation_matrix matrix try_inverse identity new new_unchecked from_ptr null null_mut keys values to_bits finish hash ok resize_with push_back pop_front unwrap_or_default
 """.split())
-SHIM_OWN = set("raw id check node from_parts upload_tracks create_rig create_bone_list from_player attach_machine sync_parameters rebuild_machine reset_layer sync_machine push_animations pull_animations of".split())
+SHIM_OWN = set("raw id check node from_parts upload_tracks create_rig create_bone_list from_player attach_machine sync_parameters rebuild_machine reset_layer sync_machine push_animations pull_animations of pop_layer_event pop_layer_event_raw".split())
 
 
 def count_args(src: str, open_paren: int):
@@ -199,7 +199,7 @@ def main():
                                             "layers", "node_index", "state_index", "transition_index", "by_index_nodes",
                                             "active_state", "active_transition", "transitions", "by_index", "known_states", "signature",
                                             # AnimationShadow
-                                            "speed", "looped", "enabled", "slice", "time"):
+                                            "speed", "looped", "enabled", "slice", "time", "pending_layer_events", "a", "b"):
                 continue
             if fld in pub_fns or fld in trait_fns:        # a method reference passed as a value
                 continue
