@@ -333,7 +333,11 @@ class Animator:
         self._check(self._l.fyx_animation_clear_events(self._h, self.id, a, instance))
 
     def pop_layer_event(self, layer: int, instance: int = 0) -> Optional[Tuple[int, int, int]]:
-        """MachineLayer::pop_event -> (kind, a, b) or None."""
+        """MachineLayer::pop_event -> (kind, a, b) or None.  Events that were still queued when the definition was re-sent
+        (rebuild_machine keeps them, indices translated) come first: an edit loses none."""
+        kept = getattr(self, "_kept_layer_events", {}).get((layer, instance))
+        if kept:
+            return kept.pop(0)
         ev = (c_int32 * 3)()
         has = c_int()
         self._check(self._l.fyx_layer_pop_event(self._h, self.id, layer, instance, ev, byref(has)))
@@ -553,6 +557,33 @@ class Animator:
                     "nodes": {n: self.node_state(li, n, inst) for n, nd in enumerate(layer.nodes)
                               if isinstance(nd, BlendAnimationsByIndex)}})
             saved.append(rec)
+        # the layers' event queues live in the layer objects in the reference and survive any edit; here they would go with
+        # fyx_machine_clear, so they are taken out first and kept, with the indices the NEW definition gives their subjects
+        kept = getattr(self, "_kept_layer_events", None)
+        if kept is None:
+            kept = self._kept_layer_events = {}
+        moved = {}
+        for li_old, layer in enumerate(old.layers):
+            li = m({0: layer_map} if layer_map is not None else None, 0, li_old, len(new.layers))
+            for inst in range(self.n_instances):
+                evs = []
+                while True:          # pop_layer_event: the events kept by an earlier rebuild first, then the library's
+                    e = self.pop_layer_event(li_old, inst)
+                    if e is None:
+                        break
+                    kind, a, b = e
+                    ns, nt = (len(new.layers[li].states), len(new.layers[li].transitions)) if li >= 0 else (0, 0)
+                    if kind == EVENT_ACTIVE_TRANSITION_CHANGED:
+                        a = m(transition_maps, li_old, a, nt)
+                    else:
+                        a = m(state_maps, li_old, a, ns)
+                        if kind == EVENT_ACTIVE_STATE_CHANGED:
+                            b = m(state_maps, li_old, b, ns)
+                    evs.append((kind, a, b))
+                if li >= 0 and evs:
+                    moved[(li, inst)] = evs
+        kept.clear()
+        kept.update(moved)
         self.machine_clear()
         self.set_machine(new)
         for inst, rec in enumerate(saved):

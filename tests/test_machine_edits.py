@@ -234,11 +234,12 @@ def _run(cctx, sc, edits_at, n_frames=None, n_instances=2):
             res = edits_at[f](desc)
             if res is not None:
                 new, in_place, maps = res
-                for li in range(len(desc.layers)):          # pending layer events do not survive fyx_machine_clear
-                    ref = _drain(lambda: o.pop_layer_event(li))
-                    for inst in range(n_instances):
-                        got = _drain(lambda: p.pop_layer_event(li, inst))
-                        assert _map_events(got, inv_state[li], inv_trans[li]) == ref
+                if f % 2:                                    # half of the edits with the layers' events still queued:
+                    for li in range(len(desc.layers)):      # rebuild_machine keeps them (the reference's queues survive edits)
+                        ref = _drain(lambda: o.pop_layer_event(li))
+                        for inst in range(n_instances):
+                            got = _drain(lambda: p.pop_layer_event(li, inst))
+                            assert _map_events(got, inv_state[li], inv_trans[li]) == ref
                 in_place(o.machine)
                 p.rebuild_machine(desc, new, **maps)
                 for li in range(len(new.layers)):           # compose with earlier permutations
@@ -263,10 +264,11 @@ def _run(cctx, sc, edits_at, n_frames=None, n_instances=2):
             back_s = s if inv_state.get(li) is None or s < 0 else inv_state[li][s]
             back_t = t if inv_trans.get(li) is None or t < 0 else inv_trans[li][t]
             assert (back_s, back_t) == o.layer_state(li), (sc.name, f, li)
-            ref = _drain(lambda: o.pop_layer_event(li))
-            for inst in range(n_instances):
-                got = _drain(lambda: p.pop_layer_event(li, inst))
-                assert _map_events(got, inv_state.get(li), inv_trans.get(li)) == ref, (sc.name, f, li)
+            if f % 3 == 2 or f == n_frames - 1:      # queues are read every third frame: edits find events still queued
+                ref = _drain(lambda: o.pop_layer_event(li))
+                for inst in range(n_instances):
+                    got = _drain(lambda: p.pop_layer_event(li, inst))
+                    assert _map_events(got, inv_state.get(li), inv_trans.get(li)) == ref, (sc.name, f, li)
         poses = [o.animation_pose(a) for a in range(len(sc.animations))]
         excluded = [set(l.mask) for l in desc.layers]
         trs = run_program(oracle, plan["ops"][offs[0]:offs[1]], poses, excluded, trs)
@@ -549,4 +551,35 @@ def test_rebuild_carries_every_instances_own_state(cctx):
     assert any(a != b for a, b in states_seen)          # the instances really were in different states
     for o in os_:
         o.close()
+    p.free()
+
+
+def test_layer_events_queued_at_the_time_of_an_edit_are_not_lost(cctx):
+    """The reference's event queue is a field of the layer and survives any edit of the layer; behind the C ABI the
+    queue would go with fyx_machine_clear, so rebuild_machine takes the events out first and serves them again --
+    with the indices the re-sent definition gives their states and transitions (the last rebuild reorders the pools)."""
+    sc = cases.transitions()
+    o = cases.build_oracle(oracle2, sc)
+    p = cases.build_product(cctx, sc, n_instances=2)
+    desc, kept_seen = sc.machine, 0
+    inv_s = inv_t = None
+    for f in range(45):
+        for idx, par in sc.script.get(f, []):
+            o.set_parameter(idx, par)
+            p.set_parameter(idx, par)
+        if f in (6, 16, 36):
+            new, in_place, maps = (edit_retime if f == 6 else edit_recondition if f == 16 else edit_permute)(desc)
+            in_place(o.machine)
+            p.rebuild_machine(desc, new, **maps)
+            kept_seen += sum(len(v) for v in p._kept_layer_events.values())
+            if maps:
+                inv_s, inv_t = _inverse(maps["state_maps"], 0), _inverse(maps["transition_maps"], 0)
+            desc = new
+        p.plan(1, sc.dt)
+        o.update_machine(sc.dt)
+    ref = _drain(lambda: o.pop_layer_event(0))
+    assert len(ref) >= 8 and kept_seen >= 6          # the script fired transitions before every one of the edits
+    for inst in range(2):
+        assert _map_events(_drain(lambda: p.pop_layer_event(0, inst)), inv_s, inv_t) == ref
+    o.close()
     p.free()
