@@ -19,6 +19,8 @@ struct Comm {
     int (*comm_destroy)(RcclComm) = nullptr;
     int (*all_gather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
     int (*broadcast)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;     // optional (exchange form 1)
+    int (*recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
     int (*group_start)() = nullptr;
     int (*group_end)() = nullptr;
     int (*comm_count)(RcclComm, int*) = nullptr;
@@ -41,6 +43,8 @@ int load_rccl(fyx_ctx* c, Comm& k) {
     k.all_gather = reinterpret_cast<int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t)>(dlsym(h, "ncclAllGather"));
     k.get_error_string = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
     k.broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t)>(dlsym(h, "ncclBroadcast"));
+    k.send = reinterpret_cast<int (*)(const void*, size_t, int, int, RcclComm, hipStream_t)>(dlsym(h, "ncclSend"));
+    k.recv = reinterpret_cast<int (*)(void*, size_t, int, int, RcclComm, hipStream_t)>(dlsym(h, "ncclRecv"));
     k.group_start = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupStart"));
     k.group_end = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupEnd"));
     k.comm_count = reinterpret_cast<int (*)(RcclComm, int*)>(dlsym(h, "ncclCommCount"));
@@ -69,6 +73,29 @@ uint32_t shard_cut(uint32_t n_verts, uint64_t g, uint64_t n_ranks) {
     const uint64_t groups = ((uint64_t)n_verts + kShardAlign - 1) / kShardAlign;
     const uint64_t v = (g * groups / n_ranks) * kShardAlign;
     return v < n_verts ? (uint32_t)v : n_verts;
+}
+
+// One rank's calls for one stream of the exchange, inside an open RCCL group.  `base` is that rank's full buffer, `me` its rank.
+//   form 0: one broadcast per shard, in place (root = the shard's owner);
+//   form 1: the rank sends its own shard to every other rank and receives every other shard where it belongs -- point to point,
+//           what RCCL turns into one fused send/recv kernel over the xGMI links (no root, no tree).
+int enqueue_stream_exchange(const Comm& k, int form, float* base, uint32_t width, uint32_t n_verts, int me, int n_ranks, hipStream_t st) {
+    constexpr int kNcclFloat32 = 7;   // rccl.h: ncclFloat32
+    const uint32_t mb = shard_cut(n_verts, (uint64_t)me, (uint64_t)n_ranks), me_e = shard_cut(n_verts, (uint64_t)me + 1, (uint64_t)n_ranks);
+    for (int r = 0; r < n_ranks; ++r) {
+        const uint32_t b = shard_cut(n_verts, (uint64_t)r, (uint64_t)n_ranks), e = shard_cut(n_verts, (uint64_t)r + 1, (uint64_t)n_ranks);
+        float* at = base + (size_t)b * width;      // rank r's shard: sent from there by r, received there by all
+        if (form == 0) {
+            if (e == b) continue;
+            if (int rc = k.broadcast(at, at, (size_t)(e - b) * width, kNcclFloat32, r, k.comm, st)) return rc;
+        } else if (r != me) {
+            if (me_e > mb)
+                if (int rc = k.send(base + (size_t)mb * width, (size_t)(me_e - mb) * width, kNcclFloat32, r, k.comm, st)) return rc;
+            if (e > b)
+                if (int rc = k.recv(at, (size_t)(e - b) * width, kNcclFloat32, r, k.comm, st)) return rc;
+        }
+    }
+    return 0;
 }
 
 }  // namespace
@@ -175,23 +202,18 @@ int fyx_allgather_skinned(fyx_ctx* c, uint32_t n_verts, float* d_pos_all, float*
     Comm& k = *c->comm;
     // on the context stream, after every skinning launch in flight (the shard must be complete before it is sent)
     if (int rc = enter_primary(c)) return rc;
-    constexpr int kNcclFloat32 = 7;   // rccl.h: ncclFloat32
+    const int form = c->comm_form;
+    if (form == 1 && (!k.send || !k.recv)) return fail(c, FYX_ERR_UNSUPPORTED, "comm.form=1 needs ncclSend / ncclRecv, which this librccl lacks");
     struct { float* p; uint32_t width; } streams[3] = {{d_pos_all, 3}, {d_normal_all, 3}, {d_tangent_all, 4}};
     int rc = k.group_start();
     if (rc) return rccl_fail(c, k, rc, "ncclGroupStart");
     int first_err = 0;
     for (const auto& s : streams) {
-        if (!s.p) continue;
-        for (int r = 0; r < k.n_ranks && !first_err; ++r) {
-            const uint32_t b = shard_cut(n_verts, (uint64_t)r, (uint64_t)k.n_ranks);
-            const uint32_t e = shard_cut(n_verts, (uint64_t)r + 1, (uint64_t)k.n_ranks);
-            if (e == b) continue;
-            float* at = s.p + (size_t)b * s.width;      // rank r's shard: sent from there by r, received there by all
-            first_err = k.broadcast(at, at, (size_t)(e - b) * s.width, kNcclFloat32, r, k.comm, c->stream);
-        }
+        if (!s.p || first_err) continue;
+        first_err = enqueue_stream_exchange(k, form, s.p, s.width, n_verts, k.rank, k.n_ranks, c->stream);
     }
     rc = k.group_end();     // always closed, also after a failed call inside the group
-    if (first_err) return rccl_fail(c, k, first_err, "ncclBroadcast");
+    if (first_err) return rccl_fail(c, k, first_err, form ? "ncclSend / ncclRecv" : "ncclBroadcast");
     if (rc) return rccl_fail(c, k, rc, "ncclGroupEnd");
     return FYX_OK;
     FYX_GUARD_END(c)
@@ -265,7 +287,8 @@ int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, flo
     for (int i = 0; i < n; ++i)
         if (int rc = enter_primary(ctxs[i])) return i == 0 ? rc : fail(c, rc, "context %d: %s", i, ctxs[i]->err.c_str());
     Comm& k0 = *c->comm;
-    constexpr int kNcclFloat32 = 7;   // rccl.h: ncclFloat32
+    const int form = c->comm_form;
+    if (form == 1 && (!k0.send || !k0.recv)) return fail(c, FYX_ERR_UNSUPPORTED, "comm.form=1 needs ncclSend / ncclRecv, which this librccl lacks");
     const uint32_t widths[3] = {3, 3, 4};
     int rc = k0.group_start();
     if (rc) return rccl_fail(c, k0, rc, "ncclGroupStart");
@@ -275,18 +298,13 @@ int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, flo
         if (hipSetDevice(ctxs[i]->device) != hipSuccess) { first_err = -1; break; }
         for (int s = 0; s < 3 && !first_err; ++s) {
             if (!sets[s]) continue;
-            for (int r = 0; r < n && !first_err; ++r) {
-                const uint32_t b = shard_cut(n_verts, (uint64_t)r, (uint64_t)n), e = shard_cut(n_verts, (uint64_t)r + 1, (uint64_t)n);
-                if (e == b) continue;
-                float* at = sets[s][i] + (size_t)b * widths[s];
-                first_err = k.broadcast(at, at, (size_t)(e - b) * widths[s], kNcclFloat32, r, k.comm, ctxs[i]->stream);
-            }
+            first_err = enqueue_stream_exchange(k, form, sets[s][i], widths[s], n_verts, i, n, ctxs[i]->stream);
         }
     }
     rc = k0.group_end();
     (void)hipSetDevice(c->device);
     if (first_err == -1) return fail(c, FYX_ERR_HIP, "hipSetDevice failed inside the exchange");
-    if (first_err) return rccl_fail(c, k0, first_err, "ncclBroadcast");
+    if (first_err) return rccl_fail(c, k0, first_err, form ? "ncclSend / ncclRecv" : "ncclBroadcast");
     if (rc) return rccl_fail(c, k0, rc, "ncclGroupEnd");
     return FYX_OK;
     FYX_GUARD_END(c)

@@ -88,6 +88,7 @@ struct fyx_ctx {
     bool primary_dirty = true;  // context-stream work enqueued since the last fork event
     int next_worker = 0;
     fyx::Comm* comm = nullptr;
+    int comm_form = 0;       // option "comm.form": how fyx_allgather_skinned moves the shards (0 one broadcast per shard, 1 grouped send / recv)
     fyx::AnimStore* anim = nullptr;
     int plan_threads = 8;    // option "anim.threads": host threads planning a crowd's frame (1 = the calling thread only)
     int sample_form = 0;     // option "anim.sample_form": 0 auto, 1 curves on the lanes, 2 instances on the lanes

@@ -680,7 +680,11 @@ int fyx_comm_info(fyx_ctx* ctx, int* rank, int* n_ranks);
  * d_pos_all + 3 * begin, ...); on return (stream-ordered) every rank holds every shard.  ONE grouped RCCL operation
  * for all streams and all (ragged) shards -- ncclGroupStart, one ncclBroadcast per (stream, rank) rooted at the shard's
  * owner, ncclGroupEnd -- on the context stream, after the GPU-side join of the skinning launches in flight.  All ranks
- * must pass the same n_verts and the same set of non-null streams. */
+ * must pass the same n_verts and the same set of non-null streams.
+ * Option "comm.form" (fyx_set_option, the same value on every rank) picks how the shards travel inside that one group:
+ * 0 (default) the broadcasts above; 1 point to point -- every rank ncclSend's its shard to each other rank and ncclRecv's
+ * each other shard where it belongs (2 (n - 1) calls per stream and rank; RCCL fuses grouped send / recv into one kernel
+ * over the xGMI links, no root and no tree).  Same bytes in the same places either way. */
 int fyx_allgather_skinned(fyx_ctx* ctx, uint32_t n_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all);
 /* ONE PROCESS driving several GPUs -- the engine is one process with one update thread, so this is the
  * form its shim uses: contexts ctxs[0..n) made by fyx_init on n different devices, every call from the same thread.

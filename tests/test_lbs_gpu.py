@@ -879,6 +879,79 @@ def test_single_rank_communicator_all_gathers_a_skinned_shard(ctx, orc):
     ctx.mesh_free(7101)
 
 
+@pytest.mark.parametrize("world,n_verts", [(8, 1_000_000), (3, 20_000), (2, 4097), (5, 1000)])
+def test_shards_skinned_in_place_make_the_whole_mesh(ctx, orc, world, n_verts):
+    """What every rank of a vertex-range split does before the exchange (bench.py's strong-scaling leg): its shard
+    -- uploaded as a mesh of its own -- is skinned by the product kernel straight into its place of the FULL streams, i.e. at the
+    non-zero offsets d_pos_all + 3 * begin, ... (16-byte aligned for the tangents, 4-byte aligned only for position / normal when
+    `begin` is odd... it never is: the cut is 256-vertex aligned).  Here one process plays all ranks in turn on one GPU; the full
+    buffers are then compared with the oracle's single pass, every byte, and the bytes past the last vertex must be untouched."""
+    nb = 256 if n_verts >= 100_000 else 24
+    m = synth.make_mesh(n_verts, nb, synth.SEED_BASE + 44)
+    pal = synth.make_palette(nb, synth.SEED_BASE + 44)
+    d_pal = ctx.to_device(pal)
+    guard = 64
+    full = [ctx.to_device(np.full(n_verts * w + guard, 0xFFFFFFFF, np.uint32)) for w in (3, 3, 4)]
+    cuts = [sharding_range(n_verts, r, world) for r in range(world)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == n_verts and all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+    for r, (b, e) in enumerate(cuts):
+        if e == b:
+            continue
+        ctx.mesh_upload_soa(7300 + r, m.pos[b:e], m.weights[b:e], m.indices[b:e], m.normal[b:e], m.tangent[b:e])
+        ctx.lbs_skin_device(7300 + r, d_pal.ptr, nb, 1, full[0].ptr + 12 * b, full[1].ptr + 12 * b, full[2].ptr + 16 * b)
+    ctx.sync()
+    ref = orc.lbs_skin(m.pos, m.weights, m.indices, pal, m.normal, m.tangent, threads=0)
+    for buf, w, key in zip(full, (3, 3, 4), ("pos", "normal", "tangent")):
+        raw = buf.download(np.uint32, n_verts * w + guard)
+        assert np.all(raw[n_verts * w:] == 0xFFFFFFFF), f"{key}: wrote past the last vertex"
+        assert np.array_equal(raw[:n_verts * w].reshape(n_verts, w), ref[key].view(np.uint32)), key
+    for r, (b, e) in enumerate(cuts):
+        if e > b:
+            ctx.mesh_free(7300 + r)
+    for d in (d_pal, *full):
+        d.free()
+
+
+def sharding_range(n_verts, rank, world):
+    from fyrox_amd.sharding import vertex_range_native
+    return vertex_range_native(n_verts, rank, world)
+
+
+def test_exchange_forms_agree_on_one_rank(ctx, orc):
+    """Option comm.form: 0 = one broadcast per shard, 1 = grouped send / recv between every pair of ranks.  With a communicator of
+    one rank form 1 has no peer (an empty group), form 0 one broadcast to itself: both must leave the skinned streams as they are."""
+    m = synth.make_mesh(5000, 16, synth.SEED_BASE + 45)
+    pal = synth.make_palette(16, synth.SEED_BASE + 45)
+    ctx.mesh_upload_soa(7400, m.pos, m.weights, m.indices, m.normal, m.tangent)
+    d_pal = ctx.to_device(pal)
+    n = m.n_verts
+    d_p, d_n, d_t = ctx.malloc(n * 12), ctx.malloc(n * 12), ctx.malloc(n * 16)
+    with pytest.raises(fyrox_amd.FyxError):
+        ctx.set_option("comm.form", 2)
+    try:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    except fyrox_amd.FyxError as err:
+        if err.code == fyrox_amd._native.FYX_ERR_UNSUPPORTED or "ncclGetUniqueId" in str(err) or "ncclCommInitRank" in str(err):
+            pytest.skip(f"RCCL could not initialise here: {err}")
+        raise
+    ref = orc.lbs_skin(m.pos, m.weights, m.indices, pal, m.normal, m.tangent, threads=0)
+    try:
+        for form in (1, 0):
+            ctx.set_option("comm.form", form)
+            assert ctx.get_option("comm.form") == form
+            ctx.lbs_skin_device(7400, d_pal.ptr, 16, 1, d_p.ptr, d_n.ptr, d_t.ptr)
+            ctx.allgather_skinned(n, d_p.ptr, d_n.ptr, d_t.ptr)
+            ctx.sync()
+            assert np.array_equal(d_p.download(np.float32, n * 3).reshape(n, 3), ref["pos"])
+            assert np.array_equal(d_t.download(np.float32, n * 4).reshape(n, 4), ref["tangent"])
+    finally:
+        ctx.set_option("comm.form", 0)
+        ctx.comm_shutdown()
+    for d in (d_pal, d_p, d_n, d_t):
+        d.free()
+    ctx.mesh_free(7400)
+
+
 def test_one_process_form_of_the_exchange(ctx, orc):
     """fyx_comm_init_all / fyx_allgather_skinned_all -- one process (one thread) driving every GPU, the engine's shape --
     as far as one GPU can take them: a communicator of one context, the in-place exchange ordered after the skinning

@@ -114,6 +114,59 @@ def _worker_in_place(rank: int, world: int, port: int, n_verts: int, n_bones: in
         dist.destroy_process_group()
 
 
+def _worker_send_recv(rank: int, world: int, port: int, n_verts: int, n_bones: int, q):
+    """The schedule of fyx_allgather_skinned with comm.form = 1, gloo standing in for RCCL: every rank sends its own shard to each
+    other rank and receives each other shard in place -- 2 (world - 1) point-to-point calls per stream, all posted before any is
+    waited for (RCCL: inside one group)."""
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seed = synth.SEED_BASE + 4
+        mesh = synth.make_mesh(n_verts, n_bones, seed)
+        pal = synth.make_palette(n_bones, seed)
+        b, e = sharding.vertex_range_native(n_verts, rank, world)
+        out = oracle.lbs_skin(mesh.pos[b:e], mesh.weights[b:e], mesh.indices[b:e], pal, mesh.normal[b:e], mesh.tangent[b:e])
+        full = {k: torch.full((n_verts, w), float("nan")) for k, w in (("pos", 3), ("normal", 3), ("tangent", 4))}
+        for k in full:
+            full[k][b:e] = torch.from_numpy(out[k])
+        reqs = []
+        for k in ("pos", "normal", "tangent"):
+            for r in range(world):
+                if r == rank:
+                    continue
+                rb, re = sharding.vertex_range_native(n_verts, r, world)
+                if e > b:
+                    reqs.append(dist.isend(full[k][b:e], dst=r))
+                if re > rb:
+                    reqs.append(dist.irecv(full[k][rb:re], src=r))      # a view: received in place
+        for rq in reqs:
+            rq.wait()
+        ref = oracle.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal, mesh.normal, mesh.tangent)
+        q.put((rank, all(np.array_equal(full[k].numpy(), ref[k]) for k in ref), (b, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_verts", [(2, 4097), (3, 1000), (2, 300)])
+def test_send_recv_gather_schedule(world, n_verts):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_send_recv, args=(r, world, port, n_verts, 16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results)
+
+
 @pytest.mark.parametrize("world,n_verts", [(2, 4097), (3, 1000), (2, 300)])
 def test_in_place_ragged_gather_schedule(world, n_verts):
     import torch.multiprocessing as mp
