@@ -267,8 +267,23 @@ CtrlLayout ctrl_layout(const Animator& A) {
     return L;
 }
 
+// The same sections 16-byte aligned and behind the 16-byte header of a CtrlInline: what travels in the kernel arguments.
+CtrlLayout ctrl_layout_inline(const Animator& A) {
+    CtrlLayout L;
+    L.rm = A.rm_enabled;
+    L.o_times = 16;
+    L.o_tick = L.o_times + align_up(A.times.size() * 4, 16);
+    L.o_off = L.o_tick + align_up(A.ticked.size(), 16);
+    L.o_ops = L.o_off + align_up(A.prog_off.size() * 4, 16);
+    L.o_slices = L.o_ops + align_up(A.ops.size() * 8, 16);
+    L.o_rmoff = L.o_slices + (L.rm ? align_up(A.slices.size() * 8, 16) : 0);
+    L.o_rmops = L.o_rmoff + (L.rm ? align_up(A.rm_prog_off.size() * 4, 16) : 0);
+    L.total = L.o_rmops + (L.rm ? align_up(A.rm_ops.size() * 16, 16) : 0);
+    return L;
+}
+
 void ctrl_write(const Animator& A, const CtrlLayout& L, char* h) {
-    memcpy(h, A.times.data(), A.times.size() * 4);
+    memcpy(h + L.o_times, A.times.data(), A.times.size() * 4);
     memcpy(h + L.o_tick, A.ticked.data(), A.ticked.size());
     memcpy(h + L.o_off, A.prog_off.data(), A.prog_off.size() * 4);
     memcpy(h + L.o_ops, A.ops.data(), A.ops.size() * 8);
@@ -281,7 +296,7 @@ void ctrl_write(const Animator& A, const CtrlLayout& L, char* h) {
 
 // Point the frame's parameters at the device copy of the control block.
 void ctrl_bind(const Animator& A, const CtrlLayout& L, const char* d, PoseFrameDev& f) {
-    f.times = reinterpret_cast<const float*>(d);
+    f.times = reinterpret_cast<const float*>(d + L.o_times);
     f.ticked = reinterpret_cast<const uint8_t*>(d + L.o_tick);
     f.prog_off = reinterpret_cast<const uint32_t*>(d + L.o_off);
     f.ops = reinterpret_cast<const uint2*>(d + L.o_ops);
@@ -317,23 +332,36 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     PoseFrameDev f;
     frame_static(c, A, f);
     int slot = 0;
+    bool in_args = false;
+    CtrlInline inl;
+    inl.bytes = 0;
     if (with_program) {
-        const CtrlLayout L = ctrl_layout(A);
-        char *h = nullptr, *d = nullptr;
-        if (int rc = ctrl_acquire(c, A.ctrl, L.total, &slot, &h, &d)) return rc;
-        ctrl_write(A, L, h);
-        if (int rc = ctrl_upload(c, A.ctrl, slot, L.total)) return rc;
-        ctrl_bind(A, L, d, f);
-        FYX_HIP(c, launch_pose_sample(f, c->stream));
-        FYX_HIP(c, launch_property_sample(f, c->stream));
-        if (L.rm) FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), c->stream));
+        // a small control block (one character, a handful of instances) rides in the kernel arguments: no copy, no event, no wait
+        const CtrlLayout Li = ctrl_layout_inline(A);
+        in_args = c->inline_ctrl && Li.total <= sizeof(CtrlInline);
+        const CtrlLayout L = in_args ? Li : ctrl_layout(A);
+        if (in_args) {
+            ctrl_write(A, L, reinterpret_cast<char*>(&inl));    // the sections start behind the header (offset 16)
+            inl.bytes = (uint32_t)L.total;
+            ctrl_bind(A, L, nullptr, f);                        // the control pointers become offsets from the start of `inl`
+        } else {
+            char *h = nullptr, *d = nullptr;
+            if (int rc = ctrl_acquire(c, A.ctrl, L.total, &slot, &h, &d)) return rc;
+            ctrl_write(A, L, h);
+            if (int rc = ctrl_upload(c, A.ctrl, slot, L.total)) return rc;
+            ctrl_bind(A, L, d, f);
+        }
+        FYX_HIP(c, launch_pose_sample(f, c->stream, &inl));
+        FYX_HIP(c, launch_property_sample(f, c->stream, &inl));
+        if (L.rm) FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), c->stream, &inl));
     }
     RigDev rd;
     if (int rc = rig_params(c, A, rd)) return rc;
-    FYX_HIP(c, launch_pose_update(f, rd, with_program, c->stream));
+    FYX_HIP(c, launch_pose_update(f, rd, with_program, c->stream, &inl));
     if (with_program) {
-        FYX_HIP(c, launch_property_update(f, c->stream));
-        if (int rc = ctrl_consumed(c, A.ctrl, slot)) return rc;
+        FYX_HIP(c, launch_property_update(f, c->stream, &inl));
+        if (!in_args)
+            if (int rc = ctrl_consumed(c, A.ctrl, slot)) return rc;
     }
     return FYX_OK;
 }

@@ -281,7 +281,34 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
     }
 }
 
-__global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f) { pose_sample_body(f, blockIdx.x, blockIdx.y, blockIdx.z); }
+// The frame's control block inside the kernel arguments (CtrlInline, fyx_internal.h): the control pointers are offsets from the
+// start of `inl`, which the kernel reads where it lies -- in the kernel-argument segment, ordinary device-visible memory.
+// KARG_OFF: where `inl` lies in the kernel-argument segment (the parameters before it are 8-byte aligned structs, CtrlInline is
+// 4-byte aligned: it follows them directly).  The address comes from the segment pointer, not from `&inl`: taking the address of
+// the by-value parameter makes the compiler copy the whole kilobyte to scratch in some kernels.
+template <size_t KARG_OFF>
+__device__ __forceinline__ PoseFrameDev ctrl_resolve(PoseFrameDev f, const CtrlInline& inl) {
+    if (inl.bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const char* cb = reinterpret_cast<const char*>((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr()) + KARG_OFF;
+#else
+        const char* cb = nullptr;    // (the host pass only parses this)
+#endif
+        f.times = reinterpret_cast<const float*>(cb + reinterpret_cast<uintptr_t>(f.times));
+        f.ticked = reinterpret_cast<const uint8_t*>(cb + reinterpret_cast<uintptr_t>(f.ticked));
+        f.ops = reinterpret_cast<const uint2*>(cb + reinterpret_cast<uintptr_t>(f.ops));
+        f.prog_off = reinterpret_cast<const uint32_t*>(cb + reinterpret_cast<uintptr_t>(f.prog_off));
+        if (f.slices) f.slices = reinterpret_cast<const float2*>(cb + reinterpret_cast<uintptr_t>(f.slices));
+        if (f.rm_ops) f.rm_ops = reinterpret_cast<const uint4*>(cb + reinterpret_cast<uintptr_t>(f.rm_ops));
+        if (f.rm_prog_off) f.rm_prog_off = reinterpret_cast<const uint32_t*>(cb + reinterpret_cast<uintptr_t>(f.rm_prog_off));
+    }
+    return f;
+}
+static_assert(sizeof(PoseFrameDev) % 8 == 0 && sizeof(RigDev) % 8 == 0 && alignof(CtrlInline) == 4, "kernel-argument layout of (PoseFrameDev[, RigDev], CtrlInline)");
+constexpr size_t kInlAfterFrame = sizeof(PoseFrameDev), kInlAfterFrameAndRig = sizeof(PoseFrameDev) + sizeof(RigDev);
+static const CtrlInline kNoInline = {};
+
+__global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f, CtrlInline inl) { pose_sample_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // Scene forms of the kernels in this file (fyx_scene_update): ONE launch covers the same stage of MANY animators.
 // Block b of the launch looks up (job, x, y, z) in a table that depends only on the scene's shape -- which animator
@@ -401,7 +428,7 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
     }
 }
 
-__global__ __launch_bounds__(64) void pose_sample_crowd_kernel(PoseFrameDev f) { pose_sample_crowd_body(f, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(64) void pose_sample_crowd_kernel(PoseFrameDev f, CtrlInline inl) { pose_sample_crowd_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y, blockIdx.z); }
 
 __global__ __launch_bounds__(64) void pose_sample_crowd_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
@@ -409,13 +436,13 @@ __global__ __launch_bounds__(64) void pose_sample_crowd_scene_kernel(const Scene
     pose_sample_crowd_body(f, b.y, b.z, b.w);
 }
 
-hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s) {
+hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl) {
     if (f.n_anims == 0 || f.n_instances == 0 || f.n_nodes == 0) return hipSuccess;
     if (f.n_instances > 65535u || f.n_anims > 65535u || f.n_nodes * 3u > 65535u) return hipErrorInvalidValue;   // grid limits
     if (f.sample_form == 2 || (f.sample_form == 0 && f.n_instances >= 32)) {
-        hipLaunchKernelGGL(pose_sample_crowd_kernel, dim3((f.n_instances + 63) / 64, f.n_nodes * 3, f.n_anims), dim3(64), 0, s, f);
+        hipLaunchKernelGGL(pose_sample_crowd_kernel, dim3((f.n_instances + 63) / 64, f.n_nodes * 3, f.n_anims), dim3(64), 0, s, f, inl ? *inl : kNoInline);
     } else {
-        hipLaunchKernelGGL(pose_sample_kernel, dim3((f.n_nodes * 16 + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(pose_sample_kernel, dim3((f.n_nodes * 16 + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f, inl ? *inl : kNoInline);
     }
     return hipGetLastError();
 }
@@ -609,8 +636,8 @@ __device__ __forceinline__ void root_motion_fold_body(const PoseFrameDev& f, uin
     }
 }
 
-__global__ __launch_bounds__(256) void root_motion_kernel(PoseFrameDev f) { root_motion_body(f, blockIdx.x, gridDim.x); }
-__global__ __launch_bounds__(64) void root_motion_fold_kernel(PoseFrameDev f) { root_motion_fold_body(f, blockIdx.x); }
+__global__ __launch_bounds__(256) void root_motion_kernel(PoseFrameDev f, CtrlInline inl) { root_motion_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void root_motion_fold_kernel(PoseFrameDev f, CtrlInline inl) { root_motion_fold_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x); }
 
 __global__ __launch_bounds__(256) void root_motion_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];          // {job, block of the job, blocks of the job, -}
@@ -623,17 +650,17 @@ __global__ __launch_bounds__(64) void root_motion_fold_scene_kernel(const SceneJ
     root_motion_fold_body(f, b.y);
 }
 
-hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s) {
+hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s, const CtrlInline* inl) {
     const uint64_t items = (uint64_t)f.n_anims * f.n_instances;
     if (items && f.rm_anim) {
         uint64_t grid = (items * 16 + 255) / 256;
         if (grid > (uint64_t)kCUs * 16) grid = (uint64_t)kCUs * 16;
-        hipLaunchKernelGGL(root_motion_kernel, dim3((uint32_t)grid), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(root_motion_kernel, dim3((uint32_t)grid), dim3(256), 0, s, f, inl ? *inl : kNoInline);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     if (run_program && f.rm_slots && f.rm_ops && f.n_instances) {
-        hipLaunchKernelGGL(root_motion_fold_kernel, dim3((f.n_instances + 63) / 64), dim3(64), 0, s, f);
+        hipLaunchKernelGGL(root_motion_fold_kernel, dim3((f.n_instances + 63) / 64), dim3(64), 0, s, f, inl ? *inl : kNoInline);
         return hipGetLastError();
     }
     return hipSuccess;
@@ -833,16 +860,16 @@ __device__ __forceinline__ void property_sample_body(const PoseFrameDev& f, uint
     f.prop_pose[((size_t)a * f.n_instances + inst) * f.n_prop_slots + slot] = out;
 }
 
-__global__ __launch_bounds__(256) void property_sample_kernel(PoseFrameDev f) { property_sample_body(f, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256) void property_sample_kernel(PoseFrameDev f, CtrlInline inl) { property_sample_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y, blockIdx.z); }
 __global__ __launch_bounds__(256) void property_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
     const PoseFrameDev f = jobs[b.x].f;
     property_sample_body(f, b.y, b.z, b.w);
 }
 
-hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s) {
+hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl) {
     if (!f.n_prop_slots || !f.n_anims || !f.n_instances) return hipSuccess;
-    hipLaunchKernelGGL(property_sample_kernel, dim3((f.n_prop_slots + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(property_sample_kernel, dim3((f.n_prop_slots + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f, inl ? *inl : kNoInline);
     return hipGetLastError();
 }
 
@@ -973,16 +1000,16 @@ __device__ __forceinline__ void property_update_body(const PoseFrameDev& f, uint
     }
 }
 
-__global__ __launch_bounds__(64) void property_update_kernel(PoseFrameDev f) { property_update_body(f, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(64) void property_update_kernel(PoseFrameDev f, CtrlInline inl) { property_update_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(64) void property_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
     const PoseFrameDev f = jobs[b.x].f;
     property_update_body(f, b.y, b.z);
 }
 
-hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s) {
+hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl) {
     if (!f.n_prop_slots || !f.n_instances) return hipSuccess;
-    hipLaunchKernelGGL(property_update_kernel, dim3((f.n_prop_slots + 63) / 64, f.n_instances), dim3(64), 0, s, f);
+    hipLaunchKernelGGL(property_update_kernel, dim3((f.n_prop_slots + 63) / 64, f.n_instances), dim3(64), 0, s, f, inl ? *inl : kNoInline);
     return hipGetLastError();
 }
 
@@ -1249,7 +1276,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
 }
 
 template <bool PROGRAM>
-__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) { pose_update_body<PROGRAM>(f, rig, blockIdx.x); }
+__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl) { pose_update_body<PROGRAM>(ctrl_resolve<kInlAfterFrameAndRig>(f, inl), rig, blockIdx.x); }
 
 // Scene form: every job of one launch has the same block size; the dynamic LDS is sized for the largest rig among them.
 __global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
@@ -1259,7 +1286,7 @@ __global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDe
     pose_update_body<true>(f, rig, b.y);
 }
 
-hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s) {
+hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s, const CtrlInline* inl) {
     if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;
     uint32_t block = ((rig.n_nodes + 63) / 64) * 64;
     if (block > 256) block = 256;
@@ -1270,14 +1297,14 @@ hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(pose_update_kernel<true>, dim3(f.n_instances), dim3(block), lds, s, f, rig);
+        hipLaunchKernelGGL(pose_update_kernel<true>, dim3(f.n_instances), dim3(block), lds, s, f, rig, inl ? *inl : kNoInline);
     } else {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_update_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(pose_update_kernel<false>, dim3(f.n_instances), dim3(block), lds, s, f, rig);
+        hipLaunchKernelGGL(pose_update_kernel<false>, dim3(f.n_instances), dim3(block), lds, s, f, rig, kNoInline);
     }
     return hipGetLastError();
 }

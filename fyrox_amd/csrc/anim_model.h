@@ -211,7 +211,7 @@ struct Animator {
 // The per-frame control block of an animator (what plan_frame produced), as it travels to the GPU: 256-byte aligned
 // sections {times, ticked, prog_off, ops [, slices, rm_prog_off, rm_ops]}.
 struct CtrlLayout {
-    size_t o_tick = 0, o_off = 0, o_ops = 0, o_slices = 0, o_rmoff = 0, o_rmops = 0, total = 0;
+    size_t o_times = 0, o_tick = 0, o_off = 0, o_ops = 0, o_slices = 0, o_rmoff = 0, o_rmops = 0, total = 0;
     bool rm = false;
 };
 

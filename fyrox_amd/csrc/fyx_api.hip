@@ -610,6 +610,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "anim.threads")) return &c->plan_threads;
     if (!strcmp(key, "anim.split")) return &c->plan_split;
     if (!strcmp(key, "anim.overlap")) return &c->pose_overlap;
+    if (!strcmp(key, "anim.inline_ctrl")) return &c->inline_ctrl;
     if (!strcmp(key, "anim.sample_form")) return &c->sample_form;
     return nullptr;
 }
@@ -634,6 +635,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_ipb must be 0 (auto) .. 4096");
     if (slot == &c->comm_form && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "comm.form must be 0 (broadcasts) or 1 (send / recv)");
     if (slot == &c->sample_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.sample_form must be 0, 1 or 2");
+    if (slot == &c->inline_ctrl && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.inline_ctrl must be 0 or 1");
     if (slot == &c->pose_overlap && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.overlap must be 0 or 1");
     if (slot == &c->plan_split && value < 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.split must be >= 1");
     if (slot == &c->plan_threads && (value < 1 || value > 64))

@@ -93,6 +93,7 @@ struct fyx_ctx {
     int plan_threads = 8;    // option "anim.threads": host threads planning a crowd's frame (1 = the calling thread only)
     int sample_form = 0;     // option "anim.sample_form": 0 auto, 1 curves on the lanes, 2 instances on the lanes
     int pose_overlap = 0;    // option "anim.overlap": 1 = pose updates do not wait for in-flight skinning launches (see enter_pose)
+    int inline_ctrl = 1;     // option "anim.inline_ctrl": 1 = a control block of <= 1 KB travels in the kernel arguments (no H2D copy)
     int plan_split = 2048;   // option "anim.split": instances per planning task
     fyx::PlanPool* plan_pool = nullptr;
     fyx::SkinBatch* skin_batch = nullptr;

@@ -321,6 +321,18 @@ struct PoseFrameDev {
     const uint32_t* rm_prog_off; // [n_instances + 1]
 };
 
+// A small per-frame control block rides INSIDE the kernel arguments of the single-animator launches (one character: a few
+// hundred bytes of sample times, tick flags and fold program) instead of in a device block uploaded by an H2D copy on its own
+// stream -- that copy, its event and the stream wait were ~8 us of a 25 us frame.  `bytes` != 0: the control pointers of the
+// PoseFrameDev beside it (times, ticked, ops, prog_off, slices, rm_ops, rm_prog_off) hold OFFSETS from the start of this struct.
+constexpr uint32_t kCtrlInlineBytes = 1008;
+struct CtrlInline {
+    uint32_t bytes;          // 0: the control block is in device memory and the pointers are pointers
+    uint32_t pad[3];
+    uint32_t words[kCtrlInlineBytes / 4];
+};
+static_assert(sizeof(CtrlInline) == 16 + kCtrlInlineBytes, "header + payload");
+
 // fyx_scene_update: one parameter block per animator of the scene, rewritten every frame (it points into the frame's
 // control block) and read by the *_scene_kernel forms, whose block tables say which job a block works for.
 struct SceneJobDev {
@@ -354,14 +366,15 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&tab
 hipError_t launch_scene(const SceneJobDev* d_jobs, const uint4* const (&d_tables)[kSceneStages],
                         const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], hipStream_t s);
 
-hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s);
-hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s);
+// `inl` (optional): the frame's control block travelling in the kernel arguments, see CtrlInline.
+hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);
+hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s, const CtrlInline* inl = nullptr);
 // Animation::update_root_motion for every ticked animation that has settings (after pose_sample:
 // rewrites the root node's pose record), then the per-instance root-motion program (machine mode).
-hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s);
+hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s, const CtrlInline* inl = nullptr);
 // Property slots: sample the Real tracks of every ticked animation / run the instance's fold program on them
-hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s);
-hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s);
+hipError_t launch_property_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);
+hipError_t launch_property_update(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);
 // out[inst][k] = (has(inst, slots[k]) ? value(inst, slots[k]) : defaults[k]) / 100  (mesh/mod.rs:794-798)
 hipError_t launch_blend_shape_weights(const PropRec* prop_out, uint32_t n_prop_slots, uint32_t n_instances,
                                       const int32_t* d_slots, const float* d_defaults, uint32_t n_shapes, float* d_out,
