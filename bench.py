@@ -666,7 +666,7 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    opt_keys = ("lbs.block", "lbs.blocks_per_cu", "lbs.prefetch", "lbs.exact", "lbs.nt", "lbs.streams", "lbs.split", "lbs.dyn", "lbs.dyn_block")
+    opt_keys = ("lbs.blocks_per_cu", "lbs.exact", "lbs.streams", "lbs.dyn", "lbs.crowd", "anim.inline_ctrl", "comm.form")
     opts = {k: ctx.get_option(k) for k in opt_keys}
     n_ranks_rccl, comm_error = None, None
     if world > 1:      # the library's own communicator (fyx_comm_init): rank 0's unique id travels over the process group

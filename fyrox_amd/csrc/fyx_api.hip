@@ -186,7 +186,6 @@ void free_mesh(Mesh& m) {
     if (m.block) (void)hipFree(m.block);
     if (m.shapes) (void)hipFree(m.shapes);
     if (m.aos) (void)hipFree(m.aos);
-    if (m.tiled) (void)hipFree(m.tiled);
     m = Mesh();
 }
 
@@ -215,13 +214,6 @@ int alloc_mesh(fyx_ctx* c, Mesh& m, uint32_t n, bool has_nrm, bool has_tan) {
 
 int finish_upload(fyx_ctx* c, uint64_t mesh_id, Mesh& m) {
     hipError_t e = hipSuccess;
-    if ((c->lbs.dyn_knobs & 0x2000) && m.n_verts >= fyx::kTiledFromVerts && m.nrm && m.tan) {   // experiment: unit-tiled inputs for lbs_skin_dyn
-        const size_t units = ((size_t)m.n_verts + 63) / 64 + 2;
-        e = hipMalloc(reinterpret_cast<void**>(&m.tiled), units * fyx::kTiledDwordsPerUnit * 4);
-        if (e == hipSuccess) e = hipMemsetAsync(m.tiled, 0, units * fyx::kTiledDwordsPerUnit * 4, c->stream);
-        if (e == hipSuccess) e = fyx::launch_retile_units(m.pos, m.nrm, m.tan, m.wgt, m.idx, m.n_verts, m.tiled, c->stream);
-        if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "unit-tiled copy"); }
-    }
     e = fyx::launch_max_bone_index(m.idx, m.n_verts, c->d_u32, c->stream);
     if (e != hipSuccess) { free_mesh(m); return hip_fail(c, e, "max_bone_index"); }
     uint32_t mx = 0;
@@ -261,7 +253,6 @@ fyx::LbsArgs make_args(const Mesh& m, const float* d_palette, uint32_t n_bones, 
     a.palette = d_palette;
     a.out_pos = op; a.out_nrm = on; a.out_tan = ot;
     a.n_verts = m.n_verts; a.n_bones = n_bones; a.n_instances = n_inst;
-    a.tiled = m.tiled;
     return a;
 }
 
@@ -528,9 +519,6 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->d_u32) (void)hipFree(c->d_u32);
     for (hipEvent_t e : c->timing_ev) (void)hipEventDestroy(e);
     c->timing_ev.clear();
-    if (c->lbs.probe_buf) (void)hipFree(c->lbs.probe_buf);
-    if (c->lbs.pool_buf) (void)hipFree(c->lbs.pool_buf);
-    delete c->lbs.pool_seq;
     for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
         if (c->workers[w]) { (void)hipStreamSynchronize(c->workers[w]); (void)hipStreamDestroy(c->workers[w]); }
         if (c->worker_done[w]) (void)hipEventDestroy(c->worker_done[w]);
@@ -586,26 +574,14 @@ int fyx_timer_end(fyx_ctx* c, float* out_ms) {
 
 static int* option_slot(fyx_ctx* c, const char* key) {
     if (!key) return nullptr;
-    if (!strcmp(key, "lbs.block")) return &c->lbs.block;
     if (!strcmp(key, "lbs.blocks_per_cu")) return &c->lbs.blocks_per_cu;
-    if (!strcmp(key, "lbs.prefetch")) return &c->lbs.prefetch;
     if (!strcmp(key, "lbs.exact")) return &c->lbs.exact;
-    if (!strcmp(key, "lbs.nt")) return &c->lbs.nt;
     if (!strcmp(key, "lbs.streams")) return &c->n_workers;
     if (!strcmp(key, "lbs.crowd")) return &c->lbs.crowd;
-    if (!strcmp(key, "lbs.crowd_block")) return &c->lbs.crowd_block;
     if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
     if (!strcmp(key, "lbs.crowd_lean")) return &c->lbs.crowd_lean;
-    if (!strcmp(key, "lbs.probe")) return &c->lbs.probe;
     if (!strcmp(key, "lbs.timing")) return &c->timing;
-    if (!strcmp(key, "lbs.split")) return &c->lbs.split;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
-    if (!strcmp(key, "lbs.dyn_bpc")) return &c->lbs.dyn_bpc;
-    if (!strcmp(key, "lbs.dyn_block")) return &c->lbs.dyn_block;
-    if (!strcmp(key, "lbs.dyn_knobs")) return &c->lbs.dyn_knobs;
-    if (!strcmp(key, "lbs.asym")) return &c->lbs.asym;
-    if (!strcmp(key, "lbs.policy")) return &c->lbs.policy;
-    if (!strcmp(key, "lbs.young_prio")) return &c->lbs.young_prio;
     if (!strcmp(key, "comm.form")) return &c->comm_form;
     if (!strcmp(key, "anim.threads")) return &c->plan_threads;
     if (!strcmp(key, "anim.split")) return &c->plan_split;
@@ -619,8 +595,6 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (!c) return FYX_ERR_INVALID_ARG;
     int* slot = option_slot(c, key);
     if (!slot) return fail(c, FYX_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
-    if ((slot == &c->lbs.block || slot == &c->lbs.dyn_block) && value != 256 && value != 512 && value != 1024)
-        return fail(c, FYX_ERR_INVALID_ARG, "%s must be 256, 512 or 1024", key);
     if (slot == &c->n_workers) {
         if (value < 1 || value > fyx_ctx::kMaxWorkers)
             return fail(c, FYX_ERR_INVALID_ARG, "lbs.streams must be 1..%d", fyx_ctx::kMaxWorkers);
@@ -629,8 +603,6 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     }
     if (slot == &c->lbs.crowd && (value < -1 || value > 1))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd must be -1 (auto), 0 or 1");
-    if (slot == &c->lbs.crowd_block && value != 256 && value != 512)
-        return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_block must be 256 or 512");
     if (slot == &c->lbs.crowd_ipb && (value < 0 || value > 4096))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_ipb must be 0 (auto) .. 4096");
     if (slot == &c->comm_form && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "comm.form must be 0 (broadcasts) or 1 (send / recv)");
@@ -642,34 +614,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");
     if (slot == &c->lbs.blocks_per_cu && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.blocks_per_cu must be 1..64");
-    if (slot == &c->lbs.dyn_bpc && (value < 0 || value > 4)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.dyn_bpc must be 0..4");
-    if (slot == &c->lbs.asym && (value < 0 || value > 63)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.asym must be 0..63");
-    if (slot == &c->lbs.young_prio && (value < 0 || value > 3)) return fail(c, FYX_ERR_INVALID_ARG, "lbs.young_prio must be 0..3");
-    if (slot == &c->lbs.dyn_knobs && ((value >> 16) & 63) && !c->lbs.pool_buf) {
-        if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
-        if (int rc = enter_primary(c)) return rc;
-        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->lbs.pool_buf), 4 * 64 * 256));
-        FYX_HIP(c, hipMemset(c->lbs.pool_buf, 0, 4 * 64 * 256));
-        c->lbs.pool_seq = new uint32_t(0);
-    }
-    if (slot == &c->lbs.probe && value && !c->lbs.probe_buf) {
-        if (c->device < 0) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
-        c->lbs.probe_words = (size_t)65536 * 4;
-        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->lbs.probe_buf), c->lbs.probe_words * 8));
-    }
     *slot = value;
-    return FYX_OK;
-}
-
-// Debug: copy the per-wave timeline the last lbs.probe=1 launch wrote ({entry, staged, last store issued, last
-// store done} in 10 ns ticks per wave).  Allocates the probe buffer on first use (64 K waves).
-int fyx_debug_read_probe(fyx_ctx* c, uint64_t* host_out, uint32_t n_waves) {
-    if (!c || !host_out) return FYX_ERR_INVALID_ARG;
-    if (int rc = enter_primary(c)) return rc;
-    if (!c->lbs.probe_buf) return fail(c, FYX_ERR_INVALID_ARG, "no probe buffer: set lbs.probe=1 first");
-    if ((size_t)n_waves * 4 > c->lbs.probe_words) return fail(c, FYX_ERR_INVALID_ARG, "n_waves too large");
-    FYX_HIP(c, hipStreamSynchronize(c->stream));
-    FYX_HIP(c, hipMemcpy(host_out, c->lbs.probe_buf, (size_t)n_waves * 32, hipMemcpyDeviceToHost));
     return FYX_OK;
 }
 
@@ -851,8 +796,9 @@ int fyx_lbs_skin_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, ui
         fyx::LbsTuning t = c->lbs;
         t.ev_start = c->timing_ev[c->timing_used];
         t.ev_stop = c->timing_ev[c->timing_used + 1];
-        c->timing_used += 2;
+        const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
         FYX_HIP(c, fyx::launch_lbs(a, t, st));
+        if (mask && a.n_verts && a.n_instances) c->timing_used += 2;   // the pair is claimed only by a launch that recorded it
         return FYX_OK;
     }
     FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
@@ -866,13 +812,16 @@ int fyx_debug_kernel_time(fyx_ctx* c, double* total_us, uint32_t* n_launches) {
     if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     double sum = 0.0;
+    uint32_t counted = 0;
     for (size_t k = 0; k + 1 < c->timing_used; k += 2) {
         float ms = 0.f;
-        FYX_HIP(c, hipEventElapsedTime(&ms, c->timing_ev[k], c->timing_ev[k + 1]));
+        // a pair whose elapsed time cannot be read (never recorded) is skipped: one bad pair must not wedge the counters
+        if (hipEventElapsedTime(&ms, c->timing_ev[k], c->timing_ev[k + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
         sum += (double)ms * 1e3;
+        ++counted;
     }
     *total_us = sum;
-    *n_launches = (uint32_t)(c->timing_used / 2);
+    *n_launches = counted;
     c->timing_used = 0;
     // the events go back to the runtime (a measurement leg may have made thousands)
     for (hipEvent_t e : c->timing_ev) (void)hipEventDestroy(e);

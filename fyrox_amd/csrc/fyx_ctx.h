@@ -21,7 +21,6 @@ struct Mesh {
     float* tan = nullptr;
     float* wgt = nullptr;
     uint32_t* idx = nullptr;
-    uint32_t* tiled = nullptr;  // unit-tiled copy of the five streams (meshes large enough for lbs_skin_dyn with all attributes)
     // BlendShapesContainer offsets, re-tiled (own allocation; replaced by fyx_mesh_set_blend_shapes)
     uint16_t* shapes = nullptr;
     uint32_t n_shapes = 0;

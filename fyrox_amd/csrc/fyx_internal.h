@@ -10,31 +10,13 @@ namespace fyx {
 constexpr int kCUs = 256;  // MI355X
 
 struct LbsTuning {
-    int block = 512;         // threads per workgroup: 256 | 512 | 1024
-    int blocks_per_cu = 4;   // persistent grid = kCUs * blocks_per_cu (capped by the work)
-    int prefetch = 1;        // software-pipeline each wave (loads of unit i+1 before math of unit i)
+    int blocks_per_cu = 4;   // lbs_skin's persistent grid = kCUs * blocks_per_cu (capped by the work)
     int exact = 1;           // 1: reference operation order, unfused; 0: FMA
-    int nt = 1;              // non-temporal streaming loads/stores
     int crowd = -1;          // instanced launches: -1 auto (crowd kernel from 4 instances), 0 never, 1 always
-    int crowd_block = 512;   // crowd kernel workgroup = vertex tile: 256 | 512
     int crowd_lean = 0;      // 1: register-lean crowd kernel at two workgroups per CU (leaves room for other kernels' waves, see lbs_kernels.hip)
     int crowd_ipb = 0;       // instances per workgroup run; 0 = auto
-    int split = 0;           // 1: equal contiguous vertex shares per wave instead of whole 64-vertex units round-robin
-    int probe = 0;           // debug: per-wave timeline of the default lbs_skin variant into probe_buf
-    uint64_t* probe_buf = nullptr;
-    size_t probe_words = 0;
-    // Large single-instance launches (lbs_skin_dyn, see lbs_kernels.hip):
-    int dyn = 1;             // 1: one workgroup per resident CU slot, units drawn from an LDS ticket counter
-    int dyn_block = 256;     // its workgroup size: 256 | 512 | 1024 (four small workgroups per CU end at more staggered times than two
-                             //   large ones: the most robust lone-launch time over the boxes of the pool, profiles/r02_policy_sweep*.json)
-    int dyn_bpc = 0;         // workgroups per CU of that launch; 0 = what is resident (1024 / dyn_block)
-    uint32_t* pool_buf = nullptr;   // lbs_skin_dyn's unit pool counters (4 sets x 64, 256 bytes apart)
-    uint32_t* pool_seq = nullptr;   // launches so far (host word): which set a launch uses
+    int dyn = 1;             // large single-instance launches: 1 = lbs_skin_dyn (units drawn from an LDS ticket counter), 0 = lbs_skin
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // option lbs.timing: this launch's own start / stop events (dispatch timestamps)
-    int dyn_knobs = 0;       // experiment switches of lbs_skin_dyn (see the kernel)
-    int asym = 0;            // lbs_skin, 2 workgroups per CU: the first-dispatched one owns asym/64 of the pair's units (0 = halves)
-    int young_prio = 0;      // lbs_skin: s_setprio for the second-dispatched half of the grid
-    int policy = 0;          // experiment builds only (FYX_EXP_POLICY): cache policy of lbs_skin_dyn's streams
 };
 
 struct LbsArgs {
@@ -50,17 +32,7 @@ struct LbsArgs {
     uint32_t n_verts;
     uint32_t n_bones;
     uint32_t n_instances;
-    const uint32_t* tiled = nullptr;   // the same inputs, one contiguous 3840-byte span per 64-vertex unit (or null)
 };
-
-// Unit-tiled copy of the five input streams (library-owned layout): per 64-vertex unit 960 dwords --
-//   [0,256)   lane l: px py pz nx     [256,512) lane l: ny nz tx ty     [512,768) lane l: tz tw w0 w1
-//   [768,960) lane l: w2 w3 idx (3 dwords)
-// so a wave reads its unit with three 16-byte and one 12-byte access per lane out of ONE span.
-constexpr uint32_t kTiledDwordsPerUnit = 960;
-constexpr uint32_t kTiledFromVerts = 524288;   // smaller meshes never take lbs_skin_dyn
-hipError_t launch_retile_units(const float* pos, const float* nrm, const float* tan, const float* wgt, const uint32_t* idx,
-                               uint32_t n_verts, uint32_t* tiled, hipStream_t stream);
 
 // Launch the skinning kernel.  Returns hipSuccess or the launch error.
 hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream);

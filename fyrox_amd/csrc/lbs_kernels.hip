@@ -52,28 +52,6 @@ __device__ __forceinline__ void stg(T* p, T v) {
     else *p = v;
 }
 
-// FYX_EXP_POLICY (experiment builds only, tools/exp/build_variants.sh): instantiates lbs_skin_dyn for every pair of
-// load / store cache policies, selected at run time by the option lbs.policy (tools/exp/policy_sweep.py).
-#ifndef FYX_EXP_POLICY
-#define FYX_EXP_POLICY 0
-#endif
-// FYX_EXP_KNOBS (experiment builds only): the start-up / work-distribution / ablation switches of lbs_skin_dyn
-// (option lbs.dyn_knobs, tools/exp/dyn_knobs.py).
-#ifndef FYX_EXP_KNOBS
-#define FYX_EXP_KNOBS 0
-#endif
-// FYX_EXP_DYN_WAVES (experiment builds only): lbs_skin_dyn with the influences walked one by one (SEQ) and the register
-// budget of that many waves per SIMD (5 -> 96 VGPRs, 6 -> 80); the launcher sizes the resident grid to match.
-// 0 = the product form (four waves per SIMD).
-#ifndef FYX_EXP_DYN_WAVES
-#define FYX_EXP_DYN_WAVES 0
-#endif
-#if FYX_EXP_DYN_WAVES
-#define FYX_DYN_ATTR __attribute__((amdgpu_waves_per_eu(FYX_EXP_DYN_WAVES, FYX_EXP_DYN_WAVES)))
-#else
-#define FYX_DYN_ATTR
-#endif
-
 template <bool NT>
 __device__ __forceinline__ void ld3(const float* p, float& x, float& y, float& z) {
     x = ldg<NT>(p); y = ldg<NT>(p + 1); z = ldg<NT>(p + 2);
@@ -294,13 +272,16 @@ __device__ __forceinline__ Skinned skin_vertex(const f32x4* __restrict__ rows,
 // Units are dealt out evenly: workgroup b owns the contiguous unit range
 // [b*T/G, (b+1)*T/G) -- at most one unit (64 vertices) of imbalance between workgroups, so every
 // CU streams the same number of bytes -- and its waves take units round-robin inside that range.
-// A range that crosses an instance boundary (crowds) is processed per instance segment; the
-// palette is (re)staged into LDS once per segment.
+// A range that crosses an instance boundary (few instances of a mesh) is processed per instance
+// segment; the palette is (re)staged into LDS once per segment.
 //
-// PREFETCH=true software-pipelines each wave: the loads of its next unit are issued before the
-// ~300 VALU + 12 LDS operations of the current one, so the wave always has a unit in flight in
-// the memory system while it computes (all waves start in lock-step at kernel launch, so
-// without this the whole chip alternates between a load phase and a compute phase).
+// Each wave is software-pipelined: the loads of its next unit are issued before the ~300 VALU + 12 LDS
+// operations of the current one, so the wave always has a unit in flight in the memory system while it
+// computes (all waves start in lock-step at kernel launch, so without this the whole chip alternates
+// between a load phase and a compute phase).  Loads and stores are non-temporal: every byte is touched once.
+// Measured and left out in rounds 1 - 2 (history: commit e6d81f8, tools/exp/README.md): workgroups of 256 / 1024
+// threads, no prefetch / two units ahead / two register sets swapping roles, cacheable accesses, per-wave
+// contiguous shares, asymmetric shares and a raised priority for the second-dispatched workgroup of a CU.
 // ---------------------------------------------------------------------------------------
 // p and n are kept as whole 96-bit values (one register triple each): a loop that carries a vertex from one
 // iteration to the next then carries the triple a dwordx3 load fills, instead of six scalars the register allocator
@@ -332,42 +313,21 @@ __device__ __forceinline__ void pin_vertex(VertexIn<MASK>& r) {
     asm volatile("" : "+v"(r.t), "+v"(r.w), "+v"(r.id));
 }
 
-// PROBE (debug, option lbs.probe): every wave records s_memrealtime (100 MHz) at kernel entry, after the palette
-// staging barrier, after its last store was issued and after that store completed -- the launch's timeline.
-// PREFETCH: 0 = none, 1 = the next unit's loads are issued before the math of the current one, 2 = two units ahead
-// (three units in flight per wave: what lets the half-empty CUs of a launch's tail still fill their share of HBM).
-template <int BLOCK, bool EXACT, bool NT, int PREFETCH, int MASK, bool PROBE = false>
-__global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_inst,
-                                                  uint32_t total_units, uint32_t split, uint64_t* probe = nullptr,
-                                                  uint32_t asym = 0, uint32_t young_prio = 0) {
-    uint64_t pt0 = 0, pt1 = 0;
-    if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
+constexpr int kSkinBlock = 512;   // threads per workgroup of lbs_skin / lbs_skin_batch / the crowd kernel's vertex tile
+
+template <bool EXACT, int MASK>
+__global__ __launch_bounds__(kSkinBlock) void lbs_skin(LbsArgs a, uint32_t units_per_inst, uint32_t total_units) {
+    constexpr bool NT = true;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
     uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);
 
-    constexpr uint32_t WPB = BLOCK / 64;
+    constexpr uint32_t WPB = kSkinBlock / 64;
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
-    uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
-    if (asym) {
-        // Two workgroups per CU (grid = 2 x CUs): the first-dispatched one (block < CUs; observed, not promised --
-        // a matter of speed only) wins the arbitration inside its CU and finishes early, so it takes asym/64 of the
-        // pair's contiguous range.
-        const uint32_t half = gridDim.x / 2, pair = blockIdx.x % half;
-        const uint32_t p0 = (uint32_t)(((uint64_t)pair * total_units) / half);
-        const uint32_t p1 = (uint32_t)(((uint64_t)(pair + 1) * total_units) / half);
-        const uint32_t cut = p0 + (uint32_t)(((uint64_t)(p1 - p0) * asym) / 64);
-        u_begin = blockIdx.x < half ? p0 : cut;
-        u_end = blockIdx.x < half ? cut : p1;
-    }
-    if (young_prio && blockIdx.x >= gridDim.x / 2) {
-        if (young_prio == 1) __builtin_amdgcn_s_setprio(1);
-        else if (young_prio == 2) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(3);
-    }
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
     if (u_begin >= u_end) return;
 
     const uint32_t inst_first = u_begin / units_per_inst;
@@ -383,41 +343,12 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         // below then waits for the (L2-resident, fast) palette only, while the vertex loads --
         // a cold HBM access at kernel start -- stay in flight across the staging barrier.
         const PaletteRegs pr = palette_fetch(a.palette + (size_t)inst * a.n_bones * 16, a.n_bones, tid);
-        // This wave's vertices of the segment: [vb, ve) visited in 64-vertex steps of stride `vstep`.
-        //   split == 0: whole units dealt round-robin to the waves (unit k of the segment -> wave k % WPB);
-        //   split == 1: the segment's vertex range cut into WPB equal contiguous shares (16-vertex aligned), so every
-        //               wave of every workgroup has the same number of bytes to move (units are too coarse for that:
-        //               3 or 4 per wave on the 1 M-vertex workload) and runs the same number of iterations.
-        uint32_t vb, ve, vstep;
-        {
-            const uint32_t s0 = seg_b * 64;
-            const uint32_t s1 = seg_e * 64 < a.n_verts ? seg_e * 64 : a.n_verts;
-            if (split == 2 && a.n_instances == 1) {
-                // units interleaved over ALL waves of the grid (wave g takes units g, g + G, g + 2G, ...): every wave
-                // sweeps the whole address range in step with the others
-                vb = (blockIdx.x * WPB + wave) * 64;
-                ve = a.n_verts;
-                vstep = gridDim.x * WPB * 64;
-            } else if (split) {
-                const uint32_t len = s1 - s0;
-                vb = s0 + (uint32_t)(((uint64_t)len * wave / WPB) & ~15ull);
-                ve = wave + 1 == WPB ? s1 : s0 + (uint32_t)(((uint64_t)len * (wave + 1) / WPB) & ~15ull);
-                vstep = 64;
-            } else {
-                vb = (seg_b + wave) * 64;
-                ve = s1;
-                vstep = WPB * 64;
-            }
-        }
-        uint32_t base = vb;
+        // this wave's vertices of the segment: whole units dealt round-robin to the waves (unit k of the segment -> wave k % WPB)
+        const uint32_t ve = seg_e * 64 < a.n_verts ? seg_e * 64 : a.n_verts;
+        constexpr uint32_t vstep = WPB * 64;
+        uint32_t base = (seg_b + wave) * 64;
         uint32_t v = base + lane;
-        // (PREFETCH == 3: a lane past the end of the wave's range works on the range's last vertex, see below)
-        VertexIn<MASK> cur = load_vertex<NT, MASK>(a, v < ve ? v : (PREFETCH == 3 && base < ve ? ve - 1 : 0));
-        VertexIn<MASK> nx1;
-        if constexpr (PREFETCH == 2) {
-            const uint32_t v1 = base + vstep + lane;
-            nx1 = load_vertex<NT, MASK>(a, v1 < ve ? v1 : 0);
-        }
+        VertexIn<MASK> cur = load_vertex<NT, MASK>(a, v < ve ? v : 0);
 
         if (inst != inst_first) __syncthreads();  // every wave is done with the previous palette
         const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
@@ -431,59 +362,12 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
         // Opaque use point: nothing that consumes the first unit's vertex data may be scheduled
         // above the staging barrier (it would drag the wait for those loads up with it).
         pin_vertex(cur);
-        if constexpr (PREFETCH == 2) pin_vertex(nx1);
-        if constexpr (PROBE) { if (inst == inst_first) pt1 = __builtin_amdgcn_s_memrealtime(); }
 
-        if constexpr (PREFETCH == 3) {
-            // Two vertex buffers that swap roles (no register copies: a copy needs every outstanding load AND store to
-            // have landed, which drains the wave's memory pipeline once per unit).  The body is straight-line
-            // vector-memory code -- five loads, three stores, always: a lane past the end of the wave's range works on
-            // the range's LAST vertex instead (same inputs, same arithmetic, same bytes stored to the same address as
-            // the lane that owns it) -- so the compiler's vmcnt bookkeeping is exact and the math waits for its own
-            // unit's loads only, with the previous unit's stores and the next unit's loads still in flight.
-            const uint32_t v_last = ve - 1;
-            auto half = [&](VertexIn<MASK>& c_, uint32_t v_c, VertexIn<MASK>& n_, uint32_t v_n) {
-                n_ = load_vertex<NT, MASK>(a, v_n);
-                pin_vertex(c_);   // the math's first touch of the loaded registers is here, not on the back edge
-                const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
-                                                           c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
-                const size_t ov = (size_t)inst * a.n_verts + v_c;
-                if constexpr (MASK & 1) st3<NT>(a.out_pos + ov * 3, o.px, o.py, o.pz);
-                if constexpr (MASK & 2) st3<NT>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
-                if constexpr (MASK & 4)
-                    stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, c_.t.w});
-            };
-            if (base < ve) {   // wave-uniform
-                VertexIn<MASK> other;
-                uint32_t vc = v < v_last ? v : v_last;   // what `cur` was loaded from
-                for (;;) {
-                    uint32_t vn = v + vstep;
-                    vn = vn < v_last ? vn : v_last;
-                    half(cur, vc, other, vn);
-                    base += vstep; v += vstep;
-                    if (base >= ve) break;
-                    uint32_t vm = v + vstep;
-                    vm = vm < v_last ? vm : v_last;
-                    half(other, vn, cur, vm);
-                    base += vstep; v += vstep;
-                    vc = vm;
-                    if (base >= ve) break;
-                }
-            }
-        } else
         while (base < ve) {  // wave-uniform
             const uint32_t bn = base + vstep;
             const uint32_t vn = bn + lane;
             VertexIn<MASK> nxt;
-            if constexpr (PREFETCH == 1) {
-                if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
-            }
-            if constexpr (PREFETCH == 2) {
-                const uint32_t b2 = bn + vstep;
-                const uint32_t v2 = b2 + lane;
-                nxt = nx1;                                  // loaded one iteration ago
-                if (b2 < ve) nx1 = load_vertex<NT, MASK>(a, v2 < ve ? v2 : 0);
-            }
+            if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
             const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, cur.id, cur.w, cur.p.x,
                                                        cur.p.y, cur.p.z, cur.n.x, cur.n.y, cur.n.z,
                                                        cur.t.x, cur.t.y, cur.t.z);
@@ -494,21 +378,9 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin(LbsArgs a, uint32_t units_per_
                 if constexpr (MASK & 4)
                     stg<NT>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, cur.t.w});
             }
-            if constexpr (PREFETCH == 0) {
-                if (bn < ve) nxt = load_vertex<NT, MASK>(a, vn < ve ? vn : 0);
-            }
             cur = nxt;
             base = bn;
             v = vn;
-        }
-    }
-    if constexpr (PROBE) {
-        const uint64_t pt2 = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint64_t pt3 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            uint64_t* r = probe + ((size_t)blockIdx.x * WPB + wave) * 4;
-            r[0] = pt0; r[1] = pt1; r[2] = pt2; r[3] = pt3;
         }
     }
 }
@@ -551,23 +423,6 @@ __device__ __forceinline__ VertexIn<MASK> load_vertex_buf(const VtxBuffers& b, u
     r.id = __builtin_amdgcn_raw_buffer_load_b32(b.idx, v * 4u, 0, AUX);
     return r;
 }
-// The same vertex out of the unit-tiled copy (MASK 7 only): v = unit * 64 + lane.
-template <int AUX>
-__device__ __forceinline__ VertexIn<7> load_vertex_tiled(__amdgpu_buffer_rsrc_t tiled, uint32_t v) {
-    const uint32_t unit = v >> 6, l = v & 63u;
-    const uint32_t b = unit * (kTiledDwordsPerUnit * 4u);
-    const f32x4 q0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tiled, b + l * 16u, 0, AUX));
-    const f32x4 q1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tiled, b + 1024u + l * 16u, 0, AUX));
-    const f32x4 q2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tiled, b + 2048u + l * 16u, 0, AUX));
-    const u32x3 q3 = __builtin_amdgcn_raw_buffer_load_b96(tiled, b + 3072u + l * 12u, 0, AUX);
-    VertexIn<7> r;
-    r.p = f32x3{q0.x, q0.y, q0.z};
-    r.n = f32x3{q0.w, q1.x, q1.y};
-    r.t = f32x4{q1.z, q1.w, q2.x, q2.y};
-    r.w = f32x4{q2.z, q2.w, __uint_as_float(q3.x), __uint_as_float(q3.y)};
-    r.id = q3.z;
-    return r;
-}
 template <int MASK, int AUX>
 __device__ __forceinline__ void store_vertex_buf(const VtxBuffers& b, uint32_t v, const Skinned& o, float tw) {
     if constexpr (MASK & 1)
@@ -580,119 +435,81 @@ __device__ __forceinline__ void store_vertex_buf(const VtxBuffers& b, uint32_t v
 
 // ---------------------------------------------------------------------------------------
 // lbs_skin_dyn: the single-instance kernel for large meshes, built around how a LONE launch spends its ~18 us
-// (timeline: tools/probe_timeline.py, profiles/r01_timeline.json for lbs_skin).
+// (timeline study of round 2: profiles/r02_lone_launch/, profiles/r01_timeline.json for lbs_skin).
 //
-//   * One workgroup per CU slot that is resident anyway (1024 threads = all 16 waves of a CU at this register budget,
-//     or two of 512), each owning one contiguous range of 64-vertex units.  Inside the workgroup the waves DRAW their
-//     units from an LDS ticket counter (one ds_add_rtn per unit) instead of taking every WPB-th one: a wave that is
-//     served faster takes more, so the workgroup ends when its work does, not when the wave that happened to get 4
-//     units instead of 3 does (measured spread inside a workgroup of lbs_skin: 1.9 us of a 16 us launch), and with one
-//     workgroup per CU the whole CU's share is balanced over its 16 waves -- lbs_skin's second-dispatched workgroup
-//     loses the arbitration inside its CU and finishes 3.4 us after the first.  (Drawing chunks from device-scope
-//     counters shared by all CUs was measured too: a returning global atomic queues behind the CU's own streaming
-//     loads, several us each -- 27 us per launch at best.  Nothing here leaves the CU.)
-//   * The palette goes first and wide: every thread fetches 16-byte columns of the palette (one dense 1 KB request
-//     per wave, the wave's FIRST vector-memory instruction) and the first unit's vertex loads right behind it; the
-//     second unit is requested as soon as the staging barrier is passed.  (Requesting both units ahead of the barrier
-//     was measured slower, 20.0 vs 19.5 us: the CU's memory queue is served in order, so the palette columns of the
-//     later waves then wait behind twice as many vertex requests of the earlier ones.)
+//   * Four workgroups of 256 threads per CU -- all 16 waves a CU holds at this register budget, resident anyway -- each
+//     owning one contiguous range of 64-vertex units.  Inside the workgroup the waves DRAW their units from an LDS ticket
+//     counter (one ds_add_rtn per unit) instead of taking every WPB-th one: a wave that is served faster takes more, so
+//     the workgroup ends when its work does, not when the wave that happened to get 4 units instead of 3 does (measured
+//     spread inside a workgroup of lbs_skin: 1.9 us of a 16 us launch).  (Drawing chunks from device-scope counters shared
+//     by all CUs was measured too: a returning global atomic queues behind the CU's own streaming loads, several us each
+//     -- 27 us per launch at best.  Nothing here leaves the CU.)
+//   * The palette goes first and wide: every thread fetches 16-byte columns of the palette (one dense 1 KB request per
+//     wave, the wave's FIRST vector-memory instruction) and the first unit's vertex loads right behind it; the second
+//     unit is requested as soon as the staging barrier is passed.  (Requesting both units ahead of the barrier was
+//     measured slower, 20.0 vs 19.5 us: the CU's memory queue is served in order, so the palette columns of the later
+//     waves then wait behind twice as many vertex requests of the earlier ones.)
 //   * The loop keeps two units in flight per wave: a register set is refilled as soon as its math is done, while the
 //     other set's loads have had a whole unit's time to land.
 //   * The streams are buffer resources: a lane past the end of the mesh loads zeros and its stores are dropped by the
-//     hardware, so every unit is five loads and three stores of straight-line vector-memory code, and the cache
-//     policy rides in the instruction: loads `nt` (read once), stores `sc1` (written through, the line is not kept
-//     dirty in the XCD's L2).  Measured over all 25 load / store policy pairs (tools/exp/policy_sweep.py,
-//     profiles/r02_policy_sweep.json): sc1 stores are 0.5 us faster than nt stores on a lone launch and 1.0 us
-//     (6 %) faster when launches overlap on two streams -- 15.2 us per 100 MB, 6.6 TB/s.
+//     hardware, so every unit is five loads and three stores of straight-line vector-memory code, and the cache policy
+//     rides in the instruction: loads `nt` (read once), stores `sc1` (written through, the line is not kept dirty in the
+//     XCD's L2).  Measured over all 25 load / store policy pairs (profiles/r02_policy_sweep_*.json): sc1 stores are
+//     0.5 us faster than nt stores on a lone launch and 1.0 us (6 %) faster when launches overlap on two streams.
 // Which wave skins a unit changes nothing in the arithmetic: results are bit-identical to lbs_skin's.
+// The experiment switches this kernel carried in round 2 (start-up pauses, unit pools with scalar-memory tickets, partner
+// stealing, unit-tiled inputs, ablations, 512 / 1024-thread workgroups, five- / six-wave register budgets, per-wave
+// timeline probe) are in the history (commit e6d81f8) with their results in DESIGN.md 5.
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, int MASK, bool PROBE = false, int LD_AUX = 2, int ST_AUX = 16>
-__global__ __launch_bounds__(BLOCK) FYX_DYN_ATTR void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint64_t* probe = nullptr,
-                                                      uint32_t knobs_arg = 0, uint32_t* pool_arg = nullptr,
-                                                      uint32_t* pool_zero = nullptr) {
-    // Experiment switches (tools/exp/dyn_knobs.py; findings in DESIGN.md 5): compiled in only with -DFYX_EXP_KNOBS=1
-    // (tools/exp/build_variants.sh).  In the product build `knobs` is the constant 0 and every branch on it is gone.
-    const uint32_t knobs = FYX_EXP_KNOBS ? knobs_arg : 0u;
-    uint32_t* const pool = FYX_EXP_KNOBS ? pool_arg : nullptr;
-    uint64_t pt0 = 0, pt1 = 0;
-    if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
+constexpr int kDynBlock = 256;
+constexpr int kDynLoadAux = 2, kDynStoreAux = 16;     // nt loads, sc1 stores
+
+template <bool EXACT, int MASK>
+__global__ __launch_bounds__(kDynBlock) void lbs_skin_dyn(LbsArgs a, uint32_t total_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
     uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);   // 16 words
     uint32_t* ticket = wave_flag + 16;
 
-    constexpr uint32_t WPB = BLOCK / 64;
-    constexpr int PIECES = 1024 / BLOCK;     // 16-byte palette columns per thread (n_bones <= 256)
+    constexpr uint32_t WPB = kDynBlock / 64;
+    constexpr int PIECES = 1024 / kDynBlock;     // 16-byte palette columns per thread (n_bones <= 256)
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    // experiment (knobs bits 16-21 = pool share in 1/64 of the units, 22-23 = pool groups 8 / 32 / 64, 24 = partner steal):
-    // the last `pool_units` units are not dealt out but drawn by the waves that run out of their own, from the counter of
-    // their hardware neighbourhood (XCD / XCD x SE / ...), with a scalar-memory atomic (its return does not queue behind
-    // the wave's vector loads).
-    const uint32_t pool_units = pool ? (uint32_t)(((uint64_t)total_units * ((knobs >> 16) & 63u)) >> 6) : 0u;
-    const uint32_t static_units = total_units - pool_units;
-    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * static_units) / gridDim.x);
-    const uint32_t n_units = (uint32_t)(((uint64_t)(blockIdx.x + 1) * static_units) / gridDim.x) - u_begin;
-    uint32_t grp = 0, n_grp = 8, grp2 = 0;
-    if (pool_units) {
-        const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508) & 7u;
-        const uint32_t se = (hw >> 13) & 3u, cu = (hw >> 8) & 15u, mode = (knobs >> 22) & 3u;
-        if (mode == 0) { n_grp = 8; grp = xcc; grp2 = xcc ^ 1u; }
-        else if (mode == 1) { n_grp = 32; grp = xcc * 4 + se; grp2 = (xcc ^ 1u) * 4 + se; }
-        else { n_grp = 64; grp = (xcc * 4 + se) * 2 + (cu >= 4 ? 1u : 0u); grp2 = grp ^ 1u; }
-        if (blockIdx.x == 0 && tid < 64 && pool_zero) pool_zero[tid * 64] = 0;   // the counters of the launch after next
-    }
-    // knobs bits 25-27 = d: the pools of the odd XCDs are (8 - d) / 8 of the even ones' (8 + d) / 8 -- they run dry earlier
-    const uint32_t pool_d = (knobs >> 25) & 7u;
-    auto pool_range = [&](uint32_t g, uint32_t& base, uint32_t& len) {
-        const uint32_t sub = n_grp >> 3, x = g / sub, j = g % sub;
-        const uint32_t w = (x & 1u) ? 8u - pool_d : 8u + pool_d;
-        const uint32_t W = sub * (((x + 1) >> 1) * (8u + pool_d) + (x >> 1) * (8u - pool_d)) + j * w;
-        base = (uint32_t)(((uint64_t)W * pool_units) / (sub * 64u));
-        len = (uint32_t)(((uint64_t)(W + w) * pool_units) / (sub * 64u)) - base;
-        base += static_units;
-    };
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t n_units = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x) - u_begin;
 
-    // palette columns first: column c of bone b is piece 4 b + c
+    // Palette columns first: column c of bone b is piece 4 b + c, and a wave fetches 64 consecutive pieces (16 bones, one dense
+    // 1 KB request).  WHICH lane takes which piece of those 64 is chosen for the LDS commit below: the 16 lanes one ds_write_b64
+    // serves together take the four columns of bones {0, 2, 4, 6} (or {1, 3, 5, 7}) of an octet, whose 8-dword (x, y) windows at
+    // the 48-byte row stride start at dwords 0 / 24 / 48 / 72 = banks 0 / 24 / 16 / 8: the four windows tile all 32 banks.  (With
+    // lanes in piece order the group was bones {0, 1, 2, 3}: windows at banks 0 / 12 / 24 / 4, the fourth on top of the first --
+    // SQ_LDS_BANK_CONFLICT 65 536 cycles per launch in round 2.)
     const uint32_t n_pieces = a.n_bones * 4;
+    const uint32_t grp16 = lane >> 4, in16 = lane & 15;
+    const uint32_t my_piece = ((uint32_t)tid & ~63u) + 4 * (8 * (grp16 >> 1) + 2 * (in16 >> 2) + (grp16 & 1)) + (in16 & 3);
     f32x4 col[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-        const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
-        col[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(knobs & 0x400u)) col[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
+        const uint32_t piece = my_piece + (uint32_t)i * kDynBlock;
+        col[i] = reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1];
     }
     // the wave's first two units (tickets wave and WPB + wave; the launcher guarantees n_units >= 2 WPB)
     const VtxBuffers vb = make_vtx_buffers(a);
-    const bool use_tiled = MASK == 7 && a.tiled != nullptr && (knobs & 0x2000u) && total_units < 1000000u;   // 32-bit buffer offsets
-    const __amdgpu_buffer_rsrc_t tiled = make_stream(a.tiled, total_units * (kTiledDwordsPerUnit * 4u));
-    auto load_unit = [&](uint32_t v) -> VertexIn<MASK> {
-        if constexpr (MASK == 7) {
-            if (use_tiled) return load_vertex_tiled<LD_AUX>(tiled, v);
-        }
-        return load_vertex_buf<MASK, LD_AUX>(vb, v);
-    };
     auto vertex_of = [&](uint32_t t) -> uint32_t { return (u_begin + t) * 64 + lane; };
     uint32_t vA = vertex_of(wave), vB = vertex_of(WPB + wave);
-    // experiment knobs (lbs.dyn_knobs): bits 0-7 = pause (x64 clocks) between the palette request and the vertex requests,
-    // bit 8 = wait for the palette columns to land first, bit 9 = request the second unit ahead of the barrier too
-    if (knobs & 0x100u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (knobs & 0x1000u) __syncthreads();   // nobody requests vertices before every wave of the workgroup has requested its columns
-    for (uint32_t i = knobs & 0xffu; i > 0; --i) __builtin_amdgcn_s_sleep(1);
-    VertexIn<MASK> A = load_unit(vA);
+    VertexIn<MASK> A = load_vertex_buf<MASK, kDynLoadAux>(vb, vA);
     VertexIn<MASK> B;   // requested behind the staging barrier (see above)
-    const bool early2 = (knobs & 0x200u) != 0;
-    if (early2) B = load_unit(vB);
 
     if (tid == 0) *ticket = 2 * WPB;
     bool pj = false;
+    // Packed-math layout (see stage_palette): A = (m00, m10, m01, m11)  B = (m02, m12, t0, t1)  C = (m20, m21, m22, t2)
+    // row3 = (m30, m31, m32, m33); a thread holds column c = (m0c, m1c, m2c, m3c) of bone b: (x, y) is one 8-byte store, z and
+    // w one 4-byte store each (the 32 lanes of a 4-byte store cover a whole octet of bones: dwords 12 b + 8 + c, all banks).
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-        const uint32_t piece = (uint32_t)tid + (uint32_t)i * BLOCK;
-        if (piece < n_pieces && !(knobs & 0x400u)) {
-            // packed-math layout (see stage_palette): A = (m00, m10, m01, m11)  B = (m02, m12, t0, t1)
-            // C = (m20, m21, m22, t2)  row3 = (m30, m31, m32, m33); column c = (m0c, m1c, m2c, m3c)
+        const uint32_t piece = my_piece + (uint32_t)i * kDynBlock;
+        if (piece < n_pieces) {
             const uint32_t b = piece >> 2, c = piece & 3;
             float* r = reinterpret_cast<float*>(rows + b * 3);
             *reinterpret_cast<f32x2*>(r + 2 * c) = f32x2{col[i].x, col[i].y};
@@ -708,69 +525,29 @@ __global__ __launch_bounds__(BLOCK) FYX_DYN_ATTR void lbs_skin_dyn(LbsArgs a, ui
 #pragma unroll
     for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
     pin_vertex(A);
-    if (!early2) B = load_unit(vB);
-    if constexpr (PROBE) pt1 = __builtin_amdgcn_s_memrealtime();
+    B = load_vertex_buf<MASK, kDynLoadAux>(vb, vB);
 
-    auto process = [&](VertexIn<MASK>& c_, uint32_t v_c, bool drain = false) {
+    auto process = [&](VertexIn<MASK>& c_, uint32_t v_c) {
         pin_vertex(c_);   // the math's first touch of the loaded registers is here
-        Skinned o;
-        if ((knobs & 0x800u) || (drain && (knobs & 0x4000u)) || (!drain && (knobs & 0x8000u))) {   // ablation (wrong results): no math
-            o.px = c_.p.x + c_.w.x; o.py = c_.p.y + c_.w.y; o.pz = c_.p.z + c_.w.z; o.nx = c_.n.x + c_.w.w; o.ny = c_.n.y; o.nz = c_.n.z;
-            o.tx = c_.t.x; o.ty = c_.t.y; o.tz = c_.t.z + __uint_as_float(c_.id) * 0.f;
-        } else {
-            o = skin_vertex<EXACT, MASK, false, FYX_EXP_DYN_WAVES != 0>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
-                                                                        c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
-        }
-        store_vertex_buf<MASK, ST_AUX>(vb, v_c, o, c_.t.w);
+        const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
+                                                   c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
+        store_vertex_buf<MASK, kDynStoreAux>(vb, v_c, o, c_.t.w);
     };
     // draw the next unit into a register set whose math is done; false when the workgroup's range is used up
     auto refill = [&](VertexIn<MASK>& n_, uint32_t& v_n) -> bool {
         uint32_t t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         t = __builtin_amdgcn_readfirstlane(t);
-        if (t < n_units) {
-            v_n = vertex_of(t);
-        } else {
-            if (!pool_units) return false;
-            uint32_t base, len, p = 1;
-            pool_range(grp, base, len);
-            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(p) : "s"(pool + grp * 64) : "memory");
-            if (p >= len) {
-                if (!(knobs & 0x1000000u)) return false;
-                pool_range(grp2, base, len);
-                p = 1;
-                asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(p) : "s"(pool + grp2 * 64) : "memory");
-                if (p >= len) return false;
-            }
-            v_n = (base + p) * 64 + lane;
-        }
-        n_ = load_unit(v_n);
+        if (t >= n_units) return false;
+        v_n = vertex_of(t);
+        n_ = load_vertex_buf<MASK, kDynLoadAux>(vb, v_n);
         return true;
     };
-    if (knobs & 0x10000000u) {   // experiment: one unit in flight per wave (B is processed first, then A alone)
-        process(B, vB);
-        for (;;) {
-            process(A, vA);
-            if (!refill(A, vA)) break;
-        }
-    } else
     for (;;) {   // wave-uniform
         process(A, vA);
-        if (!refill(A, vA)) { process(B, vB, true); break; }
+        if (!refill(A, vA)) { process(B, vB); break; }
         process(B, vB);
-        if (!refill(B, vB)) { process(A, vA, true); break; }
-    }
-    if constexpr (PROBE) {
-        const uint64_t pt2 = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint64_t pt3 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            // where the wave ran: HW_ID (wave, simd, pipe, cu, sh, se in the low 16 bits) and XCC_ID ride in the unused top bits
-            const uint64_t hw = (uint64_t)(__builtin_amdgcn_s_getreg(63492) & 0xffffu);
-            const uint64_t xcc = (uint64_t)(__builtin_amdgcn_s_getreg(63508) & 0xfu);
-            uint64_t* r = probe + ((size_t)blockIdx.x * WPB + wave) * 4;
-            r[0] = pt0; r[1] = pt1 | (xcc << 56); r[2] = pt2 | (hw << 48); r[3] = pt3;
-        }
+        if (!refill(B, vB)) { process(A, vA); break; }
     }
 }
 
@@ -913,15 +690,14 @@ static hipError_t launch_crowd_mask(const LbsArgs& a, const LbsTuning& t, hipStr
 }
 
 static hipError_t launch_crowd(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    if (t.crowd_block == 512)
-        return t.exact ? launch_crowd_mask<512, true>(a, t, s) : launch_crowd_mask<512, false>(a, t, s);
-    return t.exact ? launch_crowd_mask<256, true>(a, t, s) : launch_crowd_mask<256, false>(a, t, s);
+    // one tile size: 512 vertices (256 measured equal within 3 % in rounds 1 - 2 and left out)
+    return t.exact ? launch_crowd_mask<kSkinBlock, true>(a, t, s) : launch_crowd_mask<kSkinBlock, false>(a, t, s);
 }
 
 // ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, bool EXACT, bool NT, int PREFETCH, int MASK>
+template <bool EXACT, int MASK>
 static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     const uint32_t upi = (a.n_verts + 63) / 64;
     const uint64_t total64 = (uint64_t)upi * a.n_instances;
@@ -929,144 +705,46 @@ static hipError_t launch_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s
     if (total64 > 0xffffffffull) return hipErrorInvalidValue;
     const uint32_t total = (uint32_t)total64;
     uint32_t grid = (uint32_t)kCUs * (uint32_t)(t.blocks_per_cu > 0 ? t.blocks_per_cu : 1);
-    const uint32_t max_useful = (total + (BLOCK / 64) - 1) / (BLOCK / 64);
+    const uint32_t max_useful = (total + (kSkinBlock / 64) - 1) / (kSkinBlock / 64);
     if (grid > max_useful) grid = max_useful;
     const size_t lds = (size_t)a.n_bones * 64 + 64;  // rows + row3 + one flag per wave
-    if constexpr (BLOCK == 512 && EXACT && NT && PREFETCH == 1 && MASK == 7) {
-        if (t.probe && t.probe_buf) {   // debug timeline, only for the default variant
-            if ((size_t)grid * (BLOCK / 64) * 4 > t.probe_words) return hipErrorInvalidValue;
-            const uint32_t asym_p = (t.asym > 0 && t.asym < 64 && grid == 2u * kCUs) ? (uint32_t)t.asym : 0u;
-            hipLaunchKernelGGL((lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a,
-                               upi, total, (uint32_t)t.split, t.probe_buf, asym_p, (uint32_t)t.young_prio);
-            return hipGetLastError();
-        }
-    }
-    const uint32_t asym = (t.asym > 0 && t.asym < 64 && grid == 2u * kCUs) ? (uint32_t)t.asym : 0u;
-    FYX_LAUNCH(t, (lbs_skin<BLOCK, EXACT, NT, PREFETCH, MASK>), dim3(grid), dim3(BLOCK), (uint32_t)lds, s, a,
-               upi, total, (uint32_t)t.split, (uint64_t*)nullptr, asym, (uint32_t)t.young_prio);
+    FYX_LAUNCH(t, (lbs_skin<EXACT, MASK>), dim3(grid), dim3(kSkinBlock), (uint32_t)lds, s, a, upi, total);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool EXACT, bool NT, int PREFETCH>
-static hipError_t launch_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
-    switch (mask) {
-        case 1: return launch_one<BLOCK, EXACT, NT, PREFETCH, 1>(a, t, s);
-        case 2: return launch_one<BLOCK, EXACT, NT, PREFETCH, 2>(a, t, s);
-        case 3: return launch_one<BLOCK, EXACT, NT, PREFETCH, 3>(a, t, s);
-        case 4: return launch_one<BLOCK, EXACT, NT, PREFETCH, 4>(a, t, s);
-        case 5: return launch_one<BLOCK, EXACT, NT, PREFETCH, 5>(a, t, s);
-        case 6: return launch_one<BLOCK, EXACT, NT, PREFETCH, 6>(a, t, s);
-        case 7: return launch_one<BLOCK, EXACT, NT, PREFETCH, 7>(a, t, s);
-        default: return hipSuccess;  // nothing requested
-    }
-}
-
-template <int BLOCK>
-static hipError_t launch_block(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    if (t.prefetch == 3 && t.nt)   // one unit ahead, two register sets that swap roles
-        return t.exact ? launch_mask<BLOCK, true, true, 3>(a, t, s) : launch_mask<BLOCK, false, true, 3>(a, t, s);
-    if constexpr (BLOCK != 1024) {
-        if (t.prefetch == 2 && t.nt)   // two units ahead: streaming variants of the 256 / 512 workgroups only
-            return t.exact ? launch_mask<BLOCK, true, true, 2>(a, t, s) : launch_mask<BLOCK, false, true, 2>(a, t, s);
-    }
-    const int key = (t.exact ? 4 : 0) | (t.nt ? 2 : 0) | (t.prefetch ? 1 : 0);
-    switch (key) {
-        case 7: return launch_mask<BLOCK, true, true, 1>(a, t, s);
-        case 6: return launch_mask<BLOCK, true, true, 0>(a, t, s);
-        case 5: return launch_mask<BLOCK, true, false, 1>(a, t, s);
-        case 4: return launch_mask<BLOCK, true, false, 0>(a, t, s);
-        case 3: return launch_mask<BLOCK, false, true, 1>(a, t, s);
-        case 2: return launch_mask<BLOCK, false, true, 0>(a, t, s);
-        case 1: return launch_mask<BLOCK, false, false, 1>(a, t, s);
-        default: return launch_mask<BLOCK, false, false, 0>(a, t, s);
-    }
-}
-
-[[maybe_unused]] constexpr int kPolAux[5] = {0, 2, 16, 17, 18};   // plain, nt, sc1, sc0 sc1, sc1 nt
 // lbs_skin_dyn launch: the grid is what is resident (16 waves per CU at the kernel's register budget).  Returns
 // hipErrorNotReady when the launch does not qualify (the caller takes lbs_skin).
-template <int BLOCK, bool EXACT, int MASK>
+template <bool EXACT, int MASK>
 static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    constexpr uint32_t WPB = BLOCK / 64;
+    constexpr uint32_t WPB = kDynBlock / 64;
     const uint32_t total = (a.n_verts + 63) / 64;
-    const uint32_t resident = (FYX_EXP_DYN_WAVES ? 256u * FYX_EXP_DYN_WAVES : 1024u) / BLOCK;
-    const uint32_t grid = (uint32_t)kCUs * ((t.dyn_bpc > 0 && (uint32_t)t.dyn_bpc < resident) ? (uint32_t)t.dyn_bpc : resident);
+    const uint32_t grid = (uint32_t)kCUs * (1024u / kDynBlock);
     if (total / grid < 2 * WPB) return hipErrorNotReady;   // every wave starts with two units of its own
     const size_t lds = (size_t)a.n_bones * 64 + 64 + 16;
-    uint32_t *pool = nullptr, *pool_zero = nullptr;
-    if (t.pool_buf && ((t.dyn_knobs >> 16) & 63)) {
-        const uint32_t share = (uint32_t)((t.dyn_knobs >> 16) & 63);
-        if ((uint64_t)(total - (uint32_t)(((uint64_t)total * share) >> 6)) / grid < 2 * WPB) return hipErrorNotReady;
-        const uint32_t seq = (*t.pool_seq)++;
-        pool = t.pool_buf + (size_t)(seq & 3u) * 64 * 64;          // four sets of 64 counters, 256 bytes apart
-        pool_zero = t.pool_buf + (size_t)((seq + 2) & 3u) * 64 * 64;
-    }
-    if constexpr (EXACT && MASK == 7) {
-        if (t.probe && t.probe_buf) {
-            if ((size_t)grid * WPB * 4 > t.probe_words) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK, true>), dim3(grid), dim3(BLOCK), lds, s, a, total, t.probe_buf, (uint32_t)t.dyn_knobs, pool, pool_zero);
-            return hipGetLastError();
-        }
-    }
-#if FYX_EXP_POLICY
-    if constexpr (EXACT && MASK == 7) {   // experiment: cache policy of the streams, lbs.policy = 1 + 5 * load + store
-        if (t.policy > 0) {
-            const int ld = (t.policy - 1) / 5, st = (t.policy - 1) % 5;
-#define FYX_POL(L, S) if (ld == L && st == S) { \
-                hipLaunchKernelGGL((lbs_skin_dyn<BLOCK, EXACT, MASK, false, kPolAux[L], kPolAux[S]>), dim3(grid), dim3(BLOCK), lds, s, a, total, (uint64_t*)nullptr); \
-                return hipGetLastError(); }
-            FYX_POL(0,0) FYX_POL(0,1) FYX_POL(0,2) FYX_POL(0,3) FYX_POL(0,4)
-            FYX_POL(1,0) FYX_POL(1,1) FYX_POL(1,2) FYX_POL(1,3) FYX_POL(1,4)
-            FYX_POL(2,0) FYX_POL(2,1) FYX_POL(2,2) FYX_POL(2,3) FYX_POL(2,4)
-            FYX_POL(3,0) FYX_POL(3,1) FYX_POL(3,2) FYX_POL(3,3) FYX_POL(3,4)
-            FYX_POL(4,0) FYX_POL(4,1) FYX_POL(4,2) FYX_POL(4,3) FYX_POL(4,4)
-#undef FYX_POL
-        }
-    }
-#endif
-    FYX_LAUNCH(t, (lbs_skin_dyn<BLOCK, EXACT, MASK>), dim3(grid), dim3(BLOCK), (uint32_t)lds, s, a, total, (uint64_t*)nullptr,
-               (uint32_t)t.dyn_knobs, pool, pool_zero);
+    FYX_LAUNCH(t, (lbs_skin_dyn<EXACT, MASK>), dim3(grid), dim3(kDynBlock), (uint32_t)lds, s, a, total);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool EXACT>
-static hipError_t launch_dyn_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+template <bool EXACT, bool DYN>
+static hipError_t launch_mask(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
     const int mask = (a.out_pos ? 1 : 0) | ((a.out_nrm && a.nrm) ? 2 : 0) | ((a.out_tan && a.tan) ? 4 : 0);
+#define FYX_MASK_CASE(M) case M: if constexpr (DYN) return launch_dyn_one<EXACT, M>(a, t, s); else return launch_one<EXACT, M>(a, t, s);
     switch (mask) {
-        case 1: return launch_dyn_one<BLOCK, EXACT, 1>(a, t, s);
-        case 2: return launch_dyn_one<BLOCK, EXACT, 2>(a, t, s);
-        case 3: return launch_dyn_one<BLOCK, EXACT, 3>(a, t, s);
-        case 4: return launch_dyn_one<BLOCK, EXACT, 4>(a, t, s);
-        case 5: return launch_dyn_one<BLOCK, EXACT, 5>(a, t, s);
-        case 6: return launch_dyn_one<BLOCK, EXACT, 6>(a, t, s);
-        case 7: return launch_dyn_one<BLOCK, EXACT, 7>(a, t, s);
-        default: return hipSuccess;
+        FYX_MASK_CASE(1) FYX_MASK_CASE(2) FYX_MASK_CASE(3) FYX_MASK_CASE(4) FYX_MASK_CASE(5) FYX_MASK_CASE(6) FYX_MASK_CASE(7)
+        default: return hipSuccess;  // nothing requested
     }
-}
-
-static hipError_t launch_dyn(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
-    if (a.n_instances != 1 || a.n_bones == 0 || a.n_bones > 256 || a.n_verts > 0x0fffffffu) return hipErrorNotReady;
-    switch (t.dyn_block) {
-        case 1024: return t.exact ? launch_dyn_mask<1024, true>(a, t, s) : launch_dyn_mask<1024, false>(a, t, s);
-        case 512: return t.exact ? launch_dyn_mask<512, true>(a, t, s) : launch_dyn_mask<512, false>(a, t, s);
-        default: return t.exact ? launch_dyn_mask<256, true>(a, t, s) : launch_dyn_mask<256, false>(a, t, s);
-    }
+#undef FYX_MASK_CASE
 }
 
 hipError_t launch_lbs(const LbsArgs& a, const LbsTuning& t, hipStream_t stream) {
     if (a.n_verts == 0 || a.n_instances == 0) return hipSuccess;
-    if (t.dyn && a.n_instances == 1 && t.nt && t.prefetch) {
-        const hipError_t e = launch_dyn(a, t, stream);
+    if (t.dyn && a.n_instances == 1 && a.n_bones != 0 && a.n_bones <= 256 && a.n_verts <= 0x0fffffffu) {
+        const hipError_t e = t.exact ? launch_mask<true, true>(a, t, stream) : launch_mask<false, true>(a, t, stream);
         if (e != hipErrorNotReady) return e;
     }
     // crowds (one mesh, many palettes) keep the vertices in registers and loop over instances
     if (t.crowd > 0 || (t.crowd < 0 && a.n_instances >= 4)) return launch_crowd(a, t, stream);
-    switch (t.block) {
-        case 512: return launch_block<512>(a, t, stream);
-        case 1024: return launch_block<1024>(a, t, stream);
-        default: return launch_block<256>(a, t, stream);
-    }
+    return t.exact ? launch_mask<true, false>(a, t, stream) : launch_mask<false, false>(a, t, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1710,30 +1388,6 @@ __global__ __launch_bounds__(256) void max_bone_index_kernel(const uint32_t* __r
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));  // one per block
-}
-
-__global__ __launch_bounds__(256) void retile_units_kernel(const float* __restrict__ pos, const float* __restrict__ nrm,
-                                                           const float* __restrict__ tan, const float* __restrict__ wgt,
-                                                           const uint32_t* __restrict__ idx, uint32_t n_verts,
-                                                           uint32_t* __restrict__ tiled) {
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= n_verts) return;   // the rest of the last unit stays zero (memset by the caller)
-    const uint32_t l = v & 63u;
-    uint32_t* d = tiled + (size_t)(v >> 6) * kTiledDwordsPerUnit;
-    const f32x4 t = reinterpret_cast<const f32x4*>(tan)[v], w = reinterpret_cast<const f32x4*>(wgt)[v];
-    reinterpret_cast<f32x4*>(d)[l] = f32x4{pos[(size_t)v * 3], pos[(size_t)v * 3 + 1], pos[(size_t)v * 3 + 2], nrm[(size_t)v * 3]};
-    reinterpret_cast<f32x4*>(d + 256)[l] = f32x4{nrm[(size_t)v * 3 + 1], nrm[(size_t)v * 3 + 2], t.x, t.y};
-    reinterpret_cast<f32x4*>(d + 512)[l] = f32x4{t.z, t.w, w.x, w.y};
-    d[768 + l * 3] = __float_as_uint(w.z);
-    d[768 + l * 3 + 1] = __float_as_uint(w.w);
-    d[768 + l * 3 + 2] = idx[v];
-}
-
-hipError_t launch_retile_units(const float* pos, const float* nrm, const float* tan, const float* wgt, const uint32_t* idx,
-                               uint32_t n_verts, uint32_t* tiled, hipStream_t stream) {
-    if (n_verts == 0) return hipSuccess;
-    hipLaunchKernelGGL(retile_units_kernel, dim3((n_verts + 255) / 256), dim3(256), 0, stream, pos, nrm, tan, wgt, idx, n_verts, tiled);
-    return hipGetLastError();
 }
 
 hipError_t launch_max_bone_index(const uint32_t* d_idx, uint32_t n_verts, uint32_t* d_out,

@@ -68,36 +68,37 @@ int fyx_sync(fyx_ctx* ctx);
  * host-variant calls, fyx_palette*) joins implicitly first.  A caller that borrowed a stream
  * with fyx_set_stream must call fyx_join before consuming skinned output on that stream. */
 int fyx_join(fyx_ctx* ctx);
-/* Kernel tuning knobs (block size, grid multiple, prefetch, exact vs fused arithmetic).
- * Unknown keys return FYX_ERR_INVALID_ARG.  Keys: "lbs.block", "lbs.blocks_per_cu", "lbs.prefetch",
- * "lbs.exact" (1 = reference operation order, no FMA contraction: bit-identical to the CPU path;
- * 0 = fused multiply-add, within 1e-5 relative), "lbs.nt" (non-temporal loads/stores),
- * "lbs.streams" (1..4 worker streams for independent skinning launches, see fyx_join),
- * "lbs.crowd" (instanced launches: -1 = crowd kernel from 4 instances on, 0 never, 1 always; the
- * crowd kernel keeps a tile of vertices in registers and loops over instances), "lbs.crowd_block"
- * (256 | 512 vertices per tile), "lbs.crowd_ipb" (instances per workgroup, 0 = auto),
- * "lbs.crowd_lean" (1 = the crowd kernel in its register-lean form at two workgroups per CU: ~6 % slower alone, but it
- * leaves register room for the next frame's pose kernels to run beside it -- use with "anim.overlap"),
- * "lbs.prefetch" (0 | 1 | 2 units of loads ahead), "lbs.split" (how a launch's 64-vertex units are
- * dealt to the waves: 0 contiguous range per workgroup, units round-robin inside it; 1 equal
- * contiguous vertex shares per wave; 2 units interleaved over all waves), "lbs.probe" (debug
- * timeline, fyx_debug_read_probe), "lbs.timing" (per-launch events, fyx_debug_kernel_time); pose path: "anim.threads" / "anim.split" (host threads that
- * plan a crowd's frame and instances per planning task; crowds below 2 x anim.split stay on the
- * calling thread), "anim.sample_form" (0 auto, 1 curves of one instance on the lanes, 2
- * instances of one curve on the lanes -- same results, the crowd form is picked from 32
- * instances on), "anim.overlap" (1 = pose updates do not wait for the skinning launches in flight, so frame
- * n + 1's pose kernels run beside frame n's skinning; the caller then alternates two palette buffers per animator,
- * see INTEGRATION.md), "anim.inline_ctrl" (1, the default: a frame's control block -- sample times, tick flags, fold
- * program -- of at most 1 KB, i.e. one character or a handful of instances, travels inside the kernel arguments of the
- * pose kernels instead of through a device block and an H2D copy on the upload stream; 0 = always the copy.  Same
- * kernels, same results; a single character's frame 0.031 -> 0.018 ms), "lbs.dyn" / "lbs.dyn_block" (single-instance launches from 512 K vertices: 1 = the kernel
- * whose waves draw their 64-vertex units from a per-workgroup ticket counter, workgroups of 256 | 512 | 1024
- * threads; 0 = lbs_skin's fixed deal).  With lbs.exact = 0 the crowd kernel blends the four matrices first and
- * transforms once (the same linear map, different rounding, inside the 1e-5 bar). */
+/* Options.  Unknown keys return FYX_ERR_INVALID_ARG.
+ *   skinning:
+ *     "lbs.exact"        1 (default) = the reference's operation order, no FMA contraction: bit-identical to the CPU path;
+ *                        0 = fused multiply-adds, within 1e-5 relative (north_star's tolerance); the crowd kernel then blends
+ *                        the four matrices first and transforms once (the same linear map, different rounding)
+ *     "lbs.streams"      1..4 worker streams for independent skinning launches, see fyx_join (default 2)
+ *     "lbs.blocks_per_cu" persistent grid of lbs_skin = CUs x this (default 4)
+ *     "lbs.dyn"          single-instance launches from 512 K vertices on: 1 (default) = lbs_skin_dyn, whose waves draw their
+ *                        64-vertex units from a per-workgroup ticket counter; 0 = lbs_skin's fixed deal
+ *     "lbs.crowd"        instanced launches: -1 (default) = the crowd kernel from 4 instances on, 0 never, 1 always (it keeps
+ *                        a tile of 512 vertices in registers and loops over instances)
+ *     "lbs.crowd_ipb"    instances per workgroup run of the crowd kernel, 0 = auto
+ *     "lbs.crowd_lean"   1 = the crowd kernel in its register-lean form at two workgroups per CU: ~6 % slower alone, but it
+ *                        leaves register room for the next frame's pose kernels to run beside it -- use with "anim.overlap"
+ *     "lbs.timing"       per-launch events, see fyx_debug_kernel_time
+ *   pose path:
+ *     "anim.threads" / "anim.split"  host threads that plan a crowd's frame and instances per planning task; crowds below
+ *                        2 x anim.split stay on the calling thread
+ *     "anim.sample_form" 0 auto, 1 curves of one instance on the lanes, 2 instances of one curve on the lanes -- same
+ *                        results, the crowd form is picked from 32 instances on
+ *     "anim.overlap"     1 = pose updates do not wait for the skinning launches in flight, so frame n + 1's pose kernels run
+ *                        beside frame n's skinning; the caller then alternates two palette buffers per animator
+ *     "anim.inline_ctrl" 1 (default) = a frame's control block -- sample times, tick flags, fold program -- of at most 1 KB, i.e.
+ *                        one character or a handful of instances, travels inside the kernel arguments of the pose kernels
+ *                        instead of through a device block and an H2D copy on the upload stream; 0 = always the copy.  Same
+ *                        kernels, same results; a single character's frame 0.031 -> 0.018 ms
+ *   exchange:
+ *     "comm.form"        see fyx_allgather_skinned
+ * The kernel-variant switches of rounds 1 - 2 (workgroup sizes, prefetch depth, cache policy, work distribution, timeline
+ * probe) were experiments; their results are in DESIGN.md 5 and the code in the history (tools/exp/README.md). */
 int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
-/* Debug aid (option "lbs.probe" = 1): per-wave timeline of the last default-variant skinning launch, four
- * uint64 per wave {kernel entry, palette staged, last store issued, last store completed} in 10 ns ticks. */
-int fyx_debug_read_probe(fyx_ctx* ctx, uint64_t* host_out, uint32_t n_waves);
 /* Measurement aid (option "lbs.timing" = 1): every fyx_lbs_skin_device launch carries its own start / stop events
  * (hipExtLaunchKernel: the dispatch's begin / end timestamps, i.e. the kernel's own duration as a kernel trace
  * reports it, without the gap between dependent launches).  Waits for the work in flight, returns the sum of the

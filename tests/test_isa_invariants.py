@@ -21,7 +21,7 @@ def stats():
     if not os.path.exists(isa_stats.OBJDUMP):
         pytest.skip("llvm-objdump of the ROCm toolchain is not here")
     s = isa_stats.kernel_stats(LIB)
-    assert len(s) > 300, "the library's kernels were not found in the offload bundles"
+    assert len(s) > 100, "the library's kernels were not found in the offload bundles"
     return s
 
 
@@ -31,7 +31,7 @@ def _targs(name):
 
 
 # position of the EXACT template argument in each skinning kernel
-EXACT_ARG = {"fyx::lbs_skin": 1, "fyx::lbs_skin_dyn": 1, "fyx::lbs_skin_crowd": 1, "fyx::lbs_skin_batch": 0, "fyx::lbs_skin_ex": 0,
+EXACT_ARG = {"fyx::lbs_skin": 0, "fyx::lbs_skin_dyn": 0, "fyx::lbs_skin_crowd": 1, "fyx::lbs_skin_batch": 0, "fyx::lbs_skin_ex": 0,
              "fyx::lbs_skin_aos": 0, "fyx::lbs_skin_aos_batch": 0}
 
 
@@ -56,7 +56,7 @@ def test_exact_skinning_kernels_contain_no_contracted_multiply_add(stats):
         else:
             seen["fused"] += 1
             assert c["v_pk_fma_f32"] > 0, (name, "the fused variant is expected to use packed FMA")
-    assert seen["exact"] > 150 and seen["fused"] > 100, seen
+    assert seen["exact"] >= 50 and seen["fused"] >= 40, seen
 
 
 def test_pose_and_palette_kernels_contain_no_contracted_multiply_add(stats):
@@ -101,7 +101,7 @@ def test_register_budgets_behind_the_measured_occupancies():
     if not os.path.exists(isa_stats.READELF):
         pytest.skip("llvm-readelf of the ROCm toolchain is not here")
     res = isa_stats.kernel_resources(LIB)
-    budget = {"fyx::lbs_skin_dyn<256, true, 7, false, 2, 16>": 128, "fyx::lbs_skin<512, true, true, 3, 7, false>": 128,
+    budget = {"fyx::lbs_skin_dyn<true, 7>": 128, "fyx::lbs_skin<true, 7>": 128,
               "fyx::lbs_skin_batch<true, 7>": 128, "fyx::lbs_skin_crowd<512, true, 7, false>": 128,
               "fyx::lbs_skin_crowd<512, true, 7, true>": 80, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel": 64}
     for name, limit in budget.items():

@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=400)
 ap.add_argument("--sets", type=int, default=8)
 ap.add_argument("--rounds", type=int, default=3)
-ap.add_argument("--variants", default="1024x2,512x4,256x6")
+ap.add_argument("--variants", default="512x2,512x4,512x8")
 args = ap.parse_args()
 
 ctx = fyrox_amd.Context(0)
@@ -55,8 +55,8 @@ for r in range(args.rounds):
         ctx.set_option("lbs.blocks_per_cu", bpcu)
         res["copy"].setdefault(f"256x{bpcu}", []).append(time_it(copy, args.steps))
     for v in args.variants.split(","):
-        b, g = v.split("x")
-        ctx.set_option("lbs.block", int(b)); ctx.set_option("lbs.blocks_per_cu", int(g))
+        b, g = v.split("x")       # (the workgroup size is fixed at 512 since round 3; only the grid multiple varies)
+        ctx.set_option("lbs.blocks_per_cu", int(g))
         for exact in (1, 0):
             ctx.set_option("lbs.exact", exact)
             res["lbs"].setdefault(f"{v} exact={exact}", []).append(time_it(lbs, args.steps))

@@ -29,7 +29,6 @@ python $ROOT/tools/bench_scene.py > "$ROOT/$OUT/scene_64x4.json" 2> "$ROOT/$OUT/
 python $ROOT/tools/bench_scene.py --characters 256 --instances 1 --verts 5000 > "$ROOT/$OUT/scene_256x1.json" 2> "$ROOT/$OUT/scene_256x1.err"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_scene" -o scene -- python $ROOT/tools/bench_scene.py --characters 256 --instances 1 --verts 5000 --frames 50 --batched-only > "$ROOT/$OUT/scene_under_trace.json" 2> "$ROOT/$OUT/trace_scene.err" )
 python $ROOT/tools/bench_pose.py --opt lbs.streams=1 --opt lbs.exact=0 > "$ROOT/$OUT/pose_fused.json" 2> "$ROOT/$OUT/pose_fused.err"
-python $ROOT/tools/probe_timeline.py --opt lbs.blocks_per_cu=2 > "$ROOT/$OUT/timeline.json" 2> "$ROOT/$OUT/timeline.err"
 python $ROOT/tools/write_ceiling.py > "$ROOT/$OUT/write_ceiling.json" 2> "$ROOT/$OUT/write_ceiling.err"
 python $ROOT/tools/calib.py --rounds 2 > "$ROOT/$OUT/calibration_stream.json" 2> "$ROOT/$OUT/calib.err"
 find "$OUT" -name "*_kernel_trace.csv" -size +8M -delete   # raw per-dispatch traces of the long runs do not travel back

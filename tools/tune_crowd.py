@@ -49,7 +49,6 @@ def run(label, **opts):
 
 run("stream", crowd=0)
 for exact in (1, 0):
-    for cb in (256, 512):
-        for ipb in (0, 2, 4, 8, 16, 32, 64):
-            run("crowd", crowd=1, crowd_block=cb, crowd_ipb=ipb, exact=exact)
+    for ipb in (0, 2, 4, 8, 16, 32, 64):
+        run("crowd", crowd=1, crowd_ipb=ipb, exact=exact)
 ctx.close()
