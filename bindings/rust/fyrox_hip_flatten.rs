@@ -609,7 +609,12 @@ impl<'a> HipAnimator<'a> {
             }
             saved.push(per_layer);
         }
-        // events still queued: out of the library (they do not survive the clear), into the shim's own queue, as handles
+        // events still queued: out of the library (they do not survive the clear), into the shim's own queue, as handles.
+        // KNOWN LOSS: only instance 0's events are kept -- the `Machine` this shim mirrors is ONE machine (instance 0 is the
+        // engine's own `MachineLayer::pop_event` stream); the queued events of instances 1.. of a crowd animator are dropped by an
+        // in-place edit.  The Python mirror (fyrox_amd/anim.py::rebuild_machine) keeps them per (layer, instance); a crowd front
+        // end that needs them across edits must do the same (a queue per (layer, instance) and an instance argument to
+        // pop_layer_event).  Not done here: this file has never met a compiler and is not grown further.
         for li in 0..maps.layers.len() {
             while let Some(e) = self.pop_layer_event_raw(li as u32, 0, maps)? {
                 if maps.pending_layer_events.len() <= li {

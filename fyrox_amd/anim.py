@@ -601,8 +601,8 @@ class Animator:
                 if s < 0:
                     # MachineLayer::add_state makes a state active whenever none is (layer.rs:229-235) -- also while a
                     # transition is in flight: the first state this edit ADDED takes the place
-                    kept = {m(state_maps, li_old, k, len(nl.states)) for k in range(len(old.layers[li_old].states))}
-                    added = [k for k in range(len(nl.states)) if k not in kept]
+                    kept_states = {m(state_maps, li_old, k, len(nl.states)) for k in range(len(old.layers[li_old].states))}
+                    added = [k for k in range(len(nl.states)) if k not in kept_states]
                     if added:
                         s_new = added[0]
                 self.set_layer_state(li, s_new, m(transition_maps, li_old, t, len(nl.transitions)), inst)

@@ -1153,15 +1153,18 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         const uint32_t lane = threadIdx.x & 63u;
         if (lane < n_ops) my_op = prog[lane];
     }
-    // Every lane of every wave walks the fold, also the lanes past the last node (they redo the last node and store
-    // nothing): fold_op reads the program out of the lanes' registers with v_readlane, and a lane that is inactive when
+    // Every lane of every wave walks the fold, also the lanes past the last node (they fold the last node's operand records onto
+    // an identity transform and store nothing): fold_op reads the program out of the lanes' registers with v_readlane, and a lane that is inactive when
     // its register is read is undefined by the LLVM contract -- with a rig of 24 nodes and a program of 40 ops the ops
     // 24..39 would sit in lanes that a `node < n_nodes` loop has switched off.
     for (uint32_t node_base = 0; node_base < rig.n_nodes; node_base += blockDim.x) {   // workgroup-uniform trip count
         const bool live = node_base + threadIdx.x < rig.n_nodes;
         const uint32_t node = live ? node_base + threadIdx.x : rig.n_nodes - 1;
         f4* trs = reinterpret_cast<f4*>(f.node_trs) + (inst_base + node) * 3;
-        const f4 t0 = trs[0], t1 = trs[1], t2 = trs[2];
+        // a lane past the last node folds an identity transform, not the last node's record: the lane that owns that node (maybe in
+        // another wave of the block) writes its folded TRS back below, and an unsynchronised read of it here would be a race
+        f4 t0 = f4{0.f, 0.f, 0.f, 0.f}, t1 = f4{0.f, 0.f, 0.f, 1.f}, t2 = f4{1.f, 1.f, 1.f, 0.f};
+        if (live) { t0 = trs[0]; t1 = trs[1]; t2 = trs[2]; }
         float st[28];
         {
             const f4* sp = reinterpret_cast<const f4*>(rig.statics + (size_t)node * 28);

@@ -520,6 +520,7 @@ struct Planner {
             }
         }
         const uint32_t o0 = A.prev_prog_off[inst], o1 = A.prev_prog_off[inst + 1];
+        if (o0 > o1 || o1 > A.prev_ops.size()) return false;      // (never with a completed last frame: see FailGuard)
         S.ops.insert(S.ops.end(), A.prev_ops.begin() + o0, A.prev_ops.begin() + o1);
         return true;
     }
@@ -676,6 +677,14 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
     A.prog_off.swap(A.prev_prog_off);
     if (mode != 1 || A.prev_mode != 1) ++A.edit_gen;
     A.prev_mode = mode;
+    // A frame that does not complete (planner error, std::bad_alloc out of the pool or a vector) leaves A.ops / A.prog_off half
+    // filled, and the instances planned before the failure have already stamped their memo with this generation: the next frame
+    // would swap the torso in as the memo's source.  Whatever the exit, a failed frame invalidates every memo.
+    struct FailGuard {
+        Animator& a;
+        bool ok = false;
+        ~FailGuard() { if (!ok) { ++a.edit_gen; a.ops.clear(); a.prog_off.clear(); a.prev_ops.clear(); a.prev_prog_off.clear(); } }
+    } guard{A};
     // which animations a state's pose tree plays (node/mod.rs:116-150): the same for every instance, and the same as last
     // frame unless an API call touched the animator in between (edit_gen)
     if (mode == 1 && A.state_anims_gen != A.edit_gen) {
@@ -753,6 +762,7 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
     }
     A.prog_off[A.n_instances] = (uint32_t)A.ops.size();
     A.rm_prog_off[A.n_instances] = (uint32_t)A.rm_ops.size();
+    guard.ok = true;
     return FYX_OK;
 }
 
