@@ -152,3 +152,39 @@ def test_blend_space_triangulated_square(orc, golden):
     assert sorted((w[0][0], w[1][0])) == [0, 1] and w[2] == (w[1][0], 0.0)
     assert w[0][1] == 0.5 and w[1][1] == 0.5
     assert orc.blend_space_fetch_weights(pts, tri, (5.0, 5.0)) is None  # no edge contains the projection
+
+
+def test_transform_point_and_vector_under_identity(orc, golden):
+    # fyrox-math/src/ray.rs:868-882: Ray::transform(identity) returns the ray (exact equality)
+    g = golden["ray_transform_identity"]
+    m = np.asarray(g["matrix_rows"], np.float32).T.reshape(16)        # the oracle's matrices are column-major, as nalgebra's storage
+    assert orc.transform_point(m, g["origin"]).tolist() == g["expect_origin"]
+    assert orc.transform_vector(m, g["dir"]).tolist() == g["expect_dir"]
+    # and a point that exercises the divide: n = 1 exactly, the quotient is the operand
+    assert orc.transform_point(m, [0.1, -7.25, 3.0e7]).tolist() == np.asarray([0.1, -7.25, 3.0e7], np.float32).tolist()
+
+
+def test_vector_lerp_is_nalgebras(orc, golden):
+    # fyrox-math/src/segment.rs:186-195: begin.lerp(&end, 0.5) == (0.5, 1.0)
+    g = golden["segment_nearest_in_middle"]
+    assert orc.vec_lerp(g["begin"], g["end"], g["t"]).tolist() == g["expect"]
+
+
+def test_matrix_product_behind_aabb_transform(orc, golden):
+    # fyrox-math/src/aabb.rs:358-370: (translation * scaling) applied to the unit box by AxisAlignedBoundingBox::transform (:264-287)
+    g = golden["aabb_transform"]
+    t = np.eye(4, dtype=np.float32); t[:3, 3] = g["translation"]
+    s = np.diag(np.asarray(g["scaling"] + [1.0], np.float32))
+    m = orc.mat4_mul(t.T.reshape(16), s.T.reshape(16)).reshape(4, 4).T       # back to rows
+    basis, position = m[:3, :3], m[:3, 3]
+    lo, hi = position.copy(), position.copy()
+    bmin, bmax = np.asarray(g["box_min"], np.float32), np.asarray(g["box_max"], np.float32)
+    for i in range(3):
+        for j in range(3):
+            a, b = basis[i, j] * bmin[j], basis[i, j] * bmax[j]
+            if a < b:
+                lo[i] += a; hi[i] += b
+            else:
+                lo[i] += b; hi[i] += a
+    assert lo.tolist() == g["expect_min"] and hi.tolist() == g["expect_max"]
+    assert m[3].tolist() == [0.0, 0.0, 0.0, 1.0]
