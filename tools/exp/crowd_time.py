@@ -25,10 +25,10 @@ for exact in (1, 0):
     per, ker = [], []
     for r in range(3):
         ctx.sync(); ctx.timer_begin()
-        for _ in range(60): launch()
-        per.append(ctx.timer_end() / 60 * 1e3)
+        for _ in range(120): launch()
+        per.append(ctx.timer_end() / 120 * 1e3)
         ctx.set_option("lbs.timing", 1); ctx.kernel_time()
-        for _ in range(60): launch()
+        for _ in range(120): launch()
         us, n = ctx.kernel_time(); ctx.set_option("lbs.timing", 0)
         ker.append(us / n)
     print(json.dumps({"lib": os.path.basename(os.environ.get("FYX_LIB_PATH", "product")), "exact": exact, "period_us": round(float(np.median(per)), 2), "kernel_us": round(float(np.median(ker)), 2)}), flush=True)

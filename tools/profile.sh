@@ -18,6 +18,9 @@ python $ROOT/bench.py --steps 2000 --warmup 100 --cpu-seconds 3 > "$ROOT/$OUT/be
 python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > "$ROOT/$OUT/bench_driver_args.json" 2> "$ROOT/$OUT/bench_driver_args.err"
 # C3 crowd, pose path + instanced skinning (kernel-trace only)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_pose" -o pose -- python $ROOT/tools/bench_pose.py --frames 200 > "$ROOT/$OUT/pose_under_trace.json" 2> "$ROOT/$OUT/trace_pose.err" )
+# the crowd skinning launch ALONE (no pose kernels, no uploads beside it): exact then fused, 10 + 3 x 120 launches each
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_crowd_lone" -o crowd -- python $ROOT/tools/exp/crowd_time.py > "$ROOT/$OUT/crowd_lone_under_trace.jsonl" 2> "$ROOT/$OUT/trace_crowd_lone.err" )
+python $ROOT/tools/exp/crowd_time.py > "$ROOT/$OUT/crowd_lone.jsonl" 2> "$ROOT/$OUT/crowd_lone.err"
 python $ROOT/tools/bench_pose.py > "$ROOT/$OUT/pose_plain.json" 2> "$ROOT/$OUT/pose_plain.err"
 python $ROOT/tools/bench_pose.py --palette-output > "$ROOT/$OUT/pose_palette_output.json" 2> "$ROOT/$OUT/pose_palette_output.err"
 python $ROOT/tools/bench_pose.py --root-motion > "$ROOT/$OUT/pose_root_motion.json" 2> "$ROOT/$OUT/pose_root_motion.err"
@@ -31,6 +34,6 @@ python $ROOT/tools/bench_scene.py --characters 256 --instances 1 --verts 5000 > 
 python $ROOT/tools/bench_pose.py --opt lbs.streams=1 --opt lbs.exact=0 > "$ROOT/$OUT/pose_fused.json" 2> "$ROOT/$OUT/pose_fused.err"
 python $ROOT/tools/write_ceiling.py > "$ROOT/$OUT/write_ceiling.json" 2> "$ROOT/$OUT/write_ceiling.err"
 python $ROOT/tools/calib.py --rounds 2 > "$ROOT/$OUT/calibration_stream.json" 2> "$ROOT/$OUT/calib.err"
-find "$OUT" -name "*_kernel_trace.csv" -size +8M -delete   # raw per-dispatch traces of the long runs do not travel back
+find "$OUT" -name "*_kernel_trace.csv" -size +12M -delete   # raw per-dispatch traces of the long runs do not travel back
 find "$OUT" -name "*.csv" | head -40
 du -sh "$OUT"

@@ -30,6 +30,51 @@ for f in ("bench_driver_args.json", "bench_plain.json", "bench_under_trace.json"
         shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
 
 
+for f in ("crowd_lone_under_trace.jsonl", "crowd_lone.jsonl"):
+    p = os.path.join(src, f)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
+p = os.path.join(src, "trace_crowd_lone", "crowd_kernel_stats.csv")
+if os.path.exists(p):
+    shutil.copy(p, os.path.join(dst, f"{tag}_crowd_lone_kernel_stats.csv"))
+
+
+def crowd_spread():
+    """Why lbs_skin_crowd's duration spreads in the C3 frame trace (tools/bench_pose.py): every dispatch of the per-dispatch trace
+    with what ran beside it -- the upload stream's copy of the NEXT frame's control block and nothing else on one launch stream --
+    split into the frame loops (pose kernels before and after it on the same stream) and the skinning-only loop."""
+    p = os.path.join(src, "trace_pose", "pose_kernel_trace.csv")
+    if not os.path.exists(p):
+        return None
+    rows = list(csv.DictReader(open(p)))
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1][:28]) for r in rows)
+    crowd = [(s, e) for s, e, n in ev if n.startswith("lbs_skin_crowd")]
+    others = [(s, e, n) for s, e, n in ev if not n.startswith("lbs_skin_crowd")]
+    out = {"dispatches": len(crowd)}
+    groups = {"alone": [], "beside_another_kernel": []}
+    j = 0
+    for s, e in crowd:
+        beside = [n for os_, oe, n in others if os_ < e and oe > s]
+        groups["beside_another_kernel" if beside else "alone"].append((e - s) / 1e3)
+    for k, v in groups.items():
+        if v:
+            v.sort()
+            out[k] = {"n": len(v), "min_us": v[0], "median_us": v[len(v) // 2], "max_us": v[-1], "mean_us": sum(v) / len(v)}
+    # previous kernel on the timeline: the first crowd dispatch after a pose kernel vs after another crowd dispatch
+    prev = {"after_a_pose_kernel": [], "after_a_crowd_dispatch": []}
+    names = [(s, e, n) for s, e, n in ev]
+    for i, (s, e, n) in enumerate(names):
+        if not n.startswith("lbs_skin_crowd") or i == 0:
+            continue
+        pn = names[i - 1][2]
+        prev["after_a_crowd_dispatch" if pn.startswith("lbs_skin_crowd") else "after_a_pose_kernel"].append((e - s) / 1e3)
+    for k, v in prev.items():
+        if v:
+            v.sort()
+            out[k] = {"n": len(v), "min_us": v[0], "median_us": v[len(v) // 2], "max_us": v[-1], "mean_us": sum(v) / len(v)}
+    return out
+
+
 def trace_summary(sub):
     """per-launch throughput time from the kernel trace (first start -> last end over N launches)"""
     p = os.path.join(src, sub, "bench_kernel_trace.csv")
@@ -67,7 +112,8 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_lds"):
         v.sort()
         pmc.setdefault(k, {})[c] = {"median": v[len(v) // 2], "min": v[0], "max": v[-1], "launches": len(v)}
 
-out = {"source": src, "trace_streams2": trace_summary("trace"), "trace_streams1": trace_summary("trace_s1"), "pmc": pmc}
+out = {"source": src, "trace_streams2": trace_summary("trace"), "trace_streams1": trace_summary("trace_s1"), "pmc": pmc,
+       "crowd_duration_spread_in_the_c3_frame_trace": crowd_spread()}
 if "stream_copy" in pmc and "FETCH_SIZE" in pmc["stream_copy"] and "lbs_skin" in pmc:
     KB = 1024.0
     copy_rd_known, copy_wr_known = 48 * 1_250_000, 32 * 1_250_000
