@@ -262,6 +262,17 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     k_us, k_n = ctx.kernel_time()
     ctx.set_option("lbs.timing", 0)
     skin_kernel_us = k_us / max(k_n, 1)
+    # the same dispatch INSIDE the frame (pose kernels before it on the stream): a launch that follows another skinning launch
+    # directly inherits that launch's un-drained writes -- the kernel "ends" when the caches have accepted its 400 MB, not when
+    # HBM has them -- and runs 10 - 20 % longer than one that follows ~50 us of pose kernels (profiles/r03_summary.json,
+    # crowd_duration_spread_in_the_c3_frame_trace)
+    ctx.set_option("lbs.timing", 1)
+    ctx.kernel_time()
+    for _ in range(frames):
+        frame()
+    kf_us, kf_n = ctx.kernel_time()
+    ctx.set_option("lbs.timing", 0)
+    skin_kernel_in_frame_us = kf_us / max(kf_n, 1)
     unique = mesh.n_verts * 60 + n_instances * nb * 64 + nv * 40     # mesh read once, palettes, outputs
     fused_rec = None
     if fused:     # the same launch with lbs.exact = 0 (FMA; the crowd kernel blends the four matrices first): inside north_star's 1e-5
@@ -308,7 +319,11 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
            "roofline": {"bound": "hbm", "kernel": "lbs_skin_crowd" if n_instances >= 4 else "lbs_skin",
                         "unique_bytes_per_launch": unique, "achieved": unique / (skin_kernel_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": unique / (skin_kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                        "kernel_us": skin_kernel_us, "launch_period_us": skin_ms * 1e3},
+                        "kernel_us": skin_kernel_us, "launch_period_us": skin_ms * 1e3,
+                        "kernel_us_note": "per-dispatch events over back-to-back launches of the skinning kernel (each inherits its predecessor's write-back)",
+                        "kernel_us_in_frame": skin_kernel_in_frame_us,
+                        "frac_in_frame": unique / (skin_kernel_in_frame_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                        "in_frame_note": "the same dispatch timed inside the one-stream frame loop, behind the frame's pose kernels"},
            "parity": {"instances_checked": sorted(oracles), "frames_in_lock_step": n_par,
                       "end_to_end_max_rel_err": chain_err, "end_to_end_bit_exact": chain_exact,
                       "bit_exact": lbs_exact,

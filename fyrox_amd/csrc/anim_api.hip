@@ -137,7 +137,37 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
             recs[k].loc = key_location[k];
             recs[k].pad[0] = recs[k].pad[1] = recs[k].pad[2] = 0.f;
         }
+        // span records (TrackHot / AnimDev::spans): tracks whose first `need` curves share their key times
+        std::vector<TrackHot> hot(n_tracks);
+        std::vector<float4> spans;
+        for (uint32_t t = 0; t < n_tracks; ++t) {
+            const int kind = tracks[t].kind;
+            const uint32_t need = kind == FYX_KIND_QUAT ? 4u : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3u : 0u;
+            hot[t] = TrackHot{kind, tracks[t].n_curves, 0u, kNoSpans};
+            if (need == 0 || tracks[t].n_curves < need || tracks[t].binding >= FYX_BIND_PROPERTY0) continue;
+            const uint32_t nk = hd[t].n_keys[0];
+            bool same = nk >= 2;
+            for (uint32_t k = 1; k < need && same; ++k)
+                same = hd[t].n_keys[k] == nk &&
+                       memcmp(key_location + hd[t].first_key[k], key_location + hd[t].first_key[0], (size_t)nk * 4) == 0;
+            if (!same) continue;
+            const uint32_t stride = need == 4 ? 16u : 8u;        // f4 per record: 256 / 128 bytes
+            if (spans.size() + (size_t)(nk - 1) * stride > 0x7fffffffull) continue;
+            hot[t].n_keys = nk;
+            hot[t].span_first = (uint32_t)spans.size();
+            spans.resize(spans.size() + (size_t)(nk - 1) * stride, make_float4(0.f, 0.f, 0.f, 0.f));
+            for (uint32_t i = 1; i < nk; ++i) {
+                float4* r = spans.data() + hot[t].span_first + (size_t)(i - 1) * stride;
+                r[0] = make_float4(key_location[hd[t].first_key[0] + i - 1], key_location[hd[t].first_key[0] + i], 0.f, 0.f);
+                for (uint32_t k = 0; k < need; ++k) {
+                    r[1 + 2 * k] = aux[hd[t].first_key[k] + i - 1];
+                    r[2 + 2 * k] = aux[hd[t].first_key[k] + i];
+                }
+            }
+        }
         int rc = upload(c, &td.d_tracks, hd.data(), hd.size());
+        if (!rc) rc = upload(c, &td.d_hot, hot.data(), hot.size());
+        if (!rc && !spans.empty()) rc = upload(c, &td.d_spans, spans.data(), spans.size());
         if (!rc) rc = upload(c, &td.d_loc, key_location, (size_t)n_keys);
         if (!rc) rc = upload(c, &td.d_aux, aux.data(), aux.size());
         if (!rc) rc = upload(c, &td.d_rec, recs.data(), recs.size());

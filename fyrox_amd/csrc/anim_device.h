@@ -103,6 +103,8 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             hd[a].key_loc = an.td->d_loc;
             hd[a].key_aux = an.td->d_aux;
             hd[a].key_rec = an.td->d_rec;
+            hd[a].hot = an.td->d_hot;
+            hd[a].spans = an.td->d_spans;
             hd[a].slot_track = an.d_slot_track;
             hd[a].prop_track = an.d_prop_track;
             hd[a].n_tracks = an.td->n_tracks;

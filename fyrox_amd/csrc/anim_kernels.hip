@@ -243,23 +243,60 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
         bool valid = false;
         float v = 0.0f;
         if (track >= 0) {
-            const TrackDev* tk = an.tracks + track;
-            kind = tk->kind;
+            const TrackHot th = an.hot[track];
+            kind = th.kind;
             need = kind == FYX_KIND_QUAT ? 4 : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3 : 0;
             const bool fits = (bind == FYX_BIND_ROTATION) ? (kind == FYX_KIND_QUAT || kind == FYX_KIND_QUAT_EULER)
                                                           : (kind == FYX_KIND_VEC3);
-            valid = fits && need > 0 && (int)tk->n_curves >= need;   // else fetch() -> None
+            valid = fits && need > 0 && (int)th.n_curves >= need;   // else fetch() -> None
             if (valid && c < need) {
                 uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
                 uint32_t hint = *hp;
-                const uint32_t fk = tk->first_key[c];
+                // Steady playback: the time lies strictly inside the hinted span [key hint - 1, key hint).  Curve::value_at then
+                // clamps nothing (first.location <= left < time < right <= last.location), takes its hinted span and leaves the
+                // hint alone (curve.rs:254-314) -- and the track's span record (TrackHot) holds everything that needs: one cache
+                // line for the three curves of a Vector3 track, two for a quaternion's four.
+                bool sampled = false;
+                if (th.span_first != kNoSpans && hint >= 1 && hint < th.n_keys) {
+                    const uint32_t stride = need == 4 ? 16u : 8u;
+                    const f4* r = reinterpret_cast<const f4*>(an.spans) + th.span_first + (size_t)(hint - 1) * stride;
+                    f4 locs = r[0];
+                    if (locs.x < time && time < locs.y) {
+                        v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+                        sampled = true;
+                    } else if (locs.y < time && hint + 1 < th.n_keys) {
+                        // playback crossed the span's right key: if the time lies strictly inside the NEXT span, nothing is clamped
+                        // there either, the hinted span fails, and partition_point(k.location < time) is hint + 1 (every key up to
+                        // `hint` lies before the time, key hint + 1 after it): the reference interpolates keys hint, hint + 1
+                        r += stride;
+                        locs = r[0];
+                        if (locs.x < time && time < locs.y) {
+                            v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+                            *hp = hint + 1;
+                            sampled = true;
+                        }
+                    } else if (time < locs.x && hint >= 2) {
+                        // reverse playback crossed the left key: strictly inside the PREVIOUS span the search returns hint - 1
+                        r -= stride;
+                        locs = r[0];
+                        if (locs.x < time && time < locs.y) {
+                            v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+                            *hp = hint - 1;
+                            sampled = true;
+                        }
+                    }
+                }
+                if (!sampled) {   // everything else, decided in the reference's order on the per-curve records
+                    const TrackDev* tk = an.tracks + track;
+                    const uint32_t fk = tk->first_key[c];
 #if FYX_KEYREC
-                v = curve_value_at(RecLoc{an.key_rec + fk}, RecAux{an.key_rec + fk}, tk->n_keys[c], curve_ends(tk, (int)c), time, hint);
+                    v = curve_value_at(RecLoc{an.key_rec + fk}, RecAux{an.key_rec + fk}, tk->n_keys[c], curve_ends(tk, (int)c), time, hint);
 #else
-                v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c],
-                                   curve_ends(tk, (int)c), time, hint);
+                    v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c],
+                                       curve_ends(tk, (int)c), time, hint);
 #endif
-                *hp = hint;
+                    *hp = hint;
+                }
             }
         }
         const int has_p = __shfl((int)valid, (int)gbase + 0, 64);

@@ -13,6 +13,8 @@ struct TracksData {
     float* d_loc = nullptr;
     float4* d_aux = nullptr;
     KeyRec* d_rec = nullptr;
+    TrackHot* d_hot = nullptr;
+    float4* d_spans = nullptr;
 };
 
 struct Rig {

@@ -172,9 +172,29 @@ struct alignas(32) KeyRec {
 };
 static_assert(sizeof(KeyRec) == 32, "two keys per 64 bytes");
 
+// What the per-instance sampler reads of a track FIRST (16 bytes: the three tracks of a bone share a cache line, where their
+// TrackDev records are three lines), and the track's SPAN RECORDS.  Importers write the curves of a track on common key times
+// (glTF samplers, FBX curve nodes); for such a track every span [key i - 1, key i) of ALL its curves is one record
+//     f4 {loc[i-1], loc[i], -, -}   then per curve c:  f4 aux[c][i-1], f4 aux[c][i]       (aux = {value, kind, left tan, right tan})
+// of 128 bytes (three curves: one cache line) or 256 (four), so a bone's ten curve samples touch four lines instead of ~12.5 of
+// per-curve key records -- and the memory system moves whole 128-byte lines whatever part is read
+// (profiles/r03_crowd_study/fetch_granule.log).  A sample whose time lies strictly inside its hinted span -- the steady state of
+// playback -- needs nothing else; every other case (clamping at the ends, a hint that moved, a time exactly on a key, curves with
+// their own key times) takes the general path over TrackDev / KeyRec, which decides everything in the reference's order.
+struct TrackHot {
+    int32_t kind;            // FYX_KIND_*
+    uint32_t n_curves;
+    uint32_t n_keys;         // keys per curve of a track that has span records
+    uint32_t span_first;     // first f4 of the track's span records in AnimDev::spans, or kNoSpans
+};
+static_assert(sizeof(TrackHot) == 16, "eight tracks per cache line");
+constexpr uint32_t kNoSpans = 0xffffffffu;
+
 // One animation of an animator (shared by all its instances).
 struct AnimDev {
     const TrackDev* tracks;
+    const TrackHot* hot;         // [n_tracks]
+    const float4* spans;         // span records of the tracks whose curves share their key times
     const float* key_loc;        // locations of all keys of the tracks data
     const float4* key_aux;       // {value, kind bits, left tangent, right tangent} per key
     const KeyRec* key_rec;       // the same keys, one record each
