@@ -387,6 +387,52 @@ def test_sampling_hints_with_duplicate_key_locations(ctx, orc):
     p.free()
 
 
+def test_span_records_take_every_exit(ctx, orc):
+    """The sampler's span records (TrackHot, round 3): tracks whose curves share their key times are sampled from one record per
+    span -- inside the hinted span, the next or the previous one -- and fall back to the per-curve records for everything else.
+    One clip holds a Vector3 track and a quaternion track with common key times (128- and 256-byte records), a Vector3 track whose
+    curves have DIFFERENT key times (no records) and one with a single key; key locations are multiples of 1/32 and dt = 1/64, so
+    every second frame lands exactly on a key, the ends clamp, and the speed changes below make the hint miss by one span, by
+    several, and across the loop point.  Every frame's pose is the oracle's, bit for bit."""
+    rng = np.random.default_rng(4242)
+    rig = synth.make_rig(6, 91)
+    locs = [k / 32.0 for k in range(0, 33, 2)]                       # 17 keys over one second
+    kinds = [A.KEY_LINEAR, A.KEY_CUBIC, A.KEY_CONSTANT]
+
+    def curve(times, scale=1.0):
+        return A.Curve([A.CurveKey(t, float(rng.normal()) * scale, kinds[i % 3], float(rng.normal()), float(rng.normal()))
+                        for i, t in enumerate(times)])
+
+    tracks, target = [], []
+    tracks.append(A.Track(A.BIND_POSITION, A.KIND_VEC3, [curve(locs), curve(locs), curve(locs)])); target.append(1)
+    tracks.append(A.Track(A.BIND_ROTATION, A.KIND_QUAT, [curve(locs), curve(locs), curve(locs), curve(locs)])); target.append(1)
+    tracks.append(A.Track(A.BIND_SCALE, A.KIND_VEC3, [curve(locs), curve(locs[::2]), curve(locs)])); target.append(1)      # ragged: general path
+    tracks.append(A.Track(A.BIND_POSITION, A.KIND_VEC3, [curve(locs[:1]), curve(locs[:1]), curve(locs[:1])])); target.append(2)   # one key
+    tracks.append(A.Track(A.BIND_ROTATION, A.KIND_QUAT, [curve(locs[3:9])] * 4)); target.append(3)               # keys only in the middle: clamps
+    td = A.AnimationTracksData(tracks)
+    sc = cases.Scenario("span_records", rig, [td], [cases.AnimSpec(0, np.asarray(target, np.int32), speed=1.0)], None,
+                        n_frames=70, dt=1.0 / 64.0, has_euler=False)
+    o, p = run_scenario(ctx, orc, sc)
+    f = 0
+    for speed, frames in ((-1.0, 40), (3.0, 50), (-2.5, 60), (0.5, 30), (-7.0, 20), (1.0, 10)):
+        p.set_speed(0, speed)
+        orc._alib().fo_animation_set_speed(o.anims[0], speed)
+        for _ in range(frames):
+            o.update_animations(sc.dt)
+            p.update_animations(sc.dt)
+            check_pose(p.read(A.READ_ANIMATION_POSE)[0], o.animation_pose(0), True, f"speed {speed} frame {f}")
+            f += 1
+    for t in (0.0, 1.0, 0.4375, 0.03125, 0.96875, 0.5):      # jumps: the hints are wherever the last run left them
+        p.set_time_position(0, t)
+        orc._alib().fo_animation_set_time_position(o.anims[0], t)
+        for _ in range(3):
+            o.update_animations(sc.dt)
+            p.update_animations(sc.dt)
+            check_pose(p.read(A.READ_ANIMATION_POSE)[0], o.animation_pose(0), True, f"jump to {t}")
+    o.close()
+    p.free()
+
+
 def test_instances_diverge(ctx, orc):
     """Per-instance state: different speeds / parameters per instance vs one oracle scene each."""
     sc = cases.transitions()
