@@ -790,7 +790,7 @@ def main():
             zero(ctx, o)
         step(0)
         ctx.sync()
-        parity = lbs_parity(ctx, mesh, pal, outs[0], min(nv, 50_000))
+        parity = lbs_parity(ctx, mesh, pal, outs[0], nv)        # every vertex of the launch (the oracle on 8 threads: ~0.2 s for 1 M)
         if parity["max_rel_err"] > 1e-5:
             raise SystemExit(f"parity check failed before timing: max rel err {parity['max_rel_err']:.3e} > 1e-5")
 
