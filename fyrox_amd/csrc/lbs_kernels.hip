@@ -565,14 +565,19 @@ __global__ __launch_bounds__(kDynBlock) void lbs_skin_dyn(LbsArgs a, uint32_t to
 // blockIdx -> (tile, chunk) with tile fastest: neighbouring workgroups (which round-robin over
 // the XCDs) read the same palettes, so each palette is fetched from HBM about once per XCD.
 //
-// What bounds it (C3, 1000 x 10 k / 64 bones; ISA count of the affine path: 69 v_pk_mul + 55 v_pk_add + 22 scalar
-// mul / add + ~20 moves and address updates per vertex-instance = ~165 VALU at 4 cycles each): 42 us of VALU issue per
-// CU beside 64 us of stores at 6.3 TB/s.  In the fused mode (~45 VALU) the launch IS the stores: 66 - 68 us, 0.75 of
-// peak.  In the exact mode the two do not hide each other completely: 77 - 80 us.  Measured and rejected in round 2
-// (profiles/r02_crowd_forms_sweep.jsonl, tools/exp/crowd_sweep.py in the history): a second form with two (or four)
-// instances per barrier, the palette fetched as matrix columns by every thread instead of by the bone-owning threads,
-// outputs as per-instance buffer resources so that no wave ever waits for a store (exact vmcnt counts), `sc1` or `nt`
-// stores -- 79 - 83 us exact (sc1: 84 - 95), 66 - 68 us fused: no better, the exact mode's floor is its arithmetic.
+// What bounds it (C3, 1000 x 10 k / 64 bones; ISA count of the affine path: 69 v_pk_mul + 55 v_pk_add + 16 single mul / add
+// + ~20 moves and address updates per vertex-instance; a packed instruction issues in ~1.9 ns per SIMD, a VOP2 one in ~1.1:
+// the packed form has the single form's rate per RESULT, it only halves the instruction count): 44 - 46 us of VALU issue
+// beside 62 - 65 us of stores.  In the fused mode (~45 VALU) the launch IS the stores: 60 - 67 us, 0.75 - 0.84 of peak.  In
+// the exact mode the kernel is bound by its COMPUTE PATH (round 3, profiles/r03_crowd_study/): without its stores it still
+// takes 73 - 84 us of 79 - 87; of those the arithmetic and LDS gathers are 49, the barrier 3, and the per-instance palette fetch +
+// commit on the one bone-owning wave 21 (waves 0 - 3 finish an instance's arithmetic in 1 360 cycles, waves 4 - 7 -- who lose
+// the VALU arbitration by age -- in 2 300, and wave 0 then spends another 1 120 on its palette).  Measured against that and NOT
+// kept, all bit-identical (tools/exp/r03_crowd_forms.patch): line-aligned stores through LDS strips, stores after the commit, a
+// loading wave that never stores, a persistent grid (also with staggered starts), a ring of eight palettes with one barrier per
+// eight instances, palettes copied by LDS-DMA from a pre-packed buffer with a counted vmcnt, a raised priority for waves 4 - 7;
+// round 2: two / four instances per barrier, palette columns staged by every thread, per-instance buffer-resource outputs, sc1
+// stores.  Compute and the 400 MB of stores each take 60 - 75 us alone and overlap only partly whatever the structure.
 // ---------------------------------------------------------------------------------------
 // LEAN (option lbs.crowd_lean): the arithmetic walks the influences one by one (SEQ above: ~74 VGPRs) and the launch asks
 // for enough LDS that only two workgroups share a CU -- four waves per SIMD holding ~320 of its 512 VGPRs, which leaves
