@@ -1190,6 +1190,28 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         const uint32_t lane = threadIdx.x & 63u;
         if (lane < n_ops) my_op = prog[lane];
     }
+    // STRAIGHT programs: PUSH^d BLEND_ANIM^k POP_BLEND^d APPLY END with k <= kStraightOps -- one layer in one state whose
+    // root is a clip or one blend node (BASELINE configs 2, 3, 5).  Every accumulator the PUSHes open is empty when its
+    // child is popped into it, and an empty pose becomes a COPY of the other (pose.rs:41-47, weight ignored), so the
+    // result is the k operands blended in order into one accumulator -- the same calls to blend() in the same order as
+    // the interpreter makes.  What the straight form buys is that the k operand records are requested together instead
+    // of one dependent round trip per BLEND_ANIM (a single character is one or two waves: nothing else hides them).
+    constexpr uint32_t kStraightOps = 4;
+    uint32_t st_d = 0, st_k = 0;
+    bool straight = false;
+    if constexpr (PROGRAM) {
+        if (n_ops >= 3u && n_ops <= 64u) {
+            const uint32_t code = my_op.x & 0xffu;
+            const uint64_t m_push = __ballot(code == OP_PUSH), m_blend = __ballot(code == OP_BLEND_ANIM), m_pop = __ballot(code == OP_POP_BLEND);
+            st_d = (uint32_t)__builtin_ctzll(~m_push | (1ull << 63));
+            st_k = (uint32_t)__builtin_ctzll(~(m_blend >> st_d) | (1ull << 63));
+            const uint32_t pops = (uint32_t)__builtin_ctzll(~(m_pop >> ((st_d + st_k) & 63u)) | (1ull << 63));
+            const uint32_t tail = 2u * st_d + st_k;
+            straight = st_k >= 1u && st_k <= kStraightOps && pops == st_d && st_d + 1 < (uint32_t)kMaxFoldDepth && n_ops == tail + 2u &&
+                       ((uint32_t)__builtin_amdgcn_readlane((int)my_op.x, (int)(tail & 63u)) & 0xffu) == OP_APPLY &&
+                       ((uint32_t)__builtin_amdgcn_readlane((int)my_op.x, (int)((tail + 1u) & 63u)) & 0xffu) == OP_END;
+        }
+    }
     // Every lane of every wave walks the fold, also the lanes past the last node (they fold the last node's operand records onto
     // an identity transform and store nothing): fold_op reads the program out of the lanes' registers with v_readlane, and a lane that is inactive when
     // its register is read is undefined by the LLVM contract -- with a rig of 24 nodes and a program of 40 ops the ops
@@ -1235,7 +1257,24 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             acc.mask = 0;
             // (touching all operand records ahead of the fold, so that its loads find them in flight, measured slower:
             // 19.1 vs 17.7 us on the C3 crowd)
-            while (!cx.done) run_fold<0>(cx, acc);  // a stray POP at depth 0 is ignored
+            if (straight) {
+                Acc rec[kStraightOps];
+                float rw[kStraightOps];
+#pragma unroll
+                for (uint32_t i = 0; i < kStraightOps; ++i) {
+                    if (i >= st_k) break;
+                    const uint2 op = fold_op(cx, st_d + i);
+                    rec[i] = load_rec(cx.anim_pose + ((size_t)(op.x >> 8) * cx.anim_stride + cx.rec_index) * 3);
+                    rw[i] = __uint_as_float(op.y);
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kStraightOps; ++i) {
+                    if (i >= st_k) break;
+                    blend(acc, rec[i], rw[i]);
+                }
+                apply_pose(cx, acc);
+            } else
+                while (!cx.done) run_fold<0>(cx, acc);  // a stray POP at depth 0 is ignored
             if (cx.dirty && live) {
                 trs[0] = f4{cx.tpx, cx.tpy, cx.tpz, 0.f};
                 trs[1] = cx.tr;

@@ -357,6 +357,31 @@ def test_quaternion_only_blend_tree_is_bit_exact(ctx, orc):
     p.free()
 
 
+@pytest.mark.parametrize("n_clips", [1, 2, 3, 4, 5, 6])
+def test_blend_node_operand_counts_around_the_straight_program_limit(ctx, orc, n_clips):
+    """One layer, one state, one BlendAnimations node over n clips: up to four operands the update kernel runs the program in
+    its straight form (all operand records requested together, anim_kernels.hip pose_update_body), above that in the fold
+    interpreter -- the same blend() calls in the same order either way, so both must give the oracle's bits.  The clips
+    are partial in different ways (a node missing from the first operand takes the copy rule, a value missing from a
+    later one is dropped), and the quaternion tracks keep the comparison bit-exact."""
+    nb, seed = 20, synth.SEED_BASE + 21
+    rig = synth.make_rig(nb, seed)
+    tds, anims = [], []
+    for c in range(n_clips):
+        td, tgt = synth.make_clip(nb, seed, clip=c, euler_every=10 ** 9)
+        if c % 2 == 0:
+            td, tgt = cases._partial(td, tgt, lambda b, t, c=c: (b + c) % 5 != 0 and not (b % 3 == 1 and t.binding == A.BIND_SCALE))
+        tds.append(td)
+        anims.append(cases.AnimSpec(c, tgt, speed=[1.0, 0.8, 1.3, -0.7, 2.1, 0.4][c]))
+    nodes = [A.PlayAnimation(a) for a in range(n_clips)]
+    nodes.append(A.BlendAnimations([A.BlendPose(a, [1.0, 0.5, 0.25, 0.75, 0.6, 0.1][a]) for a in range(n_clips)]))
+    machine = A.Machine(parameters=[], layers=[A.MachineLayer(nodes=nodes, states=[A.State(root=n_clips)])])
+    sc = cases.Scenario("blend_%d" % n_clips, rig, tds, anims, machine, has_euler=False, n_frames=24)
+    o, p = run_scenario(ctx, orc, sc, n_instances=3)
+    o.close()
+    p.free()
+
+
 @pytest.mark.parametrize("kind", [A.KEY_CONSTANT, A.KEY_LINEAR, A.KEY_CUBIC])
 def test_key_kinds_sample_bit_exact(ctx, orc, kind):
     sc = cases.player_only(euler_every=10 ** 9, key_kind=kind)
