@@ -782,7 +782,19 @@ __device__ __forceinline__ uint2 fold_op(const FoldCtx& cx, uint32_t pc) {
         op.y = (uint32_t)__builtin_amdgcn_readlane((int)cx.my_op.y, (int)pc);
         return op;
     }
-    return pc < cx.n_ops ? cx.ops[pc] : make_uint2(OP_END, 0u);
+    // (the program is the same for every lane: say so, or the interpreter's control flow and counters are compiled as divergent)
+    uint2 op = pc < cx.n_ops ? cx.ops[pc] : make_uint2(OP_END, 0u);
+    op.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)op.x);
+    op.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)op.y);
+    return op;
+}
+
+__device__ __forceinline__ Acc acc_empty() {
+    Acc a;
+    a.px = a.py = a.pz = a.sx = a.sy = a.sz = 0.f;
+    a.r = f4{0.f, 0.f, 0.f, 1.f};
+    a.mask = 0;
+    return a;
 }
 
 template <int D>
@@ -1190,15 +1202,16 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         const uint32_t lane = threadIdx.x & 63u;
         if (lane < n_ops) my_op = prog[lane];
     }
-    // STRAIGHT programs: PUSH^d BLEND_ANIM^k POP_BLEND^d APPLY END with k <= kStraightOps -- one layer in one state whose
-    // root is a clip or one blend node (BASELINE configs 2, 3, 5).  Every accumulator the PUSHes open is empty when its
-    // child is popped into it, and an empty pose becomes a COPY of the other (pose.rs:41-47, weight ignored), so the
-    // result is the k operands blended in order into one accumulator -- the same calls to blend() in the same order as
-    // the interpreter makes.  What the straight form buys is that the k operand records are requested together instead
-    // of one dependent round trip per BLEND_ANIM (a single character is one or two waves: nothing else hides them).
+    // STRAIGHT programs: [PUSH^d] BLEND_ANIM^k [POP_BLEND^d] [MASK] APPLY END with k <= kStraightOps -- a machine whose layers
+    // after the first are off, in one state or in one transition between states whose roots are single clips, or one state
+    // whose root is one blend node (BASELINE configs 2, 3, 5; the host writes such programs without the PUSHes, see
+    // Planner::emit_blend).  Every pose the PUSHes open is empty when its child is popped into it, and an empty pose becomes
+    // a COPY of the other (pose.rs:41-47, weight ignored), so the result is the k operands blended in order into one
+    // accumulator -- the same calls to blend() in the same order as the interpreter (run_fold) makes, without its dispatch
+    // (an op of it costs a lone wave ~0.7 us, memory round trip included) and with all k operand records requested together.
     constexpr uint32_t kStraightOps = 4;
     uint32_t st_d = 0, st_k = 0;
-    bool straight = false;
+    bool straight = false, st_mask = false;
     if constexpr (PROGRAM) {
         if (n_ops >= 3u && n_ops <= 64u) {
             const uint32_t code = my_op.x & 0xffu;
@@ -1206,10 +1219,12 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             st_d = (uint32_t)__builtin_ctzll(~m_push | (1ull << 63));
             st_k = (uint32_t)__builtin_ctzll(~(m_blend >> st_d) | (1ull << 63));
             const uint32_t pops = (uint32_t)__builtin_ctzll(~(m_pop >> ((st_d + st_k) & 63u)) | (1ull << 63));
-            const uint32_t tail = 2u * st_d + st_k;
+            uint32_t tail = 2u * st_d + st_k;
+            const auto code_at = [&](uint32_t pc) { return (uint32_t)__builtin_amdgcn_readlane((int)my_op.x, (int)(pc & 63u)) & 0xffu; };
+            st_mask = code_at(tail) == OP_MASK;
+            if (st_mask) ++tail;
             straight = st_k >= 1u && st_k <= kStraightOps && pops == st_d && st_d + 1 < (uint32_t)kMaxFoldDepth && n_ops == tail + 2u &&
-                       ((uint32_t)__builtin_amdgcn_readlane((int)my_op.x, (int)(tail & 63u)) & 0xffu) == OP_APPLY &&
-                       ((uint32_t)__builtin_amdgcn_readlane((int)my_op.x, (int)((tail + 1u) & 63u)) & 0xffu) == OP_END;
+                       code_at(tail) == OP_APPLY && code_at(tail + 1u) == OP_END;
         }
     }
     // Every lane of every wave walks the fold, also the lanes past the last node (they fold the last node's operand records onto
@@ -1248,15 +1263,6 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             cx.rec_index = inst_base + node;
             cx.n_nodes = f.n_nodes;
             cx.node = node;
-            cx.pc = 0;
-            cx.pop_w = 0.f;
-            cx.done = false;
-            Acc acc;
-            acc.px = acc.py = acc.pz = acc.sx = acc.sy = acc.sz = 0.f;
-            acc.r = f4{0.f, 0.f, 0.f, 1.f};
-            acc.mask = 0;
-            // (touching all operand records ahead of the fold, so that its loads find them in flight, measured slower:
-            // 19.1 vs 17.7 us on the C3 crowd)
             if (straight) {
                 Acc rec[kStraightOps];
                 float rw[kStraightOps];
@@ -1267,14 +1273,23 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
                     rec[i] = load_rec(cx.anim_pose + ((size_t)(op.x >> 8) * cx.anim_stride + cx.rec_index) * 3);
                     rw[i] = __uint_as_float(op.y);
                 }
+                bool masked = false;
+                if (st_mask) masked = cx.layer_masks[(size_t)(fold_op(cx, 2u * st_d + st_k).x >> 8) * cx.n_nodes + cx.node] != 0;
+                Acc acc = acc_empty();
 #pragma unroll
                 for (uint32_t i = 0; i < kStraightOps; ++i) {
                     if (i >= st_k) break;
                     blend(acc, rec[i], rw[i]);
                 }
+                if (masked) acc.mask = 0;
                 apply_pose(cx, acc);
-            } else
+            } else {
+                cx.pc = 0;
+                cx.pop_w = 0.f;
+                cx.done = false;
+                Acc acc = acc_empty();
                 while (!cx.done) run_fold<0>(cx, acc);  // a stray POP at depth 0 is ignored
+            }
             if (cx.dirty && live) {
                 trs[0] = f4{cx.tpx, cx.tpy, cx.tpz, 0.f};
                 trs[1] = cx.tr;

@@ -121,6 +121,7 @@ struct Planner {
     MachineState* ms;
     int error = 0;       // FYX_ERR_UNSUPPORTED when the fold nests too deep
     int depth = 0;
+    bool touched = false;  // something has been blended into the pose the program is writing at this point (see emit_blend)
 
     Planner(Animator& a, PlanScratch& sc, uint32_t i, float dt_) : A(a), S(sc), inst(i), dt(dt_) {
         n_anims = (uint32_t)a.anims.size();
@@ -391,20 +392,40 @@ struct Planner {
         return found;
     }
 
-    // acc.blend_with(<pose described by recipe r>, w)
+    // acc.blend_with(<pose described by recipe r>, w).  A pose built from several others is evaluated into a pose of its own
+    // (PUSH ... POP_BLEND w) only where that changes the result:
+    //   * nothing has been blended into acc yet: an empty pose becomes a COPY of what is blended into it, weight ignored
+    //     (NodePose::blend_with, pose.rs:41-47; a node the sub-tree leaves empty stays empty either way), so the sub-tree is
+    //     written straight into acc;
+    //   * the sub-tree is one clip: its pose would be a copy of the clip's, so the clip is blended with the outer weight.
+    // `touched` is a property of the program, the same for every node: what the kernel's straight form (anim_kernels.hip,
+    // pose_update_body) relies on is that the common machines come out of here without a single PUSH.
     void emit_blend(uint32_t r, float w) {
         const Recipe rc = S.recipes[r];
-        if (rc.anim >= 0) { emit(OP_BLEND_ANIM, (uint32_t)rc.anim, w); return; }
+        if (rc.anim >= 0) { emit(OP_BLEND_ANIM, (uint32_t)rc.anim, w); touched = true; return; }
         if (rc.count == 0) return;  // blending with an empty pose changes nothing
+        if (!touched) {
+            for (uint32_t i = 0; i < rc.count; ++i) {
+                const RecipeItem it = S.items[rc.first + i];
+                emit_blend(it.recipe, it.w);
+            }
+            return;
+        }
+        if (rc.count == 1 && S.recipes[S.items[rc.first].recipe].anim >= 0) {
+            emit(OP_BLEND_ANIM, (uint32_t)S.recipes[S.items[rc.first].recipe].anim, w);
+            return;
+        }
         if (depth + 1 >= kMaxFoldDepth) { error = FYX_ERR_UNSUPPORTED; return; }
         emit(OP_PUSH, 0, 0.f);
         ++depth;
+        touched = false;
         for (uint32_t i = 0; i < rc.count; ++i) {
             const RecipeItem it = S.items[rc.first + i];
             emit_blend(it.recipe, it.w);
         }
         --depth;
         emit(OP_POP_BLEND, 0, w);
+        touched = true;
     }
 
     void collect(const LayerDef& L, int32_t handle) {  // node/mod.rs:116-150
@@ -554,12 +575,22 @@ struct Planner {
         if (try_reuse()) return;
         S.recipes.clear();
         S.items.clear();
+        touched = false;
         for (size_t li = 0; li < A.layers.size(); ++li) {
-            emit(OP_PUSH, 0, 0.f);
-            depth = 1;
+            // final_pose.blend_with(layer pose, layer.weight) (mod.rs:375-378): while the final pose is empty the layer is
+            // written straight into it (emit_blend: the copy rule -- which is also why the first layer's weight never matters)
+            const bool in_place = !touched;
+            if (!in_place) {
+                emit(OP_PUSH, 0, 0.f);
+                depth = 1;
+                touched = false;
+            }
             plan_layer((uint32_t)li);
-            depth = 0;
-            emit(OP_POP_BLEND, 0, A.layers[li].weight);
+            if (!in_place) {
+                depth = 0;
+                emit(OP_POP_BLEND, 0, A.layers[li].weight);
+                touched = true;
+            }
             if (rm()) rm_emit(RM_BLEND, machine_slot(), layer_slot((uint32_t)li), A.layers[li].weight);  // mod.rs:375-378
         }
         emit(OP_APPLY, 0, 0.f);

@@ -442,8 +442,47 @@ def removed_clips(n_bones=14, seed=synth.SEED_BASE + 18) -> Scenario:
                     removals={9: [1], 30: [3]})
 
 
+def program_forms(n_bones=22, seed=synth.SEED_BASE + 19) -> Scenario:
+    """The forms the host writes a fold program in (Planner::emit_blend) and the update kernel runs it in (straight /
+    interpreter), one after another in one scenario: a first layer that never has a state (the next layer is written
+    straight into the machine's pose), a MASKED second layer whose idle state is one clip and whose walk state is a blend
+    node with a single-clip sub-tree (blended with the outer weight), a two-clip sub-tree (a real PUSH) and a partial
+    first input -- entered and left through transitions (two operands and a MASK: straight) -- and a third layer on top."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, tgts = [], []
+    for c in range(4):
+        td, tgt = synth.make_clip(n_bones, seed, clip=c, euler_every=10 ** 9)
+        if c == 1:
+            td, tgt = _partial(td, tgt, lambda b, t: b % 4 != 1)
+        tds.append(td)
+        tgts.append(tgt)
+    anims = [AnimSpec(0, tgts[0]), AnimSpec(1, tgts[1], speed=1.4), AnimSpec(2, tgts[2], speed=-0.8), AnimSpec(3, tgts[3], speed=0.6)]
+    nothing = A.MachineLayer(nodes=[A.PlayAnimation(3)], states=[], weight=0.9)
+    body = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2), A.PlayAnimation(3),
+               A.BlendAnimations([A.BlendPose(3, 1.0)]),                                      # 4: one clip behind a blend node
+               A.BlendAnimations([A.BlendPose(2, 1.0), A.BlendPose(3, 0.4)]),                 # 5: two clips
+               A.BlendAnimations([A.BlendPose(1, 1.0), A.BlendPose(4, 0.3), A.BlendPose(5, 0.55), A.BlendPose(0, 0.2)])],   # 6
+        states=[A.State(0), A.State(6)],
+        transitions=[A.Transition(0, 1, 0.2, ("parameter", 0)), A.Transition(1, 0, 0.15, ("not", ("parameter", 0)))],
+        weight=0.7, mask=[b for b in range(n_bones) if b % 5 == 2])
+    top = A.MachineLayer(nodes=[A.PlayAnimation(2)], states=[A.State(0)], weight=0.25, mask=[0, 1, 2])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_RULE, False)], layers=[nothing, body, top])
+    script = {6: [(0, A.Parameter(A.PARAM_RULE, True))], 40: [(0, A.Parameter(A.PARAM_RULE, False))]}
+    return Scenario("program_forms", rig, tds, anims, m, script, n_frames=64, has_euler=False)
+
+
+def masked_transitions() -> Scenario:
+    """`transitions` with a layer mask: one or two clips and a MASK -- the update kernel's straight form with its mask."""
+    sc = transitions()
+    sc.machine.layers[0].mask = [1, 4, 5, 11, 23]
+    sc.name = "masked_transitions"
+    return sc
+
+
 ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like, morph_weights,
-       morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player, random_attacks, removed_clips]
+       morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player, random_attacks, removed_clips,
+       program_forms, masked_transitions]
 
 
 def with_root_motion_and_signals(make) -> Callable[[], Scenario]:
