@@ -43,18 +43,28 @@ rep("""    for (uint32_t lv = 0; lv < rig.n_levels; ++lv) {
         const uint32_t b2""", optional=True)     # (the walk of tools/exp/r03_walk16.patch: cycles between the starts of its levels)
 rep("""    f4* gout = reinterpret_cast<f4*>(f.global + inst_base * 16);""", """    STAMP(4);
     f4* gout = reinterpret_cast<f4*>(f.global + inst_base * 16);""")
-rep("""    for (uint32_t p = 0; p < rig.n_pal; ++p) {
+if "    const auto palette_column" in s:
+    rep("""    const auto palette_column""", """    STAMP(5);
+    const auto palette_column""")
+else:
+    rep("""    for (uint32_t p = 0; p < rig.n_pal; ++p) {
         const PaletteOutDev po = rig.pal[p];""", """    STAMP(5);
     for (uint32_t p = 0; p < rig.n_pal; ++p) {
         const PaletteOutDev po = rig.pal[p];""")
-rep("""            out[e] = y;
+tail = """            out[e] = y;
         }
     }
 }
-""", """            out[e] = y;
+""" if """            out[e] = y;
         }
     }
-    STAMP(6);
+}
+""" in s else """            out[e] = palette_column(node, e & 3u, bb);
+        }
+    }
+}
+"""
+rep(tail, tail[:-2] + """    STAMP(6);
     __builtin_amdgcn_s_waitcnt(0);
     STAMP(7);
     stamp[8] = clock64() - cyc0;      // shader-clock cycles between stamps 0 and 7
