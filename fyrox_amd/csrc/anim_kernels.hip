@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDe
 // Same arithmetic, same order: bit-identical to the form above.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kCurveLdsKeys = 128;   // curves up to this many keys are staged in LDS by the crowd sampler (2.5 KB per wave)
+constexpr uint32_t kSpanLdsF4 = 512;      // ... and a track's span records up to this many 16-byte words (8 KB per wave: 64 spans of a Vector3 track)
 
 __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
     // One wave = 64 instances of one (animation, node, BINDING): the position, scale and rotation tracks of a node
@@ -415,8 +416,98 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
         // ~58 cycles per such instruction and CU, five of them per curve, is what this kernel's time was made of).
         // A curve is small (20 B per key), so the wave copies the WHOLE curve into LDS with dense loads instead and
         // gathers from there, where 64 different addresses cost a few cycles.  Longer curves keep the global path.
-        __shared__ float s_loc[kCurveLdsKeys];
-        __shared__ __attribute__((aligned(16))) f4 s_aux[kCurveLdsKeys];
+        // (one LDS area for both stagings: the per-curve path runs after the span records are done with)
+        __shared__ __attribute__((aligned(16))) f4 s_stage[kSpanLdsF4];
+        static_assert(kSpanLdsF4 * 16 >= kCurveLdsKeys * 20, "the per-curve staging fits the span area");
+        f4* s_aux = s_stage;
+        float* s_loc = reinterpret_cast<float*>(s_stage + kCurveLdsKeys);
+        // The track's SPAN RECORDS first (round 3; TrackHot: curves with the same key times -- per span the two locations and both
+        // keys of every curve): staged once per wave instead of once per curve, and Curve::value_at (curve.rs:254-314) decided ONCE
+        // per instance for the three or four curves, on the span locations, in the reference's order -- clamp at the ends, the
+        // hinted span [hint - 1, hint), else partition_point(k.location < time), found without a search when it is the hint
+        // itself or a neighbour (time on the right key; playback crossed a key: at 60 frames a second over 30 keys a second
+        // half the instances do every frame) and by the search otherwise (a loop wrapped around).  Needs every hint of the track
+        // to be the same (they are unless a caller set them apart); otherwise the per-curve path below.
+        bool sampled = false;
+        {
+            const TrackHot th = an.hot[track];
+            const uint32_t stride = need == 4 ? 16u : 8u, n = th.n_keys;
+            const uint32_t n_f4 = n ? (n - 1u) * stride : 0u;
+            if (th.span_first != kNoSpans && n >= 2u && n_f4 <= kSpanLdsF4) {        // wave-uniform
+                const f4* gs = reinterpret_cast<const f4*>(an.spans) + th.span_first;
+                {   // all of a lane's loads go out before its first LDS write: one round trip, not one per 1 KB
+                    f4 t[kSpanLdsF4 / 64];
+#pragma unroll
+                    for (uint32_t k = 0; k < kSpanLdsF4 / 64; ++k) {
+                        const uint32_t i = threadIdx.x + k * 64u;
+                        t[k] = gs[i < n_f4 ? i : 0u];
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < kSpanLdsF4 / 64; ++k) {
+                        const uint32_t i = threadIdx.x + k * 64u;
+                        if (i < n_f4) s_stage[i] = t[k];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const __attribute__((address_space(3))) f4* sp = (const __attribute__((address_space(3))) f4*)s_stage;
+                const uint32_t h = h0[0];
+                const bool one_hint = h0[1] == h && h0[2] == h && (need < 4 || h0[3] == h);
+                if (active && one_hint) {
+                    const CurveEnds e0 = curve_ends(tk, 0);
+                    uint32_t new_hint = h;
+                    if (time <= e0.l_first) {
+                        new_hint = 0u;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (c < need) val[c] = curve_ends(tk, c).v_first;
+                    } else if (time >= e0.l_last) {
+                        new_hint = n - 1u;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (c < need) val[c] = curve_ends(tk, c).v_last;
+                    } else {
+                        // right key of the span that holds the time: key `hint` if the hinted span holds it, else the first key at
+                        // or after the time
+                        uint32_t right = 0u;                        // 0: not found yet (the first key lies before the time)
+                        f4 locs = f4{0.f, 0.f, 0.f, 0.f};
+                        if (h >= 1u && h < n) {
+                            locs = sp[(size_t)(h - 1u) * stride];
+                            // (time on the right key: the hinted test fails and the search returns hint -- unless the left key
+                            // has the same location, then it returns an earlier key: duplicates go to the search)
+                            if (time >= locs.x && time <= locs.y && locs.x < locs.y) right = h;
+                            else if (time > locs.y && h + 1u < n) {
+                                locs = sp[(size_t)h * stride];
+                                if (time <= locs.y) right = h + 1u;               // (time > its left key: that is the hinted span's right key)
+                            } else if (time < locs.x && h >= 2u) {
+                                locs = sp[(size_t)(h - 2u) * stride];
+                                if (time > locs.x) right = h - 1u;                // (time < its right key)
+                            }
+                        }
+                        if (!right) {                                // partition_point(k.location < time) over the keys
+                            uint32_t lo = 0u, hi = n;
+                            while (lo < hi) {
+                                const uint32_t mid = lo + (hi - lo) / 2u;
+                                const float l_mid = mid + 1u < n ? sp[(size_t)mid * stride].x : sp[(size_t)(n - 2u) * stride].y;
+                                if (l_mid < time) lo = mid + 1u; else hi = mid;
+                            }
+                            right = lo;                              // 1 <= lo <= n - 1: first < time < last
+                            locs = sp[(size_t)(right - 1u) * stride];
+                        }
+                        new_hint = right;
+                        const __attribute__((address_space(3))) f4* r = sp + (size_t)(right - 1u) * stride;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < need) val[c] = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+                    }
+                    if (new_hint != h) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < need) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = new_hint;
+                    }
+                    sampled = true;
+                }
+            }
+        }
+        const bool general = active && !sampled;      // everything else, decided in the reference's order on the per-curve records
+        if (__any(general)) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c >= need) break;
@@ -428,13 +519,14 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
                 __builtin_amdgcn_wave_barrier();                // every lane is done with the previous curve
                 for (uint32_t i = threadIdx.x; i < nk; i += 64u) { s_loc[i] = gl[i]; s_aux[i] = ga[i]; }
                 __builtin_amdgcn_wave_barrier();
-                if (active)
+                if (general)
                     val[c] = curve_value_at<false>((const __attribute__((address_space(3))) float*)s_loc,
                                                    (const __attribute__((address_space(3))) f4*)s_aux, nk, curve_ends(tk, c), time, hint);
-            } else if (active) {
+            } else if (general) {
                 val[c] = curve_value_at<false>(gl, ga, nk, curve_ends(tk, c), time, hint);
             }
-            if (active && hint != h0[c]) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = hint;
+            if (general && hint != h0[c]) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = hint;
+        }
         }
     }
     if (!active) return;

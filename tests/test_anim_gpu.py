@@ -390,9 +390,11 @@ def test_key_kinds_sample_bit_exact(ctx, orc, kind):
     p.free()
 
 
-def test_sampling_hints_with_duplicate_key_locations(ctx, orc):
+@pytest.mark.parametrize("form", [1, 2], ids=["curves_on_lanes", "instances_on_lanes"])
+def test_sampling_hints_with_duplicate_key_locations(ctx, orc, form):
     """Duplicate key locations make Curve::value_at depend on the span hint carried between frames
-    (curve.rs:254-314): the device keeps one hint per (instance, animation, track, curve)."""
+    (curve.rs:254-314): the device keeps one hint per (instance, animation, track, curve).  Both forms of the sampler."""
+    ctx.set_option("anim.sample_form", form)
     rig = synth.make_rig(4, 77)
     keys = [A.CurveKey(0.0, 0.0), A.CurveKey(0.25, 1.0), A.CurveKey(0.25, 5.0), A.CurveKey(0.5, 2.0),
             A.CurveKey(0.5, -3.0, A.KEY_CONSTANT), A.CurveKey(0.75, 4.0, A.KEY_CUBIC, 0.5, -0.25), A.CurveKey(1.0, 0.5)]
@@ -412,9 +414,11 @@ def test_sampling_hints_with_duplicate_key_locations(ctx, orc):
     p.free()
 
 
-def test_span_records_take_every_exit(ctx, orc):
+@pytest.mark.parametrize("form", [1, 2], ids=["curves_on_lanes", "instances_on_lanes"])
+def test_span_records_take_every_exit(ctx, orc, form):
     """The sampler's span records (TrackHot, round 3): tracks whose curves share their key times are sampled from one record per
-    span -- inside the hinted span, the next or the previous one -- and fall back to the per-curve records for everything else.
+    span -- inside the hinted span, the next or the previous one -- and fall back to the per-curve records for everything else
+    (the form with the curves on the lanes), or decide all of Curve::value_at on the span locations (the crowd form).
     One clip holds a Vector3 track and a quaternion track with common key times (128- and 256-byte records), a Vector3 track whose
     curves have DIFFERENT key times (no records) and one with a single key; key locations are multiples of 1/32 and dt = 1/64, so
     every second frame lands exactly on a key, the ends clamp, and the speed changes below make the hint miss by one span, by
@@ -435,6 +439,7 @@ def test_span_records_take_every_exit(ctx, orc):
     tracks.append(A.Track(A.BIND_POSITION, A.KIND_VEC3, [curve(locs[:1]), curve(locs[:1]), curve(locs[:1])])); target.append(2)   # one key
     tracks.append(A.Track(A.BIND_ROTATION, A.KIND_QUAT, [curve(locs[3:9])] * 4)); target.append(3)               # keys only in the middle: clamps
     td = A.AnimationTracksData(tracks)
+    ctx.set_option("anim.sample_form", form)
     sc = cases.Scenario("span_records", rig, [td], [cases.AnimSpec(0, np.asarray(target, np.int32), speed=1.0)], None,
                         n_frames=70, dt=1.0 / 64.0, has_euler=False)
     o, p = run_scenario(ctx, orc, sc)
