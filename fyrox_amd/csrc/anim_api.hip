@@ -165,6 +165,7 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
                 }
             }
         }
+        td.hot = hot;
         int rc = upload(c, &td.d_tracks, hd.data(), hd.size());
         if (!rc) rc = upload(c, &td.d_hot, hot.data(), hot.size());
         if (!rc && !spans.empty()) rc = upload(c, &td.d_spans, spans.data(), spans.size());

@@ -97,6 +97,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
                 if (!an.d_slot_track)
                     FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_slot_track), std::max<size_t>(slots.size() * 4, 16)));
                 FYX_HIP(c, hipMemcpy(an.d_slot_track, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+                an.slots = std::move(slots);
                 an.slots_dirty = false;
             }
             hd[a].tracks = an.td->d_tracks;
@@ -117,6 +118,36 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         dfree(A.d_anims);
         A.d_anims = nullptr;
         if (int rc = upload(c, &A.d_anims, hd.data(), hd.size())) return rc;
+        // the crowd sampler's descriptors: what pose_sample_crowd_body reads off slot table, track record and TrackHot, resolved
+        std::vector<CrowdDesc> cd((size_t)na * rig.n_nodes * 3);
+        for (uint32_t a = 0; a < na; ++a) {
+            const AnimationDef& an = A.anims[a];
+            for (uint32_t node = 0; node < rig.n_nodes; ++node) {
+                CrowdDesc* d = &cd[((size_t)a * rig.n_nodes + node) * 3];
+                uint32_t present = 0;
+                for (int b = 0; b < 3; ++b) {
+                    d[b] = CrowdDesc{nullptr, 0u, 0u, 0u, -1, 0u, 0u};
+                    const int32_t t = an.slots.size() == (size_t)rig.n_nodes * 4 ? an.slots[(size_t)node * 4 + b] : -1;
+                    if (t < 0 || (size_t)t >= an.td->hot.size()) continue;
+                    const TrackHot& th = an.td->hot[t];
+                    const uint32_t need = th.kind == FYX_KIND_QUAT ? 4u : (th.kind == FYX_KIND_VEC3 || th.kind == FYX_KIND_QUAT_EULER) ? 3u : 0u;
+                    const bool fits = b == FYX_BIND_ROTATION ? (th.kind == FYX_KIND_QUAT || th.kind == FYX_KIND_QUAT_EULER) : th.kind == FYX_KIND_VEC3;
+                    d[b].track = (uint32_t)t;
+                    d[b].kind = th.kind;
+                    d[b].need = need;
+                    d[b].valid = fits && need > 0 && th.n_curves >= need;
+                    d[b].n_keys = th.n_keys;
+                    if (d[b].valid && th.span_first != kNoSpans && an.td->d_spans) d[b].spans = an.td->d_spans + th.span_first;
+                    if (d[b].valid) present |= b == FYX_BIND_POSITION ? 1u : b == FYX_BIND_SCALE ? 2u : 4u;
+                }
+                if (an.slots.size() == (size_t)rig.n_nodes * 4 && an.slots[(size_t)node * 4 + 3] >= 0) present |= 8u;
+                for (int b = 0; b < 3; ++b) d[b].present = present;
+            }
+        }
+        dfree(A.d_crowd);
+        A.d_crowd = nullptr;
+        if (!cd.empty())
+            if (int rc = upload(c, &A.d_crowd, cd.data(), cd.size())) return rc;
         A.anims_dirty = false;
     }
     const uint32_t nps = (uint32_t)A.prop_slots.size();
@@ -239,6 +270,7 @@ RigDev rig_dev(const Rig& r) {
 void frame_static(const fyx_ctx* c, const Animator& A, PoseFrameDev& f) {
     memset(&f, 0, sizeof f);
     f.anims = A.d_anims;
+    f.crowd = A.d_crowd;
     f.n_anims = (uint32_t)A.anims.size();
     f.n_instances = A.n_instances;
     f.n_nodes = A.rig->n_nodes;

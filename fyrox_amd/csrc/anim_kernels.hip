@@ -370,177 +370,215 @@ __global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDe
 constexpr uint32_t kCurveLdsKeys = 128;   // curves up to this many keys are staged in LDS by the crowd sampler (2.5 KB per wave)
 constexpr uint32_t kSpanLdsF4 = 512;      // ... and a track's span records up to this many 16-byte words (8 KB per wave: 64 spans of a Vector3 track)
 
+// Curve::value_at (curve.rs:254-314) for the three or four curves of ONE track at once, on the track's span records staged in
+// LDS (`sp`; n keys, `stride` f4 per span): the curves share their key times, so the decisions -- clamp at the ends, the hinted
+// span [hint - 1, hint), else partition_point(k.location < time) -- are taken once, in the reference's order, and every curve's
+// hint becomes the same value.  The search result is found without searching when it is the hint itself (time on the right key)
+// or a neighbour (playback crossed a key: at 60 frames a second over 30 keys a second half the instances do every frame).
+// Returns the new hint.
+__device__ __forceinline__ uint32_t span_track_value_at(const __attribute__((address_space(3))) f4* sp, uint32_t n, uint32_t stride, int need,
+                                                        float time, uint32_t h, float (&val)[4]) {
+    const __attribute__((address_space(3))) f4* last = sp + (size_t)(n - 2u) * stride;
+    const float l_first = sp[0].x, l_last = last[0].y;
+    if (time <= l_first) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < need) val[c] = sp[1 + 2 * c].x;          // first key's value
+        return 0u;
+    }
+    if (time >= l_last) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < need) val[c] = last[2 + 2 * c].x;        // last key's value
+        return n - 1u;
+    }
+    // right key of the span that holds the time: key `hint` if the hinted span holds it, else the first key at or after the time
+    uint32_t right = 0u;                        // 0: not found yet (the first key lies before the time)
+    f4 locs = f4{0.f, 0.f, 0.f, 0.f};
+    if (h >= 1u && h < n) {
+        locs = sp[(size_t)(h - 1u) * stride];
+        // (time on the right key: the hinted test fails and the search returns hint -- unless the left key has the same
+        // location, then it returns an earlier key: duplicates go to the search)
+        if (time >= locs.x && time <= locs.y && locs.x < locs.y) right = h;
+        else if (time > locs.y && h + 1u < n) {
+            locs = sp[(size_t)h * stride];
+            if (time <= locs.y) right = h + 1u;               // (time > its left key: that is the hinted span's right key)
+        } else if (time < locs.x && h >= 2u) {
+            locs = sp[(size_t)(h - 2u) * stride];
+            if (time > locs.x) right = h - 1u;                // (time < its right key)
+        }
+    }
+    if (!right) {                                // partition_point(k.location < time) over the keys
+        uint32_t lo = 0u, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            const float l_mid = mid + 1u < n ? sp[(size_t)mid * stride].x : l_last;
+            if (l_mid < time) lo = mid + 1u; else hi = mid;
+        }
+        right = lo;                              // 1 <= lo <= n - 1: first < time < last
+        locs = sp[(size_t)(right - 1u) * stride];
+    }
+    const __attribute__((address_space(3))) f4* r = sp + (size_t)(right - 1u) * stride;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < need) val[c] = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+    return right;
+}
+
+// BLOCK: 64, or 256 = four waves (256 instances) of the same (animation, node, binding) that stage the track's span records
+// TOGETHER: a quarter of the staging loads and of the LDS per wave (8 KB per wave let 20 waves onto a CU; the kernel is made of
+// memory latency, and what hides it is waves).
+template <uint32_t BLOCK>
 __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
     // One wave = 64 instances of one (animation, node, BINDING): the position, scale and rotation tracks of a node
     // are sampled by three different waves, so a thread walks at most four curves (the chain of dependent loads
     // is what bounds this kernel) and the three 16-byte parts of the pose record have one writer each.
-    const uint32_t inst = bx * 64u + threadIdx.x, a = bz;
+    const uint32_t inst = bx * BLOCK + threadIdx.x, a = bz;
     const uint32_t node = by / 3u;
     const int bind = (int)(by - node * 3u);           // FYX_BIND_POSITION, _SCALE, _ROTATION
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // a lane without work (past the crowd, or an animation that did not tick for its instance) still helps to stage
     // the curves below
     const bool active = inst < f.n_instances && (f.ticked[(size_t)(inst < f.n_instances ? inst : 0) * f.n_anims + a] & 1u);
-    if (!__any(active)) return;
-    const float time = active ? f.times[(size_t)inst * f.n_anims + a] : 0.0f;
-    const AnimDev an = f.anims[a];
-    const int32_t* st = an.slot_track + (size_t)node * 4;     // wave-uniform: scalar loads
-    // which bindings the animation provides for this node (all three: the position wave writes the present bits)
-    bool valid[3];
-    int kinds[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        valid[b] = false;
-        kinds[b] = -1;
-        if (st[b] < 0) continue;
-        const TrackDev* tk = an.tracks + st[b];
-        const int kind = tk->kind;
-        const int need = kind == FYX_KIND_QUAT ? 4 : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3 : 0;
-        const bool fits = (b == FYX_BIND_ROTATION) ? (kind == FYX_KIND_QUAT || kind == FYX_KIND_QUAT_EULER)
-                                                   : (kind == FYX_KIND_VEC3);
-        valid[b] = fits && need > 0 && (int)tk->n_curves >= need;   // else fetch() -> None
-        kinds[b] = kind;
+    if constexpr (BLOCK == 64) {
+        if (!__any(active)) return;
     }
+    const float time = active ? f.times[(size_t)inst * f.n_anims + a] : 0.0f;
+    // span records of the track: one area for the workgroup; per-curve staging: one per wave (a lone wave uses the span area for
+    // both: its per-curve path runs after the span records are done with)
+    __shared__ __attribute__((aligned(16))) f4 s_stage[kSpanLdsF4];
+    static_assert(kSpanLdsF4 * 16 >= kCurveLdsKeys * 20, "the per-curve staging fits the span area");
+    constexpr uint32_t kCurveF4 = (kCurveLdsKeys * 20 + 15) / 16;
+    __shared__ __attribute__((aligned(16))) f4 s_curves[BLOCK == 64 ? 1 : (BLOCK / 64) * kCurveF4];
+    f4* s_own = BLOCK == 64 ? s_stage : s_curves + wave * kCurveF4;
     float val[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (valid[bind]) {
-        // (fetching the hints and keys of all four curves up front was measured slower: 44 vs 37 us on C3)
-        const int32_t track = st[bind];
-        const TrackDev* tk = an.tracks + track;
-        const int need = kinds[bind] == FYX_KIND_QUAT ? 4 : 3;
-        // the hints of the track's curves are independent of each other: one round trip for all of them
-        uint32_t h0[4] = {0u, 0u, 0u, 0u};
+    // what the final store needs to know about the node: its present bits, and for the rotation wave whether / how it is keyed
+    uint32_t present = 0;
+    bool rot_valid = false;
+    int rot_kind = -1;
+    bool sampled = false;                              // this lane's values are in val[]
+    bool described = false;                            // (wave-uniform) present / rot_valid / rot_kind are known
+
+    // The track's SPAN RECORDS first (round 3; TrackHot: curves with the same key times -- per span the two locations and both
+    // keys of every curve), found through the animator's descriptor of this (animation, node, binding) in ONE scalar load and
+    // staged once per wave in one round trip; Curve::value_at is then decided once per instance for the three or four curves
+    // (span_track_value_at).  Needs every hint of the track to be the same (they are unless a caller set them apart); what is
+    // left -- those lanes, tracks without span records, records that do not fit the staging area -- takes the per-curve path below.
+    if (f.crowd) {
+        const CrowdDesc d = f.crowd[((size_t)a * f.n_nodes + node) * 3 + (uint32_t)bind];      // wave-uniform: scalar loads
+        present = d.present;
+        rot_valid = bind == FYX_BIND_ROTATION && d.valid;
+        rot_kind = d.kind;
+        described = true;
+        if (!d.valid) {
+            sampled = true;                            // fetch() -> None: nothing to sample, the record's part is zeros
+        } else {
+            const uint32_t stride = d.need == 4u ? 16u : 8u, n = d.n_keys;
+            const uint32_t n_f4 = n >= 2u ? (n - 1u) * stride : 0u;
+            if (d.spans && n_f4 && n_f4 <= kSpanLdsF4) {
+                uint32_t h0[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < need && active) h0[c] = *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
-        // The 64 instances of the wave sit at 64 different playback positions, so a key load from global memory is a
-        // gather of 64 different addresses -- and the texture addresser takes about a cycle per address (measured:
-        // ~58 cycles per such instruction and CU, five of them per curve, is what this kernel's time was made of).
-        // A curve is small (20 B per key), so the wave copies the WHOLE curve into LDS with dense loads instead and
-        // gathers from there, where 64 different addresses cost a few cycles.  Longer curves keep the global path.
-        // (one LDS area for both stagings: the per-curve path runs after the span records are done with)
-        __shared__ __attribute__((aligned(16))) f4 s_stage[kSpanLdsF4];
-        static_assert(kSpanLdsF4 * 16 >= kCurveLdsKeys * 20, "the per-curve staging fits the span area");
-        f4* s_aux = s_stage;
-        float* s_loc = reinterpret_cast<float*>(s_stage + kCurveLdsKeys);
-        // The track's SPAN RECORDS first (round 3; TrackHot: curves with the same key times -- per span the two locations and both
-        // keys of every curve): staged once per wave instead of once per curve, and Curve::value_at (curve.rs:254-314) decided ONCE
-        // per instance for the three or four curves, on the span locations, in the reference's order -- clamp at the ends, the
-        // hinted span [hint - 1, hint), else partition_point(k.location < time), found without a search when it is the hint
-        // itself or a neighbour (time on the right key; playback crossed a key: at 60 frames a second over 30 keys a second
-        // half the instances do every frame) and by the search otherwise (a loop wrapped around).  Needs every hint of the track
-        // to be the same (they are unless a caller set them apart); otherwise the per-curve path below.
-        bool sampled = false;
-        {
-            const TrackHot th = an.hot[track];
-            const uint32_t stride = need == 4 ? 16u : 8u, n = th.n_keys;
-            const uint32_t n_f4 = n ? (n - 1u) * stride : 0u;
-            if (th.span_first != kNoSpans && n >= 2u && n_f4 <= kSpanLdsF4) {        // wave-uniform
-                const f4* gs = reinterpret_cast<const f4*>(an.spans) + th.span_first;
+                for (int c = 0; c < 4; ++c)
+                    if (c < (int)d.need && active) h0[c] = *hint_ptr(f, a, d.track, (uint32_t)c, inst);
                 {   // all of a lane's loads go out before its first LDS write: one round trip, not one per 1 KB
-                    f4 t[kSpanLdsF4 / 64];
+                    const f4* gs = reinterpret_cast<const f4*>(d.spans);
+                    f4 t[kSpanLdsF4 / BLOCK];
 #pragma unroll
-                    for (uint32_t k = 0; k < kSpanLdsF4 / 64; ++k) {
-                        const uint32_t i = threadIdx.x + k * 64u;
+                    for (uint32_t k = 0; k < kSpanLdsF4 / BLOCK; ++k) {
+                        const uint32_t i = threadIdx.x + k * BLOCK;
                         t[k] = gs[i < n_f4 ? i : 0u];
                     }
 #pragma unroll
-                    for (uint32_t k = 0; k < kSpanLdsF4 / 64; ++k) {
-                        const uint32_t i = threadIdx.x + k * 64u;
+                    for (uint32_t k = 0; k < kSpanLdsF4 / BLOCK; ++k) {
+                        const uint32_t i = threadIdx.x + k * BLOCK;
                         if (i < n_f4) s_stage[i] = t[k];
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                const __attribute__((address_space(3))) f4* sp = (const __attribute__((address_space(3))) f4*)s_stage;
+                if constexpr (BLOCK == 64) __builtin_amdgcn_wave_barrier();
+                else __syncthreads();                 // (d is the same for the whole workgroup: every wave gets here)
                 const uint32_t h = h0[0];
-                const bool one_hint = h0[1] == h && h0[2] == h && (need < 4 || h0[3] == h);
+                const bool one_hint = h0[1] == h && h0[2] == h && (d.need < 4u || h0[3] == h);
                 if (active && one_hint) {
-                    const CurveEnds e0 = curve_ends(tk, 0);
-                    uint32_t new_hint = h;
-                    if (time <= e0.l_first) {
-                        new_hint = 0u;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) if (c < need) val[c] = curve_ends(tk, c).v_first;
-                    } else if (time >= e0.l_last) {
-                        new_hint = n - 1u;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) if (c < need) val[c] = curve_ends(tk, c).v_last;
-                    } else {
-                        // right key of the span that holds the time: key `hint` if the hinted span holds it, else the first key at
-                        // or after the time
-                        uint32_t right = 0u;                        // 0: not found yet (the first key lies before the time)
-                        f4 locs = f4{0.f, 0.f, 0.f, 0.f};
-                        if (h >= 1u && h < n) {
-                            locs = sp[(size_t)(h - 1u) * stride];
-                            // (time on the right key: the hinted test fails and the search returns hint -- unless the left key
-                            // has the same location, then it returns an earlier key: duplicates go to the search)
-                            if (time >= locs.x && time <= locs.y && locs.x < locs.y) right = h;
-                            else if (time > locs.y && h + 1u < n) {
-                                locs = sp[(size_t)h * stride];
-                                if (time <= locs.y) right = h + 1u;               // (time > its left key: that is the hinted span's right key)
-                            } else if (time < locs.x && h >= 2u) {
-                                locs = sp[(size_t)(h - 2u) * stride];
-                                if (time > locs.x) right = h - 1u;                // (time < its right key)
-                            }
-                        }
-                        if (!right) {                                // partition_point(k.location < time) over the keys
-                            uint32_t lo = 0u, hi = n;
-                            while (lo < hi) {
-                                const uint32_t mid = lo + (hi - lo) / 2u;
-                                const float l_mid = mid + 1u < n ? sp[(size_t)mid * stride].x : sp[(size_t)(n - 2u) * stride].y;
-                                if (l_mid < time) lo = mid + 1u; else hi = mid;
-                            }
-                            right = lo;                              // 1 <= lo <= n - 1: first < time < last
-                            locs = sp[(size_t)(right - 1u) * stride];
-                        }
-                        new_hint = right;
-                        const __attribute__((address_space(3))) f4* r = sp + (size_t)(right - 1u) * stride;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (c < need) val[c] = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
-                    }
+                    const uint32_t new_hint = span_track_value_at((const __attribute__((address_space(3))) f4*)s_stage, n, stride, (int)d.need, time, h, val);
                     if (new_hint != h) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
-                            if (c < need) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = new_hint;
+                            if (c < (int)d.need) *hint_ptr(f, a, d.track, (uint32_t)c, inst) = new_hint;
                     }
                     sampled = true;
                 }
             }
         }
-        const bool general = active && !sampled;      // everything else, decided in the reference's order on the per-curve records
-        if (__any(general)) {
+    }
+    const bool general = active && !sampled;          // everything else, decided in the reference's order on the per-curve records
+    if (!described || __any(general)) {
+        const AnimDev an = f.anims[a];
+        const int32_t* st = an.slot_track + (size_t)node * 4;     // wave-uniform: scalar loads
+        // which bindings the animation provides for this node (all three: the position wave writes the present bits)
+        bool valid[3];
+        int kinds[3];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c >= need) break;
-            uint32_t hint = h0[c];
-            const uint32_t fk = tk->first_key[c], nk = tk->n_keys[c];
-            const float* gl = an.key_loc + fk;
-            const f4* ga = reinterpret_cast<const f4*>(an.key_aux) + fk;
-            if (nk <= kCurveLdsKeys) {   // wave-uniform
-                __builtin_amdgcn_wave_barrier();                // every lane is done with the previous curve
-                for (uint32_t i = threadIdx.x; i < nk; i += 64u) { s_loc[i] = gl[i]; s_aux[i] = ga[i]; }
-                __builtin_amdgcn_wave_barrier();
-                if (general)
-                    val[c] = curve_value_at<false>((const __attribute__((address_space(3))) float*)s_loc,
-                                                   (const __attribute__((address_space(3))) f4*)s_aux, nk, curve_ends(tk, c), time, hint);
-            } else if (general) {
-                val[c] = curve_value_at<false>(gl, ga, nk, curve_ends(tk, c), time, hint);
-            }
-            if (general && hint != h0[c]) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = hint;
+        for (int b = 0; b < 3; ++b) {
+            valid[b] = false;
+            kinds[b] = -1;
+            if (st[b] < 0) continue;
+            const TrackDev* tk = an.tracks + st[b];
+            const int kind = tk->kind;
+            const int need = kind == FYX_KIND_QUAT ? 4 : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3 : 0;
+            const bool fits = (b == FYX_BIND_ROTATION) ? (kind == FYX_KIND_QUAT || kind == FYX_KIND_QUAT_EULER)
+                                                       : (kind == FYX_KIND_VEC3);
+            valid[b] = fits && need > 0 && (int)tk->n_curves >= need;   // else fetch() -> None
+            kinds[b] = kind;
         }
+        present = (valid[FYX_BIND_POSITION] ? 1u : 0u) | (valid[FYX_BIND_SCALE] ? 2u : 0u) | (valid[FYX_BIND_ROTATION] ? 4u : 0u) | (st[3] >= 0 ? 8u : 0u);
+        rot_valid = bind == FYX_BIND_ROTATION && valid[FYX_BIND_ROTATION];
+        rot_kind = kinds[FYX_BIND_ROTATION];
+        if (valid[bind]) {
+            // (fetching the hints and keys of all four curves up front was measured slower: 44 vs 37 us on C3)
+            const int32_t track = st[bind];
+            const TrackDev* tk = an.tracks + track;
+            const int need = kinds[bind] == FYX_KIND_QUAT ? 4 : 3;
+            // the hints of the track's curves are independent of each other: one round trip for all of them
+            uint32_t h0[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < need && general) h0[c] = *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
+            // The 64 instances of the wave sit at 64 different playback positions, so a key load from global memory is a
+            // gather of 64 different addresses -- and the texture addresser takes about a cycle per address (measured:
+            // ~58 cycles per such instruction and CU, five of them per curve, is what this kernel's time was made of).
+            // A curve is small (20 B per key), so the wave copies the WHOLE curve into LDS with dense loads instead and
+            // gathers from there, where 64 different addresses cost a few cycles.  Longer curves keep the global path.
+            f4* s_aux = s_own;
+            float* s_loc = reinterpret_cast<float*>(s_own + kCurveLdsKeys);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= need) break;
+                uint32_t hint = h0[c];
+                const uint32_t fk = tk->first_key[c], nk = tk->n_keys[c];
+                const float* gl = an.key_loc + fk;
+                const f4* ga = reinterpret_cast<const f4*>(an.key_aux) + fk;
+                if (nk <= kCurveLdsKeys) {   // wave-uniform
+                    __builtin_amdgcn_wave_barrier();                // every lane is done with the previous curve
+                    for (uint32_t i = lane; i < nk; i += 64u) { s_loc[i] = gl[i]; s_aux[i] = ga[i]; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (general)
+                        val[c] = curve_value_at<false>((const __attribute__((address_space(3))) float*)s_loc,
+                                                       (const __attribute__((address_space(3))) f4*)s_aux, nk, curve_ends(tk, c), time, hint);
+                } else if (general) {
+                    val[c] = curve_value_at<false>(gl, ga, nk, curve_ends(tk, c), time, hint);
+                }
+                if (general && hint != h0[c]) *hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst) = hint;
+            }
         }
     }
     if (!active) return;
     f4* rec = reinterpret_cast<f4*>(f.anim_pose) + (((size_t)a * f.n_instances + inst) * f.n_nodes + node) * 3;
     if (bind == FYX_BIND_POSITION) {
-        const uint32_t bits = (valid[FYX_BIND_POSITION] ? 1u : 0u) | (valid[FYX_BIND_SCALE] ? 2u : 0u) |
-                              (valid[FYX_BIND_ROTATION] ? 4u : 0u) | (st[3] >= 0 ? 8u : 0u);
-        rec[0] = f4{val[0], val[1], val[2], __uint_as_float(bits)};
+        rec[0] = f4{val[0], val[1], val[2], __uint_as_float(present)};
     } else if (bind == FYX_BIND_SCALE) {
         rec[2] = f4{val[0], val[1], val[2], 0.0f};
     } else {
         f4 q = f4{0.f, 0.f, 0.f, 1.f};
-        if (valid[FYX_BIND_ROTATION]) {
-            if (kinds[FYX_BIND_ROTATION] == FYX_KIND_QUAT) {
+        if (rot_valid) {
+            if (rot_kind == FYX_KIND_QUAT) {
                 q = quat_normalize(f4{val[0], val[1], val[2], val[3]});
             } else {   // (axis * sin(angle/2), cos(angle/2)) per axis, then qz * qy * qx (fyrox-math/src/lib.rs:725-740)
                 float sx, cx, sy, cy, sz, cz;
@@ -557,19 +595,23 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
     }
 }
 
-__global__ __launch_bounds__(64) void pose_sample_crowd_kernel(PoseFrameDev f, CtrlInline inl) { pose_sample_crowd_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y, blockIdx.z); }
+template <uint32_t BLOCK>
+__global__ __launch_bounds__(BLOCK) void pose_sample_crowd_kernel(PoseFrameDev f, CtrlInline inl) { pose_sample_crowd_body<BLOCK>(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y, blockIdx.z); }
 
 __global__ __launch_bounds__(64) void pose_sample_crowd_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
     const PoseFrameDev f = jobs[b.x].f;
-    pose_sample_crowd_body(f, b.y, b.z, b.w);
+    pose_sample_crowd_body<64>(f, b.y, b.z, b.w);
 }
 
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl) {
     if (f.n_anims == 0 || f.n_instances == 0 || f.n_nodes == 0) return hipSuccess;
     if (f.n_instances > 65535u || f.n_anims > 65535u || f.n_nodes * 3u > 65535u) return hipErrorInvalidValue;   // grid limits
     if (f.sample_form == 2 || (f.sample_form == 0 && f.n_instances >= 32)) {
-        hipLaunchKernelGGL(pose_sample_crowd_kernel, dim3((f.n_instances + 63) / 64, f.n_nodes * 3, f.n_anims), dim3(64), 0, s, f, inl ? *inl : kNoInline);
+        if (f.n_instances > 64u)
+            hipLaunchKernelGGL(pose_sample_crowd_kernel<256>, dim3((f.n_instances + 255) / 256, f.n_nodes * 3, f.n_anims), dim3(256), 0, s, f, inl ? *inl : kNoInline);
+        else
+            hipLaunchKernelGGL(pose_sample_crowd_kernel<64>, dim3(1, f.n_nodes * 3, f.n_anims), dim3(64), 0, s, f, inl ? *inl : kNoInline);
     } else {
         hipLaunchKernelGGL(pose_sample_kernel, dim3((f.n_nodes * 16 + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f, inl ? *inl : kNoInline);
     }

@@ -15,6 +15,8 @@ struct TracksData {
     KeyRec* d_rec = nullptr;
     TrackHot* d_hot = nullptr;
     float4* d_spans = nullptr;
+    std::vector<TrackHot> hot;     // host copy of d_hot (the animators' crowd descriptors are made from it)
+    std::vector<uint32_t> n_keys0; // keys of every track's first curve
 };
 
 struct Rig {
@@ -42,6 +44,7 @@ struct AnimationDef {
     std::vector<int32_t> target;   // per track, <0: no TrackBinding
     std::vector<uint8_t> enabled;  // TrackBinding::enabled
     int32_t* d_slot_track = nullptr;
+    std::vector<int32_t> slots;    // host copy of d_slot_track
     int32_t* d_prop_track = nullptr;   // [animator's property slots]
     uint32_t dev_prop_slots = 0;
     bool slots_dirty = true;
@@ -160,6 +163,7 @@ struct Animator {
     uint32_t max_tracks = 0;
     // device state
     AnimDev* d_anims = nullptr;
+    CrowdDesc* d_crowd = nullptr;   // [anims][nodes][3]
     bool anims_dirty = true;
     uint32_t* d_hints = nullptr;
     float4* d_anim_pose = nullptr;

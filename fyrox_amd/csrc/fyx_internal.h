@@ -190,6 +190,20 @@ struct TrackHot {
 static_assert(sizeof(TrackHot) == 16, "eight tracks per cache line");
 constexpr uint32_t kNoSpans = 0xffffffffu;
 
+// What the crowd sampler needs to know about one (animation, node, binding) of an animator, in ONE scalar load: without it a wave
+// finds its track through the animation's record, the node's slot table, the track's record and its TrackHot -- a chain of four
+// dependent loads ahead of the first byte of key data, in a kernel that is made of such latency.
+struct CrowdDesc {
+    const float4* spans;     // the track's span records (TrackHot::span_first resolved); null: none, the general path samples it
+    uint32_t track;          // index into the tracks data (the span hints are kept per track)
+    uint32_t n_keys;         // keys per curve
+    uint32_t need;           // curves the value is made of: 3 or 4
+    int32_t kind;            // FYX_KIND_*
+    uint32_t valid;          // the animation provides this binding for the node (TrackDataContainer::fetch gives Some)
+    uint32_t present;        // the node's present bits in this animation: 1 Position, 2 Scale, 4 Rotation, 8 a Property value
+};
+static_assert(sizeof(CrowdDesc) == 32, "one s_load_dwordx8");
+
 // One animation of an animator (shared by all its instances).
 struct AnimDev {
     const TrackDev* tracks;
@@ -311,6 +325,7 @@ struct PoseFrameDev {
     uint32_t n_rm_slots;
     const uint4* rm_ops;         // all instances' root-motion programs
     const uint32_t* rm_prog_off; // [n_instances + 1]
+    const CrowdDesc* crowd;      // [n_anims][n_nodes][3 bindings] (Position, Scale, Rotation): the crowd sampler's descriptors
 };
 
 // A small per-frame control block rides INSIDE the kernel arguments of the single-animator launches (one character: a few

@@ -103,7 +103,7 @@ def test_register_budgets_behind_the_measured_occupancies():
     res = isa_stats.kernel_resources(LIB)
     budget = {"fyx::lbs_skin_dyn<true, 7>": 128, "fyx::lbs_skin<true, 7>": 128,
               "fyx::lbs_skin_batch<true, 7>": 128, "fyx::lbs_skin_crowd<512, true, 7, false>": 128,
-              "fyx::lbs_skin_crowd<512, true, 7, true>": 80, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel": 64}
+              "fyx::lbs_skin_crowd<512, true, 7, true>": 80, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel<256u>": 64, "fyx::pose_sample_crowd_kernel<64u>": 64}
     for name, limit in budget.items():
         assert name in res, name
         assert res[name]["vgpr"] + res[name]["agpr"] <= limit, (name, res[name])
