@@ -229,26 +229,28 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
         if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      // uniform across the block
         const size_t item = ((size_t)a * f.n_instances + inst) * f.n_nodes + node;
         const float time = f.times[(size_t)inst * f.n_anims + a];
-        const AnimDev an = f.anims[a];
 
         // which binding / curve this lane serves
         int bind = -1, c = 0;
         if (j < 3) { bind = FYX_BIND_POSITION; c = (int)j; }
         else if (j >= 4 && j < 8) { bind = FYX_BIND_ROTATION; c = (int)j - 4; }
         else if (j >= 8 && j < 11) { bind = FYX_BIND_SCALE; c = (int)j - 8; }
-        int32_t track = -1;
-        if (bind >= 0) track = an.slot_track[(size_t)node * 4 + bind];
-        const bool has_prop = j == 3 && an.slot_track[(size_t)node * 4 + 3] >= 0;   // lane 3 writes the present bits
+        // The animator's descriptor of (animation, node, binding) -- CrowdDesc: slot table, track record and TrackHot resolved
+        // by the host -- is two 16-byte loads off a kernel argument; the chain animation record -> slot -> TrackHot it replaces
+        // was three dependent round trips ahead of the hint.  (Lane 3 writes the present bits: they are in every descriptor.)
+        const CrowdDesc d = f.crowd[((size_t)a * f.n_nodes + node) * 3 + (uint32_t)(bind >= 0 ? bind : 0)];
+        const int32_t track = bind >= 0 && (d.valid || d.kind >= 0) ? (int32_t)d.track : -1;
+        const bool has_prop = j == 3 && (d.present & 8u);
         int kind = -1, need = 0;
         bool valid = false;
         float v = 0.0f;
         if (track >= 0) {
-            const TrackHot th = an.hot[track];
-            kind = th.kind;
-            need = kind == FYX_KIND_QUAT ? 4 : (kind == FYX_KIND_VEC3 || kind == FYX_KIND_QUAT_EULER) ? 3 : 0;
-            const bool fits = (bind == FYX_BIND_ROTATION) ? (kind == FYX_KIND_QUAT || kind == FYX_KIND_QUAT_EULER)
-                                                          : (kind == FYX_KIND_VEC3);
-            valid = fits && need > 0 && (int)th.n_curves >= need;   // else fetch() -> None
+            struct { uint32_t span_first, n_keys; } th;       // (what the span path below reads of TrackHot)
+            th.n_keys = d.n_keys;
+            th.span_first = d.spans ? 0u : kNoSpans;
+            kind = d.kind;
+            need = (int)d.need;
+            valid = d.valid != 0;                                 // else fetch() -> None
             if (valid && c < need) {
                 uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
                 uint32_t hint = *hp;
@@ -259,7 +261,7 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
                 bool sampled = false;
                 if (th.span_first != kNoSpans && hint >= 1 && hint < th.n_keys) {
                     const uint32_t stride = need == 4 ? 16u : 8u;
-                    const f4* r = reinterpret_cast<const f4*>(an.spans) + th.span_first + (size_t)(hint - 1) * stride;
+                    const f4* r = reinterpret_cast<const f4*>(d.spans) + (size_t)(hint - 1) * stride;
                     f4 locs = r[0];
                     if (locs.x < time && time < locs.y) {
                         v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
@@ -287,6 +289,7 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
                     }
                 }
                 if (!sampled) {   // everything else, decided in the reference's order on the per-curve records
+                    const AnimDev an = f.anims[a];
                     const TrackDev* tk = an.tracks + track;
                     const uint32_t fk = tk->first_key[c];
 #if FYX_KEYREC
