@@ -463,6 +463,33 @@ def test_span_records_take_every_exit(ctx, orc, form):
     p.free()
 
 
+@pytest.mark.parametrize("n_instances", [3, 70], ids=["curves_on_lanes", "instances_on_lanes"])
+def test_track_bindings_switched_off_and_on_between_frames(ctx, orc, n_instances):
+    """TrackBinding::enabled toggled while the animation plays (track.rs: a disabled binding's track is skipped by
+    Animation::update_pose, lib.rs:903-906): the node loses that value from the animation's pose, a second track bound to the
+    same node and binding takes over if there is one.  The samplers find their tracks through per-animator descriptors built on
+    the device (CrowdDesc) -- they have to follow every such change.  Both sampler forms (3 / 70 instances)."""
+    sc = cases.c5_blend_tree(n_bones=12, seed=synth.SEED_BASE + 23, euler_every=10 ** 9)
+    o, p = run_scenario(ctx, orc, sc, n_instances=n_instances, frames=6)
+    tracks = sc.tracks_data[1].tracks
+    target = sc.animations[1].target
+
+    def toggle(track, on):
+        p.set_track_enabled(1, track, on)
+        orc._alib().fo_animation_bind(o.anims[1], track, int(target[track]), int(on))
+
+    steps = {0: [(0, False), (4, False)], 5: [(1, False), (0, True)], 9: [(4, True), (2, False), (7, False)], 14: [(1, True), (2, True), (7, True)]}
+    for f in range(20):
+        for track, on in steps.get(f, []):
+            if track < len(tracks):
+                toggle(track, on)
+        o.update_machine(sc.dt)
+        p.update_machine(sc.dt)
+        check_frame(p, o, sc, n_instances, 6 + f)
+    o.close()
+    p.free()
+
+
 def test_instances_diverge(ctx, orc):
     """Per-instance state: different speeds / parameters per instance vs one oracle scene each."""
     sc = cases.transitions()
