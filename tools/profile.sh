@@ -22,6 +22,13 @@ python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > "$ROOT/$OUT/bench_driver_
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_crowd_lone" -o crowd -- python $ROOT/tools/exp/crowd_time.py > "$ROOT/$OUT/crowd_lone_under_trace.jsonl" 2> "$ROOT/$OUT/trace_crowd_lone.err" )
 python $ROOT/tools/exp/crowd_time.py > "$ROOT/$OUT/crowd_lone.jsonl" 2> "$ROOT/$OUT/crowd_lone.err"
 python $ROOT/tools/bench_pose.py > "$ROOT/$OUT/pose_plain.json" 2> "$ROOT/$OUT/pose_plain.err"
+# single characters (C2, C5): kernel trace + the frame's timeline (kernel durations and the gaps between them), and the time stamps
+# inside the update kernel (a build of the library with stamps, tools/exp/upd_stamps_build.sh, if it travelled with the snapshot)
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_character" -o chr -- python $ROOT/tools/bench_character.py > "$ROOT/$OUT/character_under_trace.json" 2> "$ROOT/$OUT/trace_character.err" )
+F=$(find "$OUT/trace_character" -name "*_kernel_trace.csv" | head -1)
+[ -n "$F" ] && python $ROOT/tools/frame_timeline.py "$F" > "$ROOT/$OUT/character_timeline.json" 2> "$ROOT/$OUT/character_timeline.err"
+python $ROOT/tools/bench_character.py > "$ROOT/$OUT/character_plain.json" 2> "$ROOT/$OUT/character_plain.err"
+[ -f $ROOT/tools/exp/libs/libfyrox_hip_updstamp.so ] && FYX_LIB_PATH=$ROOT/tools/exp/libs/libfyrox_hip_updstamp.so python $ROOT/tools/exp/upd_stamps.py > "$ROOT/$OUT/update_stamps.json" 2> "$ROOT/$OUT/update_stamps.err"
 python $ROOT/tools/bench_pose.py --palette-output > "$ROOT/$OUT/pose_palette_output.json" 2> "$ROOT/$OUT/pose_palette_output.err"
 python $ROOT/tools/bench_pose.py --root-motion > "$ROOT/$OUT/pose_root_motion.json" 2> "$ROOT/$OUT/pose_root_motion.err"
 # extended launches: blend shapes, vertex-buffer-in / vertex-buffer-out

@@ -24,7 +24,8 @@ if os.path.exists(p):
     shutil.copy(p, os.path.join(dst, f"{tag}_bench_ex_kernel_stats.csv"))
 for f in ("bench_driver_args.json", "bench_plain.json", "bench_under_trace.json", "bench_under_trace_s1.json", "pose_plain.json", "pose_under_trace.json",
           "pose_root_motion.json", "pose_fused.json", "pose_palette_output.json", "bench_ex.json", "bench_ex_under_trace.json", "timeline.json",
-          "write_ceiling.json", "calibration_stream.json", "scene_64x4.json", "scene_256x1.json", "scene_under_trace.json"):
+          "write_ceiling.json", "calibration_stream.json", "scene_64x4.json", "scene_256x1.json", "scene_under_trace.json",
+          "character_plain.json", "character_under_trace.json", "character_timeline.json", "update_stamps.json"):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
@@ -34,6 +35,9 @@ for f in ("crowd_lone_under_trace.jsonl", "crowd_lone.jsonl"):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{f}"))
+p = os.path.join(src, "trace_character", "chr_kernel_stats.csv")
+if os.path.exists(p):
+    shutil.copy(p, os.path.join(dst, f"{tag}_character_kernel_stats.csv"))
 p = os.path.join(src, "trace_crowd_lone", "crowd_kernel_stats.csv")
 if os.path.exists(p):
     shutil.copy(p, os.path.join(dst, f"{tag}_crowd_lone_kernel_stats.csv"))
