@@ -226,10 +226,6 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
     const uint32_t node = (bx * 256u + threadIdx.x) >> 4;
     {
         if (node >= f.n_nodes) return;                                   // uniform across the group
-        if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      // uniform across the block
-        const size_t item = ((size_t)a * f.n_instances + inst) * f.n_nodes + node;
-        const float time = f.times[(size_t)inst * f.n_anims + a];
-
         // which binding / curve this lane serves
         int bind = -1, c = 0;
         if (j < 3) { bind = FYX_BIND_POSITION; c = (int)j; }
@@ -238,7 +234,12 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
         // The animator's descriptor of (animation, node, binding) -- CrowdDesc: slot table, track record and TrackHot resolved
         // by the host -- is two 16-byte loads off a kernel argument; the chain animation record -> slot -> TrackHot it replaces
         // was three dependent round trips ahead of the hint.  (Lane 3 writes the present bits: they are in every descriptor.)
+        // Requested BEFORE the tick flag is looked at: its address does not depend on it, and the early return below would
+        // otherwise put a round trip of its own in front of this one.
         const CrowdDesc d = f.crowd[((size_t)a * f.n_nodes + node) * 3 + (uint32_t)(bind >= 0 ? bind : 0)];
+        const float time = f.times[(size_t)inst * f.n_anims + a];
+        if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      // uniform across the block
+        const size_t item = ((size_t)a * f.n_instances + inst) * f.n_nodes + node;
         const int32_t track = bind >= 0 && (d.valid || d.kind >= 0) ? (int32_t)d.track : -1;
         const bool has_prop = j == 3 && (d.present & 8u);
         int kind = -1, need = 0;
