@@ -16,6 +16,10 @@
 //   * thread = node; the fold program of an instance is block-uniform, so the interpreter has no
 //     divergence and its operands are scalar loads; nested blend accumulators live in VGPRs
 //     (the nesting is unrolled at compile time, kMaxFoldDepth levels -- no scratch, no LDS);
+//     the common programs -- a few clips blended in a row, which is what the host writes for a
+//     machine in one state or one transition -- skip the interpreter (straight form);
+//   * the samplers find their track through a 32-byte descriptor per (animation, node, binding)
+//     (CrowdDesc) and sample tracks whose curves share their key times from span records;
 //   * local and global matrices of the instance stay in LDS across the level-synchronous
 //     hierarchy walk (64 B x 2 per node; 1024 nodes = 128 KiB of the CU's 160 KiB);
 //   * records are float4-packed and node-contiguous, so a wave's loads are dense.
