@@ -1488,25 +1488,45 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     // inv_bind(bone_b) (scene/mesh/mod.rs:781-793) straight from the matrices still in LDS -- no separate gather
     // launch, no re-read of the global matrices.  One thread per output COLUMN (four 16-byte LDS reads, one 16-byte
     // load of inv_bind's column, one 16-byte store), nalgebra's column-axpy order per component.
+    // (four columns per thread and pass: their bone -> node loads go out together, then their inverse bind columns -- two round
+    // trips for the pass, not two per column; this is the tail of a kernel that is one wave per character)
     for (uint32_t p = 0; p < rig.n_pal; ++p) {
         const PaletteOutDev po = rig.pal[p];
         f4* out = reinterpret_cast<f4*>(po.out + (size_t)inst * po.n_bones * 16);
-        for (uint32_t e = threadIdx.x; e < po.n_bones * 4; e += blockDim.x) {
-            const uint32_t j = e & 3, b = e >> 2;
-            const int32_t node = po.bone_nodes[b];
-            f4 y;
-            if (node < 0) {
-                y = f4{j == 0 ? 1.0f : 0.0f, j == 1 ? 1.0f : 0.0f, j == 2 ? 1.0f : 0.0f, j == 3 ? 1.0f : 0.0f};
-            } else {
-                const f4 bb = reinterpret_cast<const f4*>(rig.inv_bind)[(size_t)node * 4 + j];
-                const f4* a = reinterpret_cast<const f4*>(l_global) + (size_t)node * 4;
-                const f4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-                y.x = a0.x * bb.x; y.x = a1.x * bb.y + y.x; y.x = a2.x * bb.z + y.x; y.x = a3.x * bb.w + y.x;
-                y.y = a0.y * bb.x; y.y = a1.y * bb.y + y.y; y.y = a2.y * bb.z + y.y; y.y = a3.y * bb.w + y.y;
-                y.z = a0.z * bb.x; y.z = a1.z * bb.y + y.z; y.z = a2.z * bb.z + y.z; y.z = a3.z * bb.w + y.z;
-                y.w = a0.w * bb.x; y.w = a1.w * bb.y + y.w; y.w = a2.w * bb.z + y.w; y.w = a3.w * bb.w + y.w;
+        const uint32_t n_cols = po.n_bones * 4;
+        for (uint32_t e0 = threadIdx.x; e0 < n_cols; e0 += 4u * blockDim.x) {
+            int32_t node[4];
+            f4 bb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = e0 + (uint32_t)k * blockDim.x;
+                node[k] = e < n_cols ? po.bone_nodes[e >> 2] : -1;
             }
-            out[e] = y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = e0 + (uint32_t)k * blockDim.x;
+                bb[k] = f4{0.f, 0.f, 0.f, 0.f};
+                if (node[k] >= 0) bb[k] = reinterpret_cast<const f4*>(rig.inv_bind)[(size_t)node[k] * 4 + (e & 3u)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = e0 + (uint32_t)k * blockDim.x;
+                if (e >= n_cols) continue;
+                const uint32_t j = e & 3u;
+                f4 y;
+                if (node[k] < 0) {
+                    y = f4{j == 0 ? 1.0f : 0.0f, j == 1 ? 1.0f : 0.0f, j == 2 ? 1.0f : 0.0f, j == 3 ? 1.0f : 0.0f};
+                } else {
+                    const f4 b4 = bb[k];
+                    const f4* a = reinterpret_cast<const f4*>(l_global) + (size_t)node[k] * 4;
+                    const f4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+                    y.x = a0.x * b4.x; y.x = a1.x * b4.y + y.x; y.x = a2.x * b4.z + y.x; y.x = a3.x * b4.w + y.x;
+                    y.y = a0.y * b4.x; y.y = a1.y * b4.y + y.y; y.y = a2.y * b4.z + y.y; y.y = a3.y * b4.w + y.y;
+                    y.z = a0.z * b4.x; y.z = a1.z * b4.y + y.z; y.z = a2.z * b4.z + y.z; y.z = a3.z * b4.w + y.z;
+                    y.w = a0.w * b4.x; y.w = a1.w * b4.y + y.w; y.w = a2.w * b4.z + y.w; y.w = a3.w * b4.w + y.w;
+                }
+                out[e] = y;
+            }
         }
     }
 }

@@ -51,27 +51,16 @@ else:
         const PaletteOutDev po = rig.pal[p];""", """    STAMP(5);
     for (uint32_t p = 0; p < rig.n_pal; ++p) {
         const PaletteOutDev po = rig.pal[p];""")
-tail = """            out[e] = y;
-        }
-    }
-}
-""" if """            out[e] = y;
-        }
-    }
-}
-""" in s else """            out[e] = palette_column(node, e & 3u, bb);
-        }
-    }
-}
-"""
-rep(tail, tail[:-2] + """    STAMP(6);
+# the end of pose_update_body: the closing brace ahead of the kernel's definition
+END = "}\n\ntemplate <bool PROGRAM>\n__global__ __launch_bounds__(256) void pose_update_kernel"
+assert s.count(END) == 1
+s = s.replace(END, """    STAMP(6);
     __builtin_amdgcn_s_waitcnt(0);
     STAMP(7);
     stamp[8] = clock64() - cyc0;      // shader-clock cycles between stamps 0 and 7
     if (threadIdx.x == 0) for (int q = 0; q < 9; ++q) reinterpret_cast<uint64_t*>(f.local + inst_base * 16)[q] = stamp[q];
     if (threadIdx.x == 0) for (int q = 0; q < 8; ++q) reinterpret_cast<uint64_t*>(f.local + inst_base * 16)[9 + q] = lvc[q];
-}
-""")
+""" + END, 1)
 if "uint64_t lvc[8];" not in s:      # the product's walk: no per-level stamps
     s = s.replace("    STAMP(6);", "    uint64_t lvc[8] = {0, 0, 0, 0, 0, 0, 0, 0};\n    STAMP(6);", 1)
 open(p, 'w').write(s)
