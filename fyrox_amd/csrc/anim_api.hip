@@ -237,6 +237,8 @@ int fyx_rig_create(fyx_ctx* c, uint64_t rig_id, uint32_t n_nodes, const int32_t*
         std::vector<uint32_t> cur(level_start.begin(), level_start.end() - 1);
         for (uint32_t i = 0; i < n_nodes; ++i) level_nodes[cur[depth[i]]++] = i;
     }
+    static_assert(kMaxRigNodes <= 1024, "RigDev::walk packs node (10 bits), parent + 1 (11) and depth (11) into one word");
+    for (uint32_t& e : level_nodes) e = e | (uint32_t)(parent[e] + 1) << 10 | depth[e] << 21;
     r.init_trs.assign((size_t)n_nodes * 12, 0.f);
     std::vector<float> statics((size_t)n_nodes * 28, 0.f);
     for (uint32_t i = 0; i < n_nodes; ++i) {
@@ -261,11 +263,8 @@ int fyx_rig_create(fyx_ctx* c, uint64_t rig_id, uint32_t n_nodes, const int32_t*
         } else {
             for (uint32_t i = 0; i < n_nodes; ++i) ib[(size_t)i * 16] = ib[(size_t)i * 16 + 5] = ib[(size_t)i * 16 + 10] = ib[(size_t)i * 16 + 15] = 1.f;
         }
-        int rc = upload(c, &r.d_parent, r.parent.data(), r.parent.size());
-        if (!rc) rc = upload(c, &r.d_statics, statics.data(), statics.size());
-        if (!rc) rc = upload(c, &r.d_level_nodes, level_nodes.data(), level_nodes.size());
-        if (!rc) rc = upload(c, &r.d_level_start, level_start.data(), level_start.size());
-        if (!rc) rc = upload(c, &r.d_node_level, depth.data(), depth.size());
+        int rc = upload(c, &r.d_statics, statics.data(), statics.size());
+        if (!rc) rc = upload(c, &r.d_walk, level_nodes.data(), level_nodes.size());
         if (!rc) rc = upload(c, &r.d_inv_bind, ib.data(), ib.size());
         if (rc) { free_rig(r); return rc; }
     }

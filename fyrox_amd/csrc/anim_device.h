@@ -254,11 +254,8 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
 
 RigDev rig_dev(const Rig& r) {
     RigDev d;
-    d.parent = r.d_parent;
     d.statics = r.d_statics;
-    d.level_nodes = r.d_level_nodes;
-    d.level_start = r.d_level_start;
-    d.node_level = r.d_node_level;
+    d.walk = r.d_walk;
     d.inv_bind = r.d_inv_bind;
     d.n_pal = 0;
     d.n_nodes = r.n_nodes;

@@ -1327,9 +1327,10 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         w_node[k] = 0;
         w_par[k] = -1;
         if (i < rig.n_nodes) {
-            w_node[k] = rig.level_nodes[i];
-            w_level[k] = rig.node_level[w_node[k]];
-            w_par[k] = rig.parent[w_node[k]];
+            const uint32_t e = rig.walk[i];            // node | (parent + 1) << 10 | depth << 21: one load, no chain
+            w_node[k] = e & 1023u;
+            w_par[k] = (int32_t)((e >> 10) & 2047u) - 1;
+            w_level[k] = e >> 21;
         }
     }
     // the instance's fold program: op `lane` into every wave's registers while ALL lanes are still active (v_readlane

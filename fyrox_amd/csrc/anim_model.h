@@ -23,11 +23,8 @@ struct Rig {
     uint32_t n_nodes = 0, n_levels = 0;
     std::vector<int32_t> parent;
     std::vector<float> init_trs;  // [n_nodes][12]
-    int32_t* d_parent = nullptr;
     float* d_statics = nullptr;
-    uint32_t* d_level_nodes = nullptr;
-    uint32_t* d_level_start = nullptr;
-    uint32_t* d_node_level = nullptr;
+    uint32_t* d_walk = nullptr;          // RigDev::walk
     float* d_inv_bind = nullptr;
 };
 

@@ -18,7 +18,7 @@ void dfree(void* p) { if (p) (void)hipFree(p); }
 
 void free_tracks(TracksData& t) { dfree(t.d_tracks); dfree(t.d_loc); dfree(t.d_aux); dfree(t.d_rec); dfree(t.d_hot); dfree(t.d_spans); t = TracksData(); }
 void free_rig(Rig& r) {
-    dfree(r.d_parent); dfree(r.d_statics); dfree(r.d_level_nodes); dfree(r.d_level_start); dfree(r.d_node_level); dfree(r.d_inv_bind);
+    dfree(r.d_statics); dfree(r.d_walk); dfree(r.d_inv_bind);
     r = Rig();
 }
 void free_bones(BoneList& b) { dfree(b.d_bone_nodes); b = BoneList(); }

@@ -275,12 +275,10 @@ struct RigDev {
     const float* inv_bind;       // [n_nodes][16]
     PaletteOutDev pal[kMaxPaletteOutputs];
     uint32_t n_pal;
-    const int32_t* parent;       // [n_nodes], parent index < node index or -1
     const float* statics;        // [n_nodes][28]: pre_rotation(4) post_rotation_matrix(9)
                                  //   rotation_offset(3) rotation_pivot(3) scaling_offset(3) scaling_pivot(3) pad(3)
-    const uint32_t* level_nodes; // nodes sorted by depth
-    const uint32_t* level_start; // [n_levels + 1]
-    const uint32_t* node_level;  // [n_nodes] depth of each node
+    const uint32_t* walk;        // [n_nodes] the nodes sorted by depth, one word each: node | (parent + 1) << 10 | depth << 21
+                                 //   (kMaxRigNodes = 1024: 10 + 11 + 11 bits) -- one load where node -> depth, parent were two
     uint32_t n_nodes;
     uint32_t n_levels;
 };
