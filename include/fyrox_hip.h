@@ -716,6 +716,10 @@ int fyx_init_control_only(fyx_ctx** out_ctx);
  * times and ticked are [n_instances][n_animations]; program_offset is [n_instances + 1]; ops are
  * {opcode | arg << 8, f32 weight bits} pairs (opcodes: 0 END, 1 BLEND_ANIM, 2 PUSH, 3 POP_BLEND,
  * 4 RESET, 5 MASK, 6 APPLY, 7 APPLY_ANIM).  *n_ops returns the number of pairs needed.
+ * A program is the reference's sequence of blend_with calls; a PUSH ... POP_BLEND pair (a sub-tree
+ * evaluated into a pose of its own) appears only where it changes the result -- a sub-tree blended
+ * into a pose nothing has been blended into yet is written in place, a one-clip sub-tree is one
+ * BLEND_ANIM with the outer weight (NodePose::blend_with's copy rule, pose.rs:41-47).
  * ticked: bit 0 = the animation ticked; bit 1 = that tick started a new loop cycle; bit 2 =
  * speed > 0 (what Animation::update_root_motion derives, lib.rs:539-554). */
 int fyx_animator_plan(fyx_ctx* ctx, uint64_t animator_id, int mode, float dt, float* times,
