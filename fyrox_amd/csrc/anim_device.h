@@ -366,6 +366,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     bool in_args = false;
     CtrlInline inl;
     inl.bytes = 0;
+    inl.first_ops = 0;
     if (with_program) {
         // a small control block (one character, a handful of instances) rides in the kernel arguments: no copy, no event, no wait
         const CtrlLayout Li = ctrl_layout_inline(A);
@@ -374,6 +375,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         if (in_args) {
             ctrl_write(A, L, reinterpret_cast<char*>(&inl));    // the sections start behind the header (offset 16)
             inl.bytes = (uint32_t)L.total;
+            inl.first_ops = A.prog_off.size() >= 2 && A.prog_off[0] == 0 ? A.prog_off[1] + 1u : 0u;
             ctrl_bind(A, L, nullptr, f);                        // the control pointers become offsets from the start of `inl`
         } else {
             char *h = nullptr, *d = nullptr;

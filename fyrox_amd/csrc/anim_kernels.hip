@@ -1307,7 +1307,7 @@ __device__ __forceinline__ void mat4_mul(const float* a, const float* b, float* 
 // pose_update: one workgroup per instance.
 // ---------------------------------------------------------------------------------------
 template <bool PROGRAM>
-__device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst) {
+__device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* l_local = lds;                               // [n_nodes][16]
     float* l_global = lds + (size_t)rig.n_nodes * 16;   // [n_nodes][16]
@@ -1339,9 +1339,16 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     uint32_t n_ops = 0;
     uint2 my_op = make_uint2(OP_END, 0u);
     if constexpr (PROGRAM) {
-        const uint32_t p0 = f.prog_off[inst];
+        // (instance 0's program starts at op 0; where the launch knows its length -- CtrlInline::first_ops, one character's
+        // frame -- the program is requested without a round trip for its offsets first)
+        uint32_t p0 = 0;
+        if (inst == 0 && first_ops) {
+            n_ops = first_ops - 1u;
+        } else {
+            p0 = f.prog_off[inst];
+            n_ops = f.prog_off[inst + 1] - p0;
+        }
         prog = f.ops + p0;
-        n_ops = f.prog_off[inst + 1] - p0;
         const uint32_t lane = threadIdx.x & 63u;
         if (lane < n_ops) my_op = prog[lane];
     }
@@ -1533,7 +1540,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
 }
 
 template <bool PROGRAM>
-__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl) { pose_update_body<PROGRAM>(ctrl_resolve<kInlAfterFrameAndRig>(f, inl), rig, blockIdx.x); }
+__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl) { pose_update_body<PROGRAM>(ctrl_resolve<kInlAfterFrameAndRig>(f, inl), rig, blockIdx.x, inl.bytes ? inl.first_ops : 0u); }
 
 // Scene form: every job of one launch has the same block size; the dynamic LDS is sized for the largest rig among them.
 __global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {

@@ -333,7 +333,9 @@ struct PoseFrameDev {
 constexpr uint32_t kCtrlInlineBytes = 1008;
 struct CtrlInline {
     uint32_t bytes;          // 0: the control block is in device memory and the pointers are pointers
-    uint32_t pad[3];
+    uint32_t first_ops;      // 1 + the number of ops of instance 0's fold program (which starts at op 0), 0: not given --
+                             //   the update kernel of ONE character then asks for its program without asking for its offsets first
+    uint32_t pad[2];
     uint32_t words[kCtrlInlineBytes / 4];
 };
 static_assert(sizeof(CtrlInline) == 16 + kCtrlInlineBytes, "header + payload");
