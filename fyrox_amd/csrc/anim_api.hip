@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "fyx_ctx.h"
+#include "anim_leaves.h"
 
 #include "anim_model.h"
 #include "anim_planner.h"

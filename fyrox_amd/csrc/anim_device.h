@@ -390,7 +390,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     }
     RigDev rd;
     if (int rc = rig_params(c, A, rd)) return rc;
-    FYX_HIP(c, launch_pose_update(f, rd, with_program, c->stream, &inl));
+    FYX_HIP(c, launch_pose_update(f, rd, !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral, c->stream, &inl));
     if (with_program) {
         FYX_HIP(c, launch_property_update(f, c->stream, &inl));
         if (!in_args)
@@ -532,7 +532,9 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     // 4. one launch per stage
     const uint4* tabs[kSceneStages];
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
-    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(d), tabs, S.n_blocks, S.lds_bytes, c->stream));
+    bool all_straight = c->upd_lean != 0;
+    for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
+    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(d), tabs, S.n_blocks, S.lds_bytes, all_straight, c->stream));
     return ctrl_consumed(c, S.ctrl, slot);
 }
 

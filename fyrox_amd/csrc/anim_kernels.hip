@@ -29,32 +29,10 @@
 #include "fyx_internal.h"
 
 #include "../../include/fyrox_hip.h"
+#include "anim_leaves.h"   // lerpf_, cubicf_, interpolate_loaded, span_track_value_at, classify_fold_program (host + device)
 
 namespace fyx {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-// ---------------------------------------------------------------------------------------
-// fyrox-math leaves
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float lerpf_(float a, float b, float t) { return a + (b - a) * t; }
-
-__device__ __forceinline__ float cubicf_(float p0, float p1, float t, float m0, float m1) {
-    const float t2 = t * t;
-    const float t3 = t2 * t;
-    const float scale = fabsf(p1 - p0);
-    return (2.0f * t3 - 3.0f * t2 + 1.0f) * p0 + (t3 - 2.0f * t2 + t) * m0 * scale +
-           (-2.0f * t3 + 3.0f * t2) * p1 + (t3 - t2) * m1 * scale;
-}
-
-// CurveKey::interpolate (curve.rs:87-132): dispatch on the LEFT key's kind.
-__device__ __forceinline__ float interpolate_loaded(float ll, float rl, f4 la, f4 ra, float location) {
-    const float t = (location - ll) / (rl - ll);
-    const uint32_t lk = __float_as_uint(la.y), rk = __float_as_uint(ra.y);
-    if (lk == FYX_KEY_CONSTANT) return t == 1.0f ? ra.x : la.x;
-    if (lk == FYX_KEY_LINEAR) return lerpf_(la.x, ra.x, t);
-    return cubicf_(la.x, ra.x, t, la.w, rk == FYX_KEY_CUBIC ? ra.z : 0.0f);
-}
 // (LP / AP: pointers to the key locations / {value, kind, tangents} records -- global memory, or LDS where the crowd
 // sampler has staged the curve)
 template <typename LP, typename AP>
@@ -378,58 +356,7 @@ __global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDe
 constexpr uint32_t kCurveLdsKeys = 128;   // curves up to this many keys are staged in LDS by the crowd sampler (2.5 KB per wave)
 constexpr uint32_t kSpanLdsF4 = 512;      // ... and a track's span records up to this many 16-byte words (8 KB per wave: 64 spans of a Vector3 track)
 
-// Curve::value_at (curve.rs:254-314) for the three or four curves of ONE track at once, on the track's span records staged in
-// LDS (`sp`; n keys, `stride` f4 per span): the curves share their key times, so the decisions -- clamp at the ends, the hinted
-// span [hint - 1, hint), else partition_point(k.location < time) -- are taken once, in the reference's order, and every curve's
-// hint becomes the same value.  The search result is found without searching when it is the hint itself (time on the right key)
-// or a neighbour (playback crossed a key: at 60 frames a second over 30 keys a second half the instances do every frame).
-// Returns the new hint.
-__device__ __forceinline__ uint32_t span_track_value_at(const __attribute__((address_space(3))) f4* sp, uint32_t n, uint32_t stride, int need,
-                                                        float time, uint32_t h, float (&val)[4]) {
-    const __attribute__((address_space(3))) f4* last = sp + (size_t)(n - 2u) * stride;
-    const float l_first = sp[0].x, l_last = last[0].y;
-    if (time <= l_first) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) if (c < need) val[c] = sp[1 + 2 * c].x;          // first key's value
-        return 0u;
-    }
-    if (time >= l_last) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) if (c < need) val[c] = last[2 + 2 * c].x;        // last key's value
-        return n - 1u;
-    }
-    // right key of the span that holds the time: key `hint` if the hinted span holds it, else the first key at or after the time
-    uint32_t right = 0u;                        // 0: not found yet (the first key lies before the time)
-    f4 locs = f4{0.f, 0.f, 0.f, 0.f};
-    if (h >= 1u && h < n) {
-        locs = sp[(size_t)(h - 1u) * stride];
-        // (time on the right key: the hinted test fails and the search returns hint -- unless the left key has the same
-        // location, then it returns an earlier key: duplicates go to the search)
-        if (time >= locs.x && time <= locs.y && locs.x < locs.y) right = h;
-        else if (time > locs.y && h + 1u < n) {
-            locs = sp[(size_t)h * stride];
-            if (time <= locs.y) right = h + 1u;               // (time > its left key: that is the hinted span's right key)
-        } else if (time < locs.x && h >= 2u) {
-            locs = sp[(size_t)(h - 2u) * stride];
-            if (time > locs.x) right = h - 1u;                // (time < its right key)
-        }
-    }
-    if (!right) {                                // partition_point(k.location < time) over the keys
-        uint32_t lo = 0u, hi = n;
-        while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2u;
-            const float l_mid = mid + 1u < n ? sp[(size_t)mid * stride].x : l_last;
-            if (l_mid < time) lo = mid + 1u; else hi = mid;
-        }
-        right = lo;                              // 1 <= lo <= n - 1: first < time < last
-        locs = sp[(size_t)(right - 1u) * stride];
-    }
-    const __attribute__((address_space(3))) f4* r = sp + (size_t)(right - 1u) * stride;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if (c < need) val[c] = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
-    return right;
-}
+// (span_track_value_at -- Curve::value_at for the curves of one track on its span records -- lives in anim_leaves.h)
 
 // BLOCK: 64, or 256 = four waves (256 instances) of the same (animation, node, binding) that stage the track's span records
 // TOGETHER: a quarter of the staging loads and of the LDS per wave (8 KB per wave let 20 waves onto a CU; the kernel is made of
@@ -1306,8 +1233,16 @@ __device__ __forceinline__ void mat4_mul(const float* a, const float* b, float* 
 // ---------------------------------------------------------------------------------------
 // pose_update: one workgroup per instance.
 // ---------------------------------------------------------------------------------------
-template <bool PROGRAM>
-__device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0) {
+// MODE: kUpdNoProgram -- the transforms as they are (fyx_animator_update_transforms); kUpdGeneral -- straight form + interpreter;
+// kUpdStraight -- every program of the launch is straight (the host classified them with the same function,
+// classify_fold_program): the interpreter and its kMaxFoldDepth nested accumulators are not compiled in, which is what lets a
+// crowd's update kernel sit beside the previous frame's skinning (<= 128 VGPRs instead of ~440: anim.overlap).
+// pal_mem: where the rig's palette outputs lie in memory, for callers whose RigDev is a register copy (the scene form: indexing a
+// register copy with the loop counter would put the array in scratch).
+template <int MODE>
+__device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0,
+                                                 const PaletteOutDev* __restrict__ pal_mem = nullptr) {
+    constexpr bool PROGRAM = MODE != kUpdNoProgram;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* l_local = lds;                               // [n_nodes][16]
     float* l_global = lds + (size_t)rig.n_nodes * 16;   // [n_nodes][16]
@@ -1352,30 +1287,20 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         const uint32_t lane = threadIdx.x & 63u;
         if (lane < n_ops) my_op = prog[lane];
     }
-    // STRAIGHT programs: [PUSH^d] BLEND_ANIM^k [POP_BLEND^d] [MASK] APPLY END with k <= kStraightOps -- a machine whose layers
-    // after the first are off, in one state or in one transition between states whose roots are single clips, or one state
-    // whose root is one blend node (BASELINE configs 2, 3, 5; the host writes such programs without the PUSHes, see
-    // Planner::emit_blend).  Every pose the PUSHes open is empty when its child is popped into it, and an empty pose becomes
-    // a COPY of the other (pose.rs:41-47, weight ignored), so the result is the k operands blended in order into one
-    // accumulator -- the same calls to blend() in the same order as the interpreter (run_fold) makes, without its dispatch
-    // (an op of it costs a lone wave ~0.7 us, memory round trip included) and with all k operand records requested together.
-    constexpr uint32_t kStraightOps = 4;
+    // STRAIGHT programs ([PUSH^d] BLEND_ANIM^k [POP_BLEND^d] [MASK] APPLY END, k <= kStraightOps: anim_leaves.h) skip the
+    // interpreter: the same calls to blend() in the same order as run_fold makes, without its dispatch (an op of it costs a
+    // lone wave ~0.7 us, memory round trip included) and with all k operand records requested together.
     uint32_t st_d = 0, st_k = 0;
-    bool straight = false, st_mask = false;
+    bool straight = false, st_mask = false, st_player = false;
     if constexpr (PROGRAM) {
-        if (n_ops >= 3u && n_ops <= 64u) {
-            const uint32_t code = my_op.x & 0xffu;
-            const uint64_t m_push = __ballot(code == OP_PUSH), m_blend = __ballot(code == OP_BLEND_ANIM), m_pop = __ballot(code == OP_POP_BLEND);
-            st_d = (uint32_t)__builtin_ctzll(~m_push | (1ull << 63));
-            st_k = (uint32_t)__builtin_ctzll(~(m_blend >> st_d) | (1ull << 63));
-            const uint32_t pops = (uint32_t)__builtin_ctzll(~(m_pop >> ((st_d + st_k) & 63u)) | (1ull << 63));
-            uint32_t tail = 2u * st_d + st_k;
-            const auto code_at = [&](uint32_t pc) { return (uint32_t)__builtin_amdgcn_readlane((int)my_op.x, (int)(pc & 63u)) & 0xffu; };
-            st_mask = code_at(tail) == OP_MASK;
-            if (st_mask) ++tail;
-            straight = st_k >= 1u && st_k <= kStraightOps && pops == st_d && st_d + 1 < (uint32_t)kMaxFoldDepth && n_ops == tail + 2u &&
-                       code_at(tail) == OP_APPLY && code_at(tail + 1u) == OP_END;
-        }
+        const uint32_t code = my_op.x & 0xffu;
+        const uint64_t m_push = __ballot(code == OP_PUSH), m_blend = __ballot(code == OP_BLEND_ANIM), m_pop = __ballot(code == OP_POP_BLEND);
+        const uint64_t m_apply_anim = __ballot(code == OP_APPLY_ANIM);
+        const StraightShape sh = classify_fold_program(n_ops, m_push, m_blend, m_pop, m_apply_anim, [&](uint32_t pc) -> uint32_t {
+            return (uint32_t)__builtin_amdgcn_readlane((int)my_op.x, (int)(pc & 63u)) & 0xffu; });
+        st_d = sh.d; st_k = sh.k; st_mask = sh.mask; st_player = sh.player;
+        straight = sh.straight;
+        if constexpr (MODE == kUpdStraight) straight = true;   // the host's promise (same classifier); no second path to fall into
     }
     // Every lane of every wave walks the fold, also the lanes past the last node (they fold the last node's operand records onto
     // an identity transform and store nothing): fold_op reads the program out of the lanes' registers with v_readlane, and a lane that is inactive when
@@ -1423,17 +1348,25 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
                     rec[i] = load_rec(cx.anim_pose + ((size_t)(op.x >> 8) * cx.anim_stride + cx.rec_index) * 3);
                     rw[i] = __uint_as_float(op.y);
                 }
-                bool masked = false;
-                if (st_mask) masked = cx.layer_masks[(size_t)(fold_op(cx, 2u * st_d + st_k).x >> 8) * cx.n_nodes + cx.node] != 0;
-                Acc acc = acc_empty();
+                if (st_player) {      // APPLY_ANIM^k: every pose written to the node in turn (the later one wins per value)
 #pragma unroll
-                for (uint32_t i = 0; i < kStraightOps; ++i) {
-                    if (i >= st_k) break;
-                    blend(acc, rec[i], rw[i]);
+                    for (uint32_t i = 0; i < kStraightOps; ++i) {
+                        if (i >= st_k) break;
+                        apply_pose(cx, rec[i]);
+                    }
+                } else {
+                    bool masked = false;
+                    if (st_mask) masked = cx.layer_masks[(size_t)(fold_op(cx, 2u * st_d + st_k).x >> 8) * cx.n_nodes + cx.node] != 0;
+                    Acc acc = acc_empty();
+#pragma unroll
+                    for (uint32_t i = 0; i < kStraightOps; ++i) {
+                        if (i >= st_k) break;
+                        blend(acc, rec[i], rw[i]);
+                    }
+                    if (masked) acc.mask = 0;
+                    apply_pose(cx, acc);
                 }
-                if (masked) acc.mask = 0;
-                apply_pose(cx, acc);
-            } else {
+            } else if constexpr (MODE == kUpdGeneral) {
                 cx.pc = 0;
                 cx.pop_w = 0.f;
                 cx.done = false;
@@ -1499,7 +1432,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     // (four columns per thread and pass: their bone -> node loads go out together, then their inverse bind columns -- two round
     // trips for the pass, not two per column; this is the tail of a kernel that is one wave per character)
     for (uint32_t p = 0; p < rig.n_pal; ++p) {
-        const PaletteOutDev po = rig.pal[p];
+        const PaletteOutDev po = pal_mem ? pal_mem[p] : rig.pal[p];
         f4* out = reinterpret_cast<f4*>(po.out + (size_t)inst * po.n_bones * 16);
         const uint32_t n_cols = po.n_bones * 4;
         for (uint32_t e0 = threadIdx.x; e0 < n_cols; e0 += 4u * blockDim.x) {
@@ -1539,38 +1472,45 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     }
 }
 
-template <bool PROGRAM>
-__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl) { pose_update_body<PROGRAM>(ctrl_resolve<kInlAfterFrameAndRig>(f, inl), rig, blockIdx.x, inl.bytes ? inl.first_ops : 0u); }
+// Two kernel-argument shapes: with the frame's control block inside the arguments (one character, CtrlInline) and without
+// (crowds, scenes, update_transforms: 1 KB less to copy per launch, and no SGPR pressure from a parameter nobody reads).
+template <int MODE>
+__global__ __launch_bounds__(256) void pose_update_inl_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl) { pose_update_body<MODE>(ctrl_resolve<kInlAfterFrameAndRig>(f, inl), rig, blockIdx.x, inl.first_ops); }
+template <int MODE>
+__global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) { pose_update_body<MODE>(f, rig, blockIdx.x); }
 
 // Scene form: every job of one launch has the same block size; the dynamic LDS is sized for the largest rig among them.
+template <int MODE>
 __global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
     const PoseFrameDev f = jobs[b.x].f;
-    const RigDev rig = jobs[b.x].rig;
-    pose_update_body<true>(f, rig, b.y);
+    RigDev rig = jobs[b.x].rig;
+    pose_update_body<MODE>(f, rig, b.y, 0u, jobs[b.x].rig.pal);
 }
 
-hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s, const CtrlInline* inl) {
+template <typename K, typename... Args>
+static hipError_t launch_update_one(K kernel, uint32_t grid, uint32_t block, size_t lds, hipStream_t s, Args... args) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, args...);
+    return hipGetLastError();
+}
+
+hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl) {
     if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;
     uint32_t block = ((rig.n_nodes + 63) / 64) * 64;
     if (block > 256) block = 256;
     const size_t lds = (size_t)rig.n_nodes * 32 * sizeof(float);
-    if (run_program) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_update_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(pose_update_kernel<true>, dim3(f.n_instances), dim3(block), lds, s, f, rig, inl ? *inl : kNoInline);
-    } else {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_update_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(pose_update_kernel<false>, dim3(f.n_instances), dim3(block), lds, s, f, rig, kNoInline);
+    const bool in_args = inl && inl->bytes && mode != kUpdNoProgram;
+    if (in_args) {
+        if (mode == kUpdStraight) return launch_update_one(pose_update_inl_kernel<kUpdStraight>, f.n_instances, block, lds, s, f, rig, *inl);
+        return launch_update_one(pose_update_inl_kernel<kUpdGeneral>, f.n_instances, block, lds, s, f, rig, *inl);
     }
-    return hipGetLastError();
+    if (mode == kUpdStraight) return launch_update_one(pose_update_kernel<kUpdStraight>, f.n_instances, block, lds, s, f, rig);
+    if (mode == kUpdGeneral) return launch_update_one(pose_update_kernel<kUpdGeneral>, f.n_instances, block, lds, s, f, rig);
+    return launch_update_one(pose_update_kernel<kUpdNoProgram>, f.n_instances, block, lds, s, f, rig);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1660,7 +1600,7 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[
 }
 
 hipError_t launch_scene(const SceneJobDev* d_jobs, const uint4* const (&d_tables)[kSceneStages],
-                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], hipStream_t s) {
+                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, hipStream_t s) {
     auto go = [&](int stage, auto kernel, uint32_t block, size_t lds) {
         if (n_blocks[stage]) hipLaunchKernelGGL(kernel, dim3(n_blocks[stage]), dim3(block), lds, s, d_jobs, d_tables[stage]);
     };
@@ -1673,12 +1613,15 @@ hipError_t launch_scene(const SceneJobDev* d_jobs, const uint4* const (&d_tables
     for (int k = kStageUpdate64; k <= kStageUpdate256; ++k)
         if (n_blocks[k]) max_lds = std::max(max_lds, lds_bytes[k]);
     if (max_lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_update_scene_kernel),
+        hipError_t e = hipFuncSetAttribute(all_straight ? reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdStraight>)
+                                                        : reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdGeneral>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
         if (e != hipSuccess) return e;
     }
-    for (int k = kStageUpdate64; k <= kStageUpdate256; ++k)
-        go(k, pose_update_scene_kernel, 64u * (uint32_t)(k - kStageUpdate64 + 1), lds_bytes[k]);
+    for (int k = kStageUpdate64; k <= kStageUpdate256; ++k) {
+        if (all_straight) go(k, pose_update_scene_kernel<kUpdStraight>, 64u * (uint32_t)(k - kStageUpdate64 + 1), lds_bytes[k]);
+        else go(k, pose_update_scene_kernel<kUpdGeneral>, 64u * (uint32_t)(k - kStageUpdate64 + 1), lds_bytes[k]);
+    }
     go(kStagePropUpdate, property_update_scene_kernel, 64, 0);
     return hipGetLastError();
 }

@@ -145,6 +145,7 @@ struct PlanScratch {
     std::vector<int32_t> node_recipe;
     std::vector<uint8_t> seen;
     int error = 0;
+    bool all_straight = false;      // every program of the range is straight (classify_fold_program_host)
 };
 
 struct Animator {
@@ -177,6 +178,7 @@ struct Animator {
     std::vector<uint8_t> ticked;
     std::vector<uint2> ops;
     std::vector<uint32_t> prog_off;
+    bool all_straight = false;              // every instance's program of this frame is straight: the update kernel without the interpreter
     std::vector<uint2> prev_ops;            // last frame's programs (the memo's source)
     std::vector<uint32_t> prev_prog_off;
     std::vector<std::vector<std::vector<uint32_t>>> state_anims;   // [layer][state]: animations its pose tree plays

@@ -762,17 +762,24 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
         S.ops.clear(); S.rm_ops.clear(); S.prog_len.clear(); S.rm_prog_len.clear();
         S.seen.assign(na ? na : 1, 0);
         S.error = 0;
+        S.all_straight = true;
         for (uint32_t i = i0; i < i1; ++i) {
             const size_t o0 = S.ops.size(), r0 = S.rm_ops.size();
             Planner p(A, S, i, dt);
             if (mode == 1) p.plan_absm(); else p.plan_player();
             if (p.error) S.error = p.error;
+            // which form of the update kernel may run this frame: the one without the interpreter needs EVERY program straight
+            static_assert(sizeof(uint2) == 8, "ops are {x, y} pairs");
+            if (S.all_straight)
+                S.all_straight = classify_fold_program_host(reinterpret_cast<const uint32_t*>(S.ops.data() + o0), (uint32_t)(S.ops.size() - o0)).straight;
             S.prog_len.push_back((uint32_t)(S.ops.size() - o0));
             S.rm_prog_len.push_back((uint32_t)(S.rm_ops.size() - r0));
         }
     };
     if (n_tasks > 1) pool->run(n_tasks, work); else work(0);
     uint32_t inst = 0;
+    A.all_straight = A.n_instances > 0;
+    for (unsigned k = 0; k < n_tasks; ++k) A.all_straight = A.all_straight && A.scratch[k].all_straight;
     for (unsigned k = 0; k < n_tasks; ++k) {  // merge in instance order
         const PlanScratch& S = A.scratch[k];
         if (S.error) return S.error;

@@ -55,6 +55,77 @@ int enter_primary(fyx_ctx* c) {
 int enter_pose(fyx_ctx* c) {
     if (!c->pose_overlap) return enter_primary(c);
     if (int rc = bind_device(c)) return rc;
+    // Frame n's pose update runs BESIDE frame n - 1's skinning launches and behind frame n - 2's (whose palette buffer it is about
+    // to rewrite): mark the launches made so far on every busy launch stream, wait for the marks of the previous pose entry.
+    const int cur = c->lag_cur, prev = cur ^ 1;
+    for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
+        if (c->lag_has[prev][w]) {
+            FYX_HIP(c, hipStreamWaitEvent(c->stream, c->lag_ev[prev][w], 0));
+            c->lag_has[prev][w] = false;
+        }
+        if (!c->worker_busy[w] || c->worker_launches[w] == c->worker_marked[w]) continue;   // nothing new on it since its last mark
+        if (!c->lag_ev[cur][w]) FYX_HIP(c, hipEventCreateWithFlags(&c->lag_ev[cur][w], hipEventDisableTiming));
+        FYX_HIP(c, hipEventRecord(c->lag_ev[cur][w], c->workers[w]));
+        c->lag_has[cur][w] = true;
+        c->worker_marked[w] = c->worker_launches[w];
+        // (the worker stays "busy": enter_primary still joins it)
+    }
+    c->lag_cur = prev;
+    c->primary_dirty = true;
+    return FYX_OK;
+}
+
+// The context's streams.  own_stream carries the pose path (a chain of short, latency-bound kernels), the launch streams the
+// skinning (long, bandwidth-bound): with priorities (option streams.priority, default) a workgroup slot that frees up goes to
+// the pose kernels first, so frame n + 1's pose update makes its way under frame n's skinning (anim.overlap) instead of
+// queueing behind it; with streams.pose_cus = N the two kinds of stream get disjoint sets of CUs instead.
+static hipError_t make_stream(fyx_ctx* c, bool pose, hipStream_t* out) {
+    if (c->pose_cus > 0 && c->pose_cus < fyx::kCUs) {
+        // CU-mask bits are dealt round-robin over the XCDs (bit i = CU i / 8 of XCD i % 8 in the order the driver numbers them):
+        // the low N bits are N / 8 CUs of every XCD
+        uint32_t mask[fyx::kCUs / 32];
+        for (int wd = 0; wd < fyx::kCUs / 32; ++wd) {
+            uint32_t m = 0;
+            for (int b = 0; b < 32; ++b) {
+                const bool low = wd * 32 + b < c->pose_cus;
+                if (low == pose) m |= 1u << b;
+            }
+            mask[wd] = m;
+        }
+        return hipExtStreamCreateWithCUMask(out, fyx::kCUs / 32, mask);
+    }
+    if (c->stream_priority) {
+        int least = 0, greatest = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e != hipSuccess) return e;
+        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, pose ? greatest : least);
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+// Re-creates the context's own streams after streams.priority / streams.pose_cus changed (everything in flight is waited for).
+static int recreate_streams(fyx_ctx* c) {
+    if (c->device < 0) return FYX_OK;
+    if (int rc = enter_primary(c)) return rc;
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->upload_stream) FYX_HIP(c, hipStreamSynchronize(c->upload_stream));
+    for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
+        if (!c->workers[w]) continue;
+        FYX_HIP(c, hipStreamSynchronize(c->workers[w]));
+        FYX_HIP(c, hipStreamDestroy(c->workers[w]));
+        c->workers[w] = nullptr;
+        c->worker_busy[w] = false;
+        c->worker_seen[w] = 0;
+        c->lag_has[0][w] = c->lag_has[1][w] = false;
+        c->worker_launches[w] = c->worker_marked[w] = 0;
+    }
+    const bool own_current = c->stream == c->own_stream;
+    hipStream_t fresh = nullptr;
+    FYX_HIP(c, make_stream(c, true, &fresh));
+    FYX_HIP(c, hipStreamSynchronize(c->own_stream));
+    FYX_HIP(c, hipStreamDestroy(c->own_stream));
+    c->own_stream = fresh;
+    if (own_current) c->stream = fresh;
     c->primary_dirty = true;
     return FYX_OK;
 }
@@ -71,8 +142,8 @@ int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
     const int w = c->next_worker;
     c->next_worker = (w + 1) % c->n_workers;
     if (!c->workers[w]) {
-        FYX_HIP(c, hipStreamCreateWithFlags(&c->workers[w], hipStreamNonBlocking));
-        FYX_HIP(c, hipEventCreateWithFlags(&c->worker_done[w], hipEventDisableTiming));
+        FYX_HIP(c, make_stream(c, false, &c->workers[w]));
+        if (!c->worker_done[w]) FYX_HIP(c, hipEventCreateWithFlags(&c->worker_done[w], hipEventDisableTiming));
     }
     if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     if (c->primary_dirty || c->stream != c->own_stream) {  // a borrowed stream may have foreign work
@@ -85,6 +156,7 @@ int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
         c->worker_seen[w] = c->fork_gen;
     }
     c->worker_busy[w] = true;
+    ++c->worker_launches[w];
     *out = c->workers[w];
     return FYX_OK;
 }
@@ -102,21 +174,23 @@ void free_ctrl(CtrlBuffers& B) {
 int ctrl_acquire(fyx_ctx* c, CtrlBuffers& B, size_t total, int* slot_out, char** h, char** d) {
     const int slot = B.next;
     B.next ^= 1;
-    if (B.h_busy[slot]) {
-        FYX_HIP(c, hipEventSynchronize(B.h_ev[slot]));
+    if (B.h_busy[slot]) {      // the copy out of the staging block: its own event, or the event behind the kernels that followed it
+        FYX_HIP(c, hipEventSynchronize(B.h_by_consumed[slot] ? B.d_consumed[slot] : B.h_ev[slot]));
         B.h_busy[slot] = false;
     }
     if (total > B.h_bytes[slot]) {
         if (B.h[slot]) FYX_HIP(c, hipHostFree(B.h[slot]));
         B.h[slot] = nullptr;
         const size_t want = align_up(total + total / 2, 4096);
-        FYX_HIP(c, hipHostMalloc(&B.h[slot], want, hipHostMallocDefault));
+        // coherent (fine-grained): what the host has written is what a kernel reading the block directly sees (anim.ctrl_upload = 2)
+        FYX_HIP(c, hipHostMalloc(&B.h[slot], want, hipHostMallocCoherent));
         B.h_bytes[slot] = want;
     }
     if (!B.h_ev[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.h_ev[slot], hipEventDisableTiming));
     if (total > B.d_bytes[slot]) {
         if (int rc = enter_primary(c)) return rc;            // whoever still reads the old block, on any launch stream
         FYX_HIP(c, hipStreamSynchronize(c->stream));
+        if (B.d_in_use[slot] && B.d_consumer[slot] && B.d_consumer[slot] != c->stream) FYX_HIP(c, hipEventSynchronize(B.d_consumed[slot]));
         if (B.d[slot]) (void)hipFree(B.d[slot]);
         B.d[slot] = nullptr;
         const size_t want = align_up(total + total / 2, 4096);
@@ -125,28 +199,46 @@ int ctrl_acquire(fyx_ctx* c, CtrlBuffers& B, size_t total, int* slot_out, char**
         B.d_in_use[slot] = false;
     }
     if (!B.d_consumed[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.d_consumed[slot], hipEventDisableTiming));
-    if (!c->upload_stream) FYX_HIP(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
     *slot_out = slot;
     *h = static_cast<char*>(B.h[slot]);
     *d = static_cast<char*>(B.d[slot]);
     return FYX_OK;
 }
 
-// The control block has no dependence on the kernels already queued on the context stream (the previous frame's
-// skinning, typically ~100 us of work), so it travels on its own stream and only the frame's first kernel waits for
-// it; in-stream it would sit behind that work and add its ~25 us to every frame.
+// How the control block travels (option anim.ctrl_upload):
+//   0  its own stream: the block has no dependence on the kernels already queued on the consuming stream (on ONE stream that is the
+//      previous frame's skinning, ~100 us of work), so it travels beside them and only the frame's first kernel waits for it --
+//      a copy, two event records and two stream waits per frame on the host's clock;
+//   1  a copy on the consuming stream itself, 2 a copy KERNEL there that reads the pinned block directly (a launch instead of a
+//      copy command): no event, no wait -- the order is the stream's, and the staging block is free again when the event behind
+//      the frame's kernels (ctrl_consumed) is.  Right when the consuming stream carries only pose work (anim.overlap: the
+//      skinning is on the launch streams) or short frames.
 int ctrl_upload(fyx_ctx* c, CtrlBuffers& B, int slot, size_t total, hipStream_t consumer) {
-    if (B.d_in_use[slot]) FYX_HIP(c, hipStreamWaitEvent(c->upload_stream, B.d_consumed[slot], 0));
-    FYX_HIP(c, hipMemcpyAsync(B.d[slot], B.h[slot], total, hipMemcpyHostToDevice, c->upload_stream));
-    FYX_HIP(c, hipEventRecord(B.h_ev[slot], c->upload_stream));
-    FYX_HIP(c, hipStreamWaitEvent(consumer ? consumer : c->stream, B.h_ev[slot], 0));
+    hipStream_t cs = consumer ? consumer : c->stream;
+    if (c->ctrl_mode == 0) {
+        if (!c->upload_stream) FYX_HIP(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+        if (B.d_in_use[slot]) FYX_HIP(c, hipStreamWaitEvent(c->upload_stream, B.d_consumed[slot], 0));
+        FYX_HIP(c, hipMemcpyAsync(B.d[slot], B.h[slot], total, hipMemcpyHostToDevice, c->upload_stream));
+        FYX_HIP(c, hipEventRecord(B.h_ev[slot], c->upload_stream));
+        FYX_HIP(c, hipStreamWaitEvent(cs, B.h_ev[slot], 0));
+        B.h_busy[slot] = true;
+        B.h_by_consumed[slot] = false;
+        return FYX_OK;
+    }
+    // the block's last readers ran on another stream (fyx_set_stream in between): order behind them
+    if (B.d_in_use[slot] && B.d_consumer[slot] != cs) FYX_HIP(c, hipStreamWaitEvent(cs, B.d_consumed[slot], 0));
+    if (c->ctrl_mode == 2) FYX_HIP(c, fyx::launch_ctrl_copy(B.h[slot], B.d[slot], total, cs));
+    else FYX_HIP(c, hipMemcpyAsync(B.d[slot], B.h[slot], total, hipMemcpyHostToDevice, cs));
     B.h_busy[slot] = true;
+    B.h_by_consumed[slot] = true;     // ctrl_consumed follows every upload
     return FYX_OK;
 }
 
 int ctrl_consumed(fyx_ctx* c, CtrlBuffers& B, int slot, hipStream_t consumer) {
-    FYX_HIP(c, hipEventRecord(B.d_consumed[slot], consumer ? consumer : c->stream));
+    hipStream_t cs = consumer ? consumer : c->stream;
+    FYX_HIP(c, hipEventRecord(B.d_consumed[slot], cs));
     B.d_in_use[slot] = true;
+    B.d_consumer[slot] = cs;
     return FYX_OK;
 }
 
@@ -449,8 +541,10 @@ int run_batch_plan(fyx_ctx* c, BatchPlan& P) {
             if (int rc = ctrl_upload(c, B.ctrl, slot, total, st)) return rc;
             B.last.swap(B.build);
             B.last_slot = slot;
-        } else if (B.ctrl.h_busy[slot]) {
+        } else if (B.ctrl.h_busy[slot] && !B.ctrl.h_by_consumed[slot]) {
             FYX_HIP(c, hipStreamWaitEvent(st, B.ctrl.h_ev[slot], 0));   // a borrowed stream may have changed since the upload
+        } else if (B.ctrl.d_in_use[slot] && B.ctrl.d_consumer[slot] != st) {
+            FYX_HIP(c, hipStreamWaitEvent(st, B.ctrl.d_consumed[slot], 0));   // (in-stream upload: the event behind its first readers covers it)
         }
         const char* d = static_cast<const char*>(B.ctrl.d[slot]);
         for (int k = 1; k < 8; ++k) {
@@ -490,7 +584,7 @@ int fyx_init(fyx_ctx** out_ctx, int device_ordinal) {
     if (hipSetDevice(device_ordinal) != hipSuccess) return FYX_ERR_NO_DEVICE;
     fyx_ctx* c = new fyx_ctx();
     c->device = device_ordinal;
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (make_stream(c, true, &c->own_stream) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->aabb_partials), (6 * 2048 + 8) * sizeof(float)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_u32), 64) != hipSuccess) {
         fyx_shutdown(c);
@@ -523,6 +617,9 @@ void fyx_shutdown(fyx_ctx* c) {
         if (c->workers[w]) { (void)hipStreamSynchronize(c->workers[w]); (void)hipStreamDestroy(c->workers[w]); }
         if (c->worker_done[w]) (void)hipEventDestroy(c->worker_done[w]);
     }
+    for (int k = 0; k < 2; ++k)
+        for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w)
+            if (c->lag_ev[k][w]) (void)hipEventDestroy(c->lag_ev[k][w]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -580,6 +677,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd")) return &c->lbs.crowd;
     if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
     if (!strcmp(key, "lbs.crowd_lean")) return &c->lbs.crowd_lean;
+    if (!strcmp(key, "lbs.crowd_form")) return &c->lbs.crowd_form;
     if (!strcmp(key, "lbs.timing")) return &c->timing;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
     if (!strcmp(key, "comm.form")) return &c->comm_form;
@@ -588,6 +686,10 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "anim.overlap")) return &c->pose_overlap;
     if (!strcmp(key, "anim.inline_ctrl")) return &c->inline_ctrl;
     if (!strcmp(key, "anim.sample_form")) return &c->sample_form;
+    if (!strcmp(key, "anim.update_lean")) return &c->upd_lean;
+    if (!strcmp(key, "anim.ctrl_upload")) return &c->ctrl_mode;
+    if (!strcmp(key, "streams.priority")) return &c->stream_priority;
+    if (!strcmp(key, "streams.pose_cus")) return &c->pose_cus;
     return nullptr;
 }
 
@@ -614,6 +716,18 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");
     if (slot == &c->lbs.blocks_per_cu && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.blocks_per_cu must be 1..64");
+    if (slot == &c->ctrl_mode && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.ctrl_upload must be 0 (upload stream), 1 (copy in stream) or 2 (copy kernel)");
+    if (slot == &c->stream_priority && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "streams.priority must be 0 or 1");
+    if (slot == &c->pose_cus && (value < 0 || value >= fyx::kCUs || (value & 7))) return fail(c, FYX_ERR_INVALID_ARG, "streams.pose_cus must be 0 or a multiple of 8 below %d", fyx::kCUs);
+    if (slot == &c->upd_lean && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_lean must be 0 or 1");
+    if ((slot == &c->stream_priority || slot == &c->pose_cus) && *slot != value) {
+        const int old = *slot;
+        *slot = value;
+        if (int rc = recreate_streams(c)) { *slot = old; return rc; }
+        return FYX_OK;
+    }
+    if (slot == &c->pose_overlap && *slot != value && c->device >= 0)
+        if (int rc = enter_primary(c)) return rc;      // switching the mode joins everything once
     *slot = value;
     return FYX_OK;
 }

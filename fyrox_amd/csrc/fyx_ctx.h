@@ -42,6 +42,8 @@ struct CtrlBuffers {
     size_t d_bytes[2] = {0, 0};
     hipEvent_t d_consumed[2] = {nullptr, nullptr};   // the kernels that read d[slot] have finished
     bool d_in_use[2] = {false, false};
+    hipStream_t d_consumer[2] = {nullptr, nullptr};  // the stream d_consumed[slot] was recorded on
+    bool h_by_consumed[2] = {false, false};          // the staging block is free when d_consumed[slot] is (in-stream copies: no event of its own)
     void* h[2] = {nullptr, nullptr};
     size_t h_bytes[2] = {0, 0};
     hipEvent_t h_ev[2] = {nullptr, nullptr};
@@ -82,6 +84,19 @@ struct fyx_ctx {
     hipEvent_t worker_done[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
     bool worker_busy[kMaxWorkers] = {false, false, false, false};
     uint64_t worker_seen[kMaxWorkers] = {0, 0, 0, 0};
+    // anim.overlap: the skinning launches of frame n - 2 are what frame n's pose update has to wait for (it rewrites the palette
+    // buffer they read; the caller alternates TWO palette buffers) -- not those of frame n - 1, beside which it is meant to run.
+    // Every pose entry marks "the launches so far" on each busy worker and waits for the marks of the entry before (see enter_pose).
+    hipEvent_t lag_ev[2][kMaxWorkers] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    bool lag_has[2][kMaxWorkers] = {{false, false, false, false}, {false, false, false, false}};
+    int lag_cur = 0;
+    uint64_t worker_launches[kMaxWorkers] = {0, 0, 0, 0}, worker_marked[kMaxWorkers] = {0, 0, 0, 0};   // launches made on a worker / covered by its last mark
+    int stream_priority = 1; // option "streams.priority": 1 = the context's own stream (the pose path: short latency-bound kernels) is created
+                             //   with the highest priority, the launch streams (skinning: long bandwidth-bound kernels) with the lowest
+    int pose_cus = 0;        // option "streams.pose_cus": N > 0 = the context's own stream may only use N CUs (spread over the XCDs) and the
+                             //   launch streams only the other 256 - N (hipExtStreamCreateWithCUMask); 0 = no masks
+    int ctrl_mode = 1;       // option "anim.ctrl_upload": how a control block travels -- 0 its own upload stream + events, 1 a copy on the
+                             //   consuming stream, 2 a copy kernel on the consuming stream reading the pinned block
     hipEvent_t fork_ev = nullptr;
     uint64_t fork_gen = 0;
     bool primary_dirty = true;  // context-stream work enqueued since the last fork event
@@ -93,6 +108,7 @@ struct fyx_ctx {
     int sample_form = 0;     // option "anim.sample_form": 0 auto, 1 curves on the lanes, 2 instances on the lanes
     int pose_overlap = 0;    // option "anim.overlap": 1 = pose updates do not wait for in-flight skinning launches (see enter_pose)
     int inline_ctrl = 1;     // option "anim.inline_ctrl": 1 = a control block of <= 1 KB travels in the kernel arguments (no H2D copy)
+    int upd_lean = 1;        // option "anim.update_lean": 1 = frames whose fold programs are all straight run the update kernel without the interpreter
     int plan_split = 2048;   // option "anim.split": instances per planning task
     fyx::PlanPool* plan_pool = nullptr;
     fyx::SkinBatch* skin_batch = nullptr;

@@ -15,6 +15,7 @@ struct LbsTuning {
     int crowd = -1;          // instanced launches: -1 auto (crowd kernel from 4 instances), 0 never, 1 always
     int crowd_lean = 0;      // 1: register-lean crowd kernel at two workgroups per CU (leaves room for other kernels' waves, see lbs_kernels.hip)
     int crowd_ipb = 0;       // instances per workgroup run; 0 = auto
+    int crowd_form = 0;      // experiment forms of the exact crowd kernel (lbs_kernels.hip launch_crowd_one); 0 = product
     int dyn = 1;             // large single-instance launches: 1 = lbs_skin_dyn (units drawn from an LDS ticket counter), 0 = lbs_skin
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // option lbs.timing: this launch's own start / stop events (dispatch timestamps)
 };
@@ -133,6 +134,9 @@ hipError_t launch_points_aabb(const float* d_xyz, uint64_t n_points, float* d_pa
 // out[i] = a[i] * b[i] (mat4, nalgebra operation order)
 hipError_t launch_palette(const float* d_global, const float* d_inv_bind, uint32_t n,
                           float* d_out, hipStream_t stream);
+
+// control blocks: copies `bytes` (rounded up to 16: both blocks are padded) from a pinned, device-visible host block to device memory
+hipError_t launch_ctrl_copy(const void* h_src, void* d_dst, size_t bytes, hipStream_t stream);
 
 // calibration: read 48*units bytes from d_src, write 32*units bytes to d_dst
 hipError_t launch_stream_copy(const float* d_src, float* d_dst, uint32_t units, int blocks_per_cu,
@@ -370,12 +374,18 @@ struct SceneJobShape {   // what the tables depend on
 void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&tables)[kSceneStages]);
 // One launch per non-empty stage.  d_tables[k] / n_blocks[k]: the device copy of stage k's table; lds_bytes[k]: dynamic
 // LDS of the update stages (the largest rig of the stage).
+// all_straight: every fold program of every job is straight (classify_fold_program, anim_leaves.h): the update stages run
+// the kernel form without the interpreter.
 hipError_t launch_scene(const SceneJobDev* d_jobs, const uint4* const (&d_tables)[kSceneStages],
-                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], hipStream_t s);
+                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, hipStream_t s);
 
 // `inl` (optional): the frame's control block travelling in the kernel arguments, see CtrlInline.
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);
-hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, bool run_program, hipStream_t s, const CtrlInline* inl = nullptr);
+// mode: kUpdNoProgram -- the transforms as they are; kUpdGeneral -- fold programs of any shape; kUpdStraight -- the caller
+// has classified EVERY instance's program as straight (classify_fold_program_host, anim_leaves.h): a kernel without the
+// interpreter (a third of the registers).
+enum : int { kUpdNoProgram = 0, kUpdGeneral = 1, kUpdStraight = 2 };
+hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl = nullptr);
 // Animation::update_root_motion for every ticked animation that has settings (after pose_sample:
 // rewrites the root node's pose record), then the per-instance root-motion program (machine mode).
 hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s, const CtrlInline* inl = nullptr);

@@ -79,16 +79,10 @@ def test_pose_and_palette_kernels_contain_no_contracted_multiply_add(stats):
 
 
 def test_kernels_do_not_spill(stats):
-    """No kernel keeps registers in scratch memory -- with one known exception: the scene form of the update kernel
-    (pose_update_scene_kernel: the fold interpreter's 256 VGPRs plus the job record it reads from memory instead of from
-    kernel arguments) reloads a few values (168 bytes of scratch, a handful of loads outside the per-op loop).  The
-    exception is pinned so that it cannot grow unnoticed."""
+    """No kernel keeps registers in scratch memory.  (Until round 4 the scene form of the update kernel did: it indexed a register
+    copy of its job's palette outputs with a loop counter; it now reads them where they lie.)"""
     for name, c in stats.items():
-        n = c["scratch"]
-        if name == "fyx::pose_update_scene_kernel":
-            assert n <= 24, (name, n)
-        else:
-            assert n == 0, (name, "register spills")
+        assert c["scratch"] == 0, (name, "register spills")
 
 
 def test_register_budgets_behind_the_measured_occupancies():
@@ -102,8 +96,11 @@ def test_register_budgets_behind_the_measured_occupancies():
         pytest.skip("llvm-readelf of the ROCm toolchain is not here")
     res = isa_stats.kernel_resources(LIB)
     budget = {"fyx::lbs_skin_dyn<true, 7>": 128, "fyx::lbs_skin<true, 7>": 128,
-              "fyx::lbs_skin_batch<true, 7>": 128, "fyx::lbs_skin_crowd<512, true, 7, false>": 128,
-              "fyx::lbs_skin_crowd<512, true, 7, true>": 80, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel<256u>": 64, "fyx::pose_sample_crowd_kernel<64u>": 64}
+              "fyx::lbs_skin_batch<true, 7>": 128, "fyx::lbs_skin_crowd<512, true, 7, false, 1>": 128,
+              "fyx::lbs_skin_crowd<512, true, 7, true, 1>": 80,
+              # the update kernel without the interpreter (every program of the frame straight): three waves per SIMD, and one of
+              # them fits into what ONE retiring workgroup of the crowd kernel frees on a SIMD (2 x 128) -- anim.overlap
+              "fyx::pose_update_kernel<2>": 176, "fyx::pose_update_scene_kernel<2>": 176, "fyx::pose_update_inl_kernel<2>": 176, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel<256u>": 64, "fyx::pose_sample_crowd_kernel<64u>": 64}
     for name, limit in budget.items():
         assert name in res, name
         assert res[name]["vgpr"] + res[name]["agpr"] <= limit, (name, res[name])
@@ -113,4 +110,6 @@ def test_register_budgets_behind_the_measured_occupancies():
             # ... except the vertex-buffer-out kernels with 32- and 40-byte output vertices, which hold a whole output
             # vertex per lane on top of the inputs: three waves per SIMD (<= 168)
             wide = name.startswith("fyx::lbs_skin_aos") and _targs(name)[2] in ("8u", "10u")
+            if name.startswith("fyx::lbs_skin_crowd") and _targs(name)[3:] == ["false", "2"]:
+                continue      # experiment form (lbs.crowd_form = 3): two vertices per thread with all rows live, one workgroup per CU
             assert r["vgpr"] + r["agpr"] <= (168 if wide else 128) and r["scratch_bytes"] == 0, (name, r)
