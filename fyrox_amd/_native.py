@@ -76,6 +76,7 @@ _SIGS = {
     "fyx_set_option": (c_int, [_P, c_char_p, c_int]),
     "fyx_get_option": (c_int, [_P, c_char_p, POINTER(c_int)]),
     "fyx_debug_kernel_time": (c_int, [_P, _P, _P]),
+    "fyx_debug_timeline": (c_int, [_P, _P, _P, _P, c_uint32, POINTER(c_uint32)]),
     "fyx_malloc": (c_int, [_P, c_size_t, POINTER(c_void_p)]),
     "fyx_free": (c_int, [_P, _P]),
     "fyx_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),

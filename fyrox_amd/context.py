@@ -124,6 +124,16 @@ class Context:
         self._check(self._l.fyx_debug_kernel_time(self._h, byref(us), byref(n)))
         return us.value, n.value
 
+    def timeline(self, capacity: int = 16384):
+        """(kinds, start_us, stop_us) of the launches made under option debug.timeline = 1 since the last call: kind 0 skinning,
+        1 pose_sample, 2 pose_update; times in microseconds after the first record's start."""
+        kinds = np.zeros(capacity, np.int32)
+        a, b = np.zeros(capacity, np.float64), np.zeros(capacity, np.float64)
+        n = ctypes.c_uint32()
+        self._check(self._l.fyx_debug_timeline(self._h, _ptr(kinds), _ptr(a), _ptr(b), capacity, byref(n)))
+        k = min(n.value, capacity)
+        return kinds[:k], a[:k], b[:k]
+
     def set_option(self, key: str, value: int) -> None:
         self._check(self._l.fyx_set_option(self._h, key.encode(), int(value)))
 

@@ -1023,10 +1023,11 @@ int fyx_animator_palette(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, fl
     if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
     if (bit->second.rig_id != A->rig_id) return fail(c, FYX_ERR_INVALID_ARG, "bone list belongs to another rig");
     if (!d_out) return fail(c, FYX_ERR_INVALID_ARG, "d_out_palette is null");
-    if (int rc = enter_pose(c)) return rc;
+    hipStream_t ps = nullptr;
+    if (int rc = enter_skin(c, &ps)) return rc;      // behind the frame's pose update, on its stream
     if (int rc = ensure_device_state(c, *A)) return rc;
     FYX_HIP(c, launch_palette_gather(A->d_global, A->rig->d_inv_bind, bit->second.d_bone_nodes, A->rig->n_nodes,
-                                     bit->second.n_bones, A->n_instances, d_out, c->stream));
+                                     bit->second.n_bones, A->n_instances, d_out, ps));
     return FYX_OK;
     FYX_GUARD_END(c)
 }

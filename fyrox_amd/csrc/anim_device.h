@@ -32,7 +32,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             FYX_HIP(c, hipMemcpyAsync(reinterpret_cast<char*>(A.d_node_trs) + (size_t)i * rig.n_nodes * 48,
                                       rig.init_trs.data(), (size_t)rig.n_nodes * 48, hipMemcpyHostToDevice,
                                       c->stream));
-        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        if (int rc_ = sync_all(c)) return rc_;
     }
     const uint32_t na = (uint32_t)A.anims.size();
     if (na > A.dev_anim_capacity || A.max_tracks > A.dev_track_capacity) {
@@ -40,7 +40,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         const uint32_t new_cap = std::max(na, A.dev_anim_capacity);
         const uint32_t new_tracks = std::max(A.max_tracks, A.dev_track_capacity);
         DevGuard np, nh;
-        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        if (int rc_ = sync_all(c)) return rc_;
         FYX_HIP(c, hipMalloc(&np.p, std::max<size_t>((size_t)new_cap * in * 48, 16)));
         FYX_HIP(c, hipMemset(np.p, 0, std::max<size_t>((size_t)new_cap * in * 48, 16)));
         const size_t hb = std::max<size_t>((size_t)new_cap * A.n_instances * std::max(new_tracks, 1u) * 16, 16);
@@ -66,7 +66,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
     bool any_slots = false;
     for (AnimationDef& an : A.anims) any_slots |= an.slots_dirty;
     if (any_slots || A.anims_dirty) {
-        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        if (int rc_ = sync_all(c)) return rc_;
         std::vector<AnimDev> hd(na);
         for (uint32_t a = 0; a < na; ++a) {
             AnimationDef& an = A.anims[a];
@@ -153,7 +153,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
     const uint32_t nps = (uint32_t)A.prop_slots.size();
     if (nps && (A.dev_prop_slots != nps || A.dev_prop_anims < A.dev_anim_capacity)) {
         // property storage is re-created when slots or animations are added (values applied so far are kept per slot)
-        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        if (int rc_ = sync_all(c)) return rc_;
         std::vector<int32_t> nodes(nps);
         for (uint32_t k = 0; k < nps; ++k) nodes[k] = A.prop_slots[k].first;
         dfree(A.d_prop_node);
@@ -189,7 +189,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         if (A.dev_rm_anim_capacity < A.dev_anim_capacity) {  // [anim][instance]: growing keeps the existing prefix
             DevGuard nr;
             const size_t nb = (size_t)A.dev_anim_capacity * A.n_instances * sizeof(RootMotionDev);
-            FYX_HIP(c, hipStreamSynchronize(c->stream));
+            if (int rc_ = sync_all(c)) return rc_;
             FYX_HIP(c, hipMalloc(&nr.p, std::max<size_t>(nb, 16)));
             FYX_HIP(c, hipMemset(nr.p, 0, std::max<size_t>(nb, 16)));
             if (A.d_rm_anim && A.dev_rm_anim_capacity)
@@ -208,7 +208,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         std::vector<uint32_t> nodes_now(A.layers.size());
         for (size_t l = 0; l < A.layers.size(); ++l) { nodes_now[l] = (uint32_t)A.layers[l].nodes.size(); want += nodes_now[l] + 1; }
         if (want != A.dev_rm_slots || nodes_now != A.dev_rm_layer_nodes) {
-            FYX_HIP(c, hipStreamSynchronize(c->stream));
+            if (int rc_ = sync_all(c)) return rc_;
             DevGuard ns;
             const size_t nb = (size_t)A.n_instances * want * 32;
             FYX_HIP(c, hipMalloc(&ns.p, nb));
@@ -238,7 +238,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         }
     }
     if (A.masks_dirty || A.dev_mask_layers != A.layers.size()) {
-        FYX_HIP(c, hipStreamSynchronize(c->stream));
+        if (int rc_ = sync_all(c)) return rc_;
         std::vector<uint8_t> m(std::max<size_t>(A.layers.size() * rig.n_nodes, 1), 0);
         for (size_t l = 0; l < A.layers.size(); ++l)
             for (int32_t n : A.layers[l].excluded)
@@ -358,7 +358,8 @@ int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
 
 // Send the planned frame to the GPU and run sample + update.
 int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
-    if (int rc = enter_pose(c)) return rc;
+    hipStream_t ps = nullptr;     // the frame's stream (anim.overlap: frames alternate between two)
+    if (int rc = enter_pose(c, &ps)) return rc;
     if (int rc = ensure_device_state(c, A)) return rc;
     PoseFrameDev f;
     frame_static(c, A, f);
@@ -381,22 +382,26 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
             char *h = nullptr, *d = nullptr;
             if (int rc = ctrl_acquire(c, A.ctrl, L.total, &slot, &h, &d)) return rc;
             ctrl_write(A, L, h);
-            if (int rc = ctrl_upload(c, A.ctrl, slot, L.total)) return rc;
+            if (int rc = ctrl_upload(c, A.ctrl, slot, L.total, ps)) return rc;
             ctrl_bind(A, L, d, f);
         }
-        FYX_HIP(c, launch_pose_sample(f, c->stream, &inl));
-        FYX_HIP(c, launch_property_sample(f, c->stream, &inl));
-        if (L.rm) FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), c->stream, &inl));
+        if (int rc = timeline_arm(c, 1)) return rc;
+        FYX_HIP(c, launch_pose_sample(f, ps, &inl));
+        g_launch_events = LaunchEvents();
+        FYX_HIP(c, launch_property_sample(f, ps, &inl));
+        if (L.rm) FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), ps, &inl));
     }
     RigDev rd;
     if (int rc = rig_params(c, A, rd)) return rc;
-    FYX_HIP(c, launch_pose_update(f, rd, !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral, c->stream, &inl));
+    if (int rc = timeline_arm(c, 2)) return rc;
+    FYX_HIP(c, launch_pose_update(f, rd, !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral, ps, &inl));
+    g_launch_events = LaunchEvents();
     if (with_program) {
-        FYX_HIP(c, launch_property_update(f, c->stream, &inl));
+        FYX_HIP(c, launch_property_update(f, ps, &inl));
         if (!in_args)
-            if (int rc = ctrl_consumed(c, A.ctrl, slot)) return rc;
+            if (int rc = ctrl_consumed(c, A.ctrl, slot, ps)) return rc;
     }
-    return FYX_OK;
+    return exit_pose(c);
 }
 
 // One frame of MANY animators (fyx_scene_update): every animator is planned exactly as plan_frame does (different
@@ -467,7 +472,8 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     if (int rc = scene_plan(c, S, dt)) return rc;
 
     // 2. device state, and the block tables if the scene's shape changed
-    if (int rc = enter_pose(c)) return rc;
+    hipStream_t ps = nullptr;
+    if (int rc = enter_pose(c, &ps)) return rc;
     std::vector<uint64_t> sig;
     sig.reserve(n * 3 + 1);
     sig.push_back((uint64_t)c->sample_form);
@@ -496,7 +502,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
             S.lds_bytes[k] = lds[k];
             total += tables[k].size();
         }
-        FYX_HIP(c, hipStreamSynchronize(c->stream));   // the previous scene's launches still read the old tables
+        if (int rc_ = sync_all(c)) return rc_;   // the previous scene's launches still read the old tables
         dfree(S.d_tables);
         S.d_tables = nullptr;
         S.signature.clear();
@@ -527,15 +533,16 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         ctrl_bind(A, S.layouts[k], d + S.offsets[k], jobs[k].f);
         if (int rc = rig_params(c, A, jobs[k].rig)) return rc;
     }
-    if (int rc = ctrl_upload(c, S.ctrl, slot, total)) return rc;
+    if (int rc = ctrl_upload(c, S.ctrl, slot, total, ps)) return rc;
 
     // 4. one launch per stage
     const uint4* tabs[kSceneStages];
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
     bool all_straight = c->upd_lean != 0;
     for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
-    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(d), tabs, S.n_blocks, S.lds_bytes, all_straight, c->stream));
-    return ctrl_consumed(c, S.ctrl, slot);
+    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(d), tabs, S.n_blocks, S.lds_bytes, all_straight, ps));
+    if (int rc = ctrl_consumed(c, S.ctrl, slot, ps)) return rc;
+    return exit_pose(c);
 }
 
 template <typename F>

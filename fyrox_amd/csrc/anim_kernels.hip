@@ -31,7 +31,19 @@
 #include "../../include/fyrox_hip.h"
 #include "anim_leaves.h"   // lerpf_, cubicf_, interpolate_loaded, span_track_value_at, classify_fold_program (host + device)
 
+#include <hip/hip_ext.h>
+
 namespace fyx {
+
+thread_local LaunchEvents g_launch_events;
+// a launch that takes the armed timeline events, if any (option debug.timeline)
+#define FYX_TL_LAUNCH(kernel, grid, block, lds, s, ...)                                                                      \
+    do {                                                                                                                      \
+        if (g_launch_events.start) {                                                                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, s, g_launch_events.start, g_launch_events.stop, 0, __VA_ARGS__);  \
+            g_launch_events = LaunchEvents();                                                                                 \
+        } else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                                                  \
+    } while (0)
 
 // (LP / AP: pointers to the key locations / {value, kind, tangents} records -- global memory, or LDS where the crowd
 // sampler has staged the curve)
@@ -544,11 +556,11 @@ hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlIn
     if (f.n_instances > 65535u || f.n_anims > 65535u || f.n_nodes * 3u > 65535u) return hipErrorInvalidValue;   // grid limits
     if (f.sample_form == 2 || (f.sample_form == 0 && f.n_instances >= 32)) {
         if (f.n_instances > 64u)
-            hipLaunchKernelGGL(pose_sample_crowd_kernel<256>, dim3((f.n_instances + 255) / 256, f.n_nodes * 3, f.n_anims), dim3(256), 0, s, f, inl ? *inl : kNoInline);
+            FYX_TL_LAUNCH(pose_sample_crowd_kernel<256>, dim3((f.n_instances + 255) / 256, f.n_nodes * 3, f.n_anims), dim3(256), 0, s, f, inl ? *inl : kNoInline);
         else
             hipLaunchKernelGGL(pose_sample_crowd_kernel<64>, dim3(1, f.n_nodes * 3, f.n_anims), dim3(64), 0, s, f, inl ? *inl : kNoInline);
     } else {
-        hipLaunchKernelGGL(pose_sample_kernel, dim3((f.n_nodes * 16 + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f, inl ? *inl : kNoInline);
+        FYX_TL_LAUNCH(pose_sample_kernel, dim3((f.n_nodes * 16 + 255) / 256, f.n_instances, f.n_anims), dim3(256), 0, s, f, inl ? *inl : kNoInline);
     }
     return hipGetLastError();
 }
@@ -1494,7 +1506,7 @@ static hipError_t launch_update_one(K kernel, uint32_t grid, uint32_t block, siz
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, args...);
+    FYX_TL_LAUNCH(kernel, dim3(grid), dim3(block), lds, s, args...);
     return hipGetLastError();
 }
 

@@ -26,6 +26,11 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Make the context stream wait for every in-flight worker launch (GPU-side join, no host wait).
 int join_workers(fyx_ctx* c) {
+    if (c->alt_busy) {
+        FYX_HIP(c, hipEventRecord(c->alt_done, c->alt_stream));
+        FYX_HIP(c, hipStreamWaitEvent(c->stream, c->alt_done, 0));
+        c->alt_busy = false;
+    }
     for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
         if (!c->worker_busy[w]) continue;
         FYX_HIP(c, hipEventRecord(c->worker_done[w], c->workers[w]));
@@ -52,27 +57,62 @@ int enter_primary(fyx_ctx* c) {
     return rc;
 }
 
-int enter_pose(fyx_ctx* c) {
-    if (!c->pose_overlap) return enter_primary(c);
-    if (int rc = bind_device(c)) return rc;
-    // Frame n's pose update runs BESIDE frame n - 1's skinning launches and behind frame n - 2's (whose palette buffer it is about
-    // to rewrite): mark the launches made so far on every busy launch stream, wait for the marks of the previous pose entry.
-    const int cur = c->lag_cur, prev = cur ^ 1;
-    for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
-        if (c->lag_has[prev][w]) {
-            FYX_HIP(c, hipStreamWaitEvent(c->stream, c->lag_ev[prev][w], 0));
-            c->lag_has[prev][w] = false;
-        }
-        if (!c->worker_busy[w] || c->worker_launches[w] == c->worker_marked[w]) continue;   // nothing new on it since its last mark
-        if (!c->lag_ev[cur][w]) FYX_HIP(c, hipEventCreateWithFlags(&c->lag_ev[cur][w], hipEventDisableTiming));
-        FYX_HIP(c, hipEventRecord(c->lag_ev[cur][w], c->workers[w]));
-        c->lag_has[cur][w] = true;
-        c->worker_marked[w] = c->worker_launches[w];
-        // (the worker stays "busy": enter_primary still joins it)
-    }
-    c->lag_cur = prev;
-    c->primary_dirty = true;
+int sync_all(fyx_ctx* c) {
+    if (int rc = enter_primary(c)) return rc;
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
     return FYX_OK;
+}
+
+static hipError_t make_stream(fyx_ctx* c, bool pose, hipStream_t* out);
+
+int enter_pose(fyx_ctx* c, hipStream_t* out) {
+    if (!c->pose_overlap) {
+        *out = c->stream;
+        return enter_primary(c);
+    }
+    if (int rc = bind_device(c)) return rc;
+    const int idx = c->frame_idx ^ 1;
+    c->frame_idx = idx;
+    if (!c->alt_stream) {
+        FYX_HIP(c, make_stream(c, true, &c->alt_stream));
+        FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->pose_done[k], hipEventDisableTiming));
+    }
+    hipStream_t target = idx ? c->alt_stream : c->stream;
+    if (idx) {
+        // whatever other calls have put on the context stream since the last fork (uploads, copies, a borrowed stream's work)
+        if (c->primary_dirty || c->stream != c->own_stream) {
+            if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+            FYX_HIP(c, hipEventRecord(c->fork_ev, c->stream));
+            ++c->fork_gen;
+            c->primary_dirty = false;
+            FYX_HIP(c, hipStreamWaitEvent(target, c->fork_ev, 0));
+        }
+        c->alt_busy = true;
+    }
+    // behind the previous frame's pose update (the animators' persistent state: hints, pose records, node transforms)
+    if (c->pose_done_on >= 0 && c->pose_done_on != idx) FYX_HIP(c, hipStreamWaitEvent(target, c->pose_done[c->pose_done_on], 0));
+    *out = target;
+    return FYX_OK;
+}
+
+int exit_pose(fyx_ctx* c) {
+    if (!c->pose_overlap || !c->alt_stream) return FYX_OK;
+    const int idx = c->frame_idx;
+    FYX_HIP(c, hipEventRecord(c->pose_done[idx], idx ? c->alt_stream : c->stream));
+    c->pose_done_on = idx;
+    return FYX_OK;
+}
+
+int enter_skin(fyx_ctx* c, hipStream_t* out) {
+    if (c->pose_overlap && c->alt_stream) {
+        if (int rc = bind_device(c)) return rc;
+        *out = c->frame_idx ? c->alt_stream : c->stream;
+        if (c->frame_idx) c->alt_busy = true;
+        return FYX_OK;
+    }
+    *out = c->stream;
+    return enter_primary(c);
 }
 
 // The context's streams.  own_stream carries the pose path (a chain of short, latency-bound kernels), the launch streams the
@@ -116,8 +156,15 @@ static int recreate_streams(fyx_ctx* c) {
         c->workers[w] = nullptr;
         c->worker_busy[w] = false;
         c->worker_seen[w] = 0;
-        c->lag_has[0][w] = c->lag_has[1][w] = false;
-        c->worker_launches[w] = c->worker_marked[w] = 0;
+    }
+    if (c->alt_stream) {
+        FYX_HIP(c, hipStreamSynchronize(c->alt_stream));
+        FYX_HIP(c, hipStreamDestroy(c->alt_stream));
+        c->alt_stream = nullptr;
+        FYX_HIP(c, make_stream(c, true, &c->alt_stream));
+        c->alt_busy = false;
+        c->pose_done_on = -1;
+        c->frame_idx = 0;
     }
     const bool own_current = c->stream == c->own_stream;
     hipStream_t fresh = nullptr;
@@ -133,6 +180,7 @@ static int recreate_streams(fyx_ctx* c) {
 // Pick the stream for an independent skinning launch: a worker, ordered after everything that
 // was on the context stream at this moment (one fork event per batch of context-stream work).
 int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
+    if (c->pose_overlap && c->alt_stream) return enter_skin(c, out);    // the frame's own stream: behind its pose update, in order
     if (c->n_workers <= 1) {
         int rc = enter_primary(c);
         *out = c->stream;
@@ -156,7 +204,6 @@ int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
         c->worker_seen[w] = c->fork_gen;
     }
     c->worker_busy[w] = true;
-    ++c->worker_launches[w];
     *out = c->workers[w];
     return FYX_OK;
 }
@@ -253,6 +300,18 @@ void skin_batch_destroy(SkinBatch* b) {
     if (!b) return;
     free_ctrl(b->ctrl);
     delete b;
+}
+
+int timeline_arm(fyx_ctx* c, int kind) {
+    if (!c->timeline_on) return FYX_OK;
+    if (c->timeline.size() >= 16384) return fail(c, FYX_ERR_INVALID_ARG, "debug.timeline: read the records (fyx_debug_timeline) every 16384 launches");
+    fyx_ctx::TimelineRec r{kind, nullptr, nullptr};
+    FYX_HIP(c, hipEventCreate(&r.start));
+    FYX_HIP(c, hipEventCreate(&r.stop));
+    c->timeline.push_back(r);
+    fyx::g_launch_events.start = r.start;
+    fyx::g_launch_events.stop = r.stop;
+    return FYX_OK;
 }
 
 int ensure_scratch(fyx_ctx* c, size_t bytes) {
@@ -498,8 +557,8 @@ int run_batch_plan(fyx_ctx* c, BatchPlan& P) {
     SkinBatch& B = *c->skin_batch;
     // One launch that fills the chip: nothing to gain from a worker stream, and on the context stream the table
     // buffers have a single consumer to order their reuse against.
-    if (int sr = enter_primary(c)) return sr;
-    const hipStream_t st = c->stream;
+    hipStream_t st = nullptr;
+    if (int sr = enter_skin(c, &st)) return sr;
     struct Placed { size_t o_segs = 0, o_blocks = 0; uint32_t grid = 0; };
     Placed ps[8], pa[8];
     size_t total = 0;
@@ -613,13 +672,16 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->d_u32) (void)hipFree(c->d_u32);
     for (hipEvent_t e : c->timing_ev) (void)hipEventDestroy(e);
     c->timing_ev.clear();
+    for (const fyx_ctx::TimelineRec& r : c->timeline) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    c->timeline.clear();
     for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w) {
         if (c->workers[w]) { (void)hipStreamSynchronize(c->workers[w]); (void)hipStreamDestroy(c->workers[w]); }
         if (c->worker_done[w]) (void)hipEventDestroy(c->worker_done[w]);
     }
+    if (c->alt_stream) { (void)hipStreamSynchronize(c->alt_stream); (void)hipStreamDestroy(c->alt_stream); }
+    if (c->alt_done) (void)hipEventDestroy(c->alt_done);
     for (int k = 0; k < 2; ++k)
-        for (int w = 0; w < fyx_ctx::kMaxWorkers; ++w)
-            if (c->lag_ev[k][w]) (void)hipEventDestroy(c->lag_ev[k][w]);
+        if (c->pose_done[k]) (void)hipEventDestroy(c->pose_done[k]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -690,6 +752,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "anim.ctrl_upload")) return &c->ctrl_mode;
     if (!strcmp(key, "streams.priority")) return &c->stream_priority;
     if (!strcmp(key, "streams.pose_cus")) return &c->pose_cus;
+    if (!strcmp(key, "debug.timeline")) return &c->timeline_on;
     return nullptr;
 }
 
@@ -726,8 +789,11 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         if (int rc = recreate_streams(c)) { *slot = old; return rc; }
         return FYX_OK;
     }
-    if (slot == &c->pose_overlap && *slot != value && c->device >= 0)
+    if (slot == &c->pose_overlap && *slot != value && c->device >= 0) {
         if (int rc = enter_primary(c)) return rc;      // switching the mode joins everything once
+        c->frame_idx = 0;
+        c->pose_done_on = -1;
+    }
     *slot = value;
     return FYX_OK;
 }
@@ -915,7 +981,37 @@ int fyx_lbs_skin_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, ui
         if (mask && a.n_verts && a.n_instances) c->timing_used += 2;   // the pair is claimed only by a launch that recorded it
         return FYX_OK;
     }
+    if (c->timeline_on) {
+        if (int rc = timeline_arm(c, 0)) return rc;
+        fyx::LbsTuning t = c->lbs;
+        t.ev_start = fyx::g_launch_events.start;
+        t.ev_stop = fyx::g_launch_events.stop;
+        fyx::g_launch_events = fyx::LaunchEvents();
+        FYX_HIP(c, fyx::launch_lbs(a, t, st));
+        return FYX_OK;
+    }
     FYX_HIP(c, fyx::launch_lbs(a, c->lbs, st));
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_debug_timeline(fyx_ctx* c, int32_t* kinds, double* start_us, double* stop_us, uint32_t capacity, uint32_t* n_records) {
+    if (!c || !n_records) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    if (int rc = enter_primary(c)) return rc;
+    FYX_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t n = 0;
+    hipEvent_t base = c->timeline.empty() ? nullptr : c->timeline.front().start;
+    for (const fyx_ctx::TimelineRec& r : c->timeline) {
+        float a = 0.f, b = 0.f;
+        // a pair that never got its timestamps (a launch that launched nothing) is skipped
+        if (hipEventElapsedTime(&a, base, r.start) != hipSuccess || hipEventElapsedTime(&b, base, r.stop) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (n < capacity && kinds && start_us && stop_us) { kinds[n] = r.kind; start_us[n] = (double)a * 1e3; stop_us[n] = (double)b * 1e3; }
+        ++n;
+    }
+    *n_records = n;
+    for (const fyx_ctx::TimelineRec& r : c->timeline) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    c->timeline.clear();
     return FYX_OK;
     FYX_GUARD_END(c)
 }

@@ -84,19 +84,26 @@ struct fyx_ctx {
     hipEvent_t worker_done[kMaxWorkers] = {nullptr, nullptr, nullptr, nullptr};
     bool worker_busy[kMaxWorkers] = {false, false, false, false};
     uint64_t worker_seen[kMaxWorkers] = {0, 0, 0, 0};
-    // anim.overlap: the skinning launches of frame n - 2 are what frame n's pose update has to wait for (it rewrites the palette
-    // buffer they read; the caller alternates TWO palette buffers) -- not those of frame n - 1, beside which it is meant to run.
-    // Every pose entry marks "the launches so far" on each busy worker and waits for the marks of the entry before (see enter_pose).
-    hipEvent_t lag_ev[2][kMaxWorkers] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
-    bool lag_has[2][kMaxWorkers] = {{false, false, false, false}, {false, false, false, false}};
-    int lag_cur = 0;
-    uint64_t worker_launches[kMaxWorkers] = {0, 0, 0, 0}, worker_marked[kMaxWorkers] = {0, 0, 0, 0};   // launches made on a worker / covered by its last mark
-    int stream_priority = 1; // option "streams.priority": 1 = the context's own stream (the pose path: short latency-bound kernels) is created
+    // anim.overlap: whole frames alternate between TWO streams -- frame n (its control block, pose kernels and the skinning launches
+    // that follow) runs in order on stream n & 1 (0: the context stream, 1: alt_stream), so that frame n + 1's pose update runs
+    // beside frame n's skinning.  The only cross-stream edge of a frame is "behind the previous frame's pose update" (pose_done);
+    // everything else a frame depends on -- frame n - 2's skinning, which read the palette buffer it rewrites -- lies earlier on
+    // its own stream.  See enter_pose.
+    hipStream_t alt_stream = nullptr;
+    hipEvent_t alt_done = nullptr;       // join: the context stream waits for what is on alt_stream
+    bool alt_busy = false;
+    int frame_idx = 0;                   // the stream the current frame runs on
+    hipEvent_t pose_done[2] = {nullptr, nullptr};   // recorded behind a frame's last pose kernel, one per stream
+    int pose_done_on = -1;               // stream of the last pose update, -1: none yet
+    int stream_priority = 0; // option "streams.priority": 1 = the context's own stream (the pose path: short latency-bound kernels) is created
                              //   with the highest priority, the launch streams (skinning: long bandwidth-bound kernels) with the lowest
     int pose_cus = 0;        // option "streams.pose_cus": N > 0 = the context's own stream may only use N CUs (spread over the XCDs) and the
                              //   launch streams only the other 256 - N (hipExtStreamCreateWithCUMask); 0 = no masks
     int ctrl_mode = 1;       // option "anim.ctrl_upload": how a control block travels -- 0 its own upload stream + events, 1 a copy on the
                              //   consuming stream, 2 a copy kernel on the consuming stream reading the pinned block
+    int timeline_on = 0;     // option "debug.timeline": pose_sample / pose_update / fyx_lbs_skin_device launches carry their own events
+    struct TimelineRec { int kind; hipEvent_t start, stop; };
+    std::vector<TimelineRec> timeline;       // in launch order (fyx_debug_timeline reads and clears)
     hipEvent_t fork_ev = nullptr;
     uint64_t fork_gen = 0;
     bool primary_dirty = true;  // context-stream work enqueued since the last fork event
@@ -122,12 +129,22 @@ size_t align_up(size_t x, size_t a);
 int join_workers(fyx_ctx* c);
 int bind_device(fyx_ctx* c);      // hipSetDevice(ctx's device) for the calling thread
 int enter_primary(fyx_ctx* c);
-// Entry of the pose path (fyx_*_update, fyx_scene_update, fyx_animator_palette).  Default: enter_primary.  With option
-// anim.overlap = 1 the in-flight skinning launches of the worker streams are NOT joined first, so frame n+1's pose
-// kernels (latency-bound, a few waves per CU) run under frame n's skinning (bandwidth-bound); the pose path touches
-// nothing a skinning launch reads except the palette buffers it is told to write, which the caller then alternates.
-int enter_pose(fyx_ctx* c);
+// Host-side wait for everything the context has in flight on any of its streams.
+int sync_all(fyx_ctx* c);
+// Entry of the pose path (fyx_*_update, fyx_scene_update, fyx_animator_palette); *out = the stream its work goes to.  Default:
+// enter_primary and the context stream.  With option anim.overlap = 1 a pose update starts a new FRAME on the other of the
+// context's two frame streams (see fyx_ctx::alt_stream): frame n + 1's pose kernels (latency-bound, a few waves per CU) run
+// beside frame n's skinning (bandwidth-bound).  The pose path touches nothing a skinning launch reads except the palette
+// buffers it is told to write, which the caller therefore alternates: a pose update must not be given a palette buffer that
+// a skinning launch issued since the previous pose update reads.
+int enter_pose(fyx_ctx* c, hipStream_t* out);
+// Behind the last pose kernel of the entry: the next pose entry (on the other stream, under anim.overlap) orders itself behind this point.
+int exit_pose(fyx_ctx* c);
+// The stream of an ordered skinning launch (fyx_lbs_skin_batch and friends): the current frame's under anim.overlap, else the context stream (joined).
+int enter_skin(fyx_ctx* c, hipStream_t* out);
 int ensure_scratch(fyx_ctx* c, size_t bytes);
+// debug.timeline: arms g_launch_events for the next launch and files the pair under `kind` (0 skinning, 1 pose_sample, 2 pose_update)
+int timeline_arm(fyx_ctx* c, int kind);
 void free_ctrl(CtrlBuffers& B);
 // Claims the next slot with room for `total` bytes; *h / *d are its staging and device blocks.
 int ctrl_acquire(fyx_ctx* c, CtrlBuffers& B, size_t total, int* slot_out, char** h, char** d);

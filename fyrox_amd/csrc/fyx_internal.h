@@ -20,6 +20,11 @@ struct LbsTuning {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // option lbs.timing: this launch's own start / stop events (dispatch timestamps)
 };
 
+// Option debug.timeline: the next launch made through FYX_TL_LAUNCH (anim_kernels.hip) or FYX_LAUNCH (lbs_kernels.hip, through
+// LbsTuning) carries these as its own start / stop events (the dispatch's timestamps); set by the caller for ONE launch.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local LaunchEvents g_launch_events;
+
 struct LbsArgs {
     const float* pos;        // 3N packed xyz
     const float* nrm;        // 3N or null
