@@ -368,6 +368,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     CtrlInline inl;
     inl.bytes = 0;
     inl.first_ops = 0;
+    inl.pad[0] = inl.pad[1] = 0;
     if (with_program) {
         // a small control block (one character, a handful of instances) rides in the kernel arguments: no copy, no event, no wait
         const CtrlLayout Li = ctrl_layout_inline(A);

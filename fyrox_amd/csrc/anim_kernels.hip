@@ -339,7 +339,9 @@ __device__ __forceinline__ PoseFrameDev ctrl_resolve(PoseFrameDev f, const CtrlI
     }
     return f;
 }
-static_assert(sizeof(PoseFrameDev) % 8 == 0 && sizeof(RigDev) % 8 == 0 && alignof(CtrlInline) == 4, "kernel-argument layout of (PoseFrameDev[, RigDev], CtrlInline)");
+// (the host lays the sections out 16-byte aligned from the start of CtrlInline, and the kernels read rm_ops as uint4: the offsets
+// of CtrlInline in the kernel-argument segment must be multiples of 16)
+static_assert(sizeof(PoseFrameDev) % 16 == 0 && (sizeof(PoseFrameDev) + sizeof(RigDev)) % 16 == 0 && alignof(CtrlInline) == 16, "kernel-argument layout of (PoseFrameDev[, RigDev], CtrlInline)");
 constexpr size_t kInlAfterFrame = sizeof(PoseFrameDev), kInlAfterFrameAndRig = sizeof(PoseFrameDev) + sizeof(RigDev);
 static const CtrlInline kNoInline = {};
 

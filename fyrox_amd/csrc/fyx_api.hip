@@ -274,7 +274,11 @@ int ctrl_upload(fyx_ctx* c, CtrlBuffers& B, int slot, size_t total, hipStream_t 
     }
     // the block's last readers ran on another stream (fyx_set_stream in between): order behind them
     if (B.d_in_use[slot] && B.d_consumer[slot] != cs) FYX_HIP(c, hipStreamWaitEvent(cs, B.d_consumed[slot], 0));
-    if (c->ctrl_mode == 2) FYX_HIP(c, fyx::launch_ctrl_copy(B.h[slot], B.d[slot], total, cs));
+    if (c->ctrl_mode == 2) {
+        if (int rc = timeline_arm(c, 3)) return rc;
+        FYX_HIP(c, fyx::launch_ctrl_copy(B.h[slot], B.d[slot], total, cs));
+        fyx::g_launch_events = fyx::LaunchEvents();
+    }
     else FYX_HIP(c, hipMemcpyAsync(B.d[slot], B.h[slot], total, hipMemcpyHostToDevice, cs));
     B.h_busy[slot] = true;
     B.h_by_consumed[slot] = true;     // ctrl_consumed follows every upload
@@ -739,7 +743,6 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd")) return &c->lbs.crowd;
     if (!strcmp(key, "lbs.crowd_ipb")) return &c->lbs.crowd_ipb;
     if (!strcmp(key, "lbs.crowd_lean")) return &c->lbs.crowd_lean;
-    if (!strcmp(key, "lbs.crowd_form")) return &c->lbs.crowd_form;
     if (!strcmp(key, "lbs.timing")) return &c->timing;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
     if (!strcmp(key, "comm.form")) return &c->comm_form;

@@ -99,8 +99,8 @@ struct fyx_ctx {
                              //   with the highest priority, the launch streams (skinning: long bandwidth-bound kernels) with the lowest
     int pose_cus = 0;        // option "streams.pose_cus": N > 0 = the context's own stream may only use N CUs (spread over the XCDs) and the
                              //   launch streams only the other 256 - N (hipExtStreamCreateWithCUMask); 0 = no masks
-    int ctrl_mode = 1;       // option "anim.ctrl_upload": how a control block travels -- 0 its own upload stream + events, 1 a copy on the
-                             //   consuming stream, 2 a copy kernel on the consuming stream reading the pinned block
+    int ctrl_mode = 2;       // option "anim.ctrl_upload": how a control block travels -- 0 its own upload stream + events, 1 a copy on the
+                             //   consuming stream, 2 (default) a copy kernel on the consuming stream reading the pinned block
     int timeline_on = 0;     // option "debug.timeline": pose_sample / pose_update / fyx_lbs_skin_device launches carry their own events
     struct TimelineRec { int kind; hipEvent_t start, stop; };
     std::vector<TimelineRec> timeline;       // in launch order (fyx_debug_timeline reads and clears)

@@ -15,7 +15,6 @@ struct LbsTuning {
     int crowd = -1;          // instanced launches: -1 auto (crowd kernel from 4 instances), 0 never, 1 always
     int crowd_lean = 0;      // 1: register-lean crowd kernel at two workgroups per CU (leaves room for other kernels' waves, see lbs_kernels.hip)
     int crowd_ipb = 0;       // instances per workgroup run; 0 = auto
-    int crowd_form = 0;      // experiment forms of the exact crowd kernel (lbs_kernels.hip launch_crowd_one); 0 = product
     int dyn = 1;             // large single-instance launches: 1 = lbs_skin_dyn (units drawn from an LDS ticket counter), 0 = lbs_skin
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // option lbs.timing: this launch's own start / stop events (dispatch timestamps)
 };
@@ -290,6 +289,7 @@ struct RigDev {
                                  //   (kMaxRigNodes = 1024: 10 + 11 + 11 bits) -- one load where node -> depth, parent were two
     uint32_t n_nodes;
     uint32_t n_levels;
+    uint32_t pad1[2];            // (PoseFrameDev, RigDev) is a multiple of 16 bytes: the CtrlInline behind them is 16-byte aligned
 };
 
 // One Property{..} value: the TrackValue's f32 lanes, its variant and whether it is there (== fyx_property_value)
@@ -316,6 +316,7 @@ struct PoseFrameDev {
                                  //   lanes (= instances of one curve) touch one dense span
     uint32_t max_tracks;
     uint32_t sample_form;        // 0 auto (instances on the lanes from 32 instances), 1 curves on the lanes, 2 instances on the lanes
+    uint32_t pad0[2];            // (sizeof(PoseFrameDev) is a multiple of 16: see CtrlInline)
     float4* anim_pose;           // [n_anims][n_instances][n_nodes][3]
     float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
     float* local;                // [n_instances][n_nodes][16]
@@ -340,7 +341,7 @@ struct PoseFrameDev {
 // stream -- that copy, its event and the stream wait were ~8 us of a 25 us frame.  `bytes` != 0: the control pointers of the
 // PoseFrameDev beside it (times, ticked, ops, prog_off, slices, rm_ops, rm_prog_off) hold OFFSETS from the start of this struct.
 constexpr uint32_t kCtrlInlineBytes = 1008;
-struct CtrlInline {
+struct alignas(16) CtrlInline {
     uint32_t bytes;          // 0: the control block is in device memory and the pointers are pointers
     uint32_t first_ops;      // 1 + the number of ops of instance 0's fold program (which starts at op 0), 0: not given --
                              //   the update kernel of ONE character then asks for its program without asking for its offsets first

@@ -578,12 +578,17 @@ __global__ __launch_bounds__(kDynBlock) void lbs_skin_dyn(LbsArgs a, uint32_t to
 // eight instances, palettes copied by LDS-DMA from a pre-packed buffer with a counted vmcnt, a raised priority for waves 4 - 7;
 // round 2: two / four instances per barrier, palette columns staged by every thread, per-instance buffer-resource outputs, sc1
 // stores.  Compute and the 400 MB of stores each take 60 - 75 us alone and overlap only partly whatever the structure.
+// Round 4 (tools/exp/r04_crowd_forms.patch, profiles/r04_crowd_forms.jsonl; one process, forms interleaved, bit-identical): the
+// palette path amortised over twice the vertices is no faster either -- two vertices per thread 82.1 us (influences one by one,
+// 100 VGPRs) / 86.3 (all rows live, 170 VGPRs, one workgroup per CU), a 1024-thread workgroup 82.3 / 87.9, against 79.4 - 80.1
+// for this kernel.  Exact ~0.62 - 0.64 of the HBM roofline is this structure's limit; the fused mode (<= 1e-5, inside north_star's
+// tolerance) is the crowd's fast mode.
 // ---------------------------------------------------------------------------------------
 // LEAN (option lbs.crowd_lean): the arithmetic walks the influences one by one (SEQ above: ~74 VGPRs) and the launch asks
 // for enough LDS that only two workgroups share a CU -- four waves per SIMD holding ~320 of its 512 VGPRs, which leaves
 // room for the waves of OTHER kernels: what lets the next frame's pose kernels run under this frame's skinning
 // (anim.overlap) instead of trickling in as the skinning drains.
-template <int BLOCK, bool EXACT, int MASK, bool LEAN = false, int VPT = 1>
+template <int BLOCK, bool EXACT, int MASK, bool LEAN = false>
 __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tiles, uint32_t ipb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t buf_f4 = 4 * a.n_bones;  // rows (3 per bone) + row3 (1 per bone)
@@ -604,15 +609,8 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
     const uint32_t i0 = chunk * ipb;
     const uint32_t i1 = (i0 + ipb < a.n_instances) ? i0 + ipb : a.n_instances;
     if (i0 >= i1) return;
-    // VPT vertices per thread, BLOCK apart (a wave's accesses stay dense): the per-instance palette traffic and barrier are paid
-    // once per BLOCK * VPT vertices
-    uint32_t v[VPT];
-    bool live[VPT];
-#pragma unroll
-    for (int q = 0; q < VPT; ++q) {
-        v[q] = (tile * VPT + q) * BLOCK + tid;
-        live[q] = v[q] < a.n_verts;
-    }
+    const uint32_t v = tile * BLOCK + tid;
+    const bool live = v < a.n_verts;
 
     // Only the waves whose threads own a bone (n_bones <= 256: waves 0..3) take part in the palette traffic; each
     // of those four waves owns one flag word per buffer (a wave without bones writes 0 there).
@@ -620,9 +618,7 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
     PaletteRegs pr;
     if (owner) pr = palette_fetch(a.palette + (size_t)i0 * a.n_bones * 16, a.n_bones, tid);
     // the mesh is shared by every workgroup of the launch: ordinary (cacheable) loads
-    VertexIn<MASK> vin[VPT];
-#pragma unroll
-    for (int q = 0; q < VPT; ++q) vin[q] = load_vertex<false, MASK>(a, live[q] ? v[q] : 0);
+    const VertexIn<MASK> vin = load_vertex<false, MASK>(a, live ? v : 0);
     if (wave < 4) {
         bool wave_pj = false;
         if (owner) wave_pj = __any(palette_commit(pr, a.n_bones, base, base + 3 * a.n_bones, tid)) != 0;
@@ -637,18 +633,15 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
         const f32x4* row3 = rows + 3 * a.n_bones;
         const u32x4 fl = *reinterpret_cast<const u32x4*>(flags + cur * 4);
         const bool projective = (fl.x | fl.y | fl.z | fl.w) != 0;
-#pragma unroll
-        for (int q = 0; q < VPT; ++q) {
-            // the crowd kernel is VALU-bound, so its fused mode blends the matrices first (see skin_vertex_blended)
-            const Skinned o = skin_vertex<EXACT, MASK, true, LEAN>(rows, row3, projective, vin[q].id, vin[q].w, vin[q].p.x, vin[q].p.y,
-                                                                   vin[q].p.z, vin[q].n.x, vin[q].n.y, vin[q].n.z, vin[q].t.x, vin[q].t.y, vin[q].t.z);
-            if (live[q]) {
-                const size_t ov = (size_t)inst * a.n_verts + v[q];
-                if constexpr (MASK & 1) st3<true>(a.out_pos + ov * 3, o.px, o.py, o.pz);
-                if constexpr (MASK & 2) st3<true>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
-                if constexpr (MASK & 4)
-                    stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, vin[q].t.w});
-            }
+        // the crowd kernel is VALU-bound, so its fused mode blends the matrices first (see skin_vertex_blended)
+        const Skinned o = skin_vertex<EXACT, MASK, true, LEAN>(rows, row3, projective, vin.id, vin.w, vin.p.x, vin.p.y,
+                                                               vin.p.z, vin.n.x, vin.n.y, vin.n.z, vin.t.x, vin.t.y, vin.t.z);
+        if (live) {
+            const size_t ov = (size_t)inst * a.n_verts + v;
+            if constexpr (MASK & 1) st3<true>(a.out_pos + ov * 3, o.px, o.py, o.pz);
+            if constexpr (MASK & 2) st3<true>(a.out_nrm + ov * 3, o.nx, o.ny, o.nz);
+            if constexpr (MASK & 4)
+                stg<true>(reinterpret_cast<f32x4*>(a.out_tan) + ov, f32x4{o.tx, o.ty, o.tz, vin.t.w});
         }
         if (more && wave < 4) {
             f32x4* nrows = base + (cur ^ 1) * buf_f4;
@@ -660,42 +653,34 @@ __global__ __launch_bounds__(BLOCK) void lbs_skin_crowd(LbsArgs a, uint32_t tile
     }
 }
 
-template <int BLOCK, bool EXACT, int MASK, bool LEAN = false, int VPT = 1>
-static hipError_t launch_crowd_form(const LbsArgs& a, const LbsTuning& t, hipStream_t s, size_t min_lds = 0) {
-    const uint32_t tiles = (a.n_verts + BLOCK * VPT - 1) / (BLOCK * VPT);
+template <int BLOCK, bool EXACT, int MASK>
+static hipError_t launch_crowd_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    const uint32_t tiles = (a.n_verts + BLOCK - 1) / BLOCK;
     uint32_t ipb = (uint32_t)(t.crowd_ipb > 0 ? t.crowd_ipb : 0);
     if (ipb == 0) {
-        // long enough runs to amortise the vertex loads, enough workgroups to fill the chip: the C3
-        // sweep (tools/tune_crowd.py) is flat between 8 and 16 instances per run and loses ~10 % at
-        // 2 and at 32
-        const uint64_t pairs = (uint64_t)tiles * a.n_instances * (uint64_t)(BLOCK * VPT / 512);
+        // long enough runs to amortise the vertex loads, enough workgroups to fill the chip.  C3: runs of 8 are 3 - 4 % faster than
+        // 16 in the fused mode (round 3, three boxes) and 1 - 5 % in the exact mode (round 4: 79.4 against 80.1 us alone, 72.0
+        // against 75.9 - 77.7 us inside the frame loop); 2 and 32 lose ~10 %
+        const uint64_t pairs = (uint64_t)tiles * a.n_instances;
         uint64_t want = pairs / ((uint64_t)kCUs * 4);
         if (want < 1) want = 1;
-        // the fused mode is bound by its stores alone and prefers shorter runs (C3, A/B on three boxes: 8 per run 3 - 4 % faster than 16)
-        if (want > (EXACT ? 16u : 8u)) want = EXACT ? 16u : 8u;
+        if (want > 8u) want = 8u;
         ipb = (uint32_t)want;
     }
     if (ipb > a.n_instances) ipb = a.n_instances;
     const uint32_t chunks = (a.n_instances + ipb - 1) / ipb;
     const uint64_t grid = (uint64_t)tiles * chunks;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = std::max<size_t>((size_t)a.n_bones * 64 * 2 + 2 * 4 * sizeof(uint32_t), min_lds);
-    FYX_LAUNCH(t, (lbs_skin_crowd<BLOCK, EXACT, MASK, LEAN, VPT>), dim3((uint32_t)grid), dim3(BLOCK), (uint32_t)lds, s, a, tiles, ipb);
-    return hipGetLastError();
-}
-
-template <int BLOCK, bool EXACT, int MASK>
-static hipError_t launch_crowd_one(const LbsArgs& a, const LbsTuning& t, hipStream_t s) {
+    const size_t lds = (size_t)a.n_bones * 64 * 2 + 2 * (BLOCK / 64) * sizeof(uint32_t);
     if constexpr (BLOCK == 512 && EXACT) {
-        // experiment forms (option lbs.crowd_form; all bit-identical): what the per-instance palette path + barrier cost per vertex
-        if (t.crowd_form == 1) return launch_crowd_form<512, EXACT, MASK, true, 2>(a, t, s);     // two vertices per thread, influences one by one
-        if (t.crowd_form == 2) return launch_crowd_form<1024, EXACT, MASK, false, 1>(a, t, s);   // 1024-thread workgroup
-        if (t.crowd_form == 3) return launch_crowd_form<512, EXACT, MASK, false, 2>(a, t, s);    // two vertices per thread, all twelve rows live
-        if (t.crowd_form == 4) return launch_crowd_form<1024, EXACT, MASK, true, 1>(a, t, s);    // 1024 threads, influences one by one
-        // two workgroups per CU (more than a third of the CU's 160 KB of LDS each): room for other kernels' waves
-        if (t.crowd_lean) return launch_crowd_form<BLOCK, EXACT, MASK, true, 1>(a, t, s, 56 * 1024);
+        if (t.crowd_lean) {   // two workgroups per CU: more than a third of the CU's 160 KB of LDS each
+            const size_t lean_lds = std::max<size_t>(lds, 56 * 1024);
+            FYX_LAUNCH(t, (lbs_skin_crowd<BLOCK, EXACT, MASK, true>), dim3((uint32_t)grid), dim3(BLOCK), (uint32_t)lean_lds, s, a, tiles, ipb);
+            return hipGetLastError();
+        }
     }
-    return launch_crowd_form<BLOCK, EXACT, MASK, false, 1>(a, t, s);
+    FYX_LAUNCH(t, (lbs_skin_crowd<BLOCK, EXACT, MASK>), dim3((uint32_t)grid), dim3(BLOCK), (uint32_t)lds, s, a, tiles, ipb);
+    return hipGetLastError();
 }
 
 template <int BLOCK, bool EXACT>
@@ -1638,7 +1623,13 @@ hipError_t launch_ctrl_copy(const void* h_src, void* d_dst, size_t bytes, hipStr
     if (!n16) return hipSuccess;
     uint32_t grid = (n16 + 255u) / 256u;
     if (grid > 64u) grid = 64u;     // a few waves' worth of 16-byte reads in flight saturate the link
-    hipLaunchKernelGGL(ctrl_copy_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const u32x4*>(h_src), static_cast<u32x4*>(d_dst), n16);
+    if (g_launch_events.start) {     // option debug.timeline
+        hipExtLaunchKernelGGL(ctrl_copy_kernel, dim3(grid), dim3(256), 0, stream, g_launch_events.start, g_launch_events.stop, 0,
+                              static_cast<const u32x4*>(h_src), static_cast<u32x4*>(d_dst), n16);
+        g_launch_events = LaunchEvents();
+    } else {
+        hipLaunchKernelGGL(ctrl_copy_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const u32x4*>(h_src), static_cast<u32x4*>(d_dst), n16);
+    }
     return hipGetLastError();
 }
 

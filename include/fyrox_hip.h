@@ -88,24 +88,28 @@ int fyx_join(fyx_ctx* ctx);
  *                        2 x anim.split stay on the calling thread
  *     "anim.sample_form" 0 auto, 1 curves of one instance on the lanes, 2 instances of one curve on the lanes -- same
  *                        results, the crowd form is picked from 32 instances on
- *     "anim.overlap"     1 = pose updates do not wait for the skinning launches in flight, so frame n + 1's pose kernels run
- *                        beside frame n's skinning; the caller then alternates two palette buffers per animator
- *                        -- frame n's pose update waits for frame n - 2's skinning launches (whose palette buffer it rewrites), not
- *                        for frame n - 1's, beside which it runs
+ *     "anim.overlap"     1 = whole frames alternate between TWO streams: a pose update (fyx_*_update, fyx_scene_update) starts a
+ *                        frame on the other stream, the skinning launches that follow go there too, in order behind it.  Frame
+ *                        n + 1's pose kernels so run beside frame n's skinning; its only cross-stream edge is "behind frame n's
+ *                        pose update".  The caller alternates two palette buffers per animator: a pose update must not be given
+ *                        a palette buffer that a skinning launch issued since the previous pose update reads.
+ *                        "lbs.streams" is not used in this mode.  C3: frame 0.115 -> 0.101 - 0.104 ms
  *     "anim.update_lean" 1 (default) = a frame whose fold programs are ALL straight (a few clips blended in a row: the common
  *                        machines; the host classifies with the kernel's own function) runs the update kernel built without the
  *                        fold interpreter: a third of the registers, so its waves fit beside a running skinning kernel
  *     "anim.ctrl_upload" how a frame's control block reaches the GPU when it does not fit the kernel arguments: 0 = a copy on
- *                        an upload stream of its own + events (right when pose and skinning share ONE stream: the copy travels
- *                        beside the previous frame's skinning), 1 (default) = a copy on the consuming stream, 2 = a copy kernel
- *                        there that reads the pinned block (no copy command, no event; right with "anim.overlap")
+ *                        an upload stream of its own + two events, 1 = a copy on the consuming stream, 2 (default) = a copy
+ *                        kernel on the consuming stream that reads the pinned block (no copy command, no event, no second stream;
+ *                        C3: the update call costs the host 46 us instead of 53, the frame 0.115 instead of 0.116 - 0.120 ms)
  *     "anim.inline_ctrl" 1 (default) = a frame's control block -- sample times, tick flags, fold program -- of at most 1 KB, i.e.
  *                        one character or a handful of instances, travels inside the kernel arguments of the pose kernels
  *                        instead of through a device block and an H2D copy on the upload stream; 0 = always the copy.  Same
  *                        kernels, same results; a single character's frame 0.031 -> 0.018 ms
  *   streams:
- *     "streams.priority" 1 (default) = the context's own stream (pose path) is created with the highest stream priority, the
- *                        launch streams (skinning) with the lowest: a workgroup slot that frees up goes to the pose kernels first
+ *     "streams.priority" 1 = the context's own stream (pose path) is created with the highest stream priority, the launch streams
+ *                        (skinning) with the lowest.  Default 0: measured on MI355X / ROCm 7.0, kernels of a high-priority
+ *                        stream run ~3 x slower (the crowd sampler 52 us instead of 17) and the calls that order streams of
+ *                        different priority cost the host ~150 us per frame (profiles/r04_frame_study/)
  *     "streams.pose_cus" N > 0 (multiple of 8) = the own stream may use N CUs only and the launch streams the other 256 - N
  *                        (hipExtStreamCreateWithCUMask); 0 (default) = no masks.  Changing either re-creates the streams.
  *   exchange:
@@ -123,7 +127,7 @@ int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
 int fyx_debug_kernel_time(fyx_ctx* ctx, double* total_us, uint32_t* n_launches);
 /* Measurement aid (option "debug.timeline" = 1): the pose_sample / pose_update launches of fyx_*_update and every
  * fyx_lbs_skin_device launch carry their own start / stop events.  Waits for the work in flight, writes up to `capacity`
- * records {kind: 0 skinning, 1 pose_sample, 2 pose_update; start / stop in microseconds after the first record's start} in
+ * records {kind: 0 skinning, 1 pose_sample, 2 pose_update, 3 control-block copy kernel; start / stop in microseconds after the first record's start} in
  * launch order, returns their number and starts over -- which kernels of a pipelined frame really ran beside which.
  * At most 16384 launches between two calls.  Replaces nothing in the reference. */
 int fyx_debug_timeline(fyx_ctx* ctx, int32_t* kinds, double* start_us, double* stop_us, uint32_t capacity, uint32_t* n_records);

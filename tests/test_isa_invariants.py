@@ -96,8 +96,8 @@ def test_register_budgets_behind_the_measured_occupancies():
         pytest.skip("llvm-readelf of the ROCm toolchain is not here")
     res = isa_stats.kernel_resources(LIB)
     budget = {"fyx::lbs_skin_dyn<true, 7>": 128, "fyx::lbs_skin<true, 7>": 128,
-              "fyx::lbs_skin_batch<true, 7>": 128, "fyx::lbs_skin_crowd<512, true, 7, false, 1>": 128,
-              "fyx::lbs_skin_crowd<512, true, 7, true, 1>": 80,
+              "fyx::lbs_skin_batch<true, 7>": 128, "fyx::lbs_skin_crowd<512, true, 7, false>": 128,
+              "fyx::lbs_skin_crowd<512, true, 7, true>": 80,
               # the update kernel without the interpreter (every program of the frame straight): three waves per SIMD, and one of
               # them fits into what ONE retiring workgroup of the crowd kernel frees on a SIMD (2 x 128) -- anim.overlap
               "fyx::pose_update_kernel<2>": 176, "fyx::pose_update_scene_kernel<2>": 176, "fyx::pose_update_inl_kernel<2>": 176, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel<256u>": 64, "fyx::pose_sample_crowd_kernel<64u>": 64}
@@ -110,6 +110,4 @@ def test_register_budgets_behind_the_measured_occupancies():
             # ... except the vertex-buffer-out kernels with 32- and 40-byte output vertices, which hold a whole output
             # vertex per lane on top of the inputs: three waves per SIMD (<= 168)
             wide = name.startswith("fyx::lbs_skin_aos") and _targs(name)[2] in ("8u", "10u")
-            if name.startswith("fyx::lbs_skin_crowd") and _targs(name)[3:] == ["false", "2"]:
-                continue      # experiment form (lbs.crowd_form = 3): two vertices per thread with all rows live, one workgroup per CU
             assert r["vgpr"] + r["agpr"] <= (168 if wide else 128) and r["scratch_bytes"] == 0, (name, r)

@@ -96,6 +96,7 @@ def measure(name, opts, pipelined):
     sk = [(x, y) for k_, x, y in zip(kinds, a, b) if k_ == 0]
     sa = [(x, y) for k_, x, y in zip(kinds, a, b) if k_ == 1]
     up = [(x, y) for k_, x, y in zip(kinds, a, b) if k_ == 2]
+    cp = [(x, y) for k_, x, y in zip(kinds, a, b) if k_ == 3]
     n = min(len(sk), len(sa), len(up))
     med = lambda v: round(float(np.median(v)), 2) if len(v) else None
     rec = {"config": name, "verts": VERTS, "frame_us": round(frame_us, 2), "host_loop_us_per_frame": round(host / frames * 1e6, 2),
@@ -108,6 +109,9 @@ def measure(name, opts, pipelined):
            "sample_start_after_prev_skin_start_us": med([sa[i][0] - sk[i - 1][0] for i in range(5, n)]),
            "sample_start_after_prev_skin_stop_us": med([sa[i][0] - sk[i - 1][1] for i in range(5, n)]),
            "skin_start_after_prev_skin_stop_us": med([sk[i][0] - sk[i - 1][1] for i in range(5, n)]),
+           "copy_us": med([y - x for x, y in cp[5:n]]) if len(cp) >= n else None,
+           "copy_start_after_prev_update_stop_us": med([cp[i][0] - up[i - 1][1] for i in range(5, n)]) if len(cp) >= n else None,
+           "sample_start_after_copy_stop_us": med([sa[i][0] - cp[i][1] for i in range(5, n)]) if len(cp) >= n else None,
            "frames_10_to_13": [{"sample": [round(sa[i][0] - sk[10][0], 1), round(sa[i][1] - sk[10][0], 1)], "update": [round(up[i][0] - sk[10][0], 1), round(up[i][1] - sk[10][0], 1)],
                                 "skin": [round(sk[i][0] - sk[10][0], 1), round(sk[i][1] - sk[10][0], 1)]} for i in range(10, min(14, n))],
            "opts": opts}
@@ -120,16 +124,10 @@ def measure(name, opts, pipelined):
 
 base = {"lbs.streams": 1, "anim.overlap": 0, "anim.update_lean": 1, "streams.priority": 0}
 pipe = {"lbs.streams": 1, "anim.overlap": 1, "anim.update_lean": 1, "streams.priority": 0}
-measure("serial, upload stream", {**base, "anim.ctrl_upload": 0}, False)
+ctx.set_option("lbs.crowd_ipb", int(os.environ.get("IPB", "8")))
 measure("serial, copy kernel", {**base, "anim.ctrl_upload": 2}, False)
-measure("frames alternate streams, copy kernel", {**pipe, "anim.ctrl_upload": 2}, True)
-measure("frames alternate streams, copy in stream", {**pipe, "anim.ctrl_upload": 1}, True)
-measure("frames alternate streams, upload stream", {**pipe, "anim.ctrl_upload": 0}, True)
-measure("frames alternate streams, copy kernel, lean crowd", {**pipe, "anim.ctrl_upload": 2, "lbs.crowd_lean": 1}, True)
-measure("frames alternate streams, copy kernel, general update kernel", {**pipe, "anim.ctrl_upload": 2, "anim.update_lean": 0}, True)
-measure("frames alternate streams, copy kernel, fused skinning", {**pipe, "anim.ctrl_upload": 2, "lbs.exact": 0}, True)
-ctx.set_option("lbs.exact", 1)
-measure("serial, copy kernel, fused skinning", {**base, "anim.ctrl_upload": 2, "lbs.exact": 0}, False)
-ctx.set_option("lbs.exact", 1)
-measure("frames alternate streams, copy kernel, priority streams", {**pipe, "anim.ctrl_upload": 2, "streams.priority": 1}, True)
+for prio in (0, 1):
+    for kb in (0, 16):
+        measure("frames alternate streams, wave_prio=%d, LDS pad %d KB" % (prio, kb), {**pipe, "anim.ctrl_upload": 2, "anim.pose_lds_kb": kb, "anim.wave_prio": prio}, True)
+ctx.set_option("anim.pose_lds_kb", 0)
 ctx.close()
