@@ -636,8 +636,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.extras_only:
+        # `python bench.py --gpus N` launched plainly: one rank per GPU is what the line promises, so this process becomes the
+        # launcher the driver would have used (same module, same arguments) instead of measuring one GPU under the label of N
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"# bench.py --gpus {args.gpus} without a launcher: re-executing as {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would carry the wrong n_gpus")
 
     if args.extras_only:
         # The other BASELINE configs and the scene tick, in a process of their own: their pipelined frames are bound by the host's
@@ -883,13 +896,25 @@ def main():
         gather = ctx._l.fyx_allgather_skinned
         gcalls = [partial(gather, ctx._h, ctypes.c_uint32(full.n_verts), ctypes.c_void_p(o[0].data_ptr()),
                           ctypes.c_void_p(o[1].data_ptr()), ctypes.c_void_p(o[2].data_ptr())) for o in alls]
+        # exchange form 2 (one in-place ncclAllGather per stream) wants EQUAL shards: the padded cut, buffers of world * shard vertices
+        b2, e2, shard2 = sharding.vertex_range_padded(full.n_verts, rank, world)
+        alls2, scalls2, gcalls2 = [], [], []
+        for s_ in range(sets2):
+            ctx.mesh_upload_soa(150 + s_, full.pos[b2:e2], full.weights[b2:e2], full.indices[b2:e2], full.normal[b2:e2], full.tangent[b2:e2])
+            o = (torch.zeros(world * shard2 * 3 + 16, dtype=torch.float32, device="cuda"), torch.zeros(world * shard2 * 3 + 16, dtype=torch.float32, device="cuda"),
+                 torch.zeros(world * shard2 * 4 + 16, dtype=torch.float32, device="cuda"))
+            alls2.append(o)
+            scalls2.append(partial(fn, ctx._h, ctypes.c_uint64(150 + s_), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
+                                   ctypes.c_void_p(o[0].data_ptr() + 12 * b2), ctypes.c_void_p(o[1].data_ptr() + 12 * b2), ctypes.c_void_p(o[2].data_ptr() + 16 * b2)))
+            gcalls2.append(partial(gather, ctx._h, ctypes.c_uint32(full.n_verts), ctypes.c_void_p(o[0].data_ptr()), ctypes.c_void_p(o[1].data_ptr()),
+                                   ctypes.c_void_p(o[2].data_ptr())))
 
-        def sstep(i: int, with_gather: bool):
-            rc = scalls[i % sets2]()
+        def sstep(i: int, with_gather: bool, padded: bool = False):
+            rc = (scalls2 if padded else scalls)[i % sets2]() if (e2 > b2 if padded else e > b) else 0
             if rc:
                 ctx._check(rc)
             if with_gather and have_comm:
-                rc = gcalls[i % sets2]()
+                rc = (gcalls2 if padded else gcalls)[i % sets2]()
                 if rc:
                     ctx._check(rc)
 
@@ -914,12 +939,14 @@ def main():
 
         def exchange_leg(form: int):
             """Every rank ends up holding the WHOLE skinned mesh (checked on rank 0 against the oracle, head and tail), then the
-            timed regions with the exchange in them.  `form`: option comm.form (0 one broadcast per shard, 1 grouped send / recv).
-            Returns (record, regions) on rank 0's behalf; all ranks take part."""
+            timed regions with the exchange in them.  `form`: option comm.form (0 one broadcast per shard, 1 grouped send / recv,
+            2 one in-place all-gather per stream over the padded cut).  Returns (record, regions) on rank 0's behalf; all ranks take part."""
             ctx.set_option("comm.form", form)
-            for o in alls[0]:
+            padded = form == 2
+            bufs = alls2[0] if padded else alls[0]
+            for o in bufs:
                 zero(ctx, o)
-            sstep(0, True)
+            sstep(0, True, padded)
             ctx.sync()
             ok = None
             if rank == 0 and not args.no_check:
@@ -927,13 +954,15 @@ def main():
                 n_chk = 20_000
                 tail = slice(full.n_verts - n_chk, full.n_verts)
                 ref = oracle.lbs_skin(full.pos[tail], full.weights[tail], full.indices[tail], pal, full.normal[tail], full.tangent[tail], threads=CHECK_THREADS)
-                got = dl(ctx, alls[0][0], (full.n_verts - n_chk) * 3, n_chk * 3).reshape(-1, 3)
-                ok = bool(lbs_parity(ctx, full, pal, alls[0], n_chk)["bit_exact"] and np.array_equal(got, ref["pos"]))
-            r_g, w_g, g_g = timed_regions(lambda i: sstep(i, True), args.steps, args.warmup)
+                got = dl(ctx, bufs[0], (full.n_verts - n_chk) * 3, n_chk * 3).reshape(-1, 3)      # (vertex v lies at position v in either cut)
+                ok = bool(lbs_parity(ctx, full, pal, bufs, n_chk)["bit_exact"] and np.array_equal(got, ref["pos"]))
+            r_g, w_g, g_g = timed_regions(lambda i: sstep(i, True, padded), args.steps, args.warmup)
             rec = {"value": full.n_verts * args.steps * r_g / float(np.median(w_g)), "unit": "vertices/s",
                    "ms_per_step": float(np.median(w_g)) * 1e3 / (args.steps * r_g), "timed_steps": args.steps * r_g,
-                   "collective": "fyx_allgather_skinned: one grouped RCCL op per frame (ragged shards, 40 B/vertex), " +
-                                 ("one ncclBroadcast per (stream, shard)" if form == 0 else "ncclSend / ncclRecv between every pair of ranks")}
+                   "collective": "fyx_allgather_skinned: one grouped RCCL op per frame (40 B/vertex), " +
+                                 ("ragged shards, one ncclBroadcast per (stream, shard)" if form == 0 else
+                                  "ragged shards, ncclSend / ncclRecv between every pair of ranks" if form == 1 else
+                                  f"equal padded shards of {shard2} vertices, ONE in-place ncclAllGather per stream")}
             return rec, ok, (r_g, w_g, g_g)
 
         if args.scaling == "strong":
@@ -968,6 +997,9 @@ def main():
             "config": {"workload": f"C4: {nv} verts / {args.bones} bones per GPU, 4-influence LBS of position+normal+tangent, "
                                    f"{args.sets} rotating 100 MB buffer sets, "
                                    f"{'random' if args.random_bones else 'spatially coherent'} bone indices"
+                                   + ("" if world == 1 else f"; `value` is WEAK scaling over the {world} GPUs (every GPU its own 1 M-vertex mesh, no collective); BASELINE "
+                                      "config 4 as written (ONE 1 M-vertex mesh cut by vertex range) is strong_value / strong_with_gather_value, config 3 cut by "
+                                      "instance range is crowd_value")
                                    if args.scaling == "weak" else strong["workload"],
                        "sharding": "contiguous vertex range per GPU, palette replicated",
                        "rank0_vertex_range": list(shard), "n_ranks": n_ranks_rccl if n_ranks_rccl is not None else 1,
@@ -1049,15 +1081,15 @@ def main():
         out["strong_ms_per_step"] = strong["compute_only"]["ms_per_step"]
         out["strong_with_gather_value"], out["strong_with_gather_form"] = None, None
         out["top_level_note"] = ("value = weak scaling (every GPU skins its own 1 M-vertex mesh); strong_value = BASELINE config 4, the ONE 1 M-vertex "
-                                 "mesh cut by vertex range, compute only; strong_with_gather_value = the same with the RCCL exchange, the faster of "
-                                 "the two exchange forms (both in extra.strong_scaling); crowd_value = config 3 cut by instance range, whole frames")
+                                 "mesh cut by vertex range, compute only; strong_with_gather_value = the same with the RCCL exchange, the fastest of "
+                                 "the three exchange forms (all in extra.strong_scaling); crowd_value = config 3 cut by instance range, whole frames")
 
     # ---- the exchange, last: RCCL with more than one rank has never run before the driver's multi-GPU job, so a hang in it
-    # must not cost the line -- after EXCHANGE_TIMEOUT_S rank 0 prints what it has and every rank leaves.  Both forms are timed:
+    # must not cost the line -- after EXCHANGE_TIMEOUT_S rank 0 prints what it has and every rank leaves.  All three forms are timed:
     # the driver's run is the A/B --------------------------------------------------------------------------------------------
     if strong is not None and have_comm and (world > 1 or force_exchange):
         import threading
-        for form, key in ((0, "with_allgather"), (1, "with_allgather_sendrecv")):
+        for form, key in ((0, "with_allgather"), (1, "with_allgather_sendrecv"), (2, "with_allgather_padded")):
             def give_up(key=key):
                 if rank == 0:
                     out["extra"]["strong_scaling"][key] = {"value": None, "note": f"the exchange did not finish within {EXCHANGE_TIMEOUT_S} s"}
@@ -1081,7 +1113,7 @@ def main():
                     if ok is False:
                         st[key]["note"] = "THE GATHERED BUFFER DIFFERS FROM THE ORACLE"
                     elif out.get("strong_with_gather_value") is None or rec["value"] > out["strong_with_gather_value"]:
-                        out["strong_with_gather_value"], out["strong_with_gather_form"] = rec["value"], "broadcasts" if form == 0 else "send_recv"
+                        out["strong_with_gather_value"], out["strong_with_gather_form"] = rec["value"], ("broadcasts", "send_recv", "all_gather_padded")[form]
                     if args.scaling == "strong" and args.allgather and form == 0:
                         r_g, w_g, _ = regions
                         out["value"] = float(args.verts) * args.steps * r_g / float(np.median(w_g))

@@ -176,6 +176,7 @@ _SIGS = {
     "fyx_comm_shutdown": (c_int, [_P]),
     "fyx_allgather_f32": (c_int, [_P, _P, c_size_t, _P]),
     "fyx_shard_vertex_range": (c_int, [c_uint32, c_int, c_int, POINTER(c_uint32), POINTER(c_uint32)]),
+    "fyx_shard_vertex_range_padded": (c_int, [c_uint32, c_int, c_int, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "fyx_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int)]),
     "fyx_allgather_skinned": (c_int, [_P, c_uint32, _P, _P, _P]),
     "fyx_comm_init_all": (c_int, [_P, c_int]),

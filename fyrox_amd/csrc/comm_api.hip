@@ -75,12 +75,25 @@ uint32_t shard_cut(uint32_t n_verts, uint64_t g, uint64_t n_ranks) {
     return v < n_verts ? (uint32_t)v : n_verts;
 }
 
+// The PADDED cut of exchange form 2: every rank's shard is the same S = ceil(groups / n_ranks) * kShardAlign vertices long -- rank r
+// owns [r S, min((r + 1) S, n_verts)) -- and every GPU's buffers hold n_ranks * S vertices, so that ONE in-place ncclAllGather per
+// stream (sendbuff = recvbuff + rank * count: RCCL's best-tuned collective) moves everything.  1 M vertices over 8 GPUs:
+// S = 125 184, 1 001 472 vertices of buffer, the last rank skins 123 712.
+uint32_t padded_shard(uint32_t n_verts, uint64_t n_ranks) {
+    const uint64_t groups = ((uint64_t)n_verts + kShardAlign - 1) / kShardAlign;
+    return (uint32_t)(((groups + n_ranks - 1) / n_ranks) * kShardAlign);
+}
+
 // One rank's calls for one stream of the exchange, inside an open RCCL group.  `base` is that rank's full buffer, `me` its rank.
 //   form 0: one broadcast per shard, in place (root = the shard's owner);
 //   form 1: the rank sends its own shard to every other rank and receives every other shard where it belongs -- point to point,
 //           what RCCL turns into one fused send/recv kernel over the xGMI links (no root, no tree).
 int enqueue_stream_exchange(const Comm& k, int form, float* base, uint32_t width, uint32_t n_verts, int me, int n_ranks, hipStream_t st) {
     constexpr int kNcclFloat32 = 7;   // rccl.h: ncclFloat32
+    if (form == 2) {     // equal padded shards: one in-place all-gather
+        const size_t count = (size_t)padded_shard(n_verts, (uint64_t)n_ranks) * width;
+        return k.all_gather(base + (size_t)me * count, base, count, kNcclFloat32, k.comm, st);
+    }
     const uint32_t mb = shard_cut(n_verts, (uint64_t)me, (uint64_t)n_ranks), me_e = shard_cut(n_verts, (uint64_t)me + 1, (uint64_t)n_ranks);
     for (int r = 0; r < n_ranks; ++r) {
         const uint32_t b = shard_cut(n_verts, (uint64_t)r, (uint64_t)n_ranks), e = shard_cut(n_verts, (uint64_t)r + 1, (uint64_t)n_ranks);
@@ -181,6 +194,17 @@ int fyx_shard_vertex_range(uint32_t n_verts, int rank, int n_ranks, uint32_t* be
     return FYX_OK;
 }
 
+int fyx_shard_vertex_range_padded(uint32_t n_verts, int rank, int n_ranks, uint32_t* begin, uint32_t* end, uint32_t* shard_verts) {
+    if (!begin || !end || !shard_verts || n_ranks < 1 || rank < 0 || rank >= n_ranks) return FYX_ERR_INVALID_ARG;
+    const uint64_t S = padded_shard(n_verts, (uint64_t)n_ranks);
+    if (S * (uint64_t)n_ranks > 0xffffffffull) return FYX_ERR_UNSUPPORTED;
+    const uint64_t b = S * (uint64_t)rank, e = b + S;
+    *begin = (uint32_t)(b < n_verts ? b : n_verts);
+    *end = (uint32_t)(e < n_verts ? e : n_verts);
+    *shard_verts = (uint32_t)S;
+    return FYX_OK;
+}
+
 int fyx_comm_info(fyx_ctx* c, int* rank, int* n_ranks) {
     if (!c || !rank || !n_ranks) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
@@ -213,7 +237,7 @@ int fyx_allgather_skinned(fyx_ctx* c, uint32_t n_verts, float* d_pos_all, float*
         first_err = enqueue_stream_exchange(k, form, s.p, s.width, n_verts, k.rank, k.n_ranks, c->stream);
     }
     rc = k.group_end();     // always closed, also after a failed call inside the group
-    if (first_err) return rccl_fail(c, k, first_err, form ? "ncclSend / ncclRecv" : "ncclBroadcast");
+    if (first_err) return rccl_fail(c, k, first_err, form == 2 ? "ncclAllGather" : form ? "ncclSend / ncclRecv" : "ncclBroadcast");
     if (rc) return rccl_fail(c, k, rc, "ncclGroupEnd");
     return FYX_OK;
     FYX_GUARD_END(c)
@@ -304,7 +328,7 @@ int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, flo
     rc = k0.group_end();
     (void)hipSetDevice(c->device);
     if (first_err == -1) return fail(c, FYX_ERR_HIP, "hipSetDevice failed inside the exchange");
-    if (first_err) return rccl_fail(c, k0, first_err, form ? "ncclSend / ncclRecv" : "ncclBroadcast");
+    if (first_err) return rccl_fail(c, k0, first_err, form == 2 ? "ncclAllGather" : form ? "ncclSend / ncclRecv" : "ncclBroadcast");
     if (rc) return rccl_fail(c, k0, rc, "ncclGroupEnd");
     return FYX_OK;
     FYX_GUARD_END(c)

@@ -773,7 +773,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd must be -1 (auto), 0 or 1");
     if (slot == &c->lbs.crowd_ipb && (value < 0 || value > 4096))
         return fail(c, FYX_ERR_INVALID_ARG, "lbs.crowd_ipb must be 0 (auto) .. 4096");
-    if (slot == &c->comm_form && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "comm.form must be 0 (broadcasts) or 1 (send / recv)");
+    if (slot == &c->comm_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "comm.form must be 0 (broadcasts), 1 (send / recv) or 2 (one all-gather over padded shards)");
     if (slot == &c->sample_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.sample_form must be 0, 1 or 2");
     if (slot == &c->inline_ctrl && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.inline_ctrl must be 0 or 1");
     if (slot == &c->pose_overlap && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.overlap must be 0 or 1");

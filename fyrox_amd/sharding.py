@@ -36,6 +36,18 @@ def vertex_range_native(n_verts: int, rank: int, world: int) -> Tuple[int, int]:
     return b.value, e.value
 
 
+def vertex_range_padded(n_verts: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """(begin, end, shard_verts) of exchange form 2 (comm.form = 2, fyx_shard_vertex_range_padded): equal shards of shard_verts
+    vertices, the full buffers hold world * shard_verts vertices, one in-place all-gather per stream."""
+    from ctypes import byref, c_uint32
+    from . import _native
+    b, e, s = c_uint32(), c_uint32(), c_uint32()
+    rc = _native.lib().fyx_shard_vertex_range_padded(n_verts, rank, world, byref(b), byref(e), byref(s))
+    if rc:
+        raise ValueError(f"fyx_shard_vertex_range_padded({n_verts}, {rank}, {world}) -> {rc}")
+    return b.value, e.value, s.value
+
+
 def instance_range(n_instances: int, rank: int, world: int) -> Tuple[int, int]:
     """[begin, end) of rank's instances of a crowd (zero communication)."""
     if not (0 <= rank < world):

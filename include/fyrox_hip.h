@@ -703,6 +703,11 @@ int fyx_allgather_f32(fyx_ctx* ctx, const float* d_send, size_t count, float* d_
  * 124 928 / 125 184 / ... / 124 992 vertices).  Pure function: no context, no GPU.  The reference has no counterpart
  * (one process, one GPU); this replaces nothing and exists for the all-gather below. */
 int fyx_shard_vertex_range(uint32_t n_verts, int rank, int n_ranks, uint32_t* begin, uint32_t* end);
+/* The PADDED cut of exchange form 2 (option "comm.form" = 2): every shard is the same *shard_verts = ceil(groups / n_ranks) * 256
+ * vertices long, rank r owns [r * shard_verts, min((r + 1) * shard_verts, n_verts)) and every GPU's full streams hold
+ * n_ranks * shard_verts vertices (1 000 000 over 8 GPUs: shards of 125 184, buffers of 1 001 472 vertices, the last rank skins
+ * 123 712).  Pure function.  FYX_ERR_UNSUPPORTED when n_ranks * shard_verts does not fit 32 bits. */
+int fyx_shard_vertex_range_padded(uint32_t n_verts, int rank, int n_ranks, uint32_t* begin, uint32_t* end, uint32_t* shard_verts);
 /* rank and size of the context's communicator as RCCL reports them (ncclCommUserRank / ncclCommCount). */
 int fyx_comm_info(fyx_ctx* ctx, int* rank, int* n_ranks);
 /* The exchange step, once per frame: every non-null d_*_all is a FULL skinned stream of the n_verts mesh (3 / 3 / 4
@@ -714,7 +719,10 @@ int fyx_comm_info(fyx_ctx* ctx, int* rank, int* n_ranks);
  * Option "comm.form" (fyx_set_option, the same value on every rank) picks how the shards travel inside that one group:
  * 0 (default) the broadcasts above; 1 point to point -- every rank ncclSend's its shard to each other rank and ncclRecv's
  * each other shard where it belongs (2 (n - 1) calls per stream and rank; RCCL fuses grouped send / recv into one kernel
- * over the xGMI links, no root and no tree).  Same bytes in the same places either way. */
+ * over the xGMI links, no root and no tree).  Same bytes in the same places either way.
+ * 2: ONE in-place ncclAllGather per stream over EQUAL shards -- the collective RCCL tunes hardest.  The shards are then the
+ * padded cut of fyx_shard_vertex_range_padded (not the ragged one) and every d_*_all holds n_ranks * shard_verts vertices; the
+ * vertices past n_verts in the last shard(s) are padding (whatever the buffer held travels; nothing reads it). */
 int fyx_allgather_skinned(fyx_ctx* ctx, uint32_t n_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all);
 /* ONE PROCESS driving several GPUs -- the engine is one process with one update thread, so this is the
  * form its shim uses: contexts ctxs[0..n) made by fyx_init on n different devices, every call from the same thread.

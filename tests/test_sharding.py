@@ -45,6 +45,28 @@ def test_library_cut_equals_the_python_cut():
         sharding.vertex_range_native(10, 0, 0)
 
 
+def test_padded_cut_of_exchange_form_2():
+    """fyx_shard_vertex_range_padded (comm.form = 2): equal 256-aligned shards that tile the mesh, the buffers hold world * shard
+    vertices, the BASELINE config-4 cut spelled out, and the refusals."""
+    for n in (0, 1, 255, 256, 257, 1000, 4097, 50_000, 999_999, 1_000_000, 1_000_001):
+        for world in (1, 2, 3, 4, 5, 7, 8, 16):
+            prev, shard = 0, None
+            for r in range(world):
+                b, e, s = sharding.vertex_range_padded(n, r, world)
+                shard = s if shard is None else shard
+                assert s == shard and s % sharding.VERTEX_ALIGN == 0
+                assert b == min(n, r * s) and e == min(n, (r + 1) * s) and b == prev
+                prev = e
+            assert prev == n and shard * world >= n and (n == 0 or shard * world - n < world * sharding.VERTEX_ALIGN + sharding.VERTEX_ALIGN)
+    cuts = [sharding.vertex_range_padded(1_000_000, r, 8) for r in range(8)]
+    assert {s for _, _, s in cuts} == {125_184} and 8 * 125_184 == 1_001_472
+    assert [e - b for b, e, _ in cuts] == [125_184] * 7 + [123_712]
+    with pytest.raises(ValueError):
+        sharding.vertex_range_padded(10, 2, 2)
+    with pytest.raises(ValueError):
+        sharding.vertex_range_padded(4_294_967_295, 0, 7)       # 7 shards of 613 566 976 vertices do not fit 32 bits
+
+
 def test_instance_ranges_tile_the_crowd():
     for n in (0, 1, 7, 1000):
         for world in (1, 2, 4, 8):
@@ -149,6 +171,51 @@ def _worker_send_recv(rank: int, world: int, port: int, n_verts: int, n_bones: i
         q.put((rank, all(np.array_equal(full[k].numpy(), ref[k]) for k in ref), (b, e)))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_padded(rank: int, world: int, port: int, n_verts: int, n_bones: int, q):
+    """The schedule of fyx_allgather_skinned with comm.form = 2, gloo standing in for RCCL: buffers of world * shard vertices, every
+    rank skins [begin, end) of the padded cut in place and ONE in-place all_gather_into_tensor per stream (input = the rank's own
+    slice of the output) moves everything."""
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seed = synth.SEED_BASE + 4
+        mesh = synth.make_mesh(n_verts, n_bones, seed)
+        pal = synth.make_palette(n_bones, seed)
+        b, e, shard = sharding.vertex_range_padded(n_verts, rank, world)
+        out = oracle.lbs_skin(mesh.pos[b:e], mesh.weights[b:e], mesh.indices[b:e], pal, mesh.normal[b:e], mesh.tangent[b:e])
+        full = {k: torch.full((world * shard, w), float("nan")) for k, w in (("pos", 3), ("normal", 3), ("tangent", 4))}
+        for k in full:
+            full[k][b:e] = torch.from_numpy(out[k])
+            mine = full[k][rank * shard:(rank + 1) * shard].clone()      # (gloo wants a separate input; RCCL takes the slice itself)
+            dist.all_gather_into_tensor(full[k], mine)
+        ref = oracle.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal, mesh.normal, mesh.tangent)
+        q.put((rank, all(np.array_equal(full[k][:n_verts].numpy(), ref[k]) for k in ref), (b, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_verts", [(2, 4097), (3, 1000), (2, 300)])
+def test_padded_all_gather_schedule(world, n_verts):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_padded, args=(r, world, port, n_verts, 16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results)
+    ranges = sorted(rg for _, _, rg in results)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n_verts
 
 
 @pytest.mark.parametrize("world,n_verts", [(2, 4097), (3, 1000), (2, 300)])
