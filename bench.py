@@ -222,11 +222,9 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     for _ in range(frames):
         frame()
     frame_serial_ms = ctx.timer_end() / frames
-    # pipelined: frame n+1's pose kernels do not wait for frame n's skinning (option anim.overlap, skinning on the
-    # launch streams, two palette buffers) -- nothing else changes, the same kernels compute the same values
+    # pipelined: whole frames alternate between two streams (option anim.overlap), so frame n + 1's pose kernels run beside frame n's
+    # skinning; two palette buffers -- nothing else changes, the same kernels compute the same values
     ctx.set_option("anim.overlap", 1)
-    ctx.set_option("lbs.streams", 2)
-    ctx.set_option("lbs.crowd_lean", 1)      # the crowd kernel leaves register room for the pose kernels it runs beside
     pals = (d_pal, d_pal2)
 
     def frame_pipelined(k):
@@ -243,8 +241,6 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
         frame_pipelined(k)
     frame_ms = ctx.timer_end() / frames
     ctx.set_option("anim.overlap", 0)
-    ctx.set_option("lbs.streams", 1)
-    ctx.set_option("lbs.crowd_lean", 0)
     p.set_palette_output(base + 50, d_pal.ptr)
     ctx.sync()
     ctx.timer_begin()
@@ -310,22 +306,27 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
                                   "frac": unique / (fk * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_us": fk, "launch_period_us": f_ms * 1e3},
                      "parity": {"instances_checked": sorted(refs_gpu_pal), "max_rel_err": f_err, "tolerance": 1e-5, "bit_exact": False,
                                 "note": "against the oracle on the GPU-built palettes; north_star allows 1e-5 relative"}}
-    rec = {"workload": name, "frame_ms": min(frame_ms, frame_serial_ms), "frame_mode": "pipelined" if frame_ms < frame_serial_ms else "one_stream",
+    best_ms = min(frame_ms, frame_serial_ms)
+    rec = {"workload": name, "frame_ms": best_ms, "frame_mode": "pipelined" if frame_ms < frame_serial_ms else "one_stream",
            "frame_ms_pipelined": frame_ms, "frame_ms_one_stream": frame_serial_ms, "pose_ms": pose_ms, "skin_ms": skin_ms,
-           "frame_note": "pipelined: pose of frame n+1 under the skinning of frame n (anim.overlap=1, two launch streams, two palette "
-                         "buffers); one_stream: the whole frame as one dependent chain on one stream; frame_ms is the faster of the two "
-                         "(the host picks the mode per scene: pipelining pays when the skinning outlasts the host's control plane)",
-           "skinned_vertices_per_s_frame": nv / (frame_ms * 1e-3), "skinned_vertices_per_s_skin": nv / (skin_ms * 1e-3),
+           "frame_over_skin": best_ms / skin_ms,
+           "frame_roofline_frac": unique / (best_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "frame_note": "pipelined: whole frames alternate between two streams (anim.overlap = 1, two palette buffers): frame n + 1's pose kernels "
+                         "run beside frame n's skinning; one_stream: the whole frame as one dependent chain on one stream; frame_ms is the faster "
+                         "of the two (the host picks the mode per scene); frame_roofline_frac = the skinning's unique bytes / frame_ms / 8 TB/s: "
+                         "the frame end to end against the HBM roofline",
+           "skinned_vertices_per_s_frame": nv / (best_ms * 1e-3), "skinned_vertices_per_s_skin": nv / (skin_ms * 1e-3),
            "roofline": {"bound": "hbm", "kernel": "lbs_skin_crowd" if n_instances >= 4 else "lbs_skin",
-                        "unique_bytes_per_launch": unique, "achieved": unique / (skin_kernel_in_frame_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": unique / (skin_kernel_in_frame_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                        "kernel_us": skin_kernel_in_frame_us,
-                        "kernel_us_note": "the skinning dispatch's own duration (per-dispatch events) INSIDE the frame loop of this workload, i.e. behind the "
-                                          "frame's pose kernels on the stream -- what a kernel trace of the frame reports for it",
-                        "kernel_us_back_to_back": skin_kernel_us,
-                        "frac_back_to_back": unique / (skin_kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                        "back_to_back_note": "the same dispatch when nothing but skinning launches run (each inherits its predecessor's write-back: "
-                                             "a kernel ends when the caches have accepted its stores, not when HBM has them)",
+                        "unique_bytes_per_launch": unique, "achieved": unique / (skin_kernel_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": unique / (skin_kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                        "kernel_us": skin_kernel_us,
+                        "kernel_us_note": "the skinning dispatch's own duration (per-dispatch events) when nothing but skinning launches run, back to back "
+                                          "on one stream: the definition of rounds 1 - 2 and the conservative one (each launch inherits its predecessor's "
+                                          "write-back: a kernel ends when the caches have accepted its stores, not when HBM has them)",
+                        "kernel_us_in_frame": skin_kernel_in_frame_us,
+                        "frac_in_frame": unique / (skin_kernel_in_frame_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                        "in_frame_note": "the same dispatch INSIDE the one-stream frame loop of this workload, i.e. behind the frame's pose kernels -- what a "
+                                         "kernel trace of the frame reports for it (round 3 quoted this one as `frac`)",
                         "launch_period_us": skin_ms * 1e3},
            "parity": {"instances_checked": sorted(oracles), "frames_in_lock_step": n_par,
                       "end_to_end_max_rel_err": chain_err, "end_to_end_bit_exact": chain_exact,
@@ -341,15 +342,79 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     return rec
 
 
-def _c3_record(ctx, n_instances=1000, inst_offset=0, frames=300, parity_instances=(0, 1, 15, 16, 17, 999), fused=True):
-    """BASELINE config 3 (the crowd), or this rank's instance range of it."""
+def _c3_record(ctx, n_instances=1000, inst_offset=0, frames=300, parity_instances=(0, 1, 15, 16, 17, 999), fused=True, root_motion=False):
+    """BASELINE config 3 (the crowd), or this rank's instance range of it.  root_motion: RootMotionSettings on every clip (root = node
+    0, nothing ignored) and AnimationPose::root_motion tracked through the machine (lib.rs:498-661): two more kernels per frame and the
+    planner's root-motion programs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import anim_cases as cases
     from fyrox_amd import synth
     par = sorted({i for i in parity_instances if 0 <= i < n_instances})
-    return _chain_record(ctx, f"C3: crowd of {n_instances} instances x 10k verts / 64 bones, 4-clip blend-tree machine per instance",
-                         cases.c5_blend_tree(n_bones=64, seed=synth.SEED_BASE + 3), synth.make_mesh(10_000, 64, synth.SEED_BASE + 3),
+    sc = cases.c5_blend_tree(n_bones=64, seed=synth.SEED_BASE + 3)
+    name = f"C3: crowd of {n_instances} instances x 10k verts / 64 bones, 4-clip blend-tree machine per instance"
+    if root_motion:
+        for a in sc.animations:
+            a.root_motion = (0, False, False, False, False)
+        sc.track_root_motion = True
+        name += ", root motion on every clip"
+    return _chain_record(ctx, name, sc, synth.make_mesh(10_000, 64, synth.SEED_BASE + 3),
                          n_instances, frames, True, par, inst_offset=inst_offset, fused=fused)
+
+
+def _c3_random_record(ctx, n_instances=1000, n_verts=10_000, n_bones=64, launches=200) -> dict:
+    """C3's skinning launch with FULLY RANDOM bone indices (SURVEY 8(d) worst case) against the coherent mesh, same palettes, same
+    buffers, same process: the crowd kernel's own duration (per-dispatch events), instances 0 and 999 against the oracle."""
+    import oracle as orc
+    from fyrox_amd import synth
+    seed = synth.SEED_BASE + 3
+    pal = synth.make_palette(n_bones, seed, n_instances=n_instances).reshape(n_instances, n_bones, 16)
+    d_pal = ctx.to_device(pal)
+    nv = n_verts * n_instances
+    outs = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+    unique = n_verts * 60 + n_instances * n_bones * 64 + nv * 40
+    res = {}
+    for key, coherent in (("coherent", True), ("random", False)):
+        mesh = synth.make_mesh(n_verts, n_bones, seed, coherent=coherent)
+        ctx.mesh_upload_soa(950, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+
+        def launch():
+            ctx.lbs_skin_device(950, d_pal.ptr, n_bones, n_instances, outs[0].ptr, outs[1].ptr, outs[2].ptr)
+
+        launch()
+        ctx.sync()
+        exact = True
+        for i in (0, n_instances - 1):
+            ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal[i], mesh.normal, mesh.tangent, threads=CHECK_THREADS)
+            got = dl(ctx, _Ptr(outs[0].ptr), i * n_verts * 3, n_verts * 3).reshape(-1, 3)
+            exact &= bool(np.array_equal(got, ref["pos"]))
+        if not exact:
+            raise SystemExit(f"C3, {key} bone indices: the crowd launch differs from the oracle")
+        for _ in range(20):
+            launch()
+        ctx.set_option("lbs.timing", 1)
+        ctx.kernel_time()
+        for _ in range(launches):
+            launch()
+        us, n = ctx.kernel_time()
+        ctx.set_option("lbs.timing", 0)
+        k = us / max(n, 1)
+        res[key] = {"kernel_us": k, "frac": unique / (k * 1e-6) / 1e9 / HBM_PEAK_GBPS, "bit_exact": exact}
+        ctx.mesh_free(950)
+    for b in outs:
+        b.free()
+    d_pal.free()
+    return {"workload": f"C3's skinning launch ({n_instances} x {n_verts} verts / {n_bones} bones, synthetic palettes) with coherent and with FULLY RANDOM bone "
+                        "indices (SURVEY 8(d) worst case), the kernel's own duration back to back",
+            **res, "slowdown_vs_coherent": res["random"]["kernel_us"] / res["coherent"]["kernel_us"] - 1.0}
+
+
+class _Ptr:
+    """Stands in for a torch tensor where dl() only needs the address."""
+    def __init__(self, p):
+        self._p = p
+
+    def data_ptr(self):
+        return self._p
 
 
 def _vertex_buffer_record(ctx, n_verts=1_000_000, n_bones=256, n_shapes=4, sets=6, steps=400) -> dict:
@@ -552,9 +617,11 @@ def extras(ctx) -> dict:
     guarded("c3", lambda: _c3_record(ctx))
     if isinstance(out.get("c3"), dict) and "fused" in out["c3"]:
         out["c3_fused"] = out["c3"].pop("fused")
+    guarded("c3_root_motion", lambda: _c3_record(ctx, frames=200, parity_instances=(0, 999), fused=False, root_motion=True))
     guarded("c5", lambda: _chain_record(ctx, "C5: Machine 4-clip blend tree -> palette -> 100k-vert LBS",
                                         cases.c5_blend_tree(n_bones=64), synth.make_mesh(100_000, 64, synth.SEED_BASE + 5), 1, 400, False, [0]))
     ctx.set_option("lbs.streams", streams)
+    guarded("c3_random_bones", lambda: _c3_random_record(ctx))
     for key, fn in (("scene_64x4", lambda: _scene_record(ctx, 64, 4, 20_000, 1_000_000)), ("scene_256x1", lambda: _scene_record(ctx, 256, 1, 5_000, 2_000_000)),
                     ("vertex_buffer", lambda: _vertex_buffer_record(ctx))):
         try:
@@ -631,6 +698,22 @@ def _host_control_plane_record(frames: int = 200) -> dict:
 
 # ---- main ---------------------------------------------------------------------------------------------------------------
 
+def launcher_command(n_gpus: int, argv: list) -> list:
+    """What `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) re-executes itself as: the driver's own launch line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def check_world(n_gpus: int, world: int) -> None:
+    """One rank per GPU or no line at all: `n_gpus` in the line is the number of ranks that ran."""
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: the line would carry the wrong n_gpus")
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -641,16 +724,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.extras_only:
         # `python bench.py --gpus N` launched plainly: one rank per GPU is what the line promises, so this process becomes the
         # launcher the driver would have used (same module, same arguments) instead of measuring one GPU under the label of N
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd = launcher_command(args.gpus, sys.argv[1:])
         print(f"# bench.py --gpus {args.gpus} without a launcher: re-executing as {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
         os.execv(sys.executable, cmd)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would carry the wrong n_gpus")
+    check_world(args.gpus, world)
 
     if args.extras_only:
         # The other BASELINE configs and the scene tick, in a process of their own: their pipelined frames are bound by the host's
@@ -697,7 +774,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    opt_keys = ("lbs.blocks_per_cu", "lbs.exact", "lbs.streams", "lbs.dyn", "lbs.crowd", "anim.inline_ctrl", "comm.form")
+    opt_keys = ("lbs.blocks_per_cu", "lbs.exact", "lbs.streams", "lbs.dyn", "lbs.crowd", "anim.inline_ctrl", "anim.ctrl_upload", "anim.update_lean",
+                "streams.priority", "comm.form")
     opts = {k: ctx.get_option(k) for k in opt_keys}
     n_ranks_rccl, comm_error = None, None
     if world > 1:      # the library's own communicator (fyx_comm_init): rank 0's unique id travels over the process group
@@ -830,7 +908,33 @@ def main():
         us, n = ctx.kernel_time()
         ker.append(us / max(n, 1))
     ctx.set_option("lbs.timing", 0)
-    kernel_us = max_over_ranks(float(np.median(ker)))          # the kernel's own duration, averaged over n_ser launches
+    # The same measurement on FRESH allocations of the eight output sets (hipMalloc through the library, the first sets still held, so
+    # the addresses differ): where the pages of the outputs land moves a lone launch by several per cent, and one allocation is one
+    # sample of that.  roofline.kernel_us is the median over all allocations of this process.
+    alloc_us = [float(np.median(ker))]
+    if rank == 0 and world == 1:
+        held = []
+        for rep in range(3):
+            fresh = [(ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)) for _ in range(n_sets)]
+            held.append(fresh)
+            fcalls = [partial(fn, ctx._h, ctypes.c_uint64(s_), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
+                              ctypes.c_void_p(o[0].ptr), ctypes.c_void_p(o[1].ptr), ctypes.c_void_p(o[2].ptr)) for s_, o in enumerate(fresh)]
+            ctx.set_option("lbs.streams", 1)
+            for i in range(50):
+                fcalls[i % n_sets]()
+            ctx.set_option("lbs.timing", 1)
+            ctx.kernel_time()
+            for i in range(n_ser):
+                fcalls[i % n_sets]()
+            us, n = ctx.kernel_time()
+            ctx.set_option("lbs.timing", 0)
+            alloc_us.append(us / max(n, 1))
+        for fresh in held:
+            for o in fresh:
+                for b_ in o:
+                    b_.free()
+        ctx.set_option("lbs.streams", opts["lbs.streams"])
+    kernel_us = max_over_ranks(float(np.median(alloc_us)))     # the kernel's own duration: median over the allocations, each averaged over n_ser launches
     period_us = max_over_ranks(float(np.median(ser)))          # launch to launch on one stream (adds the dependent-launch gap)
     ctx.set_option("lbs.streams", opts["lbs.streams"])
     # ---- position only: what the reference's CPU loop computes (mesh/mod.rs:501-522): 32 B read + 12 B written per vertex ----
@@ -861,6 +965,51 @@ def main():
                     "kernel_us": pk, "frac": 44 * nv / (pk * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                     "overlapped_us": ov, "overlapped_frac": 44 * nv / (ov * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                     "vertices_per_s_overlapped": nv / (ov * 1e-6)}
+    # ---- the worst case SURVEY 8(d) defines: FULLY RANDOM bone indices (a wave's 64 lanes gather 64 unrelated palette rows from LDS
+    # per influence instead of mostly the same few), same launch, same buffers, same run ----
+    random_rec = None
+    if rank == 0 and world == 1 and not args.random_bones and not args.no_extras:
+        rmesh = synth.make_mesh(args.verts, args.bones, seed, coherent=False)
+        for s_ in range(n_sets):
+            ctx.mesh_upload_soa(300 + s_, rmesh.pos, rmesh.weights, rmesh.indices, rmesh.normal, rmesh.tangent)
+        rcalls = [partial(fn, ctx._h, ctypes.c_uint64(300 + s_), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
+                          ctypes.c_void_p(o[0].data_ptr()), ctypes.c_void_p(o[1].data_ptr()), ctypes.c_void_p(o[2].data_ptr())) for s_, o in enumerate(outs)]
+        for o in outs[0]:
+            zero(ctx, o)
+        rcalls[0]()
+        ctx.sync()
+        rpar = lbs_parity(ctx, rmesh, pal, outs[0], nv)
+        if not rpar["bit_exact"]:
+            raise SystemExit("random bone indices: the launch differs from the oracle")
+        ctx.set_option("lbs.streams", 1)
+        for i in range(50):
+            rcalls[i % n_sets]()
+        ctx.set_option("lbs.timing", 1)
+        ctx.kernel_time()
+        rk = []
+        for _ in range(3):
+            for i in range(n_ser):
+                rcalls[i % n_sets]()
+            us, n = ctx.kernel_time()
+            rk.append(us / max(n, 1))
+        ctx.set_option("lbs.timing", 0)
+        ctx.set_option("lbs.streams", opts["lbs.streams"])
+        for i in range(50):
+            rcalls[i % n_sets]()
+        ctx.sync()
+        ctx.timer_begin()
+        for i in range(n_ser):
+            rcalls[i % n_sets]()
+        rov = ctx.timer_end() * 1e3 / n_ser
+        rkm = float(np.median(rk))
+        random_rec = {"workload": f"C4 with FULLY RANDOM bone indices (SURVEY 8(d) worst case): {nv} verts / {args.bones} bones, same launch and buffers",
+                      "kernel_us": rkm, "frac": BYTES_PER_VERTEX * nv / (rkm * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                      "kernel_us_coherent_same_run": kernel_us, "slowdown_vs_coherent": rkm / kernel_us - 1.0,
+                      "overlapped_us": rov, "overlapped_frac": BYTES_PER_VERTEX * nv / (rov * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                      "value": nv / (rov * 1e-6), "unit": "vertices/s (launches overlapped on the launch streams, as the headline)",
+                      "parity": rpar}
+        for s_ in range(n_sets):
+            ctx.mesh_free(300 + s_)
     # ---- no-math copy of the same bytes (60 MB in, 40 MB out per launch), same run: what a 100 MB launch can do here ----
     copy_us = None
     if rank == 0:
@@ -1008,6 +1157,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_us": kernel_us,
+                         "kernel_us_min": float(np.min(alloc_us)), "kernel_us_median": float(np.median(alloc_us)), "kernel_us_max": float(np.max(alloc_us)),
+                         "kernel_us_per_allocation": alloc_us,
+                         "allocations_note": f"{len(alloc_us)} allocations of the {args.sets} output sets in this process (the first through torch, the others "
+                                             "through fyx_malloc), each the average of the per-dispatch durations of a few hundred launches; "
+                                             "kernel_us and frac are the MEDIAN",
                          "kernel_us_note": "launches serialized on one stream, each with its own start / stop HIP events (hipExtLaunchKernel: the "
                                            f"dispatch's timestamps, what rocprofv3 --kernel-trace reports per dispatch); average of {n_ser} launches",
                          "serialized_period_us": period_us,
@@ -1024,6 +1178,8 @@ def main():
             "parity": parity,
         }
         extra = {}
+        if random_rec is not None:
+            extra["c4_random_bones"] = random_rec
         if strong is not None:
             extra["strong_scaling"] = strong
         if world == 1 and not args.no_extras and args.scaling == "weak":

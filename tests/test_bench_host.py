@@ -39,3 +39,28 @@ def test_argument_parser_defaults_match_the_driver_contract():
     finally:
         sys.argv = argv
     assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+
+
+def test_a_plain_launch_with_several_gpus_becomes_the_drivers_launch_line():
+    """`python bench.py --gpus 8` without a launcher must not measure one GPU under the label of eight: it re-executes
+    itself under torch.distributed.run with one rank per GPU, and a world size that does not match --gpus is refused."""
+    import pytest
+    b = _bench()
+    cmd = b.launcher_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    b.check_world(8, 8)
+    b.check_world(1, 1)
+    for n, w in ((8, 1), (1, 2), (4, 8)):
+        with pytest.raises(SystemExit):
+            b.check_world(n, w)
+
+
+def test_main_refuses_a_mismatching_world_before_it_touches_a_gpu():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert cp.returncode != 0 and "WORLD_SIZE=1" in (cp.stderr + cp.stdout) and "n_gpus" not in cp.stdout
