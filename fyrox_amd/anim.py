@@ -712,6 +712,34 @@ def create_bone_list(ctx, bones_id: int, rig_id: int, bone_nodes) -> None:
     ctx._check(ctx._l.fyx_bone_list_create(ctx._h, bones_id, rig_id, len(b), _ptr(b)))
 
 
+def curve_simplify(x, y, epsilon: float, max_step: float = float("inf")) -> np.ndarray:
+    """Indices of the points the glTF importer keeps (fyx_curve_simplify; gltf/simplify.rs:39-66)."""
+    import ctypes
+    from . import _native
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    out = np.zeros(max(x.size, 1), np.uint32)
+    n = ctypes.c_uint32()
+    rc = _native.lib().fyx_curve_simplify(_ptr(x), _ptr(y), x.size, ctypes.c_float(epsilon), ctypes.c_float(max_step), _ptr(out), ctypes.byref(n))
+    if rc:
+        raise ValueError(f"fyx_curve_simplify -> {rc}")
+    return out[:n.value].copy()
+
+
+def blend_space_triangulate(points_xy) -> np.ndarray:
+    """(n_triangles, 3) point indices (fyx_blend_space_triangulate; blendspace.rs:416-447)."""
+    import ctypes
+    from . import _native
+    pts = np.ascontiguousarray(points_xy, np.float32).reshape(-1, 2)
+    cap = 4 * pts.shape[0] + 4
+    out = np.zeros(3 * cap, np.uint32)
+    n = ctypes.c_uint32()
+    rc = _native.lib().fyx_blend_space_triangulate(_ptr(pts), pts.shape[0], _ptr(out), cap, ctypes.byref(n))
+    if rc:
+        raise ValueError(f"fyx_blend_space_triangulate -> {rc}")
+    return out[:3 * n.value].reshape(-1, 3).copy()
+
+
 def decode_ops(ops: np.ndarray) -> List[Tuple[str, int, float]]:
     out = []
     for x, y in ops:

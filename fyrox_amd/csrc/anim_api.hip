@@ -239,7 +239,9 @@ int fyx_rig_create(fyx_ctx* c, uint64_t rig_id, uint32_t n_nodes, const int32_t*
         for (uint32_t i = 0; i < n_nodes; ++i) level_nodes[cur[depth[i]]++] = i;
     }
     static_assert(kMaxRigNodes <= 1024, "RigDev::walk packs node (10 bits), parent + 1 (11) and depth (11) into one word");
-    for (uint32_t& e : level_nodes) e = e | (uint32_t)(parent[e] + 1) << 10 | depth[e] << 21;
+    // (ANY negative parent is a root, as everywhere else in the host code: only -1 may be incremented into the 11-bit field)
+    for (uint32_t& e : level_nodes) e = e | (parent[e] < 0 ? 0u : (uint32_t)parent[e] + 1u) << 10 | depth[e] << 21;
+    r.walk = level_nodes;
     r.init_trs.assign((size_t)n_nodes * 12, 0.f);
     std::vector<float> statics((size_t)n_nodes * 28, 0.f);
     for (uint32_t i = 0; i < n_nodes; ++i) {
@@ -994,6 +996,35 @@ int fyx_debug_scene_tables(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_
     if (out_blocks) memcpy(out_blocks, tables[stage].data(), std::min<size_t>(tables[stage].size(), capacity) * sizeof(uint4));
     return FYX_OK;
     FYX_GUARD_END(c)
+}
+
+int fyx_debug_rig_walk(fyx_ctx* c, uint64_t rig_id, uint32_t* out_words, uint32_t capacity, uint32_t* n_words) {
+    if (!c || !n_words) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    auto it = store(c).rigs.find(rig_id);
+    if (it == store(c).rigs.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "rig %llu", (unsigned long long)rig_id);
+    const std::vector<uint32_t>& w = it->second.walk;
+    *n_words = (uint32_t)w.size();
+    if (out_words) memcpy(out_words, w.data(), std::min<size_t>(w.size(), capacity) * 4);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+// The kernels' decision-making leaves, compiled for the host (anim_leaves.h): what the CPU suite runs against the oracle.
+int fyx_debug_span_value_at(const float* span_records, uint32_t n_keys, uint32_t need, float time, uint32_t hint, float out_values[4], uint32_t* out_hint) {
+    if (!span_records || !out_values || !out_hint || n_keys < 2 || need < 1 || need > 4) return FYX_ERR_INVALID_ARG;
+    const uint32_t stride = need == 4 ? 16u : 8u;           // f4 per span: pose_sample_crowd_body's choice
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
+    *out_hint = span_track_value_at(reinterpret_cast<const f4*>(span_records), n_keys, stride, (int)need, time, hint, val);
+    memcpy(out_values, val, 16);
+    return FYX_OK;
+}
+
+int fyx_debug_classify_fold_program(const uint32_t* ops_xy, uint32_t n_ops, uint32_t* out_d, uint32_t* out_k, int* out_mask, int* out_player, int* out_straight) {
+    if ((n_ops && !ops_xy) || !out_d || !out_k || !out_mask || !out_player || !out_straight) return FYX_ERR_INVALID_ARG;
+    const StraightShape s = classify_fold_program_host(ops_xy, n_ops);
+    *out_d = s.d; *out_k = s.k; *out_mask = s.mask; *out_player = s.player; *out_straight = s.straight;
+    return FYX_OK;
 }
 
 int fyx_scene_plan(fyx_ctx* c, const uint64_t* animator_ids, uint32_t n_animators, float dt) {

@@ -25,6 +25,7 @@ struct Rig {
     std::vector<float> init_trs;  // [n_nodes][12]
     float* d_statics = nullptr;
     uint32_t* d_walk = nullptr;          // RigDev::walk
+    std::vector<uint32_t> walk;          // host copy of it (fyx_debug_rig_walk)
     float* d_inv_bind = nullptr;
 };
 

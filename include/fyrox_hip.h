@@ -740,6 +740,24 @@ int fyx_comm_init_all(fyx_ctx* const* ctxs, int n);
 int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, float* const* d_pos_all,
                               float* const* d_normal_all, float* const* d_tangent_all);
 
+/* ---- importer / editor helpers (pure host functions: no context, no GPU) ---------------- */
+/* Which points of a sampled curve the glTF importer keeps (fyrox-impl/src/resource/gltf/simplify.rs:39-66 find_important_points,
+ * applied to every imported curve by gltf/animation.rs:155-163 with the binding's epsilon / max_step, :50-65: Position 0.001 / inf,
+ * Rotation pi/180 / pi/4, Scale 0.1 / inf, morph weights 0.001 / inf): Ramer-Douglas-Peucker on (x, y) with the reference's
+ * vertical distance, then at most max_step between kept values (max_step = INFINITY: no limit), and a curve of two equal values
+ * collapses to one key.  out_indices has room for n; *out_count = the number kept.  Pinned by the reference's 14 tests
+ * (simplify.rs:145-229, tests/golden/fyrox_unit_vectors.json). */
+int fyx_curve_simplify(const float* x, const float* y, uint32_t n, float epsilon, float max_step, uint32_t* out_indices, uint32_t* out_count);
+/* The triangles of a BlendSpace (blendspace.rs:416-447 triangulate, called by fetch_weights after set_points): what
+ * fyx_layer_add_blend_space takes as `triangles` when the engine does not bring its own.  Delaunay triangulation of the points in
+ * insertion order; every triangle counter-clockwise, starting at its newest point, triangles listed by newest point -- the
+ * reference's fixture (blendspace.rs:455-484: the unit square -> [2, 0, 1], [3, 0, 2]).  The reference delegates to the `spade`
+ * crate, whose face order for larger inputs nothing in the reference pins; results of fetch_weights that depend on it (the fold
+ * order of a triangle's three poses) are exact against the engine only with the engine's own triangles.  Fewer than three points:
+ * no triangles (the reference returns false); a non-finite coordinate: FYX_ERR_INVALID_ARG.  Writes min(*out_count, capacity)
+ * triangles of three point indices. */
+int fyx_blend_space_triangulate(const float* points_xy, uint32_t n_points, uint32_t* out_triangles, uint32_t capacity, uint32_t* out_count);
+
 /* ---- control plane without a GPU ----------------------------------------------------- */
 /* A context with no device: registry and control-plane calls work, every call that would touch
  * the GPU returns FYX_ERR_NO_DEVICE.  It computes no poses and no vertices -- it exists so the
@@ -770,6 +788,20 @@ int fyx_scene_plan(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t n_animat
  * Depends on the animators' shapes only; needs no GPU (a test hook, like fyx_animator_plan). */
 int fyx_debug_scene_tables(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t n_animators, int stage,
                            uint32_t* out_blocks, uint32_t capacity, uint32_t* n_blocks);
+
+/* Test hooks for the CPU suite (no GPU, no context for the last two).
+ *   fyx_debug_rig_walk: the rig's hierarchy-walk table as the update kernel reads it -- one word per node in level order:
+ *     node | (parent + 1) << 10 | depth << 21 (any negative parent is a root: field 0).
+ *   fyx_debug_span_value_at / fyx_debug_classify_fold_program: the kernels' own decision-making leaves (csrc/anim_leaves.h,
+ *     __host__ __device__) compiled for the host -- Curve::value_at for the `need` (3 or 4) curves of one track on its span
+ *     records (n_keys - 1 records of 8 or 16 float4: {loc[i-1], loc[i], -, -} then per curve {value, kind bits, left tangent,
+ *     right tangent} of keys i - 1 and i), returning the values and the new hint; and the classifier that decides whether a fold
+ *     program {opcode | arg << 8, f32 weight bits} x n_ops is "straight" (d leading PUSHes, k operands, a MASK before the APPLY,
+ *     or the AnimationPlayer's APPLY_ANIM^k END) -- the function by which the host picks the update kernel's lean form. */
+int fyx_debug_rig_walk(fyx_ctx* ctx, uint64_t rig_id, uint32_t* out_words, uint32_t capacity, uint32_t* n_words);
+int fyx_debug_span_value_at(const float* span_records, uint32_t n_keys, uint32_t need, float time, uint32_t hint, float out_values[4], uint32_t* out_hint);
+int fyx_debug_classify_fold_program(const uint32_t* ops_xy, uint32_t n_ops, uint32_t* out_d, uint32_t* out_k, int* out_mask, int* out_player,
+                                    int* out_straight);
 
 /* The root-motion program of the frame fyx_animator_plan planned last (mode 1, tracking on):
  * program_offset is [n_instances + 1]; ops are {opcode, dst slot, src slot | animation, f32

@@ -71,6 +71,8 @@ def lib() -> ctypes.CDLL:
         _lib.fo_accurate_world_bounding_box.restype = c_uint32
         _lib.fo_omp_max_threads.restype = c_int
         _lib.fo_track_fetch.restype = c_int
+        _lib.fo_find_important_points.restype = c_uint32
+        _lib.fo_blend_space_triangulate.restype = ctypes.c_int32
     return _lib
 
 
@@ -291,6 +293,23 @@ def accurate_world_bounding_box(aos, n_verts, stride, off_pos, off_weights, off_
                                          c_int(off_weights), c_int(off_indices), _p(pal),
                                          c_uint32(pal.shape[0]), _p(box))
     return box
+
+
+def find_important_points(x, y, epsilon: float, max_step: float = float("inf")) -> np.ndarray:
+    """gltf/simplify.rs:39-66: indices of the kept points."""
+    x, y = _f32(x), _f32(y)
+    out = np.zeros(max(x.size, 1), np.uint32)
+    m = lib().fo_find_important_points(_p(x), _p(y), c_uint32(x.size), c_float(epsilon), c_float(max_step), _p(out))
+    return out[:m].copy()
+
+
+def blend_space_triangulate(points_xy):
+    """blendspace.rs:416-447: (n_triangles, 3) point indices, or None where the reference's triangulate() returns false for a bad point."""
+    pts = _f32(points_xy).reshape(-1, 2)
+    cap = 4 * pts.shape[0] + 4
+    out = np.zeros(3 * cap, np.uint32)
+    m = lib().fo_blend_space_triangulate(_p(pts), c_uint32(pts.shape[0]), _p(out), c_uint32(cap))
+    return None if m < 0 else out[:3 * m].reshape(-1, 3).copy()
 
 
 def omp_max_threads() -> int:

@@ -9,6 +9,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -551,4 +552,151 @@ void fo_apply_blend_shapes(uint32_t n_verts, const float* pos, const float* nrm,
         if (nrm && out_nrm) memcpy(out_nrm + (size_t)v * 3, n, 12);
         if (tan && out_tan) memcpy(out_tan + (size_t)v * 4, t, 16);
     }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * glTF importer: curve simplification (fyrox-impl/src/resource/gltf/simplify.rs:39-140), run on every imported curve
+ * (gltf/animation.rs:155-163, :292) with the binding's epsilon / max_step (animation.rs:50-65): decides which keys a
+ * glTF-built track has.  Restated function by function, recursion included.
+ * ------------------------------------------------------------------------------------- */
+static void fo_find_points_in_span(const float* x, const float* y, uint8_t* keep, size_t start, size_t end, float epsilon) {
+    if (end <= start + 1) return;                                   /* simplify.rs:114-116 */
+    const float x0 = x[start], y0 = y[start];
+    const float slope = (y[end] - y0) / (x[end] - x0);              /* :119 */
+    size_t far_index = 0;
+    float far_dist = 0.0f;
+    for (size_t i = start + 1; i < end; ++i) {                      /* :122-129 */
+        const float y_line = y0 + slope * (x[i] - x0);
+        const float dist = fabsf(y[i] - y_line);
+        if (far_dist < dist) { far_dist = dist; far_index = i; }
+    }
+    if (far_index == 0 || far_dist < epsilon) return;               /* :131-133 */
+    keep[far_index] = 1;
+    fo_find_points_in_span(x, y, keep, start, far_index, epsilon);
+    fo_find_points_in_span(x, y, keep, far_index, end, epsilon);
+}
+
+static size_t fo_find_step(size_t start, const float* y, size_t n, const uint8_t* keep, float max_step) {   /* :86-102 */
+    const float start_y = y[start];
+    for (size_t i = start + 1; i < n; ++i) {
+        const float step = fabsf(y[i] - start_y);
+        if (step > max_step) return (i - 1 > start + 1) ? i - 1 : start + 1;
+        else if (keep[i]) return i;
+    }
+    return n - 1;
+}
+
+/* find_important_points (simplify.rs:39-66): indices of the kept points into out (room for n); returns their number.
+ * max_step: INFINITY = no step limit (is_finite() false). */
+uint32_t fo_find_important_points(const float* x, const float* y, uint32_t n, float epsilon, float max_step, uint32_t* out) {
+    if (n == 0) return 0;
+    uint8_t* keep = (uint8_t*)calloc(n, 1);
+    const size_t end = (size_t)n - 1;
+    keep[0] = 1;
+    keep[end] = 1;
+    fo_find_points_in_span(x, y, keep, 0, end, epsilon);
+    if (isfinite(max_step)) {                                       /* limit_step_size, :69-81 */
+        size_t i = 1;
+        while (i < end) {
+            if (keep[i]) { i += 1; }
+            else {
+                const size_t next = fo_find_step(i - 1, y, n, keep, max_step);
+                keep[next] = 1;
+                i = (next + 1 > i + 1) ? next + 1 : i + 1;
+            }
+        }
+    }
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) if (keep[i]) out[m++] = i;
+    if (m == 2 && fabsf(y[out[0]] - y[out[1]]) < epsilon) m = 1;    /* :62-64 */
+    free(keep);
+    return m;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * BlendSpace::triangulate (fyrox-animation/src/machine/node/blendspace.rs:416-447).  The reference inserts the points,
+ * in order, into a spade::DelaunayTriangulation (crate `spade` 2.x -- not vendored, not buildable here) and lists every
+ * inner face as the origins of its three edges.  Restated from the published algorithm + the one vector the reference
+ * holds (blendspace.rs:455-484: the unit square -> [2, 0, 1], [3, 0, 2]):
+ *   * the triangles are the Delaunay triangulation of the points; for co-circular points the diagonal that exists when
+ *     the later point arrives stays (insertion order decides: incremental insertion, strict in-circle test);
+ *   * each triangle is counter-clockwise and starts at its NEWEST point (the face was made by that point's insertion),
+ *     triangles are listed by newest point, then by the other two.
+ * The second rule is what the fixture shows; spade's face order for larger inputs is NOT pinned by anything in the
+ * reference ("parity unpinned" beyond the fixture).  Here: Bowyer-Watson, written as cavity re-triangulation over an
+ * explicit triangle list with a far-away bounding triangle; all predicates in double on f32 inputs.
+ * Returns the number of triangles (0 for fewer than three points), -1 when a coordinate is not finite (spade's insert
+ * fails: the reference returns false with no triangles).  A point equal to an earlier one adds nothing.
+ * ------------------------------------------------------------------------------------- */
+static double fo_orient2d(const double* a, const double* b, const double* c) {
+    return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
+}
+static int fo_in_circle(const double* a, const double* b, const double* c, const double* p) {   /* a, b, c counter-clockwise */
+    const double ax = a[0] - p[0], ay = a[1] - p[1], bx = b[0] - p[0], by = b[1] - p[1], cx = c[0] - p[0], cy = c[1] - p[1];
+    const double det = (ax * ax + ay * ay) * (bx * cy - cx * by) - (bx * bx + by * by) * (ax * cy - cx * ay) + (cx * cx + cy * cy) * (ax * by - bx * ay);
+    return det > 0.0;
+}
+
+int32_t fo_blend_space_triangulate(const float* xy, uint32_t n, uint32_t* out_tri, uint32_t capacity) {
+    for (uint32_t i = 0; i < 2 * n; ++i) if (!isfinite(xy[i])) return -1;
+    if (n < 3) return 0;
+    double lo[2] = {xy[0], xy[1]}, hi[2] = {xy[0], xy[1]};
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 2; ++k) { if (xy[2 * i + k] < lo[k]) lo[k] = xy[2 * i + k]; if (xy[2 * i + k] > hi[k]) hi[k] = xy[2 * i + k]; }
+    double ext = (hi[0] - lo[0] > hi[1] - lo[1]) ? hi[0] - lo[0] : hi[1] - lo[1];
+    if (ext <= 0.0) ext = 1.0;
+    const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), R = ext * 1.0e4;
+    double* P = (double*)malloc(sizeof(double) * 2 * ((size_t)n + 3));
+    for (uint32_t i = 0; i < n; ++i) { P[2 * i] = xy[2 * i]; P[2 * i + 1] = xy[2 * i + 1]; }
+    P[2 * n] = cx - 2.0 * R; P[2 * n + 1] = cy - R;              /* the bounding triangle: vertices n, n + 1, n + 2 (ccw) */
+    P[2 * n + 2] = cx + 2.0 * R; P[2 * n + 3] = cy - R;
+    P[2 * n + 4] = cx; P[2 * n + 5] = cy + 2.0 * R;
+    size_t cap_t = 16 * ((size_t)n + 4), nt = 0;
+    uint32_t* T = (uint32_t*)malloc(sizeof(uint32_t) * 3 * cap_t);
+    uint32_t* E = (uint32_t*)malloc(sizeof(uint32_t) * 2 * 3 * cap_t);
+    T[0] = n; T[1] = n + 1; T[2] = n + 2; nt = 1;
+    for (uint32_t p = 0; p < n; ++p) {
+        int dup = 0;
+        for (uint32_t q = 0; q < p && !dup; ++q) dup = (xy[2 * q] == xy[2 * p] && xy[2 * q + 1] == xy[2 * p + 1]);
+        if (dup) continue;
+        /* the cavity: every triangle whose circumcircle strictly contains p; its boundary edges get a triangle with p */
+        size_t ne = 0, keep = 0;
+        for (size_t t = 0; t < nt; ++t) {
+            const uint32_t a = T[3 * t], b = T[3 * t + 1], c = T[3 * t + 2];
+            if (fo_in_circle(&P[2 * a], &P[2 * b], &P[2 * c], &P[2 * p])) {
+                const uint32_t e[3][2] = {{a, b}, {b, c}, {c, a}};
+                for (int k = 0; k < 3; ++k) { E[2 * ne] = e[k][0]; E[2 * ne + 1] = e[k][1]; ++ne; }
+            } else {
+                T[3 * keep] = a; T[3 * keep + 1] = b; T[3 * keep + 2] = c; ++keep;
+            }
+        }
+        nt = keep;
+        for (size_t i = 0; i < ne; ++i) {
+            int shared = 0;                                         /* an edge inside the cavity appears twice, reversed */
+            for (size_t j = 0; j < ne && !shared; ++j) shared = (j != i && E[2 * j] == E[2 * i + 1] && E[2 * j + 1] == E[2 * i]);
+            if (shared) continue;
+            const uint32_t a = E[2 * i], b = E[2 * i + 1];
+            if (fo_orient2d(&P[2 * a], &P[2 * b], &P[2 * p]) <= 0.0) continue;   /* p on the edge's line: a sliver of zero area */
+            if (nt < cap_t) { T[3 * nt] = p; T[3 * nt + 1] = a; T[3 * nt + 2] = b; ++nt; }
+        }
+    }
+    /* inner faces: no bounding vertex; newest point first, counter-clockwise; listed by (newest, second, third) */
+    size_t m = 0;
+    for (size_t t = 0; t < nt; ++t) {
+        uint32_t v[3] = {T[3 * t], T[3 * t + 1], T[3 * t + 2]};
+        if (v[0] >= n || v[1] >= n || v[2] >= n) continue;
+        const int top = (v[0] > v[1] && v[0] > v[2]) ? 0 : (v[1] > v[2] ? 1 : 2);
+        T[3 * m] = v[top]; T[3 * m + 1] = v[(top + 1) % 3]; T[3 * m + 2] = v[(top + 2) % 3]; ++m;
+    }
+    for (size_t i = 1; i < m; ++i) {                                /* insertion sort, lexicographic */
+        uint32_t k[3] = {T[3 * i], T[3 * i + 1], T[3 * i + 2]};
+        size_t j = i;
+        while (j > 0 && (T[3 * (j - 1)] > k[0] || (T[3 * (j - 1)] == k[0] && (T[3 * (j - 1) + 1] > k[1] || (T[3 * (j - 1) + 1] == k[1] && T[3 * (j - 1) + 2] > k[2]))))) {
+            T[3 * j] = T[3 * (j - 1)]; T[3 * j + 1] = T[3 * (j - 1) + 1]; T[3 * j + 2] = T[3 * (j - 1) + 2]; --j;
+        }
+        T[3 * j] = k[0]; T[3 * j + 1] = k[1]; T[3 * j + 2] = k[2];
+    }
+    for (size_t i = 0; i < m && i < capacity; ++i) { out_tri[3 * i] = T[3 * i]; out_tri[3 * i + 1] = T[3 * i + 1]; out_tri[3 * i + 2] = T[3 * i + 2]; }
+    free(P); free(T); free(E);
+    return (int32_t)m;
 }

@@ -233,6 +233,10 @@ int fo_blend_space_fetch_weights(int n_points, const float* pts_xy, int n_tris, 
                                  const float sampling_point[2], int idx[3], float w[3]);
 const fo_pose* fo_machine_evaluate_pose(fo_machine*, fo_animation* const* anims, int n_anims, float dt);
 
+/* gltf/simplify.rs:39-66 find_important_points; blendspace.rs:416-447 triangulate (see fyrox_oracle.c) */
+uint32_t fo_find_important_points(const float* x, const float* y, uint32_t n, float epsilon, float max_step, uint32_t* out);
+int32_t fo_blend_space_triangulate(const float* xy, uint32_t n, uint32_t* out_tri, uint32_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

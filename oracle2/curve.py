@@ -109,3 +109,58 @@ class Curve:
         left, right = ks[max(hint - 1, 0)], ks[hint]
         t = (location - left.location) / (right.location - left.location)
         return interpolate(left, right, t), hint
+
+
+def find_important_points(points, epsilon, max_step=float("inf")):
+    """gltf/simplify.rs:39-140 in numpy float32, written from the Rust source (recursive, as the reference): the indices of the points
+    the glTF importer keeps."""
+    f = np.float32
+    xs = [f(p[0]) for p in points]
+    ys = [f(p[1]) for p in points]
+    n = len(points)
+    if n == 0:
+        return []
+    keep = [False] * n
+    keep[0] = keep[n - 1] = True
+    eps, ms = f(epsilon), f(max_step)
+
+    def span(start, end):
+        if end <= start + 1:
+            return
+        x0, y0 = xs[start], ys[start]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            slope = f(f(ys[end] - y0) / f(xs[end] - x0))
+        far_i, far_d = 0, f(0.0)
+        for i in range(start + 1, end):
+            y_line = f(y0 + f(slope * f(xs[i] - x0)))
+            dist = f(abs(f(ys[i] - y_line)))
+            if far_d < dist:
+                far_d, far_i = dist, i
+        if far_i == 0 or far_d < eps:
+            return
+        keep[far_i] = True
+        span(start, far_i)
+        span(far_i, end)
+
+    span(0, n - 1)
+    if np.isfinite(ms):
+        def find_step(start):
+            sy = ys[start]
+            for i in range(start + 1, n):
+                if f(abs(f(ys[i] - sy))) > ms:
+                    return max(i - 1, start + 1)
+                if keep[i]:
+                    return i
+            return n - 1
+        i = 1
+        while i < n - 1:
+            if keep[i]:
+                i += 1
+            else:
+                nxt = find_step(i - 1)
+                keep[nxt] = True
+                i = max(nxt + 1, i + 1)
+    res = [i for i, k in enumerate(keep) if k]
+    if len(res) == 2 and f(abs(f(ys[res[0]] - ys[res[1]]))) < eps:
+        res.pop()
+    return res

@@ -1,0 +1,176 @@
+"""The kernels' decision-making leaves, run on the CPU: csrc/anim_leaves.h is __host__ __device__ code -- the crowd sampler's
+span_track_value_at and pose_update's straight-program classifier are THE SAME functions in the kernels and behind the
+fyx_debug_* entry points called here (the CPU suite used to check a Python model of them).
+
+* span_track_value_at decides Curve::value_at (curve.rs:254-314) ONCE for the three or four curves of a track that share their key
+  times, on span records: clamp at the ends, the hinted span, else partition_point(k.location < time) -- found without a search
+  when it is the hint itself or a neighbouring key.  Against the oracle's per-curve value_at: value bits AND resulting hint, random
+  keys (duplicate locations included), times on and beside every key, every possible incoming hint.
+* classify_fold_program: the shapes the planner emits and their near misses.
+* the rig's walk table: any negative parent is a root."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import fyrox_amd
+import oracle
+from fyrox_amd import _native, anim as A
+
+OP_END, OP_BLEND_ANIM, OP_PUSH, OP_POP_BLEND, OP_RESET, OP_MASK, OP_APPLY, OP_APPLY_ANIM = range(8)
+
+
+def _span_records(loc, curves):
+    """What fyx_tracks_data_upload builds (anim_api.hip): per span {loc[i-1], loc[i], 0, 0} then per curve aux[i-1], aux[i];
+    aux = {value, key kind bits, left tangent, right tangent} with the tangents of non-cubic keys zeroed."""
+    n, need = len(loc), len(curves)
+    stride = 16 if need == 4 else 8
+    rec = np.zeros((n - 1, stride, 4), np.float32)
+    for i in range(1, n):
+        rec[i - 1, 0, 0], rec[i - 1, 0, 1] = loc[i - 1], loc[i]
+        for c, (val, kind, lt, rt) in enumerate(curves):
+            for j, k in ((1, i - 1), (2, i)):
+                cubic = int(kind[k]) == 2
+                rec[i - 1, j + 2 * c] = (val[k], np.array([int(kind[k])], np.uint32).view(np.float32)[0], lt[k] if cubic else 0.0, rt[k] if cubic else 0.0)
+    return rec
+
+
+def _device_leaf(rec, n, need, time, hint):
+    out, h = np.zeros(4, np.float32), ctypes.c_uint32()
+    rc = _native.lib().fyx_debug_span_value_at(rec.ctypes.data_as(ctypes.c_void_p), n, need, ctypes.c_float(time), hint, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h))
+    assert rc == 0
+    return out, h.value
+
+
+def _random_track(rng, n, need, duplicates):
+    step = rng.integers(1, 5, n).astype(np.float32) / np.float32(16.0)
+    if duplicates:
+        step[rng.random(n) < 0.3] = 0.0
+    loc = np.cumsum(step).astype(np.float32)
+    curves = [(rng.normal(size=n).astype(np.float32), rng.integers(0, 3, n).astype(np.uint8), rng.normal(size=n).astype(np.float32),
+               rng.normal(size=n).astype(np.float32)) for _ in range(need)]
+    return loc, curves
+
+
+@pytest.mark.parametrize("need", [3, 4])
+@pytest.mark.parametrize("duplicates", [False, True], ids=["distinct_keys", "duplicate_keys"])
+def test_span_track_value_at_decides_like_value_at(need, duplicates):
+    rng = np.random.default_rng(20260923 + 10 * need + int(duplicates))
+    checked = 0
+    for _ in range(40):
+        n = int(rng.integers(2, 12))
+        loc, curves = _random_track(rng, n, need, duplicates)
+        if loc[0] == loc[-1]:
+            continue
+        rec = _span_records(loc, curves)
+        refs = [oracle.Curve([(float(loc[i]), float(v[i]), int(k[i]), float(lt[i]), float(rt[i])) for i in range(n)]) for v, k, lt, rt in curves]
+        times = list(loc) + [(loc[i] + loc[i + 1]) / 2 for i in range(n - 1)] + [np.nextafter(x, np.float32(9)) for x in loc] + \
+                [np.nextafter(x, np.float32(-9)) for x in loc] + [loc[0] - 1, loc[-1] + 1]
+        for t in times:
+            t = float(np.float32(t))
+            for h in range(0, n + 2):          # every incoming hint, also the out-of-range ones a fresh curve can hold
+                got, got_h = _device_leaf(rec, n, need, t, h)
+                for c, ref in enumerate(refs):
+                    ref_v, ref_h = ref.value_at(t, h)
+                    assert got_h == ref_h, (duplicates, list(loc), t, h, got_h, ref_h)
+                    assert np.float32(got[c]).tobytes() == np.float32(ref_v).tobytes(), (list(loc), t, h, c, got[c], ref_v)
+                checked += 1
+    assert checked > 5000
+
+
+def _classify(ops):
+    arr = np.asarray([[code | (arg << 8), np.array([w], np.float32).view(np.uint32)[0]] for code, arg, w in ops], np.uint32).reshape(-1, 2)
+    d, k = ctypes.c_uint32(), ctypes.c_uint32()
+    m, p, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    rc = _native.lib().fyx_debug_classify_fold_program(arr.ctypes.data_as(ctypes.c_void_p), len(ops), ctypes.byref(d), ctypes.byref(k), ctypes.byref(m),
+                                                       ctypes.byref(p), ctypes.byref(s))
+    assert rc == 0
+    return {"d": d.value, "k": k.value, "mask": bool(m.value), "player": bool(p.value), "straight": bool(s.value)}
+
+
+def _blend(n):
+    return [(OP_BLEND_ANIM, a, 0.25 * (a + 1)) for a in range(n)]
+
+
+def test_fold_program_classifier():
+    tail, end = [(OP_APPLY, 0, 0.0), (OP_END, 0, 0.0)], [(OP_END, 0, 0.0)]
+    for k in range(1, 5):                                            # what Planner::emit_blend writes for the common machines
+        assert _classify(_blend(k) + tail) == {"d": 0, "k": k, "mask": False, "player": False, "straight": True}
+        assert _classify(_blend(k) + [(OP_MASK, 1, 0.0)] + tail) == {"d": 0, "k": k, "mask": True, "player": False, "straight": True}
+        for d in range(1, 7):                                        # the round-2 form with every PUSH written out
+            prog = [(OP_PUSH, 0, 0.0)] * d + _blend(k) + [(OP_POP_BLEND, 0, 0.5)] * d + tail
+            assert _classify(prog) == {"d": d, "k": k, "mask": False, "player": False, "straight": True}
+        assert _classify([(OP_APPLY_ANIM, a, 0.0) for a in range(k)] + end) == {"d": 0, "k": k, "mask": False, "player": True, "straight": True}
+    # near misses: none of them may reach the kernel form that has no interpreter
+    assert not _classify(_blend(5) + tail)["straight"]                                            # more operands than the straight form holds
+    assert not _classify([(OP_APPLY_ANIM, a, 0.0) for a in range(5)] + end)["straight"]
+    assert not _classify([(OP_PUSH, 0, 0.0)] * 7 + _blend(1) + [(OP_POP_BLEND, 0, 0.5)] * 7 + tail)["straight"]   # deeper than kMaxFoldDepth allows
+    assert not _classify([(OP_PUSH, 0, 0.0)] * 2 + _blend(2) + [(OP_POP_BLEND, 0, 0.5)] + tail)["straight"]       # pops != pushes
+    assert not _classify(_blend(2) + [(OP_PUSH, 0, 0.0)] + _blend(2) + [(OP_POP_BLEND, 0, 0.5)] + tail)["straight"]   # a nested pose after operands
+    assert not _classify(_blend(2) + [(OP_RESET, 0, 0.0)] + tail)["straight"]
+    assert not _classify(_blend(2) + tail[:1])["straight"]                                        # no END
+    assert not _classify(_blend(2) + [(OP_MASK, 0, 0.0), (OP_MASK, 1, 0.0)] + tail)["straight"]   # two layers' masks
+    assert not _classify(tail)["straight"]                                                        # nothing blended
+    assert not _classify(end)["straight"] and not _classify([])["straight"]
+    assert not _classify([(OP_APPLY_ANIM, 0, 0.0)] + _blend(1) + tail)["straight"]
+    assert not _classify([(OP_APPLY_ANIM, 0, 0.0), (OP_APPLY, 0, 0.0)] + end)["straight"]
+    assert not _classify(_blend(1) + tail + end)["straight"]                                      # trailing ops
+    long = [(OP_PUSH, 0, 0.0)] * 40 + _blend(1) + [(OP_POP_BLEND, 0, 0.5)] * 40 + tail           # past the 64 ops held in the lanes
+    assert not _classify(long)["straight"]
+
+
+def test_planner_programs_of_the_suite_are_classified_as_the_kernel_expects():
+    """Every program the planner emits for the scenario suite: straight exactly when it has the straight shape (decoded here from the
+    ops, independently of the classifier)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import anim_cases as cases
+    c = fyrox_amd.Context(control_only=True)
+    seen = {True: 0, False: 0}
+    try:
+        for make in list(cases.ALL) + [lambda s=s: cases.random_machine(s) for s in range(12)]:
+            sc = make()
+            p = cases.build_product(c, sc, 2)
+            for f in range(min(sc.n_frames, 30)):
+                for idx, par in sc.script.get(f, []):
+                    p.set_parameter(idx, par)
+                plan = p.plan(1 if sc.machine is not None else 0, sc.dt)
+                ops, off = plan["ops"], plan["offsets"]
+                for i in range(len(off) - 1):
+                    prog = [(int(x) & 0xff, int(x) >> 8, 0.0) for x in ops[off[i]:off[i + 1], 0]]
+                    codes = [q[0] for q in prog]
+                    got = _classify(prog)
+                    # the shape, spelled out: [PUSH^d] BLEND^k [POP^d] [MASK] APPLY END, or APPLY_ANIM^k END
+                    d = next((j for j, q in enumerate(codes) if q != OP_PUSH), len(codes))
+                    k = next((j for j, q in enumerate(codes[d:]) if q != OP_BLEND_ANIM), len(codes) - d)
+                    rest = codes[d + k:]
+                    want = (1 <= k <= 4 and d <= 6 and rest[:d] == [OP_POP_BLEND] * d and rest[d:] in ([OP_APPLY, OP_END], [OP_MASK, OP_APPLY, OP_END])) or \
+                           (1 <= len(codes) - 1 <= 4 and codes[:-1] == [OP_APPLY_ANIM] * (len(codes) - 1) and codes[-1] == OP_END)
+                    assert got["straight"] == want, (sc.name, f, codes)
+                    seen[want] += 1
+            p.free()
+    finally:
+        c.close()
+    assert seen[True] > 100 and seen[False] > 50
+
+
+def test_any_negative_parent_is_a_root():
+    """fyx_rig_create packs node | (parent + 1) << 10 | depth << 21 for the update kernel; a root written as -2 or INT_MIN (the rest
+    of the host code treats any negative parent as a root) must give the same table as -1."""
+    c = fyrox_amd.Context(control_only=True)
+    try:
+        tables = []
+        for k, root in enumerate((-1, -2, -(2 ** 31))):
+            rig = A.Rig(np.asarray([root, 0, 1, root, 3, 3], np.int32), [A.Transform.identity() for _ in range(6)])
+            A.create_rig(c, 10 + k, rig)
+            out, n = np.zeros(16, np.uint32), ctypes.c_uint32()
+            assert _native.lib().fyx_debug_rig_walk(c._h, 10 + k, out.ctypes.data_as(ctypes.c_void_p), 16, ctypes.byref(n)) == 0
+            tables.append(out[:n.value].tolist())
+        assert tables[0] == tables[1] == tables[2] and len(tables[0]) == 6
+        nodes = [w & 1023 for w in tables[0]]
+        parents = [((w >> 10) & 2047) - 1 for w in tables[0]]
+        depths = [w >> 21 for w in tables[0]]
+        assert sorted(nodes) == list(range(6)) and depths == sorted(depths)
+        assert {n_: p_ for n_, p_ in zip(nodes, parents)} == {0: -1, 1: 0, 2: 1, 3: -1, 4: 3, 5: 3}
+    finally:
+        c.close()
