@@ -899,16 +899,20 @@ def sharding_range(n_verts, rank, world):
 
 
 def test_exchange_forms_agree_on_one_rank(ctx, orc):
-    """Option comm.form: 0 = one broadcast per shard, 1 = grouped send / recv between every pair of ranks.  With a communicator of
-    one rank form 1 has no peer (an empty group), form 0 one broadcast to itself: both must leave the skinned streams as they are."""
+    """Option comm.form: 0 = one broadcast per shard, 1 = grouped send / recv between every pair of ranks, 2 = one in-place all-gather
+    per stream over the padded cut (buffers of n_ranks * shard vertices).  With a communicator of one rank form 1 has no peer (an empty
+    group), form 0 one broadcast to itself, form 2 an all-gather of one shard onto itself: all must leave the skinned streams as they are."""
     m = synth.make_mesh(5000, 16, synth.SEED_BASE + 45)
     pal = synth.make_palette(16, synth.SEED_BASE + 45)
     ctx.mesh_upload_soa(7400, m.pos, m.weights, m.indices, m.normal, m.tangent)
     d_pal = ctx.to_device(pal)
     n = m.n_verts
-    d_p, d_n, d_t = ctx.malloc(n * 12), ctx.malloc(n * 12), ctx.malloc(n * 16)
+    from fyrox_amd import sharding
+    b0, e0, shard = sharding.vertex_range_padded(n, 0, 1)
+    assert (b0, e0) == (0, n) and shard >= n and shard % 256 == 0
+    d_p, d_n, d_t = ctx.malloc(shard * 12), ctx.malloc(shard * 12), ctx.malloc(shard * 16)     # room for the padded shard of form 2
     with pytest.raises(fyrox_amd.FyxError):
-        ctx.set_option("comm.form", 2)
+        ctx.set_option("comm.form", 3)
     try:
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
     except fyrox_amd.FyxError as err:
@@ -917,7 +921,7 @@ def test_exchange_forms_agree_on_one_rank(ctx, orc):
         raise
     ref = orc.lbs_skin(m.pos, m.weights, m.indices, pal, m.normal, m.tangent, threads=0)
     try:
-        for form in (1, 0):
+        for form in (1, 2, 0):
             ctx.set_option("comm.form", form)
             assert ctx.get_option("comm.form") == form
             ctx.lbs_skin_device(7400, d_pal.ptr, 16, 1, d_p.ptr, d_n.ptr, d_t.ptr)
