@@ -394,8 +394,9 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     }
     RigDev rd;
     if (int rc = rig_params(c, A, rd)) return rc;
+    const int upd_mode = !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral;
     if (int rc = timeline_arm(c, 2)) return rc;
-    FYX_HIP(c, launch_pose_update(f, rd, !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral, ps, &inl));
+    FYX_HIP(c, launch_pose_update(f, rd, upd_mode, ps, &inl));
     g_launch_events = LaunchEvents();
     if (with_program) {
         FYX_HIP(c, launch_property_update(f, ps, &inl));

@@ -201,6 +201,67 @@ struct RecAux {
 };
 
 // ---------------------------------------------------------------------------------------
+// One curve of one track for ONE instance: Curve::value_at (curve.rs:254-314) with the instance's span hint, which it keeps up to
+// date.  (Round 4 measured a FUSED sample + update launch for single characters on top of this function -- one lane per (animation,
+// node), its ten curves one after another, then the update body behind a barrier: C2 18.6 us against 15.8, C5 25.5 against 18.0 with
+// the two launches; ten dependent sample chains per lane cost more than a launch boundary.  Not kept.)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a, const CrowdDesc& d, uint32_t c, uint32_t inst, float time) {
+    const uint32_t track = d.track;
+    const int need = (int)d.need;
+    float v = 0.0f;
+    uint32_t* hp = hint_ptr(f, a, track, c, inst);
+    uint32_t hint = *hp;
+    // Steady playback: the time lies strictly inside the hinted span [key hint - 1, key hint).  Curve::value_at then
+    // clamps nothing (first.location <= left < time < right <= last.location), takes its hinted span and leaves the
+    // hint alone (curve.rs:254-314) -- and the track's span record (TrackHot) holds everything that needs: one cache
+    // line for the three curves of a Vector3 track, two for a quaternion's four.
+    bool sampled = false;
+    if (d.spans && hint >= 1 && hint < d.n_keys) {
+        const uint32_t stride = need == 4 ? 16u : 8u;
+        const f4* r = reinterpret_cast<const f4*>(d.spans) + (size_t)(hint - 1) * stride;
+        f4 locs = r[0];
+        if (locs.x < time && time < locs.y) {
+            v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+            sampled = true;
+        } else if (locs.y < time && hint + 1 < d.n_keys) {
+            // playback crossed the span's right key: if the time lies strictly inside the NEXT span, nothing is clamped
+            // there either, the hinted span fails, and partition_point(k.location < time) is hint + 1 (every key up to
+            // `hint` lies before the time, key hint + 1 after it): the reference interpolates keys hint, hint + 1
+            r += stride;
+            locs = r[0];
+            if (locs.x < time && time < locs.y) {
+                v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+                *hp = hint + 1;
+                sampled = true;
+            }
+        } else if (time < locs.x && hint >= 2) {
+            // reverse playback crossed the left key: strictly inside the PREVIOUS span the search returns hint - 1
+            r -= stride;
+            locs = r[0];
+            if (locs.x < time && time < locs.y) {
+                v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+                *hp = hint - 1;
+                sampled = true;
+            }
+        }
+    }
+    if (!sampled) {   // everything else, decided in the reference's order on the per-curve records
+        const AnimDev an = f.anims[a];
+        const TrackDev* tk = an.tracks + track;
+        const uint32_t fk = tk->first_key[c];
+#if FYX_KEYREC
+        v = curve_value_at(RecLoc{an.key_rec + fk}, RecAux{an.key_rec + fk}, tk->n_keys[c], curve_ends(tk, (int)c), time, hint);
+#else
+        v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c],
+                           curve_ends(tk, (int)c), time, hint);
+#endif
+        *hp = hint;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
 // pose_sample: sixteen lanes per (animation, instance, node), ONE LANE PER CURVE.  A curve sample is
 // a chain of dependent loads (hint -> key locations -> key values), so a thread that walked the ten
 // curves of a node one after another would pay that latency ten times; here the ten chains of a node
@@ -240,62 +301,10 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
         bool valid = false;
         float v = 0.0f;
         if (track >= 0) {
-            struct { uint32_t span_first, n_keys; } th;       // (what the span path below reads of TrackHot)
-            th.n_keys = d.n_keys;
-            th.span_first = d.spans ? 0u : kNoSpans;
             kind = d.kind;
             need = (int)d.need;
             valid = d.valid != 0;                                 // else fetch() -> None
-            if (valid && c < need) {
-                uint32_t* hp = hint_ptr(f, a, (uint32_t)track, (uint32_t)c, inst);
-                uint32_t hint = *hp;
-                // Steady playback: the time lies strictly inside the hinted span [key hint - 1, key hint).  Curve::value_at then
-                // clamps nothing (first.location <= left < time < right <= last.location), takes its hinted span and leaves the
-                // hint alone (curve.rs:254-314) -- and the track's span record (TrackHot) holds everything that needs: one cache
-                // line for the three curves of a Vector3 track, two for a quaternion's four.
-                bool sampled = false;
-                if (th.span_first != kNoSpans && hint >= 1 && hint < th.n_keys) {
-                    const uint32_t stride = need == 4 ? 16u : 8u;
-                    const f4* r = reinterpret_cast<const f4*>(d.spans) + (size_t)(hint - 1) * stride;
-                    f4 locs = r[0];
-                    if (locs.x < time && time < locs.y) {
-                        v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
-                        sampled = true;
-                    } else if (locs.y < time && hint + 1 < th.n_keys) {
-                        // playback crossed the span's right key: if the time lies strictly inside the NEXT span, nothing is clamped
-                        // there either, the hinted span fails, and partition_point(k.location < time) is hint + 1 (every key up to
-                        // `hint` lies before the time, key hint + 1 after it): the reference interpolates keys hint, hint + 1
-                        r += stride;
-                        locs = r[0];
-                        if (locs.x < time && time < locs.y) {
-                            v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
-                            *hp = hint + 1;
-                            sampled = true;
-                        }
-                    } else if (time < locs.x && hint >= 2) {
-                        // reverse playback crossed the left key: strictly inside the PREVIOUS span the search returns hint - 1
-                        r -= stride;
-                        locs = r[0];
-                        if (locs.x < time && time < locs.y) {
-                            v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
-                            *hp = hint - 1;
-                            sampled = true;
-                        }
-                    }
-                }
-                if (!sampled) {   // everything else, decided in the reference's order on the per-curve records
-                    const AnimDev an = f.anims[a];
-                    const TrackDev* tk = an.tracks + track;
-                    const uint32_t fk = tk->first_key[c];
-#if FYX_KEYREC
-                    v = curve_value_at(RecLoc{an.key_rec + fk}, RecAux{an.key_rec + fk}, tk->n_keys[c], curve_ends(tk, (int)c), time, hint);
-#else
-                    v = curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c],
-                                       curve_ends(tk, (int)c), time, hint);
-#endif
-                    *hp = hint;
-                }
-            }
+            if (valid && c < need) v = sample_curve(f, a, d, (uint32_t)c, inst, time);
         }
         const int has_p = __shfl((int)valid, (int)gbase + 0, 64);
         const int has_r = __shfl((int)valid, (int)gbase + 4, 64);
@@ -1516,6 +1525,9 @@ hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode
     if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;
     uint32_t block = ((rig.n_nodes + 63) / 64) * 64;
     if (block > 256) block = 256;
+    // a few characters: the chip is empty anyway, and the kernel's strided tail (matrix stores, palette columns: 256 columns for 64
+    // bones) runs over four waves instead of one; a crowd keeps the smallest block (its waves compete with the skinning kernel's)
+    if (f.n_instances <= 64) block = 256;
     const size_t lds = (size_t)rig.n_nodes * 32 * sizeof(float);
     const bool in_args = inl && inl->bytes && mode != kUpdNoProgram;
     if (in_args) {

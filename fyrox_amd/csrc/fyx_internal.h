@@ -392,6 +392,7 @@ hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlIn
 // interpreter (a third of the registers).
 enum : int { kUpdNoProgram = 0, kUpdGeneral = 1, kUpdStraight = 2 };
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl = nullptr);
+
 // Animation::update_root_motion for every ticked animation that has settings (after pose_sample:
 // rewrites the root node's pose record), then the per-instance root-motion program (machine mode).
 hipError_t launch_root_motion(const PoseFrameDev& f, bool run_program, hipStream_t s, const CtrlInline* inl = nullptr);
