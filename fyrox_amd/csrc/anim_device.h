@@ -493,7 +493,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
             const Animator& A = *S.animators[k];
             const SceneJobShape sh = scene_shape(c, A, A.dev_prop_slots);
             scene_blocks((uint32_t)k, sh, tables);
-            const int stage = kStageUpdate64 + (int)std::min<uint32_t>((sh.n_nodes + 63) / 64, 4) - 1;
+            const int stage = kStageUpdate64 + (int)update_block_waves(sh.n_nodes, sh.n_instances) - 1;
             lds[stage] = std::max(lds[stage], (size_t)sh.n_nodes * 32 * sizeof(float));
         }
         size_t total = 0;

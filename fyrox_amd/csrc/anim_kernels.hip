@@ -1523,11 +1523,7 @@ static hipError_t launch_update_one(K kernel, uint32_t grid, uint32_t block, siz
 
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl) {
     if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;
-    uint32_t block = ((rig.n_nodes + 63) / 64) * 64;
-    if (block > 256) block = 256;
-    // a few characters: the chip is empty anyway, and the kernel's strided tail (matrix stores, palette columns: 256 columns for 64
-    // bones) runs over four waves instead of one; a crowd keeps the smallest block (its waves compete with the skinning kernel's)
-    if (f.n_instances <= 64) block = 256;
+    const uint32_t block = 64u * update_block_waves(rig.n_nodes, f.n_instances);
     const size_t lds = (size_t)rig.n_nodes * 32 * sizeof(float);
     const bool in_args = inl && inl->bytes && mode != kUpdNoProgram;
     if (in_args) {
@@ -1615,8 +1611,7 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[
     }
     if (s.root_motion_program)
         for (uint32_t x = 0; x < (s.n_instances + 63) / 64; ++x) t[kStageRootMotionFold].push_back(make_uint4(job, x, 0, 0));
-    uint32_t block = (s.n_nodes + 63) / 64;
-    if (block > 4) block = 4;
+    const uint32_t block = update_block_waves(s.n_nodes, s.n_instances);
     for (uint32_t i = 0; i < s.n_instances; ++i) t[kStageUpdate64 + (int)block - 1].push_back(make_uint4(job, i, 0, 0));
     if (s.n_prop_slots) {
         const uint32_t gx = (s.n_prop_slots + 63) / 64;

@@ -391,6 +391,15 @@ hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlIn
 // has classified EVERY instance's program as straight (classify_fold_program_host, anim_leaves.h): a kernel without the
 // interpreter (a third of the registers).
 enum : int { kUpdNoProgram = 0, kUpdGeneral = 1, kUpdStraight = 2 };
+// Waves per workgroup of the update kernel (one workgroup per instance): one per 64 nodes, at most four -- and four for an
+// animator of few instances: the chip is empty then, and the kernel's strided tail (matrix stores, palette columns: 256 columns for
+// 64 bones) runs over four waves instead of one.  A crowd keeps the smallest block: its waves compete with the skinning kernel's.
+inline uint32_t update_block_waves(uint32_t n_nodes, uint32_t n_instances) {
+    uint32_t w = (n_nodes + 63u) / 64u;
+    if (w > 4u) w = 4u;
+    if (n_instances <= 64u) w = 4u;
+    return w < 1u ? 1u : w;
+}
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl = nullptr);
 
 // Animation::update_root_motion for every ticked animation that has settings (after pose_sample:

@@ -410,7 +410,7 @@ def test_scene_block_tables_cover_every_animators_own_grid_exactly_once():
     workgroups the per-animator launch of that stage would start for animator k -- each once, nothing else -- for
     animators on both sampler forms, with and without properties and root motion, rigs from 6 to 300 nodes."""
     ctx = fyrox_amd.Context(control_only=True)
-    members = [(cases.c5_blend_tree(), 1), (cases.c5_blend_tree(), 40), (cases.morph_weights(), 3), (cases.property_kinds(), 70),
+    members = [(cases.c5_blend_tree(), 1), (cases.c5_blend_tree(), 40), (cases.c5_blend_tree(), 65), (cases.c5_blend_tree(n_bones=130), 70), (cases.morph_weights(), 3), (cases.property_kinds(), 70),
                (cases.ALL_RM[2](), 2), (cases.ALL_RM[0](), 33), (cases.player_only(), 5), (cases.removed_clips(), 1)]
     big = cases.c5_blend_tree(n_bones=300)
     members.append((big, 2))
@@ -441,7 +441,7 @@ def test_scene_block_tables_cover_every_animators_own_grid_exactly_once():
             assert sorted(of(S_RMFOLD, k)) == [(x, 0, 0) for x in range((n + 63) // 64)]
         else:
             assert got == [] and of(S_RMFOLD, k) == []
-        stage = S_U64 + min((nn + 63) // 64, 4) - 1
+        stage = S_U64 + (4 if n <= 64 else min((nn + 63) // 64, 4)) - 1      # update_block_waves: four waves for few instances
         for st in (S_U64, S_U128, S_U192, S_U256):
             assert sorted(of(st, k)) == ([(i, 0, 0) for i in range(n)] if st == stage else []), (sc.name, "update", st)
         want = {(x, i, 0) for i in range(n) for x in range((nps + 63) // 64)} if nps else set()
