@@ -71,31 +71,6 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
         return enter_primary(c);
     }
     if (int rc = bind_device(c)) return rc;
-    if (c->pose_overlap >= 2) {
-        // pose path on the context stream, skinning on alt_stream (in order there), `ahead` frames of run-ahead
-        if (!c->alt_stream) {
-            FYX_HIP(c, make_stream(c, false, &c->alt_stream));
-            FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, hipEventDisableTiming));
-            for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->pose_done[k], hipEventDisableTiming));
-        }
-        const uint64_t k = c->pose_entries++;
-        const int ahead = c->pose_overlap - 1;
-        if (c->alt_busy) {       // mark: the skinning launches issued so far
-            hipEvent_t& m = c->skin_mark[k & 3];
-            if (!m) FYX_HIP(c, hipEventCreateWithFlags(&m, hipEventDisableTiming));
-            FYX_HIP(c, hipEventRecord(m, c->alt_stream));
-            c->skin_mark_has[k & 3] = true;
-        } else {
-            c->skin_mark_has[k & 3] = false;
-        }
-        if (k >= (uint64_t)ahead && c->skin_mark_has[(k - ahead) & 3]) {
-            FYX_HIP(c, hipStreamWaitEvent(c->stream, c->skin_mark[(k - ahead) & 3], 0));
-            c->skin_mark_has[(k - ahead) & 3] = false;
-        }
-        c->primary_dirty = true;
-        *out = c->stream;
-        return FYX_OK;
-    }
     const int idx = c->frame_idx ^ 1;
     c->frame_idx = idx;
     if (!c->alt_stream) {
@@ -122,7 +97,7 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
 }
 
 int exit_pose(fyx_ctx* c) {
-    if (c->pose_overlap != 1 || !c->alt_stream) return FYX_OK;
+    if (!c->pose_overlap || !c->alt_stream) return FYX_OK;
     const int idx = c->frame_idx;
     FYX_HIP(c, hipEventRecord(c->pose_done[idx], idx ? c->alt_stream : c->stream));
     c->pose_done_on = idx;
@@ -130,19 +105,6 @@ int exit_pose(fyx_ctx* c) {
 }
 
 int enter_skin(fyx_ctx* c, hipStream_t* out) {
-    if (c->pose_overlap >= 2 && c->alt_stream) {
-        if (int rc = bind_device(c)) return rc;
-        if (c->primary_dirty || c->stream != c->own_stream) {      // behind the pose update (and whatever else is on the context stream)
-            if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
-            FYX_HIP(c, hipEventRecord(c->fork_ev, c->stream));
-            ++c->fork_gen;
-            c->primary_dirty = false;
-            FYX_HIP(c, hipStreamWaitEvent(c->alt_stream, c->fork_ev, 0));
-        }
-        c->alt_busy = true;
-        *out = c->alt_stream;
-        return FYX_OK;
-    }
     if (c->pose_overlap && c->alt_stream) {
         if (int rc = bind_device(c)) return rc;
         *out = c->frame_idx ? c->alt_stream : c->stream;
@@ -722,8 +684,6 @@ void fyx_shutdown(fyx_ctx* c) {
     }
     if (c->alt_stream) { (void)hipStreamSynchronize(c->alt_stream); (void)hipStreamDestroy(c->alt_stream); }
     if (c->alt_done) (void)hipEventDestroy(c->alt_done);
-    for (hipEvent_t m : c->skin_mark)
-        if (m) (void)hipEventDestroy(m);
     for (int k = 0; k < 2; ++k)
         if (c->pose_done[k]) (void)hipEventDestroy(c->pose_done[k]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
@@ -816,7 +776,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->comm_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "comm.form must be 0 (broadcasts), 1 (send / recv) or 2 (one all-gather over padded shards)");
     if (slot == &c->sample_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.sample_form must be 0, 1 or 2");
     if (slot == &c->inline_ctrl && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.inline_ctrl must be 0 or 1");
-    if (slot == &c->pose_overlap && (value < 0 || value > 3)) return fail(c, FYX_ERR_INVALID_ARG, "anim.overlap must be 0 .. 3");
+    if (slot == &c->pose_overlap && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.overlap must be 0 or 1");
     if (slot == &c->plan_split && value < 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.split must be >= 1");
     if (slot == &c->plan_threads && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");
@@ -836,8 +796,6 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         if (int rc = enter_primary(c)) return rc;      // switching the mode joins everything once
         c->frame_idx = 0;
         c->pose_done_on = -1;
-        c->pose_entries = 0;
-        for (bool& h : c->skin_mark_has) h = false;
     }
     *slot = value;
     return FYX_OK;

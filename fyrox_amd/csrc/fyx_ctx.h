@@ -95,12 +95,6 @@ struct fyx_ctx {
     int frame_idx = 0;                   // the stream the current frame runs on
     hipEvent_t pose_done[2] = {nullptr, nullptr};   // recorded behind a frame's last pose kernel, one per stream
     int pose_done_on = -1;               // stream of the last pose update, -1: none yet
-    // anim.overlap = 2 / 3 (experiment): the pose path stays on the context stream, the skinning goes to alt_stream, and pose update k
-    // waits for the skinning launches issued before pose update k - (overlap - 1): one or two frames of run-ahead, two or three
-    // palette buffers in rotation.  skin_mark[k % 4] = "the launches on alt_stream before pose entry k".
-    hipEvent_t skin_mark[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool skin_mark_has[4] = {false, false, false, false};
-    uint64_t pose_entries = 0;
     int stream_priority = 0; // option "streams.priority": 1 = the context's own stream (the pose path: short latency-bound kernels) is created
                              //   with the highest priority, the launch streams (skinning: long bandwidth-bound kernels) with the lowest
     int pose_cus = 0;        // option "streams.pose_cus": N > 0 = the context's own stream may only use N CUs (spread over the XCDs) and the

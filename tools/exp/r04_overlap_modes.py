@@ -4,7 +4,7 @@
   1  whole frames alternate between two streams (pose n + 1 waits for pose n ACROSS streams; two palette buffers)
   2  pose path on the context stream, skinning on a launch stream, one frame of run-ahead (two palette buffers)
   3  the same with two frames of run-ahead (three palette buffers): every cross-stream wait is satisfied a frame before it is reached
-frame_us by HIP events over 300 frames, after 60 warm-up frames; EXACT env 0 = fused skinning."""
+(Modes 2 and 3 exist only in commit "wip-overlap-modes"; the product keeps 0 and 1.)  frame_us by HIP events over 300 frames, after 60 warm-up frames; EXACT env 0 = fused skinning."""
 import ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
