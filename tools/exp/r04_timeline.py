@@ -119,15 +119,14 @@ def measure(name, opts, pipelined):
     an.free()
     ctx.set_option("anim.overlap", 0)
     ctx.set_option("lbs.streams", 1)
-    ctx.set_option("lbs.crowd_lean", 0)
 
 
-base = {"lbs.streams": 1, "anim.overlap": 0, "anim.update_lean": 1, "streams.priority": 0}
-pipe = {"lbs.streams": 1, "anim.overlap": 1, "anim.update_lean": 1, "streams.priority": 0}
-ctx.set_option("lbs.crowd_ipb", int(os.environ.get("IPB", "8")))
-measure("serial, copy kernel", {**base, "anim.ctrl_upload": 2}, False)
-for prio in (0, 1):
-    for kb in (0, 16):
-        measure("frames alternate streams, wave_prio=%d, LDS pad %d KB" % (prio, kb), {**pipe, "anim.ctrl_upload": 2, "anim.pose_lds_kb": kb, "anim.wave_prio": prio}, True)
-ctx.set_option("anim.pose_lds_kb", 0)
+base = {"lbs.streams": 1, "anim.overlap": 0}
+pipe = {"lbs.streams": 1, "anim.overlap": 1}
+measure("one chain on one stream", base, False)
+measure("frames alternate between two streams", pipe, True)
+ctx.set_option("lbs.exact", 0)
+measure("one chain on one stream, fused skinning", base, False)
+measure("frames alternate between two streams, fused skinning", pipe, True)
+ctx.set_option("lbs.exact", 1)
 ctx.close()
