@@ -139,12 +139,11 @@ impl HipSkinning {
         self.check(unsafe { fyx_skinned_aabb_device(self.ctx, key, d_palettes, n_bones, n_instances, d_out_boxes) })
     }
 
-    /// Pipelined frames: let frame n+1's pose kernels run beside frame n's skinning.  The caller then alternates two
-    /// palette buffers per animator ("Pipelined frames"); `lean_crowd` selects the crowd kernel's
-    /// register-lean form, which leaves the pose kernels room on the chip.
-    pub fn set_pipelined(&mut self, on: bool, lean_crowd: bool) -> Result<(), HipError> {
-        self.check(unsafe { fyx_set_option(self.ctx, b"anim.overlap\0".as_ptr() as *const _, on as i32) })?;
-        self.check(unsafe { fyx_set_option(self.ctx, b"lbs.crowd_lean\0".as_ptr() as *const _, (on && lean_crowd) as i32) })
+    /// Pipelined frames: whole frames alternate between two streams of the library, so frame n+1's pose kernels run beside
+    /// frame n's skinning.  The caller then alternates two palette buffers per animator: a pose update must not be given a
+    /// palette buffer that a skinning launch issued since the previous pose update reads ("Pipelined frames").
+    pub fn set_pipelined(&mut self, on: bool) -> Result<(), HipError> {
+        self.check(unsafe { fyx_set_option(self.ctx, b"anim.overlap\0".as_ptr() as *const _, on as i32) })
     }
 
     /// Additive API next to `SurfaceData` (`scene/mesh/surface.rs:265`): skin every vertex into host vectors.
@@ -216,6 +215,32 @@ impl HipSkinning {
     pub fn join(&mut self) -> Result<(), HipError> {
         self.check(unsafe { fyx_join(self.ctx) })
     }
+}
+
+/// Which keys of a sampled curve the glTF importer keeps (`resource/gltf/simplify.rs:39-66`, run on every imported curve by
+/// `gltf/animation.rs:155-163` with the binding's epsilon / max_step): indices into `x` / `y`.  No GPU, no context.
+pub fn curve_simplify(x: &[f32], y: &[f32], epsilon: f32, max_step: f32) -> Result<Vec<u32>, HipError> {
+    assert_eq!(x.len(), y.len());
+    let mut out = vec![0u32; x.len().max(1)];
+    let mut n = 0u32;
+    let rc = unsafe { fyx_curve_simplify(x.as_ptr(), y.as_ptr(), x.len() as u32, epsilon, max_step, out.as_mut_ptr(), &mut n) };
+    if rc != FYX_OK {
+        return Err(if rc == FYX_ERR_OOM { HipError::OutOfMemory } else { HipError::InvalidArg("fyx_curve_simplify".to_string()) });
+    }
+    Ok(out[..n as usize].iter().copied().collect())
+}
+
+/// `BlendSpace::triangulate` (`machine/node/blendspace.rs:416-447`) for a shim that edits blend-space points outside the engine:
+/// triangles as point indices, in the reference fixture's order (newest point first, counter-clockwise).  No GPU, no context.
+pub fn blend_space_triangulate(points_xy: &[[f32; 2]]) -> Result<Vec<[u32; 3]>, HipError> {
+    let cap = 4 * points_xy.len() as u32 + 4;
+    let mut out = vec![[0u32; 3]; cap as usize];
+    let mut n = 0u32;
+    let rc = unsafe { fyx_blend_space_triangulate(points_xy.as_ptr() as *const f32, points_xy.len() as u32, out.as_mut_ptr() as *mut u32, cap, &mut n) };
+    if rc != FYX_OK {
+        return Err(if rc == FYX_ERR_OOM { HipError::OutOfMemory } else { HipError::InvalidArg("fyx_blend_space_triangulate: a coordinate is not finite".to_string()) });
+    }
+    Ok(out[..n as usize].iter().copied().collect())
 }
 
 impl Drop for HipSkinning {
