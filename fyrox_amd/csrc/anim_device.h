@@ -396,7 +396,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     if (int rc = rig_params(c, A, rd)) return rc;
     const int upd_mode = !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral;
     if (int rc = timeline_arm(c, 2)) return rc;
-    FYX_HIP(c, launch_pose_update(f, rd, upd_mode, ps, &inl));
+    FYX_HIP(c, launch_pose_update(f, rd, upd_mode, ps, &inl, c->upd_pack));
     g_launch_events = LaunchEvents();
     if (with_program) {
         FYX_HIP(c, launch_property_update(f, ps, &inl));

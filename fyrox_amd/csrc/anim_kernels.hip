@@ -1262,25 +1262,38 @@ __device__ __forceinline__ void mat4_mul(const float* a, const float* b, float* 
 // crowd's update kernel sit beside the previous frame's skinning (<= 128 VGPRs instead of ~440: anim.overlap).
 // pal_mem: where the rig's palette outputs lie in memory, for callers whose RigDev is a register copy (the scene form: indexing a
 // register copy with the loop counter would put the array in scratch).
-template <int MODE>
+template <int MODE, int PACK = 1>
 __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0,
                                                  const PaletteOutDev* __restrict__ pal_mem = nullptr) {
     constexpr bool PROGRAM = MODE != kUpdNoProgram;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* l_local = lds;                               // [n_nodes][16]
-    float* l_global = lds + (size_t)rig.n_nodes * 16;   // [n_nodes][16]
+    // PACK > 1: the workgroup is PACK independent waves, one instance each (rigs of <= 64 nodes: pose_update_pack_kernel) -- a
+    // wave is then its own "workgroup": its index in it is the lane, its LDS area its own, its barrier the wave's program order
+    const uint32_t tid = PACK > 1 ? (threadIdx.x & 63u) : threadIdx.x;
+    const uint32_t bdim = PACK > 1 ? 64u : blockDim.x;
+    float* l_local = lds + (PACK > 1 ? (size_t)(threadIdx.x >> 6) * rig.n_nodes * 32 : 0);   // [n_nodes][16]
+    float* l_global = l_local + (size_t)rig.n_nodes * 16;                                     // [n_nodes][16]
+    auto sync = [] {
+        if constexpr (PACK > 1) {    // (LDS operations of one wave execute in program order: only the compiler has to keep it)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
     const size_t inst_base = (size_t)inst * rig.n_nodes;
 
     // Everything that does not depend on the fold is requested FIRST, so that its (cold) latency runs under the
     // fold's chain of dependent loads instead of after it: what this thread will do in the hierarchy walk (its <= 4
     // entries of the depth-sorted node list: node, level, parent -- so a level of the walk costs LDS traffic and a
     // barrier only) and, per node, the 112 bytes of the rig's static transform parts.
-    constexpr int kEntries = kMaxRigNodes / 256;   // launch_pose_update: block = min(256, n_nodes rounded up to 64)
+    constexpr int kEntries = PACK > 1 ? 1 : kMaxRigNodes / 256;   // launch_pose_update: block = min(256, n_nodes rounded up to 64); packed: <= 64 nodes on 64 lanes
     uint32_t w_node[kEntries], w_level[kEntries];
     int32_t w_par[kEntries];
 #pragma unroll
     for (int k = 0; k < kEntries; ++k) {
-        const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
+        const uint32_t i = tid + (uint32_t)k * bdim;
         w_level[k] = 0xffffffffu;
         w_node[k] = 0;
         w_par[k] = -1;
@@ -1307,7 +1320,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             n_ops = f.prog_off[inst + 1] - p0;
         }
         prog = f.ops + p0;
-        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t lane = tid & 63u;
         if (lane < n_ops) my_op = prog[lane];
     }
     // STRAIGHT programs ([PUSH^d] BLEND_ANIM^k [POP_BLEND^d] [MASK] APPLY END, k <= kStraightOps: anim_leaves.h) skip the
@@ -1329,9 +1342,9 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     // an identity transform and store nothing): fold_op reads the program out of the lanes' registers with v_readlane, and a lane that is inactive when
     // its register is read is undefined by the LLVM contract -- with a rig of 24 nodes and a program of 40 ops the ops
     // 24..39 would sit in lanes that a `node < n_nodes` loop has switched off.
-    for (uint32_t node_base = 0; node_base < rig.n_nodes; node_base += blockDim.x) {   // workgroup-uniform trip count
-        const bool live = node_base + threadIdx.x < rig.n_nodes;
-        const uint32_t node = live ? node_base + threadIdx.x : rig.n_nodes - 1;
+    for (uint32_t node_base = 0; node_base < rig.n_nodes; node_base += bdim) {   // workgroup-uniform trip count
+        const bool live = node_base + tid < rig.n_nodes;
+        const uint32_t node = live ? node_base + tid : rig.n_nodes - 1;
         f4* trs = reinterpret_cast<f4*>(f.node_trs) + (inst_base + node) * 3;
         // a lane past the last node folds an identity transform, not the last node's record: the lane that owns that node (maybe in
         // another wave of the block) writes its folded TRS back below, and an unsynchronised read of it here would be a race
@@ -1410,7 +1423,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
                 reinterpret_cast<f4*>(l_local + (size_t)node * 16)[c] = f4{m[c * 4], m[c * 4 + 1], m[c * 4 + 2], m[c * 4 + 3]};
         }
     }
-    __syncthreads();
+    sync();
 
     // level-synchronous global = parent.global * local; a root multiplies by the identity, as
     // the reference does for a node without a valid parent.  What each thread does in the walk was fetched at the top.
@@ -1435,7 +1448,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             for (int c = 0; c < 4; ++c)
                 reinterpret_cast<f4*>(l_global + (size_t)node * 16)[c] = f4{g[c * 4], g[c * 4 + 1], g[c * 4 + 2], g[c * 4 + 3]};
         }
-        __syncthreads();
+        sync();
     }
     // The global matrices leave the chip once, after the walk: a store inside the level loop would have every
     // level's barrier wait for its write acknowledgement (s_waitcnt vmcnt(0) ahead of s_barrier: ~0.65 us per level
@@ -1444,7 +1457,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     f4* lout = reinterpret_cast<f4*>(f.local + inst_base * 16);
     const f4* gin = reinterpret_cast<const f4*>(l_global);
     const f4* lin = reinterpret_cast<const f4*>(l_local);
-    for (uint32_t i = threadIdx.x; i < rig.n_nodes * 4; i += blockDim.x) {
+    for (uint32_t i = tid; i < rig.n_nodes * 4; i += bdim) {
         gout[i] = gin[i];
         lout[i] = lin[i];
     }
@@ -1458,23 +1471,23 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         const PaletteOutDev po = pal_mem ? pal_mem[p] : rig.pal[p];
         f4* out = reinterpret_cast<f4*>(po.out + (size_t)inst * po.n_bones * 16);
         const uint32_t n_cols = po.n_bones * 4;
-        for (uint32_t e0 = threadIdx.x; e0 < n_cols; e0 += 4u * blockDim.x) {
+        for (uint32_t e0 = tid; e0 < n_cols; e0 += 4u * bdim) {
             int32_t node[4];
             f4 bb[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t e = e0 + (uint32_t)k * blockDim.x;
+                const uint32_t e = e0 + (uint32_t)k * bdim;
                 node[k] = e < n_cols ? po.bone_nodes[e >> 2] : -1;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t e = e0 + (uint32_t)k * blockDim.x;
+                const uint32_t e = e0 + (uint32_t)k * bdim;
                 bb[k] = f4{0.f, 0.f, 0.f, 0.f};
                 if (node[k] >= 0) bb[k] = reinterpret_cast<const f4*>(rig.inv_bind)[(size_t)node[k] * 4 + (e & 3u)];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t e = e0 + (uint32_t)k * blockDim.x;
+                const uint32_t e = e0 + (uint32_t)k * bdim;
                 if (e >= n_cols) continue;
                 const uint32_t j = e & 3u;
                 f4 y;
@@ -1501,6 +1514,19 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pose_update_inl_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl) { pose_update_body<MODE>(ctrl_resolve<kInlAfterFrameAndRig>(f, inl), rig, blockIdx.x, inl.first_ops); }
 template <int MODE>
 __global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) { pose_update_body<MODE>(f, rig, blockIdx.x); }
+// Crowds of small rigs (<= 64 nodes: one wave per instance): PACK instances per workgroup (four: one per SIMD).  The waves share
+// nothing; what the packing buys is WHERE they land when the launch runs beside a crowd's skinning (anim.overlap): that kernel's
+// workgroups take half a CU each (two 128-VGPR waves on every SIMD), a lone update wave of ~160 VGPRs that slips into such a
+// place keeps a skinning workgroup out of it for its ~20 us, and 1000 lone waves can hold every such place of the chip; four
+// waves that arrive together take one.  Measured on the C3 frame (profiles/r04_frame_study, call17): 97.9 against 99.5 us exact,
+// 82.8 against 83.8 fused, the same bits.  A 128-VGPR form (two such workgroups per place; the statics requested after the
+// fold) spills 148 bytes and is slower (100.4).  (A workgroup past the crowd's end repeats the last instance: same values,
+// same places.)
+template <int MODE, int PACK>
+__global__ __launch_bounds__(64 * PACK) void pose_update_pack_kernel(PoseFrameDev f, RigDev rig) {
+    const uint32_t inst = blockIdx.x * PACK + (threadIdx.x >> 6);
+    pose_update_body<MODE, PACK>(f, rig, inst < f.n_instances ? inst : f.n_instances - 1u);
+}
 
 // Scene form: every job of one launch has the same block size; the dynamic LDS is sized for the largest rig among them.
 template <int MODE>
@@ -1521,7 +1547,7 @@ static hipError_t launch_update_one(K kernel, uint32_t grid, uint32_t block, siz
     return hipGetLastError();
 }
 
-hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl) {
+hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl, int pack) {
     if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;
     const uint32_t block = 64u * update_block_waves(rig.n_nodes, f.n_instances);
     const size_t lds = (size_t)rig.n_nodes * 32 * sizeof(float);
@@ -1529,6 +1555,11 @@ hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode
     if (in_args) {
         if (mode == kUpdStraight) return launch_update_one(pose_update_inl_kernel<kUpdStraight>, f.n_instances, block, lds, s, f, rig, *inl);
         return launch_update_one(pose_update_inl_kernel<kUpdGeneral>, f.n_instances, block, lds, s, f, rig, *inl);
+    }
+    if (pack > 1 && rig.n_nodes <= 64u && f.n_instances >= 64u && mode == kUpdStraight) {
+        const uint32_t p = pack >= 4 ? 4u : 2u, grid = (f.n_instances + p - 1u) / p;
+        if (p == 4u) return launch_update_one(pose_update_pack_kernel<kUpdStraight, 4>, grid, 64u * p, lds * p, s, f, rig);
+        return launch_update_one(pose_update_pack_kernel<kUpdStraight, 2>, grid, 64u * p, lds * p, s, f, rig);
     }
     if (mode == kUpdStraight) return launch_update_one(pose_update_kernel<kUpdStraight>, f.n_instances, block, lds, s, f, rig);
     if (mode == kUpdGeneral) return launch_update_one(pose_update_kernel<kUpdGeneral>, f.n_instances, block, lds, s, f, rig);

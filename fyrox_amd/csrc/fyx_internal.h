@@ -400,7 +400,7 @@ inline uint32_t update_block_waves(uint32_t n_nodes, uint32_t n_instances) {
     if (n_instances <= 64u) w = 4u;
     return w < 1u ? 1u : w;
 }
-hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl = nullptr);
+hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl = nullptr, int pack = 0);
 
 // Animation::update_root_motion for every ticked animation that has settings (after pose_sample:
 // rewrites the root node's pose record), then the per-instance root-motion program (machine mode).

@@ -531,6 +531,41 @@ def test_instances_diverge(ctx, orc):
     p.free()
 
 
+@pytest.mark.parametrize("pack", [0, 2, 4])
+def test_crowd_update_packs_instances_per_workgroup(ctx, orc, pack):
+    """anim.update_pack: a crowd's lean update launch with 1 / 2 / 4 instances of a small rig per workgroup.  67 instances (not a
+    multiple of the pack: the last workgroup repeats the last instance) at different speeds; eight of them against an oracle
+    scene each, all of them against the unpacked launch bit for bit."""
+    sc = cases.c5_blend_tree(euler_every=10 ** 6)      # quaternion tracks only: bit-exact against the oracle
+    n, probe = 67, (0, 1, 2, 3, 31, 64, 65, 66)
+    os_ = {i: cases.build_oracle(orc, sc) for i in probe}
+    ps = []
+    for pk in (0, pack):
+        ctx.set_option("anim.update_pack", pk)
+        p = cases.build_product(ctx, sc, n)
+        for i in range(n):
+            p.set_speed(0, 0.25 + 0.03 * i, instance=i)
+        got = []
+        for f in range(12):
+            p.update_machine(sc.dt)
+            got.append((p.read(A.READ_LOCAL_TRS).copy(), p.read(A.READ_GLOBAL_MATRIX).copy()))
+        ps.append(got)
+        p.free()
+    ctx.set_option("anim.update_pack", 4)
+    for i in probe:
+        orc._alib().fo_animation_set_speed(os_[i].anims[0], 0.25 + 0.03 * i)
+    for f in range(12):
+        for i in probe:
+            os_[i].update_machine(sc.dt)
+            check(ps[1][f][0][i], os_[i].node_trs(), True, f"pack {pack} frame {f} instance {i} node TRS")
+            check(ps[1][f][1][i], os_[i].global_matrices(), True, f"pack {pack} frame {f} instance {i} global matrices")
+        for k in range(2):
+            assert np.array_equal(ps[0][f][k].view(np.uint32), ps[1][f][k].view(np.uint32)), f"pack {pack} frame {f}: differs from one instance per workgroup"
+    assert not np.array_equal(ps[1][11][0][0], ps[1][11][0][66])        # the instances do differ
+    for o in os_.values():
+        o.close()
+
+
 def test_set_local_trs_places_instances(ctx, orc):
     sc = cases.by_index()
     n = 5
