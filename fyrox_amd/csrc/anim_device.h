@@ -25,7 +25,11 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
     const Rig& rig = *A.rig;
     const size_t in = (size_t)A.n_instances * rig.n_nodes;
     if (!A.d_node_trs) {
-        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_node_trs), std::max<size_t>(in * 48, 16)));
+        // (+ one word behind the records: the counter of one-launch frames, FrameSync)
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_node_trs), in * 48 + 16));
+        A.d_frame_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(A.d_node_trs) + in * 48);
+        A.frame_counter_total = 0;
+        FYX_HIP(c, hipMemsetAsync(A.d_frame_counter, 0, 16, c->stream));
         FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_local), std::max<size_t>(in * 64, 16)));
         FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_global), std::max<size_t>(in * 64, 16)));
         for (uint32_t i = 0; i < A.n_instances; ++i)  // every instance starts from the rig's transforms
@@ -364,7 +368,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     PoseFrameDev f;
     frame_static(c, A, f);
     int slot = 0;
-    bool in_args = false;
+    bool in_args = false, one_launch = false;
     CtrlInline inl;
     inl.bytes = 0;
     inl.first_ops = 0;
@@ -386,17 +390,23 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
             if (int rc = ctrl_upload(c, A.ctrl, slot, L.total, ps)) return rc;
             ctrl_bind(A, L, d, f);
         }
-        if (int rc = timeline_arm(c, 1)) return rc;
-        FYX_HIP(c, launch_pose_sample(f, ps, &inl));
-        g_launch_events = LaunchEvents();
-        FYX_HIP(c, launch_property_sample(f, ps, &inl));
-        if (L.rm) FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), ps, &inl));
+        // one character (a few instances) without root motion or property tracks: sampler and update are ONE launch
+        one_launch = c->one_launch && in_args && !L.rm && f.n_prop_slots == 0 && f.n_anims > 0 &&
+                     (f.sample_form == 1 || (f.sample_form == 0 && f.n_instances < 32));
+        if (!one_launch) {
+            if (int rc = timeline_arm(c, 1)) return rc;
+            FYX_HIP(c, launch_pose_sample(f, ps, &inl));
+            g_launch_events = LaunchEvents();
+            FYX_HIP(c, launch_property_sample(f, ps, &inl));
+            if (L.rm) FYX_HIP(c, launch_root_motion(f, !A.rm_ops.empty(), ps, &inl));
+        }
     }
     RigDev rd;
     if (int rc = rig_params(c, A, rd)) return rc;
     const int upd_mode = !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral;
     if (int rc = timeline_arm(c, 2)) return rc;
-    FYX_HIP(c, launch_pose_update(f, rd, upd_mode, ps, &inl, c->upd_pack));
+    if (one_launch) FYX_HIP(c, launch_pose_frame(f, rd, upd_mode, ps, inl, A.d_frame_counter, &A.frame_counter_total));
+    else FYX_HIP(c, launch_pose_update(f, rd, upd_mode, ps, &inl, c->upd_pack));
     g_launch_events = LaunchEvents();
     if (with_program) {
         FYX_HIP(c, launch_property_update(f, ps, &inl));

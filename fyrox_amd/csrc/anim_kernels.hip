@@ -1262,9 +1262,9 @@ __device__ __forceinline__ void mat4_mul(const float* a, const float* b, float* 
 // crowd's update kernel sit beside the previous frame's skinning (<= 128 VGPRs instead of ~440: anim.overlap).
 // pal_mem: where the rig's palette outputs lie in memory, for callers whose RigDev is a register copy (the scene form: indexing a
 // register copy with the loop counter would put the array in scratch).
-template <int MODE, int PACK = 1>
+template <int MODE, int PACK = 1, bool WAIT = false, bool WIDE = false>
 __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0,
-                                                 const PaletteOutDev* __restrict__ pal_mem = nullptr) {
+                                                 const PaletteOutDev* __restrict__ pal_mem = nullptr, const FrameSync* wait = nullptr) {
     constexpr bool PROGRAM = MODE != kUpdNoProgram;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // PACK > 1: the workgroup is PACK independent waves, one instance each (rigs of <= 64 nodes: pose_update_pack_kernel) -- a
@@ -1288,9 +1288,9 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     // fold's chain of dependent loads instead of after it: what this thread will do in the hierarchy walk (its <= 4
     // entries of the depth-sorted node list: node, level, parent -- so a level of the walk costs LDS traffic and a
     // barrier only) and, per node, the 112 bytes of the rig's static transform parts.
-    constexpr int kEntries = PACK > 1 ? 1 : kMaxRigNodes / 256;   // launch_pose_update: block = min(256, n_nodes rounded up to 64); packed: <= 64 nodes on 64 lanes
-    uint32_t w_node[kEntries], w_level[kEntries];
-    int32_t w_par[kEntries];
+    constexpr int kEntries = WIDE ? 0 : PACK > 1 ? 1 : kMaxRigNodes / 256;   // launch_pose_update: block = min(256, n_nodes rounded up to 64); packed: <= 64 nodes on 64 lanes
+    uint32_t w_node[kEntries ? kEntries : 1], w_level[kEntries ? kEntries : 1];
+    int32_t w_par[kEntries ? kEntries : 1];
 #pragma unroll
     for (int k = 0; k < kEntries; ++k) {
         const uint32_t i = tid + (uint32_t)k * bdim;
@@ -1303,6 +1303,20 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             w_par[k] = (int32_t)((e >> 10) & 2047u) - 1;
             w_level[k] = e >> 21;
         }
+    }
+    // WIDE (a workgroup of 256 threads for one character: the launches with the control block in their arguments): the walk below
+    // gives every ELEMENT of a node's matrix a lane -- sixteen nodes of a level at a time -- so a level is four dependent VALU
+    // instead of 112.  Its tables are staged here, where nothing waits for them: the depth-sorted entries and where each level
+    // starts in them (the list is sorted by depth and every depth below the deepest occurs: a node's parent is one level up).
+    uint32_t* s_walk = reinterpret_cast<uint32_t*>(lds + (size_t)rig.n_nodes * 32);   // [n_nodes]
+    uint32_t* s_off = s_walk + rig.n_nodes;                                          // [n_levels + 2]
+    if constexpr (WIDE) {
+        for (uint32_t i = threadIdx.x; i < rig.n_nodes; i += blockDim.x) {
+            const uint32_t e = rig.walk[i], before = i ? rig.walk[i - 1] : 0u;
+            s_walk[i] = e;
+            if (i == 0 || (e >> 21) != (before >> 21)) s_off[e >> 21] = i;
+        }
+        if (threadIdx.x == 0) s_off[rig.n_levels] = s_off[rig.n_levels + 1] = rig.n_nodes;
     }
     // the instance's fold program: op `lane` into every wave's registers while ALL lanes are still active (v_readlane
     // reads a lane's register whatever EXEC says, but only active lanes load)
@@ -1357,6 +1371,15 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             for (int q = 0; q < 7; ++q) {
                 const f4 v = sp[q];
                 st[q * 4] = v.x; st[q * 4 + 1] = v.y; st[q * 4 + 2] = v.z; st[q * 4 + 3] = v.w;
+            }
+        }
+        if constexpr (WAIT) {
+            // one-launch frame: the sampler's workgroups run in this grid too; everything above was requested without them
+            if (node_base == 0) {
+                if (threadIdx.x == 0)
+                    while ((int32_t)(__hip_atomic_load(wait->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait->target) < 0) __builtin_amdgcn_s_sleep(1);
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the records are read behind this, from where the samplers put them
             }
         }
         FoldCtx cx;
@@ -1427,7 +1450,35 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
 
     // level-synchronous global = parent.global * local; a root multiplies by the identity, as
     // the reference does for a node without a valid parent.  What each thread does in the walk was fetched at the top.
-    for (uint32_t lv = 0; lv < rig.n_levels; ++lv) {
+    if constexpr (WIDE) {
+        const uint32_t g = threadIdx.x >> 4, e = threadIdx.x & 15u, i = e & 3u, j = e >> 2;     // element (row i, column j) of group g's node
+        uint32_t start = s_off[0], end = s_off[1];
+        uint32_t ent = start + g < end ? s_walk[start + g] : 0u;
+        for (uint32_t lv = 0; lv < rig.n_levels; ++lv) {
+            // the next level's entry is requested before this level's matrices: it is in a register when the barrier opens
+            const uint32_t nstart = end, nend = s_off[lv + 2];
+            const uint32_t nent = nstart + g < nend ? s_walk[nstart + g] : 0u;
+            for (uint32_t k = start + g; k < end; k += 16u) {
+                const uint32_t en = k == start + g ? ent : s_walk[k];
+                const uint32_t node = en & 1023u;
+                const int32_t par = (int32_t)((en >> 10) & 2047u) - 1;
+                const f4 b = reinterpret_cast<const f4*>(l_local + (size_t)node * 16)[j];
+                float a0 = i == 0 ? 1.0f : 0.0f, a1 = i == 1 ? 1.0f : 0.0f, a2 = i == 2 ? 1.0f : 0.0f, a3 = i == 3 ? 1.0f : 0.0f;
+                if (par >= 0) {
+                    const float* a = l_global + (size_t)par * 16 + i;
+                    a0 = a[0]; a1 = a[4]; a2 = a[8]; a3 = a[12];
+                }
+                float y = a0 * b.x;       // mat4_mul's chain for this element
+                y = a1 * b.y + y;
+                y = a2 * b.z + y;
+                y = a3 * b.w + y;
+                l_global[(size_t)node * 16 + j * 4 + i] = y;
+            }
+            sync();
+            start = nstart; end = nend; ent = nent;
+        }
+    }
+    for (uint32_t lv = 0; !WIDE && lv < rig.n_levels; ++lv) {
 #pragma unroll
         for (int k = 0; k < kEntries; ++k) {
             if (w_level[k] != lv) continue;
@@ -1511,9 +1562,24 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
 // Two kernel-argument shapes: with the frame's control block inside the arguments (one character, CtrlInline) and without
 // (crowds, scenes, update_transforms: 1 KB less to copy per launch, and no SGPR pressure from a parameter nobody reads).
 template <int MODE>
-__global__ __launch_bounds__(256) void pose_update_inl_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl) { pose_update_body<MODE>(ctrl_resolve<kInlAfterFrameAndRig>(f, inl), rig, blockIdx.x, inl.first_ops); }
+__global__ __launch_bounds__(256) void pose_update_inl_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl) { pose_update_body<MODE, 1, false, true>(ctrl_resolve<kInlAfterFrameAndRig>(f, inl), rig, blockIdx.x, inl.first_ops); }
 template <int MODE>
 __global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) { pose_update_body<MODE>(f, rig, blockIdx.x); }
+// One character's frame in one launch (FrameSync, fyx_internal.h).
+template <int MODE>
+__global__ __launch_bounds__(256) void pose_frame_inl_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl, FrameSync fs) {
+    const PoseFrameDev fr = ctrl_resolve<kInlAfterFrameAndRig>(f, inl);
+    if (blockIdx.x < fs.n_sample_blocks) {
+        const uint32_t bx = blockIdx.x % fs.sx, t = blockIdx.x / fs.sx;
+        pose_sample_body(fr, bx, t % fs.sy, t / fs.sy);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every thread: its part of the records is visible device-wide ...
+        __syncthreads();                                      // ... before the workgroup reports
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(fs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    pose_update_body<MODE, 1, true, true>(fr, rig, blockIdx.x - fs.n_sample_blocks, inl.first_ops, nullptr, &fs);
+}
+
 // Crowds of small rigs (<= 64 nodes: one wave per instance): PACK instances per workgroup (four: one per SIMD).  The waves share
 // nothing; what the packing buys is WHERE they land when the launch runs beside a crowd's skinning (anim.overlap): that kernel's
 // workgroups take half a CU each (two 128-VGPR waves on every SIMD), a lone update wave of ~160 VGPRs that slips into such a
@@ -1547,14 +1613,17 @@ static hipError_t launch_update_one(K kernel, uint32_t grid, uint32_t block, siz
     return hipGetLastError();
 }
 
+// matrices + the wide walk's tables (pose_update_body<.., WIDE>)
+static size_t wide_walk_lds(const RigDev& rig) { return (size_t)rig.n_nodes * 32 * sizeof(float) + ((size_t)rig.n_nodes + rig.n_levels + 2) * sizeof(uint32_t); }
+
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl, int pack) {
     if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;
     const uint32_t block = 64u * update_block_waves(rig.n_nodes, f.n_instances);
     const size_t lds = (size_t)rig.n_nodes * 32 * sizeof(float);
     const bool in_args = inl && inl->bytes && mode != kUpdNoProgram;
-    if (in_args) {
-        if (mode == kUpdStraight) return launch_update_one(pose_update_inl_kernel<kUpdStraight>, f.n_instances, block, lds, s, f, rig, *inl);
-        return launch_update_one(pose_update_inl_kernel<kUpdGeneral>, f.n_instances, block, lds, s, f, rig, *inl);
+    if (in_args) {    // (a control block that fits the arguments is a few instances: 256 threads, the wide walk)
+        if (mode == kUpdStraight) return launch_update_one(pose_update_inl_kernel<kUpdStraight>, f.n_instances, 256u, wide_walk_lds(rig), s, f, rig, *inl);
+        return launch_update_one(pose_update_inl_kernel<kUpdGeneral>, f.n_instances, 256u, wide_walk_lds(rig), s, f, rig, *inl);
     }
     if (pack > 1 && rig.n_nodes <= 64u && f.n_instances >= 64u && mode == kUpdStraight) {
         const uint32_t p = pack >= 4 ? 4u : 2u, grid = (f.n_instances + p - 1u) / p;
@@ -1564,6 +1633,22 @@ hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode
     if (mode == kUpdStraight) return launch_update_one(pose_update_kernel<kUpdStraight>, f.n_instances, block, lds, s, f, rig);
     if (mode == kUpdGeneral) return launch_update_one(pose_update_kernel<kUpdGeneral>, f.n_instances, block, lds, s, f, rig);
     return launch_update_one(pose_update_kernel<kUpdNoProgram>, f.n_instances, block, lds, s, f, rig);
+}
+
+hipError_t launch_pose_frame(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline& inl, uint32_t* counter, uint32_t* counter_total) {
+    FrameSync fs;
+    fs.counter = counter;
+    fs.sx = (f.n_nodes * 16 + 255) / 256;
+    fs.sy = f.n_instances;
+    fs.n_sample_blocks = fs.sx * fs.sy * f.n_anims;
+    fs.pad = 0;
+    *counter_total += fs.n_sample_blocks;
+    fs.target = *counter_total;
+    const size_t lds = wide_walk_lds(rig);
+    const uint32_t grid = fs.n_sample_blocks + f.n_instances;
+    // (first_ops of instance 0 only: pose_update_body looks at it for inst == 0)
+    if (mode == kUpdStraight) return launch_update_one(pose_frame_inl_kernel<kUpdStraight>, grid, 256u, lds, s, f, rig, inl, fs);
+    return launch_update_one(pose_frame_inl_kernel<kUpdGeneral>, grid, 256u, lds, s, f, rig, inl, fs);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -168,6 +168,8 @@ struct Animator {
     float4* d_anim_pose = nullptr;
     uint32_t dev_anim_capacity = 0, dev_track_capacity = 0;
     float4* d_node_trs = nullptr;
+    uint32_t* d_frame_counter = nullptr;   // (inside d_node_trs' allocation) FrameSync::counter
+    uint32_t frame_counter_total = 0;      // what it reaches when every launch issued so far has run
     float* d_local = nullptr;
     float* d_global = nullptr;
     uint8_t* d_layer_masks = nullptr;

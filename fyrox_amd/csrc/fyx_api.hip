@@ -753,6 +753,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "anim.sample_form")) return &c->sample_form;
     if (!strcmp(key, "anim.update_lean")) return &c->upd_lean;
     if (!strcmp(key, "anim.update_pack")) return &c->upd_pack;
+    if (!strcmp(key, "anim.one_launch")) return &c->one_launch;
     if (!strcmp(key, "anim.ctrl_upload")) return &c->ctrl_mode;
     if (!strcmp(key, "streams.priority")) return &c->stream_priority;
     if (!strcmp(key, "streams.pose_cus")) return &c->pose_cus;
@@ -787,6 +788,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->stream_priority && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "streams.priority must be 0 or 1");
     if (slot == &c->pose_cus && (value < 0 || value >= fyx::kCUs || (value & 7))) return fail(c, FYX_ERR_INVALID_ARG, "streams.pose_cus must be 0 or a multiple of 8 below %d", fyx::kCUs);
     if (slot == &c->upd_lean && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_lean must be 0 or 1");
+    if (slot == &c->one_launch && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.one_launch must be 0 or 1");
     if (slot == &c->upd_pack && value != 0 && value != 2 && value != 4) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_pack must be 0, 2 or 4");
     if ((slot == &c->stream_priority || slot == &c->pose_cus) && *slot != value) {
         const int old = *slot;

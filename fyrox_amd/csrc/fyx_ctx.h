@@ -115,6 +115,7 @@ struct fyx_ctx {
     int sample_form = 0;     // option "anim.sample_form": 0 auto, 1 curves on the lanes, 2 instances on the lanes
     int pose_overlap = 0;    // option "anim.overlap": 1 = pose updates do not wait for in-flight skinning launches (see enter_pose)
     int inline_ctrl = 1;     // option "anim.inline_ctrl": 1 = a control block of <= 1 KB travels in the kernel arguments (no H2D copy)
+    int one_launch = 1;      // option "anim.one_launch": one character's sampler and update kernels as one launch (FrameSync)
     int upd_pack = 4;        // option "anim.update_pack": 0, 2 or 4 instances of a small rig (<= 64 nodes) per workgroup of a crowd's update launch
     int upd_lean = 1;        // option "anim.update_lean": 1 = frames whose fold programs are all straight run the update kernel without the interpreter
     int plan_split = 2048;   // option "anim.split": instances per planning task

@@ -401,6 +401,19 @@ inline uint32_t update_block_waves(uint32_t n_nodes, uint32_t n_instances) {
     return w < 1u ? 1u : w;
 }
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl = nullptr, int pack = 0);
+// One character's frame in ONE launch (option anim.one_launch): the sampler's workgroups first, the update's behind them IN THE
+// SAME GRID.  An update workgroup fetches what does not depend on the sampled poses (walk table, program, statics, the node's own
+// transforms), then waits until `counter` -- every sampler workgroup adds one after its records are visible device-wide -- has
+// reached `target`.  Workgroups are dispatched in index order, so a waiting update workgroup never holds a place a sampler
+// workgroup needs.  What it saves is the launch boundary between the two kernels (~3 us of a 12 us pose path).
+struct FrameSync {
+    uint32_t* counter;           // device word of the animator, only ever added to
+    uint32_t target;             // its value when all sampler workgroups of THIS frame have reported (wraps: compared as a signed difference)
+    uint32_t n_sample_blocks;    // workgroups [0, n_sample_blocks) of the grid sample, the rest update
+    uint32_t sx, sy;             // the sampler's own grid (x, y; z follows), flattened x fastest
+    uint32_t pad;
+};
+hipError_t launch_pose_frame(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline& inl, uint32_t* counter, uint32_t* counter_total);
 
 // Animation::update_root_motion for every ticked animation that has settings (after pose_sample:
 // rewrites the root node's pose record), then the per-instance root-motion program (machine mode).
