@@ -177,6 +177,7 @@ _SIGS = {
     "fyx_allgather_f32": (c_int, [_P, _P, c_size_t, _P]),
     "fyx_shard_vertex_range": (c_int, [c_uint32, c_int, c_int, POINTER(c_uint32), POINTER(c_uint32)]),
     "fyx_debug_rig_walk": (c_int, [_P, c_uint64, _P, c_uint32, POINTER(c_uint32)]),
+    "fyx_debug_rig_chunks": (c_int, [_P, c_uint64, _P, c_uint32, POINTER(c_uint32)]),
     "fyx_debug_span_value_at": (c_int, [_P, c_uint32, c_uint32, c_float, c_uint32, _P, POINTER(c_uint32)]),
     "fyx_debug_classify_fold_program": (c_int, [_P, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "fyx_curve_simplify": (c_int, [_P, _P, c_uint32, c_float, c_float, _P, POINTER(c_uint32)]),

@@ -242,6 +242,27 @@ int fyx_rig_create(fyx_ctx* c, uint64_t rig_id, uint32_t n_nodes, const int32_t*
     // (ANY negative parent is a root, as everywhere else in the host code: only -1 may be incremented into the 11-bit field)
     for (uint32_t& e : level_nodes) e = e | (parent[e] < 0 ? 0u : (uint32_t)parent[e] + 1u) << 10 | depth[e] << 21;
     r.walk = level_nodes;
+    // The same order in CHUNKS of sixteen for the wide walk (pose_update_body<.., WIDE>: a lane per matrix element, sixteen nodes
+    // at a time): a level is padded to whole chunks, so that no lane of the walk ever tests whether it has a node.  Entry:
+    // node | parent slot << 11 | (last chunk of its level) << 22, where slot n_nodes holds the identity (what a root is multiplied
+    // by) and slot n_nodes + 1 is nobody's (the padding's node: its product goes there).
+    static_assert(kMaxRigNodes + 2 <= 2048, "wide-walk entries pack node and parent slot into 11 bits each");
+    r.chunks.clear();
+    for (uint32_t l = 0; l < r.n_levels; ++l) {
+        const uint32_t b = level_start[l], e = level_start[l + 1];
+        for (uint32_t c0 = b; c0 < e; c0 += 16) {
+            const uint32_t last = c0 + 16 >= e ? 1u << 22 : 0u;
+            for (uint32_t g = 0; g < 16; ++g) {
+                uint32_t node = n_nodes + 1, slot = n_nodes;
+                if (c0 + g < e) {
+                    node = r.walk[c0 + g] & 1023u;
+                    slot = parent[node] < 0 ? n_nodes : (uint32_t)parent[node];
+                }
+                r.chunks.push_back(node | slot << 11 | last);
+            }
+        }
+    }
+    r.n_chunks = (uint32_t)(r.chunks.size() / 16);
     r.init_trs.assign((size_t)n_nodes * 12, 0.f);
     std::vector<float> statics((size_t)n_nodes * 28, 0.f);
     for (uint32_t i = 0; i < n_nodes; ++i) {
@@ -267,7 +288,11 @@ int fyx_rig_create(fyx_ctx* c, uint64_t rig_id, uint32_t n_nodes, const int32_t*
             for (uint32_t i = 0; i < n_nodes; ++i) ib[(size_t)i * 16] = ib[(size_t)i * 16 + 5] = ib[(size_t)i * 16 + 10] = ib[(size_t)i * 16 + 15] = 1.f;
         }
         int rc = upload(c, &r.d_statics, statics.data(), statics.size());
-        if (!rc) rc = upload(c, &r.d_walk, level_nodes.data(), level_nodes.size());
+        if (!rc) {      // [n_nodes] walk words, then [n_chunks][16] chunk entries
+            std::vector<uint32_t> both(level_nodes);
+            both.insert(both.end(), r.chunks.begin(), r.chunks.end());
+            rc = upload(c, &r.d_walk, both.data(), both.size());
+        }
         if (!rc) rc = upload(c, &r.d_inv_bind, ib.data(), ib.size());
         if (rc) { free_rig(r); return rc; }
     }
@@ -1004,6 +1029,18 @@ int fyx_debug_rig_walk(fyx_ctx* c, uint64_t rig_id, uint32_t* out_words, uint32_
     auto it = store(c).rigs.find(rig_id);
     if (it == store(c).rigs.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "rig %llu", (unsigned long long)rig_id);
     const std::vector<uint32_t>& w = it->second.walk;
+    *n_words = (uint32_t)w.size();
+    if (out_words) memcpy(out_words, w.data(), std::min<size_t>(w.size(), capacity) * 4);
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_debug_rig_chunks(fyx_ctx* c, uint64_t rig_id, uint32_t* out_words, uint32_t capacity, uint32_t* n_words) {
+    if (!c || !n_words) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    auto it = store(c).rigs.find(rig_id);
+    if (it == store(c).rigs.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "rig %llu", (unsigned long long)rig_id);
+    const std::vector<uint32_t>& w = it->second.chunks;
     *n_words = (uint32_t)w.size();
     if (out_words) memcpy(out_words, w.data(), std::min<size_t>(w.size(), capacity) * 4);
     return FYX_OK;

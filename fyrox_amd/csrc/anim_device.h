@@ -264,6 +264,8 @@ RigDev rig_dev(const Rig& r) {
     d.n_pal = 0;
     d.n_nodes = r.n_nodes;
     d.n_levels = r.n_levels;
+    d.n_chunks = r.n_chunks;
+    d.pad1 = 0;
     return d;
 }
 
@@ -376,7 +378,9 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     if (with_program) {
         // a small control block (one character, a handful of instances) rides in the kernel arguments: no copy, no event, no wait
         const CtrlLayout Li = ctrl_layout_inline(A);
-        in_args = c->inline_ctrl && Li.total <= sizeof(CtrlInline);
+        // (the kernels that read it there walk the hierarchy wide: a deep rig of ~1000 nodes, whose chunk table no longer fits
+        // the LDS beside its matrices, takes the uploaded block and the narrow kernels)
+        in_args = c->inline_ctrl && Li.total <= sizeof(CtrlInline) && wide_update_lds(A.rig->n_nodes, A.rig->n_chunks) <= kLdsPerWorkgroup;
         const CtrlLayout L = in_args ? Li : ctrl_layout(A);
         if (in_args) {
             ctrl_write(A, L, reinterpret_cast<char*>(&inl));    // the sections start behind the header (offset 16)

@@ -1271,8 +1271,10 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     // wave is then its own "workgroup": its index in it is the lane, its LDS area its own, its barrier the wave's program order
     const uint32_t tid = PACK > 1 ? (threadIdx.x & 63u) : threadIdx.x;
     const uint32_t bdim = PACK > 1 ? 64u : blockDim.x;
+    // (WIDE: two more slots each -- n_nodes: the identity among the globals, n_nodes + 1: the padding's node -- see the walk)
+    constexpr uint32_t kSlots = WIDE ? 2u : 0u;
     float* l_local = lds + (PACK > 1 ? (size_t)(threadIdx.x >> 6) * rig.n_nodes * 32 : 0);   // [n_nodes][16]
-    float* l_global = l_local + (size_t)rig.n_nodes * 16;                                     // [n_nodes][16]
+    float* l_global = l_local + (size_t)(rig.n_nodes + kSlots) * 16;                          // [n_nodes][16]
     auto sync = [] {
         if constexpr (PACK > 1) {    // (LDS operations of one wave execute in program order: only the compiler has to keep it)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1305,18 +1307,18 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         }
     }
     // WIDE (a workgroup of 256 threads for one character: the launches with the control block in their arguments): the walk below
-    // gives every ELEMENT of a node's matrix a lane -- sixteen nodes of a level at a time -- so a level is four dependent VALU
-    // instead of 112.  Its tables are staged here, where nothing waits for them: the depth-sorted entries and where each level
-    // starts in them (the list is sorted by depth and every depth below the deepest occurs: a node's parent is one level up).
-    uint32_t* s_walk = reinterpret_cast<uint32_t*>(lds + (size_t)rig.n_nodes * 32);   // [n_nodes]
-    uint32_t* s_off = s_walk + rig.n_nodes;                                          // [n_levels + 2]
+    // gives every ELEMENT of a node's matrix a lane -- sixteen nodes of a level at a time -- so a level is five dependent VALU
+    // instead of 112, and a lone wave issues an instruction every ~4 cycles whatever it is.  Its table (RigDev::walk's second
+    // part: the host's chunks of sixteen entries, levels padded to whole chunks) is staged here, where nothing waits for it.
+    uint32_t* s_chunks = reinterpret_cast<uint32_t*>(lds + (size_t)(rig.n_nodes + kSlots) * 32);   // [n_chunks + 1][16]
     if constexpr (WIDE) {
-        for (uint32_t i = threadIdx.x; i < rig.n_nodes; i += blockDim.x) {
-            const uint32_t e = rig.walk[i], before = i ? rig.walk[i - 1] : 0u;
-            s_walk[i] = e;
-            if (i == 0 || (e >> 21) != (before >> 21)) s_off[e >> 21] = i;
+        const uint32_t* gc = rig.walk + rig.n_nodes;
+        for (uint32_t i = threadIdx.x; i < rig.n_chunks * 16u; i += blockDim.x) s_chunks[i] = gc[i];
+        if (threadIdx.x < 16u) {
+            l_global[(size_t)rig.n_nodes * 16 + threadIdx.x] = (threadIdx.x % 5u == 0u) ? 1.0f : 0.0f;   // what a root is multiplied by
+            l_local[(size_t)(rig.n_nodes + 1u) * 16 + threadIdx.x] = 0.0f;                               // the padding's "local matrix"
+            s_chunks[rig.n_chunks * 16u + threadIdx.x] = 0u;                                            // (read ahead by the last chunk)
         }
-        if (threadIdx.x == 0) s_off[rig.n_levels] = s_off[rig.n_levels + 1] = rig.n_nodes;
     }
     // the instance's fold program: op `lane` into every wave's registers while ALL lanes are still active (v_readlane
     // reads a lane's register whatever EXEC says, but only active lanes load)
@@ -1451,31 +1453,28 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
     // level-synchronous global = parent.global * local; a root multiplies by the identity, as
     // the reference does for a node without a valid parent.  What each thread does in the walk was fetched at the top.
     if constexpr (WIDE) {
-        const uint32_t g = threadIdx.x >> 4, e = threadIdx.x & 15u, i = e & 3u, j = e >> 2;     // element (row i, column j) of group g's node
-        uint32_t start = s_off[0], end = s_off[1];
-        uint32_t ent = start + g < end ? s_walk[start + g] : 0u;
-        for (uint32_t lv = 0; lv < rig.n_levels; ++lv) {
-            // the next level's entry is requested before this level's matrices: it is in a register when the barrier opens
-            const uint32_t nstart = end, nend = s_off[lv + 2];
-            const uint32_t nent = nstart + g < nend ? s_walk[nstart + g] : 0u;
-            for (uint32_t k = start + g; k < end; k += 16u) {
-                const uint32_t en = k == start + g ? ent : s_walk[k];
-                const uint32_t node = en & 1023u;
-                const int32_t par = (int32_t)((en >> 10) & 2047u) - 1;
-                const f4 b = reinterpret_cast<const f4*>(l_local + (size_t)node * 16)[j];
-                float a0 = i == 0 ? 1.0f : 0.0f, a1 = i == 1 ? 1.0f : 0.0f, a2 = i == 2 ? 1.0f : 0.0f, a3 = i == 3 ? 1.0f : 0.0f;
-                if (par >= 0) {
-                    const float* a = l_global + (size_t)par * 16 + i;
-                    a0 = a[0]; a1 = a[4]; a2 = a[8]; a3 = a[12];
-                }
-                float y = a0 * b.x;       // mat4_mul's chain for this element
-                y = a1 * b.y + y;
-                y = a2 * b.z + y;
-                y = a3 * b.w + y;
-                l_global[(size_t)node * 16 + j * 4 + i] = y;
-            }
-            sync();
-            start = nstart; end = nend; ent = nent;
+        // Lane (g, i, j) forms element (row i, column j) of the matrix of group g's node: mat4_mul's chain for that element.  No
+        // lane asks whether it has a node (padding entries multiply the identity by zeros into a slot nobody reads) or whether its
+        // node has a parent (a root's parent slot holds the identity): a chunk is straight-line code, and the barrier closes a level.
+        // Measured (tools/exp/r04_stamps.py, nine levels): 1.3 us against 2.1 us with per-level offsets and a lane test, 2.2 - 3.1 us
+        // for the walk in which a lane forms a whole matrix.
+        const uint32_t g = threadIdx.x >> 4, e = threadIdx.x & 15u, i = e & 3u, j = e >> 2;
+        const uint32_t* cp = s_chunks + g;
+        uint32_t ent = cp[0];
+        for (uint32_t ch = 0; ch < rig.n_chunks; ++ch) {
+            cp += 16;
+            const uint32_t nent = cp[0];      // the next chunk's entry: in a register before it is needed
+            const uint32_t node = ent & 2047u, slot = (ent >> 11) & 2047u;
+            const f4 b = reinterpret_cast<const f4*>(l_local + (size_t)node * 16)[j];
+            const float* a = l_global + (size_t)slot * 16 + i;
+            const float a0 = a[0], a1 = a[4], a2 = a[8], a3 = a[12];
+            float y = a0 * b.x;
+            y = a1 * b.y + y;
+            y = a2 * b.z + y;
+            y = a3 * b.w + y;
+            l_global[(size_t)node * 16 + e] = y;          // e = j * 4 + i
+            if (__builtin_amdgcn_readfirstlane((int)ent) & (1 << 22)) sync();     // (the flag is the same in all sixteen entries of a chunk)
+            ent = nent;
         }
     }
     for (uint32_t lv = 0; !WIDE && lv < rig.n_levels; ++lv) {
@@ -1614,7 +1613,7 @@ static hipError_t launch_update_one(K kernel, uint32_t grid, uint32_t block, siz
 }
 
 // matrices + the wide walk's tables (pose_update_body<.., WIDE>)
-static size_t wide_walk_lds(const RigDev& rig) { return (size_t)rig.n_nodes * 32 * sizeof(float) + ((size_t)rig.n_nodes + rig.n_levels + 2) * sizeof(uint32_t); }
+static size_t wide_walk_lds(const RigDev& rig) { return wide_update_lds(rig.n_nodes, rig.n_chunks); }
 
 hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline* inl, int pack) {
     if (f.n_instances == 0 || rig.n_nodes == 0) return hipSuccess;

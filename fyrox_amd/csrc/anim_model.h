@@ -26,6 +26,8 @@ struct Rig {
     float* d_statics = nullptr;
     uint32_t* d_walk = nullptr;          // RigDev::walk
     std::vector<uint32_t> walk;          // host copy of it (fyx_debug_rig_walk)
+    std::vector<uint32_t> chunks;        // [n_chunks][16] the wide walk's entries (behind the walk words in d_walk; fyx_debug_rig_chunks)
+    uint32_t n_chunks = 0;
     float* d_inv_bind = nullptr;
 };
 

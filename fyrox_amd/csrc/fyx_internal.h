@@ -287,9 +287,11 @@ struct RigDev {
                                  //   rotation_offset(3) rotation_pivot(3) scaling_offset(3) scaling_pivot(3) pad(3)
     const uint32_t* walk;        // [n_nodes] the nodes sorted by depth, one word each: node | (parent + 1) << 10 | depth << 21
                                  //   (kMaxRigNodes = 1024: 10 + 11 + 11 bits) -- one load where node -> depth, parent were two
+                                 //   behind them [n_chunks][16] entries of the wide walk: node | parent slot << 11 | last-of-level << 22
     uint32_t n_nodes;
     uint32_t n_levels;
-    uint32_t pad1[2];            // (PoseFrameDev, RigDev) is a multiple of 16 bytes: the CtrlInline behind them is 16-byte aligned
+    uint32_t n_chunks;
+    uint32_t pad1;               // (PoseFrameDev, RigDev) is a multiple of 16 bytes: the CtrlInline behind them is 16-byte aligned
 };
 
 // One Property{..} value: the TrackValue's f32 lanes, its variant and whether it is there (== fyx_property_value)
@@ -394,6 +396,9 @@ enum : int { kUpdNoProgram = 0, kUpdGeneral = 1, kUpdStraight = 2 };
 // Waves per workgroup of the update kernel (one workgroup per instance): one per 64 nodes, at most four -- and four for an
 // animator of few instances: the chip is empty then, and the kernel's strided tail (matrix stores, palette columns: 256 columns for
 // 64 bones) runs over four waves instead of one.  A crowd keeps the smallest block: its waves compete with the skinning kernel's.
+// LDS of an update workgroup with the wide walk: (n_nodes + 2) local and global matrices, the chunk table + one chunk read ahead
+inline size_t wide_update_lds(uint32_t n_nodes, uint32_t n_chunks) { return (size_t)(n_nodes + 2u) * 128u + (size_t)(n_chunks + 1u) * 64u; }
+constexpr size_t kLdsPerWorkgroup = 160u * 1024u;
 inline uint32_t update_block_waves(uint32_t n_nodes, uint32_t n_instances) {
     uint32_t w = (n_nodes + 63u) / 64u;
     if (w > 4u) w = 4u;

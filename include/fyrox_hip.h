@@ -796,6 +796,9 @@ int fyx_debug_scene_tables(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t 
 /* Test hooks for the CPU suite (no GPU, no context for the last two).
  *   fyx_debug_rig_walk: the rig's hierarchy-walk table as the update kernel reads it -- one word per node in level order:
  *     node | (parent + 1) << 10 | depth << 21 (any negative parent is a root: field 0).
+ *   fyx_debug_rig_chunks: the same order as the one-character kernels walk it -- chunks of sixteen entries, every level padded to
+ *     whole chunks: node | parent slot << 11 | (last chunk of its level) << 22; parent slot n_nodes = "no parent" (the identity),
+ *     node n_nodes + 1 = padding.
  *   fyx_debug_span_value_at / fyx_debug_classify_fold_program: the kernels' own decision-making leaves (csrc/anim_leaves.h,
  *     __host__ __device__) compiled for the host -- Curve::value_at for the `need` (3 or 4) curves of one track on its span
  *     records (n_keys - 1 records of 8 or 16 float4: {loc[i-1], loc[i], -, -} then per curve {value, kind bits, left tangent,
@@ -803,6 +806,7 @@ int fyx_debug_scene_tables(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t 
  *     program {opcode | arg << 8, f32 weight bits} x n_ops is "straight" (d leading PUSHes, k operands, a MASK before the APPLY,
  *     or the AnimationPlayer's APPLY_ANIM^k END) -- the function by which the host picks the update kernel's lean form. */
 int fyx_debug_rig_walk(fyx_ctx* ctx, uint64_t rig_id, uint32_t* out_words, uint32_t capacity, uint32_t* n_words);
+int fyx_debug_rig_chunks(fyx_ctx* ctx, uint64_t rig_id, uint32_t* out_words, uint32_t capacity, uint32_t* n_words);
 int fyx_debug_span_value_at(const float* span_records, uint32_t n_keys, uint32_t need, float time, uint32_t hint, float out_values[4], uint32_t* out_hint);
 int fyx_debug_classify_fold_program(const uint32_t* ops_xy, uint32_t n_ops, uint32_t* out_d, uint32_t* out_k, int* out_mask, int* out_player,
                                     int* out_straight);

@@ -844,6 +844,20 @@ def test_large_rig_1024_nodes(ctx, orc):
     assert e.value.code == fyrox_amd._native.FYX_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("n,chain_depth", [(200, 1), (70, 3), (600, 599), (1024, 1023), (17, 16), (1, 1)],
+                         ids=["flat_199_children", "levels_of_23", "chain_of_600", "chain_of_1024_takes_the_narrow_kernels", "one_chunk_levels", "one_node"])
+def test_one_character_hierarchy_shapes(ctx, orc, n, chain_depth):
+    """The one-character update kernels walk the hierarchy by chunks of sixteen nodes (a lane per matrix element): levels wider
+    than a chunk, one-node levels, the deepest chain whose table still fits the LDS, and one whose table does not (it takes the
+    uploaded control block and the narrow kernels).  One instance, quaternion tracks: bit-exact against the oracle."""
+    rig = synth.make_rig(n, 77, chain_depth=chain_depth, exotic=True)
+    td, tgt = synth.make_clip(n, 77, 0, n_keys=5, euler_every=10 ** 9)
+    sc = cases.Scenario("shape", rig, [td], [cases.AnimSpec(0, tgt, time_slice=(0.0, 4 / 30))], None, n_frames=3, has_euler=False)
+    o, p = run_scenario(ctx, orc, sc, n_instances=1)
+    o.close()
+    p.free()
+
+
 # ---- fyx_scene_update: many animators, one launch per stage ----------------------------------------------------
 
 def _scene_members():

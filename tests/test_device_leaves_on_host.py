@@ -174,3 +174,44 @@ def test_any_negative_parent_is_a_root():
         assert {n_: p_ for n_, p_ in zip(nodes, parents)} == {0: -1, 1: 0, 2: 1, 3: -1, 4: 3, 5: 3}
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_wide_walk_chunks_cover_every_node_once_in_level_order(seed):
+    """fyx_debug_rig_chunks: the table the one-character update kernels walk.  Every node exactly once, with its parent's slot (or the
+    identity's, n_nodes), a parent always in an EARLIER level (a barrier lies between: the entry that closes a level carries the flag),
+    levels padded to whole chunks of sixteen with the padding node n_nodes + 1."""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(1, 200)) if seed else 1
+    width = [1, 1, 3, 20, 50, 2][seed]
+    parent = np.full(n, -1, np.int32)
+    for i in range(1, n):
+        parent[i] = -1 if rng.random() < 0.05 else int(rng.integers(max(0, i - width), i))
+    c = fyrox_amd.Context(control_only=True)
+    try:
+        A.create_rig(c, 5, A.Rig(parent, [A.Transform.identity() for _ in range(n)]))
+        out, cnt = np.zeros(16 * (2 * n + 4), np.uint32), ctypes.c_uint32()
+        assert _native.lib().fyx_debug_rig_chunks(c._h, 5, out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(cnt)) == 0
+        w = out[:cnt.value].reshape(-1, 16)
+    finally:
+        c.close()
+    depth = np.zeros(n, np.int64)
+    for i in range(n):
+        depth[i] = 0 if parent[i] < 0 else depth[parent[i]] + 1
+    node, slot, last = w & 2047, (w >> 11) & 2047, (w >> 22) & 1
+    assert (w >> 23 == 0).all() and (last == last[:, :1]).all()          # the flag is the chunk's
+    real = node < n
+    assert sorted(node[real].tolist()) == list(range(n)) and (node[~real] == n + 1).all() and (slot[~real] == n).all()
+    level = np.concatenate([[0], np.cumsum(last[:-1, 0])])                # the level a chunk belongs to
+    assert last[-1, 0] == 1 and level[-1] == depth.max()
+    for ch in range(w.shape[0]):
+        for g in range(16):
+            if real[ch, g]:
+                nd = int(node[ch, g])
+                assert depth[nd] == level[ch]
+                assert int(slot[ch, g]) == (n if parent[nd] < 0 else parent[nd])
+        assert real[ch, 0]                                                 # no chunk of padding only
+    # padding only at the end of a level
+    for lv in range(int(depth.max()) + 1):
+        flat = real[level == lv].reshape(-1)
+        assert not flat[np.argmin(flat):].any() or flat.all()
