@@ -258,6 +258,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
 
 RigDev rig_dev(const Rig& r) {
     RigDev d;
+    memset(&d, 0, sizeof d);      // (unused palette entries and padding too: a scene compares its job array byte for byte)
     d.statics = r.d_statics;
     d.walk = r.d_walk;
     d.inv_bind = r.d_inv_bind;
@@ -291,16 +292,18 @@ void frame_static(const fyx_ctx* c, const Animator& A, PoseFrameDev& f) {
     f.prop_out = A.d_prop_out;
 }
 
+// (sections 16-byte aligned: uint4 reads of the root-motion ops, whole uint4 copies; a scene of 256 characters is 256 such blocks)
+constexpr size_t kCtrlAlign = 16;
 CtrlLayout ctrl_layout(const Animator& A) {
     CtrlLayout L;
     L.rm = A.rm_enabled;
-    L.o_tick = align_up(A.times.size() * 4, 256);
-    L.o_off = L.o_tick + align_up(A.ticked.size(), 256);
-    L.o_ops = L.o_off + align_up(A.prog_off.size() * 4, 256);
-    L.o_slices = L.o_ops + align_up(A.ops.size() * 8, 256);
-    L.o_rmoff = L.o_slices + (L.rm ? align_up(A.slices.size() * 8, 256) : 0);
-    L.o_rmops = L.o_rmoff + (L.rm ? align_up(A.rm_prog_off.size() * 4, 256) : 0);
-    L.total = L.o_rmops + (L.rm ? align_up(A.rm_ops.size() * 16, 256) : 0);
+    L.o_tick = align_up(A.times.size() * 4, kCtrlAlign);
+    L.o_off = L.o_tick + align_up(A.ticked.size(), kCtrlAlign);
+    L.o_ops = L.o_off + align_up(A.prog_off.size() * 4, kCtrlAlign);
+    L.o_slices = L.o_ops + align_up(A.ops.size() * 8, kCtrlAlign);
+    L.o_rmoff = L.o_slices + (L.rm ? align_up(A.slices.size() * 8, kCtrlAlign) : 0);
+    L.o_rmops = L.o_rmoff + (L.rm ? align_up(A.rm_prog_off.size() * 4, kCtrlAlign) : 0);
+    L.total = L.o_rmops + (L.rm ? align_up(A.rm_ops.size() * 16, kCtrlAlign) : 0);
     return L;
 }
 
@@ -529,10 +532,12 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         S.signature = sig;
     }
 
-    // 3. one control block: the job array, then every animator's sections
+    // 3. one control block: every animator's sections.  The job array (352 bytes per animator, pointers into the animators' device
+    // state and OFFSETS into this block) stays on the device and travels only when it changed: 256 one-instance characters upload
+    // ~30 KB per frame instead of ~350 KB, which is what their copy took 11 us for.
     S.layouts.resize(n);
     S.offsets.resize(n);
-    size_t total = align_up(n * sizeof(SceneJobDev), 256);
+    size_t total = 0;
     for (size_t k = 0; k < n; ++k) {
         S.layouts[k] = ctrl_layout(*S.animators[k]);
         S.offsets[k] = total;
@@ -540,23 +545,39 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     }
     int slot = 0;
     char *h = nullptr, *d = nullptr;
-    if (int rc = ctrl_acquire(c, S.ctrl, total, &slot, &h, &d)) return rc;
-    SceneJobDev* jobs = reinterpret_cast<SceneJobDev*>(h);
+    if (int rc = ctrl_acquire(c, S.ctrl, std::max<size_t>(total, 16), &slot, &h, &d)) return rc;
+    S.h_jobs.assign(n * sizeof(SceneJobDev), 0);
+    SceneJobDev* jobs = reinterpret_cast<SceneJobDev*>(S.h_jobs.data());
     for (size_t k = 0; k < n; ++k) {
         const Animator& A = *S.animators[k];
         ctrl_write(A, S.layouts[k], h + S.offsets[k]);
         frame_static(c, A, jobs[k].f);
-        ctrl_bind(A, S.layouts[k], d + S.offsets[k], jobs[k].f);
+        ctrl_bind(A, S.layouts[k], reinterpret_cast<const char*>(S.offsets[k]), jobs[k].f);     // offsets from the block's start
         if (int rc = rig_params(c, A, jobs[k].rig)) return rc;
     }
-    if (int rc = ctrl_upload(c, S.ctrl, slot, total, ps)) return rc;
+    if (S.h_jobs != S.sent_jobs) {
+        if (S.h_jobs.size() > S.d_jobs_capacity) {
+            if (int rc_ = sync_all(c)) return rc_;       // launches in flight read the old array
+            dfree(S.d_jobs);
+            S.d_jobs = nullptr;
+            S.d_jobs_capacity = 0;
+            S.sent_jobs.clear();
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&S.d_jobs), S.h_jobs.size()));
+            S.d_jobs_capacity = S.h_jobs.size();
+        }
+        // in stream order behind the previous frame's pose kernels (enter_pose), whichever stream they ran on; pageable source:
+        // the runtime stages it before the call returns
+        FYX_HIP(c, hipMemcpyAsync(S.d_jobs, S.h_jobs.data(), S.h_jobs.size(), hipMemcpyHostToDevice, ps));
+        S.sent_jobs = S.h_jobs;
+    }
+    if (int rc = ctrl_upload(c, S.ctrl, slot, std::max<size_t>(total, 16), ps)) return rc;
 
     // 4. one launch per stage
     const uint4* tabs[kSceneStages];
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
     bool all_straight = c->upd_lean != 0;
     for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
-    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(d), tabs, S.n_blocks, S.lds_bytes, all_straight, ps));
+    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs), d, tabs, S.n_blocks, S.lds_bytes, all_straight, ps));
     if (int rc = ctrl_consumed(c, S.ctrl, slot, ps)) return rc;
     return exit_pose(c);
 }
@@ -619,6 +640,7 @@ int node_depth(const LayerDef& L, int32_t h, std::vector<int>& state) {
 void anim_store_destroy(AnimStore* s) {
     if (!s) return;
     dfree(s->scene.d_tables);
+    dfree(s->scene.d_jobs);
     free_ctrl(s->scene.ctrl);
     for (auto& kv : s->animators) free_animator(*kv.second);
     for (auto& kv : s->bones) free_bones(kv.second);

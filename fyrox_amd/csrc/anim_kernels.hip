@@ -360,9 +360,23 @@ __global__ __launch_bounds__(256) void pose_sample_kernel(PoseFrameDev f, CtrlIn
 // Block b of the launch looks up (job, x, y, z) in a table that depends only on the scene's shape -- which animator
 // it works for and which block of that animator's own grid it stands for -- copies the job's parameter block out of
 // HBM (uniform address, loaded before any store: scalar loads, exactly like kernel arguments) and runs the body above.
-__global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+// A job's frame parameters: the job array is resident (it changes when the scene does, not every frame), its control pointers
+// are offsets into the frame's control block `ctrl` -- the only thing a steady frame uploads.
+__device__ __forceinline__ PoseFrameDev scene_frame_of(const SceneJobDev* __restrict__ jobs, uint32_t job, const char* __restrict__ ctrl) {
+    PoseFrameDev f = jobs[job].f;
+    f.times = reinterpret_cast<const float*>(ctrl + reinterpret_cast<uintptr_t>(f.times));
+    f.ticked = reinterpret_cast<const uint8_t*>(ctrl + reinterpret_cast<uintptr_t>(f.ticked));
+    f.ops = reinterpret_cast<const uint2*>(ctrl + reinterpret_cast<uintptr_t>(f.ops));
+    f.prog_off = reinterpret_cast<const uint32_t*>(ctrl + reinterpret_cast<uintptr_t>(f.prog_off));
+    if (f.slices) f.slices = reinterpret_cast<const float2*>(ctrl + reinterpret_cast<uintptr_t>(f.slices));
+    if (f.rm_ops) f.rm_ops = reinterpret_cast<const uint4*>(ctrl + reinterpret_cast<uintptr_t>(f.rm_ops));
+    if (f.rm_prog_off) f.rm_prog_off = reinterpret_cast<const uint32_t*>(ctrl + reinterpret_cast<uintptr_t>(f.rm_prog_off));
+    return f;
+}
+
+__global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
-    const PoseFrameDev f = jobs[b.x].f;
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     pose_sample_body(f, b.y, b.z, b.w);
 }
 
@@ -556,9 +570,9 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
 template <uint32_t BLOCK>
 __global__ __launch_bounds__(BLOCK) void pose_sample_crowd_kernel(PoseFrameDev f, CtrlInline inl) { pose_sample_crowd_body<BLOCK>(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y, blockIdx.z); }
 
-__global__ __launch_bounds__(64) void pose_sample_crowd_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+__global__ __launch_bounds__(64) void pose_sample_crowd_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
-    const PoseFrameDev f = jobs[b.x].f;
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     pose_sample_crowd_body<64>(f, b.y, b.z, b.w);
 }
 
@@ -768,14 +782,14 @@ __device__ __forceinline__ void root_motion_fold_body(const PoseFrameDev& f, uin
 __global__ __launch_bounds__(256) void root_motion_kernel(PoseFrameDev f, CtrlInline inl) { root_motion_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(64) void root_motion_fold_kernel(PoseFrameDev f, CtrlInline inl) { root_motion_fold_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x); }
 
-__global__ __launch_bounds__(256) void root_motion_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+__global__ __launch_bounds__(256) void root_motion_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];          // {job, block of the job, blocks of the job, -}
-    const PoseFrameDev f = jobs[b.x].f;
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     root_motion_body(f, b.y, b.z);
 }
-__global__ __launch_bounds__(64) void root_motion_fold_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+__global__ __launch_bounds__(64) void root_motion_fold_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
-    const PoseFrameDev f = jobs[b.x].f;
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     root_motion_fold_body(f, b.y);
 }
 
@@ -1002,9 +1016,9 @@ __device__ __forceinline__ void property_sample_body(const PoseFrameDev& f, uint
 }
 
 __global__ __launch_bounds__(256) void property_sample_kernel(PoseFrameDev f, CtrlInline inl) { property_sample_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y, blockIdx.z); }
-__global__ __launch_bounds__(256) void property_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+__global__ __launch_bounds__(256) void property_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
-    const PoseFrameDev f = jobs[b.x].f;
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     property_sample_body(f, b.y, b.z, b.w);
 }
 
@@ -1142,9 +1156,9 @@ __device__ __forceinline__ void property_update_body(const PoseFrameDev& f, uint
 }
 
 __global__ __launch_bounds__(64) void property_update_kernel(PoseFrameDev f, CtrlInline inl) { property_update_body(ctrl_resolve<kInlAfterFrame>(f, inl), blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(64) void property_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+__global__ __launch_bounds__(64) void property_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
-    const PoseFrameDev f = jobs[b.x].f;
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     property_update_body(f, b.y, b.z);
 }
 
@@ -1595,9 +1609,9 @@ __global__ __launch_bounds__(64 * PACK) void pose_update_pack_kernel(PoseFrameDe
 
 // Scene form: every job of one launch has the same block size; the dynamic LDS is sized for the largest rig among them.
 template <int MODE>
-__global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const uint4* __restrict__ blocks) {
+__global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
-    const PoseFrameDev f = jobs[b.x].f;
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     RigDev rig = jobs[b.x].rig;
     pose_update_body<MODE>(f, rig, b.y, 0u, jobs[b.x].rig.pal);
 }
@@ -1735,10 +1749,10 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[
     }
 }
 
-hipError_t launch_scene(const SceneJobDev* d_jobs, const uint4* const (&d_tables)[kSceneStages],
+hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uint4* const (&d_tables)[kSceneStages],
                         const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, hipStream_t s) {
     auto go = [&](int stage, auto kernel, uint32_t block, size_t lds) {
-        if (n_blocks[stage]) hipLaunchKernelGGL(kernel, dim3(n_blocks[stage]), dim3(block), lds, s, d_jobs, d_tables[stage]);
+        if (n_blocks[stage]) hipLaunchKernelGGL(kernel, dim3(n_blocks[stage]), dim3(block), lds, s, d_jobs, d_ctrl, d_tables[stage]);
     };
     go(kStageSample, pose_sample_scene_kernel, 256, 0);
     go(kStageSampleCrowd, pose_sample_crowd_scene_kernel, 64, 0);

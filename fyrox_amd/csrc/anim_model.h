@@ -234,6 +234,9 @@ struct SceneBatch {
     uint32_t n_blocks[kSceneStages] = {};
     size_t lds_bytes[kSceneStages] = {};
     CtrlBuffers ctrl;
+    std::vector<char> h_jobs, sent_jobs;   // this frame's job array / the one the device holds (d_jobs)
+    char* d_jobs = nullptr;
+    size_t d_jobs_capacity = 0;
     std::vector<Animator*> animators;   // scratch of the current call
     std::vector<CtrlLayout> layouts;
     std::vector<size_t> offsets;

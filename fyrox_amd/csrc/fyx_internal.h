@@ -352,8 +352,10 @@ struct alignas(16) CtrlInline {
 };
 static_assert(sizeof(CtrlInline) == 16 + kCtrlInlineBytes, "header + payload");
 
-// fyx_scene_update: one parameter block per animator of the scene, rewritten every frame (it points into the frame's
-// control block) and read by the *_scene_kernel forms, whose block tables say which job a block works for.
+// fyx_scene_update: one parameter block per animator of the scene, read by the *_scene_kernel forms, whose block tables say which
+// job a block works for.  Its control pointers are OFFSETS into the frame's control block (the kernels get the block's address
+// beside the array), so the array itself stays on the device from frame to frame and is sent again only when its bytes change:
+// an animator's device state or palette outputs moved, or a fold program changed its length.
 struct SceneJobDev {
     PoseFrameDev f;
     RigDev rig;
@@ -384,7 +386,7 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&tab
 // LDS of the update stages (the largest rig of the stage).
 // all_straight: every fold program of every job is straight (classify_fold_program, anim_leaves.h): the update stages run
 // the kernel form without the interpreter.
-hipError_t launch_scene(const SceneJobDev* d_jobs, const uint4* const (&d_tables)[kSceneStages],
+hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uint4* const (&d_tables)[kSceneStages],
                         const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, hipStream_t s);
 
 // `inl` (optional): the frame's control block travelling in the kernel arguments, see CtrlInline.
