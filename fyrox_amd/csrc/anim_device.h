@@ -501,18 +501,23 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         if (int rc = ensure_device_state(c, A)) return rc;
         sig.push_back(((uint64_t)A.anims.size() << 32) | A.n_instances);
         sig.push_back(((uint64_t)A.rig->n_nodes << 32) | A.dev_prop_slots);
-        sig.push_back(A.rm_enabled ? 1 : 0);
+        sig.push_back(((uint64_t)A.rig->n_chunks << 1) | (A.rm_enabled ? 1 : 0));
     }
     if (sig != S.signature) {
         std::vector<uint4> tables[kSceneStages];
         size_t lds[kSceneStages] = {};
+        size_t wide256 = 0;
         for (size_t k = 0; k < n; ++k) {
             const Animator& A = *S.animators[k];
             const SceneJobShape sh = scene_shape(c, A, A.dev_prop_slots);
             scene_blocks((uint32_t)k, sh, tables);
             const int stage = kStageUpdate64 + (int)update_block_waves(sh.n_nodes, sh.n_instances) - 1;
             lds[stage] = std::max(lds[stage], (size_t)sh.n_nodes * 32 * sizeof(float));
+            if (stage == kStageUpdate256) wide256 = std::max(wide256, wide_update_lds(sh.n_nodes, A.rig->n_chunks));
         }
+        // the 256-thread updates walk the hierarchy wide (a lane per matrix element) when every rig's chunk table fits the LDS
+        S.wide_update = wide256 > 0 && wide256 <= kLdsPerWorkgroup;
+        if (S.wide_update) lds[kStageUpdate256] = wide256;
         size_t total = 0;
         for (int k = 0; k < kSceneStages; ++k) {
             if (tables[k].size() > 0x7fffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "scene too large for one launch per stage");
@@ -577,7 +582,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
     bool all_straight = c->upd_lean != 0;
     for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
-    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs), d, tabs, S.n_blocks, S.lds_bytes, all_straight, ps));
+    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs), d, tabs, S.n_blocks, S.lds_bytes, all_straight, S.wide_update, ps));
     if (int rc = ctrl_consumed(c, S.ctrl, slot, ps)) return rc;
     return exit_pose(c);
 }

@@ -1608,12 +1608,12 @@ __global__ __launch_bounds__(64 * PACK) void pose_update_pack_kernel(PoseFrameDe
 }
 
 // Scene form: every job of one launch has the same block size; the dynamic LDS is sized for the largest rig among them.
-template <int MODE>
+template <int MODE, bool WIDE = false>
 __global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
     const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     RigDev rig = jobs[b.x].rig;
-    pose_update_body<MODE>(f, rig, b.y, 0u, jobs[b.x].rig.pal);
+    pose_update_body<MODE, 1, false, WIDE>(f, rig, b.y, 0u, jobs[b.x].rig.pal);
 }
 
 template <typename K, typename... Args>
@@ -1750,7 +1750,7 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[
 }
 
 hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uint4* const (&d_tables)[kSceneStages],
-                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, hipStream_t s) {
+                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, bool wide256, hipStream_t s) {
     auto go = [&](int stage, auto kernel, uint32_t block, size_t lds) {
         if (n_blocks[stage]) hipLaunchKernelGGL(kernel, dim3(n_blocks[stage]), dim3(block), lds, s, d_jobs, d_ctrl, d_tables[stage]);
     };
@@ -1759,18 +1759,21 @@ hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uin
     go(kStagePropSample, property_sample_scene_kernel, 256, 0);
     go(kStageRootMotion, root_motion_scene_kernel, 256, 0);
     go(kStageRootMotionFold, root_motion_fold_scene_kernel, 64, 0);
-    size_t max_lds = 0;
-    for (int k = kStageUpdate64; k <= kStageUpdate256; ++k)
-        if (n_blocks[k]) max_lds = std::max(max_lds, lds_bytes[k]);
-    if (max_lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(all_straight ? reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdStraight>)
-                                                        : reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdGeneral>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
-        if (e != hipSuccess) return e;
-    }
+    auto big_lds = [&](const void* kernel, size_t lds) -> hipError_t {
+        return lds > 64 * 1024 ? hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
+    };
     for (int k = kStageUpdate64; k <= kStageUpdate256; ++k) {
-        if (all_straight) go(k, pose_update_scene_kernel<kUpdStraight>, 64u * (uint32_t)(k - kStageUpdate64 + 1), lds_bytes[k]);
-        else go(k, pose_update_scene_kernel<kUpdGeneral>, 64u * (uint32_t)(k - kStageUpdate64 + 1), lds_bytes[k]);
+        if (!n_blocks[k]) continue;
+        const uint32_t block = 64u * (uint32_t)(k - kStageUpdate64 + 1);
+        hipError_t e = hipSuccess;
+        if (k == kStageUpdate256 && wide256) {     // (the stage's LDS was sized for the wide walk's tables by the caller)
+            if (all_straight) { e = big_lds(reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdStraight, true>), lds_bytes[k]); if (e == hipSuccess) go(k, pose_update_scene_kernel<kUpdStraight, true>, block, lds_bytes[k]); }
+            else { e = big_lds(reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdGeneral, true>), lds_bytes[k]); if (e == hipSuccess) go(k, pose_update_scene_kernel<kUpdGeneral, true>, block, lds_bytes[k]); }
+        } else {
+            if (all_straight) { e = big_lds(reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdStraight>), lds_bytes[k]); if (e == hipSuccess) go(k, pose_update_scene_kernel<kUpdStraight>, block, lds_bytes[k]); }
+            else { e = big_lds(reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdGeneral>), lds_bytes[k]); if (e == hipSuccess) go(k, pose_update_scene_kernel<kUpdGeneral>, block, lds_bytes[k]); }
+        }
+        if (e != hipSuccess) return e;
     }
     go(kStagePropUpdate, property_update_scene_kernel, 64, 0);
     return hipGetLastError();

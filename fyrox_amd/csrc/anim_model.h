@@ -233,6 +233,7 @@ struct SceneBatch {
     size_t table_off[kSceneStages] = {};
     uint32_t n_blocks[kSceneStages] = {};
     size_t lds_bytes[kSceneStages] = {};
+    bool wide_update = false;              // the 256-thread update stage runs the wide hierarchy walk (its LDS is sized for it)
     CtrlBuffers ctrl;
     std::vector<char> h_jobs, sent_jobs;   // this frame's job array / the one the device holds (d_jobs)
     char* d_jobs = nullptr;

@@ -67,6 +67,7 @@ struct fyx_ctx {
     hipStream_t stream = nullptr;
     fyx::LbsTuning lbs;
     std::unordered_map<uint64_t, Mesh> meshes;
+    uint64_t mesh_gen = 0;   // bumped by everything that changes a mesh record (cached batch plans are made from them)
     std::string err = "";
     // scratch: staging for host-variant calls, grown on demand
     void* scratch = nullptr;

@@ -387,7 +387,7 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&tab
 // all_straight: every fold program of every job is straight (classify_fold_program, anim_leaves.h): the update stages run
 // the kernel form without the interpreter.
 hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uint4* const (&d_tables)[kSceneStages],
-                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, hipStream_t s);
+                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, bool wide256, hipStream_t s);
 
 // `inl` (optional): the frame's control block travelling in the kernel arguments, see CtrlInline.
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);

@@ -62,7 +62,7 @@ def test_exact_skinning_kernels_contain_no_contracted_multiply_add(stats):
 def test_pose_and_palette_kernels_contain_no_contracted_multiply_add(stats):
     """Always exact: sampling (sinf / cosf of Euler tracks bring their own polynomial FMAs: <= 1e-5 by contract, see
     DESIGN 2), the fold interpreter (nlerp: one sqrt and four divisions per blend), hierarchy, palettes, AABBs."""
-    exact_everywhere = ("fyx::pose_update_kernel", "fyx::pose_update_scene_kernel", "fyx::property_update_kernel",
+    exact_everywhere = ("fyx::pose_update_kernel", "fyx::pose_update_scene_kernel", "fyx::pose_update_inl_kernel", "fyx::pose_update_pack_kernel", "fyx::property_update_kernel",
                         "fyx::property_update_scene_kernel", "fyx::root_motion_fold_kernel", "fyx::root_motion_fold_scene_kernel",
                         "fyx::palette_kernel", "fyx::palette_gather_kernel", "fyx::skinned_aabb_kernel", "fyx::skinned_aabb_inst_kernel",
                         "fyx::points_aabb_kernel", "fyx::aabb_final_kernel", "fyx::aabb_final_inst_kernel", "fyx::blend_shape_weights_kernel")
@@ -100,7 +100,8 @@ def test_register_budgets_behind_the_measured_occupancies():
               "fyx::lbs_skin_crowd<512, true, 7, true>": 80,
               # the update kernel without the interpreter (every program of the frame straight): three waves per SIMD, and one of
               # them fits into what ONE retiring workgroup of the crowd kernel frees on a SIMD (2 x 128) -- anim.overlap
-              "fyx::pose_update_kernel<2>": 176, "fyx::pose_update_scene_kernel<2>": 176, "fyx::pose_update_inl_kernel<2>": 176, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel<256u>": 64, "fyx::pose_sample_crowd_kernel<64u>": 64}
+              "fyx::pose_update_kernel<2>": 176, "fyx::pose_update_scene_kernel<2, false>": 176, "fyx::pose_update_scene_kernel<2, true>": 176, "fyx::pose_update_inl_kernel<2>": 176,
+              "fyx::pose_update_pack_kernel<2, 4>": 176, "fyx::pose_frame_inl_kernel<2>": 176, "fyx::pose_sample_kernel": 64, "fyx::pose_sample_crowd_kernel<256u>": 64, "fyx::pose_sample_crowd_kernel<64u>": 64}
     for name, limit in budget.items():
         assert name in res, name
         assert res[name]["vgpr"] + res[name]["agpr"] <= limit, (name, res[name])

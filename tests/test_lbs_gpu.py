@@ -1068,6 +1068,53 @@ def test_batch_with_different_output_sets_and_repeated_calls(ctx, orc):
     assert np.array_equal(one.download(np.uint32, 2500 * 3), o["pos"].download(np.uint32, 2500 * 3))
 
 
+def test_batch_plan_is_reused_only_while_nothing_it_was_made_from_changed(ctx, orc):
+    """The same job array again (a scene's frame) takes the previous call's plan and device tables.  What must still come out right:
+    new palette CONTENTS behind the same pointers; a mesh uploaded again under the same id (other vertices, other device buffers);
+    a launch option changed; another batch (its tables replace the cached ones) in between."""
+    ALL3 = ("pos", "normal", "tangent")
+    specs = [(3000, 32, 1, ALL3), (1200, 16, 2, ALL3), (65, 8, 1, ALL3), (4000, 64, 1, ALL3)]
+    scene = _batch_scene(ctx, 7700, specs, synth.SEED_BASE + 420)
+    jobs = _batch_jobs(7700, specs, scene)
+    for _ in range(3):
+        ctx.lbs_skin_batch(jobs)
+    ctx.sync()
+    _check_batch(ctx, orc, specs, scene, True)
+    # 1. other palette values, same buffers
+    scene1 = []
+    for k, ((nv, nb, ni, want), (m, pal, dp, o)) in enumerate(zip(specs, scene)):
+        pal2 = synth.make_palette(nb, synth.SEED_BASE + 900 + k, n_instances=ni)
+        ctx.sync()
+        dp.upload(pal2)
+        scene1.append((m, pal2, dp, o))
+    ctx.lbs_skin_batch(jobs)
+    ctx.sync()
+    _check_batch(ctx, orc, specs, scene1, True)
+    # 2. mesh 7702 again with other vertices (same size): the cached plan holds the OLD buffers
+    m2 = synth.make_mesh(65, 8, synth.SEED_BASE + 950)
+    ctx.mesh_upload_soa(7702, m2.pos, m2.weights, m2.indices, m2.normal, m2.tangent)
+    scene2 = list(scene1)
+    scene2[2] = (m2, scene1[2][1], scene1[2][2], scene1[2][3])
+    ctx.lbs_skin_batch(jobs)
+    ctx.sync()
+    _check_batch(ctx, orc, specs, scene2, True)
+    # 3. another batch in between, and an option that changes the grid
+    specs3 = [(500, 12, 1, ALL3)]
+    scene3 = _batch_scene(ctx, 7750, specs3, synth.SEED_BASE + 470)
+    ctx.lbs_skin_batch(_batch_jobs(7750, specs3, scene3))
+    ctx.lbs_skin_batch(jobs)
+    before = ctx.get_option("lbs.blocks_per_cu")
+    ctx.set_option("lbs.blocks_per_cu", 1)
+    try:
+        ctx.lbs_skin_batch(jobs)
+        ctx.lbs_skin_batch(jobs)
+    finally:
+        ctx.set_option("lbs.blocks_per_cu", before)
+    ctx.sync()
+    _check_batch(ctx, orc, specs3, scene3, True)
+    _check_batch(ctx, orc, specs, scene2, True)
+
+
 def test_batch_argument_errors_launch_nothing(ctx):
     specs = [(500, 16, 1, ("pos",)), (500, 16, 1, ("pos",))]
     scene = _batch_scene(ctx, 7500, specs, synth.SEED_BASE + 380)
