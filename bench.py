@@ -774,7 +774,7 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    opt_keys = ("lbs.blocks_per_cu", "lbs.exact", "lbs.streams", "lbs.dyn", "lbs.crowd", "anim.inline_ctrl", "anim.ctrl_upload", "anim.update_lean", "anim.update_pack",
+    opt_keys = ("lbs.blocks_per_cu", "lbs.exact", "lbs.streams", "lbs.dyn", "lbs.crowd", "anim.inline_ctrl", "anim.ctrl_upload", "anim.update_lean", "anim.update_pack", "anim.one_launch",
                 "streams.priority", "comm.form")
     opts = {k: ctx.get_option(k) for k in opt_keys}
     n_ranks_rccl, comm_error = None, None

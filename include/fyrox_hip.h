@@ -97,6 +97,11 @@ int fyx_join(fyx_ctx* ctx);
  *     "anim.update_lean" 1 (default) = a frame whose fold programs are ALL straight (a few clips blended in a row: the common
  *                        machines; the host classifies with the kernel's own function) runs the update kernel built without the
  *                        fold interpreter: a third of the registers, so its waves fit beside a running skinning kernel
+ *     "anim.one_launch"  1 (default) = an animator whose control block fits the kernel arguments (one character, a few instances)
+ *                        and that tracks neither root motion nor property values runs its sampler and its update as ONE launch:
+ *                        the update's workgroups lie behind the sampler's in the same grid and wait on a device counter the
+ *                        sampler's workgroups add to (workgroups are dispatched in index order: the waiting one never holds a
+ *                        place a sampler needs).  0 = two launches.  Same results bit for bit
  *     "anim.update_pack" 4 (default), 2 or 0: a crowd (>= 64 instances) of a rig of at most 64 nodes runs that lean update kernel
  *                        with this many instances per workgroup (one wave each, nothing shared): beside a crowd's skinning the
  *                        four waves take ONE of the places a skinning workgroup leaves instead of up to four (C3 frame 0.0979
