@@ -1392,8 +1392,16 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         if constexpr (WAIT) {
             // one-launch frame: the sampler's workgroups run in this grid too; everything above was requested without them
             if (node_base == 0) {
-                if (threadIdx.x == 0)
-                    while ((int32_t)(__hip_atomic_load(wait->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait->target) < 0) __builtin_amdgcn_s_sleep(1);
+                if (threadIdx.x == 0) {
+                    // (bounded: ~0.5 s of the 100 MHz clock.  The samplers of this grid were dispatched before this workgroup and take
+                    // microseconds; should the counter ever be short -- a word of it overwritten from outside -- the frame computes from
+                    // what is in memory instead of holding the GPU for ever)
+                    const uint64_t t0 = wall_clock64();
+                    while ((int32_t)(__hip_atomic_load(wait->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait->target) < 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (wall_clock64() - t0 > 50000000ull) break;
+                    }
+                }
                 __syncthreads();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the records are read behind this, from where the samplers put them
             }
@@ -1655,13 +1663,14 @@ hipError_t launch_pose_frame(const PoseFrameDev& f, const RigDev& rig, int mode,
     fs.sy = f.n_instances;
     fs.n_sample_blocks = fs.sx * fs.sy * f.n_anims;
     fs.pad = 0;
-    *counter_total += fs.n_sample_blocks;
-    fs.target = *counter_total;
+    fs.target = *counter_total + fs.n_sample_blocks;
     const size_t lds = wide_walk_lds(rig);
     const uint32_t grid = fs.n_sample_blocks + f.n_instances;
     // (first_ops of instance 0 only: pose_update_body looks at it for inst == 0)
-    if (mode == kUpdStraight) return launch_update_one(pose_frame_inl_kernel<kUpdStraight>, grid, 256u, lds, s, f, rig, inl, fs);
-    return launch_update_one(pose_frame_inl_kernel<kUpdGeneral>, grid, 256u, lds, s, f, rig, inl, fs);
+    const hipError_t e = mode == kUpdStraight ? launch_update_one(pose_frame_inl_kernel<kUpdStraight>, grid, 256u, lds, s, f, rig, inl, fs)
+                                              : launch_update_one(pose_frame_inl_kernel<kUpdGeneral>, grid, 256u, lds, s, f, rig, inl, fs);
+    if (e == hipSuccess) *counter_total = fs.target;      // a launch that was refused adds nothing to the counter
+    return e;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -137,7 +137,8 @@ int fyx_debug_kernel_time(fyx_ctx* ctx, double* total_us, uint32_t* n_launches);
 /* Measurement aid (option "debug.timeline" = 1): the pose_sample / pose_update launches of fyx_*_update and every
  * fyx_lbs_skin_device launch carry their own start / stop events.  Waits for the work in flight, writes up to `capacity`
  * records {kind: 0 skinning, 1 pose_sample, 2 pose_update, 3 control-block copy kernel; start / stop in microseconds after the first record's start} in
- * launch order, returns their number and starts over -- which kernels of a pipelined frame really ran beside which.
+ * launch order, returns their number and starts over -- which kernels of a pipelined frame really ran beside which.  (A frame that
+ * runs as ONE launch, option "anim.one_launch", has no record of kind 1: its sampler is inside the kind-2 launch.)
  * At most 16384 launches between two calls.  Replaces nothing in the reference. */
 int fyx_debug_timeline(fyx_ctx* ctx, int32_t* kinds, double* start_us, double* stop_us, uint32_t capacity, uint32_t* n_records);
 int fyx_get_option(fyx_ctx* ctx, const char* key, int* value);
