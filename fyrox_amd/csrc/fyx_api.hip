@@ -4,6 +4,16 @@
 #include "fyx_ctx.h"
 
 namespace fyx {
+// Events that only order one stream of this device behind another (hipStreamWaitEvent): no host reads memory on their word, so
+// their release need not be a system-scope one (which writes the L2 back and invalidates it under whatever kernel is running).
+// FYX_EVENT_SCOPE=system restores the runtime's default for an A/B.
+static unsigned order_event_flags() {
+    static const unsigned flags = [] {
+        const char* e = getenv("FYX_EVENT_SCOPE");
+        return (e && !strcmp(e, "system")) ? (unsigned)hipEventDisableTiming : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+    }();
+    return flags;
+}
 
 int fail(fyx_ctx* c, int code, const char* fmt, ...) {
     if (c) {
@@ -75,14 +85,14 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
     c->frame_idx = idx;
     if (!c->alt_stream) {
         FYX_HIP(c, make_stream(c, true, &c->alt_stream));
-        FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, hipEventDisableTiming));
-        for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->pose_done[k], hipEventDisableTiming));
+        FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, order_event_flags()));
+        for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->pose_done[k], order_event_flags()));
     }
     hipStream_t target = idx ? c->alt_stream : c->stream;
     if (idx) {
         // whatever other calls have put on the context stream since the last fork (uploads, copies, a borrowed stream's work)
         if (c->primary_dirty || c->stream != c->own_stream) {
-            if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+            if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, order_event_flags()));
             FYX_HIP(c, hipEventRecord(c->fork_ev, c->stream));
             ++c->fork_gen;
             c->primary_dirty = false;
@@ -191,9 +201,9 @@ int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
     c->next_worker = (w + 1) % c->n_workers;
     if (!c->workers[w]) {
         FYX_HIP(c, make_stream(c, false, &c->workers[w]));
-        if (!c->worker_done[w]) FYX_HIP(c, hipEventCreateWithFlags(&c->worker_done[w], hipEventDisableTiming));
+        if (!c->worker_done[w]) FYX_HIP(c, hipEventCreateWithFlags(&c->worker_done[w], order_event_flags()));
     }
-    if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, order_event_flags()));
     if (c->primary_dirty || c->stream != c->own_stream) {  // a borrowed stream may have foreign work
         FYX_HIP(c, hipEventRecord(c->fork_ev, c->stream));
         ++c->fork_gen;
@@ -245,7 +255,7 @@ int ctrl_acquire(fyx_ctx* c, CtrlBuffers& B, size_t total, int* slot_out, char**
         B.d_bytes[slot] = want;
         B.d_in_use[slot] = false;
     }
-    if (!B.d_consumed[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.d_consumed[slot], hipEventDisableTiming));
+    if (!B.d_consumed[slot]) FYX_HIP(c, hipEventCreateWithFlags(&B.d_consumed[slot], order_event_flags()));
     *slot_out = slot;
     *h = static_cast<char*>(B.h[slot]);
     *d = static_cast<char*>(B.d[slot]);
