@@ -969,6 +969,82 @@ def test_scene_update_writes_registered_palettes_and_feeds_skinning(ctx, orc):
             check(got[i], ref, not sc.has_euler, f"{sc.name} palette (instance {i})")
 
 
+@pytest.mark.parametrize("make", [cases.c5_blend_tree, cases.player_only, cases.transitions, cases.layered], ids=lambda f: f.__name__)
+def test_frame_forms_switched_between_frames(ctx, orc, make):
+    """One character's frame has three forms -- sampler and update in one launch (anim.one_launch), two launches with the control block
+    in the kernel arguments, two launches with the block uploaded (anim.inline_ctrl = 0) -- and the update two kernel forms
+    (anim.update_lean).  Switching between them from frame to frame must be invisible: the one-launch form's device counter only
+    counts its own launches."""
+    sc = make()
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, 2)
+    forms = [(1, 1, 1), (0, 1, 1), (1, 1, 0), (0, 0, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1), (0, 1, 0)]
+    try:
+        for f in range(24):
+            one, inline, lean = forms[f % len(forms)]
+            ctx.set_option("anim.one_launch", one)
+            ctx.set_option("anim.inline_ctrl", inline)
+            ctx.set_option("anim.update_lean", lean)
+            for idx, par in sc.script.get(f, []):
+                o.set_parameter(idx, par)
+                p.set_parameter(idx, par)
+            if sc.machine is None:
+                o.update_animations(sc.dt)
+                p.update_animations(sc.dt)
+            else:
+                o.update_machine(sc.dt)
+                p.update_machine(sc.dt)
+            check_frame(p, o, sc, 2, f)
+    finally:
+        ctx.set_option("anim.one_launch", 1)
+        ctx.set_option("anim.inline_ctrl", 1)
+        ctx.set_option("anim.update_lean", 1)
+    o.close()
+    p.free()
+
+
+def test_scene_job_array_follows_what_changes_between_frames(ctx, orc):
+    """fyx_scene_update keeps its per-animator job records on the device and sends them again only when their bytes change.  What
+    changes here between frames: a palette output moved to another buffer, the list of animators reordered and shortened, an
+    animator given another machine state (its fold program changes length).  Palettes against the oracle after every frame."""
+    specs = [(cases.c5_blend_tree(euler_every=10 ** 6), 1), (cases.transitions(), 2), (cases.by_index(), 1), (cases.player_only(euler_every=10 ** 6), 3)]
+    os_ = [cases.build_oracle(orc, sc) for sc, _ in specs]
+    ps = [cases.build_product(ctx, sc, n) for sc, n in specs]
+    bufs = []
+    for k, ((sc, n), p) in enumerate(zip(specs, ps)):
+        bones = list(range(sc.rig.n_nodes))
+        A.create_bone_list(ctx, 9300 + k, p.base_id, bones)
+        pair = [ctx.malloc(n * len(bones) * 64), ctx.malloc(n * len(bones) * 64)]
+        p.set_palette_output(9300 + k, pair[0].ptr)
+        bufs.append((bones, pair))
+    orders = [[0, 1, 2, 3], [0, 1, 2, 3], [3, 2, 1, 0], [3, 2, 1, 0], [1, 3], [1, 3], [0, 1, 2, 3], [2, 0, 3, 1]]
+    stepped = [0] * len(specs)
+    for f in range(16):
+        order = orders[f % len(orders)]
+        which = (f // 3) % 2                       # the palette buffers move every third frame
+        for k in order:
+            sc, n = specs[k]
+            ps[k].set_palette_output(9300 + k, bufs[k][1][which].ptr)
+            for idx, par in sc.script.get(stepped[k], []):
+                os_[k].set_parameter(idx, par)
+                ps[k].set_parameter(idx, par)
+            os_[k].update_machine(1 / 30) if sc.machine is not None else os_[k].update_animations(1 / 30)
+            stepped[k] += 1
+        A.scene_update(ctx, [ps[k] for k in order], 1 / 30)
+        ctx.sync()
+        for k in order:
+            sc, n = specs[k]
+            bones, pair = bufs[k]
+            got = pair[which].download(np.float32, n * len(bones) * 16).reshape(n, len(bones), 16)
+            ref = os_[k].palette(bones)
+            for i in range(n):
+                check(got[i], ref, True, f"frame {f}: {sc.name} palette (instance {i})")
+    for o in os_:
+        o.close()
+    for p in ps:
+        p.free()
+
+
 def test_scene_update_argument_errors(ctx):
     sc = cases.by_index()
     p = cases.build_product(ctx, sc)
