@@ -4,6 +4,7 @@
 //   kind 1  chase:   every lane follows `hops` dependent 16-byte loads through a 64 MB table (memory latency, like the sampler)
 //   kind 2  scatter: every lane writes 16 bytes to `hops` scattered places (partial lines, like the sampler's record parts)
 //   kind 3  valu:    every lane runs `hops` x 64 dependent v_fma
+//   kind 4  records: like 2, but three adjacent lanes write one contiguous 48-byte record
 // VGPR footprint: template R (registers pinned live across the body).
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/exp/libs/libcorunner.so tools/exp/r04_corunner.hip
 #include <hip/hip_runtime.h>
@@ -27,6 +28,10 @@ __global__ __launch_bounds__(256) void corun(int kind, uint32_t us, uint32_t hop
     } else if (kind == 2) {
         uint32_t p = (gid * 2654435761u) & mask;
         for (uint32_t h = 0; h < hops; ++h) { out[p] = make_uint4(gid, h, 0, 0); p = (p * 1664525u + 1013904223u) & mask; }
+    } else if (kind == 4) {      // records: three adjacent lanes write the three 16-byte parts of one 48-byte record at a scattered place
+        const uint32_t rec = gid / 3u, part = gid % 3u;
+        uint32_t p = ((rec * 2654435761u) & mask) / 3u * 3u;
+        for (uint32_t h = 0; h < hops; ++h) { out[p + part] = make_uint4(gid, h, 0, 0); p = ((p * 1664525u + 1013904223u) & mask) / 3u * 3u; }
     } else {
         float a = keep[0], b = 1.0001f;
         for (uint32_t h = 0; h < hops * 64u; ++h) a = __builtin_fmaf(a, b, 0.5f);

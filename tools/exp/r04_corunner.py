@@ -27,17 +27,10 @@ SK = (ctx._h, ctypes.c_uint64(3), ctypes.c_void_p(pal.ptr), ctypes.c_uint32(64),
 # (name, [(kind, regs, grid, us, hops), ...])
 CONFIGS = [
     ("none", []),
-    ("occupy like the sampler: 3072 x 4 waves of 56 VGPRs sleeping 6 us", [(0, 56, 3072, 6, 0)]),
-    ("occupy like the packed update: 250 x 4 waves of 158 VGPRs sleeping 20 us", [(0, 158, 250, 20, 0)]),
-    ("occupy: 3072 x 4 waves of 32 VGPRs sleeping 6 us", [(0, 32, 3072, 6, 0)]),
-    ("occupy: 3072 x 4 waves of 120 VGPRs sleeping 6 us", [(0, 128, 3072, 6, 0)]),
-    ("chase: 768 x 4 waves of 56 VGPRs, 1 random 16-byte load per lane (197 k lines)", [(1, 56, 768, 0, 1)]),
-    ("chase: 768 x 4 waves, 4 dependent random loads per lane (786 k lines)", [(1, 56, 768, 0, 4)]),
-    ("chase: 3072 x 4 waves, 1 random load per lane (786 k lines, four times the waves)", [(1, 56, 3072, 0, 1)]),
     ("scatter: 3072 x 4 waves, one scattered 16-byte store per lane (786 k partial lines, 12.6 MB)", [(2, 56, 3072, 0, 1)]),
-    ("scatter: 768 x 4 waves, one scattered store per lane (197 k partial lines)", [(2, 56, 768, 0, 1)]),
-    ("valu: 3072 x 4 waves, 256 dependent FMAs per lane (3.1 M wave instructions)", [(3, 56, 3072, 0, 4)]),
-    ("valu: 3072 x 4 waves, 64 dependent FMAs per lane (0.8 M wave instructions)", [(3, 56, 3072, 0, 1)]),
+    ("records: 3072 x 4 waves, three adjacent lanes write one scattered 48-byte record (262 k records, 12.6 MB)", [(4, 56, 3072, 0, 1)]),
+    ("scatter: 1024 x 4 waves, one scattered store per lane (262 k partial lines, 4.2 MB)", [(2, 56, 1024, 0, 1)]),
+    ("occupy: 3072 x 4 waves of 56 VGPRs sleeping 1 us", [(0, 56, 3072, 1, 0)]),
 ]
 ctx.set_option("lbs.timing", 1)
 def run(cos, iters):
