@@ -275,6 +275,9 @@ __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a,
 // ---------------------------------------------------------------------------------------
 // Grid: x = 16-node slices of one instance, y = instance, z = animation -- no index arithmetic beyond shifts
 // (the kernel is VALU-issue bound: ~64 K waves of a few hundred instructions each for the C3 crowd).
+// WRITE_THROUGH: the record is stored with agent-scope (sc1) stores, which go through the XCD's L2 to memory -- for the one-launch frame,
+// whose update workgroups (on other XCDs, each with its own L2) read the records while this kernel is still running.
+template <bool WRITE_THROUGH = false>
 __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
     const uint32_t lane = threadIdx.x & 63u, j = threadIdx.x & 15u, gbase = lane & ~15u;
     const uint32_t a = bz, inst = by;
@@ -321,7 +324,11 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
         else if (j == 6) out = q.z;
         else if (j == 7) out = q.w;
         else out = 0.0f;
-        if (j < 12) reinterpret_cast<float*>(f.anim_pose)[item * 12 + j] = out;
+        if (j < 12) {
+            float* dst = reinterpret_cast<float*>(f.anim_pose) + item * 12 + j;
+            if constexpr (WRITE_THROUGH) __hip_atomic_store(dst, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = out;
+        }
     }
 }
 
@@ -1592,9 +1599,13 @@ __global__ __launch_bounds__(256) void pose_frame_inl_kernel(PoseFrameDev f, Rig
     const PoseFrameDev fr = ctrl_resolve<kInlAfterFrameAndRig>(f, inl);
     if (blockIdx.x < fs.n_sample_blocks) {
         const uint32_t bx = blockIdx.x % fs.sx, t = blockIdx.x / fs.sx;
-        pose_sample_body(fr, bx, t % fs.sy, t / fs.sy);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every thread: its part of the records is visible device-wide ...
-        __syncthreads();                                      // ... before the workgroup reports
+        pose_sample_body<true>(fr, bx, t % fs.sy, t / fs.sy);
+        // Every wave: its part of the records is visible device-wide before the workgroup reports.  The records are the only thing
+        // of this half that the update half reads, and they were stored with agent-scope (write-through) stores: once those are
+        // acknowledged (vmcnt = 0) they are where every XCD finds them, and the L2 write-back an agent-scope release FENCE would
+        // add (buffer_wbl2: ~0.7 us of one character's 9 - 11 us; tools/exp/r04_character_ab.py, call 38) has nothing left to do.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(fs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }

@@ -1003,6 +1003,38 @@ def test_frame_forms_switched_between_frames(ctx, orc, make):
     p.free()
 
 
+def test_one_launch_frames_equal_two_launch_frames_over_many_frames(ctx):
+    """The one-launch frame's update half reads the records its sampler half wrote in the SAME kernel, from other compute units
+    (write-through stores, a device counter, an acquire).  3000 frames of two animators in the same state -- one in each form, a
+    skinning launch behind every update to keep the memory system busy -- palettes bit for bit after every frame: a record read
+    before it had landed would be last frame's."""
+    sc = cases.c5_blend_tree()
+    nb = sc.rig.n_nodes
+    ps, pals = [], []
+    for k in range(2):
+        p = cases.build_product(ctx, sc, 1)
+        A.create_bone_list(ctx, 9500 + k, p.base_id, list(range(nb)))
+        d = ctx.malloc(nb * 64)
+        p.set_palette_output(9500 + k, d.ptr)
+        ps.append(p)
+        pals.append(d)
+    mesh = synth.make_mesh(20_000, nb, synth.SEED_BASE + 9)
+    ctx.mesh_upload_soa(9510, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    outs = (ctx.malloc(20_000 * 12 + 64), ctx.malloc(20_000 * 12 + 64), ctx.malloc(20_000 * 16 + 64))
+    try:
+        for f in range(3000):
+            for k, one in ((0, 1), (1, 0)):
+                ctx.set_option("anim.one_launch", one)
+                ps[k].update_machine(sc.dt)
+                ctx.lbs_skin_device(9510, pals[k].ptr, nb, 1, outs[0].ptr, outs[1].ptr, outs[2].ptr)
+            a, b = pals[0].download(np.uint32, nb * 16), pals[1].download(np.uint32, nb * 16)
+            assert np.array_equal(a, b), f"frame {f}: the one-launch frame differs from the two-launch frame"
+    finally:
+        ctx.set_option("anim.one_launch", 1)
+    for p in ps:
+        p.free()
+
+
 def test_scene_job_array_follows_what_changes_between_frames(ctx, orc):
     """fyx_scene_update keeps its per-animator job records on the device and sends them again only when their bytes change.  What
     changes here between frames: a palette output moved to another buffer, the list of animators reordered and shortened, an

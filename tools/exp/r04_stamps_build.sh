@@ -76,16 +76,18 @@ rep("""        if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      
 """, """        if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      // uniform across the block
         if (time == time && d.present != 0xffffffffu) SSTAMP(1);
 """)
-rep("""        if (j < 12) reinterpret_cast<float*>(f.anim_pose)[item * 12 + j] = out;
-""", """        if (j < 12) reinterpret_cast<float*>(f.anim_pose)[item * 12 + j] = out;
+rep("""            else *dst = out;
+        }
+""", """            else *dst = out;
+        }
         SSTAMP(4);
 """)
-rep("""        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every thread: its part of the records is visible device-wide ...
-        __syncthreads();                                      // ... before the workgroup reports
+rep("""        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(fs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-""", """        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every thread: its part of the records is visible device-wide ...
+""", """        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (blockIdx.x == 0 && threadIdx.x == 0) g_sst[5] = wall_clock64();
-        __syncthreads();                                      // ... before the workgroup reports
+        __syncthreads();
         if (blockIdx.x == 0 && threadIdx.x == 0) g_sst[6] = wall_clock64();
         if (threadIdx.x == 0) { const uint32_t was = __hip_atomic_fetch_add(fs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (blockIdx.x == 0 && was != 0xffffffffu) g_sst[7] = wall_clock64(); }
 """)
