@@ -1117,7 +1117,7 @@ int fyx_animator_set_palette_output(fyx_ctx* c, uint64_t animator_id, uint64_t b
     if (!d_out) return FYX_OK;
     if (v.size() >= (size_t)kMaxPaletteOutputs)
         return fail(c, FYX_ERR_UNSUPPORTED, "at most %d palette outputs per animator (use fyx_animator_palette for more)", kMaxPaletteOutputs);
-    v.push_back(Animator::PaletteOut{bones_id, d_out});
+    v.push_back(Animator::PaletteOut{bones_id, d_out, bit->second.d_bone_nodes, bit->second.n_bones});
     return FYX_OK;
     FYX_GUARD_END(c)
 }

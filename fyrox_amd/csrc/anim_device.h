@@ -353,13 +353,12 @@ void ctrl_bind(const Animator& A, const CtrlLayout& L, const char* d, PoseFrameD
 // The rig's parameters plus the palettes the update kernel writes itself.
 int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
     rd = rig_dev(*A.rig);
-    for (const Animator::PaletteOut& po : A.palette_outputs) {
-        auto bit = store(c).bones.find(po.bones_id);
-        if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu of a palette output was freed", (unsigned long long)po.bones_id);
+    (void)c;
+    for (const Animator::PaletteOut& po : A.palette_outputs) {      // (fyx_bone_list_free refuses a list that is registered here)
         PaletteOutDev& d = rd.pal[rd.n_pal++];
-        d.bone_nodes = bit->second.d_bone_nodes;
+        d.bone_nodes = po.d_bone_nodes;
         d.out = po.d_out;
-        d.n_bones = bit->second.n_bones;
+        d.n_bones = po.n_bones;
         d.pad = 0;
     }
     return FYX_OK;
@@ -551,7 +550,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     int slot = 0;
     char *h = nullptr, *d = nullptr;
     if (int rc = ctrl_acquire(c, S.ctrl, std::max<size_t>(total, 16), &slot, &h, &d)) return rc;
-    S.h_jobs.assign(n * sizeof(SceneJobDev), 0);
+    S.h_jobs.resize(n * sizeof(SceneJobDev));      // (every byte of a job is written below: frame_static and rig_dev start from zeros)
     SceneJobDev* jobs = reinterpret_cast<SceneJobDev*>(S.h_jobs.data());
     for (size_t k = 0; k < n; ++k) {
         const Animator& A = *S.animators[k];

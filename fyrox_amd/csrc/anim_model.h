@@ -197,7 +197,9 @@ struct Animator {
     std::vector<uint4> rm_ops;
     std::vector<uint32_t> rm_prog_off;
     // palettes the update kernel writes itself (fyx_animator_set_palette_output)
-    struct PaletteOut { uint64_t bones_id; float* d_out; };
+    // (d_bone_nodes / n_bones: the registered bone list's, kept here -- a bone list that is a palette output cannot be freed, and a
+    // scene of 256 characters looked each of them up in the store every frame)
+    struct PaletteOut { uint64_t bones_id; float* d_out; const int32_t* d_bone_nodes; uint32_t n_bones; };
     std::vector<PaletteOut> palette_outputs;
     // Property{..} slots: one per distinct (node, property id) any animation of the animator drives
     std::vector<std::pair<int32_t, int32_t>> prop_slots;
