@@ -4,9 +4,11 @@
 #include "fyx_ctx.h"
 
 namespace fyx {
-// Events that only order one stream of this device behind another (hipStreamWaitEvent): no host reads memory on their word, so
-// their release need not be a system-scope one (which writes the L2 back and invalidates it under whatever kernel is running).
-// FYX_EVENT_SCOPE=system restores the runtime's default for an A/B.
+// The events of the pose path -- a frame's pose update done (pose_done), the other frame stream joined (alt_done), a control block
+// consumed -- only order kernels of THIS device that read what kernels of this device wrote: their release need not be a
+// system-scope one (which writes the L2 back and invalidates it under whatever kernel is running).  FYX_EVENT_SCOPE=system restores
+// the runtime's default for an A/B.  The events around the launch streams (worker_done, fork_ev) keep the default: what is ordered
+// behind them may be an RCCL exchange, or kernels that read what other GPUs wrote into this one's memory.
 static unsigned order_event_flags() {
     static const unsigned flags = [] {
         const char* e = getenv("FYX_EVENT_SCOPE");
@@ -92,7 +94,7 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
     if (idx) {
         // whatever other calls have put on the context stream since the last fork (uploads, copies, a borrowed stream's work)
         if (c->primary_dirty || c->stream != c->own_stream) {
-            if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, order_event_flags()));
+            if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
             FYX_HIP(c, hipEventRecord(c->fork_ev, c->stream));
             ++c->fork_gen;
             c->primary_dirty = false;
@@ -201,9 +203,9 @@ int acquire_launch_stream(fyx_ctx* c, hipStream_t* out) {
     c->next_worker = (w + 1) % c->n_workers;
     if (!c->workers[w]) {
         FYX_HIP(c, make_stream(c, false, &c->workers[w]));
-        if (!c->worker_done[w]) FYX_HIP(c, hipEventCreateWithFlags(&c->worker_done[w], order_event_flags()));
+        if (!c->worker_done[w]) FYX_HIP(c, hipEventCreateWithFlags(&c->worker_done[w], hipEventDisableTiming));
     }
-    if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, order_event_flags()));
+    if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     if (c->primary_dirty || c->stream != c->own_stream) {  // a borrowed stream may have foreign work
         FYX_HIP(c, hipEventRecord(c->fork_ev, c->stream));
         ++c->fork_gen;
