@@ -142,6 +142,8 @@ _SIGS = {
     "fyx_animator_update_transforms": (c_int, [_P, c_uint64]),
     "fyx_animator_palette": (c_int, [_P, c_uint64, c_uint64, _P]),
     "fyx_animator_set_palette_output": (c_int, [_P, c_uint64, c_uint64, _P]),
+    "fyx_debug_frame_counter_add": (c_int, [_P, c_uint64, ctypes.c_int32]),
+    "fyx_animator_set_skin_output": (c_int, [_P, c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "fyx_animator_set_local_trs": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, _P]),
     "fyx_animator_read": (c_int, [_P, c_uint64, c_int, _P]),
     "fyx_animator_device_ptr": (c_int, [_P, c_uint64, c_int, POINTER(c_void_p)]),

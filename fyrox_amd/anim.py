@@ -634,6 +634,10 @@ class Animator:
         """The update calls write this palette themselves from now on (d_out = 0 unregisters)."""
         self._check(self._l.fyx_animator_set_palette_output(self._h, self.id, bones_id, d_out or None))
 
+    def set_skin_output(self, bones_id: int, mesh_id: int, d_pos: int = 0, d_normal: int = 0, d_tangent: int = 0) -> None:
+        """Every update of the animator also skins `mesh_id` with the palette output of `bones_id` (all outputs 0: remove)."""
+        self._check(self._l.fyx_animator_set_skin_output(self._h, self.id, bones_id, mesh_id, d_pos or None, d_normal or None, d_tangent or None))
+
     def set_local_trs(self, node: int, trs, first_instance: int = 0) -> None:
         trs = np.ascontiguousarray(trs, dtype=np.float32).reshape(-1, 10)
         self._check(self._l.fyx_animator_set_local_trs(self._h, self.id, node, first_instance, trs.shape[0], _ptr(trs)))

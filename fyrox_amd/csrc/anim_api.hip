@@ -369,6 +369,7 @@ int fyx_animator_create(fyx_ctx* c, uint64_t animator_id, uint64_t rig_id, uint3
     if (store(c).animators.count(animator_id))
         return fail(c, FYX_ERR_INVALID_ARG, "animator %llu already exists", (unsigned long long)animator_id);
     std::unique_ptr<Animator> a(new Animator());
+    a->id = animator_id;
     a->rig_id = rig_id;
     a->rig = &rit->second;
     a->n_instances = n_instances;
@@ -1111,13 +1112,71 @@ int fyx_animator_set_palette_output(fyx_ctx* c, uint64_t animator_id, uint64_t b
     auto& v = A->palette_outputs;
     for (size_t i = 0; i < v.size(); ++i)
         if (v[i].bones_id == bones_id) {
-            if (d_out) v[i].d_out = d_out; else v.erase(v.begin() + (long)i);
+            if (d_out) { v[i].d_out = d_out; return FYX_OK; }
+            v.erase(v.begin() + (long)i);
+            auto& so = A->skin_outputs;       // the skin outputs on this palette go with it
+            for (size_t k = so.size(); k-- > 0;)
+                if (so[k].bones_id == bones_id) so.erase(so.begin() + (long)k);
             return FYX_OK;
         }
     if (!d_out) return FYX_OK;
     if (v.size() >= (size_t)kMaxPaletteOutputs)
         return fail(c, FYX_ERR_UNSUPPORTED, "at most %d palette outputs per animator (use fyx_animator_palette for more)", kMaxPaletteOutputs);
     v.push_back(Animator::PaletteOut{bones_id, d_out, bit->second.d_bone_nodes, bit->second.n_bones});
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_set_skin_output(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, uint64_t mesh_id, float* d_out_pos, float* d_out_normal,
+                                 float* d_out_tangent) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR_RO(c, A, animator_id);
+    auto& v = A->skin_outputs;
+    size_t at = v.size();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].bones_id == bones_id && v[i].mesh_id == mesh_id) at = i;
+    if (!d_out_pos && !d_out_normal && !d_out_tangent) {      // remove
+        if (at < v.size()) v.erase(v.begin() + (long)at);
+        return FYX_OK;
+    }
+    const Animator::PaletteOut* po = nullptr;
+    for (const Animator::PaletteOut& p : A->palette_outputs)
+        if (p.bones_id == bones_id) po = &p;
+    if (!po) return fail(c, FYX_ERR_INVALID_ARG, "bone list %llu is not a palette output of animator %llu (fyx_animator_set_palette_output first: the skin output uses that palette)",
+                         (unsigned long long)bones_id, (unsigned long long)animator_id);
+    if ((reinterpret_cast<uintptr_t>(d_out_pos) | reinterpret_cast<uintptr_t>(d_out_normal)) & 3u || reinterpret_cast<uintptr_t>(d_out_tangent) & 15u)
+        return fail(c, FYX_ERR_INVALID_ARG, "skin outputs must be 4-byte (position, normal) / 16-byte (tangent) aligned");
+    if (has_device(c)) {      // what fyx_lbs_skin_device would refuse is refused here, not in the middle of a frame
+        LbsArgs a;
+        if (int rc = skin_args_of(c, mesh_id, po->d_out, po->n_bones, A->n_instances, d_out_pos, d_out_normal, d_out_tangent, &a)) return rc;
+    }
+    if (at == v.size()) {
+        if (v.size() >= (size_t)kMaxFrameSkins)
+            return fail(c, FYX_ERR_UNSUPPORTED, "at most %d skin outputs per animator (skin the others with fyx_lbs_skin_device / fyx_lbs_skin_batch)", kMaxFrameSkins);
+        v.push_back(Animator::SkinOut{bones_id, mesh_id, d_out_pos, d_out_normal, d_out_tangent});
+    } else {
+        v[at] = Animator::SkinOut{bones_id, mesh_id, d_out_pos, d_out_normal, d_out_tangent};
+    }
+    return FYX_OK;
+    FYX_GUARD_END(c)
+}
+
+int fyx_debug_frame_counter_add(fyx_ctx* c, uint64_t animator_id, int32_t delta) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    FYX_ANIMATOR_RO(c, A, animator_id);
+    if (!has_device(c)) return fail(c, FYX_ERR_NO_DEVICE, "control-only context");
+    if (int rc = sync_all(c)) return rc;
+    if (int rc = ensure_device_state(c, *A)) return rc;
+    if (!A->d_frame_counter) return fail(c, FYX_ERR_INVALID_ARG, "the animator has not run a one-launch frame yet");
+    for (uint32_t r = 0; r < kFrameCounterReplicas; ++r) {
+        uint32_t* w = A->d_frame_counter + (size_t)r * (kFrameCounterStride / 4u);
+        uint32_t v = 0;
+        FYX_HIP(c, hipMemcpy(&v, w, 4, hipMemcpyDeviceToHost));
+        v += (uint32_t)delta;
+        FYX_HIP(c, hipMemcpy(w, &v, 4, hipMemcpyHostToDevice));
+    }
     return FYX_OK;
     FYX_GUARD_END(c)
 }

@@ -25,11 +25,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
     const Rig& rig = *A.rig;
     const size_t in = (size_t)A.n_instances * rig.n_nodes;
     if (!A.d_node_trs) {
-        // (+ one word behind the records: the counter of one-launch frames, FrameSync)
-        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_node_trs), in * 48 + 16));
-        A.d_frame_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(A.d_node_trs) + in * 48);
-        A.frame_counter_total = 0;
-        FYX_HIP(c, hipMemsetAsync(A.d_frame_counter, 0, 16, c->stream));
+        FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_node_trs), std::max<size_t>(in * 48, 16)));
         FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_local), std::max<size_t>(in * 64, 16)));
         FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_global), std::max<size_t>(in * 64, 16)));
         for (uint32_t i = 0; i < A.n_instances; ++i)  // every instance starts from the rig's transforms
@@ -364,6 +360,72 @@ int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
     return FYX_OK;
 }
 
+// The skinning launches of the animator's skin outputs (fyx_animator_set_skin_output): mesh and palette looked up now -- a mesh may
+// have been uploaded again, a palette output moved -- and validated as fyx_lbs_skin_device validates its arguments.
+int skin_output_args(fyx_ctx* c, const Animator& A, LbsArgs (&out)[kMaxFrameSkins]) {
+    uint32_t k = 0;
+    for (const Animator::SkinOut& so : A.skin_outputs) {
+        const Animator::PaletteOut* po = nullptr;
+        for (const Animator::PaletteOut& p : A.palette_outputs)
+            if (p.bones_id == so.bones_id) po = &p;
+        if (!po) return fail(c, FYX_ERR_INVALID_ARG, "skin output of mesh %llu: bone list %llu is no longer a palette output of the animator",
+                             (unsigned long long)so.mesh_id, (unsigned long long)so.bones_id);
+        if (int rc = skin_args_of(c, so.mesh_id, po->d_out, po->n_bones, A.n_instances, so.d_pos, so.d_nrm, so.d_tan, &out[k])) return rc;
+        ++k;
+    }
+    return FYX_OK;
+}
+
+// Whether (and how) the one-launch frame takes the skinning along: every job's bone list, its mesh streams and its share of the
+// launch's skinning workgroups.  false: the frame skins with launches of its own (a mesh too large for the resident grid).
+bool frame_skin_plan(const fyx_ctx* c, const Animator& A, const LbsArgs* args, uint32_t n, uint32_t max_blocks, FrameSkin& sk) {
+    memset(&sk, 0, sizeof sk);
+    if (n == 0 || n > (uint32_t)kMaxFrameSkins) return false;
+    // Units per wave.  One is fastest while every skinning workgroup has a CU to itself (a lone wave issues an instruction every
+    // ~4 cycles whatever it is: a unit costs it ~0.7 us, and the units of a wave come one after another); past ~one workgroup per CU
+    // two workgroups share a CU's LDS pipeline and scheduler and the launch ends with the slowest: measured (tools/exp/r05_frame_skin.py)
+    // C2, 782 units: 196 workgroups 8.9 us, 98: 9.2, 49: 10.5; C5, 1563 units: 391 workgroups 12.0 us, 196: 10.9, 98: 12.4.
+    // anim.frame_skin_units = 0 (default): the smallest depth that keeps the launch's skinning workgroups within kFrameSkinAutoBlocks.
+    auto blocks_at = [&](uint32_t per_wave) {
+        uint64_t t = 0;
+        for (uint32_t k = 0; k < n; ++k)
+            t += (uint64_t)A.n_instances * std::max<uint32_t>(((args[k].n_verts + 63u) / 64u + 4u * per_wave - 1u) / (4u * per_wave), 1u);
+        return t;
+    };
+    uint32_t per_wave = (uint32_t)std::max(c->frame_skin_units, 0);
+    if (per_wave == 0)
+        for (per_wave = 1; per_wave < 16u && blocks_at(per_wave) > std::min(kFrameSkinAutoBlocks, max_blocks); ++per_wave) {}
+    const uint64_t want = blocks_at(per_wave), least = (uint64_t)n * A.n_instances;
+    if (least > max_blocks) return false;
+    // more work than the resident grid holds at the wanted depth: every job gets its share of the grid, waves loop over more units.
+    // (Past ~16 units per wave the launch is a streaming kernel and the launch boundary it saves no longer matters: separate launches.)
+    const double scale = want > max_blocks ? (double)max_blocks / (double)want : 1.0;
+    uint32_t block0 = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const LbsArgs& a = args[k];
+        const uint32_t upi = (a.n_verts + 63u) / 64u;
+        uint32_t bpi = std::max<uint32_t>((upi + 4u * per_wave - 1u) / (4u * per_wave), 1u);
+        bpi = std::max<uint32_t>((uint32_t)((double)bpi * scale), 1u);
+        if (upi > (uint64_t)bpi * 4u * 16u) return false;
+        const Animator::PaletteOut* po = nullptr;
+        for (const Animator::PaletteOut& p : A.palette_outputs)
+            if (p.bones_id == A.skin_outputs[k].bones_id) po = &p;
+        if (!po) return false;
+        FrameSkinJob& j = sk.job[k];
+        j.pos = a.pos; j.nrm = a.out_nrm ? a.nrm : nullptr; j.tan = a.out_tan ? a.tan : nullptr; j.wgt = a.wgt; j.idx = a.idx;
+        j.out_pos = a.out_pos; j.out_nrm = a.nrm ? a.out_nrm : nullptr; j.out_tan = a.tan ? a.out_tan : nullptr;
+        j.bone_nodes = po->d_bone_nodes;
+        j.n_verts = a.n_verts; j.n_bones = a.n_bones;
+        j.block0 = block0;
+        j.blocks_per_inst = bpi;
+        block0 += bpi * A.n_instances;
+    }
+    if (block0 > max_blocks) return false;
+    sk.n_jobs = n;
+    sk.n_blocks = block0;
+    return true;
+}
+
 // Send the planned frame to the GPU and run sample + update.
 int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     hipStream_t ps = nullptr;     // the frame's stream (anim.overlap: frames alternate between two)
@@ -410,16 +472,43 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     RigDev rd;
     if (int rc = rig_params(c, A, rd)) return rc;
     const int upd_mode = !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral;
+    // the animator's skin outputs: the kernel arguments fyx_lbs_skin_device would launch with, on the palettes this frame writes
+    LbsArgs skin_args[kMaxFrameSkins];
+    const uint32_t n_skins = (uint32_t)A.skin_outputs.size();
+    if (int rc = skin_output_args(c, A, skin_args)) return rc;
     if (int rc = timeline_arm(c, 2)) return rc;
-    if (one_launch) FYX_HIP(c, launch_pose_frame(f, rd, upd_mode, ps, inl, A.d_frame_counter, &A.frame_counter_total));
-    else FYX_HIP(c, launch_pose_update(f, rd, upd_mode, ps, &inl, c->upd_pack));
+    bool skinned = false;
+    if (one_launch) {
+        if (!A.d_frame_counter) {      // the counter of the animator's one-launch frames (FrameSync), on its first such frame
+            const size_t cb = (size_t)kFrameCounterReplicas * kFrameCounterStride;
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_frame_counter), cb));
+            A.frame_counter_total = 0;
+            FYX_HIP(c, hipMemsetAsync(A.d_frame_counter, 0, cb, ps));
+        }
+        FrameSync wait;
+        memset(&wait, 0, sizeof wait);
+        wait.timeout_ticks = (uint32_t)c->wait_timeout_ms * 100000u;     // 100 MHz
+        wait.err = reinterpret_cast<uint32_t*>(c->dev_err);
+        wait.tag = A.id;
+        FrameSkin sk;
+        const bool fused = n_skins && c->frame_skin && frame_skin_plan(c, A, skin_args, n_skins, upd_mode == kUpdStraight ? kFrameSkinMaxBlocks : kFrameSkinMaxBlocksGeneral, sk);
+        FYX_HIP(c, launch_pose_frame(f, rd, upd_mode, ps, inl, A.d_frame_counter, &A.frame_counter_total, wait, fused ? &sk : nullptr, c->lbs.exact != 0));
+        skinned = fused;
+    } else {
+        FYX_HIP(c, launch_pose_update(f, rd, upd_mode, ps, &inl, c->upd_pack));
+    }
     g_launch_events = LaunchEvents();
     if (with_program) {
         FYX_HIP(c, launch_property_update(f, ps, &inl));
         if (!in_args)
             if (int rc = ctrl_consumed(c, A.ctrl, slot, ps)) return rc;
     }
-    return exit_pose(c);
+    if (int rc = exit_pose(c)) return rc;
+    // a frame that could not take its skinning along (a crowd, root motion, property tracks, anim.frame_skin = 0): the same launches
+    // fyx_lbs_skin_device would make, in order behind the update on the frame's stream
+    if (!skinned)
+        for (uint32_t k = 0; k < n_skins; ++k) FYX_HIP(c, launch_lbs(skin_args[k], c->lbs, ps));
+    return FYX_OK;
 }
 
 // One frame of MANY animators (fyx_scene_update): every animator is planned exactly as plan_frame does (different
@@ -583,7 +672,16 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
     FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs), d, tabs, S.n_blocks, S.lds_bytes, all_straight, S.wide_update, ps));
     if (int rc = ctrl_consumed(c, S.ctrl, slot, ps)) return rc;
-    return exit_pose(c);
+    if (int rc = exit_pose(c)) return rc;
+    // the animators' skin outputs (fyx_animator_set_skin_output): behind the scene's update launch, on the frame's stream
+    for (size_t k = 0; k < n; ++k) {
+        const Animator& A = *S.animators[k];
+        if (A.skin_outputs.empty()) continue;
+        LbsArgs skin_args[kMaxFrameSkins];
+        if (int rc = skin_output_args(c, A, skin_args)) return rc;
+        for (size_t j = 0; j < A.skin_outputs.size(); ++j) FYX_HIP(c, launch_lbs(skin_args[j], c->lbs, ps));
+    }
+    return FYX_OK;
 }
 
 template <typename F>

@@ -29,13 +29,26 @@
 #include "fyx_internal.h"
 
 #include "../../include/fyrox_hip.h"
+#include "lbs_leaves.h"    // the skinning kernels' per-vertex code: the one-launch frame goes on to the vertices
 #include "anim_leaves.h"   // lerpf_, cubicf_, interpolate_loaded, span_track_value_at, classify_fold_program (host + device)
 
 #include <hip/hip_ext.h>
 
 namespace fyx {
 
+constexpr int kFrameSkinLoadAux = 2, kFrameSkinStoreAux = 16;     // nt loads, sc1 stores (lbs_skin_dyn's pair)
+
 thread_local LaunchEvents g_launch_events;
+
+// Experiment builds only (tools/exp/r05_stamps_build.sh compiles with -DFYX_FRAME_STAMPS): thread 0 of every workgroup of the one-launch
+// frame leaves wall-clock stamps (100 MHz) -- 0 entry, 1 first requests issued, 2 the samplers have reported, 3 fold done, 4 local
+// matrices in LDS, 5 walk done, 6 palette in LDS / stores issued, 7 done.  Not in the product library.
+#ifdef FYX_FRAME_STAMPS
+__device__ unsigned long long g_fstamp[1024 * 8];
+#define FSTAMP(i) do { if (threadIdx.x == 0) g_fstamp[(blockIdx.x & 1023u) * 8u + (i)] = wall_clock64(); } while (0)
+#else
+#define FSTAMP(i) do {} while (0)
+#endif
 // a launch that takes the armed timeline events, if any (option debug.timeline)
 #define FYX_TL_LAUNCH(kernel, grid, block, lds, s, ...)                                                                      \
     do {                                                                                                                      \
@@ -1277,15 +1290,32 @@ __device__ __forceinline__ void mat4_mul(const float* a, const float* b, float* 
 // ---------------------------------------------------------------------------------------
 // pose_update: one workgroup per instance.
 // ---------------------------------------------------------------------------------------
+// An in-grid wait gave up: say so where the host looks (DeviceError, pinned host-coherent memory) -- plain system-scope stores, the
+// code last; every workgroup that gives up writes the same kind of record, the last one stays.
+__device__ __forceinline__ void report_frame_wait(const FrameSync& w, uint32_t seen) {
+    if (!w.err) return;
+    DeviceError* e = reinterpret_cast<DeviceError*>(w.err);
+    __hip_atomic_store(&e->block, (uint32_t)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&e->seen, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&e->target, w.target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&e->tag, w.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&e->code, (uint32_t)kDevErrFrameWait, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // MODE: kUpdNoProgram -- the transforms as they are (fyx_animator_update_transforms); kUpdGeneral -- straight form + interpreter;
 // kUpdStraight -- every program of the launch is straight (the host classified them with the same function,
 // classify_fold_program): the interpreter and its kMaxFoldDepth nested accumulators are not compiled in, which is what lets a
 // crowd's update kernel sit beside the previous frame's skinning (<= 128 VGPRs instead of ~440: anim.overlap).
 // pal_mem: where the rig's palette outputs lie in memory, for callers whose RigDev is a register copy (the scene form: indexing a
 // register copy with the loop counter would put the array in scratch).
-template <int MODE, int PACK = 1, bool WAIT = false, bool WIDE = false>
-__device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0,
-                                                 const PaletteOutDev* __restrict__ pal_mem = nullptr, const FrameSync* wait = nullptr) {
+// QUIET (a skinning workgroup of the one-launch frame, frame_skin_body): everything up to the global matrices in LDS, NOTHING stored to
+// memory, then the palette of `skin`'s bone list straight into the skinning kernels' LDS layout (behind the update's own LDS areas).
+// Returns false when an in-grid wait timed out (reported through FrameSync::err; nothing was computed).
+template <int MODE, int PACK = 1, bool WAIT = false, bool WIDE = false, bool QUIET = false>
+__device__ __forceinline__ bool pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0,
+                                                 const PaletteOutDev* __restrict__ pal_mem = nullptr, const FrameSync* wait = nullptr,
+                                                 const FrameSkinJob* skin = nullptr) {
+    static_assert(!QUIET || (WAIT && WIDE && PACK == 1), "the quiet form belongs to the one-launch frame");
     constexpr bool PROGRAM = MODE != kUpdNoProgram;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // PACK > 1: the workgroup is PACK independent waves, one instance each (rigs of <= 64 nodes: pose_update_pack_kernel) -- a
@@ -1306,6 +1336,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         }
     };
     const size_t inst_base = (size_t)inst * rig.n_nodes;
+    if constexpr (WAIT) FSTAMP(0);
 
     // Everything that does not depend on the fold is requested FIRST, so that its (cold) latency runs under the
     // fold's chain of dependent loads instead of after it: what this thread will do in the hierarchy walk (its <= 4
@@ -1339,6 +1370,17 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             l_global[(size_t)rig.n_nodes * 16 + threadIdx.x] = (threadIdx.x % 5u == 0u) ? 1.0f : 0.0f;   // what a root is multiplied by
             l_local[(size_t)(rig.n_nodes + 1u) * 16 + threadIdx.x] = 0.0f;                               // the padding's "local matrix"
             s_chunks[rig.n_chunks * 16u + threadIdx.x] = 0u;                                            // (read ahead by the last chunk)
+        }
+    }
+    // QUIET: the bone -> node words of the palette this workgroup builds (four columns per thread: <= 256 bones), requested with the
+    // first loads of the kernel; the inverse bind columns they lead to follow just ahead of the wait for the samplers.
+    int32_t q_node[4] = {-1, -1, -1, -1};
+    f4 q_bb[4];
+    if constexpr (QUIET) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = threadIdx.x + (uint32_t)k * 256u;
+            if (e < skin->n_bones * 4u) q_node[k] = skin->bone_nodes[e >> 2];
         }
     }
     // the instance's fold program: op `lane` into every wave's registers while ALL lanes are still active (v_readlane
@@ -1396,21 +1438,47 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
                 st[q * 4] = v.x; st[q * 4 + 1] = v.y; st[q * 4 + 2] = v.z; st[q * 4 + 3] = v.w;
             }
         }
+        if constexpr (QUIET) {
+            if (node_base == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    q_bb[k] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (q_node[k] >= 0) q_bb[k] = reinterpret_cast<const f4*>(rig.inv_bind)[(size_t)q_node[k] * 4 + (threadIdx.x & 3u)];
+                }
+            }
+        }
         if constexpr (WAIT) {
             // one-launch frame: the sampler's workgroups run in this grid too; everything above was requested without them
             if (node_base == 0) {
+                FSTAMP(1);
+                uint32_t* status = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + wide_update_lds(rig.n_nodes, rig.n_chunks));
                 if (threadIdx.x == 0) {
-                    // (bounded: ~0.5 s of the 100 MHz clock.  The samplers of this grid were dispatched before this workgroup and take
-                    // microseconds; should the counter ever be short -- a word of it overwritten from outside -- the frame computes from
-                    // what is in memory instead of holding the GPU for ever)
+                    // Bounded (FrameSync::timeout_ticks of the 100 MHz clock, option anim.wait_timeout_ms).  The samplers of this grid take
+                    // microseconds and hold places of their own (fyx_internal.h: FrameSync); should the counter stay short all the same --
+                    // a word of it overwritten from outside, a dispatcher that holds the samplers back -- the workgroup REPORTS and
+                    // computes nothing: a frame is late or it is right, never silently made of stale records.
                     const uint64_t t0 = wall_clock64();
-                    while ((int32_t)(__hip_atomic_load(wait->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait->target) < 0) {
+                    uint32_t seen = 0, ok = 1;
+                    const uint32_t* word = wait->counter + (size_t)(blockIdx.x % kFrameCounterReplicas) * (kFrameCounterStride / 4u);
+                    while ((int32_t)((seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - wait->target) < 0) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (wall_clock64() - t0 > 50000000ull) break;
+                        if (wall_clock64() - t0 > (uint64_t)wait->timeout_ticks) { ok = 0; break; }
                     }
+                    if (!ok) report_frame_wait(*wait, seen);
+                    *status = ok;
                 }
                 __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the records are read behind this, from where the samplers put them
+                if (*status == 0) return false;
+                // The records are read behind this, from where the samplers put them.  The update workgroup takes the agent-scope acquire
+                // by the book (it invalidates its XCD's L2).  The skinning workgroups -- hundreds, all after the same few KB -- must NOT:
+                // measured (tools/exp/r05_stamps.py), 196 of them invalidating the L2s under one another turn a 0.7 us fold into 5 us (every
+                // record load of every workgroup goes to memory, all to the same few lines).  They do not need to either: the L2s were
+                // invalidated when this kernel started, nothing on the chip reads a record line between then and the samplers' last
+                // acknowledged write-through store (the records' only readers are behind this wait), so no L2 can hold a stale copy;
+                // the first reader of an XCD misses to memory, where the record is, and the rest hit.  Program order is the compiler's to keep.
+                if constexpr (QUIET) __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                FSTAMP(2);
             }
         }
         FoldCtx cx;
@@ -1463,7 +1531,8 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
                 Acc acc = acc_empty();
                 while (!cx.done) run_fold<0>(cx, acc);  // a stray POP at depth 0 is ignored
             }
-            if (cx.dirty && live) {
+            if constexpr (WAIT) { if (node_base == 0) FSTAMP(3); }
+            if (!QUIET && cx.dirty && live) {    // (a quiet workgroup leaves the write-back to the update workgroup: same values)
                 trs[0] = f4{cx.tpx, cx.tpy, cx.tpz, 0.f};
                 trs[1] = cx.tr;
                 trs[2] = f4{cx.tsx, cx.tsy, cx.tsz, 0.f};
@@ -1478,6 +1547,7 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
         }
     }
     sync();
+    if constexpr (WAIT) FSTAMP(4);
 
     // level-synchronous global = parent.global * local; a root multiplies by the identity, as
     // the reference does for a node without a valid parent.  What each thread does in the walk was fetched at the top.
@@ -1528,6 +1598,43 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
                 reinterpret_cast<f4*>(l_global + (size_t)node * 16)[c] = f4{g[c * 4], g[c * 4 + 1], g[c * 4 + 2], g[c * 4 + 3]};
         }
         sync();
+    }
+    if constexpr (WAIT) FSTAMP(5);
+    if constexpr (QUIET) {
+        // bone_matrices[b] = global(bone_b) * inv_bind(bone_b) (the epilogue's expression, element for element) into the packed-math
+        // layout skin_vertex reads (lbs_leaves.h): a thread holds column c = (m0c, m1c, m2c, m3c) of bone b
+        f32x4* rows = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + wide_update_lds(rig.n_nodes, rig.n_chunks) + 16u);
+        f32x4* row3 = rows + 3u * skin->n_bones;
+        uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + skin->n_bones);
+        bool pj = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = threadIdx.x + (uint32_t)k * 256u;
+            if (e >= skin->n_bones * 4u) continue;
+            const uint32_t b = e >> 2, c = e & 3u;
+            f4 y;
+            if (q_node[k] < 0) {
+                y = f4{c == 0 ? 1.0f : 0.0f, c == 1 ? 1.0f : 0.0f, c == 2 ? 1.0f : 0.0f, c == 3 ? 1.0f : 0.0f};
+            } else {
+                const f4 b4 = q_bb[k];
+                const f4* a = reinterpret_cast<const f4*>(l_global) + (size_t)q_node[k] * 4;
+                const f4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+                y.x = a0.x * b4.x; y.x = a1.x * b4.y + y.x; y.x = a2.x * b4.z + y.x; y.x = a3.x * b4.w + y.x;
+                y.y = a0.y * b4.x; y.y = a1.y * b4.y + y.y; y.y = a2.y * b4.z + y.y; y.y = a3.y * b4.w + y.y;
+                y.z = a0.z * b4.x; y.z = a1.z * b4.y + y.z; y.z = a2.z * b4.z + y.z; y.z = a3.z * b4.w + y.z;
+                y.w = a0.w * b4.x; y.w = a1.w * b4.y + y.w; y.w = a2.w * b4.z + y.w; y.w = a3.w * b4.w + y.w;
+            }
+            float* r = reinterpret_cast<float*>(rows + b * 3u);
+            *reinterpret_cast<f32x2*>(r + 2u * c) = f32x2{y.x, y.y};
+            r[8u + c] = y.z;
+            reinterpret_cast<float*>(row3 + b)[c] = y.w;
+            pj |= y.w != (c == 3u ? 1.0f : 0.0f);
+        }
+        const bool wave_pj = __any(pj) != 0;
+        if ((threadIdx.x & 63u) == 0) wave_flag[threadIdx.x >> 6] = wave_pj ? 1u : 0u;
+        __syncthreads();
+        FSTAMP(6);
+        return true;
     }
     // The global matrices leave the chip once, after the walk: a store inside the level loop would have every
     // level's barrier wait for its write acknowledgement (s_waitcnt vmcnt(0) ahead of s_barrier: ~0.65 us per level
@@ -1585,6 +1692,14 @@ __device__ __forceinline__ void pose_update_body(const PoseFrameDev& f, const Ri
             }
         }
     }
+    if constexpr (WAIT) {
+        FSTAMP(6);
+#ifdef FYX_FRAME_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FSTAMP(7);
+#endif
+    }
+    return true;
 }
 
 // Two kernel-argument shapes: with the frame's control block inside the arguments (one character, CtrlInline) and without
@@ -1594,22 +1709,106 @@ __global__ __launch_bounds__(256) void pose_update_inl_kernel(PoseFrameDev f, Ri
 template <int MODE>
 __global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) { pose_update_body<MODE>(f, rig, blockIdx.x); }
 // One character's frame in one launch (FrameSync, fyx_internal.h).
+__device__ __forceinline__ void frame_sample_block(const PoseFrameDev& fr, const FrameSync& fs) {
+    FSTAMP(0);
+    const uint32_t bx = blockIdx.x % fs.sx, t = blockIdx.x / fs.sx;
+    pose_sample_body<true>(fr, bx, t % fs.sy, t / fs.sy);
+    // Every wave: its part of the records is visible device-wide before the workgroup reports.  The records are the only thing
+    // of this half that the update half reads, and they were stored with agent-scope (write-through) stores: once those are
+    // acknowledged (vmcnt = 0) they are where every XCD finds them, and the L2 write-back an agent-scope release FENCE would
+    // add (buffer_wbl2: ~0.7 us of one character's 9 - 11 us; tools/exp/r04_character_ab.py, call 38) has nothing left to do.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < kFrameCounterReplicas)
+        __hip_atomic_fetch_add(fs.counter + (size_t)threadIdx.x * (kFrameCounterStride / 4u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FSTAMP(7);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void pose_frame_inl_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl, FrameSync fs) {
     const PoseFrameDev fr = ctrl_resolve<kInlAfterFrameAndRig>(f, inl);
     if (blockIdx.x < fs.n_sample_blocks) {
-        const uint32_t bx = blockIdx.x % fs.sx, t = blockIdx.x / fs.sx;
-        pose_sample_body<true>(fr, bx, t % fs.sy, t / fs.sy);
-        // Every wave: its part of the records is visible device-wide before the workgroup reports.  The records are the only thing
-        // of this half that the update half reads, and they were stored with agent-scope (write-through) stores: once those are
-        // acknowledged (vmcnt = 0) they are where every XCD finds them, and the L2 write-back an agent-scope release FENCE would
-        // add (buffer_wbl2: ~0.7 us of one character's 9 - 11 us; tools/exp/r04_character_ab.py, call 38) has nothing left to do.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(fs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        frame_sample_block(fr, fs);
         return;
     }
     pose_update_body<MODE, 1, true, true>(fr, rig, blockIdx.x - fs.n_sample_blocks, inl.first_ops, nullptr, &fs);
+}
+
+// A skinning workgroup of the one-launch frame (FrameSkin, fyx_internal.h): four waves; wave w of the workgroup takes units
+// u0 + w, u0 + w + 4, ... of the workgroup's share [u0, u1) of one instance of one job, two units in flight.  The per-vertex code is
+// lbs_skin_dyn's (load_vertex_buf / skin_vertex / store_vertex_buf on buffer resources: a lane past the mesh's end loads zeros and
+// stores nothing; a stream the job does not have -- no normals, an output not wanted -- is a resource of zero bytes), the palette
+// in LDS is made of the same expressions as the update kernel's palette epilogue: the vertices are lbs_skin's on the palette
+// the update workgroup writes to memory, bit for bit.
+template <int MODE, bool EXACT>
+__device__ __forceinline__ void frame_skin_body(const PoseFrameDev& fr, const RigDev& rig, uint32_t first_ops, const FrameSync& fs, const FrameSkin& sk, uint32_t b) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    FrameSkinJob j = sk.job[0];
+#pragma unroll
+    for (int k = 1; k < kMaxFrameSkins; ++k)
+        if ((uint32_t)k < sk.n_jobs && b >= sk.job[k].block0) j = sk.job[k];
+    const uint32_t rb = b - j.block0, inst = rb / j.blocks_per_inst, part = rb - inst * j.blocks_per_inst;
+    const uint32_t upi = (j.n_verts + 63u) >> 6;
+    const uint32_t u0 = (uint32_t)(((uint64_t)part * upi) / j.blocks_per_inst), u1 = (uint32_t)(((uint64_t)(part + 1u) * upi) / j.blocks_per_inst);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    LbsArgs a;
+    a.pos = j.pos; a.nrm = j.nrm; a.tan = j.tan; a.wgt = j.wgt; a.idx = j.idx;
+    a.palette = nullptr;
+    const size_t ov = (size_t)inst * j.n_verts;
+    a.out_pos = j.out_pos ? j.out_pos + ov * 3 : nullptr;
+    a.out_nrm = j.out_nrm ? j.out_nrm + ov * 3 : nullptr;
+    a.out_tan = j.out_tan ? j.out_tan + ov * 4 : nullptr;
+    a.n_verts = j.n_verts; a.n_bones = j.n_bones; a.n_instances = 1;
+    const VtxBuffers vb = make_vtx_buffers(a);
+    constexpr uint32_t kNoVertex = 0x0fffffffu;     // past the end of every stream: loads give zeros, stores are dropped
+    // the wave's first two units: nothing of them depends on the pose
+    uint32_t uA = u0 + wave, uB = uA + 4u;
+    uint32_t vA = uA < u1 ? uA * 64u + lane : kNoVertex, vB = uB < u1 ? uB * 64u + lane : kNoVertex;
+    VertexIn<7> A = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vA);
+    VertexIn<7> B = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vB);
+
+    if (!pose_update_body<MODE, 1, true, true, true>(fr, rig, inst, first_ops, nullptr, &fs, &j)) return;
+
+    const f32x4* rows = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + wide_update_lds(rig.n_nodes, rig.n_chunks) + 16u);
+    const f32x4* row3 = rows + 3u * j.n_bones;
+    const uint32_t* wave_flag = reinterpret_cast<const uint32_t*>(row3 + j.n_bones);
+    const bool projective = (wave_flag[0] | wave_flag[1] | wave_flag[2] | wave_flag[3]) != 0;
+    auto process = [&](VertexIn<7>& c_, uint32_t v_c) {
+        pin_vertex(c_);
+        const Skinned o = skin_vertex<EXACT, 7>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
+                                                c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
+        store_vertex_buf<7, kFrameSkinStoreAux>(vb, v_c, o, c_.t.w);
+    };
+    while (uA < u1) {     // wave-uniform
+        process(A, vA);
+        uA += 8u;
+        if (uA < u1) { vA = uA * 64u + lane; A = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vA); }
+        if (uB < u1) {
+            process(B, vB);
+            uB += 8u;
+            if (uB < u1) { vB = uB * 64u + lane; B = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vB); }
+        }
+    }
+#ifdef FYX_FRAME_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FSTAMP(7);
+#endif
+}
+
+// The launch: [sampler workgroups][one update workgroup per instance][skinning workgroups].
+template <int MODE, bool EXACT>
+__global__ __launch_bounds__(256) void pose_frame_skin_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl, FrameSync fs, FrameSkin sk) {
+    const PoseFrameDev fr = ctrl_resolve<kInlAfterFrameAndRig>(f, inl);
+    if (blockIdx.x < fs.n_sample_blocks) {
+        frame_sample_block(fr, fs);
+        return;
+    }
+    const uint32_t u = blockIdx.x - fs.n_sample_blocks;
+    if (u < fr.n_instances) {
+        pose_update_body<MODE, 1, true, true>(fr, rig, u, inl.first_ops, nullptr, &fs);
+        return;
+    }
+    frame_skin_body<MODE, EXACT>(fr, rig, inl.first_ops, fs, sk, u - fr.n_instances);
 }
 
 // Crowds of small rigs (<= 64 nodes: one wave per instance): PACK instances per workgroup (four: one per SIMD).  The waves share
@@ -1667,19 +1866,31 @@ hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode
     return launch_update_one(pose_update_kernel<kUpdNoProgram>, f.n_instances, block, lds, s, f, rig);
 }
 
-hipError_t launch_pose_frame(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline& inl, uint32_t* counter, uint32_t* counter_total) {
-    FrameSync fs;
+hipError_t launch_pose_frame(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline& inl, uint32_t* counter, uint32_t* counter_total,
+                             const FrameSync& wait, const FrameSkin* skin, bool exact) {
+    FrameSync fs = wait;
     fs.counter = counter;
     fs.sx = (f.n_nodes * 16 + 255) / 256;
     fs.sy = f.n_instances;
     fs.n_sample_blocks = fs.sx * fs.sy * f.n_anims;
-    fs.pad = 0;
     fs.target = *counter_total + fs.n_sample_blocks;
-    const size_t lds = wide_walk_lds(rig);
-    const uint32_t grid = fs.n_sample_blocks + f.n_instances;
-    // (first_ops of instance 0 only: pose_update_body looks at it for inst == 0)
-    const hipError_t e = mode == kUpdStraight ? launch_update_one(pose_frame_inl_kernel<kUpdStraight>, grid, 256u, lds, s, f, rig, inl, fs)
-                                              : launch_update_one(pose_frame_inl_kernel<kUpdGeneral>, grid, 256u, lds, s, f, rig, inl, fs);
+    size_t lds = wide_walk_lds(rig) + 16;      // (+ the wait's status word)
+    uint32_t grid = fs.n_sample_blocks + f.n_instances;
+    hipError_t e;
+    if (skin && skin->n_blocks) {
+        uint32_t max_bones = 0;
+        for (uint32_t k = 0; k < skin->n_jobs; ++k) max_bones = std::max(max_bones, skin->job[k].n_bones);
+        lds = wide_walk_lds(rig) + frame_skin_lds(max_bones);
+        grid += skin->n_blocks;
+        if (mode == kUpdStraight) e = exact ? launch_update_one(pose_frame_skin_kernel<kUpdStraight, true>, grid, 256u, lds, s, f, rig, inl, fs, *skin)
+                                            : launch_update_one(pose_frame_skin_kernel<kUpdStraight, false>, grid, 256u, lds, s, f, rig, inl, fs, *skin);
+        else e = exact ? launch_update_one(pose_frame_skin_kernel<kUpdGeneral, true>, grid, 256u, lds, s, f, rig, inl, fs, *skin)
+                       : launch_update_one(pose_frame_skin_kernel<kUpdGeneral, false>, grid, 256u, lds, s, f, rig, inl, fs, *skin);
+    } else {
+        // (first_ops of instance 0 only: pose_update_body looks at it for inst == 0)
+        e = mode == kUpdStraight ? launch_update_one(pose_frame_inl_kernel<kUpdStraight>, grid, 256u, lds, s, f, rig, inl, fs)
+                                 : launch_update_one(pose_frame_inl_kernel<kUpdGeneral>, grid, 256u, lds, s, f, rig, inl, fs);
+    }
     if (e == hipSuccess) *counter_total = fs.target;      // a launch that was refused adds nothing to the counter
     return e;
 }
@@ -1800,3 +2011,7 @@ hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uin
 }
 
 }  // namespace fyx
+
+#ifdef FYX_FRAME_STAMPS
+extern "C" int fyx_exp_frame_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fyx::g_fstamp), sizeof fyx::g_fstamp); }
+#endif

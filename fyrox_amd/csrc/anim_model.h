@@ -152,6 +152,7 @@ struct PlanScratch {
 };
 
 struct Animator {
+    uint64_t id = 0;
     uint64_t rig_id = 0;
     Rig* rig = nullptr;
     uint32_t n_instances = 0;
@@ -170,7 +171,7 @@ struct Animator {
     float4* d_anim_pose = nullptr;
     uint32_t dev_anim_capacity = 0, dev_track_capacity = 0;
     float4* d_node_trs = nullptr;
-    uint32_t* d_frame_counter = nullptr;   // (inside d_node_trs' allocation) FrameSync::counter
+    uint32_t* d_frame_counter = nullptr;   // FrameSync::counter: kFrameCounterReplicas words, kFrameCounterStride apart (own allocation)
     uint32_t frame_counter_total = 0;      // what it reaches when every launch issued so far has run
     float* d_local = nullptr;
     float* d_global = nullptr;
@@ -201,6 +202,10 @@ struct Animator {
     // scene of 256 characters looked each of them up in the store every frame)
     struct PaletteOut { uint64_t bones_id; float* d_out; const int32_t* d_bone_nodes; uint32_t n_bones; };
     std::vector<PaletteOut> palette_outputs;
+    // meshes every update of the animator skins itself (fyx_animator_set_skin_output): with the palette of `bones_id` -- which is
+    // one of palette_outputs -- as fyx_lbs_skin_device(mesh_id, that palette, n_bones, n_instances, outputs) right behind the update
+    struct SkinOut { uint64_t bones_id, mesh_id; float* d_pos; float* d_nrm; float* d_tan; };
+    std::vector<SkinOut> skin_outputs;
     // Property{..} slots: one per distinct (node, property id) any animation of the animator drives
     std::vector<std::pair<int32_t, int32_t>> prop_slots;
     int32_t* d_prop_node = nullptr;

@@ -75,9 +75,28 @@ int sync_all(fyx_ctx* c) {
     return FYX_OK;
 }
 
+int check_device_error(fyx_ctx* c) {
+    fyx::DeviceError* e = c->dev_err;
+    if (!e || __atomic_load_n(&e->code, __ATOMIC_ACQUIRE) == 0) return FYX_OK;
+    const fyx::DeviceError r = *e;
+    memset(e, 0, sizeof *e);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    if (r.code == fyx::kDevErrFrameWait) {
+        c->one_launch = 0;
+        return fail(c, FYX_ERR_HIP,
+                    "one-launch frame of animator %llu: workgroup %u waited %d ms for the frame's sampler workgroups (counter %u, target %u) and gave up; "
+                    "that frame computed NOTHING (poses, palettes and skin outputs are the previous frame's).  The one-launch form relies on the "
+                    "sampler workgroups of a grid being dispatched before the workgroups that wait for them; anim.one_launch is now 0 for this "
+                    "context (sampler, update and skinning as separate launches, no in-grid wait)",
+                    (unsigned long long)r.tag, r.block, c->wait_timeout_ms, r.seen, r.target);
+    }
+    return fail(c, FYX_ERR_HIP, "a kernel reported error %u (workgroup %u)", r.code, r.block);
+}
+
 static hipError_t make_stream(fyx_ctx* c, bool pose, hipStream_t* out);
 
 int enter_pose(fyx_ctx* c, hipStream_t* out) {
+    if (int rc = check_device_error(c)) return rc;      // what an earlier frame's kernels reported
     if (!c->pose_overlap) {
         *out = c->stream;
         return enter_primary(c);
@@ -435,6 +454,21 @@ fyx::LbsArgs make_args(const Mesh& m, const float* d_palette, uint32_t n_bones, 
     return a;
 }
 
+}  // namespace
+
+namespace fyx {
+int skin_args_of(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, uint32_t n_bones, uint32_t n_instances,
+                 float* d_out_pos, float* d_out_normal, float* d_out_tangent, fyx::LbsArgs* out) {
+    const Mesh* m = find_mesh(c, mesh_id);
+    if (int rc = check_skin_args(c, m, mesh_id, d_palette, n_bones, n_instances)) return rc;
+    if (d_out_normal && !m->nrm) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Normal attribute");
+    if (d_out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "mesh has no Tangent attribute");
+    *out = make_args(*m, d_palette, n_bones, n_instances, d_out_pos, d_out_normal, d_out_tangent);
+    return FYX_OK;
+}
+}  // namespace fyx
+
+namespace {
 // Validation and kernel arguments of one extended skinning job (fyx_lbs_skin_ex and its batch form).
 int build_ex_args(fyx_ctx* c, uint64_t mesh_id, const fyx_skin_desc* d, fyx::LbsExArgs& x, bool& whole_spans) {
     if (!d) return fail(c, FYX_ERR_INVALID_ARG, "desc is null");
@@ -691,10 +725,12 @@ int fyx_init(fyx_ctx** out_ctx, int device_ordinal) {
     c->device = device_ordinal;
     if (make_stream(c, true, &c->own_stream) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->aabb_partials), (6 * 2048 + 8) * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_u32), 64) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&c->d_u32), 64) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->dev_err), sizeof(fyx::DeviceError), hipHostMallocCoherent) != hipSuccess) {
         fyx_shutdown(c);
         return FYX_ERR_HIP;
     }
+    memset(c->dev_err, 0, sizeof(fyx::DeviceError));
     c->stream = c->own_stream;
     *out_ctx = c;
     return FYX_OK;
@@ -716,6 +752,7 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->aabb_partials) (void)hipFree(c->aabb_partials);
     if (c->d_u32) (void)hipFree(c->d_u32);
+    if (c->dev_err) (void)hipHostFree(c->dev_err);
     for (hipEvent_t e : c->timing_ev) (void)hipEventDestroy(e);
     c->timing_ev.clear();
     for (const fyx_ctx::TimelineRec& r : c->timeline) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
@@ -756,7 +793,7 @@ int fyx_sync(fyx_ctx* c) {
     if (!c) return FYX_ERR_INVALID_ARG;
     if (int rc = enter_primary(c)) return rc;
     FYX_HIP(c, hipStreamSynchronize(c->stream));
-    return FYX_OK;
+    return check_device_error(c);     // what the kernels that have now finished reported (an in-grid wait that gave up)
 }
 
 int fyx_timer_begin(fyx_ctx* c) {
@@ -796,6 +833,9 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "anim.update_lean")) return &c->upd_lean;
     if (!strcmp(key, "anim.update_pack")) return &c->upd_pack;
     if (!strcmp(key, "anim.one_launch")) return &c->one_launch;
+    if (!strcmp(key, "anim.frame_skin")) return &c->frame_skin;
+    if (!strcmp(key, "anim.frame_skin_units")) return &c->frame_skin_units;
+    if (!strcmp(key, "anim.wait_timeout_ms")) return &c->wait_timeout_ms;
     if (!strcmp(key, "anim.ctrl_upload")) return &c->ctrl_mode;
     if (!strcmp(key, "streams.priority")) return &c->stream_priority;
     if (!strcmp(key, "streams.pose_cus")) return &c->pose_cus;
@@ -831,6 +871,9 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->pose_cus && (value < 0 || value >= fyx::kCUs || (value & 7))) return fail(c, FYX_ERR_INVALID_ARG, "streams.pose_cus must be 0 or a multiple of 8 below %d", fyx::kCUs);
     if (slot == &c->upd_lean && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_lean must be 0 or 1");
     if (slot == &c->one_launch && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.one_launch must be 0 or 1");
+    if (slot == &c->frame_skin && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.frame_skin must be 0 or 1");
+    if (slot == &c->frame_skin_units && (value < 0 || value > 64)) return fail(c, FYX_ERR_INVALID_ARG, "anim.frame_skin_units must be 0 (auto) .. 64");
+    if (slot == &c->wait_timeout_ms && (value < 1 || value > 30000)) return fail(c, FYX_ERR_INVALID_ARG, "anim.wait_timeout_ms must be 1..30000");
     if (slot == &c->upd_pack && value != 0 && value != 2 && value != 4) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_pack must be 0, 2 or 4");
     if ((slot == &c->stream_priority || slot == &c->pose_cus) && *slot != value) {
         const int old = *slot;

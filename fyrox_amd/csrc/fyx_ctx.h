@@ -117,6 +117,11 @@ struct fyx_ctx {
     int pose_overlap = 0;    // option "anim.overlap": 1 = pose updates do not wait for in-flight skinning launches (see enter_pose)
     int inline_ctrl = 1;     // option "anim.inline_ctrl": 1 = a control block of <= 1 KB travels in the kernel arguments (no H2D copy)
     int one_launch = 1;      // option "anim.one_launch": one character's sampler and update kernels as one launch (FrameSync)
+    int frame_skin = 1;      // option "anim.frame_skin": that launch also holds the workgroups that skin the animator's skin outputs (FrameSkin)
+    int frame_skin_units = 0;   // option "anim.frame_skin_units": 64-vertex units a wave of those workgroups is given (as far as kFrameSkinMaxBlocks
+                                //   allows); 0 = the smallest depth that gives every skinning workgroup a CU of its own (kFrameSkinAutoBlocks)
+    int wait_timeout_ms = 500;  // option "anim.wait_timeout_ms": how long an in-grid wait of the one-launch frame lasts before it reports
+    fyx::DeviceError* dev_err = nullptr;   // pinned, host-coherent: what a kernel that gave up wrote (check_device_error)
     int upd_pack = 4;        // option "anim.update_pack": 0, 2 or 4 instances of a small rig (<= 64 nodes) per workgroup of a crowd's update launch
     int upd_lean = 1;        // option "anim.update_lean": 1 = frames whose fold programs are all straight run the update kernel without the interpreter
     int plan_split = 2048;   // option "anim.split": instances per planning task
@@ -146,6 +151,12 @@ int exit_pose(fyx_ctx* c);
 // The stream of an ordered skinning launch (fyx_lbs_skin_batch and friends): the current frame's under anim.overlap, else the context stream (joined).
 int enter_skin(fyx_ctx* c, hipStream_t* out);
 int ensure_scratch(fyx_ctx* c, size_t bytes);
+// What kernels reported since the last look (fyx_ctx::dev_err): FYX_OK, or FYX_ERR_HIP with the report as the context's message;
+// the block is cleared and the one-launch frame switched off for the context (anim.one_launch = 0: the multi-launch path has no in-grid wait).
+int check_device_error(fyx_ctx* c);
+// Kernel arguments of a skinning launch of a registered mesh, validated as fyx_lbs_skin_device validates them.
+int skin_args_of(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, uint32_t n_bones, uint32_t n_instances,
+                 float* d_out_pos, float* d_out_normal, float* d_out_tangent, fyx::LbsArgs* out);
 // debug.timeline: arms g_launch_events for the next launch and files the pair under `kind` (0 skinning, 1 pose_sample, 2 pose_update)
 int timeline_arm(fyx_ctx* c, int kind);
 void free_ctrl(CtrlBuffers& B);

@@ -399,7 +399,7 @@ enum : int { kUpdNoProgram = 0, kUpdGeneral = 1, kUpdStraight = 2 };
 // animator of few instances: the chip is empty then, and the kernel's strided tail (matrix stores, palette columns: 256 columns for
 // 64 bones) runs over four waves instead of one.  A crowd keeps the smallest block: its waves compete with the skinning kernel's.
 // LDS of an update workgroup with the wide walk: (n_nodes + 2) local and global matrices, the chunk table + one chunk read ahead
-inline size_t wide_update_lds(uint32_t n_nodes, uint32_t n_chunks) { return (size_t)(n_nodes + 2u) * 128u + (size_t)(n_chunks + 1u) * 64u; }
+__host__ __device__ inline size_t wide_update_lds(uint32_t n_nodes, uint32_t n_chunks) { return (size_t)(n_nodes + 2u) * 128u + (size_t)(n_chunks + 1u) * 64u; }
 constexpr size_t kLdsPerWorkgroup = 160u * 1024u;
 inline uint32_t update_block_waves(uint32_t n_nodes, uint32_t n_instances) {
     uint32_t w = (n_nodes + 63u) / 64u;
@@ -413,14 +413,61 @@ hipError_t launch_pose_update(const PoseFrameDev& f, const RigDev& rig, int mode
 // transforms), then waits until `counter` -- every sampler workgroup adds one after its records are visible device-wide -- has
 // reached `target`.  Workgroups are dispatched in index order, so a waiting update workgroup never holds a place a sampler
 // workgroup needs.  What it saves is the launch boundary between the two kernels (~3 us of a 12 us pose path).
+// The counter is kFrameCounterReplicas words kFrameCounterStride bytes apart, all kept equal: every sampler workgroup adds one to EACH
+// (sixteen lanes, one fire-and-forget atomic instruction), a waiting workgroup polls replica (its index % replicas).  A frame that
+// skins has hundreds of waiting workgroups; on ONE word their polls queue in front of the samplers' adds in that word's memory
+// channel (measured: the counter was seen 1.3 us later with 391 pollers than with one).
+constexpr uint32_t kFrameCounterReplicas = 16, kFrameCounterStride = 4096 + 256;
 struct FrameSync {
-    uint32_t* counter;           // device word of the animator, only ever added to
+    uint32_t* counter;           // replica 0 of the animator's device counter, only ever added to
     uint32_t target;             // its value when all sampler workgroups of THIS frame have reported (wraps: compared as a signed difference)
     uint32_t n_sample_blocks;    // workgroups [0, n_sample_blocks) of the grid sample, the rest update
     uint32_t sx, sy;             // the sampler's own grid (x, y; z follows), flattened x fastest
-    uint32_t pad;
+    uint32_t timeout_ticks;      // how long a workgroup waits for the counter, in ticks of the 100 MHz wall clock (option anim.wait_timeout_ms)
+    uint32_t* err;               // the context's device-error block (DeviceError below): a wait that times out reports here and the
+                                 //   workgroup computes NOTHING -- the next API call returns FYX_ERR_HIP
+    uint64_t tag;                // what the report names: the animator's id
 };
-hipError_t launch_pose_frame(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline& inl, uint32_t* counter, uint32_t* counter_total);
+// What a kernel reports to the host when it gives up (pinned, host-coherent memory; checked by fyx_sync and by every pose entry).
+struct DeviceError {
+    uint32_t code;               // 0 none; kDevErrFrameWait: an in-grid wait of a one-launch frame timed out
+    uint32_t block;              // the workgroup that gave up
+    uint32_t seen, target;       // the counter's value and what it was waited to reach
+    uint64_t tag;                // FrameSync::tag
+};
+enum : uint32_t { kDevErrFrameWait = 1 };
+
+// The frame goes on to the vertices (fyx_animator_set_skin_output): the launch that samples and updates one character ALSO holds the
+// workgroups that skin its meshes.  A skinning workgroup requests its first vertices at once (60 bytes per vertex, none of them
+// depends on the pose), then does what the update workgroup does -- waits for the samplers, folds, builds the local matrices, walks
+// the hierarchy -- WITHOUT storing any of it, forms the palette of ITS mesh straight into the skinning kernels' LDS layout and
+// skins: recomputing a 64-node pose in a workgroup that would otherwise sleep is free on an empty chip, and it takes the launch
+// boundary, the palette's trip through memory and a second in-grid wait out of the character's critical path.  Same device
+// functions as the update kernel and lbs_skin: same bits.
+constexpr int kMaxFrameSkins = 4;
+struct FrameSkinJob {
+    const float* pos; const float* nrm; const float* tan; const float* wgt; const uint32_t* idx;   // the mesh's streams
+    float* out_pos; float* out_nrm; float* out_tan;    // [n_instances][n_verts], null: not wanted
+    const int32_t* bone_nodes;   // the job's bone list [n_bones] (rig node of each bone, < 0: identity)
+    uint32_t n_verts, n_bones;
+    uint32_t block0;             // the job's first workgroup among the launch's skinning workgroups
+    uint32_t blocks_per_inst;    // workgroups per instance: an instance's 64-vertex units are dealt evenly over them
+};
+struct FrameSkin {
+    FrameSkinJob job[kMaxFrameSkins];
+    uint32_t n_jobs;
+    uint32_t n_blocks;           // skinning workgroups of the launch
+};
+// Skinning workgroups of one launch: the whole grid stays resident at once -- two 256-thread workgroups per CU at the register
+// budget of the kernel without the interpreter (230 VGPRs), one per CU with it (404) -- so no workgroup ever waits for one that
+// has no place to run, whatever order the dispatcher takes them in.
+constexpr uint32_t kFrameSkinMaxBlocks = 448, kFrameSkinMaxBlocksGeneral = 192;
+constexpr uint32_t kFrameSkinAutoBlocks = 224;     // what anim.frame_skin_units = 0 aims for: a CU per skinning workgroup (256 CUs, the pose workgroups beside them)
+// wait: timeout_ticks, err and tag of the frame's FrameSync (the rest is filled in here); skin: null, or the meshes the launch skins itself
+hipError_t launch_pose_frame(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline& inl, uint32_t* counter, uint32_t* counter_total,
+                             const FrameSync& wait, const FrameSkin* skin = nullptr, bool exact = true);
+// LDS a skinning workgroup of the one-launch frame needs behind the update's: a status word, the palette rows, a flag per wave
+__host__ __device__ inline size_t frame_skin_lds(uint32_t max_bones) { return 16u + (size_t)max_bones * 64u + 64u; }
 
 // Animation::update_root_motion for every ticked animation that has settings (after pose_sample:
 // rewrites the root node's pose record), then the per-instance root-motion program (machine mode).

@@ -674,6 +674,23 @@ int fyx_animator_palette(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, 
  * animator (one per skinned surface of the model, typically 1); the bone list must stay registered; the buffer
  * must be 16-byte aligned (matrix columns are stored as 16-byte words). */
 int fyx_animator_set_palette_output(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, float* d_out_palette);
+/* The frame goes on to the vertices.  In the engine one character's frame is ONE dependent chain: Machine::evaluate_pose
+ * (fyrox-animation/src/machine/mod.rs:344-382) -> Graph::update_hierarchical_data (scene/graph/mod.rs:1199-1241) -> the bone
+ * matrices of Mesh::collect_render_data (scene/mesh/mod.rs:781-793) -> the skinning loop (mesh/mod.rs:501-522,
+ * standard.shader:157-216).  After this call every fyx_animation_player_update / fyx_absm_update / fyx_scene_update /
+ * fyx_animator_update_transforms of the animator ALSO skins mesh `mesh_id` with the palette of `bones_id` -- which must be a palette
+ * output of the animator (fyx_animator_set_palette_output: the palette is still written to its buffer) -- into the outputs
+ * ([n_instances][n_verts], packed as fyx_lbs_skin_device packs them; NULL = that stream is not wanted), with the results
+ * fyx_lbs_skin_device(mesh_id, that palette, n_bones, n_instances, outputs) right behind the update would give, bit for bit
+ * (option lbs.exact as there).  For one character (the frames that run as one launch: anim.one_launch) the launch that
+ * samples and updates also holds the workgroups that skin: they request their vertices before the pose exists and form the
+ * palette on chip -- no second launch, no palette round trip through memory (option anim.frame_skin = 0: separate launches).
+ * Crowds, root motion, property tracks, meshes beyond ~450 k vertices: the same skinning launches fyx_lbs_skin_device makes,
+ * issued by the update call.  All three outputs NULL removes the entry; removing the palette output removes its skin outputs.
+ * At most 4 per animator.  Under anim.overlap the caller alternates the palette buffers as before; a mesh that is freed while
+ * registered makes the next update fail with FYX_ERR_UNKNOWN_ID. */
+int fyx_animator_set_skin_output(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, uint64_t mesh_id, float* d_out_pos,
+                                 float* d_out_normal, float* d_out_tangent);
 
 /* Transform::set_position / set_rotation / set_scale of one node for a range of instances
  * (placing the members of a crowd): trs = n_instances x {pos xyz, rot ijkw, scale xyz}. */
@@ -811,6 +828,11 @@ int fyx_debug_scene_tables(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t 
  *     right tangent} of keys i - 1 and i), returning the values and the new hint; and the classifier that decides whether a fold
  *     program {opcode | arg << 8, f32 weight bits} x n_ops is "straight" (d leading PUSHes, k operands, a MASK before the APPLY,
  *     or the AnimationPlayer's APPLY_ANIM^k END) -- the function by which the host picks the update kernel's lean form. */
+/* Test hook of the one-launch frame's in-grid wait: adds `delta` to the animator's device counter (the word the frame's sampler
+ * workgroups add to and its update / skinning workgroups wait on) WITHOUT telling the host side -- a negative delta is "a word
+ * overwritten from outside": the next one-launch frame's waits time out (option anim.wait_timeout_ms), that frame computes nothing,
+ * and the next fyx_sync / pose entry returns FYX_ERR_HIP with the report.  Synchronous. */
+int fyx_debug_frame_counter_add(fyx_ctx* ctx, uint64_t animator_id, int32_t delta);
 int fyx_debug_rig_walk(fyx_ctx* ctx, uint64_t rig_id, uint32_t* out_words, uint32_t capacity, uint32_t* n_words);
 int fyx_debug_rig_chunks(fyx_ctx* ctx, uint64_t rig_id, uint32_t* out_words, uint32_t capacity, uint32_t* n_words);
 int fyx_debug_span_value_at(const float* span_records, uint32_t n_keys, uint32_t need, float time, uint32_t hint, float out_values[4], uint32_t* out_hint);

@@ -1,0 +1,347 @@
+"""One character's frame as ONE launch all the way to the vertices (fyx_animator_set_skin_output, FrameSkin in csrc/fyx_internal.h).
+
+In the engine a character's frame is one dependent chain: Machine::evaluate_pose (fyrox-animation/src/machine/mod.rs:344-382) ->
+hierarchy (scene/graph/mod.rs:1199-1241) -> bone matrices (scene/mesh/mod.rs:781-793) -> the skinning loop (mesh/mod.rs:501-522).
+The launch that samples and updates a character also holds the workgroups that skin its meshes: they form the palette on chip.
+
+Bar: the vertices are those of fyx_lbs_skin_device on the palette the same update wrote to memory, BIT FOR BIT (and that palette
+and those vertices are checked against the oracle); every fallback (separate launches) gives the same bits; a wait that cannot be
+satisfied is an ERROR, never a frame made of stale data.
+"""
+import numpy as np
+import pytest
+
+import fyrox_amd
+from fyrox_amd import _native
+from fyrox_amd import anim as A
+from fyrox_amd import synth
+
+import anim_cases as cases
+from test_anim_gpu import check_frame
+
+pytestmark = pytest.mark.gpu
+
+
+class Outs:
+    def __init__(self, ctx, n):
+        self.n = n
+        self.pos, self.nrm, self.tan = ctx.malloc(n * 12 + 64), ctx.malloc(n * 12 + 64), ctx.malloc(n * 16 + 64)
+        for b, w in ((self.pos, 3), (self.nrm, 3), (self.tan, 4)):
+            b.upload(np.full(n * w, np.nan, np.float32))
+
+    def get(self):
+        return (self.pos.download(np.uint32, self.n * 3), self.nrm.download(np.uint32, self.n * 3), self.tan.download(np.uint32, self.n * 4))
+
+    def free(self):
+        for b in (self.pos, self.nrm, self.tan):
+            b.free()
+
+
+def _update(p, sc):
+    (p.update_machine if sc.machine is not None else p.update_animations)(sc.dt)
+
+
+def _oupdate(o, sc):
+    (o.update_machine if sc.machine is not None else o.update_animations)(sc.dt)
+
+
+@pytest.mark.parametrize("make,n_inst,n_verts", [
+    (cases.c5_blend_tree, 1, 100_000), (cases.player_only, 1, 50_000), (cases.transitions, 2, 4097), (cases.layered, 1, 20_001),
+    (cases.by_index, 3, 777), (cases.program_forms, 1, 9000), (cases.blend_space, 1, 63), (cases.masked_transitions, 2, 12_345)],
+    ids=lambda v: getattr(v, "__name__", str(v)))
+def test_the_frame_that_skins_equals_update_then_lbs_skin(ctx, orc, make, n_inst, n_verts):
+    """Every frame: outputs of the skin output == fyx_lbs_skin_device on the palette the update wrote; the pose side (poses, TRS,
+    matrices) against the oracle as in test_anim_gpu; at the end the vertices against the oracle's loop on the oracle's palette (exact
+    where no Euler track is involved)."""
+    sc = make()
+    nb = sc.rig.n_nodes
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, n_inst)
+    base = p.base_id
+    bones = list(range(nb))
+    A.create_bone_list(ctx, base + 50, base, bones)
+    d_pal = ctx.malloc(n_inst * nb * 64)
+    p.set_palette_output(base + 50, d_pal.ptr)
+    mesh = synth.make_mesh(n_verts, nb, synth.SEED_BASE + 21)
+    ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    fused, sep = Outs(ctx, n_inst * n_verts), Outs(ctx, n_inst * n_verts)
+    p.set_skin_output(base + 50, base + 60, fused.pos.ptr, fused.nrm.ptr, fused.tan.ptr)
+    try:
+        for f in range(14):
+            for idx, par in sc.script.get(f, []):
+                o.set_parameter(idx, par)
+                p.set_parameter(idx, par)
+            _oupdate(o, sc)
+            _update(p, sc)
+            ctx.lbs_skin_device(base + 60, d_pal.ptr, nb, n_inst, sep.pos.ptr, sep.nrm.ptr, sep.tan.ptr)
+            for a, b, what in zip(fused.get(), sep.get(), ("position", "normal", "tangent")):
+                assert np.array_equal(a, b), f"{sc.name} frame {f}: {what} of the frame that skins differs from update + lbs_skin ({int((a != b).sum())} words)"
+            check_frame(p, o, sc, n_inst, f)
+        pal = d_pal.download(np.float32, n_inst * nb * 16).reshape(n_inst, nb, 16)
+        ref_pal = o.palette(bones)
+        got = fused.pos.download(np.float32, n_inst * n_verts * 3).reshape(n_inst, n_verts, 3)
+        for i in range(n_inst):
+            ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, pal[i], mesh.normal, mesh.tangent)
+            assert np.array_equal(got[i].view(np.uint32), ref["pos"].view(np.uint32)), "vertices vs the oracle's loop on the GPU's palette"
+            if not sc.has_euler:
+                assert np.array_equal(pal[i].view(np.uint32), ref_pal.view(np.uint32)), "palette vs the oracle"
+    finally:
+        p.set_skin_output(base + 50, base + 60)
+        o.close()
+        p.free()
+        for b in (fused, sep):
+            b.free()
+        d_pal.free()
+        ctx.mesh_free(base + 60)
+
+
+def test_forms_of_the_frame_and_every_fallback_give_the_same_vertices(ctx, orc):
+    """anim.frame_skin / anim.one_launch / anim.inline_ctrl / anim.update_lean / anim.frame_skin_units switched from frame to frame; a mask
+    of outputs (position only); two skin outputs on two bone lists (one with an invalid bone handle: identity matrix)."""
+    sc = cases.c5_blend_tree(euler_every=10 ** 6)
+    nb = sc.rig.n_nodes
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, 2)
+    base = p.base_id
+    bones_a = list(range(nb))
+    bones_b = [-1] + list(range(nb - 1, 0, -1))[: nb // 2]
+    A.create_bone_list(ctx, base + 50, base, bones_a)
+    A.create_bone_list(ctx, base + 51, base, bones_b)
+    pal_a, pal_b = ctx.malloc(2 * len(bones_a) * 64), ctx.malloc(2 * len(bones_b) * 64)
+    p.set_palette_output(base + 50, pal_a.ptr)
+    p.set_palette_output(base + 51, pal_b.ptr)
+    mesh_a = synth.make_mesh(30_000, len(bones_a), synth.SEED_BASE + 22)
+    mesh_b = synth.make_mesh(5_001, len(bones_b), synth.SEED_BASE + 23)
+    ctx.mesh_upload_soa(base + 60, mesh_a.pos, mesh_a.weights, mesh_a.indices, mesh_a.normal, mesh_a.tangent)
+    ctx.mesh_upload_soa(base + 61, mesh_b.pos, mesh_b.weights, mesh_b.indices, mesh_b.normal, mesh_b.tangent)
+    fa, sa = Outs(ctx, 2 * 30_000), Outs(ctx, 2 * 30_000)
+    fb, sb = Outs(ctx, 2 * 5_001), Outs(ctx, 2 * 5_001)
+    p.set_skin_output(base + 50, base + 60, fa.pos.ptr, fa.nrm.ptr, fa.tan.ptr)
+    p.set_skin_output(base + 51, base + 61, fb.pos.ptr, 0, 0)          # position only
+    forms = [(1, 1, 1, 1, 0), (0, 1, 1, 1, 1), (1, 0, 1, 1, 2), (1, 1, 0, 1, 1), (1, 1, 1, 0, 4), (0, 0, 0, 0, 1), (1, 1, 1, 1, 16), (1, 1, 1, 1, 2)]
+    try:
+        for f in range(24):
+            fs, one, inl, lean, units = forms[f % len(forms)]
+            for k, v in (("anim.frame_skin", fs), ("anim.one_launch", one), ("anim.inline_ctrl", inl), ("anim.update_lean", lean), ("anim.frame_skin_units", units)):
+                ctx.set_option(k, v)
+            _oupdate(o, sc)
+            _update(p, sc)
+            ctx.lbs_skin_device(base + 60, pal_a.ptr, len(bones_a), 2, sa.pos.ptr, sa.nrm.ptr, sa.tan.ptr)
+            ctx.lbs_skin_device(base + 61, pal_b.ptr, len(bones_b), 2, sb.pos.ptr, 0, 0)
+            for x, y in zip(fa.get(), sa.get()):
+                assert np.array_equal(x, y), f"frame {f} form {forms[f % len(forms)]}: mesh a"
+            assert np.array_equal(fb.get()[0], sb.get()[0]), f"frame {f} form {forms[f % len(forms)]}: mesh b"
+            assert np.isnan(fb.nrm.download(np.float32, 16)).all(), "an output that is not wanted is not written"
+            check_frame(p, o, sc, 2, f)
+        ref_b = o.palette(bones_b)
+        got_b = pal_b.download(np.float32, 2 * len(bones_b) * 16).reshape(2, len(bones_b), 16)
+        assert np.array_equal(got_b[0].view(np.uint32), ref_b.view(np.uint32))
+        assert np.array_equal(got_b[0, 0], np.eye(4, dtype=np.float32).reshape(16)), "invalid bone handle -> identity"
+    finally:
+        for k, v in (("anim.frame_skin", 1), ("anim.one_launch", 1), ("anim.inline_ctrl", 1), ("anim.update_lean", 1), ("anim.frame_skin_units", 0)):
+            ctx.set_option(k, v)
+        o.close()
+        p.free()
+        for b in (fa, sa, fb, sb):
+            b.free()
+        pal_a.free()
+        pal_b.free()
+        ctx.mesh_free(base + 60)
+        ctx.mesh_free(base + 61)
+
+
+@pytest.mark.parametrize("what", ["crowd", "root_motion", "scene", "update_transforms", "fused_arithmetic"])
+def test_frames_that_cannot_take_the_skinning_along(ctx, orc, what):
+    """A crowd (the frame is not one launch), root motion (two more kernels), fyx_scene_update, fyx_animator_update_transforms, and
+    lbs.exact = 0: the skin outputs are still written by the update call, with fyx_lbs_skin_device's bits."""
+    if what == "root_motion":
+        sc = cases.with_root_motion_and_signals(cases.transitions)()
+    else:
+        sc = cases.c5_blend_tree(euler_every=10 ** 6)
+    n_inst = 40 if what == "crowd" else 1
+    nb = sc.rig.n_nodes
+    p = cases.build_product(ctx, sc, n_inst)
+    base = p.base_id
+    A.create_bone_list(ctx, base + 50, base, list(range(nb)))
+    d_pal = ctx.malloc(n_inst * nb * 64)
+    p.set_palette_output(base + 50, d_pal.ptr)
+    nv = 3000
+    mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + 24)
+    ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    fused, sep = Outs(ctx, n_inst * nv), Outs(ctx, n_inst * nv)
+    p.set_skin_output(base + 50, base + 60, fused.pos.ptr, fused.nrm.ptr, fused.tan.ptr)
+    if what == "fused_arithmetic":
+        ctx.set_option("lbs.exact", 0)
+    try:
+        for f in range(6):
+            if what == "scene":
+                A.scene_update(ctx, [p], sc.dt)
+            elif what == "update_transforms":
+                p.update_transforms()
+            else:
+                _update(p, sc)
+            ctx.lbs_skin_device(base + 60, d_pal.ptr, nb, n_inst, sep.pos.ptr, sep.nrm.ptr, sep.tan.ptr)
+            for a, b in zip(fused.get(), sep.get()):
+                assert np.array_equal(a, b), f"{what}: frame {f}"
+    finally:
+        ctx.set_option("lbs.exact", 1)
+        p.free()
+        for b in (fused, sep):
+            b.free()
+        d_pal.free()
+        ctx.mesh_free(base + 60)
+
+
+def test_skin_output_arguments_are_checked(ctx):
+    sc = cases.player_only()
+    nb = sc.rig.n_nodes
+    p = cases.build_product(ctx, sc, 1)
+    base = p.base_id
+    A.create_bone_list(ctx, base + 50, base, list(range(nb)))
+    A.create_bone_list(ctx, base + 51, base, list(range(4)))
+    d_pal, d_out = ctx.malloc(nb * 64), ctx.malloc(1000 * 16 + 64)
+    mesh = synth.make_mesh(1000, nb, synth.SEED_BASE + 25)
+    ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices)          # no normals, no tangents
+    try:
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            p.set_skin_output(base + 50, base + 60, d_out.ptr)                    # not a palette output yet
+        assert e.value.code == _native.FYX_ERR_INVALID_ARG
+        p.set_palette_output(base + 50, d_pal.ptr)
+        p.set_palette_output(base + 51, d_pal.ptr)
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            p.set_skin_output(base + 50, base + 61, d_out.ptr)                    # unknown mesh
+        assert e.value.code == _native.FYX_ERR_UNKNOWN_ID
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            p.set_skin_output(base + 50, base + 60, d_out.ptr, d_out.ptr)         # the mesh has no normals
+        assert e.value.code == _native.FYX_ERR_MISSING_ATTRIBUTE
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            p.set_skin_output(base + 51, base + 60, d_out.ptr)                    # the mesh references bones the list does not have
+        assert e.value.code == _native.FYX_ERR_BONE_INDEX
+        p.set_skin_output(base + 50, base + 60, d_out.ptr)
+        p.update_animations(sc.dt)
+        ctx.mesh_free(base + 60)                                                  # freed while registered: the next update says so
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            p.update_animations(sc.dt)
+        assert e.value.code == _native.FYX_ERR_UNKNOWN_ID
+        p.set_palette_output(base + 50, 0)                                        # removing the palette output removes its skin outputs
+        p.update_animations(sc.dt)
+        ctx.sync()
+    finally:
+        p.free()
+        d_pal.free()
+        d_out.free()
+
+
+def test_a_wait_that_cannot_be_satisfied_is_an_error_not_a_stale_frame(ctx, orc):
+    """The device counter of the one-launch frame poisoned from outside (fyx_debug_frame_counter_add): the frame's update and skinning
+    workgroups give up after anim.wait_timeout_ms, compute NOTHING (palette and vertices keep the previous frame's values, which is
+    what the error says), the next call returns FYX_ERR_HIP naming the escape hatch, the context falls back to separate launches
+    and goes on bit-exact; with the counter repaired the one-launch form works again."""
+    sc = cases.c5_blend_tree(euler_every=10 ** 6)
+    nb = sc.rig.n_nodes
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, 1)
+    base = p.base_id
+    A.create_bone_list(ctx, base + 50, base, list(range(nb)))
+    d_pal = ctx.malloc(nb * 64)
+    p.set_palette_output(base + 50, d_pal.ptr)
+    mesh = synth.make_mesh(4000, nb, synth.SEED_BASE + 26)
+    ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    outs = Outs(ctx, 4000)
+    p.set_skin_output(base + 50, base + 60, outs.pos.ptr, outs.nrm.ptr, outs.tan.ptr)
+    ctx.set_option("anim.wait_timeout_ms", 20)
+    try:
+        for f in range(3):
+            _oupdate(o, sc)
+            _update(p, sc)
+        ctx.sync()
+        pal_before, pos_before = d_pal.download(np.uint32, nb * 16), outs.pos.download(np.uint32, 4000 * 3)
+        l = _native.lib()
+        assert l.fyx_debug_frame_counter_add(ctx._h, p.id, -100000) == 0
+        _oupdate(o, sc)
+        _update(p, sc)                       # the launch is issued; its workgroups will give up
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            ctx.sync()
+        assert e.value.code == _native.FYX_ERR_HIP
+        msg = str(e.value)
+        assert "anim.one_launch" in msg and "NOTHING" in msg and str(p.id) in msg, msg
+        assert ctx.get_option("anim.one_launch") == 0
+        assert np.array_equal(d_pal.download(np.uint32, nb * 16), pal_before), "a frame that gave up must not write a palette"
+        assert np.array_equal(outs.pos.download(np.uint32, 4000 * 3), pos_before), "... nor vertices"
+        # the host side is one frame ahead of the device now (as after any HIP error inside an update); separate launches from here on
+        for f in range(3):
+            _oupdate(o, sc)
+            _update(p, sc)
+        ctx.sync()
+        ref_pal = o.palette(list(range(nb)))
+        assert np.array_equal(d_pal.download(np.float32, nb * 16).reshape(nb, 16).view(np.uint32), ref_pal.view(np.uint32))
+        ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, ref_pal, mesh.normal, mesh.tangent)
+        assert np.array_equal(outs.pos.download(np.float32, 4000 * 3).reshape(-1, 3).view(np.uint32), ref["pos"].view(np.uint32))
+        # repaired: the one-launch form again
+        assert l.fyx_debug_frame_counter_add(ctx._h, p.id, 100000) == 0
+        ctx.set_option("anim.one_launch", 1)
+        for f in range(3):
+            _oupdate(o, sc)
+            _update(p, sc)
+        ctx.sync()
+        ref_pal = o.palette(list(range(nb)))
+        assert np.array_equal(d_pal.download(np.float32, nb * 16).reshape(nb, 16).view(np.uint32), ref_pal.view(np.uint32))
+        ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, ref_pal, mesh.normal, mesh.tangent)
+        assert np.array_equal(outs.pos.download(np.float32, 4000 * 3).reshape(-1, 3).view(np.uint32), ref["pos"].view(np.uint32))
+    finally:
+        ctx.set_option("anim.wait_timeout_ms", 500)
+        ctx.set_option("anim.one_launch", 1)
+        o.close()
+        p.free()
+        outs.free()
+        d_pal.free()
+        ctx.mesh_free(base + 60)
+
+
+def test_frames_that_skin_over_many_frames_beside_a_chip_filling_co_runner(ctx):
+    """10 000 one-launch frames that skin, with a chip-filling skinning launch of another mesh in flight on the library's launch streams
+    all the time (the places the frame's workgroups wait in are contended), against an animator in the same state that runs as
+    separate launches: palettes and vertices bit for bit, checked every 500 frames and at the end."""
+    sc = cases.c5_blend_tree(euler_every=10 ** 6)
+    nb = sc.rig.n_nodes
+    ps, pals, outs = [], [], []
+    nv = 20_000
+    mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + 27)
+    big = synth.make_mesh(1_000_000, nb, synth.SEED_BASE + 28)
+    for k in range(2):
+        p = cases.build_product(ctx, sc, 1)
+        A.create_bone_list(ctx, p.base_id + 50, p.base_id, list(range(nb)))
+        d = ctx.malloc(nb * 64)
+        p.set_palette_output(p.base_id + 50, d.ptr)
+        ps.append(p)
+        pals.append(d)
+        outs.append(Outs(ctx, nv))
+    ctx.mesh_upload_soa(9710, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    ctx.mesh_upload_soa(9711, big.pos, big.weights, big.indices, big.normal, big.tangent)
+    big_out = Outs(ctx, 1_000_000)
+    big_pal = ctx.malloc(nb * 64)
+    big_pal.upload(synth.make_palette(nb, synth.SEED_BASE + 28))
+    ps[0].set_skin_output(ps[0].base_id + 50, 9710, outs[0].pos.ptr, outs[0].nrm.ptr, outs[0].tan.ptr)
+    try:
+        for f in range(10_000):
+            ctx.lbs_skin_device(9711, big_pal.ptr, nb, 1, big_out.pos.ptr, big_out.nrm.ptr, big_out.tan.ptr)      # a launch stream: beside the frames
+            ctx.set_option("anim.one_launch", 1)
+            ps[0].update_machine(sc.dt)
+            ctx.set_option("anim.one_launch", 0)
+            ps[1].update_machine(sc.dt)
+            ctx.lbs_skin_device(9710, pals[1].ptr, nb, 1, outs[1].pos.ptr, outs[1].nrm.ptr, outs[1].tan.ptr)
+            if f % 500 == 499 or f < 3:
+                assert np.array_equal(pals[0].download(np.uint32, nb * 16), pals[1].download(np.uint32, nb * 16)), f"frame {f}: palettes"
+                for a, b in zip(outs[0].get(), outs[1].get()):
+                    assert np.array_equal(a, b), f"frame {f}: vertices"
+        ctx.sync()
+    finally:
+        ctx.set_option("anim.one_launch", 1)
+        for p in ps:
+            p.free()
+        for b in outs + [big_out]:
+            b.free()
+        for b in pals + [big_pal]:
+            b.free()
+        ctx.mesh_free(9710)
+        ctx.mesh_free(9711)
