@@ -243,6 +243,26 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     ctx.set_option("anim.overlap", 0)
     p.set_palette_output(base + 50, d_pal.ptr)
     ctx.sync()
+    # one character: the frame as ONE launch through to the vertices (fyx_animator_set_skin_output: the pose launch also holds the
+    # skinning workgroups, which form the palette on chip) -- the update call is the whole frame
+    frame_one_launch_ms, one_launch_identical = None, None
+    if n_instances < 4:
+        p.set_skin_output(base + 50, base + 60, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+        for _ in range(60):
+            update(sc.dt)
+        ctx.sync()
+        ctx.timer_begin()
+        for _ in range(frames):
+            update(sc.dt)
+        frame_one_launch_ms = ctx.timer_end() / frames
+        a = [d_pos.download(np.uint32, nv * 3), d_nrm.download(np.uint32, nv * 3), d_tan.download(np.uint32, nv * 4)]
+        p.set_skin_output(base + 50, base + 60)
+        ctx.lbs_skin_device(base + 60, d_pal.ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+        ctx.sync()
+        b = [d_pos.download(np.uint32, nv * 3), d_nrm.download(np.uint32, nv * 3), d_tan.download(np.uint32, nv * 4)]
+        one_launch_identical = all(bool(np.array_equal(x, y)) for x, y in zip(a, b))
+        if not one_launch_identical:
+            raise SystemExit(f"{name}: the one-launch frame's vertices differ from fyx_lbs_skin_device on the same palette")
     ctx.timer_begin()
     for _ in range(frames):
         frame(skin=False)
@@ -306,14 +326,20 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
                                   "frac": unique / (fk * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_us": fk, "launch_period_us": f_ms * 1e3},
                      "parity": {"instances_checked": sorted(refs_gpu_pal), "max_rel_err": f_err, "tolerance": 1e-5, "bit_exact": False,
                                 "note": "against the oracle on the GPU-built palettes; north_star allows 1e-5 relative"}}
-    best_ms = min(frame_ms, frame_serial_ms)
-    rec = {"workload": name, "frame_ms": best_ms, "frame_mode": "pipelined" if frame_ms < frame_serial_ms else "one_stream",
-           "frame_ms_pipelined": frame_ms, "frame_ms_one_stream": frame_serial_ms, "pose_ms": pose_ms, "skin_ms": skin_ms,
+    modes = {"pipelined": frame_ms, "one_stream": frame_serial_ms}
+    if frame_one_launch_ms is not None:
+        modes["one_launch"] = frame_one_launch_ms
+    best_mode = min(modes, key=modes.get)
+    best_ms = modes[best_mode]
+    rec = {"workload": name, "frame_ms": best_ms, "frame_mode": best_mode,
+           "frame_ms_pipelined": frame_ms, "frame_ms_one_stream": frame_serial_ms, "frame_ms_one_launch": frame_one_launch_ms,
+           "one_launch_vertices_bit_identical_to_lbs_skin": one_launch_identical, "pose_ms": pose_ms, "skin_ms": skin_ms,
            "frame_over_skin": best_ms / skin_ms,
            "frame_roofline_frac": unique / (best_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "frame_note": "pipelined: whole frames alternate between two streams (anim.overlap = 1, two palette buffers): frame n + 1's pose kernels "
-                         "run beside frame n's skinning; one_stream: the whole frame as one dependent chain on one stream; frame_ms is the faster "
-                         "of the two (the host picks the mode per scene); frame_roofline_frac = the skinning's unique bytes / frame_ms / 8 TB/s: "
+                         "run beside frame n's skinning; one_stream: the whole frame as one dependent chain on one stream; one_launch (one character): "
+                         "fyx_animator_set_skin_output -- sampler, update and skinning workgroups in ONE launch, the update call is the frame; frame_ms is "
+                         "the fastest (the host picks the mode per scene); frame_roofline_frac = the skinning's unique bytes / frame_ms / 8 TB/s: "
                          "the frame end to end against the HBM roofline",
            "skinned_vertices_per_s_frame": nv / (best_ms * 1e-3), "skinned_vertices_per_s_skin": nv / (skin_ms * 1e-3),
            "roofline": {"bound": "hbm", "kernel": "lbs_skin_crowd" if n_instances >= 4 else "lbs_skin",
@@ -1055,8 +1081,8 @@ def main():
             alls2.append(o)
             scalls2.append(partial(fn, ctx._h, ctypes.c_uint64(150 + s_), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
                                    ctypes.c_void_p(o[0].data_ptr() + 12 * b2), ctypes.c_void_p(o[1].data_ptr() + 12 * b2), ctypes.c_void_p(o[2].data_ptr() + 16 * b2)))
-            gcalls2.append(partial(gather, ctx._h, ctypes.c_uint32(full.n_verts), ctypes.c_void_p(o[0].data_ptr()), ctypes.c_void_p(o[1].data_ptr()),
-                                   ctypes.c_void_p(o[2].data_ptr())))
+            gcalls2.append(partial(ctx._l.fyx_allgather_skinned_padded, ctx._h, ctypes.c_uint32(full.n_verts), ctypes.c_uint32(world * shard2),
+                                   ctypes.c_void_p(o[0].data_ptr()), ctypes.c_void_p(o[1].data_ptr()), ctypes.c_void_p(o[2].data_ptr())))
 
         def sstep(i: int, with_gather: bool, padded: bool = False):
             rc = (scalls2 if padded else scalls)[i % sets2]() if (e2 > b2 if padded else e > b) else 0

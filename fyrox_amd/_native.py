@@ -189,6 +189,8 @@ _SIGS = {
     "fyx_allgather_skinned": (c_int, [_P, c_uint32, _P, _P, _P]),
     "fyx_comm_init_all": (c_int, [_P, c_int]),
     "fyx_allgather_skinned_all": (c_int, [_P, c_int, c_uint32, _P, _P, _P]),
+    "fyx_allgather_skinned_padded": (c_int, [_P, c_uint32, c_uint32, _P, _P, _P]),
+    "fyx_allgather_skinned_padded_all": (c_int, [_P, c_int, c_uint32, c_uint32, _P, _P, _P]),
     "fyx_animator_plan_root_motion": (c_int, [_P, c_uint64, _P, _P, c_uint32, POINTER(c_uint32), POINTER(c_uint32), _P]),
 }
 

@@ -177,6 +177,11 @@ class Context:
         self._check(self._l.fyx_allgather_skinned(self._h, n_verts, d_pos_all or None, d_normal_all or None,
                                                   d_tangent_all or None))
 
+    def allgather_skinned_padded(self, n_verts: int, capacity_verts: int, d_pos_all: int = 0, d_normal_all: int = 0, d_tangent_all: int = 0) -> None:
+        """fyx_allgather_skinned_padded: equal padded shards, ONE in-place all-gather per stream; every buffer holds capacity_verts vertices."""
+        self._check(self._l.fyx_allgather_skinned_padded(self._h, n_verts, capacity_verts, d_pos_all or None, d_normal_all or None,
+                                                         d_tangent_all or None))
+
     # -- one process, several GPUs (every call from one thread) ---------------------------
     @staticmethod
     def comm_init_all(contexts) -> None:
@@ -196,6 +201,18 @@ class Context:
         h = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
         contexts[0]._check(contexts[0]._l.fyx_allgather_skinned_all(h, len(contexts), n_verts, arr(d_pos_all), arr(d_normal_all),
                                                                     arr(d_tangent_all)))
+
+    @staticmethod
+    def allgather_skinned_padded_all(contexts, n_verts: int, capacity_verts: int, d_pos_all=None, d_normal_all=None, d_tangent_all=None) -> None:
+        """fyx_allgather_skinned_padded_all: the padded form (one in-place all-gather per stream) for every GPU of the process."""
+        def arr(ptrs):
+            if ptrs is None:
+                return None
+            assert len(ptrs) == len(contexts)
+            return (ctypes.c_void_p * len(ptrs))(*[int(p) if p else None for p in ptrs])
+        h = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
+        contexts[0]._check(contexts[0]._l.fyx_allgather_skinned_padded_all(h, len(contexts), n_verts, capacity_verts, arr(d_pos_all),
+                                                                           arr(d_normal_all), arr(d_tangent_all)))
 
     # -- mesh registry -------------------------------------------------------------------
     def mesh_upload(self, mesh_id: int, aos: np.ndarray, n_verts: int, stride: int, *, off_pos: int,

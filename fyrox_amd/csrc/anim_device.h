@@ -636,19 +636,24 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         S.offsets[k] = total;
         total += S.layouts[k].total;
     }
-    int slot = 0;
-    char *h = nullptr, *d = nullptr;
-    if (int rc = ctrl_acquire(c, S.ctrl, std::max<size_t>(total, 16), &slot, &h, &d)) return rc;
     S.h_jobs.resize(n * sizeof(SceneJobDev));      // (every byte of a job is written below: frame_static and rig_dev start from zeros)
     SceneJobDev* jobs = reinterpret_cast<SceneJobDev*>(S.h_jobs.data());
     for (size_t k = 0; k < n; ++k) {
         const Animator& A = *S.animators[k];
-        ctrl_write(A, S.layouts[k], h + S.offsets[k]);
         frame_static(c, A, jobs[k].f);
         ctrl_bind(A, S.layouts[k], reinterpret_cast<const char*>(S.offsets[k]), jobs[k].f);     // offsets from the block's start
         if (int rc = rig_params(c, A, jobs[k].rig)) return rc;
     }
-    if (S.h_jobs != S.sent_jobs) {
+    // A job array that changed travels through the frame's PINNED staging block, behind the control sections (the block is not
+    // rewritten before the event behind this frame's kernels: ctrl_consumed) -- not from the pageable vector, which the next frame
+    // rewrites while a copy the runtime chose to make asynchronous might still read it.
+    const bool send_jobs = S.h_jobs != S.sent_jobs;
+    const size_t o_jobs = align_up(std::max<size_t>(total, 16), 256);
+    int slot = 0;
+    char *h = nullptr, *d = nullptr;
+    if (int rc = ctrl_acquire(c, S.ctrl, send_jobs ? o_jobs + S.h_jobs.size() : std::max<size_t>(total, 16), &slot, &h, &d)) return rc;
+    for (size_t k = 0; k < n; ++k) ctrl_write(*S.animators[k], S.layouts[k], h + S.offsets[k]);
+    if (send_jobs) {
         if (S.h_jobs.size() > S.d_jobs_capacity) {
             if (int rc_ = sync_all(c)) return rc_;       // launches in flight read the old array
             dfree(S.d_jobs);
@@ -658,12 +663,13 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
             FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&S.d_jobs), S.h_jobs.size()));
             S.d_jobs_capacity = S.h_jobs.size();
         }
-        // in stream order behind the previous frame's pose kernels (enter_pose), whichever stream they ran on; pageable source:
-        // the runtime stages it before the call returns
-        FYX_HIP(c, hipMemcpyAsync(S.d_jobs, S.h_jobs.data(), S.h_jobs.size(), hipMemcpyHostToDevice, ps));
+        memcpy(h + o_jobs, S.h_jobs.data(), S.h_jobs.size());
+        // in stream order behind the previous frame's pose kernels (enter_pose), whichever stream they ran on
+        FYX_HIP(c, hipMemcpyAsync(S.d_jobs, h + o_jobs, S.h_jobs.size(), hipMemcpyHostToDevice, ps));
         S.sent_jobs = S.h_jobs;
     }
     if (int rc = ctrl_upload(c, S.ctrl, slot, std::max<size_t>(total, 16), ps)) return rc;
+    if (send_jobs) S.ctrl.h_by_consumed[slot] = true;     // the staging block also fed a copy on `ps`: free when the event behind this frame's kernels is
 
     // 4. one launch per stage
     const uint4* tabs[kSceneStages];

@@ -84,6 +84,23 @@ uint32_t padded_shard(uint32_t n_verts, uint64_t n_ranks) {
     return (uint32_t)(((groups + n_ranks - 1) / n_ranks) * kShardAlign);
 }
 
+// The padded form moves n_ranks * shard vertices per stream: it exists only behind entry points that are told what the buffers hold
+// (fyx_allgather_skinned_padded*).  The ragged entry points refuse comm.form = 2 -- an option must not change how much a call writes.
+int padded_form_check(fyx_ctx* c, bool padded, uint32_t n_verts, uint32_t capacity_verts, int n_ranks) {
+    if (!padded) {
+        if (c->comm_form == 2)
+            return fail(c, FYX_ERR_INVALID_ARG, "comm.form = 2 (one all-gather over padded shards) writes n_ranks * shard_verts vertices per stream: "
+                                                 "call fyx_allgather_skinned_padded[_all], which takes the buffers' capacity");
+        return FYX_OK;
+    }
+    const uint64_t need = (uint64_t)padded_shard(n_verts, (uint64_t)n_ranks) * (uint64_t)n_ranks;
+    if (need > 0xffffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "n_ranks * shard_verts = %llu does not fit 32 bits", (unsigned long long)need);
+    if ((uint64_t)capacity_verts < need)
+        return fail(c, FYX_ERR_INVALID_ARG, "the padded exchange of %u vertices over %d ranks writes %llu vertices per stream; the buffers hold %u "
+                                             "(fyx_shard_vertex_range_padded: n_ranks * shard_verts)", n_verts, n_ranks, (unsigned long long)need, capacity_verts);
+    return FYX_OK;
+}
+
 // One rank's calls for one stream of the exchange, inside an open RCCL group.  `base` is that rank's full buffer, `me` its rank.
 //   form 0: one broadcast per shard, in place (root = the shard's owner);
 //   form 1: the rank sends its own shard to every other rank and receives every other shard where it belongs -- point to point,
@@ -218,15 +235,16 @@ int fyx_comm_info(fyx_ctx* c, int* rank, int* n_ranks) {
     FYX_GUARD_END(c)
 }
 
-int fyx_allgather_skinned(fyx_ctx* c, uint32_t n_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all) {
-    if (!c) return FYX_ERR_INVALID_ARG;
-    FYX_GUARD_BEGIN
+// capacity_verts: vertices every d_*_all holds (the padded form writes n_ranks * shard_verts of them); 0: the ragged forms of the option
+static int allgather_one(fyx_ctx* c, uint32_t n_verts, uint32_t capacity_verts, bool padded, float* d_pos_all, float* d_normal_all, float* d_tangent_all) {
+    {
     if (!c->comm || !c->comm->comm) return fail(c, FYX_ERR_INVALID_ARG, "no communicator: call fyx_comm_init first");
     if (n_verts == 0 || (!d_pos_all && !d_normal_all && !d_tangent_all)) return FYX_OK;
     Comm& k = *c->comm;
+    if (int rc = padded_form_check(c, padded, n_verts, capacity_verts, k.n_ranks)) return rc;
     // on the context stream, after every skinning launch in flight (the shard must be complete before it is sent)
     if (int rc = enter_primary(c)) return rc;
-    const int form = c->comm_form;
+    const int form = padded ? 2 : c->comm_form;
     if (form == 1 && (!k.send || !k.recv)) return fail(c, FYX_ERR_UNSUPPORTED, "comm.form=1 needs ncclSend / ncclRecv, which this librccl lacks");
     struct { float* p; uint32_t width; } streams[3] = {{d_pos_all, 3}, {d_normal_all, 3}, {d_tangent_all, 4}};
     int rc = k.group_start();
@@ -240,6 +258,20 @@ int fyx_allgather_skinned(fyx_ctx* c, uint32_t n_verts, float* d_pos_all, float*
     if (first_err) return rccl_fail(c, k, first_err, form == 2 ? "ncclAllGather" : form ? "ncclSend / ncclRecv" : "ncclBroadcast");
     if (rc) return rccl_fail(c, k, rc, "ncclGroupEnd");
     return FYX_OK;
+    }
+}
+
+int fyx_allgather_skinned(fyx_ctx* c, uint32_t n_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    return allgather_one(c, n_verts, 0, false, d_pos_all, d_normal_all, d_tangent_all);
+    FYX_GUARD_END(c)
+}
+
+int fyx_allgather_skinned_padded(fyx_ctx* c, uint32_t n_verts, uint32_t capacity_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    return allgather_one(c, n_verts, capacity_verts, true, d_pos_all, d_normal_all, d_tangent_all);
     FYX_GUARD_END(c)
 }
 
@@ -289,8 +321,8 @@ int fyx_comm_init_all(fyx_ctx* const* ctxs, int n) {
     FYX_GUARD_END(c)
 }
 
-int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, float* const* d_pos_all, float* const* d_normal_all,
-                              float* const* d_tangent_all) {
+static int allgather_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, uint32_t capacity_verts, bool padded, float* const* d_pos_all,
+                         float* const* d_normal_all, float* const* d_tangent_all) {
     if (!ctxs || n < 1) return FYX_ERR_INVALID_ARG;
     for (int i = 0; i < n; ++i)
         if (!ctxs[i]) return FYX_ERR_INVALID_ARG;
@@ -302,6 +334,7 @@ int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, flo
         if (k->n_ranks != n || k->rank != i) return fail(c, FYX_ERR_INVALID_ARG, "context %d is rank %d of %d: pass the contexts of fyx_comm_init_all, in order", i, k->rank, k->n_ranks);
     }
     if (n_verts == 0 || (!d_pos_all && !d_normal_all && !d_tangent_all)) return FYX_OK;
+    if (int rc = padded_form_check(c, padded, n_verts, capacity_verts, n)) return rc;
     float* const* sets[3] = {d_pos_all, d_normal_all, d_tangent_all};
     for (int s = 0; s < 3; ++s)
         if (sets[s])
@@ -311,7 +344,7 @@ int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, flo
     for (int i = 0; i < n; ++i)
         if (int rc = enter_primary(ctxs[i])) return i == 0 ? rc : fail(c, rc, "context %d: %s", i, ctxs[i]->err.c_str());
     Comm& k0 = *c->comm;
-    const int form = c->comm_form;
+    const int form = padded ? 2 : c->comm_form;
     if (form == 1 && (!k0.send || !k0.recv)) return fail(c, FYX_ERR_UNSUPPORTED, "comm.form=1 needs ncclSend / ncclRecv, which this librccl lacks");
     const uint32_t widths[3] = {3, 3, 4};
     int rc = k0.group_start();
@@ -332,6 +365,16 @@ int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, flo
     if (rc) return rccl_fail(c, k0, rc, "ncclGroupEnd");
     return FYX_OK;
     FYX_GUARD_END(c)
+}
+
+int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, float* const* d_pos_all, float* const* d_normal_all,
+                              float* const* d_tangent_all) {
+    return allgather_all(ctxs, n, n_verts, 0, false, d_pos_all, d_normal_all, d_tangent_all);
+}
+
+int fyx_allgather_skinned_padded_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, uint32_t capacity_verts, float* const* d_pos_all,
+                                     float* const* d_normal_all, float* const* d_tangent_all) {
+    return allgather_all(ctxs, n, n_verts, capacity_verts, true, d_pos_all, d_normal_all, d_tangent_all);
 }
 
 }  // extern "C"

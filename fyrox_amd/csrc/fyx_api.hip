@@ -4,7 +4,7 @@
 #include "fyx_ctx.h"
 
 namespace fyx {
-// The events of the pose path -- a frame's pose update done (pose_done), the other frame stream joined (alt_done), a control block
+// The events of the pose path -- a frame's pose update done (pose_done), a control block
 // consumed -- only order kernels of THIS device that read what kernels of this device wrote: their release need not be a
 // system-scope one (which writes the L2 back and invalidates it under whatever kernel is running).  FYX_EVENT_SCOPE=system restores
 // the runtime's default for an A/B.  The events around the launch streams (worker_done, fork_ev) keep the default: what is ordered
@@ -106,7 +106,9 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
     c->frame_idx = idx;
     if (!c->alt_stream) {
         FYX_HIP(c, make_stream(c, true, &c->alt_stream));
-        FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, order_event_flags()));
+        // (the join of the frame stream into the context stream keeps the system scope: under anim.overlap the frame streams carry the
+        // skinning launches too, and what waits behind this event on the context stream may be an RCCL exchange or a copy to the host)
+        FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->pose_done[k], order_event_flags()));
     }
     hipStream_t target = idx ? c->alt_stream : c->stream;
@@ -130,6 +132,10 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
 int exit_pose(fyx_ctx* c) {
     if (!c->pose_overlap || !c->alt_stream) return FYX_OK;
     const int idx = c->frame_idx;
+    // work was enqueued on alt_stream since enter_pose: whatever joined the streams in between (ensure_device_state's sync_all, a
+    // control block that grew -- both hit an animator's FIRST frame) cleared the flag, and a fyx_sync / readback that follows the
+    // update directly must still wait for these kernels
+    if (idx) c->alt_busy = true;
     FYX_HIP(c, hipEventRecord(c->pose_done[idx], idx ? c->alt_stream : c->stream));
     c->pose_done_on = idx;
     return FYX_OK;

@@ -100,8 +100,21 @@ int fyx_join(fyx_ctx* ctx);
  *     "anim.one_launch"  1 (default) = an animator whose control block fits the kernel arguments (one character, a few instances)
  *                        and that tracks neither root motion nor property values runs its sampler and its update as ONE launch:
  *                        the update's workgroups lie behind the sampler's in the same grid and wait on a device counter the
- *                        sampler's workgroups add to (workgroups are dispatched in index order: the waiting one never holds a
- *                        place a sampler needs).  0 = two launches.  Same results bit for bit
+ *                        sampler's workgroups add to.  0 = two launches.  Same results bit for bit.
+ *                        ASSUMPTION, and what happens when it fails: a waiting workgroup must never hold the place a workgroup it
+ *                        waits for needs.  The launch is sized so that its WHOLE grid is resident at once on an otherwise idle
+ *                        MI355X (then no order of dispatch can starve a sampler); beside other kernels it relies on the
+ *                        dispatcher handing out a grid's workgroups in index order (samplers first), which gfx9 hardware does
+ *                        and HIP does not promise.  A wait is therefore BOUNDED ("anim.wait_timeout_ms"): a workgroup that
+ *                        gives up writes a report, the frame computes NOTHING (poses, palettes and skin outputs keep the
+ *                        previous frame's values -- never a frame made of stale records), the next fyx_sync or pose update
+ *                        returns FYX_ERR_HIP with the animator, the counter and its target in fyx_last_error, and the context
+ *                        sets "anim.one_launch" = 0 for itself (separate launches, no in-grid wait).
+ *     "anim.frame_skin"  1 (default) = a one-launch frame also holds the workgroups that skin the animator's skin outputs
+ *                        (fyx_animator_set_skin_output); 0 = the update call issues the skinning launches behind the pose launch.
+ *                        "anim.frame_skin_units": 64-vertex units per wave of those workgroups, 0 (default) = the smallest depth
+ *                        that gives every skinning workgroup a CU of its own (C2: 1, C5: 2)
+ *     "anim.wait_timeout_ms" 1 .. 30000 (default 500): how long an in-grid wait of a one-launch frame lasts before it reports
  *     "anim.update_pack" 4 (default), 2 or 0: a crowd (>= 64 instances) of a rig of at most 64 nodes runs that lean update kernel
  *                        with this many instances per workgroup (one wave each, nothing shared): beside a crowd's skinning the
  *                        four waves take ONE of the places a skinning workgroup leaves instead of up to four (C3 frame 0.0979
@@ -749,8 +762,14 @@ int fyx_comm_info(fyx_ctx* ctx, int* rank, int* n_ranks);
  * over the xGMI links, no root and no tree).  Same bytes in the same places either way.
  * 2: ONE in-place ncclAllGather per stream over EQUAL shards -- the collective RCCL tunes hardest.  The shards are then the
  * padded cut of fyx_shard_vertex_range_padded (not the ragged one) and every d_*_all holds n_ranks * shard_verts vertices; the
- * vertices past n_verts in the last shard(s) are padding (whatever the buffer held travels; nothing reads it). */
+ * vertices past n_verts in the last shard(s) are padding (whatever the buffer held travels; nothing reads it).  Because that form
+ * WRITES n_ranks * shard_verts vertices per stream -- more than n_verts -- it runs only through fyx_allgather_skinned_padded[_all],
+ * which are told what the buffers hold (capacity_verts, in vertices, the same for every stream) and return FYX_ERR_INVALID_ARG when
+ * that is less than n_ranks * shard_verts (FYX_ERR_UNSUPPORTED when the product does not fit 32 bits); with "comm.form" = 2 the
+ * calls without a capacity refuse (FYX_ERR_INVALID_ARG): an option never changes how much a call writes.  The padded entry points
+ * always use the all-gather form, whatever the option says. */
 int fyx_allgather_skinned(fyx_ctx* ctx, uint32_t n_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all);
+int fyx_allgather_skinned_padded(fyx_ctx* ctx, uint32_t n_verts, uint32_t capacity_verts, float* d_pos_all, float* d_normal_all, float* d_tangent_all);
 /* ONE PROCESS driving several GPUs -- the engine is one process with one update thread, so this is the
  * form its shim uses: contexts ctxs[0..n) made by fyx_init on n different devices, every call from the same thread.
  * RCCL requires a thread that drives several communicators to issue each collective for all of them inside one group,
@@ -766,6 +785,8 @@ int fyx_allgather_skinned(fyx_ctx* ctx, uint32_t n_verts, float* d_pos_all, floa
 int fyx_comm_init_all(fyx_ctx* const* ctxs, int n);
 int fyx_allgather_skinned_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, float* const* d_pos_all,
                               float* const* d_normal_all, float* const* d_tangent_all);
+int fyx_allgather_skinned_padded_all(fyx_ctx* const* ctxs, int n, uint32_t n_verts, uint32_t capacity_verts, float* const* d_pos_all,
+                                     float* const* d_normal_all, float* const* d_tangent_all);
 
 /* ---- importer / editor helpers (pure host functions: no context, no GPU) ---------------- */
 /* Which points of a sampled curve the glTF importer keeps (fyrox-impl/src/resource/gltf/simplify.rs:39-66 find_important_points,

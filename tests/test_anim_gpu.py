@@ -1086,3 +1086,36 @@ def test_scene_update_argument_errors(ctx):
     assert e.value.code == fyrox_amd._native.FYX_ERR_INVALID_ARG
     ids = np.asarray([p.id, 0xdead], np.uint64)
     assert ctx._l.fyx_scene_update(ctx._h, ids.ctypes.data_as(__import__("ctypes").c_void_p), 2, 1 / 60) == fyrox_amd._native.FYX_ERR_UNKNOWN_ID
+
+
+def test_overlapped_update_then_sync_then_readback_without_a_skinning_call(orc):
+    """anim.overlap: a pose update runs on the context's second frame stream.  An animator's FIRST frame joins the streams on its way
+    (device state is created, the control block grows) -- which used to clear the "second stream has work" flag before the frame's
+    kernels were enqueued there, so a fyx_sync that followed the update directly (no skinning call in between to set the flag again)
+    returned before they had run.  Fresh context, every frame: update -> sync -> readback, palettes against the oracle."""
+    sc = cases.c5_blend_tree(euler_every=10 ** 6)
+    nb = sc.rig.n_nodes
+    with fyrox_amd.Context(0) as c2:
+        c2.set_option("anim.overlap", 1)
+        for one_launch in (1, 0):
+            c2.set_option("anim.one_launch", one_launch)
+            for n_inst in (1, 40):
+                o = cases.build_oracle(orc, sc)
+                p = cases.build_product(c2, sc, n_inst)
+                A.create_bone_list(c2, p.base_id + 50, p.base_id, list(range(nb)))
+                pals = [c2.malloc(n_inst * nb * 64) for _ in range(2)]
+                for d in pals:
+                    d.upload(np.zeros(n_inst * nb * 16, np.float32))
+                for f in range(6):
+                    p.set_palette_output(p.base_id + 50, pals[f & 1].ptr)
+                    o.update_machine(sc.dt)
+                    p.update_machine(sc.dt)
+                    c2.sync()
+                    got = pals[f & 1].download(np.float32, n_inst * nb * 16).reshape(n_inst, nb, 16)
+                    ref = o.palette(list(range(nb)))
+                    for i in (0, n_inst - 1):
+                        assert np.array_equal(got[i].view(np.uint32), ref.view(np.uint32)), f"one_launch={one_launch} instances={n_inst} frame {f}"
+                o.close()
+                p.free()
+                for d in pals:
+                    d.free()

@@ -925,7 +925,17 @@ def test_exchange_forms_agree_on_one_rank(ctx, orc):
             ctx.set_option("comm.form", form)
             assert ctx.get_option("comm.form") == form
             ctx.lbs_skin_device(7400, d_pal.ptr, 16, 1, d_p.ptr, d_n.ptr, d_t.ptr)
-            ctx.allgather_skinned(n, d_p.ptr, d_n.ptr, d_t.ptr)
+            if form == 2:
+                # the padded form writes n_ranks * shard vertices per stream: only through the entry point that is told the capacity
+                with pytest.raises(fyrox_amd.FyxError) as e:
+                    ctx.allgather_skinned(n, d_p.ptr, d_n.ptr, d_t.ptr)
+                assert e.value.code == fyrox_amd._native.FYX_ERR_INVALID_ARG and "fyx_allgather_skinned_padded" in str(e.value)
+                with pytest.raises(fyrox_amd.FyxError) as e:
+                    ctx.allgather_skinned_padded(n, n, d_p.ptr, d_n.ptr, d_t.ptr)          # buffers of n < shard vertices
+                assert e.value.code == fyrox_amd._native.FYX_ERR_INVALID_ARG
+                ctx.allgather_skinned_padded(n, shard, d_p.ptr, d_n.ptr, d_t.ptr)
+            else:
+                ctx.allgather_skinned(n, d_p.ptr, d_n.ptr, d_t.ptr)
             ctx.sync()
             assert np.array_equal(d_p.download(np.float32, n * 3).reshape(n, 3), ref["pos"])
             assert np.array_equal(d_t.download(np.float32, n * 4).reshape(n, 4), ref["tangent"])
