@@ -374,6 +374,7 @@ int fyx_animator_create(fyx_ctx* c, uint64_t animator_id, uint64_t rig_id, uint3
     a->rig = &rit->second;
     a->n_instances = n_instances;
     store(c).animators.emplace(animator_id, std::move(a));
+    ++store(c).animators_gen;
     return FYX_OK;
     FYX_GUARD_END(c)
 }
@@ -387,6 +388,7 @@ int fyx_animator_free(fyx_ctx* c, uint64_t animator_id) {
     if (has_device(c)) { if (int rc = enter_primary(c)) return rc; FYX_HIP(c, hipStreamSynchronize(c->stream)); }
     free_animator(*it->second);
     m.erase(it);
+    ++store(c).animators_gen;
     return FYX_OK;
     FYX_GUARD_END(c)
 }
@@ -546,7 +548,7 @@ int fyx_machine_set_parameter(fyx_ctx* c, uint64_t animator_id, uint32_t paramet
     p.kind = kind; p.f0 = f0; p.f1 = f1; p.u = u;
     auto assign = [&](MachineState& m) {
         Param& q = m.params[parameter];
-        if (q.kind != p.kind || memcmp(&q.f0, &p.f0, 4) || memcmp(&q.f1, &p.f1, 4) || q.u != p.u) m.memo_valid = false;
+        if (q.kind != p.kind || memcmp(&q.f0, &p.f0, 4) || memcmp(&q.f1, &p.f1, 4) || q.u != p.u) { m.memo_valid = false; A->steady_gen = 0; }
         q = p;
     };
     if (instance == FYX_ALL_INSTANCES) {
@@ -713,7 +715,7 @@ int fyx_layer_add_state(fyx_ctx* c, uint64_t animator_id, uint32_t layer, int32_
     const int32_t idx = (int32_t)L->states.size() - 1;
     if (L->initial_active < 0) L->initial_active = idx;
     for (MachineState& m : A->mstate)
-        if (layer < m.layers.size() && m.layers[layer].active_state < 0) { m.layers[layer].active_state = idx; m.memo_valid = false; }
+        if (layer < m.layers.size() && m.layers[layer].active_state < 0) { m.layers[layer].active_state = idx; m.memo_valid = false; A->steady_gen = 0; }
     if (out_state) *out_state = (uint32_t)idx;
     return FYX_OK;
     FYX_GUARD_END(c)
@@ -841,6 +843,7 @@ int fyx_machine_clear(fyx_ctx* c, uint64_t animator_id) {
         m.layers.clear();
         m.memo_valid = false;
     }
+    A->steady_gen = 0;
     A->state_anims.clear();
     A->rm_layer_base.clear();
     A->n_rm_slots = 0;
@@ -985,6 +988,12 @@ int fyx_absm_update(fyx_ctx* c, uint64_t animator_id, float dt) {
 
 static int scene_members(fyx_ctx* c, SceneBatch& S, const uint64_t* animator_ids, uint32_t n_animators) {
     if (n_animators && !animator_ids) return fail(c, FYX_ERR_INVALID_ARG, "null animator list");
+    // the same list as last frame over the same set of animators: the same members (a scene of 256 characters spent 10 us per frame
+    // on the duplicate check's hash set and the lookups)
+    if (S.members_gen == store(c).animators_gen && S.member_ids.size() == n_animators && S.animators.size() == n_animators &&
+        (n_animators == 0 || memcmp(S.member_ids.data(), animator_ids, (size_t)n_animators * 8) == 0))
+        return FYX_OK;
+    S.members_gen = 0;
     S.animators.clear();
     std::unordered_set<uint64_t> seen;
     for (uint32_t k = 0; k < n_animators; ++k) {
@@ -994,6 +1003,8 @@ static int scene_members(fyx_ctx* c, SceneBatch& S, const uint64_t* animator_ids
             return fail(c, FYX_ERR_INVALID_ARG, "animator %llu is listed twice", (unsigned long long)animator_ids[k]);
         S.animators.push_back(it->second.get());
     }
+    S.member_ids.assign(animator_ids, animator_ids + n_animators);
+    S.members_gen = store(c).animators_gen;
     return FYX_OK;
 }
 

@@ -711,10 +711,12 @@ int for_layer_states(fyx_ctx* c, Animator* A, uint32_t layer, uint32_t instance,
     if (instance != FYX_ALL_INSTANCES && instance >= A->n_instances) return fail(c, FYX_ERR_INVALID_ARG, "instance %u out of range", instance);
     ensure_machine_state(*A);
     if (instance == FYX_ALL_INSTANCES) {
+        A->steady_gen = 0;
         for (MachineState& m : A->mstate) { fn(m.layers[layer]); m.memo_valid = false; }
     } else {
         fn(A->mstate[instance].layers[layer]);
         A->mstate[instance].memo_valid = false;
+        A->steady_gen = 0;
     }
     return FYX_OK;
 }

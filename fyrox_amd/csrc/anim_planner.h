@@ -122,6 +122,7 @@ struct Planner {
     int error = 0;       // FYX_ERR_UNSUPPORTED when the fold nests too deep
     int depth = 0;
     bool touched = false;  // something has been blended into the pose the program is writing at this point (see emit_blend)
+    bool ticks_done = false;   // the frame's ticks were made by the steady path before it found a transition firing (plan_frame_core)
 
     Planner(Animator& a, PlanScratch& sc, uint32_t i, float dt_) : A(a), S(sc), inst(i), dt(dt_) {
         n_anims = (uint32_t)a.anims.size();
@@ -570,8 +571,9 @@ struct Planner {
                 if (check[k] >= 0 && (size_t)check[k] < L.states.size())
                     for (uint32_t a : A.state_anims[li][check[k]]) S.seen[a] = 1;   // collect(), done once per frame and state (plan_frame_core)
         }
-        for (uint32_t a = 0; a < n_anims; ++a)
-            if (S.seen[a] && as[a].enabled) tick(a);
+        if (!ticks_done)
+            for (uint32_t a = 0; a < n_anims; ++a)
+                if (S.seen[a] && as[a].enabled) tick(a);
         if (try_reuse()) return;
         S.recipes.clear();
         S.items.clear();
@@ -697,12 +699,127 @@ void plan_pool_destroy(PlanPool* p) { delete p; }
 
 namespace {
 
+bool logic_reads_clock(const std::vector<int32_t>& code) {
+    for (size_t pc = 0; pc < code.size();) {
+        const int32_t op = code[pc++];
+        if (op == FYX_LOGIC_IS_ANIMATION_ENDED) return true;
+        if (op == FYX_LOGIC_PARAMETER) ++pc;
+    }
+    return false;
+}
+
+// After a machine frame in which every instance's memo came out valid: what a steady frame has to do.
+void steady_prepare(Animator& A) {
+    A.steady_gen = 0;
+    if (!A.memo_static_ok || A.mstate.size() != A.n_instances || A.state_anims_gen != A.edit_gen) return;
+    const uint32_t na = (uint32_t)A.anims.size();
+    A.steady_ticks.assign((size_t)A.n_instances + 1, 0);
+    A.steady_list.clear();
+    A.steady_timed.clear();
+    std::vector<uint8_t> seen(na ? na : 1);
+    for (uint32_t i = 0; i < A.n_instances; ++i) {
+        const MachineState& ms = A.mstate[i];
+        if (!ms.memo_valid || ms.memo_gen != A.edit_gen || ms.layers.size() != A.layers.size()) return;
+        std::fill(seen.begin(), seen.end(), 0);
+        bool timed = false;
+        for (size_t li = 0; li < A.layers.size(); ++li) {
+            const LayerDef& L = A.layers[li];
+            const LayerState& LS = ms.layers[li];
+            if (LS.active_transition >= 0 || LS.active_state != LS.memo_state) return;
+            if (LS.active_state < 0 || (size_t)LS.active_state >= L.states.size()) continue;
+            for (uint32_t a : A.state_anims[li][LS.active_state]) seen[a] = 1;
+            for (const TransitionDef& tr : L.transitions)
+                if ((int32_t)tr.dest != LS.active_state && (int32_t)tr.source == LS.active_state && logic_reads_clock(tr.logic)) timed = true;
+        }
+        A.steady_ticks[i] = (uint32_t)A.steady_list.size();
+        const AnimState* as = A.anim_state.data() + (size_t)i * na;
+        for (uint32_t a = 0; a < na; ++a)
+            if (seen[a] && as[a].enabled) A.steady_list.push_back(a);      // (enabled flags change only through API calls and actions: both end steadiness)
+        if (timed) A.steady_timed.push_back(i);
+    }
+    A.steady_ticks[A.n_instances] = (uint32_t)A.steady_list.size();
+    A.steady_all = A.steady_list.size() == (size_t)A.n_instances * na;
+    for (const AnimationDef& d : A.anims) A.steady_all = A.steady_all && d.signals.empty();
+    A.steady_gen = A.edit_gen;
+}
+
+// The steady frame's ticks (what Planner::tick does, for the animations each instance ticks), then the conditions that read a clock.
+// Returns true when no transition fires: the frame is planned.  false: the ticks are made, the programs have to be planned (ticks_done).
+bool steady_frame(Animator& A, float dt) {
+    const uint32_t na = (uint32_t)A.anims.size();
+    const uint32_t* list = A.steady_list.data();
+    const uint32_t* off = A.steady_ticks.data();
+    float* times = A.times.data();
+    uint8_t* ticked = A.ticked.data();
+    AnimState* as = A.anim_state.data();
+    if (A.steady_all) {      // a crowd in one state: (instance, animation) records in memory order, no signals
+        const size_t n = (size_t)A.n_instances * na;
+        for (size_t k = 0; k < n; ++k) {
+            AnimState& s = as[k];
+            const float current = s.time, speed = s.speed, next = current + dt * speed;
+            times[k] = current;
+            if (s.looped && next >= s.start && next <= s.end) s.time = next;
+            else set_time_position(s, next);
+            const bool new_loop = s.looped && ((speed > 0.0f && s.time < current) || (speed < 0.0f && s.time > current));
+            ticked[k] = (uint8_t)(1u | (new_loop ? 2u : 0u) | (speed > 0.0f ? 4u : 0u));
+        }
+    } else
+    for (uint32_t i = 0; i < A.n_instances; ++i, as += na, times += na, ticked += na) {
+        for (uint32_t t = off[i]; t < off[i + 1]; ++t) {
+            const uint32_t a = list[t];
+            AnimState& s = as[a];
+            const float current = s.time, next = current + dt * s.speed;
+            times[a] = current;
+            const AnimationDef& def = A.anims[a];
+            if (!def.signals.empty()) {        // lib.rs:476-489, as Planner::tick
+                for (size_t k = 0; k < def.signals.size(); ++k) {
+                    const AnimationDef::Signal& sg = def.signals[k];
+                    if (!sg.enabled) continue;
+                    if ((s.speed >= 0.0f && (current < sg.time && next >= sg.time)) ||
+                        (s.speed < 0.0f && (current > sg.time && next <= sg.time) && s.events.size() < s.max_event_capacity))
+                        s.events.push_back((int32_t)k);
+                }
+            }
+            if (s.looped && next >= s.start && next <= s.end) s.time = next;      // wrapf's first line: the usual tick
+            else set_time_position(s, next);
+            const bool new_loop = s.looped && ((s.speed > 0.0f && s.time < current) || (s.speed < 0.0f && s.time > current));
+            ticked[a] = (uint8_t)(1u | (new_loop ? 2u : 0u) | (s.speed > 0.0f ? 4u : 0u));
+        }
+    }
+    if (!A.steady_timed.empty()) {
+        static thread_local PlanScratch scratch;       // (Planner wants one; logic() does not touch it)
+        for (uint32_t i : A.steady_timed) {
+            Planner p(A, scratch, i, dt);
+            for (size_t li = 0; li < A.layers.size(); ++li) {
+                const LayerDef& L = A.layers[li];
+                const LayerState& LS = p.ms->layers[li];
+                for (const TransitionDef& tr : L.transitions) {
+                    if ((int32_t)tr.dest == LS.active_state || (int32_t)tr.source != LS.active_state) continue;
+                    size_t pc = 0;
+                    if (p.logic(tr.logic, pc)) return false;
+                }
+            }
+        }
+    }
+    return true;
+}
+
 // Plans one frame of every instance of A.  Touches nothing but A (fyx_scene_update plans different animators on
 // different threads); n_tasks > 1 splits the instances over `pool`.  Returns 0 or the planner's error code.
 int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool* pool) {
     const uint32_t na = (uint32_t)A.anims.size();
-    A.times.assign((size_t)A.n_instances * na, 0.f);
-    A.ticked.assign((size_t)A.n_instances * na, 0);
+    // The steady frame: nothing but clocks has moved since the last machine frame, in which every instance reused its program.  The
+    // times / tick flags of animations that do not tick are last frame's zeros, the programs stay where they are.
+    bool ticks_done = false;
+    if (mode == 1 && A.prev_mode == 1 && A.steady_gen == A.edit_gen && A.steady_gen != 0 && A.times.size() == (size_t)A.n_instances * na) {
+        if (steady_frame(A, dt)) return FYX_OK;
+        ticks_done = true;        // a transition fires somewhere: plan the programs (the ticks are made)
+    }
+    A.steady_gen = 0;
+    if (!ticks_done) {
+        A.times.assign((size_t)A.n_instances * na, 0.f);
+        A.ticked.assign((size_t)A.n_instances * na, 0);
+    }
     // last frame's programs become the memo's source; a frame of another kind in between invalidates it
     A.ops.swap(A.prev_ops);
     A.prog_off.swap(A.prev_prog_off);
@@ -766,6 +883,7 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
         for (uint32_t i = i0; i < i1; ++i) {
             const size_t o0 = S.ops.size(), r0 = S.rm_ops.size();
             Planner p(A, S, i, dt);
+            p.ticks_done = ticks_done;
             if (mode == 1) p.plan_absm(); else p.plan_player();
             if (p.error) S.error = p.error;
             // which form of the update kernel may run this frame: the one without the interpreter needs EVERY program straight
@@ -801,6 +919,7 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
     A.prog_off[A.n_instances] = (uint32_t)A.ops.size();
     A.rm_prog_off[A.n_instances] = (uint32_t)A.rm_ops.size();
     guard.ok = true;
+    if (mode == 1) steady_prepare(A);
     return FYX_OK;
 }
 

@@ -480,9 +480,23 @@ def masked_transitions() -> Scenario:
     return sc
 
 
+def signals_and_clocks() -> Scenario:
+    """The transitions scenario with signals on every animation (one disabled, one at each end of the time slice, a small event
+    capacity on one) and NO root motion: the machine sits in one state for tens of frames at a time -- the planner's steady frames
+    (ticks and clock-reading conditions only) -- while signals fire, a one-shot clip runs out (`ended`) and a rule flips."""
+    sc = transitions()
+    for i, a in enumerate(sc.animations):
+        lo, hi = a.time_slice
+        a.signals = [(lo + (hi - lo) * 0.25, True), (lo + (hi - lo) * 0.5, False), (lo + (hi - lo) * 0.75, True), (hi, True), (lo, True)]
+        if i % 2 == 1:
+            a.max_event_capacity = 3
+    sc.name = "signals_and_clocks"
+    return sc
+
+
 ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like, morph_weights,
        morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player, random_attacks, removed_clips,
-       program_forms, masked_transitions]
+       program_forms, masked_transitions, signals_and_clocks]
 
 
 def with_root_motion_and_signals(make) -> Callable[[], Scenario]:

@@ -499,7 +499,7 @@ def test_entry_points_reject_bad_arguments_without_crashing(cctx):
 
 
 @pytest.mark.parametrize("make", [cases.c5_blend_tree, cases.transitions, cases.layered, cases.blend_space, cases.removed_clips,
-                                  cases.random_attacks] + [lambda s=s: cases.random_machine(s) for s in range(6)],
+                                  cases.random_attacks, cases.signals_and_clocks] + [lambda s=s: cases.random_machine(s) for s in range(6)],
                          ids=lambda f: getattr(f, "__name__", "random_machine"))
 def test_memoised_fold_programs_equal_programs_planned_from_scratch(make):
     """The planner reuses an instance's fold program of the last frame when nothing it depends on changed (MachineState's
