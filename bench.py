@@ -54,6 +54,77 @@ CHECK_THREADS = 8               # OpenMP threads of the oracle in the parity leg
 EXCHANGE_TIMEOUT_S = 120        # N > 1: the RCCL exchange leg may take this long before the line is printed without it
 
 
+def _read(path: str):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except Exception:     # noqa: BLE001
+        return None
+
+
+def box_facts(device_index: int = 0) -> dict:
+    """What tells a fast box from a slow one, read where the driver publishes it (sysfs of the amdgpu card, hwmon; rocm-smi as a
+    second source): current / available sclk and mclk, power now and cap, temperatures, compute- and memory-partition modes, driver
+    and firmware versions.  Never fails: a missing file is a missing key.  Called at the start, right behind the headline's timed
+    regions and at the end of the run, so that a clock that dropped under load shows."""
+    import glob
+    import shutil
+    import subprocess
+    out = {"t": time.time()}
+    try:
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            if _read(os.path.join(d, "vendor")) == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                cards.append(d)
+        out["amdgpu_cards"] = len(cards)
+        if cards:
+            d = cards[min(device_index, len(cards) - 1)]
+            out["card"] = os.path.basename(os.path.dirname(d))
+
+            def dpm(name):
+                txt = _read(os.path.join(d, name))
+                if not txt:
+                    return None
+                levels = [ln.strip() for ln in txt.splitlines() if ln.strip()]
+                cur = [ln for ln in levels if ln.endswith("*")]
+                return {"current": cur[0].rstrip("*").strip() if cur else None, "levels": levels}
+            for key, name in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("fclk", "pp_dpm_fclk"), ("socclk", "pp_dpm_socclk")):
+                v = dpm(name)
+                if v is not None:
+                    out[key] = v
+            for key in ("current_compute_partition", "current_memory_partition", "available_compute_partition", "available_memory_partition",
+                        "power_dpm_force_performance_level", "gpu_busy_percent", "mem_busy_percent", "vbios_version", "unique_id", "device", "revision"):
+                v = _read(os.path.join(d, key))
+                if v is not None:
+                    out[key] = v
+            for hm in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                for key in ("power1_cap", "power1_cap_max", "power1_average", "power1_input", "freq1_input", "freq2_input", "temp1_input", "temp2_input", "temp3_input"):
+                    v = _read(os.path.join(hm, key))
+                    if v is not None:
+                        try:
+                            out["hwmon_" + key] = int(v)
+                        except ValueError:
+                            out["hwmon_" + key] = v
+        out["amdgpu_driver_version"] = _read("/sys/module/amdgpu/version")
+        out["kernel"] = _read("/proc/sys/kernel/osrelease")
+        out["rocm_version"] = _read("/opt/rocm/.info/version")
+        smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        if smi:
+            try:
+                cp = subprocess.run([smi, "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--showmemorypartition",
+                                     "--showcomputepartition", "--showdriverversion", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+                txt = cp.stdout.strip()
+                start = txt.find("{")
+                out["rocm_smi"] = json.loads(txt[start:]) if start >= 0 else {"rc": cp.returncode, "stderr": cp.stderr[-300:]}
+            except Exception as e:     # noqa: BLE001
+                out["rocm_smi"] = {"error": repr(e)}
+        else:
+            out["rocm_smi"] = None
+    except Exception as e:     # noqa: BLE001
+        out["error"] = repr(e)
+    return out
+
+
 def emit(line: str) -> None:
     """Rank 0's ONE JSON line, as the last thing on stdout: whatever native libraries have buffered in C stdio (RCCL prints
     a version banner through it, which would otherwise come out at exit, after the line) is flushed first."""
@@ -797,6 +868,14 @@ def main():
             dist_backend, dist_cuda = "gloo", False
 
     ctx = fyrox_amd.Context(local_rank)    # owns its launch streams; torch is only used for barriers and buffers
+    box = {"at_start": box_facts(local_rank)} if rank == 0 else {}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        box["hip_device"] = {"name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "multi_processor_count": pr.multi_processor_count,
+                             "total_memory": pr.total_memory, "clock_rate_khz": getattr(pr, "clock_rate", None),
+                             "memory_clock_rate_khz": getattr(pr, "memory_clock_rate", None), "l2_cache_size": getattr(pr, "L2_cache_size", None)}
+    except Exception as e:     # noqa: BLE001
+        box["hip_device"] = {"error": repr(e)}
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
@@ -1161,6 +1240,7 @@ def main():
             except Exception:
                 traffic = None
         kname = "lbs_skin_dyn" if opts["lbs.dyn"] and nv >= 524_288 else "lbs_skin"
+        box["after_headline"] = box_facts(local_rank)
         out = {
             "metric": "skinned vertices/sec at 1M verts/256 bones; achieved HBM GB/s vs peak",
             "value": value, "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1202,6 +1282,7 @@ def main():
                              "note": "stream_copy_kernel: 60 MB read + 40 MB written, no math, one stream, same run"},
                          "position_only": pos_only},
             "parity": parity,
+            "box": box,
         }
         extra = {}
         if random_rec is not None:
@@ -1307,6 +1388,11 @@ def main():
                 break          # a failed collective leaves the communicator in an unknown state: no second form
         ctx.set_option("comm.form", 0)
     if rank == 0:
+        if isinstance(out.get("box"), dict):
+            out["box"]["at_end"] = box_facts(local_rank)
+            out["box"]["note"] = ("sysfs of the amdgpu card + hwmon + rocm-smi at the start of the run, right behind the headline's timed regions and at the "
+                                  "end: clocks (the level marked * is the current one), power now / cap (microwatts), temperatures (millidegrees), "
+                                  "compute / memory partition modes, driver versions -- what tells a slow box from a fast one")
         emit(json.dumps(out))
 
     barrier()

@@ -145,6 +145,9 @@ class Context:
     def malloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
+    def free_ptr(self, ptr: int) -> None:
+        self._check(self._l.fyx_free(self._h, ptr))
+
     def to_device(self, host: np.ndarray) -> DeviceBuffer:
         host = np.ascontiguousarray(host)
         return DeviceBuffer(self, max(host.nbytes, 16)).upload(host)
