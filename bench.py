@@ -155,6 +155,11 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C3 / C5 sub-records")
     ap.add_argument("--extras-only", action="store_true", help="(internal) run only the sub-records, in this fresh process, and print them")
     ap.add_argument("--max-repeats", type=int, default=4000)
+    ap.add_argument("--one-process", action="store_true",
+                    help="N > 1 without a launcher and without torch.distributed: ONE process drives all N GPUs, one fyx context and one "
+                         "host thread per GPU, the exchange through fyx_comm_init_all / fyx_allgather_skinned_all.  Taken automatically when "
+                         "the re-execution under torch.distributed.run fails or does not finish")
+    ap.add_argument("--launcher-timeout", type=float, default=1500.0, help="seconds the plain `--gpus N` launch gives torch.distributed.run")
     return ap.parse_args()
 
 
@@ -805,6 +810,176 @@ def launcher_command(n_gpus: int, argv: list) -> list:
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def run_under_launcher(cmd: list, timeout_s: float, runner=None):
+    """The plain `python bench.py --gpus N` road: run the launcher's command as a child, give it `timeout_s`, and say whether it
+    produced the line.  Returns (line or None, reason).  `runner` (tests): a stand-in for subprocess.run."""
+    import subprocess
+    run = runner or subprocess.run
+    try:
+        cp = run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return None, f"torch.distributed.run did not finish within {timeout_s:.0f} s"
+    except Exception as e:     # noqa: BLE001
+        return None, f"torch.distributed.run could not be started: {e!r}"
+    if cp.stderr:
+        sys.stderr.write(cp.stderr[-4000:])
+    lines = [ln for ln in (cp.stdout or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if cp.returncode == 0 and lines:
+        return lines[-1], "ok"
+    return None, f"torch.distributed.run exited with {cp.returncode} and {'no' if not lines else 'a'} line; stderr tail: {(cp.stderr or '')[-300:]!r}"
+
+
+def main_one_process(args, reason: str) -> None:
+    """N GPUs from ONE process (the engine's shape: one process, one update thread per ... here one host thread per GPU so that the launch
+    calls of 16-us kernels do not queue behind one another): no launcher, no torch process group.  Contexts on devices 0 .. N - 1 (test
+    hook FYX_BENCH_DEVICE: all on that device, which fyx_comm_init_all refuses -- the line then says so in comm_error and carries the
+    compute legs only).  Legs: `value` weak scaling (every GPU its own mesh), strong_value (ONE mesh cut by vertex range, compute only),
+    strong_with_gather_value (the same + fyx_allgather_skinned_all / _padded_all, each under a watchdog)."""
+    import threading
+    import fyrox_amd
+    from fyrox_amd import sharding, synth
+    n = args.gpus
+    forced = os.environ.get("FYX_BENCH_DEVICE")
+    devices = [int(forced)] * n if forced else list(range(n))
+    ctxs = [fyrox_amd.Context(d) for d in devices]
+    for c in ctxs:
+        for kv in args.opt:
+            k, v = kv.split("=")
+            c.set_option(k, int(v))
+    nv, nb = args.verts, args.bones
+    mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + 4, coherent=not args.random_bones)
+    pal = synth.make_palette(nb, synth.SEED_BASE + 4)
+    sets = max(2, min(args.sets, 4))
+    fn = ctxs[0]._l.fyx_lbs_skin_device
+    weak_calls, strong_calls, strong_bufs, strong_bufs_padded, strong_calls_padded = [], [], [], [], []
+    shard_p = sharding.vertex_range_padded(nv, 0, n)[2]
+    for g, c in enumerate(ctxs):
+        d_pal = c.to_device(pal)
+        calls = []
+        for s_ in range(sets):
+            c.mesh_upload_soa(100 + s_, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+            o = (c.malloc(nv * 12 + 64), c.malloc(nv * 12 + 64), c.malloc(nv * 16 + 64))
+            calls.append(partial(fn, c._h, ctypes.c_uint64(100 + s_), ctypes.c_void_p(d_pal.ptr), ctypes.c_uint32(nb), ctypes.c_uint32(1),
+                                 ctypes.c_void_p(o[0].ptr), ctypes.c_void_p(o[1].ptr), ctypes.c_void_p(o[2].ptr)))
+            if g == 0 and s_ == 0:
+                first_out = o
+        weak_calls.append(calls)
+        # strong: this GPU's shard of the ONE mesh, written in place into full-size buffers (ragged cut) / padded buffers (equal cut)
+        b, e = sharding.vertex_range_native(nv, g, n)
+        c.mesh_upload_soa(200, mesh.pos[b:e], mesh.weights[b:e], mesh.indices[b:e], mesh.normal[b:e], mesh.tangent[b:e])
+        full = (c.malloc(nv * 12 + 64), c.malloc(nv * 12 + 64), c.malloc(nv * 16 + 64))
+        strong_bufs.append(full)
+        strong_calls.append(partial(fn, c._h, ctypes.c_uint64(200), ctypes.c_void_p(d_pal.ptr), ctypes.c_uint32(nb), ctypes.c_uint32(1),
+                                    ctypes.c_void_p(full[0].ptr + 12 * b), ctypes.c_void_p(full[1].ptr + 12 * b), ctypes.c_void_p(full[2].ptr + 16 * b))
+                            if e > b else (lambda: 0))
+        b2, e2, _ = sharding.vertex_range_padded(nv, g, n)
+        c.mesh_upload_soa(201, mesh.pos[b2:e2], mesh.weights[b2:e2], mesh.indices[b2:e2], mesh.normal[b2:e2], mesh.tangent[b2:e2])
+        fullp = (c.malloc(n * shard_p * 12 + 64), c.malloc(n * shard_p * 12 + 64), c.malloc(n * shard_p * 16 + 64))
+        strong_bufs_padded.append(fullp)
+        strong_calls_padded.append(partial(fn, c._h, ctypes.c_uint64(201), ctypes.c_void_p(d_pal.ptr), ctypes.c_uint32(nb), ctypes.c_uint32(1),
+                                           ctypes.c_void_p(fullp[0].ptr + 12 * b2), ctypes.c_void_p(fullp[1].ptr + 12 * b2), ctypes.c_void_p(fullp[2].ptr + 16 * b2))
+                                   if e2 > b2 else (lambda: 0))
+    parity = None
+    if not args.no_check:
+        weak_calls[0][0]()
+        ctxs[0].sync()
+        parity = lbs_parity(ctxs[0], mesh, pal, tuple(_Ptr(b.ptr) for b in first_out), 20_000)
+        if not parity["bit_exact"]:
+            raise SystemExit("one-process bench: GPU 0's output differs from the oracle")
+
+    def timed(per_gpu_step, steps, warmup, after=None):
+        """Every GPU's `steps` launches issued by a thread of its own between a sync of all contexts before and after; `after(i)`
+        (the exchange) is called from THIS thread once per step when given -- then the launches are issued from this thread too,
+        step by step, as the engine's single update thread would."""
+        def run(count):
+            if after is not None:
+                for i in range(count):
+                    for g in range(n):
+                        per_gpu_step(g, i)
+                    after(i)
+                return
+            ths = [threading.Thread(target=lambda g=g: [per_gpu_step(g, i) for i in range(count)]) for g in range(n)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        run(warmup)
+        for c in ctxs:
+            c.sync()
+        t0 = time.perf_counter()
+        run(steps)
+        for c in ctxs:
+            c.sync()
+        return time.perf_counter() - t0
+
+    def chk(rc):
+        if rc:
+            raise RuntimeError(ctxs[0]._l.fyx_last_error(ctxs[0]._h).decode())
+
+    w = timed(lambda g, i: chk(weak_calls[g][i % sets]()), args.steps, args.warmup)
+    s_c = timed(lambda g, i: chk(strong_calls[g]()), args.steps, args.warmup)
+    out = {"metric": "skinned vertices/sec at 1M verts/256 bones; achieved HBM GB/s vs peak",
+           "value": float(nv) * n * args.steps / w, "unit": "vertices/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": w * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"C4: {nv} verts / {nb} bones per GPU, 4-influence LBS of position+normal+tangent, {sets} rotating buffer sets; `value` is WEAK "
+                                  f"scaling over the {n} GPUs (every GPU its own mesh, no collective); strong_value = BASELINE config 4 as written",
+                      "process_group": f"none: ONE process drives the {n} GPUs (fyx_comm_init_all / fyx_allgather_skinned_all), one host thread per GPU; {reason}",
+                      "devices": devices, "sharding": "contiguous vertex range per GPU, palette replicated"},
+           "roofline": None, "parity": parity,
+           "strong_value": float(nv) * args.steps / s_c, "strong_ms_per_step": s_c * 1e3 / args.steps,
+           "strong_with_gather_value": None, "strong_with_gather_form": None, "comm_error": None,
+           "timing_note": "host clock between fyx_sync of every context before and after the launches (no torch, no events across devices)",
+           "box": {"at_start": box_facts(devices[0])}}
+    # the exchange, last and under a watchdog: RCCL with more than one rank runs here for the first time
+    try:
+        fyrox_amd.Context.comm_init_all(ctxs)
+        have_comm = True
+    except Exception as e:     # noqa: BLE001
+        have_comm, out["comm_error"] = False, repr(e)
+    if have_comm:
+        legs = {}
+        for form, key in ((0, "broadcasts"), (1, "send_recv"), (2, "all_gather_padded")):
+            done = threading.Event()
+
+            def give_up(key=key):
+                if not done.is_set():
+                    legs[key] = {"value": None, "note": f"the exchange did not finish within {EXCHANGE_TIMEOUT_S} s"}
+                    out["exchange_legs"] = legs
+                    emit(json.dumps(out))
+                    os._exit(0)
+            wd = threading.Timer(EXCHANGE_TIMEOUT_S, give_up)
+            wd.daemon = True
+            wd.start()
+            try:
+                if form == 2:
+                    bufs, calls = strong_bufs_padded, strong_calls_padded
+                    gather = lambda i: fyrox_amd.Context.allgather_skinned_padded_all(ctxs, nv, n * shard_p, [b[0].ptr for b in bufs], [b[1].ptr for b in bufs], [b[2].ptr for b in bufs])   # noqa: E731
+                else:
+                    ctxs[0].set_option("comm.form", form)
+                    bufs, calls = strong_bufs, strong_calls
+                    gather = lambda i: fyrox_amd.Context.allgather_skinned_all(ctxs, nv, [b[0].ptr for b in bufs], [b[1].ptr for b in bufs], [b[2].ptr for b in bufs])   # noqa: E731
+                t = timed(lambda g, i: chk(calls[g]()), args.steps, min(args.warmup, 20), after=gather)
+                ok = None
+                if not args.no_check:      # the LAST GPU holds the whole mesh: its head (another GPU's shard) against the oracle
+                    ok = lbs_parity(ctxs[-1], mesh, pal, tuple(_Ptr(b.ptr) for b in bufs[-1]), 20_000)["bit_exact"]
+                legs[key] = {"value": float(nv) * args.steps / t, "ms_per_step": t * 1e3 / args.steps, "gathered_equals_oracle": ok}
+                if ok is not False and (out["strong_with_gather_value"] is None or legs[key]["value"] > out["strong_with_gather_value"]):
+                    out["strong_with_gather_value"], out["strong_with_gather_form"] = legs[key]["value"], key
+            except Exception as e:     # noqa: BLE001
+                legs[key] = {"value": None, "note": f"the exchange failed: {e!r}"}
+                done.set()
+                wd.cancel()
+                break
+            done.set()
+            wd.cancel()
+        ctxs[0].set_option("comm.form", 0)
+        out["exchange_legs"] = legs
+    out["box"]["at_end"] = box_facts(devices[0])
+    emit(json.dumps(out))
+    for c in ctxs:
+        c.close()
+
+
 def check_world(n_gpus: int, world: int) -> None:
     """One rank per GPU or no line at all: `n_gpus` in the line is the number of ranks that ran."""
     if world != n_gpus:
@@ -819,11 +994,19 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.extras_only:
-        # `python bench.py --gpus N` launched plainly: one rank per GPU is what the line promises, so this process becomes the
-        # launcher the driver would have used (same module, same arguments) instead of measuring one GPU under the label of N
+        if args.one_process:
+            return main_one_process(args, "asked for with --one-process")
+        # `python bench.py --gpus N` launched plainly: one rank per GPU is what the line promises, so this process runs the launcher the
+        # driver would have used (same module, same arguments) as a child -- and when that road fails or does not finish (the launcher,
+        # torch's rendezvous, a process group that never forms) takes the second one: all N GPUs from this process
         cmd = launcher_command(args.gpus, sys.argv[1:])
-        print(f"# bench.py --gpus {args.gpus} without a launcher: re-executing as {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
-        os.execv(sys.executable, cmd)
+        print(f"# bench.py --gpus {args.gpus} without a launcher: running {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+        line, reason = run_under_launcher(cmd, args.launcher_timeout)
+        if line is not None:
+            emit(line)
+            return None
+        print(f"# {reason}; falling back to --one-process", file=sys.stderr, flush=True)
+        return main_one_process(args, f"fallback: {reason}")
     check_world(args.gpus, world)
 
     if args.extras_only:
@@ -864,7 +1047,13 @@ def main():
             dist_backend = "nccl"
         except Exception as e:     # noqa: BLE001
             print(f"# rank {rank}: process group on RCCL failed ({e!r}); using gloo for the control collectives", file=sys.stderr)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            try:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            except Exception as e2:     # noqa: BLE001
+                # no process group at all under the launcher: rank 0 takes the launcher-free road over all the GPUs, the others leave
+                if rank != 0:
+                    return None
+                return main_one_process(args, f"fallback under the launcher: no torch process group ({e2!r})")
             dist_backend, dist_cuda = "gloo", False
 
     ctx = fyrox_amd.Context(local_rank)    # owns its launch streams; torch is only used for barriers and buffers

@@ -34,3 +34,35 @@ def test_plain_launch_with_two_ranks_prints_every_multi_gpu_key():
         for k in ("with_allgather", "with_allgather_sendrecv", "with_allgather_padded"):
             assert k in st
     assert d["extra"]["crowd_scaling"].get("value", 0) > 0 or "error" in d["extra"]["crowd_scaling"]
+
+
+@pytest.mark.gpu
+def test_one_process_road_prints_the_line_and_says_why_there_is_no_exchange():
+    """`python bench.py --gpus 2 --one-process` on a one-GPU box (FYX_BENCH_DEVICE=0: both contexts on GPU 0): no launcher, no torch
+    process group -- the line carries n_gpus = 2, the weak and strong compute legs, and the refusal fyx_comm_init_all gives two
+    contexts on one device in comm_error (the exchange legs need two GPUs)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FYX_BENCH_DEVICE"] = "0"
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-process", "--steps", "20", "--warmup", "5", "--sets", "2"],
+                        env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert cp.returncode == 0 and lines, (cp.returncode, cp.stdout[-2000:], cp.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["strong_value"] > 0
+    assert "ONE process" in d["config"]["process_group"] and "--one-process" in d["config"]["process_group"]
+    assert d["parity"]["bit_exact"] is True
+    assert d["strong_with_gather_value"] is None and "same GPU" in d["comm_error"]
+    assert "at_start" in d["box"] and "at_end" in d["box"]
+
+
+@pytest.mark.gpu
+def test_the_headline_line_carries_the_box_facts():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline", "--sets", "3"],
+                        env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert cp.returncode == 0 and lines, (cp.returncode, cp.stdout[-2000:], cp.stderr[-3000:])
+    d = json.loads(lines[-1])
+    for when in ("at_start", "after_headline", "at_end"):
+        assert when in d["box"], when
+    assert d["box"]["hip_device"].get("name")

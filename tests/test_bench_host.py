@@ -64,3 +64,46 @@ def test_main_refuses_a_mismatching_world_before_it_touches_a_gpu():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120)
     assert cp.returncode != 0 and "WORLD_SIZE=1" in (cp.stderr + cp.stdout) and "n_gpus" not in cp.stdout
+
+
+def test_the_launcher_road_reports_failure_so_that_the_one_process_road_is_taken():
+    """The plain `--gpus N` launch runs torch.distributed.run as a CHILD under a timeout; a child that fails, prints no line, cannot be
+    started or does not finish makes run_under_launcher return no line and a reason -- main() then runs main_one_process (all N GPUs
+    from this process through fyx_comm_init_all / fyx_allgather_skinned_all) and says so in config.process_group."""
+    import subprocess
+    b = _bench()
+    good = '{"metric": "skinned vertices/sec", "value": 1.0, "n_gpus": 2}'
+
+    class CP:
+        def __init__(self, rc, out, err=""):
+            self.returncode, self.stdout, self.stderr = rc, out, err
+
+    line, why = b.run_under_launcher(["x"], 5.0, runner=lambda *a, **k: CP(0, "# noise\n" + good + "\n"))
+    assert line == good and why == "ok"
+    line, why = b.run_under_launcher(["x"], 5.0, runner=lambda *a, **k: CP(1, good))
+    assert line is None and "exited with 1" in why
+    line, why = b.run_under_launcher(["x"], 5.0, runner=lambda *a, **k: CP(0, "nothing json here"))
+    assert line is None and "no line" in why
+
+    def hangs(*a, **k):
+        raise subprocess.TimeoutExpired(cmd="x", timeout=5.0)
+    line, why = b.run_under_launcher(["x"], 5.0, runner=hangs)
+    assert line is None and "did not finish" in why
+
+    def missing(*a, **k):
+        raise FileNotFoundError("no such interpreter")
+    line, why = b.run_under_launcher(["x"], 5.0, runner=missing)
+    assert line is None and "could not be started" in why
+    # a real child that fails (the real subprocess.run)
+    line, why = b.run_under_launcher([sys.executable, "-c", "import sys; sys.exit(3)"], 60.0)
+    assert line is None and "exited with 3" in why
+
+
+def test_one_process_flag_is_parsed():
+    b = _bench()
+    argv, sys.argv = sys.argv, ["bench.py", "--gpus", "2", "--one-process", "--launcher-timeout", "7"]
+    try:
+        a = b.parse()
+    finally:
+        sys.argv = argv
+    assert a.one_process and a.gpus == 2 and a.launcher_timeout == 7.0
