@@ -742,26 +742,38 @@ __device__ __forceinline__ void aos_segment(const LbsExArgs& x, const float* __r
     const LbsArgs& a = x.a;
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
-    uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);
+    uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + a.n_bones);   // 16 words: [0, WPB) the waves' projective flags, [8] the unit ticket
+    uint32_t* ticket = wave_flag + 8;
     constexpr uint32_t WPB = kAosBlock / 64;
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t stride = x.out_stride;                     // == input stride
-    const uint32_t span_f4 = stride * 4;                      // 64 * stride / 16
-    constexpr uint32_t per_lane = PL;
+    const uint32_t span_bytes = 64u * stride;
     unsigned char* slab = smem + (size_t)a.n_bones * 64 + 64 + (size_t)wave * 64 * stride;
     f32x4* slab4 = reinterpret_cast<f32x4*>(slab);
-    const f32x4* in4 = reinterpret_cast<const f32x4*>(x.in_aos);
     const PaletteRegs pr = palette_fetch(palette, a.n_bones, tid);
-    uint32_t u = seg_b + wave;
-    f32x4 cur[PL];
+    // Round 5 (what paid for lbs_skin_dyn): the waves DRAW their units from an LDS ticket (a wave that is served faster
+    // takes more; the segment ends when its work does), TWO spans are in flight per wave (a register set is refilled as soon as its
+    // span is parked in the slab, while the other set's loads have had a whole unit's time to land), the spans are buffer resources
+    // of exactly one span (a lane past the span's last 16 bytes loads zeros and stores nothing: no per-lane bounds tests), loads `nt`,
+    // stores `sc1`.  The input buffer is padded by one unit, so a ragged last span may be read in full.
+    auto span_in = [&](uint32_t u) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(x.in_aos) + (size_t)u * span_bytes, 0, span_bytes, 0x00020000); };
+    auto load_span = [&](f32x4 (&r)[PL], uint32_t u) {
+        const __amdgpu_buffer_rsrc_t rs = span_in(u);
 #pragma unroll
-    for (uint32_t k = 0; k < PL; ++k) {
-        const uint32_t i = lane + 64 * k;
-        // the input buffer is padded by one unit, so a ragged last span may be read in full
-        if (k < per_lane && u < seg_e && i < span_f4) cur[k] = __builtin_nontemporal_load(in4 + (size_t)u * span_f4 + i);
-    }
-    if (!first) __syncthreads();   // every wave is done with the previous palette
+        for (uint32_t k = 0; k < PL; ++k) r[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64u * k) * 16u, 0, 2));
+    };
+    // (with blend shapes the second register set costs the fourth wave per SIMD and the launch gets slower -- 42.4 against 40.3 us
+    // alone, measured: profiles/r05_vertex_buffer.jsonl -- so that form keeps ONE span in flight: ticket, buffer spans and sc1 stores only)
+    // (and the wide layouts, 32 / 40 bytes of span per lane: two sets of those would leave two waves per SIMD)
+    constexpr bool TWO = !SHAPES && PL <= 5;
+    const uint32_t n_units = seg_e - seg_b;
+    uint32_t uA = seg_b + wave, uB = uA + WPB;
+    bool vA = wave < n_units, vB = TWO && WPB + wave < n_units;
+    f32x4 A[PL], B[TWO ? PL : 1];
+    if (vA) load_span(A, uA);
+    if (!first) __syncthreads();   // every wave is done with the previous palette (and the previous segment's ticket)
+    if (tid == 0) *ticket = (TWO ? 2 : 1) * WPB;
     const bool pj = palette_commit(pr, a.n_bones, rows, row3, tid);
     const bool wave_pj = __any(pj) != 0;
     if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
@@ -769,21 +781,25 @@ __device__ __forceinline__ void aos_segment(const LbsExArgs& x, const float* __r
     bool projective = false;
 #pragma unroll
     for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
-    
-    while (u < seg_e) {  // wave-uniform
+    if constexpr (TWO) if (vB) load_span(B, uB);     // (behind the staging barrier, as lbs_skin_dyn: the palette columns of the later waves do not queue behind it)
+
+    // one unit: park the span in the slab, refill the register set, skin in the slab, stream the slab out
+    auto process = [&](f32x4 (&r)[PL], uint32_t& u, bool& valid) {
 #pragma unroll
         for (uint32_t k = 0; k < PL; ++k) {
-            const uint32_t i = lane + 64 * k;
-            if (k < per_lane && i < span_f4) slab4[i] = cur[k];
+            const uint32_t i = lane + 64u * k;
+            if (i * 16u < span_bytes) slab4[i] = r[k];
         }
-        const uint32_t un = u + WPB;
-#pragma unroll
-        for (uint32_t k = 0; k < PL; ++k) {
-            const uint32_t i = lane + 64 * k;
-            if (k < per_lane && un < seg_e && i < span_f4) cur[k] = __builtin_nontemporal_load(in4 + (size_t)un * span_f4 + i);
+        const uint32_t u_now = u;
+        {
+            uint32_t t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = __builtin_amdgcn_readfirstlane(t);
+            valid = t < n_units;
+            u = seg_b + t;
+            if (valid) load_span(r, u);
         }
         __builtin_amdgcn_wave_barrier();
-        const uint32_t v = u * 64 + lane;
         unsigned char* rec = slab + (size_t)lane * stride;
         float* pp = reinterpret_cast<float*>(rec + x.off_pos);
         float px = pp[0], py = pp[1], pz = pp[2];
@@ -797,9 +813,9 @@ __device__ __forceinline__ void aos_segment(const LbsExArgs& x, const float* __r
         const f32x4 w = {wp[0], wp[1], wp[2], wp[3]};
         const uint32_t id = *reinterpret_cast<const uint32_t*>(rec + x.in_off_idx);
         if constexpr (SHAPES) {
-            const uint16_t* col = x.shapes + ((size_t)u * 9) * 64 + lane;
+            const uint16_t* col = x.shapes + ((size_t)u_now * 9) * 64 + lane;
             const size_t shape_stride = (size_t)x.tiles_per_shape * 9 * 64;
-#pragma unroll 2
+#pragma unroll 1
             for (uint32_t sidx = 0; sidx < x.n_shapes; ++sidx) {
                 const uint16_t* c = col + (size_t)sidx * shape_stride;
                 const float ws = sw[sidx];
@@ -825,14 +841,16 @@ __device__ __forceinline__ void aos_segment(const LbsExArgs& x, const float* __r
         if (tp) { tp[0] = o.tx; tp[1] = o.ty; tp[2] = o.tz; }
         __builtin_amdgcn_wave_barrier();
         // stream the slab out; only whole vertices of a ragged last unit
-        const uint32_t n_valid = (a.n_verts - u * 64) < 64u ? (a.n_verts - u * 64) : 64u;
-        unsigned char* out_span = out_inst + (size_t)u * 64 * stride;
+        const uint32_t n_valid = (a.n_verts - u_now * 64) < 64u ? (a.n_verts - u_now * 64) : 64u;
+        unsigned char* out_span = out_inst + (size_t)u_now * span_bytes;
         if (n_valid == 64u && ((reinterpret_cast<uintptr_t>(out_span) & 15u) == 0)) {
-            f32x4* o4 = reinterpret_cast<f32x4*>(out_span);
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out_span, 0, span_bytes, 0x00020000);
 #pragma unroll
             for (uint32_t k = 0; k < PL; ++k) {
-                const uint32_t i = lane + 64 * k;
-                if (k < per_lane && i < span_f4) __builtin_nontemporal_store(slab4[i], o4 + i);
+                const uint32_t i = lane + 64u * k;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (i * 16u < span_bytes) v = slab4[i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, i * 16u, 0, 16);
             }
         } else {
             const uint32_t n_dw = n_valid * (stride / 4);
@@ -840,14 +858,20 @@ __device__ __forceinline__ void aos_segment(const LbsExArgs& x, const float* __r
             uint32_t* o32 = reinterpret_cast<uint32_t*>(out_span);
             for (uint32_t i = lane; i < n_dw; i += 64) o32[i] = s32[i];
         }
-        __builtin_amdgcn_wave_barrier();   // the slab is rewritten at the top of the loop
-        u = un;
-        (void)v;
+        __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next unit
+    };
+    for (;;) {   // wave-uniform
+        if (!vA) break;
+        process(A, uA, vA);
+        if constexpr (TWO) {
+            if (!vB) break;
+            process(B, uB, vB);
+        }
     }
 }
 
 template <bool EXACT, bool SHAPES, uint32_t PL>
-__global__ __launch_bounds__(kAosBlock) void lbs_skin_aos(LbsExArgs x, uint32_t units_per_inst, uint32_t total_units) {
+__global__ __launch_bounds__(kAosBlock, (SHAPES && PL <= 5) ? 4 : 1) void lbs_skin_aos(LbsExArgs x, uint32_t units_per_inst, uint32_t total_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LbsArgs& a = x.a;
     const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
@@ -866,7 +890,7 @@ __global__ __launch_bounds__(kAosBlock) void lbs_skin_aos(LbsExArgs x, uint32_t 
 
 // Batched form (fyx_lbs_skin_ex_batch): the segments of many meshes in one unit numbering, as lbs_skin_batch.
 template <bool EXACT, bool SHAPES, uint32_t PL>
-__global__ __launch_bounds__(kAosBlock) void lbs_skin_aos_batch(const LbsExSegDev* __restrict__ segs_g, uint32_t n_segs,
+__global__ __launch_bounds__(kAosBlock, (SHAPES && PL <= 5) ? 4 : 1) void lbs_skin_aos_batch(const LbsExSegDev* __restrict__ segs_g, uint32_t n_segs,
                                                                const uint32_t* __restrict__ block_seg, uint32_t total_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FYX_CONSTANT LbsExSegDev* segs = (const FYX_CONSTANT LbsExSegDev*)segs_g;
