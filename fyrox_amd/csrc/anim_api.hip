@@ -1120,6 +1120,7 @@ int fyx_animator_set_palette_output(fyx_ctx* c, uint64_t animator_id, uint64_t b
     if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
     if (bit->second.rig_id != A->rig_id) return fail(c, FYX_ERR_INVALID_ARG, "bone list belongs to another rig");
     if (reinterpret_cast<uintptr_t>(d_out) & 15u) return fail(c, FYX_ERR_INVALID_ARG, "palette output must be 16-byte aligned");
+    ++A->api_gen;
     auto& v = A->palette_outputs;
     for (size_t i = 0; i < v.size(); ++i)
         if (v[i].bones_id == bones_id) {
@@ -1143,6 +1144,7 @@ int fyx_animator_set_skin_output(fyx_ctx* c, uint64_t animator_id, uint64_t bone
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     FYX_ANIMATOR_RO(c, A, animator_id);
+    ++A->api_gen;
     auto& v = A->skin_outputs;
     size_t at = v.size();
     for (size_t i = 0; i < v.size(); ++i)

@@ -378,7 +378,7 @@ int skin_output_args(fyx_ctx* c, const Animator& A, LbsArgs (&out)[kMaxFrameSkin
 
 // Whether (and how) the one-launch frame takes the skinning along: every job's bone list, its mesh streams and its share of the
 // launch's skinning workgroups.  false: the frame skins with launches of its own (a mesh too large for the resident grid).
-bool frame_skin_plan(const fyx_ctx* c, const Animator& A, const LbsArgs* args, uint32_t n, uint32_t max_blocks, FrameSkin& sk) {
+bool frame_skin_plan(const fyx_ctx* c, const Animator& A, const LbsArgs* args, uint32_t n, uint32_t max_blocks, FrameSkin& sk, uint32_t auto_blocks = kFrameSkinAutoBlocks) {
     memset(&sk, 0, sizeof sk);
     if (n == 0 || n > (uint32_t)kMaxFrameSkins) return false;
     // Units per wave.  One is fastest while every skinning workgroup has a CU to itself (a lone wave issues an instruction every
@@ -394,7 +394,7 @@ bool frame_skin_plan(const fyx_ctx* c, const Animator& A, const LbsArgs* args, u
     };
     uint32_t per_wave = (uint32_t)std::max(c->frame_skin_units, 0);
     if (per_wave == 0)
-        for (per_wave = 1; per_wave < 16u && blocks_at(per_wave) > std::min(kFrameSkinAutoBlocks, max_blocks); ++per_wave) {}
+        for (per_wave = 1; per_wave < 16u && blocks_at(per_wave) > std::min(auto_blocks, max_blocks); ++per_wave) {}
     const uint64_t want = blocks_at(per_wave), least = (uint64_t)n * A.n_instances;
     if (least > max_blocks) return false;
     // more work than the resident grid holds at the wanted depth: every job gets its share of the grid, waves loop over more units.
@@ -581,15 +581,56 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     // 2. device state, and the block tables if the scene's shape changed
     hipStream_t ps = nullptr;
     if (int rc = enter_pose(c, &ps)) return rc;
+    // The animators' skin outputs ride in the scene's update launch when that is the 256-thread wide-walk stage for EVERY animator
+    // (characters: few instances each, rigs whose walk tables fit the LDS) -- each animator's plan is cached until an API call, a
+    // mesh upload or the options change it.  Share of the launch's skinning workgroups: what keeps the whole stage about resident.
+    // Only SMALL scenes: the skinning workgroups recompute their character's pose, which is free on a chip that is mostly idle (one
+    // character: 12.7 -> 8.9 us) and is not on one that is full -- measured (tools/exp/r05_scene.py, profiles/r05_scene_skin_outputs.jsonl):
+    // 256 characters x 5 k vertices 64.6 us this way against 60.3 us with the update launch + fyx_lbs_skin_batch's launch, 64 x 4 x 20 k
+    // 126 against 118.  anim.frame_skin = 2 forces it whatever the size (experiments).
+    bool any_skin = false, stage256 = c->frame_skin != 0;
+    size_t wide_all = 0;
+    uint32_t max_skin_bones = 0;
+    uint64_t skin_units = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const Animator& A = *S.animators[k];
+        any_skin = any_skin || !A.skin_outputs.empty();
+        stage256 = stage256 && update_block_waves(A.rig->n_nodes, A.n_instances) == 4u;
+        wide_all = std::max(wide_all, wide_update_lds(A.rig->n_nodes, A.rig->n_chunks));
+        for (const Animator::SkinOut& so : A.skin_outputs) {
+            auto mit = c->meshes.find(so.mesh_id);
+            if (mit != c->meshes.end()) skin_units += (uint64_t)A.n_instances * ((mit->second.n_verts + 63u) / 64u);
+        }
+    }
+    const bool skin_update = any_skin && stage256 && wide_all + frame_skin_lds(256) <= kLdsPerWorkgroup &&
+                             (skin_units <= kSceneSkinMaxUnits || c->frame_skin == 2);
     std::vector<uint64_t> sig;
-    sig.reserve(n * 3 + 1);
-    sig.push_back((uint64_t)c->sample_form);
+    sig.reserve(n * 4 + 1);
+    sig.push_back((uint64_t)c->sample_form | (skin_update ? 16u : 0u));
     for (size_t k = 0; k < n; ++k) {
         Animator& A = *S.animators[k];
         if (int rc = ensure_device_state(c, A)) return rc;
+        uint32_t skin_blocks = 0;
+        if (skin_update && !A.skin_outputs.empty()) {
+            if (A.scene_skin_api_gen != A.api_gen || A.scene_skin_mesh_gen != c->mesh_gen || A.scene_skin_units != c->frame_skin_units) {
+                LbsArgs args[kMaxFrameSkins];
+                if (int rc = skin_output_args(c, A, args)) return rc;
+                const uint32_t share = std::max<uint32_t>(1u, 512u / (uint32_t)n);
+                A.scene_skin_ok = frame_skin_plan(c, A, args, (uint32_t)A.skin_outputs.size(), kFrameSkinMaxBlocks, A.scene_skin, share);
+                if (!A.scene_skin_ok) memset(&A.scene_skin, 0, sizeof A.scene_skin);
+                A.scene_skin_api_gen = A.api_gen;
+                A.scene_skin_mesh_gen = c->mesh_gen;
+                A.scene_skin_units = c->frame_skin_units;
+            }
+            if (A.scene_skin_ok) {
+                skin_blocks = A.scene_skin.n_blocks;
+                for (uint32_t j = 0; j < A.scene_skin.n_jobs; ++j) max_skin_bones = std::max(max_skin_bones, A.scene_skin.job[j].n_bones);
+            }
+        }
         sig.push_back(((uint64_t)A.anims.size() << 32) | A.n_instances);
         sig.push_back(((uint64_t)A.rig->n_nodes << 32) | A.dev_prop_slots);
         sig.push_back(((uint64_t)A.rig->n_chunks << 1) | (A.rm_enabled ? 1 : 0));
+        sig.push_back(((uint64_t)skin_blocks << 32) | max_skin_bones);
     }
     if (sig != S.signature) {
         std::vector<uint4> tables[kSceneStages];
@@ -597,7 +638,8 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         size_t wide256 = 0;
         for (size_t k = 0; k < n; ++k) {
             const Animator& A = *S.animators[k];
-            const SceneJobShape sh = scene_shape(c, A, A.dev_prop_slots);
+            SceneJobShape sh = scene_shape(c, A, A.dev_prop_slots);
+            if (skin_update && A.scene_skin_ok && !A.skin_outputs.empty()) sh.skin_blocks = A.scene_skin.n_blocks;
             scene_blocks((uint32_t)k, sh, tables);
             const int stage = kStageUpdate64 + (int)update_block_waves(sh.n_nodes, sh.n_instances) - 1;
             lds[stage] = std::max(lds[stage], (size_t)sh.n_nodes * 32 * sizeof(float));
@@ -606,6 +648,8 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         // the 256-thread updates walk the hierarchy wide (a lane per matrix element) when every rig's chunk table fits the LDS
         S.wide_update = wide256 > 0 && wide256 <= kLdsPerWorkgroup;
         if (S.wide_update) lds[kStageUpdate256] = wide256;
+        S.skin_update = skin_update && S.wide_update && max_skin_bones > 0;
+        if (S.skin_update) lds[kStageUpdate256] = wide256 + frame_skin_lds(max_skin_bones);
         size_t total = 0;
         for (int k = 0; k < kSceneStages; ++k) {
             if (tables[k].size() > 0x7fffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "scene too large for one launch per stage");
@@ -643,6 +687,8 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         frame_static(c, A, jobs[k].f);
         ctrl_bind(A, S.layouts[k], reinterpret_cast<const char*>(S.offsets[k]), jobs[k].f);     // offsets from the block's start
         if (int rc = rig_params(c, A, jobs[k].rig)) return rc;
+        if (S.skin_update && A.scene_skin_ok && !A.skin_outputs.empty()) jobs[k].sk = A.scene_skin;
+        else memset(&jobs[k].sk, 0, sizeof jobs[k].sk);
     }
     // A job array that changed travels through the frame's PINNED staging block, behind the control sections (the block is not
     // rewritten before the event behind this frame's kernels: ctrl_consumed) -- not from the pageable vector, which the next frame
@@ -676,13 +722,14 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
     bool all_straight = c->upd_lean != 0;
     for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
-    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs), d, tabs, S.n_blocks, S.lds_bytes, all_straight, S.wide_update, ps));
+    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs), d, tabs, S.n_blocks, S.lds_bytes, all_straight, S.wide_update, ps,
+                            S.skin_update, c->lbs.exact != 0));
     if (int rc = ctrl_consumed(c, S.ctrl, slot, ps)) return rc;
     if (int rc = exit_pose(c)) return rc;
     // the animators' skin outputs (fyx_animator_set_skin_output): behind the scene's update launch, on the frame's stream
     for (size_t k = 0; k < n; ++k) {
         const Animator& A = *S.animators[k];
-        if (A.skin_outputs.empty()) continue;
+        if (A.skin_outputs.empty() || (S.skin_update && A.scene_skin_ok)) continue;     // (skinned by the update launch itself)
         LbsArgs skin_args[kMaxFrameSkins];
         if (int rc = skin_output_args(c, A, skin_args)) return rc;
         for (size_t j = 0; j < A.skin_outputs.size(); ++j) FYX_HIP(c, launch_lbs(skin_args[j], c->lbs, ps));

@@ -1315,7 +1315,7 @@ template <int MODE, int PACK = 1, bool WAIT = false, bool WIDE = false, bool QUI
 __device__ __forceinline__ bool pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0,
                                                  const PaletteOutDev* __restrict__ pal_mem = nullptr, const FrameSync* wait = nullptr,
                                                  const FrameSkinJob* skin = nullptr) {
-    static_assert(!QUIET || (WAIT && WIDE && PACK == 1), "the quiet form belongs to the one-launch frame");
+    static_assert(!QUIET || (WIDE && PACK == 1), "the quiet form belongs to the 256-thread wide-walk launches");
     constexpr bool PROGRAM = MODE != kUpdNoProgram;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // PACK > 1: the workgroup is PACK independent waves, one instance each (rigs of <= 64 nodes: pose_update_pack_kernel) -- a
@@ -1740,7 +1740,7 @@ __global__ __launch_bounds__(256) void pose_frame_inl_kernel(PoseFrameDev f, Rig
 // stores nothing; a stream the job does not have -- no normals, an output not wanted -- is a resource of zero bytes), the palette
 // in LDS is made of the same expressions as the update kernel's palette epilogue: the vertices are lbs_skin's on the palette
 // the update workgroup writes to memory, bit for bit.
-template <int MODE, bool EXACT>
+template <int MODE, bool EXACT, bool WAIT = true>
 __device__ __forceinline__ void frame_skin_body(const PoseFrameDev& fr, const RigDev& rig, uint32_t first_ops, const FrameSync& fs, const FrameSkin& sk, uint32_t b) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     FrameSkinJob j = sk.job[0];
@@ -1767,7 +1767,7 @@ __device__ __forceinline__ void frame_skin_body(const PoseFrameDev& fr, const Ri
     VertexIn<7> A = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vA);
     VertexIn<7> B = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vB);
 
-    if (!pose_update_body<MODE, 1, true, true, true>(fr, rig, inst, first_ops, nullptr, &fs, &j)) return;
+    if (!pose_update_body<MODE, 1, WAIT, true, true>(fr, rig, inst, first_ops, nullptr, &fs, &j)) return;
 
     const f32x4* rows = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + wide_update_lds(rig.n_nodes, rig.n_chunks) + 16u);
     const f32x4* row3 = rows + 3u * j.n_bones;
@@ -1832,6 +1832,25 @@ __global__ __launch_bounds__(256) void pose_update_scene_kernel(const SceneJobDe
     const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     RigDev rig = jobs[b.x].rig;
     pose_update_body<MODE, 1, false, WIDE>(f, rig, b.y, 0u, jobs[b.x].rig.pal);
+}
+
+// The scene's update stage that also skins (fyx_animator_set_skin_output on animators of a fyx_scene_update): block {job, instance, 0, -}
+// updates (and writes poses, matrices, palettes) as pose_update_scene_kernel does; block {job, k, 1, -} is skinning workgroup k of the job:
+// it recomputes the character's pose on chip and skins its share (frame_skin_body without the in-grid wait: the samplers were the
+// previous launch).  One launch where there were two, no palette round trip, the update's latency chain under other characters' stores.
+template <int MODE, bool EXACT>
+__global__ __launch_bounds__(256) void pose_update_skin_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
+    const uint4 b = blocks[blockIdx.x];
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
+    RigDev rig = jobs[b.x].rig;
+    if (b.z == 0u) {
+        pose_update_body<MODE, 1, false, true>(f, rig, b.y, 0u, jobs[b.x].rig.pal);
+        return;
+    }
+    const FrameSkin sk = jobs[b.x].sk;
+    FrameSync none;
+    none.counter = nullptr; none.target = 0; none.n_sample_blocks = 0; none.sx = none.sy = 0; none.timeout_ticks = 0; none.err = nullptr; none.tag = 0;
+    frame_skin_body<MODE, EXACT, false>(f, rig, 0u, none, sk, b.y);
 }
 
 template <typename K, typename... Args>
@@ -1973,6 +1992,8 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[
         for (uint32_t x = 0; x < (s.n_instances + 63) / 64; ++x) t[kStageRootMotionFold].push_back(make_uint4(job, x, 0, 0));
     const uint32_t block = update_block_waves(s.n_nodes, s.n_instances);
     for (uint32_t i = 0; i < s.n_instances; ++i) t[kStageUpdate64 + (int)block - 1].push_back(make_uint4(job, i, 0, 0));
+    if (block == 4u)
+        for (uint32_t k = 0; k < s.skin_blocks; ++k) t[kStageUpdate256].push_back(make_uint4(job, k, 1, 0));
     if (s.n_prop_slots) {
         const uint32_t gx = (s.n_prop_slots + 63) / 64;
         for (uint32_t i = 0; i < s.n_instances; ++i)
@@ -1981,7 +2002,8 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[
 }
 
 hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uint4* const (&d_tables)[kSceneStages],
-                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, bool wide256, hipStream_t s) {
+                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, bool wide256, hipStream_t s,
+                        bool skin256, bool exact) {
     auto go = [&](int stage, auto kernel, uint32_t block, size_t lds) {
         if (n_blocks[stage]) hipLaunchKernelGGL(kernel, dim3(n_blocks[stage]), dim3(block), lds, s, d_jobs, d_ctrl, d_tables[stage]);
     };
@@ -1997,7 +2019,14 @@ hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uin
         if (!n_blocks[k]) continue;
         const uint32_t block = 64u * (uint32_t)(k - kStageUpdate64 + 1);
         hipError_t e = hipSuccess;
-        if (k == kStageUpdate256 && wide256) {     // (the stage's LDS was sized for the wide walk's tables by the caller)
+        if (k == kStageUpdate256 && wide256 && skin256) {     // (LDS: the wide walk's tables + the skinning workgroups' palette, sized by the caller)
+            auto fused = [&](auto kernel) {
+                e = big_lds(reinterpret_cast<const void*>(kernel), lds_bytes[k]);
+                if (e == hipSuccess) go(k, kernel, block, lds_bytes[k]);
+            };
+            if (all_straight) { if (exact) fused(&pose_update_skin_scene_kernel<kUpdStraight, true>); else fused(&pose_update_skin_scene_kernel<kUpdStraight, false>); }
+            else { if (exact) fused(&pose_update_skin_scene_kernel<kUpdGeneral, true>); else fused(&pose_update_skin_scene_kernel<kUpdGeneral, false>); }
+        } else if (k == kStageUpdate256 && wide256) {     // (the stage's LDS was sized for the wide walk's tables by the caller)
             if (all_straight) { e = big_lds(reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdStraight, true>), lds_bytes[k]); if (e == hipSuccess) go(k, pose_update_scene_kernel<kUpdStraight, true>, block, lds_bytes[k]); }
             else { e = big_lds(reinterpret_cast<const void*>(&pose_update_scene_kernel<kUpdGeneral, true>), lds_bytes[k]); if (e == hipSuccess) go(k, pose_update_scene_kernel<kUpdGeneral, true>, block, lds_bytes[k]); }
         } else {

@@ -234,6 +234,13 @@ struct Animator {
     // one of palette_outputs -- as fyx_lbs_skin_device(mesh_id, that palette, n_bones, n_instances, outputs) right behind the update
     struct SkinOut { uint64_t bones_id, mesh_id; float* d_pos; float* d_nrm; float* d_tan; };
     std::vector<SkinOut> skin_outputs;
+    uint64_t api_gen = 1;                   // bumped by every API call that may change what the animator's device-side parameters hold
+    // the skin outputs as a scene's update launch takes them along (FrameSkin): made when api_gen, the context's meshes or the launch
+    // options changed, not every frame
+    FrameSkin scene_skin;
+    uint64_t scene_skin_api_gen = 0, scene_skin_mesh_gen = 0;
+    int scene_skin_units = -1;
+    bool scene_skin_ok = false;             // false: the animator's skin outputs are skinned by launches of their own behind the scene's
     // Property{..} slots: one per distinct (node, property id) any animation of the animator drives
     std::vector<std::pair<int32_t, int32_t>> prop_slots;
     int32_t* d_prop_node = nullptr;
@@ -269,6 +276,7 @@ struct SceneBatch {
     uint32_t n_blocks[kSceneStages] = {};
     size_t lds_bytes[kSceneStages] = {};
     bool wide_update = false;              // the 256-thread update stage runs the wide hierarchy walk (its LDS is sized for it)
+    bool skin_update = false;              // ... and also holds the animators' skinning workgroups (pose_update_skin_scene_kernel)
     CtrlBuffers ctrl;
     std::vector<char> h_jobs, sent_jobs;   // this frame's job array / the one the device holds (d_jobs)
     char* d_jobs = nullptr;

@@ -53,6 +53,7 @@ Animator* find_animator(fyx_ctx* c, uint64_t id) {
     if (!a) return fail((c), FYX_ERR_UNKNOWN_ID, "animator %llu is not registered", (unsigned long long)(id))
 #define FYX_ANIMATOR(c, a, id)                                                                   \
     FYX_ANIMATOR_RO(c, a, id);                                                                   \
+    ++a->api_gen;                                                                                \
     ++a->edit_gen
 
 // ------------------------------------------------------------------------------------------

@@ -352,15 +352,7 @@ struct alignas(16) CtrlInline {
 };
 static_assert(sizeof(CtrlInline) == 16 + kCtrlInlineBytes, "header + payload");
 
-// fyx_scene_update: one parameter block per animator of the scene, read by the *_scene_kernel forms, whose block tables say which
-// job a block works for.  Its control pointers are OFFSETS into the frame's control block (the kernels get the block's address
-// beside the array), so the array itself stays on the device from frame to frame and is sent again only when its bytes change:
-// an animator's device state or palette outputs moved, or a fold program changed its length.
-struct SceneJobDev {
-    PoseFrameDev f;
-    RigDev rig;
-};
-
+struct SceneJobDev;     // (below: it holds a FrameSkin)
 // The stages of a scene frame.  Each has a table of {job, x, y, z} per block (uint4), built by scene_blocks() from the
 // jobs' shapes alone (so it is uploaded once per scene, not per frame) in the order the launch runs them.
 enum SceneStage : int {
@@ -379,6 +371,7 @@ enum SceneStage : int {
 struct SceneJobShape {   // what the tables depend on
     uint32_t n_anims, n_instances, n_nodes, n_prop_slots, sample_form;
     bool root_motion, root_motion_program;
+    uint32_t skin_blocks = 0;     // skinning workgroups of the job in the update stage (the 256-thread stage only: {job, block, 1, -} behind the job's {job, instance, 0, -})
 };
 // Appends job `job`'s blocks to the per-stage tables.
 void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&tables)[kSceneStages]);
@@ -386,8 +379,11 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&tab
 // LDS of the update stages (the largest rig of the stage).
 // all_straight: every fold program of every job is straight (classify_fold_program, anim_leaves.h): the update stages run
 // the kernel form without the interpreter.
+// skin256: the 256-thread update stage's table also holds the jobs' skinning workgroups (SceneJobShape::skin_blocks): ONE launch updates
+// and skins (the skinning workgroups recompute their character's pose on chip, FrameSkin); exact: lbs.exact for them.
 hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uint4* const (&d_tables)[kSceneStages],
-                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, bool wide256, hipStream_t s);
+                        const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, bool wide256, hipStream_t s,
+                        bool skin256 = false, bool exact = true);
 
 // `inl` (optional): the frame's control block travelling in the kernel arguments, see CtrlInline.
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);
@@ -462,7 +458,19 @@ struct FrameSkin {
 // budget of the kernel without the interpreter (230 VGPRs), one per CU with it (404) -- so no workgroup ever waits for one that
 // has no place to run, whatever order the dispatcher takes them in.
 constexpr uint32_t kFrameSkinMaxBlocks = 448, kFrameSkinMaxBlocksGeneral = 192;
+constexpr uint32_t kSceneSkinMaxUnits = 4096;      // a scene's update launch takes the skin outputs along up to this many 64-vertex units (~260 k vertices): see scene_frame
 constexpr uint32_t kFrameSkinAutoBlocks = 224;     // what anim.frame_skin_units = 0 aims for: a CU per skinning workgroup (256 CUs, the pose workgroups beside them)
+
+// fyx_scene_update: one parameter block per animator of the scene, read by the *_scene_kernel forms, whose block tables say which
+// job a block works for.  Its control pointers are OFFSETS into the frame's control block (the kernels get the block's address
+// beside the array), so the array itself stays on the device from frame to frame and is sent again only when its bytes change:
+// an animator's device state or palette outputs moved, or a fold program changed its length.
+struct SceneJobDev {
+    PoseFrameDev f;
+    RigDev rig;
+    FrameSkin sk;        // the animator's skin outputs the scene's update launch skins itself (n_jobs = 0: none)
+};
+
 // wait: timeout_ticks, err and tag of the frame's FrameSync (the rest is filled in here); skin: null, or the meshes the launch skins itself
 hipError_t launch_pose_frame(const PoseFrameDev& f, const RigDev& rig, int mode, hipStream_t s, const CtrlInline& inl, uint32_t* counter, uint32_t* counter_total,
                              const FrameSync& wait, const FrameSkin* skin = nullptr, bool exact = true);

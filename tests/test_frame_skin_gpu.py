@@ -345,3 +345,63 @@ def test_frames_that_skin_over_many_frames_beside_a_chip_filling_co_runner(ctx):
             b.free()
         ctx.mesh_free(9710)
         ctx.mesh_free(9711)
+
+
+def test_a_scene_whose_update_launch_skins(ctx, orc):
+    """fyx_scene_update over several animators, some with skin outputs (one with two, one with two instances), one without: the
+    scene's update stage holds their skinning workgroups (pose_update_skin_scene_kernel).  Every frame: the skin outputs against
+    fyx_lbs_skin_device on the palettes the same update wrote; palettes of every animator against an oracle; options switched
+    between frames (anim.frame_skin = 0: separate launches behind the scene's; anim.frame_skin_units; anim.update_lean)."""
+    specs = [(cases.c5_blend_tree(euler_every=10 ** 6), 1, 6000), (cases.transitions(), 2, 1500), (cases.layered(), 1, 0),
+             (cases.player_only(euler_every=10 ** 6), 1, 9001), (cases.by_index(), 1, 300)]
+    chars = []
+    for sc, n_inst, nv in specs:
+        o = cases.build_oracle(orc, sc)
+        p = cases.build_product(ctx, sc, n_inst)
+        nb = sc.rig.n_nodes
+        base = p.base_id
+        A.create_bone_list(ctx, base + 50, base, list(range(nb)))
+        d_pal = ctx.malloc(n_inst * nb * 64)
+        p.set_palette_output(base + 50, d_pal.ptr)
+        rec = {"sc": sc, "o": o, "p": p, "nb": nb, "n_inst": n_inst, "pal": d_pal, "meshes": []}
+        if nv:
+            for j, (verts, mask) in enumerate(((nv, 7), (nv // 3 + 65, 1)) if sc.name == "c5_blend_tree" else ((nv, 7),)):
+                mesh = synth.make_mesh(verts, nb, synth.SEED_BASE + 30 + j)
+                ctx.mesh_upload_soa(base + 60 + j, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+                f, s = Outs(ctx, n_inst * verts), Outs(ctx, n_inst * verts)
+                p.set_skin_output(base + 50, base + 60 + j, f.pos.ptr, f.nrm.ptr if mask & 2 else 0, f.tan.ptr if mask & 4 else 0)
+                rec["meshes"].append((base + 60 + j, verts, mask, f, s))
+        chars.append(rec)
+    forms = [(1, 0, 1), (0, 0, 1), (2, 4, 1), (1, 1, 0), (2, 16, 1), (1, 0, 1)]
+    try:
+        for f in range(18):
+            fs, units, lean = forms[f % len(forms)]
+            ctx.set_option("anim.frame_skin", fs)
+            ctx.set_option("anim.frame_skin_units", units)
+            ctx.set_option("anim.update_lean", lean)
+            for ch in chars:
+                for idx, par in ch["sc"].script.get(f, []):
+                    ch["o"].set_parameter(idx, par)
+                    ch["p"].set_parameter(idx, par)
+                _oupdate(ch["o"], ch["sc"])
+            A.scene_update(ctx, [ch["p"] for ch in chars], chars[0]["sc"].dt)
+            for ch in chars:
+                for mid, verts, mask, fo, so in ch["meshes"]:
+                    ctx.lbs_skin_device(mid, ch["pal"].ptr, ch["nb"], ch["n_inst"], so.pos.ptr, so.nrm.ptr if mask & 2 else 0, so.tan.ptr if mask & 4 else 0)
+                    for k, (x, y) in enumerate(zip(fo.get(), so.get())):
+                        if mask & (1, 2, 4)[k]:
+                            assert np.array_equal(x, y), f"frame {f} form {forms[f % len(forms)]}: {ch['sc'].name} mesh {mid} stream {k}"
+                pal = ch["pal"].download(np.float32, ch["n_inst"] * ch["nb"] * 16).reshape(ch["n_inst"], ch["nb"], 16)
+                ref = ch["o"].palette(list(range(ch["nb"])))
+                assert np.array_equal(pal[0].view(np.uint32), ref.view(np.uint32)), f"frame {f}: palette of {ch['sc'].name}"
+    finally:
+        for k, v in (("anim.frame_skin", 1), ("anim.frame_skin_units", 0), ("anim.update_lean", 1)):
+            ctx.set_option(k, v)
+        for ch in chars:
+            ch["o"].close()
+            ch["p"].free()
+            ch["pal"].free()
+            for mid, verts, mask, fo, so in ch["meshes"]:
+                fo.free()
+                so.free()
+                ctx.mesh_free(mid)
