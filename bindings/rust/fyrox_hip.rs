@@ -322,6 +322,14 @@ impl<'a> HipAnimator<'a> {
         self.hip.check(rc)
     }
 
+    /// Every update of this animator also skins surface `mesh_key` with the palette output of `bones_id` into the three streams
+    /// (`[n_instances][n_verts]`, null = not wanted; all null removes the entry): the character's frame is ONE call -- and, for one
+    /// character, one launch (fyx_animator_set_skin_output, include/fyrox_hip.h).
+    pub fn set_skin_output(&mut self, bones_id: u64, mesh_key: u64, d_pos: *mut f32, d_normal: *mut f32, d_tangent: *mut f32) -> Result<(), HipError> {
+        let rc = unsafe { fyx_animator_set_skin_output(self.hip.ctx, self.id, bones_id, mesh_key, d_pos, d_normal, d_tangent) };
+        self.hip.check(rc)
+    }
+
     /// `Mesh::collect_render_data`'s `bone_matrices` (`scene/mesh/mod.rs:781-793`) for every instance, on the device.
     pub fn palette(&mut self, bones_id: u64, d_out: *mut f32) -> Result<(), HipError> {
         let rc = unsafe { fyx_animator_palette(self.hip.ctx, self.id, bones_id, d_out) };

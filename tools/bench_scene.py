@@ -28,6 +28,7 @@ ap.add_argument("--bones", type=int, default=64)
 ap.add_argument("--frames", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=60)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--shared-clips", action="store_true", help="diagnostic: every character plays the SAME four tracks data (their span records stay in cache)")
 ap.add_argument("--batched-only", action="store_true", help="skip the one-by-one legs (short runs under a profiler)")
 args = ap.parse_args()
 
@@ -44,9 +45,11 @@ for k in range(K):
     A.create_rig(ctx, rid, rig)
     an = A.Animator(ctx, aid, rid, rig, N)
     for c in range(4):
-        td, tgt = synth.make_clip(args.bones, seed, clip=c)
-        A.upload_tracks_data(ctx, 10_000 + 4 * k + c, td)
-        an.add_animation(10_000 + 4 * k + c, tgt, time_slice=(0.0, 1.0), speed=[1.0, 0.8, 1.3, -0.7][c])
+        td, tgt = synth.make_clip(args.bones, synth.SEED_BASE + 100 if args.shared_clips else seed, clip=c)
+        tid = 10_000 + c if args.shared_clips else 10_000 + 4 * k + c
+        if not (args.shared_clips and k > 0):
+            A.upload_tracks_data(ctx, tid, td)
+        an.add_animation(tid, tgt, time_slice=(0.0, 1.0), speed=[1.0, 0.8, 1.3, -0.7][c])
     an.set_machine(synth.make_c5_machine())
     for i in range(N):
         for c in range(4):
