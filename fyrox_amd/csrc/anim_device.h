@@ -62,6 +62,19 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         A.dev_track_capacity = new_tracks;
         A.anims_dirty = true;
     }
+    // the per-instance sampler's own hints: one word per (animation, node, binding, curve, instance)
+    {
+        const size_t want = (size_t)std::max(A.dev_anim_capacity, 1u) * rig.n_nodes * 12 * A.n_instances;
+        if (want > A.slot_hint_words) {
+            if (int rc_ = sync_all(c)) return rc_;
+            dfree(A.d_slot_hints);
+            A.d_slot_hints = nullptr;
+            A.slot_hint_words = 0;
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_slot_hints), std::max<size_t>(want * 4, 16)));
+            FYX_HIP(c, hipMemset(A.d_slot_hints, 0, std::max<size_t>(want * 4, 16)));
+            A.slot_hint_words = want;
+        }
+    }
     // slot tables + animation descriptors
     bool any_slots = false;
     for (AnimationDef& an : A.anims) any_slots |= an.slots_dirty;
@@ -276,6 +289,7 @@ void frame_static(const fyx_ctx* c, const Animator& A, PoseFrameDev& f) {
     f.n_nodes = A.rig->n_nodes;
     f.layer_masks = A.d_layer_masks;
     f.hints = A.d_hints;
+    f.slot_hints = A.d_slot_hints;
     f.max_tracks = A.dev_track_capacity;
     f.sample_form = (uint32_t)c->sample_form;
     f.anim_pose = A.d_anim_pose;

@@ -219,12 +219,11 @@ struct RecAux {
 // node), its ten curves one after another, then the update body behind a barrier: C2 18.6 us against 15.8, C5 25.5 against 18.0 with
 // the two launches; ten dependent sample chains per lane cost more than a launch boundary.  Not kept.)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a, const CrowdDesc& d, uint32_t c, uint32_t inst, float time) {
+// hp / hint: the curve's span hint and where it lives (the caller requested it together with the descriptor)
+__device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a, const CrowdDesc& d, uint32_t c, uint32_t* hp, uint32_t hint, float time) {
     const uint32_t track = d.track;
     const int need = (int)d.need;
     float v = 0.0f;
-    uint32_t* hp = hint_ptr(f, a, track, c, inst);
-    uint32_t hint = *hp;
     // Steady playback: the time lies strictly inside the hinted span [key hint - 1, key hint).  Curve::value_at then
     // clamps nothing (first.location <= left < time < right <= last.location), takes its hinted span and leaves the
     // hint alone (curve.rs:254-314) -- and the track's span record (TrackHot) holds everything that needs: one cache
@@ -308,6 +307,11 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
         // Requested BEFORE the tick flag is looked at: its address does not depend on it, and the early return below would
         // otherwise put a round trip of its own in front of this one.
         const CrowdDesc d = f.crowd[((size_t)a * f.n_nodes + node) * 3 + (uint32_t)(bind >= 0 ? bind : 0)];
+        // ... and the lane's span hint with it: its slot is a function of (animation, node, binding, curve, instance), nothing the
+        // descriptor has to say first (round 5: one dependent round trip less in a kernel that is made of them)
+        uint32_t* hp = f.slot_hints + ((((size_t)a * f.n_nodes + node) * 3 + (uint32_t)(bind >= 0 ? bind : 0)) * 4 + (uint32_t)c) * f.n_instances + inst;
+        uint32_t hint = 0;
+        if (bind >= 0) hint = *hp;
         const float time = f.times[(size_t)inst * f.n_anims + a];
         if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      // uniform across the block
         const size_t item = ((size_t)a * f.n_instances + inst) * f.n_nodes + node;
@@ -320,7 +324,7 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
             kind = d.kind;
             need = (int)d.need;
             valid = d.valid != 0;                                 // else fetch() -> None
-            if (valid && c < need) v = sample_curve(f, a, d, (uint32_t)c, inst, time);
+            if (valid && c < need) v = sample_curve(f, a, d, (uint32_t)c, hp, hint, time);
         }
         const int has_p = __shfl((int)valid, (int)gbase + 0, 64);
         const int has_r = __shfl((int)valid, (int)gbase + 4, 64);

@@ -188,6 +188,8 @@ struct Animator {
     CrowdDesc* d_crowd = nullptr;   // [anims][nodes][3]
     bool anims_dirty = true;
     uint32_t* d_hints = nullptr;
+    uint32_t* d_slot_hints = nullptr;       // PoseFrameDev::slot_hints (hints are advisory: a fresh array of zeros is "no hint")
+    size_t slot_hint_words = 0;
     float4* d_anim_pose = nullptr;
     uint32_t dev_anim_capacity = 0, dev_track_capacity = 0;
     float4* d_node_trs = nullptr;

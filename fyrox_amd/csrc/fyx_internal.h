@@ -318,7 +318,8 @@ struct PoseFrameDev {
                                  //   lanes (= instances of one curve) touch one dense span
     uint32_t max_tracks;
     uint32_t sample_form;        // 0 auto (instances on the lanes from 32 instances), 1 curves on the lanes, 2 instances on the lanes
-    uint32_t pad0[2];            // (sizeof(PoseFrameDev) is a multiple of 16: see CtrlInline)
+    uint32_t* slot_hints;        // [n_anims][n_nodes][3 bindings][4 curves][n_instances]: the per-instance sampler's span hints, indexed by what the
+                                 //   lane knows BEFORE it has its descriptor (round 5: the hint's load no longer waits for the descriptor's)
     float4* anim_pose;           // [n_anims][n_instances][n_nodes][3]
     float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
     float* local;                // [n_instances][n_nodes][16]
