@@ -740,14 +740,28 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
                             S.skin_update, c->lbs.exact != 0));
     if (int rc = ctrl_consumed(c, S.ctrl, slot, ps)) return rc;
     if (int rc = exit_pose(c)) return rc;
-    // the animators' skin outputs (fyx_animator_set_skin_output): behind the scene's update launch, on the frame's stream
+    // the animators' skin outputs that did not ride in the update launch (a large scene, anim.frame_skin = 0, a stage that is not the
+    // 256-thread one): ONE batched skinning launch for all of them, behind the scene's update launch on the frame's stream -- what
+    // fyx_lbs_skin_batch does for the same list (its plan and device tables are cached from frame to frame)
+    S.skin_jobs.clear();
     for (size_t k = 0; k < n; ++k) {
         const Animator& A = *S.animators[k];
         if (A.skin_outputs.empty() || (S.skin_update && A.scene_skin_ok)) continue;     // (skinned by the update launch itself)
-        LbsArgs skin_args[kMaxFrameSkins];
-        if (int rc = skin_output_args(c, A, skin_args)) return rc;
-        for (size_t j = 0; j < A.skin_outputs.size(); ++j) FYX_HIP(c, launch_lbs(skin_args[j], c->lbs, ps));
+        for (const Animator::SkinOut& so : A.skin_outputs) {
+            const Animator::PaletteOut* po = nullptr;
+            for (const Animator::PaletteOut& p : A.palette_outputs)
+                if (p.bones_id == so.bones_id) po = &p;
+            if (!po) return fail(c, FYX_ERR_INVALID_ARG, "skin output of mesh %llu: bone list %llu is no longer a palette output of the animator",
+                                 (unsigned long long)so.mesh_id, (unsigned long long)so.bones_id);
+            fyx_skin_job j;
+            memset(&j, 0, sizeof j);
+            j.mesh_id = so.mesh_id; j.d_palette = po->d_out; j.n_bones = po->n_bones; j.n_instances = A.n_instances;
+            j.d_out_pos = so.d_pos; j.d_out_normal = so.d_nrm; j.d_out_tangent = so.d_tan;
+            S.skin_jobs.push_back(j);
+        }
     }
+    if (!S.skin_jobs.empty())
+        if (int rc = fyx_lbs_skin_batch(c, S.skin_jobs.data(), (uint32_t)S.skin_jobs.size())) return rc;
     return FYX_OK;
 }
 
