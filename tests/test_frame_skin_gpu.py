@@ -150,7 +150,7 @@ def test_forms_of_the_frame_and_every_fallback_give_the_same_vertices(ctx, orc):
         ctx.mesh_free(base + 61)
 
 
-@pytest.mark.parametrize("what", ["crowd", "root_motion", "scene", "update_transforms", "fused_arithmetic"])
+@pytest.mark.parametrize("what", ["crowd", "root_motion", "scene", "big_scene", "update_transforms", "fused_arithmetic"])
 def test_frames_that_cannot_take_the_skinning_along(ctx, orc, what):
     """A crowd (the frame is not one launch), root motion (two more kernels), fyx_scene_update, fyx_animator_update_transforms, and
     lbs.exact = 0: the skin outputs are still written by the update call, with fyx_lbs_skin_device's bits."""
@@ -165,7 +165,7 @@ def test_frames_that_cannot_take_the_skinning_along(ctx, orc, what):
     A.create_bone_list(ctx, base + 50, base, list(range(nb)))
     d_pal = ctx.malloc(n_inst * nb * 64)
     p.set_palette_output(base + 50, d_pal.ptr)
-    nv = 3000
+    nv = 300_000 if what == "big_scene" else 3000      # big_scene: past kSceneSkinMaxUnits -- ONE batched launch behind the scene's update launch
     mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + 24)
     ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
     fused, sep = Outs(ctx, n_inst * nv), Outs(ctx, n_inst * nv)
@@ -174,7 +174,7 @@ def test_frames_that_cannot_take_the_skinning_along(ctx, orc, what):
         ctx.set_option("lbs.exact", 0)
     try:
         for f in range(6):
-            if what == "scene":
+            if what in ("scene", "big_scene"):
                 A.scene_update(ctx, [p], sc.dt)
             elif what == "update_transforms":
                 p.update_transforms()
