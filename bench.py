@@ -125,6 +125,60 @@ def box_facts(device_index: int = 0) -> dict:
     return out
 
 
+def pmc_traffic(n_verts: int, n_bones: int, timeout_s: float = 150.0) -> dict:
+    """roofline.traffic measured in THIS run: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, each with --kernel-trace only, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: separate passes, no other trace domain) over tools/pmc_probe_headline.py -- a dozen
+    launches of a stream copy of KNOWN bytes (60 MB read + 40 MB written) and a dozen of the headline kernel.  The counters are in KB and
+    FETCH_SIZE counts a 128-byte request as 64 on gfx950: both are calibrated on the copy in the same pass.  Returns {"hbm_bytes_per_launch",
+    "read", "written", factors, "source"} or {"error": ...}; never raises."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof:
+        return {"error": "rocprofv3 is not installed"}
+    probe = os.path.join(ROOT, "tools", "pmc_probe_headline.py")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="fyx_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cp = subprocess.run([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, probe, "12",
+                                 str(n_verts), str(n_bones)], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if cp.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {counter}: rc {cp.returncode}, {'no' if not files else 'a'} counter file; {cp.stderr[-300:]!r}"}
+            groups = {"copy": [], "skin": []}
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] != counter:
+                    continue
+                name = r["Kernel_Name"]
+                key = "copy" if "stream_copy" in name else "skin" if "lbs_skin" in name else None
+                if key:
+                    groups[key].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+            if len(groups["copy"]) < 4 or len(groups["skin"]) < 4:
+                return {"error": f"--pmc {counter}: {len(groups['copy'])} copy and {len(groups['skin'])} skinning dispatches in the counter file"}
+            med = {k: statistics.median(v for _, v in sorted(g)[2:]) for k, g in groups.items()}     # the first launches warm the caches
+            known = 60e6 if counter == "FETCH_SIZE" else 40e6
+            factor = known / (med["copy"] * 1024.0)
+            out[counter] = {"factor_on_the_stream_copy": factor, "bytes": med["skin"] * 1024.0 * factor, "raw_kb": med["skin"], "dispatches": len(groups["skin"]) - 2}
+        return {"hbm_bytes_per_launch": out["FETCH_SIZE"]["bytes"] + out["WRITE_SIZE"]["bytes"], "read": out["FETCH_SIZE"]["bytes"], "written": out["WRITE_SIZE"]["bytes"],
+                "fetch_factor_on_stream_copy": out["FETCH_SIZE"]["factor_on_the_stream_copy"], "write_factor_on_stream_copy": out["WRITE_SIZE"]["factor_on_the_stream_copy"],
+                "dispatches_per_counter": out["FETCH_SIZE"]["dispatches"],
+                "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/pmc_probe_headline.py, "
+                          "calibrated on the stream copy of known bytes in the same pass (FETCH_SIZE counts 128-byte requests as 64 on gfx950)"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"a rocprofv3 pass did not finish within {timeout_s:.0f} s"}
+    except Exception as e:     # noqa: BLE001
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def emit(line: str) -> None:
     """Rank 0's ONE JSON line, as the last thing on stdout: whatever native libraries have buffered in C stdio (RCCL prints
     a version banner through it, which would otherwise come out at exit, after the line) is flushed first."""
@@ -155,6 +209,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C3 / C5 sub-records")
     ap.add_argument("--extras-only", action="store_true", help="(internal) run only the sub-records, in this fresh process, and print them")
     ap.add_argument("--max-repeats", type=int, default=4000)
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic now (two rocprofv3 --pmc passes of ~15 s in child processes); replay the builder's")
     ap.add_argument("--one-process", action="store_true",
                     help="N > 1 without a launcher and without torch.distributed: ONE process drives all N GPUs, one fyx context and one "
                          "host thread per GPU, the exchange through fyx_comm_init_all / fyx_allgather_skinned_all.  Taken automatically when "
@@ -1468,9 +1523,14 @@ def main():
         launch_us = float(np.median(gpus)) * 1e3 / timed_steps          # per launch in the timed region (launches overlap)
         bytes_launch = BYTES_PER_VERTEX * nv
         achieved = bytes_launch / (kernel_us * 1e-6) / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_live = None, None, None
+        if world == 1 and not args.no_pmc and not args.random_bones:      # measured now, by two short rocprofv3 passes in child processes
+            ctx.sync()
+            traffic_live = pmc_traffic(nv, args.bones)
+            if "error" not in traffic_live:
+                traffic, traffic_src = traffic_live["hbm_bytes_per_launch"], traffic_live["source"]
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):                        # PMC-derived HBM bytes per launch (see profiles/README.md)
+        if traffic is None and os.path.exists(tpath):    # the builder's last PMC run, labelled as such (see profiles/README.md)
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 traffic_src = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, builder run; not measured in this run)"
@@ -1498,7 +1558,7 @@ def main():
                        "process_group": dist_backend,
                        "kernel_options": opts},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_measurement": traffic_live,
                          "kernel": kname, "kernel_us": kernel_us,
                          "kernel_us_min": float(np.min(alloc_us)), "kernel_us_median": float(np.median(alloc_us)), "kernel_us_max": float(np.max(alloc_us)),
                          "kernel_us_per_allocation": alloc_us,

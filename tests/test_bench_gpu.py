@@ -66,3 +66,11 @@ def test_the_headline_line_carries_the_box_facts():
     for when in ("at_start", "after_headline", "at_end"):
         assert when in d["box"], when
     assert d["box"]["hip_device"].get("name")
+    # roofline.traffic: measured in this run by two rocprofv3 --pmc passes (or, when rocprofv3 cannot run here, the reason and the labelled replay)
+    tm = d["roofline"]["traffic_measurement"]
+    assert isinstance(tm, dict)
+    if "error" not in tm:
+        assert 0.95e8 < tm["hbm_bytes_per_launch"] < 1.2e8, tm
+        assert d["roofline"]["traffic"] == tm["hbm_bytes_per_launch"] and "measured in this run" in d["roofline"]["traffic_source"]
+    else:
+        assert d["roofline"]["traffic"] is None or "not measured in this run" in d["roofline"]["traffic_source"]

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=gpurun_out/prof05
 mkdir -p $OUT
-HEAD="python $ROOT/bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-extras"
+HEAD="python $ROOT/bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-extras --no-pmc"
 # 1. the headline leg three times, each process under the kernel trace AND reading its own per-dispatch events (one launch stream)
 for k in 1 2; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/head$k" -o bench -- $HEAD --opt lbs.streams=1 > "$ROOT/$OUT/head$k.json" 2> "$ROOT/$OUT/head$k.err" )
