@@ -616,25 +616,37 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
             if (mit != c->meshes.end()) skin_units += (uint64_t)A.n_instances * ((mit->second.n_verts + 63u) / 64u);
         }
     }
-    const bool skin_update = any_skin && stage256 && wide_all + frame_skin_lds(256) <= kLdsPerWorkgroup &&
-                             (skin_units <= kSceneSkinMaxUnits || c->frame_skin == 2);
+    // The scene as ONE launch (scene_frame_kernel, kStageFrame): every animator a character of the per-instance sampler form without root
+    // motion or property tracks -- sampler, update and skinning workgroups of all of them in one grid, job after job.  Built, tested
+    // (2000 frames against the stage-by-stage form, a poisoned counter) and MEASURED SLOWER (profiles/r05_scene_one_launch.jsonl: 256 x 5 k
+    // 73.0 us against 60.3, 64 x 4 x 20 k 138.6 against 107.8, 32 x 5 k 27.4 against 26.3 / 21.9 with the update stage skinning): the
+    // samplers inherit the fused kernel's 157 registers (three waves per SIMD instead of eight) and waiting workgroups hold places.  It runs
+    // only when asked for: anim.frame_skin = 3.
+    bool one_frame = c->one_launch != 0 && c->frame_skin != 0 && any_skin && stage256 && wide_all + frame_skin_lds(256) <= kLdsPerWorkgroup;
+    for (size_t k = 0; k < n && one_frame; ++k) {
+        const Animator& A = *S.animators[k];
+        one_frame = !A.rm_enabled && A.prop_slots.empty() && !A.anims.empty() && (c->sample_form == 1 || (c->sample_form == 0 && A.n_instances < 32));
+    }
+    one_frame = one_frame && c->frame_skin == 3;
+    const bool skin_update = (any_skin && stage256 && wide_all + frame_skin_lds(256) <= kLdsPerWorkgroup &&
+                              (skin_units <= kSceneSkinMaxUnits || c->frame_skin == 2) && c->frame_skin != 3) || one_frame;
     std::vector<uint64_t> sig;
     sig.reserve(n * 4 + 1);
-    sig.push_back((uint64_t)c->sample_form | (skin_update ? 16u : 0u));
+    sig.push_back((uint64_t)c->sample_form | (skin_update ? 16u : 0u) | (one_frame ? 32u : 0u));
     for (size_t k = 0; k < n; ++k) {
         Animator& A = *S.animators[k];
         if (int rc = ensure_device_state(c, A)) return rc;
         uint32_t skin_blocks = 0;
         if (skin_update && !A.skin_outputs.empty()) {
-            if (A.scene_skin_api_gen != A.api_gen || A.scene_skin_mesh_gen != c->mesh_gen || A.scene_skin_units != c->frame_skin_units) {
+            if (A.scene_skin_api_gen != A.api_gen || A.scene_skin_mesh_gen != c->mesh_gen || A.scene_skin_units != c->frame_skin_units + (one_frame ? 1000 : 0)) {
                 LbsArgs args[kMaxFrameSkins];
                 if (int rc = skin_output_args(c, A, args)) return rc;
-                const uint32_t share = std::max<uint32_t>(1u, 512u / (uint32_t)n);
+                const uint32_t share = std::max<uint32_t>(1u, (one_frame ? 640u : 512u) / (uint32_t)n);
                 A.scene_skin_ok = frame_skin_plan(c, A, args, (uint32_t)A.skin_outputs.size(), kFrameSkinMaxBlocks, A.scene_skin, share);
                 if (!A.scene_skin_ok) memset(&A.scene_skin, 0, sizeof A.scene_skin);
                 A.scene_skin_api_gen = A.api_gen;
                 A.scene_skin_mesh_gen = c->mesh_gen;
-                A.scene_skin_units = c->frame_skin_units;
+                A.scene_skin_units = c->frame_skin_units + (one_frame ? 1000 : 0);
             }
             if (A.scene_skin_ok) {
                 skin_blocks = A.scene_skin.n_blocks;
@@ -654,6 +666,13 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
             const Animator& A = *S.animators[k];
             SceneJobShape sh = scene_shape(c, A, A.dev_prop_slots);
             if (skin_update && A.scene_skin_ok && !A.skin_outputs.empty()) sh.skin_blocks = A.scene_skin.n_blocks;
+            if (one_frame) {      // the whole scene in one launch: this job's samplers, then its update workgroups, then its skinning workgroups
+                const uint32_t nsb = ((sh.n_nodes * 16u + 255u) / 256u) * sh.n_instances * sh.n_anims;
+                for (uint32_t i = 0; i < nsb; ++i) tables[kStageFrame].push_back(make_uint4((uint32_t)k, i, 0, 0));
+                for (uint32_t i = 0; i < sh.n_instances; ++i) tables[kStageFrame].push_back(make_uint4((uint32_t)k, i, 1, 0));
+                for (uint32_t i = 0; i < sh.skin_blocks; ++i) tables[kStageFrame].push_back(make_uint4((uint32_t)k, i, 2, 0));
+                continue;
+            }
             scene_blocks((uint32_t)k, sh, tables);
             const int stage = kStageUpdate64 + (int)update_block_waves(sh.n_nodes, sh.n_instances) - 1;
             lds[stage] = std::max(lds[stage], (size_t)sh.n_nodes * 32 * sizeof(float));
@@ -662,8 +681,10 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         // the 256-thread updates walk the hierarchy wide (a lane per matrix element) when every rig's chunk table fits the LDS
         S.wide_update = wide256 > 0 && wide256 <= kLdsPerWorkgroup;
         if (S.wide_update) lds[kStageUpdate256] = wide256;
-        S.skin_update = skin_update && S.wide_update && max_skin_bones > 0;
+        S.skin_update = skin_update && (S.wide_update || one_frame) && max_skin_bones > 0;
         if (S.skin_update) lds[kStageUpdate256] = wide256 + frame_skin_lds(max_skin_bones);
+        S.one_frame = one_frame && S.skin_update;
+        if (one_frame) lds[kStageFrame] = wide_all + frame_skin_lds(std::max(max_skin_bones, 1u));
         size_t total = 0;
         for (int k = 0; k < kSceneStages; ++k) {
             if (tables[k].size() > 0x7fffffffull) return fail(c, FYX_ERR_UNSUPPORTED, "scene too large for one launch per stage");
@@ -694,6 +715,9 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         S.offsets[k] = total;
         total += S.layouts[k].total;
     }
+    // (the one-launch frame: every job's counter target of THIS frame, behind the animators' sections)
+    const size_t o_targets = align_up(total, 16);
+    if (S.one_frame) total = o_targets + align_up(n * 4, 16);
     S.h_jobs.resize(n * sizeof(SceneJobDev));      // (every byte of a job is written below: frame_static and rig_dev start from zeros)
     SceneJobDev* jobs = reinterpret_cast<SceneJobDev*>(S.h_jobs.data());
     for (size_t k = 0; k < n; ++k) {
@@ -703,6 +727,22 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         if (int rc = rig_params(c, A, jobs[k].rig)) return rc;
         if (S.skin_update && A.scene_skin_ok && !A.skin_outputs.empty()) jobs[k].sk = A.scene_skin;
         else memset(&jobs[k].sk, 0, sizeof jobs[k].sk);
+        jobs[k].counter = nullptr;
+        jobs[k].tag = 0;
+        jobs[k].n_sample_blocks = jobs[k].sx = 0;
+        if (S.one_frame) {
+            Animator& Aw = *S.animators[k];
+            if (!Aw.d_frame_counter) {      // the animator's frame counter, on its first one-launch frame (as run_frame)
+                const size_t cb = (size_t)kFrameCounterReplicas * kFrameCounterStride;
+                FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&Aw.d_frame_counter), cb));
+                Aw.frame_counter_total = 0;
+                FYX_HIP(c, hipMemsetAsync(Aw.d_frame_counter, 0, cb, ps));
+            }
+            jobs[k].counter = Aw.d_frame_counter;
+            jobs[k].tag = Aw.id;
+            jobs[k].sx = (A.rig->n_nodes * 16u + 255u) / 256u;
+            jobs[k].n_sample_blocks = jobs[k].sx * A.n_instances * (uint32_t)A.anims.size();
+        }
     }
     // A job array that changed travels through the frame's PINNED staging block, behind the control sections (the block is not
     // rewritten before the event behind this frame's kernels: ctrl_consumed) -- not from the pageable vector, which the next frame
@@ -713,6 +753,10 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     char *h = nullptr, *d = nullptr;
     if (int rc = ctrl_acquire(c, S.ctrl, send_jobs ? o_jobs + S.h_jobs.size() : std::max<size_t>(total, 16), &slot, &h, &d)) return rc;
     for (size_t k = 0; k < n; ++k) ctrl_write(*S.animators[k], S.layouts[k], h + S.offsets[k]);
+    if (S.one_frame) {
+        uint32_t* tg = reinterpret_cast<uint32_t*>(h + o_targets);
+        for (size_t k = 0; k < n; ++k) tg[k] = S.animators[k]->frame_counter_total + jobs[k].n_sample_blocks;
+    }
     if (send_jobs) {
         if (S.h_jobs.size() > S.d_jobs_capacity) {
             if (int rc_ = sync_all(c)) return rc_;       // launches in flight read the old array
@@ -736,8 +780,14 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
     bool all_straight = c->upd_lean != 0;
     for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
+    SceneWait sw;
+    sw.o_targets = (uint32_t)o_targets;
+    sw.timeout_ticks = (uint32_t)c->wait_timeout_ms * 100000u;
+    sw.err = reinterpret_cast<uint32_t*>(c->dev_err);
     FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs), d, tabs, S.n_blocks, S.lds_bytes, all_straight, S.wide_update, ps,
-                            S.skin_update, c->lbs.exact != 0));
+                            S.skin_update, c->lbs.exact != 0, S.one_frame ? &sw : nullptr));
+    if (S.one_frame)      // (a launch that was refused has added nothing to the counters)
+        for (size_t k = 0; k < n; ++k) S.animators[k]->frame_counter_total += jobs[k].n_sample_blocks;
     if (int rc = ctrl_consumed(c, S.ctrl, slot, ps)) return rc;
     if (int rc = exit_pose(c)) return rc;
     // the animators' skin outputs that did not ride in the update launch (a large scene, anim.frame_skin = 0, a stage that is not the

@@ -1315,7 +1315,11 @@ __device__ __forceinline__ void report_frame_wait(const FrameSync& w, uint32_t s
 // QUIET (a skinning workgroup of the one-launch frame, frame_skin_body): everything up to the global matrices in LDS, NOTHING stored to
 // memory, then the palette of `skin`'s bone list straight into the skinning kernels' LDS layout (behind the update's own LDS areas).
 // Returns false when an in-grid wait timed out (reported through FrameSync::err; nothing was computed).
-template <int MODE, int PACK = 1, bool WAIT = false, bool WIDE = false, bool QUIET = false>
+// INV: the update workgroup's agent-scope acquire behind the wait (one character: by the book; a scene's one-launch frame has hundreds of
+// update workgroups and leaves it out for the reason the skinning workgroups do, see the WAIT block)
+// LATE (with QUIET): the palette's bone -> node words and inverse bind columns are requested behind the walk instead of at the top -- a
+// scene's workgroups hide that latency behind one another, and twenty registers less across the fold are a wave more per SIMD.
+template <int MODE, int PACK = 1, bool WAIT = false, bool WIDE = false, bool QUIET = false, bool INV = true, bool LATE = false>
 __device__ __forceinline__ bool pose_update_body(const PoseFrameDev& f, const RigDev& rig, const uint32_t inst, const uint32_t first_ops = 0,
                                                  const PaletteOutDev* __restrict__ pal_mem = nullptr, const FrameSync* wait = nullptr,
                                                  const FrameSkinJob* skin = nullptr) {
@@ -1380,7 +1384,7 @@ __device__ __forceinline__ bool pose_update_body(const PoseFrameDev& f, const Ri
     // first loads of the kernel; the inverse bind columns they lead to follow just ahead of the wait for the samplers.
     int32_t q_node[4] = {-1, -1, -1, -1};
     f4 q_bb[4];
-    if constexpr (QUIET) {
+    if constexpr (QUIET && !LATE) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t e = threadIdx.x + (uint32_t)k * 256u;
@@ -1442,7 +1446,7 @@ __device__ __forceinline__ bool pose_update_body(const PoseFrameDev& f, const Ri
                 st[q * 4] = v.x; st[q * 4 + 1] = v.y; st[q * 4 + 2] = v.z; st[q * 4 + 3] = v.w;
             }
         }
-        if constexpr (QUIET) {
+        if constexpr (QUIET && !LATE) {
             if (node_base == 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1480,7 +1484,7 @@ __device__ __forceinline__ bool pose_update_body(const PoseFrameDev& f, const Ri
                 // invalidated when this kernel started, nothing on the chip reads a record line between then and the samplers' last
                 // acknowledged write-through store (the records' only readers are behind this wait), so no L2 can hold a stale copy;
                 // the first reader of an XCD misses to memory, where the record is, and the rest hit.  Program order is the compiler's to keep.
-                if constexpr (QUIET) __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                if constexpr (QUIET || !INV) __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 FSTAMP(2);
             }
@@ -1610,6 +1614,18 @@ __device__ __forceinline__ bool pose_update_body(const PoseFrameDev& f, const Ri
         f32x4* rows = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + wide_update_lds(rig.n_nodes, rig.n_chunks) + 16u);
         f32x4* row3 = rows + 3u * skin->n_bones;
         uint32_t* wave_flag = reinterpret_cast<uint32_t*>(row3 + skin->n_bones);
+        if constexpr (LATE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = threadIdx.x + (uint32_t)k * 256u;
+                if (e < skin->n_bones * 4u) q_node[k] = skin->bone_nodes[e >> 2];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q_bb[k] = f4{0.f, 0.f, 0.f, 0.f};
+                if (q_node[k] >= 0) q_bb[k] = reinterpret_cast<const f4*>(rig.inv_bind)[(size_t)q_node[k] * 4 + (threadIdx.x & 3u)];
+            }
+        }
         bool pj = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1713,9 +1729,9 @@ __global__ __launch_bounds__(256) void pose_update_inl_kernel(PoseFrameDev f, Ri
 template <int MODE>
 __global__ __launch_bounds__(256) void pose_update_kernel(PoseFrameDev f, RigDev rig) { pose_update_body<MODE>(f, rig, blockIdx.x); }
 // One character's frame in one launch (FrameSync, fyx_internal.h).
-__device__ __forceinline__ void frame_sample_block(const PoseFrameDev& fr, const FrameSync& fs) {
+__device__ __forceinline__ void frame_sample_block(const PoseFrameDev& fr, const FrameSync& fs, uint32_t block) {
     FSTAMP(0);
-    const uint32_t bx = blockIdx.x % fs.sx, t = blockIdx.x / fs.sx;
+    const uint32_t bx = block % fs.sx, t = block / fs.sx;
     pose_sample_body<true>(fr, bx, t % fs.sy, t / fs.sy);
     // Every wave: its part of the records is visible device-wide before the workgroup reports.  The records are the only thing
     // of this half that the update half reads, and they were stored with agent-scope (write-through) stores: once those are
@@ -1732,7 +1748,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pose_frame_inl_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl, FrameSync fs) {
     const PoseFrameDev fr = ctrl_resolve<kInlAfterFrameAndRig>(f, inl);
     if (blockIdx.x < fs.n_sample_blocks) {
-        frame_sample_block(fr, fs);
+        frame_sample_block(fr, fs, blockIdx.x);
         return;
     }
     pose_update_body<MODE, 1, true, true>(fr, rig, blockIdx.x - fs.n_sample_blocks, inl.first_ops, nullptr, &fs);
@@ -1744,7 +1760,10 @@ __global__ __launch_bounds__(256) void pose_frame_inl_kernel(PoseFrameDev f, Rig
 // stores nothing; a stream the job does not have -- no normals, an output not wanted -- is a resource of zero bytes), the palette
 // in LDS is made of the same expressions as the update kernel's palette epilogue: the vertices are lbs_skin's on the palette
 // the update workgroup writes to memory, bit for bit.
-template <int MODE, bool EXACT, bool WAIT = true>
+// PREFETCH: the wave's first two units are requested before the pose is recomputed (one character: the chip is idle and the latency is the
+// frame's) -- or behind it (a scene's one-launch frame: other workgroups hide the latency, and 30 registers less held across the update
+// body put a third wave on every SIMD).
+template <int MODE, bool EXACT, bool WAIT = true, bool PREFETCH = true>
 __device__ __forceinline__ void frame_skin_body(const PoseFrameDev& fr, const RigDev& rig, uint32_t first_ops, const FrameSync& fs, const FrameSkin& sk, uint32_t b) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     FrameSkinJob j = sk.job[0];
@@ -1768,10 +1787,17 @@ __device__ __forceinline__ void frame_skin_body(const PoseFrameDev& fr, const Ri
     // the wave's first two units: nothing of them depends on the pose
     uint32_t uA = u0 + wave, uB = uA + 4u;
     uint32_t vA = uA < u1 ? uA * 64u + lane : kNoVertex, vB = uB < u1 ? uB * 64u + lane : kNoVertex;
-    VertexIn<7> A = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vA);
-    VertexIn<7> B = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vB);
+    VertexIn<7> A, B;
+    if constexpr (PREFETCH) {
+        A = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vA);
+        B = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vB);
+    }
 
-    if (!pose_update_body<MODE, 1, WAIT, true, true>(fr, rig, inst, first_ops, nullptr, &fs, &j)) return;
+    if (!pose_update_body<MODE, 1, WAIT, true, true, true, !PREFETCH>(fr, rig, inst, first_ops, nullptr, &fs, &j)) return;
+    if constexpr (!PREFETCH) {
+        A = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vA);
+        B = load_vertex_buf<7, kFrameSkinLoadAux>(vb, vB);
+    }
 
     const f32x4* rows = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + wide_update_lds(rig.n_nodes, rig.n_chunks) + 16u);
     const f32x4* row3 = rows + 3u * j.n_bones;
@@ -1804,7 +1830,7 @@ template <int MODE, bool EXACT>
 __global__ __launch_bounds__(256) void pose_frame_skin_kernel(PoseFrameDev f, RigDev rig, CtrlInline inl, FrameSync fs, FrameSkin sk) {
     const PoseFrameDev fr = ctrl_resolve<kInlAfterFrameAndRig>(f, inl);
     if (blockIdx.x < fs.n_sample_blocks) {
-        frame_sample_block(fr, fs);
+        frame_sample_block(fr, fs, blockIdx.x);
         return;
     }
     const uint32_t u = blockIdx.x - fs.n_sample_blocks;
@@ -1855,6 +1881,39 @@ __global__ __launch_bounds__(256) void pose_update_skin_scene_kernel(const Scene
     FrameSync none;
     none.counter = nullptr; none.target = 0; none.n_sample_blocks = 0; none.sx = none.sy = 0; none.timeout_ticks = 0; none.err = nullptr; none.tag = 0;
     frame_skin_body<MODE, EXACT, false>(f, rig, 0u, none, sk, b.y);
+}
+
+// A scene of characters as ONE launch (kStageFrame): block {job, k, kind, -} is sampler workgroup k of the job (kind 0), its update
+// workgroup for instance k (1) or its skinning workgroup k (2), job after job.  The update and skinning workgroups wait on their JOB's
+// frame counter, which only that job's sampler workgroups add to -- workgroups with LOWER indices, so with a dispatcher that hands out
+// each XCD's share of a grid in index order the lowest unfinished workgroup of the launch can always run: it is a sampler, or all it
+// waits for is done.  What it buys: a character's skinning runs while later characters are still being sampled (the sampler's DRAM
+// latency under the skinning's streaming, which one launch per stage serialises), one launch where there were three.  A wait is
+// bounded and loud as in the one-character frame (FrameSync::err).
+template <int MODE, bool EXACT>
+__global__ __launch_bounds__(256) void scene_frame_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks, SceneWait w) {
+    const uint4 b = blocks[blockIdx.x];
+    const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
+    FrameSync fs;
+    fs.counter = jobs[b.x].counter;
+    fs.target = reinterpret_cast<const uint32_t*>(ctrl + w.o_targets)[b.x];
+    fs.n_sample_blocks = jobs[b.x].n_sample_blocks;
+    fs.sx = jobs[b.x].sx;
+    fs.sy = f.n_instances;
+    fs.timeout_ticks = w.timeout_ticks;
+    fs.err = w.err;
+    fs.tag = jobs[b.x].tag;
+    if (b.z == 0u) {
+        frame_sample_block(f, fs, b.y);
+        return;
+    }
+    RigDev rig = jobs[b.x].rig;
+    if (b.z == 1u) {
+        pose_update_body<MODE, 1, true, true, false, false>(f, rig, b.y, 0u, jobs[b.x].rig.pal, &fs);
+        return;
+    }
+    const FrameSkin sk = jobs[b.x].sk;
+    frame_skin_body<MODE, EXACT, true, false>(f, rig, 0u, fs, sk, b.y);
 }
 
 template <typename K, typename... Args>
@@ -2007,7 +2066,21 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[
 
 hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uint4* const (&d_tables)[kSceneStages],
                         const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, bool wide256, hipStream_t s,
-                        bool skin256, bool exact) {
+                        bool skin256, bool exact, const SceneWait* frame) {
+    if (frame) {      // the whole scene in one launch
+        if (!n_blocks[kStageFrame]) return hipSuccess;
+        auto one = [&](auto kernel) -> hipError_t {
+            const size_t lds = lds_bytes[kStageFrame];
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            FYX_TL_LAUNCH(kernel, dim3(n_blocks[kStageFrame]), dim3(256), lds, s, d_jobs, d_ctrl, d_tables[kStageFrame], *frame);
+            return hipGetLastError();
+        };
+        if (all_straight) return exact ? one(&scene_frame_kernel<kUpdStraight, true>) : one(&scene_frame_kernel<kUpdStraight, false>);
+        return exact ? one(&scene_frame_kernel<kUpdGeneral, true>) : one(&scene_frame_kernel<kUpdGeneral, false>);
+    }
     auto go = [&](int stage, auto kernel, uint32_t block, size_t lds) {
         if (n_blocks[stage]) hipLaunchKernelGGL(kernel, dim3(n_blocks[stage]), dim3(block), lds, s, d_jobs, d_ctrl, d_tables[stage]);
     };

@@ -279,6 +279,7 @@ struct SceneBatch {
     size_t lds_bytes[kSceneStages] = {};
     bool wide_update = false;              // the 256-thread update stage runs the wide hierarchy walk (its LDS is sized for it)
     std::vector<fyx_skin_job> skin_jobs;   // the skin outputs skinned by one batched launch behind the scene's (scratch of the current call)
+    bool one_frame = false;                // the scene runs as ONE launch (scene_frame_kernel)
     bool skin_update = false;              // ... and also holds the animators' skinning workgroups (pose_update_skin_scene_kernel)
     CtrlBuffers ctrl;
     std::vector<char> h_jobs, sent_jobs;   // this frame's job array / the one the device holds (d_jobs)

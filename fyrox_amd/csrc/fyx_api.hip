@@ -877,7 +877,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->pose_cus && (value < 0 || value >= fyx::kCUs || (value & 7))) return fail(c, FYX_ERR_INVALID_ARG, "streams.pose_cus must be 0 or a multiple of 8 below %d", fyx::kCUs);
     if (slot == &c->upd_lean && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_lean must be 0 or 1");
     if (slot == &c->one_launch && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.one_launch must be 0 or 1");
-    if (slot == &c->frame_skin && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.frame_skin must be 0, 1 or 2");
+    if (slot == &c->frame_skin && (value < 0 || value > 3)) return fail(c, FYX_ERR_INVALID_ARG, "anim.frame_skin must be 0 .. 3");
     if (slot == &c->frame_skin_units && (value < 0 || value > 64)) return fail(c, FYX_ERR_INVALID_ARG, "anim.frame_skin_units must be 0 (auto) .. 64");
     if (slot == &c->wait_timeout_ms && (value < 1 || value > 30000)) return fail(c, FYX_ERR_INVALID_ARG, "anim.wait_timeout_ms must be 1..30000");
     if (slot == &c->upd_pack && value != 0 && value != 2 && value != 4) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_pack must be 0, 2 or 4");

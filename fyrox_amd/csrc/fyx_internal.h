@@ -354,6 +354,7 @@ struct alignas(16) CtrlInline {
 static_assert(sizeof(CtrlInline) == 16 + kCtrlInlineBytes, "header + payload");
 
 struct SceneJobDev;     // (below: it holds a FrameSkin)
+struct SceneWait;
 // The stages of a scene frame.  Each has a table of {job, x, y, z} per block (uint4), built by scene_blocks() from the
 // jobs' shapes alone (so it is uploaded once per scene, not per frame) in the order the launch runs them.
 enum SceneStage : int {
@@ -367,6 +368,8 @@ enum SceneStage : int {
     kStageUpdate192,
     kStageUpdate256,
     kStagePropUpdate,      //                                       {job, slot slice, instance, -}
+    kStageFrame,           // the WHOLE frame of a scene of characters in one launch (scene_frame_kernel), job after job:
+                           //   {job, sampler block, 0, -} ..., {job, instance, 1, -} ..., {job, skinning block, 2, -} ...
     kSceneStages
 };
 struct SceneJobShape {   // what the tables depend on
@@ -382,9 +385,10 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&tab
 // the kernel form without the interpreter.
 // skin256: the 256-thread update stage's table also holds the jobs' skinning workgroups (SceneJobShape::skin_blocks): ONE launch updates
 // and skins (the skinning workgroups recompute their character's pose on chip, FrameSkin); exact: lbs.exact for them.
+// frame: null, or the scene runs as ONE launch (kStageFrame's table; every other stage's is ignored).
 hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uint4* const (&d_tables)[kSceneStages],
                         const uint32_t (&n_blocks)[kSceneStages], const size_t (&lds_bytes)[kSceneStages], bool all_straight, bool wide256, hipStream_t s,
-                        bool skin256 = false, bool exact = true);
+                        bool skin256 = false, bool exact = true, const SceneWait* frame = nullptr);
 
 // `inl` (optional): the frame's control block travelling in the kernel arguments, see CtrlInline.
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);
@@ -470,6 +474,18 @@ struct SceneJobDev {
     PoseFrameDev f;
     RigDev rig;
     FrameSkin sk;        // the animator's skin outputs the scene's update launch skins itself (n_jobs = 0: none)
+    // the one-launch scene frame (kStageFrame): the animator's frame counter (FrameSync::counter, 16 replicas), what a report names, and
+    // its sampler grid -- the frame's TARGET travels in the control block (it changes every frame, this record does not)
+    uint32_t* counter;
+    uint64_t tag;
+    uint32_t n_sample_blocks, sx;
+};
+// What every workgroup of scene_frame_kernel gets besides its job: where the per-job targets lie in the control block, how long a wait
+// lasts and where it reports.
+struct SceneWait {
+    uint32_t o_targets;          // byte offset of uint32_t targets[n_jobs] in the frame's control block
+    uint32_t timeout_ticks;
+    uint32_t* err;
 };
 
 // wait: timeout_ticks, err and tag of the frame's FrameSync (the rest is filled in here); skin: null, or the meshes the launch skins itself

@@ -111,7 +111,10 @@ int fyx_join(fyx_ctx* ctx);
  *                        returns FYX_ERR_HIP with the animator, the counter and its target in fyx_last_error, and the context
  *                        sets "anim.one_launch" = 0 for itself (separate launches, no in-grid wait).
  *     "anim.frame_skin"  1 (default) = a one-launch frame also holds the workgroups that skin the animator's skin outputs
- *                        (fyx_animator_set_skin_output); 0 = the update call issues the skinning launches behind the pose launch.
+ *                        (fyx_animator_set_skin_output), and the update stage of a SMALL scene (fyx_scene_update, up to ~260 k skinned
+ *                        vertices) those of its animators; 0 = the update call issues the skinning launches behind the pose launch(es);
+ *                        2 = the scene's update stage skins whatever the scene's size, 3 = a scene of characters runs as ONE launch
+ *                        (samplers, updates, skinning, per-character waits) -- both measured slower on large scenes, kept for experiments.
  *                        "anim.frame_skin_units": 64-vertex units per wave of those workgroups, 0 (default) = the smallest depth
  *                        that gives every skinning workgroup a CU of its own (C2: 1, C5: 2)
  *     "anim.wait_timeout_ms" 1 .. 30000 (default 500): how long an in-grid wait of a one-launch frame lasts before it reports

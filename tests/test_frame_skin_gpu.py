@@ -351,7 +351,8 @@ def test_a_scene_whose_update_launch_skins(ctx, orc):
     """fyx_scene_update over several animators, some with skin outputs (one with two, one with two instances), one without: the
     scene's update stage holds their skinning workgroups (pose_update_skin_scene_kernel).  Every frame: the skin outputs against
     fyx_lbs_skin_device on the palettes the same update wrote; palettes of every animator against an oracle; options switched
-    between frames (anim.frame_skin = 0: separate launches behind the scene's; anim.frame_skin_units; anim.update_lean)."""
+    between frames (anim.frame_skin = 0: separate launches behind the scene's, 2: the update stage skins, 3: the WHOLE scene -- samplers,
+    updates, skinning -- is one launch with per-character waits; anim.frame_skin_units; anim.update_lean)."""
     specs = [(cases.c5_blend_tree(euler_every=10 ** 6), 1, 6000), (cases.transitions(), 2, 1500), (cases.layered(), 1, 0),
              (cases.player_only(euler_every=10 ** 6), 1, 9001), (cases.by_index(), 1, 300)]
     chars = []
@@ -372,9 +373,9 @@ def test_a_scene_whose_update_launch_skins(ctx, orc):
                 p.set_skin_output(base + 50, base + 60 + j, f.pos.ptr, f.nrm.ptr if mask & 2 else 0, f.tan.ptr if mask & 4 else 0)
                 rec["meshes"].append((base + 60 + j, verts, mask, f, s))
         chars.append(rec)
-    forms = [(1, 0, 1), (0, 0, 1), (2, 4, 1), (1, 1, 0), (2, 16, 1), (1, 0, 1)]
+    forms = [(1, 0, 1), (0, 0, 1), (2, 4, 1), (3, 0, 1), (1, 1, 0), (3, 2, 0), (2, 16, 1), (3, 8, 1), (1, 0, 1)]
     try:
-        for f in range(18):
+        for f in range(27):
             fs, units, lean = forms[f % len(forms)]
             ctx.set_option("anim.frame_skin", fs)
             ctx.set_option("anim.frame_skin_units", units)
@@ -405,3 +406,66 @@ def test_a_scene_whose_update_launch_skins(ctx, orc):
                 fo.free()
                 so.free()
                 ctx.mesh_free(mid)
+
+
+def test_a_scene_frame_in_one_launch_over_many_frames_and_its_timeout(ctx, orc):
+    """anim.frame_skin = 3: fyx_scene_update runs samplers, updates and skinning of every character in ONE launch (scene_frame_kernel).
+    2000 frames of 24 characters (more workgroups than the chip holds at once: the waits really wait) against the same scene run
+    stage by stage (anim.frame_skin = 0) in a second set of animators: palettes and vertices bit for bit; then one character's
+    counter poisoned: the frame reports, writes nothing for that character, and the context goes on with separate launches."""
+    sc = cases.c5_blend_tree(euler_every=10 ** 6)
+    nb = sc.rig.n_nodes
+    nv = 9000
+    mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + 31)
+    ctx.mesh_upload_soa(9800, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    sets = []
+    for s_ in range(2):
+        chars = []
+        for k in range(24):
+            p = cases.build_product(ctx, sc, 1)
+            for a in range(len(sc.animations)):
+                p.set_time_position(a, (k * 0.37 + a * 0.11) % 1.0)
+            A.create_bone_list(ctx, p.base_id + 50, p.base_id, list(range(nb)))
+            d_pal = ctx.malloc(nb * 64)
+            p.set_palette_output(p.base_id + 50, d_pal.ptr)
+            o = Outs(ctx, nv)
+            p.set_skin_output(p.base_id + 50, 9800, o.pos.ptr, o.nrm.ptr, o.tan.ptr)
+            chars.append((p, d_pal, o))
+        sets.append(chars)
+    ctx.set_option("anim.wait_timeout_ms", 50)
+    try:
+        for f in range(2000):
+            ctx.set_option("anim.frame_skin", 3)
+            A.scene_update(ctx, [c_[0] for c_ in sets[0]], sc.dt)
+            ctx.set_option("anim.frame_skin", 0)
+            A.scene_update(ctx, [c_[0] for c_ in sets[1]], sc.dt)
+            if f % 400 == 399 or f < 2:
+                for (pa, da, oa), (pb, db, ob) in zip(sets[0], sets[1]):
+                    assert np.array_equal(da.download(np.uint32, nb * 16), db.download(np.uint32, nb * 16)), f"frame {f}: palette"
+                    for x, y in zip(oa.get(), ob.get()):
+                        assert np.array_equal(x, y), f"frame {f}: vertices"
+        ctx.sync()
+        # a counter poisoned from outside: that frame reports; the poisoned character's outputs are untouched
+        victim = sets[0][5]
+        before = victim[2].pos.download(np.uint32, nv * 3)
+        assert _native.lib().fyx_debug_frame_counter_add(ctx._h, victim[0].id, -100000) == 0
+        ctx.set_option("anim.frame_skin", 3)
+        A.scene_update(ctx, [c_[0] for c_ in sets[0]], sc.dt)
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            ctx.sync()
+        assert e.value.code == _native.FYX_ERR_HIP and str(victim[0].id) in str(e.value)
+        assert np.array_equal(victim[2].pos.download(np.uint32, nv * 3), before)
+        assert ctx.get_option("anim.one_launch") == 0
+        assert _native.lib().fyx_debug_frame_counter_add(ctx._h, victim[0].id, 100000) == 0
+        A.scene_update(ctx, [c_[0] for c_ in sets[0]], sc.dt)       # stage by stage now (anim.one_launch = 0)
+        ctx.sync()
+    finally:
+        ctx.set_option("anim.wait_timeout_ms", 500)
+        ctx.set_option("anim.frame_skin", 1)
+        ctx.set_option("anim.one_launch", 1)
+        for chars in sets:
+            for p, d, o in chars:
+                p.free()
+                d.free()
+                o.free()
+        ctx.mesh_free(9800)
