@@ -1331,6 +1331,45 @@ def main():
                 for b_ in o:
                     b_.free()
         ctx.set_option("lbs.streams", opts["lbs.streams"])
+    # The same launch against the NUMBER of rotating 100 MB sets (round 5: tools/exp/r05_sets_sweep.py).  The rotation exists to keep the
+    # 256 MiB Infinity Cache out of the number; how many sets it takes also decides how much memory the launches walk over, and the kernel's
+    # time steps with that footprint (one set -- what an engine's frame loop does -- is the fastest; 2 - 6 sets are flat; past ~700 MB
+    # it climbs again and levels off beyond ~1.2 GB: address translation, not the cache).  roofline.frac stays on --sets (8: comparable
+    # with rounds 1 - 4); SURVEY 8(d) prescribes ">= 6 sets".
+    by_sets = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            extra_outs, more = [], list(calls)
+            for s_ in range(n_sets, 16):
+                ctx.mesh_upload_soa(5000 + s_, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+                o = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+                extra_outs.append(o)
+                more.append(partial(fn, ctx._h, ctypes.c_uint64(5000 + s_), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
+                                    ctypes.c_void_p(o[0].ptr), ctypes.c_void_p(o[1].ptr), ctypes.c_void_p(o[2].ptr)))
+            ctx.set_option("lbs.streams", 1)
+            by_sets = {}
+            for k in sorted({1, 2, 4, 6, n_sets, 12, 16}):
+                if k > len(more):
+                    continue
+                for i in range(40):
+                    more[i % k]()
+                ctx.set_option("lbs.timing", 1)
+                ctx.kernel_time()
+                for i in range(600):
+                    more[i % k]()
+                us, n = ctx.kernel_time()
+                ctx.set_option("lbs.timing", 0)
+                by_sets[str(k)] = {"kernel_us": us / max(n, 1), "frac": BYTES_PER_VERTEX * nv / (us / max(n, 1) * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                   "footprint_MB": k * BYTES_PER_VERTEX * nv / 1e6}
+            for o in extra_outs:
+                for b_ in o:
+                    b_.free()
+            for s_ in range(n_sets, 16):
+                ctx.mesh_free(5000 + s_)
+        except Exception as e:     # noqa: BLE001
+            by_sets = {"error": repr(e)}
+            ctx.set_option("lbs.timing", 0)
+        ctx.set_option("lbs.streams", opts["lbs.streams"])
     kernel_us = max_over_ranks(float(np.median(alloc_us)))     # the kernel's own duration: median over the allocations, each averaged over n_ser launches
     period_us = max_over_ranks(float(np.median(ser)))          # launch to launch on one stream (adds the dependent-launch gap)
     ctx.set_option("lbs.streams", opts["lbs.streams"])
@@ -1568,6 +1607,11 @@ def main():
                          "kernel_us_note": "launches serialized on one stream, each with its own start / stop HIP events (hipExtLaunchKernel: the "
                                            f"dispatch's timestamps, what rocprofv3 --kernel-trace reports per dispatch); average of {n_ser} launches",
                          "serialized_period_us": period_us,
+                         "by_number_of_rotating_sets": by_sets,
+                         "frac_at_6_sets": (by_sets or {}).get("6", {}).get("frac") if isinstance(by_sets, dict) else None,
+                         "kernel_us_at_6_sets": (by_sets or {}).get("6", {}).get("kernel_us") if isinstance(by_sets, dict) else None,
+                         "by_number_of_rotating_sets_note": "the same lone launch rotating over the first k of up to 16 buffer sets of 100 MB (inputs AND outputs): the kernel's time "
+                                                            "depends on the footprint the rotation walks over; frac above is at --sets (default 8, as in every round); SURVEY 8(d) asks for >= 6",
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "overlapped": {"avg_launch_us": launch_us, "achieved": bytes_launch / (launch_us * 1e-6) / 1e9,
                                         "frac": bytes_launch / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
