@@ -634,6 +634,18 @@ def _vertex_buffer_record(ctx, n_verts=1_000_000, n_bones=256, n_shapes=4, sets=
             per[streams] = ctx.timer_end() * 1e3 / steps
         ctx.set_option("lbs.streams", 1)
         us = per[1]
+        # the same lone launches against the number of rotating sets (the footprint the rotation walks over: see roofline.by_number_of_rotating_sets
+        # of the headline -- six sets of this record are 0.8 - 1.25 GB, past the knee)
+        by_sets = {}
+        for k in (1, 2, 3, 4, sets):
+            for i in range(20):
+                launch(i % k, shapes)
+            ctx.sync()
+            ctx.timer_begin()
+            for i in range(steps):
+                launch(i % k, shapes)
+            t_us = ctx.timer_end() * 1e3 / steps
+            by_sets[str(k)] = {"launch_period_us": t_us, "frac": bpv * n_verts / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "footprint_MB": k * bpv * n_verts / 1e6}
         res["with_%d_blend_shapes" % n_shapes if shapes else "plain"] = {
             "algorithmic_bytes_per_vertex": bpv, "launch_period_us_one_stream": us, "launch_period_us_two_streams": per[2],
             "vertices_per_s": n_verts / (per[2] * 1e-6),
@@ -641,7 +653,9 @@ def _vertex_buffer_record(ctx, n_verts=1_000_000, n_bones=256, n_shapes=4, sets=
                          "achieved": bpv * n_verts / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": bpv * n_verts / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                          "frac_two_streams": bpv * n_verts / (per[2] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                         "note": "launch period on one stream (includes the dependent-launch gap); frac_two_streams: launches overlapped"},
+                         "by_number_of_rotating_sets": by_sets,
+                         "note": "launch period on one stream (includes the dependent-launch gap) over all the sets; frac_two_streams: launches overlapped; "
+                                 "by_number_of_rotating_sets: the lone launches over the first k sets (footprint k x bytes per launch)"},
             "parity": {"checked_vertices": n_chk, "bit_exact": True, "note": "every byte of the first vertices of the output vertex buffer: skinned "
                        "attributes against the oracle, all other bytes against the input"}}
     for k in range(sets):
