@@ -7,7 +7,7 @@ set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=/tmp/fyx_asan; mkdir -p $OUT
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-for f in anim_api fyx_api comm_api anim_kernels lbs_kernels; do
+for f in anim_api fyx_api comm_api anim_kernels lbs_kernels host_geom; do
   $HIPCC -O1 -g -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fsanitize=address -fno-gpu-sanitize -Wno-unused-function \
          -c $ROOT/fyrox_amd/csrc/$f.hip -o $OUT/$f.o &
 done; wait
