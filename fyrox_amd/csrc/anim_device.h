@@ -591,6 +591,9 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     const size_t n = S.animators.size();
     // 1. host control plane
     if (int rc = scene_plan(c, S, dt)) return rc;
+    // a scene of ONE animator is that animator's own frame: the control block in the kernel arguments, sampler + update (+ skinning) in
+    // one launch where the animator qualifies -- 8.6 us for a character where the scene's stages (copy kernel, sampler, update) take ~19
+    if (n == 1) return run_frame(c, *S.animators[0], true);
 
     // 2. device state, and the block tables if the scene's shape changed
     hipStream_t ps = nullptr;
