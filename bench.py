@@ -354,18 +354,24 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
         frame()
     frame_serial_ms = ctx.timer_end() / frames
     # pipelined: whole frames alternate between two streams (option anim.overlap), so frame n + 1's pose kernels run beside frame n's
-    # skinning; two palette buffers -- nothing else changes, the same kernels compute the same values
+    # skinning; a PAIR of palette buffers registered once (the frames of the two streams write one each) and two sets of vertex
+    # outputs (consecutive frames' skinning launches are not ordered against each other: a renderer draws frame n from one set
+    # while frame n + 1 is skinned into the other) -- nothing else changes, the same kernels compute the same values
     ctx.set_option("anim.overlap", 1)
     pals = (d_pal, d_pal2)
+    outs2 = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+    out_sets = ((d_pos, d_nrm, d_tan), outs2)
+    p.set_palette_output_pair(base + 50, d_pal.ptr, d_pal2.ptr)
 
-    def frame_pipelined(k):
-        dp = pals[k & 1]
-        p.set_palette_output(base + 50, dp.ptr)
+    def frame_pipelined(k):     # frame k of the mode runs on stream (k + 1) & 1 (the mode's first frame starts on the second stream)
+        dp, o = pals[(k + 1) & 1], out_sets[(k + 1) & 1]
         update(sc.dt)
-        ctx.lbs_skin_device(base + 60, dp.ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+        ctx.lbs_skin_device(base + 60, dp.ptr, nb, n_instances, o[0].ptr, o[1].ptr, o[2].ptr)
 
     for k in range(20):
         frame_pipelined(k)
+        if p.current_palette(base + 50) != pals[(k + 1) & 1].ptr:
+            raise SystemExit(f"{name}: pipelined frame {k} wrote the other palette buffer of the pair")
     ctx.sync()
     ctx.timer_begin()
     for k in range(frames):
@@ -374,6 +380,42 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     ctx.set_option("anim.overlap", 0)
     p.set_palette_output(base + 50, d_pal.ptr)
     ctx.sync()
+    # the pipelined frames computed what the serial ones compute: the last frame's vertices against fyx_lbs_skin_device on the palette it wrote
+    last = (20 + frames - 1 + 1) & 1
+    got_p = [b.download(np.uint32, nv * w) for b, w in zip(out_sets[last], (3, 3, 4))]
+    ctx.lbs_skin_device(base + 60, pals[last].ptr, nb, n_instances, *(b.ptr for b in out_sets[last ^ 1]))
+    ctx.sync()
+    if not all(np.array_equal(x, b.download(np.uint32, nv * w)) for x, b, w in zip(got_p, out_sets[last ^ 1], (3, 3, 4))):
+        raise SystemExit(f"{name}: the pipelined frames' vertices differ from a skinning launch on the palette they wrote")
+    del got_p
+    for b in outs2:
+        b.free()
+    # the same with the mesh registered as the animator's skin output: the update call is the frame, ONE set of vertex outputs, and the
+    # library orders frame n + 1's skinning launch behind frame n's (its pose kernels still run beside frame n's skinning)
+    frame_pipelined_registered_ms, registered_identical = None, None
+    if n_instances >= 4:
+        ctx.set_option("anim.overlap", 1)
+        p.set_palette_output_pair(base + 50, d_pal.ptr, d_pal2.ptr)
+        p.set_skin_output(base + 50, base + 60, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+        for _ in range(20):
+            update(sc.dt)
+        ctx.sync()
+        ctx.timer_begin()
+        for _ in range(frames):
+            update(sc.dt)
+        frame_pipelined_registered_ms = ctx.timer_end() / frames
+        cur = p.current_palette(base + 50)
+        a = [d_pos.download(np.uint32, nv * 3), d_nrm.download(np.uint32, nv * 3), d_tan.download(np.uint32, nv * 4)]
+        ctx.set_option("anim.overlap", 0)
+        p.set_skin_output(base + 50, base + 60)
+        p.set_palette_output(base + 50, d_pal.ptr)
+        ctx.lbs_skin_device(base + 60, cur, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+        ctx.sync()
+        b = [d_pos.download(np.uint32, nv * 3), d_nrm.download(np.uint32, nv * 3), d_tan.download(np.uint32, nv * 4)]
+        registered_identical = all(bool(np.array_equal(x, y)) for x, y in zip(a, b))
+        if not registered_identical:
+            raise SystemExit(f"{name}: pipelined frames with a registered skin output differ from fyx_lbs_skin_device on the palette they wrote")
+        del a, b
     # one character: the frame as ONE launch through to the vertices (fyx_animator_set_skin_output: the pose launch also holds the
     # skinning workgroups, which form the palette on chip) -- the update call is the whole frame
     frame_one_launch_ms, one_launch_identical = None, None
@@ -458,17 +500,24 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
                      "parity": {"instances_checked": sorted(refs_gpu_pal), "max_rel_err": f_err, "tolerance": 1e-5, "bit_exact": False,
                                 "note": "against the oracle on the GPU-built palettes; north_star allows 1e-5 relative"}}
     modes = {"pipelined": frame_ms, "one_stream": frame_serial_ms}
+    if frame_pipelined_registered_ms is not None:
+        modes["pipelined_registered_skin_output"] = frame_pipelined_registered_ms
     if frame_one_launch_ms is not None:
         modes["one_launch"] = frame_one_launch_ms
     best_mode = min(modes, key=modes.get)
     best_ms = modes[best_mode]
     rec = {"workload": name, "frame_ms": best_ms, "frame_mode": best_mode,
            "frame_ms_pipelined": frame_ms, "frame_ms_one_stream": frame_serial_ms, "frame_ms_one_launch": frame_one_launch_ms,
+           "frame_ms_pipelined_registered_skin_output": frame_pipelined_registered_ms,
+           "pipelined_registered_vertices_bit_identical_to_lbs_skin": registered_identical,
            "one_launch_vertices_bit_identical_to_lbs_skin": one_launch_identical, "pose_ms": pose_ms, "skin_ms": skin_ms,
            "frame_over_skin": best_ms / skin_ms,
            "frame_roofline_frac": unique / (best_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-           "frame_note": "pipelined: whole frames alternate between two streams (anim.overlap = 1, two palette buffers): frame n + 1's pose kernels "
-                         "run beside frame n's skinning; one_stream: the whole frame as one dependent chain on one stream; one_launch (one character): "
+           "frame_note": "pipelined: whole frames alternate between two streams (anim.overlap = 1, a palette pair registered once, TWO sets of vertex "
+                         "outputs: the caller's skinning launches of consecutive frames are not ordered against each other): frame n + 1's pose kernels "
+                         "run beside frame n's skinning; pipelined_registered_skin_output: the same with the mesh registered as the animator's skin "
+                         "output -- the update call is the frame, ONE set of vertex outputs, the library orders frame n + 1's skinning behind frame n's; "
+                         "one_stream: the whole frame as one dependent chain on one stream; one_launch (one character): "
                          "fyx_animator_set_skin_output -- sampler, update and skinning workgroups in ONE launch, the update call is the frame; frame_ms is "
                          "the fastest (the host picks the mode per scene); frame_roofline_frac = the skinning's unique bytes / frame_ms / 8 TB/s: "
                          "the frame end to end against the HBM roofline",
@@ -756,10 +805,21 @@ def _scene_record(ctx, n_chars: int, n_inst: int, n_verts: int, id_base: int, fr
         ctx.sync()
         return best
     host_ms = host_cost()
+
+    def host_sections_of(**kw):      # option debug.host_times: what fyx_scene_update's sections cost the calling thread, per frame
+        ctx.set_option("debug.host_times", 1)
+        ctx.host_times()
+        for _ in range(200):
+            frame(**kw)
+        ctx.sync()
+        ht = ctx.host_times()
+        ctx.set_option("debug.host_times", 0)
+        return {k: ht[i] / max(ht[6], 1.0) for i, k in enumerate(("plan_us", "state_and_jobs_us", "control_block_us", "stage_launches_us",
+                                                                  "event_records_us", "skin_batch_us"))}
     # the same scene with the meshes registered as the animators' skin outputs (fyx_animator_set_skin_output): fyx_scene_update's update
     # launch also holds the skinning workgroups (they recompute their character's pose on chip) -- one call, one launch less, no
     # palette round trip; same bits (checked below against the batch's outputs)
-    f2_ms, host2_ms, same = None, None, None
+    f2_ms, host2_ms, same, host_sections2 = None, None, None, None
     try:
         ref_out = [c_[3][0].download(np.uint32, n_verts * n_inst * 3) for c_ in (chars[0], chars[-1])]
         for an, mid, d_pal, outs, *_ in chars:
@@ -768,6 +828,7 @@ def _scene_record(ctx, n_chars: int, n_inst: int, n_verts: int, id_base: int, fr
             frame(skin=False)
         f2_ms = timed(skin=False)
         host2_ms = host_cost(skin=False)
+        host_sections2 = host_sections_of(skin=False)
         # parity of the mode: skin with the batch call on the palettes the last update wrote, compare with what that update skinned itself
         got = [c_[3][0].download(np.uint32, n_verts * n_inst * 3) for c_ in (chars[0], chars[-1])]
         for an, mid, d_pal, outs, *_ in chars:
@@ -783,11 +844,53 @@ def _scene_record(ctx, n_chars: int, n_inst: int, n_verts: int, id_base: int, fr
         raise
     except Exception as e:     # noqa: BLE001
         f2_ms, same = None, repr(e)
+    # pipelined scene frames (anim.overlap): whole frames alternate between two streams, every animator's palette output is a PAIR
+    # registered once (fyx_animator_set_palette_output_pair: the frames of the two streams write one buffer each), the skin outputs
+    # read the frame's own and the library orders frame n + 1's skinning of the vertex buffers behind frame n's.  Frame n + 1's
+    # sampler / update launches run beside frame n's skinning launch.
+    f3_ms, host3_ms, same3, host_sections = None, None, None, None
+    try:
+        pals2 = [ctx.malloc(n_inst * nb * 64) for _ in chars]
+        frees += pals2
+        for (an, mid, d_pal, outs, *_), p2 in zip(chars, pals2):
+            an.set_palette_output_pair(an.bones_id, d_pal.ptr, p2.ptr)
+            an.set_skin_output(an.bones_id, mid, outs[0].ptr, outs[1].ptr, outs[2].ptr)
+        ctx.set_option("anim.overlap", 1)
+        for _ in range(30):
+            frame(skin=False)
+        f3_ms = timed(skin=False)
+        host3_ms = host_cost(skin=False)
+        host_sections = host_sections_of(skin=False)
+        # parity of the mode: the vertices the last pipelined frame skinned against the batch call on the palettes that frame wrote
+        got = [c_[3][0].download(np.uint32, n_verts * n_inst * 3) for c_ in (chars[0], chars[-1])]
+        cur = [an.current_palette(an.bones_id) for an, *_ in chars]
+        ctx.set_option("anim.overlap", 0)
+        for (an, mid, d_pal, *_) in chars:
+            an.set_skin_output(an.bones_id, mid)
+            an.set_palette_output(an.bones_id, d_pal.ptr)
+        jobs_cur = (SkinJob * n_chars)(*[SkinJob(mid, pc, nb, n_inst, o[0].ptr, o[1].ptr, o[2].ptr) for (_, mid, _p, o, *_), pc in zip(chars, cur)])
+        ctx._check(batch(ctx._h, jobs_cur, n_chars))
+        ctx.sync()
+        again = [c_[3][0].download(np.uint32, n_verts * n_inst * 3) for c_ in (chars[0], chars[-1])]
+        same3 = all(bool(np.array_equal(x, y)) for x, y in zip(got, again))
+        if not same3:
+            raise SystemExit("scene record: the pipelined frames' vertices differ from fyx_lbs_skin_batch on the palettes they wrote")
+    except SystemExit:
+        raise
+    except Exception as e:     # noqa: BLE001
+        f3_ms, same3 = None, repr(e)
+        ctx.set_option("anim.overlap", 0)
     total = n_chars * n_inst * n_verts
     rec = {"workload": f"scene tick: {n_chars} distinct characters x {n_inst} instance(s) x {n_verts} verts / {nb} bones, 4-clip blend-tree machine each; "
                        "one fyx_scene_update + one fyx_lbs_skin_batch per frame",
            "frame_ms": min(f_ms, f2_ms) if f2_ms else f_ms, "frame_mode": "skin_outputs" if f2_ms and f2_ms < f_ms else "scene_update_then_skin_batch",
            "frame_ms_scene_update_then_skin_batch": f_ms, "frame_ms_skin_outputs": f2_ms, "skin_outputs_bit_identical_to_skin_batch": same,
+           "frame_ms_pipelined": f3_ms, "pipelined_bit_identical_to_skin_batch": same3, "host_ms_pipelined": host3_ms,
+           "pipelined_note": "anim.overlap = 1 with palette pairs and registered skin outputs: frames alternate between two streams, frame n + 1's "
+                             "sampler / update launches run beside frame n's skinning launch; frame_ms stays the one-stream frame",
+           "host_sections_pipelined_us": host_sections, "host_sections_skin_outputs_us": host_sections2,
+           "host_sections_note": "option debug.host_times: what the sections of fyx_scene_update cost the calling thread per frame while frames queue up "
+                                 "(a section that has to wait for a control-block slot of a frame still in flight includes that wait)",
            "host_ms_scene_update_then_skin_batch": host_ms, "host_ms_skin_outputs": host2_ms,
            "gpu_side_ms": (min(f_ms, f2_ms) if f2_ms else f_ms) if host_ms < f_ms else None,
            "gpu_side_note": "frame_ms is HIP-event time over queued frames; host_ms_* is what issuing a frame costs the calling thread (no wait): where it is "

@@ -330,6 +330,28 @@ impl<'a> HipAnimator<'a> {
         self.hip.check(rc)
     }
 
+    /// The update calls write this bone list's palettes (`[n_instances][n_bones]` column-major mat4) themselves from now on; null
+    /// unregisters (fyx_animator_set_palette_output).
+    pub fn set_palette_output(&mut self, bones_id: u64, d_out: *mut f32) -> Result<(), HipError> {
+        let rc = unsafe { fyx_animator_set_palette_output(self.hip.ctx, self.id, bones_id, d_out) };
+        self.hip.check(rc)
+    }
+
+    /// Two palette buffers for pipelined frames (`anim.overlap`): registered once, the frames of the library's two frame streams write
+    /// one each, skin outputs read the frame's own (fyx_animator_set_palette_output_pair).
+    pub fn set_palette_output_pair(&mut self, bones_id: u64, d_out: *mut f32, d_out_alt: *mut f32) -> Result<(), HipError> {
+        let rc = unsafe { fyx_animator_set_palette_output_pair(self.hip.ctx, self.id, bones_id, d_out, d_out_alt) };
+        self.hip.check(rc)
+    }
+
+    /// The buffer of a palette output that the most recent update call wrote (for a pair: the current frame's).
+    pub fn current_palette(&mut self, bones_id: u64) -> Result<*mut f32, HipError> {
+        let mut p: *mut f32 = std::ptr::null_mut();
+        let rc = unsafe { fyx_animator_current_palette(self.hip.ctx, self.id, bones_id, &mut p) };
+        self.hip.check(rc)?;
+        Ok(p)
+    }
+
     /// `Mesh::collect_render_data`'s `bone_matrices` (`scene/mesh/mod.rs:781-793`) for every instance, on the device.
     pub fn palette(&mut self, bones_id: u64, d_out: *mut f32) -> Result<(), HipError> {
         let rc = unsafe { fyx_animator_palette(self.hip.ctx, self.id, bones_id, d_out) };

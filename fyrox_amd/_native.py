@@ -142,6 +142,9 @@ _SIGS = {
     "fyx_animator_update_transforms": (c_int, [_P, c_uint64]),
     "fyx_animator_palette": (c_int, [_P, c_uint64, c_uint64, _P]),
     "fyx_animator_set_palette_output": (c_int, [_P, c_uint64, c_uint64, _P]),
+    "fyx_animator_set_palette_output_pair": (c_int, [_P, c_uint64, c_uint64, _P, _P]),
+    "fyx_animator_current_palette": (c_int, [_P, c_uint64, c_uint64, _P]),
+    "fyx_debug_host_times": (c_int, [_P, _P, c_uint32]),
     "fyx_debug_frame_counter_add": (c_int, [_P, c_uint64, ctypes.c_int32]),
     "fyx_animator_set_skin_output": (c_int, [_P, c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "fyx_animator_set_local_trs": (c_int, [_P, c_uint64, c_uint32, c_uint32, c_uint32, _P]),

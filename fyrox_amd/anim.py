@@ -634,6 +634,16 @@ class Animator:
         """The update calls write this palette themselves from now on (d_out = 0 unregisters)."""
         self._check(self._l.fyx_animator_set_palette_output(self._h, self.id, bones_id, d_out or None))
 
+    def set_palette_output_pair(self, bones_id: int, d_out: int, d_out_alt: int) -> None:
+        """Two buffers for pipelined frames (option anim.overlap): the frames of the two frame streams write one each."""
+        self._check(self._l.fyx_animator_set_palette_output_pair(self._h, self.id, bones_id, d_out or None, d_out_alt or None))
+
+    def current_palette(self, bones_id: int) -> int:
+        """The buffer of the palette output that the most recent update call wrote."""
+        p = c_void_p()
+        self._check(self._l.fyx_animator_current_palette(self._h, self.id, bones_id, byref(p)))
+        return p.value or 0
+
     def set_skin_output(self, bones_id: int, mesh_id: int, d_pos: int = 0, d_normal: int = 0, d_tangent: int = 0) -> None:
         """Every update of the animator also skins `mesh_id` with the palette output of `bones_id` (all outputs 0: remove)."""
         self._check(self._l.fyx_animator_set_skin_output(self._h, self.id, bones_id, mesh_id, d_pos or None, d_normal or None, d_tangent or None))

@@ -142,6 +142,13 @@ class Context:
         self._check(self._l.fyx_get_option(self._h, key.encode(), byref(v)))
         return v.value
 
+    def host_times(self) -> list:
+        """Option debug.host_times: microseconds fyx_scene_update's sections cost the calling thread since the last call (fyx_debug_host_times)."""
+        import numpy as np
+        out = np.zeros(8, np.float64)
+        self._check(self._l.fyx_debug_host_times(self._h, out.ctypes.data_as(c_void_p), 8))
+        return out.tolist()
+
     def malloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 

@@ -1113,9 +1113,30 @@ int fyx_animator_palette(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, fl
 }
 
 int fyx_animator_set_palette_output(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, float* d_out) {
+    return fyx_animator_set_palette_output_pair(c, animator_id, bones_id, d_out, nullptr);
+}
+
+int fyx_animator_current_palette(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, float** d_palette) {
+    if (!c || !d_palette) return FYX_ERR_INVALID_ARG;
+    FYX_GUARD_BEGIN
+    *d_palette = nullptr;
+    FYX_ANIMATOR_RO(c, A, animator_id);
+    for (const Animator::PaletteOut& p : A->palette_outputs)
+        if (p.bones_id == bones_id) {
+            *d_palette = palette_of(c, p);
+            return FYX_OK;
+        }
+    return fail(c, FYX_ERR_INVALID_ARG, "bone list %llu is not a palette output of animator %llu", (unsigned long long)bones_id, (unsigned long long)animator_id);
+    FYX_GUARD_END(c)
+}
+
+int fyx_animator_set_palette_output_pair(fyx_ctx* c, uint64_t animator_id, uint64_t bones_id, float* d_out, float* d_out_alt) {
     if (!c) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
     FYX_ANIMATOR_RO(c, A, animator_id);
+    if (!d_out && d_out_alt) return fail(c, FYX_ERR_INVALID_ARG, "a second palette buffer without a first");
+    if (d_out && d_out == d_out_alt) return fail(c, FYX_ERR_INVALID_ARG, "the pair's two palette buffers are the same buffer");
+    if (reinterpret_cast<uintptr_t>(d_out_alt) & 15u) return fail(c, FYX_ERR_INVALID_ARG, "palette output must be 16-byte aligned");
     auto bit = store(c).bones.find(bones_id);
     if (bit == store(c).bones.end()) return fail(c, FYX_ERR_UNKNOWN_ID, "bone list %llu is not registered", (unsigned long long)bones_id);
     if (bit->second.rig_id != A->rig_id) return fail(c, FYX_ERR_INVALID_ARG, "bone list belongs to another rig");
@@ -1124,7 +1145,7 @@ int fyx_animator_set_palette_output(fyx_ctx* c, uint64_t animator_id, uint64_t b
     auto& v = A->palette_outputs;
     for (size_t i = 0; i < v.size(); ++i)
         if (v[i].bones_id == bones_id) {
-            if (d_out) { v[i].d_out = d_out; return FYX_OK; }
+            if (d_out) { v[i].d_out = d_out; v[i].d_out_alt = d_out_alt; return FYX_OK; }
             v.erase(v.begin() + (long)i);
             auto& so = A->skin_outputs;       // the skin outputs on this palette go with it
             for (size_t k = so.size(); k-- > 0;)
@@ -1134,7 +1155,7 @@ int fyx_animator_set_palette_output(fyx_ctx* c, uint64_t animator_id, uint64_t b
     if (!d_out) return FYX_OK;
     if (v.size() >= (size_t)kMaxPaletteOutputs)
         return fail(c, FYX_ERR_UNSUPPORTED, "at most %d palette outputs per animator (use fyx_animator_palette for more)", kMaxPaletteOutputs);
-    v.push_back(Animator::PaletteOut{bones_id, d_out, bit->second.d_bone_nodes, bit->second.n_bones});
+    v.push_back(Animator::PaletteOut{bones_id, d_out, bit->second.d_bone_nodes, bit->second.n_bones, d_out_alt});
     return FYX_OK;
     FYX_GUARD_END(c)
 }

@@ -360,14 +360,19 @@ void ctrl_bind(const Animator& A, const CtrlLayout& L, const char* d, PoseFrameD
     }
 }
 
+// The buffer a palette output's CURRENT frame writes (and its skinning reads): the pair's second buffer for the frames of the second
+// frame stream (anim.overlap; enter_pose has chosen the frame's stream before anything asks).
+inline float* palette_of(const fyx_ctx* c, const Animator::PaletteOut& po) {
+    return (po.d_out_alt && c->pose_overlap && c->frame_idx) ? po.d_out_alt : po.d_out;
+}
+
 // The rig's parameters plus the palettes the update kernel writes itself.
 int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
     rd = rig_dev(*A.rig);
-    (void)c;
     for (const Animator::PaletteOut& po : A.palette_outputs) {      // (fyx_bone_list_free refuses a list that is registered here)
         PaletteOutDev& d = rd.pal[rd.n_pal++];
         d.bone_nodes = po.d_bone_nodes;
-        d.out = po.d_out;
+        d.out = palette_of(c, po);
         d.n_bones = po.n_bones;
         d.pad = 0;
     }
@@ -384,7 +389,7 @@ int skin_output_args(fyx_ctx* c, const Animator& A, LbsArgs (&out)[kMaxFrameSkin
             if (p.bones_id == so.bones_id) po = &p;
         if (!po) return fail(c, FYX_ERR_INVALID_ARG, "skin output of mesh %llu: bone list %llu is no longer a palette output of the animator",
                              (unsigned long long)so.mesh_id, (unsigned long long)so.bones_id);
-        if (int rc = skin_args_of(c, so.mesh_id, po->d_out, po->n_bones, A.n_instances, so.d_pos, so.d_nrm, so.d_tan, &out[k])) return rc;
+        if (int rc = skin_args_of(c, so.mesh_id, palette_of(c, *po), po->n_bones, A.n_instances, so.d_pos, so.d_nrm, so.d_tan, &out[k])) return rc;
         ++k;
     }
     return FYX_OK;
@@ -506,6 +511,10 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         wait.tag = A.id;
         FrameSkin sk;
         const bool fused = n_skins && c->frame_skin && frame_skin_plan(c, A, skin_args, n_skins, upd_mode == kUpdStraight ? kFrameSkinMaxBlocks : kFrameSkinMaxBlocksGeneral, sk);
+        // (registered skin outputs are the same vertex buffers every frame: a launch that writes them lies behind the other frame stream's
+        // skinning of them -- for a pose launch that skins, the whole launch)
+        if (fused)
+            if (int rc = skin_outputs_order(c, ps)) return rc;
         FYX_HIP(c, launch_pose_frame(f, rd, upd_mode, ps, inl, A.d_frame_counter, &A.frame_counter_total, wait, fused ? &sk : nullptr, c->lbs.exact != 0));
         skinned = fused;
     } else {
@@ -520,8 +529,11 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     if (int rc = exit_pose(c)) return rc;
     // a frame that could not take its skinning along (a crowd, root motion, property tracks, anim.frame_skin = 0): the same launches
     // fyx_lbs_skin_device would make, in order behind the update on the frame's stream
-    if (!skinned)
+    if (!skinned && n_skins) {
+        if (int rc = skin_outputs_order(c, ps)) return rc;
         for (uint32_t k = 0; k < n_skins; ++k) FYX_HIP(c, launch_lbs(skin_args[k], c->lbs, ps));
+        if (int rc = skin_outputs_issued(c, ps)) return rc;
+    }
     return FYX_OK;
 }
 
@@ -589,8 +601,19 @@ SceneJobShape scene_shape(const fyx_ctx* c, const Animator& A, uint32_t n_prop_s
 
 int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     const size_t n = S.animators.size();
+    // (option debug.host_times: the sections' cost to the calling thread, fyx_debug_host_times)
+    using HostClock = std::chrono::steady_clock;
+    HostClock::time_point ht0;
+    if (c->host_times_on) ht0 = HostClock::now();
+    auto host_section = [&](int k) {
+        if (!c->host_times_on) return;
+        const HostClock::time_point t = HostClock::now();
+        c->host_times[k] += std::chrono::duration<double, std::micro>(t - ht0).count();
+        ht0 = t;
+    };
     // 1. host control plane
     if (int rc = scene_plan(c, S, dt)) return rc;
+    host_section(0);
     // a scene of ONE animator is that animator's own frame: the control block in the kernel arguments, sampler + update (+ skinning) in
     // one launch where the animator qualifies -- 8.6 us for a character where the scene's stages (copy kernel, sampler, update) take ~19
     if (n == 1) return run_frame(c, *S.animators[0], true);
@@ -747,10 +770,12 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
             jobs[k].n_sample_blocks = jobs[k].sx * A.n_instances * (uint32_t)A.anims.size();
         }
     }
+    host_section(1);
     // A job array that changed travels through the frame's PINNED staging block, behind the control sections (the block is not
     // rewritten before the event behind this frame's kernels: ctrl_consumed) -- not from the pageable vector, which the next frame
     // rewrites while a copy the runtime chose to make asynchronous might still read it.
-    const bool send_jobs = S.h_jobs != S.sent_jobs;
+    const int par = c->pose_overlap ? c->frame_idx : 0;      // the frame's stream: its own resident job array
+    const bool send_jobs = S.h_jobs != S.sent_jobs[par];
     const size_t o_jobs = align_up(std::max<size_t>(total, 16), 256);
     int slot = 0;
     char *h = nullptr, *d = nullptr;
@@ -761,38 +786,43 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         for (size_t k = 0; k < n; ++k) tg[k] = S.animators[k]->frame_counter_total + jobs[k].n_sample_blocks;
     }
     if (send_jobs) {
-        if (S.h_jobs.size() > S.d_jobs_capacity) {
+        if (S.h_jobs.size() > S.d_jobs_capacity[par]) {
             if (int rc_ = sync_all(c)) return rc_;       // launches in flight read the old array
-            dfree(S.d_jobs);
-            S.d_jobs = nullptr;
-            S.d_jobs_capacity = 0;
-            S.sent_jobs.clear();
-            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&S.d_jobs), S.h_jobs.size()));
-            S.d_jobs_capacity = S.h_jobs.size();
+            dfree(S.d_jobs[par]);
+            S.d_jobs[par] = nullptr;
+            S.d_jobs_capacity[par] = 0;
+            S.sent_jobs[par].clear();
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&S.d_jobs[par]), S.h_jobs.size()));
+            S.d_jobs_capacity[par] = S.h_jobs.size();
         }
         memcpy(h + o_jobs, S.h_jobs.data(), S.h_jobs.size());
         // in stream order behind the previous frame's pose kernels (enter_pose), whichever stream they ran on
-        FYX_HIP(c, hipMemcpyAsync(S.d_jobs, h + o_jobs, S.h_jobs.size(), hipMemcpyHostToDevice, ps));
-        S.sent_jobs = S.h_jobs;
+        FYX_HIP(c, hipMemcpyAsync(S.d_jobs[par], h + o_jobs, S.h_jobs.size(), hipMemcpyHostToDevice, ps));
+        S.sent_jobs[par] = S.h_jobs;
     }
     if (int rc = ctrl_upload(c, S.ctrl, slot, std::max<size_t>(total, 16), ps)) return rc;
     if (send_jobs) S.ctrl.h_by_consumed[slot] = true;     // the staging block also fed a copy on `ps`: free when the event behind this frame's kernels is
 
+    host_section(2);
     // 4. one launch per stage
     const uint4* tabs[kSceneStages];
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
     bool all_straight = c->upd_lean != 0;
     for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
+    if (S.skin_update)      // (the update launch skins: it lies behind the other frame stream's skinning of the same vertex buffers)
+        if (int rc = skin_outputs_order(c, ps)) return rc;
     SceneWait sw;
     sw.o_targets = (uint32_t)o_targets;
     sw.timeout_ticks = (uint32_t)c->wait_timeout_ms * 100000u;
     sw.err = reinterpret_cast<uint32_t*>(c->dev_err);
-    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs), d, tabs, S.n_blocks, S.lds_bytes, all_straight, S.wide_update, ps,
+    FYX_HIP(c, launch_scene(reinterpret_cast<const SceneJobDev*>(S.d_jobs[par]), d, tabs, S.n_blocks, S.lds_bytes, all_straight, S.wide_update, ps,
                             S.skin_update, c->lbs.exact != 0, S.one_frame ? &sw : nullptr));
     if (S.one_frame)      // (a launch that was refused has added nothing to the counters)
         for (size_t k = 0; k < n; ++k) S.animators[k]->frame_counter_total += jobs[k].n_sample_blocks;
+    host_section(3);
     if (int rc = ctrl_consumed(c, S.ctrl, slot, ps)) return rc;
     if (int rc = exit_pose(c)) return rc;
+    host_section(4);
     // the animators' skin outputs that did not ride in the update launch (a large scene, anim.frame_skin = 0, a stage that is not the
     // 256-thread one): ONE batched skinning launch for all of them, behind the scene's update launch on the frame's stream -- what
     // fyx_lbs_skin_batch does for the same list (its plan and device tables are cached from frame to frame)
@@ -808,13 +838,18 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
                                  (unsigned long long)so.mesh_id, (unsigned long long)so.bones_id);
             fyx_skin_job j;
             memset(&j, 0, sizeof j);
-            j.mesh_id = so.mesh_id; j.d_palette = po->d_out; j.n_bones = po->n_bones; j.n_instances = A.n_instances;
+            j.mesh_id = so.mesh_id; j.d_palette = palette_of(c, *po); j.n_bones = po->n_bones; j.n_instances = A.n_instances;
             j.d_out_pos = so.d_pos; j.d_out_normal = so.d_nrm; j.d_out_tangent = so.d_tan;
             S.skin_jobs.push_back(j);
         }
     }
-    if (!S.skin_jobs.empty())
+    if (!S.skin_jobs.empty()) {
+        if (int rc = skin_outputs_order(c, ps)) return rc;
         if (int rc = fyx_lbs_skin_batch(c, S.skin_jobs.data(), (uint32_t)S.skin_jobs.size())) return rc;
+        if (int rc = skin_outputs_issued(c, ps)) return rc;
+    }
+    host_section(5);
+    if (c->host_times_on) c->host_times[6] += 1.0;
     return FYX_OK;
 }
 
@@ -878,7 +913,8 @@ int node_depth(const LayerDef& L, int32_t h, std::vector<int>& state) {
 void anim_store_destroy(AnimStore* s) {
     if (!s) return;
     dfree(s->scene.d_tables);
-    dfree(s->scene.d_jobs);
+    dfree(s->scene.d_jobs[0]);
+    dfree(s->scene.d_jobs[1]);
     free_ctrl(s->scene.ctrl);
     for (auto& kv : s->animators) free_animator(*kv.second);
     for (auto& kv : s->bones) free_bones(kv.second);

@@ -230,7 +230,12 @@ struct Animator {
     // palettes the update kernel writes itself (fyx_animator_set_palette_output)
     // (d_bone_nodes / n_bones: the registered bone list's, kept here -- a bone list that is a palette output cannot be freed, and a
     // scene of 256 characters looked each of them up in the store every frame)
-    struct PaletteOut { uint64_t bones_id; float* d_out; const int32_t* d_bone_nodes; uint32_t n_bones; };
+    struct PaletteOut {
+        uint64_t bones_id; float* d_out; const int32_t* d_bone_nodes; uint32_t n_bones;
+        // fyx_animator_set_palette_output_pair: the buffer of the frames that run on the SECOND frame stream under anim.overlap (frames
+        // alternate between two streams, and so between the two buffers: frame n + 1's update does not write what frame n's skinning reads)
+        float* d_out_alt = nullptr;
+    };
     std::vector<PaletteOut> palette_outputs;
     // meshes every update of the animator skins itself (fyx_animator_set_skin_output): with the palette of `bones_id` -- which is
     // one of palette_outputs -- as fyx_lbs_skin_device(mesh_id, that palette, n_bones, n_instances, outputs) right behind the update
@@ -282,9 +287,11 @@ struct SceneBatch {
     bool one_frame = false;                // the scene runs as ONE launch (scene_frame_kernel)
     bool skin_update = false;              // ... and also holds the animators' skinning workgroups (pose_update_skin_scene_kernel)
     CtrlBuffers ctrl;
-    std::vector<char> h_jobs, sent_jobs;   // this frame's job array / the one the device holds (d_jobs)
-    char* d_jobs = nullptr;
-    size_t d_jobs_capacity = 0;
+    // this frame's job array / the one the device holds -- one per frame stream: under anim.overlap the frames of the two streams
+    // differ in the palette buffers they write (palette pairs), and each keeps its array resident
+    std::vector<char> h_jobs, sent_jobs[2];
+    char* d_jobs[2] = {nullptr, nullptr};
+    size_t d_jobs_capacity[2] = {0, 0};
     std::vector<Animator*> animators;   // the members of the current call ...
     std::vector<uint64_t> member_ids;   // ... which are the previous call's when the id list and the store's set of animators are (members_gen)
     uint64_t members_gen = 0;

@@ -110,6 +110,7 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
         // skinning launches too, and what waits behind this event on the context stream may be an RCCL exchange or a copy to the host)
         FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->pose_done[k], order_event_flags()));
+        for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->skin_done[k], order_event_flags()));
     }
     hipStream_t target = idx ? c->alt_stream : c->stream;
     if (idx) {
@@ -138,6 +139,20 @@ int exit_pose(fyx_ctx* c) {
     if (idx) c->alt_busy = true;
     FYX_HIP(c, hipEventRecord(c->pose_done[idx], idx ? c->alt_stream : c->stream));
     c->pose_done_on = idx;
+    return FYX_OK;
+}
+
+int skin_outputs_order(fyx_ctx* c, hipStream_t st) {
+    if (!c->pose_overlap || !c->alt_stream) return FYX_OK;
+    if (c->skin_done_on >= 0 && c->skin_done_on != c->frame_idx) FYX_HIP(c, hipStreamWaitEvent(st, c->skin_done[c->skin_done_on], 0));
+    c->skin_done_on = -1;     // (what follows on `st` lies behind it; a pose launch that skins is covered by the frame's pose_done)
+    return FYX_OK;
+}
+
+int skin_outputs_issued(fyx_ctx* c, hipStream_t st) {
+    if (!c->pose_overlap || !c->alt_stream) return FYX_OK;
+    FYX_HIP(c, hipEventRecord(c->skin_done[c->frame_idx], st));
+    c->skin_done_on = c->frame_idx;
     return FYX_OK;
 }
 
@@ -201,6 +216,7 @@ static int recreate_streams(fyx_ctx* c) {
         FYX_HIP(c, make_stream(c, true, &c->alt_stream));
         c->alt_busy = false;
         c->pose_done_on = -1;
+        c->skin_done_on = -1;
         c->frame_idx = 0;
     }
     const bool own_current = c->stream == c->own_stream;
@@ -623,9 +639,15 @@ void fill_block_segs(uint32_t* bs, uint32_t grid, uint32_t units, const std::vec
 void batch_plan_free(void* p) { delete static_cast<BatchPlan*>(p); }
 
 // reuse: P is the plan of the previous call (SkinBatch::plan) and nothing it was made from changed -- its tables are on the device.
-int run_batch_plan(fyx_ctx* c, BatchPlan& P, bool reuse = false) {
-    if (!c->skin_batch) c->skin_batch = new SkinBatch();
-    SkinBatch& B = *c->skin_batch;
+// The cached batch a call works in: `which` < 0 picks the one used longest ago.
+SkinBatch& batch_entry(fyx_ctx* c, int which) {
+    const int e = which >= 0 ? which : 1 - c->skin_batch_last;
+    if (!c->skin_batch[e]) c->skin_batch[e] = new SkinBatch();
+    c->skin_batch_last = e;
+    return *c->skin_batch[e];
+}
+
+int run_batch_plan(fyx_ctx* c, SkinBatch& B, BatchPlan& P, bool reuse = false) {
     // One launch that fills the chip: nothing to gain from a worker stream, and on the context stream the table
     // buffers have a single consumer to order their reuse against.
     hipStream_t st = nullptr;
@@ -752,7 +774,7 @@ void fyx_shutdown(fyx_ctx* c) {
     fyx::comm_destroy(c->comm);
     c->comm = nullptr;
     fyx::plan_pool_destroy(c->plan_pool);
-    fyx::skin_batch_destroy(c->skin_batch);
+    for (fyx::SkinBatch* b : c->skin_batch) fyx::skin_batch_destroy(b);
     c->plan_pool = nullptr;
     for (auto& kv : c->meshes) free_mesh(kv.second);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -771,6 +793,8 @@ void fyx_shutdown(fyx_ctx* c) {
     if (c->alt_done) (void)hipEventDestroy(c->alt_done);
     for (int k = 0; k < 2; ++k)
         if (c->pose_done[k]) (void)hipEventDestroy(c->pose_done[k]);
+    for (int k = 0; k < 2; ++k)
+        if (c->skin_done[k]) (void)hipEventDestroy(c->skin_done[k]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -846,6 +870,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "streams.priority")) return &c->stream_priority;
     if (!strcmp(key, "streams.pose_cus")) return &c->pose_cus;
     if (!strcmp(key, "debug.timeline")) return &c->timeline_on;
+    if (!strcmp(key, "debug.host_times")) return &c->host_times_on;
     return nullptr;
 }
 
@@ -891,6 +916,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         if (int rc = enter_primary(c)) return rc;      // switching the mode joins everything once
         c->frame_idx = 0;
         c->pose_done_on = -1;
+        c->skin_done_on = -1;
     }
     *slot = value;
     return FYX_OK;
@@ -1115,6 +1141,13 @@ int fyx_debug_timeline(fyx_ctx* c, int32_t* kinds, double* start_us, double* sto
     FYX_GUARD_END(c)
 }
 
+int fyx_debug_host_times(fyx_ctx* c, double* out_us, uint32_t capacity) {
+    if (!c || (capacity && !out_us)) return FYX_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < capacity; ++k) out_us[k] = k < 8 ? c->host_times[k] : 0.0;
+    for (double& t : c->host_times) t = 0.0;
+    return FYX_OK;
+}
+
 int fyx_debug_kernel_time(fyx_ctx* c, double* total_us, uint32_t* n_launches) {
     if (!c || !total_us || !n_launches) return FYX_ERR_INVALID_ARG;
     FYX_GUARD_BEGIN
@@ -1144,12 +1177,16 @@ int fyx_lbs_skin_batch(fyx_ctx* c, const fyx_skin_job* jobs, uint32_t n_jobs) {
     FYX_GUARD_BEGIN
     if (n_jobs && !jobs) return fail(c, FYX_ERR_INVALID_ARG, "jobs is null");
     if (n_jobs == 0) return FYX_OK;
-    if (!c->skin_batch) c->skin_batch = new SkinBatch();
-    SkinBatch& B = *c->skin_batch;
     const size_t key_bytes = (size_t)n_jobs * sizeof(fyx_skin_job);
-    if (B.plan && B.jobs_key.size() == key_bytes && B.key_mesh_gen == c->mesh_gen && memcmp(&B.key_tuning, &c->lbs, sizeof c->lbs) == 0 &&
-        memcmp(B.jobs_key.data(), jobs, key_bytes) == 0)
-        return run_batch_plan(c, *static_cast<BatchPlan*>(B.plan), true);
+    // (two cached batches: under anim.overlap a scene's frames alternate between two job arrays -- the palette buffers of the two frame streams)
+    for (int e = 0; e < 2; ++e) {
+        const int k = e ? 1 - c->skin_batch_last : c->skin_batch_last;      // the last one first: a scene on one stream hits it every frame
+        SkinBatch* Bk = c->skin_batch[k];
+        if (Bk && Bk->plan && Bk->jobs_key.size() == key_bytes && Bk->key_mesh_gen == c->mesh_gen && memcmp(&Bk->key_tuning, &c->lbs, sizeof c->lbs) == 0 &&
+            memcmp(Bk->jobs_key.data(), jobs, key_bytes) == 0)
+            return run_batch_plan(c, batch_entry(c, k), *static_cast<BatchPlan*>(Bk->plan), true);
+    }
+    SkinBatch& B = batch_entry(c, -1);
     B.jobs_key.clear();
     if (!B.plan) { B.plan = new BatchPlan(); B.plan_free = batch_plan_free; }
     BatchPlan& P = *static_cast<BatchPlan*>(B.plan);
@@ -1162,7 +1199,7 @@ int fyx_lbs_skin_batch(fyx_ctx* c, const fyx_skin_job* jobs, uint32_t n_jobs) {
         if (J.d_out_tangent && !m->tan) return fail(c, FYX_ERR_MISSING_ATTRIBUTE, "job %u: mesh has no Tangent attribute", j);
         if (int rc = P.add_soa(c, make_args(*m, J.d_palette, J.n_bones, J.n_instances, J.d_out_pos, J.d_out_normal, J.d_out_tangent))) return rc;
     }
-    if (int rc = run_batch_plan(c, P)) return rc;
+    if (int rc = run_batch_plan(c, B, P)) return rc;
     B.jobs_key.assign(reinterpret_cast<const char*>(jobs), reinterpret_cast<const char*>(jobs) + key_bytes);
     B.key_mesh_gen = c->mesh_gen;
     B.key_tuning = c->lbs;
@@ -1237,7 +1274,7 @@ int fyx_lbs_skin_ex_batch(fyx_ctx* c, const uint64_t* mesh_ids, const fyx_skin_d
         }
         if (rc) return rc;
     }
-    return run_batch_plan(c, P);
+    return run_batch_plan(c, batch_entry(c, -1), P);
     FYX_GUARD_END(c)
 }
 

@@ -96,12 +96,19 @@ struct fyx_ctx {
     int frame_idx = 0;                   // the stream the current frame runs on
     hipEvent_t pose_done[2] = {nullptr, nullptr};   // recorded behind a frame's last pose kernel, one per stream
     int pose_done_on = -1;               // stream of the last pose update, -1: none yet
+    // The skinning the LIBRARY issues for registered skin outputs (fyx_animator_set_skin_output) writes the same vertex buffers every
+    // frame: under anim.overlap the launches of frame n + 1 are ordered behind those of frame n on the other stream (skin_outputs_order /
+    // skin_outputs_issued).  Skinning calls of the caller are not: their output buffers are the caller's to alternate.
+    hipEvent_t skin_done[2] = {nullptr, nullptr};
+    int skin_done_on = -1;
     int stream_priority = 0; // option "streams.priority": 1 = the context's own stream (the pose path: short latency-bound kernels) is created
                              //   with the highest priority, the launch streams (skinning: long bandwidth-bound kernels) with the lowest
     int pose_cus = 0;        // option "streams.pose_cus": N > 0 = the context's own stream may only use N CUs (spread over the XCDs) and the
                              //   launch streams only the other 256 - N (hipExtStreamCreateWithCUMask); 0 = no masks
     int ctrl_mode = 2;       // option "anim.ctrl_upload": how a control block travels -- 0 its own upload stream + events, 1 a copy on the
                              //   consuming stream, 2 (default) a copy kernel on the consuming stream reading the pinned block
+    int host_times_on = 0;   // option "debug.host_times": fyx_scene_update adds up what its sections cost the calling thread (fyx_debug_host_times)
+    double host_times[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int timeline_on = 0;     // option "debug.timeline": pose_sample / pose_update / fyx_lbs_skin_device launches carry their own events
     struct TimelineRec { int kind; hipEvent_t start, stop; };
     std::vector<TimelineRec> timeline;       // in launch order (fyx_debug_timeline reads and clears)
@@ -126,7 +133,8 @@ struct fyx_ctx {
     int upd_lean = 1;        // option "anim.update_lean": 1 = frames whose fold programs are all straight run the update kernel without the interpreter
     int plan_split = 2048;   // option "anim.split": instances per planning task
     fyx::PlanPool* plan_pool = nullptr;
-    fyx::SkinBatch* skin_batch = nullptr;
+    fyx::SkinBatch* skin_batch[2] = {nullptr, nullptr};     // two cached batches (the frames of the two frame streams skin from different palettes)
+    int skin_batch_last = 0;
 };
 
 
@@ -150,6 +158,10 @@ int enter_pose(fyx_ctx* c, hipStream_t* out);
 int exit_pose(fyx_ctx* c);
 // The stream of an ordered skinning launch (fyx_lbs_skin_batch and friends): the current frame's under anim.overlap, else the context stream (joined).
 int enter_skin(fyx_ctx* c, hipStream_t* out);
+// Around the library's own skinning of registered skin outputs on the frame's stream `st` (see fyx_ctx::skin_done): `order` before a
+// launch that writes them (also a pose launch that holds skinning workgroups), `issued` behind skinning launches of their own.
+int skin_outputs_order(fyx_ctx* c, hipStream_t st);
+int skin_outputs_issued(fyx_ctx* c, hipStream_t st);
 int ensure_scratch(fyx_ctx* c, size_t bytes);
 // What kernels reported since the last look (fyx_ctx::dev_err): FYX_OK, or FYX_ERR_HIP with the report as the context's message;
 // the block is cleared and the one-launch frame switched off for the context (anim.one_launch = 0: the multi-launch path has no in-grid wait).

@@ -92,7 +92,10 @@ int fyx_join(fyx_ctx* ctx);
  *                        frame on the other stream, the skinning launches that follow go there too, in order behind it.  Frame
  *                        n + 1's pose kernels so run beside frame n's skinning; its only cross-stream edge is "behind frame n's
  *                        pose update".  The caller alternates two palette buffers per animator: a pose update must not be given
- *                        a palette buffer that a skinning launch issued since the previous pose update reads.
+ *                        a palette buffer that a skinning launch issued since the previous pose update reads (INTEGRATION.md;
+ *                        fyx_animator_set_palette_output_pair registers both once).  The skinning launches of two consecutive
+ *                        frames are NOT ordered against each other: a caller that skins itself alternates its vertex outputs
+ *                        as well (what a renderer that draws frame n while frame n + 1 is skinned does anyway).
  *                        "lbs.streams" is not used in this mode.  C3: frame 0.115 -> 0.101 - 0.104 ms
  *     "anim.update_lean" 1 (default) = a frame whose fold programs are ALL straight (a few clips blended in a row: the common
  *                        machines; the host classifies with the kernel's own function) runs the update kernel built without the
@@ -141,6 +144,7 @@ int fyx_join(fyx_ctx* ctx);
  *     "comm.form"        see fyx_allgather_skinned
  *   measurement:
  *     "debug.timeline"   see fyx_debug_timeline
+ *     "debug.host_times" see fyx_debug_host_times
  * The kernel-variant switches of rounds 1 - 2 (workgroup sizes, prefetch depth, cache policy, work distribution, timeline
  * probe) were experiments; their results are in DESIGN.md 5 and the code in the history (tools/exp/README.md). */
 int fyx_set_option(fyx_ctx* ctx, const char* key, int value);
@@ -157,6 +161,11 @@ int fyx_debug_kernel_time(fyx_ctx* ctx, double* total_us, uint32_t* n_launches);
  * runs as ONE launch, option "anim.one_launch", has no record of kind 1: its sampler is inside the kind-2 launch.)
  * At most 16384 launches between two calls.  Replaces nothing in the reference. */
 int fyx_debug_timeline(fyx_ctx* ctx, int32_t* kinds, double* start_us, double* stop_us, uint32_t capacity, uint32_t* n_records);
+/* Measurement aid (option "debug.host_times" = 1): what fyx_scene_update's sections cost the CALLING THREAD, summed in microseconds
+ * since the last call: [0] control plane (every animator's frame planned), [1] device state, launch plans and the job array,
+ * [2] control block written and its upload enqueued, [3] the stages' launches, [4] event records behind them, [5] the skin
+ * outputs' batched launch (list, cached plan, launch), [6] number of frames, [7] unused.  Up to 8 values; starts over. */
+int fyx_debug_host_times(fyx_ctx* ctx, double* out_us, uint32_t capacity);
 int fyx_get_option(fyx_ctx* ctx, const char* key, int* value);
 
 /* GPU-side timing on the context's stream (hipEvent pair): begin records an event, end records
@@ -690,6 +699,17 @@ int fyx_animator_palette(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, 
  * animator (one per skinned surface of the model, typically 1); the bone list must stay registered; the buffer
  * must be 16-byte aligned (matrix columns are stored as 16-byte words). */
 int fyx_animator_set_palette_output(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, float* d_out_palette);
+/* The same registration with TWO buffers, for pipelined frames ("anim.overlap" = 1: whole frames alternate between two streams
+ * of the library).  The frames of the first stream write d_out_palette, those of the second d_out_palette_alt -- so frame n + 1's
+ * update never writes the palette frame n's skinning still reads, and the caller registers once instead of swapping the pointer
+ * every frame (a scene of 256 animators: 256 calls per frame, each of which invalidates the animator's cached launch plans).
+ * Skin outputs registered on the bone list (fyx_animator_set_skin_output) skin from the frame's own buffer; a caller that skins
+ * itself asks fyx_animator_current_palette.  Without "anim.overlap" only d_out_palette is written.  d_out_palette_alt = NULL is
+ * fyx_animator_set_palette_output.  Both 16-byte aligned, distinct. */
+int fyx_animator_set_palette_output_pair(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, float* d_out_palette, float* d_out_palette_alt);
+/* The buffer of a registered palette output that the animator's most recent update call wrote (or writes: the call is
+ * asynchronous) -- for a pair, the one of the frame's stream.  Host-side lookup, no GPU work. */
+int fyx_animator_current_palette(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, float** d_palette);
 /* The frame goes on to the vertices.  In the engine one character's frame is ONE dependent chain: Machine::evaluate_pose
  * (fyrox-animation/src/machine/mod.rs:344-382) -> Graph::update_hierarchical_data (scene/graph/mod.rs:1199-1241) -> the bone
  * matrices of Mesh::collect_render_data (scene/mesh/mod.rs:781-793) -> the skinning loop (mesh/mod.rs:501-522,
@@ -703,8 +723,10 @@ int fyx_animator_set_palette_output(fyx_ctx* ctx, uint64_t animator_id, uint64_t
  * palette on chip -- no second launch, no palette round trip through memory (option anim.frame_skin = 0: separate launches).
  * Crowds, root motion, property tracks, meshes beyond ~450 k vertices: the same skinning launches fyx_lbs_skin_device makes,
  * issued by the update call.  All three outputs NULL removes the entry; removing the palette output removes its skin outputs.
- * At most 4 per animator.  Under anim.overlap the caller alternates the palette buffers as before; a mesh that is freed while
- * registered makes the next update fail with FYX_ERR_UNKNOWN_ID. */
+ * At most 4 per animator.  Under anim.overlap the palette buffers alternate as before (the caller's pointer swap, or a pair
+ * registered once: fyx_animator_set_palette_output_pair); the vertex outputs are the same buffers every frame, so the library
+ * orders frame n + 1's skinning of them behind frame n's (frame n + 1's pose kernels still run beside frame n's skinning).  A mesh
+ * that is freed while registered makes the next update fail with FYX_ERR_UNKNOWN_ID. */
 int fyx_animator_set_skin_output(fyx_ctx* ctx, uint64_t animator_id, uint64_t bones_id, uint64_t mesh_id, float* d_out_pos,
                                  float* d_out_normal, float* d_out_tangent);
 

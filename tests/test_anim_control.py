@@ -537,3 +537,30 @@ def test_memoised_fold_programs_equal_programs_planned_from_scratch(make):
                     assert ps[0].event_count(a, i) == ps[1].event_count(a, i)
     for c in ctxs:
         c.close()
+
+
+def test_palette_output_pairs_are_checked_and_looked_up_on_the_host(cctx):
+    """fyx_animator_set_palette_output_pair / fyx_animator_current_palette are host-side registrations: argument errors are refused
+    before anything changes, the lookup answers without a GPU (no anim.overlap: the first buffer)."""
+    sc = cases.player_only(n_bones=8)
+    p = cases.build_product(cctx, sc, 1)
+    base = p.base_id
+    A.create_bone_list(cctx, base + 50, base, list(range(8)))
+    with pytest.raises(fyrox_amd.FyxError, match="not a palette output"):
+        p.current_palette(base + 50)
+    with pytest.raises(fyrox_amd.FyxError, match="same buffer"):
+        p.set_palette_output_pair(base + 50, 0x10000, 0x10000)
+    with pytest.raises(fyrox_amd.FyxError, match="16-byte"):
+        p.set_palette_output_pair(base + 50, 0x10000, 0x20008)
+    with pytest.raises(fyrox_amd.FyxError, match="without a first"):
+        p.set_palette_output_pair(base + 50, 0, 0x20000)
+    with pytest.raises(fyrox_amd.FyxError, match="not a palette output"):
+        p.current_palette(base + 50)
+    p.set_palette_output_pair(base + 50, 0x10000, 0x20000)
+    assert p.current_palette(base + 50) == 0x10000
+    p.set_palette_output(base + 50, 0x30000)              # the plain call replaces the pair
+    assert p.current_palette(base + 50) == 0x30000
+    p.set_palette_output(base + 50, 0)
+    with pytest.raises(fyrox_amd.FyxError, match="not a palette output"):
+        p.current_palette(base + 50)
+    p.free()

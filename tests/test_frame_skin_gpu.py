@@ -469,3 +469,81 @@ def test_a_scene_frame_in_one_launch_over_many_frames_and_its_timeout(ctx, orc):
                 d.free()
                 o.free()
         ctx.mesh_free(9800)
+
+
+@pytest.mark.parametrize("frame_skin", [0, 1, 3], ids=["batch_behind_the_update", "update_stage_skins", "one_launch"])
+def test_a_pipelined_scene_with_palette_pairs_equals_the_one_stream_scene(ctx, orc, frame_skin):
+    """anim.overlap with palette PAIRS (fyx_animator_set_palette_output_pair): registered once, the frames of the two frame streams
+    write one buffer each, the registered skin outputs read the frame's own, and the library orders frame n + 1's skinning of the
+    (same) vertex buffers behind frame n's.  N frames are issued WITHOUT a host wait in between; afterwards the vertices are those of
+    the last frame and the two palette buffers those of the last two frames of the same scene run on one stream -- bit for bit --
+    and the last frame's palettes are the oracle's."""
+    specs = [(cases.c5_blend_tree(euler_every=10 ** 6), 1, 7000), (cases.transitions(), 2, 2500), (cases.player_only(euler_every=10 ** 6), 1, 9001),
+             (cases.by_index(), 1, 3000), (cases.layered(), 1, 0), (cases.c5_blend_tree(seed=synth.SEED_BASE + 77, euler_every=10 ** 6), 1, 12_000)]
+    n_frames = 23
+    runs = []
+    for overlap in (0, 1):
+        chars = []
+        for sc, n_inst, nv in specs:
+            p = cases.build_product(ctx, sc, n_inst)
+            nb, base = sc.rig.n_nodes, p.base_id
+            A.create_bone_list(ctx, base + 50, base, list(range(nb)))
+            pals = [ctx.malloc(n_inst * nb * 64) for _ in range(2)]
+            for b in pals:
+                b.upload(np.full(n_inst * nb * 16, np.nan, np.float32))
+            p.set_palette_output_pair(base + 50, pals[0].ptr, pals[1].ptr)
+            rec = {"sc": sc, "p": p, "nb": nb, "n_inst": n_inst, "pals": pals, "out": None, "mid": base + 60, "history": []}
+            if nv:
+                mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + 41)
+                ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+                rec["out"] = Outs(ctx, n_inst * nv)
+                p.set_skin_output(base + 50, base + 60, rec["out"].pos.ptr, rec["out"].nrm.ptr, rec["out"].tan.ptr)
+            chars.append(rec)
+        ctx.set_option("anim.frame_skin", frame_skin)
+        ctx.set_option("anim.overlap", overlap)
+        try:
+            for f in range(n_frames):
+                for ch in chars:
+                    for idx, par in ch["sc"].script.get(f, []):
+                        ch["p"].set_parameter(idx, par)
+                A.scene_update(ctx, [ch["p"] for ch in chars], chars[0]["sc"].dt)
+                for ch in chars:
+                    cur = ch["p"].current_palette(ch["p"].base_id + 50)
+                    assert cur == ch["pals"][(f + 1) & 1 if overlap else 0].ptr, f"frame {f}: current palette of {ch['sc'].name}"
+                if not overlap and f >= n_frames - 2:      # the one-stream run: the palettes of the last two frames
+                    for ch in chars:
+                        ch["history"].append(ch["pals"][0].download(np.uint32, ch["n_inst"] * ch["nb"] * 16))
+            ctx.sync()
+            if overlap:     # frame f ran on stream (f + 1) & 1 (the first frame of the mode starts on the second stream)
+                for ch in chars:
+                    last = (n_frames - 1 + 1) & 1
+                    ch["history"] = [ch["pals"][last ^ 1].download(np.uint32, ch["n_inst"] * ch["nb"] * 16),
+                                     ch["pals"][last].download(np.uint32, ch["n_inst"] * ch["nb"] * 16)]
+            runs.append([(ch["history"], ch["out"].get() if ch["out"] else None) for ch in chars])
+        finally:
+            ctx.set_option("anim.overlap", 0)
+            ctx.set_option("anim.frame_skin", 1)
+            for ch in chars:
+                ch["p"].free()
+                for b in ch["pals"]:
+                    b.free()
+                if ch["out"]:
+                    ch["out"].free()
+                    ctx.mesh_free(ch["mid"])
+    for k, ((h0, v0), (h1, v1)) in enumerate(zip(*runs)):
+        name = specs[k][0].name
+        assert np.array_equal(h0[0], h1[0]), f"{name}: palette of frame N - 2"
+        assert np.array_equal(h0[1], h1[1]), f"{name}: palette of frame N - 1"
+        if v0 is not None:
+            for s, (x, y) in enumerate(zip(v0, v1)):
+                assert np.array_equal(x, y), f"{name}: vertex stream {s} after the pipelined frames"
+    # the last frame's palette of the first character against the oracle
+    sc = specs[0][0]
+    o = cases.build_oracle(orc, sc)
+    for f in range(n_frames):
+        for idx, par in sc.script.get(f, []):
+            o.set_parameter(idx, par)
+        _oupdate(o, sc)
+    ref = o.palette(list(range(sc.rig.n_nodes)))
+    assert np.array_equal(runs[1][0][0][1].reshape(-1, 16)[:sc.rig.n_nodes], ref.view(np.uint32).reshape(-1, 16))
+    o.close()
