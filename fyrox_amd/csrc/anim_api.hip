@@ -994,6 +994,7 @@ static int scene_members(fyx_ctx* c, SceneBatch& S, const uint64_t* animator_ids
         (n_animators == 0 || memcmp(S.member_ids.data(), animator_ids, (size_t)n_animators * 8) == 0))
         return FYX_OK;
     S.members_gen = 0;
+    ++S.members_epoch;
     S.animators.clear();
     std::unordered_set<uint64_t> seen;
     for (uint32_t k = 0; k < n_animators; ++k) {

@@ -332,6 +332,12 @@ CtrlLayout ctrl_layout_inline(const Animator& A) {
     return L;
 }
 
+// What changes from one steady frame to the next (anim_planner.h, steady_frame): the clocks and the tick flags.
+void ctrl_write_clocks(const Animator& A, const CtrlLayout& L, char* h) {
+    memcpy(h + L.o_times, A.times.data(), A.times.size() * 4);
+    memcpy(h + L.o_tick, A.ticked.data(), A.ticked.size());
+}
+
 void ctrl_write(const Animator& A, const CtrlLayout& L, char* h) {
     memcpy(h + L.o_times, A.times.data(), A.times.size() * 4);
     memcpy(h + L.o_tick, A.ticked.data(), A.ticked.size());
@@ -621,6 +627,27 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     // 2. device state, and the block tables if the scene's shape changed
     hipStream_t ps = nullptr;
     if (int rc = enter_pose(c, &ps)) return rc;
+    const int par = c->pose_overlap ? c->frame_idx : 0;      // the frame's stream: its own resident job array
+    // Has anything changed that the launch plans, the job array or the control block's layout are made from (SceneBatch::static_gen)?
+    bool unchanged = S.static_gen != 0 && S.seen.size() == n && S.seen_members_epoch == S.members_epoch && S.seen_options_gen == c->options_gen &&
+                     S.seen_mesh_gen == c->mesh_gen;
+    for (size_t k = 0; k < n && unchanged; ++k) unchanged = S.seen[k].api_gen == S.animators[k]->api_gen;
+    bool fast = unchanged && S.fast_eligible && S.jobs_gen[par] == S.static_gen;
+    // programs planned again since (a transition, a parameter): the section must still lie where the job array says and fit its place
+    for (size_t k = 0; k < n && fast; ++k) {
+        const Animator& A = *S.animators[k];
+        if (S.seen[k].prog_gen == A.prog_gen) continue;
+        const CtrlLayout L = ctrl_layout(A);
+        const CtrlLayout& O = S.layouts[k];
+        if (L.rm || L.o_times != O.o_times || L.o_tick != O.o_tick || L.o_off != O.o_off || L.o_ops != O.o_ops || L.total > S.caps[k]) {
+            fast = unchanged = false;      // (laid out again below: a new state)
+            break;
+        }
+        S.layouts[k] = L;
+        S.seen[k].prog_gen = A.prog_gen;
+    }
+    SceneJobDev* jobs = nullptr;
+    if (!fast) {
     // The animators' skin outputs ride in the scene's update launch when that is the 256-thread wide-walk stage for EVERY animator
     // (characters: few instances each, rigs whose walk tables fit the LDS) -- each animator's plan is cached until an API call, a
     // mesh upload or the options change it.  Share of the launch's skinning workgroups: what keeps the whole stage about resident.
@@ -736,16 +763,21 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     S.layouts.resize(n);
     S.offsets.resize(n);
     size_t total = 0;
+    if (!unchanged || S.caps.size() != n) S.caps.assign(n, 0);
     for (size_t k = 0; k < n; ++k) {
         S.layouts[k] = ctrl_layout(*S.animators[k]);
         S.offsets[k] = total;
-        total += S.layouts[k].total;
+        // the section's place: its size and half as much again (a transition's program is longer than a state's), kept while the state lasts
+        S.caps[k] = std::max(S.caps[k], align_up(S.layouts[k].total + std::max<size_t>(S.layouts[k].total / 2, 128), 64));
+        total += S.caps[k];
     }
     // (the one-launch frame: every job's counter target of THIS frame, behind the animators' sections)
-    const size_t o_targets = align_up(total, 16);
-    if (S.one_frame) total = o_targets + align_up(n * 4, 16);
+    S.o_targets = align_up(total, 16);
+    if (S.one_frame) total = S.o_targets + align_up(n * 4, 16);
+    S.ctrl_total = total;
+    S.any_skin = any_skin;
     S.h_jobs.resize(n * sizeof(SceneJobDev));      // (every byte of a job is written below: frame_static and rig_dev start from zeros)
-    SceneJobDev* jobs = reinterpret_cast<SceneJobDev*>(S.h_jobs.data());
+    jobs = reinterpret_cast<SceneJobDev*>(S.h_jobs.data());
     for (size_t k = 0; k < n; ++k) {
         const Animator& A = *S.animators[k];
         frame_static(c, A, jobs[k].f);
@@ -770,17 +802,49 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
             jobs[k].n_sample_blocks = jobs[k].sx * A.n_instances * (uint32_t)A.anims.size();
         }
     }
+    bool eligible = !S.one_frame;
+    for (size_t k = 0; k < n; ++k) {
+        const Animator& A = *S.animators[k];
+        eligible = eligible && !A.rm_enabled && A.prop_slots.empty() && A.dev_prop_slots == 0;
+    }
+    S.fast_eligible = eligible;
+    if (unchanged)
+        for (size_t k = 0; k < n; ++k) S.seen[k].prog_gen = S.animators[k]->prog_gen;
+    else {                 // a new state: what the other frame stream holds and what the control slots hold belong to the old one
+        ++S.static_gen;
+        S.seen.resize(n);
+        for (size_t k = 0; k < n; ++k) S.seen[k] = SceneBatch::Seen{S.animators[k]->api_gen, S.animators[k]->prog_gen};
+        S.seen_members_epoch = S.members_epoch;
+        S.seen_options_gen = c->options_gen;
+        S.seen_mesh_gen = c->mesh_gen;
+    }
+    }      // (!fast)
+    const size_t total = S.ctrl_total, o_targets = S.o_targets;
+    bool all_straight = c->upd_lean != 0;      // (a property of the frame's programs)
+    for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
     host_section(1);
     // A job array that changed travels through the frame's PINNED staging block, behind the control sections (the block is not
     // rewritten before the event behind this frame's kernels: ctrl_consumed) -- not from the pageable vector, which the next frame
     // rewrites while a copy the runtime chose to make asynchronous might still read it.
-    const int par = c->pose_overlap ? c->frame_idx : 0;      // the frame's stream: its own resident job array
-    const bool send_jobs = S.h_jobs != S.sent_jobs[par];
+    const bool send_jobs = !fast && S.h_jobs != S.sent_jobs[par];
     const size_t o_jobs = align_up(std::max<size_t>(total, 16), 256);
     int slot = 0;
     char *h = nullptr, *d = nullptr;
     if (int rc = ctrl_acquire(c, S.ctrl, send_jobs ? o_jobs + S.h_jobs.size() : std::max<size_t>(total, 16), &slot, &h, &d)) return rc;
-    for (size_t k = 0; k < n; ++k) ctrl_write(*S.animators[k], S.layouts[k], h + S.offsets[k]);
+    // a steady frame into a slot whose last full write was made in this state: programs and offsets are where that write left them
+    // (staging block and device block: the copy below moves the whole block again), clocks and tick flags are this frame's
+    std::vector<uint64_t>& in_slot = S.slot_prog[slot];
+    const bool slot_laid_out = fast && S.slot_gen[slot] == S.static_gen && in_slot.size() == n;
+    if (!slot_laid_out) in_slot.assign(n, 0);
+    for (size_t k = 0; k < n; ++k) {
+        const Animator& A = *S.animators[k];
+        if (in_slot[k] == A.prog_gen) ctrl_write_clocks(A, S.layouts[k], h + S.offsets[k]);
+        else {
+            ctrl_write(A, S.layouts[k], h + S.offsets[k]);
+            in_slot[k] = A.prog_gen;
+        }
+    }
+    S.slot_gen[slot] = S.static_gen;
     if (S.one_frame) {
         uint32_t* tg = reinterpret_cast<uint32_t*>(h + o_targets);
         for (size_t k = 0; k < n; ++k) tg[k] = S.animators[k]->frame_counter_total + jobs[k].n_sample_blocks;
@@ -800,6 +864,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         FYX_HIP(c, hipMemcpyAsync(S.d_jobs[par], h + o_jobs, S.h_jobs.size(), hipMemcpyHostToDevice, ps));
         S.sent_jobs[par] = S.h_jobs;
     }
+    if (!fast) S.jobs_gen[par] = S.static_gen;
     if (int rc = ctrl_upload(c, S.ctrl, slot, std::max<size_t>(total, 16), ps)) return rc;
     if (send_jobs) S.ctrl.h_by_consumed[slot] = true;     // the staging block also fed a copy on `ps`: free when the event behind this frame's kernels is
 
@@ -807,8 +872,6 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     // 4. one launch per stage
     const uint4* tabs[kSceneStages];
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
-    bool all_straight = c->upd_lean != 0;
-    for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
     if (S.skin_update)      // (the update launch skins: it lies behind the other frame stream's skinning of the same vertex buffers)
         if (int rc = skin_outputs_order(c, ps)) return rc;
     SceneWait sw;
@@ -826,8 +889,10 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     // the animators' skin outputs that did not ride in the update launch (a large scene, anim.frame_skin = 0, a stage that is not the
     // 256-thread one): ONE batched skinning launch for all of them, behind the scene's update launch on the frame's stream -- what
     // fyx_lbs_skin_batch does for the same list (its plan and device tables are cached from frame to frame)
-    S.skin_jobs.clear();
-    for (size_t k = 0; k < n; ++k) {
+    std::vector<fyx_skin_job>& skin_jobs = S.skin_jobs_of[par];
+    const bool list_cached = fast && S.skin_jobs_gen[par] == S.static_gen;      // (the frame stream's list of this state)
+    if (!list_cached) skin_jobs.clear();
+    for (size_t k = 0; k < n && !list_cached; ++k) {
         const Animator& A = *S.animators[k];
         if (A.skin_outputs.empty() || (S.skin_update && A.scene_skin_ok)) continue;     // (skinned by the update launch itself)
         for (const Animator::SkinOut& so : A.skin_outputs) {
@@ -840,16 +905,20 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
             memset(&j, 0, sizeof j);
             j.mesh_id = so.mesh_id; j.d_palette = palette_of(c, *po); j.n_bones = po->n_bones; j.n_instances = A.n_instances;
             j.d_out_pos = so.d_pos; j.d_out_normal = so.d_nrm; j.d_out_tangent = so.d_tan;
-            S.skin_jobs.push_back(j);
+            skin_jobs.push_back(j);
         }
     }
-    if (!S.skin_jobs.empty()) {
+    S.skin_jobs_gen[par] = S.static_gen;
+    if (!skin_jobs.empty()) {
         if (int rc = skin_outputs_order(c, ps)) return rc;
-        if (int rc = fyx_lbs_skin_batch(c, S.skin_jobs.data(), (uint32_t)S.skin_jobs.size())) return rc;
+        if (int rc = fyx_lbs_skin_batch(c, skin_jobs.data(), (uint32_t)skin_jobs.size())) return rc;
         if (int rc = skin_outputs_issued(c, ps)) return rc;
     }
     host_section(5);
-    if (c->host_times_on) c->host_times[6] += 1.0;
+    if (c->host_times_on) {
+        c->host_times[6] += 1.0;
+        if (fast) c->host_times[7] += 1.0;
+    }
     return FYX_OK;
 }
 

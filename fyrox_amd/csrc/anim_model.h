@@ -241,6 +241,8 @@ struct Animator {
     // one of palette_outputs -- as fyx_lbs_skin_device(mesh_id, that palette, n_bones, n_instances, outputs) right behind the update
     struct SkinOut { uint64_t bones_id, mesh_id; float* d_pos; float* d_nrm; float* d_tan; };
     std::vector<SkinOut> skin_outputs;
+    uint64_t prog_gen = 1;                  // bumped by every frame that plans programs (every frame but the steady ones): a scene's steady frames
+                                            //   find the control sections other than clocks and tick flags where their last full write left them
     uint64_t api_gen = 1;                   // bumped by every API call that may change what the animator's device-side parameters hold
     // the skin outputs as a scene's update launch takes them along (FrameSkin): made when api_gen, the context's meshes or the launch
     // options changed, not every frame
@@ -283,7 +285,6 @@ struct SceneBatch {
     uint32_t n_blocks[kSceneStages] = {};
     size_t lds_bytes[kSceneStages] = {};
     bool wide_update = false;              // the 256-thread update stage runs the wide hierarchy walk (its LDS is sized for it)
-    std::vector<fyx_skin_job> skin_jobs;   // the skin outputs skinned by one batched launch behind the scene's (scratch of the current call)
     bool one_frame = false;                // the scene runs as ONE launch (scene_frame_kernel)
     bool skin_update = false;              // ... and also holds the animators' skinning workgroups (pose_update_skin_scene_kernel)
     CtrlBuffers ctrl;
@@ -292,6 +293,25 @@ struct SceneBatch {
     std::vector<char> h_jobs, sent_jobs[2];
     char* d_jobs[2] = {nullptr, nullptr};
     size_t d_jobs_capacity[2] = {0, 0};
+    // A frame in which nothing the job array and the launch plans are made from has changed since the last frame that made them -- same
+    // members, no API call on any of them, same options and meshes -- goes straight to "write the control block, upload, launch": what it
+    // skips cost a scene of 256 characters ~15 us of the calling thread per frame.  Every animator's control section has a CAPACITY
+    // (its size plus slack) and the sections lie capacity after capacity, so an animator whose programs were planned again (a
+    // transition: prog_gen) rewrites its own section where it is and moves nobody else's -- the job array holds offsets into the block;
+    // the animators whose frame was a steady one write clocks and tick flags only (the rest of their section is where the slot's last
+    // full write left it).  static_gen counts the states; an animator that tracks root motion or properties ends eligibility.
+    struct Seen { uint64_t api_gen, prog_gen; };
+    std::vector<Seen> seen;
+    std::vector<size_t> caps;               // [member]: bytes of its control section's place
+    uint64_t members_epoch = 1, seen_members_epoch = 0, seen_options_gen = 0, seen_mesh_gen = 0;
+    uint64_t static_gen = 0;
+    uint64_t jobs_gen[2] = {0, 0};          // static_gen d_jobs[frame stream] was made at
+    uint64_t slot_gen[2] = {0, 0};          // static_gen control slot k's sections were laid out at ...
+    std::vector<uint64_t> slot_prog[2];     // ... and [member]: the prog_gen of the programs its section holds there
+    uint64_t skin_jobs_gen[2] = {0, 0};     // static_gen of skin_jobs_of[frame stream]
+    std::vector<fyx_skin_job> skin_jobs_of[2];
+    bool fast_eligible = false, any_skin = false;
+    size_t ctrl_total = 0, o_targets = 0;
     std::vector<Animator*> animators;   // the members of the current call ...
     std::vector<uint64_t> member_ids;   // ... which are the previous call's when the id list and the store's set of animators are (members_gen)
     uint64_t members_gen = 0;

@@ -817,6 +817,7 @@ int plan_frame_core(Animator& A, int mode, float dt, unsigned n_tasks, PlanPool*
         ticks_done = true;        // a transition fires somewhere: plan the programs (the ticks are made)
     }
     A.steady_gen = 0;
+    ++A.prog_gen;
     if (!ticks_done) {
         A.times.assign((size_t)A.n_instances * na, 0.f);
         A.ticked.assign((size_t)A.n_instances * na, 0);

@@ -878,6 +878,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (!c) return FYX_ERR_INVALID_ARG;
     int* slot = option_slot(c, key);
     if (!slot) return fail(c, FYX_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
+    ++c->options_gen;
     if (slot == &c->n_workers) {
         if (value < 1 || value > fyx_ctx::kMaxWorkers)
             return fail(c, FYX_ERR_INVALID_ARG, "lbs.streams must be 1..%d", fyx_ctx::kMaxWorkers);

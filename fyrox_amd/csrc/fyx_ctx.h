@@ -107,6 +107,7 @@ struct fyx_ctx {
                              //   launch streams only the other 256 - N (hipExtStreamCreateWithCUMask); 0 = no masks
     int ctrl_mode = 2;       // option "anim.ctrl_upload": how a control block travels -- 0 its own upload stream + events, 1 a copy on the
                              //   consuming stream, 2 (default) a copy kernel on the consuming stream reading the pinned block
+    uint64_t options_gen = 1;  // bumped by every fyx_set_option (cached launch plans of a scene are made from the options)
     int host_times_on = 0;   // option "debug.host_times": fyx_scene_update adds up what its sections cost the calling thread (fyx_debug_host_times)
     double host_times[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int timeline_on = 0;     // option "debug.timeline": pose_sample / pose_update / fyx_lbs_skin_device launches carry their own events

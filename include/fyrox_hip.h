@@ -164,7 +164,8 @@ int fyx_debug_timeline(fyx_ctx* ctx, int32_t* kinds, double* start_us, double* s
 /* Measurement aid (option "debug.host_times" = 1): what fyx_scene_update's sections cost the CALLING THREAD, summed in microseconds
  * since the last call: [0] control plane (every animator's frame planned), [1] device state, launch plans and the job array,
  * [2] control block written and its upload enqueued, [3] the stages' launches, [4] event records behind them, [5] the skin
- * outputs' batched launch (list, cached plan, launch), [6] number of frames, [7] unused.  Up to 8 values; starts over. */
+ * outputs' batched launch (list, cached plan, launch), [6] number of frames, [7] number of those that were steady frames of an unchanged
+ * scene (launch plans, job array and the control block's programs kept: only clocks and tick flags written).  Up to 8 values; starts over. */
 int fyx_debug_host_times(fyx_ctx* ctx, double* out_us, uint32_t capacity);
 int fyx_get_option(fyx_ctx* ctx, const char* key, int* value);
 

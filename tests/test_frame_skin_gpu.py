@@ -547,3 +547,103 @@ def test_a_pipelined_scene_with_palette_pairs_equals_the_one_stream_scene(ctx, o
     ref = o.palette(list(range(sc.rig.n_nodes)))
     assert np.array_equal(runs[1][0][0][1].reshape(-1, 16)[:sc.rig.n_nodes], ref.view(np.uint32).reshape(-1, 16))
     o.close()
+
+
+@pytest.mark.parametrize("overlap", [0, 1], ids=["one_stream", "pipelined"])
+def test_steady_scene_frames_keep_their_plans_and_follow_every_change(ctx, orc, overlap):
+    """A scene in which nothing changes but the clocks keeps its launch plans, its job array and the programs in its control block
+    (SceneBatch::static_gen, csrc/anim_model.h): such frames write clocks and tick flags only.  Every frame here is checked against
+    oracles (palettes) and against fyx_lbs_skin_device on the palette the frame wrote (vertices), through changes of every kind the
+    cached state is made from: a parameter that fires a transition (programs replanned), an animation's speed (API call), an option,
+    a palette output moved, a mesh uploaded again, the member list reordered and shortened.  debug.host_times counts the steady frames:
+    most frames are, none of the frames right after a change is."""
+    specs = [(cases.c5_blend_tree(euler_every=10 ** 6), 1, 5000), (cases.transitions(), 2, 1200), (cases.by_index(), 1, 0),
+             (cases.c5_blend_tree(seed=synth.SEED_BASE + 91, euler_every=10 ** 6), 1, 7001), (cases.masked_transitions(), 1, 900)]
+    chars = []
+    for j, (sc, n_inst, nv) in enumerate(specs):
+        o = cases.build_oracle(orc, sc)
+        p = cases.build_product(ctx, sc, n_inst)
+        nb, base = sc.rig.n_nodes, p.base_id
+        A.create_bone_list(ctx, base + 50, base, list(range(nb)))
+        pals = [ctx.malloc(n_inst * nb * 64) for _ in range(3)]
+        p.set_palette_output_pair(base + 50, pals[0].ptr, pals[1].ptr)
+        rec = {"sc": sc, "o": o, "p": p, "nb": nb, "n_inst": n_inst, "pals": pals, "nv": nv, "mid": base + 60, "stepped": 0, "alt": pals[1]}
+        if nv:
+            rec["mesh"] = synth.make_mesh(nv, nb, synth.SEED_BASE + 50 + j)
+            m = rec["mesh"]
+            ctx.mesh_upload_soa(base + 60, m.pos, m.weights, m.indices, m.normal, m.tangent)
+            rec["out"], rec["ref"] = Outs(ctx, n_inst * nv), Outs(ctx, n_inst * nv)
+            p.set_skin_output(base + 50, base + 60, rec["out"].pos.ptr, rec["out"].nrm.ptr, rec["out"].tan.ptr)
+        chars.append(rec)
+    order = list(range(len(chars)))
+    changes = {}           # frame -> what is changed before it
+    changes[22] = "speed"
+    changes[30] = "option"
+    changes[37] = "palette"
+    changes[44] = "mesh"
+    changes[51] = "members"
+    changes[58] = "members_back"
+    ctx.set_option("anim.overlap", overlap)
+    ctx.set_option("debug.host_times", 1)
+    ctx.host_times()
+    steady = []
+    try:
+        for f in range(66):
+            what = changes.get(f)
+            if what == "speed":
+                chars[0]["p"].set_speed(1, 0.5)
+                orc._alib().fo_animation_set_speed(chars[0]["o"].anims[1], 0.5)
+            elif what == "option":
+                ctx.set_option("anim.update_lean", 0)
+            elif what == "palette":
+                ch = chars[3]
+                ch["p"].set_palette_output_pair(ch["p"].base_id + 50, ch["pals"][0].ptr, ch["pals"][2].ptr)
+                ch["alt"] = ch["pals"][2]
+            elif what == "mesh":
+                ch = chars[1]
+                ch["mesh"] = synth.make_mesh(ch["nv"], ch["nb"], synth.SEED_BASE + 99)
+                m = ch["mesh"]
+                ctx.mesh_upload_soa(ch["mid"], m.pos, m.weights, m.indices, m.normal, m.tangent)
+            elif what == "members":
+                order = [4, 0, 3]
+            elif what == "members_back":
+                order = [0, 1, 2, 3, 4]
+            for k in order:
+                ch = chars[k]
+                for idx, par in ch["sc"].script.get(ch["stepped"], []):
+                    ch["o"].set_parameter(idx, par)
+                    ch["p"].set_parameter(idx, par)
+                _oupdate(ch["o"], ch["sc"])
+                ch["stepped"] += 1
+            A.scene_update(ctx, [chars[k]["p"] for k in order], chars[0]["sc"].dt)
+            ht = ctx.host_times()
+            assert ht[6] == 1.0
+            steady.append(ht[7] == 1.0)
+            for k in order:
+                ch = chars[k]
+                cur = ch["p"].current_palette(ch["p"].base_id + 50)
+                buf = ch["pals"][0] if cur == ch["pals"][0].ptr else ch["alt"]
+                assert cur == buf.ptr
+                pal = buf.download(np.float32, ch["n_inst"] * ch["nb"] * 16).reshape(ch["n_inst"], ch["nb"], 16)
+                ref = ch["o"].palette(list(range(ch["nb"])))
+                assert np.array_equal(pal[0].view(np.uint32), ref.view(np.uint32)), f"frame {f} ({what}): palette of {ch['sc'].name}"
+                if ch["nv"]:
+                    ctx.lbs_skin_device(ch["mid"], cur, ch["nb"], ch["n_inst"], ch["ref"].pos.ptr, ch["ref"].nrm.ptr, ch["ref"].tan.ptr)
+                    for s, (x, y) in enumerate(zip(ch["out"].get(), ch["ref"].get())):
+                        assert np.array_equal(x, y), f"frame {f} ({what}): {ch['sc'].name} vertex stream {s}"
+        for f in changes:
+            assert not steady[f], f"frame {f} follows a change ({changes[f]}) and was treated as a steady frame"
+        assert sum(steady) >= 20, steady
+    finally:
+        ctx.set_option("debug.host_times", 0)
+        ctx.set_option("anim.overlap", 0)
+        ctx.set_option("anim.update_lean", 1)
+        for ch in chars:
+            ch["o"].close()
+            ch["p"].free()
+            for b in ch["pals"]:
+                b.free()
+            if ch["nv"]:
+                ch["out"].free()
+                ch["ref"].free()
+                ctx.mesh_free(ch["mid"])

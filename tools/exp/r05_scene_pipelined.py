@@ -16,8 +16,11 @@ import fyrox_amd        # noqa: E402
 
 
 def main():
-    shapes = sys.argv[1:] or ["256x1x5000", "64x4x20000", "32x1x5000"]
+    shapes = [a for a in sys.argv[1:] if "=" not in a] or ["256x1x5000", "64x4x20000", "32x1x5000"]
+    opts = [a.split("=") for a in sys.argv[1:] if "=" in a]
     with fyrox_amd.Context(0) as ctx:
+        for k_, v_ in opts:
+            ctx.set_option(k_, int(v_))
         for k, s in enumerate(shapes):
             nc, ni, nv = (int(x) for x in s.split("x"))
             rec = bench._scene_record(ctx, nc, ni, nv, 5_000_000 + k * 1_000_000)
@@ -25,6 +28,7 @@ def main():
                                             "pipelined_bit_identical_to_skin_batch", "host_ms_pipelined", "host_ms_skin_outputs", "host_sections_pipelined_us", "host_sections_skin_outputs_us",
                                             "pose_ms", "skin_ms")}
             keep["scene"] = s
+            keep["options"] = dict(opts)
             print(json.dumps(keep), flush=True)
 
 
