@@ -390,6 +390,36 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     del got_p
     for b in outs2:
         b.free()
+    # streams BY KIND (anim.overlap = 2): every pose kernel on the context stream, every skinning launch on the second stream, each in
+    # order -- frame n + 1's pose kernels run beside frame n's skinning, no queue waits for an event still to come, and ONE set of
+    # vertex outputs is enough; the palette pair as above
+    frame_by_kind_ms = None
+    if n_instances >= 4:
+        ctx.set_option("anim.overlap", 2)
+        p.set_palette_output_pair(base + 50, d_pal.ptr, d_pal2.ptr)
+
+        def frame_by_kind(k):
+            update(sc.dt)
+            ctx.lbs_skin_device(base + 60, pals[(k + 1) & 1].ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+
+        for k in range(20):
+            frame_by_kind(k)
+            if p.current_palette(base + 50) != pals[(k + 1) & 1].ptr:
+                raise SystemExit(f"{name}: frame {k} of anim.overlap = 2 wrote the other palette buffer of the pair")
+        ctx.sync()
+        ctx.timer_begin()
+        for k in range(frames):
+            frame_by_kind(k)
+        frame_by_kind_ms = ctx.timer_end() / frames
+        ctx.set_option("anim.overlap", 0)
+        p.set_palette_output(base + 50, d_pal.ptr)
+        ctx.sync()
+        got_p = [b.download(np.uint32, nv * w) for b, w in zip((d_pos, d_nrm, d_tan), (3, 3, 4))]
+        ctx.lbs_skin_device(base + 60, pals[(20 + frames) & 1].ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
+        ctx.sync()
+        if not all(np.array_equal(x, b.download(np.uint32, nv * w)) for x, b, w in zip(got_p, (d_pos, d_nrm, d_tan), (3, 3, 4))):
+            raise SystemExit(f"{name}: the frames of anim.overlap = 2 left vertices that differ from a skinning launch on the palette the last one wrote")
+        del got_p
     # the same with the mesh registered as the animator's skin output: the update call is the frame, ONE set of vertex outputs, and the
     # library orders frame n + 1's skinning launch behind frame n's (its pose kernels still run beside frame n's skinning)
     frame_pipelined_registered_ms, registered_identical = None, None
@@ -502,13 +532,15 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     modes = {"pipelined": frame_ms, "one_stream": frame_serial_ms}
     if frame_pipelined_registered_ms is not None:
         modes["pipelined_registered_skin_output"] = frame_pipelined_registered_ms
+    if frame_by_kind_ms is not None:
+        modes["pipelined_streams_by_kind"] = frame_by_kind_ms
     if frame_one_launch_ms is not None:
         modes["one_launch"] = frame_one_launch_ms
     best_mode = min(modes, key=modes.get)
     best_ms = modes[best_mode]
     rec = {"workload": name, "frame_ms": best_ms, "frame_mode": best_mode,
            "frame_ms_pipelined": frame_ms, "frame_ms_one_stream": frame_serial_ms, "frame_ms_one_launch": frame_one_launch_ms,
-           "frame_ms_pipelined_registered_skin_output": frame_pipelined_registered_ms,
+           "frame_ms_pipelined_registered_skin_output": frame_pipelined_registered_ms, "frame_ms_pipelined_streams_by_kind": frame_by_kind_ms,
            "pipelined_registered_vertices_bit_identical_to_lbs_skin": registered_identical,
            "one_launch_vertices_bit_identical_to_lbs_skin": one_launch_identical, "pose_ms": pose_ms, "skin_ms": skin_ms,
            "frame_over_skin": best_ms / skin_ms,
@@ -517,6 +549,8 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
                          "outputs: the caller's skinning launches of consecutive frames are not ordered against each other): frame n + 1's pose kernels "
                          "run beside frame n's skinning; pipelined_registered_skin_output: the same with the mesh registered as the animator's skin "
                          "output -- the update call is the frame, ONE set of vertex outputs, the library orders frame n + 1's skinning behind frame n's; "
+                         "pipelined_streams_by_kind: anim.overlap = 2 -- pose kernels on one stream, skinning launches on another, each in order, ONE set "
+                         "of vertex outputs; "
                          "one_stream: the whole frame as one dependent chain on one stream; one_launch (one character): "
                          "fyx_animator_set_skin_output -- sampler, update and skinning workgroups in ONE launch, the update call is the frame; frame_ms is "
                          "the fastest (the host picks the mode per scene); frame_roofline_frac = the skinning's unique bytes / frame_ms / 8 TB/s: "
@@ -848,37 +882,42 @@ def _scene_record(ctx, n_chars: int, n_inst: int, n_verts: int, id_base: int, fr
     # registered once (fyx_animator_set_palette_output_pair: the frames of the two streams write one buffer each), the skin outputs
     # read the frame's own and the library orders frame n + 1's skinning of the vertex buffers behind frame n's.  Frame n + 1's
     # sampler / update launches run beside frame n's skinning launch.
+    # anim.overlap = 2: streams by kind -- every pose kernel on the context stream, the skinning launches on the second stream, each in order.
     f3_ms, host3_ms, same3, host_sections = None, None, None, None
+    f4_ms, host4_ms, host_sections4 = None, None, None
     try:
         pals2 = [ctx.malloc(n_inst * nb * 64) for _ in chars]
         frees += pals2
-        for (an, mid, d_pal, outs, *_), p2 in zip(chars, pals2):
-            an.set_palette_output_pair(an.bones_id, d_pal.ptr, p2.ptr)
-            an.set_skin_output(an.bones_id, mid, outs[0].ptr, outs[1].ptr, outs[2].ptr)
-        ctx.set_option("anim.overlap", 1)
-        for _ in range(30):
-            frame(skin=False)
-        f3_ms = timed(skin=False)
-        host3_ms = host_cost(skin=False)
-        host_sections = host_sections_of(skin=False)
-        # parity of the mode: the vertices the last pipelined frame skinned against the batch call on the palettes that frame wrote
-        got = [c_[3][0].download(np.uint32, n_verts * n_inst * 3) for c_ in (chars[0], chars[-1])]
-        cur = [an.current_palette(an.bones_id) for an, *_ in chars]
-        ctx.set_option("anim.overlap", 0)
-        for (an, mid, d_pal, *_) in chars:
-            an.set_skin_output(an.bones_id, mid)
-            an.set_palette_output(an.bones_id, d_pal.ptr)
-        jobs_cur = (SkinJob * n_chars)(*[SkinJob(mid, pc, nb, n_inst, o[0].ptr, o[1].ptr, o[2].ptr) for (_, mid, _p, o, *_), pc in zip(chars, cur)])
-        ctx._check(batch(ctx._h, jobs_cur, n_chars))
-        ctx.sync()
-        again = [c_[3][0].download(np.uint32, n_verts * n_inst * 3) for c_ in (chars[0], chars[-1])]
-        same3 = all(bool(np.array_equal(x, y)) for x, y in zip(got, again))
-        if not same3:
-            raise SystemExit("scene record: the pipelined frames' vertices differ from fyx_lbs_skin_batch on the palettes they wrote")
+        for mode in (1, 2):
+            for (an, mid, d_pal, outs, *_), p2 in zip(chars, pals2):
+                an.set_palette_output_pair(an.bones_id, d_pal.ptr, p2.ptr)
+                an.set_skin_output(an.bones_id, mid, outs[0].ptr, outs[1].ptr, outs[2].ptr)
+            ctx.set_option("anim.overlap", mode)
+            for _ in range(30):
+                frame(skin=False)
+            t_ms, h_ms, h_sec = timed(skin=False), host_cost(skin=False), host_sections_of(skin=False)
+            if mode == 1:
+                f3_ms, host3_ms, host_sections = t_ms, h_ms, h_sec
+            else:
+                f4_ms, host4_ms, host_sections4 = t_ms, h_ms, h_sec
+            # parity of the mode: the vertices the last pipelined frame skinned against the batch call on the palettes that frame wrote
+            got = [c_[3][0].download(np.uint32, n_verts * n_inst * 3) for c_ in (chars[0], chars[-1])]
+            cur = [an.current_palette(an.bones_id) for an, *_ in chars]
+            ctx.set_option("anim.overlap", 0)
+            for (an, mid, d_pal, *_) in chars:
+                an.set_skin_output(an.bones_id, mid)
+                an.set_palette_output(an.bones_id, d_pal.ptr)
+            jobs_cur = (SkinJob * n_chars)(*[SkinJob(mid, pc, nb, n_inst, o[0].ptr, o[1].ptr, o[2].ptr) for (_, mid, _p, o, *_), pc in zip(chars, cur)])
+            ctx._check(batch(ctx._h, jobs_cur, n_chars))
+            ctx.sync()
+            again = [c_[3][0].download(np.uint32, n_verts * n_inst * 3) for c_ in (chars[0], chars[-1])]
+            same3 = all(bool(np.array_equal(x, y)) for x, y in zip(got, again))
+            if not same3:
+                raise SystemExit(f"scene record: the pipelined frames' vertices (anim.overlap = {mode}) differ from fyx_lbs_skin_batch on the palettes they wrote")
     except SystemExit:
         raise
     except Exception as e:     # noqa: BLE001
-        f3_ms, same3 = None, repr(e)
+        same3 = repr(e)
         ctx.set_option("anim.overlap", 0)
     total = n_chars * n_inst * n_verts
     rec = {"workload": f"scene tick: {n_chars} distinct characters x {n_inst} instance(s) x {n_verts} verts / {nb} bones, 4-clip blend-tree machine each; "
@@ -886,8 +925,10 @@ def _scene_record(ctx, n_chars: int, n_inst: int, n_verts: int, id_base: int, fr
            "frame_ms": min(f_ms, f2_ms) if f2_ms else f_ms, "frame_mode": "skin_outputs" if f2_ms and f2_ms < f_ms else "scene_update_then_skin_batch",
            "frame_ms_scene_update_then_skin_batch": f_ms, "frame_ms_skin_outputs": f2_ms, "skin_outputs_bit_identical_to_skin_batch": same,
            "frame_ms_pipelined": f3_ms, "pipelined_bit_identical_to_skin_batch": same3, "host_ms_pipelined": host3_ms,
+           "frame_ms_pipelined_streams_by_kind": f4_ms, "host_ms_pipelined_streams_by_kind": host4_ms, "host_sections_pipelined_streams_by_kind_us": host_sections4,
            "pipelined_note": "anim.overlap = 1 with palette pairs and registered skin outputs: frames alternate between two streams, frame n + 1's "
-                             "sampler / update launches run beside frame n's skinning launch; frame_ms stays the one-stream frame",
+                             "sampler / update launches run beside frame n's skinning launch; streams_by_kind: anim.overlap = 2, pose kernels on one "
+                             "stream and skinning launches on another, each in order; frame_ms stays the one-stream frame",
            "host_sections_pipelined_us": host_sections, "host_sections_skin_outputs_us": host_sections2,
            "host_sections_note": "option debug.host_times: what the sections of fyx_scene_update cost the calling thread per frame while frames queue up "
                                  "(a section that has to wait for a control-block slot of a frame still in flight includes that wait)",

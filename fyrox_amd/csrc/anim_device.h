@@ -455,6 +455,12 @@ bool frame_skin_plan(const fyx_ctx* c, const Animator& A, const LbsArgs* args, u
 int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     hipStream_t ps = nullptr;     // the frame's stream (anim.overlap: frames alternate between two)
     if (int rc = enter_pose(c, &ps)) return rc;
+    if (c->pose_overlap == 2) {      // a palette output with ONE buffer: this frame rewrites what the previous frame's skinning reads
+        bool single = false;
+        for (const Animator::PaletteOut& po : A.palette_outputs) single = single || !po.d_out_alt;
+        if (single)
+            if (int rc = pose_behind_all_skinning(c, ps)) return rc;
+    }
     if (int rc = ensure_device_state(c, A)) return rc;
     PoseFrameDev f;
     frame_static(c, A, f);
@@ -520,7 +526,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         // (registered skin outputs are the same vertex buffers every frame: a launch that writes them lies behind the other frame stream's
         // skinning of them -- for a pose launch that skins, the whole launch)
         if (fused)
-            if (int rc = skin_outputs_order(c, ps)) return rc;
+            if (int rc = skin_outputs_order(c, ps, true)) return rc;
         FYX_HIP(c, launch_pose_frame(f, rd, upd_mode, ps, inl, A.d_frame_counter, &A.frame_counter_total, wait, fused ? &sk : nullptr, c->lbs.exact != 0));
         skinned = fused;
     } else {
@@ -536,9 +542,11 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     // a frame that could not take its skinning along (a crowd, root motion, property tracks, anim.frame_skin = 0): the same launches
     // fyx_lbs_skin_device would make, in order behind the update on the frame's stream
     if (!skinned && n_skins) {
-        if (int rc = skin_outputs_order(c, ps)) return rc;
-        for (uint32_t k = 0; k < n_skins; ++k) FYX_HIP(c, launch_lbs(skin_args[k], c->lbs, ps));
-        if (int rc = skin_outputs_issued(c, ps)) return rc;
+        hipStream_t ss = nullptr;      // the stream of the frame's skinning (anim.overlap = 2: the second stream; else the frame's own)
+        if (int rc = enter_skin(c, &ss)) return rc;
+        if (int rc = skin_outputs_order(c, ss, false)) return rc;
+        for (uint32_t k = 0; k < n_skins; ++k) FYX_HIP(c, launch_lbs(skin_args[k], c->lbs, ss));
+        if (int rc = skin_outputs_issued(c, ss)) return rc;
     }
     return FYX_OK;
 }
@@ -803,9 +811,11 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         }
     }
     bool eligible = !S.one_frame;
+    S.single_palette = false;
     for (size_t k = 0; k < n; ++k) {
         const Animator& A = *S.animators[k];
         eligible = eligible && !A.rm_enabled && A.prop_slots.empty() && A.dev_prop_slots == 0;
+        for (const Animator::PaletteOut& po : A.palette_outputs) S.single_palette = S.single_palette || !po.d_out_alt;
     }
     S.fast_eligible = eligible;
     if (unchanged)
@@ -819,6 +829,8 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         S.seen_mesh_gen = c->mesh_gen;
     }
     }      // (!fast)
+    if (S.single_palette)      // (anim.overlap = 2, a palette output with ONE buffer: this frame rewrites what the previous frame's skinning reads)
+        if (int rc = pose_behind_all_skinning(c, ps)) return rc;
     const size_t total = S.ctrl_total, o_targets = S.o_targets;
     bool all_straight = c->upd_lean != 0;      // (a property of the frame's programs)
     for (size_t k = 0; k < n; ++k) all_straight = all_straight && S.animators[k]->all_straight;
@@ -873,7 +885,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     const uint4* tabs[kSceneStages];
     for (int k = 0; k < kSceneStages; ++k) tabs[k] = S.d_tables + S.table_off[k];
     if (S.skin_update)      // (the update launch skins: it lies behind the other frame stream's skinning of the same vertex buffers)
-        if (int rc = skin_outputs_order(c, ps)) return rc;
+        if (int rc = skin_outputs_order(c, ps, true)) return rc;
     SceneWait sw;
     sw.o_targets = (uint32_t)o_targets;
     sw.timeout_ticks = (uint32_t)c->wait_timeout_ms * 100000u;
@@ -910,9 +922,11 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     }
     S.skin_jobs_gen[par] = S.static_gen;
     if (!skin_jobs.empty()) {
-        if (int rc = skin_outputs_order(c, ps)) return rc;
+        hipStream_t ss = nullptr;
+        if (int rc = enter_skin(c, &ss)) return rc;
+        if (int rc = skin_outputs_order(c, ss, false)) return rc;
         if (int rc = fyx_lbs_skin_batch(c, skin_jobs.data(), (uint32_t)skin_jobs.size())) return rc;
-        if (int rc = skin_outputs_issued(c, ps)) return rc;
+        if (int rc = skin_outputs_issued(c, ss)) return rc;
     }
     host_section(5);
     if (c->host_times_on) {

@@ -104,6 +104,17 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
     if (int rc = bind_device(c)) return rc;
     const int idx = c->frame_idx ^ 1;
     c->frame_idx = idx;
+    if (c->pose_overlap == 2 && c->alt_stream) {
+        // Streams BY KIND: every pose kernel on the context stream, every skinning launch on the second stream, each in order.  Frame n's
+        // pose path writes the palette buffers frame n - 2's skinning read (pairs: fyx_animator_set_palette_output_pair, or the caller's
+        // two buffers): it waits for the skinning issued up to the start of frame n - 1, an event recorded a frame ago -- usually long
+        // since signalled, so that no queue sits blocked on another (what a blocked queue costs on this runtime: ~12 us per hop).
+        FYX_HIP(c, hipEventRecord(c->skin_done[idx ^ 1], c->alt_stream));      // the skinning of the frames up to n - 1
+        c->skin_mark[idx ^ 1] = true;
+        if (c->skin_mark[idx]) FYX_HIP(c, hipStreamWaitEvent(c->stream, c->skin_done[idx], 0));      // ... up to n - 2
+        *out = c->stream;
+        return FYX_OK;
+    }
     if (!c->alt_stream) {
         FYX_HIP(c, make_stream(c, true, &c->alt_stream));
         // (the join of the frame stream into the context stream keeps the system scope: under anim.overlap the frame streams carry the
@@ -111,6 +122,10 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
         FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->pose_done[k], order_event_flags()));
         for (int k = 0; k < 2; ++k) FYX_HIP(c, hipEventCreateWithFlags(&c->skin_done[k], order_event_flags()));
+        if (c->pose_overlap == 2) {      // (the first frame of the mode: nothing on the second stream yet)
+            *out = c->stream;
+            return FYX_OK;
+        }
     }
     hipStream_t target = idx ? c->alt_stream : c->stream;
     if (idx) {
@@ -133,6 +148,12 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
 int exit_pose(fyx_ctx* c) {
     if (!c->pose_overlap || !c->alt_stream) return FYX_OK;
     const int idx = c->frame_idx;
+    if (c->pose_overlap == 2) {      // the frame's skinning launches (second stream) wait for this point of the context stream
+        FYX_HIP(c, hipEventRecord(c->pose_done[idx], c->stream));
+        c->pose_done_on = idx;
+        c->skin_waits_pose = true;
+        return FYX_OK;
+    }
     // work was enqueued on alt_stream since enter_pose: whatever joined the streams in between (ensure_device_state's sync_all, a
     // control block that grew -- both hit an animator's FIRST frame) cleared the flag, and a fyx_sync / readback that follows the
     // update directly must still wait for these kernels
@@ -142,21 +163,47 @@ int exit_pose(fyx_ctx* c) {
     return FYX_OK;
 }
 
-int skin_outputs_order(fyx_ctx* c, hipStream_t st) {
-    if (!c->pose_overlap || !c->alt_stream) return FYX_OK;
+// anim.overlap = 2, a pose launch that itself writes vertex outputs (a frame that skins in its own launch) or a palette buffer without a
+// second one: behind ALL the skinning issued so far, not only the frames up to n - 2.
+int pose_behind_all_skinning(fyx_ctx* c, hipStream_t ps) {
+    if (c->pose_overlap != 2 || !c->alt_stream || !c->skin_mark[c->frame_idx ^ 1]) return FYX_OK;
+    FYX_HIP(c, hipStreamWaitEvent(ps, c->skin_done[c->frame_idx ^ 1], 0));
+    return FYX_OK;
+}
+
+int skin_outputs_order(fyx_ctx* c, hipStream_t st, bool pose_launch) {
+    // (2: skinning launches are one stream's, in order; a POSE launch that writes vertex outputs lies behind all of them)
+    if (c->pose_overlap == 2) return pose_launch ? pose_behind_all_skinning(c, st) : FYX_OK;
     if (c->skin_done_on >= 0 && c->skin_done_on != c->frame_idx) FYX_HIP(c, hipStreamWaitEvent(st, c->skin_done[c->skin_done_on], 0));
     c->skin_done_on = -1;     // (what follows on `st` lies behind it; a pose launch that skins is covered by the frame's pose_done)
     return FYX_OK;
 }
 
 int skin_outputs_issued(fyx_ctx* c, hipStream_t st) {
-    if (!c->pose_overlap || !c->alt_stream) return FYX_OK;
+    if (!c->pose_overlap || !c->alt_stream || c->pose_overlap == 2) return FYX_OK;      // (2: the skinning launches are one stream's, in order)
     FYX_HIP(c, hipEventRecord(c->skin_done[c->frame_idx], st));
     c->skin_done_on = c->frame_idx;
     return FYX_OK;
 }
 
 int enter_skin(fyx_ctx* c, hipStream_t* out) {
+    if (c->pose_overlap == 2 && c->alt_stream) {
+        if (int rc = bind_device(c)) return rc;
+        if (c->primary_dirty) {      // other calls have put work on the context stream (uploads, copies): behind all of it, the frame's pose update included
+            if (!c->fork_ev) FYX_HIP(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+            FYX_HIP(c, hipEventRecord(c->fork_ev, c->stream));
+            ++c->fork_gen;
+            c->primary_dirty = false;
+            c->skin_waits_pose = false;
+            FYX_HIP(c, hipStreamWaitEvent(c->alt_stream, c->fork_ev, 0));
+        } else if (c->skin_waits_pose && c->pose_done_on >= 0) {      // the frame's first skinning launch: behind its pose update
+            FYX_HIP(c, hipStreamWaitEvent(c->alt_stream, c->pose_done[c->pose_done_on], 0));
+            c->skin_waits_pose = false;
+        }
+        c->alt_busy = true;
+        *out = c->alt_stream;
+        return FYX_OK;
+    }
     if (c->pose_overlap && c->alt_stream) {
         if (int rc = bind_device(c)) return rc;
         *out = c->frame_idx ? c->alt_stream : c->stream;
@@ -217,6 +264,8 @@ static int recreate_streams(fyx_ctx* c) {
         c->alt_busy = false;
         c->pose_done_on = -1;
         c->skin_done_on = -1;
+        c->skin_mark[0] = c->skin_mark[1] = false;
+        c->skin_waits_pose = false;
         c->frame_idx = 0;
     }
     const bool own_current = c->stream == c->own_stream;
@@ -892,7 +941,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->comm_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "comm.form must be 0 (broadcasts), 1 (send / recv) or 2 (one all-gather over padded shards)");
     if (slot == &c->sample_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.sample_form must be 0, 1 or 2");
     if (slot == &c->inline_ctrl && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.inline_ctrl must be 0 or 1");
-    if (slot == &c->pose_overlap && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.overlap must be 0 or 1");
+    if (slot == &c->pose_overlap && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.overlap must be 0, 1 or 2");
     if (slot == &c->plan_split && value < 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.split must be >= 1");
     if (slot == &c->plan_threads && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");
@@ -918,6 +967,8 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         c->frame_idx = 0;
         c->pose_done_on = -1;
         c->skin_done_on = -1;
+        c->skin_mark[0] = c->skin_mark[1] = false;
+        c->skin_waits_pose = false;
     }
     *slot = value;
     return FYX_OK;

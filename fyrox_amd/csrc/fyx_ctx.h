@@ -101,6 +101,10 @@ struct fyx_ctx {
     // skin_outputs_issued).  Skinning calls of the caller are not: their output buffers are the caller's to alternate.
     hipEvent_t skin_done[2] = {nullptr, nullptr};
     int skin_done_on = -1;
+    // anim.overlap = 2 (streams by kind: pose kernels on the context stream, skinning on alt_stream): skin_done[k] is recorded on alt_stream at the
+    // start of the frames of parity k ^ 1 (skin_mark: it has been), skin_waits_pose: the frame's first skinning launch still has to wait for its pose update
+    bool skin_mark[2] = {false, false};
+    bool skin_waits_pose = false;
     int stream_priority = 0; // option "streams.priority": 1 = the context's own stream (the pose path: short latency-bound kernels) is created
                              //   with the highest priority, the launch streams (skinning: long bandwidth-bound kernels) with the lowest
     int pose_cus = 0;        // option "streams.pose_cus": N > 0 = the context's own stream may only use N CUs (spread over the XCDs) and the
@@ -161,7 +165,8 @@ int exit_pose(fyx_ctx* c);
 int enter_skin(fyx_ctx* c, hipStream_t* out);
 // Around the library's own skinning of registered skin outputs on the frame's stream `st` (see fyx_ctx::skin_done): `order` before a
 // launch that writes them (also a pose launch that holds skinning workgroups), `issued` behind skinning launches of their own.
-int skin_outputs_order(fyx_ctx* c, hipStream_t st);
+int skin_outputs_order(fyx_ctx* c, hipStream_t st, bool pose_launch);
+int pose_behind_all_skinning(fyx_ctx* c, hipStream_t ps);
 int skin_outputs_issued(fyx_ctx* c, hipStream_t st);
 int ensure_scratch(fyx_ctx* c, size_t bytes);
 // What kernels reported since the last look (fyx_ctx::dev_err): FYX_OK, or FYX_ERR_HIP with the report as the context's message;

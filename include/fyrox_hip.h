@@ -88,7 +88,13 @@ int fyx_join(fyx_ctx* ctx);
  *                        2 x anim.split stay on the calling thread
  *     "anim.sample_form" 0 auto, 1 curves of one instance on the lanes, 2 instances of one curve on the lanes -- same
  *                        results, the crowd form is picked from 32 instances on
- *     "anim.overlap"     1 = whole frames alternate between TWO streams: a pose update (fyx_*_update, fyx_scene_update) starts a
+ *     "anim.overlap"     2 = streams BY KIND: every pose kernel on the context stream, every skinning launch (the caller's and the
+ *                        library's own) on a second stream, each in order; a frame's first skinning launch waits for its pose update,
+ *                        a frame's pose update for the skinning of the frame before the previous one (two palette buffers per animator,
+ *                        as below: fyx_animator_set_palette_output_pair; an output with one buffer makes its frames wait for ALL
+ *                        earlier skinning).  Frame n + 1's pose kernels run beside frame n's skinning, no queue sits blocked on an
+ *                        event that is still to come, and ONE set of vertex outputs is enough (the skinning launches are in order).
+ *                        1 = whole frames alternate between TWO streams: a pose update (fyx_*_update, fyx_scene_update) starts a
  *                        frame on the other stream, the skinning launches that follow go there too, in order behind it.  Frame
  *                        n + 1's pose kernels so run beside frame n's skinning; its only cross-stream edge is "behind frame n's
  *                        pose update".  The caller alternates two palette buffers per animator: a pose update must not be given

@@ -667,7 +667,7 @@ def test_pipelined_frames_are_bit_identical_to_one_stream_frames(ctx, orc):
     n_inst, n_frames, nb = 40, 14, 64
     mesh = synth.make_mesh(10_000, nb, synth.SEED_BASE + 3)
     results = []
-    for overlap in (0, 1):
+    for overlap in (0, 1, 2):
         sc = cases.c5_blend_tree(n_bones=nb, seed=synth.SEED_BASE + 3, euler_every=10 ** 9)
         p = cases.build_product(ctx, sc, n_inst)
         base = p.base_id
@@ -713,7 +713,8 @@ def test_pipelined_frames_are_bit_identical_to_one_stream_frames(ctx, orc):
         p.free()
     for f in range(n_frames):
         for k in range(3):
-            assert np.array_equal(results[0][f][k], results[1][f][k]), f"frame {f}, stream {k}: pipelined != one-stream"
+            for mode in (1, 2):
+                assert np.array_equal(results[0][f][k], results[mode][f][k]), f"frame {f}, stream {k}: pipelined (anim.overlap = {mode}) != one-stream"
 
 
 def test_animated_morph_weights_drive_blend_shapes_into_a_vertex_buffer(ctx, orc):

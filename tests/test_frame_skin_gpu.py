@@ -471,8 +471,9 @@ def test_a_scene_frame_in_one_launch_over_many_frames_and_its_timeout(ctx, orc):
         ctx.mesh_free(9800)
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["streams_by_frame", "streams_by_kind"])
 @pytest.mark.parametrize("frame_skin", [0, 1, 3], ids=["batch_behind_the_update", "update_stage_skins", "one_launch"])
-def test_a_pipelined_scene_with_palette_pairs_equals_the_one_stream_scene(ctx, orc, frame_skin):
+def test_a_pipelined_scene_with_palette_pairs_equals_the_one_stream_scene(ctx, orc, frame_skin, mode):
     """anim.overlap with palette PAIRS (fyx_animator_set_palette_output_pair): registered once, the frames of the two frame streams
     write one buffer each, the registered skin outputs read the frame's own, and the library orders frame n + 1's skinning of the
     (same) vertex buffers behind frame n's.  N frames are issued WITHOUT a host wait in between; afterwards the vertices are those of
@@ -482,7 +483,7 @@ def test_a_pipelined_scene_with_palette_pairs_equals_the_one_stream_scene(ctx, o
              (cases.by_index(), 1, 3000), (cases.layered(), 1, 0), (cases.c5_blend_tree(seed=synth.SEED_BASE + 77, euler_every=10 ** 6), 1, 12_000)]
     n_frames = 23
     runs = []
-    for overlap in (0, 1):
+    for overlap in (0, mode):
         chars = []
         for sc, n_inst, nv in specs:
             p = cases.build_product(ctx, sc, n_inst)
@@ -549,7 +550,7 @@ def test_a_pipelined_scene_with_palette_pairs_equals_the_one_stream_scene(ctx, o
     o.close()
 
 
-@pytest.mark.parametrize("overlap", [0, 1], ids=["one_stream", "pipelined"])
+@pytest.mark.parametrize("overlap", [0, 1, 2], ids=["one_stream", "streams_by_frame", "streams_by_kind"])
 def test_steady_scene_frames_keep_their_plans_and_follow_every_change(ctx, orc, overlap):
     """A scene in which nothing changes but the clocks keeps its launch plans, its job array and the programs in its control block
     (SceneBatch::static_gen, csrc/anim_model.h): such frames write clocks and tick flags only.  Every frame here is checked against

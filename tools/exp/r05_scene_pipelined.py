@@ -24,7 +24,7 @@ def main():
         for k, s in enumerate(shapes):
             nc, ni, nv = (int(x) for x in s.split("x"))
             rec = bench._scene_record(ctx, nc, ni, nv, 5_000_000 + k * 1_000_000)
-            keep = {k_: rec[k_] for k_ in ("frame_ms", "frame_mode", "frame_ms_scene_update_then_skin_batch", "frame_ms_skin_outputs", "frame_ms_pipelined",
+            keep = {k_: rec[k_] for k_ in ("frame_ms", "frame_mode", "frame_ms_scene_update_then_skin_batch", "frame_ms_skin_outputs", "frame_ms_pipelined", "frame_ms_pipelined_streams_by_kind", "host_ms_pipelined_streams_by_kind", "host_sections_pipelined_streams_by_kind_us",
                                             "pipelined_bit_identical_to_skin_batch", "host_ms_pipelined", "host_ms_skin_outputs", "host_sections_pipelined_us", "host_sections_skin_outputs_us",
                                             "pose_ms", "skin_ms")}
             keep["scene"] = s
