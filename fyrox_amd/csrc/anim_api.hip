@@ -152,18 +152,27 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
                 same = hd[t].n_keys[k] == nk &&
                        memcmp(key_location + hd[t].first_key[k], key_location + hd[t].first_key[0], (size_t)nk * 4) == 0;
             if (!same) continue;
-            const uint32_t stride = need == 4 ? 16u : 8u;        // f4 per record: 256 / 128 bytes
+            const uint32_t stride = span_stride(need);           // f4 per record: 64 bytes (three curves) / 80 (four)
             if (spans.size() + (size_t)(nk - 1) * stride > 0x7fffffffull) continue;
             hot[t].n_keys = nk;
             hot[t].span_first = (uint32_t)spans.size();
             spans.resize(spans.size() + (size_t)(nk - 1) * stride, make_float4(0.f, 0.f, 0.f, 0.f));
             for (uint32_t i = 1; i < nk; ++i) {
                 float4* r = spans.data() + hot[t].span_first + (size_t)(i - 1) * stride;
-                r[0] = make_float4(key_location[hd[t].first_key[0] + i - 1], key_location[hd[t].first_key[0] + i], 0.f, 0.f);
+                // what CurveKey::interpolate reads of keys i - 1 and i (curve.rs:87-132; aux = {value, kind bits, left tangent, right tangent}):
+                // the two values, the left key's kind and right tangent, the right key's left tangent when THAT key is cubic (else 0)
+                uint32_t kinds = 0;
                 for (uint32_t k = 0; k < need; ++k) {
-                    r[1 + 2 * k] = aux[hd[t].first_key[k] + i - 1];
-                    r[2 + 2 * k] = aux[hd[t].first_key[k] + i];
+                    const float4 la = aux[hd[t].first_key[k] + i - 1], ra = aux[hd[t].first_key[k] + i];
+                    uint32_t lk = 0, rk = 0;
+                    memcpy(&lk, &la.y, 4);
+                    memcpy(&rk, &ra.y, 4);
+                    kinds |= (lk & 0xffu) << (8u * k);
+                    r[1 + k] = make_float4(la.x, ra.x, la.w, rk == (uint32_t)FYX_KEY_CUBIC ? ra.z : 0.0f);
                 }
+                float kinds_f = 0.f;
+                memcpy(&kinds_f, &kinds, 4);
+                r[0] = make_float4(key_location[hd[t].first_key[0] + i - 1], key_location[hd[t].first_key[0] + i], kinds_f, 0.f);
             }
         }
         td.hot = hot;
@@ -1063,7 +1072,7 @@ int fyx_debug_rig_chunks(fyx_ctx* c, uint64_t rig_id, uint32_t* out_words, uint3
 // The kernels' decision-making leaves, compiled for the host (anim_leaves.h): what the CPU suite runs against the oracle.
 int fyx_debug_span_value_at(const float* span_records, uint32_t n_keys, uint32_t need, float time, uint32_t hint, float out_values[4], uint32_t* out_hint) {
     if (!span_records || !out_values || !out_hint || n_keys < 2 || need < 1 || need > 4) return FYX_ERR_INVALID_ARG;
-    const uint32_t stride = need == 4 ? 16u : 8u;           // f4 per span: pose_sample_crowd_body's choice
+    const uint32_t stride = span_stride(need);              // f4 per span: header + one part per curve
     float val[4] = {0.f, 0.f, 0.f, 0.f};
     *out_hint = span_track_value_at(reinterpret_cast<const f4*>(span_records), n_keys, stride, (int)need, time, hint, val);
     memcpy(out_values, val, 16);

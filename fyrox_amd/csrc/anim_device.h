@@ -775,8 +775,14 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     for (size_t k = 0; k < n; ++k) {
         S.layouts[k] = ctrl_layout(*S.animators[k]);
         S.offsets[k] = total;
-        // the section's place: its size and half as much again (a transition's program is longer than a state's), kept while the state lasts
-        S.caps[k] = std::max(S.caps[k], align_up(S.layouts[k].total + std::max<size_t>(S.layouts[k].total / 2, 128), 64));
+        // the section's place: its size and a quarter as much again (a transition's program is longer than a state's), KEPT while the state
+        // lasts (the block travels whole every frame: 256 characters 30 KB of sections, 4.1 us of copy kernel; with half as much again 4.8).
+        // While this path runs for another reason (the other frame stream's first frame of a state) a place moves only when its section
+        // has outgrown it -- and that is a new state: the other stream's resident job array holds the old offsets.
+        if (!(unchanged && S.layouts[k].total <= S.caps[k])) {
+            unchanged = false;
+            S.caps[k] = std::max(S.caps[k], align_up(S.layouts[k].total + std::max<size_t>(S.layouts[k].total / 4, 64), 16));
+        }
         total += S.caps[k];
     }
     // (the one-launch frame: every job's counter target of THIS frame, behind the animators' sections)

@@ -230,11 +230,11 @@ __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a,
     // line for the three curves of a Vector3 track, two for a quaternion's four.
     bool sampled = false;
     if (d.spans && hint >= 1 && hint < d.n_keys) {
-        const uint32_t stride = need == 4 ? 16u : 8u;
+        const uint32_t stride = span_stride((uint32_t)need);
         const f4* r = reinterpret_cast<const f4*>(d.spans) + (size_t)(hint - 1) * stride;
         f4 locs = r[0];
         if (locs.x < time && time < locs.y) {
-            v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+            v = interpolate_span(locs.x, locs.y, span_kind(locs, c), r[1 + c], time);
             sampled = true;
         } else if (locs.y < time && hint + 1 < d.n_keys) {
             // playback crossed the span's right key: if the time lies strictly inside the NEXT span, nothing is clamped
@@ -243,7 +243,7 @@ __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a,
             r += stride;
             locs = r[0];
             if (locs.x < time && time < locs.y) {
-                v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+                v = interpolate_span(locs.x, locs.y, span_kind(locs, c), r[1 + c], time);
                 *hp = hint + 1;
                 sampled = true;
             }
@@ -252,7 +252,7 @@ __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a,
             r -= stride;
             locs = r[0];
             if (locs.x < time && time < locs.y) {
-                v = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+                v = interpolate_span(locs.x, locs.y, span_kind(locs, c), r[1 + c], time);
                 *hp = hint - 1;
                 sampled = true;
             }
@@ -467,7 +467,7 @@ __device__ __forceinline__ void pose_sample_crowd_body(const PoseFrameDev& f, ui
         if (!d.valid) {
             sampled = true;                            // fetch() -> None: nothing to sample, the record's part is zeros
         } else {
-            const uint32_t stride = d.need == 4u ? 16u : 8u, n = d.n_keys;
+            const uint32_t stride = span_stride(d.need), n = d.n_keys;
             const uint32_t n_f4 = n >= 2u ? (n - 1u) * stride : 0u;
             if (d.spans && n_f4 && n_f4 <= kSpanLdsF4) {
                 uint32_t h0[4] = {0u, 0u, 0u, 0u};

@@ -55,6 +55,19 @@ FYX_HD float interpolate_loaded(float ll, float rl, f4 la, f4 ra, float location
     return cubicf_(la.x, ra.x, t, la.w, rk == FYX_KEY_CUBIC ? ra.z : 0.0f);
 }
 
+// The same dispatch on a SPAN RECORD's part for one curve: cv = {left key's value, right key's value, left key's right tangent,
+// right key's left tangent if the right key is cubic else 0} -- the four numbers CurveKey::interpolate reads of the two keys -- and
+// the left key's kind (the builder of the records makes the selection of the last one: same values into the same operations).
+FYX_HD float interpolate_span(float ll, float rl, uint32_t lk, f4 cv, float location) {
+    const float t = (location - ll) / (rl - ll);
+    if (lk == FYX_KEY_CONSTANT) return t == 1.0f ? cv.y : cv.x;
+    if (lk == FYX_KEY_LINEAR) return lerpf_(cv.x, cv.y, t);
+    return cubicf_(cv.x, cv.y, t, cv.z, cv.w);
+}
+// stride of a track's span records in f4 (header + one part per curve), and curve c's kind out of the header's third word
+FYX_HD uint32_t span_stride(uint32_t need) { return need + 1u; }
+FYX_HD uint32_t span_kind(f4 header, uint32_t c) { return (f2u(header.z) >> (8u * c)) & 0xffu; }
+
 // ---------------------------------------------------------------------------------------
 // Curve::value_at (curve.rs:254-314) for the three or four curves of ONE track at once, on the track's span records
 // (`sp`: LDS in the crowd sampler, plain memory on the host; n keys, `stride` f4 per span; record layout: TrackHot in
@@ -70,12 +83,12 @@ FYX_HD uint32_t span_track_value_at(SP sp, uint32_t n, uint32_t stride, int need
     const float l_first = sp[0].x, l_last = last[0].y;
     if (time <= l_first) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (c < need) val[c] = sp[1 + 2 * c].x;          // first key's value
+        for (int c = 0; c < 4; ++c) if (c < need) val[c] = sp[1 + c].x;              // first key's value
         return 0u;
     }
     if (time >= l_last) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (c < need) val[c] = last[2 + 2 * c].x;        // last key's value
+        for (int c = 0; c < 4; ++c) if (c < need) val[c] = last[1 + c].y;            // last key's value
         return n - 1u;
     }
     // right key of the span that holds the time: key `hint` if the hinted span holds it, else the first key at or after the time
@@ -107,7 +120,7 @@ FYX_HD uint32_t span_track_value_at(SP sp, uint32_t n, uint32_t stride, int need
     SP r = sp + (size_t)(right - 1u) * stride;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        if (c < need) val[c] = interpolate_loaded(locs.x, locs.y, r[1 + 2 * c], r[2 + 2 * c], time);
+        if (c < need) val[c] = interpolate_span(locs.x, locs.y, span_kind(locs, (uint32_t)c), r[1 + c], time);
     return right;
 }
 

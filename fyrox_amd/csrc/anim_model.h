@@ -296,7 +296,7 @@ struct SceneBatch {
     // A frame in which nothing the job array and the launch plans are made from has changed since the last frame that made them -- same
     // members, no API call on any of them, same options and meshes -- goes straight to "write the control block, upload, launch": what it
     // skips cost a scene of 256 characters ~15 us of the calling thread per frame.  Every animator's control section has a CAPACITY
-    // (its size plus slack) and the sections lie capacity after capacity, so an animator whose programs were planned again (a
+    // (its size plus a quarter) and the sections lie capacity after capacity, so an animator whose programs were planned again (a
     // transition: prog_gen) rewrites its own section where it is and moves nobody else's -- the job array holds offsets into the block;
     // the animators whose frame was a steady one write clocks and tick flags only (the rest of their section is where the slot's last
     // full write left it).  static_gen counts the states; an animator that tracks root motion or properties ends eligibility.

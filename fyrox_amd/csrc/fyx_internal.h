@@ -183,10 +183,12 @@ static_assert(sizeof(KeyRec) == 32, "two keys per 64 bytes");
 // What the per-instance sampler reads of a track FIRST (16 bytes: the three tracks of a bone share a cache line, where their
 // TrackDev records are three lines), and the track's SPAN RECORDS.  Importers write the curves of a track on common key times
 // (glTF samplers, FBX curve nodes); for such a track every span [key i - 1, key i) of ALL its curves is one record
-//     f4 {loc[i-1], loc[i], -, -}   then per curve c:  f4 aux[c][i-1], f4 aux[c][i]       (aux = {value, kind, left tan, right tan})
-// of 128 bytes (three curves: one cache line) or 256 (four), so a bone's ten curve samples touch four lines instead of ~12.5 of
-// per-curve key records -- and the memory system moves whole 128-byte lines whatever part is read
-// (profiles/r03_crowd_study/fetch_granule.log).  A sample whose time lies strictly inside its hinted span -- the steady state of
+//     f4 {loc[i-1], loc[i], the curves' left-key kinds (8 bits each), -}   then per curve c:
+//     f4 {value[c][i-1], value[c][i], right tangent[c][i-1], left tangent[c][i] if key i is cubic else 0}
+// of 64 bytes (three curves) or 80 (four) -- exactly what CurveKey::interpolate reads of the two keys (round 5; rounds 3 - 4 held both
+// keys' full 16-byte records: 128 / 256 bytes per span, of which a sample used 7 words per curve) -- so a bone's ten curve samples
+// touch three or four lines instead of ~12.5 of per-curve key records, and a scene of characters with their own clips moves 208
+// bytes per (animation, node) instead of 512 (profiles/r03_crowd_study/fetch_granule.log: the memory system moves whole lines).  A sample whose time lies strictly inside its hinted span -- the steady state of
 // playback -- needs nothing else; every other case (clamping at the ends, a hint that moved, a time exactly on a key, curves with
 // their own key times) takes the general path over TrackDev / KeyRec, which decides everything in the reference's order.
 struct TrackHot {

@@ -877,8 +877,9 @@ int fyx_debug_scene_tables(fyx_ctx* ctx, const uint64_t* animator_ids, uint32_t 
  *     node n_nodes + 1 = padding.
  *   fyx_debug_span_value_at / fyx_debug_classify_fold_program: the kernels' own decision-making leaves (csrc/anim_leaves.h,
  *     __host__ __device__) compiled for the host -- Curve::value_at for the `need` (3 or 4) curves of one track on its span
- *     records (n_keys - 1 records of 8 or 16 float4: {loc[i-1], loc[i], -, -} then per curve {value, kind bits, left tangent,
- *     right tangent} of keys i - 1 and i), returning the values and the new hint; and the classifier that decides whether a fold
+ *     records (n_keys - 1 records of need + 1 float4: {loc[i-1], loc[i], the curves' left-key kinds as 8-bit fields of a u32, -}
+ *     then per curve {value of key i - 1, value of key i, right tangent of key i - 1, left tangent of key i if that key is cubic
+ *     else 0}), returning the values and the new hint; and the classifier that decides whether a fold
  *     program {opcode | arg << 8, f32 weight bits} x n_ops is "straight" (d leading PUSHes, k operands, a MASK before the APPLY,
  *     or the AnimationPlayer's APPLY_ANIM^k END) -- the function by which the host picks the update kernel's lean form. */
 /* Test hook of the one-launch frame's in-grid wait: adds `delta` to the animator's device counter (the word the frame's sampler

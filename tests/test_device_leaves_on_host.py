@@ -21,17 +21,18 @@ OP_END, OP_BLEND_ANIM, OP_PUSH, OP_POP_BLEND, OP_RESET, OP_MASK, OP_APPLY, OP_AP
 
 
 def _span_records(loc, curves):
-    """What fyx_tracks_data_upload builds (anim_api.hip): per span {loc[i-1], loc[i], 0, 0} then per curve aux[i-1], aux[i];
-    aux = {value, key kind bits, left tangent, right tangent} with the tangents of non-cubic keys zeroed."""
+    """What fyx_tracks_data_upload builds (anim_api.hip): per span a header {loc[i-1], loc[i], the curves' left-key kinds as 8-bit fields of
+    a u32, 0}, then per curve {value[i-1], value[i], right tangent of key i - 1 (0 unless that key is cubic), left tangent of key i (0 unless
+    THAT key is cubic)} -- what CurveKey::interpolate reads of the two keys."""
     n, need = len(loc), len(curves)
-    stride = 16 if need == 4 else 8
+    stride = need + 1
     rec = np.zeros((n - 1, stride, 4), np.float32)
     for i in range(1, n):
-        rec[i - 1, 0, 0], rec[i - 1, 0, 1] = loc[i - 1], loc[i]
+        kinds = 0
         for c, (val, kind, lt, rt) in enumerate(curves):
-            for j, k in ((1, i - 1), (2, i)):
-                cubic = int(kind[k]) == 2
-                rec[i - 1, j + 2 * c] = (val[k], np.array([int(kind[k])], np.uint32).view(np.float32)[0], lt[k] if cubic else 0.0, rt[k] if cubic else 0.0)
+            kinds |= (int(kind[i - 1]) & 0xff) << (8 * c)
+            rec[i - 1, 1 + c] = (val[i - 1], val[i], rt[i - 1] if int(kind[i - 1]) == 2 else 0.0, lt[i] if int(kind[i]) == 2 else 0.0)
+        rec[i - 1, 0] = (loc[i - 1], loc[i], np.array([kinds], np.uint32).view(np.float32)[0], 0.0)
     return rec
 
 
