@@ -116,7 +116,8 @@ int enter_pose(fyx_ctx* c, hipStream_t* out) {
         return FYX_OK;
     }
     if (!c->alt_stream) {
-        FYX_HIP(c, make_stream(c, true, &c->alt_stream));
+        // (streams.priority / streams.pose_cus: a frame stream carries pose kernels; the second stream of anim.overlap = 2 carries skinning only)
+        FYX_HIP(c, make_stream(c, c->pose_overlap != 2, &c->alt_stream));
         // (the join of the frame stream into the context stream keeps the system scope: under anim.overlap the frame streams carry the
         // skinning launches too, and what waits behind this event on the context stream may be an RCCL exchange or a copy to the host)
         FYX_HIP(c, hipEventCreateWithFlags(&c->alt_done, hipEventDisableTiming));
@@ -260,7 +261,7 @@ static int recreate_streams(fyx_ctx* c) {
         FYX_HIP(c, hipStreamSynchronize(c->alt_stream));
         FYX_HIP(c, hipStreamDestroy(c->alt_stream));
         c->alt_stream = nullptr;
-        FYX_HIP(c, make_stream(c, true, &c->alt_stream));
+        FYX_HIP(c, make_stream(c, c->pose_overlap != 2, &c->alt_stream));
         c->alt_busy = false;
         c->pose_done_on = -1;
         c->skin_done_on = -1;
@@ -969,6 +970,10 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
         c->skin_done_on = -1;
         c->skin_mark[0] = c->skin_mark[1] = false;
         c->skin_waits_pose = false;
+        if (c->alt_stream && (c->stream_priority || c->pose_cus > 0)) {      // the second stream changes its kind between the two modes
+            *slot = value;
+            return recreate_streams(c);
+        }
     }
     *slot = value;
     return FYX_OK;
