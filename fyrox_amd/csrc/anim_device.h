@@ -789,7 +789,6 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     S.o_targets = align_up(total, 16);
     if (S.one_frame) total = S.o_targets + align_up(n * 4, 16);
     S.ctrl_total = total;
-    S.any_skin = any_skin;
     S.h_jobs.resize(n * sizeof(SceneJobDev));      // (every byte of a job is written below: frame_static and rig_dev start from zeros)
     jobs = reinterpret_cast<SceneJobDev*>(S.h_jobs.data());
     for (size_t k = 0; k < n; ++k) {

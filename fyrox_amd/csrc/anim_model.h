@@ -310,7 +310,8 @@ struct SceneBatch {
     std::vector<uint64_t> slot_prog[2];     // ... and [member]: the prog_gen of the programs its section holds there
     uint64_t skin_jobs_gen[2] = {0, 0};     // static_gen of skin_jobs_of[frame stream]
     std::vector<fyx_skin_job> skin_jobs_of[2];
-    bool fast_eligible = false, any_skin = false, single_palette = false;
+    bool fast_eligible = false;             // no member tracks root motion or properties, and the scene is not the one-launch form
+    bool single_palette = false;            // a member has a palette output without a second buffer (anim.overlap = 2: its frames wait for all earlier skinning)
     size_t ctrl_total = 0, o_targets = 0;
     std::vector<Animator*> animators;   // the members of the current call ...
     std::vector<uint64_t> member_ids;   // ... which are the previous call's when the id list and the store's set of animators are (members_gen)
