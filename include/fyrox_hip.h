@@ -88,12 +88,15 @@ int fyx_join(fyx_ctx* ctx);
  *                        2 x anim.split stay on the calling thread
  *     "anim.sample_form" 0 auto, 1 curves of one instance on the lanes, 2 instances of one curve on the lanes -- same
  *                        results, the crowd form is picked from 32 instances on
- *     "anim.overlap"     2 = streams BY KIND: every pose kernel on the context stream, every skinning launch (the caller's and the
+ *     "anim.overlap"     0 (default) = a frame is one dependent chain on the context stream.
+ *                        2 = streams BY KIND: every pose kernel on the context stream, every skinning launch (the caller's and the
  *                        library's own) on a second stream, each in order; a frame's first skinning launch waits for its pose update,
  *                        a frame's pose update for the skinning of the frame before the previous one (two palette buffers per animator,
  *                        as below: fyx_animator_set_palette_output_pair; an output with one buffer makes its frames wait for ALL
  *                        earlier skinning).  Frame n + 1's pose kernels run beside frame n's skinning, no queue sits blocked on an
  *                        event that is still to come, and ONE set of vertex outputs is enough (the skinning launches are in order).
+ *                        Scenes: as fast as 1 (256 characters 0.060 -> 0.056 ms); a crowd: no faster than 0 (its consecutive
+ *                        skinning launches no longer overlap).
  *                        1 = whole frames alternate between TWO streams: a pose update (fyx_*_update, fyx_scene_update) starts a
  *                        frame on the other stream, the skinning launches that follow go there too, in order behind it.  Frame
  *                        n + 1's pose kernels so run beside frame n's skinning; its only cross-stream edge is "behind frame n's
@@ -102,7 +105,7 @@ int fyx_join(fyx_ctx* ctx);
  *                        fyx_animator_set_palette_output_pair registers both once).  The skinning launches of two consecutive
  *                        frames are NOT ordered against each other: a caller that skins itself alternates its vertex outputs
  *                        as well (what a renderer that draws frame n while frame n + 1 is skinned does anyway).
- *                        "lbs.streams" is not used in this mode.  C3: frame 0.115 -> 0.101 - 0.104 ms
+ *                        "lbs.streams" is not used in modes 1 and 2.  C3: frame 0.113 -> 0.094 - 0.101 ms in mode 1
  *     "anim.update_lean" 1 (default) = a frame whose fold programs are ALL straight (a few clips blended in a row: the common
  *                        machines; the host classifies with the kernel's own function) runs the update kernel built without the
  *                        fold interpreter: a third of the registers, so its waves fit beside a running skinning kernel
