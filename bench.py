@@ -26,8 +26,10 @@ What the one JSON line says (rank 0 prints it):
   extra.strong_scaling  N > 1: the SAME 1 M-vertex mesh cut by vertex range over the N GPUs (BASELINE config 4), compute
                         only and with the RCCL exchange (fyx_allgather_skinned) in BOTH of its forms (comm.form 0 / 1).
   extra.crowd_scaling   N > 1: C3 cut by instance range, per-rank pose + skinning, no communication.
-  strong_value, strong_with_gather_value, crowd_value   N > 1: the three numbers above at the top level.  `value` stays the
-                        weak-scaling job (every GPU its own 1 M vertices, no collective).
+  N > 1                 `value` = BASELINE config 4 as written (strong scaling, compute only; = strong_value); value_with_gather = the same
+                        with the fastest exchange form; weak_value = every GPU its own 1 M vertices, no collective; crowd_value = C3 by instances.
+The line is a DIGEST (< 6 KB: contract keys, roofline, parity, cpu_baseline, numbers of the sub-records); the full record with every
+sub-record, note and box fact goes to bench_full.json (`full_record` in the line names it).
 """
 from __future__ import annotations
 
@@ -189,6 +191,159 @@ def emit(line: str) -> None:
     print(line, flush=True)
 
 
+LINE_LIMIT = 6144              # bytes: the driver's parser gave up on round 5's 34 KB line
+
+
+def _dig(d, *path):
+    """d[path[0]][path[1]]... or None: a sub-record that did not run is a missing number, never an exception."""
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _num(x, digits=5):
+    """Numbers of the compact line: 5 significant digits (the full record keeps what was measured)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def compact_record(full: dict, full_path: str | None) -> dict:
+    """The ONE line the driver parses: the contract's keys, `roofline`, `parity`, `cpu_baseline`, and a DIGEST of the sub-records --
+    numbers only, no prose.  Everything else (box facts at three points of the run, per-set sweeps, notes, the sub-records whole) is
+    the full record, written beside it (`full_record`)."""
+    r = full.get("roofline") or {}
+    ex = full.get("extra") or {}
+    cfg = full.get("config") or {}
+    roof = None
+    if r:
+        tsrc = r.get("traffic_source") or ""
+        roof = {"bound": r.get("bound"), "kernel": r.get("kernel"), "kernel_us": _num(r.get("kernel_us")),
+                "achieved": _num(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"), "frac": _num(r.get("frac")),
+                "traffic": _num(r.get("traffic"), 7),
+                "traffic_source": None if r.get("traffic") is None else "pmc_in_this_run" if tsrc.startswith("measured in this run") else "replayed_builder_pmc",
+                "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"),
+                "sets": cfg.get("sets"),
+                "frac_at_6_sets": _num(r.get("frac_at_6_sets")), "kernel_us_at_6_sets": _num(r.get("kernel_us_at_6_sets")),
+                "frac_at_1_set": _num(_dig(r, "by_number_of_rotating_sets", "1", "frac")),
+                "kernel_us_min": _num(r.get("kernel_us_min")), "kernel_us_max": _num(r.get("kernel_us_max")),
+                "overlapped": {"frac": _num(_dig(r, "overlapped", "frac")), "avg_launch_us": _num(_dig(r, "overlapped", "avg_launch_us")),
+                               "launch_streams": _dig(r, "overlapped", "launch_streams")},
+                "copy_ceiling": {"frac": _num(_dig(r, "copy_ceiling", "frac")), "kernel_us": _num(_dig(r, "copy_ceiling", "kernel_us"))},
+                "position_only_frac": _num(_dig(r, "position_only", "frac"))}
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data", "timed_steps", "repeats")}
+    out["value"], out["ms_per_step"] = _num(out["value"], 7), _num(out["ms_per_step"], 6)
+    out["config"] = {k: cfg.get(k) for k in ("workload", "sharding", "n_ranks", "process_group", "sets") if k in cfg}
+    out["roofline"] = roof
+    par = full.get("parity")
+    out["parity"] = None if not isinstance(par, dict) else {k: _num(par.get(k)) for k in ("max_rel_err", "bit_exact", "checked_vertices")}
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": (cb.get("sample") or "")[:160], "omp_value": _num(cb.get("omp_value")), "omp_cores": cb.get("omp_cores")}
+    # N > 1: the other scalings beside `value`
+    for k in ("weak_value", "weak_ms_per_step", "strong_value", "strong_ms_per_step", "value_with_gather", "value_with_gather_form",
+              "strong_with_gather_value", "strong_with_gather_form", "crowd_value", "crowd_frame_ms", "comm_error"):
+        if k in full:
+            v = full[k]
+            out[k] = v[:200] if isinstance(v, str) else _num(v, 7)
+    legs = full.get("exchange_legs") or _dig(ex, "strong_scaling")
+    if isinstance(legs, dict):
+        dl_ = {}
+        for k, v in legs.items():
+            if isinstance(v, dict) and "value" in v and k != "compute_only":
+                dl_[k] = {"value": _num(v.get("value"), 7), "ms_per_step": _num(v.get("ms_per_step"))}
+        if dl_:
+            out["exchange_legs"] = dl_
+        if legs.get("gathered_equals_oracle") is not None:
+            out["gathered_equals_oracle"] = legs.get("gathered_equals_oracle")
+    dg = {}
+
+    def put(key, *path):
+        v = _dig(ex, *path)
+        if v is not None:
+            dg[key] = _num(v)
+    for c in ("c2", "c5", "c3", "c3_root_motion"):
+        put(f"{c}_frame_ms", c, "frame_ms")
+        put(f"{c}_frame_ms_one_stream", c, "frame_ms_one_stream")
+        put(f"{c}_skin_ms", c, "skin_ms")
+        put(f"{c}_pose_ms", c, "pose_ms")
+        put(f"{c}_bit_exact_frames", c, "parity", "frames_in_lock_step")
+        put(f"{c}_max_rel_err", c, "parity", "end_to_end_max_rel_err")
+    put("c3_crowd_kernel_us", "c3", "roofline", "kernel_us")
+    put("c3_crowd_kernel_frac", "c3", "roofline", "frac")
+    put("c3_fused_frac", "c3_fused", "roofline", "frac")
+    put("c3_fused_max_rel_err", "c3_fused", "parity", "max_rel_err")
+    put("c4_random_bones_frac", "c4_random_bones", "frac")
+    put("c4_random_bones_slowdown", "c4_random_bones", "slowdown_vs_coherent")
+    put("c3_random_bones_slowdown", "c3_random_bones", "slowdown_vs_coherent")
+    for s in ("scene_256x1", "scene_64x4"):
+        put(f"{s}_frame_ms", s, "frame_ms")
+        put(f"{s}_frame_ms_pipelined", s, "frame_ms_pipelined")
+        put(f"{s}_host_ms", s, "host_ms_skin_outputs")
+        put(f"{s}_pose_ms", s, "pose_ms")
+        put(f"{s}_skin_ms", s, "skin_ms")
+        put(f"{s}_skin_frac", s, "skin_roofline", "frac")
+        put(f"{s}_bit_exact", s, "parity", "bit_exact")
+    for key, name in (("vb_plain", "plain"), ("vb_4_shapes", "with_4_blend_shapes")):
+        put(f"{key}_frac", "vertex_buffer", name, "roofline", "frac")
+        put(f"{key}_frac_two_streams", "vertex_buffer", name, "roofline", "frac_two_streams")
+        put(f"{key}_frac_at_4_sets", "vertex_buffer", name, "roofline", "by_number_of_rotating_sets", "4", "frac")
+    put("c3_plan_us_with_memo", "host_control_plane", "c3_plan_us_with_memo")
+    put("scene_256x1_plan_us", "host_control_plane", "scene_256x1_plan_us")
+    if dg:
+        out["digest"] = dg
+    b = full.get("box")
+    if isinstance(b, dict):
+        ah = b.get("after_headline") or b.get("at_end") or b.get("at_start") or {}
+        out["box"] = {"sclk_under_load": _dig(ah, "sclk", "current"), "mclk": _dig(ah, "mclk", "current"),
+                      "partition": f"{ah.get('current_compute_partition')}/{ah.get('current_memory_partition')}",
+                      "power_w_under_load": None if ah.get("hwmon_power1_input") is None else ah["hwmon_power1_input"] // 1_000_000,
+                      "power_cap_w": None if ah.get("hwmon_power1_cap") is None else ah["hwmon_power1_cap"] // 1_000_000,
+                      "cus": _dig(b, "hip_device", "multi_processor_count")}
+    out["full_record"] = full_path
+    return out
+
+
+def compact_line(full: dict, full_path: str | None) -> str:
+    """json of compact_record, never longer than LINE_LIMIT: if a future key pushes it over, the digest goes first, then the box."""
+    rec = compact_record(full, full_path)
+    line = json.dumps(rec, separators=(",", ":"))
+    for victim in ("digest", "box", "exchange_legs"):
+        if len(line) <= LINE_LIMIT:
+            break
+        rec.pop(victim, None)
+        rec["dropped_for_length"] = rec.get("dropped_for_length", []) + [victim]
+        line = json.dumps(rec, separators=(",", ":"))
+    return line
+
+
+def finish(full: dict, full_path: str | None = None) -> None:
+    """Rank 0's last act: the full record to `full_path` (default bench_full.json beside this file, and a copy under gpurun_out/ when that
+    exists), then the compact line as the LAST thing on stdout."""
+    path = full_path or os.path.join(ROOT, "bench_full.json")
+    written = None
+    for p in (path, os.path.join(ROOT, "gpurun_out", os.path.basename(path))):
+        try:
+            if os.path.isdir(os.path.dirname(p)):
+                with open(p, "w") as f:
+                    json.dump(full, f)
+                written = written or os.path.relpath(p, ROOT)
+        except Exception as e:     # noqa: BLE001
+            print(f"# could not write {p}: {e!r}", file=sys.stderr)
+    emit(compact_line(full, written))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,9 +353,9 @@ def parse():
     ap.add_argument("--verts", type=int, default=N_VERTS)
     ap.add_argument("--bones", type=int, default=N_BONES)
     ap.add_argument("--random-bones", action="store_true", help="fully random bone indices (worst-case LDS gather)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N>1: weak = every GPU skins its own 1 M-vertex shard of an N x 1 M scene (headline); "
-                         "strong = the 1 M-vertex mesh itself is cut over the N GPUs (BASELINE config 4)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="what `value` is at N > 1.  Default: strong = BASELINE config 4 as written, ONE 1 M-vertex mesh cut by vertex range over the N "
+                         "GPUs, compute only (weak_value and value_with_gather beside it); weak = every GPU skins its own 1 M-vertex mesh.  N = 1: the same thing")
     ap.add_argument("--allgather", action="store_true", help="strong scaling: include the RCCL exchange in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -215,6 +370,7 @@ def parse():
                          "host thread per GPU, the exchange through fyx_comm_init_all / fyx_allgather_skinned_all.  Taken automatically when "
                          "the re-execution under torch.distributed.run fails or does not finish")
     ap.add_argument("--launcher-timeout", type=float, default=1500.0, help="seconds the plain `--gpus N` launch gives torch.distributed.run")
+    ap.add_argument("--full-record", default=None, help="where the FULL record goes (default bench_full.json beside bench.py); the one stdout line is its digest")
     return ap.parse_args()
 
 
@@ -1094,8 +1250,8 @@ def main_one_process(args, reason: str) -> None:
     """N GPUs from ONE process (the engine's shape: one process, one update thread per ... here one host thread per GPU so that the launch
     calls of 16-us kernels do not queue behind one another): no launcher, no torch process group.  Contexts on devices 0 .. N - 1 (test
     hook FYX_BENCH_DEVICE: all on that device, which fyx_comm_init_all refuses -- the line then says so in comm_error and carries the
-    compute legs only).  Legs: `value` weak scaling (every GPU its own mesh), strong_value (ONE mesh cut by vertex range, compute only),
-    strong_with_gather_value (the same + fyx_allgather_skinned_all / _padded_all, each under a watchdog)."""
+    compute legs only).  Legs: strong_value (ONE mesh cut by vertex range, compute only: `value` unless --scaling weak), weak_value (every GPU
+    its own mesh), value_with_gather (strong + fyx_allgather_skinned_all / _padded_all, each under a watchdog)."""
     import threading
     import fyrox_amd
     from fyrox_amd import sharding, synth
@@ -1179,16 +1335,22 @@ def main_one_process(args, reason: str) -> None:
 
     w = timed(lambda g, i: chk(weak_calls[g][i % sets]()), args.steps, args.warmup)
     s_c = timed(lambda g, i: chk(strong_calls[g]()), args.steps, args.warmup)
+    weak_v, weak_ms, strong_v, strong_ms = float(nv) * n * args.steps / w, w * 1e3 / args.steps, float(nv) * args.steps / s_c, s_c * 1e3 / args.steps
+    as_weak = args.scaling == "weak"
     out = {"metric": "skinned vertices/sec at 1M verts/256 bones; achieved HBM GB/s vs peak",
-           "value": float(nv) * n * args.steps / w, "unit": "vertices/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": w * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"C4: {nv} verts / {nb} bones per GPU, 4-influence LBS of position+normal+tangent, {sets} rotating buffer sets; `value` is WEAK "
-                                  f"scaling over the {n} GPUs (every GPU its own mesh, no collective); strong_value = BASELINE config 4 as written",
+           "value": weak_v if as_weak else strong_v, "unit": "vertices/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": weak_ms if as_weak else strong_ms, "higher_is_better": True, "scaling": "weak" if as_weak else "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "timed_steps": args.steps, "repeats": 1,
+           "config": {"workload": (f"C4: {nv} verts / {nb} bones per GPU, 4-influence LBS of position+normal+tangent, {sets} rotating buffer sets; `value` is WEAK "
+                                   f"scaling over the {n} GPUs (every GPU its own mesh, no collective); strong_value = BASELINE config 4 as written") if as_weak else
+                                  (f"C4 as written: {nv} verts / {nb} bones cut by contiguous vertex range over {n} GPU(s), palette replicated, every GPU writes its shard "
+                                   "in place; `value` is this STRONG-scaling job, compute only; value_with_gather = the same with the RCCL exchange (fastest form); "
+                                   "weak_value = every GPU its own 1 M-vertex mesh"),
                       "process_group": f"none: ONE process drives the {n} GPUs (fyx_comm_init_all / fyx_allgather_skinned_all), one host thread per GPU; {reason}",
-                      "devices": devices, "sharding": "contiguous vertex range per GPU, palette replicated"},
+                      "devices": devices, "sharding": "contiguous vertex range per GPU, palette replicated", "n_ranks": n, "sets": sets},
            "roofline": None, "parity": parity,
-           "strong_value": float(nv) * args.steps / s_c, "strong_ms_per_step": s_c * 1e3 / args.steps,
-           "strong_with_gather_value": None, "strong_with_gather_form": None, "comm_error": None,
+           "strong_value": strong_v, "strong_ms_per_step": strong_ms, "weak_value": weak_v, "weak_ms_per_step": weak_ms,
+           "value_with_gather": None, "value_with_gather_form": None, "comm_error": None,
            "timing_note": "host clock between fyx_sync of every context before and after the launches (no torch, no events across devices)",
            "box": {"at_start": box_facts(devices[0])}}
     # the exchange, last and under a watchdog: RCCL with more than one rank runs here for the first time
@@ -1206,7 +1368,7 @@ def main_one_process(args, reason: str) -> None:
                 if not done.is_set():
                     legs[key] = {"value": None, "note": f"the exchange did not finish within {EXCHANGE_TIMEOUT_S} s"}
                     out["exchange_legs"] = legs
-                    emit(json.dumps(out))
+                    finish(out, args.full_record)
                     os._exit(0)
             wd = threading.Timer(EXCHANGE_TIMEOUT_S, give_up)
             wd.daemon = True
@@ -1224,8 +1386,8 @@ def main_one_process(args, reason: str) -> None:
                 if not args.no_check:      # the LAST GPU holds the whole mesh: its head (another GPU's shard) against the oracle
                     ok = lbs_parity(ctxs[-1], mesh, pal, tuple(_Ptr(b.ptr) for b in bufs[-1]), 20_000)["bit_exact"]
                 legs[key] = {"value": float(nv) * args.steps / t, "ms_per_step": t * 1e3 / args.steps, "gathered_equals_oracle": ok}
-                if ok is not False and (out["strong_with_gather_value"] is None or legs[key]["value"] > out["strong_with_gather_value"]):
-                    out["strong_with_gather_value"], out["strong_with_gather_form"] = legs[key]["value"], key
+                if ok is not False and (out["value_with_gather"] is None or legs[key]["value"] > out["value_with_gather"]):
+                    out["value_with_gather"], out["value_with_gather_form"] = legs[key]["value"], key
             except Exception as e:     # noqa: BLE001
                 legs[key] = {"value": None, "note": f"the exchange failed: {e!r}"}
                 done.set()
@@ -1236,7 +1398,7 @@ def main_one_process(args, reason: str) -> None:
         ctxs[0].set_option("comm.form", 0)
         out["exchange_legs"] = legs
     out["box"]["at_end"] = box_facts(devices[0])
-    emit(json.dumps(out))
+    finish(out, args.full_record)
     for c in ctxs:
         c.close()
 
@@ -1269,6 +1431,9 @@ def main():
         print(f"# {reason}; falling back to --one-process", file=sys.stderr, flush=True)
         return main_one_process(args, f"fallback: {reason}")
     check_world(args.gpus, world)
+    if args.scaling is None:
+        args.scaling = "weak" if world == 1 else "strong"
+    run_weak = args.scaling == "weak" or world > 1        # N > 1: both scalings are measured, --scaling says which one is `value`
 
     if args.extras_only:
         # The other BASELINE configs and the scene tick, in a process of their own: their pipelined frames are bound by the host's
@@ -1441,8 +1606,10 @@ def main():
             raise SystemExit(f"parity check failed before timing: max rel err {parity['max_rel_err']:.3e} > 1e-5")
 
     strong = None
-    if args.scaling == "weak":
-        repeats, walls, gpus = timed_regions(step, args.steps, args.warmup)
+    weak_regions = None
+    if run_weak:
+        weak_regions = timed_regions(step, args.steps, args.warmup)
+        repeats, walls, gpus = weak_regions
     # ---- the kernel alone: launches serialized on ONE stream (HIP-event average per launch == rocprofv3 kernel duration) --
     n_ser = max(500, min(args.steps, 2000))
     ctx.set_option("lbs.streams", 1)
@@ -1747,12 +1914,14 @@ def main():
                                    f"{args.sets} rotating 100 MB buffer sets, "
                                    f"{'random' if args.random_bones else 'spatially coherent'} bone indices"
                                    + ("" if world == 1 else f"; `value` is WEAK scaling over the {world} GPUs (every GPU its own 1 M-vertex mesh, no collective); BASELINE "
-                                      "config 4 as written (ONE 1 M-vertex mesh cut by vertex range) is strong_value / strong_with_gather_value, config 3 cut by "
+                                      "config 4 as written (ONE 1 M-vertex mesh cut by vertex range) is strong_value / value_with_gather, config 3 cut by "
                                       "instance range is crowd_value")
-                                   if args.scaling == "weak" else strong["workload"],
+                                   if args.scaling == "weak" else strong["workload"] + ("" if world == 1 else
+                                   "; `value` is this STRONG-scaling job, compute only; value_with_gather = the same with the RCCL exchange (fastest form); "
+                                   "weak_value = every GPU its own 1 M-vertex mesh; crowd_value = config 3 cut by instance range"),
                        "sharding": "contiguous vertex range per GPU, palette replicated",
                        "rank0_vertex_range": list(shard), "n_ranks": n_ranks_rccl if n_ranks_rccl is not None else 1,
-                       "process_group": dist_backend,
+                       "process_group": dist_backend, "sets": args.sets,
                        "kernel_options": opts},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_measurement": traffic_live,
@@ -1771,8 +1940,9 @@ def main():
                          "by_number_of_rotating_sets_note": "the same lone launch rotating over the first k of up to 16 buffer sets of 100 MB (inputs AND outputs): the kernel's time "
                                                             "depends on the footprint the rotation walks over; frac above is at --sets (default 8, as in every round); SURVEY 8(d) asks for >= 6",
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "overlapped": {"avg_launch_us": launch_us, "achieved": bytes_launch / (launch_us * 1e-6) / 1e9,
-                                        "frac": bytes_launch / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                         "overlapped": {"avg_launch_us": launch_us, "achieved": BYTES_PER_VERTEX * per_rank_verts / (launch_us * 1e-6) / 1e9,
+                                        "frac": BYTES_PER_VERTEX * per_rank_verts / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                        "vertices_per_launch": per_rank_verts,
                                         "launch_streams": opts["lbs.streams"],
                                         "note": "time per launch of the timed region: consecutive launches overlap on the launch streams"},
                          "copy_ceiling": None if copy_us is None else {
@@ -1838,13 +2008,16 @@ def main():
                 out["crowd_value"], out["crowd_frame_ms"] = crowd["value"], crowd["frame_ms_slowest_rank"]
 
     if rank == 0 and strong is not None and (world > 1 or force_exchange):
-        # BASELINE config 4 where a reader of the top level finds it (the headline `value` stays the weak-scaling job)
+        # Both scalings at the top level whichever one `value` is: strong_value = BASELINE config 4 (the ONE 1 M-vertex mesh cut by vertex
+        # range, compute only), weak_value = every GPU its own 1 M-vertex mesh, value_with_gather = config 4 with the RCCL exchange, the
+        # fastest of the three exchange forms (all in extra.strong_scaling); crowd_value = config 3 cut by instance range, whole frames
         out["strong_value"] = strong["compute_only"]["value"]
         out["strong_ms_per_step"] = strong["compute_only"]["ms_per_step"]
-        out["strong_with_gather_value"], out["strong_with_gather_form"] = None, None
-        out["top_level_note"] = ("value = weak scaling (every GPU skins its own 1 M-vertex mesh); strong_value = BASELINE config 4, the ONE 1 M-vertex "
-                                 "mesh cut by vertex range, compute only; strong_with_gather_value = the same with the RCCL exchange, the fastest of "
-                                 "the three exchange forms (all in extra.strong_scaling); crowd_value = config 3 cut by instance range, whole frames")
+        if weak_regions is not None:
+            r_w, w_w, _ = weak_regions
+            out["weak_value"] = float(world) * nv * args.steps * r_w / float(np.median(w_w))
+            out["weak_ms_per_step"] = float(np.median(w_w)) * 1e3 / (args.steps * r_w)
+        out["value_with_gather"], out["value_with_gather_form"] = None, None
 
     # ---- the exchange, last: RCCL with more than one rank has never run before the driver's multi-GPU job, so a hang in it
     # must not cost the line -- after EXCHANGE_TIMEOUT_S rank 0 prints what it has and every rank leaves.  All three forms are timed:
@@ -1855,7 +2028,7 @@ def main():
             def give_up(key=key):
                 if rank == 0:
                     out["extra"]["strong_scaling"][key] = {"value": None, "note": f"the exchange did not finish within {EXCHANGE_TIMEOUT_S} s"}
-                    emit(json.dumps(out))
+                    finish(out, args.full_record)
                 os._exit(0)
 
             watchdog = threading.Timer(EXCHANGE_TIMEOUT_S, give_up)
@@ -1874,8 +2047,8 @@ def main():
                     st["gathered_equals_oracle"] = ok if st.get("gathered_equals_oracle") in (None, True) else False
                     if ok is False:
                         st[key]["note"] = "THE GATHERED BUFFER DIFFERS FROM THE ORACLE"
-                    elif out.get("strong_with_gather_value") is None or rec["value"] > out["strong_with_gather_value"]:
-                        out["strong_with_gather_value"], out["strong_with_gather_form"] = rec["value"], ("broadcasts", "send_recv", "all_gather_padded")[form]
+                    elif out.get("value_with_gather") is None or rec["value"] > out["value_with_gather"]:
+                        out["value_with_gather"], out["value_with_gather_form"] = rec["value"], ("broadcasts", "send_recv", "all_gather_padded")[form]
                     if args.scaling == "strong" and args.allgather and form == 0:
                         r_g, w_g, _ = regions
                         out["value"] = float(args.verts) * args.steps * r_g / float(np.median(w_g))
@@ -1892,7 +2065,7 @@ def main():
             out["box"]["note"] = ("sysfs of the amdgpu card + hwmon + rocm-smi at the start of the run, right behind the headline's timed regions and at the "
                                   "end: clocks (the level marked * is the current one), power now / cap (microwatts), temperatures (millidegrees), "
                                   "compute / memory partition modes, driver versions -- what tells a slow box from a fast one")
-        emit(json.dumps(out))
+        finish(out, args.full_record)
 
     barrier()
     ctx.close()
