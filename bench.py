@@ -452,7 +452,7 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     p.set_palette_output(base + 50, d_pal.ptr)
     ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
     nv = mesh.n_verts * n_instances
-    d_pos, d_nrm, d_tan = ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)
+    d_pos, d_nrm, d_tan = ctx.malloc_streams([nv * 12 + 64, nv * 12 + 64, nv * 16 + 64])
     oracles = {}
     # every instance at its own phase (a crowd), a function of its GLOBAL index (inst_offset: this rank's first instance when the
     # crowd is cut by instance range over several GPUs); the sampled ones get an oracle of their own
@@ -515,7 +515,7 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     # while frame n + 1 is skinned into the other) -- nothing else changes, the same kernels compute the same values
     ctx.set_option("anim.overlap", 1)
     pals = (d_pal, d_pal2)
-    outs2 = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+    outs2 = tuple(ctx.malloc_streams([nv * 12 + 64, nv * 12 + 64, nv * 16 + 64]))
     out_sets = ((d_pos, d_nrm, d_tan), outs2)
     p.set_palette_output_pair(base + 50, d_pal.ptr, d_pal2.ptr)
 
@@ -766,7 +766,7 @@ def _c3_random_record(ctx, n_instances=1000, n_verts=10_000, n_bones=64, launche
     pal = synth.make_palette(n_bones, seed, n_instances=n_instances).reshape(n_instances, n_bones, 16)
     d_pal = ctx.to_device(pal)
     nv = n_verts * n_instances
-    outs = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+    outs = tuple(ctx.malloc_streams([nv * 12 + 64, nv * 12 + 64, nv * 16 + 64]))
     unique = n_verts * 60 + n_instances * n_bones * 64 + nv * 40
     res = {}
     for key, coherent in (("coherent", True), ("random", False)):
@@ -811,6 +811,24 @@ class _Ptr:
 
     def data_ptr(self):
         return self._p
+
+
+class _Out:
+    """An output stream of its own allocation (fyx_malloc_streams), with the two methods of a torch tensor dl() / zero() use."""
+    def __init__(self, buf, n_floats):
+        self.buf, self._n = buf, n_floats
+
+    def data_ptr(self):
+        return self.buf.ptr
+
+    def numel(self):
+        return self._n
+
+
+def output_streams(ctx, n_verts: int) -> tuple:
+    """Position / normal / tangent outputs of n_verts vertices, each stream an allocation of its own (include/fyrox_hip.h, fyx_malloc_streams)."""
+    p, n, t = ctx.malloc_streams([n_verts * 12 + 64, n_verts * 12 + 64, n_verts * 16 + 64])
+    return (_Out(p, n_verts * 3 + 16), _Out(n, n_verts * 3 + 16), _Out(t, n_verts * 4 + 16))
 
 
 def _vertex_buffer_record(ctx, n_verts=1_000_000, n_bones=256, n_shapes=4, sets=6, steps=400) -> dict:
@@ -932,7 +950,7 @@ def _scene_record(ctx, n_chars: int, n_inst: int, n_verts: int, id_base: int, fr
         ctx.mesh_upload_soa(mid, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
         nv = n_verts * n_inst
         d_pal = ctx.malloc(n_inst * nb * 64)
-        outs = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+        outs = tuple(ctx.malloc_streams([nv * 12 + 64, nv * 12 + 64, nv * 16 + 64]))
         an.set_palette_output(bid, d_pal.ptr)
         an.bones_id = bid
         chars.append((an, mid, d_pal, outs, mesh, rig, seed))
@@ -1275,7 +1293,7 @@ def main_one_process(args, reason: str) -> None:
         calls = []
         for s_ in range(sets):
             c.mesh_upload_soa(100 + s_, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
-            o = (c.malloc(nv * 12 + 64), c.malloc(nv * 12 + 64), c.malloc(nv * 16 + 64))
+            o = tuple(c.malloc_streams([nv * 12 + 64, nv * 12 + 64, nv * 16 + 64]))
             calls.append(partial(fn, c._h, ctypes.c_uint64(100 + s_), ctypes.c_void_p(d_pal.ptr), ctypes.c_uint32(nb), ctypes.c_uint32(1),
                                  ctypes.c_void_p(o[0].ptr), ctypes.c_void_p(o[1].ptr), ctypes.c_void_p(o[2].ptr)))
             if g == 0 and s_ == 0:
@@ -1284,14 +1302,14 @@ def main_one_process(args, reason: str) -> None:
         # strong: this GPU's shard of the ONE mesh, written in place into full-size buffers (ragged cut) / padded buffers (equal cut)
         b, e = sharding.vertex_range_native(nv, g, n)
         c.mesh_upload_soa(200, mesh.pos[b:e], mesh.weights[b:e], mesh.indices[b:e], mesh.normal[b:e], mesh.tangent[b:e])
-        full = (c.malloc(nv * 12 + 64), c.malloc(nv * 12 + 64), c.malloc(nv * 16 + 64))
+        full = tuple(c.malloc_streams([nv * 12 + 64, nv * 12 + 64, nv * 16 + 64]))
         strong_bufs.append(full)
         strong_calls.append(partial(fn, c._h, ctypes.c_uint64(200), ctypes.c_void_p(d_pal.ptr), ctypes.c_uint32(nb), ctypes.c_uint32(1),
                                     ctypes.c_void_p(full[0].ptr + 12 * b), ctypes.c_void_p(full[1].ptr + 12 * b), ctypes.c_void_p(full[2].ptr + 16 * b))
                             if e > b else (lambda: 0))
         b2, e2, _ = sharding.vertex_range_padded(nv, g, n)
         c.mesh_upload_soa(201, mesh.pos[b2:e2], mesh.weights[b2:e2], mesh.indices[b2:e2], mesh.normal[b2:e2], mesh.tangent[b2:e2])
-        fullp = (c.malloc(n * shard_p * 12 + 64), c.malloc(n * shard_p * 12 + 64), c.malloc(n * shard_p * 16 + 64))
+        fullp = tuple(c.malloc_streams([n * shard_p * 12 + 64, n * shard_p * 12 + 64, n * shard_p * 16 + 64]))
         strong_bufs_padded.append(fullp)
         strong_calls_padded.append(partial(fn, c._h, ctypes.c_uint64(201), ctypes.c_void_p(d_pal.ptr), ctypes.c_uint32(nb), ctypes.c_uint32(1),
                                            ctypes.c_void_p(fullp[0].ptr + 12 * b2), ctypes.c_void_p(fullp[1].ptr + 12 * b2), ctypes.c_void_p(fullp[2].ptr + 16 * b2))
@@ -1581,9 +1599,7 @@ def main():
     outs = []
     for s in range(args.sets):
         ctx.mesh_upload_soa(s, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
-        outs.append((torch.empty(nv * 3 + 16, dtype=torch.float32, device="cuda"),
-                     torch.empty(nv * 3 + 16, dtype=torch.float32, device="cuda"),
-                     torch.empty(nv * 4 + 16, dtype=torch.float32, device="cuda")))
+        outs.append(output_streams(ctx, nv))       # every output stream its own allocation, made by the library: the same on every box
     # One foreign call per step with the ctypes arguments converted once: ~1 us of Python per launch.
     calls = [partial(fn, ctx._h, ctypes.c_uint64(s), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones),
                      ctypes.c_uint32(1), ctypes.c_void_p(o[0].data_ptr()), ctypes.c_void_p(o[1].data_ptr()),
@@ -1637,7 +1653,7 @@ def main():
     if rank == 0 and world == 1:
         held = []
         for rep in range(3):
-            fresh = [(ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)) for _ in range(n_sets)]
+            fresh = [tuple(ctx.malloc_streams([nv * 12 + 64, nv * 12 + 64, nv * 16 + 64])) for _ in range(n_sets)]
             held.append(fresh)
             fcalls = [partial(fn, ctx._h, ctypes.c_uint64(s_), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
                               ctypes.c_void_p(o[0].ptr), ctypes.c_void_p(o[1].ptr), ctypes.c_void_p(o[2].ptr)) for s_, o in enumerate(fresh)]
@@ -1667,7 +1683,7 @@ def main():
             extra_outs, more = [], list(calls)
             for s_ in range(n_sets, 16):
                 ctx.mesh_upload_soa(5000 + s_, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
-                o = (ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64))
+                o = tuple(ctx.malloc_streams([nv * 12 + 64, nv * 12 + 64, nv * 16 + 64]))
                 extra_outs.append(o)
                 more.append(partial(fn, ctx._h, ctypes.c_uint64(5000 + s_), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
                                     ctypes.c_void_p(o[0].ptr), ctypes.c_void_p(o[1].ptr), ctypes.c_void_p(o[2].ptr)))
@@ -1797,9 +1813,9 @@ def main():
         alls = []
         for s in range(sets2):
             ctx.mesh_upload_soa(100 + s, full.pos[b:e], full.weights[b:e], full.indices[b:e], full.normal[b:e], full.tangent[b:e])
-            alls.append((torch.zeros(full.n_verts * 3 + 16, dtype=torch.float32, device="cuda"),
-                         torch.zeros(full.n_verts * 3 + 16, dtype=torch.float32, device="cuda"),
-                         torch.zeros(full.n_verts * 4 + 16, dtype=torch.float32, device="cuda")))
+            alls.append(output_streams(ctx, full.n_verts))
+            for o_ in alls[-1]:
+                zero(ctx, o_)
         scalls = [partial(fn, ctx._h, ctypes.c_uint64(100 + s), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones),
                           ctypes.c_uint32(1), ctypes.c_void_p(o[0].data_ptr() + 12 * b), ctypes.c_void_p(o[1].data_ptr() + 12 * b),
                           ctypes.c_void_p(o[2].data_ptr() + 16 * b)) for s, o in enumerate(alls)]
@@ -1811,8 +1827,9 @@ def main():
         alls2, scalls2, gcalls2 = [], [], []
         for s_ in range(sets2):
             ctx.mesh_upload_soa(150 + s_, full.pos[b2:e2], full.weights[b2:e2], full.indices[b2:e2], full.normal[b2:e2], full.tangent[b2:e2])
-            o = (torch.zeros(world * shard2 * 3 + 16, dtype=torch.float32, device="cuda"), torch.zeros(world * shard2 * 3 + 16, dtype=torch.float32, device="cuda"),
-                 torch.zeros(world * shard2 * 4 + 16, dtype=torch.float32, device="cuda"))
+            o = output_streams(ctx, world * shard2)
+            for o_ in o:
+                zero(ctx, o_)
             alls2.append(o)
             scalls2.append(partial(fn, ctx._h, ctypes.c_uint64(150 + s_), ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
                                    ctypes.c_void_p(o[0].data_ptr() + 12 * b2), ctypes.c_void_p(o[1].data_ptr() + 12 * b2), ctypes.c_void_p(o[2].data_ptr() + 16 * b2)))
@@ -1928,8 +1945,8 @@ def main():
                          "kernel": kname, "kernel_us": kernel_us,
                          "kernel_us_min": float(np.min(alloc_us)), "kernel_us_median": float(np.median(alloc_us)), "kernel_us_max": float(np.max(alloc_us)),
                          "kernel_us_per_allocation": alloc_us,
-                         "allocations_note": f"{len(alloc_us)} allocations of the {args.sets} output sets in this process (the first through torch, the others "
-                                             "through fyx_malloc), each the average of the per-dispatch durations of a few hundred launches; "
+                         "allocations_note": f"{len(alloc_us)} allocations of the {args.sets} output sets in this process (all through fyx_malloc_streams: one "
+                                             "device allocation per output stream), each the average of the per-dispatch durations of a few hundred launches; "
                                              "kernel_us and frac are the MEDIAN",
                          "kernel_us_note": "launches serialized on one stream, each with its own start / stop HIP events (hipExtLaunchKernel: the "
                                            f"dispatch's timestamps, what rocprofv3 --kernel-trace reports per dispatch); average of {n_ser} launches",

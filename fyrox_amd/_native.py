@@ -79,6 +79,7 @@ _SIGS = {
     "fyx_debug_timeline": (c_int, [_P, _P, _P, _P, c_uint32, POINTER(c_uint32)]),
     "fyx_malloc": (c_int, [_P, c_size_t, POINTER(c_void_p)]),
     "fyx_free": (c_int, [_P, _P]),
+    "fyx_malloc_streams": (c_int, [_P, c_uint32, _P, _P]),
     "fyx_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
     "fyx_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
     "fyx_mesh_upload": (c_int, [_P, c_uint64, _P, c_uint32, c_uint32, c_int, c_int, c_int, c_int, c_int]),

@@ -26,9 +26,12 @@ def _f32(a, shape=None) -> np.ndarray:
 class DeviceBuffer:
     """A raw HBM allocation owned by a Context (fyx_malloc / fyx_free)."""
 
-    def __init__(self, ctx: "Context", nbytes: int):
+    def __init__(self, ctx: "Context", nbytes: int, ptr: int | None = None):
         self.ctx = ctx
         self.nbytes = int(nbytes)
+        if ptr is not None:      # (an allocation made elsewhere: fyx_malloc_streams)
+            self.ptr = ptr
+            return
         p = c_void_p()
         ctx._check(ctx._l.fyx_malloc(ctx._h, self.nbytes, byref(p)))
         self.ptr = p.value or 0
@@ -137,6 +140,10 @@ class Context:
     def set_option(self, key: str, value: int) -> None:
         self._check(self._l.fyx_set_option(self._h, key.encode(), int(value)))
 
+    def last_error(self) -> str:
+        """fyx_last_error: the message of the last failure -- or warning (a one-launch frame that was run again)."""
+        return self._l.fyx_last_error(self._h).decode()
+
     def get_option(self, key: str) -> int:
         v = c_int()
         self._check(self._l.fyx_get_option(self._h, key.encode(), byref(v)))
@@ -151,6 +158,15 @@ class Context:
 
     def malloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def malloc_streams(self, sizes) -> list:
+        """fyx_malloc_streams: one device allocation PER output stream (never ranges of one block: include/fyrox_hip.h)."""
+        import ctypes
+        n = len(sizes)
+        arr = (ctypes.c_size_t * n)(*[int(s) for s in sizes])
+        out = (c_void_p * n)()
+        self._check(self._l.fyx_malloc_streams(self._h, n, arr, out))
+        return [DeviceBuffer(self, int(s), out[i] or 0) for i, s in enumerate(sizes)]
 
     def free_ptr(self, ptr: int) -> None:
         self._check(self._l.fyx_free(self._h, ptr))

@@ -34,6 +34,28 @@
 
 using namespace fyx;
 
+// A one-launch frame reported a timed-out in-grid wait (check_device_error): everything in flight is waited for, then the latest frame of
+// the animator -- of the whole scene, if that is how it was last updated -- runs again on the frame stream it ran on (palette pairs: the
+// same buffer), as separate launches (the caller has switched anim.one_launch off), and is waited for.  The host control plane is not run
+// again: clocks, programs and events are the planned frame's.  Pose records, hints and transforms take the same values twice.
+int fyx::reissue_frame(fyx_ctx* c, uint64_t tag) {
+    auto it = store(c).animators.find(tag);
+    if (it == store(c).animators.end()) return FYX_OK;      // (freed since: nothing of it is left to be wrong)
+    Animator& A = *it->second;
+    if (A.last_frame_kind == 0) return FYX_OK;
+    if (int rc = sync_all(c)) return rc;
+    if (c->alt_stream) FYX_HIP(c, hipStreamSynchronize(c->alt_stream));
+    if (c->pose_overlap) c->frame_idx ^= 1;      // enter_pose toggles it back: the frame's own stream and palette buffers
+    SceneBatch& S = store(c).scene;
+    const bool in_scene = A.last_frame_kind == 3 && S.members_gen == store(c).animators_gen &&
+                          std::find(S.animators.begin(), S.animators.end(), &A) != S.animators.end();
+    const int rc = in_scene ? scene_frame(c, S, 0.0f, true) : run_frame(c, A, A.last_frame_kind != 2);
+    if (rc) return rc;
+    if (int rc2 = sync_all(c)) return rc2;
+    if (c->alt_stream) FYX_HIP(c, hipStreamSynchronize(c->alt_stream));
+    return FYX_OK;
+}
+
 extern "C" {
 
 int fyx_init_control_only(fyx_ctx** out_ctx) {
@@ -1133,7 +1155,7 @@ int fyx_animator_current_palette(fyx_ctx* c, uint64_t animator_id, uint64_t bone
     FYX_ANIMATOR_RO(c, A, animator_id);
     for (const Animator::PaletteOut& p : A->palette_outputs)
         if (p.bones_id == bones_id) {
-            *d_palette = palette_of(c, p);
+            *d_palette = palette_last_written(*A, p);
             return FYX_OK;
         }
     return fail(c, FYX_ERR_INVALID_ARG, "bone list %llu is not a palette output of animator %llu", (unsigned long long)bones_id, (unsigned long long)animator_id);

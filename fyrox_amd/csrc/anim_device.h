@@ -371,6 +371,11 @@ void ctrl_bind(const Animator& A, const CtrlLayout& L, const char* d, PoseFrameD
 inline float* palette_of(const fyx_ctx* c, const Animator::PaletteOut& po) {
     return (po.d_out_alt && c->pose_overlap && c->frame_idx) ? po.d_out_alt : po.d_out;
 }
+// ... and the buffer the animator's most recent frame wrote, whatever frames of OTHER animators have started since
+// (fyx_animator_current_palette).
+inline float* palette_last_written(const Animator& A, const Animator::PaletteOut& po) {
+    return (po.d_out_alt && A.last_frame_alt) ? po.d_out_alt : po.d_out;
+}
 
 // The rig's parameters plus the palettes the update kernel writes itself.
 int rig_params(fyx_ctx* c, const Animator& A, RigDev& rd) {
@@ -462,6 +467,8 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
             if (int rc = pose_behind_all_skinning(c, ps)) return rc;
     }
     if (int rc = ensure_device_state(c, A)) return rc;
+    A.last_frame_alt = (c->pose_overlap && c->frame_idx) ? 1 : 0;
+    A.last_frame_kind = with_program ? 1 : 2;
     PoseFrameDev f;
     frame_static(c, A, f);
     int slot = 0;
@@ -613,7 +620,8 @@ SceneJobShape scene_shape(const fyx_ctx* c, const Animator& A, uint32_t n_prop_s
     return sh;
 }
 
-int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
+// replay: the device side of the frame planned last, again (reissue_frame): the host control plane has run, its results are in the animators
+int scene_frame(fyx_ctx* c, SceneBatch& S, float dt, bool replay = false) {
     const size_t n = S.animators.size();
     // (option debug.host_times: the sections' cost to the calling thread, fyx_debug_host_times)
     using HostClock = std::chrono::steady_clock;
@@ -626,7 +634,8 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
         ht0 = t;
     };
     // 1. host control plane
-    if (int rc = scene_plan(c, S, dt)) return rc;
+    if (!replay)
+        if (int rc = scene_plan(c, S, dt)) return rc;
     host_section(0);
     // a scene of ONE animator is that animator's own frame: the control block in the kernel arguments, sampler + update (+ skinning) in
     // one launch where the animator qualifies -- 8.6 us for a character where the scene's stages (copy kernel, sampler, update) take ~19
@@ -636,6 +645,7 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt) {
     hipStream_t ps = nullptr;
     if (int rc = enter_pose(c, &ps)) return rc;
     const int par = c->pose_overlap ? c->frame_idx : 0;      // the frame's stream: its own resident job array
+    for (size_t k = 0; k < n; ++k) { S.animators[k]->last_frame_alt = par; S.animators[k]->last_frame_kind = 3; }
     // Has anything changed that the launch plans, the job array or the control block's layout are made from (SceneBatch::static_gen)?
     bool unchanged = S.static_gen != 0 && S.seen.size() == n && S.seen_members_epoch == S.members_epoch && S.seen_options_gen == c->options_gen &&
                      S.seen_mesh_gen == c->mesh_gen;

@@ -237,6 +237,12 @@ struct Animator {
         float* d_out_alt = nullptr;
     };
     std::vector<PaletteOut> palette_outputs;
+    // Which buffer of a palette pair the animator's MOST RECENT frame wrote (run_frame / scene_frame record it): 1 = the second.  The
+    // context's frame_idx answers that for the frame in progress only -- every pose entry toggles it, other animators' updates included.
+    int last_frame_alt = 0;
+    // ... and how that frame was issued: 0 none yet, 1 run_frame with the planned programs, 2 run_frame without (update_transforms),
+    // 3 as a member of the scene (reissue_frame runs it again the same way, minus the in-grid waits)
+    int last_frame_kind = 0;
     // meshes every update of the animator skins itself (fyx_animator_set_skin_output): with the palette of `bones_id` -- which is
     // one of palette_outputs -- as fyx_lbs_skin_device(mesh_id, that palette, n_bones, n_instances, outputs) right behind the update
     struct SkinOut { uint64_t bones_id, mesh_id; float* d_pos; float* d_nrm; float* d_tan; };

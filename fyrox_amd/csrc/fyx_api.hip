@@ -19,7 +19,7 @@ static unsigned order_event_flags() {
 
 int fail(fyx_ctx* c, int code, const char* fmt, ...) {
     if (c) {
-        char buf[512];
+        char buf[1024];
         va_list ap;
         va_start(ap, fmt);
         vsnprintf(buf, sizeof buf, fmt, ap);
@@ -79,16 +79,28 @@ int check_device_error(fyx_ctx* c) {
     fyx::DeviceError* e = c->dev_err;
     if (!e || __atomic_load_n(&e->code, __ATOMIC_ACQUIRE) == 0) return FYX_OK;
     const fyx::DeviceError r = *e;
-    memset(e, 0, sizeof *e);
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    // Only the code is taken back, with an exchange: kernels of later frames may be writing a report of their own right now (theirs
+    // then stays for the next check instead of being zeroed half-written).
+    __atomic_exchange_n(&e->code, 0u, __ATOMIC_SEQ_CST);
     if (r.code == fyx::kDevErrFrameWait) {
-        c->one_launch = 0;
-        return fail(c, FYX_ERR_HIP,
-                    "one-launch frame of animator %llu: workgroup %u waited %d ms for the frame's sampler workgroups (counter %u, target %u) and gave up; "
-                    "that frame computed NOTHING (poses, palettes and skin outputs are the previous frame's).  The one-launch form relies on the "
-                    "sampler workgroups of a grid being dispatched before the workgroups that wait for them; anim.one_launch is now 0 for this "
-                    "context (sampler, update and skinning as separate launches, no in-grid wait)",
-                    (unsigned long long)r.tag, r.block, c->wait_timeout_ms, r.seen, r.target);
+        // The frame whose wait gave up computed NOTHING (no pose, no palette, no vertex: a frame is late or it is right) -- and the
+        // engine's chain never skips a frame (machine/mod.rs:344-382 -> mesh/mod.rs:781-793): the one-launch form is switched off for
+        // the context and the animator's latest frame is run again NOW as separate launches, which cannot wait for anything, and waited
+        // for.  The caller gets FYX_OK and correct outputs; what happened stays readable in fyx_last_error and in "debug.frames_reissued".
+        if (c->one_launch) { c->one_launch = 0; ++c->options_gen; }      // (cached scene plans are made from the options)
+        if (c->reissuing) return FYX_OK;      // (a second workgroup's report of the same frame, seen while that frame is being re-run)
+        c->reissuing = true;
+        const int rc = fyx::reissue_frame(c, r.tag);
+        c->reissuing = false;
+        if (rc) return rc;      // (fyx_last_error says what the re-run failed with)
+        ++c->frames_reissued;
+        fail(c, FYX_OK,
+             "warning: one-launch frame of animator %llu: workgroup %u waited %d ms for the frame's sampler workgroups (counter %u, target %u) and gave "
+             "up; that launch computed nothing and the frame was run AGAIN as separate launches (sampler, update, skinning; no in-grid wait): its "
+             "outputs are correct.  The one-launch form relies on the sampler workgroups of a grid being dispatched before the workgroups that wait "
+             "for them; anim.one_launch is now 0 for this context",
+             (unsigned long long)r.tag, r.block, c->wait_timeout_ms, r.seen, r.target);
+        return FYX_OK;
     }
     return fail(c, FYX_ERR_HIP, "a kernel reported error %u (workgroup %u)", r.code, r.block);
 }
@@ -904,6 +916,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd_lean")) return &c->lbs.crowd_lean;
     if (!strcmp(key, "lbs.timing")) return &c->timing;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
+    if (!strcmp(key, "lbs.dyn_map")) return &c->lbs.dyn_map;
     if (!strcmp(key, "comm.form")) return &c->comm_form;
     if (!strcmp(key, "anim.threads")) return &c->plan_threads;
     if (!strcmp(key, "anim.split")) return &c->plan_split;
@@ -921,6 +934,7 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "streams.pose_cus")) return &c->pose_cus;
     if (!strcmp(key, "debug.timeline")) return &c->timeline_on;
     if (!strcmp(key, "debug.host_times")) return &c->host_times_on;
+    if (!strcmp(key, "debug.frames_reissued")) return &c->frames_reissued;
     return nullptr;
 }
 
@@ -928,7 +942,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (!c) return FYX_ERR_INVALID_ARG;
     int* slot = option_slot(c, key);
     if (!slot) return fail(c, FYX_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
-    ++c->options_gen;
+    // (options_gen -- what cached scene plans are compared against -- moves where a value is accepted, below: a refused value changes nothing)
     if (slot == &c->n_workers) {
         if (value < 1 || value > fyx_ctx::kMaxWorkers)
             return fail(c, FYX_ERR_INVALID_ARG, "lbs.streams must be 1..%d", fyx_ctx::kMaxWorkers);
@@ -957,6 +971,7 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->frame_skin_units && (value < 0 || value > 64)) return fail(c, FYX_ERR_INVALID_ARG, "anim.frame_skin_units must be 0 (auto) .. 64");
     if (slot == &c->wait_timeout_ms && (value < 1 || value > 30000)) return fail(c, FYX_ERR_INVALID_ARG, "anim.wait_timeout_ms must be 1..30000");
     if (slot == &c->upd_pack && value != 0 && value != 2 && value != 4) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_pack must be 0, 2 or 4");
+    ++c->options_gen;
     if ((slot == &c->stream_priority || slot == &c->pose_cus) && *slot != value) {
         const int old = *slot;
         *slot = value;
@@ -993,6 +1008,26 @@ int fyx_malloc(fyx_ctx* c, size_t bytes, void** out) {
     if (bytes == 0) return FYX_OK;
     if (int rc = bind_device(c)) return rc;
     FYX_HIP(c, hipMalloc(out, bytes));
+    return FYX_OK;
+}
+
+int fyx_malloc_streams(fyx_ctx* c, uint32_t n, const size_t* bytes, void** out) {
+    if (!c) return FYX_ERR_INVALID_ARG;
+    if (n && (!bytes || !out)) return fail(c, FYX_ERR_INVALID_ARG, "fyx_malloc_streams: null array");
+    for (uint32_t i = 0; i < n; ++i) out[i] = nullptr;
+    if (int rc = bind_device(c)) return rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (bytes[i] == 0) continue;
+        const hipError_t e = hipMalloc(&out[i], bytes[i]);      // one allocation per stream: the point of the call
+        if (e != hipSuccess) {
+            for (uint32_t k = 0; k < i; ++k) {
+                if (out[k]) (void)hipFree(out[k]);
+                out[k] = nullptr;
+            }
+            out[i] = nullptr;
+            return fail(c, e == hipErrorOutOfMemory ? FYX_ERR_OOM : FYX_ERR_HIP, "fyx_malloc_streams: stream %u of %u (%zu bytes): %s", i, n, bytes[i], hipGetErrorString(e));
+        }
+    }
     return FYX_OK;
 }
 

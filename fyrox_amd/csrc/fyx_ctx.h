@@ -134,6 +134,8 @@ struct fyx_ctx {
                                 //   allows); 0 = the smallest depth that gives every skinning workgroup a CU of its own (kFrameSkinAutoBlocks)
     int wait_timeout_ms = 500;  // option "anim.wait_timeout_ms": how long an in-grid wait of the one-launch frame lasts before it reports
     fyx::DeviceError* dev_err = nullptr;   // pinned, host-coherent: what a kernel that gave up wrote (check_device_error)
+    bool reissuing = false;                // check_device_error is re-running a frame whose in-grid wait gave up (no second report is acted on meanwhile)
+    int frames_reissued = 0;               // how many frames that has happened to (fyx_get_option "debug.frames_reissued")
     int upd_pack = 4;        // option "anim.update_pack": 0, 2 or 4 instances of a small rig (<= 64 nodes) per workgroup of a crowd's update launch
     int upd_lean = 1;        // option "anim.update_lean": 1 = frames whose fold programs are all straight run the update kernel without the interpreter
     int plan_split = 2048;   // option "anim.split": instances per planning task
@@ -172,6 +174,9 @@ int ensure_scratch(fyx_ctx* c, size_t bytes);
 // What kernels reported since the last look (fyx_ctx::dev_err): FYX_OK, or FYX_ERR_HIP with the report as the context's message;
 // the block is cleared and the one-launch frame switched off for the context (anim.one_launch = 0: the multi-launch path has no in-grid wait).
 int check_device_error(fyx_ctx* c);
+// The latest frame of the animator `tag` names (or of the scene it was last updated in), run again as separate launches -- no in-grid
+// wait -- and waited for: what check_device_error does about a one-launch frame that reported a timed-out wait (anim_api.hip).
+int reissue_frame(fyx_ctx* c, uint64_t tag);
 // Kernel arguments of a skinning launch of a registered mesh, validated as fyx_lbs_skin_device validates them.
 int skin_args_of(fyx_ctx* c, uint64_t mesh_id, const float* d_palette, uint32_t n_bones, uint32_t n_instances,
                  float* d_out_pos, float* d_out_normal, float* d_out_tangent, fyx::LbsArgs* out);

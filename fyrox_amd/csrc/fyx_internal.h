@@ -16,6 +16,7 @@ struct LbsTuning {
     int crowd_lean = 0;      // 1: register-lean crowd kernel at two workgroups per CU (leaves room for other kernels' waves, see lbs_kernels.hip)
     int crowd_ipb = 0;       // instances per workgroup run; 0 = auto
     int dyn = 1;             // large single-instance launches: 1 = lbs_skin_dyn (units drawn from an LDS ticket counter), 0 = lbs_skin
+    int dyn_map = 0;         // lbs_skin_dyn's workgroup -> unit range map: 0 = blockIdx order, 1 = one contiguous eighth of the mesh per XCD
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // option lbs.timing: this launch's own start / stop events (dispatch timestamps)
 };
 

@@ -118,10 +118,11 @@ int fyx_join(fyx_ctx* ctx);
  *                        MI355X (then no order of dispatch can starve a sampler); beside other kernels it relies on the
  *                        dispatcher handing out a grid's workgroups in index order (samplers first), which gfx9 hardware does
  *                        and HIP does not promise.  A wait is therefore BOUNDED ("anim.wait_timeout_ms"): a workgroup that
- *                        gives up writes a report, the frame computes NOTHING (poses, palettes and skin outputs keep the
- *                        previous frame's values -- never a frame made of stale records), the next fyx_sync or pose update
- *                        returns FYX_ERR_HIP with the animator, the counter and its target in fyx_last_error, and the context
- *                        sets "anim.one_launch" = 0 for itself (separate launches, no in-grid wait).
+ *                        gives up writes a report and that launch computes NOTHING (never a frame made of stale records).  The next
+ *                        fyx_sync or pose update sees the report, sets "anim.one_launch" = 0 for the context (separate launches, no
+ *                        in-grid wait) and RUNS THE FRAME AGAIN that way before it returns: no frame is lost, the call returns
+ *                        FYX_OK, fyx_last_error holds a warning naming the animator, the counter and its target, and
+ *                        fyx_get_option("debug.frames_reissued") counts such frames (fyx_get_option("anim.one_launch") reads 0).
  *     "anim.frame_skin"  1 (default) = a one-launch frame also holds the workgroups that skin the animator's skin outputs
  *                        (fyx_animator_set_skin_output), and the update stage of a SMALL scene (fyx_scene_update, up to ~260 k skinned
  *                        vertices) those of its animators; 0 = the update call issues the skinning launches behind the pose launch(es);
@@ -186,6 +187,12 @@ int fyx_timer_end(fyx_ctx* ctx, float* out_ms);
 /* ---- device memory (for callers without their own HIP allocator) ---------------------- */
 int fyx_malloc(fyx_ctx* ctx, size_t bytes, void** out_device_ptr);
 int fyx_free(fyx_ctx* ctx, void* device_ptr);
+/* The OUTPUT streams of skinning launches (position / normal / tangent of every buffer set a renderer rotates through), allocated the way
+ * that measured fastest: `n` allocations of `bytes[i]` bytes, EACH ONE ITS OWN device allocation -- never ranges carved out of one block
+ * (C3's three output streams inside one 499 MB block: 77 - 80 us per launch at every spacing tried, as three allocations 61 - 63 us;
+ * profiles/r05_placement_pool/).  out_device_ptrs[i] = NULL for bytes[i] = 0; on failure nothing stays allocated.  Free each with
+ * fyx_free.  (The reference allocates a mesh's buffers one by one too: scene/mesh/buffer.rs:404-415.) */
+int fyx_malloc_streams(fyx_ctx* ctx, uint32_t n, const size_t* bytes, void** out_device_ptrs);
 int fyx_memcpy_h2d(fyx_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
 int fyx_memcpy_d2h(fyx_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
 

@@ -232,11 +232,12 @@ def test_skin_output_arguments_are_checked(ctx):
         d_out.free()
 
 
-def test_a_wait_that_cannot_be_satisfied_is_an_error_not_a_stale_frame(ctx, orc):
+def test_a_wait_that_cannot_be_satisfied_costs_no_frame(ctx, orc):
     """The device counter of the one-launch frame poisoned from outside (fyx_debug_frame_counter_add): the frame's update and skinning
-    workgroups give up after anim.wait_timeout_ms, compute NOTHING (palette and vertices keep the previous frame's values, which is
-    what the error says), the next call returns FYX_ERR_HIP naming the escape hatch, the context falls back to separate launches
-    and goes on bit-exact; with the counter repaired the one-launch form works again."""
+    workgroups give up after anim.wait_timeout_ms and compute NOTHING; the next fyx_sync sees their report, switches the context to
+    separate launches and runs THAT frame again (the engine's chain never skips a frame) -- it returns FYX_OK, the
+    palette and the vertices are the poisoned frame's own, bit for bit against the oracle, and fyx_last_error / debug.frames_reissued say
+    what happened; the context goes on bit-exact, and with the counter repaired the one-launch form works again."""
     sc = cases.c5_blend_tree(euler_every=10 ** 6)
     nb = sc.rig.n_nodes
     o = cases.build_oracle(orc, sc)
@@ -259,16 +260,19 @@ def test_a_wait_that_cannot_be_satisfied_is_an_error_not_a_stale_frame(ctx, orc)
         l = _native.lib()
         assert l.fyx_debug_frame_counter_add(ctx._h, p.id, -100000) == 0
         _oupdate(o, sc)
+        reissued = ctx.get_option("debug.frames_reissued")
         _update(p, sc)                       # the launch is issued; its workgroups will give up
-        with pytest.raises(fyrox_amd.FyxError) as e:
-            ctx.sync()
-        assert e.value.code == _native.FYX_ERR_HIP
-        msg = str(e.value)
-        assert "anim.one_launch" in msg and "NOTHING" in msg and str(p.id) in msg, msg
-        assert ctx.get_option("anim.one_launch") == 0
-        assert np.array_equal(d_pal.download(np.uint32, nb * 16), pal_before), "a frame that gave up must not write a palette"
-        assert np.array_equal(outs.pos.download(np.uint32, 4000 * 3), pos_before), "... nor vertices"
-        # the host side is one frame ahead of the device now (as after any HIP error inside an update); separate launches from here on
+        ctx.sync()                           # ... and the frame is run again as separate launches, inside this call
+        msg = ctx.last_error()
+        assert msg.startswith("warning") and "anim.one_launch" in msg and "AGAIN" in msg and str(p.id) in msg, msg
+        assert ctx.get_option("anim.one_launch") == 0 and ctx.get_option("debug.frames_reissued") == reissued + 1
+        ref_pal = o.palette(list(range(nb)))                  # the poisoned frame's own palette and vertices
+        assert not np.array_equal(ref_pal.view(np.uint32).reshape(-1), pal_before)
+        assert np.array_equal(d_pal.download(np.float32, nb * 16).reshape(nb, 16).view(np.uint32), ref_pal.view(np.uint32)), "the re-issued frame's palette"
+        ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, ref_pal, mesh.normal, mesh.tangent)
+        assert not np.array_equal(ref["pos"].view(np.uint32).reshape(-1), pos_before)
+        assert np.array_equal(outs.pos.download(np.float32, 4000 * 3).reshape(-1, 3).view(np.uint32), ref["pos"].view(np.uint32)), "... and its vertices"
+        # separate launches from here on
         for f in range(3):
             _oupdate(o, sc)
             _update(p, sc)
@@ -445,17 +449,24 @@ def test_a_scene_frame_in_one_launch_over_many_frames_and_its_timeout(ctx, orc):
                     for x, y in zip(oa.get(), ob.get()):
                         assert np.array_equal(x, y), f"frame {f}: vertices"
         ctx.sync()
-        # a counter poisoned from outside: that frame reports; the poisoned character's outputs are untouched
+        # a counter poisoned from outside: that frame reports, and the whole scene's frame is run again stage by stage inside fyx_sync --
+        # the poisoned character's outputs are THIS frame's, equal to the other set's (same scene, separate launches)
         victim = sets[0][5]
         before = victim[2].pos.download(np.uint32, nv * 3)
         assert _native.lib().fyx_debug_frame_counter_add(ctx._h, victim[0].id, -100000) == 0
         ctx.set_option("anim.frame_skin", 3)
         A.scene_update(ctx, [c_[0] for c_ in sets[0]], sc.dt)
-        with pytest.raises(fyrox_amd.FyxError) as e:
-            ctx.sync()
-        assert e.value.code == _native.FYX_ERR_HIP and str(victim[0].id) in str(e.value)
-        assert np.array_equal(victim[2].pos.download(np.uint32, nv * 3), before)
+        ctx.sync()
+        assert ctx.last_error().startswith("warning") and str(victim[0].id) in ctx.last_error()
         assert ctx.get_option("anim.one_launch") == 0
+        ctx.set_option("anim.frame_skin", 0)
+        A.scene_update(ctx, [c_[0] for c_ in sets[1]], sc.dt)
+        ctx.sync()
+        for (pa, da, oa), (pb, db, ob) in zip(sets[0], sets[1]):
+            assert np.array_equal(da.download(np.uint32, nb * 16), db.download(np.uint32, nb * 16)), "palette of the re-issued scene frame"
+            for x, y in zip(oa.get(), ob.get()):
+                assert np.array_equal(x, y), "vertices of the re-issued scene frame"
+        assert not np.array_equal(victim[2].pos.download(np.uint32, nv * 3), before)
         assert _native.lib().fyx_debug_frame_counter_add(ctx._h, victim[0].id, 100000) == 0
         A.scene_update(ctx, [c_[0] for c_ in sets[0]], sc.dt)       # stage by stage now (anim.one_launch = 0)
         ctx.sync()
@@ -648,3 +659,55 @@ def test_steady_scene_frames_keep_their_plans_and_follow_every_change(ctx, orc, 
                 ch["out"].free()
                 ch["ref"].free()
                 ctx.mesh_free(ch["mid"])
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["streams_by_frame", "streams_by_kind"])
+def test_current_palette_is_the_animators_own_last_frame_whatever_other_animators_did_since(ctx, orc, mode):
+    """fyx_animator_current_palette answered from the CONTEXT's frame index, which every pose entry toggles.  Two animators
+    updated one after the other each frame (A then B) under anim.overlap: asked AFTER B's update, A's current palette must still be the
+    buffer A's update wrote -- and a caller that skins A from it gets this frame's vertices, every frame, against the oracle."""
+    sa, sb = cases.c5_blend_tree(euler_every=10 ** 6), cases.player_only(euler_every=10 ** 6)
+    chars = []
+    for sc, nv in ((sa, 5000), (sb, 3000)):
+        p = cases.build_product(ctx, sc, 1)
+        nb, base = sc.rig.n_nodes, p.base_id
+        A.create_bone_list(ctx, base + 50, base, list(range(nb)))
+        pals = [ctx.malloc(nb * 64) for _ in range(2)]
+        for b in pals:
+            b.upload(np.full(nb * 16, np.nan, np.float32))
+        p.set_palette_output_pair(base + 50, pals[0].ptr, pals[1].ptr)
+        mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + 43)
+        ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+        chars.append({"sc": sc, "p": p, "nb": nb, "pals": pals, "mesh": mesh, "mid": base + 60, "out": Outs(ctx, nv), "o": cases.build_oracle(orc, sc), "wrote": []})
+    ctx.set_option("anim.overlap", mode)
+    try:
+        for f in range(9):
+            for ch in chars:
+                _update(ch["p"], ch["sc"])
+                ch["wrote"].append(ch["p"].current_palette(ch["p"].base_id + 50))      # right behind its own update
+                _oupdate(ch["o"], ch["sc"])
+            for ch in chars:      # ... and after the OTHER animator's update: the same buffer, holding this frame's palette
+                cur = ch["p"].current_palette(ch["p"].base_id + 50)
+                assert cur == ch["wrote"][-1], f"frame {f}: {ch['sc'].name}'s current palette moved when another animator was updated"
+                assert cur in (ch["pals"][0].ptr, ch["pals"][1].ptr)
+                ctx.lbs_skin_device(ch["mid"], cur, ch["nb"], 1, ch["out"].pos.ptr, ch["out"].nrm.ptr, ch["out"].tan.ptr)
+            ctx.sync()
+            for ch in chars:
+                m, ref_pal = ch["mesh"], ch["o"].palette(list(range(ch["nb"])))
+                which = 0 if ch["wrote"][-1] == ch["pals"][0].ptr else 1
+                assert np.array_equal(ch["pals"][which].download(np.uint32, ch["nb"] * 16), ref_pal.view(np.uint32).reshape(-1)), f"frame {f}: palette of {ch['sc'].name}"
+                ref = orc.lbs_skin(m.pos, m.weights, m.indices, ref_pal, m.normal, m.tangent)
+                got = ch["out"].get()
+                for s, k in enumerate(("pos", "normal", "tangent")):
+                    assert np.array_equal(got[s], np.ascontiguousarray(ref[k]).view(np.uint32).reshape(-1)), f"frame {f}: {ch['sc'].name} {k}"
+        # the two animators' frames alternate streams, so each animator's own frames all ran on ONE stream: one buffer of its pair
+        assert len(set(chars[0]["wrote"])) == 1 and len(set(chars[1]["wrote"])) == 1
+    finally:
+        ctx.set_option("anim.overlap", 0)
+        for ch in chars:
+            ch["p"].free()
+            ch["o"].close()
+            for b in ch["pals"]:
+                b.free()
+            ch["out"].free()
+            ctx.mesh_free(ch["mid"])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import fyrox_amd
-from fyrox_amd import synth
+from fyrox_amd import _native, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -1404,3 +1404,33 @@ def test_lean_crowd_kernel_is_bit_identical(ctx, orc, n_verts, n_bones, n_inst, 
     for b in outs:
         b.free()
     d_pal.free(); ctx.mesh_free(9300)
+
+
+def test_output_streams_are_separate_allocations(ctx, orc):
+    """fyx_malloc_streams: the placement rule in code -- every output stream of a skinning launch is a device
+    allocation of its own.  The pointers are distinct allocations (each can be freed on its own), a zero-size stream is NULL, a
+    request that cannot be met leaves nothing behind, and a launch into the streams is the oracle's."""
+    n_verts, n_bones = 70_001, 64
+    bufs = ctx.malloc_streams([n_verts * 12 + 64, 0, n_verts * 16 + 64, n_verts * 12 + 64])
+    assert bufs[1].ptr == 0 and len({b.ptr for b in bufs if b.ptr}) == 3
+    m = synth.make_mesh(n_verts, n_bones, 4321)
+    pal = synth.make_palette(n_bones, 4321)
+    upload(ctx, 6, m)
+    d_pal = ctx.to_device(pal)
+    ctx.lbs_skin_device(6, d_pal.ptr, n_bones, 1, bufs[0].ptr, bufs[3].ptr, bufs[2].ptr)
+    ctx.sync()
+    ref = oracle_skin(orc, m, pal)
+    got = {"pos": bufs[0].download(np.float32, n_verts * 3).reshape(-1, 3), "normal": bufs[3].download(np.float32, n_verts * 3).reshape(-1, 3),
+           "tangent": bufs[2].download(np.float32, n_verts * 4).reshape(-1, 4)}
+    assert_bit_exact(got, ref)
+    bufs[0].free()          # one stream freed on its own: the others stay usable
+    ctx.lbs_skin_device(6, d_pal.ptr, n_bones, 1, 0, bufs[3].ptr, bufs[2].ptr)
+    ctx.sync()
+    assert np.array_equal(bufs[3].download(np.float32, n_verts * 3).reshape(-1, 3), ref["normal"])
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        ctx.malloc_streams([1 << 20, 1 << 50, 1 << 20])      # the second cannot be met: the first is released again, nothing is returned
+    assert e.value.code in (_native.FYX_ERR_OOM, _native.FYX_ERR_HIP)
+    for b in bufs[1:]:
+        b.free()
+    d_pal.free()
+    ctx.mesh_free(6)
