@@ -235,6 +235,11 @@ def compact_record(full: dict, full_path: str | None) -> dict:
                 "sets": cfg.get("sets"),
                 "frac_at_6_sets": _num(r.get("frac_at_6_sets")), "kernel_us_at_6_sets": _num(r.get("kernel_us_at_6_sets")),
                 "frac_at_1_set": _num(_dig(r, "by_number_of_rotating_sets", "1", "frac")),
+                "frac_at_16_sets": _num(_dig(r, "by_number_of_rotating_sets", "16", "frac")),
+                "frac_in16_out1": _num(_dig(r, "by_number_of_rotating_sets", "inputs_vs_outputs", "in16_out1", "frac")),
+                "frac_in16_out6": _num(_dig(r, "by_number_of_rotating_sets", "inputs_vs_outputs", "in16_out6", "frac")),
+                "frac_in16_out16": _num(_dig(r, "by_number_of_rotating_sets", "inputs_vs_outputs", "in16_out16", "frac")),
+                "frac_in1_out16": _num(_dig(r, "by_number_of_rotating_sets", "inputs_vs_outputs", "in1_out16", "frac")),
                 "kernel_us_min": _num(r.get("kernel_us_min")), "kernel_us_max": _num(r.get("kernel_us_max")),
                 "overlapped": {"frac": _num(_dig(r, "overlapped", "frac")), "avg_launch_us": _num(_dig(r, "overlapped", "avg_launch_us")),
                                "launch_streams": _dig(r, "overlapped", "launch_streams")},
@@ -546,36 +551,7 @@ def _chain_record(ctx, name, sc, mesh, n_instances, frames, desync, parity_insta
     del got_p
     for b in outs2:
         b.free()
-    # streams BY KIND (anim.overlap = 2): every pose kernel on the context stream, every skinning launch on the second stream, each in
-    # order -- frame n + 1's pose kernels run beside frame n's skinning, no queue waits for an event still to come, and ONE set of
-    # vertex outputs is enough; the palette pair as above
-    frame_by_kind_ms = None
-    if n_instances >= 4:
-        ctx.set_option("anim.overlap", 2)
-        p.set_palette_output_pair(base + 50, d_pal.ptr, d_pal2.ptr)
-
-        def frame_by_kind(k):
-            update(sc.dt)
-            ctx.lbs_skin_device(base + 60, pals[(k + 1) & 1].ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
-
-        for k in range(20):
-            frame_by_kind(k)
-            if p.current_palette(base + 50) != pals[(k + 1) & 1].ptr:
-                raise SystemExit(f"{name}: frame {k} of anim.overlap = 2 wrote the other palette buffer of the pair")
-        ctx.sync()
-        ctx.timer_begin()
-        for k in range(frames):
-            frame_by_kind(k)
-        frame_by_kind_ms = ctx.timer_end() / frames
-        ctx.set_option("anim.overlap", 0)
-        p.set_palette_output(base + 50, d_pal.ptr)
-        ctx.sync()
-        got_p = [b.download(np.uint32, nv * w) for b, w in zip((d_pos, d_nrm, d_tan), (3, 3, 4))]
-        ctx.lbs_skin_device(base + 60, pals[(20 + frames) & 1].ptr, nb, n_instances, d_pos.ptr, d_nrm.ptr, d_tan.ptr)
-        ctx.sync()
-        if not all(np.array_equal(x, b.download(np.uint32, nv * w)) for x, b, w in zip(got_p, (d_pos, d_nrm, d_tan), (3, 3, 4))):
-            raise SystemExit(f"{name}: the frames of anim.overlap = 2 left vertices that differ from a skinning launch on the palette the last one wrote")
-        del got_p
+    frame_by_kind_ms = None      # (the streams-by-kind mode is a debug option since round 6: it measured the one-stream time for crowds)
     # the same with the mesh registered as the animator's skin output: the update call is the frame, ONE set of vertex outputs, and the
     # library orders frame n + 1's skinning launch behind frame n's (its pose kernels still run beside frame n's skinning)
     frame_pipelined_registered_ms, registered_identical = None, None
@@ -1062,7 +1038,7 @@ def _scene_record(ctx, n_chars: int, n_inst: int, n_verts: int, id_base: int, fr
     try:
         pals2 = [ctx.malloc(n_inst * nb * 64) for _ in chars]
         frees += pals2
-        for mode in (1, 2):
+        for mode in (1,):      # (debug.overlap = 2, streams by kind, measured the same for scenes in round 5: no longer in the record)
             for (an, mid, d_pal, outs, *_), p2 in zip(chars, pals2):
                 an.set_palette_output_pair(an.bones_id, d_pal.ptr, p2.ptr)
                 an.set_skin_output(an.bones_id, mid, outs[0].ptr, outs[1].ptr, outs[2].ptr)
@@ -1702,6 +1678,27 @@ def main():
                 ctx.set_option("lbs.timing", 0)
                 by_sets[str(k)] = {"kernel_us": us / max(n, 1), "frac": BYTES_PER_VERTEX * nv / (us / max(n, 1) * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                    "footprint_MB": k * BYTES_PER_VERTEX * nv / 1e6}
+            # Inputs and outputs rotated SEPARATELY (round 6): what the launch pays for is the number of OUTPUT sets -- while they fit the
+            # 256 MiB Infinity Cache (<= 6 x 40 MB) the memory-side cache absorbs the launch's stores and HBM carries the 60 MB of reads
+            # alone; past it every store reaches HBM.  The number of input sets does not matter beyond 2 (profiles/r06_lone_launch/).
+            if len(more) >= 16:
+                all_in = [ctypes.c_uint64(s_) for s_ in range(n_sets)] + [ctypes.c_uint64(5000 + s_) for s_ in range(n_sets, 16)]
+                all_out = [tuple(ctypes.c_void_p(t_.data_ptr()) for t_ in o) for o in outs] + [tuple(ctypes.c_void_p(b_.ptr) for b_ in o) for o in extra_outs]
+
+                def split_case(n_in, n_out):
+                    cs = [partial(fn, ctx._h, all_in[i % n_in], ctypes.c_void_p(d_pal.data_ptr()), ctypes.c_uint32(args.bones), ctypes.c_uint32(1),
+                                  *all_out[i % n_out]) for i in range(16)]
+                    for i in range(48):
+                        cs[i % 16]()
+                    ctx.set_option("lbs.timing", 1)
+                    ctx.kernel_time()
+                    for i in range(608):
+                        cs[i % 16]()
+                    us_, n_ = ctx.kernel_time()
+                    ctx.set_option("lbs.timing", 0)
+                    k_ = us_ / max(n_, 1)
+                    return {"kernel_us": k_, "frac": BYTES_PER_VERTEX * nv / (k_ * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+                by_sets["inputs_vs_outputs"] = {f"in{i_}_out{o_}": split_case(i_, o_) for i_, o_ in ((16, 1), (16, 6), (16, 8), (16, 16), (1, 16), (1, 1))}
             for o in extra_outs:
                 for b_ in o:
                     b_.free()
@@ -1954,8 +1951,12 @@ def main():
                          "by_number_of_rotating_sets": by_sets,
                          "frac_at_6_sets": (by_sets or {}).get("6", {}).get("frac") if isinstance(by_sets, dict) else None,
                          "kernel_us_at_6_sets": (by_sets or {}).get("6", {}).get("kernel_us") if isinstance(by_sets, dict) else None,
-                         "by_number_of_rotating_sets_note": "the same lone launch rotating over the first k of up to 16 buffer sets of 100 MB (inputs AND outputs): the kernel's time "
-                                                            "depends on the footprint the rotation walks over; frac above is at --sets (default 8, as in every round); SURVEY 8(d) asks for >= 6",
+                         "by_number_of_rotating_sets_note": "the same lone launch rotating over the first k of up to 16 buffer sets of 100 MB (inputs AND outputs); inputs_vs_outputs "
+                                                            "rotates them separately: the time follows the number of OUTPUT sets -- up to 6 x 40 MB the 256 MiB Infinity Cache absorbs "
+                                                            "the stores and HBM carries the reads alone, from 12 sets on every byte is HBM's (frac_all_in_hbm); one set is what the chip's "
+                                                            "fabric moves at best (fabric_ceiling_frac).  frac above is at --sets (default 8, as in every round); SURVEY 8(d) asks for >= 6",
+                         "frac_all_in_hbm": (by_sets or {}).get("16", {}).get("frac") if isinstance(by_sets, dict) else None,
+                         "fabric_ceiling_frac": (by_sets or {}).get("1", {}).get("frac") if isinstance(by_sets, dict) else None,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "overlapped": {"avg_launch_us": launch_us, "achieved": BYTES_PER_VERTEX * per_rank_verts / (launch_us * 1e-6) / 1e9,
                                         "frac": BYTES_PER_VERTEX * per_rank_verts / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,

@@ -10,7 +10,7 @@
 use super::hip_sys::*; // bindings/rust/fyrox_hip_sys.rs
 use crate::core::algebra::{Matrix4, UnitQuaternion, Vector3};
 use crate::scene::mesh::buffer::{VertexAttributeUsage, VertexBuffer};
-use std::{ffi::CStr, ptr};
+use std::{ffi::c_void, ffi::CStr, ptr};
 
 /// `fyx_status` as a Rust error.  `BoneIndex` is the slice-index panic of `scene/mesh/mod.rs:514`,
 /// `MissingAttribute` is `VertexFetchError::NoSuchAttribute` (`scene/mesh/buffer.rs:1279`).
@@ -255,6 +255,35 @@ pub struct SkinnedVertices {
     pub normals: Vec<Vector3<f32>>,
     pub tangents: Vec<[f32; 4]>,
     pub aabb: [f32; 6],
+}
+
+/// Device-side output streams of one skinned surface (what `fyx_lbs_skin_device`, `fyx_lbs_skin_batch` and
+/// `fyx_animator_set_skin_output` write): position / normal / tangent of `n_verts * n_instances` vertices, EACH STREAM ITS OWN
+/// ALLOCATION (`fyx_malloc_streams`: ranges carved out of one block measured 77 - 80 us per crowd launch against 61 - 63,
+/// profiles/r05_placement_pool/).  A renderer that draws frame n while frame n + 1 is skinned keeps two of these per surface.
+pub struct DeviceSkinnedVertices {
+    ctx: *mut FyxCtx,
+    pub positions: *mut f32,
+    pub normals: *mut f32,
+    pub tangents: *mut f32,
+}
+
+impl DeviceSkinnedVertices {
+    pub fn new(hip: &mut HipSkinning, n_verts: u32, n_instances: u32) -> Result<Self, HipError> {
+        let n = n_verts as usize * n_instances as usize;
+        let bytes: [usize; 3] = [n * 12, n * 12, n * 16];
+        let mut ptrs: [*mut c_void; 3] = [std::ptr::null_mut(); 3];
+        check_rc(hip.ctx, unsafe { fyx_malloc_streams(hip.ctx, 3, bytes.as_ptr(), ptrs.as_mut_ptr()) })?;
+        Ok(Self { ctx: hip.ctx, positions: ptrs[0] as *mut f32, normals: ptrs[1] as *mut f32, tangents: ptrs[2] as *mut f32 })
+    }
+}
+
+impl Drop for DeviceSkinnedVertices {
+    fn drop(&mut self) {
+        for p in [self.positions, self.normals, self.tangents] {
+            unsafe { fyx_free(self.ctx, p as *mut c_void) };
+        }
+    }
 }
 
 /// N instances of one animated model: `AnimationPlayer` (`scene/animation/mod.rs:190-346`) and, optionally, the

@@ -25,6 +25,7 @@ ACTION_NONE, ACTION_REWIND, ACTION_ENABLE, ACTION_DISABLE, ACTION_ENABLE_RANDOM 
 LOGIC_PARAMETER, LOGIC_AND, LOGIC_OR, LOGIC_XOR, LOGIC_NOT, LOGIC_IS_ANIMATION_ENDED = range(6)
 ALL_INSTANCES = 0xFFFFFFFF
 READ_LOCAL_TRS, READ_LOCAL_MATRIX, READ_GLOBAL_MATRIX, READ_ANIMATION_POSE = 0, 1, 2, 16
+READ_ANIMATION_BLEND_VIEW = 65536      # + animation: what a blend reads of the animation's pose (include/fyrox_hip.h)
 OP_NAMES = ("END", "BLEND_ANIM", "PUSH", "POP_BLEND", "RESET", "MASK", "APPLY", "APPLY_ANIM")
 RM_OP_NAMES = ("END", "SET_ANIM", "BLEND", "COPY")
 EVENTS_ALL, EVENTS_MAX_WEIGHT, EVENTS_MIN_WEIGHT = range(3)

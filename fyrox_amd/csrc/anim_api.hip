@@ -95,10 +95,10 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
             return fail(c, FYX_ERR_INVALID_ARG, "track %u: binding %d", t, d.binding);
         const bool vec3 = d.kind == FYX_KIND_VEC3;
         const bool quat = d.kind == FYX_KIND_QUAT || d.kind == FYX_KIND_QUAT_EULER;
-        if ((d.binding == FYX_BIND_ROTATION && !quat) || (d.binding != FYX_BIND_ROTATION && !vec3))
-            return fail(c, FYX_ERR_UNSUPPORTED,
-                        "track %u: value kind %d cannot be applied to binding %d (the reference logs an error and skips it)",
-                        t, d.kind, d.binding);
+        // (a kind that its binding cannot take -- a Real track bound to Position -- is accepted as the reference accepts it: the value
+        // sits in its node's list, blends with nothing and is never applied: scene/animation/mod.rs:147-186, value.rs:221-230)
+        (void)vec3; (void)quat;
+        if (d.kind < FYX_KIND_REAL || d.kind > FYX_KIND_QUAT) return fail(c, FYX_ERR_INVALID_ARG, "track %u: value kind %d", t, d.kind);
         if (d.n_curves > 4) return fail(c, FYX_ERR_INVALID_ARG, "track %u has %u curves", t, d.n_curves);
         for (uint32_t k = 0; k < d.n_curves; ++k) total += d.curve_n_keys[k];
     }
@@ -438,6 +438,8 @@ int fyx_animator_add_animation(fyx_ctx* c, uint64_t animator_id, uint64_t tracks
     an.td = &td;
     an.target.assign(td.n_tracks, -1);
     an.enabled.assign(td.n_tracks, 1);
+    // Several tracks on one binding of one node, or a kind the binding cannot take: the node's pose is a list (pose.rs:107-121) and
+    // such an animation keeps two views of it (AnimationDef::dup, built with the device state from the ENABLED tracks).
     std::vector<uint8_t> used((size_t)A->rig->n_nodes * 3, 0);
     std::vector<std::pair<int32_t, int32_t>> new_slots = A->prop_slots, seen_props;
     for (uint32_t t = 0; t < td.n_tracks; ++t) {
@@ -447,13 +449,12 @@ int fyx_animator_add_animation(fyx_ctx* c, uint64_t animator_id, uint64_t tracks
             return fail(c, FYX_ERR_INVALID_ARG, "track %u targets node %d of a %u-node rig", t, track_target[t], A->rig->n_nodes);
         if (track_target[t] >= 0 && td.tracks[t].binding >= FYX_BIND_PROPERTY0) {
             const std::pair<int32_t, int32_t> key(track_target[t], td.tracks[t].binding - FYX_BIND_PROPERTY0);
-            if (std::find(seen_props.begin(), seen_props.end(), key) != seen_props.end())
-                return fail(c, FYX_ERR_UNSUPPORTED, "two tracks drive the same property of node %d", track_target[t]);
+            if (std::find(seen_props.begin(), seen_props.end(), key) != seen_props.end()) an.maybe_dup = true;
             seen_props.push_back(key);
             if (std::find(new_slots.begin(), new_slots.end(), key) == new_slots.end()) new_slots.push_back(key);
         } else if (track_target[t] >= 0) {
             uint8_t& u = used[(size_t)track_target[t] * 3 + td.tracks[t].binding];
-            if (u) return fail(c, FYX_ERR_UNSUPPORTED, "two tracks drive the same binding of node %d", track_target[t]);
+            if (u || !kind_fits(td.tracks[t].binding, td.tracks[t].kind)) an.maybe_dup = true;
             u = 1;
         }
     }
@@ -1281,8 +1282,15 @@ static int locate(fyx_ctx* c, Animator* A, int what, void** ptr, size_t* bytes) 
     if (what == FYX_READ_LOCAL_TRS) { *ptr = A->d_node_trs; *bytes = in * 48; return FYX_OK; }
     if (what == FYX_READ_LOCAL_MATRIX) { *ptr = A->d_local; *bytes = in * 64; return FYX_OK; }
     if (what == FYX_READ_GLOBAL_MATRIX) { *ptr = A->d_global; *bytes = in * 64; return FYX_OK; }
-    if (what >= FYX_READ_ANIMATION_POSE && (size_t)(what - FYX_READ_ANIMATION_POSE) < A->anims.size()) {
-        *ptr = reinterpret_cast<char*>(A->d_anim_pose) + (size_t)(what - FYX_READ_ANIMATION_POSE) * in * 48;
+    // (an animator that keeps two device animations per animation: 2 a holds what the pose applies, 2 a + 1 what a blend reads of it)
+    const size_t per_anim = A->shadows ? 2 : 1;
+    if (what >= FYX_READ_ANIMATION_POSE && what < FYX_READ_ANIMATION_BLEND_VIEW && (size_t)(what - FYX_READ_ANIMATION_POSE) < A->anims.size()) {
+        *ptr = reinterpret_cast<char*>(A->d_anim_pose) + (size_t)(what - FYX_READ_ANIMATION_POSE) * per_anim * in * 48;
+        *bytes = in * 48;
+        return FYX_OK;
+    }
+    if (what >= FYX_READ_ANIMATION_BLEND_VIEW && (size_t)(what - FYX_READ_ANIMATION_BLEND_VIEW) < A->anims.size()) {
+        *ptr = reinterpret_cast<char*>(A->d_anim_pose) + ((size_t)(what - FYX_READ_ANIMATION_BLEND_VIEW) * per_anim + (per_anim - 1)) * in * 48;
         *bytes = in * 48;
         return FYX_OK;
     }
@@ -1443,7 +1451,7 @@ int fyx_animation_read_root_motion(fyx_ctx* c, uint64_t animator_id, uint32_t an
     if (int rc = ensure_device_state(c, *A)) return rc;
     static_assert(sizeof(fyx_root_motion) == 32, "fyx_root_motion layout");
     // the first 32 bytes of a RootMotionDev are exactly a fyx_root_motion
-    FYX_HIP(c, hipMemcpy2DAsync(host_out, sizeof(fyx_root_motion), A->d_rm_anim + (size_t)animation * A->n_instances,
+    FYX_HIP(c, hipMemcpy2DAsync(host_out, sizeof(fyx_root_motion), A->d_rm_anim + (size_t)animation * (A->shadows ? 2 : 1) * A->n_instances,
                                 sizeof(RootMotionDev), sizeof(fyx_root_motion), A->n_instances, hipMemcpyDeviceToHost, c->stream));
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     for (uint32_t i = 0; i < A->n_instances; ++i)
@@ -1547,7 +1555,7 @@ int fyx_animator_read_properties(fyx_ctx* c, uint64_t animator_id, int32_t anima
     if (int rc = ensure_device_state(c, *A)) return rc;
     const size_t per = (size_t)A->n_instances * A->dev_prop_slots;
     static_assert(sizeof(fyx_property_value) == sizeof(PropRec), "same record on both sides of the boundary");
-    const PropRec* src = animation < 0 ? A->d_prop_out : A->d_prop_pose + (size_t)animation * per;
+    const PropRec* src = animation < 0 ? A->d_prop_out : A->d_prop_pose + (size_t)animation * (A->shadows ? 2 : 1) * per;
     FYX_HIP(c, hipMemcpyAsync(host_out, src, per * sizeof(PropRec), hipMemcpyDeviceToHost, c->stream));
     FYX_HIP(c, hipStreamSynchronize(c->stream));
     return FYX_OK;

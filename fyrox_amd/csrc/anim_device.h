@@ -18,6 +18,59 @@ struct DevGuard {
     void* release() { void* r = p; p = nullptr; return r; }
 };
 
+// Curves TrackDataContainer::fetch reads of a kind (container.rs:182-297): with fewer it answers None and the node's list gets no value.
+inline uint32_t kind_need(int kind) {
+    switch (kind) {
+        case FYX_KIND_REAL: return 1u;
+        case FYX_KIND_VEC2: return 2u;
+        case FYX_KIND_VEC3: case FYX_KIND_QUAT_EULER: return 3u;
+        default: return 4u;      // Vector4, UnitQuaternion
+    }
+}
+// BoundValueCollectionExt::apply's `if let` (scene/animation/mod.rs:147-186): the TrackValue variant a binding takes.
+inline bool kind_fits(int binding, int kind) {
+    return binding == FYX_BIND_ROTATION ? (kind == FYX_KIND_QUAT || kind == FYX_KIND_QUAT_EULER) : kind == FYX_KIND_VEC3;
+}
+
+// The two views of an animation's node lists (AnimationDef::slots / slots_f): Animation::update_pose pushes the enabled, bound tracks'
+// values in track order (lib.rs:895-914).
+void build_track_views(const Animator& A, AnimationDef& an, std::vector<int32_t>& ptrack_a, std::vector<int32_t>& ptrack_f) {
+    const uint32_t n_nodes = A.rig->n_nodes;
+    std::vector<int32_t> sa((size_t)n_nodes * 4, -1), sf((size_t)n_nodes * 4, -1);
+    std::vector<uint8_t> bl(n_nodes, 0), first_seen((size_t)n_nodes * 3, 0);
+    ptrack_a.assign(std::max<size_t>(A.prop_slots.size(), 1), -1);
+    ptrack_f.assign(ptrack_a.size(), -1);
+    for (uint32_t t = 0; t < an.td->n_tracks; ++t) {
+        if (an.target[t] < 0 || !an.enabled[t]) continue;
+        const fyx_track_desc& tr = an.td->tracks[t];
+        if (tr.n_curves < kind_need(tr.kind)) continue;      // fetch() -> None: no value
+        const size_t node = (size_t)an.target[t];
+        if (tr.binding >= FYX_BIND_PROPERTY0) {
+            const std::pair<int32_t, int32_t> key(an.target[t], tr.binding - FYX_BIND_PROPERTY0);
+            const size_t sl = std::find(A.prop_slots.begin(), A.prop_slots.end(), key) - A.prop_slots.begin();
+            if (sl < ptrack_a.size()) {
+                ptrack_a[sl] = (int32_t)t;                                     // applied in order: the last one stays
+                if (ptrack_f[sl] < 0) ptrack_f[sl] = (int32_t)t;               // find(): the first one
+            }
+            sa[node * 4 + 3] = sf[node * 4 + 3] = (int32_t)t;                  // the node's pose is not empty
+            continue;
+        }
+        const int b = tr.binding;
+        const bool fits = kind_fits(b, tr.kind);
+        if (fits) sa[node * 4 + b] = (int32_t)t;
+        else bl[node] |= 8u;
+        if (!first_seen[node * 3 + b]) {
+            first_seen[node * 3 + b] = 1;
+            if (fits) sf[node * 4 + b] = (int32_t)t;
+            else bl[node] |= (uint8_t)(1u << b);
+        }
+    }
+    an.dup = sa != sf || ptrack_a != ptrack_f;
+    an.slots = std::move(sa);
+    an.slots_f = std::move(sf);
+    an.blockers = std::move(bl);
+}
+
 // ------------------------------------------------------------------------------------------
 // Device side of an animator
 // ------------------------------------------------------------------------------------------
@@ -34,7 +87,49 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
                                       c->stream));
         if (int rc_ = sync_all(c)) return rc_;
     }
-    const uint32_t na = (uint32_t)A.anims.size();
+    // the two views of every animation whose bindings changed (host side), and whether the animator needs two records per animation:
+    // a machine blends poses, and a blend reads the READ view of the other pose (a player only applies: the APPLY view is all it needs)
+    std::vector<std::vector<int32_t>> new_pa(A.anims.size()), new_pf(A.anims.size());
+    bool any_dup = false;
+    for (size_t a = 0; a < A.anims.size(); ++a) {
+        if (A.anims[a].slots_dirty) build_track_views(A, A.anims[a], new_pa[a], new_pf[a]);
+        any_dup = any_dup || (A.anims[a].dup && !A.anims[a].removed);
+    }
+    if (any_dup && !A.layers.empty() && !A.shadows) {
+        // From one device animation per animation to two: device animation a becomes 2 a and 2 a + 1, both holding what a held (until
+        // now the two views were the same record).  Pose records, sampled property values and root-motion state move; span hints start
+        // over (advisory).
+        if (int rc_ = sync_all(c)) return rc_;
+        auto spread = [&](void** arr, size_t row_bytes, uint32_t rows) -> int {
+            if (!*arr || !rows || !row_bytes) return FYX_OK;
+            DevGuard n2;
+            FYX_HIP(c, hipMalloc(&n2.p, std::max<size_t>(2 * row_bytes * rows, 16)));
+            FYX_HIP(c, hipMemcpy2D(n2.p, 2 * row_bytes, *arr, row_bytes, row_bytes, rows, hipMemcpyDeviceToDevice));
+            FYX_HIP(c, hipMemcpy2D(static_cast<char*>(n2.p) + row_bytes, 2 * row_bytes, *arr, row_bytes, row_bytes, rows, hipMemcpyDeviceToDevice));
+            dfree(*arr);
+            *arr = n2.release();
+            return FYX_OK;
+        };
+        if (int rc = spread(reinterpret_cast<void**>(&A.d_anim_pose), in * 48, A.dev_anim_capacity)) return rc;
+        if (int rc = spread(reinterpret_cast<void**>(&A.d_prop_pose), (size_t)A.n_instances * A.dev_prop_slots * sizeof(PropRec), A.dev_prop_anims)) return rc;
+        if (int rc = spread(reinterpret_cast<void**>(&A.d_rm_anim), (size_t)A.n_instances * sizeof(RootMotionDev), A.dev_rm_anim_capacity)) return rc;
+        if (A.d_hints && A.dev_anim_capacity && A.dev_track_capacity) {
+            const size_t hb = (size_t)2 * A.dev_anim_capacity * A.n_instances * A.dev_track_capacity * 16;
+            dfree(A.d_hints);
+            A.d_hints = nullptr;
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_hints), std::max<size_t>(hb, 16)));
+            FYX_HIP(c, hipMemset(A.d_hints, 0, std::max<size_t>(hb, 16)));
+        }
+        if (A.d_slot_hints) FYX_HIP(c, hipMemset(A.d_slot_hints, 0, A.slot_hint_words * 4));
+        if (A.d_cursors) FYX_HIP(c, hipMemset(A.d_cursors, 0xff, A.cursor_recs * 256));
+        A.dev_anim_capacity *= 2;
+        A.dev_prop_anims *= 2;
+        A.dev_rm_anim_capacity *= 2;
+        A.shadows = true;
+        A.anims_dirty = true;
+    }
+    const uint32_t n_real = (uint32_t)A.anims.size();
+    const uint32_t na = A.n_dev_anims();      // DEVICE animations from here on
     if (na > A.dev_anim_capacity || A.max_tracks > A.dev_track_capacity) {
         // grow pose records / hints; existing contents are preserved
         const uint32_t new_cap = std::max(na, A.dev_anim_capacity);
@@ -62,8 +157,10 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         A.dev_track_capacity = new_tracks;
         A.anims_dirty = true;
     }
-    // the per-instance sampler's own hints: one word per (animation, node, binding, curve, instance)
-    {
+    // The per-instance sampler's own state -- cursors (256 bytes per (animation, instance, node)) and, for tracks without span records, one
+    // hint word per (animation, node, binding, curve, instance) -- only while the animator runs that form (launch_pose_sample's rule: a
+    // crowd's form reads neither, and a 10 000-instance crowd would carry hundreds of MB of them for nothing: ADVICE r5).
+    if (c->sample_form == 1 || (c->sample_form == 0 && A.n_instances < 32)) {
         const size_t want = (size_t)std::max(A.dev_anim_capacity, 1u) * rig.n_nodes * 12 * A.n_instances;
         if (want > A.slot_hint_words) {
             if (int rc_ = sync_all(c)) return rc_;
@@ -74,6 +171,16 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             FYX_HIP(c, hipMemset(A.d_slot_hints, 0, std::max<size_t>(want * 4, 16)));
             A.slot_hint_words = want;
         }
+        const size_t recs = (size_t)std::max(A.dev_anim_capacity, 1u) * in;
+        if (recs > A.cursor_recs) {
+            if (int rc_ = sync_all(c)) return rc_;
+            dfree(A.d_cursors);
+            A.d_cursors = nullptr;
+            A.cursor_recs = 0;
+            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_cursors), std::max<size_t>(recs * 256, 256)));
+            FYX_HIP(c, hipMemset(A.d_cursors, 0xff, std::max<size_t>(recs * 256, 256)));      // nothing cached
+            A.cursor_recs = recs;
+        }
     }
     // slot tables + animation descriptors
     bool any_slots = false;
@@ -81,46 +188,40 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
     if (any_slots || A.anims_dirty) {
         if (int rc_ = sync_all(c)) return rc_;
         std::vector<AnimDev> hd(na);
-        for (uint32_t a = 0; a < na; ++a) {
+        for (uint32_t a = 0; a < n_real; ++a) {
             AnimationDef& an = A.anims[a];
-            if (an.slots_dirty) {
-                std::vector<int32_t> slots((size_t)rig.n_nodes * 4, -1);
-                std::vector<int32_t> ptrack(std::max<size_t>(A.prop_slots.size(), 1), -1);
-                for (uint32_t t = 0; t < an.td->n_tracks; ++t) {
-                    if (an.target[t] < 0 || !an.enabled[t]) continue;
-                    const int b = an.td->tracks[t].binding;
-                    if (b >= FYX_BIND_PROPERTY0) {
-                        if (an.td->tracks[t].n_curves < 1) continue;   // fetch() -> None
-                        const std::pair<int32_t, int32_t> key(an.target[t], b - FYX_BIND_PROPERTY0);
-                        const size_t sl = std::find(A.prop_slots.begin(), A.prop_slots.end(), key) - A.prop_slots.begin();
-                        if (sl < ptrack.size()) ptrack[sl] = (int32_t)t;
-                        slots[(size_t)an.target[t] * 4 + 3] = (int32_t)t;   // the node's pose is not empty
-                        continue;
-                    }
-                    int32_t& s = slots[(size_t)an.target[t] * 4 + b];
-                    if (s < 0) s = (int32_t)t;
-                }
-                if (an.dev_prop_slots < ptrack.size()) {
+            if (an.slots_dirty) {      // (the views were built above)
+                const std::vector<int32_t>&pa = new_pa[a], &pf = new_pf[a];
+                if (an.dev_prop_slots < pa.size()) {
                     dfree(an.d_prop_track);
-                    an.d_prop_track = nullptr;
-                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_prop_track), std::max<size_t>(ptrack.size() * 4, 16)));
-                    an.dev_prop_slots = (uint32_t)ptrack.size();
+                    dfree(an.d_prop_track_f);
+                    an.d_prop_track = an.d_prop_track_f = nullptr;
+                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_prop_track), std::max<size_t>(pa.size() * 4, 16)));
+                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_prop_track_f), std::max<size_t>(pa.size() * 4, 16)));
+                    an.dev_prop_slots = (uint32_t)pa.size();
                 }
-                FYX_HIP(c, hipMemcpy(an.d_prop_track, ptrack.data(), ptrack.size() * 4, hipMemcpyHostToDevice));
-                if (!an.d_slot_track)
-                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_slot_track), std::max<size_t>(slots.size() * 4, 16)));
-                FYX_HIP(c, hipMemcpy(an.d_slot_track, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
-                an.slots = std::move(slots);
+                FYX_HIP(c, hipMemcpy(an.d_prop_track, pa.data(), pa.size() * 4, hipMemcpyHostToDevice));
+                FYX_HIP(c, hipMemcpy(an.d_prop_track_f, pf.data(), pf.size() * 4, hipMemcpyHostToDevice));
+                if (!an.d_slot_track) {
+                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_slot_track), std::max<size_t>(an.slots.size() * 4, 16)));
+                    FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&an.d_slot_track_f), std::max<size_t>(an.slots.size() * 4, 16)));
+                }
+                FYX_HIP(c, hipMemcpy(an.d_slot_track, an.slots.data(), an.slots.size() * 4, hipMemcpyHostToDevice));
+                FYX_HIP(c, hipMemcpy(an.d_slot_track_f, an.slots_f.data(), an.slots_f.size() * 4, hipMemcpyHostToDevice));
                 an.slots_dirty = false;
             }
+        }
+        for (uint32_t a = 0; a < na; ++a) {
+            const AnimationDef& an = A.anims[A.shadows ? a >> 1 : a];
+            const bool read_view = A.shadows && (a & 1u);
             hd[a].tracks = an.td->d_tracks;
             hd[a].key_loc = an.td->d_loc;
             hd[a].key_aux = an.td->d_aux;
             hd[a].key_rec = an.td->d_rec;
             hd[a].hot = an.td->d_hot;
             hd[a].spans = an.td->d_spans;
-            hd[a].slot_track = an.d_slot_track;
-            hd[a].prop_track = an.d_prop_track;
+            hd[a].slot_track = read_view ? an.d_slot_track_f : an.d_slot_track;
+            hd[a].prop_track = read_view ? an.d_prop_track_f : an.d_prop_track;
             hd[a].n_tracks = an.td->n_tracks;
             hd[a].rm_node = an.rm_node;
             hd[a].rm_ignore = an.rm_ignore;
@@ -134,13 +235,15 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         // the crowd sampler's descriptors: what pose_sample_crowd_body reads off slot table, track record and TrackHot, resolved
         std::vector<CrowdDesc> cd((size_t)na * rig.n_nodes * 3);
         for (uint32_t a = 0; a < na; ++a) {
-            const AnimationDef& an = A.anims[a];
+            const AnimationDef& an = A.anims[A.shadows ? a >> 1 : a];
+            const std::vector<int32_t>& view = (A.shadows && (a & 1u)) ? an.slots_f : an.slots;
             for (uint32_t node = 0; node < rig.n_nodes; ++node) {
                 CrowdDesc* d = &cd[((size_t)a * rig.n_nodes + node) * 3];
-                uint32_t present = 0;
+                // (16: the node's list holds a value that is no operand of any blend and is never applied -- but the list is not empty)
+                uint32_t present = node < an.blockers.size() && an.blockers[node] ? 16u : 0u;
                 for (int b = 0; b < 3; ++b) {
                     d[b] = CrowdDesc{nullptr, 0u, 0u, 0u, -1, 0u, 0u};
-                    const int32_t t = an.slots.size() == (size_t)rig.n_nodes * 4 ? an.slots[(size_t)node * 4 + b] : -1;
+                    const int32_t t = view.size() == (size_t)rig.n_nodes * 4 ? view[(size_t)node * 4 + b] : -1;
                     if (t < 0 || (size_t)t >= an.td->hot.size()) continue;
                     const TrackHot& th = an.td->hot[t];
                     const uint32_t need = th.kind == FYX_KIND_QUAT ? 4u : (th.kind == FYX_KIND_VEC3 || th.kind == FYX_KIND_QUAT_EULER) ? 3u : 0u;
@@ -153,7 +256,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
                     if (d[b].valid && th.span_first != kNoSpans && an.td->d_spans) d[b].spans = an.td->d_spans + th.span_first;
                     if (d[b].valid) present |= b == FYX_BIND_POSITION ? 1u : b == FYX_BIND_SCALE ? 2u : 4u;
                 }
-                if (an.slots.size() == (size_t)rig.n_nodes * 4 && an.slots[(size_t)node * 4 + 3] >= 0) present |= 8u;
+                if (view.size() == (size_t)rig.n_nodes * 4 && view[(size_t)node * 4 + 3] >= 0) present |= 8u;
                 for (int b = 0; b < 3; ++b) d[b].present = present;
             }
         }
@@ -161,6 +264,9 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         A.d_crowd = nullptr;
         if (!cd.empty())
             if (int rc = upload(c, &A.d_crowd, cd.data(), cd.size())) return rc;
+        // (what the cursors cached belongs to the old bindings)
+        FYX_HIP(c, launch_cursor_stale(A.d_cursors, A.cursor_recs, c->stream));
+        if (A.d_cursors) FYX_HIP(c, hipStreamSynchronize(c->stream));      // (the frame's sampler may run on the other frame stream)
         A.anims_dirty = false;
     }
     const uint32_t nps = (uint32_t)A.prop_slots.size();
@@ -284,12 +390,14 @@ void frame_static(const fyx_ctx* c, const Animator& A, PoseFrameDev& f) {
     memset(&f, 0, sizeof f);
     f.anims = A.d_anims;
     f.crowd = A.d_crowd;
-    f.n_anims = (uint32_t)A.anims.size();
+    f.n_anims = A.n_dev_anims();
+    f.shadows = A.shadows ? 1u : 0u;
     f.n_instances = A.n_instances;
     f.n_nodes = A.rig->n_nodes;
     f.layer_masks = A.d_layer_masks;
     f.hints = A.d_hints;
     f.slot_hints = A.d_slot_hints;
+    f.cursors = A.d_cursors;
     f.max_tracks = A.dev_track_capacity;
     f.sample_form = (uint32_t)c->sample_form;
     f.anim_pose = A.d_anim_pose;
@@ -304,16 +412,45 @@ void frame_static(const fyx_ctx* c, const Animator& A, PoseFrameDev& f) {
 
 // (sections 16-byte aligned: uint4 reads of the root-motion ops, whole uint4 copies; a scene of 256 characters is 256 such blocks)
 constexpr size_t kCtrlAlign = 16;
+// The frame's control sections as the kernels index them: per DEVICE animation.  With two device animations per animation
+// (Animator::shadows) the planner's arrays are spread out -- clocks, tick flags and time slices once for each of the pair, and the
+// programs' animation operands doubled (2 a: the apply view; the two-record folds read 2 a + 1 themselves).
+void expand_ctrl(Animator& A) {
+    if (!A.shadows) return;
+    const size_t n = A.times.size();
+    A.x_times.resize(2 * n);
+    A.x_ticked.resize(2 * n);
+    for (size_t k = 0; k < n; ++k) {
+        A.x_times[2 * k] = A.x_times[2 * k + 1] = A.times[k];
+        A.x_ticked[2 * k] = A.x_ticked[2 * k + 1] = A.ticked[k];
+    }
+    A.x_slices.resize(2 * A.slices.size());
+    for (size_t k = 0; k < A.slices.size(); ++k) A.x_slices[2 * k] = A.x_slices[2 * k + 1] = A.slices[k];
+    A.x_ops = A.ops;
+    for (uint2& op : A.x_ops) {
+        const uint32_t code = op.x & 0xffu;
+        if (code == OP_BLEND_ANIM || code == OP_APPLY_ANIM) op.x = code | ((op.x >> 8) * 2u) << 8;
+    }
+    A.x_rm_ops = A.rm_ops;
+    for (uint4& op : A.x_rm_ops)
+        if (op.x == RM_SET_ANIM) op.z *= 2u;
+}
+inline const std::vector<float>& ctrl_times(const Animator& A) { return A.shadows ? A.x_times : A.times; }
+inline const std::vector<uint8_t>& ctrl_ticked(const Animator& A) { return A.shadows ? A.x_ticked : A.ticked; }
+inline const std::vector<float2>& ctrl_slices(const Animator& A) { return A.shadows ? A.x_slices : A.slices; }
+inline const std::vector<uint2>& ctrl_ops(const Animator& A) { return A.shadows ? A.x_ops : A.ops; }
+inline const std::vector<uint4>& ctrl_rm_ops(const Animator& A) { return A.shadows ? A.x_rm_ops : A.rm_ops; }
+
 CtrlLayout ctrl_layout(const Animator& A) {
     CtrlLayout L;
     L.rm = A.rm_enabled;
-    L.o_tick = align_up(A.times.size() * 4, kCtrlAlign);
-    L.o_off = L.o_tick + align_up(A.ticked.size(), kCtrlAlign);
+    L.o_tick = align_up(ctrl_times(A).size() * 4, kCtrlAlign);
+    L.o_off = L.o_tick + align_up(ctrl_ticked(A).size(), kCtrlAlign);
     L.o_ops = L.o_off + align_up(A.prog_off.size() * 4, kCtrlAlign);
-    L.o_slices = L.o_ops + align_up(A.ops.size() * 8, kCtrlAlign);
-    L.o_rmoff = L.o_slices + (L.rm ? align_up(A.slices.size() * 8, kCtrlAlign) : 0);
+    L.o_slices = L.o_ops + align_up(ctrl_ops(A).size() * 8, kCtrlAlign);
+    L.o_rmoff = L.o_slices + (L.rm ? align_up(ctrl_slices(A).size() * 8, kCtrlAlign) : 0);
     L.o_rmops = L.o_rmoff + (L.rm ? align_up(A.rm_prog_off.size() * 4, kCtrlAlign) : 0);
-    L.total = L.o_rmops + (L.rm ? align_up(A.rm_ops.size() * 16, kCtrlAlign) : 0);
+    L.total = L.o_rmops + (L.rm ? align_up(ctrl_rm_ops(A).size() * 16, kCtrlAlign) : 0);
     return L;
 }
 
@@ -322,31 +459,31 @@ CtrlLayout ctrl_layout_inline(const Animator& A) {
     CtrlLayout L;
     L.rm = A.rm_enabled;
     L.o_times = 16;
-    L.o_tick = L.o_times + align_up(A.times.size() * 4, 16);
-    L.o_off = L.o_tick + align_up(A.ticked.size(), 16);
+    L.o_tick = L.o_times + align_up(ctrl_times(A).size() * 4, 16);
+    L.o_off = L.o_tick + align_up(ctrl_ticked(A).size(), 16);
     L.o_ops = L.o_off + align_up(A.prog_off.size() * 4, 16);
-    L.o_slices = L.o_ops + align_up(A.ops.size() * 8, 16);
-    L.o_rmoff = L.o_slices + (L.rm ? align_up(A.slices.size() * 8, 16) : 0);
+    L.o_slices = L.o_ops + align_up(ctrl_ops(A).size() * 8, 16);
+    L.o_rmoff = L.o_slices + (L.rm ? align_up(ctrl_slices(A).size() * 8, 16) : 0);
     L.o_rmops = L.o_rmoff + (L.rm ? align_up(A.rm_prog_off.size() * 4, 16) : 0);
-    L.total = L.o_rmops + (L.rm ? align_up(A.rm_ops.size() * 16, 16) : 0);
+    L.total = L.o_rmops + (L.rm ? align_up(ctrl_rm_ops(A).size() * 16, 16) : 0);
     return L;
 }
 
 // What changes from one steady frame to the next (anim_planner.h, steady_frame): the clocks and the tick flags.
 void ctrl_write_clocks(const Animator& A, const CtrlLayout& L, char* h) {
-    memcpy(h + L.o_times, A.times.data(), A.times.size() * 4);
-    memcpy(h + L.o_tick, A.ticked.data(), A.ticked.size());
+    memcpy(h + L.o_times, ctrl_times(A).data(), ctrl_times(A).size() * 4);
+    memcpy(h + L.o_tick, ctrl_ticked(A).data(), ctrl_ticked(A).size());
 }
 
 void ctrl_write(const Animator& A, const CtrlLayout& L, char* h) {
-    memcpy(h + L.o_times, A.times.data(), A.times.size() * 4);
-    memcpy(h + L.o_tick, A.ticked.data(), A.ticked.size());
+    memcpy(h + L.o_times, ctrl_times(A).data(), ctrl_times(A).size() * 4);
+    memcpy(h + L.o_tick, ctrl_ticked(A).data(), ctrl_ticked(A).size());
     memcpy(h + L.o_off, A.prog_off.data(), A.prog_off.size() * 4);
-    memcpy(h + L.o_ops, A.ops.data(), A.ops.size() * 8);
+    memcpy(h + L.o_ops, ctrl_ops(A).data(), ctrl_ops(A).size() * 8);
     if (L.rm) {
-        memcpy(h + L.o_slices, A.slices.data(), A.slices.size() * 8);
+        memcpy(h + L.o_slices, ctrl_slices(A).data(), ctrl_slices(A).size() * 8);
         memcpy(h + L.o_rmoff, A.rm_prog_off.data(), A.rm_prog_off.size() * 4);
-        memcpy(h + L.o_rmops, A.rm_ops.data(), A.rm_ops.size() * 16);
+        memcpy(h + L.o_rmops, ctrl_rm_ops(A).data(), ctrl_rm_ops(A).size() * 16);
     }
 }
 
@@ -467,6 +604,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
             if (int rc = pose_behind_all_skinning(c, ps)) return rc;
     }
     if (int rc = ensure_device_state(c, A)) return rc;
+    expand_ctrl(A);      // (two device animations per animation: the control sections per device animation)
     A.last_frame_alt = (c->pose_overlap && c->frame_idx) ? 1 : 0;
     A.last_frame_kind = with_program ? 1 : 2;
     PoseFrameDev f;
@@ -482,7 +620,9 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         const CtrlLayout Li = ctrl_layout_inline(A);
         // (the kernels that read it there walk the hierarchy wide: a deep rig of ~1000 nodes, whose chunk table no longer fits
         // the LDS beside its matrices, takes the uploaded block and the narrow kernels)
-        in_args = c->inline_ctrl && Li.total <= sizeof(CtrlInline) && wide_update_lds(A.rig->n_nodes, A.rig->n_chunks) <= kLdsPerWorkgroup;
+        // (... and so does an animator whose folds keep two records per animation: kUpdDup is the plain launch's)
+        // (+ 16: the one-launch frame's wait status word lies behind the walk's areas)
+        in_args = c->inline_ctrl && !A.shadows && Li.total <= sizeof(CtrlInline) && wide_update_lds(A.rig->n_nodes, A.rig->n_chunks) + 16u <= kLdsPerWorkgroup;
         const CtrlLayout L = in_args ? Li : ctrl_layout(A);
         if (in_args) {
             ctrl_write(A, L, reinterpret_cast<char*>(&inl));    // the sections start behind the header (offset 16)
@@ -509,7 +649,7 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
     }
     RigDev rd;
     if (int rc = rig_params(c, A, rd)) return rc;
-    const int upd_mode = !with_program ? kUpdNoProgram : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral;
+    const int upd_mode = !with_program ? kUpdNoProgram : A.shadows ? kUpdDup : (A.all_straight && c->upd_lean) ? kUpdStraight : kUpdGeneral;
     // the animator's skin outputs: the kernel arguments fyx_lbs_skin_device would launch with, on the palettes this frame writes
     LbsArgs skin_args[kMaxFrameSkins];
     const uint32_t n_skins = (uint32_t)A.skin_outputs.size();
@@ -529,7 +669,12 @@ int run_frame(fyx_ctx* c, Animator& A, bool with_program) {
         wait.err = reinterpret_cast<uint32_t*>(c->dev_err);
         wait.tag = A.id;
         FrameSkin sk;
-        const bool fused = n_skins && c->frame_skin && frame_skin_plan(c, A, skin_args, n_skins, upd_mode == kUpdStraight ? kFrameSkinMaxBlocks : kFrameSkinMaxBlocksGeneral, sk);
+        bool fused = n_skins && c->frame_skin && frame_skin_plan(c, A, skin_args, n_skins, upd_mode == kUpdStraight ? kFrameSkinMaxBlocks : kFrameSkinMaxBlocksGeneral, sk);
+        if (fused) {      // the skinning workgroups' palette lies behind the walk's LDS areas: a deep rig whose walk nearly fills the LDS skins with launches of its own
+            uint32_t max_bones = 0;
+            for (uint32_t k = 0; k < sk.n_jobs; ++k) max_bones = std::max(max_bones, sk.job[k].n_bones);
+            fused = wide_update_lds(A.rig->n_nodes, A.rig->n_chunks) + frame_skin_lds(max_bones) <= kLdsPerWorkgroup;
+        }
         // (registered skin outputs are the same vertex buffers every frame: a launch that writes them lies behind the other frame stream's
         // skinning of them -- for a pose launch that skins, the whole launch)
         if (fused)
@@ -640,6 +785,24 @@ int scene_frame(fyx_ctx* c, SceneBatch& S, float dt, bool replay = false) {
     // a scene of ONE animator is that animator's own frame: the control block in the kernel arguments, sampler + update (+ skinning) in
     // one launch where the animator qualifies -- 8.6 us for a character where the scene's stages (copy kernel, sampler, update) take ~19
     if (n == 1) return run_frame(c, *S.animators[0], true);
+    // An animator whose machine folds two records per animation (AnimationDef::dup) has no scene form: such a scene runs its members one
+    // by one (same results: the scene's launches ARE the members' frames side by side).
+    {
+        bool one_by_one = false;
+        for (size_t k = 0; k < n && !one_by_one; ++k) {
+            const Animator& A = *S.animators[k];
+            if (A.shadows) one_by_one = true;
+            if (!A.layers.empty())
+                for (const AnimationDef& an : A.anims) one_by_one = one_by_one || (an.maybe_dup && !an.removed);
+        }
+        if (one_by_one) {
+            for (size_t k = 0; k < n; ++k) {
+                if (int rc = run_frame(c, *S.animators[k], true)) return rc;
+                S.animators[k]->last_frame_kind = 1;
+            }
+            return FYX_OK;
+        }
+    }
 
     // 2. device state, and the block tables if the scene's shape changed
     hipStream_t ps = nullptr;

@@ -25,6 +25,15 @@ FYX_HD uint32_t f2u(float v) {
     return u;
 #endif
 }
+FYX_HD float u2f(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+#endif
+}
 FYX_HD float absf_(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return fabsf(v);

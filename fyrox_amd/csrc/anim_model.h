@@ -48,6 +48,19 @@ struct AnimationDef {
     int32_t* d_prop_track = nullptr;   // [animator's property slots]
     uint32_t dev_prop_slots = 0;
     bool slots_dirty = true;
+    // A node's pose is a LIST of values (pose.rs:107-121): several enabled tracks may feed one binding of one node, and a track's
+    // kind may fit no binding (a Real track bound to Position).  What can be observed of such a list is two values per binding:
+    // the one the pose APPLIES -- the last value whose kind fits, scene/animation/mod.rs:147-186 -- and the one a blend READS when
+    // this pose is the `other` -- the first value of the binding, whatever its kind (value.rs:438-444; a kind that differs blends
+    // with nothing).  `slots` / d_slot_track / d_prop_track are the APPLY view; these are the READ view, and `dup` says the two
+    // differ somewhere (then a machine's folds keep two records per animation: Animator::shadows).
+    std::vector<int32_t> slots_f;      // [n_nodes][4]: first track of the binding if its kind fits, else -1 (entry 3 as in `slots`)
+    std::vector<uint8_t> blockers;     // [n_nodes] bit b: the binding's FIRST value has a kind that does not fit; bit 3: some value of the node fits no binding
+    int32_t* d_slot_track_f = nullptr;
+    int32_t* d_prop_track_f = nullptr;
+    bool dup = false;
+    bool maybe_dup = false;            // (host, set when tracks are bound: two tracks on one (node, binding) or a kind that fits no binding -- the
+                                       //   animator then stays off the launches that have no two-record fold: one-launch frames, scenes)
     // AnimationSignal (signal.rs): the index stands for the {id, name} pair the shim keeps
     struct Signal { float time; uint8_t enabled; };
     std::vector<Signal> signals;
@@ -183,6 +196,15 @@ struct Animator {
     std::vector<MachineState> mstate;   // [inst]
     std::vector<uint64_t> rng;          // [inst] StateAction::EnableRandomAnimation's generator state (lazily sized)
     uint32_t max_tracks = 0;
+    // Two device animations per animation (AnimationDef::dup in an animator with a machine): 2 a the apply view, 2 a + 1 the read view.
+    // Sticky once set (records, hints and root-motion state are laid out [device animation]...).
+    bool shadows = false;
+    uint32_t n_dev_anims() const { return (uint32_t)anims.size() * (shadows ? 2u : 1u); }
+    std::vector<float> x_times;             // the frame's control sections per DEVICE animation (shadows only; run_frame fills them)
+    std::vector<uint8_t> x_ticked;
+    std::vector<float2> x_slices;
+    std::vector<uint2> x_ops;
+    std::vector<uint4> x_rm_ops;
     // device state
     AnimDev* d_anims = nullptr;
     CrowdDesc* d_crowd = nullptr;   // [anims][nodes][3]
@@ -190,6 +212,8 @@ struct Animator {
     uint32_t* d_hints = nullptr;
     uint32_t* d_slot_hints = nullptr;       // PoseFrameDev::slot_hints (hints are advisory: a fresh array of zeros is "no hint")
     size_t slot_hint_words = 0;
+    float4* d_cursors = nullptr;            // PoseFrameDev::cursors: 256 bytes per (device animation, instance, node); with slot_hints, only while
+    size_t cursor_recs = 0;                 //   the animator runs the per-instance sampler (a crowd's form reads neither)
     float4* d_anim_pose = nullptr;
     uint32_t dev_anim_capacity = 0, dev_track_capacity = 0;
     float4* d_node_trs = nullptr;

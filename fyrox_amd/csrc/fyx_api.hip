@@ -916,17 +916,16 @@ static int* option_slot(fyx_ctx* c, const char* key) {
     if (!strcmp(key, "lbs.crowd_lean")) return &c->lbs.crowd_lean;
     if (!strcmp(key, "lbs.timing")) return &c->timing;
     if (!strcmp(key, "lbs.dyn")) return &c->lbs.dyn;
-    if (!strcmp(key, "lbs.dyn_map")) return &c->lbs.dyn_map;
     if (!strcmp(key, "comm.form")) return &c->comm_form;
     if (!strcmp(key, "anim.threads")) return &c->plan_threads;
     if (!strcmp(key, "anim.split")) return &c->plan_split;
-    if (!strcmp(key, "anim.overlap")) return &c->pose_overlap;
+    if (!strcmp(key, "anim.overlap") || !strcmp(key, "debug.overlap")) return &c->pose_overlap;
     if (!strcmp(key, "anim.inline_ctrl")) return &c->inline_ctrl;
     if (!strcmp(key, "anim.sample_form")) return &c->sample_form;
     if (!strcmp(key, "anim.update_lean")) return &c->upd_lean;
     if (!strcmp(key, "anim.update_pack")) return &c->upd_pack;
     if (!strcmp(key, "anim.one_launch")) return &c->one_launch;
-    if (!strcmp(key, "anim.frame_skin")) return &c->frame_skin;
+    if (!strcmp(key, "anim.frame_skin") || !strcmp(key, "debug.frame_skin")) return &c->frame_skin;
     if (!strcmp(key, "anim.frame_skin_units")) return &c->frame_skin_units;
     if (!strcmp(key, "anim.wait_timeout_ms")) return &c->wait_timeout_ms;
     if (!strcmp(key, "anim.ctrl_upload")) return &c->ctrl_mode;
@@ -956,7 +955,11 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->comm_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "comm.form must be 0 (broadcasts), 1 (send / recv) or 2 (one all-gather over padded shards)");
     if (slot == &c->sample_form && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.sample_form must be 0, 1 or 2");
     if (slot == &c->inline_ctrl && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.inline_ctrl must be 0 or 1");
-    if (slot == &c->pose_overlap && (value < 0 || value > 2)) return fail(c, FYX_ERR_INVALID_ARG, "anim.overlap must be 0, 1 or 2");
+    // (the forms that did not pay -- streams by kind, the scene's update stage skinning whatever its size, the scene as one launch --
+    // are reachable under their debug.* names only: the public options describe one way to do each thing)
+    const bool debug_key = !strncmp(key, "debug.", 6);
+    if (slot == &c->pose_overlap && (value < 0 || value > (debug_key ? 2 : 1)))
+        return fail(c, FYX_ERR_INVALID_ARG, debug_key ? "debug.overlap must be 0, 1 or 2 (streams by kind)" : "anim.overlap must be 0 or 1");
     if (slot == &c->plan_split && value < 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.split must be >= 1");
     if (slot == &c->plan_threads && (value < 1 || value > 64))
         return fail(c, FYX_ERR_INVALID_ARG, "anim.threads must be 1..64");
@@ -967,7 +970,8 @@ int fyx_set_option(fyx_ctx* c, const char* key, int value) {
     if (slot == &c->pose_cus && (value < 0 || value >= fyx::kCUs || (value & 7))) return fail(c, FYX_ERR_INVALID_ARG, "streams.pose_cus must be 0 or a multiple of 8 below %d", fyx::kCUs);
     if (slot == &c->upd_lean && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_lean must be 0 or 1");
     if (slot == &c->one_launch && value != 0 && value != 1) return fail(c, FYX_ERR_INVALID_ARG, "anim.one_launch must be 0 or 1");
-    if (slot == &c->frame_skin && (value < 0 || value > 3)) return fail(c, FYX_ERR_INVALID_ARG, "anim.frame_skin must be 0 .. 3");
+    if (slot == &c->frame_skin && (value < 0 || value > (debug_key ? 3 : 1)))
+        return fail(c, FYX_ERR_INVALID_ARG, debug_key ? "debug.frame_skin must be 0 .. 3" : "anim.frame_skin must be 0 or 1");
     if (slot == &c->frame_skin_units && (value < 0 || value > 64)) return fail(c, FYX_ERR_INVALID_ARG, "anim.frame_skin_units must be 0 (auto) .. 64");
     if (slot == &c->wait_timeout_ms && (value < 1 || value > 30000)) return fail(c, FYX_ERR_INVALID_ARG, "anim.wait_timeout_ms must be 1..30000");
     if (slot == &c->upd_pack && value != 0 && value != 2 && value != 4) return fail(c, FYX_ERR_INVALID_ARG, "anim.update_pack must be 0, 2 or 4");

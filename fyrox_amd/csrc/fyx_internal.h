@@ -16,7 +16,6 @@ struct LbsTuning {
     int crowd_lean = 0;      // 1: register-lean crowd kernel at two workgroups per CU (leaves room for other kernels' waves, see lbs_kernels.hip)
     int crowd_ipb = 0;       // instances per workgroup run; 0 = auto
     int dyn = 1;             // large single-instance launches: 1 = lbs_skin_dyn (units drawn from an LDS ticket counter), 0 = lbs_skin
-    int dyn_map = 0;         // lbs_skin_dyn's workgroup -> unit range map: 0 = blockIdx order, 1 = one contiguous eighth of the mesh per XCD
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // option lbs.timing: this launch's own start / stop events (dispatch timestamps)
 };
 
@@ -323,12 +322,24 @@ struct PoseFrameDev {
     uint32_t sample_form;        // 0 auto (instances on the lanes from 32 instances), 1 curves on the lanes, 2 instances on the lanes
     uint32_t* slot_hints;        // [n_anims][n_nodes][3 bindings][4 curves][n_instances]: the per-instance sampler's span hints, indexed by what the
                                  //   lane knows BEFORE it has its descriptor (round 5: the hint's load no longer waits for the descriptor's)
+    // The per-instance sampler's CURSORS (round 6): 256 bytes per (animation, instance, node) -- the span record each of the node's three
+    // tracks is in (header {left time, right time, key kinds} + one part per curve: what Curve::value_at reads while playback stays inside
+    // that span) and, per track, a link {span table, n_keys << 16 | hint, flags}.  Steady playback is ONE round trip: cursor -> value;
+    // a crossed key goes on to the neighbouring span through the link and rewrites the cursor; everything else takes the descriptor path.
+    //   f4 [0] Position header, [1..3] its curves; [4] Rotation header, [5..8] curves; [9] Scale header, [10..12] curves; [13 + binding] links
+    // All 0xff = nothing cached.  Null: the animator runs the crowd form.
+    float4* cursors;
+    uint64_t pad_cursors;
     float4* anim_pose;           // [n_anims][n_instances][n_nodes][3]
     float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
     float* local;                // [n_instances][n_nodes][16]
     float* global;               // [n_instances][n_nodes][16]
     // Property{..} bindings (value.rs:221-230, :404-427): one slot per (node, property) of the animator
     uint32_t n_prop_slots;
+    uint32_t shadows;            // 1: the animator keeps TWO device animations per animation -- 2 a: what the animation's pose APPLIES (per
+                                 //   binding the LAST applicable value of the node's list), 2 a + 1: what a blend READS of it as `other` (the
+                                 //   FIRST value of the binding; BoundValueCollection::blend_with's find, value.rs:438-444).  n_anims counts both;
+                                 //   the ops of the frame's programs name 2 a.  0: one record per animation (every list holds one value per binding)
     const int32_t* prop_node;    // [n_prop_slots] node of each slot
     PropRec* prop_pose;          // [n_anims][n_instances][n_prop_slots]
     PropRec* prop_out;           // [n_instances][n_prop_slots] value applied last (present = has been applied)
@@ -395,10 +406,14 @@ hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uin
 
 // `inl` (optional): the frame's control block travelling in the kernel arguments, see CtrlInline.
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);
+// Voids what an animator's sampler cursors cached (PoseFrameDev::cursors), keeping the span hints they carry.
+hipError_t launch_cursor_stale(float4* cursors, size_t n_recs, hipStream_t s);
 // mode: kUpdNoProgram -- the transforms as they are; kUpdGeneral -- fold programs of any shape; kUpdStraight -- the caller
 // has classified EVERY instance's program as straight (classify_fold_program_host, anim_leaves.h): a kernel without the
 // interpreter (a third of the registers).
-enum : int { kUpdNoProgram = 0, kUpdGeneral = 1, kUpdStraight = 2 };
+// kUpdDup -- fold programs of any shape over TWO records per animation (PoseFrameDev::shadows: animations with several values of one
+// binding on a node, see anim_model.h AnimationDef::dup): the plain one-workgroup-per-instance launch only.
+enum : int { kUpdNoProgram = 0, kUpdGeneral = 1, kUpdStraight = 2, kUpdDup = 3 };
 // Waves per workgroup of the update kernel (one workgroup per instance): one per 64 nodes, at most four -- and four for an
 // animator of few instances: the chip is empty then, and the kernel's strided tail (matrix stores, palette columns: 256 columns for
 // 64 bones) runs over four waves instead of one.  A crowd keeps the smallest block: its waves compete with the skinning kernel's.

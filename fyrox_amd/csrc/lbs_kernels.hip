@@ -164,7 +164,7 @@ constexpr int kDynBlock = 256;
 constexpr int kDynLoadAux = 2, kDynStoreAux = 16;     // nt loads, sc1 stores
 
 template <bool EXACT, int MASK>
-__global__ __launch_bounds__(kDynBlock) void lbs_skin_dyn(LbsArgs a, uint32_t total_units, uint32_t xcd_ranges) {
+__global__ __launch_bounds__(kDynBlock) void lbs_skin_dyn(LbsArgs a, uint32_t total_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* rows = reinterpret_cast<f32x4*>(smem);
     f32x4* row3 = rows + 3 * a.n_bones;
@@ -175,13 +175,8 @@ __global__ __launch_bounds__(kDynBlock) void lbs_skin_dyn(LbsArgs a, uint32_t to
     constexpr int PIECES = 1024 / kDynBlock;     // 16-byte palette columns per thread (n_bones <= 256)
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    // Which range: in blockIdx order (adjacent ranges on adjacent workgroups = on all eight XCDs in turn), or -- option lbs.dyn_map = 1 --
-    // ranked by (XCD, order within the XCD) as the crowd kernel does: workgroups are dealt round-robin over the XCDs in blockIdx order,
-    // so XCD x then owns ONE contiguous eighth of every stream and its L2 / translation caches see an eighth of the launch's pages.
-    uint32_t wg = blockIdx.x;
-    if (xcd_ranges) wg = (wg >> 3) + (wg & 7u) * (gridDim.x >> 3);      // the grid is a multiple of 8 (launch_dyn_one)
-    const uint32_t u_begin = (uint32_t)(((uint64_t)wg * total_units) / gridDim.x);
-    const uint32_t n_units = (uint32_t)(((uint64_t)(wg + 1) * total_units) / gridDim.x) - u_begin;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t n_units = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x) - u_begin;
 
     // Palette columns first: column c of bone b is piece 4 b + c, and a wave fetches 64 consecutive pieces (16 bones, one dense
     // 1 KB request).  WHICH lane takes which piece of those 64 is chosen for the LDS commit below: the 16 lanes one ds_write_b64
@@ -434,7 +429,7 @@ static hipError_t launch_dyn_one(const LbsArgs& a, const LbsTuning& t, hipStream
     const uint32_t grid = (uint32_t)kCUs * (1024u / kDynBlock);
     if (total / grid < 2 * WPB) return hipErrorNotReady;   // every wave starts with two units of its own
     const size_t lds = (size_t)a.n_bones * 64 + 64 + 16;
-    FYX_LAUNCH(t, (lbs_skin_dyn<EXACT, MASK>), dim3(grid), dim3(kDynBlock), (uint32_t)lds, s, a, total, (uint32_t)(t.dyn_map == 1));
+    FYX_LAUNCH(t, (lbs_skin_dyn<EXACT, MASK>), dim3(grid), dim3(kDynBlock), (uint32_t)lds, s, a, total);
     return hipGetLastError();
 }
 

@@ -89,14 +89,6 @@ int fyx_join(fyx_ctx* ctx);
  *     "anim.sample_form" 0 auto, 1 curves of one instance on the lanes, 2 instances of one curve on the lanes -- same
  *                        results, the crowd form is picked from 32 instances on
  *     "anim.overlap"     0 (default) = a frame is one dependent chain on the context stream.
- *                        2 = streams BY KIND: every pose kernel on the context stream, every skinning launch (the caller's and the
- *                        library's own) on a second stream, each in order; a frame's first skinning launch waits for its pose update,
- *                        a frame's pose update for the skinning of the frame before the previous one (two palette buffers per animator,
- *                        as below: fyx_animator_set_palette_output_pair; an output with one buffer makes its frames wait for ALL
- *                        earlier skinning).  Frame n + 1's pose kernels run beside frame n's skinning, no queue sits blocked on an
- *                        event that is still to come, and ONE set of vertex outputs is enough (the skinning launches are in order).
- *                        Scenes: as fast as 1 (256 characters 0.060 -> 0.056 ms); a crowd: no faster than 0 (its consecutive
- *                        skinning launches no longer overlap).
  *                        1 = whole frames alternate between TWO streams: a pose update (fyx_*_update, fyx_scene_update) starts a
  *                        frame on the other stream, the skinning launches that follow go there too, in order behind it.  Frame
  *                        n + 1's pose kernels so run beside frame n's skinning; its only cross-stream edge is "behind frame n's
@@ -105,7 +97,9 @@ int fyx_join(fyx_ctx* ctx);
  *                        fyx_animator_set_palette_output_pair registers both once).  The skinning launches of two consecutive
  *                        frames are NOT ordered against each other: a caller that skins itself alternates its vertex outputs
  *                        as well (what a renderer that draws frame n while frame n + 1 is skinned does anyway).
- *                        "lbs.streams" is not used in modes 1 and 2.  C3: frame 0.113 -> 0.094 - 0.101 ms in mode 1
+ *                        "lbs.streams" is not used then.  C3: frame 0.113 -> 0.094 - 0.101 ms; a scene of 256 characters 0.060 ->
+ *                        0.056 ms.  (A second pipelined form -- streams by kind -- measured the same for scenes and the one-stream time
+ *                        for crowds; it is "debug.overlap" = 2, for experiments: DESIGN.md section 4.)
  *     "anim.update_lean" 1 (default) = a frame whose fold programs are ALL straight (a few clips blended in a row: the common
  *                        machines; the host classifies with the kernel's own function) runs the update kernel built without the
  *                        fold interpreter: a third of the registers, so its waves fit beside a running skinning kernel
@@ -125,9 +119,8 @@ int fyx_join(fyx_ctx* ctx);
  *                        fyx_get_option("debug.frames_reissued") counts such frames (fyx_get_option("anim.one_launch") reads 0).
  *     "anim.frame_skin"  1 (default) = a one-launch frame also holds the workgroups that skin the animator's skin outputs
  *                        (fyx_animator_set_skin_output), and the update stage of a SMALL scene (fyx_scene_update, up to ~260 k skinned
- *                        vertices) those of its animators; 0 = the update call issues the skinning launches behind the pose launch(es);
- *                        2 = the scene's update stage skins whatever the scene's size, 3 = a scene of characters runs as ONE launch
- *                        (samplers, updates, skinning, per-character waits) -- both measured slower on large scenes, kept for experiments.
+ *                        vertices) those of its animators; 0 = the update call issues the skinning launches behind the pose launch(es).
+ *                        (Two further forms measured slower on large scenes are "debug.frame_skin" = 2 / 3, for experiments.)
  *                        "anim.frame_skin_units": 64-vertex units per wave of those workgroups, 0 (default) = the smallest depth
  *                        that gives every skinning workgroup a CU of its own (C2: 1, C5: 2)
  *     "anim.wait_timeout_ms" 1 .. 30000 (default 500): how long an in-grid wait of a one-launch frame lasts before it reports
@@ -433,7 +426,11 @@ int fyx_animator_free(fyx_ctx* ctx, uint64_t animator_id);
  * track_target[t] = rig node the t-th track drives (negative: no TrackBinding for the track),
  * track_enabled[t] = TrackBinding::enabled (NULL: all enabled).  The new animation has the
  * reference's defaults: speed 1, looped, enabled, time 0, time_slice 0..0 (lib.rs:928-950).
- * Two enabled tracks with the same binding on one node are FYX_ERR_UNSUPPORTED. */
+ * Several tracks may feed one binding of one node, and a track's kind need not fit its binding, exactly as in the reference: every
+ * enabled track's value goes into its node's list in track order (lib.rs:895-914); blends pair each value with the FIRST same-binding
+ * value of the other pose (value.rs:438-444, kinds that differ: no-op), and the list is applied in order, the last fitting value
+ * winning (scene/animation/mod.rs:147-186).  Such an animator runs its machine on a two-record fold (no one-launch frame, scenes run
+ * its members one by one); span hints of tracks that are neither first nor last of their binding are not kept warm. */
 int fyx_animator_add_animation(fyx_ctx* ctx, uint64_t animator_id, uint64_t tracks_id,
                                const int32_t* track_target, const uint8_t* track_enabled,
                                uint32_t* out_animation);
@@ -756,8 +753,14 @@ int fyx_animator_set_local_trs(fyx_ctx* ctx, uint64_t animator_id, uint32_t node
  * LOCAL_TRS 12 floats {pos xyz, 0, rot ijkw, scale xyz, 0}; LOCAL/GLOBAL_MATRIX 16 floats;
  * ANIMATION_POSE + animation: the animation's current pose, 12 floats {pos xyz, present-bits
  * as u32 (1 Position, 2 Scale, 4 Rotation), rot ijkw, scale xyz, 0}. */
+/* Present bits: 8 = the node's pose holds a Property value, 16 = it holds a value whose kind fits no binding (never applied, blends with
+ * nothing, but the pose is not empty: pose.rs:41-47).  A node's pose is a LIST (pose.rs:107-121) and may hold several values of one
+ * binding; ANIMATION_POSE shows per binding the value the pose APPLIES (the last one whose kind fits, scene/animation/mod.rs:147-186),
+ * ANIMATION_BLEND_VIEW + animation the one a blend READS when this pose is the other operand (the first one, value.rs:438-444; bit
+ * clear when that one's kind does not fit).  The two are the same record unless tracks share a binding of a node AND the animator has
+ * a machine (an AnimationPlayer blends nothing: it keeps the apply view only and answers both selectors with it). */
 enum { FYX_READ_LOCAL_TRS = 0, FYX_READ_LOCAL_MATRIX = 1, FYX_READ_GLOBAL_MATRIX = 2,
-       FYX_READ_ANIMATION_POSE = 16 };
+       FYX_READ_ANIMATION_POSE = 16, FYX_READ_ANIMATION_BLEND_VIEW = 65536 };
 int fyx_animator_read(fyx_ctx* ctx, uint64_t animator_id, int what, float* host_out);
 /* Device address of the same arrays (what as above), for consumers on the GPU. */
 int fyx_animator_device_ptr(fyx_ctx* ctx, uint64_t animator_id, int what, void** out_device_ptr);

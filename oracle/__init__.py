@@ -397,28 +397,34 @@ def blend_space_fetch_weights(points_xy, triangles, sampling_point):
     return [(int(idx[i]), float(w[i])) for i in range(3)] if ok else None
 
 
-def _pose_records(pose_ptr, n_nodes: int) -> np.ndarray:
-    """(n_nodes, 12) records in the product's layout {pos, present-bits}{rot}{scale,0}: first value per binding."""
+def _pose_records(pose_ptr, n_nodes: int, view: str = "apply") -> np.ndarray:
+    """(n_nodes, 12) records in the product's layout {pos, present-bits}{rot}{scale,0} of a pose's value LISTS (pose.rs:107-121).
+    view "apply": per binding the value BoundValueCollectionExt::apply leaves on the node -- the LAST one whose kind fits
+    (scene/animation/mod.rs:147-186); view "read": the one BoundValueCollection::blend_with finds when this pose is the other
+    operand -- the FIRST of the binding, bit clear when its kind does not fit (value.rs:438-444: kinds that differ blend with nothing).
+    Bit 8: a Property value; bit 16: a value whose kind fits no binding (the list is not empty)."""
     l = _alib()
     out = np.zeros((n_nodes, 12), np.float32)
     out[:, 7] = 1.0
     bits = np.zeros(n_nodes, np.uint32)
     bv = _BoundValue()
+    where = {BIND_POSITION: (slice(0, 3), 3, 1, VAL_VEC3), BIND_SCALE: (slice(8, 11), 3, 2, VAL_VEC3), BIND_ROTATION: (slice(4, 8), 4, 4, VAL_QUAT)}
     for n in range(n_nodes):
         seen = set()
         for i in range(l.fo_pose_value_count(pose_ptr, n)):
             l.fo_pose_get_value(pose_ptr, n, i, byref(bv))
-            if bv.binding in seen:
-                continue
-            seen.add(bv.binding)
-            if bv.binding == BIND_POSITION and bv.kind == VAL_VEC3:
-                out[n, 0:3] = bv.v[0:3]; bits[n] |= 1
-            elif bv.binding == BIND_SCALE and bv.kind == VAL_VEC3:
-                out[n, 8:11] = bv.v[0:3]; bits[n] |= 2
-            elif bv.binding == BIND_ROTATION and bv.kind == VAL_QUAT:
-                out[n, 4:8] = bv.v[0:4]; bits[n] |= 4
-            elif bv.binding >= 3:
+            if bv.binding >= 3:
                 bits[n] |= 8          # a Property value: the node's pose is not empty
+                continue
+            sl, cnt, bit, kind = where[bv.binding]
+            first = bv.binding not in seen
+            seen.add(bv.binding)
+            if bv.kind != kind:
+                bits[n] |= 16
+                continue
+            if view == "apply" or first:
+                out[n, sl] = bv.v[0:cnt]
+                bits[n] |= bit
     out[:, 3] = bits.view(np.float32)
     return out
 
@@ -528,16 +534,16 @@ class AnimScene:
         f0, f1, u = p.packed()
         self.l.fo_machine_set_parameter(self.machine, index, p.kind, f0, f1, u)
 
-    def _pose_properties(self, pose_ptr) -> dict:
-        """{(node, property id): (TrackValue variant, its f32 lanes)} of the Property values a pose holds (first value per
-        binding, as BoundValueCollection's lookups find it)."""
+    def _pose_properties(self, pose_ptr, view: str = "apply") -> dict:
+        """{(node, property id): (TrackValue variant, its f32 lanes)} of the Property values a pose holds: view "apply" the LAST value
+        of a binding (apply_to_object writes them in order), view "read" the FIRST (what BoundValueCollection's find returns)."""
         out = {}
         bv = _BoundValue()
         lanes = {VAL_REAL: 1, VAL_VEC2: 2, VAL_VEC3: 3, VAL_VEC4: 4, VAL_QUAT: 4}
         for n in range(min(self.l.fo_pose_node_capacity(pose_ptr), self.n_nodes)):
             for i in range(self.l.fo_pose_value_count(pose_ptr, n)):
                 self.l.fo_pose_get_value(pose_ptr, n, i, byref(bv))
-                if bv.binding >= 3 and (n, bv.binding - 3) not in out:
+                if bv.binding >= 3 and (view == "apply" or (n, bv.binding - 3) not in out):
                     v = np.zeros(4, np.float32)
                     v[:lanes[bv.kind]] = np.asarray(bv.v[:lanes[bv.kind]], np.float32)
                     out[(n, bv.binding - 3)] = (int(bv.kind), v)
@@ -546,8 +552,8 @@ class AnimScene:
     def _apply_properties(self, pose_ptr) -> None:   # value.rs:404-427: written through reflection
         self.props.update(self._pose_properties(pose_ptr))
 
-    def animation_properties(self, a: int) -> dict:
-        return self._pose_properties(self.l.fo_animation_pose(self._anim(a)))
+    def animation_properties(self, a: int, view: str = "apply") -> dict:
+        return self._pose_properties(self.l.fo_animation_pose(self._anim(a)), view)
 
     def _anim(self, a: int):
         h = self.anims[a]
@@ -575,8 +581,8 @@ class AnimScene:
         self.l.fo_pose_apply(pose, self.nodes, self.n_nodes)
         self._apply_properties(pose)
 
-    def animation_pose(self, a: int) -> np.ndarray:
-        return _pose_records(self.l.fo_animation_pose(self._anim(a)), self.n_nodes)
+    def animation_pose(self, a: int, view: str = "apply") -> np.ndarray:
+        return _pose_records(self.l.fo_animation_pose(self._anim(a)), self.n_nodes, view)
 
     def machine_pose(self) -> np.ndarray:
         return _pose_records(self.l.fo_machine_pose(self.machine), self.n_nodes)

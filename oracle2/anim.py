@@ -689,28 +689,31 @@ class Machine:
 
 
 # ---- the scene around it: nodes' transforms, apply, matrices ----------------------------------------------------------------
-def _records(pose: Pose, n_nodes: int) -> np.ndarray:
-    """(n_nodes, 12) float32: pos xyz, present bits (1 position, 2 scale, 4 rotation, 8 a property value), rot ijkw,
-    scale xyz, 0 -- the layout tests compare poses in"""
+def _records(pose: Pose, n_nodes: int, view: str = "apply") -> np.ndarray:
+    """(n_nodes, 12) float32: pos xyz, present bits (1 position, 2 scale, 4 rotation, 8 a property value, 16 a value whose kind fits no
+    binding), rot ijkw, scale xyz, 0 -- the layout tests compare poses in.  A node's pose is a list: view "apply" shows per binding the value
+    apply() leaves on the node (the last one whose kind fits), view "read" the one a lookup by binding finds (the first; bit clear when its
+    kind does not fit)"""
     out = np.zeros((n_nodes, 12), np.float32)
     out[:, 7] = 1.0                                   # an absent rotation reads as the identity
     bits = np.zeros(n_nodes, np.uint32)
+    where = {BIND_POSITION: (slice(0, 3), 1, "v3"), BIND_SCALE: (slice(8, 11), 2, "v3"), BIND_ROTATION: (slice(4, 8), 4, "quat")}
     for node, values in pose.poses.items():
         if not (0 <= node < n_nodes):
             continue
         seen = set()
         for binding, (kind, v) in values:
-            if binding in seen:                       # lookups by binding find the first value
-                continue
-            seen.add(binding)
-            if binding == BIND_POSITION and kind == "v3":
-                out[node, 0:3] = v; bits[node] |= 1
-            elif binding == BIND_SCALE and kind == "v3":
-                out[node, 8:11] = v; bits[node] |= 2
-            elif binding == BIND_ROTATION and kind == "quat":
-                out[node, 4:8] = v; bits[node] |= 4
-            elif binding >= BIND_PROPERTY0:
+            if binding >= BIND_PROPERTY0:
                 bits[node] |= 8
+                continue
+            first = binding not in seen
+            seen.add(binding)
+            sl, bit, fits = where[binding]
+            if kind != fits:
+                bits[node] |= 16
+            elif view == "apply" or first:
+                out[node, sl] = v
+                bits[node] |= bit
     out[:, 3] = bits.view(np.float32)
     return out
 
@@ -800,8 +803,8 @@ class AnimScene:
         """AnimationBlendingStateMachine::update (absm.rs:311-326)"""
         self._apply(self.machine.evaluate(self.anims, dt))
 
-    def animation_pose(self, a: int) -> np.ndarray:
-        return _records(self.anims[a].pose, self.n_nodes)
+    def animation_pose(self, a: int, view: str = "apply") -> np.ndarray:
+        return _records(self.anims[a].pose, self.n_nodes, view)
 
     def machine_pose(self) -> np.ndarray:
         return _records(self.machine.final, self.n_nodes)

@@ -494,9 +494,117 @@ def signals_and_clocks() -> Scenario:
     return sc
 
 
+def _listy_tracks(n_bones: int, seed: int, clip: int):
+    """A clip whose node poses are LISTS with more than one value per binding (pose.rs:107-121: every enabled track pushes its value, in
+    track order) and with values whose kind fits no binding (a Real track bound to Position: never applied, blends with nothing, but the
+    list is not empty).  What the reference does with them: blends pair each value with the FIRST same-binding value of the other pose
+    (value.rs:438-444; kinds that differ: no-op), apply writes them in order and the LAST fitting one stays
+    (scene/animation/mod.rs:147-186), an empty list becomes a copy of the other (pose.rs:41-47)."""
+    td, tgt = synth.make_clip(n_bones, seed, clip, euler_every=10 ** 9)
+    other, _ = synth.make_clip(n_bones, seed + 77, clip + 4, euler_every=10 ** 9)      # donor of the extra tracks' keys
+    tracks, target = list(td.tracks), [int(b) for b in tgt]
+
+    def donor(node, binding):
+        return other.tracks[node * 3 + {A.BIND_POSITION: 0, A.BIND_ROTATION: 1, A.BIND_SCALE: 2}[binding]]
+
+    def add(node, track, front=False):
+        if front:
+            tracks.insert(0, track)
+            target.insert(0, node)
+        else:
+            tracks.append(track)
+            target.append(node)
+
+    def drop(node, binding=None):
+        keep = [(t, b) for t, b in zip(tracks, target) if not (b == node and (binding is None or t.binding == binding))]
+        tracks[:] = [t for t, _ in keep]
+        target[:] = [b for _, b in keep]
+
+    real = lambda node: A.Track(A.BIND_POSITION, A.KIND_REAL, donor(node, A.BIND_POSITION).curves[:1])
+    if clip == 0:
+        add(3, donor(3, A.BIND_POSITION))                                   # [P, P']: blends read P, apply leaves P'
+        add(5, real(5), front=True)                                         # [Real, P]: nothing blends INTO this P from... and P is what is applied
+        drop(7, A.BIND_SCALE)
+        add(7, A.Track(A.BIND_SCALE, A.KIND_VEC2, donor(7, A.BIND_SCALE).curves[:2]))      # Scale holds only a value that fits nothing
+        add(9, donor(9, A.BIND_ROTATION), front=True)                       # [R', R]
+        add(11, A.Track(A.BIND_ROTATION, A.KIND_VEC3, donor(11, A.BIND_POSITION).curves))  # [R, Vec3]: the last value does not fit
+        drop(2)
+        add(2, A.Track(A.BIND_POSITION, A.KIND_QUAT, donor(2, A.BIND_ROTATION).curves))    # the whole node: one value that fits nothing
+        add(13, donor(13, A.BIND_SCALE))
+        add(13, A.Track(A.BIND_SCALE, A.KIND_VEC3, donor(12, A.BIND_SCALE).curves))         # three Scale values
+    elif clip == 1:
+        add(3, donor(3, A.BIND_POSITION))                                   # both operands of the blend hold two Positions
+        add(5, donor(5, A.BIND_POSITION), front=True)
+        add(9, A.Track(A.BIND_ROTATION, A.KIND_VEC4, donor(9, A.BIND_ROTATION).curves), front=True)   # [Vec4, R]: a blend READS the Vec4
+        add(13, donor(13, A.BIND_SCALE))
+        drop(6)                                                             # node 6 only in the other clips
+    else:
+        add(5, real(5))                                                     # [P, Real]
+        add(7, donor(7, A.BIND_SCALE), front=True)
+        drop(4)
+        add(1, A.Track(A.BIND_ROTATION, A.KIND_QUAT, donor(1, A.BIND_ROTATION).curves[:3]))  # too few curves: fetch -> None, no value at all
+    return A.AnimationTracksData(tracks), np.asarray(target, np.int32)
+
+
+def duplicate_bindings(n_bones=16, seed=synth.SEED_BASE + 21) -> Scenario:
+    """a machine over clips whose node poses hold several values per binding -- nested blends (the fold's PUSH /
+    POP_BLEND), a transition between states, a second layer with a mask; one track is switched off and on again at run time."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(3):
+        td, tgt = _listy_tracks(n_bones, seed, c)
+        tds.append(td)
+        anims.append(AnimSpec(c, tgt, speed=[1.0, 1.4, -0.8][c]))
+    base = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2),
+               A.BlendAnimations([A.BlendPose(0, 0.6), A.BlendPose(1, 0.4)]),                   # 3
+               A.BlendAnimations([A.BlendPose(2, 1.0), A.BlendPose(3, 0.7), A.BlendPose(1, parameter=1)]),     # 4: a nested blend in the middle
+               A.BlendAnimations([A.BlendPose(1, 1.0), A.BlendPose(0, 0.5)])],                   # 5: the operands the other way round
+        states=[A.State(4), A.State(5), A.State(0)],
+        transitions=[A.Transition(0, 1, 0.2, ("parameter", 0)), A.Transition(1, 2, 0.15, ("not", ("parameter", 0))),
+                     A.Transition(2, 0, 0.1, ("parameter", 0))])
+    upper = A.MachineLayer(nodes=[A.PlayAnimation(2), A.PlayAnimation(0), A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, 0.3)])],
+                           states=[A.State(2)], weight=0.5, mask=[3, 5, 6])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_RULE, False), A.Parameter(A.PARAM_WEIGHT, 0.25)], layers=[base, upper])
+    script = {6: [(0, A.Parameter(A.PARAM_RULE, True))], 14: [(1, A.Parameter(A.PARAM_WEIGHT, 0.8))], 30: [(0, A.Parameter(A.PARAM_RULE, False))],
+              48: [(0, A.Parameter(A.PARAM_RULE, True))]}
+    return Scenario("duplicate_bindings", rig, tds, anims, m, script, n_frames=64, has_euler=False)
+
+
+def duplicate_bindings_player(n_bones=16, seed=synth.SEED_BASE + 22) -> Scenario:
+    """The same clips under an AnimationPlayer: nothing is blended, every enabled animation's list is applied in turn."""
+    sc = duplicate_bindings(n_bones, seed)
+    return Scenario("duplicate_bindings_player", sc.rig, sc.tracks_data, sc.animations, None, n_frames=24, has_euler=False)
+
+
+def duplicate_properties(n_bones=8, seed=synth.SEED_BASE + 23) -> Scenario:
+    """Two tracks on one Property of one node (the same id and value type = the same ValueBinding), of the same and of different value
+    kinds, blended by a machine: find() returns the first, apply_to_object writes both in order."""
+    rig = synth.make_rig(n_bones, seed)
+    tds, anims = [], []
+    for c in range(2):
+        td, tgt = synth.make_clip(n_bones, seed, c, n_keys=9, fps=8.0, euler_every=10 ** 9)
+        o, _ = synth.make_clip(n_bones, seed + 5, c + 2, n_keys=9, fps=8.0, euler_every=10 ** 9)
+        tracks, target = list(td.tracks), [int(b) for b in tgt]
+        for node, prop, kind, curves in ((2, 0, A.KIND_REAL, o.tracks[0].curves[:1]), (2, 0, A.KIND_REAL, o.tracks[3].curves[:1]),
+                                         (4, 1, A.KIND_VEC3, o.tracks[6].curves), (4, 1, A.KIND_REAL, o.tracks[9].curves[:1]),
+                                         (5, 2, A.KIND_VEC2, o.tracks[12].curves[:2])):
+            if c == 1 and node == 4 and kind == A.KIND_VEC3:
+                continue          # the second clip's property (4, 1) holds the Real only
+            tracks.append(A.Track(A.BIND_PROPERTY0 + prop, kind, curves))
+            target.append(node)
+        tds.append(A.AnimationTracksData(tracks))
+        anims.append(AnimSpec(c, np.asarray(target, np.int32), speed=[1.0, 0.7][c]))
+    layer = A.MachineLayer(nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, 0.35)]),
+                                  A.BlendAnimations([A.BlendPose(1, 1.0), A.BlendPose(0, 0.6)])],
+                           states=[A.State(2), A.State(3)], transitions=[A.Transition(0, 1, 0.25, ("parameter", 0))])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_RULE, False)], layers=[layer])
+    return Scenario("duplicate_properties", rig, tds, anims, m, {8: [(0, A.Parameter(A.PARAM_RULE, True))]}, n_frames=30, has_euler=False)
+
+
 ALL = [c5_blend_tree, player_only, transitions, by_index, blend_space, layered, fbx_like, gltf_like, morph_weights,
        morph_weights_player, property_kinds, property_kinds_euler, property_kinds_player, random_attacks, removed_clips,
-       program_forms, masked_transitions, signals_and_clocks]
+       program_forms, masked_transitions, signals_and_clocks, duplicate_bindings, duplicate_bindings_player, duplicate_properties]
 
 
 def with_root_motion_and_signals(make) -> Callable[[], Scenario]:

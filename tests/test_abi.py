@@ -109,7 +109,7 @@ def test_options_are_validated_and_readable_without_a_gpu():
     try:
         for key, good, bad in (("lbs.exact", 0, None), ("lbs.streams", 1, 9), ("lbs.crowd", -1, 2), ("lbs.crowd_ipb", 8, 5000),
                                ("lbs.blocks_per_cu", 2, 65), ("lbs.dyn", 0, None), ("anim.threads", 3, 0), ("anim.split", 64, 0),
-                               ("anim.sample_form", 2, 3), ("anim.overlap", 2, 3), ("anim.inline_ctrl", 0, 2), ("comm.form", 2, 3),
+                               ("anim.sample_form", 2, 3), ("anim.overlap", 1, 2), ("debug.overlap", 2, 3), ("anim.frame_skin", 1, 2), ("debug.frame_skin", 3, 4), ("anim.inline_ctrl", 0, 2), ("comm.form", 2, 3),
                                    ("anim.ctrl_upload", 0, 3), ("anim.update_lean", 0, 2), ("anim.update_pack", 2, 3), ("anim.one_launch", 0, 2), ("debug.timeline", 0, None),
                                ("lbs.timing", 1, None)):
             if key == "lbs.streams":

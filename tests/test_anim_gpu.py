@@ -136,11 +136,14 @@ def check_frame(p, o, sc, n_instances, f):
     for a in range(len(sc.animations)):
         if a in gone:      # its record stays what it was (the pose PlayAnimation nodes keep using); nothing to compare with
             continue
-        got = p.read(A.READ_ANIMATION_POSE + a)
-        ref = o.animation_pose(a)
-        for i in (0, n_instances - 1):
-            check_pose(got[i], ref, exact, f"{sc.name} frame {f} animation {a} pose (instance {i})", None if exact else taint.pose[a])
-        _all_instances_equal_the_first(got, f"{sc.name} frame {f} animation {a} pose")
+        # the pose's two views (a node's pose is a LIST: include/fyrox_hip.h, FYX_READ_ANIMATION_BLEND_VIEW): what it applies, what a blend reads of it
+        # (an animator without a machine blends nothing and keeps the apply view only)
+        for what, view in ((A.READ_ANIMATION_POSE, "apply"), (A.READ_ANIMATION_BLEND_VIEW, "read" if sc.machine is not None else "apply")):
+            got = p.read(what + a)
+            ref = o.animation_pose(a, view)
+            for i in (0, n_instances - 1):
+                check_pose(got[i], ref, exact, f"{sc.name} frame {f} animation {a} pose, {view} view (instance {i})", None if exact else taint.pose[a])
+            _all_instances_equal_the_first(got, f"{sc.name} frame {f} animation {a} pose, {view} view")
     trs, loc, glo = p.read(A.READ_LOCAL_TRS), p.read(A.READ_LOCAL_MATRIX), p.read(A.READ_GLOBAL_MATRIX)
     for name, arr in (("node TRS", trs), ("local matrices", loc), ("global matrices", glo)):
         _all_instances_equal_the_first(arr, f"{sc.name} frame {f} {name}")
@@ -679,7 +682,7 @@ def test_pipelined_frames_are_bit_identical_to_one_stream_frames(ctx, orc):
         ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
         nv = mesh.n_verts * n_inst
         outs = [(ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 12 + 64), ctx.malloc(nv * 16 + 64)) for _ in range(n_frames)]
-        ctx.set_option("anim.overlap", overlap)
+        ctx.set_option("debug.overlap", overlap)
         ctx.set_option("lbs.streams", 2 if overlap else 1)
         try:
             for f in range(n_frames):

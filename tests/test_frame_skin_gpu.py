@@ -122,7 +122,7 @@ def test_forms_of_the_frame_and_every_fallback_give_the_same_vertices(ctx, orc):
     try:
         for f in range(24):
             fs, one, inl, lean, units = forms[f % len(forms)]
-            for k, v in (("anim.frame_skin", fs), ("anim.one_launch", one), ("anim.inline_ctrl", inl), ("anim.update_lean", lean), ("anim.frame_skin_units", units)):
+            for k, v in (("debug.frame_skin", fs), ("anim.one_launch", one), ("anim.inline_ctrl", inl), ("anim.update_lean", lean), ("anim.frame_skin_units", units)):
                 ctx.set_option(k, v)
             _oupdate(o, sc)
             _update(p, sc)
@@ -381,7 +381,7 @@ def test_a_scene_whose_update_launch_skins(ctx, orc):
     try:
         for f in range(27):
             fs, units, lean = forms[f % len(forms)]
-            ctx.set_option("anim.frame_skin", fs)
+            ctx.set_option("debug.frame_skin", fs)
             ctx.set_option("anim.frame_skin_units", units)
             ctx.set_option("anim.update_lean", lean)
             for ch in chars:
@@ -439,7 +439,7 @@ def test_a_scene_frame_in_one_launch_over_many_frames_and_its_timeout(ctx, orc):
     ctx.set_option("anim.wait_timeout_ms", 50)
     try:
         for f in range(2000):
-            ctx.set_option("anim.frame_skin", 3)
+            ctx.set_option("debug.frame_skin", 3)
             A.scene_update(ctx, [c_[0] for c_ in sets[0]], sc.dt)
             ctx.set_option("anim.frame_skin", 0)
             A.scene_update(ctx, [c_[0] for c_ in sets[1]], sc.dt)
@@ -454,7 +454,7 @@ def test_a_scene_frame_in_one_launch_over_many_frames_and_its_timeout(ctx, orc):
         victim = sets[0][5]
         before = victim[2].pos.download(np.uint32, nv * 3)
         assert _native.lib().fyx_debug_frame_counter_add(ctx._h, victim[0].id, -100000) == 0
-        ctx.set_option("anim.frame_skin", 3)
+        ctx.set_option("debug.frame_skin", 3)
         A.scene_update(ctx, [c_[0] for c_ in sets[0]], sc.dt)
         ctx.sync()
         assert ctx.last_error().startswith("warning") and str(victim[0].id) in ctx.last_error()
@@ -511,8 +511,8 @@ def test_a_pipelined_scene_with_palette_pairs_equals_the_one_stream_scene(ctx, o
                 rec["out"] = Outs(ctx, n_inst * nv)
                 p.set_skin_output(base + 50, base + 60, rec["out"].pos.ptr, rec["out"].nrm.ptr, rec["out"].tan.ptr)
             chars.append(rec)
-        ctx.set_option("anim.frame_skin", frame_skin)
-        ctx.set_option("anim.overlap", overlap)
+        ctx.set_option("debug.frame_skin", frame_skin)
+        ctx.set_option("debug.overlap", overlap)
         try:
             for f in range(n_frames):
                 for ch in chars:
@@ -595,7 +595,7 @@ def test_steady_scene_frames_keep_their_plans_and_follow_every_change(ctx, orc, 
     changes[44] = "mesh"
     changes[51] = "members"
     changes[58] = "members_back"
-    ctx.set_option("anim.overlap", overlap)
+    ctx.set_option("debug.overlap", overlap)
     ctx.set_option("debug.host_times", 1)
     ctx.host_times()
     steady = []
@@ -679,7 +679,7 @@ def test_current_palette_is_the_animators_own_last_frame_whatever_other_animator
         mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + 43)
         ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
         chars.append({"sc": sc, "p": p, "nb": nb, "pals": pals, "mesh": mesh, "mid": base + 60, "out": Outs(ctx, nv), "o": cases.build_oracle(orc, sc), "wrote": []})
-    ctx.set_option("anim.overlap", mode)
+    ctx.set_option("debug.overlap", mode)
     try:
         for f in range(9):
             for ch in chars:

@@ -88,7 +88,8 @@ def _compare_frame(o1, o2, sc, f):
     for a in range(len(sc.animations)):
         if a in gone:
             continue
-        same(o1.animation_pose(a), o2.animation_pose(a), f"{sc.name} frame {f}: animation {a} pose")
+        for view in ("apply", "read"):      # (a node's pose is a list: what it applies, what a blend reads of it)
+            same(o1.animation_pose(a, view), o2.animation_pose(a, view), f"{sc.name} frame {f}: animation {a} pose, {view} view")
         s1, s2 = o1.animation_state(a), o2.animation_state(a)
         assert s1["enabled"] == s2["enabled"] and s1["has_ended"] == s2["has_ended"], (sc.name, f, a)
         same([s1["time_position"]], [s2["time_position"]], f"{sc.name} frame {f}: animation {a} time")
@@ -141,7 +142,8 @@ SCENARIOS = [cases.random_attacks, cases.c5_blend_tree, cases.player_only, cases
              cases.fbx_like, cases.gltf_like, cases.morph_weights, cases.morph_weights_player, cases.property_kinds,
              cases.property_kinds_euler, cases.property_kinds_player, cases.removed_clips, cases.looping_root_motion,
              cases.with_root_motion_and_signals(cases.c5_blend_tree), cases.with_root_motion_and_signals(cases.transitions),
-             cases.with_root_motion_and_signals(cases.layered)]
+             cases.with_root_motion_and_signals(cases.layered), cases.duplicate_bindings, cases.duplicate_bindings_player, cases.duplicate_properties,
+             cases.with_root_motion_and_signals(cases.duplicate_bindings)]
 
 
 @pytest.mark.parametrize("make", SCENARIOS, ids=lambda m: getattr(m, "__name__", "rm"))
