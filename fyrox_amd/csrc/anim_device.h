@@ -121,7 +121,6 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             FYX_HIP(c, hipMemset(A.d_hints, 0, std::max<size_t>(hb, 16)));
         }
         if (A.d_slot_hints) FYX_HIP(c, hipMemset(A.d_slot_hints, 0, A.slot_hint_words * 4));
-        if (A.d_cursors) FYX_HIP(c, hipMemset(A.d_cursors, 0xff, A.cursor_recs * 256));
         A.dev_anim_capacity *= 2;
         A.dev_prop_anims *= 2;
         A.dev_rm_anim_capacity *= 2;
@@ -157,9 +156,8 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         A.dev_track_capacity = new_tracks;
         A.anims_dirty = true;
     }
-    // The per-instance sampler's own state -- cursors (256 bytes per (animation, instance, node)) and, for tracks without span records, one
-    // hint word per (animation, node, binding, curve, instance) -- only while the animator runs that form (launch_pose_sample's rule: a
-    // crowd's form reads neither, and a 10 000-instance crowd would carry hundreds of MB of them for nothing: ADVICE r5).
+    // The per-instance sampler's own hints -- one word per (animation, node, binding, curve, instance) -- only while the animator runs that
+    // form (launch_pose_sample's rule: a crowd's form never reads them, and a 10 000-instance crowd would carry 120 MB for nothing: ADVICE r5).
     if (c->sample_form == 1 || (c->sample_form == 0 && A.n_instances < 32)) {
         const size_t want = (size_t)std::max(A.dev_anim_capacity, 1u) * rig.n_nodes * 12 * A.n_instances;
         if (want > A.slot_hint_words) {
@@ -170,16 +168,6 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_slot_hints), std::max<size_t>(want * 4, 16)));
             FYX_HIP(c, hipMemset(A.d_slot_hints, 0, std::max<size_t>(want * 4, 16)));
             A.slot_hint_words = want;
-        }
-        const size_t recs = (size_t)std::max(A.dev_anim_capacity, 1u) * in;
-        if (recs > A.cursor_recs) {
-            if (int rc_ = sync_all(c)) return rc_;
-            dfree(A.d_cursors);
-            A.d_cursors = nullptr;
-            A.cursor_recs = 0;
-            FYX_HIP(c, hipMalloc(reinterpret_cast<void**>(&A.d_cursors), std::max<size_t>(recs * 256, 256)));
-            FYX_HIP(c, hipMemset(A.d_cursors, 0xff, std::max<size_t>(recs * 256, 256)));      // nothing cached
-            A.cursor_recs = recs;
         }
     }
     // slot tables + animation descriptors
@@ -264,9 +252,6 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         A.d_crowd = nullptr;
         if (!cd.empty())
             if (int rc = upload(c, &A.d_crowd, cd.data(), cd.size())) return rc;
-        // (what the cursors cached belongs to the old bindings)
-        FYX_HIP(c, launch_cursor_stale(A.d_cursors, A.cursor_recs, c->stream));
-        if (A.d_cursors) FYX_HIP(c, hipStreamSynchronize(c->stream));      // (the frame's sampler may run on the other frame stream)
         A.anims_dirty = false;
     }
     const uint32_t nps = (uint32_t)A.prop_slots.size();
@@ -397,7 +382,6 @@ void frame_static(const fyx_ctx* c, const Animator& A, PoseFrameDev& f) {
     f.layer_masks = A.d_layer_masks;
     f.hints = A.d_hints;
     f.slot_hints = A.d_slot_hints;
-    f.cursors = A.d_cursors;
     f.max_tracks = A.dev_track_capacity;
     f.sample_form = (uint32_t)c->sample_form;
     f.anim_pose = A.d_anim_pose;

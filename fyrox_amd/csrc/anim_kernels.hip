@@ -289,140 +289,43 @@ __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a,
 // (the kernel is VALU-issue bound: ~64 K waves of a few hundred instructions each for the C3 crowd).
 // WRITE_THROUGH: the record is stored with agent-scope (sc1) stores, which go through the XCD's L2 to memory -- for the one-launch frame,
 // whose update workgroups (on other XCDs, each with its own L2) read the records while this kernel is still running.
-// Link flags of a cursor (PoseFrameDev::cursors): 0xffffffff = never written
-constexpr uint32_t kCurInit = 1u, kCurValid = 2u, kCurKindShift = 2u, kCurSpans = 32u, kCurPresentShift = 8u;
-
-// The per-curve general path of sample_curve on a hint the caller keeps: clamps, hinted span, neighbours, binary search, in the reference's
-// order on the per-curve key records.
-__device__ __forceinline__ float sample_general(const PoseFrameDev& f, uint32_t a, uint32_t track, uint32_t c, uint32_t& hint, float time) {
-    const AnimDev an = f.anims[a];
-    const TrackDev* tk = an.tracks + track;
-    const uint32_t fk = tk->first_key[c];
-#if FYX_KEYREC
-    return curve_value_at(RecLoc{an.key_rec + fk}, RecAux{an.key_rec + fk}, tk->n_keys[c], curve_ends(tk, (int)c), time, hint);
-#else
-    return curve_value_at(an.key_loc + fk, reinterpret_cast<const f4*>(an.key_aux) + fk, tk->n_keys[c], curve_ends(tk, (int)c), time, hint);
-#endif
-}
-
-// ITER: 16-node slices a workgroup samples, one after another with ALL their cursor loads requested up front.  One character's launches
-// keep 1 (sixteen nodes per workgroup: more workgroups for one instance's chain of round trips); a scene's launch takes 4 -- a quarter of
-// the workgroups, all of them resident at once, each paying the scene form's two scalar round trips (block table, job) once for 64 nodes.
-template <bool WRITE_THROUGH = false, int ITER = 1>
+template <bool WRITE_THROUGH = false>
 __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t bx, uint32_t by, uint32_t bz) {
     const uint32_t lane = threadIdx.x & 63u, j = threadIdx.x & 15u, gbase = lane & ~15u;
     const uint32_t a = bz, inst = by;
-    // which binding / curve this lane serves
-    int bind = -1, c = 0;
-    uint32_t hb = 0;                                                 // the binding's header in the cursor
-    if (j < 3) { bind = FYX_BIND_POSITION; c = (int)j; hb = 0u; }
-    else if (j >= 4 && j < 8) { bind = FYX_BIND_ROTATION; c = (int)j - 4; hb = 4u; }
-    else if (j >= 8 && j < 11) { bind = FYX_BIND_SCALE; c = (int)j - 8; hb = 9u; }
-    // The cursors first (round 6): header, this curve's part and the track's link lie in ONE 256-byte record, requested together with
-    // the clock -- in steady playback nothing else is read.  (Lane 3 writes the present bits: they ride in every link.)
-    f4 hdr_[ITER], piece_[ITER], link_[ITER];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const uint32_t node = ((bx * (uint32_t)ITER + (uint32_t)it) * 256u + threadIdx.x) >> 4;
-        hdr_[it] = piece_[it] = link_[it] = f4{0.f, 0.f, 0.f, 0.f};
-        if (node >= f.n_nodes) continue;                                 // uniform across the group
-        const f4* cur = reinterpret_cast<const f4*>(f.cursors) + (((size_t)a * f.n_instances + inst) * f.n_nodes + node) * 16u;
-        link_[it] = cur[13u + (uint32_t)(bind >= 0 ? bind : 0)];
-        if (bind >= 0) { hdr_[it] = cur[hb]; piece_[it] = cur[hb + 1u + (uint32_t)c]; }
-    }
-    const float time = f.times[(size_t)inst * f.n_anims + a];
-    if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;          // uniform across the block
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const uint32_t node = ((bx * (uint32_t)ITER + (uint32_t)it) * 256u + threadIdx.x) >> 4;
-        if (node >= f.n_nodes) continue;                                 // uniform across the group
+    const uint32_t node = (bx * 256u + threadIdx.x) >> 4;
+    {
+        if (node >= f.n_nodes) return;                                   // uniform across the group
+        // which binding / curve this lane serves
+        int bind = -1, c = 0;
+        if (j < 3) { bind = FYX_BIND_POSITION; c = (int)j; }
+        else if (j >= 4 && j < 8) { bind = FYX_BIND_ROTATION; c = (int)j - 4; }
+        else if (j >= 8 && j < 11) { bind = FYX_BIND_SCALE; c = (int)j - 8; }
+        // The animator's descriptor of (animation, node, binding) -- CrowdDesc: slot table, track record and TrackHot resolved
+        // by the host -- is two 16-byte loads off a kernel argument; the chain animation record -> slot -> TrackHot it replaces
+        // was three dependent round trips ahead of the hint.  (Lane 3 writes the present bits: they are in every descriptor.)
+        // Requested BEFORE the tick flag is looked at: its address does not depend on it, and the early return below would
+        // otherwise put a round trip of its own in front of this one.
+        const CrowdDesc d = f.crowd[((size_t)a * f.n_nodes + node) * 3 + (uint32_t)(bind >= 0 ? bind : 0)];
+        // ... and the lane's span hint with it: its slot is a function of (animation, node, binding, curve, instance), nothing the
+        // descriptor has to say first (round 5: one dependent round trip less in a kernel that is made of them)
+        uint32_t* hp = f.slot_hints + ((((size_t)a * f.n_nodes + node) * 3 + (uint32_t)(bind >= 0 ? bind : 0)) * 4 + (uint32_t)c) * f.n_instances + inst;
+        uint32_t hint = 0;
+        if (bind >= 0) hint = *hp;
+        const float time = f.times[(size_t)inst * f.n_anims + a];
+        if (!(f.ticked[(size_t)inst * f.n_anims + a] & 1u)) return;      // uniform across the block
         const size_t item = ((size_t)a * f.n_instances + inst) * f.n_nodes + node;
-        f4* cur = reinterpret_cast<f4*>(f.cursors) + item * 16u;
-        f4 hdr = hdr_[it], piece = piece_[it];
-        const f4 link = link_[it];
-        const size_t desc_at = ((size_t)a * f.n_nodes + node) * 3 + (uint32_t)(bind >= 0 ? bind : 0);
-        uint32_t flags = f2u(link.w);
-        int kind = -1;
+        const int32_t track = bind >= 0 && (d.valid || d.kind >= 0) ? (int32_t)d.track : -1;
+        const bool has_prop = j == 3 && (d.present & 8u);
+        int kind = -1, need = 0;
         bool valid = false;
         float v = 0.0f;
-        uint32_t present = (flags >> kCurPresentShift) & 0xffu;
-        if (flags == 0xffffffffu && bind < 0) present = f.crowd[desc_at].present;        // (first frame: the links are written below)
-        if (bind >= 0) {
-            // what the link says about the track -- or, before the first frame has written it, the descriptor
-            const f4* spans = reinterpret_cast<const f4*>(((uint64_t)f2u(link.y) << 32) | (uint64_t)f2u(link.x));
-            uint32_t n_keys = f2u(link.z) >> 16, hint = f2u(link.z) & 0xffffu, track = 0;
-            bool have_desc = false;
-            CrowdDesc d;
-            if (flags == 0xffffffffu) {
-                d = f.crowd[desc_at];
-                have_desc = true;
-                const bool cursorable = d.valid && d.spans && d.n_keys >= 2u && d.n_keys <= 0xffffu;
-                flags = kCurInit | (d.valid ? kCurValid : 0u) | (((uint32_t)d.kind & 7u) << kCurKindShift) | (cursorable ? kCurSpans : 0u) | ((d.present & 0xffu) << kCurPresentShift);
-                spans = reinterpret_cast<const f4*>(d.spans);
-                n_keys = d.n_keys;
-                hint = f2u(link.z) == 0xffffffffu || hint >= n_keys ? 0u : hint;      // (a link made stale by an edit keeps its hint: cursor_stale_kernel)
-                hdr.x = __builtin_nanf("");
-                if (c == 0) cur[13u + (uint32_t)bind] = f4{u2f((uint32_t)(uintptr_t)spans), u2f((uint32_t)((uintptr_t)spans >> 32)), u2f(n_keys << 16), u2f(flags)};
-            }
-            kind = (int)((flags >> kCurKindShift) & 7u);
-            valid = (flags & kCurValid) != 0u;
-            const int need = kind == FYX_KIND_QUAT ? 4 : 3;
-            if (valid && c < need) {
-                if (flags & kCurSpans) {
-                    const uint32_t stride = span_stride((uint32_t)need);
-                    bool sampled = false, moved = false;
-                    if (hdr.x < time && time < hdr.y) {
-                        // steady playback: strictly inside the cached span Curve::value_at clamps nothing, takes this span whatever its
-                        // hint says and leaves the hint at the span's right key (curve.rs:254-314)
-                        v = interpolate_span(hdr.x, hdr.y, span_kind(hdr, (uint32_t)c), piece, time);
-                        sampled = true;
-                    } else if (hdr.y < time && hint + 1u < n_keys) {
-                        // playback crossed the span's right key: strictly inside the NEXT span partition_point(k.location < time) is hint + 1
-                        const f4* r = spans + (size_t)hint * stride;
-                        const f4 h2 = r[0], p2 = r[1 + c];
-                        if (h2.x < time && time < h2.y) {
-                            v = interpolate_span(h2.x, h2.y, span_kind(h2, (uint32_t)c), p2, time);
-                            hint += 1u; hdr = h2; piece = p2; sampled = moved = true;
-                        }
-                    } else if (time < hdr.x && hint >= 2u) {
-                        // reverse playback crossed the left key: strictly inside the PREVIOUS span the search returns hint - 1
-                        const f4* r = spans + (size_t)(hint - 2u) * stride;
-                        const f4 h2 = r[0], p2 = r[1 + c];
-                        if (h2.x < time && time < h2.y) {
-                            v = interpolate_span(h2.x, h2.y, span_kind(h2, (uint32_t)c), p2, time);
-                            hint -= 1u; hdr = h2; piece = p2; sampled = moved = true;
-                        }
-                    }
-                    if (!sampled) {
-                        // everything else (the first frame, a clamp at either end, a jump, a time exactly on a key): the reference's decisions on
-                        // the per-curve records; then the cursor takes the span the hint now names (none: hint 0 / past the last key)
-                        if (!have_desc) track = f.crowd[desc_at].track; else track = d.track;
-                        v = sample_general(f, a, track, (uint32_t)c, hint, time);
-                        if (hint >= 1u && hint < n_keys) {
-                            const f4* r = spans + (size_t)(hint - 1u) * stride;
-                            hdr = r[0];
-                            piece = r[1 + c];
-                        } else {
-                            hdr = f4{__builtin_nanf(""), 0.f, 0.f, 0.f};
-                        }
-                        moved = true;
-                    }
-                    if (moved) {
-                        cur[hb + 1u + (uint32_t)c] = piece;
-                        if (c == 0) {
-                            cur[hb] = hdr;
-                            cur[13u + (uint32_t)bind] = f4{u2f((uint32_t)(uintptr_t)spans), u2f((uint32_t)((uintptr_t)spans >> 32)), u2f((n_keys << 16) | (hint & 0xffffu)), u2f(flags)};
-                        }
-                    }
-                } else {
-                    // a track whose curves do not share their key times (no span records), or too long for the link: per-curve hints, as before
-                    if (!have_desc) d = f.crowd[desc_at];
-                    uint32_t* hp = f.slot_hints + ((desc_at * 4u) + (uint32_t)c) * f.n_instances + inst;
-                    v = sample_curve(f, a, d, (uint32_t)c, hp, *hp, time);
-                }
-            }
+        if (track >= 0) {
+            kind = d.kind;
+            need = (int)d.need;
+            valid = d.valid != 0;                                 // else fetch() -> None
+            if (valid && c < need) v = sample_curve(f, a, d, (uint32_t)c, hp, hint, time);
         }
-        const bool has_prop = j == 3 && (present & 8u);
         const int has_p = __shfl((int)valid, (int)gbase + 0, 64);
         const int has_r = __shfl((int)valid, (int)gbase + 4, 64);
         const int has_s = __shfl((int)valid, (int)gbase + 8, 64);
@@ -432,7 +335,7 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
 
         float out;
         if (j < 3 || (j >= 8 && j < 11)) out = v;   // an absent binding sampled nothing: 0
-        else if (j == 3) out = __uint_as_float((has_p ? 1u : 0u) | (has_s ? 2u : 0u) | (has_r ? 4u : 0u) | (has_prop ? 8u : 0u) | (present & 16u));   // (16: the node's list holds a value that fits no binding)
+        else if (j == 3) out = __uint_as_float((has_p ? 1u : 0u) | (has_s ? 2u : 0u) | (has_r ? 4u : 0u) | (has_prop ? 8u : 0u) | (d.present & 16u));   // (16: the node's list holds a value that fits no binding)
         else if (j == 4) out = q.x;
         else if (j == 5) out = q.y;
         else if (j == 6) out = q.z;
@@ -495,11 +398,10 @@ __device__ __forceinline__ PoseFrameDev scene_frame_of(const SceneJobDev* __rest
     return f;
 }
 
-constexpr int kSceneSampleIter = 4;      // 64 nodes per workgroup of the scene's sampler (scene_blocks deals its table out accordingly)
 __global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
     const uint4 b = blocks[blockIdx.x];
     const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
-    pose_sample_body<false, kSceneSampleIter>(f, b.y, b.z, b.w);
+    pose_sample_body(f, b.y, b.z, b.w);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -696,27 +598,6 @@ __global__ __launch_bounds__(64) void pose_sample_crowd_scene_kernel(const Scene
     const uint4 b = blocks[blockIdx.x];
     const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
     pose_sample_crowd_body<64>(f, b.y, b.z, b.w);
-}
-
-// The animator's tracks were bound again (a track switched on or off, an animation added): what the cursors cached of the old bindings is
-// void, the span hints they carried stay (TrackBinding keeps its hints through such edits; a hint is advisory wherever it points).
-__global__ __launch_bounds__(256) void cursor_stale_kernel(float4* __restrict__ cursors, size_t n_recs) {
-    const size_t e = (size_t)blockIdx.x * 256u + threadIdx.x;      // one thread per (record, binding)
-    if (e >= n_recs * 3u) return;
-    const size_t rec = e / 3u;
-    const uint32_t b = (uint32_t)(e - rec * 3u);
-    f4* cur = reinterpret_cast<f4*>(cursors) + rec * 16u;
-    f4 link = cur[13u + b];
-    if (f2u(link.w) != 0xffffffffu) {
-        link.w = u2f(0xffffffffu);
-        cur[13u + b] = link;
-    }
-    cur[b == (uint32_t)FYX_BIND_POSITION ? 0u : b == (uint32_t)FYX_BIND_ROTATION ? 4u : 9u].x = __builtin_nanf("");
-}
-hipError_t launch_cursor_stale(float4* cursors, size_t n_recs, hipStream_t s) {
-    if (!cursors || !n_recs) return hipSuccess;
-    hipLaunchKernelGGL(cursor_stale_kernel, dim3((uint32_t)((n_recs * 3u + 255u) / 256u)), dim3(256), 0, s, cursors, n_recs);
-    return hipGetLastError();
 }
 
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl) {
@@ -2284,7 +2165,7 @@ void scene_blocks(uint32_t job, const SceneJobShape& s, std::vector<uint4> (&t)[
                 for (uint32_t y = 0; y < s.n_nodes * 3; ++y)
                     for (uint32_t x = 0; x < gx; ++x) t[kStageSampleCrowd].push_back(make_uint4(job, x, y, a));
         } else {
-            const uint32_t gx = (s.n_nodes * 16 + 256 * kSceneSampleIter - 1) / (256 * kSceneSampleIter);      // (pose_sample_scene_kernel: 64 nodes per workgroup)
+            const uint32_t gx = (s.n_nodes * 16 + 255) / 256;
             for (uint32_t a = 0; a < s.n_anims; ++a)
                 for (uint32_t i = 0; i < s.n_instances; ++i)
                     for (uint32_t x = 0; x < gx; ++x) t[kStageSample].push_back(make_uint4(job, x, i, a));

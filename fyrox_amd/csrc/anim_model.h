@@ -212,8 +212,6 @@ struct Animator {
     uint32_t* d_hints = nullptr;
     uint32_t* d_slot_hints = nullptr;       // PoseFrameDev::slot_hints (hints are advisory: a fresh array of zeros is "no hint")
     size_t slot_hint_words = 0;
-    float4* d_cursors = nullptr;            // PoseFrameDev::cursors: 256 bytes per (device animation, instance, node); with slot_hints, only while
-    size_t cursor_recs = 0;                 //   the animator runs the per-instance sampler (a crowd's form reads neither)
     float4* d_anim_pose = nullptr;
     uint32_t dev_anim_capacity = 0, dev_track_capacity = 0;
     float4* d_node_trs = nullptr;

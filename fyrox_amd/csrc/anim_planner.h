@@ -26,7 +26,7 @@ void free_animator(Animator& a) {
     for (auto& an : a.anims) { dfree(an.d_slot_track); dfree(an.d_prop_track); dfree(an.d_slot_track_f); dfree(an.d_prop_track_f); }
     dfree(a.d_prop_node); dfree(a.d_prop_pose); dfree(a.d_prop_out);
     dfree(a.d_anims); dfree(a.d_crowd); dfree(a.d_hints); dfree(a.d_anim_pose); dfree(a.d_node_trs); dfree(a.d_local);
-    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_rm_anim); dfree(a.d_rm_slots); dfree(a.d_frame_counter); dfree(a.d_slot_hints); dfree(a.d_cursors);
+    dfree(a.d_global); dfree(a.d_layer_masks); dfree(a.d_rm_anim); dfree(a.d_rm_slots); dfree(a.d_frame_counter); dfree(a.d_slot_hints);
     free_ctrl(a.ctrl);
 }
 

@@ -322,14 +322,6 @@ struct PoseFrameDev {
     uint32_t sample_form;        // 0 auto (instances on the lanes from 32 instances), 1 curves on the lanes, 2 instances on the lanes
     uint32_t* slot_hints;        // [n_anims][n_nodes][3 bindings][4 curves][n_instances]: the per-instance sampler's span hints, indexed by what the
                                  //   lane knows BEFORE it has its descriptor (round 5: the hint's load no longer waits for the descriptor's)
-    // The per-instance sampler's CURSORS (round 6): 256 bytes per (animation, instance, node) -- the span record each of the node's three
-    // tracks is in (header {left time, right time, key kinds} + one part per curve: what Curve::value_at reads while playback stays inside
-    // that span) and, per track, a link {span table, n_keys << 16 | hint, flags}.  Steady playback is ONE round trip: cursor -> value;
-    // a crossed key goes on to the neighbouring span through the link and rewrites the cursor; everything else takes the descriptor path.
-    //   f4 [0] Position header, [1..3] its curves; [4] Rotation header, [5..8] curves; [9] Scale header, [10..12] curves; [13 + binding] links
-    // All 0xff = nothing cached.  Null: the animator runs the crowd form.
-    float4* cursors;
-    uint64_t pad_cursors;
     float4* anim_pose;           // [n_anims][n_instances][n_nodes][3]
     float4* node_trs;            // [n_instances][n_nodes][3]: {pos,_} {rot} {scale,_}
     float* local;                // [n_instances][n_nodes][16]
@@ -406,8 +398,6 @@ hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uin
 
 // `inl` (optional): the frame's control block travelling in the kernel arguments, see CtrlInline.
 hipError_t launch_pose_sample(const PoseFrameDev& f, hipStream_t s, const CtrlInline* inl = nullptr);
-// Voids what an animator's sampler cursors cached (PoseFrameDev::cursors), keeping the span hints they carry.
-hipError_t launch_cursor_stale(float4* cursors, size_t n_recs, hipStream_t s);
 // mode: kUpdNoProgram -- the transforms as they are; kUpdGeneral -- fold programs of any shape; kUpdStraight -- the caller
 // has classified EVERY instance's program as straight (classify_fold_program_host, anim_leaves.h): a kernel without the
 // interpreter (a third of the registers).

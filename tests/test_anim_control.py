@@ -447,9 +447,7 @@ def test_scene_block_tables_cover_every_animators_own_grid_exactly_once():
         want = {(x, y, a) for a in range(na) for y in range(nn * 3) for x in range((n + 63) // 64)} if crowd else set()
         got = of(S_CROWD, k)
         assert len(got) == len(set(got)) and set(got) == want, (sc.name, "crowd sampler")
-        # (the scene's sampler takes 64 nodes per workgroup -- pose_sample_body<.., ITER = 4>, four 16-node slices with all their loads
-        # requested up front -- where the animator's own launch takes 16)
-        want = set() if crowd else {(x, i, a) for a in range(na) for i in range(n) for x in range((nn * 16 + 1023) // 1024)}
+        want = set() if crowd else {(x, i, a) for a in range(na) for i in range(n) for x in range((nn * 16 + 255) // 256)}
         got = of(S_SAMPLE, k)
         assert len(got) == len(set(got)) and set(got) == want, (sc.name, "sampler")
         want = {(x, i, a) for a in range(na) for i in range(n) for x in range((nps + 255) // 256)} if nps else set()
