@@ -49,6 +49,14 @@ __device__ unsigned long long g_fstamp[1024 * 8];
 #else
 #define FSTAMP(i) do {} while (0)
 #endif
+// Experiment builds only (tools/exp/r06_scene_stamps_build.sh, -DFYX_SCENE_STAMPS): thread 0 of every workgroup of the scene's sampler leaves
+// wall-clock stamps (100 MHz) -- 0 entry, 1 the job's parameters have arrived, 2 this lane's curve is sampled, 3 the record's stores are issued.
+#ifdef FYX_SCENE_STAMPS
+__device__ unsigned long long g_sstamp[8192 * 4];
+#define SSTAMP(i) do { if (threadIdx.x == 0) g_sstamp[(blockIdx.x & 8191u) * 4u + (i)] = wall_clock64(); } while (0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
 // a launch that takes the armed timeline events, if any (option debug.timeline)
 #define FYX_TL_LAUNCH(kernel, grid, block, lds, s, ...)                                                                      \
     do {                                                                                                                      \
@@ -326,6 +334,10 @@ __device__ __forceinline__ void pose_sample_body(const PoseFrameDev& f, uint32_t
             valid = d.valid != 0;                                 // else fetch() -> None
             if (valid && c < need) v = sample_curve(f, a, d, (uint32_t)c, hp, hint, time);
         }
+#ifdef FYX_SCENE_STAMPS
+        asm volatile("" : "+v"(v));
+        SSTAMP(2);
+#endif
         const int has_p = __shfl((int)valid, (int)gbase + 0, 64);
         const int has_r = __shfl((int)valid, (int)gbase + 4, 64);
         const int has_s = __shfl((int)valid, (int)gbase + 8, 64);
@@ -399,9 +411,14 @@ __device__ __forceinline__ PoseFrameDev scene_frame_of(const SceneJobDev* __rest
 }
 
 __global__ __launch_bounds__(256) void pose_sample_scene_kernel(const SceneJobDev* __restrict__ jobs, const char* __restrict__ ctrl, const uint4* __restrict__ blocks) {
+    SSTAMP(0);
     const uint4 b = blocks[blockIdx.x];
     const PoseFrameDev f = scene_frame_of(jobs, b.x, ctrl);
+#ifdef FYX_SCENE_STAMPS
+    { uint32_t nn = f.n_nodes; asm volatile("" : "+s"(nn)); SSTAMP(1); }
+#endif
     pose_sample_body(f, b.y, b.z, b.w);
+    SSTAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2250,6 +2267,10 @@ hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uin
 
 }  // namespace fyx
 
+#ifdef FYX_SCENE_STAMPS
+extern "C" int fyx_exp_scene_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fyx::g_sstamp), sizeof fyx::g_sstamp); }
+extern "C" int fyx_exp_scene_stamps_clear() { static unsigned long long z[8192 * 4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(fyx::g_sstamp), z, sizeof z); }
+#endif
 #ifdef FYX_FRAME_STAMPS
 extern "C" int fyx_exp_frame_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fyx::g_fstamp), sizeof fyx::g_fstamp); }
 #endif
