@@ -197,10 +197,40 @@ int fyx_tracks_data_upload(fyx_ctx* c, uint64_t tracks_id, uint32_t n_tracks, co
                 r[0] = make_float4(key_location[hd[t].first_key[0] + i - 1], key_location[hd[t].first_key[0] + i], kinds_f, 0.f);
             }
         }
+        // ... and once more as rows (TracksData::d_span_rows): the tracks whose key times are the first span-record track's
+        std::vector<float4> rows;
+        td.row_first.assign(n_tracks, kNoSpans);
+        {
+            int32_t lead = -1;
+            uint32_t stride_row = 0;
+            std::vector<uint32_t> members;
+            for (uint32_t t = 0; t < n_tracks; ++t) {
+                if (hot[t].span_first == kNoSpans) continue;
+                if (lead < 0) lead = (int32_t)t;
+                if (hot[t].n_keys != hot[lead].n_keys ||
+                    memcmp(key_location + hd[t].first_key[0], key_location + hd[lead].first_key[0], (size_t)hot[t].n_keys * 4) != 0) continue;
+                td.row_first[t] = stride_row;
+                stride_row += span_stride(hot[t].kind == FYX_KIND_QUAT ? 4u : 3u);
+                members.push_back(t);
+            }
+            const uint64_t total = lead >= 0 ? (uint64_t)(hot[lead].n_keys - 1u) * stride_row : 0;
+            if (members.size() >= 2 && total <= 0x7fffffffull && stride_row < (1u << 23)) {
+                rows.resize((size_t)total);
+                for (uint32_t t : members) {
+                    const uint32_t st = span_stride(hot[t].kind == FYX_KIND_QUAT ? 4u : 3u);
+                    for (uint32_t i = 0; i + 1 < hot[t].n_keys; ++i)
+                        memcpy(rows.data() + (size_t)i * stride_row + td.row_first[t], spans.data() + hot[t].span_first + (size_t)i * st, (size_t)st * 16);
+                }
+                td.row_stride = stride_row;
+            } else {
+                td.row_first.assign(n_tracks, kNoSpans);
+            }
+        }
         td.hot = hot;
         int rc = upload(c, &td.d_tracks, hd.data(), hd.size());
         if (!rc) rc = upload(c, &td.d_hot, hot.data(), hot.size());
         if (!rc && !spans.empty()) rc = upload(c, &td.d_spans, spans.data(), spans.size());
+        if (!rc && !rows.empty()) rc = upload(c, &td.d_span_rows, rows.data(), rows.size());
         if (!rc) rc = upload(c, &td.d_loc, key_location, (size_t)n_keys);
         if (!rc) rc = upload(c, &td.d_aux, aux.data(), aux.size());
         if (!rc) rc = upload(c, &td.d_rec, recs.data(), recs.size());

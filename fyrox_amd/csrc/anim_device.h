@@ -170,7 +170,9 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             A.slot_hint_words = want;
         }
     }
-    // slot tables + animation descriptors
+    // slot tables + animation descriptors (made for the sampler form the animator runs: launch_pose_sample's rule)
+    const int inst_form = (c->sample_form == 1 || (c->sample_form == 0 && A.n_instances < 32)) ? 1 : 0;
+    if (A.desc_form != inst_form) A.anims_dirty = true;
     bool any_slots = false;
     for (AnimationDef& an : A.anims) any_slots |= an.slots_dirty;
     if (any_slots || A.anims_dirty) {
@@ -241,7 +243,13 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
                     d[b].need = need;
                     d[b].valid = fits && need > 0 && th.n_curves >= need;
                     d[b].n_keys = th.n_keys;
-                    if (d[b].valid && th.span_first != kNoSpans && an.td->d_spans) d[b].spans = an.td->d_spans + th.span_first;
+                    if (d[b].valid && th.span_first != kNoSpans && an.td->d_spans) {
+                        // the per-instance sampler reads one span of every track per frame: the [span][track] copy where the track is in it;
+                        // the crowd form stages a track's whole table in LDS: the track's own
+                        const bool row = inst_form && an.td->d_span_rows && (size_t)t < an.td->row_first.size() && an.td->row_first[t] != kNoSpans;
+                        d[b].spans = row ? an.td->d_span_rows + an.td->row_first[t] : an.td->d_spans + th.span_first;
+                        d[b].valid |= (row ? an.td->row_stride : span_stride(need)) << 8;
+                    }
                     if (d[b].valid) present |= b == FYX_BIND_POSITION ? 1u : b == FYX_BIND_SCALE ? 2u : 4u;
                 }
                 if (view.size() == (size_t)rig.n_nodes * 4 && view[(size_t)node * 4 + 3] >= 0) present |= 8u;
@@ -253,6 +261,7 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
         if (!cd.empty())
             if (int rc = upload(c, &A.d_crowd, cd.data(), cd.size())) return rc;
         A.anims_dirty = false;
+        A.desc_form = inst_form;
     }
     const uint32_t nps = (uint32_t)A.prop_slots.size();
     if (nps && (A.dev_prop_slots != nps || A.dev_prop_anims < A.dev_anim_capacity)) {

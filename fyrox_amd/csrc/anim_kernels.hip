@@ -230,15 +230,18 @@ struct RecAux {
 // hp / hint: the curve's span hint and where it lives (the caller requested it together with the descriptor)
 __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a, const CrowdDesc& d, uint32_t c, uint32_t* hp, uint32_t hint, float time) {
     const uint32_t track = d.track;
-    const int need = (int)d.need;
     float v = 0.0f;
     // Steady playback: the time lies strictly inside the hinted span [key hint - 1, key hint).  Curve::value_at then
     // clamps nothing (first.location <= left < time < right <= last.location), takes its hinted span and leaves the
     // hint alone (curve.rs:254-314) -- and the track's span record (TrackHot) holds everything that needs: one cache
-    // line for the three curves of a Vector3 track, two for a quaternion's four.
+    // line for the three curves of a Vector3 track, two for a quaternion's four.  Where the clip's tracks share one time grid
+    // the records lie [span][track] (TracksData::d_span_rows, round 6): the 192 records a 64-node character reads of a clip in
+    // a frame are one dense run, not a line here and a line there.  (Requesting the neighbouring span -- the next row -- together
+    // with the hinted one, so that a crossed key costs no second round trip, was measured on top of that: 19.4 against 19.8 us,
+    // not kept; the frames that take 20 us instead of 12 are not slow because of that trip.)
     bool sampled = false;
     if (d.spans && hint >= 1 && hint < d.n_keys) {
-        const uint32_t stride = span_stride((uint32_t)need);
+        const uint32_t stride = d.valid >> 8;       // (f4 to the next span's record: the track's own table, or a row of [span][track])
         const f4* r = reinterpret_cast<const f4*>(d.spans) + (size_t)(hint - 1) * stride;
         f4 locs = r[0];
         if (locs.x < time && time < locs.y) {

@@ -15,6 +15,13 @@ struct TracksData {
     KeyRec* d_rec = nullptr;
     TrackHot* d_hot = nullptr;
     float4* d_spans = nullptr;
+    // The same span records a second time, laid out [span][track] for the tracks that share their key times with the first such track
+    // (every importer-made clip: one time grid for all bones): the per-instance sampler reads ONE span of every track of a clip per
+    // frame, and in this order those are one dense run instead of a scattered line per track (round 6).  row_first[t]: track t's record
+    // of span 0 in d_span_rows, or kNoSpans (the track keeps its own table); row_stride: f4 from one span's row to the next.
+    float4* d_span_rows = nullptr;
+    std::vector<uint32_t> row_first;
+    uint32_t row_stride = 0;
     std::vector<TrackHot> hot;     // host copy of d_hot (the animators' crowd descriptors are made from it)
     std::vector<uint32_t> n_keys0; // keys of every track's first curve
 };
@@ -208,6 +215,7 @@ struct Animator {
     // device state
     AnimDev* d_anims = nullptr;
     CrowdDesc* d_crowd = nullptr;   // [anims][nodes][3]
+    int desc_form = -1;             // the sampler form the descriptors were made for (1 per instance: span rows; 0 crowd: per-track tables)
     bool anims_dirty = true;
     uint32_t* d_hints = nullptr;
     uint32_t* d_slot_hints = nullptr;       // PoseFrameDev::slot_hints (hints are advisory: a fresh array of zeros is "no hint")

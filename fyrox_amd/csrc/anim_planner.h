@@ -16,7 +16,7 @@ AnimStore& store(fyx_ctx* c) {
 
 void dfree(void* p) { if (p) (void)hipFree(p); }
 
-void free_tracks(TracksData& t) { dfree(t.d_tracks); dfree(t.d_loc); dfree(t.d_aux); dfree(t.d_rec); dfree(t.d_hot); dfree(t.d_spans); t = TracksData(); }
+void free_tracks(TracksData& t) { dfree(t.d_tracks); dfree(t.d_loc); dfree(t.d_aux); dfree(t.d_rec); dfree(t.d_hot); dfree(t.d_spans); dfree(t.d_span_rows); t = TracksData(); }
 void free_rig(Rig& r) {
     dfree(r.d_statics); dfree(r.d_walk); dfree(r.d_inv_bind);
     r = Rig();

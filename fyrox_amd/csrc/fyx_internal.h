@@ -209,7 +209,8 @@ struct CrowdDesc {
     uint32_t n_keys;         // keys per curve
     uint32_t need;           // curves the value is made of: 3 or 4
     int32_t kind;            // FYX_KIND_*
-    uint32_t valid;          // the animation provides this binding for the node (TrackDataContainer::fetch gives Some)
+    uint32_t valid;          // bit 0: the animation provides this binding for the node (TrackDataContainer::fetch gives Some); bits 8 ..: f4 from one
+                             //   span's record to the next in `spans` (need + 1 in a track's own table, the row stride in TracksData::d_span_rows)
     uint32_t present;        // the node's present bits in this animation: 1 Position, 2 Scale, 4 Rotation, 8 a Property value
 };
 static_assert(sizeof(CrowdDesc) == 32, "one s_load_dwordx8");
