@@ -54,8 +54,11 @@ __device__ unsigned long long g_fstamp[1024 * 8];
 #ifdef FYX_SCENE_STAMPS
 __device__ unsigned long long g_sstamp[8192 * 4];
 #define SSTAMP(i) do { if (threadIdx.x == 0) g_sstamp[(blockIdx.x & 8191u) * 4u + (i)] = wall_clock64(); } while (0)
+__device__ unsigned int g_spath[4];      // curve samples by exit: 0 inside the hinted span, 1 next span, 2 previous span, 3 the general path
+#define SPATH(i) atomicAdd(&g_spath[i], 1u)
 #else
 #define SSTAMP(i) do {} while (0)
+#define SPATH(i) do {} while (0)
 #endif
 // a launch that takes the armed timeline events, if any (option debug.timeline)
 #define FYX_TL_LAUNCH(kernel, grid, block, lds, s, ...)                                                                      \
@@ -247,6 +250,7 @@ __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a,
         if (locs.x < time && time < locs.y) {
             v = interpolate_span(locs.x, locs.y, span_kind(locs, c), r[1 + c], time);
             sampled = true;
+            SPATH(0);
         } else if (locs.y < time && hint + 1 < d.n_keys) {
             // playback crossed the span's right key: if the time lies strictly inside the NEXT span, nothing is clamped
             // there either, the hinted span fails, and partition_point(k.location < time) is hint + 1 (every key up to
@@ -257,6 +261,7 @@ __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a,
                 v = interpolate_span(locs.x, locs.y, span_kind(locs, c), r[1 + c], time);
                 *hp = hint + 1;
                 sampled = true;
+                SPATH(1);
             }
         } else if (time < locs.x && hint >= 2) {
             // reverse playback crossed the left key: strictly inside the PREVIOUS span the search returns hint - 1
@@ -266,10 +271,35 @@ __device__ __forceinline__ float sample_curve(const PoseFrameDev& f, uint32_t a,
                 v = interpolate_span(locs.x, locs.y, span_kind(locs, c), r[1 + c], time);
                 *hp = hint - 1;
                 sampled = true;
+                SPATH(2);
             }
         }
     }
+    if (!sampled && d.spans && d.n_keys >= 2u) {
+        // The hint is far off: a looping animation wrapped (forwards: the time is back in the FIRST span with the hint at the last key;
+        // backwards: the other way round), or it has just left a clamp at either end.  A time STRICTLY inside any span s -- key s - 1 before
+        // it, key s after it -- is interpolated over exactly those two keys whatever the incoming hint is: nothing is clamped, no other
+        // span's test can pass (keys are sorted), and partition_point(k.location < time) is s, which becomes the hint (curve.rs:254-314).
+        // So the first and the last span are worth one more round trip before the per-curve search (round 6: in a scene of 256 characters
+        // ~17 clips wrap every frame, and the workgroups that searched for them were what the whole launch waited for).
+        const uint32_t stride = d.valid >> 8;
+        const f4* first = reinterpret_cast<const f4*>(d.spans);
+        const f4* last = first + (size_t)(d.n_keys - 2u) * stride;
+        const f4 lf = first[0], ll = last[0], pf = first[1 + c], pl = last[1 + c];
+        if (lf.x < time && time < lf.y) {
+            v = interpolate_span(lf.x, lf.y, span_kind(lf, c), pf, time);
+            *hp = 1u;
+            sampled = true;
+            SPATH(1);
+        } else if (ll.x < time && time < ll.y) {
+            v = interpolate_span(ll.x, ll.y, span_kind(ll, c), pl, time);
+            *hp = d.n_keys - 1u;
+            sampled = true;
+            SPATH(2);
+        }
+    }
     if (!sampled) {   // everything else, decided in the reference's order on the per-curve records
+        SPATH(3);
         const AnimDev an = f.anims[a];
         const TrackDev* tk = an.tracks + track;
         const uint32_t fk = tk->first_key[c];
@@ -2272,7 +2302,8 @@ hipError_t launch_scene(const SceneJobDev* d_jobs, const char* d_ctrl, const uin
 
 #ifdef FYX_SCENE_STAMPS
 extern "C" int fyx_exp_scene_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fyx::g_sstamp), sizeof fyx::g_sstamp); }
-extern "C" int fyx_exp_scene_stamps_clear() { static unsigned long long z[8192 * 4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(fyx::g_sstamp), z, sizeof z); }
+extern "C" int fyx_exp_scene_stamps_clear() { static unsigned long long z[8192 * 4]; static unsigned int zp[4]; (void)hipMemcpyToSymbol(HIP_SYMBOL(fyx::g_spath), zp, sizeof zp); return (int)hipMemcpyToSymbol(HIP_SYMBOL(fyx::g_sstamp), z, sizeof z); }
+extern "C" int fyx_exp_scene_paths(unsigned int* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fyx::g_spath), sizeof fyx::g_spath); }
 #endif
 #ifdef FYX_FRAME_STAMPS
 extern "C" int fyx_exp_frame_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fyx::g_fstamp), sizeof fyx::g_fstamp); }

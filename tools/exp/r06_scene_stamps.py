@@ -33,6 +33,7 @@ for k in range(K):
     animators.append(an)
 n_wg = K * 4 * ((NB * 16 + 255) // 256)
 rows = []
+per_frame = []
 for f in range(50):
     raw.fyx_exp_scene_stamps_clear()
     A.scene_update(ctx, animators, 1.0 / 60.0)
@@ -40,6 +41,9 @@ for f in range(50):
     buf = np.zeros(8192 * 4, np.uint64)
     assert raw.fyx_exp_scene_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     st = buf.reshape(8192, 4)[:n_wg].astype(np.int64)
+    paths = np.zeros(4, np.uint32)
+    assert raw.fyx_exp_scene_paths(paths.ctypes.data_as(ctypes.c_void_p)) == 0
+    per_frame.append([int(x) for x in paths] + [float((st[:, 3].max() - st[:, 0].min()) * 10.0)])
     if f < 10:
         continue
     t0 = st[:, 0].min()
@@ -51,4 +55,5 @@ for f in range(50):
                  "started_by_us": [int((start <= t).sum()) for t in (1000, 2000, 4000, 6000, 8000, 10000, 12000, 16000, 20000)]})
 med = {k: np.median(np.asarray([r[k] for r in rows], float), axis=0).round(0).tolist() for k in rows[0]}
 print(json.dumps({"what": "pose_sample_scene_kernel, 256 x 1 x 64 nodes x 4 clips; ns; percentiles 5 / 50 / 95 / 100 over the 4096 workgroups, medians over 40 frames",
-                  "n_workgroups": n_wg, **med, "started_by_us_at": [1, 2, 4, 6, 8, 10, 12, 16, 20]}))
+                  "n_workgroups": n_wg, **med, "started_by_us_at": [1, 2, 4, 6, 8, 10, 12, 16, 20],
+                  "per_frame_curve_samples_by_exit_inside_next_prev_general_then_kernel_ns": per_frame}))
