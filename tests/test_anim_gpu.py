@@ -1123,3 +1123,60 @@ def test_overlapped_update_then_sync_then_readback_without_a_skinning_call(orc):
                 p.free()
                 for d in pals:
                     d.free()
+
+
+@pytest.mark.parametrize("n_instances", [1, 3])
+def test_list_poses_appear_while_the_machine_runs(ctx, orc, n_instances):
+    """The animator goes from one device animation per animation to two (Animator::shadows) in the middle of playback: a machine blends
+    two plain clips and a third whose tracks are all switched off; after six frames they are switched on -- and that clip's node poses
+    are lists (two Positions on a node, a Real bound to Position, ...).  Pose records, sampled values and transforms of the running
+    clips move to their new places (ensure_device_state's spread); every frame before and after is the oracle's."""
+    n_bones, seed = 16, synth.SEED_BASE + 31
+    rig = synth.make_rig(n_bones, seed)
+    td0, t0 = synth.make_clip(n_bones, seed, 0, euler_every=10 ** 9)
+    td1, t1 = synth.make_clip(n_bones, seed, 1, euler_every=10 ** 9)
+    td2, t2 = cases._listy_tracks(n_bones, seed, 0)
+    off = np.zeros(len(td2.tracks), np.uint8)
+    anims = [cases.AnimSpec(0, t0, speed=1.1), cases.AnimSpec(1, t1, speed=-0.9), cases.AnimSpec(2, t2, enabled_tracks=off, speed=1.3)]
+    layer = A.MachineLayer(
+        nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.PlayAnimation(2),
+               A.BlendAnimations([A.BlendPose(0, 0.6), A.BlendPose(2, 0.5)]),
+               A.BlendAnimations([A.BlendPose(2, 1.0), A.BlendPose(3, 0.7), A.BlendPose(1, 0.4)])],
+        states=[A.State(4)])
+    sc = cases.Scenario("late_list_clip", rig, [td0, td1, td2], anims, A.Machine(parameters=[], layers=[layer]), n_frames=30, has_euler=False)
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, n_instances)
+    try:
+        for f in range(30):
+            if f == 6:
+                for t, node in enumerate(t2):
+                    orc._alib().fo_animation_bind(o.anims[2], t, int(node), 1)
+                    p.set_track_enabled(2, t, True)
+            o.update_machine(sc.dt)
+            p.update_machine(sc.dt)
+            check_frame(p, o, sc, n_instances, f)
+    finally:
+        o.close()
+        p.free()
+
+
+def test_a_scene_with_a_member_whose_poses_are_lists(ctx, orc):
+    """fyx_scene_update over characters of which one blends list poses (the two-record fold has no scene form: such a scene runs its
+    members one by one): every member's transforms are its oracle's, frame by frame."""
+    scs = [cases.c5_blend_tree(n_bones=24, euler_every=10 ** 6), cases.duplicate_bindings(), cases.transitions(), cases.duplicate_properties()]
+    os_, ps = [cases.build_oracle(orc, sc) for sc in scs], [cases.build_product(ctx, sc, 2) for sc in scs]
+    try:
+        for f in range(24):
+            for sc, o, p in zip(scs, os_, ps):
+                for idx, par in sc.script.get(f, []):
+                    o.set_parameter(idx, par)
+                    p.set_parameter(idx, par)
+                o.update_machine(sc.dt)
+            A.scene_update(ctx, ps, scs[0].dt)
+            for sc, o, p in zip(scs, os_, ps):
+                check_frame(p, o, sc, 2, f)
+    finally:
+        for o in os_:
+            o.close()
+        for p in ps:
+            p.free()
