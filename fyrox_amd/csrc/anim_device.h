@@ -37,7 +37,7 @@ inline bool kind_fits(int binding, int kind) {
 void build_track_views(const Animator& A, AnimationDef& an, std::vector<int32_t>& ptrack_a, std::vector<int32_t>& ptrack_f) {
     const uint32_t n_nodes = A.rig->n_nodes;
     std::vector<int32_t> sa((size_t)n_nodes * 4, -1), sf((size_t)n_nodes * 4, -1);
-    std::vector<uint8_t> bl(n_nodes, 0), first_seen((size_t)n_nodes * 3, 0);
+    std::vector<uint8_t> bl(n_nodes, 0), mu(n_nodes, 0), first_seen((size_t)n_nodes * 3, 0);
     ptrack_a.assign(std::max<size_t>(A.prop_slots.size(), 1), -1);
     ptrack_f.assign(ptrack_a.size(), -1);
     for (uint32_t t = 0; t < an.td->n_tracks; ++t) {
@@ -57,8 +57,12 @@ void build_track_views(const Animator& A, AnimationDef& an, std::vector<int32_t>
         }
         const int b = tr.binding;
         const bool fits = kind_fits(b, tr.kind);
-        if (fits) sa[node * 4 + b] = (int32_t)t;
-        else bl[node] |= 8u;
+        if (fits) {
+            if (sa[node * 4 + b] >= 0) mu[node] |= (uint8_t)(1u << b);
+            sa[node * 4 + b] = (int32_t)t;
+        } else {
+            bl[node] |= 8u;
+        }
         if (!first_seen[node * 3 + b]) {
             first_seen[node * 3 + b] = 1;
             if (fits) sf[node * 4 + b] = (int32_t)t;
@@ -69,6 +73,7 @@ void build_track_views(const Animator& A, AnimationDef& an, std::vector<int32_t>
     an.slots = std::move(sa);
     an.slots_f = std::move(sf);
     an.blockers = std::move(bl);
+    an.multi = std::move(mu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -214,7 +219,12 @@ int ensure_device_state(fyx_ctx* c, Animator& A) {
             hd[a].prop_track = read_view ? an.d_prop_track_f : an.d_prop_track;
             hd[a].n_tracks = an.td->n_tracks;
             hd[a].rm_node = an.rm_node;
-            hd[a].rm_ignore = an.rm_ignore;
+            // (16 / 32: the root node's list holds two or more Vector3 Positions / UnitQuaternion Rotations.  The loop of lib.rs:558-657 walks
+            //  them all; what stays of it is the LAST one's RootMotion -- the apply view's value -- computed with the remainders already taken
+            //  by the first.  The read view's own RootMotion is never observed.)
+            const uint8_t mu = an.rm_node >= 0 && (size_t)an.rm_node < an.multi.size() ? an.multi[(size_t)an.rm_node] : 0;
+            hd[a].rm_ignore = an.rm_ignore | (!read_view && (mu & (1u << FYX_BIND_POSITION)) ? 16u : 0u)
+                                           | (!read_view && (mu & (1u << FYX_BIND_ROTATION)) ? 32u : 0u);
             hd[a].rm_pos_track = an.rm_pos_track;
             hd[a].rm_rot_track = an.rm_rot_track;
             hd[a].pad = 0;

@@ -764,7 +764,7 @@ __device__ __forceinline__ void root_motion_body(const PoseFrameDev& f, uint32_t
             float delta[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float remainder = (prev.rem_flags & 1u) ? prev.position_offset_remainder[k] : 0.0f;
+                const float remainder = ((prev.rem_flags & 1u) && !(an.rm_ignore & 16u)) ? prev.position_offset_remainder[k] : 0.0f;  // .take().unwrap_or_default()
                 const float current_offset = p[k] - prev.prev_position[k];
                 delta[k] = current_offset + remainder;
             }
@@ -790,7 +790,7 @@ __device__ __forceinline__ void root_motion_body(const PoseFrameDev& f, uint32_t
                 rm.prev_rotation[0] = pose_rotation.x; rm.prev_rotation[1] = pose_rotation.y;
                 rm.prev_rotation[2] = pose_rotation.z; rm.prev_rotation[3] = pose_rotation.w;
             }
-            const f4 remainder = (prev.rem_flags & 2u)
+            const f4 remainder = ((prev.rem_flags & 2u) && !(an.rm_ignore & 32u))
                 ? f4{prev.rotation_remainder[0], prev.rotation_remainder[1], prev.rotation_remainder[2], prev.rotation_remainder[3]}
                 : f4{0.f, 0.f, 0.f, 1.f};
             const f4 pp = f4{prev.prev_rotation[0], prev.prev_rotation[1], prev.prev_rotation[2], prev.prev_rotation[3]};

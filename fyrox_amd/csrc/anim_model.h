@@ -63,6 +63,8 @@ struct AnimationDef {
     // differ somewhere (then a machine's folds keep two records per animation: Animator::shadows).
     std::vector<int32_t> slots_f;      // [n_nodes][4]: first track of the binding if its kind fits, else -1 (entry 3 as in `slots`)
     std::vector<uint8_t> blockers;     // [n_nodes] bit b: the binding's FIRST value has a kind that does not fit; bit 3: some value of the node fits no binding
+    std::vector<uint8_t> multi;        // [n_nodes] bit b: TWO OR MORE values of binding b fit (update_root_motion walks every one of them: the first
+                                       //   takes the remainders of the last loop, lib.rs:575-578 / :634-637, the one that stays -- the last -- finds None)
     int32_t* d_slot_track_f = nullptr;
     int32_t* d_prop_track_f = nullptr;
     bool dup = false;

@@ -227,7 +227,8 @@ struct AnimDev {
                                  //   >= 0 when the animation holds a Property value for the node
     const int32_t* prop_track;   // [n_prop_slots]: Real track feeding a (node, property) slot of the animator, -1 none
     uint32_t n_tracks;
-    // RootMotionSettings (lib.rs:307-319): rm_node < 0 = None; rm_ignore bits 1 x, 2 y, 4 z, 8 rotations;
+    // RootMotionSettings (lib.rs:307-319): rm_node < 0 = None; rm_ignore bits 1 x, 2 y, 4 z, 8 rotations; 16 / 32: the remainders of the last
+    // loop were taken by an earlier Position / Rotation value of the root node's list (AnimationDef::multi);
     // rm_pos_track / rm_rot_track: FIRST track of the tracks data bound to Position / Rotation
     // (fetch_position_at_time / fetch_rotation_at_time, lib.rs:507-534), -1 none
     int32_t rm_node;

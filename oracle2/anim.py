@@ -351,8 +351,12 @@ class ByIndexNode:
                         prev_in, cur_in = self.inputs[self.prev_index], self.inputs[cur]
                         self.blend_time = min(self.blend_time + cx.dt, cur_in[0])     # f32::min
                         k = self.blend_time / cur_in[0]
-                        self.out.blend_with(cx.nodes[prev_in[1]].eval(cx), ONE - k)
-                        self.out.blend_with(cx.nodes[cur_in[1]].eval(cx), k)
+                        # nodes[handle] panics on a handle that does not resolve; both restatements and the product skip it instead
+                        pn, cn = cx.node(prev_in[1]), cx.node(cur_in[1])
+                        if pn is not None:
+                            self.out.blend_with(pn.eval(cx), ONE - k)
+                        if cn is not None:
+                            self.out.blend_with(cn.eval(cx), k)
                         if k >= ONE:
                             self.prev_index = cur
                             self.blend_time = ZERO
@@ -362,7 +366,9 @@ class ByIndexNode:
             if not applied:
                 self.blend_time = ZERO
                 if cur < len(self.inputs):
-                    cx.nodes[self.inputs[cur][1]].eval(cx).clone_into(self.out)
+                    cn = cx.node(self.inputs[cur][1])
+                    if cn is not None:
+                        cn.eval(cx).clone_into(self.out)
         return self.out
 
     def collect(self, cx, acc):

@@ -663,14 +663,17 @@ ALL_RM = [with_root_motion_and_signals(f) for f in ALL] + [looping_root_motion]
 
 # ---- randomly generated machines ------------------------------------------------------------------------
 
-def random_machine(seed: int, n_bones: int = 7) -> Scenario:
+def random_machine(seed: int, n_bones: int = 7, listy: bool = False) -> Scenario:
     """A random but valid animation set-up: 3-5 partial clips (some with Real Property tracks, signals, root motion,
     reverse / zero speed, non-looping, sub-range time slices, disabled), 1-3 layers of random pose-node DAGs (all four
     node types, invalid handles, shared sub-trees, nested blends up to depth 4), random states / transitions with
     random condition trees and actions, masks, mistyped parameter references, and a script that rewrites parameters
     (sometimes with another kind) every few frames.  Quaternion rotation tracks only, so everything must be
-    bit-exact."""
+    bit-exact.  listy = True (a generator of its own, so the plain scenario of a seed stays what it was) also gives the clips what
+    _listy_tracks gives by hand: further tracks on a (node, binding) or (node, property) that already has one, anywhere in the track
+    order, value kinds that fit no binding, property tracks of every vector kind, tracks with too few curves."""
     rng = np.random.default_rng(seed)
+    lrng = np.random.default_rng(seed + 10 ** 6)
     f32 = lambda x: float(np.float32(x))
     rig = synth.make_rig(n_bones, 1000 + seed, exotic=bool(rng.integers(2)))
     n_clips = int(rng.integers(3, 6))
@@ -688,6 +691,29 @@ def random_machine(seed: int, n_bones: int = 7) -> Scenario:
                                   [A.Curve([A.CurveKey(f32(ts[k]), f32(rng.random() * 100), int(rng.integers(0, 3)),
                                                        f32(rng.normal()), f32(rng.normal())) for k in range(nk)])]))
             target.append(2 + (c + p_) % 2)
+        if listy:
+            donor, _ = synth.make_clip(n_bones, 5000 + seed, clip=c + 7, n_keys=int(lrng.integers(2, 7)), fps=8.0,
+                                       key_kind=int(lrng.integers(0, 3)), euler_every=10 ** 9)
+            need = {A.KIND_REAL: 1, A.KIND_VEC2: 2, A.KIND_VEC3: 3, A.KIND_VEC4: 4, A.KIND_QUAT: 4}
+            for _ in range(int(lrng.integers(1, 6))):
+                node = int(lrng.integers(0, n_bones))
+                d = donor.tracks[node * 3 + int(lrng.integers(0, 3))]
+                quat = donor.tracks[node * 3 + 1]
+                r = lrng.random()
+                if r < 0.4:
+                    t = d                                                    # one more value on a Position / Rotation / Scale
+                elif r < 0.6:                                              # a kind its binding cannot take
+                    kind = int(lrng.choice([k for k in need if k != d.kind]))
+                    t = A.Track(d.binding, kind, quat.curves[:need[kind]])
+                elif r < 0.9:                                              # a property, maybe one that already has a track
+                    kind = int(lrng.choice(list(need)))
+                    t = A.Track(A.BIND_PROPERTY0 + int(lrng.integers(0, 3)), kind, quat.curves[:need[kind]])
+                    node = 2 + int(lrng.integers(0, 3)) % n_bones
+                else:                                                        # fetch() -> None: no value at all
+                    t = A.Track(d.binding, d.kind, d.curves[:len(d.curves) - 1])
+                at = int(lrng.integers(0, len(tracks) + 1))
+                tracks.insert(at, t)
+                target.insert(at, node)
         tds.append(A.AnimationTracksData(tracks))
         lo = f32(rng.random() * 0.3)
         hi = f32(lo + 0.2 + rng.random() * 0.6)
@@ -777,7 +803,7 @@ def random_machine(seed: int, n_bones: int = 7) -> Scenario:
     for f in range(n_frames):
         if rng.random() < 0.35:
             script[f] = [(int(rng.integers(0, n_params)), rand_param()) for _ in range(int(rng.integers(1, 3)))]
-    return Scenario(f"random_machine[{seed}]", rig, tds, anims, A.Machine(parameters=params, layers=layers), script,
+    return Scenario(f"random_machine[{seed}{', listy' if listy else ''}]", rig, tds, anims, A.Machine(parameters=params, layers=layers), script,
                     n_frames=n_frames, dt=f32(rng.choice([1 / 60, 1 / 24, 0.11])), has_euler=False,
                     track_root_motion=any(a.root_motion is not None for a in anims) or bool(rng.integers(2)),
                     random_seed=seed * 7919 + 13)

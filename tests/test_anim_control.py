@@ -5,6 +5,8 @@ order) emits sample times + a fold program per frame.  Here a small Python inter
 program on the ORACLE's animation poses (with the oracle's blend primitives) and the result must equal
 the oracle's own Machine::evaluate_pose / update_animations bit for bit -- which pins the control
 plane's logic and the program semantics without touching the HIP kernels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -141,6 +143,11 @@ def _drain(pop):
 @pytest.mark.parametrize("seed", range(40))
 def test_control_plane_matches_oracle_on_random_machines(orc, cctx, seed):
     _check_control_plane(orc, cctx, cases.random_machine(seed))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FYX_FUZZ_SEEDS", 16))))
+def test_control_plane_matches_oracle_on_random_machines_with_lists_of_values(orc, cctx, seed):
+    _check_control_plane(orc, cctx, cases.random_machine(seed, listy=True))
 
 
 @pytest.mark.parametrize("make", cases.ALL + cases.ALL_RM, ids=lambda f: f.__name__)

@@ -287,6 +287,22 @@ def test_random_machines_match_oracle(ctx, orc, seed):
     p.free()
 
 
+# (103 ... 344: found by tools/fuzz_gpu.py -- the root node's list holds two Positions or Rotations and a loop has just wrapped: the remainders
+#  are taken by the first value, the one that stays finds None, lib.rs:575-578)
+@pytest.mark.parametrize("seed", list(range(16)) + [103, 118, 205, 241, 344])
+def test_random_machines_with_lists_of_values_match_oracle(ctx, orc, seed):
+    """random_machine(listy=True): further tracks on a (node, binding) or property that already has one, anywhere in the track order,
+    kinds that fit no binding, property tracks of every vector kind, tracks with too few curves -- under random machines, in all three
+    sampler forms (seed % 3)."""
+    sc = cases.random_machine(seed, listy=True)
+    ctx.set_option("anim.sample_form", seed % 3)
+    o, p = run_scenario(ctx, orc, sc, n_instances=2 + seed % 3)
+    for a in range(len(sc.animations)):
+        assert _drain(lambda: p.pop_event(a, 0)) == _drain(lambda: o.pop_event(a))
+    o.close()
+    p.free()
+
+
 @pytest.mark.parametrize("make", cases.ALL_RM, ids=lambda f: f.__name__)
 def test_root_motion_and_signals_match_oracle(ctx, orc, make):
     """Animation::update_root_motion on the GPU (root pose rewritten before blending), AnimationPose::root_motion

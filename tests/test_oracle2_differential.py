@@ -157,6 +157,12 @@ def test_random_machines_bit_for_bit(seed):
     _run(cases.random_machine(seed))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FYX_FUZZ_SEEDS", 16))))
+def test_random_machines_with_lists_of_values_bit_for_bit(seed):
+    """random_machine(listy=True): further tracks on one (node, binding), kinds that fit nothing, property tracks of every kind."""
+    _run(cases.random_machine(seed, listy=True))
+
+
 # ---- oracle2 on its own against the reference's golden vectors ------------------------------------------------------------
 
 def test_oracle2_against_the_reference_vectors():
