@@ -809,6 +809,50 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False) -> Scenario
                     random_seed=seed * 7919 + 13)
 
 
+def random_curves(seed: int, n_bones: int = 6) -> Scenario:
+    """Clips made of ODD curves under a two-clip blend: 0 - 9 keys a curve, locations on a coarse lattice so that keys coincide (and whole
+    runs of them: Curve::value_at's partition_point and the span hints see duplicate locations), every CurveKeyKind mixed within one curve,
+    steep tangents, curves of one track on one time grid (span records) or each on its own (the general path), single-key and empty curves,
+    a root-motion node, a time slice that starts before the first key or ends behind the last.  Quaternion rotation tracks only."""
+    rng = np.random.default_rng(seed + 3 * 10 ** 6)
+    f32 = lambda x: float(np.float32(x))
+    rig = synth.make_rig(n_bones, 3000 + seed, exotic=bool(rng.integers(2)))
+
+    def keys(times, scale, offset):
+        return [A.CurveKey(f32(t), f32(offset + rng.normal() * scale), int(rng.integers(0, 3)), f32(rng.normal() * 4), f32(rng.normal() * 4))
+                for t in times]
+
+    def grid():
+        n = int(rng.choice([0, 1, 1, 2, 3, 5, 9]))
+        step = float(rng.choice([0.125, 0.0625, 0.25]))
+        return np.sort(rng.integers(0, 9, n) * step).astype(np.float32)
+
+    tds, anims = [], []
+    for c in range(2):
+        tracks, target = [], []
+        for b in range(n_bones):
+            for binding, kind, n_curves, scale, offset in ((A.BIND_POSITION, A.KIND_VEC3, 3, 0.3, 0.0), (A.BIND_ROTATION, A.KIND_QUAT, 4, 0.5, 0.3),
+                                                           (A.BIND_SCALE, A.KIND_VEC3, 3, 0.05, 1.0)):
+                if rng.random() < 0.15:
+                    continue
+                shared = grid() if rng.random() < 0.6 else None
+                tracks.append(A.Track(binding, kind, [A.Curve(keys(shared if shared is not None else grid(), scale, offset)) for _ in range(n_curves)]))
+                target.append(b)
+        tds.append(A.AnimationTracksData(tracks))
+        lo = f32(rng.choice([0.0, 0.0, -0.1, 0.2]))
+        hi = f32(lo + rng.choice([0.3, 1.0, 1.3]))
+        spec = AnimSpec(c, np.asarray(target, np.int32), time_slice=(lo, hi), speed=f32(rng.choice([1.0, 3.1, -1.7, 0.4])),
+                        looped=bool(rng.random() < 0.7))
+        if rng.random() < 0.5:
+            spec.root_motion = (int(rng.integers(0, 2)), bool(rng.integers(2)), False, bool(rng.integers(2)), bool(rng.integers(2)))
+        anims.append(spec)
+    layer = A.MachineLayer(nodes=[A.PlayAnimation(0), A.PlayAnimation(1), A.BlendAnimations([A.BlendPose(0, 1.0), A.BlendPose(1, f32(rng.random()))])],
+                           states=[A.State(2)])
+    machine = A.Machine(parameters=[], layers=[layer]) if rng.random() < 0.7 else None
+    return Scenario(f"random_curves[{seed}]", rig, tds, anims, machine, n_frames=40, dt=f32(rng.choice([1 / 60, 1 / 24, 0.11, 0.31])),
+                    has_euler=False, track_root_motion=any(a.root_motion is not None for a in anims))
+
+
 # ---- builders -------------------------------------------------------------------------------------
 
 def build_oracle(orc, sc: Scenario):

@@ -303,6 +303,17 @@ def test_random_machines_with_lists_of_values_match_oracle(ctx, orc, seed):
     p.free()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_curves_match_oracle(ctx, orc, seed):
+    """random_curves: coinciding keys, mixed key kinds, empty and single-key curves, tracks whose curves sit on different time grids, slices
+    that reach past the keys -- all three sampler forms."""
+    sc = cases.random_curves(seed)
+    ctx.set_option("anim.sample_form", seed % 3)
+    o, p = run_scenario(ctx, orc, sc, n_instances=1 + seed % 3 if seed % 4 else 70)
+    o.close()
+    p.free()
+
+
 @pytest.mark.parametrize("make", cases.ALL_RM, ids=lambda f: f.__name__)
 def test_root_motion_and_signals_match_oracle(ctx, orc, make):
     """Animation::update_root_motion on the GPU (root pose rewritten before blending), AnimationPose::root_motion

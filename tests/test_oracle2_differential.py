@@ -163,6 +163,12 @@ def test_random_machines_with_lists_of_values_bit_for_bit(seed):
     _run(cases.random_machine(seed, listy=True))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FYX_FUZZ_SEEDS", 16))))
+def test_random_curves_bit_for_bit(seed):
+    """random_curves: coinciding keys, mixed key kinds, empty and single-key curves, curves of a track on different time grids."""
+    _run(cases.random_curves(seed))
+
+
 # ---- oracle2 on its own against the reference's golden vectors ------------------------------------------------------------
 
 def test_oracle2_against_the_reference_vectors():

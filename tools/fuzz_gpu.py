@@ -18,12 +18,117 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def run_with_edits(T, cases, orc, ctx, sc, n_instances, seed):
+    """tests/test_anim_gpu.py::run_scenario with the setters of Animation called on both sides between frames (lib.rs:432-466, :664-666,
+    track.rs TrackBinding::set_enabled, signal.rs)."""
+    import numpy as np
+    rng = np.random.default_rng(seed + 5 * 10 ** 6)
+    lib = orc._alib()
+    f32 = lambda x: float(np.float32(x))
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, n_instances)
+    n_nodes = sc.rig.n_nodes
+    alive = [True] * len(sc.animations)
+    for f in range(sc.n_frames):
+        for idx, par in sc.script.get(f, []):
+            o.set_parameter(idx, par)
+            p.set_parameter(idx, par)
+        for a in sc.removals.get(f, []):
+            o.remove_animation(a)
+            p.remove_animation(a)
+            alive[a] = False
+        for _ in range(int(rng.integers(0, 3)) if rng.random() < 0.4 else 0):
+            a = int(rng.integers(0, len(sc.animations)))
+            if not alive[a]:
+                continue
+            h, spec = o.anims[a], sc.animations[a]
+            td = sc.tracks_data[spec.tracks]
+            kind = int(rng.integers(0, 11))
+            if kind == 0 and td.tracks:
+                t, on = int(rng.integers(0, len(td.tracks))), bool(rng.integers(2))
+                lib.fo_animation_bind(h, t, int(spec.target[t]), int(on))
+                p.set_track_enabled(a, t, on)
+            elif kind == 1:
+                v = f32(rng.choice([1.0, 0.5, 2.5, -1.0, -0.3, 0.0]))
+                lib.fo_animation_set_speed(h, v); p.set_speed(a, v)
+            elif kind == 2:
+                v = bool(rng.integers(2))
+                lib.fo_animation_set_loop(h, int(v)); p.set_loop(a, v)
+            elif kind == 3:
+                v = bool(rng.random() < 0.7)
+                lib.fo_animation_set_enabled(h, int(v)); p.set_enabled(a, v)
+            elif kind == 4:
+                lib.fo_animation_rewind(h); p.rewind(a)
+            elif kind == 5:
+                v = f32(rng.random() * 1.4 - 0.2)
+                lib.fo_animation_set_time_position(h, v); p.set_time_position(a, v)
+            elif kind == 6:
+                lo = f32(rng.random() * 0.4)
+                hi = f32(lo + 0.05 + rng.random() * 0.6)
+                lib.fo_animation_set_time_slice(h, lo, hi); p.set_time_slice(a, lo, hi)
+            elif kind == 7 and sc.track_root_motion:
+                node = int(rng.integers(-1, min(n_nodes, 4)))
+                fl = [bool(rng.integers(2)) for _ in range(4)]
+                lib.fo_animation_set_root_motion_settings(h, node, *[int(x) for x in fl])
+                p.set_root_motion_settings(a, None if node < 0 else node, *fl)
+            elif kind == 8 and spec.signals:
+                sg, on = int(rng.integers(0, len(spec.signals))), bool(rng.integers(2))
+                lib.fo_animation_set_signal_enabled(h, sg, int(on)); p.set_signal_enabled(a, sg, on)
+            elif kind == 9:
+                o.clear_events(a); p.clear_events(a)
+            elif kind == 10:
+                cap = int(rng.integers(0, 6))
+                lib.fo_animation_set_max_event_capacity(h, cap); p.set_max_event_capacity(a, cap)
+        if sc.machine is None:
+            o.update_animations(sc.dt)
+            p.update_animations(sc.dt)
+        else:
+            o.update_machine(sc.dt)
+            p.update_machine(sc.dt)
+        T.check_frame(p, o, sc, n_instances, f)
+    return o, p
+
+
+def run_scene(T, cases, A, orc, ctx, seeds, listy, bones):
+    """fyx_scene_update over a changing list of random machines (order shuffled, a member left out of some frames, parameters scripted per
+    member) against one oracle per member."""
+    import numpy as np
+    rng = np.random.default_rng(seeds[0] + 9 * 10 ** 6)
+    scs = [cases.random_machine(s, n_bones=bones, listy=listy and k % 2 == 0) for k, s in enumerate(seeds)]
+    n_inst = [1 + int(rng.integers(0, 3)) for _ in scs]
+    dt = scs[0].dt
+    os_ = [cases.build_oracle(orc, sc) for sc in scs]
+    ps = [cases.build_product(ctx, sc, n) for sc, n in zip(scs, n_inst)]
+    try:
+        for f in range(28):
+            for sc, o, p in zip(scs, os_, ps):
+                for idx, par in sc.script.get(f, []):
+                    o.set_parameter(idx, par)
+                    p.set_parameter(idx, par)
+            members = [k for k in rng.permutation(len(scs)) if rng.random() < 0.85]
+            for k in members:
+                os_[k].update_machine(dt)
+            A.scene_update(ctx, [ps[k] for k in members], dt)
+            for k in members:
+                T.check_frame(ps[k], os_[k], scs[k], n_inst[k], f)
+    finally:
+        for o in os_:
+            o.close()
+        for p in ps:
+            p.free()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=100)
     ap.add_argument("--count", type=int, default=100)
     ap.add_argument("--listy", action="store_true")
     ap.add_argument("--bones", type=int, default=7)
+    ap.add_argument("--curves", action="store_true", help="tests/anim_cases.py::random_curves instead of random_machine")
+    ap.add_argument("--edits", action="store_true", help="random run-time edits between frames: track bindings switched, speeds, loops, "
+                    "time positions and slices, enabled flags, rewinds, root-motion settings, signals, event queues")
+    ap.add_argument("--scene", type=int, default=0, help="members per scene: the seeds run in groups through fyx_scene_update")
+    ap.add_argument("--opt", action="append", default=[], help="key=value context options for the whole run")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
@@ -31,17 +136,31 @@ def main():
     import oracle
     import anim_cases as cases
     import test_anim_gpu as T
+    from fyrox_amd import anim as A
 
     oracle.lib()
     ctx = fyrox_amd.Context(0)
     fails, t0 = [], time.time()
-    for seed in range(args.first, args.first + args.count):
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    if args.scene:
+        for first in range(args.first, args.first + args.count, args.scene):
+            seeds = list(range(first, first + args.scene))
+            ctx.set_option("anim.sample_form", first % 3)
+            try:
+                run_scene(T, cases, A, oracle, ctx, seeds, args.listy, args.bones)
+            except Exception as e:   # noqa: BLE001
+                fails.append({"seeds": [seeds[0], seeds[-1]], "listy": args.listy, "sample_form": first % 3,
+                              "error": (str(e).strip().splitlines() or [repr(e)])[0][:300],
+                              "where": traceback.format_exc().strip().splitlines()[-3][:200]})
+    for seed in (range(args.first, args.first + args.count) if not args.scene else ()):
         form, n_inst = seed % 3, 1 + seed % 4 if seed % 5 else 70
-        sc = cases.random_machine(seed, n_bones=args.bones, listy=args.listy)
+        sc = cases.random_curves(seed, n_bones=args.bones) if args.curves else cases.random_machine(seed, n_bones=args.bones, listy=args.listy)
         ctx.set_option("anim.sample_form", form)
         o = p = None
         try:
-            o, p = T.run_scenario(ctx, oracle, sc, n_instances=n_inst)
+            o, p = (run_with_edits(T, cases, oracle, ctx, sc, n_inst, seed) if args.edits else T.run_scenario(ctx, oracle, sc, n_instances=n_inst))
             for a in range(len(sc.animations)):
                 assert T._drain(lambda: p.pop_event(a, 0)) == T._drain(lambda: o.pop_event(a)), f"events of animation {a}"
         except Exception as e:   # noqa: BLE001 -- every failure is a finding
@@ -57,7 +176,7 @@ def main():
             except Exception:   # noqa: BLE001
                 pass
     ctx.set_option("anim.sample_form", 0)
-    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "bones": args.bones,
+    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "curves": args.curves, "edits": args.edits, "scene": args.scene, "options": args.opt, "bones": args.bones,
            "first_seed": args.first, "seeds": args.count, "failures": len(fails), "failed": fails[:40], "seconds": round(time.time() - t0, 1)}
     line = json.dumps(rec)
     print(line)
