@@ -118,6 +118,65 @@ def run_scene(T, cases, A, orc, ctx, seeds, listy, bones):
             p.free()
 
 
+def run_skin(T, cases, A, orc, ctx, sc, n_inst, seed):
+    """The frame that goes through to the vertices (fyx_animator_set_skin_output): random bone lists (invalid handles among them), mesh
+    sizes, launch forms switched from frame to frame; palette and vertices of every frame against the oracle's palette and loop."""
+    import numpy as np
+    from fyrox_amd import synth
+    rng = np.random.default_rng(seed + 7 * 10 ** 6)
+    nn = sc.rig.n_nodes
+    o = cases.build_oracle(orc, sc)
+    p = cases.build_product(ctx, sc, n_inst)
+    base = p.base_id
+    bones = [int(b) if rng.random() > 0.1 else -1 for b in rng.integers(0, nn, int(rng.integers(1, 2 * nn)))]
+    nb = len(bones)
+    nv = int(rng.choice([1, 63, 64, 65, 777, 4097, int(rng.integers(1, 30_000))]))
+    A.create_bone_list(ctx, base + 50, base, bones)
+    d_pal = ctx.malloc(n_inst * nb * 64)
+    p.set_palette_output(base + 50, d_pal.ptr)
+    mesh = synth.make_mesh(nv, nb, synth.SEED_BASE + seed)
+    ctx.mesh_upload_soa(base + 60, mesh.pos, mesh.weights, mesh.indices, mesh.normal, mesh.tangent)
+    outs = [ctx.malloc(n_inst * nv * w * 4 + 64) for w in (3, 3, 4)]
+    p.set_skin_output(base + 50, base + 60, outs[0].ptr, outs[1].ptr, outs[2].ptr)
+    keys = ("debug.frame_skin", "anim.one_launch", "anim.inline_ctrl", "anim.update_lean", "anim.frame_skin_units")
+    try:
+        for f in range(min(sc.n_frames, 24)):
+            for idx, par in sc.script.get(f, []):
+                o.set_parameter(idx, par)
+                p.set_parameter(idx, par)
+            form = (int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([0, 1, 2, 4, 16])))
+            for k, v in zip(keys, form):
+                ctx.set_option(k, v)
+            if rng.random() < 0.3:
+                (o.update_machine if sc.machine is not None else o.update_animations)(sc.dt)
+                A.scene_update(ctx, [p], sc.dt)
+            else:
+                (o.update_machine if sc.machine is not None else o.update_animations)(sc.dt)
+                (p.update_machine if sc.machine is not None else p.update_animations)(sc.dt)
+            ctx.sync()
+            ref_pal = o.palette(bones)
+            pal = d_pal.download(np.float32, n_inst * nb * 16).reshape(n_inst, nb, 16)
+            ref = orc.lbs_skin(mesh.pos, mesh.weights, mesh.indices, ref_pal, mesh.normal, mesh.tangent)
+            for i in range(n_inst):
+                assert np.array_equal(pal[i].view(np.uint32), ref_pal.view(np.uint32)), f"{sc.name} frame {f} form {form}: palette of instance {i}"
+            for buf, key, w in zip(outs, ("pos", "normal", "tangent"), (3, 3, 4)):
+                got = buf.download(np.uint32, n_inst * nv * w).reshape(n_inst, nv * w)
+                for i in range(n_inst):
+                    assert np.array_equal(got[i], ref[key].view(np.uint32).reshape(-1)), f"{sc.name} frame {f} form {form}: {key} of instance {i} ({nv} vertices, {nb} bones)"
+            T.check_frame(p, o, sc, n_inst, f)
+    finally:
+        for k, v in zip(keys, (1, 1, 1, 1, 0)):
+            ctx.set_option(k, v)
+        p.set_skin_output(base + 50, base + 60)
+        o.close()
+        p.free()
+        for b in outs:
+            b.free()
+        d_pal.free()
+        ctx.mesh_free(base + 60)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=100)
@@ -127,6 +186,7 @@ def main():
     ap.add_argument("--curves", action="store_true", help="tests/anim_cases.py::random_curves instead of random_machine")
     ap.add_argument("--edits", action="store_true", help="random run-time edits between frames: track bindings switched, speeds, loops, "
                     "time positions and slices, enabled flags, rewinds, root-motion settings, signals, event queues")
+    ap.add_argument("--skin", action="store_true", help="with a registered palette and skin output: the frame through to the vertices")
     ap.add_argument("--scene", type=int, default=0, help="members per scene: the seeds run in groups through fyx_scene_update")
     ap.add_argument("--opt", action="append", default=[], help="key=value context options for the whole run")
     ap.add_argument("--out", default=None)
@@ -160,6 +220,9 @@ def main():
         ctx.set_option("anim.sample_form", form)
         o = p = None
         try:
+            if args.skin:
+                run_skin(T, cases, A, oracle, ctx, sc, min(n_inst, 3), seed)
+                continue
             o, p = (run_with_edits(T, cases, oracle, ctx, sc, n_inst, seed) if args.edits else T.run_scenario(ctx, oracle, sc, n_instances=n_inst))
             for a in range(len(sc.animations)):
                 assert T._drain(lambda: p.pop_event(a, 0)) == T._drain(lambda: o.pop_event(a)), f"events of animation {a}"
@@ -176,7 +239,7 @@ def main():
             except Exception:   # noqa: BLE001
                 pass
     ctx.set_option("anim.sample_form", 0)
-    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "curves": args.curves, "edits": args.edits, "scene": args.scene, "options": args.opt, "bones": args.bones,
+    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "curves": args.curves, "edits": args.edits, "skin": args.skin, "scene": args.scene, "options": args.opt, "bones": args.bones,
            "first_seed": args.first, "seeds": args.count, "failures": len(fails), "failed": fails[:40], "seconds": round(time.time() - t0, 1)}
     line = json.dumps(rec)
     print(line)
