@@ -620,7 +620,12 @@ ExKind ex_kind(const fyx::LbsExArgs& x, bool whole_spans) {
 
 // Everything a batch call launches: segments for the batched kernels, the rest one launch each.
 struct BatchPlan {
-    struct SoaGroup { std::vector<fyx::LbsSegDev> segs; uint32_t units = 0, max_bones = 0; };
+    struct SoaGroup {
+        std::vector<fyx::LbsSegDev> segs;
+        uint32_t units = 0, max_bones = 0;
+        bool big = false;      // a mesh whose streams do not fit a buffer resource's 32-bit range: lbs_skin_batch, not its dyn form
+        fyx::LbsTuning tuning(const fyx::LbsTuning& t) const { fyx::LbsTuning r = t; if (big) r.dyn = 0; return r; }
+    };
     struct AosGroup { std::vector<fyx::LbsExSegDev> segs; uint32_t units = 0, max_bones = 0, max_stride = 0; };
     SoaGroup soa[8];                 // by output mask
     AosGroup aos[8];                 // by (layout bucket, blend shapes)
@@ -653,6 +658,7 @@ struct BatchPlan {
             G.segs.push_back(sg);
             G.units += upi;
             G.max_bones = std::max(G.max_bones, a.n_bones);
+            G.big = G.big || a.n_verts > 0x0fffffffu;
         }
         return FYX_OK;
     }
@@ -728,7 +734,7 @@ int run_batch_plan(fyx_ctx* c, SkinBatch& B, BatchPlan& P, bool reuse = false) {
     if (!reuse) {
     for (int k = 1; k < 8; ++k) {
         if (P.soa[k].segs.empty()) continue;
-        ps[k].grid = fyx::lbs_batch_grid(P.soa[k].units, c->lbs);
+        ps[k].grid = fyx::lbs_batch_grid(P.soa[k].units, P.soa[k].tuning(c->lbs));
         ps[k].o_segs = total;
         total += align_up(P.soa[k].segs.size() * sizeof(fyx::LbsSegDev), 256);
         ps[k].o_blocks = total;
@@ -778,7 +784,7 @@ int run_batch_plan(fyx_ctx* c, SkinBatch& B, BatchPlan& P, bool reuse = false) {
             if (G.segs.empty()) continue;
             FYX_HIP(c, fyx::launch_lbs_batch(reinterpret_cast<const fyx::LbsSegDev*>(d + ps[k].o_segs), (uint32_t)G.segs.size(),
                                              reinterpret_cast<const uint32_t*>(d + ps[k].o_blocks), ps[k].grid, G.units, G.max_bones,
-                                             k, c->lbs, st));
+                                             k, G.tuning(c->lbs), st));
         }
         for (int k = 0; k < 8; ++k) {
             const BatchPlan::AosGroup& G = P.aos[k];

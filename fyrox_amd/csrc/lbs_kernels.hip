@@ -538,7 +538,113 @@ __global__ __launch_bounds__(512) void lbs_skin_batch(const LbsSegDev* __restric
     }
 }
 
+// lbs_skin_batch_dyn (option lbs.dyn, the default): the batch in lbs_skin_dyn's form.  lbs_skin_batch above is lbs_skin's structure -- 512-thread
+// workgroups at 104 VGPRs, so only two of a CU's four are resident and the launch runs in two rounds; eight waves that take every eighth
+// unit of a workgroup's ~20 (two or three each: the workgroup ends with the waves that got three); one unit requested ahead.  Here: four
+// 256-thread workgroups per CU, all resident; the four waves of a workgroup DRAW the units of the workgroup's range from an LDS ticket, two
+// units in flight per wave; palette columns fetched by every thread; the streams of a segment as buffer resources (the ragged last unit of a
+// mesh needs no bounds test), loads nt, stores sc1.  A workgroup whose range crosses into another mesh does all of that again per segment.
+// Same per-vertex code: bit-identical results.  256 meshes x 5 000 vertices / 64 bones (128 MB): see DESIGN 5.
+constexpr int kBatchDynBlock = 256;
+
+template <bool EXACT, int MASK>
+__global__ __launch_bounds__(kBatchDynBlock) void lbs_skin_batch_dyn(const LbsSegDev* __restrict__ segs_g, uint32_t n_segs,
+                                                                     const uint32_t* __restrict__ block_seg, uint32_t total_units) {
+    constexpr uint32_t WPB = kBatchDynBlock / 64;
+    constexpr int PIECES = 1024 / kBatchDynBlock;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* const wave_flag = reinterpret_cast<uint32_t*>(smem);          // 4 words; word 8: the ticket; the palette from byte 64
+    uint32_t* const ticket = wave_flag + 8;
+    f32x4* const rows = reinterpret_cast<f32x4*>(smem + 64);
+    const FYX_CONSTANT LbsSegDev* segs = (const FYX_CONSTANT LbsSegDev*)segs_g;
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)blockIdx.x * total_units) / gridDim.x);
+    const uint32_t u_end = (uint32_t)(((uint64_t)(blockIdx.x + 1) * total_units) / gridDim.x);
+    if (u_begin >= u_end) return;
+    const uint32_t grp16 = lane >> 4, in16 = lane & 15;
+    const uint32_t my_piece = ((uint32_t)tid & ~63u) + 4 * (8 * (grp16 >> 1) + 2 * (in16 >> 2) + (grp16 & 1)) + (in16 & 3);   // (see lbs_skin_dyn)
+    bool first = true;
+    for (uint32_t seg = block_seg[blockIdx.x]; seg < n_segs; ++seg) {   // workgroup-uniform
+        const uint32_t s_u0 = segs[seg].unit0;
+        if (s_u0 >= u_end) break;
+        LbsArgs a;
+        a.pos = segs[seg].pos; a.nrm = segs[seg].nrm; a.tan = segs[seg].tan; a.wgt = segs[seg].wgt; a.idx = segs[seg].idx;
+        a.palette = segs[seg].palette;
+        a.out_pos = segs[seg].out_pos; a.out_nrm = segs[seg].out_nrm; a.out_tan = segs[seg].out_tan;
+        a.n_verts = segs[seg].n_verts; a.n_bones = segs[seg].n_bones; a.n_instances = 1;
+        const uint32_t upi = (a.n_verts + 63) / 64;
+        if (s_u0 + upi <= u_begin) continue;
+        const uint32_t seg_b = (u_begin > s_u0 ? u_begin : s_u0) - s_u0;
+        const uint32_t n_units = (u_end < s_u0 + upi ? u_end : s_u0 + upi) - s_u0 - seg_b;
+        f32x4* const row3 = rows + 3 * a.n_bones;
+
+        const uint32_t n_pieces = a.n_bones * 4;
+        f32x4 col[PIECES];
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const uint32_t piece = my_piece + (uint32_t)i * kBatchDynBlock;
+            col[i] = n_pieces ? reinterpret_cast<const f32x4*>(a.palette)[piece < n_pieces ? piece : n_pieces - 1] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const VtxBuffers vb = make_vtx_buffers(a);
+        auto vertex_of = [&](uint32_t t) -> uint32_t { return (seg_b + t) * 64 + lane; };
+        bool hasA = wave < n_units, hasB = WPB + wave < n_units;      // wave-uniform
+        uint32_t vA = vertex_of(wave), vB = vertex_of(WPB + wave);
+        VertexIn<MASK> A, B;
+        if (hasA) A = load_vertex_buf<MASK, kDynLoadAux>(vb, vA);
+
+        if (!first) __syncthreads();  // every wave is done with the previous segment's palette and ticket
+        first = false;
+        if (tid == 0) *ticket = 2 * WPB;
+        bool pj = false;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const uint32_t piece = my_piece + (uint32_t)i * kBatchDynBlock;
+            if (piece < n_pieces) {
+                const uint32_t b = piece >> 2, c = piece & 3;
+                float* r = reinterpret_cast<float*>(rows + b * 3);
+                *reinterpret_cast<f32x2*>(r + 2 * c) = f32x2{col[i].x, col[i].y};
+                r[8 + c] = col[i].z;
+                reinterpret_cast<float*>(row3 + b)[c] = col[i].w;
+                pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);
+            }
+        }
+        const bool wave_pj = __any(pj) != 0;
+        if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;
+        __syncthreads();
+        bool projective = false;
+#pragma unroll
+        for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;
+        if (hasA) pin_vertex(A);
+        if (hasB) B = load_vertex_buf<MASK, kDynLoadAux>(vb, vB);
+
+        auto process = [&](VertexIn<MASK>& c_, uint32_t v_c) {
+            pin_vertex(c_);
+            const Skinned o = skin_vertex<EXACT, MASK>(rows, row3, projective, c_.id, c_.w, c_.p.x, c_.p.y, c_.p.z,
+                                                       c_.n.x, c_.n.y, c_.n.z, c_.t.x, c_.t.y, c_.t.z);
+            store_vertex_buf<MASK, kDynStoreAux>(vb, v_c, o, c_.t.w);
+        };
+        auto refill = [&](VertexIn<MASK>& n_, uint32_t& v_n) -> bool {
+            uint32_t t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= n_units) return false;
+            v_n = vertex_of(t);
+            n_ = load_vertex_buf<MASK, kDynLoadAux>(vb, v_n);
+            return true;
+        };
+        while (hasA || hasB) {   // wave-uniform
+            if (hasA) { process(A, vA); hasA = refill(A, vA); }
+            if (hasB) { process(B, vB); hasB = refill(B, vB); }
+        }
+    }
+}
+
 uint32_t lbs_batch_grid(uint32_t total_units, const LbsTuning& t) {
+    if (t.dyn) {     // four resident workgroups of four waves per CU; a workgroup should have a unit per wave at least
+        const uint32_t grid = (uint32_t)kCUs * (1024u / kBatchDynBlock), max_useful = (total_units + 3) / 4;
+        return grid > max_useful ? max_useful : grid;
+    }
     uint32_t grid = (uint32_t)kCUs * (uint32_t)(t.blocks_per_cu > 0 ? t.blocks_per_cu : 1);
     const uint32_t max_useful = (total_units + 7) / 8;
     return grid > max_useful ? max_useful : grid;
@@ -546,10 +652,11 @@ uint32_t lbs_batch_grid(uint32_t total_units, const LbsTuning& t) {
 
 template <bool EXACT>
 static hipError_t launch_batch_mask(const LbsSegDev* d_segs, uint32_t n_segs, const uint32_t* d_block_seg, uint32_t grid,
-                                    uint32_t total_units, size_t lds, int mask, hipStream_t s) {
+                                    uint32_t total_units, size_t lds, int mask, bool dyn, hipStream_t s) {
 #define FYX_BATCH_CASE(M)                                                                                          \
     case M:                                                                                                        \
-        hipLaunchKernelGGL((lbs_skin_batch<EXACT, M>), dim3(grid), dim3(512), lds, s, d_segs, n_segs, d_block_seg, \
+        if (dyn) hipLaunchKernelGGL((lbs_skin_batch_dyn<EXACT, M>), dim3(grid), dim3(kBatchDynBlock), lds, s, d_segs, n_segs, d_block_seg, total_units); \
+        else hipLaunchKernelGGL((lbs_skin_batch<EXACT, M>), dim3(grid), dim3(512), lds, s, d_segs, n_segs, d_block_seg, \
                            total_units);                                                                           \
         break;
     switch (mask) {
@@ -564,8 +671,9 @@ hipError_t launch_lbs_batch(const LbsSegDev* d_segs, uint32_t n_segs, const uint
                             uint32_t total_units, uint32_t max_bones, int mask, const LbsTuning& t, hipStream_t stream) {
     if (n_segs == 0 || total_units == 0 || grid == 0) return hipSuccess;
     const size_t lds = (size_t)max_bones * 64 + 64;
-    return t.exact ? launch_batch_mask<true>(d_segs, n_segs, d_block_seg, grid, total_units, lds, mask, stream)
-                   : launch_batch_mask<false>(d_segs, n_segs, d_block_seg, grid, total_units, lds, mask, stream);
+    const bool dyn = t.dyn != 0 && max_bones <= 256;     // (the grid was made by lbs_batch_grid from the same tuning)
+    return t.exact ? launch_batch_mask<true>(d_segs, n_segs, d_block_seg, grid, total_units, lds, mask, dyn, stream)
+                   : launch_batch_mask<false>(d_segs, n_segs, d_block_seg, grid, total_units, lds, mask, dyn, stream);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1035,13 +1035,16 @@ def _check_batch(ctx, orc, specs, scene, exact):
 
 
 @pytest.mark.parametrize("exact", [1, 0])
-def test_batch_of_many_meshes_is_bit_exact(ctx, orc, exact):
+@pytest.mark.parametrize("dyn", [1, 0], ids=["batch_dyn", "batch"])
+def test_batch_of_many_meshes_is_bit_exact(ctx, orc, exact, dyn):
     """Ragged sizes (1 vertex, just under / over a unit, just over a workgroup's share), different bone counts,
-    instanced jobs, an empty mesh, one job big enough to take the crowd launch -- all in one call."""
+    instanced jobs, an empty mesh, one job big enough to take the crowd launch -- all in one call; both forms of the batched
+    kernel (lbs.dyn: units drawn from an LDS ticket, streams as buffer resources / lbs_skin's structure)."""
     ALL3 = ("pos", "normal", "tangent")
     specs = [(1, 4, 1, ALL3), (63, 8, 2, ALL3), (65, 64, 1, ALL3), (5000, 64, 1, ALL3), (4097, 256, 3, ALL3),
              (0, 16, 1, ALL3), (20_000, 96, 1, ALL3), (777, 33, 5, ALL3), (300, 12, 17, ALL3), (12_345, 200, 1, ALL3)]
     ctx.set_option("lbs.exact", exact)
+    ctx.set_option("lbs.dyn", dyn)
     try:
         scene = _batch_scene(ctx, 7300, specs, synth.SEED_BASE + 300)
         ctx.lbs_skin_batch(_batch_jobs(7300, specs, scene))
@@ -1247,10 +1250,12 @@ def test_ex_batch_validates_every_job_first(ctx):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_batch_of_hundreds_of_tiny_meshes_equals_per_mesh_launches(ctx, seed):
+@pytest.mark.parametrize("dyn", [1, 0], ids=["batch_dyn", "batch"])
+def test_batch_of_hundreds_of_tiny_meshes_equals_per_mesh_launches(ctx, seed, dyn):
     """Workgroups whose unit range spans many segments (meshes of 1..200 vertices, so most segments are 1-3 units):
     both batched kernels against the per-mesh launches, bit for bit, guard bytes behind every output."""
     rng = np.random.default_rng(seed)
+    ctx.set_option("lbs.dyn", dyn)      # (meshes this small never take lbs_skin_dyn on their own: the option picks the batched kernel's form)
     L = synth.ANIMATED_VERTEX
     n_jobs = 300
     jobs_soa, jobs_aos, singles = [], [], []
