@@ -17,7 +17,7 @@ import numpy as np
 
 # ValueBinding / TrackValueKind / CurveKeyKind (values of include/fyrox_hip.h)
 BIND_POSITION, BIND_SCALE, BIND_ROTATION = 0, 1, 2
-BIND_PROPERTY0 = 3   # ValueBinding::Property{name, ..}: BIND_PROPERTY0 + id (Real tracks only)
+BIND_PROPERTY0 = 3   # ValueBinding::Property{name, ..}: BIND_PROPERTY0 + id (tracks of every TrackValueKind)
 KIND_REAL, KIND_VEC2, KIND_VEC3, KIND_VEC4, KIND_QUAT_EULER, KIND_QUAT = range(6)
 KEY_CONSTANT, KEY_LINEAR, KEY_CUBIC = 0, 1, 2
 PARAM_WEIGHT, PARAM_RULE, PARAM_INDEX, PARAM_SAMPLING_POINT = range(4)

@@ -74,9 +74,10 @@ int fyx_join(fyx_ctx* ctx);
  *                        0 = fused multiply-adds, within 1e-5 relative (north_star's tolerance); the crowd kernel then blends
  *                        the four matrices first and transforms once (the same linear map, different rounding)
  *     "lbs.streams"      1..4 worker streams for independent skinning launches, see fyx_join (default 2)
- *     "lbs.blocks_per_cu" persistent grid of lbs_skin = CUs x this (default 4)
- *     "lbs.dyn"          single-instance launches from 512 K vertices on: 1 (default) = lbs_skin_dyn, whose waves draw their
- *                        64-vertex units from a per-workgroup ticket counter; 0 = lbs_skin's fixed deal
+ *     "lbs.blocks_per_cu" persistent grid of lbs_skin (and of the lbs.dyn = 0 batch) = CUs x this (default 4)
+ *     "lbs.dyn"          single-instance launches from 512 K vertices on, and every fyx_lbs_skin_batch launch: 1 (default) = the
+ *                        kernels whose waves draw their 64-vertex units from a per-workgroup ticket counter (lbs_skin_dyn,
+ *                        lbs_skin_batch_dyn); 0 = lbs_skin's fixed deal.  Same bits.
  *     "lbs.crowd"        instanced launches: -1 (default) = the crowd kernel from 4 instances on, 0 never, 1 always (it keeps
  *                        a tile of 512 vertices in registers and loops over instances)
  *     "lbs.crowd_ipb"    instances per workgroup run of the crowd kernel, 0 = auto
@@ -353,7 +354,7 @@ int fyx_palette_device(fyx_ctx* ctx, const float* d_global, const float* d_inv_b
 /* ValueBinding (fyrox-animation/src/value.rs:355-373). */
 enum { FYX_BIND_POSITION = 0, FYX_BIND_SCALE = 1, FYX_BIND_ROTATION = 2,
        /* ValueBinding::Property{name, value_type}: FYX_BIND_PROPERTY0 + id, the id standing for the name
-        * (bindings compare by name and type, value.rs:355-373).  TrackValueKind::Real only. */
+        * (bindings compare by name and type, value.rs:355-373).  Tracks of every TrackValueKind. */
        FYX_BIND_PROPERTY0 = 3 };
 /* TrackValueKind (container.rs:40-62) */
 enum { FYX_KIND_REAL = 0, FYX_KIND_VEC2 = 1, FYX_KIND_VEC3 = 2, FYX_KIND_VEC4 = 3,
