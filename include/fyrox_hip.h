@@ -98,8 +98,8 @@ int fyx_join(fyx_ctx* ctx);
  *                        fyx_animator_set_palette_output_pair registers both once).  The skinning launches of two consecutive
  *                        frames are NOT ordered against each other: a caller that skins itself alternates its vertex outputs
  *                        as well (what a renderer that draws frame n while frame n + 1 is skinned does anyway).
- *                        "lbs.streams" is not used then.  C3: frame 0.113 -> 0.094 - 0.101 ms; a scene of 256 characters 0.060 ->
- *                        0.056 ms.  (A second pipelined form -- streams by kind -- measured the same for scenes and the one-stream time
+ *                        "lbs.streams" is not used then.  C3: frame 0.113 -> 0.094 - 0.101 ms (a scene of 256 small characters gains nothing
+ *                        since its skinning is one round of resident workgroups: 0.051 ms either way).  (A second pipelined form -- streams by kind -- measured the same for scenes and the one-stream time
  *                        for crowds; it is "debug.overlap" = 2, for experiments: DESIGN.md section 4.)
  *     "anim.update_lean" 1 (default) = a frame whose fold programs are ALL straight (a few clips blended in a row: the common
  *                        machines; the host classifies with the kernel's own function) runs the update kernel built without the
