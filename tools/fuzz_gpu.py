@@ -89,6 +89,88 @@ def run_with_edits(T, cases, orc, ctx, sc, n_instances, seed):
     return o, p
 
 
+class InstanceView:
+    """One instance of an animator behind the readers tests/test_anim_gpu.py::check_frame uses."""
+
+    def __init__(self, p, i):
+        self.p, self.i = p, i
+
+    def read(self, what):
+        return self.p.read(what)[self.i:self.i + 1]
+
+    def animation_root_motion(self, a):
+        return self.p.animation_root_motion(a)[self.i:self.i + 1]
+
+    def machine_root_motion(self, layer=-1):
+        return self.p.machine_root_motion(layer)[self.i:self.i + 1]
+
+    def read_properties(self, animation=-1):
+        return self.p.read_properties(animation)[self.i:self.i + 1]
+
+    def layer_state(self, layer, instance=0):
+        return self.p.layer_state(layer, self.i)
+
+    def property_slot(self, node, prop):
+        return self.p.property_slot(node, prop)
+
+    def property_count(self):
+        return self.p.property_count()
+
+
+def run_diverge(T, cases, A, orc, ctx, sc, n_inst, seed):
+    """Instances that go their own ways: parameters, speeds, time positions, enabled flags and rewinds set PER INSTANCE (the library keeps
+    a memo of planned programs per instance and steady frames per animator), one oracle per instance."""
+    import numpy as np
+    rng = np.random.default_rng(seed + 11 * 10 ** 6)
+    f32 = lambda x: float(np.float32(x))
+    lib = orc._alib()
+    os_ = [cases.build_oracle(orc, sc) for _ in range(n_inst)]
+    p = cases.build_product(ctx, sc, n_inst)
+    views = [InstanceView(p, i) for i in range(n_inst)]
+    watch = sorted({0, n_inst - 1, int(rng.integers(0, n_inst)), int(rng.integers(0, n_inst))})
+    try:
+        for f in range(sc.n_frames):
+            for idx, par in sc.script.get(f, []):
+                who = range(n_inst) if rng.random() < 0.5 else [int(rng.integers(0, n_inst))]
+                for i in who:
+                    os_[i].set_parameter(idx, par)
+                if len(who) == n_inst:
+                    p.set_parameter(idx, par)
+                else:
+                    p.set_parameter(idx, par, instance=who[0])
+            if rng.random() < 0.35:
+                a, i = int(rng.integers(0, len(sc.animations))), int(rng.integers(0, n_inst))
+                who = [i] if rng.random() < 0.7 else list(range(n_inst))
+                inst = i if len(who) == 1 else A.ALL_INSTANCES
+                kind = int(rng.integers(0, 5))
+                v = f32(rng.choice([1.0, 0.5, 2.5, -1.0, 0.0])) if kind == 0 else f32(rng.random() * 1.2 - 0.1)
+                on = bool(rng.integers(2))
+                for j in who:
+                    h = os_[j].anims[a]
+                    if kind == 0: lib.fo_animation_set_speed(h, v)
+                    elif kind == 1: lib.fo_animation_set_time_position(h, v)
+                    elif kind == 2: lib.fo_animation_set_enabled(h, int(on))
+                    elif kind == 3: lib.fo_animation_rewind(h)
+                    else: lib.fo_animation_set_loop(h, int(on))
+                if kind == 0: p.set_speed(a, v, instance=inst)
+                elif kind == 1: p.set_time_position(a, v, instance=inst)
+                elif kind == 2: p.set_enabled(a, on, instance=inst)
+                elif kind == 3: p.rewind(a, instance=inst)
+                else: p.set_loop(a, on, instance=inst)
+            for o in os_:
+                (o.update_machine if sc.machine is not None else o.update_animations)(sc.dt)
+            (p.update_machine if sc.machine is not None else p.update_animations)(sc.dt)
+            for i in watch:
+                T.check_frame(views[i], os_[i], sc, 1, f)
+        for i in watch:
+            for a in range(len(sc.animations)):
+                assert T._drain(lambda: p.pop_event(a, i)) == T._drain(lambda: os_[i].pop_event(a)), f"events of animation {a}, instance {i}"
+    finally:
+        for o in os_:
+            o.close()
+        p.free()
+
+
 def run_scene(T, cases, A, orc, ctx, seeds, listy, bones):
     """fyx_scene_update over a changing list of random machines (order shuffled, a member left out of some frames, parameters scripted per
     member) against one oracle per member."""
@@ -186,6 +268,7 @@ def main():
     ap.add_argument("--curves", action="store_true", help="tests/anim_cases.py::random_curves instead of random_machine")
     ap.add_argument("--edits", action="store_true", help="random run-time edits between frames: track bindings switched, speeds, loops, "
                     "time positions and slices, enabled flags, rewinds, root-motion settings, signals, event queues")
+    ap.add_argument("--diverge", action="store_true", help="per-instance parameters and clocks, one oracle per instance")
     ap.add_argument("--skin", action="store_true", help="with a registered palette and skin output: the frame through to the vertices")
     ap.add_argument("--scene", type=int, default=0, help="members per scene: the seeds run in groups through fyx_scene_update")
     ap.add_argument("--opt", action="append", default=[], help="key=value context options for the whole run")
@@ -223,6 +306,9 @@ def main():
             if args.skin:
                 run_skin(T, cases, A, oracle, ctx, sc, min(n_inst, 3), seed)
                 continue
+            if args.diverge:
+                run_diverge(T, cases, A, oracle, ctx, sc, max(n_inst, 2) if n_inst < 70 else 40, seed)
+                continue
             o, p = (run_with_edits(T, cases, oracle, ctx, sc, n_inst, seed) if args.edits else T.run_scenario(ctx, oracle, sc, n_instances=n_inst))
             for a in range(len(sc.animations)):
                 assert T._drain(lambda: p.pop_event(a, 0)) == T._drain(lambda: o.pop_event(a)), f"events of animation {a}"
@@ -239,7 +325,7 @@ def main():
             except Exception:   # noqa: BLE001
                 pass
     ctx.set_option("anim.sample_form", 0)
-    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "curves": args.curves, "edits": args.edits, "skin": args.skin, "scene": args.scene, "options": args.opt, "bones": args.bones,
+    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "curves": args.curves, "edits": args.edits, "diverge": args.diverge, "skin": args.skin, "scene": args.scene, "options": args.opt, "bones": args.bones,
            "first_seed": args.first, "seeds": args.count, "failures": len(fails), "failed": fails[:40], "seconds": round(time.time() - t0, 1)}
     line = json.dumps(rec)
     print(line)
