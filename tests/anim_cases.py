@@ -708,7 +708,7 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False) -> Scenario
                 elif r < 0.9:                                              # a property, maybe one that already has a track
                     kind = int(lrng.choice(list(need)))
                     t = A.Track(A.BIND_PROPERTY0 + int(lrng.integers(0, 3)), kind, quat.curves[:need[kind]])
-                    node = 2 + int(lrng.integers(0, 3)) % n_bones
+                    node = (2 + int(lrng.integers(0, 3))) % n_bones
                 else:                                                        # fetch() -> None: no value at all
                     t = A.Track(d.binding, d.kind, d.curves[:len(d.curves) - 1])
                 at = int(lrng.integers(0, len(tracks) + 1))
