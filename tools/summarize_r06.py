@@ -27,10 +27,16 @@ def line(path):
 
 
 out = {"what": "round 6, final library: the evidence behind DESIGN.md section 0", "bench_lines": [line("r06_bench_driver_args.json"), line("r06_bench_plain.json")]}
-d = stats("r06_bench_driver_args_kernel_stats.csv", "lbs_skin_dyn<true, 7>")
+d = stats("r06_bench_streams1_kernel_stats.csv", "lbs_skin_dyn<true, 7>")
 d["frac_of_8TBps"] = round(100e6 / (d["avg_us"] * 1e-6) / 8e12, 4)
-c = stats("r06_bench_driver_args_kernel_stats.csv", "stream_copy_kernel")
-out["headline_kernel_under_trace"] = {"lbs_skin_dyn": d, "stream_copy_kernel_same_bytes": c, "note": "python bench.py --gpus 1 --steps 20 --warmup 5 under rocprofv3 --kernel-trace --stats"}
+c = stats("r06_bench_streams1_kernel_stats.csv", "stream_copy_kernel")
+c["frac_of_8TBps"] = round(100e6 / (c["avg_us"] * 1e-6) / 8e12, 4)
+out["headline_kernel_alone_under_trace"] = {"lbs_skin_dyn": d, "stream_copy_kernel_same_bytes": c,
+                                             "note": "python bench.py --steps 1000 --warmup 100 --opt lbs.streams=1 (LONE launches, 8 rotating sets) under rocprofv3 --kernel-trace --stats"}
+d2 = stats("r06_bench_streams2_kernel_stats.csv", "lbs_skin_dyn<true, 7>")
+d3 = stats("r06_bench_driver_args_kernel_stats.csv", "lbs_skin_dyn<true, 7>")
+out["headline_kernel_overlapped_under_trace"] = {"two_launch_streams": d2, "driver_arguments_whole_run": d3,
+                                                  "note": "launches overlapped on two streams: a dispatch lasts longer, two are in flight; `value` is their throughput"}
 out["scene_256x1_kernels_under_trace"] = [stats("r06_scene_kernel_stats.csv", n) for n in ("lbs_skin_batch_dyn<true, 7>", "pose_sample_scene_kernel", "pose_update_scene_kernel", "ctrl_copy_kernel")]
 out["scene_256x1_batched_kernel_before"] = stats("r06_scene_sampler/scene_kernel_stats_wrap_exits.csv", "lbs_skin_batch<true, 7>")
 ex = json.load(open(os.path.join(P, "r06_bench_ex.json")))["results"]
