@@ -532,6 +532,10 @@ def _listy_tracks(n_bones: int, seed: int, clip: int):
         add(2, A.Track(A.BIND_POSITION, A.KIND_QUAT, donor(2, A.BIND_ROTATION).curves))    # the whole node: one value that fits nothing
         add(13, donor(13, A.BIND_SCALE))
         add(13, A.Track(A.BIND_SCALE, A.KIND_VEC3, donor(12, A.BIND_SCALE).curves))         # three Scale values
+        # the node root motion is taken from (with_root_motion_and_signals: node 0) holds two Positions and two Rotations: update_root_motion
+        # walks them all, the first takes the remainders of the last loop, the one that stays finds None (lib.rs:575-578, :634-637)
+        add(0, donor(0, A.BIND_POSITION))
+        add(0, donor(0, A.BIND_ROTATION), front=True)
     elif clip == 1:
         add(3, donor(3, A.BIND_POSITION))                                   # both operands of the blend hold two Positions
         add(5, donor(5, A.BIND_POSITION), front=True)
@@ -543,6 +547,7 @@ def _listy_tracks(n_bones: int, seed: int, clip: int):
         add(7, donor(7, A.BIND_SCALE), front=True)
         drop(4)
         add(1, A.Track(A.BIND_ROTATION, A.KIND_QUAT, donor(1, A.BIND_ROTATION).curves[:3]))  # too few curves: fetch -> None, no value at all
+        add(1, donor(1, A.BIND_POSITION), front=True)                       # [P', P, ...] on this clip's root-motion node
     return A.AnimationTracksData(tracks), np.asarray(target, np.int32)
 
 
