@@ -618,7 +618,8 @@ def test_blend_shapes_fused_mode_within_tolerance(ctx, orc):
     ctx.mesh_free(61)
 
 
-@pytest.mark.parametrize("n_verts,n_inst,shapes", [(9_001, 2, 0), (64, 1, 2), (63, 3, 0), (50_000, 1, 3), (1, 1, 1), (4096, 2, 0)])
+# (the last two: long enough for every wave of lbs_skin_aos to go back to its workgroup's ticket -- twelve / six units per workgroup)
+@pytest.mark.parametrize("n_verts,n_inst,shapes", [(9_001, 2, 0), (64, 1, 2), (63, 3, 0), (50_000, 1, 3), (1, 1, 1), (4096, 2, 0), (600_000, 1, 0), (300_000, 1, 2)])
 @pytest.mark.parametrize("exact", [1, 0])
 def test_vertex_buffer_in_vertex_buffer_out(ctx, orc, n_verts, n_inst, shapes, exact):
     """out_stride == 0: the mesh's own AnimatedVertex layout (vertex.rs:139-155).  Every output vertex is the input
@@ -1052,6 +1053,27 @@ def test_batch_of_many_meshes_is_bit_exact(ctx, orc, exact, dyn):
         _check_batch(ctx, orc, specs, scene, bool(exact))
     finally:
         ctx.set_option("lbs.exact", 1)
+
+
+@pytest.mark.parametrize("dyn", [1, 0], ids=["batch_dyn", "batch"])
+def test_batch_long_enough_for_every_wave_to_draw_again(ctx, orc, dyn):
+    """A batch of ~15 000 units: a workgroup's range is ~15 units, so the waves of lbs_skin_batch_dyn go back to the ticket after their first two
+    (tools/mutants.py: a ticket that skipped one unit of every segment survived the suite while no batch in it gave a workgroup more than
+    eight).  Ragged meshes, two- and three-instance jobs (below the crowd launch's threshold), a workgroup range that crosses mesh boundaries
+    more than once; every vertex against the oracle."""
+    ALL3 = ("pos", "normal", "tangent")
+    specs = [(60_001, 64, 1, ALL3), (90_000, 128, 1, ALL3), (33_333, 24, 3, ALL3), (120_007, 256, 1, ALL3), (70, 5, 1, ALL3), (45_000, 64, 2, ALL3),
+             (200_000, 96, 1, ALL3), (1_000, 16, 1, ALL3), (80_129, 200, 1, ALL3)]
+    ctx.set_option("lbs.dyn", dyn)
+    scene = _batch_scene(ctx, 7350, specs, synth.SEED_BASE + 320)
+    ctx.lbs_skin_batch(_batch_jobs(7350, specs, scene))
+    ctx.sync()
+    _check_batch(ctx, orc, specs, scene, True)
+    for k, (m, pal, dp, o) in enumerate(scene):
+        for b in list(o.values()) + [dp]:
+            if b:
+                b.free()
+        ctx.mesh_free(7350 + k)
 
 
 def test_batch_with_different_output_sets_and_repeated_calls(ctx, orc):

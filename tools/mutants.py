@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Mutation check of the GPU parity suite: does `pytest -m gpu` notice a one-line change of the device code?
+
+    python tools/mutants.py build        # here (no GPU): one library per mutant under fyrox_amd/mutants/ (git-ignored *.so, travels with gpurun)
+    python tools/mutants.py run [--out gpurun_out/mutants.json]      # on the GPU box: each mutant under the suite, first failing test recorded
+
+A mutant is a single textual replacement in fyrox_amd/csrc (arithmetic re-associated, a comparison relaxed, an exit dropped, a word not
+written): the kind of slip that changes LAST BITS or one edge case.  A mutant that survives names a hole in the suite.  The sources are
+restored after every build; the shipped library is never replaced here (the run step swaps libraries in a scratch copy of the tree)."""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "fyrox_amd", "csrc")
+OUT = os.path.join(ROOT, "fyrox_amd", "mutants")
+LIB = os.path.join(ROOT, "fyrox_amd", "libfyrox_hip.so")
+
+# (name, file, old, new, what it is)
+MUTANTS = [
+    ("lerpf_other_form", "anim_leaves.h", "return a + (b - a) * t; }", "return a * (1.0f - t) + b * t; }",
+     "fyrox-math lerpf written as a (1 - t) + b t: same value, other rounding"),
+    ("constant_key_never_takes_right", "anim_leaves.h", "if (lk == FYX_KEY_CONSTANT) return t == 1.0f ? cv.y : cv.x;\n    if (lk == FYX_KEY_LINEAR) return lerpf_(cv.x, cv.y, t);",
+     "if (lk == FYX_KEY_CONSTANT) return cv.x;\n    if (lk == FYX_KEY_LINEAR) return lerpf_(cv.x, cv.y, t);", "CurveKeyKind::Constant at t == 1 (span records)"),
+    ("nlerp_without_the_flip", "anim_kernels.hip", "        if (dot4(a, o.r) < 0.0f) a = f4{-a.x, -a.y, -a.z, -a.w};\n        const f4 l = f4{a.x * omw + o.r.x * w",
+     "        const f4 l = f4{a.x * omw + o.r.x * w", "value.rs:449-454: self is not negated when dot < 0"),
+    ("position_lerp_other_form", "anim_kernels.hip", "        self.px = self.px * omw + o.px * w;", "        self.px = self.px + (o.px - self.px) * w;",
+     "nalgebra lerp of one component as a + (b - a) w"),
+    ("root_motion_ignore_bits_swapped", "anim_kernels.hip", "rm.delta_position[0] = (an.rm_ignore & 1u) ? 0.0f : delta[0];", "rm.delta_position[0] = (an.rm_ignore & 2u) ? 0.0f : delta[0];",
+     "RootMotionSettings::ignore_x_movement read from ignore_y"),
+    ("root_motion_remainder_not_taken", "anim_kernels.hip", "((prev.rem_flags & 1u) && !(an.rm_ignore & 16u))", "(prev.rem_flags & 1u)",
+     "round 6's own bug: the second Position of the root node's list takes the remainder again"),
+    ("first_span_exit_not_strict", "anim_kernels.hip", "if (lf.x < time && time < lf.y) {", "if (lf.x <= time && time <= lf.y) {",
+     "the first-span exit of sample_curve takes times ON its keys"),
+    ("hierarchy_element_chain_reordered", "anim_kernels.hip", "            float y = a0 * b.x;\n            y = a1 * b.y + y;\n            y = a2 * b.z + y;\n            y = a3 * b.w + y;",
+     "            float y = a3 * b.w;\n            y = a2 * b.z + y;\n            y = a1 * b.y + y;\n            y = a0 * b.x + y;", "global = parent * local summed from the last column backwards (wide walk)"),
+    ("skin_dot_reassociated", "lbs_leaves.h", "if constexpr (EXACT) return (a * x + b * y) + c * z;", "if constexpr (EXACT) return a * x + (b * y + c * z);",
+     "M3x3 * v as a x + (b y + c z)"),
+    ("skin_translation_added_first", "lbs_leaves.h", "z = ((C.x * px + C.y * py) + C.z * pz) + C.w;", "z = C.w + ((C.x * px + C.y * py) + C.z * pz);",
+     "an EQUIVALENT mutant on purpose (IEEE addition commutes): must survive -- the harness's control"),
+    ("tangent_w_not_passed_through", "lbs_leaves.h", "__builtin_bit_cast(u32x4, f32x4{o.tx, o.ty, o.tz, tw}), b.out_tan", "__builtin_bit_cast(u32x4, f32x4{o.tx, o.ty, o.tz, o.tz}), b.out_tan",
+     "tangent.w of the buffer-resource kernels (lbs_skin_dyn, lbs_skin_batch_dyn)"),
+    ("batch_ticket_skips_a_unit", "lbs_kernels.hip", "        if (tid == 0) *ticket = 2 * WPB;\n        bool pj = false;", "        if (tid == 0) *ticket = 2 * WPB + 1;\n        bool pj = false;",
+     "lbs_skin_batch_dyn: one unit of every segment is never drawn"),
+    ("aos_ticket_skips_a_unit", "lbs_kernels.hip", "    if (tid == 0) *ticket = (TWO ? 2 : 1) * WPB;", "    if (tid == 0) *ticket = (TWO ? 2 : 1) * WPB + 1;",
+     "lbs_skin_aos: one unit of every segment is never drawn"),
+    ("staged_output_tangent_w_masked", "lbs_kernels.hip", "wmask |= 15ull << (x.off_tan / 4);", "wmask |= 7ull << (x.off_tan / 4);",
+     "lbs_skin_ex's staged interleaved output: tangent.w not written"),
+    ("projective_divide_skipped", "lbs_leaves.h", "if (n != 0.0f) { xy.x = xy.x / n; xy.y = xy.y / n; z = z / n; }", "if (n != 0.0f && n != 1.0f) { xy.x = xy.x / n; xy.y = xy.y / n; z = z / n; }",
+     "an EQUIVALENT mutant on purpose (x / 1 == x): must survive"),
+    ("crowd_last_instance_of_a_run_dropped", "lbs_kernels.hip", "    const uint32_t i1 = (i0 + ipb < a.n_instances) ? i0 + ipb : a.n_instances;\n    if (i0 >= i1) return;\n    const uint32_t v = tile * BLOCK + tid;",
+     "    const uint32_t i1 = (i0 + ipb < a.n_instances) ? i0 + ipb : a.n_instances - 1;\n    if (i0 >= i1) return;\n    const uint32_t v = tile * BLOCK + tid;", "the crowd kernel never skins the last instance"),
+    ("palette_commit_row3_wrong_column", "lbs_kernels.hip", "            reinterpret_cast<float*>(row3 + b)[c] = col[i].w;\n            pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);\n        }\n    }\n    const bool wave_pj = __any(pj) != 0;\n    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;\n    __syncthreads();\n    bool projective = false;\n#pragma unroll\n    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;\n    pin_vertex(A);",
+     "            reinterpret_cast<float*>(row3 + b)[c] = col[i].z;\n            pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);\n        }\n    }\n    const bool wave_pj = __any(pj) != 0;\n    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;\n    __syncthreads();\n    bool projective = false;\n#pragma unroll\n    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;\n    pin_vertex(A);",
+     "lbs_skin_dyn stages the projective row from the wrong component"),
+]
+
+
+def build(only=None):
+    os.makedirs(OUT, exist_ok=True)
+    made, t0 = [], time.time()
+    if only and os.path.exists(os.path.join(OUT, "index.json")):
+        made = [m["name"] for m in json.load(open(os.path.join(OUT, "index.json"))) if m["name"] not in only]
+    for name, fn, old, new, what in MUTANTS:
+        if only and name not in only:
+            continue
+        path = os.path.join(SRC, fn)
+        src = open(path).read()
+        if src.count(old) != 1:
+            print(f"{name}: the text to replace occurs {src.count(old)} times in {fn}: skipped", file=sys.stderr)
+            continue
+        keep = LIB + ".keep"
+        shutil.copy2(LIB, keep)
+        try:
+            open(path, "w").write(src.replace(old, new))
+            r = subprocess.run(["make", "-C", SRC], capture_output=True, text=True)
+            if r.returncode != 0:
+                print(f"{name}: does not build\n{r.stderr[-800:]}", file=sys.stderr)
+                continue
+            shutil.copy2(LIB, os.path.join(OUT, name + ".so"))
+            made.append(name)
+            print(f"{name}: built ({time.time() - t0:.0f} s)", flush=True)
+        finally:
+            open(path, "w").write(src)
+            shutil.move(keep, LIB)
+    # the objects of the last mutant are newer than the restored sources' library: rebuild what the tree ships
+    subprocess.run(["touch"] + [os.path.join(SRC, f) for f in sorted({m[1] for m in MUTANTS})], check=True)
+    r = subprocess.run(["make", "-C", SRC], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+    json.dump([{"name": m[0], "file": m[1], "what": m[4]} for m in MUTANTS if m[0] in made], open(os.path.join(OUT, "index.json"), "w"), indent=1)
+    print(f"{len(made)} mutants under {OUT}; the shipped library rebuilt from the restored sources")
+
+
+def run(out, only=None):
+    idx = [m for m in json.load(open(os.path.join(OUT, "index.json"))) if not only or m["name"] in only]
+    good = LIB + ".shipped"
+    shutil.copy2(LIB, good)
+    res = []
+    try:
+        for m in idx:
+            shutil.copy2(os.path.join(OUT, m["name"] + ".so"), LIB)
+            t0 = time.time()
+            r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True)
+            tail = [l for l in r.stdout.splitlines() if l.startswith("FAILED") or l.startswith("ERROR")]
+            res.append(dict(m, killed=r.returncode != 0, by=(tail[0][:200] if tail else None), seconds=round(time.time() - t0, 1)))
+            print(json.dumps(res[-1]), flush=True)
+    finally:
+        shutil.move(good, LIB)
+    rec = {"what": "one-line mutants of the device code under `pytest -m gpu -x`", "mutants": len(res), "killed": sum(r["killed"] for r in res),
+           "survived": [r["name"] for r in res if not r["killed"]], "results": res}
+    if out:
+        os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+        json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps({k: rec[k] for k in ("mutants", "killed", "survived")}))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("step", choices=("build", "run"))
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="comma-separated mutant names")
+    a = ap.parse_args()
+    only = a.only.split(",") if a.only else None
+    build(only) if a.step == "build" else run(a.out, only)
