@@ -13,6 +13,7 @@ import pytest
 import fyrox_amd
 from fyrox_amd import _native
 from fyrox_amd import anim as A
+from fyrox_amd import synth
 
 import anim_cases as cases
 
@@ -239,6 +240,38 @@ def _check_control_plane(orc, cctx, sc):
             for a, spec in enumerate(sc.animations):   # the slices and flags the root-motion kernel receives
                 assert tuple(rp["slices"][0, a]) == tuple(np.float32(x) for x in spec.time_slice)
     o.close()
+
+
+def test_a_looping_animation_on_its_last_key_has_not_ended(orc, cctx):
+    """Animation::has_ended is `!looped && |time - end| <= eps` (lib.rs:736-738): a LOOPING clip whose time position sits exactly on the end of its
+    slice (wrapf keeps a value inside [start, end] as it is) has not ended, and an IsAnimationEnded transition on it does not fire; switched to
+    non-looping at the same position it has, and the transition fires on the next update.  (tools/mutants_host.py: a has_ended without the
+    loop test survived the scenario suite -- no scenario ever parks a looping clip on its last key.)"""
+    n_bones, seed = 6, synth.SEED_BASE + 41
+    rig = synth.make_rig(n_bones, seed)
+    td, tgt = synth.make_clip(n_bones, seed, 0, n_keys=5, fps=4.0, euler_every=10 ** 9)
+    layer = A.MachineLayer(nodes=[A.PlayAnimation(0), A.PlayAnimation(0)], states=[A.State(0), A.State(1)],
+                           transitions=[A.Transition(0, 1, 0.1, ("ended", 0))])
+    sc = cases.Scenario("ended", rig, [td], [cases.AnimSpec(0, tgt, time_slice=(0.0, 1.0), speed=0.0, looped=True)],
+                        A.Machine(parameters=[], layers=[layer]), n_frames=4, has_euler=False)
+    o, p = cases.build_oracle(orc, sc), cases.build_product(cctx, sc, 1)
+    try:
+        orc._alib().fo_animation_set_time_position(o.anims[0], 1.0)
+        p.set_time_position(0, 1.0)
+        for f in range(3):
+            assert p.animation_state(0) == o.animation_state(0) and not p.animation_state(0)["has_ended"]
+            o.update_machine(0.05)
+            p.plan(1, 0.05)
+            assert p.layer_state(0) == o.layer_state(0) == (0, -1), "the transition must not fire on a looping clip"
+        orc._alib().fo_animation_set_loop(o.anims[0], 0)
+        p.set_loop(0, False)
+        assert p.animation_state(0) == o.animation_state(0) and p.animation_state(0)["has_ended"]
+        o.update_machine(0.05)
+        p.plan(1, 0.05)
+        assert p.layer_state(0) == o.layer_state(0) and p.layer_state(0)[1] == 0, "now it fires"
+    finally:
+        o.close()
+        p.free()
 
 
 def test_transitions_scenario_visits_every_state(orc):

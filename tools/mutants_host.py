@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Mutation check of the CPU suite's hold on the HOST control plane (no GPU): one-line mutants of csrc/anim_planner.h / anim_api.hip, each built
+into the library and run under the control-plane tests (tests/test_anim_control.py, test_machine_edits.py, test_device_leaves_on_host.py).
+
+    python tools/mutants_host.py [--out profiles/r06_fuzz/mutants_host.json]
+
+The sources and the shipped library are restored after every mutant."""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "fyrox_amd", "csrc")
+LIB = os.path.join(ROOT, "fyrox_amd", "libfyrox_hip.so")
+TESTS = ["tests/test_anim_control.py", "tests/test_machine_edits.py", "tests/test_device_leaves_on_host.py"]
+
+MUTANTS = [
+    ("signal_on_the_current_time", "anim_planner.h", "(current < sg.time && next >= sg.time)", "(current <= sg.time && next >= sg.time)", "lib.rs:476-489: a signal AT the current time fires"),
+    ("signal_cap_guards_both_branches", "anim_planner.h", "if ((s.speed >= 0.0f && (current < sg.time && next >= sg.time)) ||",
+     "if ((s.speed >= 0.0f && (current < sg.time && next >= sg.time) && s.events.size() < s.max_event_capacity) ||", "the precedence quirk of lib.rs:478-482 'repaired'"),
+    ("wrapf_upper_bound_strict", "anim_planner.h", "    if (n >= max_limit) {\n        n -= num_of_max * max_limit;", "    if (n > max_limit) {\n        n -= num_of_max * max_limit;", "fyrox-math wrapf"),
+    ("looped_animations_end", "anim_planner.h", "return !s.looped && fabsf(s.time - s.end) <= FLT_EPSILON; }", "return fabsf(s.time - s.end) <= FLT_EPSILON; }", "Animation::has_ended"),
+    ("xor_is_or", "anim_planner.h", "return l ^ r; }", "return l | r; }", "LogicNode::Xor"),
+    ("ended_of_an_invalid_handle_is_false", "anim_planner.h", "return true;  // invalid handle: is_none_or -> true", "return false;", "LogicNode::IsAnimationEnded on a handle that does not resolve"),
+    ("weight_parameter_of_any_kind", "anim_planner.h", "w = (p && p->kind == FYX_PARAM_WEIGHT) ? p->f0 : 0.0f;", "w = p ? p->f0 : 0.0f;", "BlendPose weight from a parameter of another kind"),
+    ("rewind_to_the_end", "anim_planner.h", "case FYX_ACTION_REWIND_ANIMATION: set_time_position(s, s.start); break;", "case FYX_ACTION_REWIND_ANIMATION: set_time_position(s, s.end); break;", "StateAction::RewindAnimation"),
+    ("transition_factor_after_the_clamp_only", "anim_planner.h", "                if (ts.elapsed > tr.time) ts.elapsed = tr.time;\n                ts.blend_factor = ts.elapsed / tr.time;",
+     "                ts.blend_factor = ts.elapsed / tr.time;\n                if (ts.elapsed > tr.time) ts.elapsed = tr.time;", "transition.rs:315-321: the factor formed before the clamp"),
+    ("by_index_weights_swapped", "anim_planner.h", "its[cnt++] = {(uint32_t)pr, 1.0f - interpolator};", "its[cnt++] = {(uint32_t)pr, interpolator};", "BlendAnimationsByIndex: the previous input's weight"),
+    ("new_loop_flag_never_set", "anim_planner.h", "(uint8_t)(1u | (new_loop ? 2u : 0u) | (s.speed > 0.0f ? 4u : 0u));", "(uint8_t)(1u | (s.speed > 0.0f ? 4u : 0u));", "what update_root_motion is told about a wrapped loop"),
+    ("max_weight_strategy_takes_the_first_of_equals", "anim_api.hip", "if (strategy == FYX_EVENTS_MAX_WEIGHT) { if (!(w < bw)) { best = (int)i; bw = w; } }",
+     "if (strategy == FYX_EVENTS_MAX_WEIGHT) { if (w > bw) { best = (int)i; bw = w; } }", "collect_active_animations_events: max_by's tie-break (the last of equals)"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    keep = LIB + ".shipped"
+    shutil.copy2(LIB, keep)
+    res = []
+    try:
+        for name, fn, old, new, what in MUTANTS:
+            path = os.path.join(SRC, fn)
+            src = open(path).read()
+            if a.only and name not in a.only.split(","):
+                continue
+            if src.count(old) < 1:      # (a text that occurs twice -- the tick and the steady path's copy of it -- is replaced in both places)
+                res.append({"name": name, "file": fn, "what": what, "built": False, "note": "the text does not occur"})
+                print(json.dumps(res[-1]), flush=True)
+                continue
+            t0 = time.time()
+            try:
+                open(path, "w").write(src.replace(old, new))
+                b = subprocess.run(["make", "-C", SRC], capture_output=True, text=True)
+                if b.returncode != 0:
+                    res.append({"name": name, "file": fn, "what": what, "built": False, "note": b.stderr[-300:]})
+                    continue
+                r = subprocess.run([sys.executable, "-m", "pytest", *TESTS, "-x", "-q", "-n", "6", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True)
+                tail = [l for l in r.stdout.splitlines() if l.startswith("FAILED") or l.startswith("ERROR")]
+                res.append({"name": name, "file": fn, "what": what, "built": True, "killed": r.returncode != 0, "by": tail[0][:160] if tail else None, "seconds": round(time.time() - t0, 1)})
+            finally:
+                open(path, "w").write(src)
+            print(json.dumps(res[-1]), flush=True)
+    finally:
+        subprocess.run(["make", "-C", SRC], capture_output=True, text=True)     # the restored sources are newer than the last mutant's objects
+        os.remove(keep)
+    built = [r for r in res if r.get("built")]
+    rec = {"what": "one-line mutants of the host control plane under the CPU control-plane tests", "mutants": len(built), "killed": sum(r["killed"] for r in built),
+           "survived": [r["name"] for r in built if not r["killed"]], "results": res}
+    if a.out:
+        json.dump(rec, open(a.out, "w"), indent=1)
+    print(json.dumps({k: rec[k] for k in ("mutants", "killed", "survived")}))
+
+
+if __name__ == "__main__":
+    main()
