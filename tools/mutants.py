@@ -54,6 +54,25 @@ MUTANTS = [
      "an EQUIVALENT mutant on purpose (x / 1 == x): must survive"),
     ("crowd_last_instance_of_a_run_dropped", "lbs_kernels.hip", "    const uint32_t i1 = (i0 + ipb < a.n_instances) ? i0 + ipb : a.n_instances;\n    if (i0 >= i1) return;\n    const uint32_t v = tile * BLOCK + tid;",
      "    const uint32_t i1 = (i0 + ipb < a.n_instances) ? i0 + ipb : a.n_instances - 1;\n    if (i0 >= i1) return;\n    const uint32_t v = tile * BLOCK + tid;", "the crowd kernel never skins the last instance"),
+    # ---- second batch ----
+    ("quat_normalize_by_reciprocal", "anim_kernels.hip", "    return f4{q.x / n, q.y / n, q.z / n, q.w / n};", "    const float r_ = 1.0f / n;\n    return f4{q.x * r_, q.y * r_, q.z * r_, q.w * r_};",
+     "UnitQuaternion normalisation as a multiplication by 1 / n"),
+    ("quat_to_matrix_term_order", "anim_kernels.hip", "o.m[0] = ww + ii - jj - kk;", "o.m[0] = ww - jj + ii - kk;", "rotation matrix diagonal summed in another order"),
+    ("local_matrix_translation_reassociated", "anim_kernels.hip", "out[12 + row] = ro[row] + rp[row] + t[row] - rpx * f0", "out[12 + row] = ro[row] + (rp[row] + t[row]) - rpx * f0",
+     "calculate_local_transform's translation row, first two additions re-associated"),
+    ("mask_clears_nothing_on_node_0", "anim_kernels.hip", "                if (cx.layer_masks[(size_t)arg * cx.n_nodes + cx.node]) acc.mask = 0;\n                break;\n            case OP_APPLY:\n                apply_pose(cx, acc);",
+     "                if (cx.node && cx.layer_masks[(size_t)arg * cx.n_nodes + cx.node]) acc.mask = 0;\n                break;\n            case OP_APPLY:\n                apply_pose(cx, acc);",
+     "LayerMask::should_animate ignored for node 0 (general fold)"),
+    ("list_not_empty_bit_dropped", "anim_kernels.hip", "| (has_prop ? 8u : 0u) | (d.present & 16u));", "| (has_prop ? 8u : 0u));", "a value that fits no binding no longer makes its node's list non-empty"),
+    ("property_vec3_lerp_other_form", "anim_kernels.hip", "            self.v.x = self.v.x * omw + o.v.x * w; self.v.y = self.v.y * omw + o.v.y * w; self.v.z = self.v.z * omw + o.v.z * w;\n            break;\n        case FYX_VALUE_VEC4:",
+     "            self.v.x = self.v.x + (o.v.x - self.v.x) * w; self.v.y = self.v.y * omw + o.v.y * w; self.v.z = self.v.z * omw + o.v.z * w;\n            break;\n        case FYX_VALUE_VEC4:",
+     "a Vector3 property's first lane blended as a + (b - a) w"),
+    ("crowd_span_clamp_at_first_key_strict", "anim_leaves.h", "    if (time <= l_first) {", "    if (time < l_first) {", "Curve::value_at's clamp at the first key (span-record form: crowd sampler)"),
+    ("duplicate_key_locations_take_the_hint", "anim_leaves.h", "if (time >= locs.x && time <= locs.y && locs.x < locs.y) right = h;", "if (time >= locs.x && time <= locs.y) right = h;",
+     "the hinted span accepted although its two keys share a location"),
+    ("blend_shape_offsets_position_only_twice", "lbs_kernels.hip", "                        px = px + h2f(h[0]) * ws; py = py + h2f(h[1]) * ws; pz = pz + h2f(h[2]) * ws;\n                        nx = nx + h2f(h[3]) * ws; ny = ny + h2f(h[4]) * ws; nz = nz + h2f(h[5]) * ws;\n                        t.x = t.x + h2f(h[6]) * ws; t.y = t.y + h2f(h[7]) * ws; t.z = t.z + h2f(h[8]) * ws;\n                    } else {\n                        px = __builtin_fmaf(h2f(h[0]), ws, px); py = __builtin_fmaf(h2f(h[1]), ws, py);\n                        pz = __builtin_fmaf(h2f(h[2]), ws, pz); nx = __builtin_fmaf(h2f(h[3]), ws, nx);\n                        ny = __builtin_fmaf(h2f(h[4]), ws, ny); nz = __builtin_fmaf(h2f(h[5]), ws, nz);\n                        t.x = __builtin_fmaf(h2f(h[6]), ws, t.x); t.y = __builtin_fmaf(h2f(h[7]), ws, t.y);\n                        t.z = __builtin_fmaf(h2f(h[8]), ws, t.z);\n                    }\n                }\n            }\n            const Skinned o = skin_vertex<EXACT, 7>(rows, row3, projective, id, w, px, py, pz, nx, ny, nz, t.x, t.y, t.z);\n            if constexpr (AOS) {",
+     "                        px = px + h2f(h[0]) * ws; py = py + h2f(h[1]) * ws; pz = pz + h2f(h[2]) * ws;\n                        nx = nx + h2f(h[3]) * ws; ny = ny + h2f(h[4]) * ws; nz = nz + h2f(h[5]) * ws;\n                        t.x = t.x + h2f(h[6]) * ws; t.y = t.y + h2f(h[7]) * ws; t.z = t.z + h2f(h[7]) * ws;\n                    } else {\n                        px = __builtin_fmaf(h2f(h[0]), ws, px); py = __builtin_fmaf(h2f(h[1]), ws, py);\n                        pz = __builtin_fmaf(h2f(h[2]), ws, pz); nx = __builtin_fmaf(h2f(h[3]), ws, nx);\n                        ny = __builtin_fmaf(h2f(h[4]), ws, ny); nz = __builtin_fmaf(h2f(h[5]), ws, nz);\n                        t.x = __builtin_fmaf(h2f(h[6]), ws, t.x); t.y = __builtin_fmaf(h2f(h[7]), ws, t.y);\n                        t.z = __builtin_fmaf(h2f(h[8]), ws, t.z);\n                    }\n                }\n            }\n            const Skinned o = skin_vertex<EXACT, 7>(rows, row3, projective, id, w, px, py, pz, nx, ny, nz, t.x, t.y, t.z);\n            if constexpr (AOS) {",
+     "lbs_skin_ex (exact): the tangent's z offset of a blend shape read from its y plane"),
     ("palette_commit_row3_wrong_column", "lbs_kernels.hip", "            reinterpret_cast<float*>(row3 + b)[c] = col[i].w;\n            pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);\n        }\n    }\n    const bool wave_pj = __any(pj) != 0;\n    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;\n    __syncthreads();\n    bool projective = false;\n#pragma unroll\n    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;\n    pin_vertex(A);",
      "            reinterpret_cast<float*>(row3 + b)[c] = col[i].z;\n            pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);\n        }\n    }\n    const bool wave_pj = __any(pj) != 0;\n    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;\n    __syncthreads();\n    bool projective = false;\n#pragma unroll\n    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;\n    pin_vertex(A);",
      "lbs_skin_dyn stages the projective row from the wrong component"),
