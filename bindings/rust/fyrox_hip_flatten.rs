@@ -21,6 +21,7 @@ use crate::generic_animation::{
     value::ValueBinding,
     AnimationTracksData,
 };
+use crate::graph::SceneGraph; // the trait that declares try_get_node (fyrox-graph/src/lib.rs; `pub use fyrox_graph as graph`, fyrox-impl/src/lib.rs:58)
 use crate::scene::{
     animation::{
         absm::{Event, LogicNode, Machine, PoseNode, State, StateAction, Transition},

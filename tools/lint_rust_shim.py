@@ -7,6 +7,7 @@ that sank the first version of the shim: names that do not exist in the referenc
   * every `.method(` called on a value and every `Type::function(` must exist as a `pub fn` somewhere in the reference
     crates the path touches (or be a std / nalgebra / shim-own name from the allow-lists below);
   * every `Enum::Variant` used in a pattern must be a variant of that reference enum;
+  * a method that only a TRAIT of the reference declares (e.g. `SceneGraph::try_get_node`) needs that trait in a `use` of the file;
   * every extern function called (`fyx_*`) must be declared in bindings/rust/fyrox_hip_sys.rs (generated from the header)
     and be called with as many arguments as it is declared with.
 
@@ -21,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 SHIM = [os.path.join(ROOT, "bindings", "rust", f) for f in ("fyrox_hip.rs", "fyrox_hip_flatten.rs")]
 SYS = os.path.join(ROOT, "bindings", "rust", "fyrox_hip_sys.rs")
-CRATES = ["fyrox-impl/src", "fyrox-animation/src", "fyrox-core/src", "fyrox-math/src", "fyrox-resource/src"]
+CRATES = ["fyrox-impl/src", "fyrox-animation/src", "fyrox-core/src", "fyrox-math/src", "fyrox-resource/src", "fyrox-graph/src"]
 
 # methods of std, core, nalgebra, fxhash and the shim's own types (not defined in the reference tree)
 STD_METHODS = set("""
@@ -87,7 +88,7 @@ def module_file(crate_dir, segments):
 
 
 # crate-level re-exports the shim relies on (fyrox-impl/src/lib.rs:50-60): crate::core = fyrox_core, crate::generic_animation = fyrox_animation
-ALIASES = {"core": "fyrox-core/src", "generic_animation": "fyrox-animation/src"}
+ALIASES = {"core": "fyrox-core/src", "generic_animation": "fyrox-animation/src", "graph": "fyrox-graph/src"}
 
 
 def check_path(path, sources, findings, where):
@@ -130,6 +131,16 @@ def main():
     pub_fns = set(re.findall(r"pub(?:\([a-z]+\))?\s+(?:const\s+)?(?:unsafe\s+)?fn\s+([a-zA-Z_0-9]+)", all_ref))
     trait_fns = set(re.findall(r"^\s+fn\s+([a-zA-Z_0-9]+)", all_ref, flags=re.M))       # trait methods are not `pub fn`
     pub_fields = set(re.findall(r"^\s+pub\s+([a-z_0-9]+)\s*:", all_ref, flags=re.M))
+    # methods DECLARED by a trait of the reference: callable only with that trait in scope (`use ...::Trait;`)
+    trait_decl = {}
+    for m in re.finditer(r"pub\s+trait\s+([A-Za-z0-9_]+)[^{;]*\{", all_ref):
+        depth, i = 1, m.end()
+        while depth and i < len(all_ref):
+            depth += all_ref[i] == "{"
+            depth -= all_ref[i] == "}"
+            i += 1
+        for fn in re.findall(r"^\s+fn\s+([a-zA-Z_0-9]+)", all_ref[m.end():i], flags=re.M):
+            trait_decl.setdefault(fn, set()).add(m.group(1))
     enums = {}
     for m in re.finditer(r"pub\s+enum\s+([A-Za-z0-9_]+)[^{]*\{", all_ref):
         body, depth, i = "", 1, m.end()
@@ -184,6 +195,12 @@ def main():
         # ---- methods
         for m in re.finditer(r"\.([a-z_][a-z0-9_]*)\s*\(", src):
             fn = m.group(1)
+            if fn not in STD_METHODS and fn not in SHIM_OWN and fn not in pub_fns and fn in trait_decl:
+                used = set(re.findall(r"\b([A-Z][A-Za-z0-9_]*)\b", " ".join(re.findall(r"\buse\s+[^;]+;", src))))
+                if not (trait_decl[fn] & used):
+                    line = src[:m.start()].count("\n") + 1
+                    findings.append(f"{name}:{line}: `.{fn}(` is a method of the trait(s) {sorted(trait_decl[fn])}: none of them is in a `use` of this file")
+                continue
             if fn in STD_METHODS or fn in SHIM_OWN or fn in pub_fns or fn in trait_fns:
                 continue
             line = src[:m.start()].count("\n") + 1
