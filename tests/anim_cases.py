@@ -139,6 +139,12 @@ def blend_space(n_bones=16, seed=synth.SEED_BASE + 9) -> Scenario:
         x = 0.5 + 0.9 * np.cos(f * 0.21)   # wanders outside the unit square: nearest-edge branch
         y = 0.5 + 0.9 * np.sin(f * 0.13)
         script[f] = [(0, A.Parameter(A.PARAM_SAMPLING_POINT, (float(np.float32(x)), float(np.float32(y)))))]
+    # sampling points ON the triangles' edges and corners: barycentric_is_inside (fyrox-math/src/lib.rs:326-328) is closed on two
+    # sides (u >= 0, v >= 0) and OPEN on the third (u + v < 1), so a point on the shared diagonal is outside [2, 0, 1] (w == 0 there) and
+    # inside [3, 0, 2] (u == 0), and the sequential fold makes those two answers different poses
+    on_edges = [(0.5, 0.5), (0.25, 0.25), (1.0, 0.5), (0.5, 0.0), (0.0, 0.5), (0.5, 1.0), (0.0, 0.0), (1.0, 1.0), (1.0, 0.0), (0.0, 1.0)]
+    for k, pt in enumerate(on_edges):
+        script[3 + 4 * k] = [(0, A.Parameter(A.PARAM_SAMPLING_POINT, pt))]
     return Scenario("blend_space", rig, tds, anims, m, script, n_frames=48, has_euler=False)
 
 

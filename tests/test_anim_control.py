@@ -289,6 +289,24 @@ def test_transitions_scenario_visits_every_state(orc):
     o.close()
 
 
+def test_mesh_upload_checks_its_layout_before_it_needs_a_device(cctx):
+    """fyx_mesh_upload validates the vertex layout first (an attribute must END inside the vertex: AnimatedVertex is 68 bytes,
+    vertex.rs:139-155), so the refusals are the same on a context without a device; a layout that passes then needs one."""
+    aos = np.zeros(680, np.uint8)
+    for kw, status in [(dict(off_pos=0, off_weights=60, off_indices=64), "FYX_ERR_INVALID_ARG"),       # weights 60 + 16 > 68
+                       (dict(off_pos=57, off_weights=32, off_indices=48), "FYX_ERR_INVALID_ARG"),      # position 57 + 12 > 68
+                       (dict(off_pos=0, off_weights=48, off_indices=65), "FYX_ERR_INVALID_ARG"),       # indices 65 + 4 > 68
+                       (dict(off_pos=0, off_normal=60, off_weights=32, off_indices=48), "FYX_ERR_INVALID_ARG"),
+                       (dict(off_pos=0, off_tangent=56, off_weights=16, off_indices=32), "FYX_ERR_INVALID_ARG"),
+                       (dict(off_pos=0, off_weights=-1, off_indices=64), "FYX_ERR_MISSING_ATTRIBUTE")]:
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            cctx.mesh_upload(14, aos, 10, 68, **kw)
+        assert e.value.status == status, kw
+    with pytest.raises(fyrox_amd.FyxError) as e:      # the reference's own layout fits exactly (indices 64 + 4 == 68): only the device is missing
+        cctx.mesh_upload(14, aos, 10, 68, off_pos=0, off_normal=20, off_tangent=32, off_weights=48, off_indices=64)
+    assert e.value.code == _native.FYX_ERR_NO_DEVICE
+
+
 def test_control_only_context_refuses_data_path(cctx):
     l = _native.lib()
     sc = cases.by_index()

@@ -59,6 +59,28 @@ def test_simplify_three_implementations_agree_on_importer_shaped_curves():
     assert kept_total > 500
 
 
+def test_simplify_ties_and_thresholds():
+    """find_points_in_span's two comparisons on values a float holds exactly (gltf/simplify.rs:118-131): `far_point_dist < dist` keeps
+    the FIRST of equally far points, `far_point_dist < epsilon` keeps a point that is EXACTLY epsilon off the line.  Expected indices by
+    hand from the reference's text; the three implementations agree with them."""
+    cases = [
+        # (points, epsilon, expected)
+        ([(0.0, 0.0), (1.0, 0.5), (2.0, 0.0)], 0.5, [0, 1, 2]),                  # 0.5 < 0.5 is false: kept
+        ([(0.0, 0.0), (1.0, 0.5), (2.0, 0.0)], 0.5000001, [0]),                  # dropped; the two ends are then one value: one key (simplify.rs:62-64)
+        ([(0.0, 0.0), (1.0, 2.0), (2.0, 2.0)], 1.0000001, [0, 2]),              # 1.0 off the chord, dropped; the ends differ by 2.0: two keys
+        ([(0.0, 0.0), (1.0, 2.0), (2.0, 2.0)], 1.0, [0, 1, 2]),
+        # keys 1 and 2 both lie 1.0 off the chord: key 1 wins, then key 2 is 0.5 off (1, 1) - (3, 0): dropped at 0.75.
+        # (had key 2 won, key 1 would be 0.5 off (0, 0) - (2, 1) and the answer [0, 2, 3])
+        ([(0.0, 0.0), (1.0, 1.0), (2.0, 1.0), (3.0, 0.0)], 0.75, [0, 1, 3]),
+        ([(0.0, 0.0), (1.0, 1.0), (2.0, 1.0), (3.0, 0.0)], 0.5, [0, 1, 2, 3]),   # ... and kept when 0.5 is the threshold itself
+    ]
+    for pts, eps, want in cases:
+        x, y = [p[0] for p in pts], [p[1] for p in pts]
+        assert list(oracle.find_important_points(x, y, eps, float("inf"))) == want, (pts, eps)
+        assert o2c.find_important_points(pts, eps, float("inf")) == want, (pts, eps)
+        assert list(A.curve_simplify(x, y, eps, float("inf"))) == want, (pts, eps)
+
+
 def test_simplify_argument_errors():
     from fyrox_amd import _native
     lib = _native.lib()

@@ -16,7 +16,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fyrox_amd", "csrc")
 LIB = os.path.join(ROOT, "fyrox_amd", "libfyrox_hip.so")
-TESTS = ["tests/test_anim_control.py", "tests/test_machine_edits.py", "tests/test_device_leaves_on_host.py"]
+TESTS = ["tests/test_anim_control.py", "tests/test_machine_edits.py", "tests/test_device_leaves_on_host.py"]      # + BATCH2_TESTS (below) since the second batch
 
 MUTANTS = [
     ("signal_on_the_current_time", "anim_planner.h", "(current < sg.time && next >= sg.time)", "(current <= sg.time && next >= sg.time)", "lib.rs:476-489: a signal AT the current time fires"),
@@ -34,7 +34,20 @@ MUTANTS = [
     ("new_loop_flag_never_set", "anim_planner.h", "(uint8_t)(1u | (new_loop ? 2u : 0u) | (s.speed > 0.0f ? 4u : 0u));", "(uint8_t)(1u | (s.speed > 0.0f ? 4u : 0u));", "what update_root_motion is told about a wrapped loop"),
     ("max_weight_strategy_takes_the_first_of_equals", "anim_api.hip", "if (strategy == FYX_EVENTS_MAX_WEIGHT) { if (!(w < bw)) { best = (int)i; bw = w; } }",
      "if (strategy == FYX_EVENTS_MAX_WEIGHT) { if (w > bw) { best = (int)i; bw = w; } }", "collect_active_animations_events: max_by's tie-break (the last of equals)"),
+    # ---- second batch: the rest of the host code the CPU suite reaches (blend-space weights, the curve simplifier, the shard cuts)
+    ("blend_space_inside_test_closed", "anim_planner.h", "if (u >= 0.0f && v >= 0.0f && u + v < 1.0f) {", "if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {", "fyrox-math get_barycentric_coords / is_inside: u + v < 1 is strict"),
+    ("blend_space_nearest_edge_takes_the_last_of_equals", "anim_planner.h", "if (distance < min_distance) {", "if (distance <= min_distance) {", "blendspace.rs:380-410: the first of equally near edges wins"),
+    ("blend_space_two_points_weights_swapped", "anim_planner.h", "w[0] = 1.0f - t; w[1] = t; w[2] = 0.0f;\n                return true;\n            }\n        }\n        const size_t nt", "w[0] = t; w[1] = 1.0f - t; w[2] = 0.0f;\n                return true;\n            }\n        }\n        const size_t nt", "blendspace.rs:350-362: the segment's weights"),
+    ("simplify_keeps_a_point_at_epsilon", "host_geom.hip", "if (far == 0 || far_dist < epsilon) continue;", "if (far == 0 || far_dist <= epsilon) continue;", "simplify.rs:128-131: a point exactly epsilon away is kept"),
+    ("simplify_farthest_takes_the_last_of_equals", "host_geom.hip", "if (far_dist < dist) { far_dist = dist; far = i; }", "if (far_dist <= dist) { far_dist = dist; far = i; }", "simplify.rs:118-124: the first of equally far points"),
+    ("simplify_two_equal_keys_stay_two", "host_geom.hip", "if (m == 2 && std::fabs(y[out_indices[0]] - y[out_indices[1]]) < epsilon) m = 1;", "if (false) m = 1;", "simplify.rs:62-64: a flat curve collapses to one key"),
+    ("simplify_step_limit_off_by_one", "host_geom.hip", "next = std::max(k - 1, start + 1); break; }", "next = std::max(k, start + 1); break; }", "simplify.rs:85-101 find_step: the key BEFORE the one that oversteps"),
+    ("shard_cut_rounds_the_groups_down", "comm_api.hip", "    const uint64_t groups = ((uint64_t)n_verts + kShardAlign - 1) / kShardAlign;\n    const uint64_t v = (g * groups / n_ranks) * kShardAlign;", "    const uint64_t groups = ((uint64_t)n_verts) / kShardAlign;\n    const uint64_t v = (g * groups / n_ranks) * kShardAlign;", "the ragged cut: a mesh's last partial group belongs to the last rank"),
+    ("padded_shard_rounds_down", "comm_api.hip", "return (uint32_t)(((groups + n_ranks - 1) / n_ranks) * kShardAlign);", "return (uint32_t)((groups / n_ranks) * kShardAlign);", "the padded cut: ceil(groups / n_ranks)"),
+    ("mesh_upload_attribute_may_overhang_the_stride", "fyx_api.hip", "if (a.off >= 0 && (uint64_t)a.off + a.size > stride)", "if (a.off >= 0 && (uint64_t)a.off > stride)", "fyx_mesh_upload: an attribute that does not fit the vertex is refused"),
 ]
+
+BATCH2_TESTS = ["tests/test_import_helpers.py", "tests/test_sharding.py", "tests/test_abi.py", "tests/test_oracle_golden.py", "tests/test_cpp_host.py"]
 
 
 def main():
@@ -62,7 +75,7 @@ def main():
                 if b.returncode != 0:
                     res.append({"name": name, "file": fn, "what": what, "built": False, "note": b.stderr[-300:]})
                     continue
-                r = subprocess.run([sys.executable, "-m", "pytest", *TESTS, "-x", "-q", "-n", "6", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True)
+                r = subprocess.run([sys.executable, "-m", "pytest", *TESTS, *BATCH2_TESTS, "-x", "-q", "-n", "6", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True)
                 tail = [l for l in r.stdout.splitlines() if l.startswith("FAILED") or l.startswith("ERROR")]
                 res.append({"name": name, "file": fn, "what": what, "built": True, "killed": r.returncode != 0, "by": tail[0][:160] if tail else None, "seconds": round(time.time() - t0, 1)})
             finally:
