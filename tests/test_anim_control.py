@@ -289,6 +289,46 @@ def test_transitions_scenario_visits_every_state(orc):
     o.close()
 
 
+def _logic_by_index(cond, names):
+    if cond[0] == "parameter":
+        return ("parameter", names.index(cond[1]))
+    return (cond[0],) + tuple(_logic_by_index(c, names) for c in cond[1:])
+
+
+def test_logic_node_doc_example_fires_the_transition(orc, cctx):
+    """The one output the reference asserts of LogicNode::calculate_value: its doc-test (transition.rs:93-115), `!Run && Jump` over Run =
+    Rule(false), Jump = Rule(true) -> true.  Here the expression is the condition of a transition between two states: it has fired after
+    one update exactly when the expression is true -- on the oracle, the second oracle and the product's planner; the other three rows of
+    the truth table beside it (they follow from the same text, the reference asserts only the first)."""
+    import json
+    import oracle2
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fyrox_unit_vectors.json")))["logic_node_doc_example"]
+    names = list(g["parameters"])
+    cond = _logic_by_index(g["logic"], names)
+    n_bones, seed = 5, synth.SEED_BASE + 43
+    rig = synth.make_rig(n_bones, seed)
+    td, tgt = synth.make_clip(n_bones, seed, 0, n_keys=4, fps=4.0, euler_every=10 ** 9)
+    for run, jump in [(g["parameters"]["Run"], g["parameters"]["Jump"]), (True, True), (False, False), (True, False)]:
+        want = g["expect"] if (run, jump) == (g["parameters"]["Run"], g["parameters"]["Jump"]) else ((not run) and jump)
+        layer = A.MachineLayer(nodes=[A.PlayAnimation(0), A.PlayAnimation(0)], states=[A.State(0), A.State(1)],
+                               transitions=[A.Transition(0, 1, 0.5, cond)])
+        m = A.Machine(parameters=[A.Parameter(A.PARAM_RULE, run), A.Parameter(A.PARAM_RULE, jump)], layers=[layer])
+        sc = cases.Scenario("logic_doc", rig, [td], [cases.AnimSpec(0, tgt)], m, n_frames=1, has_euler=False)
+        o, p = cases.build_oracle(orc, sc), cases.build_product(cctx, sc, 1)
+        o2 = cases.build_oracle(oracle2, sc)
+        try:
+            o.update_machine(0.1)
+            o2.update_machine(0.1)
+            p.plan(1, 0.1)
+            fired = (-1, 0) if want else (0, -1)          # (active state, active transition): a fired transition clears the state (layer.rs:640-648)
+            assert o.layer_state(0) == fired, (run, jump)
+            assert o2.layer_state(0) == fired, (run, jump)
+            assert p.layer_state(0) == fired, (run, jump)
+        finally:
+            o.close()
+            p.free()
+
+
 def test_mesh_upload_checks_its_layout_before_it_needs_a_device(cctx):
     """fyx_mesh_upload validates the vertex layout first (an attribute must END inside the vertex: AnimatedVertex is 68 bytes,
     vertex.rs:139-155), so the refusals are the same on a context without a device; a layout that passes then needs one."""

@@ -76,6 +76,21 @@ MUTANTS = [
     ("palette_commit_row3_wrong_column", "lbs_kernels.hip", "            reinterpret_cast<float*>(row3 + b)[c] = col[i].w;\n            pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);\n        }\n    }\n    const bool wave_pj = __any(pj) != 0;\n    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;\n    __syncthreads();\n    bool projective = false;\n#pragma unroll\n    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;\n    pin_vertex(A);",
      "            reinterpret_cast<float*>(row3 + b)[c] = col[i].z;\n            pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);\n        }\n    }\n    const bool wave_pj = __any(pj) != 0;\n    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;\n    __syncthreads();\n    bool projective = false;\n#pragma unroll\n    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;\n    pin_vertex(A);",
      "lbs_skin_dyn stages the projective row from the wrong component"),
+    # ---- third batch (third session)
+    ("cubic_tangent_scale_signed", "anim_leaves.h", "    const float scale = absf_(p1 - p0);", "    const float scale = p1 - p0;", "cubicf: tangents scaled by |p1 - p0| (fyrox-math/src/lib.rs:212-221)"),
+    ("euler_order_reversed", "anim_kernels.hip", "            q = quat_mul(quat_mul(qz, qy), qx);\n        }\n    }\n    if (has_r && rkind == FYX_KIND_QUAT) q = quat_normalize(f4{r0, r1, r2, r3});", "            q = quat_mul(quat_mul(qx, qy), qz);\n        }\n    }\n    if (has_r && rkind == FYX_KIND_QUAT) q = quat_normalize(f4{r0, r1, r2, r3});", "quat_from_euler XYZ = qz * qy * qx (fyrox-math/src/lib.rs:725-740)"),
+    ("quat_mul_cross_term_sign", "anim_kernels.hip", "    const float i = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;", "    const float i = a.w * b.x + a.x * b.w - a.y * b.z + a.z * b.y;", "Hamilton product, i component"),
+    ("max_bone_index_ignores_the_fourth_influence", "lbs_kernels.hip", "max((id >> 16) & 0xffu, id >> 24)));", "max((id >> 16) & 0xffu, (id >> 16) & 0xffu)));", "upload validation: the largest bone index of a mesh"),
+    ("palette_product_terms_reordered", "lbs_kernels.hip", "    y = a[4 + i] * b[j * 4 + 1] + y;\n    y = a[8 + i] * b[j * 4 + 2] + y;\n    y = a[12 + i] * b[j * 4 + 3] + y;\n    out[e] = y;",
+     "    y = a[8 + i] * b[j * 4 + 2] + y;\n    y = a[4 + i] * b[j * 4 + 1] + y;\n    y = a[12 + i] * b[j * 4 + 3] + y;\n    out[e] = y;", "fyx_palette: global * inv_bind, k ascending"),
+    ("aabb_upper_bound_starts_at_zero", "lbs_kernels.hip", "    float mx[3] = {-__FLT_MAX__, -__FLT_MAX__, -__FLT_MAX__};\n    for (uint32_t v = blockIdx.x * kAabbBlock + threadIdx.x; v < a.n_verts;\n",
+     "    float mx[3] = {0.0f, 0.0f, 0.0f};\n    for (uint32_t v = blockIdx.x * kAabbBlock + threadIdx.x; v < a.n_verts;\n", "accurate_world_bounding_box starts from (+MAX, -MAX) (fyrox-math/src/aabb.rs:33-40)"),
+    ("unaligned_word_bytes_swapped", "lbs_kernels.hip", "return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);", "return (uint32_t)p[0] | ((uint32_t)p[2] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[3] << 24);",
+     "little-endian field reads of a vertex buffer whose attributes are not 4-byte aligned (buffer.rs:1279-1321)"),
+    ("root_motion_relative_rotation_other_side", "anim_kernels.hip", "const f4 current_relative_rotation = quat_mul(conj(pp), pose_rotation);", "const f4 current_relative_rotation = quat_mul(pose_rotation, conj(pp));",
+     "lib.rs:610-640: prev_rotation.inverse() * pose_rotation"),
+    ("root_motion_rotation_remainder_other_side", "anim_kernels.hip", "const f4 d = quat_mul(remainder, current_relative_rotation);", "const f4 d = quat_mul(current_relative_rotation, remainder);", "lib.rs:640-650: remainder * current_relative_rotation"),
+    ("constant_key_right_value_early", "anim_leaves.h", "    if (lk == FYX_KEY_CONSTANT) return t == 1.0f ? ra.x : la.x;", "    if (lk == FYX_KEY_CONSTANT) return t >= 0.5f ? ra.x : la.x;", "stepf (curve.rs:25-31) in the key-record sampler"),
 ]
 
 
