@@ -329,6 +329,59 @@ def test_logic_node_doc_example_fires_the_transition(orc, cctx):
             p.free()
 
 
+def _planned_blend_space_weights(cctx, pts, tris, sp):
+    """BlendSpace::fetch_weights as the PRODUCT's planner decides it: a one-state machine whose root is a blend space over one PlayAnimation
+    per point; the frame's fold program is BLEND_ANIM (animation, weight) x 3, APPLY, END -- the (index, weight) triple itself.  [] when
+    nothing is blended (fetch_weights returned None)."""
+    n_bones, seed = 4, synth.SEED_BASE + 44
+    rig = synth.make_rig(n_bones, seed)
+    td, tgt = synth.make_clip(n_bones, seed, 0, n_keys=3, fps=4.0, euler_every=10 ** 9)
+    n = len(pts)
+    layer = A.MachineLayer(nodes=[A.PlayAnimation(i) for i in range(n)] + [A.BlendSpace(0, [A.BlendSpacePoint(tuple(q), i) for i, q in enumerate(pts)],
+                                                                                       [tuple(t) for t in tris])], states=[A.State(n)])
+    m = A.Machine(parameters=[A.Parameter(A.PARAM_SAMPLING_POINT, tuple(sp))], layers=[layer])
+    sc = cases.Scenario("bs", rig, [td], [cases.AnimSpec(0, tgt) for _ in range(max(n, 1))], m, n_frames=1, has_euler=False)
+    p = cases.build_product(cctx, sc, 1)
+    try:
+        ops = p.plan(1, 0.1)["ops"]
+    finally:
+        p.free()
+    return [(int(o[0]) >> 8, float(np.array([o[1]], np.uint32).view(np.float32)[0])) for o in ops if (int(o[0]) & 0xff) == 1]     # OP_BLEND_ANIM
+
+
+def test_planner_fetch_weights_on_the_reference_vectors(orc, cctx):
+    """The product's own fetch_weights against what the reference's tests hold: the five cases of blendspace.rs:486-537 (exact (index, weight)
+    triples), test_get_barycentric_coords_2d (fyrox-math/src/lib.rs:1198-1209) and test_barycentric_is_inside (:1224-1233).  The last two
+    assert the two helpers fetch_weights is made of; here they are reached through it: a triangle and a sampling point that PRODUCE the
+    asserted coordinates -- in the unit right triangle a = (0, 0), b = (1, 0), c = (0, 1) a point p has v = p.x, w = p.y, u = 1 - v - w -- are
+    inside (three distinct indices, the coordinates as weights) or not (the nearest-edge branch: the third index repeats the second)."""
+    import json
+    import oracle2
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fyrox_unit_vectors.json")))
+    for case in g["blend_space_fetch_weights"]["cases"]:
+        want = [] if case["expected"] is None else [(int(i), float(w)) for i, w in case["expected"]]
+        assert _planned_blend_space_weights(cctx, case["points"], case["triangles"], case["sampling_point"]) == want, case
+    for case in g["barycentric_coords_2d"]["cases"]:
+        pts = [case["a"], case["b"], case["c"]]
+        want = [(0, case["expect"][0]), (1, case["expect"][1]), (2, case["expect"][2])]
+        assert _planned_blend_space_weights(cctx, pts, [(0, 1, 2)], case["p"]) == want, case
+        assert orc.blend_space_fetch_weights(np.asarray(pts, np.float32), np.asarray([[0, 1, 2]], np.uint32), tuple(case["p"])) == want
+    tri_pts = [(0.0, 0.0), (1.0, 0.0), (0.0, 1.0)]
+    f32 = np.float32
+    for case in g["barycentric_is_inside"]["cases"]:
+        u, v, _ = case["bary"]
+        sp = (float(f32(v)), float(f32(1.0) - f32(u) - f32(v)))                 # v = p.x, w = p.y
+        uu = f32(1.0) - f32(sp[0]) - f32(sp[1])                                 # what get_barycentric_coords_2d makes of it (inv_denom == 1)
+        assert (uu >= 0) == (u >= 0) and (f32(sp[0]) >= 0) == (v >= 0) and ((uu + f32(sp[0]) < 1) == (u + v < 1)), "the point realises the asserted case"
+        for got in (_planned_blend_space_weights(cctx, tri_pts, [(0, 1, 2)], sp),
+                    orc.blend_space_fetch_weights(np.asarray(tri_pts, np.float32), np.asarray([[0, 1, 2]], np.uint32), sp)):
+            inside = got is not None and len(got) == 3 and [i for i, _ in got] == [0, 1, 2]
+            assert inside == case["inside"], (case, got)
+        node = oracle2.anim.BlendSpaceNode(A.BlendSpace(0, [A.BlendSpacePoint(q, 0) for q in tri_pts], [(0, 1, 2)]))
+        got2 = node.fetch_weights((f32(sp[0]), f32(sp[1])))
+        assert (got2 is not None and [i for i, _ in got2] == [0, 1, 2]) == case["inside"], (case, got2)
+
+
 def test_mesh_upload_checks_its_layout_before_it_needs_a_device(cctx):
     """fyx_mesh_upload validates the vertex layout first (an attribute must END inside the vertex: AnimatedVertex is 68 bytes,
     vertex.rs:139-155), so the refusals are the same on a context without a device; a layout that passes then needs one."""
