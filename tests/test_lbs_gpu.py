@@ -791,7 +791,7 @@ def test_vertex_buffer_path_handles_any_f32_layout(ctx, orc, stride, offs, n_ver
     ctx.mesh_free(66)
 
 
-def test_vertex_buffer_path_rejects_oversized_or_unaligned_layouts(ctx):
+def test_vertex_buffer_path_rejects_oversized_or_unaligned_layouts(ctx, orc):
     from fyrox_amd import _native
     m = synth.make_mesh(64, 8, 5)
     pal, out = ctx.to_device(synth.make_palette(8, 5)), ctx.malloc(64 * 200)
@@ -801,9 +801,31 @@ def test_vertex_buffer_path_rejects_oversized_or_unaligned_layouts(ctx):
         with pytest.raises(fyrox_amd.FyxError) as e:
             ctx.lbs_skin_ex(67, pal.ptr, 8, 1, d_out_vertices=out.ptr, out_stride=0)
         assert e.value.code == _native.FYX_ERR_UNSUPPORTED
-        assert ctx.lbs_skin(67, synth.make_palette(8, 5), want=("pos",))["pos"].shape == (64, 3)   # the SoA path still serves it
+        got = ctx.lbs_skin(67, synth.make_palette(8, 5), want=("pos",))["pos"]                       # the SoA path still serves it
+        ref = orc.lbs_skin(m.pos, m.weights, m.indices, synth.make_palette(8, 5), threads=0)["pos"]
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), stride
         ctx.mesh_free(67)
     pal.free(); out.free()
+
+
+@pytest.mark.parametrize("stride,offs", [
+    (61, dict(pos=1, normal=13, tangent=25, weights=41, indices=57)),      # a byte in front: nothing is word-aligned in any vertex
+    (70, dict(pos=2, normal=14, tangent=26, weights=42, indices=58)),      # half-word offsets and a stride that is no multiple of 4
+    (69, dict(pos=0, normal=20, tangent=32, weights=48, indices=64)),      # AnimatedVertex + one byte: aligned in every fourth vertex only
+], ids=lambda v: str(v) if isinstance(v, int) else "")
+def test_upload_of_a_layout_whose_attributes_are_not_word_aligned(ctx, orc, stride, offs):
+    """A VertexBuffer's layout is any list of attributes (buffer.rs:404-415: u8 attributes may precede f32 ones), and the reference reads
+    every field byte-wise little-endian (buffer.rs:1279-1321).  fyx_mesh_upload's gather to the attribute streams reads such fields
+    byte by byte too (deinterleave_kernel's unaligned road; tools/mutants.py: two of its bytes swapped survived the suite until this test)."""
+    m = synth.make_mesh(777, 24, synth.SEED_BASE + 47, coherent=False)
+    pal = synth.make_palette(24, synth.SEED_BASE + 47)
+    src = _custom_aos(m, stride, offs)
+    ctx.mesh_upload(68, src.reshape(-1), m.n_verts, stride, off_pos=offs["pos"], off_normal=offs["normal"], off_tangent=offs["tangent"],
+                    off_weights=offs["weights"], off_indices=offs["indices"])
+    try:
+        assert_bit_exact(ctx.lbs_skin(68, pal), orc.lbs_skin(m.pos, m.weights, m.indices, pal, m.normal, m.tangent, threads=0))
+    finally:
+        ctx.mesh_free(68)
 
 
 def test_single_rank_communicator_all_gathers_a_skinned_shard(ctx, orc):

@@ -1,0 +1,198 @@
+"""The reference's OWN known-answer vectors (tests/golden/fyrox_unit_vectors.json, each block citing its #[test]) through the PRODUCT --
+not the oracle.  tests/test_oracle_golden.py pins the checker on them; here the library itself answers: the host control plane and the
+`__host__ __device__` leaves on the CPU, the kernels on the GPU, all through the C ABI.
+
+  wrapf                    fyrox-math/src/lib.rs:1142-1147      fyx_animation_set_time_position of a looping clip (lib.rs:432-440)
+  Curve::value_at          fyrox-math/src/curve.rs:429-512      the span-record leaf on the host; both sampler forms on the device
+  CurveKey::interpolate    curve.rs:528-566                     the sampler, through a hinted span (t = 0) and a searched one (t = 1)
+  quat_from_euler          fyrox-math/src/lib.rs:1462-1478      a UnitQuaternionEuler track (device sincosf: 1e-5)
+  hierarchy propagation    scene/graph/mod.rs:2646-2739         the update kernel's walk, before and after a node is moved
+  global scale             scene/graph/mod.rs:2602-2644         the same walk on scales
+(BlendSpace::fetch_weights and the barycentric helpers: tests/test_anim_control.py; the 76-byte vertex buffer: tests/test_lbs_gpu.py;
+the simplifier's 14 vectors: tests/test_import_helpers.py.)"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+
+import fyrox_amd
+from fyrox_amd import _native
+from fyrox_amd import anim as A
+from fyrox_amd import synth
+
+from test_device_leaves_on_host import _device_leaf, _span_records
+
+_ids = [50_000]
+
+
+def _one_node_rig(n=1, parent=None):
+    return A.Rig(parent=np.asarray([-1] * n if parent is None else parent, np.int32), transforms=[A.Transform.identity() for _ in range(n)])
+
+
+def _player(ctx, rig, td, target, **kw):
+    base = _ids[0]
+    _ids[0] += 10
+    A.create_rig(ctx, base, rig)
+    A.upload_tracks_data(ctx, base + 1, td)
+    an = A.Animator(ctx, base, base, rig, 1)
+    an.add_animation(base + 1, np.asarray(target, np.int32), **kw)
+    return an
+
+
+def _keys(rows):
+    """golden key = [location, value, kind, left_tangent, right_tangent]"""
+    return [A.CurveKey(float(k[0]), float(k[1]), int(k[2]), float(k[3]), float(k[4])) for k in rows]
+
+
+# ---- CPU: the control plane and the host-compiled device leaf -------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def cctx():
+    c = fyrox_amd.Context(control_only=True)
+    yield c
+    c.close()
+
+
+def test_wrapf_vectors_through_set_time_position(cctx, golden):
+    """Animation::set_time_position of a looping animation is wrapf(time, time_slice.start, time_slice.end) (lib.rs:432-440)."""
+    td = A.AnimationTracksData([A.Track(A.BIND_POSITION, A.KIND_VEC3, [A.Curve([A.CurveKey(0.0, 0.0)]) for _ in range(3)])])
+    for n, lo, hi, expect in golden["wrapf"]["cases"]:
+        an = _player(cctx, _one_node_rig(), td, [0], looped=True, time_slice=(lo, hi), speed=0.0)
+        try:
+            an.set_time_position(0, n)
+            assert an.animation_state(0)["time_position"] == expect, (n, lo, hi)
+        finally:
+            an.free()
+
+
+def test_curve_vectors_through_the_span_record_leaf(golden):
+    """csrc/anim_leaves.h::span_track_value_at (the crowd sampler's Curve::value_at, the same function in the kernel and behind
+    fyx_debug_span_value_at) on the reference's curves of two and more keys, with the reference's `&mut 0` hint."""
+    checked = 0
+    for case in golden["curve_value_at"]["cases"]:
+        ks = case["keys"]
+        if len(ks) < 2:
+            continue                                                    # no span: the kernels clamp before they reach the leaf (GPU test below)
+        loc = np.asarray([k[0] for k in ks], np.float32)
+        curve = (np.asarray([k[1] for k in ks], np.float32), np.asarray([k[2] for k in ks], np.uint8), np.asarray([k[3] for k in ks], np.float32),
+                 np.asarray([k[4] for k in ks], np.float32))
+        rec = _span_records(loc, [curve, curve, curve])
+        for t, expect in case["fetch"]:
+            got, _ = _device_leaf(rec, len(ks), 3, float(t), 0)
+            assert got[0] == got[1] == got[2] == np.float32(expect), (ks, t, got)
+            checked += 1
+    assert checked >= 8
+
+
+# ---- GPU: the kernels ------------------------------------------------------------------------------------------------------------
+
+def _sample_x(an, t):
+    an.set_time_position(0, t)
+    an.update_animations(0.0)              # tick: update_pose at the current time, then the clock moves by dt * speed = 0
+    return an.read(A.READ_LOCAL_TRS)[0, 0, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [1, 2], ids=["curves_on_lanes", "instances_on_lanes"])
+def test_curve_vectors_through_the_sampler(ctx, golden, form):
+    ctx.set_option("anim.sample_form", form)
+    try:
+        for case in golden["curve_value_at"]["cases"]:
+            zero = A.Curve([A.CurveKey(0.0, 0.0)])
+            td = A.AnimationTracksData([A.Track(A.BIND_POSITION, A.KIND_VEC3, [A.Curve(_keys(case["keys"])), zero, zero])])
+            an = _player(ctx, _one_node_rig(), td, [0], looped=False, time_slice=(-8.0, 8.0), speed=0.0)
+            try:
+                for t, expect in case["fetch"]:
+                    assert _sample_x(an, float(t)) == np.float32(expect), (case["keys"], t)
+            finally:
+                an.free()
+    finally:
+        ctx.set_option("anim.sample_form", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [1, 2], ids=["curves_on_lanes", "instances_on_lanes"])
+def test_curve_key_interpolate_vectors_through_the_sampler(ctx, golden, form):
+    """CurveKey::interpolate(left, right, t) at t = 0 and t = 1 for every pair of kinds.  A two-key curve would answer both from its end
+    clamps, so the pair sits between two outer keys: t = 0 is reached through the HINTED span (a sample at 0.5 first leaves the hint on
+    the pair; `left.location <= 0 < right.location` then holds), t = 1 through the search (the hinted test fails ON the right key,
+    partition_point returns it: span [left, right], t = 1)."""
+    g = golden["curve_key_interpolate"]
+    ctx.set_option("anim.sample_form", form)
+    try:
+        for left, right, t, expect in g["cases"]:
+            (lv, lk, llt, lrt), (rv, rk, rlt, rrt) = g["keys"][left], g["keys"][right]
+            pair = A.Curve([A.CurveKey(-1.0, 99.0), A.CurveKey(0.0, lv, int(lk), llt, lrt), A.CurveKey(1.0, rv, int(rk), rlt, rrt), A.CurveKey(2.0, 77.0)])
+            zero = A.Curve([A.CurveKey(0.0, 0.0)])
+            td = A.AnimationTracksData([A.Track(A.BIND_POSITION, A.KIND_VEC3, [pair, zero, zero])])
+            an = _player(ctx, _one_node_rig(), td, [0], looped=False, time_slice=(-8.0, 8.0), speed=0.0)
+            try:
+                _sample_x(an, 0.5)
+                assert _sample_x(an, float(t)) == np.float32(expect), (left, right, t)
+            finally:
+                an.free()
+    finally:
+        ctx.set_option("anim.sample_form", 0)
+
+
+@pytest.mark.gpu
+def test_quat_from_euler_vector_through_an_euler_track(ctx, golden):
+    g = golden["quat_from_euler"]
+    f = np.float32
+    e = [f(x) for x in g["euler"]]
+    s = [f(math.sin(float(f(a * f(0.5))))) for a in e]
+    c = [f(math.cos(float(f(a * f(0.5))))) for a in e]
+    (sr, sp, sy), (cr, cp, cy) = s, c
+    expect = np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy], np.float32)
+    td = A.AnimationTracksData([A.Track(A.BIND_ROTATION, A.KIND_QUAT_EULER, [A.Curve([A.CurveKey(0.0, float(a))]) for a in e])])
+    an = _player(ctx, _one_node_rig(), td, [0], speed=0.0)
+    try:
+        an.update_animations(0.0)
+        got = an.read(A.READ_LOCAL_TRS)[0, 0, 4:8]
+        # the reference asserts exact equality of its two f32 routes; the device's sincosf is within 1 ulp of libm's: 1e-5
+        assert np.allclose(got, expect, rtol=0.0, atol=1e-5), (got, expect)
+    finally:
+        an.free()
+
+
+def _static_animator(ctx, rig):
+    base = _ids[0]
+    _ids[0] += 10
+    A.create_rig(ctx, base, rig)
+    return A.Animator(ctx, base, base, rig, 1)
+
+
+@pytest.mark.gpu
+def test_hierarchy_propagation_vectors_through_the_update_kernel(ctx, golden):
+    g = golden["graph_hierarchy"]
+    rig = _one_node_rig(4, g["parent"])
+    for t, p in zip(rig.transforms, g["local_position"]):
+        t.local_position[:] = p
+    an = _static_animator(ctx, rig)
+    try:
+        an.update_animations(0.0)
+        glob = an.read(A.READ_GLOBAL_MATRIX)[0]
+        assert glob[:, 12:15].tolist() == g["global_position"]
+        assert np.array_equal(glob[:, 15], np.ones(4, np.float32))
+        moved = [i for i, (a, b) in enumerate(zip(g["local_position"], g["local_position_after"])) if a != b]
+        for i in moved:                                                 # Transform::set_position of the moved node
+            an.set_local_trs(i, [*g["local_position_after"][i], 0, 0, 0, 1, 1, 1, 1])
+        an.update_animations(0.0)
+        assert an.read(A.READ_GLOBAL_MATRIX)[0][:, 12:15].tolist() == g["global_position_after"]
+    finally:
+        an.free()
+
+
+@pytest.mark.gpu
+def test_global_scale_vectors_through_the_update_kernel(ctx, golden):
+    g = golden["graph_global_scale"]
+    rig = _one_node_rig(3, [-1, 0, 1])
+    for t, s in zip(rig.transforms, g["local_scale"]):
+        t.local_scale[:] = s
+    an = _static_animator(ctx, rig)
+    try:
+        an.update_animations(0.0)
+        assert an.read(A.READ_GLOBAL_MATRIX)[0][:, [0, 5, 10]].tolist() == g["global_scale"]
+    finally:
+        an.free()
