@@ -5,6 +5,7 @@ not the oracle.  tests/test_oracle_golden.py pins the checker on them; here the 
   wrapf                    fyrox-math/src/lib.rs:1142-1147      fyx_animation_set_time_position of a looping clip (lib.rs:432-440)
   Curve::value_at          fyrox-math/src/curve.rs:429-512      the span-record leaf on the host; both sampler forms on the device
   CurveKey::interpolate    curve.rs:528-566                     the sampler, through a hinted span (t = 0) and a searched one (t = 1)
+  cubicf (inf_sup_cubicf)  fyrox-math/src/lib.rs:1155-1159      both oracles, the host-compiled leaf, the sampler
   quat_from_euler          fyrox-math/src/lib.rs:1462-1478      a UnitQuaternionEuler track (device sincosf: 1e-5)
   hierarchy propagation    scene/graph/mod.rs:2646-2739         the update kernel's walk, before and after a node is moved
   global scale             scene/graph/mod.rs:2602-2644         the same walk on scales
@@ -85,6 +86,33 @@ def test_curve_vectors_through_the_span_record_leaf(golden):
     assert checked >= 8
 
 
+def _inf_sup_ts(p0, p1, m0, m1):
+    """t0, t1 of inf_sup_cubicf (fyrox-math/src/lib.rs:235-249), in f32, in the reference's operation order."""
+    f = np.float32
+    p0, p1, m0, m1 = f(p0), f(p1), f(m0), f(m1)
+    d = -np.sqrt(f(9.0) * p0 * p0 + f(6.0) * p0 * (f(-3.0) * p1 + m1 + m0) + f(9.0) * p1 * p1 - f(6.0) * p1 * (m1 + m0) + m1 * m1 + m1 * m0 + m0 * m0)
+    k = f(3.0) * (f(2.0) * p0 - f(2.0) * p1 + m1 + m0)
+    v = f(3.0) * p0 - f(3.0) * p1 + m1 + f(2.0) * m0
+    return float((-d + v) / k), float((d + v) / k)
+
+
+def test_inf_sup_cubicf_vectors(orc, golden):
+    """cubicf (lib.rs:212-221) at the two interior times test_inf_sup_cubicf reaches it with: the oracle's CurveKey::interpolate, the second
+    oracle's, and the device's span-record leaf compiled for the host -- a Cubic key at 0 (right tangent m0) and one at 1 (left tangent m1)."""
+    import oracle2.curve as o2c
+    for c in golden["inf_sup_cubicf"]["cases"]:
+        ts = _inf_sup_ts(c["p0"], c["p1"], c["m0"], c["m1"])
+        assert 0.0 < ts[1] < ts[0] < 1.0
+        loc = np.asarray([0.0, 1.0], np.float32)
+        curve = (np.asarray([c["p0"], c["p1"]], np.float32), np.asarray([2, 2], np.uint8), np.asarray([9.0, c["m1"]], np.float32), np.asarray([c["m0"], 9.0], np.float32))
+        rec = _span_records(loc, [curve, curve, curve])
+        for t, expect in zip(ts, c["expect"]):
+            assert orc.key_interpolate((c["p0"], 2, 9.0, c["m0"]), (c["p1"], 2, c["m1"], 9.0), t) == expect
+            assert float(o2c.interpolate(o2c.Key(0.0, c["p0"], 2, 9.0, c["m0"]), o2c.Key(1.0, c["p1"], 2, c["m1"], 9.0), np.float32(t))) == expect
+            got, _ = _device_leaf(rec, 2, 3, t, 0)
+            assert got[0] == got[1] == got[2] == np.float32(expect)
+
+
 # ---- GPU: the kernels ------------------------------------------------------------------------------------------------------------
 
 def _sample_x(an, t):
@@ -130,6 +158,25 @@ def test_curve_key_interpolate_vectors_through_the_sampler(ctx, golden, form):
             try:
                 _sample_x(an, 0.5)
                 assert _sample_x(an, float(t)) == np.float32(expect), (left, right, t)
+            finally:
+                an.free()
+    finally:
+        ctx.set_option("anim.sample_form", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [1, 2], ids=["curves_on_lanes", "instances_on_lanes"])
+def test_inf_sup_cubicf_vectors_through_the_sampler(ctx, golden, form):
+    ctx.set_option("anim.sample_form", form)
+    try:
+        for c in golden["inf_sup_cubicf"]["cases"]:
+            pair = A.Curve([A.CurveKey(0.0, c["p0"], A.KEY_CUBIC, 9.0, c["m0"]), A.CurveKey(1.0, c["p1"], A.KEY_CUBIC, c["m1"], 9.0)])
+            zero = A.Curve([A.CurveKey(0.0, 0.0)])
+            td = A.AnimationTracksData([A.Track(A.BIND_POSITION, A.KIND_VEC3, [pair, zero, zero])])
+            an = _player(ctx, _one_node_rig(), td, [0], looped=False, time_slice=(-8.0, 8.0), speed=0.0)
+            try:
+                for t, expect in zip(_inf_sup_ts(c["p0"], c["p1"], c["m0"], c["m1"]), c["expect"]):
+                    assert _sample_x(an, t) == np.float32(expect), (c, t)
             finally:
                 an.free()
     finally:
