@@ -674,7 +674,7 @@ ALL_RM = [with_root_motion_and_signals(f) for f in ALL] + [looping_root_motion]
 
 # ---- randomly generated machines ------------------------------------------------------------------------
 
-def random_machine(seed: int, n_bones: int = 7, listy: bool = False) -> Scenario:
+def random_machine(seed: int, n_bones: int = 7, listy: bool = False, lattice: bool = False) -> Scenario:
     """A random but valid animation set-up: 3-5 partial clips (some with Real Property tracks, signals, root motion,
     reverse / zero speed, non-looping, sub-range time slices, disabled), 1-3 layers of random pose-node DAGs (all four
     node types, invalid handles, shared sub-trees, nested blends up to depth 4), random states / transitions with
@@ -682,9 +682,14 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False) -> Scenario
     (sometimes with another kind) every few frames.  Quaternion rotation tracks only, so everything must be
     bit-exact.  listy = True (a generator of its own, so the plain scenario of a seed stays what it was) also gives the clips what
     _listy_tracks gives by hand: further tracks on a (node, binding) or (node, property) that already has one, anywhere in the track
-    order, value kinds that fit no binding, property tracks of every vector kind, tracks with too few curves."""
+    order, value kinds that fit no binding, property tracks of every vector kind, tracks with too few curves.
+    lattice = True (again a generator of its own) puts the blend spaces' points and every sampling point on a coarse lattice of exactly
+    representable coordinates, so that sampling points land ON points and edges of the triangles (barycentric_is_inside is closed on two sides
+    and open on the third), coincide with each other, and triangles degenerate -- what random reals never do."""
     rng = np.random.default_rng(seed)
     lrng = np.random.default_rng(seed + 10 ** 6)
+    erng = np.random.default_rng(seed + 9 * 10 ** 6)
+    lat = lambda: float(erng.choice([0.0, 0.25, 0.5, 0.75, 1.0, 1.0, 0.0, -0.25, 1.25]))
     f32 = lambda x: float(np.float32(x))
     rig = synth.make_rig(n_bones, 1000 + seed, exotic=bool(rng.integers(2)))
     n_clips = int(rng.integers(3, 6))
@@ -748,7 +753,8 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False) -> Scenario
             return A.Parameter(k, bool(rng.integers(2)))
         if k == A.PARAM_INDEX:
             return A.Parameter(k, int(rng.integers(0, 4)))
-        return A.Parameter(k, (f32(rng.random() * 1.6 - 0.3), f32(rng.random() * 1.6 - 0.3)))
+        xy = (f32(rng.random() * 1.6 - 0.3), f32(rng.random() * 1.6 - 0.3))
+        return A.Parameter(k, (lat(), lat()) if lattice else xy)
 
     params = [rand_param() for _ in range(n_params)]
     pref = lambda: int(rng.integers(-1, n_params + 1))              # includes missing parameters
@@ -787,6 +793,8 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False) -> Scenario
             else:
                 npts = int(rng.integers(1, 5))
                 pts = [A.BlendSpacePoint((f32(rng.random()), f32(rng.random())), src(2)) for _ in range(npts)]
+                if lattice:
+                    pts = [A.BlendSpacePoint((min(max(lat(), 0.0), 1.0), min(max(lat(), 0.0), 1.0)), p_.pose_source) for p_ in pts]
                 tris = [] if npts < 3 else ([(0, 1, 2)] if npts == 3 else [(0, 1, 2), (0, 2, 3)])
                 node = A.BlendSpace(pref(), pts, tris)
                 srcs = [p_.pose_source for p_ in pts]
@@ -814,7 +822,7 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False) -> Scenario
     for f in range(n_frames):
         if rng.random() < 0.35:
             script[f] = [(int(rng.integers(0, n_params)), rand_param()) for _ in range(int(rng.integers(1, 3)))]
-    return Scenario(f"random_machine[{seed}{', listy' if listy else ''}]", rig, tds, anims, A.Machine(parameters=params, layers=layers), script,
+    return Scenario(f"random_machine[{seed}{', listy' if listy else ''}{', lattice' if lattice else ''}]", rig, tds, anims, A.Machine(parameters=params, layers=layers), script,
                     n_frames=n_frames, dt=f32(rng.choice([1 / 60, 1 / 24, 0.11])), has_euler=False,
                     track_root_motion=any(a.root_motion is not None for a in anims) or bool(rng.integers(2)),
                     random_seed=seed * 7919 + 13)

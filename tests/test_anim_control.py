@@ -151,6 +151,13 @@ def test_control_plane_matches_oracle_on_random_machines_with_lists_of_values(or
     _check_control_plane(orc, cctx, cases.random_machine(seed, listy=True))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_control_plane_matches_oracle_on_random_machines_on_a_lattice(orc, cctx, seed):
+    """Sampling points ON the corners and edges of the blend spaces' triangles, coinciding points, degenerate triangles (NaN weights): the
+    planner's fetch_weights makes the oracle's decisions (tools/mutants_host.py: the open third side of barycentric_is_inside)."""
+    _check_control_plane(orc, cctx, cases.random_machine(seed, listy=bool(seed % 2), lattice=True))
+
+
 @pytest.mark.parametrize("make", cases.ALL + cases.ALL_RM, ids=lambda f: f.__name__)
 def test_control_plane_matches_oracle(orc, cctx, make):
     _check_control_plane(orc, cctx, make())

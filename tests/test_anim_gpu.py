@@ -303,6 +303,17 @@ def test_random_machines_with_lists_of_values_match_oracle(ctx, orc, seed):
     p.free()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_machines_on_a_lattice_match_oracle(ctx, orc, seed):
+    """random_machine(lattice=True): sampling points ON the corners and edges of the blend spaces' triangles, coinciding points, degenerate
+    triangles whose weights are NaN -- the fold on the device carries whatever weights the planner hands it, bit for bit."""
+    sc = cases.random_machine(seed, listy=bool(seed % 2), lattice=True)
+    ctx.set_option("anim.sample_form", seed % 3)
+    o, p = run_scenario(ctx, orc, sc, n_instances=1 + seed % 3)
+    o.close()
+    p.free()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_curves_match_oracle(ctx, orc, seed):
     """random_curves: coinciding keys, mixed key kinds, empty and single-key curves, tracks whose curves sit on different time grids, slices

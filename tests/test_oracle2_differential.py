@@ -163,6 +163,13 @@ def test_random_machines_with_lists_of_values_bit_for_bit(seed):
     _run(cases.random_machine(seed, listy=True))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_machines_on_a_lattice_bit_for_bit(seed):
+    """random_machine(lattice=True): blend-space points and sampling points on exactly representable coordinates -- sampling points ON the
+    triangles' corners and edges, coinciding points, degenerate triangles (0 / 0 in get_barycentric_coords_2d: NaN weights on both sides)."""
+    _run(cases.random_machine(seed, listy=bool(seed % 2), lattice=True))
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FYX_FUZZ_SEEDS", 16))))
 def test_random_curves_bit_for_bit(seed):
     """random_curves: coinciding keys, mixed key kinds, empty and single-key curves, curves of a track on different time grids."""

@@ -171,12 +171,12 @@ def run_diverge(T, cases, A, orc, ctx, sc, n_inst, seed):
         p.free()
 
 
-def run_scene(T, cases, A, orc, ctx, seeds, listy, bones):
+def run_scene(T, cases, A, orc, ctx, seeds, listy, bones, lattice=False):
     """fyx_scene_update over a changing list of random machines (order shuffled, a member left out of some frames, parameters scripted per
     member) against one oracle per member."""
     import numpy as np
     rng = np.random.default_rng(seeds[0] + 9 * 10 ** 6)
-    scs = [cases.random_machine(s, n_bones=bones, listy=listy and k % 2 == 0) for k, s in enumerate(seeds)]
+    scs = [cases.random_machine(s, n_bones=bones, listy=listy and k % 2 == 0, lattice=lattice) for k, s in enumerate(seeds)]
     n_inst = [1 + int(rng.integers(0, 3)) for _ in scs]
     dt = scs[0].dt
     os_ = [cases.build_oracle(orc, sc) for sc in scs]
@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--first", type=int, default=100)
     ap.add_argument("--count", type=int, default=100)
     ap.add_argument("--listy", action="store_true")
+    ap.add_argument("--lattice", action="store_true", help="blend-space points and sampling points on a coarse lattice (points ON edges and corners)")
     ap.add_argument("--bones", type=int, default=7)
     ap.add_argument("--curves", action="store_true", help="tests/anim_cases.py::random_curves instead of random_machine")
     ap.add_argument("--edits", action="store_true", help="random run-time edits between frames: track bindings switched, speeds, loops, "
@@ -292,14 +293,14 @@ def main():
             seeds = list(range(first, first + args.scene))
             ctx.set_option("anim.sample_form", first % 3)
             try:
-                run_scene(T, cases, A, oracle, ctx, seeds, args.listy, args.bones)
+                run_scene(T, cases, A, oracle, ctx, seeds, args.listy, args.bones, args.lattice)
             except Exception as e:   # noqa: BLE001
                 fails.append({"seeds": [seeds[0], seeds[-1]], "listy": args.listy, "sample_form": first % 3,
                               "error": (str(e).strip().splitlines() or [repr(e)])[0][:300],
                               "where": traceback.format_exc().strip().splitlines()[-3][:200]})
     for seed in (range(args.first, args.first + args.count) if not args.scene else ()):
         form, n_inst = seed % 3, 1 + seed % 4 if seed % 5 else 70
-        sc = cases.random_curves(seed, n_bones=args.bones) if args.curves else cases.random_machine(seed, n_bones=args.bones, listy=args.listy)
+        sc = cases.random_curves(seed, n_bones=args.bones) if args.curves else cases.random_machine(seed, n_bones=args.bones, listy=args.listy, lattice=args.lattice)
         ctx.set_option("anim.sample_form", form)
         o = p = None
         try:
@@ -325,7 +326,7 @@ def main():
             except Exception:   # noqa: BLE001
                 pass
     ctx.set_option("anim.sample_form", 0)
-    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "curves": args.curves, "edits": args.edits, "diverge": args.diverge, "skin": args.skin, "scene": args.scene, "options": args.opt, "bones": args.bones,
+    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "lattice": args.lattice, "curves": args.curves, "edits": args.edits, "diverge": args.diverge, "skin": args.skin, "scene": args.scene, "options": args.opt, "bones": args.bones,
            "first_seed": args.first, "seeds": args.count, "failures": len(fails), "failed": fails[:40], "seconds": round(time.time() - t0, 1)}
     line = json.dumps(rec)
     print(line)
