@@ -685,7 +685,8 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False, lattice: bo
     order, value kinds that fit no binding, property tracks of every vector kind, tracks with too few curves.
     lattice = True (again a generator of its own) puts the blend spaces' points and every sampling point on a coarse lattice of exactly
     representable coordinates, so that sampling points land ON points and edges of the triangles (barycentric_is_inside is closed on two sides
-    and open on the third), coincide with each other, and triangles degenerate -- what random reals never do."""
+    and open on the third), coincide with each other, and triangles degenerate -- and the clocks on a binary lattice (see the end of the
+    function) -- what random reals never do."""
     rng = np.random.default_rng(seed)
     lrng = np.random.default_rng(seed + 10 ** 6)
     erng = np.random.default_rng(seed + 9 * 10 ** 6)
@@ -748,7 +749,8 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False, lattice: bo
     def rand_param():
         k = int(rng.integers(0, 4))
         if k == A.PARAM_WEIGHT:
-            return A.Parameter(k, f32(rng.random() * 1.2 - 0.1))
+            w = f32(rng.random() * 1.2 - 0.1)
+            return A.Parameter(k, float(erng.choice([0.0, 0.25, 0.5, 1.0, 1.0, 0.0, -0.25, 1.25])) if lattice else w)
         if k == A.PARAM_RULE:
             return A.Parameter(k, bool(rng.integers(2)))
         if k == A.PARAM_INDEX:
@@ -822,8 +824,33 @@ def random_machine(seed: int, n_bones: int = 7, listy: bool = False, lattice: bo
     for f in range(n_frames):
         if rng.random() < 0.35:
             script[f] = [(int(rng.integers(0, n_params)), rand_param()) for _ in range(int(rng.integers(1, 3)))]
+    dt = f32(rng.choice([1 / 60, 1 / 24, 0.11]))
+    if lattice:
+        # the clocks on a binary lattice too: slices, signals, transition and cross-fade times, speeds and the frame step are multiples of
+        # 1 / 32, weights quarters -- so a signal sits exactly ON a frame's time, a transition's elapsed time lands exactly on its length,
+        # a clip stops exactly on its slice's end, a weight is exactly 0 or 1: every `<` / `<=` of the path at equality
+        snap = lambda x, q=32: float(np.round(float(x) * q) / q)
+        for spec in anims:
+            lo = snap(spec.time_slice[0], 16)
+            hi = max(snap(spec.time_slice[1], 16), lo + 0.125)
+            spec.time_slice = (lo, hi)
+            spec.speed = float(erng.choice([1.0, 0.5, 2.0, -1.0, -2.0, 0.0, 1.0]))
+            spec.signals = [(min(max(snap(t), lo), hi), en) for t, en in spec.signals]
+        for layer in layers:
+            layer.weight = float(erng.choice([0.0, 0.25, 0.5, 1.0, 1.0]))
+            for tr in layer.transitions:
+                tr.transition_time = max(snap(tr.transition_time), 1.0 / 32)
+            for node in layer.nodes:
+                if isinstance(node, A.BlendAnimationsByIndex):
+                    for i in node.inputs:
+                        i.blend_time = max(snap(i.blend_time), 1.0 / 32)
+                elif isinstance(node, A.BlendAnimations):
+                    for b in node.pose_sources:
+                        if b.parameter is None:
+                            b.weight = float(erng.choice([0.0, 0.25, 0.5, 0.75, 1.0]))
+        dt = float(erng.choice([1 / 64, 1 / 32, 1 / 16]))
     return Scenario(f"random_machine[{seed}{', listy' if listy else ''}{', lattice' if lattice else ''}]", rig, tds, anims, A.Machine(parameters=params, layers=layers), script,
-                    n_frames=n_frames, dt=f32(rng.choice([1 / 60, 1 / 24, 0.11])), has_euler=False,
+                    n_frames=n_frames, dt=dt, has_euler=False,
                     track_root_motion=any(a.root_motion is not None for a in anims) or bool(rng.integers(2)),
                     random_seed=seed * 7919 + 13)
 
