@@ -641,6 +641,29 @@ def with_root_motion_and_signals(make) -> Callable[[], Scenario]:
     return build
 
 
+def with_subnormal_values(make) -> Callable[[], Scenario]:
+    """The same scenario with its numbers pushed below 2^-126: Position keys (and the rig's rest positions) scaled by 1e-39 -- lerps, cubic
+    splines and `a (1 - w) + b w` blends of subnormal values, subnormal translations in the local matrices -- and Scale keys of every third
+    bone by 1e-13, so that three levels of hierarchy multiply matrix columns down into the subnormal range and out of it (to zero).  Rust f32
+    arithmetic keeps subnormal numbers; so must every kernel of the path."""
+    def build() -> Scenario:
+        sc = make()
+        for td in sc.tracks_data:
+            for k, tr in enumerate(td.tracks):
+                if tr.binding == A.BIND_POSITION or (tr.binding == A.BIND_SCALE and (k // 3) % 3 == 0):
+                    f = np.float32(1e-39 if tr.binding == A.BIND_POSITION else 1e-13)
+                    for c in tr.curves:
+                        for key in c.keys:
+                            key.value = float(np.float32(key.value) * f)
+        for t in sc.rig.transforms:
+            for i in range(3):
+                t.local_position[i] = float(np.float32(t.local_position[i]) * np.float32(1e-39))
+        sc.name += "+subnormal"
+        return sc
+    build.__name__ = make.__name__ + "_subnormal"
+    return build
+
+
 def looping_root_motion(n_bones=12, seed=synth.SEED_BASE + 11) -> Scenario:
     """Root motion across loop boundaries in both directions (the position / rotation remainder branch,
     lib.rs:563-570, :626-633), a non-looping clip that clamps at its end, a clip whose root has no rotation
@@ -670,6 +693,15 @@ def looping_root_motion(n_bones=12, seed=synth.SEED_BASE + 11) -> Scenario:
 
 
 ALL_RM = [with_root_motion_and_signals(f) for f in ALL] + [looping_root_motion]
+
+
+def _c5_quaternion_tracks() -> Scenario:
+    return c5_blend_tree(euler_every=10 ** 9)
+
+
+_c5_quaternion_tracks.__name__ = "c5_blend_tree_quat"
+SUBNORMAL = [with_subnormal_values(f) for f in (_c5_quaternion_tracks, gltf_like, transitions, layered, looping_root_motion,
+                                               with_root_motion_and_signals(by_index))]
 
 
 # ---- randomly generated machines ------------------------------------------------------------------------

@@ -260,6 +260,21 @@ def test_scenario_matches_oracle(ctx, orc, make):
     p.free()
 
 
+@pytest.mark.parametrize("make", cases.SUBNORMAL, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("form", [1, 2], ids=["curves_on_lanes", "instances_on_lanes"])
+def test_scenario_with_subnormal_values_matches_oracle(ctx, orc, make, form):
+    """with_subnormal_values: Position keys and rest positions scaled by 1e-39, a third of the Scale tracks by 1e-13 -- samples, lerps, blends,
+    local matrices, the hierarchy's products and the palettes in and below the subnormal range.  The reference's f32 arithmetic (Rust, IEEE)
+    keeps subnormal numbers; every kernel of the path must: poses, TRS, matrices and palettes bit for bit against the oracle, both sampler forms."""
+    sc = make()
+    ctx.set_option("anim.sample_form", form)
+    o, p = run_scenario(ctx, orc, sc, n_instances=3, frames=min(sc.n_frames, 40))
+    g = p.read(A.READ_GLOBAL_MATRIX)
+    assert int(((np.abs(g) < 1.17e-38) & (g != 0)).sum()) > 50, "the frame holds subnormal numbers"
+    o.close()
+    p.free()
+
+
 @pytest.mark.parametrize("make", cases.ALL, ids=lambda f: f.__name__)
 @pytest.mark.parametrize("n_instances", [2, 70])
 def test_scenario_with_instances_on_the_lanes(ctx, orc, make, n_instances):

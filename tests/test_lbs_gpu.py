@@ -237,6 +237,34 @@ def test_drawn_kernel_projective_palette_and_nan_propagation(ctx, orc):
     ctx.mesh_free(6)
 
 
+@pytest.mark.parametrize("n_verts", [5000, 300_011], ids=["lbs_skin", "lbs_skin_dyn"])
+def test_subnormal_inputs_products_and_results_bit_exact(ctx, orc, n_verts):
+    """IEEE f32 all the way down: the reference's arithmetic (Rust f32 on the CPU) keeps subnormal numbers, so must the kernels -- packed
+    multiplies and adds, the homogeneous divide (a projective bone), the accumulation.  Positions, normals and weights scaled so that
+    inputs, products and results fall below 2^-126 (1.18e-38) for a third of the vertices each; every bit against the oracle."""
+    m = synth.make_mesh(n_verts, 16, 909)
+    rng = np.random.default_rng(909)
+    pos, nrm, tan, w = m.pos.copy(), m.normal.copy(), m.tangent.copy(), m.weights.copy()
+    third = rng.integers(0, 3, n_verts)
+    pos[third == 0] *= np.float32(1e-39)                           # subnormal inputs
+    nrm[third == 0] *= np.float32(3e-42)
+    pos[third == 1] *= np.float32(1e-30)                           # normal inputs, subnormal products with the small weights below
+    w[third == 1] *= np.float32(1e-9)
+    tan[third == 2, :3] *= np.float32(1e-37)                       # results that cancel into the subnormal range
+    pal = synth.make_palette(16, 909).copy()
+    pal[:, 12:15] *= np.float32(1e-40)                             # translations that do not drown the small positions
+    pal[3, 3] = 0.125; pal[3, 7] = -0.25; pal[3, 15] = 1.5         # bone 3 is projective: subnormal numerators through the divide
+    assert (np.abs(pos[pos != 0]) < 1.17e-38).any()
+    ctx.mesh_upload_soa(6, pos, w, m.indices, nrm, tan)
+    try:
+        ref = orc.lbs_skin(pos, w, m.indices, pal, nrm, tan, threads=0)
+        sub = lambda a: int(((np.abs(a) < 1.17e-38) & (a != 0)).sum())
+        assert sub(ref["pos"]) > n_verts // 10 and sub(ref["normal"]) > n_verts // 10, "the case produces subnormal results"
+        assert_bit_exact(ctx.lbs_skin(6, pal), ref)
+    finally:
+        ctx.mesh_free(6)
+
+
 def test_drawn_kernel_repeated_overlapping_launches(ctx, orc):
     """Launches dealt over the worker streams overlap; every one must produce the same bytes."""
     m = synth.make_mesh(1_000_000, 256, synth.SEED_BASE + 4)

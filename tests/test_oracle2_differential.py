@@ -120,7 +120,7 @@ def _compare_frame(o1, o2, sc, f):
         same(np.asarray(v1[:lanes]), np.asarray(v2), f"{sc.name} frame {f}: property {k}")
 
 
-def _run(sc, frames=None):
+def _run(sc, frames=None, probe=None):
     o1, o2 = cases.build_oracle(oracle, sc), cases.build_oracle(oracle2, sc)
     for f in range(sc.n_frames if frames is None else frames):
         for idx, par in sc.script.get(f, []):
@@ -135,6 +135,8 @@ def _run(sc, frames=None):
             else:
                 o.update_machine(sc.dt)
         _compare_frame(o1, o2, sc, f)
+        if probe is not None:
+            probe(o1)
     o1.close()
 
 
@@ -150,6 +152,21 @@ SCENARIOS = [cases.random_attacks, cases.c5_blend_tree, cases.player_only, cases
 def test_scenarios_bit_for_bit(make):
     sc = make()
     _run(sc, frames=min(sc.n_frames, 40))
+
+
+@pytest.mark.parametrize("make", cases.SUBNORMAL, ids=lambda m: m.__name__)
+def test_scenarios_with_subnormal_values_bit_for_bit(make):
+    """Positions and scales below 2^-126 (with_subnormal_values): numpy float32 and the C oracle both keep subnormal numbers, as Rust does;
+    the poses must actually hold some."""
+    sc = make()
+    seen = [0, 0]
+
+    def probe(o):
+        for k, m in enumerate((o.local_matrices(), o.global_matrices())):
+            seen[k] += int(((np.abs(m) < 1.17e-38) & (m != 0)).sum())
+
+    _run(sc, frames=min(sc.n_frames, 40), probe=probe)
+    assert seen[0] > 100 and seen[1] > 100, seen
 
 
 @pytest.mark.parametrize("seed", range(40))
