@@ -261,6 +261,39 @@ def test_subnormal_inputs_products_and_results_bit_exact(ctx, orc, n_verts):
         sub = lambda a: int(((np.abs(a) < 1.17e-38) & (a != 0)).sum())
         assert sub(ref["pos"]) > n_verts // 10 and sub(ref["normal"]) > n_verts // 10, "the case produces subnormal results"
         assert_bit_exact(ctx.lbs_skin(6, pal), ref)
+        got_box = ctx.lbs_skin(6, pal, want=("pos",), aabb=True)["aabb"]              # the AABB reduction keeps them too
+        ok = ~np.isnan(ref["pos"]).any(axis=1)
+        assert np.array_equal(got_box, np.concatenate([ref["pos"][ok].min(0), ref["pos"][ok].max(0)]))
+        if n_verts <= 5000:
+            # the crowd kernel (40 instances of the mesh, each with its own small palette), exact mode
+            pals = np.concatenate([pal] + [pal * np.float32(0.5 ** k) for k in range(1, 40)])
+            refc = {k: np.concatenate([orc.lbs_skin(pos, w, m.indices, pals[i * 16:(i + 1) * 16], nrm, tan, threads=0)[k] for i in range(40)]) for k in ref}
+            assert_bit_exact(ctx.lbs_skin(6, pals, n_instances=40), refc)
+    finally:
+        ctx.mesh_free(6)
+
+
+@pytest.mark.parametrize("n_verts", [5000, 300_011], ids=["lbs_skin", "lbs_skin_dyn"])
+def test_overflow_to_infinity_and_nan_like_the_cpu(ctx, orc, n_verts):
+    """The other end of the range: positions near f32::MAX whose products and sums overflow to +-inf, and infinities of opposite sign that
+    meet in the accumulation (NaN).  Same infinities in the same places, NaN where the CPU has NaN, every finite value bit for bit."""
+    m = synth.make_mesh(n_verts, 16, 910)
+    rng = np.random.default_rng(910)
+    pos, nrm = m.pos.copy(), m.normal.copy()
+    big = rng.random(n_verts) < 0.5
+    pos[big] *= np.float32(3e38)
+    nrm[big] *= np.float32(2e38)
+    pal = synth.make_palette(16, 910).copy()
+    pal[:, :12] *= np.float32(1.5)                                 # a scale that pushes |m x| over the top
+    ctx.mesh_upload_soa(6, pos, m.weights, m.indices, nrm, m.tangent)
+    try:
+        ref = orc.lbs_skin(pos, m.weights, m.indices, pal, nrm, m.tangent, threads=0)
+        assert np.isinf(ref["pos"]).sum() > n_verts // 20 and np.isnan(ref["pos"]).sum() > 10, "the case overflows and cancels"
+        got = ctx.lbs_skin(6, pal)
+        for k in ("pos", "normal", "tangent"):
+            assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), k
+            ok = ~np.isnan(ref[k])
+            assert np.array_equal(got[k][ok].view(np.uint32), ref[k][ok].view(np.uint32)), k
     finally:
         ctx.mesh_free(6)
 
