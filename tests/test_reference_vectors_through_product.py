@@ -24,7 +24,7 @@ from fyrox_amd import synth
 
 from test_device_leaves_on_host import _device_leaf, _span_records
 
-_ids = [50_000]
+_ids = [1_000_000_000]      # far from the ids tests/anim_cases.py::build_product hands out (1000, 1100, ...) on the shared context
 
 
 def _one_node_rig(n=1, parent=None):
