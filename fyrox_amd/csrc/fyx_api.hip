@@ -31,6 +31,7 @@ int fail(fyx_ctx* c, int code, const char* fmt, ...) {
 
 int hip_fail(fyx_ctx* c, hipError_t e, const char* what) {
     const int code = (e == hipErrorOutOfMemory) ? FYX_ERR_OOM : FYX_ERR_HIP;
+    (void)hipGetLastError();      // reported here: not to be found again by the next launch's hipGetLastError (see FYX_GUARD_BEGIN)
     return fail(c, code, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
 }
 

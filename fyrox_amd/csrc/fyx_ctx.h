@@ -200,7 +200,10 @@ int ctrl_consumed(fyx_ctx* c, CtrlBuffers& B, int slot, hipStream_t consumer = n
 // Entry points whose context is called `c` bind the calling thread to the context's GPU first (see bind_device);
 // fyx_init / fyx_init_control_only, which have no context yet, use FYX_GUARD_BEGIN_NOCTX.
 #define FYX_GUARD_BEGIN_NOCTX try {
-#define FYX_GUARD_BEGIN try { if ((c) && (c)->device >= 0) (void)hipSetDevice((c)->device);
+// ... and start from a clean slate: the runtime keeps the LAST error of the thread until somebody asks for it (hipGetLastError), and the
+// launch helpers ask after every launch -- an allocation that failed and was reported two calls ago (or a failed call of the application's
+// own) must not come back as this call's launch error.
+#define FYX_GUARD_BEGIN try { if ((c) && (c)->device >= 0) { (void)hipSetDevice((c)->device); (void)hipGetLastError(); }
 #define FYX_GUARD_END(c)                                                        \
     } catch (const std::bad_alloc&) {                                           \
         return fyx::fail((c), FYX_ERR_OOM, "host allocation failed");           \

@@ -474,6 +474,36 @@ def test_positions_only_and_missing_attributes(ctx, orc):
     assert np.array_equal(got["normal"], oracle_skin(orc, m, pal)["normal"])
 
 
+def test_a_reported_failure_does_not_come_back_as_the_next_launch_error(ctx, orc):
+    """The HIP runtime keeps a thread's last error until somebody asks for it, and the library asks after every kernel launch: an
+    allocation that failed -- and was reported as FYX_ERR_OOM -- must not resurface as the launch error of the next frame's pose update or
+    of the next skinning call (found when a GPU test file that updates poses first ran BEHIND this file's allocation-failure cases)."""
+    from fyrox_amd import anim as A
+    with pytest.raises(fyrox_amd.FyxError) as e:
+        ctx.malloc(1 << 50)
+    assert e.value.status == "FYX_ERR_OOM"
+    rig = synth.make_rig(5, 31)
+    td, tgt = synth.make_clip(5, 31, 0, n_keys=4, fps=4.0, euler_every=10 ** 9)
+    A.create_rig(ctx, 2_000_000_001, rig)
+    A.upload_tracks_data(ctx, 2_000_000_002, td)
+    an = A.Animator(ctx, 2_000_000_003, 2_000_000_001, rig, 1)
+    an.add_animation(2_000_000_002, tgt)
+    try:
+        an.update_animations(1 / 60)                       # the one-launch frame: launch + hipGetLastError
+        with pytest.raises(fyrox_amd.FyxError):
+            ctx.malloc(1 << 50)
+        m = synth.make_mesh(3000, 8, 32)
+        pal = synth.make_palette(8, 32)
+        upload(ctx, 15, m)
+        assert_bit_exact(ctx.lbs_skin(15, pal), oracle_skin(orc, m, pal))
+        with pytest.raises(fyrox_amd.FyxError):
+            ctx.malloc(1 << 50)
+        an.update_animations(1 / 60)
+    finally:
+        an.free()
+        ctx.mesh_free(15)
+
+
 def test_error_codes(ctx):
     m = synth.make_mesh(100, 8, 61)
     upload(ctx, 13, m)
