@@ -1496,9 +1496,11 @@ int fyx_skinned_aabb_device(fyx_ctx* c, uint64_t mesh_id, const float* d_palette
 int fyx_calib_stream_copy(fyx_ctx* c, const float* d_src, float* d_dst, uint32_t units) {
     if (!c) return FYX_ERR_INVALID_ARG;
     if (units && (!d_src || !d_dst)) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    FYX_GUARD_BEGIN
     if (int jr = enter_primary(c)) return jr;
     FYX_HIP(c, fyx::launch_stream_copy(d_src, d_dst, units, c->lbs.blocks_per_cu, c->stream));
     return FYX_OK;
+    FYX_GUARD_END(c)
 }
 
 // ---- palette ------------------------------------------------------------------------------
@@ -1507,9 +1509,11 @@ int fyx_palette_device(fyx_ctx* c, const float* d_global, const float* d_inv_bin
                        float* d_out) {
     if (!c) return FYX_ERR_INVALID_ARG;
     if (n && (!d_global || !d_inv_bind || !d_out)) return fail(c, FYX_ERR_INVALID_ARG, "null pointer");
+    FYX_GUARD_BEGIN
     if (int jr = enter_primary(c)) return jr;
     FYX_HIP(c, fyx::launch_palette(d_global, d_inv_bind, n, d_out, c->stream));
     return FYX_OK;
+    FYX_GUARD_END(c)
 }
 
 int fyx_palette(fyx_ctx* c, const float* global, const float* inv_bind, uint32_t n, float* out) {
