@@ -16,4 +16,6 @@ RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | he
 cp $ROOT/fyrox_amd/libfyrox_hip.so $OUT/libfyrox_hip.real.so
 trap 'cp $OUT/libfyrox_hip.real.so $ROOT/fyrox_amd/libfyrox_hip.so' EXIT
 cp $OUT/libfyrox_hip.so $ROOT/fyrox_amd/libfyrox_hip.so
+# (a command of the caller's instead of the tests: `tools/asan_control_plane.sh python tools/fuzz_api_host.py --count 300`)
+if [ $# -gt 0 ]; then cd $ROOT && LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 "$@"; exit $?; fi
 cd $ROOT && LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 python -m pytest tests/test_anim_control.py tests/test_machine_edits.py tests/test_abi.py -x -q -p no:cacheprovider
