@@ -474,6 +474,123 @@ def test_positions_only_and_missing_attributes(ctx, orc):
     assert np.array_equal(got["normal"], oracle_skin(orc, m, pal)["normal"])
 
 
+def _nan_aware_equal(got, ref, what):
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), what
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got[ok].view(np.uint32), ref[ok].view(np.uint32)), what
+
+
+@pytest.mark.parametrize("entry,value", [(3, 0.125), (7, -0.25), (11, 0.5), (15, 2.0), (15, 0.0)], ids=["m30", "m31", "m32", "m33", "last_row_zero"])
+def test_every_entry_of_the_last_row_decides_the_homogeneous_path(ctx, orc, entry, value):
+    """Matrix4::transform_point divides by n = m30 x + m31 y + m32 z + m33 whenever n != 0 (nalgebra; scene/mesh/mod.rs:515-517): a matrix is
+    affine for the kernels only if its last row is EXACTLY (0, 0, 0, 1), and each of the four entries alone must send it down the divide
+    path -- in every kernel's own copy of that test (tools/mutants.py, fourth batch: four of them ignored one entry each and the suite, whose
+    projective palettes always changed m30, m31 and m33 together, did not notice).  A last row of zeros makes n == 0: then nothing is divided
+    (a kernel that divides anyway writes inf / NaN).  lbs_skin, lbs_skin_dyn, the crowd kernel, both batched forms, the vertex-buffer kernel
+    and the two AABB kernels; every bit against the oracle."""
+    nb = 12
+    pal = synth.make_palette(nb, 5150).copy()
+    pal[5, entry] = value                                       # (m33 = 0 on an otherwise affine matrix: the whole last row is zero, n == 0)
+    # lbs_skin (one persistent launch of a mid-size mesh) and its AABB forms
+    m = synth.make_mesh(6000, nb, 5151, coherent=False)
+    ref = orc.lbs_skin(m.pos, m.weights, m.indices, pal, m.normal, m.tangent, threads=0)
+    upload(ctx, 21, m)
+    L = synth.ANIMATED_VERTEX
+    try:
+        got = ctx.lbs_skin(21, pal)
+        for k in ("pos", "normal", "tangent"):
+            _nan_aware_equal(got[k], ref[k], f"lbs_skin {k}")
+        # the two AABB kernels (stage_palette): with an entry that sends the bone's vertices FAR out (n close to 0 for some of them), so that
+        # the box itself -- all the AABB calls return -- cannot come out right by treating the matrix as affine
+        pal_far = pal.copy()
+        if value != 0.0:
+            pal_far[5, entry] = 0.01 if entry == 15 else (0.99 if value > 0 else -0.99)
+        far = orc.lbs_skin(m.pos, m.weights, m.indices, pal_far, threads=0)["pos"]
+        finite = ~np.isnan(far).any(axis=1)
+        box = np.concatenate([far[finite].min(0), far[finite].max(0)])
+        if value != 0.0:
+            aff = orc.lbs_skin(m.pos, m.weights, m.indices, synth.make_palette(nb, 5150), threads=0)["pos"]
+            assert not np.array_equal(box, np.concatenate([aff.min(0), aff.max(0)])), "the case moves the box"
+        assert np.array_equal(ctx.skinned_aabb(21, pal_far), box), "skinned_aabb_kernel (stage_palette)"
+        d_pal, d_box = ctx.to_device(np.concatenate([pal_far, synth.make_palette(nb, 5152)])), ctx.malloc(48)
+        ctx.skinned_aabb_device(21, d_pal.ptr, nb, 2, d_box.ptr)
+        ctx.sync()
+        assert np.array_equal(d_box.download(np.float32, 12)[:6], box), "skinned_aabb_inst_kernel"
+        d_pal.free(); d_box.free()
+        # the crowd kernel: the projective palette in the MIDDLE of a run of affine ones (the double buffer's flags)
+        pals = np.concatenate([synth.make_palette(nb, 5160 + i) if i != 3 else pal for i in range(6)])
+        refc = {k: np.concatenate([orc.lbs_skin(m.pos, m.weights, m.indices, pals[i * nb:(i + 1) * nb], m.normal, m.tangent, threads=0)[k]
+                                   for i in range(6)]) for k in ref}
+        gotc = ctx.lbs_skin(21, pals, n_instances=6)
+        for k in ("pos", "normal", "tangent"):
+            _nan_aware_equal(gotc[k], refc[k], f"lbs_skin_crowd {k}")
+        # the vertex-buffer kernel (AnimatedVertex in, the same layout out)
+        ctx.mesh_upload(22, m.to_animated_vertex_aos(), m.n_verts, L["stride"], off_pos=L["off_pos"], off_normal=L["off_normal"],
+                        off_tangent=L["off_tangent"], off_weights=L["off_weights"], off_indices=L["off_indices"])
+        d_pal, buf = ctx.to_device(pal), ctx.malloc(m.n_verts * L["stride"] + 64)
+        ctx.lbs_skin_ex(22, d_pal.ptr, nb, 1, d_out_vertices=buf.ptr, out_stride=0)
+        ctx.sync()
+        raw = buf.download(np.uint8, m.n_verts * L["stride"]).reshape(m.n_verts, L["stride"])
+        for k, off, size in (("pos", L["off_pos"], 12), ("normal", L["off_normal"], 12), ("tangent", L["off_tangent"], 12)):
+            _nan_aware_equal(np.ascontiguousarray(raw[:, off:off + size]).view(np.float32), np.ascontiguousarray(ref[k][:, :3]), f"lbs_skin_aos {k}")
+        d_pal.free(); buf.free()
+    finally:
+        ctx.mesh_free(21)
+        ctx.mesh_free(22)
+    # lbs_skin_dyn (a large single-instance launch)
+    big = synth.make_mesh(530_011, nb, 5153)
+    upload(ctx, 21, big)
+    try:
+        got, _ = _skin_device_masked(ctx, 21, big, pal, ("pos", "normal", "tangent"))
+        refb = oracle_skin(orc, big, pal)
+        for k in ("pos", "normal", "tangent"):
+            _nan_aware_equal(got[k], refb[k], f"lbs_skin_dyn {k}")
+    finally:
+        ctx.mesh_free(21)
+    # both batched forms: the projective palette belongs to ONE job of the batch
+    for dyn in (1, 0):
+        ctx.set_option("lbs.dyn", dyn)
+        specs = [(9000, nb, 1, ("pos", "normal", "tangent")), (7000, nb, 1, ("pos", "normal", "tangent")), (5000, nb, 2, ("pos", "normal", "tangent"))]
+        scene = _batch_scene(ctx, 7600, specs, 5170)
+        try:
+            mm, _, dp, o = scene[1]
+            dp.upload(pal)
+            scene[1] = (mm, pal, dp, o)
+            ctx.lbs_skin_batch(_batch_jobs(7600, specs, scene))
+            ctx.sync()
+            for (nv, nbb, ni, want), (mm, pp, dp, o) in zip(specs, scene):
+                refj = oracle_skin(orc, mm, pp, ni)
+                for key, width in (("pos", 3), ("normal", 3), ("tangent", 4)):
+                    _nan_aware_equal(o[key].download(np.float32, ni * nv * width).reshape(ni * nv, width), refj[key], f"batch dyn={dyn} {key}")
+        finally:
+            for k, (mm, pp, dp, o) in enumerate(scene):
+                for b in list(o.values()) + [dp]:
+                    b.free()
+                ctx.mesh_free(7600 + k)
+    ctx.set_option("lbs.dyn", 1)
+
+
+def test_a_palette_one_matrix_short_of_the_largest_bone_index_is_refused(ctx):
+    """The Rust loop indexes `bone_matrices[bone_index as usize]` (scene/mesh/mod.rs:514): a palette that ends exactly ON the mesh's largest
+    bone index is one matrix short.  n_bones == max index is refused, max index + 1 accepted (the check's `>=`; tools/mutants.py: `>` survived
+    a suite whose short palettes were all much shorter)."""
+    m = synth.make_mesh(500, 8, 5180)
+    idx = m.indices.copy()
+    idx[7, 2] = 7                                               # the largest index there is, whatever the generator drew
+    ctx.mesh_upload_soa(23, m.pos, m.weights, idx, m.normal, m.tangent)
+    try:
+        assert ctx.mesh_info(23)["max_bone_index"] == 7
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            ctx.lbs_skin(23, synth.make_palette(7, 5180))
+        assert e.value.status == "FYX_ERR_BONE_INDEX"
+        with pytest.raises(fyrox_amd.FyxError) as e:
+            ctx.skinned_aabb(23, synth.make_palette(7, 5180))
+        assert e.value.status == "FYX_ERR_BONE_INDEX"
+        assert ctx.lbs_skin(23, synth.make_palette(8, 5180), want=("pos",))["pos"].shape == (500, 3)
+    finally:
+        ctx.mesh_free(23)
+
+
 def test_a_reported_failure_does_not_come_back_as_the_next_launch_error(ctx, orc):
     """The HIP runtime keeps a thread's last error until somebody asks for it, and the library asks after every kernel launch: an
     allocation that failed -- and was reported as FYX_ERR_OOM -- must not resurface as the launch error of the next frame's pose update or

@@ -91,6 +91,20 @@ MUTANTS = [
      "lib.rs:610-640: prev_rotation.inverse() * pose_rotation"),
     ("root_motion_rotation_remainder_other_side", "anim_kernels.hip", "const f4 d = quat_mul(remainder, current_relative_rotation);", "const f4 d = quat_mul(current_relative_rotation, remainder);", "lib.rs:640-650: remainder * current_relative_rotation"),
     ("constant_key_right_value_early", "anim_leaves.h", "    if (lk == FYX_KEY_CONSTANT) return t == 1.0f ? ra.x : la.x;", "    if (lk == FYX_KEY_CONSTANT) return t >= 0.5f ? ra.x : la.x;", "stepf (curve.rs:25-31) in the key-record sampler"),
+    # ---- fourth batch (third session): the homogeneous path's decisions, the crowd kernel's double buffer, the palette-length check
+    ("crowd_projective_flag_into_the_current_buffer", "lbs_kernels.hip", "            if (lane == 0) flags[(cur ^ 1) * 4 + wave] = wave_pj ? 1u : 0u;", "            if (lane == 0) flags[cur * 4 + wave] = wave_pj ? 1u : 0u;",
+     "lbs_skin_crowd: the next instance's projective flag belongs to the next buffer"),
+    ("palette_commit_ignores_m32", "lbs_leaves.h", "    return !(r.c0.w == 0.0f && r.c1.w == 0.0f && r.c2.w == 0.0f && r.c3.w == 1.0f);", "    return !(r.c0.w == 0.0f && r.c1.w == 0.0f && r.c3.w == 1.0f);",
+     "a matrix whose only non-affine entry is m32 (crowd kernel / lbs_skin staging)"),
+    ("dyn_projective_test_looks_at_m33_only", "lbs_kernels.hip", "            pj |= col[i].w != (c == 3 ? 1.0f : 0.0f);\n        }\n    }\n    const bool wave_pj = __any(pj) != 0;\n    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;\n    __syncthreads();\n    bool projective = false;\n#pragma unroll\n    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;\n    pin_vertex(A);",
+     "            pj |= c == 3 && col[i].w != 1.0f;\n        }\n    }\n    const bool wave_pj = __any(pj) != 0;\n    if (lane == 0) wave_flag[wave] = wave_pj ? 1u : 0u;\n    __syncthreads();\n    bool projective = false;\n#pragma unroll\n    for (uint32_t wv = 0; wv < WPB; ++wv) projective |= wave_flag[wv] != 0;\n    pin_vertex(A);",
+     "lbs_skin_dyn: a matrix with m33 == 1 and a non-zero m30 / m31 / m32 is projective too"),
+    ("stage_palette_ignores_m31", "lbs_leaves.h", "        projective |= !(c0.w == 0.0f && c1.w == 0.0f && c2.w == 0.0f && c3.w == 1.0f);", "        projective |= !(c0.w == 0.0f && c2.w == 0.0f && c3.w == 1.0f);",
+     "stage_palette (the AABB kernels): a matrix whose only non-affine entry is m31"),
+    ("projective_divides_by_zero_too", "lbs_leaves.h", "                if (n != 0.0f) { xy.x = xy.x / n; xy.y = xy.y / n; z = z / n; }", "                { xy.x = xy.x / n; xy.y = xy.y / n; z = z / n; }",
+     "transform_point divides only when the homogeneous coordinate is not zero (nalgebra)"),
+    ("palette_one_bone_short_is_accepted", "fyx_api.hip", "    if (m->n_verts > 0 && m->max_bone_index >= n_bones)", "    if (m->n_verts > 0 && m->max_bone_index > n_bones)",
+     "a palette exactly one matrix short of the mesh's largest bone index is refused (the Rust loop would panic on the index)"),
 ]
 
 
@@ -129,7 +143,7 @@ def build(only=None):
     print(f"{len(made)} mutants under {OUT}; the shipped library rebuilt from the restored sources")
 
 
-def run(out, only=None):
+def run(out, only=None, tests=None, k=None):
     idx = [m for m in json.load(open(os.path.join(OUT, "index.json"))) if not only or m["name"] in only]
     good = LIB + ".shipped"
     shutil.copy2(LIB, good)
@@ -138,8 +152,9 @@ def run(out, only=None):
         for m in idx:
             shutil.copy2(os.path.join(OUT, m["name"] + ".so"), LIB)
             t0 = time.time()
-            r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True)
+            r = subprocess.run([sys.executable, "-m", "pytest", *(tests.split() if tests else ["tests"]), *(["-k", k] if k else []), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True)
             tail = [l for l in r.stdout.splitlines() if l.startswith("FAILED") or l.startswith("ERROR")]
+            assert r.returncode in (0, 1), f"pytest did not run the tests (exit code {r.returncode}):\n{r.stdout[-600:]}"      # 5 = nothing collected: not a kill
             res.append(dict(m, killed=r.returncode != 0, by=(tail[0][:200] if tail else None), seconds=round(time.time() - t0, 1)))
             print(json.dumps(res[-1]), flush=True)
     finally:
@@ -157,6 +172,8 @@ if __name__ == "__main__":
     ap.add_argument("step", choices=("build", "run"))
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="comma-separated mutant names")
+    ap.add_argument("--tests", default=None, help="test files instead of the whole suite (to show that a NEW test kills a survivor)")
+    ap.add_argument("--k", default=None, help="pytest -k expression to go with --tests")
     a = ap.parse_args()
     only = a.only.split(",") if a.only else None
-    build(only) if a.step == "build" else run(a.out, only)
+    build(only) if a.step == "build" else run(a.out, only, a.tests, a.k)
