@@ -53,7 +53,23 @@ def test_the_frame_that_skins_equals_update_then_lbs_skin(ctx, orc, make, n_inst
     """Every frame: outputs of the skin output == fyx_lbs_skin_device on the palette the update wrote; the pose side (poses, TRS,
     matrices) against the oracle as in test_anim_gpu; at the end the vertices against the oracle's loop on the oracle's palette (exact
     where no Euler track is involved)."""
-    sc = make()
+    _frame_that_skins(ctx, orc, make(), n_inst, n_verts)
+
+
+@pytest.mark.parametrize("entry", [3, 7, 11, 15], ids=["m30", "m31", "m32", "m33"])
+def test_the_frame_that_skins_takes_the_homogeneous_path_for_any_entry_of_the_last_row(ctx, orc, entry):
+    """The skinning workgroups of the one-launch frame form their palette on chip and decide THERE whether a matrix is affine (their own
+    copy of the test, anim_kernels.hip frame_skin_body).  A bone whose inverse bind matrix has ONE non-affine entry in its last row gives a
+    palette matrix with exactly that last row (the global matrix's is (0, 0, 0, 1)): each entry alone must take the divide path --
+    bit for bit what update + lbs_skin gives, and the oracle."""
+    sc = cases.transitions()
+    ib = np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (sc.rig.n_nodes, 1)) if sc.rig.inv_bind is None else np.array(sc.rig.inv_bind, np.float32).reshape(-1, 16)
+    ib[5, entry] = {3: 0.125, 7: -0.25, 11: 0.5, 15: 2.0}[entry]
+    sc.rig.inv_bind = ib
+    _frame_that_skins(ctx, orc, sc, 2, 4097)
+
+
+def _frame_that_skins(ctx, orc, sc, n_inst, n_verts):
     nb = sc.rig.n_nodes
     o = cases.build_oracle(orc, sc)
     p = cases.build_product(ctx, sc, n_inst)

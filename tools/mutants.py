@@ -105,6 +105,8 @@ MUTANTS = [
      "transform_point divides only when the homogeneous coordinate is not zero (nalgebra)"),
     ("palette_one_bone_short_is_accepted", "fyx_api.hip", "    if (m->n_verts > 0 && m->max_bone_index >= n_bones)", "    if (m->n_verts > 0 && m->max_bone_index > n_bones)",
      "a palette exactly one matrix short of the mesh's largest bone index is refused (the Rust loop would panic on the index)"),
+    ("frame_skin_projective_test_looks_at_m33_only", "anim_kernels.hip", "            pj |= y.w != (c == 3u ? 1.0f : 0.0f);", "            pj |= c == 3u && y.w != 1.0f;",
+     "the one-launch frame's skinning workgroups: their own copy of the affine test"),
 ]
 
 
