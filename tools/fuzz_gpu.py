@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--count", type=int, default=100)
     ap.add_argument("--listy", action="store_true")
     ap.add_argument("--lattice", action="store_true", help="blend-space points and sampling points on a coarse lattice (points ON edges and corners)")
+    ap.add_argument("--subnormal", action="store_true", help="tests/anim_cases.py::with_subnormal_values over every scenario: Position keys x 1e-39, a third of the Scale keys x 1e-13")
     ap.add_argument("--bones", type=int, default=7)
     ap.add_argument("--curves", action="store_true", help="tests/anim_cases.py::random_curves instead of random_machine")
     ap.add_argument("--edits", action="store_true", help="random run-time edits between frames: track bindings switched, speeds, loops, "
@@ -301,6 +302,8 @@ def main():
     for seed in (range(args.first, args.first + args.count) if not args.scene else ()):
         form, n_inst = seed % 3, 1 + seed % 4 if seed % 5 else 70
         sc = cases.random_curves(seed, n_bones=args.bones) if args.curves else cases.random_machine(seed, n_bones=args.bones, listy=args.listy, lattice=args.lattice)
+        if args.subnormal:
+            sc = cases.with_subnormal_values(lambda sc=sc: sc)()
         ctx.set_option("anim.sample_form", form)
         o = p = None
         try:
@@ -326,7 +329,7 @@ def main():
             except Exception:   # noqa: BLE001
                 pass
     ctx.set_option("anim.sample_form", 0)
-    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "lattice": args.lattice, "curves": args.curves, "edits": args.edits, "diverge": args.diverge, "skin": args.skin, "scene": args.scene, "options": args.opt, "bones": args.bones,
+    rec = {"what": "random machines on the GPU against the oracle, every frame", "listy": args.listy, "lattice": args.lattice, "subnormal": args.subnormal, "curves": args.curves, "edits": args.edits, "diverge": args.diverge, "skin": args.skin, "scene": args.scene, "options": args.opt, "bones": args.bones,
            "first_seed": args.first, "seeds": args.count, "failures": len(fails), "failed": fails[:40], "seconds": round(time.time() - t0, 1)}
     line = json.dumps(rec)
     print(line)
