@@ -70,7 +70,9 @@ int fyx_sync(fyx_ctx* ctx);
 int fyx_join(fyx_ctx* ctx);
 /* Options.  Unknown keys return FYX_ERR_INVALID_ARG.
  *   skinning:
- *     "lbs.exact"        1 (default) = the reference's operation order, no FMA contraction: bit-identical to the CPU path;
+ *     "lbs.exact"        1 (default) = the reference's operation order, no FMA contraction: bit-identical to the CPU path
+ *                        (subnormal numbers kept, overflow to +-inf, NaN where the CPU has NaN -- WHICH NaN, its sign and payload,
+ *                        is specified neither by IEEE 754 nor by Rust: x86 makes 0xffc00000 of 0 / 0, this device 0x7fc00000);
  *                        0 = fused multiply-adds, within 1e-5 relative (north_star's tolerance); the crowd kernel then blends
  *                        the four matrices first and transforms once (the same linear map, different rounding)
  *     "lbs.streams"      1..4 worker streams for independent skinning launches, see fyx_join (default 2)
