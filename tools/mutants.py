@@ -107,6 +107,15 @@ MUTANTS = [
      "a palette exactly one matrix short of the mesh's largest bone index is refused (the Rust loop would panic on the index)"),
     ("frame_skin_projective_test_looks_at_m33_only", "anim_kernels.hip", "            pj |= y.w != (c == 3u ? 1.0f : 0.0f);", "            pj |= c == 3u && y.w != 1.0f;",
      "the one-launch frame's skinning workgroups: their own copy of the affine test"),
+    # ---- fifth batch: the copies of `global * inv_bind` / `parent * local` (nalgebra's k-ascending axpy chain) in the pose kernels
+    ("mat4_mul_terms_reordered", "anim_kernels.hip", "            y = a[4 + i] * b[j * 4 + 1] + y;\n            y = a[8 + i] * b[j * 4 + 2] + y;\n            y = a[12 + i] * b[j * 4 + 3] + y;\n            out[j * 4 + i] = y;",
+     "            y = a[8 + i] * b[j * 4 + 2] + y;\n            y = a[4 + i] * b[j * 4 + 1] + y;\n            y = a[12 + i] * b[j * 4 + 3] + y;\n            out[j * 4 + i] = y;", "mat4_mul (the hierarchy's narrow walk)"),
+    ("frame_skin_palette_terms_reordered", "anim_kernels.hip", "                const f4 b4 = q_bb[k];\n                const f4* a = reinterpret_cast<const f4*>(l_global) + (size_t)q_node[k] * 4;\n                const f4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];\n                y.x = a0.x * b4.x; y.x = a1.x * b4.y + y.x; y.x = a2.x * b4.z + y.x; y.x = a3.x * b4.w + y.x;",
+     "                const f4 b4 = q_bb[k];\n                const f4* a = reinterpret_cast<const f4*>(l_global) + (size_t)q_node[k] * 4;\n                const f4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];\n                y.x = a0.x * b4.x; y.x = a2.x * b4.z + y.x; y.x = a1.x * b4.y + y.x; y.x = a3.x * b4.w + y.x;", "the palette the one-launch frame's skinning workgroups form on chip"),
+    ("update_epilogue_palette_terms_reordered", "anim_kernels.hip", "                    const f4 b4 = bb[k];\n                    const f4* a = reinterpret_cast<const f4*>(l_global) + (size_t)node[k] * 4;\n                    const f4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];\n                    y.x = a0.x * b4.x; y.x = a1.x * b4.y + y.x; y.x = a2.x * b4.z + y.x; y.x = a3.x * b4.w + y.x;",
+     "                    const f4 b4 = bb[k];\n                    const f4* a = reinterpret_cast<const f4*>(l_global) + (size_t)node[k] * 4;\n                    const f4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];\n                    y.x = a0.x * b4.x; y.x = a2.x * b4.z + y.x; y.x = a1.x * b4.y + y.x; y.x = a3.x * b4.w + y.x;", "the palette the update kernel writes in its epilogue"),
+    ("palette_gather_terms_reordered", "anim_kernels.hip", "            y = a[4 + i] * bb[j * 4 + 1] + y;\n            y = a[8 + i] * bb[j * 4 + 2] + y;", "            y = a[8 + i] * bb[j * 4 + 2] + y;\n            y = a[4 + i] * bb[j * 4 + 1] + y;", "palette_gather_kernel (fyx_animator_palette)"),
+    ("palette_gather_invalid_bone_is_zero", "anim_kernels.hip", "            y = (i == j) ? 1.0f : 0.0f;", "            y = 0.0f;", "an invalid bone handle yields the identity (scene/mesh/mod.rs:789-791)"),
 ]
 
 
