@@ -45,6 +45,19 @@ MUTANTS = [
     ("shard_cut_rounds_the_groups_down", "comm_api.hip", "    const uint64_t groups = ((uint64_t)n_verts + kShardAlign - 1) / kShardAlign;\n    const uint64_t v = (g * groups / n_ranks) * kShardAlign;", "    const uint64_t groups = ((uint64_t)n_verts) / kShardAlign;\n    const uint64_t v = (g * groups / n_ranks) * kShardAlign;", "the ragged cut: a mesh's last partial group belongs to the last rank"),
     ("padded_shard_rounds_down", "comm_api.hip", "return (uint32_t)(((groups + n_ranks - 1) / n_ranks) * kShardAlign);", "return (uint32_t)((groups / n_ranks) * kShardAlign);", "the padded cut: ceil(groups / n_ranks)"),
     ("mesh_upload_attribute_may_overhang_the_stride", "fyx_api.hip", "if (a.off >= 0 && (uint64_t)a.off + a.size > stride)", "if (a.off >= 0 && (uint64_t)a.off > stride)", "fyx_mesh_upload: an attribute that does not fit the vertex is refused"),
+    # ---- third batch: MachineLayer::evaluate_pose's order of things (layer.rs:590-706)
+    ("transition_to_the_active_state_may_fire", "anim_planner.h", "if ((int32_t)tr.dest == LS.active_state || (int32_t)tr.source != LS.active_state) continue;", "if ((int32_t)tr.source != LS.active_state) continue;",
+     "layer.rs:606-611: a transition whose destination is the active state is skipped"),
+    ("leave_event_after_the_enter_event", "anim_planner.h", "                        layer_event(LS, FYX_EVENT_STATE_LEAVE, LS.active_state, -1);             // layer.rs:620\n                        if (tr.dest < L.states.size()) apply_actions(L.states[tr.dest].on_enter);\n                        layer_event(LS, FYX_EVENT_STATE_ENTER, (int32_t)tr.dest, -1);            // :634",
+     "                        if (tr.dest < L.states.size()) apply_actions(L.states[tr.dest].on_enter);\n                        layer_event(LS, FYX_EVENT_STATE_ENTER, (int32_t)tr.dest, -1);            // :634\n                        layer_event(LS, FYX_EVENT_STATE_LEAVE, LS.active_state, -1);             // layer.rs:620", "the order of a firing transition's events"),
+    ("later_transition_wins", "anim_planner.h", "                        layer_event(LS, FYX_EVENT_ACTIVE_TRANSITION_CHANGED, (int32_t)t, -1);    // :645\n                        break;", "                        layer_event(LS, FYX_EVENT_ACTIVE_TRANSITION_CHANGED, (int32_t)t, -1);    // :645\n                        continue;",
+     "layer.rs:605-651: the FIRST transition whose condition holds fires, the search stops"),
+    ("transition_done_without_epsilon", "anim_planner.h", "                if (fabsf(tr.time - ts.elapsed) <= FLT_EPSILON) {  // is_done", "                if (tr.time == ts.elapsed + 1.0f) {  // is_done",
+     "a control: a transition that never finishes"),
+    ("state_changed_event_before_transition_changed", "anim_planner.h", "                    LS.active_transition = -1;\n                    layer_event(LS, FYX_EVENT_ACTIVE_TRANSITION_CHANGED, -1, -1);                 // :673\n                    LS.active_state = (int32_t)tr.dest;\n                    layer_event(LS, FYX_EVENT_ACTIVE_STATE_CHANGED, (int32_t)tr.source, (int32_t)tr.dest);  // :677",
+     "                    LS.active_transition = -1;\n                    LS.active_state = (int32_t)tr.dest;\n                    layer_event(LS, FYX_EVENT_ACTIVE_STATE_CHANGED, (int32_t)tr.source, (int32_t)tr.dest);  // :677\n                    layer_event(LS, FYX_EVENT_ACTIVE_TRANSITION_CHANGED, -1, -1);                 // :673", "the order of a finished transition's events"),
+    ("every_states_root_is_not_evaluated", "anim_planner.h", "            for (const StateDef& s : L.states) eval_node(L, LS, s.root, nr);  // state.update", "            if (LS.active_state >= 0) eval_node(L, LS, L.states[LS.active_state].root, nr); else for (const StateDef& s : L.states) eval_node(L, LS, s.root, nr);  // state.update",
+     "layer.rs:601-603: EVERY state's root is evaluated every frame (by-index nodes of inactive states keep their clocks running)"),
 ]
 
 BATCH2_TESTS = ["tests/test_import_helpers.py", "tests/test_sharding.py", "tests/test_abi.py", "tests/test_oracle_golden.py", "tests/test_cpp_host.py"]
